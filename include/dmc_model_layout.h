@@ -1,0 +1,120 @@
+/* dmc_model_layout.h -- the flat "compiled model" blob that crosses the C-ABI.
+ *
+ * The reference hands MuJoCo an MJCF string and gets back an opaque mjModel
+ * (dm_control/mujoco/wrapper/core.py:151-182, MjModel.from_xml_string).  MuJoCo's
+ * XML compiler is third-party and absent, so this repo's own MJCF compiler
+ * (dm_control_amd/mjcf_compiler.py) produces the constant tables below, named
+ * after the mjModel fields the reference reads (dm_control/mujoco/index.py:93-174).
+ *
+ * Blob format (two flat arrays):
+ *   ints  = [DMC_MODEL_MAGIC, DMC_MODEL_VERSION, <header ints>, <int fields...>]
+ *   reals = [<header reals>, <real fields...>]           (always float64)
+ * Field order is exactly the order of the X-macro lists in this file; the
+ * Python packer parses this header, so this file is the single source of truth.
+ *
+ * Count expressions use the header size names (nq, nv, ...).
+ */
+#ifndef DMC_MODEL_LAYOUT_H_
+#define DMC_MODEL_LAYOUT_H_
+
+#define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
+#define DMC_MODEL_VERSION 3
+
+/* ---- header ints (sizes, then options) --------------------------------- */
+#define DMC_MODEL_HEADER_INTS(X) \
+  X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) \
+  X(nsensor) X(nsensordata) X(npair) X(nkey) \
+  X(opt_integrator) X(opt_cone) X(opt_solver) X(opt_iterations) \
+  X(opt_ls_iterations) X(opt_noslip_iterations) \
+  X(opt_disableflags) X(opt_enableflags)
+
+/* ---- header reals ------------------------------------------------------- */
+#define DMC_MODEL_HEADER_REALS(X) \
+  X(opt_timestep) X(opt_gravity_x) X(opt_gravity_y) X(opt_gravity_z) \
+  X(opt_impratio) X(opt_tolerance) X(opt_ls_tolerance) X(opt_noslip_tolerance) \
+  X(stat_meaninertia)
+
+/* ---- int fields: X(name, count_expr) ------------------------------------ */
+#define DMC_MODEL_INT_FIELDS(X) \
+  X(body_parentid, nbody) X(body_rootid, nbody) X(body_weldid, nbody) \
+  X(body_jntadr, nbody) X(body_jntnum, nbody) X(body_dofadr, nbody) \
+  X(body_dofnum, nbody) X(body_geomadr, nbody) X(body_geomnum, nbody) \
+  X(jnt_type, njnt) X(jnt_qposadr, njnt) X(jnt_dofadr, njnt) \
+  X(jnt_bodyid, njnt) X(jnt_limited, njnt) \
+  X(dof_bodyid, nv) X(dof_jntid, nv) X(dof_parentid, nv) \
+  X(geom_type, ngeom) X(geom_contype, ngeom) X(geom_conaffinity, ngeom) \
+  X(geom_condim, ngeom) X(geom_bodyid, ngeom) X(geom_priority, ngeom) \
+  X(site_bodyid, nsite) X(site_type, nsite) \
+  X(actuator_trntype, nu) X(actuator_dyntype, nu) X(actuator_gaintype, nu) \
+  X(actuator_biastype, nu) X(actuator_trnid, 2*nu) \
+  X(actuator_ctrllimited, nu) X(actuator_forcelimited, nu) \
+  X(sensor_type, nsensor) X(sensor_objtype, nsensor) X(sensor_objid, nsensor) \
+  X(sensor_adr, nsensor) X(sensor_dim, nsensor) X(sensor_needstage, nsensor) \
+  X(pair_geom1, npair) X(pair_geom2, npair)
+
+/* ---- real fields: X(name, count_expr) ----------------------------------- */
+#define DMC_MODEL_REAL_FIELDS(X) \
+  X(qpos0, nq) X(qpos_spring, nq) \
+  X(body_pos, 3*nbody) X(body_quat, 4*nbody) X(body_ipos, 3*nbody) \
+  X(body_iquat, 4*nbody) X(body_mass, nbody) X(body_subtreemass, nbody) \
+  X(body_inertia, 3*nbody) X(body_invweight0, 2*nbody) \
+  X(jnt_pos, 3*njnt) X(jnt_axis, 3*njnt) X(jnt_stiffness, njnt) \
+  X(jnt_range, 2*njnt) X(jnt_margin, njnt) X(jnt_solref, 2*njnt) \
+  X(jnt_solimp, 5*njnt) \
+  X(dof_armature, nv) X(dof_damping, nv) X(dof_invweight0, nv) \
+  X(dof_frictionloss, nv) \
+  X(geom_size, 3*ngeom) X(geom_pos, 3*ngeom) X(geom_quat, 4*ngeom) \
+  X(geom_friction, 3*ngeom) X(geom_solmix, ngeom) X(geom_solref, 2*ngeom) \
+  X(geom_solimp, 5*ngeom) X(geom_margin, ngeom) X(geom_gap, ngeom) \
+  X(geom_rbound, ngeom) \
+  X(site_size, 3*nsite) X(site_pos, 3*nsite) X(site_quat, 4*nsite) \
+  X(actuator_gear, 6*nu) X(actuator_ctrlrange, 2*nu) \
+  X(actuator_forcerange, 2*nu) X(actuator_gainprm, 10*nu) \
+  X(actuator_biasprm, 10*nu) X(actuator_dynprm, 10*nu) \
+  X(sensor_cutoff, nsensor) \
+  X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
+
+/* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
+ * them, dm_control/mujoco/__init__.py:26; only the subset in use) ---------- */
+enum { DMC_JNT_FREE = 0, DMC_JNT_BALL = 1, DMC_JNT_SLIDE = 2, DMC_JNT_HINGE = 3 };
+enum { DMC_GEOM_PLANE = 0, DMC_GEOM_HFIELD = 1, DMC_GEOM_SPHERE = 2,
+       DMC_GEOM_CAPSULE = 3, DMC_GEOM_ELLIPSOID = 4, DMC_GEOM_CYLINDER = 5,
+       DMC_GEOM_BOX = 6, DMC_GEOM_MESH = 7 };
+enum { DMC_INT_EULER = 0, DMC_INT_RK4 = 1, DMC_INT_IMPLICIT = 2,
+       DMC_INT_IMPLICITFAST = 3 };
+enum { DMC_CONE_PYRAMIDAL = 0, DMC_CONE_ELLIPTIC = 1 };
+enum { DMC_SOL_PGS = 0, DMC_SOL_CG = 1, DMC_SOL_NEWTON = 2 };
+enum { DMC_TRN_JOINT = 0 };
+enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2 };
+enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
+enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };
+enum { DMC_OBJ_BODY = 1, DMC_OBJ_JOINT = 3, DMC_OBJ_SITE = 6, DMC_OBJ_ACTUATOR = 19 };
+enum { DMC_STAGE_NONE = 0, DMC_STAGE_POS = 1, DMC_STAGE_VEL = 2, DMC_STAGE_ACC = 3 };
+enum { DMC_SENS_TOUCH = 0, DMC_SENS_ACCELEROMETER = 1, DMC_SENS_VELOCIMETER = 2,
+       DMC_SENS_GYRO = 3, DMC_SENS_FORCE = 4, DMC_SENS_TORQUE = 5,
+       DMC_SENS_JOINTPOS = 9, DMC_SENS_JOINTVEL = 10, DMC_SENS_ACTUATORFRC = 15,
+       DMC_SENS_FRAMEPOS = 26, DMC_SENS_SUBTREECOM = 37, DMC_SENS_SUBTREELINVEL = 38 };
+/* mjtDisableBit, in the order of dm_control/mjcf/schema.xml:82-103 */
+enum { DMC_DSBL_CONSTRAINT = 1 << 0, DMC_DSBL_EQUALITY = 1 << 1,
+       DMC_DSBL_FRICTIONLOSS = 1 << 2, DMC_DSBL_LIMIT = 1 << 3,
+       DMC_DSBL_CONTACT = 1 << 4, DMC_DSBL_SPRING = 1 << 5,
+       DMC_DSBL_DAMPER = 1 << 6, DMC_DSBL_GRAVITY = 1 << 7,
+       DMC_DSBL_CLAMPCTRL = 1 << 8, DMC_DSBL_WARMSTART = 1 << 9,
+       DMC_DSBL_FILTERPARENT = 1 << 10, DMC_DSBL_ACTUATION = 1 << 11,
+       DMC_DSBL_REFSAFE = 1 << 12, DMC_DSBL_SENSOR = 1 << 13,
+       DMC_DSBL_MIDPHASE = 1 << 14, DMC_DSBL_EULERDAMP = 1 << 15,
+       DMC_DSBL_AUTORESET = 1 << 16 };
+enum { DMC_ENBL_OVERRIDE = 1 << 0, DMC_ENBL_ENERGY = 1 << 1 };
+/* mjtWarning order as used by Physics.check_invalid_state
+ * (dm_control/mujoco/engine.py:345-368) */
+enum { DMC_WARN_INERTIA = 0, DMC_WARN_CONTACTFULL = 1, DMC_WARN_CNSTRFULL = 2,
+       DMC_WARN_VGEOMFULL = 3, DMC_WARN_BADQPOS = 4, DMC_WARN_BADQVEL = 5,
+       DMC_WARN_BADQACC = 6, DMC_WARN_BADCTRL = 7, DMC_NWARNING = 8 };
+
+#define DMC_MINVAL 1e-15
+#define DMC_MAXVAL 1e10
+#define DMC_MINMU  1e-5
+#define DMC_MINIMP 0.0001
+#define DMC_MAXIMP 0.9999
+
+#endif  /* DMC_MODEL_LAYOUT_H_ */

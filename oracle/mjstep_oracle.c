@@ -1,0 +1,1472 @@
+/* mjstep_oracle.c -- TEST INFRASTRUCTURE ONLY (parity oracle + CPU baseline).
+ *
+ * A plain-C, fp64, single-environment restatement of the arithmetic behind the
+ * reference's hot path: dm_control.mujoco.Physics.step()
+ * (dm_control/mujoco/engine.py:147-176) -> mujoco.mj_step / mj_step1 / mj_step2
+ * / mj_forward (engine.py:156,158,160,162,176,343).
+ *
+ * The arithmetic itself lives in the third-party dependency `mujoco==3.11.0`
+ * (requirements.txt:9, setup.py:194), whose source is NOT under /root/reference
+ * and whose wheel cannot be installed here.  This file therefore restates
+ * MuJoCo's published algorithm (computation chapter of the MuJoCo docs; stage
+ * list in SURVEY.md Appendix A) stage by stage, and is anchored on what the
+ * reference itself pins at the boundary: the step1/step2 split documented in
+ * engine.py:147-162,335-341, the default constants in dm_control/mjcf/schema.xml,
+ * the quaternion conventions in dm_control/utils/transformations.py, and the
+ * known-answer tests of SURVEY.md 8(c) (tests/test_oracle_kat.py), including the
+ * one numeric golden the reference holds: dm_control/mujoco/README.md:46-49.
+ *
+ * PARITY UNPINNED at trajectory level: the reference holds no golden qpos
+ * vectors and MuJoCo itself cannot be run here.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product path (dm_control_amd/csrc) never links it.
+ *
+ * Conventions: quaternions wxyz; free joint qvel = [v_world(3), omega_local(3)];
+ * spatial vectors are [angular(3), linear(3)] expressed in a frame located at
+ * the subtree COM of the kinematic-tree root and aligned with the world.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/dmc_model_layout.h"
+
+#define MINVAL DMC_MINVAL
+#define MAXVAL DMC_MAXVAL
+#define mjMAX(a, b) ((a) > (b) ? (a) : (b))
+#define mjMIN(a, b) ((a) < (b) ? (a) : (b))
+
+/* ------------------------------------------------------------------------- */
+/* model / data                                                               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+#define X(n) int n;
+  DMC_MODEL_HEADER_INTS(X)
+#undef X
+#define X(n) double n;
+  DMC_MODEL_HEADER_REALS(X)
+#undef X
+#define X(n, c) int* n;
+  DMC_MODEL_INT_FIELDS(X)
+#undef X
+#define X(n, c) double* n;
+  DMC_MODEL_REAL_FIELDS(X)
+#undef X
+  int* ibuf;
+  double* rbuf;
+  int nconmax, njmax;
+} Model;
+
+enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2 };
+
+typedef struct {
+  double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
+  int dim, geom1, geom2, efc_address, exclude;
+} Contact;
+
+typedef struct {
+  /* state */
+  double time;
+  double *qpos, *qvel, *act, *qacc_warmstart, *ctrl, *qfrc_applied, *xfrc_applied;
+  /* position-dependent */
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
+  double *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
+  double *subtree_com, *cinert, *cdof, *crb, *qM, *qL; /* qL: dense Cholesky of M */
+  /* velocity-dependent */
+  double *cvel, *cdof_dot, *qfrc_bias, *qfrc_passive, *subtree_linvel;
+  double *actuator_length, *actuator_velocity;
+  /* acceleration */
+  double *actuator_force, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc;
+  double *qfrc_constraint, *cacc, *cfrc_int, *cfrc_ext;
+  double *sensordata;
+  /* contacts & constraints */
+  int ncon, nefc;
+  Contact* contact;
+  int *efc_type, *efc_id, *efc_state;
+  double *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_R, *efc_D, *efc_aref;
+  double *efc_vel, *efc_force, *efc_KBIP;
+  /* solver stats */
+  int solver_iter;
+  int warning[DMC_NWARNING];
+  /* scratch */
+  double *w_Jaref, *w_Jv, *w_Ma, *w_Mv, *w_grad, *w_Mgrad, *w_search, *w_quad, *w_H, *w_tmp;
+  double* mem;
+} Data;
+
+/* ------------------------------------------------------------------------- */
+/* small math                                                                 */
+/* ------------------------------------------------------------------------- */
+static double dot3(const double* a, const double* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static void cross3(double* r, const double* a, const double* b) {
+  double t0 = a[1]*b[2] - a[2]*b[1], t1 = a[2]*b[0] - a[0]*b[2], t2 = a[0]*b[1] - a[1]*b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+static double normalize3(double* v) {
+  double n = sqrt(dot3(v, v));
+  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; }
+  else { double s = 1 / n; v[0] *= s; v[1] *= s; v[2] *= s; }
+  return n;
+}
+static double normalize4(double* q) {
+  double n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else if (fabs(n - 1) > MINVAL) { double s = 1 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+  return n;
+}
+static void mul_quat(double* r, const double* a, const double* b) {
+  double t[4] = {a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3],
+                 a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2],
+                 a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1],
+                 a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0]};
+  memcpy(r, t, sizeof t);
+}
+static void quat2mat(double* m, const double* q) {
+  double q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+  double q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3];
+  double q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02);
+  m[3] = 2*(q12 + q03); m[5] = 2*(q23 - q01);
+  m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
+}
+static void rot_vec_quat(double* r, const double* v, const double* q) {
+  double m[9]; quat2mat(m, q);
+  double t0 = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  double t1 = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  double t2 = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+static void mul_mat_vec3(double* r, const double* m, const double* v) {
+  double t0 = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  double t1 = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  double t2 = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+static void mul_matT_vec3(double* r, const double* m, const double* v) {
+  double t0 = m[0]*v[0] + m[3]*v[1] + m[6]*v[2];
+  double t1 = m[1]*v[0] + m[4]*v[1] + m[7]*v[2];
+  double t2 = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+static void axisangle2quat(double* q, const double* axis, double angle) {
+  if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+}
+static void quat_integrate(double* quat, const double* vel, double scale) {
+  double tmp[3] = {vel[0], vel[1], vel[2]}, qrot[4];
+  double angle = scale * normalize3(tmp);
+  axisangle2quat(qrot, tmp, angle);
+  normalize4(quat);
+  mul_quat(quat, quat, qrot);
+}
+/* spatial algebra */
+static void inert_com(double* res, const double* inert, const double* mat, const double* dif, double mass) {
+  double tmp[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tmp[3*r + c] = mat[3*r + c] * inert[c];
+  /* res = tmp * mat' */
+  res[0] = tmp[0]*mat[0] + tmp[1]*mat[1] + tmp[2]*mat[2];
+  res[1] = tmp[3]*mat[3] + tmp[4]*mat[4] + tmp[5]*mat[5];
+  res[2] = tmp[6]*mat[6] + tmp[7]*mat[7] + tmp[8]*mat[8];
+  res[3] = tmp[0]*mat[3] + tmp[1]*mat[4] + tmp[2]*mat[5];
+  res[4] = tmp[0]*mat[6] + tmp[1]*mat[7] + tmp[2]*mat[8];
+  res[5] = tmp[3]*mat[6] + tmp[4]*mat[7] + tmp[5]*mat[8];
+  res[0] += mass * (dif[1]*dif[1] + dif[2]*dif[2]);
+  res[1] += mass * (dif[0]*dif[0] + dif[2]*dif[2]);
+  res[2] += mass * (dif[0]*dif[0] + dif[1]*dif[1]);
+  res[3] -= mass * dif[0]*dif[1];
+  res[4] -= mass * dif[0]*dif[2];
+  res[5] -= mass * dif[1]*dif[2];
+  res[6] = mass*dif[0]; res[7] = mass*dif[1]; res[8] = mass*dif[2];
+  res[9] = mass;
+}
+static void mul_inert_vec(double* res, const double* i, const double* v) {
+  res[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
+  res[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
+  res[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
+  res[3] = i[8]*v[1] - i[7]*v[2] + i[9]*v[3];
+  res[4] = i[6]*v[2] - i[8]*v[0] + i[9]*v[4];
+  res[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
+}
+static void cross_motion(double* res, const double* vel, const double* v) {
+  res[0] = -vel[2]*v[1] + vel[1]*v[2];
+  res[1] =  vel[2]*v[0] - vel[0]*v[2];
+  res[2] = -vel[1]*v[0] + vel[0]*v[1];
+  res[3] = -vel[2]*v[4] + vel[1]*v[5];
+  res[4] =  vel[2]*v[3] - vel[0]*v[5];
+  res[5] = -vel[1]*v[3] + vel[0]*v[4];
+  res[3] += -vel[5]*v[1] + vel[4]*v[2];
+  res[4] +=  vel[5]*v[0] - vel[3]*v[2];
+  res[5] += -vel[4]*v[0] + vel[3]*v[1];
+}
+static void cross_force(double* res, const double* vel, const double* f) {
+  res[0] = -vel[2]*f[1] + vel[1]*f[2];
+  res[1] =  vel[2]*f[0] - vel[0]*f[2];
+  res[2] = -vel[1]*f[0] + vel[0]*f[1];
+  res[3] = -vel[2]*f[4] + vel[1]*f[5];
+  res[4] =  vel[2]*f[3] - vel[0]*f[5];
+  res[5] = -vel[1]*f[3] + vel[0]*f[4];
+  res[0] += -vel[5]*f[4] + vel[4]*f[5];
+  res[1] +=  vel[5]*f[3] - vel[3]*f[5];
+  res[2] += -vel[4]*f[3] + vel[3]*f[4];
+}
+static void dof_com(double* res, const double* axis, const double* offset) {
+  if (offset) { res[0] = axis[0]; res[1] = axis[1]; res[2] = axis[2]; cross3(res + 3, axis, offset); }
+  else { res[0] = res[1] = res[2] = 0; res[3] = axis[0]; res[4] = axis[1]; res[5] = axis[2]; }
+}
+static double dot_n(const double* a, const double* b, int n) {
+  double s = 0; for (int i = 0; i < n; i++) s += a[i]*b[i]; return s;
+}
+/* dense Cholesky A = L L' (lower, row-major n x n); returns rank deficiency */
+static int chol_factor(double* L, const double* A, int n) {
+  int bad = 0;
+  for (int j = 0; j < n; j++) {
+    double s = A[j*n + j];
+    for (int k = 0; k < j; k++) s -= L[j*n + k]*L[j*n + k];
+    if (s < MINVAL) { s = MINVAL; bad++; }
+    double ljj = sqrt(s);
+    L[j*n + j] = ljj;
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i*n + j];
+      for (int k = 0; k < j; k++) t -= L[i*n + k]*L[j*n + k];
+      L[i*n + j] = t / ljj;
+    }
+    for (int i = 0; i < j; i++) L[i*n + j] = 0;
+  }
+  return bad;
+}
+static void chol_solve(double* x, const double* L, const double* b, int n) {
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= L[i*n + k]*x[k];
+    x[i] = s / L[i*n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k*n + i]*x[k];
+    x[i] = s / L[i*n + i];
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* construction                                                               */
+/* ------------------------------------------------------------------------- */
+static const char* g_err = "";
+const char* ora_last_error(void) { return g_err; }
+
+Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int nreals) {
+  if (nints < 2 || ints[0] != (int32_t)DMC_MODEL_MAGIC || ints[1] != DMC_MODEL_VERSION) {
+    g_err = "bad model blob magic/version"; return NULL;
+  }
+  Model* m = (Model*)calloc(1, sizeof(Model));
+  m->ibuf = (int*)malloc(sizeof(int) * (size_t)nints);
+  m->rbuf = (double*)malloc(sizeof(double) * (size_t)nreals);
+  memcpy(m->ibuf, ints, sizeof(int) * (size_t)nints);
+  memcpy(m->rbuf, reals, sizeof(double) * (size_t)nreals);
+  int ip = 2, rp = 0;
+#define X(n) m->n = m->ibuf[ip++];
+  DMC_MODEL_HEADER_INTS(X)
+#undef X
+#define X(n) m->n = m->rbuf[rp++];
+  DMC_MODEL_HEADER_REALS(X)
+#undef X
+  int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  (void)nsensor; (void)npair; (void)nkey;
+#define X(n, c) m->n = m->ibuf + ip; ip += (c);
+  DMC_MODEL_INT_FIELDS(X)
+#undef X
+#define X(n, c) m->n = m->rbuf + rp; rp += (c);
+  DMC_MODEL_REAL_FIELDS(X)
+#undef X
+  if (ip != nints || rp != nreals) {
+    g_err = "model blob size mismatch"; free(m->ibuf); free(m->rbuf); free(m); return NULL;
+  }
+  m->nconmax = 4 * npair + 4;
+  m->njmax = 2 * njnt + 10 * m->nconmax;
+  return m;
+}
+void ora_model_free(Model* m) { if (m) { free(m->ibuf); free(m->rbuf); free(m); } }
+int ora_model_opt_int(Model* m, const char* name, int set, int value) {
+#define OI(f) if (!strcmp(name, #f)) { if (set) m->opt_##f = value; return m->opt_##f; }
+  OI(integrator) OI(cone) OI(solver) OI(iterations) OI(ls_iterations) OI(disableflags) OI(enableflags)
+#undef OI
+  return -1;
+}
+double ora_model_opt_real(Model* m, const char* name, int set, double value) {
+#define OR(f) if (!strcmp(name, #f)) { if (set) m->opt_##f = value; return m->opt_##f; }
+  OR(timestep) OR(gravity_x) OR(gravity_y) OR(gravity_z) OR(impratio) OR(tolerance) OR(ls_tolerance)
+#undef OR
+  return NAN;
+}
+int* ora_model_int_field(Model* m, const char* name, int* count) {
+  int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  (void)nsensor; (void)npair; (void)nkey;
+#define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
+  DMC_MODEL_INT_FIELDS(X)
+#undef X
+  return NULL;
+}
+double* ora_model_real_field(Model* m, const char* name, int* count) {
+  int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  (void)nsensor; (void)npair; (void)nkey;
+#define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
+  DMC_MODEL_REAL_FIELDS(X)
+#undef X
+  return NULL;
+}
+
+#define DATA_REAL_FIELDS(X) \
+  X(qpos, m->nq) X(qvel, m->nv) X(act, m->na) X(qacc_warmstart, m->nv) X(ctrl, m->nu) \
+  X(qfrc_applied, m->nv) X(xfrc_applied, 6*m->nbody) \
+  X(xpos, 3*m->nbody) X(xquat, 4*m->nbody) X(xmat, 9*m->nbody) X(xipos, 3*m->nbody) \
+  X(ximat, 9*m->nbody) X(xanchor, 3*m->njnt) X(xaxis, 3*m->njnt) \
+  X(geom_xpos, 3*m->ngeom) X(geom_xmat, 9*m->ngeom) X(site_xpos, 3*m->nsite) X(site_xmat, 9*m->nsite) \
+  X(subtree_com, 3*m->nbody) X(cinert, 10*m->nbody) X(cdof, 6*m->nv) X(crb, 10*m->nbody) \
+  X(qM, m->nv*m->nv) X(qL, m->nv*m->nv) \
+  X(cvel, 6*m->nbody) X(cdof_dot, 6*m->nv) X(qfrc_bias, m->nv) X(qfrc_passive, m->nv) \
+  X(subtree_linvel, 3*m->nbody) X(actuator_length, m->nu) X(actuator_velocity, m->nu) \
+  X(actuator_force, m->nu) X(qfrc_actuator, m->nv) X(qfrc_smooth, m->nv) X(qacc_smooth, m->nv) \
+  X(qacc, m->nv) X(qfrc_constraint, m->nv) X(cacc, 6*m->nbody) X(cfrc_int, 6*m->nbody) \
+  X(cfrc_ext, 6*m->nbody) X(sensordata, m->nsensordata) \
+  X(efc_J, m->njmax*m->nv) X(efc_pos, m->njmax) X(efc_margin, m->njmax) \
+  X(efc_diagApprox, m->njmax) X(efc_R, m->njmax) X(efc_D, m->njmax) X(efc_aref, m->njmax) \
+  X(efc_vel, m->njmax) X(efc_force, m->njmax) X(efc_KBIP, 4*m->njmax) \
+  X(w_Jaref, m->njmax) X(w_Jv, m->njmax) X(w_Ma, m->nv) X(w_Mv, m->nv) X(w_grad, m->nv) \
+  X(w_Mgrad, m->nv) X(w_search, m->nv) X(w_quad, 3*m->njmax) X(w_H, 2*m->nv*m->nv) \
+  X(w_tmp, 16*(m->nv + m->nbody + 8))
+
+void ora_reset(const Model* m, Data* d, int key);
+
+Data* ora_data_create(const Model* m) {
+  Data* d = (Data*)calloc(1, sizeof(Data));
+  size_t total = 0;
+#define X(n, c) total += (size_t)(c) + 1;
+  DATA_REAL_FIELDS(X)
+#undef X
+  d->mem = (double*)calloc(total, sizeof(double));
+  double* p = d->mem;
+#define X(n, c) d->n = p; p += (size_t)(c) + 1;
+  DATA_REAL_FIELDS(X)
+#undef X
+  d->contact = (Contact*)calloc((size_t)m->nconmax + 1, sizeof(Contact));
+  d->efc_type = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
+  d->efc_id = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
+  d->efc_state = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
+  ora_reset(m, d, -1);
+  return d;
+}
+void ora_data_free(Data* d) {
+  if (d) { free(d->mem); free(d->contact); free(d->efc_type); free(d->efc_id); free(d->efc_state); free(d); }
+}
+void ora_data_copy(const Model* m, Data* dst, const Data* src) {
+  size_t total = 0;
+#define X(n, c) total += (size_t)(c) + 1;
+  DATA_REAL_FIELDS(X)
+#undef X
+  memcpy(dst->mem, src->mem, total * sizeof(double));
+  memcpy(dst->contact, src->contact, ((size_t)m->nconmax + 1) * sizeof(Contact));
+  memcpy(dst->efc_type, src->efc_type, ((size_t)m->njmax + 1) * sizeof(int));
+  memcpy(dst->efc_id, src->efc_id, ((size_t)m->njmax + 1) * sizeof(int));
+  memcpy(dst->efc_state, src->efc_state, ((size_t)m->njmax + 1) * sizeof(int));
+  dst->time = src->time; dst->ncon = src->ncon; dst->nefc = src->nefc;
+  dst->solver_iter = src->solver_iter;
+  memcpy(dst->warning, src->warning, sizeof src->warning);
+}
+double* ora_data_field(const Model* m, Data* d, const char* name, int* count) {
+#define X(n, c) if (!strcmp(name, #n)) { *count = (c); return d->n; }
+  DATA_REAL_FIELDS(X)
+#undef X
+  if (!strcmp(name, "time")) { *count = 1; return &d->time; }
+  return NULL;
+}
+int ora_data_int(const Data* d, const char* name) {
+  if (!strcmp(name, "ncon")) return d->ncon;
+  if (!strcmp(name, "nefc")) return d->nefc;
+  if (!strcmp(name, "solver_iter")) return d->solver_iter;
+  return -1;
+}
+int* ora_data_warning(Data* d) { return d->warning; }
+int* ora_data_efc_int(Data* d, const char* name) {
+  if (!strcmp(name, "efc_type")) return d->efc_type;
+  if (!strcmp(name, "efc_id")) return d->efc_id;
+  if (!strcmp(name, "efc_state")) return d->efc_state;
+  return NULL;
+}
+/* contact i -> out[0..29]: dist, pos3, frame9, includemargin, friction5, solref2,
+ * solimp5, dim, geom1, geom2, efc_address */
+void ora_data_contact(const Data* d, int i, double* out) {
+  const Contact* c = d->contact + i;
+  int k = 0;
+  out[k++] = c->dist;
+  for (int j = 0; j < 3; j++) out[k++] = c->pos[j];
+  for (int j = 0; j < 9; j++) out[k++] = c->frame[j];
+  out[k++] = c->includemargin;
+  for (int j = 0; j < 5; j++) out[k++] = c->friction[j];
+  for (int j = 0; j < 2; j++) out[k++] = c->solref[j];
+  for (int j = 0; j < 5; j++) out[k++] = c->solimp[j];
+  out[k++] = c->dim; out[k++] = c->geom1; out[k++] = c->geom2; out[k++] = c->efc_address;
+}
+
+/* mj_resetData / mj_resetDataKeyframe (engine.py:318,323) */
+void ora_reset(const Model* m, Data* d, int key) {
+  size_t total = 0;
+#define X(n, c) total += (size_t)(c) + 1;
+  DATA_REAL_FIELDS(X)
+#undef X
+  memset(d->mem, 0, total * sizeof(double));
+  d->time = 0; d->ncon = 0; d->nefc = 0; d->solver_iter = 0;
+  memset(d->warning, 0, sizeof d->warning);
+  memcpy(d->qpos, m->qpos0, sizeof(double) * (size_t)m->nq);
+  for (int i = 0; i < m->nbody; i++) { d->xquat[4*i] = 1; d->xmat[9*i] = d->xmat[9*i+4] = d->xmat[9*i+8] = 1;
+    d->ximat[9*i] = d->ximat[9*i+4] = d->ximat[9*i+8] = 1; }
+  if (key >= 0 && key < m->nkey) {
+    memcpy(d->qpos, m->key_qpos + (size_t)key*m->nq, sizeof(double) * (size_t)m->nq);
+    memcpy(d->qvel, m->key_qvel + (size_t)key*m->nv, sizeof(double) * (size_t)m->nv);
+    memcpy(d->ctrl, m->key_ctrl + (size_t)key*m->nu, sizeof(double) * (size_t)m->nu);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* position stage                                                             */
+/* ------------------------------------------------------------------------- */
+static void kinematics(const Model* m, Data* d) {
+  d->xpos[0] = d->xpos[1] = d->xpos[2] = 0;
+  d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+  d->xipos[0] = d->xipos[1] = d->xipos[2] = 0;
+  for (int k = 0; k < 9; k++) d->xmat[k] = d->ximat[k] = (k % 4 == 0);
+  for (int i = 1; i < m->nbody; i++) {
+    double xpos[3], xquat[4];
+    int jntadr = m->body_jntadr[i], jntnum = m->body_jntnum[i];
+    if (jntnum == 1 && m->jnt_type[jntadr] == DMC_JNT_FREE) {
+      int qa = m->jnt_qposadr[jntadr];
+      memcpy(xpos, d->qpos + qa, 3 * sizeof(double));
+      memcpy(xquat, d->qpos + qa + 3, 4 * sizeof(double));
+      normalize4(xquat);
+      memcpy(d->xanchor + 3*jntadr, xpos, 3 * sizeof(double));
+      memcpy(d->xaxis + 3*jntadr, m->jnt_axis + 3*jntadr, 3 * sizeof(double));
+    } else {
+      int pid = m->body_parentid[i];
+      mul_mat_vec3(xpos, d->xmat + 9*pid, m->body_pos + 3*i);
+      xpos[0] += d->xpos[3*pid]; xpos[1] += d->xpos[3*pid+1]; xpos[2] += d->xpos[3*pid+2];
+      mul_quat(xquat, d->xquat + 4*pid, m->body_quat + 4*i);
+      for (int j = jntadr; j < jntadr + jntnum; j++) {
+        int qa = m->jnt_qposadr[j];
+        double* anchor = d->xanchor + 3*j; double* axis = d->xaxis + 3*j;
+        rot_vec_quat(axis, m->jnt_axis + 3*j, xquat);
+        rot_vec_quat(anchor, m->jnt_pos + 3*j, xquat);
+        anchor[0] += xpos[0]; anchor[1] += xpos[1]; anchor[2] += xpos[2];
+        int t = m->jnt_type[j];
+        if (t == DMC_JNT_SLIDE) {
+          double q = d->qpos[qa] - m->qpos0[qa];
+          xpos[0] += axis[0]*q; xpos[1] += axis[1]*q; xpos[2] += axis[2]*q;
+        } else if (t == DMC_JNT_BALL || t == DMC_JNT_HINGE) {
+          double qloc[4], vec[3];
+          if (t == DMC_JNT_BALL) { memcpy(qloc, d->qpos + qa, 4 * sizeof(double)); normalize4(qloc); }
+          else axisangle2quat(qloc, m->jnt_axis + 3*j, d->qpos[qa] - m->qpos0[qa]);
+          mul_quat(xquat, xquat, qloc);
+          rot_vec_quat(vec, m->jnt_pos + 3*j, xquat);
+          xpos[0] = anchor[0] - vec[0]; xpos[1] = anchor[1] - vec[1]; xpos[2] = anchor[2] - vec[2];
+        }
+      }
+    }
+    normalize4(xquat);
+    memcpy(d->xpos + 3*i, xpos, sizeof xpos);
+    memcpy(d->xquat + 4*i, xquat, sizeof xquat);
+    quat2mat(d->xmat + 9*i, xquat);
+    double v[3], q[4];
+    mul_mat_vec3(v, d->xmat + 9*i, m->body_ipos + 3*i);
+    d->xipos[3*i] = xpos[0] + v[0]; d->xipos[3*i+1] = xpos[1] + v[1]; d->xipos[3*i+2] = xpos[2] + v[2];
+    mul_quat(q, xquat, m->body_iquat + 4*i);
+    quat2mat(d->ximat + 9*i, q);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g]; double v[3], q[4];
+    mul_mat_vec3(v, d->xmat + 9*b, m->geom_pos + 3*g);
+    for (int k = 0; k < 3; k++) d->geom_xpos[3*g + k] = d->xpos[3*b + k] + v[k];
+    mul_quat(q, d->xquat + 4*b, m->geom_quat + 4*g);
+    quat2mat(d->geom_xmat + 9*g, q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s]; double v[3], q[4];
+    mul_mat_vec3(v, d->xmat + 9*b, m->site_pos + 3*s);
+    for (int k = 0; k < 3; k++) d->site_xpos[3*s + k] = d->xpos[3*b + k] + v[k];
+    mul_quat(q, d->xquat + 4*b, m->site_quat + 4*s);
+    quat2mat(d->site_xmat + 9*s, q);
+  }
+}
+
+static void com_pos(const Model* m, Data* d) {
+  int nbody = m->nbody;
+  memset(d->subtree_com, 0, sizeof(double) * 3 * (size_t)nbody);
+  for (int i = nbody - 1; i >= 0; i--) {
+    double* sc = d->subtree_com + 3*i;
+    for (int k = 0; k < 3; k++) sc[k] += d->xipos[3*i + k] * m->body_mass[i];
+    if (i) { double* pc = d->subtree_com + 3*m->body_parentid[i]; for (int k = 0; k < 3; k++) pc[k] += sc[k]; }
+    if (m->body_subtreemass[i] < MINVAL) memcpy(sc, d->xipos + 3*i, 3 * sizeof(double));
+    else { double s = 1.0 / mjMAX(MINVAL, m->body_subtreemass[i]); sc[0] *= s; sc[1] *= s; sc[2] *= s; }
+  }
+  memset(d->cinert, 0, 10 * sizeof(double));
+  for (int i = 1; i < nbody; i++) {
+    double off[3]; const double* rc = d->subtree_com + 3*m->body_rootid[i];
+    for (int k = 0; k < 3; k++) off[k] = d->xipos[3*i + k] - rc[k];
+    inert_com(d->cinert + 10*i, m->body_inertia + 3*i, d->ximat + 9*i, off, m->body_mass[i]);
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int da = 6 * m->jnt_dofadr[j], bi = m->jnt_bodyid[j], skip = 0;
+    double off[3], axis[3]; const double* rc = d->subtree_com + 3*m->body_rootid[bi];
+    for (int k = 0; k < 3; k++) off[k] = rc[k] - d->xanchor[3*j + k];
+    switch (m->jnt_type[j]) {
+      case DMC_JNT_FREE:
+        for (int i = 0; i < 3; i++) { axis[0] = axis[1] = axis[2] = 0; axis[i] = 1; dof_com(d->cdof + da + 6*i, axis, NULL); }
+        skip = 3; /* fallthrough */
+      case DMC_JNT_BALL:
+        for (int i = 0; i < 3; i++) {
+          axis[0] = d->xmat[9*bi + i]; axis[1] = d->xmat[9*bi + 3 + i]; axis[2] = d->xmat[9*bi + 6 + i];
+          dof_com(d->cdof + da + 6*(i + skip), axis, off);
+        }
+        break;
+      case DMC_JNT_SLIDE: dof_com(d->cdof + da, d->xaxis + 3*j, NULL); break;
+      case DMC_JNT_HINGE: dof_com(d->cdof + da, d->xaxis + 3*j, off); break;
+    }
+  }
+}
+
+static void crb(const Model* m, Data* d) {
+  int nbody = m->nbody, nv = m->nv;
+  memcpy(d->crb, d->cinert, sizeof(double) * 10 * (size_t)nbody);
+  for (int i = nbody - 1; i > 0; i--) if (m->body_parentid[i] > 0)
+    for (int k = 0; k < 10; k++) d->crb[10*m->body_parentid[i] + k] += d->crb[10*i + k];
+  memset(d->qM, 0, sizeof(double) * (size_t)nv * (size_t)nv);
+  for (int i = 0; i < nv; i++) {
+    double buf[6];
+    mul_inert_vec(buf, d->crb + 10*m->dof_bodyid[i], d->cdof + 6*i);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      double v = dot_n(d->cdof + 6*j, buf, 6);
+      if (j == i) v += m->dof_armature[i];
+      d->qM[i*nv + j] = v; d->qM[j*nv + i] = v;
+    }
+  }
+  chol_factor(d->qL, d->qM, nv);
+}
+
+/* ---- collision ----------------------------------------------------------- */
+static void make_frame(double* f) {
+  normalize3(f);
+  if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  }
+  double t = dot3(f, f + 3);
+  f[3] -= t*f[0]; f[4] -= t*f[1]; f[5] -= t*f[2];
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+static int raw_plane_sphere(Contact* c, double margin, const double* ppos, const double* nrm,
+                            const double* spos, double radius) {
+  double dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  double dist = dot3(dif, nrm) - radius;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->pos[k] = spos[k] - nrm[k]*(radius + dist*0.5); c->frame[k] = nrm[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
+static int raw_sphere_sphere(Contact* c, double margin, const double* p1, double r1, const double* p2, double r2) {
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double cdist = sqrt(dot3(dif, dif));
+  double dist = cdist - r1 - r2;
+  if (dist > margin) return 0;
+  double n[3];
+  if (cdist < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] = dif[0]/cdist; n[1] = dif[1]/cdist; n[2] = dif[2]/cdist; }
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->pos[k] = p1[k] + n[k]*(r1 + dist*0.5); c->frame[k] = n[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
+static int collide_plane_capsule(Contact* c, double margin, const double* p1, const double* m1,
+                                 const double* p2, const double* m2, const double* s2) {
+  double nrm[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
+  double seg[3] = {axis[0]*s2[1], axis[1]*s2[1], axis[2]*s2[1]}, pos[3], t1[3], t2[3];
+  double dp = dot3(nrm, axis);
+  for (int k = 0; k < 3; k++) t1[k] = axis[k] - nrm[k]*dp;
+  normalize3(t1);
+  cross3(t2, nrm, t1);
+  int n = 0;
+  for (int k = 0; k < 3; k++) pos[k] = p2[k] + seg[k];
+  n += raw_plane_sphere(c + n, margin, p1, nrm, pos, s2[0]);
+  for (int k = 0; k < 3; k++) pos[k] = p2[k] - seg[k];
+  n += raw_plane_sphere(c + n, margin, p1, nrm, pos, s2[0]);
+  for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { c[i].frame[3 + k] = t1[k]; c[i].frame[6 + k] = t2[k]; }
+  return n;
+}
+static int collide_plane_box(Contact* c, double margin, const double* p1, const double* m1,
+                             const double* p2, const double* m2, const double* s2) {
+  double nrm[3] = {m1[2], m1[5], m1[8]};
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double dist = dot3(dif, nrm);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    double vec[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3];
+    mul_mat_vec3(corner, m2, vec);
+    double ldist = dot3(nrm, corner);
+    if (dist + ldist > margin || ldist > 0) continue;
+    c[cnt].dist = dist + ldist;
+    for (int k = 0; k < 3; k++) { c[cnt].frame[k] = nrm[k]; c[cnt].frame[3 + k] = 0;
+      c[cnt].pos[k] = corner[k] + p2[k] - nrm[k]*c[cnt].dist*0.5; }
+    if (++cnt >= 4) return 4;
+  }
+  return cnt;
+}
+static int collide_sphere_capsule(Contact* c, double margin, const double* p1, const double* s1,
+                                  const double* p2, const double* m2, const double* s2) {
+  double axis[3] = {m2[2], m2[5], m2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  double x = dot3(axis, vec);
+  x = mjMAX(-s2[1], mjMIN(s2[1], x));
+  double q[3] = {p2[0] + axis[0]*x, p2[1] + axis[1]*x, p2[2] + axis[2]*x};
+  return raw_sphere_sphere(c, margin, p1, s1[0], q, s2[0]);
+}
+static int collide_capsule_capsule(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
+                                   const double* p2, const double* m2, const double* s2) {
+  double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+  double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+  double u = -dot3(a1, dif), v = dot3(a2, dif), det = ma*mc - mb*mb;
+  double v1[3], v2[3];
+  if (fabs(det) >= MINVAL) {
+    double x1 = (mc*u - mb*v) / det, x2 = (ma*v - mb*u) / det;
+    if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb*s1[1]) / mc; }
+    else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb*s1[1]) / mc; }
+    if (x2 > s2[1]) { x2 = s2[1]; x1 = (u - mb*s2[1]) / ma; x1 = mjMAX(-s1[1], mjMIN(s1[1], x1)); }
+    else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = (u + mb*s2[1]) / ma; x1 = mjMAX(-s1[1], mjMIN(s1[1], x1)); }
+    for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+    return raw_sphere_sphere(c, margin, v1, s1[0], v2, s2[0]);
+  }
+  /* parallel axes: up to two contacts from the segment end points */
+  int n = 0;
+  for (int s = 1; s >= -1 && n < 2; s -= 2) {
+    double x1 = s * s1[1], x2 = (v - mb*x1) / mc;
+    if (x2 >= -s2[1] && x2 <= s2[1]) {
+      for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+      n += raw_sphere_sphere(c + n, margin, v1, s1[0], v2, s2[0]);
+    }
+  }
+  for (int s = 1; s >= -1 && n < 2; s -= 2) {
+    double x2 = s * s2[1], x1 = (u - mb*x2) / ma;
+    if (x1 > -s1[1] && x1 < s1[1]) {
+      for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+      n += raw_sphere_sphere(c + n, margin, v1, s1[0], v2, s2[0]);
+    }
+  }
+  return n;
+}
+
+static void collision(const Model* m, Data* d) {
+  d->ncon = 0;
+  if (m->opt_disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)) return;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    double margin = mjMAX(m->geom_margin[g1], m->geom_margin[g2]);
+    double gap = mjMAX(m->geom_gap[g1], m->geom_gap[g2]);
+    const double *p1 = d->geom_xpos + 3*g1, *p2 = d->geom_xpos + 3*g2;
+    const double *m1 = d->geom_xmat + 9*g1, *m2 = d->geom_xmat + 9*g2;
+    const double *s1 = m->geom_size + 3*g1, *s2 = m->geom_size + 3*g2;
+    /* bounding-sphere / plane-distance rejection (pure pruning: the narrow
+     * phase below only returns contacts with dist <= margin) */
+    if (t1 == DMC_GEOM_PLANE) {
+      double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, nrm[3] = {m1[2], m1[5], m1[8]};
+      if (dot3(dif, nrm) > m->geom_rbound[g2] + margin) continue;
+    } else {
+      double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+      if (dot3(dif, dif) > bound*bound) continue;
+    }
+    if (d->ncon + 4 > m->nconmax) { d->warning[DMC_WARN_CONTACTFULL]++; break; }
+    Contact* c = d->contact + d->ncon;
+    int n = 0;
+    if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_SPHERE) { double nrm[3] = {m1[2], m1[5], m1[8]}; n = raw_plane_sphere(c, margin, p1, nrm, p2, s2[0]); }
+    else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) n = collide_plane_capsule(c, margin, p1, m1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) n = collide_plane_box(c, margin, p1, m1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) n = raw_sphere_sphere(c, margin, p1, s1[0], p2, s2[0]);
+    else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) n = collide_sphere_capsule(c, margin, p1, s1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) n = collide_capsule_capsule(c, margin, p1, m1, s1, p2, m2, s2);
+    else continue; /* pair type not restated (no such pair in the supported models) */
+    /* contact parameters (max / priority / solmix) */
+    for (int i = 0; i < n; i++) {
+      Contact* ci = c + i;
+      ci->geom1 = g1; ci->geom2 = g2; ci->includemargin = margin - gap; ci->exclude = 0; ci->efc_address = -1;
+      int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
+      double fr[3];
+      if (pr1 == pr2) {
+        ci->dim = mjMAX(m->geom_condim[g1], m->geom_condim[g2]);
+        for (int k = 0; k < 3; k++) fr[k] = mjMAX(m->geom_friction[3*g1 + k], m->geom_friction[3*g2 + k]);
+      } else {
+        int gp = pr1 > pr2 ? g1 : g2;
+        ci->dim = m->geom_condim[gp];
+        for (int k = 0; k < 3; k++) fr[k] = m->geom_friction[3*gp + k];
+      }
+      double mix;
+      if (pr1 != pr2) mix = pr1 > pr2 ? 1 : 0;
+      else {
+        double sm1 = m->geom_solmix[g1], sm2 = m->geom_solmix[g2];
+        if (sm1 >= MINVAL && sm2 >= MINVAL) mix = sm1 / (sm1 + sm2);
+        else if (sm1 < MINVAL && sm2 < MINVAL) mix = 0.5;
+        else mix = sm1 < MINVAL ? 0.0 : 1.0;
+      }
+      const double *r1 = m->geom_solref + 2*g1, *r2 = m->geom_solref + 2*g2;
+      if (r1[0] > 0 && r2[0] > 0) for (int k = 0; k < 2; k++) ci->solref[k] = mix*r1[k] + (1 - mix)*r2[k];
+      else for (int k = 0; k < 2; k++) ci->solref[k] = mjMIN(r1[k], r2[k]);
+      for (int k = 0; k < 5; k++) ci->solimp[k] = mix*m->geom_solimp[5*g1 + k] + (1 - mix)*m->geom_solimp[5*g2 + k];
+      ci->friction[0] = ci->friction[1] = mjMAX(DMC_MINMU, fr[0]);
+      ci->friction[2] = mjMAX(DMC_MINMU, fr[1]);
+      ci->friction[3] = ci->friction[4] = mjMAX(DMC_MINMU, fr[2]);
+      if (ci->frame[3] == 0 && ci->frame[4] == 0 && ci->frame[5] == 0) make_frame(ci->frame);
+    }
+    d->ncon += n;
+  }
+}
+
+/* ---- constraints --------------------------------------------------------- */
+/* translational (jp) and rotational (jr) Jacobian column `dof` of a world point
+ * attached to `body`; zero if dof is not an ancestor of body */
+static void jac_col(const Model* m, const Data* d, int body, const double* point, int dof, double* jp, double* jr) {
+  jp[0] = jp[1] = jp[2] = 0; jr[0] = jr[1] = jr[2] = 0;
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body <= 0) return;
+  int i = m->body_dofadr[body] + m->body_dofnum[body] - 1, found = 0;
+  for (; i >= 0; i = m->dof_parentid[i]) if (i == dof) { found = 1; break; }
+  if (!found) return;
+  const double* rc = d->subtree_com + 3*m->body_rootid[body];
+  double off[3] = {point[0] - rc[0], point[1] - rc[1], point[2] - rc[2]}, tmp[3];
+  const double* cd = d->cdof + 6*dof;
+  jr[0] = cd[0]; jr[1] = cd[1]; jr[2] = cd[2];
+  cross3(tmp, cd, off);
+  jp[0] = cd[3] + tmp[0]; jp[1] = cd[4] + tmp[1]; jp[2] = cd[5] + tmp[2];
+}
+static void get_impedance(const double* solimp_in, double pos, double margin, double* imp) {
+  double s[5];
+  s[0] = mjMAX(DMC_MINIMP, mjMIN(DMC_MAXIMP, solimp_in[0]));
+  s[1] = mjMAX(DMC_MINIMP, mjMIN(DMC_MAXIMP, solimp_in[1]));
+  s[2] = mjMAX(0, solimp_in[2]);
+  s[3] = mjMAX(DMC_MINIMP, mjMIN(DMC_MAXIMP, solimp_in[3]));
+  s[4] = mjMAX(1, solimp_in[4]);
+  if (s[0] == s[1] || s[2] <= MINVAL) { *imp = 0.5*(s[0] + s[1]); return; }
+  double x = (pos - margin) / s[2];
+  if (x < 0) x = -x;
+  if (x >= 1) { *imp = s[1]; return; }
+  if (x == 0) { *imp = s[0]; return; }
+  double y;
+  if (s[4] == 1) y = x;
+  else if (x <= s[3]) y = (1 / pow(s[3], s[4] - 1)) * pow(x, s[4]);
+  else y = 1 - (1 / pow(1 - s[3], s[4] - 1)) * pow(1 - x, s[4]);
+  *imp = s[0] + y*(s[1] - s[0]);
+}
+
+static void make_constraint(const Model* m, Data* d) {
+  int nv = m->nv;
+  d->nefc = 0;
+  for (int i = 0; i < d->ncon; i++) d->contact[i].efc_address = -1;
+  if (m->opt_disableflags & DMC_DSBL_CONSTRAINT) return;
+  /* joint limits */
+  if (!(m->opt_disableflags & DMC_DSBL_LIMIT)) for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j]) continue;
+    int t = m->jnt_type[j];
+    if (t != DMC_JNT_SLIDE && t != DMC_JNT_HINGE) continue; /* ball limits not restated */
+    double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[2*j + (side + 1)/2] - value);
+      if (dist < margin) {
+        if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+        int r = d->nefc++;
+        memset(d->efc_J + (size_t)r*nv, 0, sizeof(double) * (size_t)nv);
+        d->efc_J[(size_t)r*nv + m->jnt_dofadr[j]] = -(double)side;
+        d->efc_pos[r] = dist; d->efc_margin[r] = margin; d->efc_type[r] = CT_LIMIT; d->efc_id[r] = j;
+      }
+    }
+  }
+  /* contacts */
+  if (!(m->opt_disableflags & DMC_DSBL_CONTACT)) for (int ci = 0; ci < d->ncon; ci++) {
+    Contact* c = d->contact + ci;
+    if (c->exclude) continue;
+    int dim = c->dim, b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+    int nrow = dim == 1 ? 1 : 2*(dim - 1);
+    if (m->opt_cone != DMC_CONE_PYRAMIDAL && dim > 1) { g_err = "elliptic cones not restated"; nrow = 2*(dim - 1); }
+    if (d->nefc + nrow > m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+    /* contact-frame Jacobian difference: rows 0..2 translational, 3..5 rotational */
+    double* jac = d->w_tmp; /* 6*nv */
+    for (int k = 0; k < nv; k++) {
+      double jp1[3], jr1[3], jp2[3], jr2[3], dp[3], dr[3];
+      jac_col(m, d, b1, c->pos, k, jp1, jr1);
+      jac_col(m, d, b2, c->pos, k, jp2, jr2);
+      for (int a = 0; a < 3; a++) { dp[a] = jp2[a] - jp1[a]; dr[a] = jr2[a] - jr1[a]; }
+      for (int a = 0; a < 3; a++) {
+        jac[a*nv + k] = dot3(c->frame + 3*a, dp);
+        jac[(3 + a)*nv + k] = dot3(c->frame + 3*a, dr);
+      }
+    }
+    c->efc_address = d->nefc;
+    if (dim == 1) {
+      int r = d->nefc++;
+      memcpy(d->efc_J + (size_t)r*nv, jac, sizeof(double) * (size_t)nv);
+      d->efc_pos[r] = c->dist; d->efc_margin[r] = c->includemargin; d->efc_type[r] = CT_FRICTIONLESS; d->efc_id[r] = ci;
+    } else {
+      for (int k = 1; k < dim; k++) for (int s = 0; s < 2; s++) {
+        int r = d->nefc++;
+        double f = s == 0 ? c->friction[k - 1] : -c->friction[k - 1];
+        for (int a = 0; a < nv; a++) d->efc_J[(size_t)r*nv + a] = jac[a] + f*jac[k*nv + a];
+        d->efc_pos[r] = c->dist; d->efc_margin[r] = c->includemargin; d->efc_type[r] = CT_PYRAMIDAL; d->efc_id[r] = ci;
+      }
+    }
+  }
+  /* diagApprox, impedance, R, D, KBIP, aref */
+  int nefc = d->nefc;
+  for (int i = 0; i < nefc; i++) {
+    const double *solref, *solimp; double dA;
+    if (d->efc_type[i] == CT_LIMIT) {
+      int j = d->efc_id[i];
+      solref = m->jnt_solref + 2*j; solimp = m->jnt_solimp + 5*j;
+      dA = m->dof_invweight0[m->jnt_dofadr[j]];
+    } else {
+      const Contact* c = d->contact + d->efc_id[i];
+      int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+      double tran = m->body_invweight0[2*b1] + m->body_invweight0[2*b2];
+      double rot = m->body_invweight0[2*b1 + 1] + m->body_invweight0[2*b2 + 1];
+      solref = c->solref; solimp = c->solimp;
+      if (d->efc_type[i] == CT_FRICTIONLESS) dA = tran;
+      else { int j = i - c->efc_address; double fri = c->friction[j/2]; dA = tran + fri*fri*(j < 4 ? tran : rot); }
+    }
+    d->efc_diagApprox[i] = dA;
+    double ref[2] = {solref[0], solref[1]};
+    if (!(m->opt_disableflags & DMC_DSBL_REFSAFE) && ref[0] > 0) ref[0] = mjMAX(ref[0], 2*m->opt_timestep);
+    double imp; get_impedance(solimp, d->efc_pos[i], d->efc_margin[i], &imp);
+    d->efc_R[i] = mjMAX(MINVAL, (1 - imp)*dA/imp);
+    double dmax = mjMAX(DMC_MINIMP, mjMIN(DMC_MAXIMP, solimp[1])), K, B;
+    if (ref[0] > 0) { K = 1 / mjMAX(MINVAL, dmax*dmax*ref[0]*ref[0]*ref[1]*ref[1]); B = 2 / mjMAX(MINVAL, dmax*ref[0]); }
+    else { K = -ref[0] / mjMAX(MINVAL, dmax*dmax); B = -ref[1] / mjMAX(MINVAL, dmax); }
+    d->efc_KBIP[4*i] = K; d->efc_KBIP[4*i + 1] = B; d->efc_KBIP[4*i + 2] = imp; d->efc_KBIP[4*i + 3] = 0;
+  }
+  /* pyramidal contacts: all edges share Rpy = 2 mu^2 R(first edge) */
+  for (int i = 0; i < nefc; i++) if (d->efc_type[i] == CT_PYRAMIDAL) {
+    Contact* c = d->contact + d->efc_id[i];
+    int n = 2*(c->dim - 1);
+    c->mu = c->friction[0];
+    double Rpy = 2 * c->mu * c->mu * d->efc_R[i];
+    for (int j = 0; j < n; j++) d->efc_R[i + j] = Rpy;
+    i += n - 1;
+  }
+  for (int i = 0; i < nefc; i++) {
+    d->efc_D[i] = 1 / d->efc_R[i];
+    d->efc_vel[i] = dot_n(d->efc_J + (size_t)i*nv, d->qvel, nv);
+    d->efc_aref[i] = -d->efc_KBIP[4*i + 1]*d->efc_vel[i]
+                     - d->efc_KBIP[4*i]*d->efc_KBIP[4*i + 2]*(d->efc_pos[i] - d->efc_margin[i]);
+  }
+}
+
+static void transmission(const Model* m, Data* d) {
+  for (int i = 0; i < m->nu; i++) {
+    int j = m->actuator_trnid[2*i];
+    d->actuator_length[i] = m->actuator_gear[6*i] * d->qpos[m->jnt_qposadr[j]];
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* velocity stage                                                             */
+/* ------------------------------------------------------------------------- */
+static void com_vel(const Model* m, Data* d) {
+  memset(d->cvel, 0, 6 * sizeof(double));
+  for (int i = 1; i < m->nbody; i++) {
+    double cvel[6], tmp[6];
+    memcpy(cvel, d->cvel + 6*m->body_parentid[i], sizeof cvel);
+    int bda = m->body_dofadr[i];
+    int dofs = 0;
+    for (int j = m->body_jntadr[i]; j < m->body_jntadr[i] + m->body_jntnum[i]; j++) {
+      int t = m->jnt_type[j];
+      if (t == DMC_JNT_FREE) {
+        memset(d->cdof_dot + 6*bda, 0, 18 * sizeof(double));
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) cvel[a] += d->cdof[6*(bda + k) + a] * d->qvel[bda + k];
+        dofs += 3;
+      }
+      if (t == DMC_JNT_FREE || t == DMC_JNT_BALL) {
+        for (int k = 0; k < 3; k++) cross_motion(d->cdof_dot + 6*(bda + dofs + k), cvel, d->cdof + 6*(bda + dofs + k));
+        for (int a = 0; a < 6; a++) tmp[a] = 0;
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) tmp[a] += d->cdof[6*(bda + dofs + k) + a] * d->qvel[bda + dofs + k];
+        for (int a = 0; a < 6; a++) cvel[a] += tmp[a];
+        dofs += 3;
+      } else {
+        cross_motion(d->cdof_dot + 6*(bda + dofs), cvel, d->cdof + 6*(bda + dofs));
+        for (int a = 0; a < 6; a++) cvel[a] += d->cdof[6*(bda + dofs) + a] * d->qvel[bda + dofs];
+        dofs += 1;
+      }
+    }
+    memcpy(d->cvel + 6*i, cvel, sizeof cvel);
+  }
+}
+static void passive(const Model* m, Data* d) {
+  int nv = m->nv;
+  memset(d->qfrc_passive, 0, sizeof(double) * (size_t)nv);
+  if (!(m->opt_disableflags & DMC_DSBL_SPRING)) for (int j = 0; j < m->njnt; j++) {
+    double k = m->jnt_stiffness[j];
+    if (k == 0) continue;
+    int t = m->jnt_type[j], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE) d->qfrc_passive[da] -= k * (d->qpos[qa] - m->qpos_spring[qa]);
+    /* free/ball springs: not present in the supported models */
+  }
+  if (!(m->opt_disableflags & DMC_DSBL_DAMPER)) for (int i = 0; i < nv; i++)
+    d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+}
+/* mj_rne with flg_acc = 0 */
+static void rne(const Model* m, Data* d) {
+  int nbody = m->nbody, nv = m->nv;
+  double* loc_cacc = d->w_tmp;                 /* 6*nbody */
+  double* loc_cfrc = d->w_tmp + 6*nbody;       /* 6*nbody */
+  memset(loc_cacc, 0, 6 * sizeof(double));
+  if (!(m->opt_disableflags & DMC_DSBL_GRAVITY)) {
+    loc_cacc[3] = -m->opt_gravity_x; loc_cacc[4] = -m->opt_gravity_y; loc_cacc[5] = -m->opt_gravity_z;
+  }
+  memset(loc_cfrc, 0, 6 * sizeof(double));
+  for (int i = 1; i < nbody; i++) {
+    int bda = m->body_dofadr[i];
+    double tmp[6], tmp1[6];
+    for (int a = 0; a < 6; a++) tmp[a] = 0;
+    for (int k = 0; k < m->body_dofnum[i]; k++) for (int a = 0; a < 6; a++) tmp[a] += d->cdof_dot[6*(bda + k) + a] * d->qvel[bda + k];
+    for (int a = 0; a < 6; a++) loc_cacc[6*i + a] = loc_cacc[6*m->body_parentid[i] + a] + tmp[a];
+    mul_inert_vec(loc_cfrc + 6*i, d->cinert + 10*i, loc_cacc + 6*i);
+    mul_inert_vec(tmp, d->cinert + 10*i, d->cvel + 6*i);
+    cross_force(tmp1, d->cvel + 6*i, tmp);
+    for (int a = 0; a < 6; a++) loc_cfrc[6*i + a] += tmp1[a];
+  }
+  for (int i = nbody - 1; i > 0; i--) if (m->body_parentid[i])
+    for (int a = 0; a < 6; a++) loc_cfrc[6*m->body_parentid[i] + a] += loc_cfrc[6*i + a];
+  for (int i = 0; i < nv; i++) d->qfrc_bias[i] = dot_n(d->cdof + 6*i, loc_cfrc + 6*m->dof_bodyid[i], 6);
+}
+static void subtree_vel(const Model* m, Data* d) {
+  int nbody = m->nbody;
+  for (int i = 0; i < nbody; i++) {
+    const double* rc = d->subtree_com + 3*m->body_rootid[i];
+    double dif[3] = {d->xipos[3*i] - rc[0], d->xipos[3*i + 1] - rc[1], d->xipos[3*i + 2] - rc[2]}, tmp[3];
+    cross3(tmp, dif, d->cvel + 6*i);
+    for (int k = 0; k < 3; k++) d->subtree_linvel[3*i + k] = m->body_mass[i] * (d->cvel[6*i + 3 + k] - tmp[k]);
+  }
+  for (int i = nbody - 1; i >= 0; i--) {
+    if (i) for (int k = 0; k < 3; k++) d->subtree_linvel[3*m->body_parentid[i] + k] += d->subtree_linvel[3*i + k];
+    double s = 1 / mjMAX(MINVAL, m->body_subtreemass[i]);
+    for (int k = 0; k < 3; k++) d->subtree_linvel[3*i + k] *= s;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* sensors                                                                    */
+/* ------------------------------------------------------------------------- */
+/* 6D velocity [rot; lin] of a frame at `pos` attached to `body`; local != 0 rotates into `mat` */
+static void object_velocity(const Model* m, const Data* d, int body, const double* pos, const double* mat, int local, double* res) {
+  const double* rc = d->subtree_com + 3*m->body_rootid[body];
+  double dif[3] = {pos[0] - rc[0], pos[1] - rc[1], pos[2] - rc[2]}, tmp[3];
+  const double* cv = d->cvel + 6*body;
+  cross3(tmp, dif, cv);
+  double lin[3] = {cv[3] - tmp[0], cv[4] - tmp[1], cv[5] - tmp[2]};
+  if (local) { mul_matT_vec3(res, mat, cv); mul_matT_vec3(res + 3, mat, lin); }
+  else { memcpy(res, cv, 3 * sizeof(double)); memcpy(res + 3, lin, 3 * sizeof(double)); }
+}
+void ora_object_velocity(const Model* m, const Data* d, int objtype, int id, int local, double* res) {
+  if (objtype == DMC_OBJ_SITE) object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, local, res);
+  else object_velocity(m, d, id, d->xpos + 3*id, d->xmat + 9*id, local, res);
+}
+static void sensor_stage(const Model* m, Data* d, int stage) {
+  if (m->opt_disableflags & DMC_DSBL_SENSOR) return;
+  int need_subtree = 0;
+  for (int i = 0; i < m->nsensor; i++) if (m->sensor_needstage[i] == stage && m->sensor_type[i] == DMC_SENS_SUBTREELINVEL) need_subtree = 1;
+  if (need_subtree) subtree_vel(m, d);
+  for (int i = 0; i < m->nsensor; i++) {
+    if (m->sensor_needstage[i] != stage) continue;
+    double* out = d->sensordata + m->sensor_adr[i];
+    int id = m->sensor_objid[i];
+    double v6[6];
+    switch (m->sensor_type[i]) {
+      case DMC_SENS_JOINTPOS: out[0] = d->qpos[m->jnt_qposadr[id]]; break;
+      case DMC_SENS_JOINTVEL: out[0] = d->qvel[m->jnt_dofadr[id]]; break;
+      case DMC_SENS_ACTUATORFRC: out[0] = d->actuator_force[id]; break;
+      case DMC_SENS_SUBTREECOM: memcpy(out, d->subtree_com + 3*id, 3 * sizeof(double)); break;
+      case DMC_SENS_SUBTREELINVEL: memcpy(out, d->subtree_linvel + 3*id, 3 * sizeof(double)); break;
+      case DMC_SENS_VELOCIMETER:
+        object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, 1, v6);
+        memcpy(out, v6 + 3, 3 * sizeof(double)); break;
+      case DMC_SENS_GYRO:
+        object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, 1, v6);
+        memcpy(out, v6, 3 * sizeof(double)); break;
+      default: break; /* acceleration-stage site sensors: see sensor_acc() */
+    }
+  }
+}
+/* mj_rnePostConstraint: cacc, cfrc_int, cfrc_ext including contact forces */
+static void contact_force_local(const Model* m, const Data* d, int id, double* f6);
+static void rne_post_constraint(const Model* m, Data* d) {
+  int nbody = m->nbody;
+  memset(d->cfrc_ext, 0, sizeof(double) * 6 * (size_t)nbody);
+  for (int i = 1; i < nbody; i++) {
+    const double* xf = d->xfrc_applied + 6*i;
+    int nz = 0; for (int a = 0; a < 6; a++) if (xf[a] != 0) nz = 1;
+    if (!nz) continue;
+    /* xfrc_applied = [force, torque] at the body COM (xipos) */
+    const double* rc = d->subtree_com + 3*m->body_rootid[i];
+    double dif[3] = {d->xipos[3*i] - rc[0], d->xipos[3*i + 1] - rc[1], d->xipos[3*i + 2] - rc[2]}, t[3];
+    cross3(t, dif, xf);
+    for (int k = 0; k < 3; k++) { d->cfrc_ext[6*i + k] += xf[3 + k] + t[k]; d->cfrc_ext[6*i + 3 + k] += xf[k]; }
+  }
+  for (int ci = 0; ci < d->ncon; ci++) {
+    const Contact* c = d->contact + ci;
+    if (c->efc_address < 0) continue;
+    double lf[6], gf[3], gt[3];
+    contact_force_local(m, d, ci, lf);
+    mul_matT_vec3(gf, c->frame, lf); mul_matT_vec3(gt, c->frame, lf + 3);
+    int b[2] = {m->geom_bodyid[c->geom1], m->geom_bodyid[c->geom2]};
+    for (int s = 0; s < 2; s++) {
+      if (!b[s]) continue;
+      double sign = s == 0 ? -1 : 1;
+      const double* rc = d->subtree_com + 3*m->body_rootid[b[s]];
+      double dif[3] = {c->pos[0] - rc[0], c->pos[1] - rc[1], c->pos[2] - rc[2]}, t[3];
+      cross3(t, dif, gf);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6*b[s] + k] += sign*(gt[k] + t[k]); d->cfrc_ext[6*b[s] + 3 + k] += sign*gf[k]; }
+    }
+  }
+  memset(d->cacc, 0, 6 * sizeof(double));
+  if (!(m->opt_disableflags & DMC_DSBL_GRAVITY)) { d->cacc[3] = -m->opt_gravity_x; d->cacc[4] = -m->opt_gravity_y; d->cacc[5] = -m->opt_gravity_z; }
+  memset(d->cfrc_int, 0, 6 * sizeof(double));
+  for (int i = 1; i < nbody; i++) {
+    int bda = m->body_dofadr[i];
+    double csum[6], tmp[6], tmp1[6];
+    for (int a = 0; a < 6; a++) csum[a] = d->cacc[6*m->body_parentid[i] + a];
+    for (int k = 0; k < m->body_dofnum[i]; k++) for (int a = 0; a < 6; a++)
+      csum[a] += d->cdof_dot[6*(bda + k) + a]*d->qvel[bda + k] + d->cdof[6*(bda + k) + a]*d->qacc[bda + k];
+    memcpy(d->cacc + 6*i, csum, sizeof csum);
+    mul_inert_vec(tmp, d->cinert + 10*i, d->cacc + 6*i);
+    mul_inert_vec(tmp1, d->cinert + 10*i, d->cvel + 6*i);
+    double tmp2[6]; cross_force(tmp2, d->cvel + 6*i, tmp1);
+    for (int a = 0; a < 6; a++) d->cfrc_int[6*i + a] = tmp[a] + tmp2[a] - d->cfrc_ext[6*i + a];
+  }
+  for (int i = nbody - 1; i > 0; i--) for (int a = 0; a < 6; a++) d->cfrc_int[6*m->body_parentid[i] + a] += d->cfrc_int[6*i + a];
+}
+/* ray (pnt, vec) vs site volume; returns distance or -1 (sphere, capsule, box) */
+static double ray_geom(const double* pos, const double* mat, const double* size, const double* pnt, const double* vec, int type) {
+  double dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, lp[3], lv[3];
+  mul_matT_vec3(lp, mat, dif); mul_matT_vec3(lv, mat, vec);
+  double best = -1;
+  if (type == DMC_GEOM_SPHERE || type == DMC_GEOM_CAPSULE) {
+    /* sphere(s): solve |lp + x lv - c|^2 = r^2 */
+    double r = size[0];
+    for (int part = 0; part < (type == DMC_GEOM_CAPSULE ? 3 : 1); part++) {
+      double a, b, c;
+      if (type == DMC_GEOM_CAPSULE && part == 0) { /* cylinder side */
+        a = lv[0]*lv[0] + lv[1]*lv[1]; b = lp[0]*lv[0] + lp[1]*lv[1]; c = lp[0]*lp[0] + lp[1]*lp[1] - r*r;
+      } else {
+        double cz = type == DMC_GEOM_CAPSULE ? (part == 1 ? size[1] : -size[1]) : 0;
+        double q[3] = {lp[0], lp[1], lp[2] - cz};
+        a = dot3(lv, lv); b = dot3(q, lv); c = dot3(q, q) - r*r;
+      }
+      if (a < MINVAL) continue;
+      double det = b*b - a*c;
+      if (det < 0) continue;
+      double sq = sqrt(det), xs[2] = {(-b - sq)/a, (-b + sq)/a};
+      for (int k = 0; k < 2; k++) {
+        double x = xs[k];
+        if (x < 0) continue;
+        double z = lp[2] + x*lv[2];
+        if (type == DMC_GEOM_CAPSULE) {
+          if (part == 0 && fabs(z) > size[1]) continue;
+          if (part == 1 && z < size[1]) continue;
+          if (part == 2 && z > -size[1]) continue;
+        }
+        if (best < 0 || x < best) best = x;
+      }
+    }
+    /* point inside volume counts as hit at 0 */
+    return best;
+  }
+  if (type == DMC_GEOM_BOX) {
+    int inside = fabs(lp[0]) <= size[0] && fabs(lp[1]) <= size[1] && fabs(lp[2]) <= size[2];
+    if (inside) return 0;
+    for (int ax = 0; ax < 3; ax++) {
+      if (fabs(lv[ax]) < MINVAL) continue;
+      for (int s = -1; s <= 1; s += 2) {
+        double x = (s*size[ax] - lp[ax]) / lv[ax];
+        if (x < 0) continue;
+        int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        if (fabs(lp[a1] + x*lv[a1]) <= size[a1] && fabs(lp[a2] + x*lv[a2]) <= size[a2])
+          if (best < 0 || x < best) best = x;
+      }
+    }
+    return best;
+  }
+  return -1;
+}
+static void sensor_acc(const Model* m, Data* d) {
+  if (m->opt_disableflags & DMC_DSBL_SENSOR) return;
+  int need_rne = 0;
+  for (int i = 0; i < m->nsensor; i++) if (m->sensor_needstage[i] == DMC_STAGE_ACC) {
+    int t = m->sensor_type[i];
+    if (t == DMC_SENS_ACCELEROMETER || t == DMC_SENS_FORCE || t == DMC_SENS_TORQUE) need_rne = 1;
+  }
+  if (need_rne) rne_post_constraint(m, d);
+  for (int i = 0; i < m->nsensor; i++) {
+    if (m->sensor_needstage[i] != DMC_STAGE_ACC) continue;
+    double* out = d->sensordata + m->sensor_adr[i];
+    int id = m->sensor_objid[i], t = m->sensor_type[i];
+    if (t == DMC_SENS_ACTUATORFRC) { out[0] = d->actuator_force[id]; continue; }
+    int body = m->site_bodyid[id];
+    const double* spos = d->site_xpos + 3*id; const double* smat = d->site_xmat + 9*id;
+    const double* rc = d->subtree_com + 3*m->body_rootid[body];
+    if (t == DMC_SENS_TOUCH) {
+      out[0] = 0;
+      for (int ci = 0; ci < d->ncon; ci++) {
+        const Contact* c = d->contact + ci;
+        if (c->efc_address < 0) continue;
+        int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+        if (b1 != body && b2 != body) continue;
+        double lf[6]; contact_force_local(m, d, ci, lf);
+        if (lf[0] <= 0) continue;
+        double ray[3] = {c->frame[0]*lf[0], c->frame[1]*lf[0], c->frame[2]*lf[0]};
+        normalize3(ray);
+        if (b2 == body) { ray[0] = -ray[0]; ray[1] = -ray[1]; ray[2] = -ray[2]; }
+        if (ray_geom(spos, smat, m->site_size + 3*id, c->pos, ray, m->site_type[id]) >= 0) out[0] += lf[0];
+      }
+    } else if (t == DMC_SENS_ACCELEROMETER) {
+      /* linear acceleration of the site frame, incl. Coriolis term, in site frame */
+      double dif[3] = {spos[0] - rc[0], spos[1] - rc[1], spos[2] - rc[2]}, tmp[3], lin[3], vel[6], cor[3];
+      const double* ca = d->cacc + 6*body;
+      cross3(tmp, dif, ca);
+      for (int k = 0; k < 3; k++) lin[k] = ca[3 + k] - tmp[k];
+      object_velocity(m, d, body, spos, smat, 0, vel);
+      cross3(cor, vel, vel + 3);
+      for (int k = 0; k < 3; k++) lin[k] += cor[k];
+      mul_matT_vec3(out, smat, lin);
+    } else if (t == DMC_SENS_FORCE) {
+      mul_matT_vec3(out, smat, d->cfrc_int + 6*body + 3);
+    } else if (t == DMC_SENS_TORQUE) {
+      double dif[3] = {spos[0] - rc[0], spos[1] - rc[1], spos[2] - rc[2]}, tmp[3], tq[3];
+      cross3(tmp, dif, d->cfrc_int + 6*body + 3);
+      for (int k = 0; k < 3; k++) tq[k] = d->cfrc_int[6*body + k] - tmp[k];
+      mul_matT_vec3(out, smat, tq);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* actuation / smooth acceleration                                            */
+/* ------------------------------------------------------------------------- */
+static void fwd_actuation(const Model* m, Data* d) {
+  int nv = m->nv, nu = m->nu;
+  memset(d->qfrc_actuator, 0, sizeof(double) * (size_t)nv);
+  memset(d->actuator_force, 0, sizeof(double) * (size_t)nu);
+  if (m->opt_disableflags & DMC_DSBL_ACTUATION) return;
+  for (int i = 0; i < nu; i++) if (isnan(d->ctrl[i]) || fabs(d->ctrl[i]) > MAXVAL) {
+    d->warning[DMC_WARN_BADCTRL]++;
+    memset(d->ctrl, 0, sizeof(double) * (size_t)nu);
+    break;
+  }
+  for (int i = 0; i < nu; i++) {
+    double ctrl = d->ctrl[i];
+    if (m->actuator_ctrllimited[i] && !(m->opt_disableflags & DMC_DSBL_CLAMPCTRL))
+      ctrl = mjMAX(m->actuator_ctrlrange[2*i], mjMIN(m->actuator_ctrlrange[2*i + 1], ctrl));
+    const double *gp = m->actuator_gainprm + 10*i, *bp = m->actuator_biasprm + 10*i;
+    double gain = gp[0], bias = 0;
+    if (m->actuator_gaintype[i] == DMC_GAIN_AFFINE) gain = gp[0] + gp[1]*d->actuator_length[i] + gp[2]*d->actuator_velocity[i];
+    if (m->actuator_biastype[i] == DMC_BIAS_AFFINE) bias = bp[0] + bp[1]*d->actuator_length[i] + bp[2]*d->actuator_velocity[i];
+    double force = gain*ctrl + bias;
+    if (m->actuator_forcelimited[i]) force = mjMAX(m->actuator_forcerange[2*i], mjMIN(m->actuator_forcerange[2*i + 1], force));
+    d->actuator_force[i] = force;
+    d->qfrc_actuator[m->jnt_dofadr[m->actuator_trnid[2*i]]] += m->actuator_gear[6*i] * force;
+  }
+}
+static void fwd_acceleration(const Model* m, Data* d) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_applied[i] + d->qfrc_actuator[i];
+  /* xfrc_applied: Cartesian [force, torque] at body COM projected through the body Jacobian */
+  for (int b = 1; b < m->nbody; b++) {
+    const double* xf = d->xfrc_applied + 6*b;
+    int nz = 0; for (int a = 0; a < 6; a++) if (xf[a] != 0) nz = 1;
+    if (!nz) continue;
+    for (int k = 0; k < nv; k++) { double jp[3], jr[3]; jac_col(m, d, b, d->xipos + 3*b, k, jp, jr); d->qfrc_smooth[k] += dot3(jp, xf) + dot3(jr, xf + 3); }
+  }
+  chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, nv);
+}
+
+/* ------------------------------------------------------------------------- */
+/* constraint solver: Newton on the primal          */
+/* ------------------------------------------------------------------------- */
+enum { ST_SATISFIED = 0, ST_QUADRATIC = 1 };
+static double constraint_update(const Model* m, Data* d, const double* jar, int flg_state_only) {
+  (void)m; (void)flg_state_only;
+  double cost = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    if (jar[i] < 0) { d->efc_state[i] = ST_QUADRATIC; d->efc_force[i] = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; }
+    else { d->efc_state[i] = ST_SATISFIED; d->efc_force[i] = 0; }
+  }
+  return cost;
+}
+typedef struct { double alpha, cost, deriv[2]; } LSPoint;
+typedef struct { double quadGauss[3]; int nefc; const double *jar, *jv, *quad; int evals; } LSCtx;
+static void ls_eval(const LSCtx* c, LSPoint* p) {
+  double a = p->alpha, qt[3] = {c->quadGauss[0], c->quadGauss[1], c->quadGauss[2]};
+  for (int i = 0; i < c->nefc; i++) if (c->jar[i] + a*c->jv[i] < 0) { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; }
+  p->cost = a*a*qt[2] + a*qt[1] + qt[0];
+  p->deriv[0] = 2*a*qt[2] + qt[1];
+  p->deriv[1] = 2*qt[2];
+  if (p->deriv[1] <= 0) p->deriv[1] = MINVAL;
+  ((LSCtx*)c)->evals++;
+}
+static int ls_update_bracket(const LSCtx* c, LSPoint* p, const LSPoint cand[3], LSPoint* pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; i++) {
+    if (p->deriv[0] < 0 && cand[i].deriv[0] < 0 && p->deriv[0] < cand[i].deriv[0]) { *p = cand[i]; flag = 1; }
+    else if (p->deriv[0] > 0 && cand[i].deriv[0] > 0 && p->deriv[0] > cand[i].deriv[0]) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) { pnext->alpha = p->alpha - p->deriv[0]/p->deriv[1]; ls_eval(c, pnext); }
+  return flag;
+}
+static double primal_search(const Model* m, Data* d, double gauss, double scale) {
+  int nv = m->nv, nefc = d->nefc;
+  double *search = d->w_search, *Mv = d->w_Mv, *jv = d->w_Jv, *jar = d->w_Jaref, *quad = d->w_quad;
+  for (int i = 0; i < nv; i++) Mv[i] = dot_n(d->qM + (size_t)i*nv, search, nv);
+  for (int i = 0; i < nefc; i++) jv[i] = dot_n(d->efc_J + (size_t)i*nv, search, nv);
+  LSCtx c; c.nefc = nefc; c.jar = jar; c.jv = jv; c.quad = quad; c.evals = 0;
+  c.quadGauss[0] = gauss;
+  c.quadGauss[1] = dot_n(search, d->w_Ma, nv) - dot_n(d->qfrc_smooth, search, nv);
+  c.quadGauss[2] = 0.5 * dot_n(search, Mv, nv);
+  for (int i = 0; i < nefc; i++) {
+    double dj0 = d->efc_D[i]*jar[i];
+    quad[3*i] = 0.5*jar[i]*dj0; quad[3*i + 1] = jv[i]*dj0; quad[3*i + 2] = 0.5*d->efc_D[i]*jv[i]*jv[i];
+  }
+  double snorm = sqrt(dot_n(search, search, nv));
+  if (snorm < MINVAL) return 0;
+  double gtol = m->opt_tolerance * m->opt_ls_tolerance * snorm / scale;
+  int lsmax = m->opt_ls_iterations;
+  LSPoint p0, p1, p2, pmid, p1next, p2next;
+  p0.alpha = 0; ls_eval(&c, &p0);
+  p1.alpha = p0.alpha - p0.deriv[0]/p0.deriv[1]; ls_eval(&c, &p1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+  int dir = p1.deriv[0] < 0 ? 1 : -1, p2update = 0;
+  p2 = p1;
+  while (p1.deriv[0]*dir <= -gtol && c.evals < lsmax) {
+    p2 = p1; p2update = 1;
+    p1.alpha -= p1.deriv[0]/p1.deriv[1]; ls_eval(&c, &p1);
+    if (fabs(p1.deriv[0]) < gtol) return p1.alpha;
+  }
+  if (c.evals >= lsmax) return p1.alpha;
+  if (!p2update) return p1.alpha;
+  p2next = p1;
+  p1next.alpha = p1.alpha - p1.deriv[0]/p1.deriv[1]; ls_eval(&c, &p1next);
+  while (c.evals < lsmax) {
+    pmid.alpha = 0.5*(p1.alpha + p2.alpha); ls_eval(&c, &pmid);
+    LSPoint cand[3] = {p1next, p2next, pmid};
+    int best = -1;
+    for (int i = 0; i < 3; i++) if (fabs(cand[i].deriv[0]) < gtol && (best == -1 || cand[i].cost < cand[best].cost)) best = i;
+    if (best >= 0) return cand[best].alpha;
+    int b1 = ls_update_bracket(&c, &p1, cand, &p1next);
+    int b2 = ls_update_bracket(&c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : 0;
+  }
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0;
+}
+static void newton_gradient(const Model* m, Data* d) {
+  int nv = m->nv, nefc = d->nefc;
+  double *H = d->w_H, *L = d->w_H + (size_t)nv*nv;
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
+  for (int i = 0; i < nv; i++) d->w_grad[i] = d->w_Ma[i] - d->qfrc_smooth[i] - d->qfrc_constraint[i];
+  memcpy(H, d->qM, sizeof(double) * (size_t)nv * (size_t)nv);
+  for (int r = 0; r < nefc; r++) if (d->efc_state[r] == ST_QUADRATIC) {
+    const double* J = d->efc_J + (size_t)r*nv; double D = d->efc_D[r];
+    for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double s = D*J[i]; for (int j = 0; j <= i; j++) H[i*nv + j] += s*J[j]; }
+  }
+  for (int i = 0; i < nv; i++) for (int j = i + 1; j < nv; j++) H[i*nv + j] = H[j*nv + i];
+  chol_factor(L, H, nv);
+  chol_solve(d->w_Mgrad, L, d->w_grad, nv);
+}
+static double total_cost(const Model* m, Data* d, double constraint_cost, double* gauss_out) {
+  int nv = m->nv; double g = 0;
+  for (int i = 0; i < nv; i++) g += (d->w_Ma[i] - d->qfrc_smooth[i]) * (d->qacc[i] - d->qacc_smooth[i]);
+  g *= 0.5; *gauss_out = g;
+  return constraint_cost + g;
+}
+static void fwd_constraint(const Model* m, Data* d) {
+  int nv = m->nv, nefc = d->nefc;
+  d->solver_iter = 0;
+  if (!nefc) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
+    memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * (size_t)nv);
+    memset(d->qfrc_constraint, 0, sizeof(double) * (size_t)nv);
+    return;
+  }
+  double *jar = d->w_Jaref, *Ma = d->w_Ma;
+  /* warmstart: keep qacc_warmstart only if its cost beats qacc_smooth */
+  if (!(m->opt_disableflags & DMC_DSBL_WARMSTART)) {
+    memcpy(d->qacc, d->qacc_warmstart, sizeof(double) * (size_t)nv);
+    for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc, nv) - d->efc_aref[i];
+    for (int i = 0; i < nv; i++) Ma[i] = dot_n(d->qM + (size_t)i*nv, d->qacc, nv);
+    double gauss, cw = total_cost(m, d, constraint_update(m, d, jar, 1), &gauss);
+    for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc_smooth, nv) - d->efc_aref[i];
+    double cs = constraint_update(m, d, jar, 1);
+    if (cw > cs) memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
+  } else memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
+  double scale = 1 / (m->stat_meaninertia * mjMAX(1, nv));
+  for (int i = 0; i < nv; i++) Ma[i] = dot_n(d->qM + (size_t)i*nv, d->qacc, nv);
+  for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc, nv) - d->efc_aref[i];
+  double gauss, cost = total_cost(m, d, constraint_update(m, d, jar, 0), &gauss);
+  newton_gradient(m, d);
+  for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i];
+  int iter = 0;
+  while (iter < m->opt_iterations) {
+    double alpha = primal_search(m, d, gauss, scale);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) { d->qacc[i] += alpha*d->w_search[i]; Ma[i] += alpha*d->w_Mv[i]; }
+    for (int i = 0; i < nefc; i++) jar[i] += alpha*d->w_Jv[i];
+    double oldcost = cost;
+    cost = total_cost(m, d, constraint_update(m, d, jar, 0), &gauss);
+    newton_gradient(m, d);
+    for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i];
+    double improvement = scale*(oldcost - cost);
+    double gradient = scale*sqrt(dot_n(d->w_grad, d->w_grad, nv));
+    iter++;
+    if (improvement < m->opt_tolerance || gradient < m->opt_tolerance) break;
+  }
+  d->solver_iter = iter;
+  /* final forces at the solution */
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * (size_t)nv);
+}
+/* mj_contactForce in the contact frame: [normal, tangent1, tangent2, torsion, roll1, roll2] */
+static void contact_force_local(const Model* m, const Data* d, int id, double* f6) {
+  (void)m;
+  const Contact* c = d->contact + id;
+  memset(f6, 0, 6 * sizeof(double));
+  if (c->efc_address < 0) return;
+  const double* f = d->efc_force + c->efc_address;
+  if (c->dim == 1) { f6[0] = f[0]; return; }
+  for (int k = 0; k < 2*(c->dim - 1); k++) f6[0] += f[k];
+  for (int k = 1; k < c->dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * c->friction[k - 1];
+}
+void ora_contact_force(const Model* m, const Data* d, int id, double* f6) { contact_force_local(m, d, id, f6); }
+
+/* ------------------------------------------------------------------------- */
+/* pipeline                                                                   */
+/* ------------------------------------------------------------------------- */
+static void fwd_position(const Model* m, Data* d) {
+  kinematics(m, d); com_pos(m, d); crb(m, d); collision(m, d); make_constraint(m, d); transmission(m, d);
+}
+static void fwd_velocity(const Model* m, Data* d) {
+  for (int i = 0; i < m->nu; i++) d->actuator_velocity[i] = m->actuator_gear[6*i] * d->qvel[m->jnt_dofadr[m->actuator_trnid[2*i]]];
+  com_vel(m, d); passive(m, d); rne(m, d);
+}
+static int bad_vec(const double* v, int n) { for (int i = 0; i < n; i++) if (isnan(v[i]) || v[i] > MAXVAL || v[i] < -MAXVAL) return 1; return 0; }
+static void check_pos(const Model* m, Data* d) {
+  if (bad_vec(d->qpos, m->nq)) { int w[DMC_NWARNING]; memcpy(w, d->warning, sizeof w); w[DMC_WARN_BADQPOS]++;
+    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1); memcpy(d->warning, w, sizeof w); }
+}
+static void check_vel(const Model* m, Data* d) {
+  if (bad_vec(d->qvel, m->nv)) { int w[DMC_NWARNING]; memcpy(w, d->warning, sizeof w); w[DMC_WARN_BADQVEL]++;
+    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1); memcpy(d->warning, w, sizeof w); }
+}
+static void forward_skip(const Model* m, Data* d, int skipsensor) {
+  fwd_position(m, d); if (!skipsensor) sensor_stage(m, d, DMC_STAGE_POS);
+  fwd_velocity(m, d); if (!skipsensor) sensor_stage(m, d, DMC_STAGE_VEL);
+  fwd_actuation(m, d); fwd_acceleration(m, d); fwd_constraint(m, d);
+  if (!skipsensor) sensor_acc(m, d);
+}
+void ora_forward(const Model* m, Data* d) { forward_skip(m, d, 0); }
+static void check_acc(const Model* m, Data* d) {
+  if (bad_vec(d->qacc, m->nv)) { int w[DMC_NWARNING]; memcpy(w, d->warning, sizeof w); w[DMC_WARN_BADQACC]++;
+    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) { ora_reset(m, d, -1); memcpy(d->warning, w, sizeof w); ora_forward(m, d); }
+    memcpy(d->warning, w, sizeof w); }
+}
+static void integrate_pos(const Model* m, double* qpos, const double* qvel, double dt) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    switch (m->jnt_type[j]) {
+      case DMC_JNT_FREE:
+        for (int k = 0; k < 3; k++) qpos[qa + k] += dt*qvel[da + k];
+        quat_integrate(qpos + qa + 3, qvel + da + 3, dt); break;
+      case DMC_JNT_BALL: quat_integrate(qpos + qa, qvel + da, dt); break;
+      default: qpos[qa] += dt*qvel[da];
+    }
+  }
+}
+static void advance(const Model* m, Data* d, const double* qacc, const double* qvel_for_pos) {
+  double dt = m->opt_timestep;
+  for (int i = 0; i < m->nv; i++) d->qvel[i] += dt*qacc[i];
+  integrate_pos(m, d->qpos, qvel_for_pos ? qvel_for_pos : d->qvel, dt);
+  d->time += dt;
+}
+static void euler(const Model* m, Data* d) {
+  int nv = m->nv, damped = 0;
+  if (!(m->opt_disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
+  if (damped) {
+    double *H = d->w_H, *L = d->w_H + (size_t)nv*nv, *qfrc = d->w_grad, *qacc = d->w_Mgrad;
+    memcpy(H, d->qM, sizeof(double) * (size_t)nv * (size_t)nv);
+    for (int i = 0; i < nv; i++) { H[i*nv + i] += m->opt_timestep*m->dof_damping[i]; qfrc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i]; }
+    chol_factor(L, H, nv);
+    chol_solve(qacc, L, qfrc, nv);
+    advance(m, d, qacc, NULL);
+  } else advance(m, d, d->qacc, NULL);
+}
+static void rk4(const Model* m, Data* d) {
+  static const double A[9] = {0.5, 0, 0, 0, 0.5, 0, 0, 0, 1}, B[4] = {1.0/6, 1.0/3, 1.0/3, 1.0/6}, T[3] = {0.5, 0.5, 1};
+  int nq = m->nq, nv = m->nv; double h = m->opt_timestep, time = d->time;
+  double* buf = (double*)malloc(sizeof(double) * (size_t)(4*(nq + nv) + 4*2*nv + 2*nv));
+  double *X[4], *F[4], *dX = buf + 4*(nq + nv) + 8*nv;
+  for (int i = 0; i < 4; i++) { X[i] = buf + i*(nq + nv); F[i] = buf + 4*(nq + nv) + i*2*nv; }
+  memcpy(X[0], d->qpos, sizeof(double)*(size_t)nq); memcpy(X[0] + nq, d->qvel, sizeof(double)*(size_t)nv);
+  memcpy(F[0], d->qvel, sizeof(double)*(size_t)nv); memcpy(F[0] + nv, d->qacc, sizeof(double)*(size_t)nv);
+  for (int i = 1; i < 4; i++) {
+    for (int k = 0; k < 2*nv; k++) { dX[k] = 0; for (int j = 0; j < 3; j++) dX[k] += A[(i - 1)*3 + j] * (j < i ? F[j][k] : 0); }
+    memcpy(X[i], X[0], sizeof(double)*(size_t)nq);
+    integrate_pos(m, X[i], dX, h);
+    for (int k = 0; k < nv; k++) X[i][nq + k] = X[0][nq + k] + h*dX[nv + k];
+    memcpy(d->qpos, X[i], sizeof(double)*(size_t)nq); memcpy(d->qvel, X[i] + nq, sizeof(double)*(size_t)nv);
+    d->time = time + h*T[i - 1];
+    forward_skip(m, d, 1);
+    memcpy(F[i], d->qvel, sizeof(double)*(size_t)nv); memcpy(F[i] + nv, d->qacc, sizeof(double)*(size_t)nv);
+  }
+  for (int k = 0; k < 2*nv; k++) { dX[k] = 0; for (int j = 0; j < 4; j++) dX[k] += B[j]*F[j][k]; }
+  memcpy(d->qpos, X[0], sizeof(double)*(size_t)nq); memcpy(d->qvel, X[0] + nq, sizeof(double)*(size_t)nv);
+  d->time = time;
+  advance(m, d, dX + nv, dX);
+  free(buf);
+}
+void ora_step1(const Model* m, Data* d) {
+  check_pos(m, d); check_vel(m, d);
+  fwd_position(m, d); sensor_stage(m, d, DMC_STAGE_POS);
+  fwd_velocity(m, d); sensor_stage(m, d, DMC_STAGE_VEL);
+}
+void ora_step2(const Model* m, Data* d) {
+  fwd_actuation(m, d); fwd_acceleration(m, d); fwd_constraint(m, d); sensor_acc(m, d);
+  check_acc(m, d);
+  euler(m, d); /* mj_step2 always integrates with Euler (engine.py:149-154) */
+}
+void ora_step(const Model* m, Data* d, int nstep) {
+  for (int s = 0; s < nstep; s++) {
+    check_pos(m, d); check_vel(m, d);
+    ora_forward(m, d);
+    check_acc(m, d);
+    if (m->opt_integrator == DMC_INT_RK4) rk4(m, d); else euler(m, d);
+  }
+}
+/* Physics.step(nstep) with legacy_step=True (engine.py:147-162) */
+void ora_physics_step_legacy(const Model* m, Data* d, int nstep) {
+  if (m->opt_integrator != DMC_INT_RK4) { ora_step2(m, d); if (nstep > 1) ora_step(m, d, nstep - 1); }
+  else ora_step(m, d, nstep);
+  ora_step1(m, d);
+}
+/* batch convenience for the CPU baseline: B independent datas, nstep legacy steps each */
+void ora_physics_step_legacy_many(const Model* m, Data** ds, int B, int nstep) {
+  for (int e = 0; e < B; e++) ora_physics_step_legacy(m, ds[e], nstep);
+}

@@ -1,0 +1,274 @@
+"""Pins the fp64 CPU oracle against every known answer the reference holds for
+the step path.  The reference has no trajectory goldens; these
+are its analytic KATs plus the one numeric golden (mujoco/README.md:46-49)."""
+import numpy as np
+import pytest
+
+from dm_control_amd import mjcf_compiler as mc
+from oracle.oracle import OraclePhysics
+
+G = 9.81
+
+
+def _phys(xml, **kw):
+  return OraclePhysics(mc.compile_xml(xml), **kw)
+
+
+def test_readme_quickstart_golden():
+  # dm_control/mujoco/README.md:10-49: box+sphere on a slide joint dropped on a
+  # plane; geom z after 1 s printed by real MuJoCo as [0.19996362 0.39996362].
+  p = _phys("""
+  <mujoco><worldbody>
+    <geom name="floor" type="plane" size="1 1 .1"/>
+    <body name="box" pos="0 0 .3">
+      <joint name="up_down" type="slide" axis="0 0 1"/>
+      <geom name="box" type="box" size=".2 .2 .2"/>
+      <geom name="sphere" pos=".2 .2 .2" size=".1"/>
+    </body></worldbody></mujoco>""")
+  p.reset()
+  p.qpos[0] = 0.5
+  p.after_reset()
+  np.testing.assert_allclose(p.geom_xpos.reshape(-1, 3),
+                             [[0, 0, 0], [0, 0, .8], [.2, .2, 1.]], atol=1e-12)
+  while p.time < 1.:
+    p.step()
+  z = p.geom_xpos.reshape(-1, 3)[1:, 2]
+  np.testing.assert_allclose(z, [0.19996362, 0.39996362], atol=5e-9)
+
+
+def test_contact_force_equals_weight():
+  # wrapper/core_test.py:393-416
+  m = mc.compile_xml("""
+  <mujoco><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='box' pos='0 0 .1'><freejoint/>
+      <geom name='box' type='box' size='.1 .1 .1'/></body>
+  </worldbody></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  for _ in range(500):
+    p.step()
+  normal = sum(p.contact_force(i)[0, 0] for i in range(p.ncon))
+  assert p.ncon == 4
+  np.testing.assert_allclose(normal, G * m.body_mass[1], rtol=0, atol=1e-7)
+
+
+def test_disable_flags_and_touch_sensor():
+  # wrapper/core_test.py:291-330
+  m = mc.compile_xml("""
+  <mujoco><option gravity="0 0 -9.81"/><worldbody>
+    <geom name="floor" type="plane" pos="0 0 0" size="10 10 0.1"/>
+    <body name="cube" pos="0 0 0.1">
+      <geom type="box" size="0.1 0.1 0.1" mass="1"/>
+      <site name="cube_site" type="box" size="0.1 0.1 0.1"/>
+      <joint type="slide"/></body></worldbody>
+    <sensor><touch name="touch_sensor" site="cube_site"/></sensor></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  for _ in range(100):
+    p.step()
+  assert abs(p.qvel[0]) < 5e-5
+  assert abs(p.sensordata[0] - G) < 5e-3
+  flags = p.model.opt_int('disableflags')
+  p.model.opt_int('disableflags', flags | (1 << 4) | (1 << 7))   # contact, gravity
+  p.step()
+  assert abs(p.qvel[0]) < 5e-5
+  assert p.sensordata[0] == 0
+  p.model.opt_int('disableflags', flags | (1 << 4))
+  for _ in range(10):
+    p.step()
+  assert p.qvel[0] < -0.1
+  p.model.opt_int('disableflags', flags)
+
+
+@pytest.mark.parametrize('condim,expected', [(3, [False, False, False]),
+                                             (4, [True, False, False]),
+                                             (6, [True, True, True])])
+def test_contact_torque_components(condim, expected):
+  # wrapper/core_test.py:426-462
+  m = mc.compile_xml("""
+  <mujoco><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='ball' pos='0 0 .1'><freejoint/>
+      <geom name='ball' size='.1' friction='1 .1 .1'/></body>
+  </worldbody></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  p.model.field('geom_condim')[:] = condim
+  p.qvel[3:] = 1.0
+  for _ in range(10):
+    p.step()
+  assert p.ncon == 1
+  torque = p.contact_force(0)[1]
+  np.testing.assert_array_equal(torque != 0, expected)
+
+
+@pytest.mark.parametrize('qpos,linvel,angvel,local', [
+    ([0., 0.], [1.5, 0, 0], [0, 1, 0], False),
+    ([0., np.pi], [0.5, 0, 0], [0, 1, 0], False),
+    ([0., np.pi], [-0.5, 0, 0], [0, 1, 0], True)])
+def test_object_velocity(qpos, linvel, angvel, local):
+  # wrapper/core_test.py:340-391 (the reference queries the geom; a site at the
+  # same pose is used here)
+  m = mc.compile_xml("""
+  <mujoco><worldbody><body name='cart'>
+    <joint type='slide' axis='1 0 0'/>
+    <geom name='cart' type='box' size='0.2 0.2 0.2'/>
+    <body name='pole'><joint name='hinge' type='hinge' axis='0 1 0'/>
+      <geom name='mass' pos='0 0 .5' size='0.04'/>
+      <site name='mass' pos='0 0 .5'/></body></body></worldbody></mujoco>""")
+  p = OraclePhysics(m)
+  p.qpos[:] = qpos
+  p.qvel[:] = [1., 1.]
+  p.step1()
+  v = p.object_velocity(mc.C['DMC_OBJ_SITE'], 0, local)
+  np.testing.assert_allclose(v[1], linvel, atol=1e-6)
+  np.testing.assert_allclose(v[0], angvel, atol=1e-6)
+
+
+_TEST_CARTPOLE = """
+<mujoco model='test_cartpole'>
+  <compiler inertiafromgeom='true'/>
+  <option timestep='0.01'/>
+  <default><joint damping='0.05' solreflimit='.08 1'/>
+    <geom contype='0' friction='1 0.1 0.1'/></default>
+  <worldbody>
+    <geom name='floor' pos='0 0 -1' size='4 4 4' type='plane'/>
+    <body name='cart' pos='0 0 0'>
+      <joint name='slider' type='slide' limited='true' axis='1 0 0' range='-1 1'/>
+      <geom name='cart' type='box' size='0.2 0.1 0.05'/>
+      <site name='cart sensor' type='box' size='0.2 0.1 0.05'/>
+      <body name='pole' pos='0 0 0'>
+        <joint name='hinge' type='hinge' axis='0 1 0'/>
+        <geom name='cpole' type='capsule' fromto='0 0 0 0 0 0.6' size='0.045 0.3'/>
+        <site type='sphere' size='.01' name='tip' pos='.001 0 .6'/>
+      </body></body></worldbody>
+  <actuator><motor name='slide' joint='slider' gear='50' ctrllimited='true' ctrlrange='-1 1'/></actuator>
+  <sensor><accelerometer name="accelerometer" site="cart sensor"/>
+    <touch name="collision" site="cart sensor"/></sensor>
+  <keyframe><key name="hanging_down" qpos="0 1.57"/></keyframe>
+</mujoco>"""
+
+
+def test_accelerometer_after_reset():
+  # engine_test.py:591-597
+  p = _phys(_TEST_CARTPOLE)
+  p.reset()
+  p.after_reset()
+  assert abs(p.sensordata[2] - G) < 1e-9
+
+
+def test_actuation_not_applied_in_after_reset():
+  # engine_test.py:599-604
+  p = _phys(_TEST_CARTPOLE)
+  p.ctrl[0] = 1.
+  p.after_reset()
+  assert p.actuator_force[0] == 0.
+  p.forward()
+  assert p.actuator_force[0] == 1.
+
+
+@pytest.mark.parametrize('integrator', [0, 1])
+def test_nstep_equals_n_single_steps(integrator):
+  # engine_test.py:627-663 (bit-exact)
+  def run(split):
+    p = _phys(_TEST_CARTPOLE)
+    p.model.opt_int('integrator', integrator)
+    p.reset()
+    p.qvel[:] = 1
+    p.after_reset()
+    if split:
+      for _ in range(4):
+        p.step()
+    else:
+      p.step(4)
+    return np.concatenate([p.qpos, p.qvel]), p.time
+  a, ta = run(True)
+  b, tb = run(False)
+  np.testing.assert_array_equal(a, b)
+  assert ta == tb
+
+
+def test_keyframe_reset():
+  p = _phys(_TEST_CARTPOLE)
+  p.reset(0)
+  np.testing.assert_array_equal(p.qpos, [0, 1.57])
+
+
+@pytest.mark.parametrize('bad', [np.inf, np.nan, 1e15])
+def test_bad_qpos_warning(bad):
+  # engine_test.py:502-511: BADQPOS is warning index 4 and resets the data
+  p = _phys(_TEST_CARTPOLE)
+  p.qpos[0] = bad
+  p.mj_step()
+  assert p.warning[mc.C['DMC_WARN_BADQPOS']] == 1
+  assert np.all(np.isfinite(p.qpos))
+
+
+def test_nan_ctrl_warning():
+  # engine_test.py:513-523
+  p = _phys(_TEST_CARTPOLE)
+  p.ctrl[0] = np.nan
+  p.mj_step()
+  assert p.warning[mc.C['DMC_WARN_BADCTRL']] == 1
+
+
+def test_copy_continues_identically():
+  # engine_test.py:549-572
+  p = _phys(_TEST_CARTPOLE)
+  p.qvel[:] = [0.3, -0.7]
+  for _ in range(5):
+    p.step()
+  q = p.copy()
+  for _ in range(10):
+    p.step()
+    q.step()
+  np.testing.assert_array_equal(p.qpos, q.qpos)
+  np.testing.assert_array_equal(p.xpos, q.xpos)
+  assert p.time == q.time
+
+
+def test_semi_implicit_euler_matches_lqr_linearisation():
+  # suite/lqr_test.py:38-59 / lqr_solver.py:44-82 pin the update
+  #   v' = v + dt*M^-1(-K q - B v'),  q' = q + dt*v'   (joint damping implicit)
+  m = mc.compile_xml("""
+  <mujoco><option timestep="0.03" gravity="0 0 0"/><worldbody><body>
+    <joint name="j" type="slide" axis="1 0 0" stiffness="7" damping="0.4"/>
+    <geom size="0.1" mass="2"/></body></worldbody></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  p.qpos[0], p.qvel[0] = 0.3, -0.2
+  q, v, dt, k, b, mass = 0.3, -0.2, 0.03, 7.0, 0.4, 2.0
+  for _ in range(20):
+    p.step()
+    v = v + dt * (-k*q - b*v) / (mass + dt*b)
+    q = q + dt * v
+  np.testing.assert_allclose([p.qpos[0], p.qvel[0]], [q, v], rtol=1e-12)
+
+
+def test_quaternion_conventions():
+  # utils/transformations.py:364-386,447-458: wxyz, Hamilton, v' = q v q*
+  q = mc.axisangle_to_quat([0, 0, 1], np.pi / 2)
+  np.testing.assert_allclose(mc.rot_vec(q, [1, 0, 0]), [0, 1, 0], atol=1e-15)
+  a = mc.axisangle_to_quat([1, 0, 0], 0.3)
+  b = mc.axisangle_to_quat([0, 1, 0], -0.8)
+  ab = mc.quat_mul(a, b)
+  np.testing.assert_allclose(mc.quat_to_mat(ab), mc.quat_to_mat(a) @ mc.quat_to_mat(b), atol=1e-15)
+  np.testing.assert_allclose(mc.mat_to_quat(mc.quat_to_mat(ab)), ab, atol=1e-14)
+
+
+def test_energy_conservation_free_pendulum():
+  # Frictionless double pendulum under gravity: RK4 keeps total energy to O(dt^4).
+  m = mc.compile_xml("""
+  <mujoco><option timestep="0.002" integrator="RK4"/><worldbody><body pos="0 0 1">
+    <joint type="hinge" axis="0 1 0"/><geom type="capsule" fromto="0 0 0 .4 0 0" size=".03"/>
+    <body pos=".4 0 0"><joint type="hinge" axis="0 1 0"/>
+      <geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/></body></body>
+  </worldbody></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+
+  def energy():
+    p.forward()
+    nv = m.nv
+    ke = 0.5 * p.qvel @ p.qM.reshape(nv, nv) @ p.qvel
+    pe = sum(m.body_mass[i] * G * p.xipos[3*i + 2] for i in range(m.nbody))
+    return ke + pe
+  e0 = energy()
+  p.step(500)
+  assert abs(energy() - e0) < 1e-7
