@@ -1,0 +1,66 @@
+"""ctypes binding of libdmc_hip.so (include/dmc_batch.h).  There is no CPU
+fallback: if the HIP library is missing or fails to load, importing raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdmc_hip.so')
+
+EXPORTS = [
+    'dmc_last_error', 'dmc_model_create', 'dmc_model_destroy', 'dmc_batch_create',
+    'dmc_batch_destroy', 'dmc_batch_step', 'dmc_batch_forward', 'dmc_batch_reset',
+    'dmc_batch_field_rows', 'dmc_batch_get', 'dmc_batch_set', 'dmc_batch_get_int',
+    'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
+    'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
+    'dmc_batch_sync', 'dmc_batch_info', 'dmc_batch_time_steps',
+    'dmc_batch_debug_enable', 'dmc_batch_debug_get',
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+  pass
+
+
+def lib():
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise NativeError(
+        'libdmc_hip.so not built: run `python -m dm_control_amd.build` '
+        '(or __graft_entry__.build()).  There is no CPU fallback.')
+  L = ctypes.CDLL(LIB_PATH)
+  vp, ci, cd, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p
+  L.dmc_last_error.restype = cs
+  L.dmc_model_create.argtypes = [vp, ci, vp, ci, ctypes.POINTER(vp)]
+  L.dmc_model_destroy.argtypes = [vp]
+  L.dmc_batch_create.argtypes = [vp, ci, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]
+  L.dmc_batch_destroy.argtypes = [vp]
+  L.dmc_batch_step.argtypes = [vp, ci, ci, vp]
+  L.dmc_batch_forward.argtypes = [vp, ci, vp]
+  L.dmc_batch_reset.argtypes = [vp, vp, ci]
+  L.dmc_batch_field_rows.argtypes = [vp, cs, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+  L.dmc_batch_get.argtypes = [vp, cs, vp]
+  L.dmc_batch_set.argtypes = [vp, cs, vp]
+  L.dmc_batch_get_int.argtypes = [vp, cs, vp]
+  L.dmc_batch_set_int.argtypes = [vp, cs, vp]
+  L.dmc_batch_device_ptr.restype = vp
+  L.dmc_batch_device_ptr.argtypes = [vp, cs]
+  L.dmc_batch_bind.argtypes = [vp, cs, vp]
+  L.dmc_batch_set_output_mask.argtypes = [vp, ci]
+  L.dmc_batch_set_opt_int.argtypes = [vp, cs, ci]
+  L.dmc_batch_set_opt_real.argtypes = [vp, cs, cd]
+  L.dmc_batch_sync.argtypes = [vp]
+  L.dmc_batch_info.argtypes = [vp, vp]
+  L.dmc_batch_time_steps.argtypes = [vp, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
+  L.dmc_batch_debug_enable.argtypes = [vp, ci]
+  L.dmc_batch_debug_get.argtypes = [vp, cs, ci, vp, ctypes.POINTER(ci)]
+  _lib = L
+  return L
+
+
+def check(rc):
+  if rc != 0:
+    raise NativeError(lib().dmc_last_error().decode() or ('error %d' % rc))

@@ -1,0 +1,154 @@
+"""BatchedPhysics: B independent environments stepped by one HIP kernel launch.
+
+Host-side mirror of the reference's `mujoco.Physics` step surface
+(dm_control/mujoco/engine.py:139-176,306-343) over the C-ABI in
+include/dmc_batch.h.  Arrays are (B, n) on the host; on the device they are
+structure-of-arrays (n, B).
+"""
+import ctypes
+
+import numpy as np
+
+from dm_control_amd import _native
+from dm_control_amd import mjcf_compiler
+
+OUT = dict(sensor=1 << 0, xpos=1 << 1, xquat=1 << 2, xmat=1 << 3, xipos=1 << 4,
+           geom=1 << 5, site=1 << 6, subtree_com=1 << 7, qacc=1 << 8,
+           actuator=1 << 9, contact=1 << 10, qfrc=1 << 11)
+OUT_ALL = 0x7fffffff
+
+
+class BatchedPhysics:
+
+  def __init__(self, model, batch_size, device_id=0, precision=32, nconmax=0,
+               njmax=0, lanes_per_env=0):
+    if not isinstance(model, mjcf_compiler.Model):
+      raise TypeError('model must be a compiled mjcf_compiler.Model')
+    L = _native.lib()
+    self.model = model
+    self.batch_size = int(batch_size)
+    self.precision = precision
+    ints, reals = model.pack()
+    self._model_ptr = ctypes.c_void_p()
+    _native.check(L.dmc_model_create(ints.ctypes.data, ints.size, reals.ctypes.data,
+                                     reals.size, ctypes.byref(self._model_ptr)))
+    self._ptr = ctypes.c_void_p()
+    rc = L.dmc_batch_create(self._model_ptr, self.batch_size, device_id, precision,
+                            nconmax, njmax, lanes_per_env, ctypes.byref(self._ptr))
+    if rc != 0:
+      L.dmc_model_destroy(self._model_ptr)
+      self._model_ptr = None
+      _native.check(rc)
+    self.legacy_step = True
+
+  @classmethod
+  def from_xml_string(cls, xml_string, batch_size, assets=None, **kw):
+    return cls(mjcf_compiler.compile_xml(xml_string, assets), batch_size, **kw)
+
+  def close(self):
+    L = _native.lib()
+    if getattr(self, '_ptr', None):
+      L.dmc_batch_destroy(self._ptr)
+      self._ptr = None
+    if getattr(self, '_model_ptr', None):
+      L.dmc_model_destroy(self._model_ptr)
+      self._model_ptr = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # -- info ---------------------------------------------------------------------
+  def info(self):
+    a = np.zeros(10, dtype=np.int32)
+    _native.check(_native.lib().dmc_batch_info(self._ptr, a.ctypes.data))
+    keys = ['B', 'precision', 'lanes_per_env', 'waves_per_block', 'envs_per_block',
+            'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes']
+    return dict(zip(keys, (int(x) for x in a)))
+
+  def _rows(self, name):
+    rows, is_int = ctypes.c_int(), ctypes.c_int()
+    _native.check(_native.lib().dmc_batch_field_rows(self._ptr, name.encode(),
+                                                     ctypes.byref(rows), ctypes.byref(is_int)))
+    return rows.value, bool(is_int.value)
+
+  # -- field access -----------------------------------------------------------------
+  def get(self, name):
+    rows, is_int = self._rows(name)
+    if is_int:
+      out = np.zeros((self.batch_size, rows), dtype=np.int32)
+      _native.check(_native.lib().dmc_batch_get_int(self._ptr, name.encode(), out.ctypes.data))
+    else:
+      out = np.zeros((self.batch_size, rows), dtype=np.float64)
+      if rows:
+        _native.check(_native.lib().dmc_batch_get(self._ptr, name.encode(), out.ctypes.data))
+    return out
+
+  def set(self, name, value):
+    rows, is_int = self._rows(name)
+    dt = np.int32 if is_int else np.float64
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt).reshape(
+        (-1, rows) if np.ndim(value) > 1 else (1, rows) if np.ndim(value) == 1 else (1, 1)),
+        (self.batch_size, rows)))
+    if not rows:
+      return
+    fn = _native.lib().dmc_batch_set_int if is_int else _native.lib().dmc_batch_set
+    _native.check(fn(self._ptr, name.encode(), a.ctypes.data))
+
+  def device_ptr(self, name):
+    p = _native.lib().dmc_batch_device_ptr(self._ptr, name.encode())
+    if not p:
+      raise KeyError(name)
+    return p
+
+  def bind(self, name, device_ptr):
+    _native.check(_native.lib().dmc_batch_bind(self._ptr, name.encode(), device_ptr))
+
+  def set_output_mask(self, mask):
+    _native.check(_native.lib().dmc_batch_set_output_mask(self._ptr, int(mask)))
+
+  def set_opt(self, name, value):
+    L = _native.lib()
+    if isinstance(value, (int, np.integer)) and name in ('disableflags', 'iterations', 'ls_iterations'):
+      _native.check(L.dmc_batch_set_opt_int(self._ptr, name.encode(), int(value)))
+    else:
+      _native.check(L.dmc_batch_set_opt_real(self._ptr, name.encode(), float(value)))
+
+  # -- the hot path ---------------------------------------------------------------------
+  def set_control(self, control):
+    self.set('ctrl', control)
+
+  def step(self, nstep=1, stream=None):
+    _native.check(_native.lib().dmc_batch_step(self._ptr, int(nstep), int(self.legacy_step), stream))
+
+  def forward(self, disable_actuation=False, stream=None):
+    _native.check(_native.lib().dmc_batch_forward(self._ptr, int(disable_actuation), stream))
+
+  def reset(self, env_mask=None, keyframe_id=None):
+    m = None
+    if env_mask is not None:
+      m = np.ascontiguousarray(np.asarray(env_mask, dtype=np.uint8))
+    _native.check(_native.lib().dmc_batch_reset(
+        self._ptr, m.ctypes.data if m is not None else None,
+        -1 if keyframe_id is None else int(keyframe_id)))
+
+  def sync(self):
+    _native.check(_native.lib().dmc_batch_sync(self._ptr))
+
+  def time_steps(self, nstep, reps, stream=None):
+    ms = ctypes.c_float()
+    _native.check(_native.lib().dmc_batch_time_steps(self._ptr, int(nstep), int(self.legacy_step),
+                                                     int(reps), stream, ctypes.byref(ms)))
+    return ms.value
+
+  # -- debug ----------------------------------------------------------------------------
+  def debug_enable(self, n):
+    _native.check(_native.lib().dmc_batch_debug_enable(self._ptr, int(n)))
+
+  def debug_get(self, name, env=0, maxcount=1 << 16):
+    buf = np.zeros(maxcount)
+    cnt = ctypes.c_int()
+    _native.check(_native.lib().dmc_batch_debug_get(self._ptr, name.encode(), env, buf.ctypes.data, ctypes.byref(cnt)))
+    return buf[:cnt.value].copy()

@@ -1,0 +1,436 @@
+// dmc_api.hip -- host side of libdmc_hip.so: the C-ABI of include/dmc_batch.h.
+// Owns device memory (SoA mjData arrays), builds the kernel tables / LDS layout
+// and launches the fused step kernel.  No CPU fallback exists: every entry point
+// that computes runs the HIP kernel or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dmc_batch.h"
+#include "step_kernel.hip.h"
+#include "step_tables.h"
+
+namespace dmc {
+hipError_t launch_step_f32(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<float>& o,
+                           const int* g_mi, const float* g_mr, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask);
+hipError_t launch_step_f64(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<double>& o,
+                           const int* g_mi, const double* g_mr, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask);
+}  // namespace dmc
+
+using namespace dmc;
+
+static thread_local std::string g_err;
+static int fail(const std::string& msg, int code = -1) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_), -2); \
+  } while (0)
+
+struct dmc_model {
+  HostModel hm;
+};
+
+struct Field {
+  std::string name;
+  int rows;
+  bool is_int;
+  void* dev;       // current binding
+  void* owned;     // hipMalloc'ed by us (may differ from dev after dmc_batch_bind)
+};
+
+struct dmc_batch {
+  const dmc_model* model;
+  int B, device, precision;
+  StepTables tb;
+  LaunchGeom geom;
+  int* d_mi;
+  void* d_mr;
+  std::vector<Field> fields;
+  std::map<std::string, int> index;
+  int outmask;
+  int ndebug;
+  void* d_debug;
+  int* d_debug_i;
+  size_t elem;  // sizeof(T)
+};
+
+extern "C" const char* dmc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int dmc_model_create(const int32_t* ints, int n_ints, const double* reals, int n_reals, dmc_model** out) {
+  if (!ints || !reals || !out) return fail("null argument");
+  dmc_model* m = new dmc_model;
+  std::string err;
+  if (!host_model_parse(&m->hm, ints, n_ints, reals, n_reals, &err)) { delete m; return fail(err); }
+  *out = m;
+  return 0;
+}
+extern "C" void dmc_model_destroy(dmc_model* m) { delete m; }
+
+static Field* find_field(dmc_batch* b, const char* name) {
+  auto it = b->index.find(name);
+  return it == b->index.end() ? nullptr : &b->fields[it->second];
+}
+
+static int choose_geometry(dmc_batch* b, int lanes_per_env) {
+  const StepLayout& L = b->tb.L;
+  const size_t tables = (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem;
+  const size_t env_bytes = (size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int);
+  const size_t lds_cu = 160 * 1024;
+  int lpe = lanes_per_env ? lanes_per_env : 64;
+  if (lpe != 64 && lpe != 32 && lpe != 16) return fail("lanes_per_env must be 64, 32 or 16");
+  const int epw = 64 / lpe;
+  int best_w = 0; long best_score = -1;
+  for (int w = 4; w >= 1; w--) {
+    const size_t bytes = tables + (size_t)w * epw * env_bytes;
+    if (bytes > lds_cu) continue;
+    long blocks = (long)(lds_cu / bytes);
+    if (blocks * w > 32) blocks = 32 / w;           // 32 waves per CU
+    const long score = blocks * w * epw;            // resident envs per CU
+    if (score > best_score) { best_score = score; best_w = w; }
+  }
+  if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
+  LaunchGeom& g = b->geom;
+  g.lpe = lpe; g.waves = best_w; g.envs_per_block = best_w * epw;
+  g.lds_bytes = (int)(tables + (size_t)g.envs_per_block * env_bytes);
+  g.grid = (b->B + g.envs_per_block - 1) / g.envs_per_block;
+  return 0;
+}
+
+static int upload_tables(dmc_batch* b) {
+  const StepLayout& L = b->tb.L;
+  HIP_TRY(hipMemcpy(b->d_mi, b->tb.mi.data(), (size_t)L.n_mi * sizeof(int), hipMemcpyHostToDevice));
+  if (b->precision == 64) {
+    HIP_TRY(hipMemcpy(b->d_mr, b->tb.mr.data(), (size_t)L.n_mr * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> f(b->tb.mr.begin(), b->tb.mr.end());
+    HIP_TRY(hipMemcpy(b->d_mr, f.data(), (size_t)L.n_mr * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
+                                int nconmax, int njmax, int lanes_per_env, dmc_batch** out) {
+  if (!m || !out) return fail("null argument");
+  if (batch_size < 1) return fail("batch_size must be >= 1");
+  if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail("no HIP device available: the batched step has no CPU fallback", -3);
+  if (device_id < 0 || device_id >= ndev) return fail("invalid device id");
+  HIP_TRY(hipSetDevice(device_id));
+  dmc_batch* b = new dmc_batch();
+  b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
+  b->elem = precision == 64 ? sizeof(double) : sizeof(float);
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr;
+  std::string err;
+  if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
+  if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
+  const StepLayout& L = b->tb.L;
+  const StepDims& d = L.d;
+  hipError_t e = hipMalloc(&b->d_mi, (size_t)L.n_mi * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&b->d_mr, (size_t)L.n_mr * b->elem);
+  if (e != hipSuccess) { delete b; return fail(std::string("hipMalloc: ") + hipGetErrorString(e), -2); }
+  if (upload_tables(b)) { delete b; return -2; }
+  struct Spec { const char* name; int rows; bool is_int; };
+  const int nb = d.nbody;
+  const Spec specs[] = {
+      {"qpos", d.nq, false}, {"qvel", d.nv, false}, {"ctrl", d.nu, false}, {"qacc_warmstart", d.nv, false},
+      {"qfrc_applied", d.nv, false}, {"time", 1, false},
+      {"sensordata", d.nsensordata, false}, {"xpos", 3*nb, false}, {"xquat", 4*nb, false}, {"xmat", 9*nb, false},
+      {"xipos", 3*nb, false}, {"geom_xpos", 3*d.ngeom, false}, {"geom_xmat", 9*d.ngeom, false},
+      {"site_xpos", 3*d.nsite, false}, {"site_xmat", 9*d.nsite, false}, {"subtree_com", 3*nb, false},
+      {"qacc", d.nv, false}, {"actuator_force", d.nu, false}, {"qfrc_actuator", d.nv, false},
+      {"qfrc_bias", d.nv, false}, {"qfrc_constraint", d.nv, false},
+      {"contact_dist", d.nconmax, false}, {"contact_pos", 3*d.nconmax, false}, {"contact_frame", 9*d.nconmax, false},
+      {"ncon", 1, true}, {"nefc", 1, true}, {"solver_iter", 1, true}, {"warning", DMC_NWARNING, true},
+      {"contact_geom1", d.nconmax, true}, {"contact_geom2", d.nconmax, true}};
+  for (const Spec& s : specs) {
+    Field f; f.name = s.name; f.rows = s.rows; f.is_int = s.is_int; f.dev = nullptr; f.owned = nullptr;
+    const size_t bytes = (size_t)std::max(1, s.rows) * b->B * (s.is_int ? sizeof(int) : b->elem);
+    e = hipMalloc(&f.owned, bytes);
+    if (e == hipSuccess) e = hipMemset(f.owned, 0, bytes);
+    if (e != hipSuccess) { *out = nullptr; dmc_batch_destroy(b); return fail(std::string("hipMalloc field: ") + hipGetErrorString(e), -2); }
+    f.dev = f.owned;
+    b->index[f.name] = (int)b->fields.size();
+    b->fields.push_back(f);
+  }
+  *out = b;
+  return dmc_batch_reset(b, nullptr, -1);
+}
+
+extern "C" void dmc_batch_destroy(dmc_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (Field& f : b->fields) if (f.owned) (void)hipFree(f.owned);
+  if (b->d_mi) (void)hipFree(b->d_mi);
+  if (b->d_mr) (void)hipFree(b->d_mr);
+  if (b->d_debug) (void)hipFree(b->d_debug);
+  if (b->d_debug_i) (void)hipFree(b->d_debug_i);
+  delete b;
+}
+
+template <typename T>
+static void fill_io(dmc_batch* b, StepIO<T>* io) {
+  auto P = [&](const char* n) { return find_field(b, n)->dev; };
+  io->B = b->B;
+  io->qpos = (T*)P("qpos"); io->qvel = (T*)P("qvel"); io->ctrl = (T*)P("ctrl");
+  io->qacc_warmstart = (T*)P("qacc_warmstart"); io->qfrc_applied = (T*)P("qfrc_applied"); io->time = (T*)P("time");
+  io->sensordata = (T*)P("sensordata"); io->xpos = (T*)P("xpos"); io->xquat = (T*)P("xquat"); io->xmat = (T*)P("xmat");
+  io->xipos = (T*)P("xipos"); io->geom_xpos = (T*)P("geom_xpos"); io->geom_xmat = (T*)P("geom_xmat");
+  io->site_xpos = (T*)P("site_xpos"); io->site_xmat = (T*)P("site_xmat"); io->subtree_com = (T*)P("subtree_com");
+  io->qacc = (T*)P("qacc"); io->actuator_force = (T*)P("actuator_force"); io->qfrc_actuator = (T*)P("qfrc_actuator");
+  io->qfrc_bias = (T*)P("qfrc_bias"); io->qfrc_constraint = (T*)P("qfrc_constraint");
+  io->contact_dist = (T*)P("contact_dist"); io->contact_pos = (T*)P("contact_pos"); io->contact_frame = (T*)P("contact_frame");
+  io->ncon = (int*)P("ncon"); io->nefc = (int*)P("nefc"); io->solver_iter = (int*)P("solver_iter");
+  io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
+  io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
+}
+
+static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  hipError_t e;
+  if (b->precision == 64) {
+    StepIO<double> io; fill_io(b, &io);
+    e = launch_step_f64(b->geom, (hipStream_t)stream, b->tb.L, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask);
+  } else {
+    StepIO<float> io; fill_io(b, &io);
+    e = launch_step_f32(b->geom, (hipStream_t)stream, b->tb.L, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask);
+  }
+  if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e), -2);
+  return 0;
+}
+
+extern "C" int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream) {
+  if (!b) return fail("null batch");
+  if (nstep < 1) return fail("nstep must be >= 1");
+  return launch(b, nstep, legacy_step ? 1 : 0, 0, hip_stream);
+}
+extern "C" int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream) {
+  if (!b) return fail("null batch");
+  return launch(b, 0, 0, disable_actuation ? 2 : 1, hip_stream);
+}
+extern "C" int dmc_batch_sync(dmc_batch* b) {
+  if (!b) return fail("null batch");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+// ---- host <-> device field transfer (env-major host, SoA device) ------------------
+static int get_real(dmc_batch* b, Field* f, double* dst) {
+  const size_t n = (size_t)f->rows * b->B;
+  if (!n) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (b->precision == 64) {
+    std::vector<double> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), f->dev, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) dst[(size_t)e * f->rows + k] = tmp[(size_t)k * b->B + e];
+  } else {
+    std::vector<float> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), f->dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) dst[(size_t)e * f->rows + k] = tmp[(size_t)k * b->B + e];
+  }
+  return 0;
+}
+static int set_real(dmc_batch* b, Field* f, const double* src) {
+  const size_t n = (size_t)f->rows * b->B;
+  if (!n) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (b->precision == 64) {
+    std::vector<double> tmp(n);
+    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = src[(size_t)e * f->rows + k];
+    HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> tmp(n);
+    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = (float)src[(size_t)e * f->rows + k];
+    HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+extern "C" int dmc_batch_field_rows(const dmc_batch* b, const char* name, int* rows, int* is_int) {
+  if (!b || !name) return fail("null argument");
+  Field* f = find_field(const_cast<dmc_batch*>(b), name);
+  if (!f) return fail(std::string("unknown field: ") + name);
+  if (rows) *rows = f->rows;
+  if (is_int) *is_int = f->is_int;
+  return 0;
+}
+extern "C" int dmc_batch_get(dmc_batch* b, const char* name, double* dst) {
+  if (!b || !name || !dst) return fail("null argument");
+  Field* f = find_field(b, name);
+  if (!f || f->is_int) return fail(std::string("unknown real field: ") + name);
+  return get_real(b, f, dst);
+}
+extern "C" int dmc_batch_set(dmc_batch* b, const char* name, const double* src) {
+  if (!b || !name || !src) return fail("null argument");
+  Field* f = find_field(b, name);
+  if (!f || f->is_int) return fail(std::string("unknown real field: ") + name);
+  return set_real(b, f, src);
+}
+extern "C" int dmc_batch_get_int(dmc_batch* b, const char* name, int32_t* dst) {
+  if (!b || !name || !dst) return fail("null argument");
+  Field* f = find_field(b, name);
+  if (!f || !f->is_int) return fail(std::string("unknown int field: ") + name);
+  const size_t n = (size_t)f->rows * b->B;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int32_t> tmp(n);
+  HIP_TRY(hipMemcpy(tmp.data(), f->dev, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) dst[(size_t)e * f->rows + k] = tmp[(size_t)k * b->B + e];
+  return 0;
+}
+extern "C" int dmc_batch_set_int(dmc_batch* b, const char* name, const int32_t* src) {
+  if (!b || !name || !src) return fail("null argument");
+  Field* f = find_field(b, name);
+  if (!f || !f->is_int) return fail(std::string("unknown int field: ") + name);
+  const size_t n = (size_t)f->rows * b->B;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int32_t> tmp(n);
+  for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = src[(size_t)e * f->rows + k];
+  HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" void* dmc_batch_device_ptr(dmc_batch* b, const char* name) {
+  if (!b || !name) { fail("null argument"); return nullptr; }
+  Field* f = find_field(b, name);
+  if (!f) { fail(std::string("unknown field: ") + name); return nullptr; }
+  return f->dev;
+}
+extern "C" int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr) {
+  if (!b || !name) return fail("null argument");
+  Field* f = find_field(b, name);
+  if (!f) return fail(std::string("unknown field: ") + name);
+  f->dev = device_ptr ? device_ptr : f->owned;
+  return 0;
+}
+extern "C" int dmc_batch_set_output_mask(dmc_batch* b, int mask) {
+  if (!b) return fail("null batch");
+  b->outmask = mask;
+  return 0;
+}
+extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) {
+  if (!b || !name) return fail("null argument");
+  StepOpts<double>& o = b->tb.opts;
+  if (!strcmp(name, "disableflags")) o.disableflags = value;
+  else if (!strcmp(name, "iterations")) o.iterations = value;
+  else if (!strcmp(name, "ls_iterations")) o.ls_iterations = value;
+  else return fail(std::string("unknown int option: ") + name);
+  return 0;
+}
+extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value) {
+  if (!b || !name) return fail("null argument");
+  StepOpts<double>& o = b->tb.opts;
+  if (!strcmp(name, "timestep")) o.timestep = value;
+  else if (!strcmp(name, "tolerance")) o.tolerance = value;
+  else if (!strcmp(name, "ls_tolerance")) o.ls_tolerance = value;
+  else if (!strcmp(name, "gravity_x")) o.gravity[0] = value;
+  else if (!strcmp(name, "gravity_y")) o.gravity[1] = value;
+  else if (!strcmp(name, "gravity_z")) o.gravity[2] = value;
+  else return fail(std::string("unknown real option: ") + name);
+  return 0;
+}
+
+extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe) {
+  if (!b) return fail("null batch");
+  const HostModel& m = b->model->hm;
+  if (keyframe >= m.nkey) return fail("keyframe out of range");
+  const int B = b->B;
+  auto reset_real = [&](const char* name, const double* init, int rows) -> int {
+    Field* f = find_field(b, name);
+    if (!rows) return 0;
+    std::vector<double> host((size_t)B * rows);
+    if (env_mask) { if (get_real(b, f, host.data())) return -2; }
+    for (int e = 0; e < B; e++) if (!env_mask || env_mask[e]) for (int k = 0; k < rows; k++) host[(size_t)e * rows + k] = init ? init[k] : 0.0;
+    return set_real(b, f, host.data());
+  };
+  const double* q0 = keyframe >= 0 ? &m.key_qpos[(size_t)keyframe * m.nq] : m.qpos0.data();
+  const double* v0 = keyframe >= 0 ? &m.key_qvel[(size_t)keyframe * m.nv] : nullptr;
+  const double* c0 = keyframe >= 0 ? &m.key_ctrl[(size_t)keyframe * m.nu] : nullptr;
+  if (reset_real("qpos", q0, m.nq)) return -2;
+  if (reset_real("qvel", v0, m.nv)) return -2;
+  if (reset_real("ctrl", c0, m.nu)) return -2;
+  if (reset_real("qacc_warmstart", nullptr, m.nv)) return -2;
+  if (reset_real("qfrc_applied", nullptr, m.nv)) return -2;
+  if (reset_real("time", nullptr, 1)) return -2;
+  // mj_resetData clears warnings as well
+  Field* w = find_field(b, "warning");
+  std::vector<int32_t> wh((size_t)B * DMC_NWARNING, 0);
+  if (env_mask) { if (dmc_batch_get_int(b, "warning", wh.data())) return -2; for (int e = 0; e < B; e++) if (env_mask[e]) for (int k = 0; k < DMC_NWARNING; k++) wh[(size_t)e * DMC_NWARNING + k] = 0; }
+  (void)w;
+  return dmc_batch_set_int(b, "warning", wh.data());
+}
+
+extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
+  if (!b || !info) return fail("null argument");
+  const StepLayout& L = b->tb.L;
+  info[0] = b->B; info[1] = b->precision; info[2] = b->geom.lpe; info[3] = b->geom.waves; info[4] = b->geom.envs_per_block;
+  info[5] = b->geom.lds_bytes; info[6] = b->geom.grid; info[7] = L.d.nconmax; info[8] = L.d.njmax;
+  info[9] = (int)((size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int));
+  return 0;
+}
+
+extern "C" int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, void* hip_stream, float* ms_per_launch) {
+  if (!b || !ms_per_launch || reps < 1) return fail("bad argument");
+  HIP_TRY(hipSetDevice(b->device));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, (hipStream_t)hip_stream));
+  for (int r = 0; r < reps; r++) { int rc = dmc_batch_step(b, nstep, legacy_step, hip_stream); if (rc) return rc; }
+  HIP_TRY(hipEventRecord(e1, (hipStream_t)hip_stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / reps;
+  return 0;
+}
+
+extern "C" int dmc_batch_debug_enable(dmc_batch* b, int n) {
+  if (!b) return fail("null batch");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->d_debug) { (void)hipFree(b->d_debug); b->d_debug = nullptr; }
+  if (b->d_debug_i) { (void)hipFree(b->d_debug_i); b->d_debug_i = nullptr; }
+  b->ndebug = 0;
+  if (n <= 0) return 0;
+  if (n > b->B) n = b->B;
+  const StepLayout& L = b->tb.L;
+  HIP_TRY(hipMalloc(&b->d_debug, (size_t)L.n_sr * n * b->elem));
+  HIP_TRY(hipMalloc((void**)&b->d_debug_i, (size_t)L.n_si * n * sizeof(int)));
+  HIP_TRY(hipMemset(b->d_debug, 0, (size_t)L.n_sr * n * b->elem));
+  HIP_TRY(hipMemset(b->d_debug_i, 0, (size_t)L.n_si * n * sizeof(int)));
+  b->ndebug = n;
+  return 0;
+}
+extern "C" int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int env, double* dst, int* count) {
+  if (!b || !scratch_name || !dst || !count) return fail("null argument");
+  if (env < 0 || env >= b->ndebug) return fail("env outside the debug window");
+  int off, cnt, kind;
+  if (!step_layout_find(&b->tb.L, scratch_name, &off, &cnt, &kind)) return fail(std::string("unknown scratch array: ") + scratch_name);
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int n = b->ndebug;
+  const size_t total = (size_t)cnt * n;
+  if (kind) {
+    std::vector<int> tmp(total);
+    HIP_TRY(hipMemcpy(tmp.data(), b->d_debug_i + (size_t)off * n, total * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; i++) dst[i] = tmp[(size_t)i * n + env];
+  } else if (b->precision == 64) {
+    std::vector<double> tmp(total);
+    HIP_TRY(hipMemcpy(tmp.data(), (double*)b->d_debug + (size_t)off * n, total * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; i++) dst[i] = tmp[(size_t)i * n + env];
+  } else {
+    std::vector<float> tmp(total);
+    HIP_TRY(hipMemcpy(tmp.data(), (float*)b->d_debug + (size_t)off * n, total * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; i++) dst[i] = tmp[(size_t)i * n + env];
+  }
+  *count = cnt;
+  return 0;
+}

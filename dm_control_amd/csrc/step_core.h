@@ -1,0 +1,1343 @@
+// step_core.h -- the batched physics step, one environment per LPE-lane group.
+//
+// Replaces, for a whole batch at once, what the reference does one environment
+// at a time through mujoco.mj_step / mj_step1 / mj_step2 / mj_forward
+// (dm_control/mujoco/engine.py:147-176,335-343): kinematics + COM frame, CRB mass
+// matrix + factorisation, collision, constraint assembly, velocity stage (RNE
+// bias, passive), actuation, Newton constraint solve, semi-implicit Euler.
+//
+// Execution model (MI355X / gfx950): a group of LPE lanes of one 64-wide
+// wavefront owns one environment.  Everything the group shares lives in LDS
+// (`s`/`si` scratch, `mi`/`mr` model tables); lanes split loops as
+// `for (i = lane; i < n; i += LPE)` and meet at DMC_WSYNC() (a wave-level
+// fence: LDS ops of one wave retire in order, so no s_barrier is needed).
+// Cross-lane arithmetic goes through group_sum/group_scan only, so the same
+// source is valid for any LPE in {1,..,64}; tests/emu compiles it with LPE=1 on
+// the host purely to unit-test the indexing logic without a GPU.
+//
+// Arithmetic order deliberately mirrors the fp64 oracle (oracle/mjstep_oracle.c)
+// wherever a lane-parallel form with the identical operation order exists
+// (tree accumulations in child-descending order, right-looking Cholesky,
+// column-oriented substitution), so that the fp64 instantiation tracks the
+// oracle to rounding noise; reductions over constraint rows are the exception.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/dmc_model_layout.h"
+#include "step_layout.h"
+
+#ifdef DMC_HOST_EMU
+#define DMC_DEV inline
+#define DMC_WSYNC() ((void)0)
+#else
+#define DMC_DEV __device__ __forceinline__
+#define DMC_WSYNC()                                             \
+  do {                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
+    __builtin_amdgcn_wave_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      \
+  } while (0)
+#endif
+
+namespace dmc {
+
+// output selection bits (which derived arrays a launch writes back to HBM)
+enum {
+  OUT_SENSOR = 1 << 0, OUT_XPOS = 1 << 1, OUT_XQUAT = 1 << 2, OUT_XMAT = 1 << 3,
+  OUT_XIPOS = 1 << 4, OUT_GEOM = 1 << 5, OUT_SITE = 1 << 6, OUT_SUBTREE_COM = 1 << 7,
+  OUT_QACC = 1 << 8, OUT_ACTUATOR = 1 << 9, OUT_CONTACT = 1 << 10, OUT_QFRC = 1 << 11,
+  OUT_ALL = 0x7fffffff
+};
+
+// SoA device arrays: element (k, env) of a field lives at base[k * B + env]
+template <typename T>
+struct StepIO {
+  int B;
+  T *qpos, *qvel, *ctrl, *qacc_warmstart, *qfrc_applied, *time;
+  T *sensordata, *xpos, *xquat, *xmat, *xipos, *geom_xpos, *geom_xmat;
+  T *site_xpos, *site_xmat, *subtree_com, *qacc, *actuator_force, *qfrc_actuator;
+  T *qfrc_bias, *qfrc_constraint, *contact_dist, *contact_pos, *contact_frame;
+  int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
+  T* debug;      // optional: (n_sr, ndebug) dump of the env scratch after forward
+  int* debug_i;  // optional: (n_si, ndebug)
+  int ndebug;
+};
+
+// ---------------------------------------------------------------------------
+// scalar math (expression order mirrors the oracle)
+// ---------------------------------------------------------------------------
+template <typename T> DMC_DEV T t_sqrt(T x) { return (T)sqrt((double)x); }
+template <> DMC_DEV float t_sqrt<float>(float x) { return sqrtf(x); }
+template <typename T> DMC_DEV T t_sin(T x) { return (T)sin((double)x); }
+template <> DMC_DEV float t_sin<float>(float x) { return sinf(x); }
+template <typename T> DMC_DEV T t_cos(T x) { return (T)cos((double)x); }
+template <> DMC_DEV float t_cos<float>(float x) { return cosf(x); }
+template <typename T> DMC_DEV T t_pow(T x, T y) { return (T)pow((double)x, (double)y); }
+template <> DMC_DEV float t_pow<float>(float x, float y) { return powf(x, y); }
+template <typename T> DMC_DEV T t_abs(T x) { return x < 0 ? -x : x; }
+template <typename T> DMC_DEV T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> DMC_DEV T t_min(T a, T b) { return a < b ? a : b; }
+template <typename T> DMC_DEV bool t_bad(T x) { return !(x == x) || x > (T)DMC_MAXVAL || x < -(T)DMC_MAXVAL; }
+
+template <typename T> DMC_DEV T dot3(const T* a, const T* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+template <typename T> DMC_DEV void cross3(T* r, const T* a, const T* b) {
+  T t0 = a[1]*b[2] - a[2]*b[1], t1 = a[2]*b[0] - a[0]*b[2], t2 = a[0]*b[1] - a[1]*b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+template <typename T> DMC_DEV T normalize3(T* v) {
+  T n = t_sqrt(dot3(v, v));
+  if (n < (T)DMC_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; }
+  else { T s = 1 / n; v[0] *= s; v[1] *= s; v[2] *= s; }
+  return n;
+}
+template <typename T> DMC_DEV void normalize4(T* q) {
+  T n = t_sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  if (n < (T)DMC_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else if (t_abs(n - 1) > (T)DMC_MINVAL) { T s = 1 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+template <typename T> DMC_DEV void mul_quat(T* r, const T* a, const T* b) {
+  T t0 = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
+  T t1 = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+  T t2 = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1];
+  T t3 = a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+template <typename T> DMC_DEV void quat2mat(T* m, const T* q) {
+  T q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+  T q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3];
+  T q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2*(q12 - q03); m[2] = 2*(q13 + q02);
+  m[3] = 2*(q12 + q03); m[5] = 2*(q23 - q01);
+  m[6] = 2*(q13 - q02); m[7] = 2*(q23 + q01);
+}
+template <typename T> DMC_DEV void mul_mat_vec3(T* r, const T* m, const T* v) {
+  T t0 = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  T t1 = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  T t2 = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+template <typename T> DMC_DEV void mul_matT_vec3(T* r, const T* m, const T* v) {
+  T t0 = m[0]*v[0] + m[3]*v[1] + m[6]*v[2];
+  T t1 = m[1]*v[0] + m[4]*v[1] + m[7]*v[2];
+  T t2 = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
+  r[0] = t0; r[1] = t1; r[2] = t2;
+}
+template <typename T> DMC_DEV void rot_vec_quat(T* r, const T* v, const T* q) {
+  T m[9]; quat2mat(m, q); mul_mat_vec3(r, m, v);
+}
+template <typename T> DMC_DEV void axisangle2quat(T* q, const T* axis, T angle) {
+  if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  T s = t_sin(angle * (T)0.5);
+  q[0] = t_cos(angle * (T)0.5); q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+}
+template <typename T> DMC_DEV void quat_integrate(T* quat, const T* vel, T scale) {
+  T tmp[3] = {vel[0], vel[1], vel[2]}, qrot[4];
+  T angle = scale * normalize3(tmp);
+  axisangle2quat(qrot, tmp, angle);
+  normalize4(quat);
+  mul_quat(quat, quat, qrot);
+}
+template <typename T> DMC_DEV void inert_com(T* res, const T* inert, const T* mat, const T* dif, T mass) {
+  T tmp[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tmp[3*r + c] = mat[3*r + c] * inert[c];
+  res[0] = tmp[0]*mat[0] + tmp[1]*mat[1] + tmp[2]*mat[2];
+  res[1] = tmp[3]*mat[3] + tmp[4]*mat[4] + tmp[5]*mat[5];
+  res[2] = tmp[6]*mat[6] + tmp[7]*mat[7] + tmp[8]*mat[8];
+  res[3] = tmp[0]*mat[3] + tmp[1]*mat[4] + tmp[2]*mat[5];
+  res[4] = tmp[0]*mat[6] + tmp[1]*mat[7] + tmp[2]*mat[8];
+  res[5] = tmp[3]*mat[6] + tmp[4]*mat[7] + tmp[5]*mat[8];
+  res[0] += mass * (dif[1]*dif[1] + dif[2]*dif[2]);
+  res[1] += mass * (dif[0]*dif[0] + dif[2]*dif[2]);
+  res[2] += mass * (dif[0]*dif[0] + dif[1]*dif[1]);
+  res[3] -= mass * dif[0]*dif[1];
+  res[4] -= mass * dif[0]*dif[2];
+  res[5] -= mass * dif[1]*dif[2];
+  res[6] = mass*dif[0]; res[7] = mass*dif[1]; res[8] = mass*dif[2];
+  res[9] = mass;
+}
+template <typename T> DMC_DEV void mul_inert_vec(T* res, const T* i, const T* v) {
+  res[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
+  res[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
+  res[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
+  res[3] = i[8]*v[1] - i[7]*v[2] + i[9]*v[3];
+  res[4] = i[6]*v[2] - i[8]*v[0] + i[9]*v[4];
+  res[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
+}
+template <typename T> DMC_DEV void cross_motion(T* res, const T* vel, const T* v) {
+  res[0] = -vel[2]*v[1] + vel[1]*v[2];
+  res[1] =  vel[2]*v[0] - vel[0]*v[2];
+  res[2] = -vel[1]*v[0] + vel[0]*v[1];
+  res[3] = -vel[2]*v[4] + vel[1]*v[5];
+  res[4] =  vel[2]*v[3] - vel[0]*v[5];
+  res[5] = -vel[1]*v[3] + vel[0]*v[4];
+  res[3] += -vel[5]*v[1] + vel[4]*v[2];
+  res[4] +=  vel[5]*v[0] - vel[3]*v[2];
+  res[5] += -vel[4]*v[0] + vel[3]*v[1];
+}
+template <typename T> DMC_DEV void cross_force(T* res, const T* vel, const T* f) {
+  res[0] = -vel[2]*f[1] + vel[1]*f[2];
+  res[1] =  vel[2]*f[0] - vel[0]*f[2];
+  res[2] = -vel[1]*f[0] + vel[0]*f[1];
+  res[3] = -vel[2]*f[4] + vel[1]*f[5];
+  res[4] =  vel[2]*f[3] - vel[0]*f[5];
+  res[5] = -vel[1]*f[3] + vel[0]*f[4];
+  res[0] += -vel[5]*f[4] + vel[4]*f[5];
+  res[1] +=  vel[5]*f[3] - vel[3]*f[5];
+  res[2] += -vel[4]*f[3] + vel[3]*f[4];
+}
+template <typename T> DMC_DEV T dot_n(const T* a, const T* b, int n) {
+  T s = 0; for (int i = 0; i < n; i++) s += a[i]*b[i]; return s;
+}
+
+// ---------------------------------------------------------------------------
+// group primitives (LPE lanes of one wave)
+// ---------------------------------------------------------------------------
+template <int LPE, typename V> DMC_DEV V group_sum(V v) {
+#ifndef DMC_HOST_EMU
+#pragma unroll
+  for (int o = LPE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPE);
+#endif
+  return v;
+}
+template <int LPE> DMC_DEV int group_max(int v) {
+#ifndef DMC_HOST_EMU
+#pragma unroll
+  for (int o = LPE / 2; o > 0; o >>= 1) { int w = __shfl_xor(v, o, LPE); v = w > v ? w : v; }
+#endif
+  return v;
+}
+// exclusive prefix sum over the group; *total receives the group sum
+template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
+#ifndef DMC_HOST_EMU
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < LPE; o <<= 1) { int w = __shfl_up(inc, o, LPE); if (lane >= o) inc += w; }
+  *total = __shfl(inc, LPE - 1, LPE);
+  return inc - v;
+#else
+  (void)lane; *total = v; return 0;
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// the step
+// ---------------------------------------------------------------------------
+template <typename T, int LPE>
+struct StepCore {
+  const StepLayout& L;
+  const StepOpts<T>& o;
+  const int* mi;
+  const T* mr;
+  T* s;
+  int* si;
+  int lane;
+
+  DMC_DEV StepCore(const StepLayout& L_, const StepOpts<T>& o_, const int* mi_, const T* mr_, T* s_, int* si_, int lane_)
+      : L(L_), o(o_), mi(mi_), mr(mr_), s(s_), si(si_), lane(lane_) {}
+
+#define MI(n) (mi + L.mi_##n)
+#define MR(n) (mr + L.mr_##n)
+#define S(n) (s + L.s_##n)
+#define SI(n) (si + L.si_##n)
+#define FOR_LANES(i, n) for (int i = lane; i < (n); i += LPE)
+
+  // ---- state I/O (SoA in HBM <-> LDS) --------------------------------------
+  DMC_DEV void load_state(const StepIO<T>& io, int env) {
+    const int B = io.B;
+    FOR_LANES(i, L.d.nq) S(qpos)[i] = io.qpos[(size_t)i*B + env];
+    FOR_LANES(i, L.d.nv) {
+      S(qvel)[i] = io.qvel[(size_t)i*B + env];
+      S(qacc_warmstart)[i] = io.qacc_warmstart[(size_t)i*B + env];
+      S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;
+    }
+    FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
+    if (lane == 0) {
+      S(misc)[MISC_TIME] = io.time[env];
+      for (int k = 0; k < 8; k++) SI(imisc)[IM_WARN + k] = 0;
+      SI(imisc)[IM_NCON] = 0; SI(imisc)[IM_NEFC] = 0; SI(imisc)[IM_ITER] = 0;
+      // world body
+      T* xp = S(xpos); T* xq = S(xquat); T* xm = S(xmat); T* xi = S(xipos); T* xim = S(ximat);
+      xp[0] = xp[1] = xp[2] = 0; xi[0] = xi[1] = xi[2] = 0;
+      xq[0] = 1; xq[1] = xq[2] = xq[3] = 0;
+      for (int k = 0; k < 9; k++) xm[k] = xim[k] = (k % 4 == 0) ? (T)1 : (T)0;
+      for (int k = 0; k < 10; k++) { S(cinert)[k] = 0; S(crb)[k] = 0; }
+      for (int k = 0; k < 6; k++) { S(cvel)[k] = 0; S(cfrc)[k] = 0; }
+    }
+    FOR_LANES(i, L.d.nv * L.d.nv) { S(qM)[i] = 0; }
+    FOR_LANES(i, L.d.nsensordata) S(sensordata)[i] = 0;
+    DMC_WSYNC();
+  }
+  DMC_DEV void store_state(const StepIO<T>& io, int env) {
+    const int B = io.B;
+    FOR_LANES(i, L.d.nq) io.qpos[(size_t)i*B + env] = S(qpos)[i];
+    FOR_LANES(i, L.d.nv) {
+      io.qvel[(size_t)i*B + env] = S(qvel)[i];
+      io.qacc_warmstart[(size_t)i*B + env] = S(qacc_warmstart)[i];
+    }
+    if (lane == 0) {
+      io.time[env] = S(misc)[MISC_TIME];
+      for (int k = 0; k < 8; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
+    }
+    // ctrl may have been zeroed by a BADCTRL warning (mj_fwdActuation semantics)
+    if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) io.ctrl[(size_t)i*B + env] = S(ctrl)[i];
+  }
+  DMC_DEV void store_outputs(const StepIO<T>& io, int env, int mask) {
+    const int B = io.B;
+    const int nb = L.d.nbody;
+    if (mask & OUT_SENSOR) FOR_LANES(i, L.d.nsensordata) io.sensordata[(size_t)i*B + env] = S(sensordata)[i];
+    if (mask & OUT_XPOS) FOR_LANES(i, 3*nb) io.xpos[(size_t)i*B + env] = S(xpos)[i];
+    if (mask & OUT_XQUAT) FOR_LANES(i, 4*nb) io.xquat[(size_t)i*B + env] = S(xquat)[i];
+    if (mask & OUT_XMAT) FOR_LANES(i, 9*nb) io.xmat[(size_t)i*B + env] = S(xmat)[i];
+    if (mask & OUT_XIPOS) FOR_LANES(i, 3*nb) io.xipos[(size_t)i*B + env] = S(xipos)[i];
+    if (mask & OUT_SUBTREE_COM) FOR_LANES(i, 3*nb) io.subtree_com[(size_t)i*B + env] = S(subtree_com)[i];
+    if (mask & OUT_GEOM) {
+      FOR_LANES(i, 3*L.d.ngeom) io.geom_xpos[(size_t)i*B + env] = S(geom_xpos)[i];
+      FOR_LANES(i, 9*L.d.ngeom) io.geom_xmat[(size_t)i*B + env] = S(geom_xmat)[i];
+    }
+    if (mask & OUT_SITE) FOR_LANES(sid, L.d.nsite) {
+      int b = MI(site_bodyid)[sid]; T v[3], q[4], m[9];
+      mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*sid);
+      for (int k = 0; k < 3; k++) io.site_xpos[(size_t)(3*sid + k)*B + env] = S(xpos)[3*b + k] + v[k];
+      mul_quat(q, S(xquat) + 4*b, MR(site_quat) + 4*sid);
+      quat2mat(m, q);
+      for (int k = 0; k < 9; k++) io.site_xmat[(size_t)(9*sid + k)*B + env] = m[k];
+    }
+    if (mask & OUT_QACC) FOR_LANES(i, L.d.nv) io.qacc[(size_t)i*B + env] = S(qacc)[i];
+    if (mask & OUT_QFRC) FOR_LANES(i, L.d.nv) {
+      io.qfrc_bias[(size_t)i*B + env] = S(qfrc_bias)[i];
+      io.qfrc_constraint[(size_t)i*B + env] = S(qfrc_constraint)[i];
+      io.qfrc_actuator[(size_t)i*B + env] = S(qfrc_actuator)[i];
+    }
+    if (mask & OUT_ACTUATOR) FOR_LANES(i, L.d.nu) io.actuator_force[(size_t)i*B + env] = S(actuator_force)[i];
+    if (lane == 0) {
+      io.ncon[env] = SI(imisc)[IM_NCON]; io.nefc[env] = SI(imisc)[IM_NEFC]; io.solver_iter[env] = SI(imisc)[IM_ITER];
+    }
+    if (mask & OUT_CONTACT) {
+      const int nc = SI(imisc)[IM_NCON];
+      FOR_LANES(c, L.d.nconmax) {
+        bool live = c < nc;
+        io.contact_geom1[(size_t)c*B + env] = live ? SI(con_geom1)[c] : -1;
+        io.contact_geom2[(size_t)c*B + env] = live ? SI(con_geom2)[c] : -1;
+        io.contact_dist[(size_t)c*B + env] = live ? S(con_dist)[c] : (T)0;
+        for (int k = 0; k < 3; k++) io.contact_pos[(size_t)(3*c + k)*B + env] = live ? S(con_pos)[3*c + k] : (T)0;
+        for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? S(con_frame)[9*c + k] : (T)0;
+      }
+    }
+  }
+  DMC_DEV void dump_debug(const StepIO<T>& io, int env) {
+    if (!io.debug || env >= io.ndebug) return;
+    FOR_LANES(i, L.n_sr) io.debug[(size_t)i*io.ndebug + env] = s[i];
+    FOR_LANES(i, L.n_si) io.debug_i[(size_t)i*io.ndebug + env] = si[i];
+  }
+
+  // ---- kinematics (mj_kinematics) --------------------------------------------
+  DMC_DEV void body_kinematics(int i) {
+    T xpos[3], xquat[4];
+    const int jntadr = MI(body_jntadr)[i], jntnum = MI(body_jntnum)[i];
+    if (jntnum == 1 && MI(jnt_type)[jntadr] == DMC_JNT_FREE) {
+      const int qa = MI(jnt_qposadr)[jntadr];
+      for (int k = 0; k < 3; k++) xpos[k] = S(qpos)[qa + k];
+      for (int k = 0; k < 4; k++) xquat[k] = S(qpos)[qa + 3 + k];
+      normalize4(xquat);
+      for (int k = 0; k < 3; k++) { S(xanchor)[3*jntadr + k] = xpos[k]; S(xaxis)[3*jntadr + k] = MR(jnt_axis)[3*jntadr + k]; }
+    } else {
+      const int pid = MI(body_parentid)[i];
+      mul_mat_vec3(xpos, S(xmat) + 9*pid, MR(body_pos) + 3*i);
+      xpos[0] += S(xpos)[3*pid]; xpos[1] += S(xpos)[3*pid + 1]; xpos[2] += S(xpos)[3*pid + 2];
+      mul_quat(xquat, S(xquat) + 4*pid, MR(body_quat) + 4*i);
+      for (int j = jntadr; j < jntadr + jntnum; j++) {
+        const int qa = MI(jnt_qposadr)[j];
+        T anchor[3], axis[3];
+        rot_vec_quat(axis, MR(jnt_axis) + 3*j, xquat);
+        rot_vec_quat(anchor, MR(jnt_pos) + 3*j, xquat);
+        anchor[0] += xpos[0]; anchor[1] += xpos[1]; anchor[2] += xpos[2];
+        for (int k = 0; k < 3; k++) { S(xanchor)[3*j + k] = anchor[k]; S(xaxis)[3*j + k] = axis[k]; }
+        const int t = MI(jnt_type)[j];
+        if (t == DMC_JNT_SLIDE) {
+          T q = S(qpos)[qa] - MR(qpos0)[qa];
+          xpos[0] += axis[0]*q; xpos[1] += axis[1]*q; xpos[2] += axis[2]*q;
+        } else if (t == DMC_JNT_BALL || t == DMC_JNT_HINGE) {
+          T qloc[4], vec[3];
+          if (t == DMC_JNT_BALL) { for (int k = 0; k < 4; k++) qloc[k] = S(qpos)[qa + k]; normalize4(qloc); }
+          else axisangle2quat(qloc, MR(jnt_axis) + 3*j, S(qpos)[qa] - MR(qpos0)[qa]);
+          mul_quat(xquat, xquat, qloc);
+          rot_vec_quat(vec, MR(jnt_pos) + 3*j, xquat);
+          xpos[0] = anchor[0] - vec[0]; xpos[1] = anchor[1] - vec[1]; xpos[2] = anchor[2] - vec[2];
+        }
+      }
+    }
+    normalize4(xquat);
+    T mat[9], v[3], q[4];
+    quat2mat(mat, xquat);
+    for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = xpos[k];
+    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = xquat[k];
+    for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = mat[k];
+    mul_mat_vec3(v, mat, MR(body_ipos) + 3*i);
+    for (int k = 0; k < 3; k++) S(xipos)[3*i + k] = xpos[k] + v[k];
+    mul_quat(q, xquat, MR(body_iquat) + 4*i);
+    quat2mat(mat, q);
+    for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = mat[k];
+  }
+  DMC_DEV void kinematics() {
+    for (int lev = 0; lev < L.d.nlevel; lev++) {
+      const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
+      for (int k = a0 + lane; k < a1; k += LPE) body_kinematics(MI(level_body)[k]);
+      DMC_WSYNC();
+    }
+    FOR_LANES(g, L.d.ngeom) {
+      const int b = MI(geom_bodyid)[g]; T v[3], q[4], m[9];
+      mul_mat_vec3(v, S(xmat) + 9*b, MR(geom_pos) + 3*g);
+      for (int k = 0; k < 3; k++) S(geom_xpos)[3*g + k] = S(xpos)[3*b + k] + v[k];
+      mul_quat(q, S(xquat) + 4*b, MR(geom_quat) + 4*g);
+      quat2mat(m, q);
+      for (int k = 0; k < 9; k++) S(geom_xmat)[9*g + k] = m[k];
+    }
+    DMC_WSYNC();
+  }
+
+  // ---- COM frame: subtree_com, cinert, cdof (mj_comPos) -------------------------
+  DMC_DEV void subtree_com_body(int b) {
+    T acc[3] = {0, 0, 0};
+    for (int c = MI(child_adr)[b]; c < MI(child_adr)[b + 1]; c++) {
+      const int ch = MI(child_list)[c];
+      for (int k = 0; k < 3; k++) acc[k] += S(subtree_usum)[3*ch + k];
+    }
+    const T mass = MR(body_mass)[b];
+    for (int k = 0; k < 3; k++) acc[k] += S(xipos)[3*b + k] * mass;
+    for (int k = 0; k < 3; k++) S(subtree_usum)[3*b + k] = acc[k];
+    if (MR(body_subtreemass)[b] < (T)DMC_MINVAL) for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = S(xipos)[3*b + k];
+    else { const T sc = MR(body_invsubtreemass)[b]; for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = acc[k] * sc; }
+  }
+  DMC_DEV void com_pos() {
+    for (int lev = L.d.nlevel - 1; lev >= 0; lev--) {
+      const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
+      for (int k = a0 + lane; k < a1; k += LPE) subtree_com_body(MI(level_body)[k]);
+      DMC_WSYNC();
+    }
+    if (lane == 0) subtree_com_body(0);
+    DMC_WSYNC();
+    for (int i = 1 + lane; i < L.d.nbody; i += LPE) {
+      T off[3], ci[10]; const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
+      for (int k = 0; k < 3; k++) off[k] = S(xipos)[3*i + k] - rc[k];
+      inert_com(ci, MR(body_inertia) + 3*i, S(ximat) + 9*i, off, MR(body_mass)[i]);
+      for (int k = 0; k < 10; k++) S(cinert)[10*i + k] = ci[k];
+    }
+    FOR_LANES(j, L.d.njnt) {
+      const int da = 6*MI(jnt_dofadr)[j], bi = MI(jnt_bodyid)[j], t = MI(jnt_type)[j];
+      T off[3], axis[3], cr[3]; const T* rc = S(subtree_com) + 3*MI(body_rootid)[bi];
+      for (int k = 0; k < 3; k++) off[k] = rc[k] - S(xanchor)[3*j + k];
+      T* cd = S(cdof) + da;
+      if (t == DMC_JNT_FREE || t == DMC_JNT_BALL) {
+        int skip = 0;
+        if (t == DMC_JNT_FREE) {
+          for (int i = 0; i < 3; i++) for (int k = 0; k < 6; k++) cd[6*i + k] = (k == 3 + i) ? (T)1 : (T)0;
+          skip = 3;
+        }
+        for (int i = 0; i < 3; i++) {
+          axis[0] = S(xmat)[9*bi + i]; axis[1] = S(xmat)[9*bi + 3 + i]; axis[2] = S(xmat)[9*bi + 6 + i];
+          cross3(cr, axis, off);
+          T* c = cd + 6*(i + skip);
+          c[0] = axis[0]; c[1] = axis[1]; c[2] = axis[2]; c[3] = cr[0]; c[4] = cr[1]; c[5] = cr[2];
+        }
+      } else if (t == DMC_JNT_SLIDE) {
+        cd[0] = cd[1] = cd[2] = 0;
+        for (int k = 0; k < 3; k++) cd[3 + k] = S(xaxis)[3*j + k];
+      } else {
+        for (int k = 0; k < 3; k++) axis[k] = S(xaxis)[3*j + k];
+        cross3(cr, axis, off);
+        cd[0] = axis[0]; cd[1] = axis[1]; cd[2] = axis[2]; cd[3] = cr[0]; cd[4] = cr[1]; cd[5] = cr[2];
+      }
+    }
+    DMC_WSYNC();
+  }
+
+  // ---- dense Cholesky / solves in LDS (same operation order as the oracle) -----
+  // in-place right-looking factorisation of the lower triangle of A (n x n)
+  DMC_DEV void chol_factor_inplace(T* A, int n) {
+    for (int k = 0; k < n; k++) {
+      T akk = A[k*n + k];
+      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+      const T lkk = t_sqrt(akk);
+      DMC_WSYNC();
+      if (lane == 0) A[k*n + k] = lkk;
+      for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] / lkk;
+      DMC_WSYNC();
+      const int m = n - k - 1;
+      for (int idx = lane; idx < m*m; idx += LPE) {
+        const int r = idx / m, c = idx - r*m;
+        if (c <= r) { const int i = k + 1 + r, j = k + 1 + c; A[i*n + j] -= A[i*n + k]*A[j*n + k]; }
+      }
+      DMC_WSYNC();
+    }
+  }
+  // x = (L L')^-1 b ; x and b may alias
+  DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
+    FOR_LANES(i, n) x[i] = b[i];
+    DMC_WSYNC();
+    for (int k = 0; k < n; k++) {
+      const T xk = x[k] / Lm[k*n + k];
+      DMC_WSYNC();
+      if (lane == 0) x[k] = xk;
+      for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[i*n + k]*xk;
+      DMC_WSYNC();
+    }
+    for (int k = n - 1; k >= 0; k--) {
+      const T xk = x[k] / Lm[k*n + k];
+      DMC_WSYNC();
+      if (lane == 0) x[k] = xk;
+      for (int i = lane; i < k; i += LPE) x[i] -= Lm[k*n + i]*xk;
+      DMC_WSYNC();
+    }
+  }
+
+  // ---- CRB mass matrix + factor (mj_crb, mj_factorM) ----------------------------
+  DMC_DEV void crb_mass_matrix() {
+    const int nv = L.d.nv;
+    for (int i = 10 + lane; i < 10*L.d.nbody; i += LPE) S(crb)[i] = S(cinert)[i];
+    DMC_WSYNC();
+    for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
+      const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
+      for (int idx = lane; idx < cnt*10; idx += LPE) {
+        const int b = MI(level_body)[a0 + idx/10], comp = idx % 10;
+        const int c0 = MI(child_adr)[b], c1 = MI(child_adr)[b + 1];
+        if (c1 > c0) {
+          T v = S(crb)[10*b + comp];
+          for (int c = c0; c < c1; c++) v += S(crb)[10*MI(child_list)[c] + comp];
+          S(crb)[10*b + comp] = v;
+        }
+      }
+      DMC_WSYNC();
+    }
+    FOR_LANES(i, nv) {
+      T buf[6]; mul_inert_vec(buf, S(crb) + 10*MI(dof_bodyid)[i], S(cdof) + 6*i);
+      for (int k = 0; k < 6; k++) S(mbuf)[6*i + k] = buf[k];
+    }
+    DMC_WSYNC();
+    FOR_LANES(p, L.d.nM) {
+      const int i = MI(mpair_i)[p], j = MI(mpair_j)[p];
+      T v = dot_n(S(cdof) + 6*j, S(mbuf) + 6*i, 6);
+      if (i == j) v += MR(dof_armature)[i];
+      S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v;
+    }
+    DMC_WSYNC();
+    FOR_LANES(i, nv*nv) S(qL)[i] = S(qM)[i];
+    DMC_WSYNC();
+    chol_factor_inplace(S(qL), nv);
+  }
+
+  // ---- collision (mj_collision over the static candidate pair list) -------------
+  DMC_DEV static void make_frame(T* f) {
+    normalize3(f);
+    if (t_sqrt(dot3(f + 3, f + 3)) < (T)0.5) {
+      f[3] = f[4] = f[5] = 0;
+      if (f[1] < (T)0.5 && f[1] > (T)-0.5) f[4] = 1; else f[5] = 1;
+    }
+    T t = dot3(f, f + 3);
+    f[3] -= t*f[0]; f[4] -= t*f[1]; f[5] -= t*f[2];
+    normalize3(f + 3);
+    cross3(f + 6, f, f + 3);
+  }
+  struct Hit { T dist, pos[3], nrm[3]; };
+  DMC_DEV static int plane_sphere(Hit* h, T margin, const T* ppos, const T* nrm, const T* spos, T radius) {
+    T dif[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+    T dist = dot3(dif, nrm) - radius;
+    if (dist > margin) return 0;
+    h->dist = dist;
+    for (int k = 0; k < 3; k++) { h->pos[k] = spos[k] - nrm[k]*(radius + dist*(T)0.5); h->nrm[k] = nrm[k]; }
+    return 1;
+  }
+  DMC_DEV static int sphere_sphere(Hit* h, T margin, const T* p1, T r1, const T* p2, T r2) {
+    T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    T cdist = t_sqrt(dot3(dif, dif));
+    T dist = cdist - r1 - r2;
+    if (dist > margin) return 0;
+    T n[3];
+    if (cdist < (T)DMC_MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else { n[0] = dif[0]/cdist; n[1] = dif[1]/cdist; n[2] = dif[2]/cdist; }
+    h->dist = dist;
+    for (int k = 0; k < 3; k++) { h->pos[k] = p1[k] + n[k]*(r1 + dist*(T)0.5); h->nrm[k] = n[k]; }
+    return 1;
+  }
+  // narrow phase for one pair; returns number of hits (<= 4); tang = optional shared tangent
+  DMC_DEV int narrow_phase(int g1, int g2, T margin, Hit* h, T* tang, bool* has_tang) {
+    const int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+    const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
+    const T *m1 = S(geom_xmat) + 9*g1, *m2 = S(geom_xmat) + 9*g2;
+    const T *s1 = MR(geom_size) + 3*g1, *s2 = MR(geom_size) + 3*g2;
+    *has_tang = false;
+    if (t1 == DMC_GEOM_PLANE) {
+      T nrm[3] = {m1[2], m1[5], m1[8]};
+      T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      if (dot3(dif, nrm) > MR(geom_rbound)[g2] + margin) return 0;
+      if (t2 == DMC_GEOM_SPHERE) return plane_sphere(h, margin, p1, nrm, p2, s2[0]);
+      if (t2 == DMC_GEOM_CAPSULE) {
+        T axis[3] = {m2[2], m2[5], m2[8]};
+        T seg[3] = {axis[0]*s2[1], axis[1]*s2[1], axis[2]*s2[1]}, pos[3];
+        T dp = dot3(nrm, axis);
+        for (int k = 0; k < 3; k++) tang[k] = axis[k] - nrm[k]*dp;
+        normalize3(tang);
+        *has_tang = true;
+        int n = 0;
+        for (int k = 0; k < 3; k++) pos[k] = p2[k] + seg[k];
+        n += plane_sphere(h + n, margin, p1, nrm, pos, s2[0]);
+        for (int k = 0; k < 3; k++) pos[k] = p2[k] - seg[k];
+        n += plane_sphere(h + n, margin, p1, nrm, pos, s2[0]);
+        return n;
+      }
+      if (t2 == DMC_GEOM_BOX) {
+        T dist = dot3(dif, nrm);
+        int cnt = 0;
+        for (int i = 0; i < 8; i++) {
+          T vec[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3];
+          mul_mat_vec3(corner, m2, vec);
+          T ldist = dot3(nrm, corner);
+          if (dist + ldist > margin || ldist > 0 || cnt >= 4) continue;
+          h[cnt].dist = dist + ldist;
+          for (int k = 0; k < 3; k++) { h[cnt].nrm[k] = nrm[k]; h[cnt].pos[k] = corner[k] + p2[k] - nrm[k]*h[cnt].dist*(T)0.5; }
+          cnt++;
+        }
+        return cnt;
+      }
+      return 0;
+    }
+    {
+      T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      T bound = MR(geom_rbound)[g1] + MR(geom_rbound)[g2] + margin;
+      if (dot3(dif, dif) > bound*bound) return 0;
+    }
+    if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) return sphere_sphere(h, margin, p1, s1[0], p2, s2[0]);
+    if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) {
+      T axis[3] = {m2[2], m2[5], m2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+      T x = dot3(axis, vec);
+      x = t_max(-s2[1], t_min(s2[1], x));
+      T q[3] = {p2[0] + axis[0]*x, p2[1] + axis[1]*x, p2[2] + axis[2]*x};
+      return sphere_sphere(h, margin, p1, s1[0], q, s2[0]);
+    }
+    if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) {
+      T a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+      T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+      T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+      T u = -dot3(a1, dif), v = dot3(a2, dif), det = ma*mc - mb*mb;
+      T v1[3], v2[3];
+      if (t_abs(det) >= (T)DMC_MINVAL) {
+        T x1 = (mc*u - mb*v) / det, x2 = (ma*v - mb*u) / det;
+        if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb*s1[1]) / mc; }
+        else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb*s1[1]) / mc; }
+        if (x2 > s2[1]) { x2 = s2[1]; x1 = (u - mb*s2[1]) / ma; x1 = t_max(-s1[1], t_min(s1[1], x1)); }
+        else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = (u + mb*s2[1]) / ma; x1 = t_max(-s1[1], t_min(s1[1], x1)); }
+        for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+        return sphere_sphere(h, margin, v1, s1[0], v2, s2[0]);
+      }
+      int n = 0;
+      for (int sg = 1; sg >= -1 && n < 2; sg -= 2) {
+        T x1 = sg * s1[1], x2 = (v - mb*x1) / mc;
+        if (x2 >= -s2[1] && x2 <= s2[1]) {
+          for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+          n += sphere_sphere(h + n, margin, v1, s1[0], v2, s2[0]);
+        }
+      }
+      for (int sg = 1; sg >= -1 && n < 2; sg -= 2) {
+        T x2 = sg * s2[1], x1 = (u - mb*x2) / ma;
+        if (x1 > -s1[1] && x1 < s1[1]) {
+          for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+          n += sphere_sphere(h + n, margin, v1, s1[0], v2, s2[0]);
+        }
+      }
+      return n;
+    }
+    return 0;
+  }
+  DMC_DEV void collision() {
+    int base = 0;
+    const bool enabled = !(o.disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT));
+    const int npair = enabled ? L.d.npair : 0;
+    int overflow = 0;
+    for (int p0 = 0; p0 < npair; p0 += LPE) {
+      const int p = p0 + lane;
+      Hit h[4]; T tang[3] = {0, 0, 0}; bool has_tang = false;
+      int n = 0, g1 = 0, g2 = 0;
+      if (p < npair) {
+        g1 = MI(pair_geom1)[p]; g2 = MI(pair_geom2)[p];
+        n = narrow_phase(g1, g2, MR(pair_margin)[p], h, tang, &has_tang);
+      }
+      int total;
+      int off = base + group_scan<LPE>(n, lane, &total);
+      for (int i = 0; i < 4; i++) if (i < n) {
+        const int c = off + i;
+        if (c >= L.d.nconmax) { overflow = 1; continue; }
+        T f[9];
+        for (int k = 0; k < 3; k++) { f[k] = h[i].nrm[k]; f[3 + k] = has_tang ? tang[k] : (T)0; }
+        if (has_tang) cross3(f + 6, f, f + 3); else make_frame(f);
+        S(con_dist)[c] = h[i].dist;
+        for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = h[i].pos[k];
+        for (int k = 0; k < 9; k++) S(con_frame)[9*c + k] = f[k];
+        S(con_includemargin)[c] = MR(pair_margin)[p] - MR(pair_gap)[p];
+        for (int k = 0; k < 3; k++) S(con_friction)[3*c + k] = MR(pair_friction)[3*p + k];
+        for (int k = 0; k < 2; k++) S(con_solref)[2*c + k] = MR(pair_solref)[2*p + k];
+        for (int k = 0; k < 5; k++) S(con_solimp)[5*c + k] = MR(pair_solimp)[5*p + k];
+        SI(con_geom1)[c] = g1; SI(con_geom2)[c] = g2; SI(con_dim)[c] = MI(pair_dim)[p];
+        SI(con_efc)[c] = -1;
+      }
+      base += total;
+    }
+    overflow = group_max<LPE>(overflow);
+    if (base > L.d.nconmax) base = L.d.nconmax;
+    if (lane == 0) { SI(imisc)[IM_NCON] = base; if (overflow) SI(imisc)[IM_WARN + DMC_WARN_CONTACTFULL]++; }
+    DMC_WSYNC();
+  }
+
+  // ---- constraint assembly (mj_makeConstraint + impedance) ----------------------
+  DMC_DEV static T get_impedance(const T* si_, T pos, T margin) {
+    T s0 = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, si_[0]));
+    T s1 = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, si_[1]));
+    T s2 = t_max((T)0, si_[2]);
+    T s3 = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, si_[3]));
+    T s4 = t_max((T)1, si_[4]);
+    if (s0 == s1 || s2 <= (T)DMC_MINVAL) return (T)0.5*(s0 + s1);
+    T x = (pos - margin) / s2;
+    if (x < 0) x = -x;
+    if (x >= 1) return s1;
+    if (x == 0) return s0;
+    T y;
+    if (s4 == 1) y = x;
+    else if (x <= s3) y = (1 / t_pow(s3, s4 - 1)) * t_pow(x, s4);
+    else y = 1 - (1 / t_pow(1 - s3, s4 - 1)) * t_pow(1 - x, s4);
+    return s0 + y*(s1 - s0);
+  }
+  DMC_DEV bool dof_in_chain(int lastdof, int dofid) const {
+    if (lastdof < 0) return false;
+    const unsigned m = (unsigned)(dofid < 32 ? MI(dof_anc_lo)[lastdof] : MI(dof_anc_hi)[lastdof]);
+    return (m >> (dofid & 31)) & 1u;
+  }
+  DMC_DEV void make_constraint() {
+    const int nv = L.d.nv, njmax = L.d.njmax;
+    int nefc = 0, overflow = 0;
+    const bool enabled = !(o.disableflags & DMC_DSBL_CONSTRAINT);
+    // joint limits
+    if (enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int j0 = 0; j0 < L.d.njnt; j0 += LPE) {
+      const int j = j0 + lane;
+      int cnt = 0; T dist[2] = {0, 0}; int side[2] = {0, 0}; T margin = 0;
+      if (j < L.d.njnt && MI(jnt_limited)[j]) {
+        const int t = MI(jnt_type)[j];
+        if (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE) {
+          const T value = S(qpos)[MI(jnt_qposadr)[j]];
+          margin = MR(jnt_margin)[j];
+          for (int sd = -1; sd <= 1; sd += 2) {
+            T ds = sd * (MR(jnt_range)[2*j + (sd + 1)/2] - value);
+            if (ds < margin) { dist[cnt] = ds; side[cnt] = sd; cnt++; }
+          }
+        }
+      }
+      int total;
+      const int off = nefc + group_scan<LPE>(cnt, lane, &total);
+      for (int i = 0; i < 2; i++) if (i < cnt) {
+        const int r = off + i;
+        if (r >= njmax) { overflow = 1; continue; }
+        for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
+        S(efc_J)[r*nv + MI(jnt_dofadr)[j]] = -(T)side[i];
+        S(efc_pos)[r] = dist[i]; S(efc_margin)[r] = margin; SI(efc_type)[r] = EFC_LIMIT; SI(efc_id)[r] = j;
+      }
+      nefc += total;
+    }
+    if (nefc > njmax) nefc = njmax;
+    const int nefc_lim = nefc;
+    // contact rows: headers
+    const int ncon = (enabled && !(o.disableflags & DMC_DSBL_CONTACT)) ? SI(imisc)[IM_NCON] : 0;
+    for (int c0 = 0; c0 < ncon; c0 += LPE) {
+      const int c = c0 + lane;
+      int nrow = 0, dim = 0;
+      if (c < ncon) {
+        dim = SI(con_dim)[c];
+        nrow = dim == 1 ? 1 : 2*(dim - 1);
+        if (S(con_dist)[c] >= S(con_includemargin)[c]) nrow = 0;   // in the gap: excluded
+      }
+      int total;
+      const int off = nefc + group_scan<LPE>(nrow, lane, &total);
+      if (c < ncon) {
+        if (nrow == 0) SI(con_efc)[c] = -1;
+        else if (off + nrow > njmax) { SI(con_efc)[c] = -1; overflow = 1; }
+        else {
+          SI(con_efc)[c] = off;
+          for (int r = off; r < off + nrow; r++) {
+            S(efc_pos)[r] = S(con_dist)[c]; S(efc_margin)[r] = S(con_includemargin)[c];
+            SI(efc_type)[r] = dim == 1 ? EFC_FRICTIONLESS : EFC_PYRAMIDAL; SI(efc_id)[r] = c;
+          }
+        }
+      }
+      nefc += total;
+    }
+    overflow = group_max<LPE>(overflow);
+    if (overflow) {
+      // Row offsets are monotonic, so everything before the first contact that
+      // did not fit is contiguous: nefc = end of the last accepted contact (or
+      // the limit rows if no contact fit).
+      int last = nefc_lim;
+      for (int c = lane; c < ncon; c += LPE) if (SI(con_efc)[c] >= 0) {
+        const int dim = SI(con_dim)[c]; const int e = SI(con_efc)[c] + (dim == 1 ? 1 : 2*(dim - 1));
+        last = e > last ? e : last;
+      }
+      nefc = group_max<LPE>(last);
+      if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++;
+    }
+    if (lane == 0) SI(imisc)[IM_NEFC] = nefc;
+    DMC_WSYNC();
+    // contact Jacobian columns: item = (contact, dof)
+    for (int idx = lane; idx < ncon*nv; idx += LPE) {
+      const int c = idx / nv, dd = idx - c*nv;
+      const int r0 = SI(con_efc)[c];
+      if (r0 < 0) continue;
+      const int dim = SI(con_dim)[c];
+      const int b1 = MI(geom_bodyid)[SI(con_geom1)[c]], b2 = MI(geom_bodyid)[SI(con_geom2)[c]];
+      const bool in1 = dof_in_chain(MI(body_lastdof)[b1], dd), in2 = dof_in_chain(MI(body_lastdof)[b2], dd);
+      T jac[6] = {0, 0, 0, 0, 0, 0};
+      if (in1 || in2) {
+        const T* cd = S(cdof) + 6*dd; const T* pos = S(con_pos) + 3*c;
+        T jp1[3] = {0, 0, 0}, jr1[3] = {0, 0, 0}, jp2[3] = {0, 0, 0}, jr2[3] = {0, 0, 0}, off[3], tmp[3], dp[3], dr[3];
+        if (in1) {
+          const T* rc = S(subtree_com) + 3*MI(body_rootid)[b1];
+          for (int k = 0; k < 3; k++) off[k] = pos[k] - rc[k];
+          cross3(tmp, cd, off);
+          for (int k = 0; k < 3; k++) { jr1[k] = cd[k]; jp1[k] = cd[3 + k] + tmp[k]; }
+        }
+        if (in2) {
+          const T* rc = S(subtree_com) + 3*MI(body_rootid)[b2];
+          for (int k = 0; k < 3; k++) off[k] = pos[k] - rc[k];
+          cross3(tmp, cd, off);
+          for (int k = 0; k < 3; k++) { jr2[k] = cd[k]; jp2[k] = cd[3 + k] + tmp[k]; }
+        }
+        for (int k = 0; k < 3; k++) { dp[k] = jp2[k] - jp1[k]; dr[k] = jr2[k] - jr1[k]; }
+        const T* fr = S(con_frame) + 9*c;
+        for (int a = 0; a < 3; a++) { jac[a] = dot3(fr + 3*a, dp); jac[3 + a] = dot3(fr + 3*a, dr); }
+      }
+      if (dim == 1) S(efc_J)[r0*nv + dd] = jac[0];
+      else for (int k = 1; k < dim; k++) {
+        const T f = S(con_friction)[3*c + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+        S(efc_J)[(r0 + 2*(k - 1))*nv + dd] = jac[0] + f*jac[k];
+        S(efc_J)[(r0 + 2*(k - 1) + 1)*nv + dd] = jac[0] + (-f)*jac[k];
+      }
+    }
+    DMC_WSYNC();
+    // per-row parameters: D, aref
+    for (int i = lane; i < nefc; i += LPE) {
+      const T *solref, *solimp; T dA, R;
+      const int type = SI(efc_type)[i], id = SI(efc_id)[i];
+      T mu = 0; T dA0 = 0;
+      if (type == EFC_LIMIT) {
+        solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
+        dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
+      } else {
+        const int b1 = MI(geom_bodyid)[SI(con_geom1)[id]], b2 = MI(geom_bodyid)[SI(con_geom2)[id]];
+        const T tran = MR(body_invweight0)[2*b1] + MR(body_invweight0)[2*b2];
+        const T rot = MR(body_invweight0)[2*b1 + 1] + MR(body_invweight0)[2*b2 + 1];
+        solref = S(con_solref) + 2*id; solimp = S(con_solimp) + 5*id;
+        if (type == EFC_FRICTIONLESS) dA = tran;
+        else {
+          const int j = i - SI(con_efc)[id];
+          const int k = j/2;   // friction index 0,1: slide; 2: torsion; 3,4: roll
+          const T fri = S(con_friction)[3*id + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
+          dA = tran + fri*fri*(j < 4 ? tran : rot);
+          mu = S(con_friction)[3*id];
+          dA0 = tran + mu*mu*tran;
+        }
+      }
+      T ref0 = solref[0], ref1 = solref[1];
+      if (!(o.disableflags & DMC_DSBL_REFSAFE) && ref0 > 0) ref0 = t_max(ref0, 2*o.timestep);
+      const T imp = get_impedance(solimp, S(efc_pos)[i], S(efc_margin)[i]);
+      if (type == EFC_PYRAMIDAL) { const T R0 = t_max((T)DMC_MINVAL, (1 - imp)*dA0/imp); R = 2*mu*mu*R0; }
+      else R = t_max((T)DMC_MINVAL, (1 - imp)*dA/imp);
+      const T dmax = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, solimp[1]));
+      T K, Bd;
+      if (ref0 > 0) { K = 1 / t_max((T)DMC_MINVAL, dmax*dmax*ref0*ref0*ref1*ref1); Bd = 2 / t_max((T)DMC_MINVAL, dmax*ref0); }
+      else { K = -ref0 / t_max((T)DMC_MINVAL, dmax*dmax); Bd = -ref1 / t_max((T)DMC_MINVAL, dmax); }
+      S(efc_D)[i] = 1 / R;
+      const T vel = dot_n(S(efc_J) + i*nv, S(qvel), nv);
+      S(efc_aref)[i] = -Bd*vel - K*imp*(S(efc_pos)[i] - S(efc_margin)[i]);
+    }
+    DMC_WSYNC();
+  }
+
+  // ---- velocity stage (mj_comVel, mj_passive, mj_rne) -----------------------------
+  DMC_DEV void body_com_vel(int i) {
+    T cvel[6], tmp[6], cdd[6];
+    for (int a = 0; a < 6; a++) cvel[a] = S(cvel)[6*MI(body_parentid)[i] + a];
+    const int bda = MI(body_dofadr)[i];
+    int dofs = 0;
+    for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
+      const int t = MI(jnt_type)[j];
+      if (t == DMC_JNT_FREE) {
+        for (int k = 0; k < 18; k++) S(cdof_dot)[6*bda + k] = 0;
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) cvel[a] += S(cdof)[6*(bda + k) + a] * S(qvel)[bda + k];
+        dofs += 3;
+      }
+      if (t == DMC_JNT_FREE || t == DMC_JNT_BALL) {
+        for (int k = 0; k < 3; k++) {
+          cross_motion(cdd, cvel, S(cdof) + 6*(bda + dofs + k));
+          for (int a = 0; a < 6; a++) S(cdof_dot)[6*(bda + dofs + k) + a] = cdd[a];
+        }
+        for (int a = 0; a < 6; a++) tmp[a] = 0;
+        for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) tmp[a] += S(cdof)[6*(bda + dofs + k) + a] * S(qvel)[bda + dofs + k];
+        for (int a = 0; a < 6; a++) cvel[a] += tmp[a];
+        dofs += 3;
+      } else {
+        cross_motion(cdd, cvel, S(cdof) + 6*(bda + dofs));
+        for (int a = 0; a < 6; a++) S(cdof_dot)[6*(bda + dofs) + a] = cdd[a];
+        for (int a = 0; a < 6; a++) cvel[a] += S(cdof)[6*(bda + dofs) + a] * S(qvel)[bda + dofs];
+        dofs += 1;
+      }
+    }
+    for (int a = 0; a < 6; a++) S(cvel)[6*i + a] = cvel[a];
+  }
+  DMC_DEV void com_vel() {
+    for (int lev = 0; lev < L.d.nlevel; lev++) {
+      const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
+      for (int k = a0 + lane; k < a1; k += LPE) body_com_vel(MI(level_body)[k]);
+      DMC_WSYNC();
+    }
+  }
+  DMC_DEV void passive_and_rne() {
+    const int nv = L.d.nv;
+    FOR_LANES(i, nv) {
+      T f = 0;
+      const int j = MI(dof_jntid)[i], t = MI(jnt_type)[j];
+      const T k = MR(jnt_stiffness)[j];
+      if (!(o.disableflags & DMC_DSBL_SPRING) && k != 0 && (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE)) {
+        const int qa = MI(jnt_qposadr)[j];
+        f -= k * (S(qpos)[qa] - MR(qpos_spring)[qa]);
+      }
+      if (!(o.disableflags & DMC_DSBL_DAMPER)) f -= MR(dof_damping)[i] * S(qvel)[i];
+      S(qfrc_passive)[i] = f;
+    }
+    if (lane == 0) {
+      T* ca = S(cacc);
+      ca[0] = ca[1] = ca[2] = 0; ca[3] = ca[4] = ca[5] = 0;
+      if (!(o.disableflags & DMC_DSBL_GRAVITY)) { ca[3] = -o.gravity[0]; ca[4] = -o.gravity[1]; ca[5] = -o.gravity[2]; }
+    }
+    DMC_WSYNC();
+    for (int lev = 0; lev < L.d.nlevel; lev++) {
+      const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
+      for (int kk = a0 + lane; kk < a1; kk += LPE) {
+        const int i = MI(level_body)[kk], bda = MI(body_dofadr)[i];
+        T tmp[6], tmp1[6], ca[6], cf[6];
+        for (int a = 0; a < 6; a++) tmp[a] = 0;
+        for (int k = 0; k < MI(body_dofnum)[i]; k++) for (int a = 0; a < 6; a++) tmp[a] += S(cdof_dot)[6*(bda + k) + a] * S(qvel)[bda + k];
+        for (int a = 0; a < 6; a++) ca[a] = S(cacc)[6*MI(body_parentid)[i] + a] + tmp[a];
+        for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = ca[a];
+        mul_inert_vec(cf, S(cinert) + 10*i, ca);
+        mul_inert_vec(tmp, S(cinert) + 10*i, S(cvel) + 6*i);
+        cross_force(tmp1, S(cvel) + 6*i, tmp);
+        for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = cf[a] + tmp1[a];
+      }
+      DMC_WSYNC();
+    }
+    for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
+      const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
+      for (int idx = lane; idx < cnt*6; idx += LPE) {
+        const int b = MI(level_body)[a0 + idx/6], comp = idx % 6;
+        const int c0 = MI(child_adr)[b], c1 = MI(child_adr)[b + 1];
+        if (c1 > c0) {
+          T v = S(cfrc)[6*b + comp];
+          for (int c = c0; c < c1; c++) v += S(cfrc)[6*MI(child_list)[c] + comp];
+          S(cfrc)[6*b + comp] = v;
+        }
+      }
+      DMC_WSYNC();
+    }
+    FOR_LANES(i, nv) S(qfrc_bias)[i] = dot_n(S(cdof) + 6*i, S(cfrc) + 6*MI(dof_bodyid)[i], 6);
+    DMC_WSYNC();
+  }
+
+  // ---- sensors (position / velocity stage) -------------------------------------------
+  DMC_DEV void subtree_vel() {
+    FOR_LANES(i, L.d.nbody) {
+      const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
+      T dif[3] = {S(xipos)[3*i] - rc[0], S(xipos)[3*i + 1] - rc[1], S(xipos)[3*i + 2] - rc[2]}, tmp[3];
+      cross3(tmp, dif, S(cvel) + 6*i);
+      for (int k = 0; k < 3; k++) S(subtree_usum)[3*i + k] = MR(body_mass)[i] * (S(cvel)[6*i + 3 + k] - tmp[k]);
+    }
+    DMC_WSYNC();
+    for (int lev = L.d.nlevel - 1; lev >= -1; lev--) {
+      const int a0 = lev >= 0 ? MI(level_adr)[lev] : 0, cnt = lev >= 0 ? MI(level_adr)[lev + 1] - a0 : 1;
+      for (int idx = lane; idx < cnt*3; idx += LPE) {
+        const int b = lev >= 0 ? MI(level_body)[a0 + idx/3] : 0, comp = idx % 3;
+        T v = S(subtree_usum)[3*b + comp];
+        for (int c = MI(child_adr)[b]; c < MI(child_adr)[b + 1]; c++) v += S(subtree_usum)[3*MI(child_list)[c] + comp];
+        S(subtree_usum)[3*b + comp] = v;
+        S(subtree_linvel)[3*b + comp] = v * (1 / t_max((T)DMC_MINVAL, MR(body_subtreemass)[b]));
+      }
+      DMC_WSYNC();
+    }
+  }
+  DMC_DEV void object_velocity(int body, const T* pos, const T* mat, T* res) {
+    const T* rc = S(subtree_com) + 3*MI(body_rootid)[body];
+    T dif[3] = {pos[0] - rc[0], pos[1] - rc[1], pos[2] - rc[2]}, tmp[3];
+    const T* cv = S(cvel) + 6*body;
+    cross3(tmp, dif, cv);
+    T lin[3] = {cv[3] - tmp[0], cv[4] - tmp[1], cv[5] - tmp[2]};
+    mul_matT_vec3(res, mat, cv); mul_matT_vec3(res + 3, mat, lin);
+  }
+  DMC_DEV void sensors(int stage) {
+    if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
+    int need = 0;
+    for (int i = 0; i < L.d.nsensor; i++) if (MI(sensor_stage)[i] == stage && MI(sensor_type)[i] == DMC_SENS_SUBTREELINVEL) need = 1;
+    if (need) subtree_vel();
+    FOR_LANES(i, L.d.nsensor) {
+      if (MI(sensor_stage)[i] != stage) continue;
+      T* out = S(sensordata) + MI(sensor_adr)[i];
+      const int id = MI(sensor_objid)[i], t = MI(sensor_type)[i];
+      if (t == DMC_SENS_JOINTPOS) out[0] = S(qpos)[MI(jnt_qposadr)[id]];
+      else if (t == DMC_SENS_JOINTVEL) out[0] = S(qvel)[MI(jnt_dofadr)[id]];
+      else if (t == DMC_SENS_ACTUATORFRC) out[0] = S(actuator_force)[id];
+      else if (t == DMC_SENS_SUBTREECOM) for (int k = 0; k < 3; k++) out[k] = S(subtree_com)[3*id + k];
+      else if (t == DMC_SENS_SUBTREELINVEL) for (int k = 0; k < 3; k++) out[k] = S(subtree_linvel)[3*id + k];
+      else if (t == DMC_SENS_VELOCIMETER || t == DMC_SENS_GYRO) {
+        const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
+        mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+        for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*b + k] + v[k];
+        mul_quat(q, S(xquat) + 4*b, MR(site_quat) + 4*id);
+        quat2mat(m, q);
+        object_velocity(b, sp, m, v6);
+        for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_GYRO ? v6[k] : v6[3 + k];
+      }
+    }
+    DMC_WSYNC();
+  }
+
+  // ---- actuation + smooth acceleration ---------------------------------------------
+  DMC_DEV void fwd_actuation(bool disable_actuation) {
+    const int nv = L.d.nv, nu = L.d.nu;
+    if (disable_actuation || (o.disableflags & DMC_DSBL_ACTUATION)) {
+      FOR_LANES(i, nv) S(qfrc_actuator)[i] = 0;
+      FOR_LANES(i, nu) S(actuator_force)[i] = 0;
+      DMC_WSYNC();
+      return;
+    }
+    int bad = 0;
+    FOR_LANES(i, nu) if (t_bad(S(ctrl)[i])) bad = 1;
+    bad = group_max<LPE>(bad);
+    if (bad) {
+      DMC_WSYNC();
+      FOR_LANES(i, nu) S(ctrl)[i] = 0;
+      if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]++;
+      DMC_WSYNC();
+    }
+    FOR_LANES(i, nu) {
+      T ctrl = S(ctrl)[i];
+      const int fl = MI(act_flags)[i];
+      if ((fl & ACTF_CTRLLIMITED) && !(o.disableflags & DMC_DSBL_CLAMPCTRL))
+        ctrl = t_max(MR(act_ctrlrange)[2*i], t_min(MR(act_ctrlrange)[2*i + 1], ctrl));
+      const T* gp = MR(act_gainprm) + 3*i; const T* bp = MR(act_biasprm) + 3*i;
+      const T gear = MR(act_gear)[i];
+      const T len = gear * S(qpos)[MI(act_qpos)[i]], vel = gear * S(qvel)[MI(act_dof)[i]];
+      T gain = gp[0], bias = 0;
+      if (fl & ACTF_GAIN_AFFINE) gain = gp[0] + gp[1]*len + gp[2]*vel;
+      if (fl & ACTF_BIAS_AFFINE) bias = bp[0] + bp[1]*len + bp[2]*vel;
+      T force = gain*ctrl + bias;
+      if (fl & ACTF_FORCELIMITED) force = t_max(MR(act_forcerange)[2*i], t_min(MR(act_forcerange)[2*i + 1], force));
+      S(actuator_force)[i] = force;
+    }
+    DMC_WSYNC();
+    FOR_LANES(dd, nv) {
+      T f = 0;
+      for (int i = 0; i < nu; i++) if (MI(act_dof)[i] == dd) f += MR(act_gear)[i] * S(actuator_force)[i];
+      S(qfrc_actuator)[dd] = f;
+    }
+    DMC_WSYNC();
+  }
+  DMC_DEV void fwd_acceleration() {
+    FOR_LANES(i, L.d.nv) S(qfrc_smooth)[i] = S(qfrc_passive)[i] - S(qfrc_bias)[i] + S(qfrc_applied)[i] + S(qfrc_actuator)[i];
+    DMC_WSYNC();
+    chol_solve(S(qacc_smooth), S(qL), S(qfrc_smooth), L.d.nv);
+  }
+
+  // ---- Newton solver on the primal (mj_fwdConstraint / mj_solNewton) -----------------
+  // efc_state/efc_force from efc_jar; returns the constraint cost (group-uniform)
+  DMC_DEV T constraint_update(int nefc) {
+    T cost = 0;
+    for (int i = lane; i < nefc; i += LPE) {
+      const T jar = S(efc_jar)[i];
+      if (jar < 0) { SI(efc_state)[i] = 1; S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
+      else { SI(efc_state)[i] = 0; S(efc_force)[i] = 0; }
+    }
+    cost = group_sum<LPE>(cost);
+    DMC_WSYNC();
+    return cost;
+  }
+  DMC_DEV T gauss_cost() {
+    T g = 0;
+    FOR_LANES(i, L.d.nv) g += (S(sv_Ma)[i] - S(qfrc_smooth)[i]) * (S(qacc)[i] - S(qacc_smooth)[i]);
+    return (T)0.5 * group_sum<LPE>(g);
+  }
+  DMC_DEV void mul_M(T* res, const T* v) {
+    const int nv = L.d.nv;
+    FOR_LANES(i, nv) res[i] = dot_n(S(qM) + i*nv, v, nv);
+  }
+  DMC_DEV void jar_from(const T* qacc, int nefc) {
+    const int nv = L.d.nv;
+    for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] = dot_n(S(efc_J) + i*nv, qacc, nv) - S(efc_aref)[i];
+  }
+  DMC_DEV void constraint_force_to_joint(int nefc) {
+    const int nv = L.d.nv;
+    FOR_LANES(i, nv) {
+      T f = 0;
+      for (int r = 0; r < nefc; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_J)[r*nv + i]*fr; }
+      S(qfrc_constraint)[i] = f;
+    }
+  }
+  DMC_DEV void newton_gradient(int nefc) {
+    const int nv = L.d.nv;
+    constraint_force_to_joint(nefc);
+    DMC_WSYNC();
+    FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
+    for (int idx = lane; idx < nv*nv; idx += LPE) {
+      const int i = idx / nv, j = idx - i*nv;
+      if (j > i) continue;
+      T h = S(qM)[i*nv + j];
+      for (int r = 0; r < nefc; r++) if (SI(efc_state)[r]) {
+        const T ji = S(efc_J)[r*nv + i];
+        if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
+      }
+      S(qH)[i*nv + j] = h;
+    }
+    DMC_WSYNC();
+    chol_factor_inplace(S(qH), nv);
+    chol_solve(S(sv_Mgrad), S(qH), S(sv_grad), nv);
+  }
+  struct LSPoint { T alpha, cost, d0, d1; };
+  DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
+    const T a = p->alpha;
+    T q0 = 0, q1 = 0, q2 = 0;
+    for (int i = lane; i < nefc; i += LPE) {
+      const T jar = S(efc_jar)[i], jv = S(efc_jv)[i];
+      if (jar + a*jv < 0) {
+        const T D = S(efc_D)[i], dj0 = D*jar;
+        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+      }
+    }
+    q0 = group_sum<LPE>(q0) + qg[0]; q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
+    p->cost = a*a*q2 + a*q1 + q0;
+    p->d0 = 2*a*q2 + q1;
+    p->d1 = 2*q2;
+    if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+    (*evals)++;
+  }
+  DMC_DEV int ls_update_bracket(LSPoint* p, const LSPoint* cand, LSPoint* pnext, const T* qg, int nefc, int* evals) {
+    int flag = 0;
+    for (int i = 0; i < 3; i++) {
+      if (p->d0 < 0 && cand[i].d0 < 0 && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
+      else if (p->d0 > 0 && cand[i].d0 > 0 && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
+    }
+    if (flag) { pnext->alpha = p->alpha - p->d0/p->d1; ls_eval(pnext, qg, nefc, evals); }
+    return flag;
+  }
+  DMC_DEV T primal_search(int nefc, T gauss, T scale) {
+    const int nv = L.d.nv;
+    mul_M(S(sv_Mv), S(sv_search));
+    for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = dot_n(S(efc_J) + i*nv, S(sv_search), nv);
+    DMC_WSYNC();
+    T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    FOR_LANES(i, nv) {
+      const T sr = S(sv_search)[i];
+      a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; a3 += sr*S(sv_Mv)[i]; a4 += sr*sr;
+    }
+    a1 = group_sum<LPE>(a1); a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
+    T qg[3] = {gauss, a1 - a2, (T)0.5*a3};
+    const T snorm = t_sqrt(a4);
+    if (snorm < (T)DMC_MINVAL) return 0;
+    const T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
+    const int lsmax = o.ls_iterations;
+    int evals = 0;
+    LSPoint p0, p1, p2, pmid, p1next, p2next;
+    p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals);
+    p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals);
+    if (p0.cost < p1.cost) p1 = p0;
+    if (t_abs(p1.d0) < gtol) return p1.alpha;
+    const int dir = p1.d0 < 0 ? 1 : -1;
+    int p2update = 0;
+    p2 = p1;
+    while (p1.d0*dir <= -gtol && evals < lsmax) {
+      p2 = p1; p2update = 1;
+      p1.alpha -= p1.d0/p1.d1; ls_eval(&p1, qg, nefc, &evals);
+      if (t_abs(p1.d0) < gtol) return p1.alpha;
+    }
+    if (evals >= lsmax) return p1.alpha;
+    if (!p2update) return p1.alpha;
+    p2next = p1;
+    p1next.alpha = p1.alpha - p1.d0/p1.d1; ls_eval(&p1next, qg, nefc, &evals);
+    while (evals < lsmax) {
+      pmid.alpha = (T)0.5*(p1.alpha + p2.alpha); ls_eval(&pmid, qg, nefc, &evals);
+      LSPoint cand[3] = {p1next, p2next, pmid};
+      int best = -1;
+      for (int i = 0; i < 3; i++) if (t_abs(cand[i].d0) < gtol && (best == -1 || cand[i].cost < cand[best].cost)) best = i;
+      if (best >= 0) return cand[best].alpha;
+      const int b1 = ls_update_bracket(&p1, cand, &p1next, qg, nefc, &evals);
+      const int b2 = ls_update_bracket(&p2, cand, &p2next, qg, nefc, &evals);
+      if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : (T)0;
+    }
+    if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+    if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+    return 0;
+  }
+  DMC_DEV void fwd_constraint() {
+    const int nv = L.d.nv, nefc = SI(imisc)[IM_NEFC];
+    if (!nefc) {
+      FOR_LANES(i, nv) { const T a = S(qacc_smooth)[i]; S(qacc)[i] = a; S(qacc_warmstart)[i] = a; S(qfrc_constraint)[i] = 0; }
+      if (lane == 0) SI(imisc)[IM_ITER] = 0;
+      DMC_WSYNC();
+      return;
+    }
+    if (!(o.disableflags & DMC_DSBL_WARMSTART)) {
+      FOR_LANES(i, nv) S(qacc)[i] = S(qacc_warmstart)[i];
+      DMC_WSYNC();
+      jar_from(S(qacc), nefc);
+      mul_M(S(sv_Ma), S(qacc));
+      DMC_WSYNC();
+      const T cw = constraint_update(nefc) + gauss_cost();
+      jar_from(S(qacc_smooth), nefc);
+      DMC_WSYNC();
+      const T cs = constraint_update(nefc);
+      if (cw > cs) FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
+    } else FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
+    DMC_WSYNC();
+    const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
+    mul_M(S(sv_Ma), S(qacc));
+    jar_from(S(qacc), nefc);
+    DMC_WSYNC();
+    T cc = constraint_update(nefc);
+    T gauss = gauss_cost();
+    T cost = cc + gauss;
+    newton_gradient(nefc);
+    FOR_LANES(i, nv) S(sv_search)[i] = -S(sv_Mgrad)[i];
+    DMC_WSYNC();
+    int iter = 0;
+    while (iter < o.iterations) {
+      const T alpha = primal_search(nefc, gauss, scale);
+      if (alpha == 0) break;
+      FOR_LANES(i, nv) { S(qacc)[i] += alpha*S(sv_search)[i]; S(sv_Ma)[i] += alpha*S(sv_Mv)[i]; }
+      for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
+      DMC_WSYNC();
+      const T oldcost = cost;
+      cc = constraint_update(nefc);
+      gauss = gauss_cost();
+      cost = cc + gauss;
+      newton_gradient(nefc);
+      T g2 = 0;
+      FOR_LANES(i, nv) { S(sv_search)[i] = -S(sv_Mgrad)[i]; g2 += S(sv_grad)[i]*S(sv_grad)[i]; }
+      g2 = group_sum<LPE>(g2);
+      DMC_WSYNC();
+      const T improvement = scale*(oldcost - cost), gradient = scale*t_sqrt(g2);
+      iter++;
+      if (improvement < o.tolerance || gradient < o.tolerance) break;
+    }
+    constraint_force_to_joint(nefc);
+    FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
+    if (lane == 0) SI(imisc)[IM_ITER] = iter;
+    DMC_WSYNC();
+  }
+
+  // ---- integration (mj_Euler with implicit joint damping) ---------------------------------
+  DMC_DEV void euler() {
+    const int nv = L.d.nv;
+    const T dt = o.timestep;
+    const T* qacc = S(qacc);
+    if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {
+      FOR_LANES(i, nv*nv) S(qH)[i] = S(qM)[i];
+      FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
+      DMC_WSYNC();
+      FOR_LANES(i, nv) S(qH)[i*nv + i] += dt*MR(dof_damping)[i];
+      DMC_WSYNC();
+      chol_factor_inplace(S(qH), nv);
+      chol_solve(S(sv_Mgrad), S(qH), S(sv_grad), nv);
+      qacc = S(sv_Mgrad);
+    }
+    FOR_LANES(i, nv) S(qvel)[i] += dt*qacc[i];
+    DMC_WSYNC();
+    FOR_LANES(j, L.d.njnt) {
+      const int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j], t = MI(jnt_type)[j];
+      if (t == DMC_JNT_FREE) {
+        for (int k = 0; k < 3; k++) S(qpos)[qa + k] += dt*S(qvel)[da + k];
+        T q[4], w[3];
+        for (int k = 0; k < 4; k++) q[k] = S(qpos)[qa + 3 + k];
+        for (int k = 0; k < 3; k++) w[k] = S(qvel)[da + 3 + k];
+        quat_integrate(q, w, dt);
+        for (int k = 0; k < 4; k++) S(qpos)[qa + 3 + k] = q[k];
+      } else if (t == DMC_JNT_BALL) {
+        T q[4], w[3];
+        for (int k = 0; k < 4; k++) q[k] = S(qpos)[qa + k];
+        for (int k = 0; k < 3; k++) w[k] = S(qvel)[da + k];
+        quat_integrate(q, w, dt);
+        for (int k = 0; k < 4; k++) S(qpos)[qa + k] = q[k];
+      } else S(qpos)[qa] += dt*S(qvel)[da];
+    }
+    if (lane == 0) S(misc)[MISC_TIME] += dt;
+    DMC_WSYNC();
+  }
+
+  // ---- checks / reset ---------------------------------------------------------------------
+  DMC_DEV void reset_state() {
+    FOR_LANES(i, L.d.nq) S(qpos)[i] = MR(qpos0)[i];
+    FOR_LANES(i, L.d.nv) { S(qvel)[i] = 0; S(qacc_warmstart)[i] = 0; S(qfrc_applied)[i] = 0; }
+    FOR_LANES(i, L.d.nu) S(ctrl)[i] = 0;
+    if (lane == 0) S(misc)[MISC_TIME] = 0;
+    DMC_WSYNC();
+  }
+  DMC_DEV void check_pos_vel() {
+    int badp = 0, badv = 0;
+    FOR_LANES(i, L.d.nq) if (t_bad(S(qpos)[i])) badp = 1;
+    badp = group_max<LPE>(badp);
+    if (badp) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQPOS]++; if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); } }
+    FOR_LANES(i, L.d.nv) if (t_bad(S(qvel)[i])) badv = 1;
+    badv = group_max<LPE>(badv);
+    if (badv) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQVEL]++; if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); } }
+  }
+  DMC_DEV bool bad_acc() {
+    int bad = 0;
+    FOR_LANES(i, L.d.nv) if (t_bad(S(qacc)[i])) bad = 1;
+    return group_max<LPE>(bad) != 0;
+  }
+
+  // ---- pipeline -----------------------------------------------------------------------------
+  DMC_DEV void fwd_position() { kinematics(); com_pos(); crb_mass_matrix(); collision(); make_constraint(); }
+  DMC_DEV void forward(bool disable_actuation) {
+    fwd_position(); sensors(DMC_STAGE_POS);
+    com_vel(); passive_and_rne(); sensors(DMC_STAGE_VEL);
+    fwd_actuation(disable_actuation); fwd_acceleration(); fwd_constraint();
+    sensors(DMC_STAGE_ACC);
+  }
+  // mj_step1 outputs for the state after the last integration (legacy_step)
+  DMC_DEV void trailing_step1() {
+    check_pos_vel();
+    kinematics(); com_pos(); collision(); sensors(DMC_STAGE_POS);
+    com_vel(); sensors(DMC_STAGE_VEL);
+  }
+  // mode: 0 = Physics.step(nstep) ; 1 = mj_forward ; 2 = mj_forward with actuation disabled
+  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask) {
+    load_state(io, env);
+    if (mode != 0) {
+      forward(mode == 2);
+      dump_debug(io, env);
+      store_outputs(io, env, outmask);
+      store_state(io, env);
+      return;
+    }
+    for (int it = 0; it < nstep; it++) {
+      check_pos_vel();
+      forward(false);
+      if (bad_acc()) {
+        if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;
+        if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); forward(false); }
+      }
+      if (it == nstep - 1) { dump_debug(io, env); if (!legacy) store_outputs(io, env, outmask); }
+      euler();
+    }
+    if (legacy) { trailing_step1(); store_outputs(io, env, outmask); }
+    store_state(io, env);
+  }
+#undef MI
+#undef MR
+#undef S
+#undef SI
+#undef FOR_LANES
+};
+
+}  // namespace dmc

@@ -1,0 +1,66 @@
+// step_kernel.hip.h -- the __global__ wrapper around StepCore and its launcher.
+// Included by step_kernels_f32.hip (fp-contract=fast) and step_kernels_f64.hip
+// (fp-contract=off, so the fp64 instantiation rounds like the oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "step_core.h"
+
+namespace dmc {
+
+struct LaunchGeom {
+  int lpe;             // lanes per environment: 64, 32 or 16
+  int waves;           // wavefronts per workgroup (1..4)
+  int envs_per_block;  // waves * 64 / lpe
+  int lds_bytes;       // dynamic LDS per workgroup
+  int grid;            // workgroups
+};
+
+template <typename T, int LPE>
+__global__ void __launch_bounds__(256)
+step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
+            StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* mi = reinterpret_cast<int*>(smem);
+  T* mr = reinterpret_cast<T*>(smem + (size_t)L.n_mi * sizeof(int));
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  // stage the model constant tables once per workgroup (shared by all its envs)
+  for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
+  for (int i = tid; i < L.n_mr; i += nthr) mr[i] = g_mr[i];
+  __syncthreads();
+  const int epb = nthr / LPE;
+  const int g = tid / LPE, lane = tid % LPE;
+  // XCD-aware env mapping: consecutive workgroups land on different XCDs
+  // (block b -> XCD b % 8); envs of one workgroup stay contiguous so that each
+  // SoA row is touched in epb-element segments.
+  const int env = blockIdx.x * epb + g;
+  if (env >= io.B) return;
+  const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
+  unsigned char* base = smem + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
+  T* s = reinterpret_cast<T*>(base);
+  int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
+  StepCore<T, LPE> core(L, o, mi, mr, s, si, lane);
+  core.run(io, env, nstep, legacy, mode, outmask);
+}
+
+template <typename T>
+inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<T>& o,
+                                const int* g_mi, const T* g_mr, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask) {
+  const dim3 grid(g.grid), block(g.waves * 64);
+#define DMC_LAUNCH(LPE)                                                                                         \
+  {                                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, LPE>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
+    if (e != hipSuccess) return e;                                                                              \
+    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, L, o, g_mi, g_mr, io, nstep,    \
+                       legacy, mode, outmask);                                                                  \
+  }
+  if (g.lpe == 64) DMC_LAUNCH(64)
+  else if (g.lpe == 32) DMC_LAUNCH(32)
+  else if (g.lpe == 16) DMC_LAUNCH(16)
+  else return hipErrorInvalidValue;
+#undef DMC_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace dmc

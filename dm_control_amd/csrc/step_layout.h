@@ -1,0 +1,167 @@
+// step_layout.h -- LDS layout of the fused step kernel.
+//
+// One workgroup stages ONE copy of the model constant tables (identical for all
+// environments of a batch) in LDS, followed by one private scratch region per
+// environment instance handled by the workgroup.  Offsets are computed on the
+// host once per (model, precision, caps) and passed to the kernel by value.
+//
+//   [ int tables | real tables | env0 real scratch | env0 int scratch | env1 ... ]
+//
+// Table / scratch lists are X-macros: X(name, count_expression).  Count
+// expressions are evaluated on the host against `StepDims`.
+#pragma once
+#include <stdint.h>
+
+struct StepDims {
+  int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;
+  int nlevel;    // number of tree depths >= 1
+  int nchild;    // nbody - 1 (size of the child list)
+  int nM;        // number of (dof i, ancestor dof j) pairs incl. diagonal
+  int nconmax;   // contact cap per environment
+  int njmax;     // constraint-row cap per environment
+};
+
+// ---- model tables (ints) -----------------------------------------------------
+#define STEP_MODEL_INT_TABLES(X)                                               \
+  X(body_parentid, d.nbody) X(body_rootid, d.nbody) X(body_jntadr, d.nbody)    \
+  X(body_jntnum, d.nbody) X(body_dofadr, d.nbody) X(body_dofnum, d.nbody)      \
+  X(body_lastdof, d.nbody)     /* last dof on the path root->body, or -1 */    \
+  X(level_adr, d.nlevel + 1) X(level_body, d.nchild)                           \
+  X(child_adr, d.nbody + 1) X(child_list, d.nchild)   /* children, descending */ \
+  X(jnt_type, d.njnt) X(jnt_qposadr, d.njnt) X(jnt_dofadr, d.njnt)             \
+  X(jnt_bodyid, d.njnt) X(jnt_limited, d.njnt)                                 \
+  X(dof_bodyid, d.nv) X(dof_jntid, d.nv) X(dof_parentid, d.nv)                 \
+  X(dof_anc_lo, d.nv) X(dof_anc_hi, d.nv)  /* bitmask of ancestor dofs (incl. self) */ \
+  X(mpair_i, d.nM) X(mpair_j, d.nM)                                            \
+  X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
+  X(pair_geom1, d.npair) X(pair_geom2, d.npair) X(pair_dim, d.npair)           \
+  X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \
+  X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
+  X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
+  X(sensor_stage, d.nsensor)
+
+// ---- model tables (reals) ----------------------------------------------------
+#define STEP_MODEL_REAL_TABLES(X)                                              \
+  X(qpos0, d.nq) X(qpos_spring, d.nq)                                          \
+  X(body_pos, 3 * d.nbody) X(body_quat, 4 * d.nbody) X(body_ipos, 3 * d.nbody) \
+  X(body_iquat, 4 * d.nbody) X(body_mass, d.nbody) X(body_inertia, 3 * d.nbody) \
+  X(body_subtreemass, d.nbody) X(body_invsubtreemass, d.nbody)                 \
+  X(body_invweight0, 2 * d.nbody)                                              \
+  X(jnt_pos, 3 * d.njnt) X(jnt_axis, 3 * d.njnt) X(jnt_stiffness, d.njnt)      \
+  X(jnt_range, 2 * d.njnt) X(jnt_margin, d.njnt) X(jnt_solref, 2 * d.njnt)     \
+  X(jnt_solimp, 5 * d.njnt)                                                    \
+  X(dof_armature, d.nv) X(dof_damping, d.nv) X(dof_invweight0, d.nv)           \
+  X(geom_size, 3 * d.ngeom) X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom) \
+  X(geom_rbound, d.ngeom)                                                      \
+  X(pair_margin, d.npair) X(pair_gap, d.npair) X(pair_friction, 3 * d.npair)   \
+  X(pair_solref, 2 * d.npair) X(pair_solimp, 5 * d.npair)                      \
+  X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
+  X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
+  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
+
+// ---- per-environment scratch (reals) -------------------------------------------
+#define STEP_SCRATCH_REAL(X)                                                   \
+  X(qpos, d.nq) X(qvel, d.nv) X(ctrl, d.nu) X(qacc_warmstart, d.nv)            \
+  X(qfrc_applied, d.nv)                                                        \
+  X(xpos, 3 * d.nbody) X(xquat, 4 * d.nbody) X(xmat, 9 * d.nbody)              \
+  X(xipos, 3 * d.nbody) X(ximat, 9 * d.nbody)                                  \
+  X(xanchor, 3 * d.njnt) X(xaxis, 3 * d.njnt)                                  \
+  X(geom_xpos, 3 * d.ngeom) X(geom_xmat, 9 * d.ngeom)                          \
+  X(subtree_com, 3 * d.nbody) X(subtree_usum, 3 * d.nbody)                     \
+  X(cinert, 10 * d.nbody) X(crb, 10 * d.nbody)                                 \
+  X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv) X(mbuf, 6 * d.nv)                    \
+  X(cvel, 6 * d.nbody) X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody)               \
+  X(qM, d.nv * d.nv) X(qL, d.nv * d.nv) X(qH, d.nv * d.nv)                     \
+  X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
+  X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
+  X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
+  X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
+  X(sv_search, d.nv) X(sv_tmp, d.nv)                                           \
+  X(subtree_linvel, 3 * d.nbody) X(sensordata, d.nsensordata)                  \
+  X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, 9 * d.nconmax) \
+  X(con_includemargin, d.nconmax) X(con_friction, 3 * d.nconmax)               \
+  X(con_solref, 2 * d.nconmax) X(con_solimp, 5 * d.nconmax)                    \
+  X(efc_J, d.njmax * d.nv) X(efc_pos, d.njmax) X(efc_margin, d.njmax)          \
+  X(efc_D, d.njmax) X(efc_aref, d.njmax) X(efc_jar, d.njmax)                   \
+  X(efc_jv, d.njmax) X(efc_force, d.njmax)                                     \
+  X(misc, 16)
+
+// ---- per-environment scratch (ints) --------------------------------------------
+#define STEP_SCRATCH_INT(X)                                                    \
+  X(con_geom1, d.nconmax) X(con_geom2, d.nconmax) X(con_dim, d.nconmax)        \
+  X(con_efc, d.nconmax)                                                        \
+  X(efc_type, d.njmax) X(efc_id, d.njmax) X(efc_state, d.njmax)                \
+  X(imisc, 16)
+
+// indices into the `misc` / `imisc` scratch
+enum { MISC_TIME = 0 };
+enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..10: 8 warning counters */ };
+
+// act_flags bits
+enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8 };
+enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2 };
+
+struct StepLayout {
+  StepDims d;
+  // offsets in elements (ints for int tables, reals for real tables/scratch)
+#define X(name, cnt) int mi_##name;
+  STEP_MODEL_INT_TABLES(X)
+#undef X
+#define X(name, cnt) int mr_##name;
+  STEP_MODEL_REAL_TABLES(X)
+#undef X
+#define X(name, cnt) int s_##name;
+  STEP_SCRATCH_REAL(X)
+#undef X
+#define X(name, cnt) int si_##name;
+  STEP_SCRATCH_INT(X)
+#undef X
+  int n_mi, n_mr;          // table sizes (elements)
+  int n_sr, n_si;          // per-env scratch sizes (elements)
+};
+
+// scalar options broadcast to every wave
+template <typename T>
+struct StepOpts {
+  T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
+  int integrator, cone, iterations, ls_iterations, disableflags;
+  int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
+};
+
+static inline void step_layout_build(StepLayout* L, const StepDims& d) {
+  L->d = d;
+  int o = 0;
+#define X(name, cnt) L->mi_##name = o; o += (cnt);
+  STEP_MODEL_INT_TABLES(X)
+#undef X
+  L->n_mi = (o + 3) & ~3;
+  o = 0;
+#define X(name, cnt) L->mr_##name = o; o += (cnt);
+  STEP_MODEL_REAL_TABLES(X)
+#undef X
+  L->n_mr = (o + 3) & ~3;
+  o = 0;
+#define X(name, cnt) L->s_##name = o; o += (cnt);
+  STEP_SCRATCH_REAL(X)
+#undef X
+  L->n_sr = (o + 3) & ~3;
+  o = 0;
+#define X(name, cnt) L->si_##name = o; o += (cnt);
+  STEP_SCRATCH_INT(X)
+#undef X
+  L->n_si = (o + 3) & ~3;
+}
+
+// name -> (offset, count) of a per-env scratch array; kind: 0 real, 1 int.  Used
+// by the debug dump (tests compare kernel intermediates with the oracle).
+#include <string.h>
+static inline int step_layout_find(const StepLayout* L, const char* name, int* off, int* cnt, int* kind) {
+  const StepDims& d = L->d;
+#define X(n, c) if (!strcmp(name, #n)) { *off = L->s_##n; *cnt = (c); *kind = 0; return 1; }
+  STEP_SCRATCH_REAL(X)
+#undef X
+#define X(n, c) if (!strcmp(name, #n)) { *off = L->si_##n; *cnt = (c); *kind = 1; return 1; }
+  STEP_SCRATCH_INT(X)
+#undef X
+  return 0;
+}

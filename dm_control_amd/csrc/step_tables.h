@@ -1,0 +1,252 @@
+// step_tables.h -- host-side: model blob -> kernel constant tables + LDS layout.
+//
+// Pure C++ (no HIP calls) so that tests/emu can reuse it.  Everything here runs
+// once per (model, caps); the per-step path never touches it.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dmc_model_layout.h"
+#include "step_layout.h"
+
+namespace dmc {
+
+struct HostModel {
+#define X(n) int n;
+  DMC_MODEL_HEADER_INTS(X)
+#undef X
+#define X(n) double n;
+  DMC_MODEL_HEADER_REALS(X)
+#undef X
+#define X(n, c) std::vector<int> n;
+  DMC_MODEL_INT_FIELDS(X)
+#undef X
+#define X(n, c) std::vector<double> n;
+  DMC_MODEL_REAL_FIELDS(X)
+#undef X
+  std::vector<int32_t> blob_i;
+  std::vector<double> blob_r;
+};
+
+inline bool host_model_parse(HostModel* m, const int32_t* ints, int nints, const double* reals, int nreals, std::string* err) {
+  if (nints < 2 || ints[0] != (int32_t)DMC_MODEL_MAGIC || ints[1] != DMC_MODEL_VERSION) { *err = "bad model blob magic/version"; return false; }
+  long ip = 2, rp = 0;
+  auto need_i = [&](long n) { return ip + n <= nints; };
+  auto need_r = [&](long n) { return rp + n <= nreals; };
+#define X(n) if (!need_i(1)) { *err = "model blob truncated"; return false; } m->n = ints[ip++];
+  DMC_MODEL_HEADER_INTS(X)
+#undef X
+#define X(n) if (!need_r(1)) { *err = "model blob truncated"; return false; } m->n = reals[rp++];
+  DMC_MODEL_HEADER_REALS(X)
+#undef X
+  const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
+  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
+#define X(n, c) { long cnt = (c); if (cnt < 0 || !need_i(cnt)) { *err = "model blob truncated"; return false; } m->n.assign(ints + ip, ints + ip + cnt); ip += cnt; }
+  DMC_MODEL_INT_FIELDS(X)
+#undef X
+#define X(n, c) { long cnt = (c); if (cnt < 0 || !need_r(cnt)) { *err = "model blob truncated"; return false; } m->n.assign(reals + rp, reals + rp + cnt); rp += cnt; }
+  DMC_MODEL_REAL_FIELDS(X)
+#undef X
+  if (ip != nints || rp != nreals) { *err = "model blob size mismatch"; return false; }
+  m->blob_i.assign(ints, ints + nints);
+  m->blob_r.assign(reals, reals + nreals);
+  return true;
+}
+
+struct StepTables {
+  StepLayout L;
+  std::vector<int> mi;       // int tables, laid out per L.mi_*
+  std::vector<double> mr;    // real tables (fp64 master copy), per L.mr_*
+  StepOpts<double> opts;
+  int max_contacts, max_rows;  // upper bounds if no cap applied
+};
+
+// returns false + err for models the kernel does not support
+inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, int njmax, std::string* err) {
+  StepDims d;
+  std::memset(&d, 0, sizeof d);
+  d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom;
+  d.nsite = m.nsite; d.nsensor = m.nsensor; d.nsensordata = m.nsensordata; d.npair = m.npair;
+  if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
+  if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
+  if (m.opt_cone != DMC_CONE_PYRAMIDAL) {
+    bool fric = false;
+    for (int g = 0; g < m.ngeom; g++) if (m.geom_condim[g] > 1) fric = true;
+    if (fric && m.npair) { *err = "elliptic friction cones are not implemented in the HIP path yet"; return false; }
+  }
+  if (m.opt_solver != DMC_SOL_NEWTON) { *err = "only the Newton solver is implemented in the HIP path"; return false; }
+  if (m.opt_integrator != DMC_INT_EULER) { *err = "only the Euler integrator is implemented in the HIP path"; return false; }
+  if (m.opt_noslip_iterations > 0) { *err = "noslip iterations are not implemented in the HIP path"; return false; }
+  for (int i = 0; i < m.nv; i++) if (m.dof_frictionloss[i] != 0) { *err = "dof frictionloss is not implemented"; return false; }
+  for (int j = 0; j < m.njnt; j++) {
+    if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
+    if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
+  }
+  // tree levels
+  std::vector<int> depth(m.nbody, 0);
+  int nlevel = 0;
+  for (int b = 1; b < m.nbody; b++) { depth[b] = depth[m.body_parentid[b]] + 1; nlevel = std::max(nlevel, depth[b]); }
+  d.nlevel = nlevel; d.nchild = std::max(0, m.nbody - 1);
+  // M sparsity
+  std::vector<int> mp_i, mp_j;
+  for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) { mp_i.push_back(i); mp_j.push_back(j); }
+  d.nM = (int)mp_i.size();
+  // contact / row caps
+  int maxc = 0, maxr = 0, nlim = 0;
+  for (int j = 0; j < m.njnt; j++) if (m.jnt_limited[j]) nlim++;
+  std::vector<int> pdim(m.npair);
+  for (int p = 0; p < m.npair; p++) {
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    int nc = 1;
+    if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) nc = 2;
+    else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) nc = 4;
+    else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) nc = 1;   // 2 only for exactly parallel axes
+    const bool known = (t1 == DMC_GEOM_PLANE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE || t2 == DMC_GEOM_BOX)) ||
+                       (t1 == DMC_GEOM_SPHERE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE)) ||
+                       (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE);
+    if (!known) { *err = "geom pair type not implemented in the HIP collision kernel (need plane/sphere/capsule, plane-box)"; return false; }
+    int dim;
+    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    if (pr1 == pr2) dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
+    else dim = m.geom_condim[pr1 > pr2 ? g1 : g2];
+    pdim[p] = dim;
+    maxc += nc; maxr += nc * (dim == 1 ? 1 : 2*(dim - 1));
+  }
+  t->max_contacts = maxc; t->max_rows = maxr + nlim;
+  int maxrow_per_contact = 1;
+  for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : 2*(pdim[p] - 1));
+  if (nconmax <= 0) nconmax = std::min(maxc, 24);
+  nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
+  if (njmax <= 0) njmax = nlim + nconmax * maxrow_per_contact;
+  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim)));
+  d.nconmax = nconmax; d.njmax = njmax;
+  step_layout_build(&t->L, d);
+  const StepLayout& L = t->L;
+  t->mi.assign(L.n_mi, 0);
+  t->mr.assign(L.n_mr, 0.0);
+  int* mi = t->mi.data(); double* mr = t->mr.data();
+  auto cpi = [&](int off, const std::vector<int>& v) { std::copy(v.begin(), v.end(), mi + off); };
+  auto cpr = [&](int off, const std::vector<double>& v) { std::copy(v.begin(), v.end(), mr + off); };
+  cpi(L.mi_body_parentid, m.body_parentid); cpi(L.mi_body_rootid, m.body_rootid);
+  cpi(L.mi_body_jntadr, m.body_jntadr); cpi(L.mi_body_jntnum, m.body_jntnum);
+  cpi(L.mi_body_dofadr, m.body_dofadr); cpi(L.mi_body_dofnum, m.body_dofnum);
+  {
+    std::vector<int> last(m.nbody, -1);
+    for (int b = 1; b < m.nbody; b++) {
+      last[b] = last[m.body_parentid[b]];
+      if (m.body_dofnum[b]) last[b] = m.body_dofadr[b] + m.body_dofnum[b] - 1;
+    }
+    cpi(L.mi_body_lastdof, last);
+  }
+  {
+    int* la = mi + L.mi_level_adr; int* lb = mi + L.mi_level_body;
+    int k = 0;
+    for (int lev = 1; lev <= nlevel; lev++) { la[lev - 1] = k; for (int b = 1; b < m.nbody; b++) if (depth[b] == lev) lb[k++] = b; }
+    la[nlevel] = k;
+    int* ca = mi + L.mi_child_adr; int* cl = mi + L.mi_child_list;
+    k = 0;
+    for (int b = 0; b < m.nbody; b++) { ca[b] = k; for (int c = m.nbody - 1; c > b; c--) if (m.body_parentid[c] == b && c != 0) cl[k++] = c; }
+    ca[m.nbody] = k;
+  }
+  cpi(L.mi_jnt_type, m.jnt_type); cpi(L.mi_jnt_qposadr, m.jnt_qposadr); cpi(L.mi_jnt_dofadr, m.jnt_dofadr);
+  cpi(L.mi_jnt_bodyid, m.jnt_bodyid); cpi(L.mi_jnt_limited, m.jnt_limited);
+  cpi(L.mi_dof_bodyid, m.dof_bodyid); cpi(L.mi_dof_jntid, m.dof_jntid); cpi(L.mi_dof_parentid, m.dof_parentid);
+  for (int i = 0; i < m.nv; i++) {
+    uint64_t mask = 0;
+    for (int j = i; j >= 0; j = m.dof_parentid[j]) mask |= (uint64_t)1 << j;
+    mi[L.mi_dof_anc_lo + i] = (int)(uint32_t)(mask & 0xffffffffu);
+    mi[L.mi_dof_anc_hi + i] = (int)(uint32_t)(mask >> 32);
+  }
+  cpi(L.mi_mpair_i, mp_i); cpi(L.mi_mpair_j, mp_j);
+  cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);
+  cpi(L.mi_pair_geom1, m.pair_geom1); cpi(L.mi_pair_geom2, m.pair_geom2); cpi(L.mi_pair_dim, pdim);
+  cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);
+  for (int i = 0; i < m.nu; i++) {
+    const int j = m.actuator_trnid[2*i];
+    if (m.actuator_trntype[i] != DMC_TRN_JOINT || j < 0 || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "only hinge/slide joint transmissions are implemented"; return false; }
+    if (m.actuator_dyntype[i] != DMC_DYN_NONE) { *err = "actuator dynamics are not implemented"; return false; }
+    mi[L.mi_act_dof + i] = m.jnt_dofadr[j]; mi[L.mi_act_qpos + i] = m.jnt_qposadr[j];
+    int fl = 0;
+    if (m.actuator_ctrllimited[i]) fl |= ACTF_CTRLLIMITED;
+    if (m.actuator_forcelimited[i]) fl |= ACTF_FORCELIMITED;
+    if (m.actuator_gaintype[i] == DMC_GAIN_AFFINE) fl |= ACTF_GAIN_AFFINE;
+    if (m.actuator_biastype[i] == DMC_BIAS_AFFINE) fl |= ACTF_BIAS_AFFINE;
+    mi[L.mi_act_flags + i] = fl;
+    mr[L.mr_act_gear + i] = m.actuator_gear[6*i];
+    for (int k = 0; k < 2; k++) { mr[L.mr_act_ctrlrange + 2*i + k] = m.actuator_ctrlrange[2*i + k]; mr[L.mr_act_forcerange + 2*i + k] = m.actuator_forcerange[2*i + k]; }
+    for (int k = 0; k < 3; k++) { mr[L.mr_act_gainprm + 3*i + k] = m.actuator_gainprm[10*i + k]; mr[L.mr_act_biasprm + 3*i + k] = m.actuator_biasprm[10*i + k]; }
+  }
+  cpi(L.mi_sensor_type, m.sensor_type); cpi(L.mi_sensor_objid, m.sensor_objid);
+  cpi(L.mi_sensor_adr, m.sensor_adr); cpi(L.mi_sensor_stage, m.sensor_needstage);
+  cpr(L.mr_qpos0, m.qpos0); cpr(L.mr_qpos_spring, m.qpos_spring);
+  cpr(L.mr_body_pos, m.body_pos); cpr(L.mr_body_quat, m.body_quat); cpr(L.mr_body_ipos, m.body_ipos);
+  cpr(L.mr_body_iquat, m.body_iquat); cpr(L.mr_body_mass, m.body_mass); cpr(L.mr_body_inertia, m.body_inertia);
+  cpr(L.mr_body_subtreemass, m.body_subtreemass); cpr(L.mr_body_invweight0, m.body_invweight0);
+  for (int b = 0; b < m.nbody; b++) mr[L.mr_body_invsubtreemass + b] = 1.0 / std::max((double)DMC_MINVAL, m.body_subtreemass[b]);
+  cpr(L.mr_jnt_pos, m.jnt_pos); cpr(L.mr_jnt_axis, m.jnt_axis); cpr(L.mr_jnt_stiffness, m.jnt_stiffness);
+  cpr(L.mr_jnt_range, m.jnt_range); cpr(L.mr_jnt_margin, m.jnt_margin); cpr(L.mr_jnt_solref, m.jnt_solref);
+  cpr(L.mr_jnt_solimp, m.jnt_solimp);
+  cpr(L.mr_dof_armature, m.dof_armature); cpr(L.mr_dof_damping, m.dof_damping); cpr(L.mr_dof_invweight0, m.dof_invweight0);
+  cpr(L.mr_geom_size, m.geom_size); cpr(L.mr_geom_pos, m.geom_pos); cpr(L.mr_geom_quat, m.geom_quat);
+  cpr(L.mr_geom_rbound, m.geom_rbound);
+  // per-pair contact parameters (mixing rules: max / priority / solmix), SURVEY.md Appendix A.5
+  for (int p = 0; p < m.npair; p++) {
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    mr[L.mr_pair_margin + p] = std::max(m.geom_margin[g1], m.geom_margin[g2]);
+    mr[L.mr_pair_gap + p] = std::max(m.geom_gap[g1], m.geom_gap[g2]);
+    double fr[3];
+    if (pr1 == pr2) for (int k = 0; k < 3; k++) fr[k] = std::max(m.geom_friction[3*g1 + k], m.geom_friction[3*g2 + k]);
+    else { const int gp = pr1 > pr2 ? g1 : g2; for (int k = 0; k < 3; k++) fr[k] = m.geom_friction[3*gp + k]; }
+    for (int k = 0; k < 3; k++) mr[L.mr_pair_friction + 3*p + k] = std::max((double)DMC_MINMU, fr[k]);
+    double mix;
+    if (pr1 != pr2) mix = pr1 > pr2 ? 1 : 0;
+    else {
+      const double sm1 = m.geom_solmix[g1], sm2 = m.geom_solmix[g2];
+      if (sm1 >= DMC_MINVAL && sm2 >= DMC_MINVAL) mix = sm1 / (sm1 + sm2);
+      else if (sm1 < DMC_MINVAL && sm2 < DMC_MINVAL) mix = 0.5;
+      else mix = sm1 < DMC_MINVAL ? 0.0 : 1.0;
+    }
+    const double *r1 = &m.geom_solref[2*g1], *r2 = &m.geom_solref[2*g2];
+    for (int k = 0; k < 2; k++) mr[L.mr_pair_solref + 2*p + k] = (r1[0] > 0 && r2[0] > 0) ? mix*r1[k] + (1 - mix)*r2[k] : std::min(r1[k], r2[k]);
+    for (int k = 0; k < 5; k++) mr[L.mr_pair_solimp + 5*p + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
+  }
+  cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);
+  // sensors the kernel can compute
+  for (int i = 0; i < m.nsensor; i++) {
+    const int st = m.sensor_type[i];
+    const bool ok = st == DMC_SENS_JOINTPOS || st == DMC_SENS_JOINTVEL || st == DMC_SENS_ACTUATORFRC ||
+                    st == DMC_SENS_SUBTREECOM || st == DMC_SENS_SUBTREELINVEL || st == DMC_SENS_VELOCIMETER ||
+                    st == DMC_SENS_GYRO || st == DMC_SENS_ACCELEROMETER || st == DMC_SENS_FORCE ||
+                    st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH;
+    if (!ok) { *err = "sensor type not implemented"; return false; }
+  }
+  StepOpts<double>& o = t->opts;
+  o.timestep = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;
+  o.impratio = m.opt_impratio; o.tolerance = m.opt_tolerance; o.ls_tolerance = m.opt_ls_tolerance;
+  o.meaninertia = m.stat_meaninertia;
+  o.integrator = m.opt_integrator; o.cone = m.opt_cone; o.iterations = m.opt_iterations;
+  o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
+  o.any_damping = 0;
+  for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
+  return true;
+}
+
+template <typename T>
+inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
+  StepOpts<T> o;
+  o.timestep = (T)s.timestep; for (int k = 0; k < 3; k++) o.gravity[k] = (T)s.gravity[k];
+  o.impratio = (T)s.impratio; o.tolerance = (T)s.tolerance; o.ls_tolerance = (T)s.ls_tolerance;
+  o.meaninertia = (T)s.meaninertia; o.integrator = s.integrator; o.cone = s.cone;
+  o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
+  o.any_damping = s.any_damping;
+  return o;
+}
+
+}  // namespace dmc

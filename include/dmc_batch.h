@@ -1,0 +1,106 @@
+/* dmc_batch.h -- C-ABI of the MI355X batched physics step (libdmc_hip.so).
+ *
+ * The reference has no plugin registry for its physics backend: the seam is the
+ * set of pybind11 functions that take (MjModel, MjData) and are called from
+ * dm_control/mujoco/engine.py and wrapper/core.py.  Each entry
+ * point below names the reference call it replaces for a whole batch of
+ * independent environments.  Plain pointers and sizes only; every function
+ * returns 0 on success or a negative error code and never throws/aborts
+ * (dmc_last_error() returns a thread-local message).
+ *
+ * Memory model: one dmc_batch owns B environments on ONE GPU.  Every mjData
+ * array is stored structure-of-arrays across the batch: element k of env e of
+ * field F lives at F_dev[k * B + e] (dtype = batch precision, ints int32).
+ */
+#ifndef DMC_BATCH_H_
+#define DMC_BATCH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmc_model dmc_model;
+typedef struct dmc_batch dmc_batch;
+
+const char* dmc_last_error(void);
+
+/* Replaces mujoco.MjModel.from_xml_string as consumed by
+ * wrapper.MjModel.from_xml_string (dm_control/mujoco/wrapper/core.py:180-182,289):
+ * takes the compiled constant tables (include/dmc_model_layout.h) produced by
+ * dm_control_amd/mjcf_compiler.py. */
+int dmc_model_create(const int32_t* ints, int n_ints, const double* reals, int n_reals, dmc_model** out);
+void dmc_model_destroy(dmc_model* m);
+
+/* Replaces mujoco.MjData(model) (wrapper/core.py:475), B times.
+ * precision: 32 or 64.  nconmax/njmax: per-env contact / constraint-row caps
+ * (0 = automatic); exceeding them raises mjWARN_CONTACTFULL / mjWARN_CNSTRFULL
+ * counters like MuJoCo's own caps.  lanes_per_env: 64, 32 or 16 (0 = 64). */
+int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
+                     int nconmax, int njmax, int lanes_per_env, dmc_batch** out);
+void dmc_batch_destroy(dmc_batch* b);
+
+/* Replaces Physics.step(nstep) = mj_step2; mj_step(nstep-1); mj_step1 when
+ * legacy_step != 0 (dm_control/mujoco/engine.py:147-162) or mj_step(nstep)
+ * otherwise (engine.py:176), for every env, in ONE kernel launch.
+ * hip_stream: hipStream_t to launch on (NULL = default stream).  Asynchronous. */
+int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream);
+
+/* Replaces mujoco.mj_forward (engine.py:343); disable_actuation != 0 mirrors the
+ * mjDSBL_ACTUATION context used by Physics.reset/after_reset (engine.py:326-333). */
+int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);
+
+/* Replaces mujoco.mj_resetData / mj_resetDataKeyframe (engine.py:318,323) for the
+ * envs whose mask byte is non-zero (mask == NULL: all).  keyframe < 0: qpos0. */
+int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
+
+/* Field access by mjData name ("qpos", "qvel", "ctrl", "qacc_warmstart", "time",
+ * "qfrc_applied", "sensordata", "xpos", "xquat", "xmat", "xipos", "geom_xpos",
+ * "geom_xmat", "site_xpos", "site_xmat", "subtree_com", "qacc", "actuator_force",
+ * "qfrc_actuator", "qfrc_bias", "qfrc_constraint", "contact_dist", "contact_pos",
+ * "contact_frame"; int32: "ncon", "nefc", "solver_iter", "warning",
+ * "contact_geom1", "contact_geom2").  Replaces the numpy views MjData exposes
+ * (wrapper/core.py:438-447).  Host buffers are env-major: (B, rows), float64 /
+ * int32 regardless of the batch precision.  Synchronous. */
+int dmc_batch_field_rows(const dmc_batch* b, const char* name, int* rows, int* is_int);
+int dmc_batch_get(dmc_batch* b, const char* name, double* dst);
+int dmc_batch_set(dmc_batch* b, const char* name, const double* src);
+int dmc_batch_get_int(dmc_batch* b, const char* name, int32_t* dst);
+int dmc_batch_set_int(dmc_batch* b, const char* name, const int32_t* src);
+
+/* Zero-copy access: the SoA device array of a field, (rows, B) in batch
+ * precision; and rebinding a field to caller-owned device memory of that shape
+ * (e.g. a torch tensor) so producers/consumers on the GPU never round-trip. */
+void* dmc_batch_device_ptr(dmc_batch* b, const char* name);
+int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr);
+
+/* Which derived arrays a step/forward writes back to HBM (bit mask, see
+ * dm_control_amd/csrc/step_core.h OUT_*; default: all). */
+int dmc_batch_set_output_mask(dmc_batch* b, int mask);
+
+/* Model options that tasks mutate between steps (wrapper/core.py:389-426):
+ * "disableflags", "iterations", "ls_iterations" / "timestep", "tolerance",
+ * "ls_tolerance", "gravity_x|y|z". */
+int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value);
+int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value);
+
+int dmc_batch_sync(dmc_batch* b);
+
+/* info[0..9] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
+ * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes}. */
+int dmc_batch_info(const dmc_batch* b, int* info);
+
+/* Time `reps` back-to-back step launches with hipEvents on `hip_stream`;
+ * returns the average milliseconds per launch in *ms_per_launch. */
+int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, void* hip_stream, float* ms_per_launch);
+
+/* Debug: dump the LDS scratch of the first `n` envs after the forward pass of
+ * the last substep; read arrays back by scratch name (step_layout.h). */
+int dmc_batch_debug_enable(dmc_batch* b, int n);
+int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int env, double* dst, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DMC_BATCH_H_ */

@@ -244,9 +244,9 @@ static void chol_solve(double* x, const double* L, const double* b, int n) {
     for (int k = 0; k < i; k++) s -= L[i*n + k]*x[k];
     x[i] = s / L[i*n + i];
   }
-  for (int i = n - 1; i >= 0; i--) {
+  for (int i = n - 1; i >= 0; i--) {   /* k descending: the order a column-oriented parallel solve produces */
     double s = x[i];
-    for (int k = i + 1; k < n; k++) s -= L[k*n + i]*x[k];
+    for (int k = n - 1; k > i; k--) s -= L[k*n + i]*x[k];
     x[i] = s / L[i*n + i];
   }
 }
@@ -701,7 +701,7 @@ static void collision(const Model* m, Data* d) {
     /* contact parameters (max / priority / solmix) */
     for (int i = 0; i < n; i++) {
       Contact* ci = c + i;
-      ci->geom1 = g1; ci->geom2 = g2; ci->includemargin = margin - gap; ci->exclude = 0; ci->efc_address = -1;
+      ci->geom1 = g1; ci->geom2 = g2; ci->includemargin = margin - gap; ci->exclude = (ci->dist >= margin - gap); ci->efc_address = -1;
       int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
       double fr[3];
       if (pr1 == pr2) {
@@ -1370,11 +1370,13 @@ static void fwd_velocity(const Model* m, Data* d) {
 static int bad_vec(const double* v, int n) { for (int i = 0; i < n; i++) if (isnan(v[i]) || v[i] > MAXVAL || v[i] < -MAXVAL) return 1; return 0; }
 static void check_pos(const Model* m, Data* d) {
   if (bad_vec(d->qpos, m->nq)) { int w[DMC_NWARNING]; memcpy(w, d->warning, sizeof w); w[DMC_WARN_BADQPOS]++;
-    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1); memcpy(d->warning, w, sizeof w); }
+    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1);
+    memcpy(d->warning, w, sizeof w); }
 }
 static void check_vel(const Model* m, Data* d) {
   if (bad_vec(d->qvel, m->nv)) { int w[DMC_NWARNING]; memcpy(w, d->warning, sizeof w); w[DMC_WARN_BADQVEL]++;
-    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1); memcpy(d->warning, w, sizeof w); }
+    if (!(m->opt_disableflags & DMC_DSBL_AUTORESET)) ora_reset(m, d, -1);
+    memcpy(d->warning, w, sizeof w); }
 }
 static void forward_skip(const Model* m, Data* d, int skipsensor) {
   fwd_position(m, d); if (!skipsensor) sensor_stage(m, d, DMC_STAGE_POS);
@@ -1469,4 +1471,13 @@ void ora_physics_step_legacy(const Model* m, Data* d, int nstep) {
 /* batch convenience for the CPU baseline: B independent datas, nstep legacy steps each */
 void ora_physics_step_legacy_many(const Model* m, Data** ds, int B, int nstep) {
   for (int e = 0; e < B; e++) ora_physics_step_legacy(m, ds[e], nstep);
+}
+
+/* CPU-baseline rollout: T legacy Physics.step() calls for B independent datas,
+ * actions laid out (T, B, nu).  Single thread; callers shard envs over threads. */
+void ora_rollout_legacy(const Model* m, Data** ds, int B, int T, int nsub, const double* actions) {
+  for (int t = 0; t < T; t++) for (int e = 0; e < B; e++) {
+    memcpy(ds[e]->ctrl, actions + ((size_t)t*B + e)*m->nu, sizeof(double) * (size_t)m->nu);
+    ora_physics_step_legacy(m, ds[e], nsub);
+  }
 }

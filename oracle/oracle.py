@@ -64,6 +64,7 @@ def lib():
     L.ora_step.argtypes = [vp, vp, ci]
     L.ora_physics_step_legacy.argtypes = [vp, vp, ci]
     L.ora_physics_step_legacy_many.argtypes = [vp, ctypes.POINTER(vp), ci, ci]
+    L.ora_rollout_legacy.argtypes = [vp, ctypes.POINTER(vp), ci, ci, ci, pd]
     L.ora_contact_force.argtypes = [vp, vp, ci, pd]
     L.ora_object_velocity.argtypes = [vp, vp, ci, ci, ci, pd]
     _lib = L
@@ -212,3 +213,15 @@ class OraclePhysics:
     other = OraclePhysics(self.model, self.legacy_step)
     lib().ora_data_copy(self.model.ptr, other.ptr, self.ptr)
     return other
+
+
+def rollout_legacy(physics_list, actions, nsub=1):
+  """Steps every OraclePhysics in `physics_list` through actions (T, B, nu) in C
+  (single thread).  Used by the CPU baseline and by parity tests."""
+  B = len(physics_list)
+  actions = np.ascontiguousarray(actions, dtype=np.float64)
+  T = actions.shape[0]
+  assert actions.shape[1] == B
+  arr = (ctypes.c_void_p * B)(*[p.ptr for p in physics_list])
+  lib().ora_rollout_legacy(physics_list[0].model.ptr, arr, B, T, nsub,
+                           actions.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))

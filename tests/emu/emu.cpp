@@ -1,0 +1,82 @@
+// emu.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles dm_control_amd/csrc/step_core.h
+// for the host with LPE = 1 (one "lane" per environment) so the kernel's
+// indexing / algorithm logic can be unit-tested against the oracle without a
+// GPU.  Nothing in the product imports or links this.
+#define DMC_HOST_EMU 1
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../dm_control_amd/csrc/step_core.h"
+#include "../../dm_control_amd/csrc/step_tables.h"
+
+using namespace dmc;
+
+struct Emu {
+  HostModel hm;
+  StepTables tb;
+  std::vector<float> mr32;
+};
+
+static std::string g_err;
+
+extern "C" {
+const char* emu_last_error() { return g_err.c_str(); }
+void* emu_create(const int32_t* ints, int ni, const double* reals, int nr, int nconmax, int njmax) {
+  Emu* e = new Emu;
+  if (!host_model_parse(&e->hm, ints, ni, reals, nr, &g_err)) { delete e; return nullptr; }
+  if (!step_tables_build(&e->tb, e->hm, nconmax, njmax, &g_err)) { delete e; return nullptr; }
+  e->mr32.assign(e->tb.mr.begin(), e->tb.mr.end());
+  return e;
+}
+void emu_free(void* h) { delete (Emu*)h; }
+int emu_dims(void* h, int* out) {
+  Emu* e = (Emu*)h; const StepLayout& L = e->tb.L;
+  out[0] = L.n_sr; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr;
+  return 0;
+}
+int emu_find(void* h, const char* name, int* off, int* cnt, int* kind) { return step_layout_find(&((Emu*)h)->tb.L, name, off, cnt, kind); }
+
+}  // extern "C"
+
+// io arrays are for ONE environment (B = 1).  prec: 64 or 32 (fp32 converts in/out).
+template <typename T>
+static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int legacy, int mode, double* dbg, int* dbgi) {
+  const StepLayout& L = e->tb.L;
+  StepOpts<T> o = step_opts_cast<T>(e->tb.opts);
+  std::vector<T> s(L.n_sr, (T)0); std::vector<int> si(L.n_si, 0);
+  // field order matches tests/emu_lib.py
+  const int nb = L.d.nbody;
+  const int sizes[] = {L.d.nq, L.d.nv, L.d.nu, L.d.nv, L.d.nv, 1,
+                       L.d.nsensordata, 3*nb, 4*nb, 9*nb, 3*nb, 3*L.d.ngeom, 9*L.d.ngeom,
+                       3*L.d.nsite, 9*L.d.nsite, 3*nb, L.d.nv, L.d.nu, L.d.nv, L.d.nv, L.d.nv,
+                       L.d.nconmax, 3*L.d.nconmax, 9*L.d.nconmax};
+  const int NF = sizeof(sizes)/sizeof(int);
+  std::vector<std::vector<T>> buf(NF);
+  for (int k = 0; k < NF; k++) { buf[k].resize(sizes[k] + 1); for (int i = 0; i < sizes[k]; i++) buf[k][i] = (T)f[k][i]; }
+  std::vector<T> dbuf(L.n_sr); std::vector<int> dibuf(L.n_si);
+  StepIO<T> io;
+  io.B = 1;
+  io.qpos = buf[0].data(); io.qvel = buf[1].data(); io.ctrl = buf[2].data(); io.qacc_warmstart = buf[3].data();
+  io.qfrc_applied = buf[4].data(); io.time = buf[5].data();
+  io.sensordata = buf[6].data(); io.xpos = buf[7].data(); io.xquat = buf[8].data(); io.xmat = buf[9].data();
+  io.xipos = buf[10].data(); io.geom_xpos = buf[11].data(); io.geom_xmat = buf[12].data();
+  io.site_xpos = buf[13].data(); io.site_xmat = buf[14].data(); io.subtree_com = buf[15].data();
+  io.qacc = buf[16].data(); io.actuator_force = buf[17].data(); io.qfrc_actuator = buf[18].data();
+  io.qfrc_bias = buf[19].data(); io.qfrc_constraint = buf[20].data();
+  io.contact_dist = buf[21].data(); io.contact_pos = buf[22].data(); io.contact_frame = buf[23].data();
+  io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
+  io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
+  StepCore<T, 1> core(L, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
+  core.run(io, 0, nstep, legacy, mode, OUT_ALL);
+  for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
+  if (dbg) { for (int i = 0; i < L.n_sr; i++) dbg[i] = (double)dbuf[i]; for (int i = 0; i < L.n_si; i++) dbgi[i] = dibuf[i]; }
+}
+extern "C" {
+int emu_run(void* h, int prec, double** f, int** fi, int nstep, int legacy, int mode, double* dbg, int* dbgi) {
+  Emu* e = (Emu*)h;
+  if (prec == 64) run_t<double>(e, e->tb.mr.data(), f, fi, nstep, legacy, mode, dbg, dbgi);
+  else run_t<float>(e, e->mr32.data(), f, fi, nstep, legacy, mode, dbg, dbgi);
+  return 0;
+}
+}

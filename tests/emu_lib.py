@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE: host build (LPE=1) of the kernel core, see tests/emu/emu.cpp."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, 'emu', 'emu.cpp')
+_LIB = os.path.join(_HERE, 'emu', 'libemu.so')
+_lib = None
+
+FIELDS = ['qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time',
+          'sensordata', 'xpos', 'xquat', 'xmat', 'xipos', 'geom_xpos', 'geom_xmat',
+          'site_xpos', 'site_xmat', 'subtree_com', 'qacc', 'actuator_force',
+          'qfrc_actuator', 'qfrc_bias', 'qfrc_constraint',
+          'contact_dist', 'contact_pos', 'contact_frame']
+IFIELDS = ['ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2']
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    csrc = os.path.join(os.path.dirname(_HERE), 'dm_control_amd', 'csrc')
+    deps = [_SRC] + [os.path.join(csrc, f) for f in ('step_core.h', 'step_layout.h', 'step_tables.h')]
+    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in deps):
+      subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+                             '-o', _LIB, _SRC])
+    L = ctypes.CDLL(_LIB)
+    L.emu_last_error.restype = ctypes.c_char_p
+    L.emu_create.restype = ctypes.c_void_p
+    L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.emu_free.argtypes = [ctypes.c_void_p]
+    L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+    L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    _lib = L
+  return _lib
+
+
+class EmuPhysics:
+
+  def __init__(self, compiled, prec=64, nconmax=0, njmax=0):
+    self.m = compiled
+    self.prec = prec
+    ints, reals = compiled.pack()
+    self.h = lib().emu_create(ints.ctypes.data, ints.size, reals.ctypes.data, reals.size, nconmax, njmax)
+    if not self.h:
+      raise ValueError(lib().emu_last_error().decode())
+    dims = np.zeros(6, dtype=np.int32)
+    lib().emu_dims(self.h, dims.ctypes.data)
+    self.n_sr, self.n_si, self.nconmax, self.njmax = [int(x) for x in dims[:4]]
+    m = compiled
+    nb = m.nbody
+    sizes = [m.nq, m.nv, m.nu, m.nv, m.nv, 1, m.nsensordata, 3*nb, 4*nb, 9*nb, 3*nb,
+             3*m.ngeom, 9*m.ngeom, 3*m.nsite, 9*m.nsite, 3*nb, m.nv, m.nu, m.nv, m.nv, m.nv,
+             self.nconmax, 3*self.nconmax, 9*self.nconmax]
+    self.f = {n: np.zeros(max(s, 1)) for n, s in zip(FIELDS, sizes)}
+    self._sizes = dict(zip(FIELDS, sizes))
+    self.fi = {'ncon': np.zeros(1, np.int32), 'nefc': np.zeros(1, np.int32),
+               'solver_iter': np.zeros(1, np.int32), 'warning': np.zeros(8, np.int32),
+               'contact_geom1': np.zeros(self.nconmax, np.int32),
+               'contact_geom2': np.zeros(self.nconmax, np.int32)}
+    self.f['qpos'][:m.nq] = m.qpos0
+    self.dbg = np.zeros(self.n_sr)
+    self.dbgi = np.zeros(self.n_si, np.int32)
+
+  def __del__(self):
+    if getattr(self, 'h', None):
+      lib().emu_free(self.h)
+      self.h = None
+
+  def __getattr__(self, name):
+    if name in FIELDS:
+      return self.f[name][:self._sizes[name]]
+    if name in IFIELDS:
+      return self.fi[name]
+    raise AttributeError(name)
+
+  def _run(self, nstep, legacy, mode):
+    pf = (ctypes.c_void_p * len(FIELDS))(*[self.f[n].ctypes.data for n in FIELDS])
+    pi = (ctypes.c_void_p * len(IFIELDS))(*[self.fi[n].ctypes.data for n in IFIELDS])
+    lib().emu_run(self.h, self.prec, pf, pi, nstep, legacy, mode, self.dbg.ctypes.data, self.dbgi.ctypes.data)
+
+  def step(self, nstep=1, legacy=True):
+    self._run(nstep, int(legacy), 0)
+
+  def forward(self, disable_actuation=False):
+    self._run(0, 0, 2 if disable_actuation else 1)
+
+  def scratch(self, name):
+    off, cnt, kind = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if not lib().emu_find(self.h, name.encode(), ctypes.byref(off), ctypes.byref(cnt), ctypes.byref(kind)):
+      raise KeyError(name)
+    src = self.dbgi if kind.value else self.dbg
+    return src[off.value:off.value + cnt.value]

@@ -1,0 +1,308 @@
+"""Parity tests proper: the HIP kernel, called through the C-ABI, against the fp64
+CPU oracle on identical seeded inputs.  Tolerances (north_star): rel qpos error
+<= 1e-4 over 1000 steps for the fp32 production kernel; the fp64 kernel must
+track the oracle to 1e-9."""
+import os
+
+import numpy as np
+import pytest
+
+from dm_control_amd import mjcf_compiler as mc
+
+pytestmark = pytest.mark.gpu
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      'dm_control_amd', 'suite', 'assets')
+TOL_F32_1000 = 1e-4     # north_star: "within 1e-4 rel qpos error vs CPU mj_step over 1000 steps"
+TOL_F64_1000 = 1e-9
+
+
+def _model(name):
+  with open(os.path.join(ASSETS, name + '.xml')) as f:
+    return mc.compile_xml(f.read())
+
+
+@pytest.fixture(scope='module')
+def cheetah():
+  return _model('cheetah')
+
+
+def _batch(model, B, **kw):
+  from dm_control_amd.batch import BatchedPhysics
+  return BatchedPhysics(model, B, **kw)
+
+
+def _oracles(model, q, v=None):
+  from oracle.oracle import OraclePhysics
+  out = []
+  for e in range(q.shape[0]):
+    p = OraclePhysics(model)
+    p.qpos[:] = q[e]
+    if v is not None:
+      p.qvel[:] = v[e]
+    p.forward()
+    out.append(p)
+  return out
+
+
+def _rel_err(qg, qo):
+  return float((np.abs(qg - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))).max())
+
+
+def _cheetah_init(model, n, seed0=0):
+  # Cheetah.initialize_episode (suite/cheetah.py:63-76): limited joints ~ U(range)
+  q = np.tile(model.qpos0, (n, 1))
+  lim = model.jnt_limited == 1
+  lo, hi = model.jnt_range[lim].T
+  for e in range(n):
+    q[e, lim] = np.random.RandomState(seed0 + e).uniform(lo, hi)
+  return q
+
+
+@pytest.mark.parametrize('lanes', [64, 32, 16])
+def test_forward_stages_fp64(cheetah, lanes):
+  m = cheetah
+  NE = 16
+  rs = np.random.RandomState(0)
+  q = np.tile(m.qpos0, (NE, 1))
+  q[:, 3:] += rs.uniform(-0.4, 0.4, (NE, 6))
+  q[:, 2] += rs.uniform(-0.5, 0.5, NE)
+  q[:, 1] = rs.uniform(-0.6, 0.1, NE)
+  v = rs.uniform(-1, 1, (NE, m.nv))
+  c = rs.uniform(-1, 1, (NE, m.nu))
+  b = _batch(m, NE, precision=64, lanes_per_env=lanes)
+  b.debug_enable(NE)
+  b.set('qpos', q); b.set('qvel', v); b.set('ctrl', c)
+  b.forward()
+  from oracle.oracle import OraclePhysics
+  for e in range(NE):
+    o = OraclePhysics(m)
+    o.qpos[:], o.qvel[:], o.ctrl[:] = q[e], v[e], c[e]
+    o.forward()
+    im = b.debug_get('imisc', e)
+    assert int(im[0]) == o.ncon and int(im[1]) == o.nefc
+    ne = o.nefc
+    for name, ref in (('xpos', o.xpos), ('xmat', o.xmat), ('cdof', o.cdof), ('qM', o.qM),
+                      ('qfrc_bias', o.qfrc_bias), ('efc_J', o.efc_J[:ne*m.nv]),
+                      ('efc_D', o.efc_D[:ne]), ('efc_aref', o.efc_aref[:ne])):
+      np.testing.assert_array_equal(b.debug_get(name, e)[:ref.size], ref, err_msg='%s env %d' % (name, e))
+    np.testing.assert_allclose(b.debug_get('qacc', e), o.qacc, rtol=1e-10, atol=1e-8)
+  # derived outputs through the public field API
+  np.testing.assert_allclose(b.get('ncon')[:, 0], [int(b.debug_get('imisc', e)[0]) for e in range(NE)])
+  b.close()
+
+
+@pytest.mark.parametrize('precision,lanes,tol', [(64, 64, TOL_F64_1000), (32, 64, TOL_F32_1000),
+                                                  (32, 32, TOL_F32_1000), (32, 16, TOL_F32_1000)])
+def test_cheetah_1000_step_rollout(cheetah, precision, lanes, tol):
+  """BASELINE config 2 on a 32-env subset: task initialisation (random limited
+  joints + 200 settle steps), then 1000 random-action steps, open loop."""
+  from oracle import oracle
+  m = cheetah
+  NE, T = 32, 1000
+  q = _cheetah_init(m, NE)
+  b = _batch(m, NE, precision=precision, lanes_per_env=lanes)
+  b.set('qpos', q)
+  refs = _oracles(m, q)
+  b.step(200)
+  oracle.rollout_legacy(refs, np.zeros((200, NE, m.nu)))
+  b.set('time', np.zeros((NE, 1)))
+  rs = np.random.RandomState(0)
+  acts = rs.uniform(-1, 1, (T, NE, m.nu)).astype(np.float32).astype(np.float64)
+  worst = _rel_err(b.get('qpos'), np.stack([p.qpos for p in refs]))
+  for t in range(T):
+    b.set_control(acts[t])
+    b.step()
+    oracle.rollout_legacy(refs, acts[t:t + 1])
+    if t % 10 == 9 or t == T - 1:
+      worst = max(worst, _rel_err(b.get('qpos'), np.stack([p.qpos for p in refs])))
+  assert worst < tol, worst
+  assert not b.get('warning').any()
+  sens = b.get('sensordata')
+  np.testing.assert_allclose(sens, np.stack([p.sensordata for p in refs]), atol=max(tol * 100, 1e-7))
+  np.testing.assert_allclose(b.get('time')[:, 0], T * m.opt.timestep, rtol=1e-5)
+  b.close()
+
+
+def test_fused_nstep_equals_single_steps(cheetah):
+  m = cheetah
+  q = _cheetah_init(m, 8)
+  a, b = _batch(m, 8, precision=32), _batch(m, 8, precision=32)
+  for x in (a, b):
+    x.set('qpos', q)
+    x.set_control(np.full((8, m.nu), 0.25))
+  for _ in range(6):
+    a.step(1)
+  b.step(6)
+  np.testing.assert_array_equal(a.get('qpos'), b.get('qpos'))
+  np.testing.assert_array_equal(a.get('qvel'), b.get('qvel'))
+  np.testing.assert_array_equal(a.get('sensordata'), b.get('sensordata'))
+  a.close(); b.close()
+
+
+def test_legacy_vs_nonlegacy_outputs(cheetah):
+  # legacy_step: derived fields belong to the NEW state (trailing mj_step1,
+  # engine.py:147-162); non-legacy: to the state before the last integration.
+  m = cheetah
+  q = _cheetah_init(m, 4)
+  a, b = _batch(m, 4, precision=64), _batch(m, 4, precision=64)
+  for x in (a, b):
+    x.set('qpos', q)
+  b.legacy_step = False
+  a.step(3); b.step(3)
+  np.testing.assert_array_equal(a.get('qpos'), b.get('qpos'))
+  refs = _oracles(m, a.get('qpos'), a.get('qvel'))
+  np.testing.assert_allclose(a.get('xpos'), np.stack([p.xpos for p in refs]), atol=1e-12)
+  assert np.abs(a.get('xpos') - b.get('xpos')).max() > 1e-6
+  a.close(); b.close()
+
+
+@pytest.mark.parametrize('B', [1, 3, 5, 67])
+def test_ragged_batch_sizes_and_slot_independence(cheetah, B):
+  """An environment's result must not depend on which slot / workgroup it sits in."""
+  m = cheetah
+  q1 = _cheetah_init(m, 1, seed0=7)
+  ref = _batch(m, 1, precision=32)
+  ref.set('qpos', q1)
+  ref.step(25)
+  want = ref.get('qpos')[0]
+  b = _batch(m, B, precision=32)
+  q = _cheetah_init(m, B, seed0=100)
+  q[B - 1] = q1[0]
+  b.set('qpos', q)
+  b.step(25)
+  np.testing.assert_array_equal(b.get('qpos')[B - 1], want)
+  assert np.all(np.isfinite(b.get('qpos')))
+  ref.close(); b.close()
+
+
+def test_full_batch_4096_properties(cheetah):
+  """BASELINE size: determinism, permutation equivariance, agreement of a sparse
+  sample with the oracle, no warnings."""
+  from oracle import oracle
+  m = cheetah
+  B, T = 4096, 50
+  q = _cheetah_init(m, B)
+  rs = np.random.RandomState(3)
+  acts = rs.uniform(-1, 1, (T, B, m.nu))
+  perm = rs.permutation(B)
+
+  def run(qq, aa):
+    b = _batch(m, B, precision=32)
+    b.set('qpos', qq)
+    for t in range(T):
+      b.set_control(aa[t])
+      b.step()
+    out = b.get('qpos'), b.get('sensordata'), b.get('warning')
+    b.close()
+    return out
+  q1, s1, w1 = run(q, acts)
+  q2, s2, _ = run(q, acts)
+  np.testing.assert_array_equal(q1, q2)
+  np.testing.assert_array_equal(s1, s2)
+  q3, _, _ = run(q[perm], acts[:, perm])
+  np.testing.assert_array_equal(q3, q1[perm])
+  assert not w1.any()
+  sample = np.arange(0, B, 257)
+  refs = _oracles(m, q[sample])
+  oracle.rollout_legacy(refs, acts[:, sample])
+  assert _rel_err(q1[sample], np.stack([p.qpos for p in refs])) < 1e-4
+
+
+def test_reset_mask_and_keyframe():
+  m = mc.compile_xml("""
+  <mujoco><worldbody><body><joint name="a" type="hinge" axis="0 1 0"/><geom size=".1" pos=".3 0 0"/>
+  </body></worldbody><keyframe><key qpos="0.5" qvel="-1"/></keyframe></mujoco>""")
+  b = _batch(m, 4, precision=64)
+  b.step(10)
+  before = b.get('qpos').copy()
+  b.reset(env_mask=[1, 0, 0, 1])
+  after = b.get('qpos')
+  assert after[0, 0] == 0 and after[3, 0] == 0
+  np.testing.assert_array_equal(after[1:3], before[1:3])
+  assert b.get('time')[0, 0] == 0 and b.get('time')[1, 0] > 0
+  b.reset(keyframe_id=0)
+  np.testing.assert_array_equal(b.get('qpos'), np.full((4, 1), 0.5))
+  np.testing.assert_array_equal(b.get('qvel'), np.full((4, 1), -1.0))
+  b.close()
+
+
+def test_bad_state_raises_warning_and_resets_only_that_env(cheetah):
+  # engine_test.py:502-523 semantics, per environment
+  m = cheetah
+  W = mc.C
+  b = _batch(m, 4, precision=32)
+  q = np.tile(m.qpos0, (4, 1))
+  q[1, 0] = np.inf
+  q[2, 3] = np.nan
+  b.set('qpos', q)
+  c = np.zeros((4, m.nu))
+  c[3, 0] = np.nan
+  b.set_control(c)
+  b.step()
+  w = b.get('warning')
+  assert w[1, W['DMC_WARN_BADQPOS']] == 1 and w[2, W['DMC_WARN_BADQPOS']] == 1
+  assert w[3, W['DMC_WARN_BADCTRL']] == 1
+  assert not w[0].any()
+  assert np.all(np.isfinite(b.get('qpos')))
+  b.close()
+
+
+def test_contact_cap_warning(cheetah):
+  m = cheetah
+  b = _batch(m, 2, precision=32, nconmax=2, njmax=10)
+  q = np.tile(m.qpos0, (2, 1))
+  q[1, 1] = -0.62
+  b.set('qpos', q)
+  b.forward()
+  w = b.get('warning')
+  assert w[1, mc.C['DMC_WARN_CONTACTFULL']] >= 1 and not w[0].any()
+  assert b.get('ncon')[1, 0] == 2
+  b.close()
+
+
+def test_readme_golden_through_the_hip_path():
+  # dm_control/mujoco/README.md:10-49 on the GPU kernel (fp64): plane-box contacts,
+  # slide joint, pyramidal cone, Newton, Euler.
+  m = mc.compile_xml("""
+  <mujoco><worldbody>
+    <geom name="floor" type="plane" size="1 1 .1"/>
+    <body name="box" pos="0 0 .3">
+      <joint name="up_down" type="slide" axis="0 0 1"/>
+      <geom name="box" type="box" size=".2 .2 .2"/>
+      <geom name="sphere" pos=".2 .2 .2" size=".1"/>
+    </body></worldbody></mujoco>""")
+  b = _batch(m, 2, precision=64)
+  b.set('qpos', np.full((2, 1), 0.5))
+  b.forward(disable_actuation=True)
+  np.testing.assert_allclose(b.get('geom_xpos')[0].reshape(-1, 3), [[0, 0, 0], [0, 0, .8], [.2, .2, 1.]], atol=1e-12)
+  while b.get('time')[0, 0] < 1.:
+    b.step(10)
+  # 1.0 s is not an exact multiple in floating point: replicate `while time < 1: step()`
+  b2 = _batch(m, 1, precision=64)
+  b2.set('qpos', np.full((1, 1), 0.5))
+  n = 0
+  t = 0.0
+  while t < 1.:
+    t += m.opt.timestep
+    n += 1
+  b2.step(n)
+  z = b2.get('geom_xpos')[0].reshape(-1, 3)[1:, 2]
+  np.testing.assert_allclose(z, [0.19996362, 0.39996362], atol=5e-9)
+  b.close(); b2.close()
+
+
+def test_zero_copy_device_binding(cheetah):
+  import torch
+  m = cheetah
+  B = 16
+  b = _batch(m, B, precision=32)
+  ctrl = torch.full((m.nu, B), 0.5, dtype=torch.float32, device='cuda')
+  b.bind('ctrl', ctrl.data_ptr())
+  b.step(5, stream=torch.cuda.current_stream().cuda_stream)
+  torch.cuda.synchronize()
+  a = _batch(m, B, precision=32)
+  a.set_control(np.full((B, m.nu), 0.5))
+  a.step(5)
+  np.testing.assert_array_equal(a.get('qpos'), b.get('qpos'))
+  a.close(); b.close()

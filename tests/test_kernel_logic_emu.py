@@ -1,0 +1,87 @@
+"""Host-logic test: the kernel core (dm_control_amd/csrc/step_core.h) compiled for
+the CPU with one lane per environment (tests/emu) against the fp64 oracle.  This
+checks indexing / algorithm logic without a GPU; the real parity tests are the
+`-m gpu` ones that call the HIP kernel through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from dm_control_amd import mjcf_compiler as mc
+from emu_lib import EmuPhysics
+from oracle.oracle import OraclePhysics
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      'dm_control_amd', 'suite', 'assets')
+
+
+def _cheetah():
+  with open(os.path.join(ASSETS, 'cheetah.xml')) as f:
+    return mc.compile_xml(f.read())
+
+
+def test_forward_stages_bit_exact_fp64():
+  m = _cheetah()
+  rs = np.random.RandomState(0)
+  for trial in range(4):
+    o, e = OraclePhysics(m), EmuPhysics(m, 64)
+    q = m.qpos0.copy()
+    q[2:] += rs.uniform(-0.3, 0.3, 7)
+    q[1] = rs.uniform(-0.6, 0.0)
+    v, c = rs.uniform(-1, 1, 9), rs.uniform(-1, 1, 6)
+    o.qpos[:], o.qvel[:], o.ctrl[:] = q, v, c
+    e.qpos[:], e.qvel[:], e.ctrl[:] = q, v, c
+    o.forward()
+    e.forward()
+    assert o.ncon == e.ncon[0] and o.nefc == e.nefc[0]
+    for name in ('xpos', 'xmat', 'subtree_com', 'qfrc_bias', 'sensordata'):
+      np.testing.assert_array_equal(getattr(o, name), getattr(e, name), err_msg=name)
+    ne = o.nefc
+    np.testing.assert_array_equal(o.qM, e.scratch('qM'))
+    np.testing.assert_array_equal(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv])
+    np.testing.assert_array_equal(o.efc_aref[:ne], e.scratch('efc_aref')[:ne])
+    np.testing.assert_allclose(o.qacc, e.qacc, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize('prec,tol', [(64, 1e-10), (32, 1e-4)])
+def test_trajectory_1000_steps(prec, tol):
+  # north_star tolerance: 1e-4 rel qpos error over 1000 steps
+  m = _cheetah()
+  o, e = OraclePhysics(m), EmuPhysics(m, prec)
+  rs = np.random.RandomState(1)
+  q = m.qpos0.copy()
+  q[3:] += rs.uniform(-0.3, 0.3, 6)
+  o.qpos[:] = q
+  e.qpos[:] = q
+  o.forward()
+  worst = 0.0
+  for _ in range(1000):
+    c = rs.uniform(-1, 1, 6)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    worst = max(worst, np.abs(o.qpos - e.qpos).max() / max(1, np.abs(o.qpos).max()))
+  assert worst < tol
+  assert not e.warning.any()
+
+
+def test_nstep_fused_equals_single_steps():
+  m = _cheetah()
+  a, b = EmuPhysics(m, 64), EmuPhysics(m, 64)
+  a.ctrl[:] = 0.3
+  b.ctrl[:] = 0.3
+  for _ in range(5):
+    a.step(1)
+  b.step(5)
+  np.testing.assert_array_equal(a.qpos, b.qpos)
+  np.testing.assert_array_equal(a.sensordata, b.sensordata)
+
+
+def test_contact_cap_raises_warning():
+  m = _cheetah()
+  e = EmuPhysics(m, 64, nconmax=2, njmax=10)
+  e.qpos[1] = -0.62   # whole body pressed into the ground: > 2 contacts
+  e.forward()
+  assert e.warning[mc.C['DMC_WARN_CONTACTFULL']] >= 1
+  assert e.ncon[0] == 2
