@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdmc_hip.so')
+_VARIANT = 'prof' if os.environ.get('DMC_USE_PROF') else os.environ.get('DMC_LIB_VARIANT')
+LIB_PATH = os.path.join(_HERE, 'libdmc_hip_%s.so' % _VARIANT if _VARIANT else 'libdmc_hip.so')
 
 EXPORTS = [
     'dmc_last_error', 'dmc_model_create', 'dmc_model_destroy', 'dmc_batch_create',
@@ -13,7 +14,8 @@ EXPORTS = [
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
     'dmc_batch_sync', 'dmc_batch_info', 'dmc_batch_time_steps',
-    'dmc_batch_debug_enable', 'dmc_batch_debug_get',
+    'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
+    'dmc_batch_prof_get',
 ]
 
 _lib = None
@@ -57,6 +59,8 @@ def lib():
   L.dmc_batch_time_steps.argtypes = [vp, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
   L.dmc_batch_debug_enable.argtypes = [vp, ci]
   L.dmc_batch_debug_get.argtypes = [vp, cs, ci, vp, ctypes.POINTER(ci)]
+  L.dmc_batch_prof_enable.argtypes = [vp, ci]
+  L.dmc_batch_prof_get.argtypes = [vp, vp, ctypes.POINTER(ci)]
   _lib = L
   return L
 

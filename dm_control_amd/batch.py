@@ -143,6 +143,19 @@ class BatchedPhysics:
                                                      int(reps), stream, ctypes.byref(ms)))
     return ms.value
 
+  PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
+                'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
+                'euler', 'trailing_step1', 'store']
+
+  def prof_enable(self, on=True):
+    _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))
+
+  def prof_get(self):
+    buf = np.zeros(32)
+    n = ctypes.c_int()
+    _native.check(_native.lib().dmc_batch_prof_get(self._ptr, buf.ctypes.data, ctypes.byref(n)))
+    return dict(zip(self.PROF_NAMES, buf[:n.value]))
+
   # -- debug ----------------------------------------------------------------------------
   def debug_enable(self, n):
     _native.check(_native.lib().dmc_batch_debug_enable(self._ptr, int(n)))

@@ -30,13 +30,22 @@ def _stale(target, sources):
   return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, profile=False, variant=None, extra_flags=()):
+  """profile=True builds libdmc_hip_prof.so with per-phase cycle counters
+  (-DDMC_PROFILE) next to the production library.  variant/extra_flags build an
+  experimental libdmc_hip_<variant>.so (tuning studies; select it at run time
+  with DMC_LIB_VARIANT=<variant>)."""
   deps = [os.path.join(CSRC, d) for d in _DEPS]
   objs = []
   procs = []
+  tag = 'prof' if profile else variant
+  lib = LIB.replace('.so', '_%s.so' % tag) if tag else LIB
   for src, flags in _UNITS:
     s = os.path.join(CSRC, src)
-    o = os.path.join(CSRC, src.replace('.hip', '.o'))
+    o = os.path.join(CSRC, src.replace('.hip', '_%s.o' % tag if tag else '.o'))
+    flags = flags + list(extra_flags)
+    if profile:
+      flags = flags + ['-DDMC_PROFILE=1']
     objs.append(o)
     if force or _stale(o, [s] + deps):
       cmd = [HIPCC] + _COMMON + flags + ['-c', s, '-o', o]
@@ -46,13 +55,16 @@ def build(force=False, verbose=False):
   for cmd, p in procs:
     if p.wait() != 0:
       raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-  if force or procs or _stale(LIB, objs):
-    cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+  if force or procs or _stale(lib, objs):
+    cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
       print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-  return LIB
+  return lib
 
 
 if __name__ == '__main__':
-  print(build(force='--force' in sys.argv, verbose=True))
+  var = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--variant=')]
+  xf = [a for a in sys.argv if a.startswith('-D') or a.startswith('-m')]
+  print(build(force='--force' in sys.argv, verbose=True, profile='--profile' in sys.argv,
+              variant=var[0] if var else None, extra_flags=xf))

@@ -39,6 +39,7 @@ struct Field {
   std::string name;
   int rows;
   bool is_int;
+  bool is_f64;     // stored as double regardless of the batch precision (time)
   void* dev;       // current binding
   void* owned;     // hipMalloc'ed by us (may differ from dev after dmc_batch_bind)
 };
@@ -56,6 +57,7 @@ struct dmc_batch {
   int ndebug;
   void* d_debug;
   int* d_debug_i;
+  long long* d_prof;
   size_t elem;  // sizeof(T)
 };
 
@@ -81,7 +83,9 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   const size_t tables = (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem;
   const size_t env_bytes = (size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int);
   const size_t lds_cu = 160 * 1024;
-  int lpe = lanes_per_env ? lanes_per_env : 64;
+  // automatic: small models (cheetah, nv = 9) leave most of a 64-lane group idle, so
+  // two environments share a wavefront; measured on MI355X (scripts/perf_probe.py)
+  int lpe = lanes_per_env ? lanes_per_env : (b->tb.L.d.nv <= 12 ? 32 : 64);
   if (lpe != 64 && lpe != 32 && lpe != 16) return fail("lanes_per_env must be 64, 32 or 16");
   const int epw = 64 / lpe;
   int best_w = 0; long best_score = -1;
@@ -125,7 +129,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr; b->d_prof = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
@@ -149,8 +153,8 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
       {"ncon", 1, true}, {"nefc", 1, true}, {"solver_iter", 1, true}, {"warning", DMC_NWARNING, true},
       {"contact_geom1", d.nconmax, true}, {"contact_geom2", d.nconmax, true}};
   for (const Spec& s : specs) {
-    Field f; f.name = s.name; f.rows = s.rows; f.is_int = s.is_int; f.dev = nullptr; f.owned = nullptr;
-    const size_t bytes = (size_t)std::max(1, s.rows) * b->B * (s.is_int ? sizeof(int) : b->elem);
+    Field f; f.name = s.name; f.rows = s.rows; f.is_int = s.is_int; f.is_f64 = !strcmp(s.name, "time"); f.dev = nullptr; f.owned = nullptr;
+    const size_t bytes = (size_t)std::max(1, s.rows) * b->B * (s.is_int ? sizeof(int) : (f.is_f64 ? sizeof(double) : b->elem));
     e = hipMalloc(&f.owned, bytes);
     if (e == hipSuccess) e = hipMemset(f.owned, 0, bytes);
     if (e != hipSuccess) { *out = nullptr; dmc_batch_destroy(b); return fail(std::string("hipMalloc field: ") + hipGetErrorString(e), -2); }
@@ -170,6 +174,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_mr) (void)hipFree(b->d_mr);
   if (b->d_debug) (void)hipFree(b->d_debug);
   if (b->d_debug_i) (void)hipFree(b->d_debug_i);
+  if (b->d_prof) (void)hipFree(b->d_prof);
   delete b;
 }
 
@@ -178,7 +183,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   auto P = [&](const char* n) { return find_field(b, n)->dev; };
   io->B = b->B;
   io->qpos = (T*)P("qpos"); io->qvel = (T*)P("qvel"); io->ctrl = (T*)P("ctrl");
-  io->qacc_warmstart = (T*)P("qacc_warmstart"); io->qfrc_applied = (T*)P("qfrc_applied"); io->time = (T*)P("time");
+  io->qacc_warmstart = (T*)P("qacc_warmstart"); io->qfrc_applied = (T*)P("qfrc_applied"); io->time = (double*)P("time"); io->prof = b->d_prof;
   io->sensordata = (T*)P("sensordata"); io->xpos = (T*)P("xpos"); io->xquat = (T*)P("xquat"); io->xmat = (T*)P("xmat");
   io->xipos = (T*)P("xipos"); io->geom_xpos = (T*)P("geom_xpos"); io->geom_xmat = (T*)P("geom_xmat");
   io->site_xpos = (T*)P("site_xpos"); io->site_xmat = (T*)P("site_xmat"); io->subtree_com = (T*)P("subtree_com");
@@ -226,7 +231,7 @@ static int get_real(dmc_batch* b, Field* f, double* dst) {
   if (!n) return 0;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  if (b->precision == 64) {
+  if (b->precision == 64 || f->is_f64) {
     std::vector<double> tmp(n);
     HIP_TRY(hipMemcpy(tmp.data(), f->dev, n * sizeof(double), hipMemcpyDeviceToHost));
     for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) dst[(size_t)e * f->rows + k] = tmp[(size_t)k * b->B + e];
@@ -242,7 +247,7 @@ static int set_real(dmc_batch* b, Field* f, const double* src) {
   if (!n) return 0;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  if (b->precision == 64) {
+  if (b->precision == 64 || f->is_f64) {
     std::vector<double> tmp(n);
     for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = src[(size_t)e * f->rows + k];
     HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
@@ -432,5 +437,31 @@ extern "C" int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int e
     for (int i = 0; i < cnt; i++) dst[i] = tmp[(size_t)i * n + env];
   }
   *count = cnt;
+  return 0;
+}
+
+// ---- per-phase cycle profile (only meaningful in -DDMC_PROFILE builds) -----------
+extern "C" int dmc_batch_prof_enable(dmc_batch* b, int enable) {
+  if (!b) return fail("null batch");
+#ifndef DMC_PROFILE
+  if (enable) return fail("library built without DMC_PROFILE");
+#endif
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->d_prof) { (void)hipFree(b->d_prof); b->d_prof = nullptr; }
+  if (!enable) return 0;
+  HIP_TRY(hipMalloc((void**)&b->d_prof, (size_t)PROF_N * b->B * sizeof(long long)));
+  HIP_TRY(hipMemset(b->d_prof, 0, (size_t)PROF_N * b->B * sizeof(long long)));
+  return 0;
+}
+// dst: (PROF_N) mean cycles per env, accumulated since enable; returns PROF_N in *n
+extern "C" int dmc_batch_prof_get(dmc_batch* b, double* dst, int* n) {
+  if (!b || !dst || !n) return fail("null argument");
+  if (!b->d_prof) return fail("profiling not enabled");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<long long> tmp((size_t)PROF_N * b->B);
+  HIP_TRY(hipMemcpy(tmp.data(), b->d_prof, tmp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int k = 0; k < PROF_N; k++) { double s = 0; for (int e = 0; e < b->B; e++) s += (double)tmp[(size_t)k * b->B + e]; dst[k] = s / b->B; }
+  *n = PROF_N;
   return 0;
 }

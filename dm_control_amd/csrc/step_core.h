@@ -29,9 +29,15 @@
 
 #ifdef DMC_HOST_EMU
 #define DMC_DEV inline
+#define DMC_FN inline
+#define DMC_LDS
 #define DMC_WSYNC() ((void)0)
 #else
 #define DMC_DEV __device__ __forceinline__
+// out-of-line device functions (one copy of the code for all call sites) taking
+// explicitly LDS-qualified pointers so that they still compile to ds_* ops
+#define DMC_FN __device__ __attribute__((noinline))
+#define DMC_LDS __attribute__((address_space(3)))
 #define DMC_WSYNC()                                             \
   do {                                                          \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
@@ -41,6 +47,14 @@
 #endif
 
 namespace dmc {
+
+#if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
+#define DMC_PROF(id) do { long long t_ = (long long)__builtin_readcyclecounter(); prof_[id] += t_ - prof_last_; prof_last_ = t_; } while (0)
+#else
+#define DMC_PROF(id) ((void)0)
+#endif
+enum { PROF_LOAD = 0, PROF_KIN, PROF_COM, PROF_CRB, PROF_COLL, PROF_CONSTR, PROF_COMVEL, PROF_RNE, PROF_SENS, PROF_ACT,
+       PROF_ACC, PROF_SOL_INIT, PROF_SOL_GRAD, PROF_SOL_LS, PROF_SOL_UPD, PROF_EULER, PROF_TRAIL, PROF_STORE, PROF_N };
 
 // output selection bits (which derived arrays a launch writes back to HBM)
 enum {
@@ -54,11 +68,13 @@ enum {
 template <typename T>
 struct StepIO {
   int B;
-  T *qpos, *qvel, *ctrl, *qacc_warmstart, *qfrc_applied, *time;
+  T *qpos, *qvel, *ctrl, *qacc_warmstart, *qfrc_applied;
+  double* time;   // always fp64: 1000 x 0.01 s must not drift in fp32 batches
   T *sensordata, *xpos, *xquat, *xmat, *xipos, *geom_xpos, *geom_xmat;
   T *site_xpos, *site_xmat, *subtree_com, *qacc, *actuator_force, *qfrc_actuator;
   T *qfrc_bias, *qfrc_constraint, *contact_dist, *contact_pos, *contact_frame;
   int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
+  long long* prof;   // optional (DMC_PROFILE builds): (PROF_N, B) cycle counters
   T* debug;      // optional: (n_sr, ndebug) dump of the env scratch after forward
   int* debug_i;  // optional: (n_si, ndebug)
   int ndebug;
@@ -222,6 +238,72 @@ template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 }
 
 // ---------------------------------------------------------------------------
+// out-of-line LDS routines shared by several call sites
+// ---------------------------------------------------------------------------
+// in-place right-looking Cholesky of the lower triangle of A (n x n), same
+// operation order as the oracle's left-looking loop
+template <typename T, int LPE>
+DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
+  for (int k = 0; k < n; k++) {
+    T akk = A[k*n + k];
+    if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+    const T lkk = t_sqrt(akk);
+    DMC_WSYNC();
+    if (lane == 0) A[k*n + k] = lkk;
+    for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] / lkk;
+    DMC_WSYNC();
+    const int m = n - k - 1;
+    // trailing update A[i][j] -= L[i][k] L[j][k], k < j <= i: walk rows per lane
+    for (int i = k + 1 + lane; i < n; i += LPE) {
+      const T lik = A[i*n + k];
+      for (int j = k + 1; j <= i; j++) A[i*n + j] -= lik*A[j*n + k];
+    }
+    (void)m;
+    DMC_WSYNC();
+  }
+}
+// x = (L L')^-1 b (x may alias b)
+template <typename T, int LPE>
+DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b, int n, int lane) {
+  for (int i = lane; i < n; i += LPE) x[i] = b[i];
+  DMC_WSYNC();
+  for (int k = 0; k < n; k++) {
+    const T xk = x[k] / Lm[k*n + k];
+    DMC_WSYNC();
+    if (lane == 0) x[k] = xk;
+    for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[i*n + k]*xk;
+    DMC_WSYNC();
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    const T xk = x[k] / Lm[k*n + k];
+    DMC_WSYNC();
+    if (lane == 0) x[k] = xk;
+    for (int i = lane; i < k; i += LPE) x[i] -= Lm[k*n + i]*xk;
+    DMC_WSYNC();
+  }
+}
+// line-search evaluation: cost / derivatives of the piecewise quadratic at alpha
+template <typename T> struct LSPoint { T alpha, cost, d0, d1; };
+template <typename T, int LPE>
+DMC_FN void ls_eval_lds(LSPoint<T>* p, const DMC_LDS T* jar_, const DMC_LDS T* jv_, const DMC_LDS T* D_,
+                        T qg0, T qg1, T qg2, int nefc, int lane) {
+  const T a = p->alpha;
+  T q0 = 0, q1 = 0, q2 = 0;
+  for (int i = lane; i < nefc; i += LPE) {
+    const T jar = jar_[i], jv = jv_[i];
+    if (jar + a*jv < 0) {
+      const T D = D_[i], dj0 = D*jar;
+      q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+    }
+  }
+  q0 = group_sum<LPE>(q0) + qg0; q1 = group_sum<LPE>(q1) + qg1; q2 = group_sum<LPE>(q2) + qg2;
+  p->cost = a*a*q2 + a*q1 + q0;
+  p->d0 = 2*a*q2 + q1;
+  p->d1 = 2*q2;
+  if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+}
+
+// ---------------------------------------------------------------------------
 // the step
 // ---------------------------------------------------------------------------
 template <typename T, int LPE>
@@ -233,6 +315,10 @@ struct StepCore {
   T* s;
   int* si;
   int lane;
+  double time_;           // simulation time of this env (group-uniform)
+#ifdef DMC_PROFILE
+  long long prof_[24]; long long prof_last_;
+#endif
 
   DMC_DEV StepCore(const StepLayout& L_, const StepOpts<T>& o_, const int* mi_, const T* mr_, T* s_, int* si_, int lane_)
       : L(L_), o(o_), mi(mi_), mr(mr_), s(s_), si(si_), lane(lane_) {}
@@ -253,17 +339,17 @@ struct StepCore {
       S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;
     }
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
+    time_ = io.time[env];
     if (lane == 0) {
-      S(misc)[MISC_TIME] = io.time[env];
       for (int k = 0; k < 8; k++) SI(imisc)[IM_WARN + k] = 0;
       SI(imisc)[IM_NCON] = 0; SI(imisc)[IM_NEFC] = 0; SI(imisc)[IM_ITER] = 0;
       // world body
-      T* xp = S(xpos); T* xq = S(xquat); T* xm = S(xmat); T* xi = S(xipos); T* xim = S(ximat);
+      T* xp = S(xpos); T* xq = S(xquat); T* xm = S(xmat); T* xi = S(xipos);
       xp[0] = xp[1] = xp[2] = 0; xi[0] = xi[1] = xi[2] = 0;
       xq[0] = 1; xq[1] = xq[2] = xq[3] = 0;
-      for (int k = 0; k < 9; k++) xm[k] = xim[k] = (k % 4 == 0) ? (T)1 : (T)0;
-      for (int k = 0; k < 10; k++) { S(cinert)[k] = 0; S(crb)[k] = 0; }
-      for (int k = 0; k < 6; k++) { S(cvel)[k] = 0; S(cfrc)[k] = 0; }
+      for (int k = 0; k < 9; k++) xm[k] = (k % 4 == 0) ? (T)1 : (T)0;
+      for (int k = 0; k < 10; k++) S(cinert)[k] = 0;
+      for (int k = 0; k < 6; k++) S(cvel)[k] = 0;
     }
     FOR_LANES(i, L.d.nv * L.d.nv) { S(qM)[i] = 0; }
     FOR_LANES(i, L.d.nsensordata) S(sensordata)[i] = 0;
@@ -277,7 +363,7 @@ struct StepCore {
       io.qacc_warmstart[(size_t)i*B + env] = S(qacc_warmstart)[i];
     }
     if (lane == 0) {
-      io.time[env] = S(misc)[MISC_TIME];
+      io.time[env] = time_;
       for (int k = 0; k < 8; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
     }
     // ctrl may have been zeroed by a BADCTRL warning (mj_fwdActuation semantics)
@@ -318,8 +404,8 @@ struct StepCore {
       const int nc = SI(imisc)[IM_NCON];
       FOR_LANES(c, L.d.nconmax) {
         bool live = c < nc;
-        io.contact_geom1[(size_t)c*B + env] = live ? SI(con_geom1)[c] : -1;
-        io.contact_geom2[(size_t)c*B + env] = live ? SI(con_geom2)[c] : -1;
+        io.contact_geom1[(size_t)c*B + env] = live ? MI(pair_geom1)[SI(con_pair)[c]] : -1;
+        io.contact_geom2[(size_t)c*B + env] = live ? MI(pair_geom2)[SI(con_pair)[c]] : -1;
         io.contact_dist[(size_t)c*B + env] = live ? S(con_dist)[c] : (T)0;
         for (int k = 0; k < 3; k++) io.contact_pos[(size_t)(3*c + k)*B + env] = live ? S(con_pos)[3*c + k] : (T)0;
         for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? S(con_frame)[9*c + k] : (T)0;
@@ -453,43 +539,10 @@ struct StepCore {
     DMC_WSYNC();
   }
 
-  // ---- dense Cholesky / solves in LDS (same operation order as the oracle) -----
-  // in-place right-looking factorisation of the lower triangle of A (n x n)
-  DMC_DEV void chol_factor_inplace(T* A, int n) {
-    for (int k = 0; k < n; k++) {
-      T akk = A[k*n + k];
-      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-      const T lkk = t_sqrt(akk);
-      DMC_WSYNC();
-      if (lane == 0) A[k*n + k] = lkk;
-      for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] / lkk;
-      DMC_WSYNC();
-      const int m = n - k - 1;
-      for (int idx = lane; idx < m*m; idx += LPE) {
-        const int r = idx / m, c = idx - r*m;
-        if (c <= r) { const int i = k + 1 + r, j = k + 1 + c; A[i*n + j] -= A[i*n + k]*A[j*n + k]; }
-      }
-      DMC_WSYNC();
-    }
-  }
-  // x = (L L')^-1 b ; x and b may alias
+  // ---- dense Cholesky / solves in LDS (out-of-line: chol_factor_lds / chol_solve_lds) ----
+  DMC_DEV void chol_factor_inplace(T* A, int n) { chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane); }
   DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
-    FOR_LANES(i, n) x[i] = b[i];
-    DMC_WSYNC();
-    for (int k = 0; k < n; k++) {
-      const T xk = x[k] / Lm[k*n + k];
-      DMC_WSYNC();
-      if (lane == 0) x[k] = xk;
-      for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[i*n + k]*xk;
-      DMC_WSYNC();
-    }
-    for (int k = n - 1; k >= 0; k--) {
-      const T xk = x[k] / Lm[k*n + k];
-      DMC_WSYNC();
-      if (lane == 0) x[k] = xk;
-      for (int i = lane; i < k; i += LPE) x[i] -= Lm[k*n + i]*xk;
-      DMC_WSYNC();
-    }
+    chol_solve_lds<T, LPE>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, n, lane);
   }
 
   // ---- CRB mass matrix + factor (mj_crb, mj_factorM) ----------------------------
@@ -522,9 +575,9 @@ struct StepCore {
       S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v;
     }
     DMC_WSYNC();
-    FOR_LANES(i, nv*nv) S(qL)[i] = S(qM)[i];
+    FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
     DMC_WSYNC();
-    chol_factor_inplace(S(qL), nv);
+    chol_factor_inplace(S(qLH), nv);
   }
 
   // ---- collision (mj_collision over the static candidate pair list) -------------
@@ -672,11 +725,7 @@ struct StepCore {
         S(con_dist)[c] = h[i].dist;
         for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = h[i].pos[k];
         for (int k = 0; k < 9; k++) S(con_frame)[9*c + k] = f[k];
-        S(con_includemargin)[c] = MR(pair_margin)[p] - MR(pair_gap)[p];
-        for (int k = 0; k < 3; k++) S(con_friction)[3*c + k] = MR(pair_friction)[3*p + k];
-        for (int k = 0; k < 2; k++) S(con_solref)[2*c + k] = MR(pair_solref)[2*p + k];
-        for (int k = 0; k < 5; k++) S(con_solimp)[5*c + k] = MR(pair_solimp)[5*p + k];
-        SI(con_geom1)[c] = g1; SI(con_geom2)[c] = g2; SI(con_dim)[c] = MI(pair_dim)[p];
+        SI(con_pair)[c] = p;
         SI(con_efc)[c] = -1;
       }
       base += total;
@@ -736,7 +785,7 @@ struct StepCore {
         if (r >= njmax) { overflow = 1; continue; }
         for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
         S(efc_J)[r*nv + MI(jnt_dofadr)[j]] = -(T)side[i];
-        S(efc_pos)[r] = dist[i]; S(efc_margin)[r] = margin; SI(efc_type)[r] = EFC_LIMIT; SI(efc_id)[r] = j;
+        S(efc_aref)[r] = dist[i]; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, j);
       }
       nefc += total;
     }
@@ -747,10 +796,13 @@ struct StepCore {
     for (int c0 = 0; c0 < ncon; c0 += LPE) {
       const int c = c0 + lane;
       int nrow = 0, dim = 0;
+      T incl = 0;
       if (c < ncon) {
-        dim = SI(con_dim)[c];
+        const int p = SI(con_pair)[c];
+        dim = MI(pair_dim)[p];
+        incl = MR(pair_margin)[p] - MR(pair_gap)[p];
         nrow = dim == 1 ? 1 : 2*(dim - 1);
-        if (S(con_dist)[c] >= S(con_includemargin)[c]) nrow = 0;   // in the gap: excluded
+        if (S(con_dist)[c] >= incl) nrow = 0;   // in the gap: excluded
       }
       int total;
       const int off = nefc + group_scan<LPE>(nrow, lane, &total);
@@ -760,8 +812,8 @@ struct StepCore {
         else {
           SI(con_efc)[c] = off;
           for (int r = off; r < off + nrow; r++) {
-            S(efc_pos)[r] = S(con_dist)[c]; S(efc_margin)[r] = S(con_includemargin)[c];
-            SI(efc_type)[r] = dim == 1 ? EFC_FRICTIONLESS : EFC_PYRAMIDAL; SI(efc_id)[r] = c;
+            S(efc_aref)[r] = S(con_dist)[c]; S(efc_D)[r] = incl;
+            SI(efc_tid)[r] = EFC_TID(dim == 1 ? EFC_FRICTIONLESS : EFC_PYRAMIDAL, c);
           }
         }
       }
@@ -774,7 +826,7 @@ struct StepCore {
       // the limit rows if no contact fit).
       int last = nefc_lim;
       for (int c = lane; c < ncon; c += LPE) if (SI(con_efc)[c] >= 0) {
-        const int dim = SI(con_dim)[c]; const int e = SI(con_efc)[c] + (dim == 1 ? 1 : 2*(dim - 1));
+        const int dim = MI(pair_dim)[SI(con_pair)[c]]; const int e = SI(con_efc)[c] + (dim == 1 ? 1 : 2*(dim - 1));
         last = e > last ? e : last;
       }
       nefc = group_max<LPE>(last);
@@ -787,8 +839,9 @@ struct StepCore {
       const int c = idx / nv, dd = idx - c*nv;
       const int r0 = SI(con_efc)[c];
       if (r0 < 0) continue;
-      const int dim = SI(con_dim)[c];
-      const int b1 = MI(geom_bodyid)[SI(con_geom1)[c]], b2 = MI(geom_bodyid)[SI(con_geom2)[c]];
+      const int cp = SI(con_pair)[c];
+      const int dim = MI(pair_dim)[cp];
+      const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
       const bool in1 = dof_in_chain(MI(body_lastdof)[b1], dd), in2 = dof_in_chain(MI(body_lastdof)[b2], dd);
       T jac[6] = {0, 0, 0, 0, 0, 0};
       if (in1 || in2) {
@@ -812,7 +865,7 @@ struct StepCore {
       }
       if (dim == 1) S(efc_J)[r0*nv + dd] = jac[0];
       else for (int k = 1; k < dim; k++) {
-        const T f = S(con_friction)[3*c + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+        const T f = MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
         S(efc_J)[(r0 + 2*(k - 1))*nv + dd] = jac[0] + f*jac[k];
         S(efc_J)[(r0 + 2*(k - 1) + 1)*nv + dd] = jac[0] + (-f)*jac[k];
       }
@@ -821,29 +874,31 @@ struct StepCore {
     // per-row parameters: D, aref
     for (int i = lane; i < nefc; i += LPE) {
       const T *solref, *solimp; T dA, R;
-      const int type = SI(efc_type)[i], id = SI(efc_id)[i];
+      const int type = EFC_TYPE(SI(efc_tid)[i]), id = EFC_ID(SI(efc_tid)[i]);
+      const T pos = S(efc_aref)[i], margin = S(efc_D)[i];   // staged by the row headers above
       T mu = 0; T dA0 = 0;
       if (type == EFC_LIMIT) {
         solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
         dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
       } else {
-        const int b1 = MI(geom_bodyid)[SI(con_geom1)[id]], b2 = MI(geom_bodyid)[SI(con_geom2)[id]];
+        const int cp = SI(con_pair)[id];
+        const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
         const T tran = MR(body_invweight0)[2*b1] + MR(body_invweight0)[2*b2];
         const T rot = MR(body_invweight0)[2*b1 + 1] + MR(body_invweight0)[2*b2 + 1];
-        solref = S(con_solref) + 2*id; solimp = S(con_solimp) + 5*id;
+        solref = MR(pair_solref) + 2*cp; solimp = MR(pair_solimp) + 5*cp;
         if (type == EFC_FRICTIONLESS) dA = tran;
         else {
           const int j = i - SI(con_efc)[id];
           const int k = j/2;   // friction index 0,1: slide; 2: torsion; 3,4: roll
-          const T fri = S(con_friction)[3*id + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
+          const T fri = MR(pair_friction)[3*cp + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
           dA = tran + fri*fri*(j < 4 ? tran : rot);
-          mu = S(con_friction)[3*id];
+          mu = MR(pair_friction)[3*cp];
           dA0 = tran + mu*mu*tran;
         }
       }
       T ref0 = solref[0], ref1 = solref[1];
       if (!(o.disableflags & DMC_DSBL_REFSAFE) && ref0 > 0) ref0 = t_max(ref0, 2*o.timestep);
-      const T imp = get_impedance(solimp, S(efc_pos)[i], S(efc_margin)[i]);
+      const T imp = get_impedance(solimp, pos, margin);
       if (type == EFC_PYRAMIDAL) { const T R0 = t_max((T)DMC_MINVAL, (1 - imp)*dA0/imp); R = 2*mu*mu*R0; }
       else R = t_max((T)DMC_MINVAL, (1 - imp)*dA/imp);
       const T dmax = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, solimp[1]));
@@ -852,7 +907,7 @@ struct StepCore {
       else { K = -ref0 / t_max((T)DMC_MINVAL, dmax*dmax); Bd = -ref1 / t_max((T)DMC_MINVAL, dmax); }
       S(efc_D)[i] = 1 / R;
       const T vel = dot_n(S(efc_J) + i*nv, S(qvel), nv);
-      S(efc_aref)[i] = -Bd*vel - K*imp*(S(efc_pos)[i] - S(efc_margin)[i]);
+      S(efc_aref)[i] = -Bd*vel - K*imp*(pos - margin);
     }
     DMC_WSYNC();
   }
@@ -953,16 +1008,16 @@ struct StepCore {
       const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
       T dif[3] = {S(xipos)[3*i] - rc[0], S(xipos)[3*i + 1] - rc[1], S(xipos)[3*i + 2] - rc[2]}, tmp[3];
       cross3(tmp, dif, S(cvel) + 6*i);
-      for (int k = 0; k < 3; k++) S(subtree_usum)[3*i + k] = MR(body_mass)[i] * (S(cvel)[6*i + 3 + k] - tmp[k]);
+      for (int k = 0; k < 3; k++) S(subtree_mom)[3*i + k] = MR(body_mass)[i] * (S(cvel)[6*i + 3 + k] - tmp[k]);
     }
     DMC_WSYNC();
     for (int lev = L.d.nlevel - 1; lev >= -1; lev--) {
       const int a0 = lev >= 0 ? MI(level_adr)[lev] : 0, cnt = lev >= 0 ? MI(level_adr)[lev + 1] - a0 : 1;
       for (int idx = lane; idx < cnt*3; idx += LPE) {
         const int b = lev >= 0 ? MI(level_body)[a0 + idx/3] : 0, comp = idx % 3;
-        T v = S(subtree_usum)[3*b + comp];
-        for (int c = MI(child_adr)[b]; c < MI(child_adr)[b + 1]; c++) v += S(subtree_usum)[3*MI(child_list)[c] + comp];
-        S(subtree_usum)[3*b + comp] = v;
+        T v = S(subtree_mom)[3*b + comp];
+        for (int c = MI(child_adr)[b]; c < MI(child_adr)[b + 1]; c++) v += S(subtree_mom)[3*MI(child_list)[c] + comp];
+        S(subtree_mom)[3*b + comp] = v;
         S(subtree_linvel)[3*b + comp] = v * (1 / t_max((T)DMC_MINVAL, MR(body_subtreemass)[b]));
       }
       DMC_WSYNC();
@@ -1047,7 +1102,7 @@ struct StepCore {
   DMC_DEV void fwd_acceleration() {
     FOR_LANES(i, L.d.nv) S(qfrc_smooth)[i] = S(qfrc_passive)[i] - S(qfrc_bias)[i] + S(qfrc_applied)[i] + S(qfrc_actuator)[i];
     DMC_WSYNC();
-    chol_solve(S(qacc_smooth), S(qL), S(qfrc_smooth), L.d.nv);
+    chol_solve(S(qacc_smooth), S(qLH), S(qfrc_smooth), L.d.nv);
   }
 
   // ---- Newton solver on the primal (mj_fwdConstraint / mj_solNewton) -----------------
@@ -1056,8 +1111,8 @@ struct StepCore {
     T cost = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const T jar = S(efc_jar)[i];
-      if (jar < 0) { SI(efc_state)[i] = 1; S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
-      else { SI(efc_state)[i] = 0; S(efc_force)[i] = 0; }
+      if (jar < 0) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
+      else S(efc_force)[i] = 0;
     }
     cost = group_sum<LPE>(cost);
     DMC_WSYNC();
@@ -1093,32 +1148,20 @@ struct StepCore {
       const int i = idx / nv, j = idx - i*nv;
       if (j > i) continue;
       T h = S(qM)[i*nv + j];
-      for (int r = 0; r < nefc; r++) if (SI(efc_state)[r]) {
+      for (int r = 0; r < nefc; r++) if (S(efc_jar)[r] < 0) {
         const T ji = S(efc_J)[r*nv + i];
         if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
       }
-      S(qH)[i*nv + j] = h;
+      S(qLH)[i*nv + j] = h;
     }
     DMC_WSYNC();
-    chol_factor_inplace(S(qH), nv);
-    chol_solve(S(sv_Mgrad), S(qH), S(sv_grad), nv);
+    chol_factor_inplace(S(qLH), nv);
+    chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
   }
-  struct LSPoint { T alpha, cost, d0, d1; };
+  typedef dmc::LSPoint<T> LSPoint;
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
-    const T a = p->alpha;
-    T q0 = 0, q1 = 0, q2 = 0;
-    for (int i = lane; i < nefc; i += LPE) {
-      const T jar = S(efc_jar)[i], jv = S(efc_jv)[i];
-      if (jar + a*jv < 0) {
-        const T D = S(efc_D)[i], dj0 = D*jar;
-        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
-      }
-    }
-    q0 = group_sum<LPE>(q0) + qg[0]; q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
-    p->cost = a*a*q2 + a*q1 + q0;
-    p->d0 = 2*a*q2 + q1;
-    p->d1 = 2*q2;
-    if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+    ls_eval_lds<T, LPE>(p, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv), (const DMC_LDS T*)S(efc_D),
+                        qg[0], qg[1], qg[2], nefc, lane);
     (*evals)++;
   }
   DMC_DEV int ls_update_bracket(LSPoint* p, const LSPoint* cand, LSPoint* pnext, const T* qg, int nefc, int* evals) {
@@ -1206,12 +1249,15 @@ struct StepCore {
     T cc = constraint_update(nefc);
     T gauss = gauss_cost();
     T cost = cc + gauss;
+    DMC_PROF(PROF_SOL_INIT);
     newton_gradient(nefc);
     FOR_LANES(i, nv) S(sv_search)[i] = -S(sv_Mgrad)[i];
     DMC_WSYNC();
+    DMC_PROF(PROF_SOL_GRAD);
     int iter = 0;
     while (iter < o.iterations) {
       const T alpha = primal_search(nefc, gauss, scale);
+      DMC_PROF(PROF_SOL_LS);
       if (alpha == 0) break;
       FOR_LANES(i, nv) { S(qacc)[i] += alpha*S(sv_search)[i]; S(sv_Ma)[i] += alpha*S(sv_Mv)[i]; }
       for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
@@ -1220,19 +1266,28 @@ struct StepCore {
       cc = constraint_update(nefc);
       gauss = gauss_cost();
       cost = cc + gauss;
+      DMC_PROF(PROF_SOL_UPD);
       newton_gradient(nefc);
-      T g2 = 0;
-      FOR_LANES(i, nv) { S(sv_search)[i] = -S(sv_Mgrad)[i]; g2 += S(sv_grad)[i]*S(sv_grad)[i]; }
-      g2 = group_sum<LPE>(g2);
+      DMC_PROF(PROF_SOL_GRAD);
+      T g2 = 0, ma2 = 0;
+      FOR_LANES(i, nv) { S(sv_search)[i] = -S(sv_Mgrad)[i]; g2 += S(sv_grad)[i]*S(sv_grad)[i]; ma2 += S(sv_Ma)[i]*S(sv_Ma)[i]; }
+      g2 = group_sum<LPE>(g2); ma2 = group_sum<LPE>(ma2);
       DMC_WSYNC();
       const T improvement = scale*(oldcost - cost), gradient = scale*t_sqrt(g2);
       iter++;
-      if (improvement < o.tolerance || gradient < o.tolerance) break;
+      // MuJoCo's criteria, floored at what the arithmetic can resolve: a cost
+      // change below ~8 ulp of the cost (or a gradient below ~8 ulp of |M a|) is
+      // rounding noise.  For fp64 the floor is far below `tolerance` (no-op).
+      const T eps8 = 8 * (sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16);
+      const T tol_imp = t_max(o.tolerance, eps8*scale*t_abs(cost));
+      const T tol_grad = t_max(o.tolerance, eps8*scale*t_sqrt(ma2));
+      if (improvement < tol_imp || gradient < tol_grad) break;
     }
     constraint_force_to_joint(nefc);
     FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
     DMC_WSYNC();
+    DMC_PROF(PROF_SOL_UPD);
   }
 
   // ---- integration (mj_Euler with implicit joint damping) ---------------------------------
@@ -1241,13 +1296,13 @@ struct StepCore {
     const T dt = o.timestep;
     const T* qacc = S(qacc);
     if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {
-      FOR_LANES(i, nv*nv) S(qH)[i] = S(qM)[i];
+      FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
       DMC_WSYNC();
-      FOR_LANES(i, nv) S(qH)[i*nv + i] += dt*MR(dof_damping)[i];
+      FOR_LANES(i, nv) S(qLH)[i*nv + i] += dt*MR(dof_damping)[i];
       DMC_WSYNC();
-      chol_factor_inplace(S(qH), nv);
-      chol_solve(S(sv_Mgrad), S(qH), S(sv_grad), nv);
+      chol_factor_inplace(S(qLH), nv);
+      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
       qacc = S(sv_Mgrad);
     }
     FOR_LANES(i, nv) S(qvel)[i] += dt*qacc[i];
@@ -1269,7 +1324,7 @@ struct StepCore {
         for (int k = 0; k < 4; k++) S(qpos)[qa + k] = q[k];
       } else S(qpos)[qa] += dt*S(qvel)[da];
     }
-    if (lane == 0) S(misc)[MISC_TIME] += dt;
+    time_ += o.timestep_d;
     DMC_WSYNC();
   }
 
@@ -1278,7 +1333,7 @@ struct StepCore {
     FOR_LANES(i, L.d.nq) S(qpos)[i] = MR(qpos0)[i];
     FOR_LANES(i, L.d.nv) { S(qvel)[i] = 0; S(qacc_warmstart)[i] = 0; S(qfrc_applied)[i] = 0; }
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = 0;
-    if (lane == 0) S(misc)[MISC_TIME] = 0;
+    time_ = 0;
     DMC_WSYNC();
   }
   DMC_DEV void check_pos_vel() {
@@ -1297,41 +1352,63 @@ struct StepCore {
   }
 
   // ---- pipeline -----------------------------------------------------------------------------
-  DMC_DEV void fwd_position() { kinematics(); com_pos(); crb_mass_matrix(); collision(); make_constraint(); }
-  DMC_DEV void forward(bool disable_actuation) {
-    fwd_position(); sensors(DMC_STAGE_POS);
-    com_vel(); passive_and_rne(); sensors(DMC_STAGE_VEL);
-    fwd_actuation(disable_actuation); fwd_acceleration(); fwd_constraint();
-    sensors(DMC_STAGE_ACC);
+  // One pass of the pipeline.  partial = the trailing mj_step1 of a legacy
+  // Physics.step(): position + velocity stage for the outputs only.
+  DMC_DEV void forward(bool disable_actuation, bool partial, int outmask) {
+    kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM);
+    if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
+    if (!partial || (outmask & OUT_CONTACT)) { collision(); DMC_PROF(PROF_COLL); }
+    if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); }
+    sensors(DMC_STAGE_POS); DMC_PROF(PROF_SENS);
+    com_vel(); DMC_PROF(PROF_COMVEL);
+    if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); }
+    sensors(DMC_STAGE_VEL); DMC_PROF(PROF_SENS);
+    if (!partial) {
+      fwd_actuation(disable_actuation); DMC_PROF(PROF_ACT); fwd_acceleration(); DMC_PROF(PROF_ACC); fwd_constraint();
+      sensors(DMC_STAGE_ACC); DMC_PROF(PROF_SENS);
+    }
   }
-  // mj_step1 outputs for the state after the last integration (legacy_step)
-  DMC_DEV void trailing_step1() {
-    check_pos_vel();
-    kinematics(); com_pos(); collision(); sensors(DMC_STAGE_POS);
-    com_vel(); sensors(DMC_STAGE_VEL);
+  DMC_DEV void prof_begin() {
+#if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
+    for (int k = 0; k < 24; k++) prof_[k] = 0;
+    prof_last_ = (long long)__builtin_readcyclecounter();
+#endif
+  }
+  DMC_DEV void prof_end(const StepIO<T>& io, int env) {
+#if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
+    if (io.prof && lane == 0) for (int k = 0; k < PROF_N; k++) io.prof[(size_t)k*io.B + env] += prof_[k];
+#else
+    (void)io; (void)env;
+#endif
   }
   // mode: 0 = Physics.step(nstep) ; 1 = mj_forward ; 2 = mj_forward with actuation disabled
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask) {
+    prof_begin();
     load_state(io, env);
-    if (mode != 0) {
-      forward(mode == 2);
-      dump_debug(io, env);
-      store_outputs(io, env, outmask);
-      store_state(io, env);
-      return;
-    }
-    for (int it = 0; it < nstep; it++) {
-      check_pos_vel();
-      forward(false);
-      if (bad_acc()) {
-        if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;
-        if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); forward(false); }
+    DMC_PROF(PROF_LOAD);
+    // passes through the single forward() call site: nstep full passes (+ the
+    // trailing mj_step1 pass for legacy_step), or one full pass for mj_forward
+    const int npass = mode != 0 ? 1 : nstep + (legacy ? 1 : 0);
+    for (int it = 0; it < npass; it++) {
+      const bool partial = mode == 0 && it == nstep;
+      if (mode == 0) check_pos_vel();
+      for (int attempt = 0; attempt < 2; attempt++) {
+        forward(mode == 2, partial, outmask);
+        if (partial || mode != 0 || attempt == 1 || !bad_acc()) break;
+        if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
+        if (o.disableflags & DMC_DSBL_AUTORESET) break;
+        DMC_WSYNC(); reset_state();
       }
+      if (mode != 0 || partial) break;
       if (it == nstep - 1) { dump_debug(io, env); if (!legacy) store_outputs(io, env, outmask); }
       euler();
+      DMC_PROF(PROF_EULER);
     }
-    if (legacy) { trailing_step1(); store_outputs(io, env, outmask); }
+    if (mode != 0) dump_debug(io, env);
+    if (mode != 0 || legacy) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
     store_state(io, env);
+    DMC_PROF(PROF_STORE);
+    prof_end(io, env);
   }
 #undef MI
 #undef MR

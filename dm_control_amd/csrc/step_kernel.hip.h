@@ -16,8 +16,12 @@ struct LaunchGeom {
   int grid;            // workgroups
 };
 
+#ifndef DMC_MIN_WAVES
+#define DMC_MIN_WAVES 2   // waves per SIMD the register allocator must leave room for
+#endif
+
 template <typename T, int LPE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
             StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -60,37 +60,44 @@ struct StepDims {
   X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
 
 // ---- per-environment scratch (reals) -------------------------------------------
+// Persistent arrays (live across the whole substep) ...
 #define STEP_SCRATCH_REAL(X)                                                   \
   X(qpos, d.nq) X(qvel, d.nv) X(ctrl, d.nu) X(qacc_warmstart, d.nv)            \
   X(qfrc_applied, d.nv)                                                        \
   X(xpos, 3 * d.nbody) X(xquat, 4 * d.nbody) X(xmat, 9 * d.nbody)              \
-  X(xipos, 3 * d.nbody) X(ximat, 9 * d.nbody)                                  \
-  X(xanchor, 3 * d.njnt) X(xaxis, 3 * d.njnt)                                  \
+  X(xipos, 3 * d.nbody)                                                        \
   X(geom_xpos, 3 * d.ngeom) X(geom_xmat, 9 * d.ngeom)                          \
-  X(subtree_com, 3 * d.nbody) X(subtree_usum, 3 * d.nbody)                     \
-  X(cinert, 10 * d.nbody) X(crb, 10 * d.nbody)                                 \
-  X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv) X(mbuf, 6 * d.nv)                    \
-  X(cvel, 6 * d.nbody) X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody)               \
-  X(qM, d.nv * d.nv) X(qL, d.nv * d.nv) X(qH, d.nv * d.nv)                     \
+  X(subtree_com, 3 * d.nbody)                                                  \
+  X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cvel, 6 * d.nbody)               \
+  X(qM, d.nv * d.nv) X(qLH, d.nv * d.nv)  /* Cholesky of M, later of H / M+hB */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
-  X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
-  X(sv_search, d.nv) X(sv_tmp, d.nv)                                           \
   X(subtree_linvel, 3 * d.nbody) X(sensordata, d.nsensordata)                  \
   X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, 9 * d.nconmax) \
-  X(con_includemargin, d.nconmax) X(con_friction, 3 * d.nconmax)               \
-  X(con_solref, 2 * d.nconmax) X(con_solimp, 5 * d.nconmax)                    \
-  X(efc_J, d.njmax * d.nv) X(efc_pos, d.njmax) X(efc_margin, d.njmax)          \
-  X(efc_D, d.njmax) X(efc_aref, d.njmax) X(efc_jar, d.njmax)                   \
-  X(efc_jv, d.njmax) X(efc_force, d.njmax)                                     \
+  X(efc_J, d.njmax * d.nv)                                                     \
+  X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
+  X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
+  X(efc_force, d.njmax)                                                        \
   X(misc, 16)
+// ... followed by ONE region shared by three overlays whose lifetimes do not
+// intersect: position-stage temporaries, velocity-stage temporaries, solver.
+#define STEP_SCRATCH_OVL_POS(X)                                                \
+  X(ximat, 9 * d.nbody) X(xanchor, 3 * d.njnt) X(xaxis, 3 * d.njnt)            \
+  X(crb, 10 * d.nbody) X(mbuf, 6 * d.nv) X(subtree_usum, 3 * d.nbody)
+#define STEP_SCRATCH_OVL_VEL(X)                                                \
+  X(cdof_dot, 6 * d.nv) X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody)              \
+  X(subtree_mom, 3 * d.nbody)
+#define STEP_SCRATCH_OVL_SOL(X)                                                \
+  X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
+  X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)
+#define STEP_SCRATCH_ALL_REAL(X) \
+  STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 
 // ---- per-environment scratch (ints) --------------------------------------------
 #define STEP_SCRATCH_INT(X)                                                    \
-  X(con_geom1, d.nconmax) X(con_geom2, d.nconmax) X(con_dim, d.nconmax)        \
-  X(con_efc, d.nconmax)                                                        \
-  X(efc_type, d.njmax) X(efc_id, d.njmax) X(efc_state, d.njmax)                \
+  X(con_pair, d.nconmax) X(con_efc, d.nconmax)                                 \
+  X(efc_tid, d.njmax)   /* (id << 2) | type */                                 \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch
@@ -100,6 +107,9 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..10: 8 warning cou
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8 };
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2 };
+#define EFC_TID(type, id) (((id) << 2) | (type))
+#define EFC_TYPE(tid) ((tid) & 3)
+#define EFC_ID(tid) ((tid) >> 2)
 
 struct StepLayout {
   StepDims d;
@@ -111,7 +121,7 @@ struct StepLayout {
   STEP_MODEL_REAL_TABLES(X)
 #undef X
 #define X(name, cnt) int s_##name;
-  STEP_SCRATCH_REAL(X)
+  STEP_SCRATCH_ALL_REAL(X)
 #undef X
 #define X(name, cnt) int si_##name;
   STEP_SCRATCH_INT(X)
@@ -126,6 +136,7 @@ struct StepOpts {
   T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
   int integrator, cone, iterations, ls_iterations, disableflags;
   int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
+  double timestep_d; // fp64 copy for the time accumulator
 };
 
 static inline void step_layout_build(StepLayout* L, const StepDims& d) {
@@ -144,6 +155,22 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #define X(name, cnt) L->s_##name = o; o += (cnt);
   STEP_SCRATCH_REAL(X)
 #undef X
+  {
+    const int base = o;
+    int top = base;
+    o = base;
+#define X(name, cnt) L->s_##name = o; o += (cnt);
+    STEP_SCRATCH_OVL_POS(X)
+    if (o > top) top = o;
+    o = base;
+    STEP_SCRATCH_OVL_VEL(X)
+    if (o > top) top = o;
+    o = base;
+    STEP_SCRATCH_OVL_SOL(X)
+    if (o > top) top = o;
+#undef X
+    o = top;
+  }
   L->n_sr = (o + 3) & ~3;
   o = 0;
 #define X(name, cnt) L->si_##name = o; o += (cnt);
@@ -158,7 +185,7 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 static inline int step_layout_find(const StepLayout* L, const char* name, int* off, int* cnt, int* kind) {
   const StepDims& d = L->d;
 #define X(n, c) if (!strcmp(name, #n)) { *off = L->s_##n; *cnt = (c); *kind = 0; return 1; }
-  STEP_SCRATCH_REAL(X)
+  STEP_SCRATCH_ALL_REAL(X)
 #undef X
 #define X(n, c) if (!strcmp(name, #n)) { *off = L->si_##n; *cnt = (c); *kind = 1; return 1; }
   STEP_SCRATCH_INT(X)

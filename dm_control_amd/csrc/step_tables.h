@@ -121,7 +121,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   t->max_contacts = maxc; t->max_rows = maxr + nlim;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : 2*(pdim[p] - 1));
-  if (nconmax <= 0) nconmax = std::min(maxc, 24);
+  if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
   if (njmax <= 0) njmax = nlim + nconmax * maxrow_per_contact;
   njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim)));
@@ -228,7 +228,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (!ok) { *err = "sensor type not implemented"; return false; }
   }
   StepOpts<double>& o = t->opts;
-  o.timestep = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;
+  o.timestep = m.opt_timestep; o.timestep_d = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;
   o.impratio = m.opt_impratio; o.tolerance = m.opt_tolerance; o.ls_tolerance = m.opt_ls_tolerance;
   o.meaninertia = m.stat_meaninertia;
   o.integrator = m.opt_integrator; o.cone = m.opt_cone; o.iterations = m.opt_iterations;
@@ -245,7 +245,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.impratio = (T)s.impratio; o.tolerance = (T)s.tolerance; o.ls_tolerance = (T)s.ls_tolerance;
   o.meaninertia = (T)s.meaninertia; o.integrator = s.integrator; o.cone = s.cone;
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
-  o.any_damping = s.any_damping;
+  o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
   return o;
 }
 

@@ -10,7 +10,8 @@
  *
  * Memory model: one dmc_batch owns B environments on ONE GPU.  Every mjData
  * array is stored structure-of-arrays across the batch: element k of env e of
- * field F lives at F_dev[k * B + e] (dtype = batch precision, ints int32).
+ * field F lives at F_dev[k * B + e] (dtype = batch precision, ints int32;
+ * "time" is always float64).
  */
 #ifndef DMC_BATCH_H_
 #define DMC_BATCH_H_
@@ -36,7 +37,7 @@ void dmc_model_destroy(dmc_model* m);
 /* Replaces mujoco.MjData(model) (wrapper/core.py:475), B times.
  * precision: 32 or 64.  nconmax/njmax: per-env contact / constraint-row caps
  * (0 = automatic); exceeding them raises mjWARN_CONTACTFULL / mjWARN_CNSTRFULL
- * counters like MuJoCo's own caps.  lanes_per_env: 64, 32 or 16 (0 = 64). */
+ * counters like MuJoCo's own caps.  lanes_per_env: 64, 32 or 16 (0 = automatic: 32 for nv <= 12, else 64). */
 int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
                      int nconmax, int njmax, int lanes_per_env, dmc_batch** out);
 void dmc_batch_destroy(dmc_batch* b);
@@ -99,6 +100,12 @@ int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, voi
  * the last substep; read arrays back by scratch name (step_layout.h). */
 int dmc_batch_debug_enable(dmc_batch* b, int n);
 int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int env, double* dst, int* count);
+
+/* Per-phase shader-cycle profile of the fused kernel (libraries built with
+ * -DDMC_PROFILE only; otherwise enable fails).  dst[k] = mean cycles per env of
+ * phase k (order: step_core.h PROF_*), accumulated since enable. */
+int dmc_batch_prof_enable(dmc_batch* b, int enable);
+int dmc_batch_prof_get(dmc_batch* b, double* dst, int* n);
 
 #ifdef __cplusplus
 }

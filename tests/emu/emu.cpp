@@ -58,7 +58,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   StepIO<T> io;
   io.B = 1;
   io.qpos = buf[0].data(); io.qvel = buf[1].data(); io.ctrl = buf[2].data(); io.qacc_warmstart = buf[3].data();
-  io.qfrc_applied = buf[4].data(); io.time = buf[5].data();
+  io.qfrc_applied = buf[4].data(); double tm = f[5][0]; io.time = &tm; io.prof = nullptr;
   io.sensordata = buf[6].data(); io.xpos = buf[7].data(); io.xquat = buf[8].data(); io.xmat = buf[9].data();
   io.xipos = buf[10].data(); io.geom_xpos = buf[11].data(); io.geom_xmat = buf[12].data();
   io.site_xpos = buf[13].data(); io.site_xmat = buf[14].data(); io.subtree_com = buf[15].data();
@@ -70,6 +70,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   StepCore<T, 1> core(L, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
   core.run(io, 0, nstep, legacy, mode, OUT_ALL);
   for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
+  f[5][0] = tm;
   if (dbg) { for (int i = 0; i < L.n_sr; i++) dbg[i] = (double)dbuf[i]; for (int i = 0; i < L.n_si; i++) dbgi[i] = dibuf[i]; }
 }
 extern "C" {
