@@ -42,8 +42,7 @@ def parse():
   ap.add_argument('--parity-envs', type=int, default=32)
   ap.add_argument('--parity-steps', type=int, default=200)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-envs', type=int, default=256)
-  ap.add_argument('--cpu-steps', type=int, default=500)
+  ap.add_argument('--cpu-envs', type=int, default=4096)
   return ap.parse_args()
 
 
@@ -63,33 +62,39 @@ def initial_qpos(model, n, seed0):
   return q
 
 
-def cpu_baseline(model, q0, actions, nthreads):
+def cpu_baseline(model, q0, action_fn, nthreads, target_s=8.0, max_steps=1000):
   """Times the fp64 oracle (oracle/, test infrastructure) on host cores over a
-  bounded sample of the same workload.  kind = 'port' (MuJoCo itself is absent)."""
+  bounded sample of the same workload (~target_s seconds of wall clock on all
+  host cores).  kind = 'port': MuJoCo itself is not installable here."""
   from concurrent.futures import ThreadPoolExecutor
   from oracle import oracle
-  T, B = actions.shape[0], actions.shape[1]
+  B = q0.shape[0]
   phys = []
   for e in range(B):
     p = oracle.OraclePhysics(model)
     p.qpos[:] = q0[e]
     p.forward()
     phys.append(p)
-  zero = np.zeros((200, B, model.nu))
   shards = [list(range(i, B, nthreads)) for i in range(nthreads)]
+  shards = [s for s in shards if s]
 
   def run(acts):
     def work(idx):
       oracle.rollout_legacy([phys[i] for i in idx], np.ascontiguousarray(acts[:, idx]))
-    with ThreadPoolExecutor(nthreads) as ex:
+    with ThreadPoolExecutor(len(shards)) as ex:
       list(ex.map(work, shards))
-  run(zero)   # settle (untimed)
+  run(np.zeros((200, B, model.nu)))   # settle (untimed)
   t0 = time.time()
-  run(actions)
+  run(action_fn(0, 20))               # calibration chunk
+  rate = 20 * B / max(time.time() - t0, 1e-6)
+  T = int(min(max_steps, max(50, target_s * rate / B)))
+  acts = action_fn(20, T)
+  t0 = time.time()
+  run(acts)
   dt = time.time() - t0
-  return dict(value=T * B / dt, unit='env-steps/s', cores=nthreads, kind='port',
-              sample='%d envs x %d steps, fp64 C restatement of mj_step (oracle/), %d threads, %.1f s'
-                     % (B, T, nthreads, dt)), phys
+  return dict(value=T * B / dt, unit='env-steps/s', cores=len(shards), kind='port',
+              sample='%d envs x %d steps (%.1f s wall), fp64 C restatement of mj_step (oracle/), one thread per core'
+                     % (B, T, dt))
 
 
 def main():
@@ -211,8 +216,10 @@ def main():
       try:
         nthreads = os.cpu_count() or 1
         nb = min(args.cpu_envs, B)
-        acts = actions_host[W:W + min(args.cpu_steps, K), :nb].astype(np.float64)
-        cb, _ = cpu_baseline(model, q0[:nb], acts, nthreads)
+
+        def action_fn(t0, n):
+          return np.random.RandomState(99 + t0).uniform(-1, 1, (n, nb, model.nu))
+        cb = cpu_baseline(model, q0[:nb], action_fn, nthreads)
         out['cpu_baseline'] = cb
       except Exception as ex:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'value': None, 'error': repr(ex)}

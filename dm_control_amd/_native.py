@@ -33,6 +33,13 @@ def lib():
     raise NativeError(
         'libdmc_hip.so not built: run `python -m dm_control_amd.build` '
         '(or __graft_entry__.build()).  There is no CPU fallback.')
+  # PyTorch-ROCm bundles its own HIP runtime; load it first so that this library
+  # and torch share ONE libamdhip64 (two runtimes in a process cannot both see
+  # the GPU).  torch is only plumbing here (device memory, streams, RCCL).
+  try:
+    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  except ImportError:
+    pass
   L = ctypes.CDLL(LIB_PATH)
   vp, ci, cd, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_char_p
   L.dmc_last_error.restype = cs
