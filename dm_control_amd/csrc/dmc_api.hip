@@ -323,7 +323,11 @@ extern "C" int dmc_batch_set_output_mask(dmc_batch* b, int mask) {
 extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) {
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
-  if (!strcmp(name, "disableflags")) o.disableflags = value;
+  if (!strcmp(name, "disableflags")) {
+    if (b->tb.has_unsupported_pairs && !(value & DMC_DSBL_CONTACT))
+      return fail("cannot enable contacts: the model has geom pair types the collision kernel does not implement");
+    o.disableflags = value;
+  }
   else if (!strcmp(name, "iterations")) o.iterations = value;
   else if (!strcmp(name, "ls_iterations")) o.ls_iterations = value;
   else return fail(std::string("unknown int option: ") + name);

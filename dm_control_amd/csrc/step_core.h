@@ -1031,6 +1031,185 @@ struct StepCore {
     T lin[3] = {cv[3] - tmp[0], cv[4] - tmp[1], cv[5] - tmp[2]};
     mul_matT_vec3(res, mat, cv); mul_matT_vec3(res + 3, mat, lin);
   }
+  // ---- acceleration-stage support: contact wrench, mj_rnePostConstraint, touch rays --------
+  // contact force in the contact frame [normal, tangent1, tangent2, torsion, roll1, roll2]
+  DMC_DEV void contact_force_local(int c, T* f6) {
+    for (int k = 0; k < 6; k++) f6[k] = 0;
+    const int r0 = SI(con_efc)[c];
+    if (r0 < 0) return;
+    const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
+    const T* f = S(efc_force) + r0;
+    if (dim == 1) { f6[0] = f[0]; return; }
+    for (int k = 0; k < 2*(dim - 1); k++) f6[0] += f[k];
+    for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+  }
+  DMC_DEV void rne_post_constraint() {
+    const int nb = L.d.nbody, ncon = SI(imisc)[IM_NCON];
+    // external (contact) wrench per body, contacts visited in index order
+    FOR_LANES(b, nb) {
+      T acc[6] = {0, 0, 0, 0, 0, 0};
+      if (b > 0) for (int c = 0; c < ncon; c++) {
+        if (SI(con_efc)[c] < 0) continue;
+        const int cp = SI(con_pair)[c];
+        const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+        if (b1 != b && b2 != b) continue;
+        T lf[6], gf[3], gt[3], dif[3], t[3];
+        contact_force_local(c, lf);
+        mul_matT_vec3(gf, S(con_frame) + 9*c, lf); mul_matT_vec3(gt, S(con_frame) + 9*c, lf + 3);
+        const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
+        for (int k = 0; k < 3; k++) dif[k] = S(con_pos)[3*c + k] - rc[k];
+        cross3(t, dif, gf);
+        if (b1 == b) for (int k = 0; k < 3; k++) { acc[k] += -(gt[k] + t[k]); acc[3 + k] += -gf[k]; }
+        if (b2 == b) for (int k = 0; k < 3; k++) { acc[k] += (gt[k] + t[k]); acc[3 + k] += gf[k]; }
+      }
+      for (int k = 0; k < 6; k++) S(cfrc_ext)[6*b + k] = acc[k];
+    }
+    if (lane == 0) {
+      T* ca = S(cacc);
+      ca[0] = ca[1] = ca[2] = 0; ca[3] = ca[4] = ca[5] = 0;
+      if (!(o.disableflags & DMC_DSBL_GRAVITY)) { ca[3] = -o.gravity[0]; ca[4] = -o.gravity[1]; ca[5] = -o.gravity[2]; }
+      for (int k = 0; k < 6; k++) S(cfrc)[k] = 0;
+    }
+    DMC_WSYNC();
+    for (int lev = 0; lev < L.d.nlevel; lev++) {
+      const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
+      for (int kk = a0 + lane; kk < a1; kk += LPE) {
+        const int i = MI(level_body)[kk], bda = MI(body_dofadr)[i];
+        T csum[6], tmp[6], tmp1[6], tmp2[6];
+        for (int a = 0; a < 6; a++) csum[a] = S(cacc)[6*MI(body_parentid)[i] + a];
+        for (int k = 0; k < MI(body_dofnum)[i]; k++) for (int a = 0; a < 6; a++)
+          csum[a] += S(cdof_dot)[6*(bda + k) + a]*S(qvel)[bda + k] + S(cdof)[6*(bda + k) + a]*S(qacc)[bda + k];
+        for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = csum[a];
+        mul_inert_vec(tmp, S(cinert) + 10*i, csum);
+        mul_inert_vec(tmp1, S(cinert) + 10*i, S(cvel) + 6*i);
+        cross_force(tmp2, S(cvel) + 6*i, tmp1);
+        for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = tmp[a] + tmp2[a] - S(cfrc_ext)[6*i + a];
+      }
+      DMC_WSYNC();
+    }
+    for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
+      const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
+      for (int idx = lane; idx < cnt*6; idx += LPE) {
+        const int b = MI(level_body)[a0 + idx/6], comp = idx % 6;
+        const int c0 = MI(child_adr)[b], c1 = MI(child_adr)[b + 1];
+        if (c1 > c0) {
+          T v = S(cfrc)[6*b + comp];
+          for (int c = c0; c < c1; c++) v += S(cfrc)[6*MI(child_list)[c] + comp];
+          S(cfrc)[6*b + comp] = v;
+        }
+      }
+      DMC_WSYNC();
+    }
+  }
+  // ray (pnt, vec) against a site volume in its own frame; distance or -1
+  DMC_DEV static T ray_geom(const T* pos, const T* mat, const T* size, const T* pnt, const T* vec, int type) {
+    T dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, lp[3], lv[3];
+    mul_matT_vec3(lp, mat, dif); mul_matT_vec3(lv, mat, vec);
+    T best = -1;
+    if (type == DMC_GEOM_SPHERE || type == DMC_GEOM_CAPSULE) {
+      const T r = size[0];
+      const int nparts = type == DMC_GEOM_CAPSULE ? 3 : 1;
+      for (int part = 0; part < nparts; part++) {
+        T a, b, c;
+        if (type == DMC_GEOM_CAPSULE && part == 0) {
+          a = lv[0]*lv[0] + lv[1]*lv[1]; b = lp[0]*lv[0] + lp[1]*lv[1]; c = lp[0]*lp[0] + lp[1]*lp[1] - r*r;
+        } else {
+          const T cz = type == DMC_GEOM_CAPSULE ? (part == 1 ? size[1] : -size[1]) : (T)0;
+          T q[3] = {lp[0], lp[1], lp[2] - cz};
+          a = dot3(lv, lv); b = dot3(q, lv); c = dot3(q, q) - r*r;
+        }
+        if (a < (T)DMC_MINVAL) continue;
+        const T det = b*b - a*c;
+        if (det < 0) continue;
+        const T sq = t_sqrt(det);
+        for (int k = 0; k < 2; k++) {
+          const T x = k == 0 ? (-b - sq)/a : (-b + sq)/a;
+          if (x < 0) continue;
+          const T z = lp[2] + x*lv[2];
+          if (type == DMC_GEOM_CAPSULE) {
+            if (part == 0 && t_abs(z) > size[1]) continue;
+            if (part == 1 && z < size[1]) continue;
+            if (part == 2 && z > -size[1]) continue;
+          }
+          if (best < 0 || x < best) best = x;
+        }
+      }
+      return best;
+    }
+    if (type == DMC_GEOM_BOX) {
+      if (t_abs(lp[0]) <= size[0] && t_abs(lp[1]) <= size[1] && t_abs(lp[2]) <= size[2]) return 0;
+      for (int ax = 0; ax < 3; ax++) {
+        if (t_abs(lv[ax]) < (T)DMC_MINVAL) continue;
+        for (int sg = -1; sg <= 1; sg += 2) {
+          const T x = (sg*size[ax] - lp[ax]) / lv[ax];
+          if (x < 0) continue;
+          const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+          if (t_abs(lp[a1] + x*lv[a1]) <= size[a1] && t_abs(lp[a2] + x*lv[a2]) <= size[a2])
+            if (best < 0 || x < best) best = x;
+        }
+      }
+      return best;
+    }
+    return -1;
+  }
+  DMC_DEV void sensors_acc() {
+    if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
+    int need = 0;
+    for (int i = 0; i < L.d.nsensor; i++) {
+      const int t = MI(sensor_type)[i];
+      if (MI(sensor_stage)[i] == DMC_STAGE_ACC && (t == DMC_SENS_ACCELEROMETER || t == DMC_SENS_FORCE || t == DMC_SENS_TORQUE)) need = 1;
+    }
+    if (need) rne_post_constraint();
+    const int ncon = SI(imisc)[IM_NCON];
+    FOR_LANES(i, L.d.nsensor) {
+      if (MI(sensor_stage)[i] != DMC_STAGE_ACC) continue;
+      T* out = S(sensordata) + MI(sensor_adr)[i];
+      const int id = MI(sensor_objid)[i], t = MI(sensor_type)[i];
+      if (t == DMC_SENS_ACTUATORFRC) { out[0] = S(actuator_force)[id]; continue; }
+      const int body = MI(site_bodyid)[id];
+      T v[3], q[4], smat[9], spos[3];
+      mul_mat_vec3(v, S(xmat) + 9*body, MR(site_pos) + 3*id);
+      for (int k = 0; k < 3; k++) spos[k] = S(xpos)[3*body + k] + v[k];
+      mul_quat(q, S(xquat) + 4*body, MR(site_quat) + 4*id);
+      quat2mat(smat, q);
+      const T* rc = S(subtree_com) + 3*MI(body_rootid)[body];
+      if (t == DMC_SENS_TOUCH) {
+        T tot = 0;
+        for (int c = 0; c < ncon; c++) {
+          if (SI(con_efc)[c] < 0) continue;
+          const int cp = SI(con_pair)[c];
+          const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+          if (b1 != body && b2 != body) continue;
+          T lf[6]; contact_force_local(c, lf);
+          if (lf[0] <= 0) continue;
+          const T* fr = S(con_frame) + 9*c;
+          T ray[3] = {fr[0]*lf[0], fr[1]*lf[0], fr[2]*lf[0]};
+          normalize3(ray);
+          if (b2 == body) { ray[0] = -ray[0]; ray[1] = -ray[1]; ray[2] = -ray[2]; }
+          if (ray_geom(spos, smat, MR(site_size) + 3*id, S(con_pos) + 3*c, ray, MI(site_type)[id]) >= 0) tot += lf[0];
+        }
+        out[0] = tot;
+      } else if (t == DMC_SENS_ACCELEROMETER) {
+        T dif[3] = {spos[0] - rc[0], spos[1] - rc[1], spos[2] - rc[2]}, tmp[3], lin[3], cor[3], tmp2[3], vlin[3];
+        const T* ca = S(cacc) + 6*body; const T* cv = S(cvel) + 6*body;
+        cross3(tmp, dif, ca);
+        for (int k = 0; k < 3; k++) lin[k] = ca[3 + k] - tmp[k];
+        cross3(tmp2, dif, cv);
+        for (int k = 0; k < 3; k++) vlin[k] = cv[3 + k] - tmp2[k];
+        cross3(cor, cv, vlin);
+        for (int k = 0; k < 3; k++) lin[k] += cor[k];
+        mul_matT_vec3(out, smat, lin);
+      } else if (t == DMC_SENS_FORCE) {
+        mul_matT_vec3(out, smat, S(cfrc) + 6*body + 3);
+      } else if (t == DMC_SENS_TORQUE) {
+        T dif[3] = {spos[0] - rc[0], spos[1] - rc[1], spos[2] - rc[2]}, tmp[3], tq[3];
+        cross3(tmp, dif, S(cfrc) + 6*body + 3);
+        for (int k = 0; k < 3; k++) tq[k] = S(cfrc)[6*body + k] - tmp[k];
+        mul_matT_vec3(out, smat, tq);
+      }
+    }
+    DMC_WSYNC();
+  }
   DMC_DEV void sensors(int stage) {
     if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
     int need = 0;
@@ -1328,6 +1507,49 @@ struct StepCore {
     DMC_WSYNC();
   }
 
+  // ---- RK4 (mj_RungeKutta, N = 4): stages run through the single forward() site ----------
+  DMC_DEV void integrate_pos_from(const T* q0, const T* vel, T h) {
+    FOR_LANES(j, L.d.njnt) {
+      const int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j], t = MI(jnt_type)[j];
+      if (t == DMC_JNT_FREE || t == DMC_JNT_BALL) {
+        int qo = qa, dofo = da;
+        if (t == DMC_JNT_FREE) { for (int k = 0; k < 3; k++) S(qpos)[qa + k] = q0[qa + k] + h*vel[da + k]; qo += 3; dofo += 3; }
+        T q[4], w[3];
+        for (int k = 0; k < 4; k++) q[k] = q0[qo + k];
+        for (int k = 0; k < 3; k++) w[k] = vel[dofo + k];
+        quat_integrate(q, w, h);
+        for (int k = 0; k < 4; k++) S(qpos)[qo + k] = q[k];
+      } else S(qpos)[qa] = q0[qa] + h*vel[da];
+    }
+  }
+  // after the forward pass of `stage`: accumulate B[stage]*F[stage]; prepare X[stage+1]
+  DMC_DEV void rk4_stage(int stage) {
+    const int nv = L.d.nv;
+    const T h = o.timestep;
+    const T Bw = (stage == 0 || stage == 3) ? (T)(1.0/6) : (T)(1.0/3);
+    if (stage == 0) {
+      FOR_LANES(i, L.d.nq) S(rk_q0)[i] = S(qpos)[i];
+      FOR_LANES(i, nv) { S(rk_v0)[i] = S(qvel)[i]; S(rk_dq)[i] = Bw*S(qvel)[i]; S(rk_dv)[i] = Bw*S(qacc)[i]; }
+    } else FOR_LANES(i, nv) { S(rk_dq)[i] += Bw*S(qvel)[i]; S(rk_dv)[i] += Bw*S(qacc)[i]; }
+    DMC_WSYNC();
+    if (stage < 3) {
+      const T a = stage == 2 ? (T)1 : (T)0.5;
+      // X[stage+1] = X[0] (+) h * a * F[stage]; sv_grad/sv_Mgrad are free scratch here
+      FOR_LANES(i, nv) { S(sv_grad)[i] = a*S(qvel)[i]; S(sv_Mgrad)[i] = a*S(qacc)[i]; }
+      DMC_WSYNC();
+      integrate_pos_from(S(rk_q0), S(sv_grad), h);
+      FOR_LANES(i, nv) S(qvel)[i] = S(rk_v0)[i] + h*S(sv_Mgrad)[i];
+      DMC_WSYNC();
+    }
+  }
+  DMC_DEV void rk4_finish() {
+    const T h = o.timestep;
+    FOR_LANES(i, L.d.nv) S(qvel)[i] = S(rk_v0)[i] + h*S(rk_dv)[i];
+    integrate_pos_from(S(rk_q0), S(rk_dq), h);
+    time_ += o.timestep_d;
+    DMC_WSYNC();
+  }
+
   // ---- checks / reset ---------------------------------------------------------------------
   DMC_DEV void reset_state() {
     FOR_LANES(i, L.d.nq) S(qpos)[i] = MR(qpos0)[i];
@@ -1354,18 +1576,21 @@ struct StepCore {
   // ---- pipeline -----------------------------------------------------------------------------
   // One pass of the pipeline.  partial = the trailing mj_step1 of a legacy
   // Physics.step(): position + velocity stage for the outputs only.
-  DMC_DEV void forward(bool disable_actuation, bool partial, int outmask) {
+  DMC_DEV void forward(bool disable_actuation, bool partial, int outmask, bool skipsensor) {
     kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM);
     if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
     if (!partial || (outmask & OUT_CONTACT)) { collision(); DMC_PROF(PROF_COLL); }
     if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); }
-    sensors(DMC_STAGE_POS); DMC_PROF(PROF_SENS);
+    if (!skipsensor) sensors(DMC_STAGE_POS);
+    DMC_PROF(PROF_SENS);
     com_vel(); DMC_PROF(PROF_COMVEL);
     if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); }
-    sensors(DMC_STAGE_VEL); DMC_PROF(PROF_SENS);
+    if (!skipsensor) sensors(DMC_STAGE_VEL);
+    DMC_PROF(PROF_SENS);
     if (!partial) {
       fwd_actuation(disable_actuation); DMC_PROF(PROF_ACT); fwd_acceleration(); DMC_PROF(PROF_ACC); fwd_constraint();
-      sensors(DMC_STAGE_ACC); DMC_PROF(PROF_SENS);
+      if (!skipsensor) sensors_acc();
+      DMC_PROF(PROF_SENS);
     }
   }
   DMC_DEV void prof_begin() {
@@ -1392,16 +1617,20 @@ struct StepCore {
     for (int it = 0; it < npass; it++) {
       const bool partial = mode == 0 && it == nstep;
       if (mode == 0) check_pos_vel();
-      for (int attempt = 0; attempt < 2; attempt++) {
-        forward(mode == 2, partial, outmask);
-        if (partial || mode != 0 || attempt == 1 || !bad_acc()) break;
-        if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
-        if (o.disableflags & DMC_DSBL_AUTORESET) break;
-        DMC_WSYNC(); reset_state();
+      const int nstage = (mode == 0 && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
+      int stage = 0, retried = 0;
+      while (stage < nstage) {
+        forward(mode == 2, partial, outmask, stage > 0);
+        if (stage == 0 && mode == 0 && !partial && !retried && bad_acc()) {
+          if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
+          if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
+        }
+        if (stage == 0 && mode == 0 && !partial && it == nstep - 1) { dump_debug(io, env); if (!legacy) store_outputs(io, env, outmask); }
+        if (nstage > 1) rk4_stage(stage);
+        stage++;
       }
       if (mode != 0 || partial) break;
-      if (it == nstep - 1) { dump_debug(io, env); if (!legacy) store_outputs(io, env, outmask); }
-      euler();
+      if (nstage > 1) rk4_finish(); else euler();
       DMC_PROF(PROF_EULER);
     }
     if (mode != 0) dump_debug(io, env);

@@ -19,6 +19,7 @@ struct StepDims {
   int nM;        // number of (dof i, ancestor dof j) pairs incl. diagonal
   int nconmax;   // contact cap per environment
   int njmax;     // constraint-row cap per environment
+  int rk4;       // 1: RK4 integrator (extra stage buffers)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -68,7 +69,8 @@ struct StepDims {
   X(xipos, 3 * d.nbody)                                                        \
   X(geom_xpos, 3 * d.ngeom) X(geom_xmat, 9 * d.ngeom)                          \
   X(subtree_com, 3 * d.nbody)                                                  \
-  X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cvel, 6 * d.nbody)               \
+  X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv)              \
+  X(cvel, 6 * d.nbody)                                                         \
   X(qM, d.nv * d.nv) X(qLH, d.nv * d.nv)  /* Cholesky of M, later of H / M+hB */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
@@ -79,6 +81,8 @@ struct StepDims {
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
   X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
   X(efc_force, d.njmax)                                                        \
+  X(rk_q0, d.rk4 * d.nq) X(rk_v0, d.rk4 * d.nv) X(rk_dq, d.rk4 * d.nv)         \
+  X(rk_dv, d.rk4 * d.nv)                                                       \
   X(misc, 16)
 // ... followed by ONE region shared by three overlays whose lifetimes do not
 // intersect: position-stage temporaries, velocity-stage temporaries, solver.
@@ -86,7 +90,7 @@ struct StepDims {
   X(ximat, 9 * d.nbody) X(xanchor, 3 * d.njnt) X(xaxis, 3 * d.njnt)            \
   X(crb, 10 * d.nbody) X(mbuf, 6 * d.nv) X(subtree_usum, 3 * d.nbody)
 #define STEP_SCRATCH_OVL_VEL(X)                                                \
-  X(cdof_dot, 6 * d.nv) X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody)              \
+  X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody) X(cfrc_ext, 6 * d.nbody)           \
   X(subtree_mom, 3 * d.nbody)
 #define STEP_SCRATCH_OVL_SOL(X)                                                \
   X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \

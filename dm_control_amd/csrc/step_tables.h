@@ -64,6 +64,7 @@ struct StepTables {
   std::vector<double> mr;    // real tables (fp64 master copy), per L.mr_*
   StepOpts<double> opts;
   int max_contacts, max_rows;  // upper bounds if no cap applied
+  int has_unsupported_pairs = 0;  // pair types outside the collision kernel (legal only with contacts disabled)
 };
 
 // returns false + err for models the kernel does not support
@@ -80,7 +81,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (fric && m.npair) { *err = "elliptic friction cones are not implemented in the HIP path yet"; return false; }
   }
   if (m.opt_solver != DMC_SOL_NEWTON) { *err = "only the Newton solver is implemented in the HIP path"; return false; }
-  if (m.opt_integrator != DMC_INT_EULER) { *err = "only the Euler integrator is implemented in the HIP path"; return false; }
+  if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
+  d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
   if (m.opt_noslip_iterations > 0) { *err = "noslip iterations are not implemented in the HIP path"; return false; }
   for (int i = 0; i < m.nv; i++) if (m.dof_frictionloss[i] != 0) { *err = "dof frictionloss is not implemented"; return false; }
   for (int j = 0; j < m.njnt; j++) {
@@ -110,7 +112,11 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     const bool known = (t1 == DMC_GEOM_PLANE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE || t2 == DMC_GEOM_BOX)) ||
                        (t1 == DMC_GEOM_SPHERE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE)) ||
                        (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE);
-    if (!known) { *err = "geom pair type not implemented in the HIP collision kernel (need plane/sphere/capsule, plane-box)"; return false; }
+    if (!known) {
+      // tolerated only while contacts are disabled (e.g. suite cartpole): the pair then never collides
+      if (m.opt_disableflags & DMC_DSBL_CONTACT) { t->has_unsupported_pairs = 1; nc = 0; }
+      else { *err = "geom pair type not implemented in the HIP collision kernel (need plane/sphere/capsule, plane-box)"; return false; }
+    }
     int dim;
     const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
     if (pr1 == pr2) dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
@@ -226,6 +232,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
                     st == DMC_SENS_GYRO || st == DMC_SENS_ACCELEROMETER || st == DMC_SENS_FORCE ||
                     st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH;
     if (!ok) { *err = "sensor type not implemented"; return false; }
+    if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX) { *err = "touch sensor sites must be sphere, capsule or box"; return false; } }
   }
   StepOpts<double>& o = t->opts;
   o.timestep = m.opt_timestep; o.timestep_d = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;

@@ -1,0 +1,218 @@
+"""RL environment loop over a physics backend.
+
+Host-side mirror of the reference's plug-in seam, `dm_control/rl/control.py`:
+`Environment` (:28-165: reset :82, step :99), `compute_n_steps` (:168), the
+`Physics` ABC (:206-267), `PhysicsError` (:270), the `Task` ABC (:274-371) and
+`flatten_observation` (:374).  Same names, argument meaning and error
+behaviour, so suite-style tasks run unchanged; additionally every method is
+batch-aware: with a batched `Physics` (batch_size B > 1) observations / rewards
+carry a leading batch dimension and the episode bookkeeping is shared (all
+environments of a batch run in lock-step, auto-reset per environment is the
+task's choice).
+"""
+import abc
+import collections
+import contextlib
+
+import numpy as np
+
+from dm_control_amd.envs import dm_env_api as dm_env
+from dm_control_amd.envs.dm_env_api import specs
+
+FLAT_OBSERVATION_KEY = 'observations'
+
+
+class PhysicsError(RuntimeError):
+  """Raised if the state of the physics simulation becomes divergent."""
+
+
+class Physics(metaclass=abc.ABCMeta):
+  """Simulates a physical environment (abstract)."""
+
+  legacy_step = True
+
+  @abc.abstractmethod
+  def step(self, n_sub_steps=1):
+    pass
+
+  @abc.abstractmethod
+  def time(self):
+    pass
+
+  @abc.abstractmethod
+  def timestep(self):
+    pass
+
+  def set_control(self, control):
+    raise NotImplementedError('set_control is not supported.')
+
+  @contextlib.contextmanager
+  def reset_context(self):
+    """`with physics.reset_context(): <set state>` -- reset() on entry (a
+    PhysicsError there is swallowed), after_reset() on exit."""
+    try:
+      self.reset()
+    except PhysicsError:
+      pass
+    yield self
+    self.after_reset()
+
+  @abc.abstractmethod
+  def reset(self):
+    pass
+
+  @abc.abstractmethod
+  def after_reset(self):
+    pass
+
+  def check_divergence(self):
+    """Raises PhysicsError if the state is divergent; default: no-op."""
+
+
+class Task(metaclass=abc.ABCMeta):
+  """Defines a task in a `control.Environment` (abstract)."""
+
+  @abc.abstractmethod
+  def initialize_episode(self, physics):
+    pass
+
+  @abc.abstractmethod
+  def before_step(self, action, physics):
+    pass
+
+  def after_step(self, physics):
+    pass
+
+  @abc.abstractmethod
+  def action_spec(self, physics):
+    pass
+
+  def step_spec(self, physics):
+    raise NotImplementedError()
+
+  @abc.abstractmethod
+  def get_observation(self, physics):
+    pass
+
+  @abc.abstractmethod
+  def get_reward(self, physics):
+    pass
+
+  def get_termination(self, physics):
+    """None while the episode continues, else the final discount."""
+
+  @abc.abstractmethod
+  def observation_spec(self, physics):
+    pass
+
+
+def compute_n_steps(control_timestep, physics_timestep, tolerance=1e-8):
+  """Number of physics steps per control step; ValueError if not an integer
+  multiple or smaller than the physics step."""
+  if control_timestep < physics_timestep:
+    raise ValueError('Control timestep ({}) cannot be smaller than physics timestep ({}).'.format(
+        control_timestep, physics_timestep))
+  ratio = control_timestep / physics_timestep
+  if abs(ratio - round(ratio)) > tolerance:
+    raise ValueError('Control timestep ({}) must be an integer multiple of physics timestep ({})'.format(
+        control_timestep, physics_timestep))
+  return int(round(ratio))
+
+
+def flatten_observation(observation, output_key=FLAT_OBSERVATION_KEY):
+  """Flattens a dict of arrays into {output_key: 1-D array}; key order is
+  preserved for ordered dicts and sorted otherwise."""
+  if not isinstance(observation, collections.abc.MutableMapping):
+    raise ValueError('Can only flatten dict-like observations.')
+  keys = observation.keys() if isinstance(observation, collections.OrderedDict) else sorted(observation.keys())
+  flat = np.concatenate([np.ravel(observation[k]) for k in keys])
+  return type(observation)([(output_key, flat)])
+
+
+def _spec_from_observation(observation):
+  out = collections.OrderedDict()
+  for key, value in observation.items():
+    value = np.asarray(value)
+    out[key] = specs.Array(value.shape, value.dtype, name=key)
+  return out
+
+
+class Environment(dm_env.Environment):
+  """Physics-based RL environment: before_step -> physics.step(n_sub_steps) ->
+  after_step -> reward / observation / termination -> TimeStep."""
+
+  def __init__(self, physics, task, time_limit=float('inf'), control_timestep=None,
+               n_sub_steps=None, flat_observation=False, legacy_step=True):
+    self._task = task
+    self._physics = physics
+    self._physics.legacy_step = legacy_step
+    self._flat_observation = flat_observation
+    if n_sub_steps is not None and control_timestep is not None:
+      raise ValueError('Both n_sub_steps and control_timestep were supplied.')
+    if n_sub_steps is not None:
+      self._n_sub_steps = n_sub_steps
+    elif control_timestep is not None:
+      self._n_sub_steps = compute_n_steps(control_timestep, self._physics.timestep())
+    else:
+      self._n_sub_steps = 1
+    if time_limit == float('inf'):
+      self._step_limit = float('inf')
+    else:
+      self._step_limit = time_limit / (self._physics.timestep() * self._n_sub_steps)
+    self._step_count = 0
+    self._reset_next_step = True
+
+  def _observe(self):
+    obs = self._task.get_observation(self._physics)
+    return flatten_observation(obs) if self._flat_observation else obs
+
+  def reset(self):
+    self._reset_next_step = False
+    self._step_count = 0
+    with self._physics.reset_context():
+      self._task.initialize_episode(self._physics)
+    return dm_env.TimeStep(dm_env.StepType.FIRST, None, None, self._observe())
+
+  def step(self, action):
+    if self._reset_next_step:
+      return self.reset()
+    self._task.before_step(action, self._physics)
+    self._physics.step(self._n_sub_steps)
+    self._task.after_step(self._physics)
+    reward = self._task.get_reward(self._physics)
+    observation = self._observe()
+    self._step_count += 1
+    if self._step_count >= self._step_limit:
+      discount = 1.0
+    else:
+      discount = self._task.get_termination(self._physics)
+    if discount is not None:
+      self._reset_next_step = True
+      return dm_env.TimeStep(dm_env.StepType.LAST, reward, discount, observation)
+    return dm_env.TimeStep(dm_env.StepType.MID, reward, 1.0, observation)
+
+  def action_spec(self):
+    return self._task.action_spec(self._physics)
+
+  def step_spec(self):
+    return self._task.step_spec(self._physics)
+
+  def observation_spec(self):
+    try:
+      return self._task.observation_spec(self._physics)
+    except NotImplementedError:
+      obs = self._task.get_observation(self._physics)
+      if self._flat_observation:
+        obs = flatten_observation(obs)
+      return _spec_from_observation(obs)
+
+  @property
+  def physics(self):
+    return self._physics
+
+  @property
+  def task(self):
+    return self._task
+
+  def control_timestep(self):
+    return self._physics.timestep() * self._n_sub_steps

@@ -1,0 +1,401 @@
+"""`Physics`: the reference's `mujoco.Physics` facade over the HIP batch.
+
+Mirrors dm_control/mujoco/engine.py:83-622 for the step surface: from_xml_string
+/ from_xml_path (:446-476), step (:164), forward (:335), reset (:306),
+after_reset (:329), reset_context, set_control (:139), get_state / set_state
+(:235-285), copy (:287), check_invalid_state (:345-368), suppress_physics_errors
+(:125), control / position / velocity / activation / state / time / timestep
+(:589-622), `.model`, `.data`, `.named.{model,data}`, and `action_spec` (:1093).
+Rendering (Camera, render) is out of scope (no GL on the compute path).
+
+batch_size == 1 (default): arrays have the reference's shapes, so suite tasks are
+drop-in.  batch_size == B > 1: every data array gains a leading batch dimension.
+
+`physics.data` is a host mirror of the device arrays: reads fetch lazily (and
+are cached until the next step/forward/reset), writes to the input fields
+(`qpos qvel ctrl qacc_warmstart qfrc_applied time`) are uploaded before the
+next kernel launch.  High-throughput callers use `physics.batch`
+(`BatchedPhysics`: device pointers, zero-copy binds) instead of the mirror.
+"""
+import contextlib
+import logging
+
+import numpy as np
+
+from dm_control_amd import mjcf_compiler
+from dm_control_amd.batch import BatchedPhysics
+from dm_control_amd.envs import control
+from dm_control_amd.envs.dm_env_api import specs
+
+mjMAXVAL = mjcf_compiler.C['DMC_MAXVAL']
+_WARNING_NAMES = ['mjWARN_INERTIA', 'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL', 'mjWARN_VGEOMFULL',
+                  'mjWARN_BADQPOS', 'mjWARN_BADQVEL', 'mjWARN_BADQACC', 'mjWARN_BADCTRL']
+_INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
+
+_INPUT_FIELDS = ('qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')
+_INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
+# field -> (row object kind for named access, columns per row)
+_FIELD_AXES = {
+    'qpos': ('joint_q', None), 'qvel': ('joint_v', None), 'qacc': ('joint_v', None),
+    'qacc_warmstart': ('joint_v', None), 'qfrc_applied': ('joint_v', None),
+    'qfrc_actuator': ('joint_v', None), 'qfrc_bias': ('joint_v', None),
+    'qfrc_constraint': ('joint_v', None),
+    'ctrl': ('actuator', None), 'actuator_force': ('actuator', None),
+    'sensordata': ('sensor', None),
+    'xpos': ('body', 3), 'xquat': ('body', 4), 'xmat': ('body', 9), 'xipos': ('body', 3),
+    'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
+    'site_xpos': ('site', 3), 'site_xmat': ('site', 9),
+}
+_COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'],
+         9: ['xx', 'xy', 'xz', 'yx', 'yy', 'yz', 'zx', 'zy', 'zz']}
+
+
+class _Data:
+  """Host mirror of the batched mjData arrays (see module docstring)."""
+
+  def __init__(self, physics):
+    object.__setattr__(self, '_p', physics)
+    object.__setattr__(self, '_cache', {})
+    object.__setattr__(self, '_touched', set())
+
+  def _fetch(self, name):
+    p = self._p
+    a = p.batch.get(name)
+    rows = a.shape[1]
+    if name in _FIELD_AXES and _FIELD_AXES[name][1]:
+      c = _FIELD_AXES[name][1]
+      a = a.reshape(a.shape[0], rows // c, c)
+    if name in ('time', 'ncon', 'nefc', 'solver_iter'):
+      a = a[:, 0]
+    return a[0] if p.batch_size == 1 else a
+
+  def __getattr__(self, name):
+    if name.startswith('_'):
+      raise AttributeError(name)
+    if name == 'time' and self._p.batch_size == 1:
+      return float(self._get('time'))
+    return self._get(name)
+
+  def _get(self, name):
+    if name not in self._cache:
+      try:
+        self._cache[name] = self._fetch(name)
+      except Exception as e:
+        raise AttributeError('%s (%s)' % (name, e))
+    if name in _INPUT_FIELDS:
+      self._touched.add(name)
+    return self._cache[name]
+
+  def __setattr__(self, name, value):
+    if name not in _INPUT_FIELDS:
+      raise AttributeError('data.%s is read-only' % name)
+    cur = self._get(name)
+    if np.ndim(cur) == 0:
+      self._cache[name] = np.asarray(float(value))
+    else:
+      cur[...] = value
+    self._touched.add(name)
+
+  def _upload(self):
+    p = self._p
+    for name in list(self._touched):
+      a = np.asarray(self._cache[name], dtype=np.float64)
+      p.batch.set(name, a.reshape(p.batch_size, -1))
+    self._touched.clear()
+
+  def _invalidate(self):
+    self._cache.clear()
+    self._touched.clear()
+
+  @property
+  def contact(self):
+    """Active contacts of a single environment as a structured array with the
+    reference's field names (wrapper/core.py:564-567)."""
+    if self._p.batch_size != 1:
+      raise NotImplementedError('data.contact is per environment; use contact_* fields for batches')
+    n = int(self._get('ncon'))
+    out = np.zeros(n, dtype=[('geom1', np.int32), ('geom2', np.int32), ('dist', np.float64),
+                             ('pos', np.float64, 3), ('frame', np.float64, 9)])
+    out['geom1'] = self._get('contact_geom1')[:n]
+    out['geom2'] = self._get('contact_geom2')[:n]
+    out['dist'] = self._get('contact_dist')[:n]
+    out['pos'] = self._get('contact_pos').reshape(-1, 3)[:n]
+    out['frame'] = self._get('contact_frame').reshape(-1, 9)[:n]
+    return out
+
+
+class _Axis:
+  """Row (or column) names -> indices; ragged rows span several entries."""
+
+  def __init__(self, names, starts=None, sizes=None):
+    self.names = list(names)
+    self.starts = starts
+    self.sizes = sizes
+    self.lookup = {n: i for i, n in enumerate(self.names) if n}
+
+  def convert(self, key):
+    if isinstance(key, (str, bytes)):
+      key = key.decode() if isinstance(key, bytes) else key
+      if key not in self.lookup:
+        raise KeyError(key)
+      i = self.lookup[key]
+      if self.starts is None:
+        return i
+      # ragged axes (qpos by joint, sensordata by sensor, ...) always yield a slice,
+      # like the reference's RaggedNamedAxis: qpos['slider'] has shape (1,)
+      return slice(int(self.starts[i]), int(self.starts[i] + self.sizes[i]))
+    if isinstance(key, (list, tuple, np.ndarray)) and len(key) and isinstance(key[0], (str, bytes)):
+      idx = []
+      for k in key:
+        c = self.convert(k)
+        idx.extend(range(c.start, c.stop) if isinstance(c, slice) else [c])
+      return idx
+    return key
+
+
+class FieldIndexer:
+  """`physics.named.data.xpos['torso', 'z']`-style access (reference:
+  dm_control/mujoco/index.py:455-560); batched arrays index their trailing axes."""
+
+  def __init__(self, getter, row_axis, col_axis=None, batched=False, setter=None):
+    self._get, self._rows, self._cols, self._batched, self._set = getter, row_axis, col_axis, batched, setter
+
+  def _convert(self, key):
+    if not isinstance(key, tuple):
+      key = (key,)
+    if len(key) > 2:
+      raise IndexError('too many indices')
+    out = [self._rows.convert(key[0])]
+    if len(key) == 2:
+      if self._cols is None:
+        raise IndexError('field has no named columns')
+      out.append(self._cols.convert(key[1]))
+    if self._batched:
+      out = [slice(None)] + out
+    if len(out) > 1 and all(isinstance(o, list) for o in out[-2:]):
+      out[-2] = np.asarray(out[-2])[:, None]   # outer (orthogonal) indexing like the reference
+      out[-1] = np.asarray(out[-1])[None, :]
+    return tuple(out)
+
+  def __getitem__(self, key):
+    return self._get()[self._convert(key)]
+
+  def __setitem__(self, key, value):
+    self._get()[self._convert(key)] = value
+    if self._set:
+      self._set()
+
+  @property
+  def axes(self):
+    return self._rows, self._cols
+
+  def __repr__(self):
+    return 'FieldIndexer(rows=%r)' % (self._rows.names,)
+
+
+class _Named:
+  pass
+
+
+def _make_axes(model):
+  m = model
+  jq = _Axis(m.names['joint'], m.jnt_qposadr, [{0: 7, 1: 4, 2: 1, 3: 1}[t] for t in m.jnt_type])
+  jv = _Axis(m.names['joint'], m.jnt_dofadr, [{0: 6, 1: 3, 2: 1, 3: 1}[t] for t in m.jnt_type])
+  return {
+      'joint_q': jq, 'joint_v': jv,
+      'actuator': _Axis(m.names['actuator']),
+      'sensor': _Axis(m.names['sensor'], m.sensor_adr, m.sensor_dim),
+      'body': _Axis(m.names['body']), 'geom': _Axis(m.names['geom']), 'site': _Axis(m.names['site']),
+      'joint': _Axis(m.names['joint']),
+  }
+
+
+_MODEL_FIELD_AXES = {
+    'body_mass': 'body', 'body_pos': 'body', 'body_quat': 'body', 'body_inertia': 'body',
+    'geom_size': 'geom', 'geom_pos': 'geom', 'geom_friction': 'geom', 'geom_type': 'geom',
+    'jnt_range': 'joint', 'jnt_limited': 'joint', 'jnt_type': 'joint', 'jnt_axis': 'joint',
+    'jnt_stiffness': 'joint', 'qpos0': 'joint_q', 'dof_damping': 'joint_v', 'dof_armature': 'joint_v',
+    'actuator_gear': 'actuator', 'actuator_ctrlrange': 'actuator', 'actuator_ctrllimited': 'actuator',
+    'site_pos': 'site', 'site_size': 'site', 'sensor_type': 'sensor',
+}
+
+
+class Physics(control.Physics):
+  """Batched MuJoCo-semantics physics on one MI355X (see module docstring)."""
+
+  _contexts = None
+
+  def __init__(self, model, batch_size=1, device_id=0, precision=64, **batch_kwargs):
+    """`precision`: 64 (default: drop-in numerics, tracks the CPU reference to
+    rounding) or 32 (the throughput configuration BASELINE.json benchmarks)."""
+    if not isinstance(model, mjcf_compiler.Model):
+      raise TypeError('model must be a compiled Model; use Physics.from_xml_string')
+    self.model = model
+    self.batch_size = int(batch_size)
+    self.batch = BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, **batch_kwargs)
+    self.data = _Data(self)
+    self._warnings_cause_exception = True
+    self._warnings_seen = np.zeros((self.batch_size, 8), dtype=np.int64)
+    self._build_named()
+    self.after_reset()
+
+  # -- construction -----------------------------------------------------------------
+  @classmethod
+  def from_model(cls, model, **kw):
+    return cls(model, **kw)
+
+  @classmethod
+  def from_xml_string(cls, xml_string, assets=None, **kw):
+    return cls(mjcf_compiler.compile_xml(xml_string, assets), **kw)
+
+  @classmethod
+  def from_xml_path(cls, file_path, **kw):
+    with open(file_path) as f:
+      return cls.from_xml_string(f.read(), **kw)
+
+  def _build_named(self):
+    axes = _make_axes(self.model)
+    batched = self.batch_size > 1
+    named = _Named()
+    named.data = _Named()
+    named.model = _Named()
+    for field, (rowkind, ncol) in _FIELD_AXES.items():
+      cols = _Axis(_COLS[ncol]) if ncol else None
+      touch = (lambda f=field: self.data._touched.add(f)) if field in _INPUT_FIELDS else None
+      setattr(named.data, field, FieldIndexer(lambda f=field: self.data._get(f), axes[rowkind], cols, batched, touch))
+    for field, rowkind in _MODEL_FIELD_AXES.items():
+      if hasattr(self.model, field):
+        setattr(named.model, field, FieldIndexer(lambda f=field: getattr(self.model, f), axes[rowkind], None, False))
+    self.named = named
+
+  # -- the step surface -----------------------------------------------------------------
+  def set_control(self, control_values):
+    self.data.ctrl = control_values
+
+  def step(self, nstep=1):
+    """Advances every environment by `nstep` substeps in one kernel launch."""
+    with self.check_invalid_state():
+      self.data._upload()
+      self.batch.legacy_step = bool(self.legacy_step)
+      self.batch.step(nstep)
+      self.data._invalidate()
+
+  def forward(self):
+    with self.check_invalid_state():
+      self.data._upload()
+      self.batch.forward(False)
+      self.data._invalidate()
+
+  def reset(self, keyframe_id=None):
+    """mj_resetData (+keyframe) then forward with actuation disabled."""
+    if keyframe_id is not None and not 0 <= keyframe_id < self.model.nkey:
+      raise ValueError('keyframe_id {} is out of range [0, {})'.format(keyframe_id, self.model.nkey))
+    self.data._invalidate()
+    self.batch.reset(keyframe_id=keyframe_id)
+    self._warnings_seen[:] = 0
+    self.after_reset()
+
+  def after_reset(self):
+    with self.check_invalid_state():
+      self.data._upload()
+      self.batch.forward(True)
+      self.data._invalidate()
+
+  @contextlib.contextmanager
+  def check_invalid_state(self):
+    """Raises PhysicsError (or logs, under suppress_physics_errors) if the
+    enclosed launch incremented any warning counter (engine.py:345-368)."""
+    yield
+    w = self.batch.get('warning').astype(np.int64)
+    new = w > self._warnings_seen
+    self._warnings_seen = w
+    if new.any():
+      names = [_WARNING_NAMES[i] for i in np.nonzero(new.any(axis=0))[0]]
+      msg = _INVALID_PHYSICS_STATE.format(warning_names=', '.join(names))
+      if self._warnings_cause_exception:
+        raise control.PhysicsError(msg)
+      logging.warning(msg)
+
+  @contextlib.contextmanager
+  def suppress_physics_errors(self):
+    prev = self._warnings_cause_exception
+    self._warnings_cause_exception = False
+    try:
+      yield
+    finally:
+      self._warnings_cause_exception = prev
+
+  def check_divergence(self):
+    pass
+
+  # -- state -------------------------------------------------------------------------------
+  def get_state(self):
+    """Concatenated [qpos, qvel] (na == 0 in the supported models)."""
+    return np.concatenate([np.asarray(self.data.qpos), np.asarray(self.data.qvel)], axis=-1)
+
+  def set_state(self, physics_state):
+    s = np.asarray(physics_state, dtype=np.float64)
+    nq, nv = self.model.nq, self.model.nv
+    if s.shape[-1] != nq + nv:
+      raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (nq + nv,)))
+    self.data.qpos = s[..., :nq]
+    self.data.qvel = s[..., nq:]
+
+  def copy(self, share_model=False):
+    del share_model
+    other = Physics(self.model, batch_size=self.batch_size, precision=self.batch.precision)
+    for name in _INPUT_FIELDS:
+      other.batch.set(name, np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1))
+    other.legacy_step = self.legacy_step
+    other.data._invalidate()
+    # refresh derived arrays, then restore the solver warm start that forward()
+    # overwrote, so that the copy continues bit-identically (engine_test.py:549-572)
+    other.batch.forward(True)
+    other.batch.set('qacc_warmstart', np.asarray(self.data._get('qacc_warmstart'), dtype=np.float64).reshape(self.batch_size, -1))
+    other._warnings_seen = other.batch.get('warning').astype(np.int64)
+    return other
+
+  def free(self):
+    if getattr(self, 'batch', None) is not None:
+      self.batch.close()
+      self.batch = None
+
+  def __del__(self):
+    try:
+      self.free()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # -- accessors (engine.py:589-622) ---------------------------------------------------------
+  def timestep(self):
+    return self.model.opt.timestep
+
+  def time(self):
+    return self.data.time
+
+  def control(self):
+    return np.array(self.data.ctrl)
+
+  def activation(self):
+    return np.zeros((0,)) if self.batch_size == 1 else np.zeros((self.batch_size, 0))
+
+  def state(self):
+    return self.get_state()
+
+  def position(self):
+    return np.array(self.data.qpos)
+
+  def velocity(self):
+    return np.array(self.data.qvel)
+
+
+def action_spec(physics):
+  """BoundedArray over the actuator control ranges; unlimited actuators get
+  +-mjMAXVAL (engine.py:1093-1103)."""
+  m = physics.model
+  limited = m.actuator_ctrllimited.ravel().astype(bool)
+  lo = np.where(limited, m.actuator_ctrlrange[:, 0], -mjMAXVAL)
+  hi = np.where(limited, m.actuator_ctrlrange[:, 1], mjMAXVAL)
+  shape = (m.nu,) if physics.batch_size == 1 else (physics.batch_size, m.nu)
+  return specs.BoundedArray(shape=shape, dtype=float, minimum=np.broadcast_to(lo, shape),
+                            maximum=np.broadcast_to(hi, shape))

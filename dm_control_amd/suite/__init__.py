@@ -1,0 +1,42 @@
+"""`suite.load(domain, task)` over the HIP physics backend.
+
+Mirrors dm_control/suite/__init__.py:93-150 (`load`, `build_environment`,
+ALL_TASKS / BENCHMARKING) for the domains whose models the BASELINE configs
+name: cartpole, cheetah, humanoid.  Extra keyword: `physics_kwargs`
+(batch_size, precision, device_id, ...) to run a whole batch behind the same
+`Environment` API.
+"""
+import collections
+
+from dm_control_amd.suite import cartpole
+from dm_control_amd.suite import cheetah
+from dm_control_amd.suite import humanoid
+
+_DOMAINS = collections.OrderedDict(cartpole=cartpole, cheetah=cheetah, humanoid=humanoid)
+
+ALL_TASKS = tuple((d, t) for d, mod in _DOMAINS.items() for t in mod.TASKS)
+BENCHMARKING = tuple((d, t) for d, mod in _DOMAINS.items() for t, (_, tag) in mod.TASKS.items()
+                     if tag == 'benchmarking')
+TASKS_BY_DOMAIN = collections.OrderedDict((d, tuple(mod.TASKS)) for d, mod in _DOMAINS.items())
+
+
+def build_environment(domain_name, task_name, task_kwargs=None, environment_kwargs=None, physics_kwargs=None):
+  if domain_name not in _DOMAINS:
+    raise ValueError('Domain {!r} does not exist.'.format(domain_name))
+  domain = _DOMAINS[domain_name]
+  if task_name not in domain.TASKS:
+    raise ValueError('Level {!r} does not exist in domain {!r}.'.format(task_name, domain_name))
+  kwargs = dict(task_kwargs or {})
+  if environment_kwargs is not None:
+    kwargs['environment_kwargs'] = dict(environment_kwargs)
+  if physics_kwargs is not None:
+    kwargs['physics_kwargs'] = dict(physics_kwargs)
+  env = domain.TASKS[task_name][0](**kwargs)
+  env.task.visualize_reward = False
+  return env
+
+
+def load(domain_name, task_name, task_kwargs=None, environment_kwargs=None, visualize_reward=False,
+         physics_kwargs=None):
+  del visualize_reward  # rendering-only
+  return build_environment(domain_name, task_name, task_kwargs, environment_kwargs, physics_kwargs)

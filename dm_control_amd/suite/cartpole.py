@@ -1,0 +1,97 @@
+"""Cartpole domain (reference: dm_control/suite/cartpole.py): balance,
+balance_sparse, swingup, swingup_sparse (single pole)."""
+import collections
+
+import numpy as np
+
+from dm_control_amd import physics as physics_lib
+from dm_control_amd.envs import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.suite import rewards
+
+_DEFAULT_TIME_LIMIT = 10
+TASKS = {}
+
+
+def get_model_and_assets():
+  return common.read_model('cartpole.xml'), None
+
+
+def _make(swing_up, sparse):
+  def factory(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None, physics_kwargs=None):
+    physics = Physics.from_xml_string(*get_model_and_assets(), **(physics_kwargs or {}))
+    task = Balance(swing_up=swing_up, sparse=sparse, random=random)
+    return control.Environment(physics, task, time_limit=time_limit, **(environment_kwargs or {}))
+  return factory
+
+
+balance = _make(False, False)
+balance_sparse = _make(False, True)
+swingup = _make(True, False)
+swingup_sparse = _make(True, True)
+for _n in ('balance', 'balance_sparse', 'swingup', 'swingup_sparse'):
+  TASKS[_n] = (globals()[_n], 'benchmarking')
+
+
+class Physics(physics_lib.Physics):
+
+  def cart_position(self):
+    return self.named.data.qpos['slider'][..., 0]
+
+  def angular_vel(self):
+    return self.data.qvel[..., 1:]
+
+  def pole_angle_cosine(self):
+    return self.named.data.xmat[2:, 'zz']
+
+  def bounded_position(self):
+    cart = np.asarray(self.cart_position())[..., None]
+    poles = self.named.data.xmat[2:, ['zz', 'xz']]
+    return np.concatenate([cart, poles.reshape(poles.shape[:-2] + (-1,))], axis=-1)
+
+
+class Balance(base.Task):
+  _CART_RANGE = (-.25, .25)
+  _ANGLE_COSINE_RANGE = (.995, 1)
+
+  def __init__(self, swing_up, sparse, random=None):
+    self._sparse = sparse
+    self._swing_up = swing_up
+    super().__init__(random=random)
+
+  def initialize_episode(self, physics):
+    nv = physics.model.nv
+    lead = () if physics.batch_size == 1 else (physics.batch_size,)
+    qpos = physics.named.data.qpos
+    if self._swing_up:
+      qpos['slider'] = .01 * self.random.randn(*lead, 1)
+      qpos['hinge_1'] = np.pi + .01 * self.random.randn(*lead, 1)
+      if nv > 2:
+        physics.data.qpos[..., 2:] = .1 * self.random.randn(*lead, nv - 2)
+    else:
+      qpos['slider'] = self.random.uniform(-.1, .1, lead + (1,))
+      physics.data.qpos[..., 1:] = self.random.uniform(-.034, .034, lead + (nv - 1,))
+    physics.data.qvel = 0.01 * self.random.randn(*lead, nv)
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    obs = collections.OrderedDict()
+    obs['position'] = physics.bounded_position()
+    obs['velocity'] = physics.velocity()
+    return obs
+
+  def _get_reward(self, physics, sparse):
+    if sparse:
+      cart_in_bounds = rewards.tolerance(physics.cart_position(), self._CART_RANGE)
+      angle_in_bounds = rewards.tolerance(physics.pole_angle_cosine(), self._ANGLE_COSINE_RANGE).prod(axis=-1)
+      return cart_in_bounds * angle_in_bounds
+    upright = (physics.pole_angle_cosine() + 1) / 2
+    centered = (1 + rewards.tolerance(physics.cart_position(), margin=2)) / 2
+    small_control = rewards.tolerance(physics.control(), margin=1, value_at_margin=0, sigmoid='quadratic')[..., 0]
+    small_control = (4 + small_control) / 5
+    small_velocity = (1 + rewards.tolerance(physics.angular_vel(), margin=5).min(axis=-1)) / 2
+    return upright.mean(axis=-1) * small_control * small_velocity * centered
+
+  def get_reward(self, physics):
+    return self._get_reward(physics, sparse=self._sparse)

@@ -1,0 +1,173 @@
+"""Host-side logic that needs no GPU: the env loop over a mock physics (mirrors
+dm_control/rl/control_test.py:35-134), dm_env shim, rewards, named axes."""
+import collections
+
+import numpy as np
+import pytest
+
+from dm_control_amd.envs import control
+from dm_control_amd.envs import dm_env_api as dm_env
+from dm_control_amd.suite import rewards
+
+
+class _MockPhysics(control.Physics):
+
+  def __init__(self, dt=0.01):
+    self.dt, self.t, self.calls = dt, 0.0, []
+
+  def step(self, n_sub_steps=1):
+    self.calls.append(('step', n_sub_steps))
+    self.t += self.dt * n_sub_steps
+
+  def time(self):
+    return self.t
+
+  def timestep(self):
+    return self.dt
+
+  def reset(self):
+    self.calls.append('reset')
+    self.t = 0.0
+
+  def after_reset(self):
+    self.calls.append('after_reset')
+
+
+class _MockTask(control.Task):
+
+  def __init__(self, terminate_at=None):
+    self.terminate_at, self.n = terminate_at, 0
+
+  def initialize_episode(self, physics):
+    physics.calls.append('init')
+    self.n = 0
+
+  def before_step(self, action, physics):
+    physics.calls.append(('before', float(action)))
+
+  def after_step(self, physics):
+    self.n += 1
+
+  def action_spec(self, physics):
+    return dm_env.specs.BoundedArray((1,), float, -1, 1)
+
+  def get_observation(self, physics):
+    return collections.OrderedDict(b=np.array([physics.t]), a=np.zeros((2, 2)))
+
+  def get_reward(self, physics):
+    return 0.5
+
+  def get_termination(self, physics):
+    return 0.0 if self.terminate_at is not None and self.n >= self.terminate_at else None
+
+  def observation_spec(self, physics):
+    raise NotImplementedError()
+
+
+def test_env_loop_order_and_time_limit():
+  phys = _MockPhysics()
+  env = control.Environment(phys, _MockTask(), time_limit=0.05, n_sub_steps=1)
+  ts = env.reset()
+  assert ts.first() and ts.reward is None and ts.discount is None
+  assert phys.calls == ['reset', 'init', 'after_reset']
+  steps = 0
+  while not ts.last():
+    ts = env.step(0.25)
+    steps += 1
+  assert steps == 5 and ts.discount == 1.0 and ts.reward == 0.5
+  assert phys.calls[3:5] == [('before', 0.25), ('step', 1)]
+  assert env.step(0.0).first()   # auto-reset after LAST
+
+
+def test_termination_discount_and_substeps():
+  phys = _MockPhysics(dt=0.002)
+  env = control.Environment(phys, _MockTask(terminate_at=3), control_timestep=0.01)
+  assert env.control_timestep() == pytest.approx(0.01)
+  env.reset()
+  for _ in range(2):
+    assert env.step(0.0).mid()
+  ts = env.step(0.0)
+  assert ts.last() and ts.discount == 0.0
+  assert ('step', 5) in phys.calls
+  assert phys.legacy_step is True
+
+
+def test_constructor_errors_and_compute_n_steps():
+  with pytest.raises(ValueError):
+    control.Environment(_MockPhysics(), _MockTask(), n_sub_steps=2, control_timestep=0.1)
+  assert control.compute_n_steps(0.025, 0.005) == 5
+  with pytest.raises(ValueError):
+    control.compute_n_steps(0.003, 0.002)
+  with pytest.raises(ValueError):
+    control.compute_n_steps(0.001, 0.002)
+
+
+def test_flatten_and_observation_spec():
+  env = control.Environment(_MockPhysics(), _MockTask(), flat_observation=True)
+  ts = env.reset()
+  assert list(ts.observation) == [control.FLAT_OBSERVATION_KEY]
+  assert ts.observation[control.FLAT_OBSERVATION_KEY].shape == (5,)
+  spec = env.observation_spec()
+  assert spec[control.FLAT_OBSERVATION_KEY].shape == (5,)
+  unsorted = {'z': np.ones(1), 'a': np.zeros(2)}
+  np.testing.assert_array_equal(control.flatten_observation(unsorted)[control.FLAT_OBSERVATION_KEY], [0, 0, 1])
+
+
+def test_reset_context_swallows_physics_error():
+  class Bad(_MockPhysics):
+    def reset(self):
+      raise control.PhysicsError('diverged')
+  p = Bad()
+  with p.reset_context():
+    pass
+  assert p.calls == ['after_reset']
+
+
+def test_specs():
+  s = dm_env.specs.BoundedArray((2,), float, [-1, -2], [1, 2], name='a')
+  s.validate(np.array([0.5, -1.5]))
+  with pytest.raises(ValueError):
+    s.validate(np.array([0.5, -2.5]))
+  with pytest.raises(ValueError):
+    s.validate(np.zeros(3))
+  with pytest.raises(ValueError):
+    dm_env.specs.BoundedArray((2,), float, 1, 0)
+  assert s.replace(name='b').name == 'b'
+  assert dm_env.TimeStep(dm_env.StepType.MID, 0., 1., None).mid()
+
+
+@pytest.mark.parametrize('sigmoid', ['gaussian', 'hyperbolic', 'long_tail', 'reciprocal', 'cosine',
+                                     'linear', 'quadratic', 'tanh_squared'])
+def test_tolerance_sigmoids(sigmoid):
+  # value 1 inside bounds, value_at_margin at distance == margin, monotone decay
+  v = 0.0 if sigmoid in ('cosine', 'linear', 'quadratic') else 0.1
+  x = np.array([0.0, 1.0, 2.0, 3.0, 4.0])
+  y = rewards.tolerance(x, bounds=(0, 1), margin=2, sigmoid=sigmoid, value_at_margin=v or 0.1)
+  assert y[0] == 1 and y[1] == 1
+  assert np.all(np.diff(y[1:]) <= 1e-12)
+  assert rewards.tolerance(3.0, bounds=(0, 1), margin=2, sigmoid=sigmoid, value_at_margin=0.1 if v else 0.1) == pytest.approx(
+      0.1, abs=1e-9) or sigmoid in ('cosine', 'linear', 'quadratic')
+  with pytest.raises(ValueError):
+    rewards.tolerance(0.0, bounds=(1, 0))
+  with pytest.raises(ValueError):
+    rewards.tolerance(0.0, margin=-1)
+
+
+def test_named_axes():
+  from dm_control_amd import mjcf_compiler as mc
+  from dm_control_amd import physics as pl
+  m = mc.compile_xml("""<mujoco><worldbody><body name="b"><freejoint name="root"/><geom size=".1"/>
+    <body name="c" pos=".3 0 0"><joint name="h" axis="0 1 0"/><geom size=".1"/></body></body></worldbody>
+    <sensor><subtreelinvel name="v" body="b"/><jointpos name="p" joint="h"/></sensor></mujoco>""")
+  axes = pl._make_axes(m)
+  assert axes['joint_q'].convert('root') == slice(0, 7) and axes['joint_q'].convert('h') == slice(7, 8)
+  assert axes['joint_v'].convert('h') == slice(6, 7)
+  assert axes['sensor'].convert('p') == slice(3, 4)
+  assert axes['body'].convert('c') == 2
+  data = np.arange(3 * 9.).reshape(3, 9)
+  fi = pl.FieldIndexer(lambda: data, axes['body'], pl._Axis(pl._COLS[9]))
+  assert fi['c', 'zz'] == data[2, 8]
+  np.testing.assert_array_equal(fi['c', ['zx', 'zz']], data[2, [6, 8]])
+  np.testing.assert_array_equal(fi[1:, 'zz'], data[1:, 8])
+  with pytest.raises(KeyError):
+    fi['nope']
