@@ -62,10 +62,10 @@ class BatchedPhysics:
 
   # -- info ---------------------------------------------------------------------
   def info(self):
-    a = np.zeros(10, dtype=np.int32)
+    a = np.zeros(11, dtype=np.int32)
     _native.check(_native.lib().dmc_batch_info(self._ptr, a.ctypes.data))
     keys = ['B', 'precision', 'lanes_per_env', 'waves_per_block', 'envs_per_block',
-            'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes']
+            'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes', 'static_id']
     return dict(zip(keys, (int(x) for x in a)))
 
   def _rows(self, name):
@@ -145,7 +145,7 @@ class BatchedPhysics:
 
   PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
                 'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
-                'euler', 'trailing_step1', 'store']
+                'euler', 'trailing_step1', 'store', 'kin_lev0', 'kin_lev1', 'kin_lev2', 'kin_lev3', 'kin_lev4+', 'x23']
 
   def prof_enable(self, on=True):
     _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))

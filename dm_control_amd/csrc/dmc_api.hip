@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -102,6 +103,14 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   g.lpe = lpe; g.waves = best_w; g.envs_per_block = best_w * epw;
   g.lds_bytes = (int)(tables + (size_t)g.envs_per_block * env_bytes);
   g.grid = (b->B + g.envs_per_block - 1) / g.envs_per_block;
+  g.static_id = -1;
+#if DMC_NSTATIC > 0
+  {
+    static const StepLayout baked[DMC_NSTATIC] = DMC_STATIC_LAYOUT_LIST;
+    for (int k = 0; k < DMC_NSTATIC; k++) if (!memcmp(&baked[k], &L, sizeof(StepLayout))) g.static_id = k;
+    if (getenv("DMC_NO_STATIC")) g.static_id = -1;
+  }
+#endif
   return 0;
 }
 
@@ -382,6 +391,7 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[0] = b->B; info[1] = b->precision; info[2] = b->geom.lpe; info[3] = b->geom.waves; info[4] = b->geom.envs_per_block;
   info[5] = b->geom.lds_bytes; info[6] = b->geom.grid; info[7] = L.d.nconmax; info[8] = L.d.njmax;
   info[9] = (int)((size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int));
+  info[10] = b->geom.static_id;
   return 0;
 }
 
@@ -453,8 +463,8 @@ extern "C" int dmc_batch_prof_enable(dmc_batch* b, int enable) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->d_prof) { (void)hipFree(b->d_prof); b->d_prof = nullptr; }
   if (!enable) return 0;
-  HIP_TRY(hipMalloc((void**)&b->d_prof, (size_t)PROF_N * b->B * sizeof(long long)));
-  HIP_TRY(hipMemset(b->d_prof, 0, (size_t)PROF_N * b->B * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&b->d_prof, (size_t)24 * b->B * sizeof(long long)));
+  HIP_TRY(hipMemset(b->d_prof, 0, (size_t)24 * b->B * sizeof(long long)));
   return 0;
 }
 // dst: (PROF_N) mean cycles per env, accumulated since enable; returns PROF_N in *n
@@ -463,9 +473,9 @@ extern "C" int dmc_batch_prof_get(dmc_batch* b, double* dst, int* n) {
   if (!b->d_prof) return fail("profiling not enabled");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<long long> tmp((size_t)PROF_N * b->B);
+  std::vector<long long> tmp((size_t)24 * b->B);
   HIP_TRY(hipMemcpy(tmp.data(), b->d_prof, tmp.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  for (int k = 0; k < PROF_N; k++) { double s = 0; for (int e = 0; e < b->B; e++) s += (double)tmp[(size_t)k * b->B + e]; dst[k] = s / b->B; }
-  *n = PROF_N;
+  for (int k = 0; k < 24; k++) { double s = 0; for (int e = 0; e < b->B; e++) s += (double)tmp[(size_t)k * b->B + e]; dst[k] = s / b->B; }
+  *n = 24;
   return 0;
 }

@@ -210,12 +210,45 @@ template <typename T> DMC_DEV T dot_n(const T* a, const T* b, int n) {
 // ---------------------------------------------------------------------------
 // group primitives (LPE lanes of one wave)
 // ---------------------------------------------------------------------------
+#ifndef DMC_HOST_EMU
+// DPP cross-lane moves inside a 16-lane row (no LDS traffic, ~VALU latency)
+template <int CTRL> DMC_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> DMC_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> DMC_DEV double dpp_f(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+DMC_DEV int dpp_v(int v, int) { return v; }
+#endif
+// Sum over the LPE lanes of a group; every lane receives the total.  Same
+// pairing tree as an xor butterfly (1, 2, 4, 8 inside a row via DPP quad_perm /
+// row_half_mirror / row_mirror, then 16 and 32 via ds_bpermute).
 template <int LPE, typename V> DMC_DEV V group_sum(V v) {
+#ifndef DMC_HOST_EMU
+  if (LPE >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (LPE >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (LPE >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
+  if (LPE >= 16) v += dpp_f<0x140>(v);  // row_mirror
+  if (LPE >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPE >= 64) v += __shfl_xor(v, 32, 64);
+#endif
+  return v;
+}
+template <int LPE> DMC_DEV int group_sum_i(int v) {
 #ifndef DMC_HOST_EMU
 #pragma unroll
   for (int o = LPE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPE);
 #endif
   return v;
+}
+// value held by lane `k` of the group (k group-uniform)
+template <int LPE, typename V> DMC_DEV V group_bcast(V v, int k) {
+#ifndef DMC_HOST_EMU
+  return __shfl(v, k, LPE);
+#else
+  (void)k; return v;
+#endif
 }
 template <int LPE> DMC_DEV int group_max(int v) {
 #ifndef DMC_HOST_EMU
@@ -240,42 +273,90 @@ template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 // ---------------------------------------------------------------------------
 // out-of-line LDS routines shared by several call sites
 // ---------------------------------------------------------------------------
-// in-place right-looking Cholesky of the lower triangle of A (n x n), same
-// operation order as the oracle's left-looking loop
+// In-place Cholesky of the lower triangle of A (n x n), same operation order as
+// the oracle.  On exit: strict lower part = L, diagonal = 1/L[k][k], and (fast
+// path) the strict UPPER part holds L transposed (U[k][i] = L[i][k]).
+//   n <= LPE : lane i owns row i; ONE wave fence per column.  Column k of the
+//              rows below is read unscaled and scaled redundantly by each reader
+//              (x * inv, identical rounding), scaled values are parked in the
+//              upper triangle so no lane overwrites what another still reads;
+//              the diagonal store is delayed by one column for the same reason.
+//   n >  LPE : generic right-looking form, rows strided over lanes.
 template <typename T, int LPE>
 DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
+  if (n <= LPE) {
+    const int i = lane;
+    T prev_inv = 0;
+    for (int k = 0; k < n; k++) {
+      DMC_WSYNC();
+      if (k > 0 && i == k - 1) A[(k - 1)*n + (k - 1)] = prev_inv;
+      T akk = A[k*n + k];
+      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+      const T inv = 1 / t_sqrt(akk);
+      prev_inv = inv;
+      if (i > k && i < n) {
+        const T lik = A[i*n + k] * inv;
+        for (int j = k + 1; j <= i; j++) A[i*n + j] -= lik * (A[j*n + k] * inv);
+        A[k*n + i] = lik;            // L[i][k] parked in the upper triangle
+      }
+    }
+    DMC_WSYNC();
+    if (i == n - 1) A[(n - 1)*n + (n - 1)] = prev_inv;
+    // move the parked column values into the lower triangle as well
+    if (i < n) for (int k = 0; k < i; k++) A[i*n + k] = A[k*n + i];
+    DMC_WSYNC();
+    return;
+  }
   for (int k = 0; k < n; k++) {
     T akk = A[k*n + k];
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-    const T lkk = t_sqrt(akk);
+    const T inv = 1 / t_sqrt(akk);
     DMC_WSYNC();
-    if (lane == 0) A[k*n + k] = lkk;
-    for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] / lkk;
+    if (lane == 0) A[k*n + k] = inv;
+    for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] * inv;
     DMC_WSYNC();
-    const int m = n - k - 1;
-    // trailing update A[i][j] -= L[i][k] L[j][k], k < j <= i: walk rows per lane
     for (int i = k + 1 + lane; i < n; i += LPE) {
       const T lik = A[i*n + k];
       for (int j = k + 1; j <= i; j++) A[i*n + j] -= lik*A[j*n + k];
     }
-    (void)m;
     DMC_WSYNC();
   }
 }
-// x = (L L')^-1 b (x may alias b)
+// x = (L L')^-1 b (x may alias b); Lm as produced by chol_factor_lds
+//   n <= LPE : lane i carries x[i] in a register; the pivot value travels by a
+//              cross-lane broadcast, no LDS round trip, no fence inside the loops.
 template <typename T, int LPE>
 DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b, int n, int lane) {
+  if (n <= LPE && LPE > 1) {
+    const int i = lane;
+    T sreg = i < n ? b[i] : (T)0;
+    for (int k = 0; k < n; k++) {
+      const T lik = (i > k && i < n) ? Lm[i*n + k] : (T)0;
+      const T xk = group_bcast<LPE>(sreg, k) * Lm[k*n + k];
+      if (i == k) sreg = xk;
+      if (i > k && i < n) sreg -= lik*xk;
+    }
+    for (int k = n - 1; k >= 0; k--) {
+      const T lki = i < k ? Lm[k*n + i] : (T)0;
+      const T xk = group_bcast<LPE>(sreg, k) * Lm[k*n + k];
+      if (i == k) sreg = xk;
+      if (i < k) sreg -= lki*xk;
+    }
+    if (i < n) x[i] = sreg;
+    DMC_WSYNC();
+    return;
+  }
   for (int i = lane; i < n; i += LPE) x[i] = b[i];
   DMC_WSYNC();
   for (int k = 0; k < n; k++) {
-    const T xk = x[k] / Lm[k*n + k];
+    const T xk = x[k] * Lm[k*n + k];
     DMC_WSYNC();
     if (lane == 0) x[k] = xk;
     for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[i*n + k]*xk;
     DMC_WSYNC();
   }
   for (int k = n - 1; k >= 0; k--) {
-    const T xk = x[k] / Lm[k*n + k];
+    const T xk = x[k] * Lm[k*n + k];
     DMC_WSYNC();
     if (lane == 0) x[k] = xk;
     for (int i = lane; i < k; i += LPE) x[i] -= Lm[k*n + i]*xk;
@@ -1601,7 +1682,7 @@ struct StepCore {
   }
   DMC_DEV void prof_end(const StepIO<T>& io, int env) {
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
-    if (io.prof && lane == 0) for (int k = 0; k < PROF_N; k++) io.prof[(size_t)k*io.B + env] += prof_[k];
+    if (io.prof && lane == 0) for (int k = 0; k < 24; k++) io.prof[(size_t)k*io.B + env] += prof_[k];
 #else
     (void)io; (void)env;
 #endif

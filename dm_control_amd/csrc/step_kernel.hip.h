@@ -14,16 +14,28 @@ struct LaunchGeom {
   int envs_per_block;  // waves * 64 / lpe
   int lds_bytes;       // dynamic LDS per workgroup
   int grid;            // workgroups
+  int static_id;       // >= 0: layout equals the baked layout with this id (specialised kernel)
 };
 
 #ifndef DMC_MIN_WAVES
 #define DMC_MIN_WAVES 2   // waves per SIMD the register allocator must leave room for
 #endif
 
+// Build-generated: LDS layouts of the suite models, baked in as compile-time
+// constants (dm_control_amd/build.py -> gen_static_layouts).  A batch whose
+// runtime layout equals a baked one runs the specialised instantiation, in which
+// every LDS offset is an immediate and every size a constant.
+#if __has_include("static_layouts.gen.h")
+#include "static_layouts.gen.h"
+#endif
+#ifndef DMC_NSTATIC
+#define DMC_NSTATIC 0
+#endif
+
 template <typename T, int LPE>
-__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
-step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
-            StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
+__device__ __forceinline__ void step_kernel_body(const StepLayout& L, const StepOpts<T>& o, const int* __restrict__ g_mi,
+                                                 const T* __restrict__ g_mr, const StepIO<T>& io, int nstep, int legacy,
+                                                 int mode, int outmask) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* mi = reinterpret_cast<int*>(smem);
   T* mr = reinterpret_cast<T*>(smem + (size_t)L.n_mi * sizeof(int));
@@ -34,9 +46,8 @@ step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* 
   __syncthreads();
   const int epb = nthr / LPE;
   const int g = tid / LPE, lane = tid % LPE;
-  // XCD-aware env mapping: consecutive workgroups land on different XCDs
-  // (block b -> XCD b % 8); envs of one workgroup stay contiguous so that each
-  // SoA row is touched in epb-element segments.
+  // consecutive workgroups land on different XCDs (block b -> XCD b % 8); envs of
+  // one workgroup stay contiguous so each SoA row is touched in epb-element segments
   const int env = blockIdx.x * epb + g;
   if (env >= io.B) return;
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
@@ -46,6 +57,37 @@ step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* 
   StepCore<T, LPE> core(L, o, mi, mr, s, si, lane);
   core.run(io, env, nstep, legacy, mode, outmask);
 }
+
+template <typename T, int LPE>
+__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
+step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
+            StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
+  step_kernel_body<T, LPE>(L, o, g_mi, g_mr, io, nstep, legacy, mode, outmask);
+}
+
+#if DMC_NSTATIC > 0
+template <int SID> struct StaticLayout;
+#define DMC_DEF_STATIC(ID)                                                            \
+  static __device__ const StepLayout kStaticLayout##ID = DMC_STATIC_LAYOUT_##ID;     \
+  template <> struct StaticLayout<ID> {                                               \
+    static __device__ __forceinline__ const StepLayout& get() { return kStaticLayout##ID; } \
+  };
+DMC_DEF_STATIC(0)
+#if DMC_NSTATIC > 1
+DMC_DEF_STATIC(1)
+#endif
+#if DMC_NSTATIC > 2
+DMC_DEF_STATIC(2)
+#endif
+#undef DMC_DEF_STATIC
+
+template <typename T, int LPE, int SID>
+__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
+step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
+                   StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
+  step_kernel_body<T, LPE>(StaticLayout<SID>::get(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask);
+}
+#endif
 
 template <typename T>
 inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<T>& o,
@@ -59,11 +101,27 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
     hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, L, o, g_mi, g_mr, io, nstep,    \
                        legacy, mode, outmask);                                                                  \
   }
+#define DMC_LAUNCH_STATIC(LPE, SID)                                                                             \
+  {                                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_static<T, LPE, SID>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
+    if (e != hipSuccess) return e;                                                                              \
+    hipLaunchKernelGGL((step_kernel_static<T, LPE, SID>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, io,  \
+                       nstep, legacy, mode, outmask);                                                           \
+    return hipGetLastError();                                                                                   \
+  }
+#if DMC_NSTATIC > 0
+  // specialised instantiations exist for (static id, lanes) pairs listed in DMC_STATIC_INSTANCES
+#define DMC_X(SID, LPE) if (g.static_id == SID && g.lpe == LPE) DMC_LAUNCH_STATIC(LPE, SID)
+  DMC_STATIC_INSTANCES(DMC_X)
+#undef DMC_X
+#endif
   if (g.lpe == 64) DMC_LAUNCH(64)
   else if (g.lpe == 32) DMC_LAUNCH(32)
   else if (g.lpe == 16) DMC_LAUNCH(16)
   else return hipErrorInvalidValue;
 #undef DMC_LAUNCH
+#undef DMC_LAUNCH_STATIC
   return hipGetLastError();
 }
 

@@ -88,8 +88,9 @@ int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value);
 
 int dmc_batch_sync(dmc_batch* b);
 
-/* info[0..9] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
- * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes}. */
+/* info[0..10] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
+ * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id}
+ * (static_id >= 0: a model-specialised kernel instantiation is in use). */
 int dmc_batch_info(const dmc_batch* b, int* info);
 
 /* Time `reps` back-to-back step launches with hipEvents on `hip_stream`;

@@ -220,19 +220,21 @@ static void dof_com(double* res, const double* axis, const double* offset) {
 static double dot_n(const double* a, const double* b, int n) {
   double s = 0; for (int i = 0; i < n; i++) s += a[i]*b[i]; return s;
 }
-/* dense Cholesky A = L L' (lower, row-major n x n); returns rank deficiency */
+/* dense Cholesky A = L L' (lower, row-major n x n); the DIAGONAL of L holds
+ * 1/L[j][j] (MuJoCo keeps the inverse diagonal too: qLDiagInv) and the strict
+ * lower part L[i][j] = t * (1/L[j][j]); returns rank deficiency */
 static int chol_factor(double* L, const double* A, int n) {
   int bad = 0;
   for (int j = 0; j < n; j++) {
     double s = A[j*n + j];
     for (int k = 0; k < j; k++) s -= L[j*n + k]*L[j*n + k];
     if (s < MINVAL) { s = MINVAL; bad++; }
-    double ljj = sqrt(s);
-    L[j*n + j] = ljj;
+    double inv = 1 / sqrt(s);
+    L[j*n + j] = inv;
     for (int i = j + 1; i < n; i++) {
       double t = A[i*n + j];
       for (int k = 0; k < j; k++) t -= L[i*n + k]*L[j*n + k];
-      L[i*n + j] = t / ljj;
+      L[i*n + j] = t * inv;
     }
     for (int i = 0; i < j; i++) L[i*n + j] = 0;
   }
@@ -242,12 +244,12 @@ static void chol_solve(double* x, const double* L, const double* b, int n) {
   for (int i = 0; i < n; i++) {
     double s = b[i];
     for (int k = 0; k < i; k++) s -= L[i*n + k]*x[k];
-    x[i] = s / L[i*n + i];
+    x[i] = s * L[i*n + i];
   }
   for (int i = n - 1; i >= 0; i--) {   /* k descending: the order a column-oriented parallel solve produces */
     double s = x[i];
     for (int k = n - 1; k > i; k--) s -= L[k*n + i]*x[k];
-    x[i] = s / L[i*n + i];
+    x[i] = s * L[i*n + i];
   }
 }
 
