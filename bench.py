@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_STEP = 260          # cheetah fp32 SoA, state + ctrl in, state + sensordata out
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 BATCH_PER_GPU = 4096
 
@@ -97,6 +98,15 @@ def cpu_baseline(model, q0, action_fn, nthreads, target_s=8.0, max_steps=1000):
                      % (B, T, dt))
 
 
+def _pmc_traffic():
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+  try:
+    with open(PMC_TRAFFIC_FILE) as f:
+      return json.load(f)['hbm_bytes_per_launch']
+  except Exception:  # pylint: disable=broad-except
+    return None
+
+
 def main():
   args = parse()
   import torch
@@ -164,6 +174,28 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
+  # ---- rollout leg: the same K env-steps, same resident action tensor, ONE launch per
+  # chunk of <= 250 steps, per-step qpos/qvel/sensordata written to HBM (dmc_batch_rollout)
+  chunk = min(250, K)
+  nchunks = max(1, K // chunk)
+  qs = torch.empty((chunk, model.nq, B), dtype=tdtype, device=dev)
+  vs = torch.empty((chunk, model.nv, B), dtype=tdtype, device=dev)
+  ss = torch.empty((chunk, model.nsensordata, B), dtype=tdtype, device=dev)
+  phys.rollout(min(W, chunk) or 1, 1, actions[0:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  r0 = time.perf_counter()
+  for c in range(nchunks):
+    phys.rollout(chunk, 1, actions[W + c*chunk:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  rollout_elapsed = time.perf_counter() - r0
+  if world > 1:
+    t = torch.tensor([rollout_elapsed], dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    rollout_elapsed = float(t.item())
   warn = phys.get('warning').sum(axis=0)
 
   if rank == 0:
@@ -179,10 +211,15 @@ def main():
                    'batch_per_gpu': B, 'n_sub_steps': 1, 'info': phys.info()},
         'physics_steps_per_s': value,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(),
                      'kernel_ms_avg': kernel_ms, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_STEP * B,
                      'note': 'latency/LDS/VALU-bound kernel: compulsory HBM traffic is 260 B per env-step'},
         'warnings_after_run': [int(x) for x in warn],
+        'rollout': {'value': world * B * nchunks * chunk / rollout_elapsed, 'unit': 'env-steps/s',
+                    'steps': nchunks * chunk, 'launches': nchunks,
+                    'note': 'same workload via dmc_batch_rollout: per-step actions read from / per-step '
+                            'qpos,qvel,sensordata written to HBM, no launch per step; `value` above is the '
+                            'host-in-the-loop mode (one Physics.step() launch per env-step)'},
     }
     # ---- parity vs the CPU oracle on the first envs (checker only, untimed) -------
     try:

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'libdmc_hip_%s.so' % _VARIANT if _VARIANT else 'l
 
 EXPORTS = [
     'dmc_last_error', 'dmc_model_create', 'dmc_model_destroy', 'dmc_batch_create',
-    'dmc_batch_destroy', 'dmc_batch_step', 'dmc_batch_forward', 'dmc_batch_reset',
+    'dmc_batch_destroy', 'dmc_batch_step', 'dmc_batch_rollout', 'dmc_batch_forward', 'dmc_batch_reset',
     'dmc_batch_field_rows', 'dmc_batch_get', 'dmc_batch_set', 'dmc_batch_get_int',
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
@@ -49,6 +49,7 @@ def lib():
   L.dmc_batch_destroy.argtypes = [vp]
   L.dmc_batch_step.argtypes = [vp, ci, ci, vp]
   L.dmc_batch_forward.argtypes = [vp, ci, vp]
+  L.dmc_batch_rollout.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
   L.dmc_batch_reset.argtypes = [vp, vp, ci]
   L.dmc_batch_field_rows.argtypes = [vp, cs, ctypes.POINTER(ci), ctypes.POINTER(ci)]
   L.dmc_batch_get.argtypes = [vp, cs, vp]

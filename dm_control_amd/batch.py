@@ -123,6 +123,13 @@ class BatchedPhysics:
   def step(self, nstep=1, stream=None):
     _native.check(_native.lib().dmc_batch_step(self._ptr, int(nstep), int(self.legacy_step), stream))
 
+  def rollout(self, nsteps, n_sub_steps=1, ctrl_seq=None, qpos_seq=None, qvel_seq=None, sensordata_seq=None,
+              stream=None):
+    """`nsteps` env-steps in ONE launch; *_seq are device pointers to (nsteps, rows, B)
+    arrays in batch precision (None: skip)."""
+    _native.check(_native.lib().dmc_batch_rollout(self._ptr, int(nsteps), int(n_sub_steps), ctrl_seq, qpos_seq,
+                                                  qvel_seq, sensordata_seq, stream))
+
   def forward(self, disable_actuation=False, stream=None):
     _native.check(_native.lib().dmc_batch_forward(self._ptr, int(disable_actuation), stream))
 

@@ -17,9 +17,9 @@
 
 namespace dmc {
 hipError_t launch_step_f32(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<float>& o,
-                           const int* g_mi, const float* g_mr, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask);
+                           const int* g_mi, const float* g_mr, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask, int nsub);
 hipError_t launch_step_f64(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<double>& o,
-                           const int* g_mi, const double* g_mr, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask);
+                           const int* g_mi, const double* g_mr, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask, int nsub);
 }  // namespace dmc
 
 using namespace dmc;
@@ -204,15 +204,21 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
 }
 
-static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream) {
+struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsub; };
+static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq = nullptr) {
   HIP_TRY(hipSetDevice(b->device));
   hipError_t e;
+  const int nsub = sq ? sq->nsub : 1;
   if (b->precision == 64) {
     StepIO<double> io; fill_io(b, &io);
-    e = launch_step_f64(b->geom, (hipStream_t)stream, b->tb.L, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask);
+    io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;
+    io.qvel_seq = sq ? (double*)sq->qvel : nullptr; io.sensor_seq = sq ? (double*)sq->sensor : nullptr;
+    e = launch_step_f64(b->geom, (hipStream_t)stream, b->tb.L, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
   } else {
     StepIO<float> io; fill_io(b, &io);
-    e = launch_step_f32(b->geom, (hipStream_t)stream, b->tb.L, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask);
+    io.ctrl_seq = sq ? (const float*)sq->ctrl : nullptr; io.qpos_seq = sq ? (float*)sq->qpos : nullptr;
+    io.qvel_seq = sq ? (float*)sq->qvel : nullptr; io.sensor_seq = sq ? (float*)sq->sensor : nullptr;
+    e = launch_step_f32(b->geom, (hipStream_t)stream, b->tb.L, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e), -2);
   return 0;
@@ -226,6 +232,13 @@ extern "C" int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hi
 extern "C" int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream) {
   if (!b) return fail("null batch");
   return launch(b, 0, 0, disable_actuation ? 2 : 1, hip_stream);
+}
+extern "C" int dmc_batch_rollout(dmc_batch* b, int nsteps, int n_sub_steps, const void* ctrl_seq, void* qpos_seq,
+                                 void* qvel_seq, void* sensordata_seq, void* hip_stream) {
+  if (!b) return fail("null batch");
+  if (nsteps < 1 || n_sub_steps < 1) return fail("nsteps and n_sub_steps must be >= 1");
+  SeqArgs sq = {ctrl_seq, qpos_seq, qvel_seq, sensordata_seq, n_sub_steps};
+  return launch(b, nsteps, 1, 3, hip_stream, &sq);
 }
 extern "C" int dmc_batch_sync(dmc_batch* b) {
   if (!b) return fail("null batch");

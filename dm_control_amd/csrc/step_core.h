@@ -74,6 +74,8 @@ struct StepIO {
   T *site_xpos, *site_xmat, *subtree_com, *qacc, *actuator_force, *qfrc_actuator;
   T *qfrc_bias, *qfrc_constraint, *contact_dist, *contact_pos, *contact_frame;
   int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
+  // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
+  const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   long long* prof;   // optional (DMC_PROFILE builds): (PROF_N, B) cycle counters
   T* debug;      // optional: (n_sr, ndebug) dump of the env scratch after forward
   int* debug_i;  // optional: (n_si, ndebug)
@@ -1655,9 +1657,9 @@ struct StepCore {
   }
 
   // ---- pipeline -----------------------------------------------------------------------------
-  // One pass of the pipeline.  partial = the trailing mj_step1 of a legacy
-  // Physics.step(): position + velocity stage for the outputs only.
-  DMC_DEV void forward(bool disable_actuation, bool partial, int outmask, bool skipsensor) {
+  // Position + velocity stage (mj_step1 without the checks).  partial = only what
+  // the outputs need (the trailing mj_step1 of a legacy Physics.step()).
+  DMC_DEV void stage_posvel(bool partial, int outmask, bool skipsensor) {
     kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM);
     if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
     if (!partial || (outmask & OUT_CONTACT)) { collision(); DMC_PROF(PROF_COLL); }
@@ -1668,11 +1670,12 @@ struct StepCore {
     if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); }
     if (!skipsensor) sensors(DMC_STAGE_VEL);
     DMC_PROF(PROF_SENS);
-    if (!partial) {
-      fwd_actuation(disable_actuation); DMC_PROF(PROF_ACT); fwd_acceleration(); DMC_PROF(PROF_ACC); fwd_constraint();
-      if (!skipsensor) sensors_acc();
-      DMC_PROF(PROF_SENS);
-    }
+  }
+  // Acceleration stage (mj_step2 without the integrator)
+  DMC_DEV void stage_acc(bool disable_actuation, bool skipsensor) {
+    fwd_actuation(disable_actuation); DMC_PROF(PROF_ACT); fwd_acceleration(); DMC_PROF(PROF_ACC); fwd_constraint();
+    if (!skipsensor) sensors_acc();
+    DMC_PROF(PROF_SENS);
   }
   DMC_DEV void prof_begin() {
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
@@ -1687,35 +1690,57 @@ struct StepCore {
     (void)io; (void)env;
 #endif
   }
-  // mode: 0 = Physics.step(nstep) ; 1 = mj_forward ; 2 = mj_forward with actuation disabled
-  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask) {
+  DMC_DEV void load_ctrl_seq(const StepIO<T>& io, int env, int t) {
+    const int B = io.B, nu = L.d.nu;
+    DMC_WSYNC();
+    FOR_LANES(i, nu) S(ctrl)[i] = io.ctrl_seq[((size_t)t*nu + i)*B + env];
+    DMC_WSYNC();
+  }
+  DMC_DEV void store_seq(const StepIO<T>& io, int env, int t) {
+    const int B = io.B;
+    if (io.qpos_seq) FOR_LANES(i, L.d.nq) io.qpos_seq[((size_t)t*L.d.nq + i)*B + env] = S(qpos)[i];
+    if (io.qvel_seq) FOR_LANES(i, L.d.nv) io.qvel_seq[((size_t)t*L.d.nv + i)*B + env] = S(qvel)[i];
+    if (io.sensor_seq) FOR_LANES(i, L.d.nsensordata) io.sensor_seq[((size_t)t*L.d.nsensordata + i)*B + env] = S(sensordata)[i];
+  }
+  // mode: 0 = Physics.step(nstep) ; 1 = mj_forward ; 2 = mj_forward with actuation disabled ;
+  //       3 = rollout: nstep env-steps of `nsub` substeps each, controls read from and
+  //           per-step results written to (T, rows, B) sequence buffers -- legacy ordering
+  //           (mj_step2 ... mj_step1) with NO redundant pass: the mj_step1 that closes
+  //           env-step t is the position/velocity stage that opens env-step t+1.
+  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub) {
     prof_begin();
     load_state(io, env);
     DMC_PROF(PROF_LOAD);
-    // passes through the single forward() call site: nstep full passes (+ the
-    // trailing mj_step1 pass for legacy_step), or one full pass for mj_forward
-    const int npass = mode != 0 ? 1 : nstep + (legacy ? 1 : 0);
+    const bool stepping = mode == 0 || mode == 3;
+    const int ntotal = mode == 3 ? nstep*nsub : nstep;
+    // passes through the single stage_posvel()/stage_acc() call sites: ntotal full
+    // passes (+ the trailing mj_step1 pass for legacy_step), or one pass for mj_forward
+    const int npass = !stepping ? 1 : ntotal + ((legacy || mode == 3) ? 1 : 0);
     for (int it = 0; it < npass; it++) {
-      const bool partial = mode == 0 && it == nstep;
-      if (mode == 0) check_pos_vel();
-      const int nstage = (mode == 0 && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
+      const bool partial = stepping && it == ntotal;
+      if (mode == 3 && !partial && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
+      if (stepping) check_pos_vel();
+      const int nstage = (stepping && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
       int stage = 0, retried = 0;
       while (stage < nstage) {
-        forward(mode == 2, partial, outmask, stage > 0);
-        if (stage == 0 && mode == 0 && !partial && !retried && bad_acc()) {
+        stage_posvel(partial, outmask, stage > 0);
+        if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
+        if (partial) break;
+        stage_acc(mode == 2, stage > 0);
+        if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
           if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
         }
-        if (stage == 0 && mode == 0 && !partial && it == nstep - 1) { dump_debug(io, env); if (!legacy) store_outputs(io, env, outmask); }
+        if (stage == 0 && stepping && it == ntotal - 1) { dump_debug(io, env); if (mode == 0 && !legacy) store_outputs(io, env, outmask); }
         if (nstage > 1) rk4_stage(stage);
         stage++;
       }
-      if (mode != 0 || partial) break;
+      if (!stepping || partial) break;
       if (nstage > 1) rk4_finish(); else euler();
       DMC_PROF(PROF_EULER);
     }
-    if (mode != 0) dump_debug(io, env);
-    if (mode != 0 || legacy) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
+    if (!stepping) dump_debug(io, env);
+    if (!stepping || legacy || mode == 3) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
     store_state(io, env);
     DMC_PROF(PROF_STORE);
     prof_end(io, env);

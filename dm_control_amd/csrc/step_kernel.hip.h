@@ -35,7 +35,7 @@ struct LaunchGeom {
 template <typename T, int LPE>
 __device__ __forceinline__ void step_kernel_body(const StepLayout& L, const StepOpts<T>& o, const int* __restrict__ g_mi,
                                                  const T* __restrict__ g_mr, const StepIO<T>& io, int nstep, int legacy,
-                                                 int mode, int outmask) {
+                                                 int mode, int outmask, int nsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* mi = reinterpret_cast<int*>(smem);
   T* mr = reinterpret_cast<T*>(smem + (size_t)L.n_mi * sizeof(int));
@@ -55,14 +55,14 @@ __device__ __forceinline__ void step_kernel_body(const StepLayout& L, const Step
   T* s = reinterpret_cast<T*>(base);
   int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
   StepCore<T, LPE> core(L, o, mi, mr, s, si, lane);
-  core.run(io, env, nstep, legacy, mode, outmask);
+  core.run(io, env, nstep, legacy, mode, outmask, nsub);
 }
 
 template <typename T, int LPE>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
-            StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
-  step_kernel_body<T, LPE>(L, o, g_mi, g_mr, io, nstep, legacy, mode, outmask);
+            StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
+  step_kernel_body<T, LPE>(L, o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
 }
 
 #if DMC_NSTATIC > 0
@@ -84,14 +84,14 @@ DMC_DEF_STATIC(2)
 template <typename T, int LPE, int SID>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
-                   StepIO<T> io, int nstep, int legacy, int mode, int outmask) {
-  step_kernel_body<T, LPE>(StaticLayout<SID>::get(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask);
+                   StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
+  step_kernel_body<T, LPE>(StaticLayout<SID>::get(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
 }
 #endif
 
 template <typename T>
 inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<T>& o,
-                                const int* g_mi, const T* g_mr, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask) {
+                                const int* g_mi, const T* g_mr, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
   const dim3 grid(g.grid), block(g.waves * 64);
 #define DMC_LAUNCH(LPE)                                                                                         \
   {                                                                                                             \
@@ -99,7 +99,7 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, L, o, g_mi, g_mr, io, nstep,    \
-                       legacy, mode, outmask);                                                                  \
+                       legacy, mode, outmask, nsub);                                                                  \
   }
 #define DMC_LAUNCH_STATIC(LPE, SID)                                                                             \
   {                                                                                                             \
@@ -107,7 +107,7 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
     hipLaunchKernelGGL((step_kernel_static<T, LPE, SID>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, io,  \
-                       nstep, legacy, mode, outmask);                                                           \
+                       nstep, legacy, mode, outmask, nsub);                                                           \
     return hipGetLastError();                                                                                   \
   }
 #if DMC_NSTATIC > 0

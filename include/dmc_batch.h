@@ -48,6 +48,16 @@ void dmc_batch_destroy(dmc_batch* b);
  * hip_stream: hipStream_t to launch on (NULL = default stream).  Asynchronous. */
 int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream);
 
+/* Random-action / open-loop rollouts without a launch per step: plays `nsteps`
+ * env-steps of `n_sub_steps` physics steps each (the loop of
+ * control.Environment.step, dm_control/rl/control.py:99-127, with the task's
+ * before_step = set_control) in ONE launch.  ctrl_seq: device (nsteps, nu, B) or
+ * NULL (keep ctrl); *_seq outputs: device (nsteps, rows, B) or NULL.  Each
+ * env-step has legacy_step semantics; the closing mj_step1 of step t doubles as
+ * the opening position/velocity stage of step t+1, so nothing is computed twice. */
+int dmc_batch_rollout(dmc_batch* b, int nsteps, int n_sub_steps, const void* ctrl_seq, void* qpos_seq,
+                      void* qvel_seq, void* sensordata_seq, void* hip_stream);
+
 /* Replaces mujoco.mj_forward (engine.py:343); disable_actuation != 0 mirrors the
  * mjDSBL_ACTUATION context used by Physics.reset/after_reset (engine.py:326-333). */
 int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);

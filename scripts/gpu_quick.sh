@@ -9,6 +9,6 @@ for l in sys.stdin:
     try: r=json.loads(l)
     except Exception: print(l.strip()[:200]); continue
     i=r.get('info',{})
-    print('prec',r.get('prec'),'lanes',r.get('lanes'),'nstep',r.get('nstep'),'ms %.4f'%r.get('ms_per_launch',-1),'Msteps/s %.2f'%(r.get('steps_per_s',0)/1e6),'epb',i.get('envs_per_block'),'lds',i.get('lds_bytes_per_block'),'grid',i.get('grid'), r.get('error',''))
+    print('prec',r.get('prec'),'lanes',r.get('lanes'),'nstep',r.get('nstep'),'ms %.4f'%r.get('ms_per_launch',-1),'Msteps/s %.2f'%(r.get('steps_per_s',0)/1e6),'rollout %.2f'%(r.get('rollout_steps_per_s',0)/1e6),'epb',i.get('envs_per_block'),'static',i.get('static_id'), r.get('error',''))
 "
 if [ -n "$PHASES" ]; then timeout 600 python scripts/phase_profile.py 2>&1 | head -45; fi

@@ -41,6 +41,16 @@ def probe(prec, lanes, nconmax, njmax, nstep=1, reps=50, stats=False):
                warnings=b.get('warning').sum(axis=0).tolist())
   ms = b.time_steps(nstep, reps)
   res.update(ms_per_launch=ms, steps_per_s=B * nstep / (ms * 1e-3))
+  if os.environ.get('ROLLOUT'):
+    import torch, time
+    T = 200
+    td = torch.float32 if prec == 32 else torch.float64
+    ctrl = (torch.rand((T, m.nu, B), device='cuda', dtype=td) * 2 - 1)
+    ss = torch.zeros((T, m.nsensordata, B), dtype=td, device='cuda')
+    qs = torch.zeros((T, m.nq, B), dtype=td, device='cuda'); vs = torch.zeros((T, m.nv, B), dtype=td, device='cuda')
+    b.rollout(T, 1, ctrl.data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr()); b.sync()
+    t0 = time.perf_counter(); b.rollout(T, 1, ctrl.data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr()); b.sync(); dt = time.perf_counter() - t0
+    res.update(rollout_steps_per_s=B * T / dt)
   b.close()
   return res
 

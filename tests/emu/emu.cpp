@@ -58,7 +58,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   StepIO<T> io;
   io.B = 1;
   io.qpos = buf[0].data(); io.qvel = buf[1].data(); io.ctrl = buf[2].data(); io.qacc_warmstart = buf[3].data();
-  io.qfrc_applied = buf[4].data(); double tm = f[5][0]; io.time = &tm; io.prof = nullptr;
+  io.qfrc_applied = buf[4].data(); double tm = f[5][0]; io.time = &tm; io.prof = nullptr; io.ctrl_seq = nullptr; io.qpos_seq = nullptr; io.qvel_seq = nullptr; io.sensor_seq = nullptr;
   io.sensordata = buf[6].data(); io.xpos = buf[7].data(); io.xquat = buf[8].data(); io.xmat = buf[9].data();
   io.xipos = buf[10].data(); io.geom_xpos = buf[11].data(); io.geom_xmat = buf[12].data();
   io.site_xpos = buf[13].data(); io.site_xmat = buf[14].data(); io.subtree_com = buf[15].data();
@@ -68,7 +68,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   StepCore<T, 1> core(L, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
-  core.run(io, 0, nstep, legacy, mode, OUT_ALL);
+  core.run(io, 0, nstep, legacy, mode, OUT_ALL, 1);
   for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
   f[5][0] = tm;
   if (dbg) { for (int i = 0; i < L.n_sr; i++) dbg[i] = (double)dbuf[i]; for (int i = 0; i < L.n_si; i++) dbgi[i] = dibuf[i]; }

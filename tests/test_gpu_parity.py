@@ -372,3 +372,38 @@ def test_zero_copy_device_binding(cheetah):
   a.step(5)
   np.testing.assert_array_equal(a.get('qpos'), b.get('qpos'))
   a.close(); b.close()
+
+
+@pytest.mark.parametrize('precision,nsub', [(32, 1), (64, 3)])
+def test_rollout_equals_per_step_loop(cheetah, precision, nsub):
+  """One-launch rollout (per-step controls and outputs in (T, rows, B) device
+  buffers) must reproduce the launch-per-step loop bit for bit."""
+  import torch
+  m = cheetah
+  B, T = 16, 25
+  td = torch.float32 if precision == 32 else torch.float64
+  q = _cheetah_init(m, B, seed0=20)
+  rs = np.random.RandomState(1)
+  acts = rs.uniform(-1, 1, (T, B, m.nu))
+  loop = _batch(m, B, precision=precision)
+  loop.set('qpos', q)
+  want_q, want_v, want_s = [], [], []
+  for t in range(T):
+    loop.set_control(acts[t])
+    loop.step(nsub)
+    want_q.append(loop.get('qpos')); want_v.append(loop.get('qvel')); want_s.append(loop.get('sensordata'))
+  ro = _batch(m, B, precision=precision)
+  ro.set('qpos', q)
+  ctrl = torch.from_numpy(np.ascontiguousarray(acts.transpose(0, 2, 1))).to('cuda').to(td).contiguous()
+  qs = torch.zeros((T, m.nq, B), dtype=td, device='cuda')
+  vs = torch.zeros((T, m.nv, B), dtype=td, device='cuda')
+  ss = torch.zeros((T, m.nsensordata, B), dtype=td, device='cuda')
+  ro.rollout(T, nsub, ctrl.data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr())
+  ro.sync()
+  np.testing.assert_array_equal(qs.cpu().numpy().transpose(0, 2, 1).astype(np.float64), np.stack(want_q))
+  np.testing.assert_array_equal(vs.cpu().numpy().transpose(0, 2, 1).astype(np.float64), np.stack(want_v))
+  np.testing.assert_array_equal(ss.cpu().numpy().transpose(0, 2, 1).astype(np.float64), np.stack(want_s))
+  np.testing.assert_array_equal(ro.get('qpos'), loop.get('qpos'))
+  np.testing.assert_array_equal(ro.get('sensordata'), loop.get('sensordata'))
+  np.testing.assert_allclose(ro.get('time'), loop.get('time'), rtol=0, atol=0)
+  loop.close(); ro.close()
