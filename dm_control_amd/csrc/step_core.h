@@ -276,53 +276,37 @@ template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 // out-of-line LDS routines shared by several call sites
 // ---------------------------------------------------------------------------
 // In-place Cholesky of the lower triangle of A (n x n), same operation order as
-// the oracle.  On exit: strict lower part = L, diagonal = 1/L[k][k], and (fast
-// path) the strict UPPER part holds L transposed (U[k][i] = L[i][k]).
-//   n <= LPE : lane i owns row i; ONE wave fence per column.  Column k of the
-//              rows below is read unscaled and scaled redundantly by each reader
-//              (x * inv, identical rounding), scaled values are parked in the
-//              upper triangle so no lane overwrites what another still reads;
-//              the diagonal store is delayed by one column for the same reason.
-//   n >  LPE : generic right-looking form, rows strided over lanes.
+// the oracle.  On exit: strict lower part = L, diagonal = 1/L[k][k] (the strict
+// upper part is scratch).  Entry-parallel right-looking form with ONE wave fence
+// per column: in column step k every remaining lower-triangle entry (i, j), j > k,
+// is updated by one lane with  A[i][j] -= (A[i][k] inv) (A[j][k] inv)  -- column k
+// is read UNSCALED and scaled redundantly by each reader (same rounding as scaling
+// once), while the scaled L[i][k] is parked in the upper triangle (A[k][i]) so that
+// nothing a concurrent reader needs is overwritten.  tri_*: lower-triangle entries
+// sorted by column (step_tables.h), so the live entries of step k are a suffix.
 template <typename T, int LPE>
-DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
-  if (n <= LPE) {
-    const int i = lane;
-    T prev_inv = 0;
-    for (int k = 0; k < n; k++) {
-      DMC_WSYNC();
-      if (k > 0 && i == k - 1) A[(k - 1)*n + (k - 1)] = prev_inv;
-      T akk = A[k*n + k];
-      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-      const T inv = 1 / t_sqrt(akk);
-      prev_inv = inv;
-      if (i > k && i < n) {
-        const T lik = A[i*n + k] * inv;
-        for (int j = k + 1; j <= i; j++) A[i*n + j] -= lik * (A[j*n + k] * inv);
-        A[k*n + i] = lik;            // L[i][k] parked in the upper triangle
-      }
-    }
-    DMC_WSYNC();
-    if (i == n - 1) A[(n - 1)*n + (n - 1)] = prev_inv;
-    // move the parked column values into the lower triangle as well
-    if (i < n) for (int k = 0; k < i; k++) A[i*n + k] = A[k*n + i];
-    DMC_WSYNC();
-    return;
-  }
+DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane, const DMC_LDS int* tri_i, const DMC_LDS int* tri_j,
+                            const DMC_LDS int* tri_col) {
+  const int ntri = tri_col[n];
   for (int k = 0; k < n; k++) {
+    DMC_WSYNC();
     T akk = A[k*n + k];
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
     const T inv = 1 / t_sqrt(akk);
-    DMC_WSYNC();
-    if (lane == 0) A[k*n + k] = inv;
-    for (int i = k + 1 + lane; i < n; i += LPE) A[i*n + k] = A[i*n + k] * inv;
-    DMC_WSYNC();
-    for (int i = k + 1 + lane; i < n; i += LPE) {
-      const T lik = A[i*n + k];
-      for (int j = k + 1; j <= i; j++) A[i*n + j] -= lik*A[j*n + k];
+    for (int idx = tri_col[k] + lane; idx < ntri; idx += LPE) {
+      const int i = tri_i[idx], j = tri_j[idx];
+      const T lik = A[i*n + k] * inv;
+      if (j > k) A[i*n + j] -= lik * (A[j*n + k] * inv);
+      else if (i > k) A[k*n + i] = lik;      // j == k: park L[i][k] in the upper triangle
+      else A[k*n + k] = inv;                 // the diagonal (all reads of it are already issued)
     }
-    DMC_WSYNC();
   }
+  DMC_WSYNC();
+  for (int idx = lane; idx < ntri; idx += LPE) {
+    const int i = tri_i[idx], j = tri_j[idx];
+    if (i > j) A[i*n + j] = A[j*n + i];
+  }
+  DMC_WSYNC();
 }
 // x = (L L')^-1 b (x may alias b); Lm as produced by chol_factor_lds
 //   n <= LPE : lane i carries x[i] in a register; the pivot value travels by a
@@ -502,58 +486,91 @@ struct StepCore {
   }
 
   // ---- kinematics (mj_kinematics) --------------------------------------------
-  DMC_DEV void body_kinematics(int i) {
-    T xpos[3], xquat[4];
+  // Same transforms as MuJoCo, re-associated for a wide machine:
+  //   A. every body in parallel: pose RELATIVE TO ITS PARENT from its own joints
+  //      (all trig / joint algebra happens here, off the tree's critical path);
+  //   B. per tree depth: compose with the parent's world pose (one quaternion
+  //      product + one rotation per body);
+  //   C. every joint / body / geom in parallel: anchors, axes, inertial and geom frames.
+  // The serial chain is nlevel cheap compositions instead of nlevel full joint
+  // evaluations; results differ from the body-by-body order only by rounding.
+  DMC_DEV void body_local_pose(int i) {
+    T p[3], q[4];
     const int jntadr = MI(body_jntadr)[i], jntnum = MI(body_jntnum)[i];
     if (jntnum == 1 && MI(jnt_type)[jntadr] == DMC_JNT_FREE) {
       const int qa = MI(jnt_qposadr)[jntadr];
-      for (int k = 0; k < 3; k++) xpos[k] = S(qpos)[qa + k];
-      for (int k = 0; k < 4; k++) xquat[k] = S(qpos)[qa + 3 + k];
-      normalize4(xquat);
-      for (int k = 0; k < 3; k++) { S(xanchor)[3*jntadr + k] = xpos[k]; S(xaxis)[3*jntadr + k] = MR(jnt_axis)[3*jntadr + k]; }
+      for (int k = 0; k < 3; k++) p[k] = S(qpos)[qa + k];
+      for (int k = 0; k < 4; k++) q[k] = S(qpos)[qa + 3 + k];
+      normalize4(q);
+      for (int k = 0; k < 3; k++) { S(xanchor)[3*jntadr + k] = p[k]; S(xaxis)[3*jntadr + k] = MR(jnt_axis)[3*jntadr + k]; }
     } else {
-      const int pid = MI(body_parentid)[i];
-      mul_mat_vec3(xpos, S(xmat) + 9*pid, MR(body_pos) + 3*i);
-      xpos[0] += S(xpos)[3*pid]; xpos[1] += S(xpos)[3*pid + 1]; xpos[2] += S(xpos)[3*pid + 2];
-      mul_quat(xquat, S(xquat) + 4*pid, MR(body_quat) + 4*i);
+      for (int k = 0; k < 3; k++) p[k] = MR(body_pos)[3*i + k];
+      for (int k = 0; k < 4; k++) q[k] = MR(body_quat)[4*i + k];
       for (int j = jntadr; j < jntadr + jntnum; j++) {
-        const int qa = MI(jnt_qposadr)[j];
-        T anchor[3], axis[3];
-        rot_vec_quat(axis, MR(jnt_axis) + 3*j, xquat);
-        rot_vec_quat(anchor, MR(jnt_pos) + 3*j, xquat);
-        anchor[0] += xpos[0]; anchor[1] += xpos[1]; anchor[2] += xpos[2];
+        const int qa = MI(jnt_qposadr)[j], t = MI(jnt_type)[j];
+        T R[9], axis[3], anchor[3];
+        quat2mat(R, q);
+        mul_mat_vec3(axis, R, MR(jnt_axis) + 3*j);
+        mul_mat_vec3(anchor, R, MR(jnt_pos) + 3*j);
+        anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
         for (int k = 0; k < 3; k++) { S(xanchor)[3*j + k] = anchor[k]; S(xaxis)[3*j + k] = axis[k]; }
-        const int t = MI(jnt_type)[j];
         if (t == DMC_JNT_SLIDE) {
-          T q = S(qpos)[qa] - MR(qpos0)[qa];
-          xpos[0] += axis[0]*q; xpos[1] += axis[1]*q; xpos[2] += axis[2]*q;
+          const T d = S(qpos)[qa] - MR(qpos0)[qa];
+          p[0] += axis[0]*d; p[1] += axis[1]*d; p[2] += axis[2]*d;
         } else if (t == DMC_JNT_BALL || t == DMC_JNT_HINGE) {
           T qloc[4], vec[3];
           if (t == DMC_JNT_BALL) { for (int k = 0; k < 4; k++) qloc[k] = S(qpos)[qa + k]; normalize4(qloc); }
           else axisangle2quat(qloc, MR(jnt_axis) + 3*j, S(qpos)[qa] - MR(qpos0)[qa]);
-          mul_quat(xquat, xquat, qloc);
-          rot_vec_quat(vec, MR(jnt_pos) + 3*j, xquat);
-          xpos[0] = anchor[0] - vec[0]; xpos[1] = anchor[1] - vec[1]; xpos[2] = anchor[2] - vec[2];
+          mul_quat(q, q, qloc);
+          rot_vec_quat(vec, MR(jnt_pos) + 3*j, q);
+          p[0] = anchor[0] - vec[0]; p[1] = anchor[1] - vec[1]; p[2] = anchor[2] - vec[2];
         }
       }
     }
-    normalize4(xquat);
-    T mat[9], v[3], q[4];
-    quat2mat(mat, xquat);
-    for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = xpos[k];
-    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = xquat[k];
-    for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = mat[k];
-    mul_mat_vec3(v, mat, MR(body_ipos) + 3*i);
-    for (int k = 0; k < 3; k++) S(xipos)[3*i + k] = xpos[k] + v[k];
-    mul_quat(q, xquat, MR(body_iquat) + 4*i);
-    quat2mat(mat, q);
-    for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = mat[k];
+    for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
+    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+  }
+  DMC_DEV void body_compose(int i) {
+    const int pid = MI(body_parentid)[i];
+    T p[3], q[4], m[9];
+    if (pid == 0) {
+      for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*i + k];
+      for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*i + k];
+    } else {
+      mul_mat_vec3(p, S(xmat) + 9*pid, S(xpos) + 3*i);
+      for (int k = 0; k < 3; k++) p[k] += S(xpos)[3*pid + k];
+      mul_quat(q, S(xquat) + 4*pid, S(xquat) + 4*i);
+    }
+    normalize4(q);
+    quat2mat(m, q);
+    for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
+    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+    for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = m[k];
   }
   DMC_DEV void kinematics() {
+    for (int i = 1 + lane; i < L.d.nbody; i += LPE) body_local_pose(i);
+    DMC_WSYNC();
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
-      for (int k = a0 + lane; k < a1; k += LPE) body_kinematics(MI(level_body)[k]);
+      for (int k = a0 + lane; k < a1; k += LPE) body_compose(MI(level_body)[k]);
       DMC_WSYNC();
+    }
+    FOR_LANES(j, L.d.njnt) {
+      const int pid = MI(body_parentid)[MI(jnt_bodyid)[j]];
+      if (pid != 0) {
+        T a[3], ax[3];
+        mul_mat_vec3(a, S(xmat) + 9*pid, S(xanchor) + 3*j);
+        mul_mat_vec3(ax, S(xmat) + 9*pid, S(xaxis) + 3*j);
+        for (int k = 0; k < 3; k++) { S(xanchor)[3*j + k] = a[k] + S(xpos)[3*pid + k]; S(xaxis)[3*j + k] = ax[k]; }
+      }
+    }
+    for (int i = 1 + lane; i < L.d.nbody; i += LPE) {
+      T v[3], q[4], m[9];
+      mul_mat_vec3(v, S(xmat) + 9*i, MR(body_ipos) + 3*i);
+      for (int k = 0; k < 3; k++) S(xipos)[3*i + k] = S(xpos)[3*i + k] + v[k];
+      mul_quat(q, S(xquat) + 4*i, MR(body_iquat) + 4*i);
+      quat2mat(m, q);
+      for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = m[k];
     }
     FOR_LANES(g, L.d.ngeom) {
       const int b = MI(geom_bodyid)[g]; T v[3], q[4], m[9];
@@ -623,7 +640,10 @@ struct StepCore {
   }
 
   // ---- dense Cholesky / solves in LDS (out-of-line: chol_factor_lds / chol_solve_lds) ----
-  DMC_DEV void chol_factor_inplace(T* A, int n) { chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane); }
+  DMC_DEV void chol_factor_inplace(T* A, int n) {
+    chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane, (const DMC_LDS int*)MI(tri_i), (const DMC_LDS int*)MI(tri_j),
+                            (const DMC_LDS int*)MI(tri_col));
+  }
   DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
     chol_solve_lds<T, LPE>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, n, lane);
   }
@@ -1406,9 +1426,8 @@ struct StepCore {
     constraint_force_to_joint(nefc);
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
-    for (int idx = lane; idx < nv*nv; idx += LPE) {
-      const int i = idx / nv, j = idx - i*nv;
-      if (j > i) continue;
+    for (int idx = lane; idx < L.d.ntri; idx += LPE) {
+      const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
       T h = S(qM)[i*nv + j];
       for (int r = 0; r < nefc; r++) if (S(efc_jar)[r] < 0) {
         const T ji = S(efc_J)[r*nv + i];

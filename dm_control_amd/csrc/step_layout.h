@@ -20,6 +20,7 @@ struct StepDims {
   int nconmax;   // contact cap per environment
   int njmax;     // constraint-row cap per environment
   int rk4;       // 1: RK4 integrator (extra stage buffers)
+  int ntri;      // nv (nv + 1) / 2: lower-triangle entries of an nv x nv matrix
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -34,6 +35,8 @@ struct StepDims {
   X(dof_bodyid, d.nv) X(dof_jntid, d.nv) X(dof_parentid, d.nv)                 \
   X(dof_anc_lo, d.nv) X(dof_anc_hi, d.nv)  /* bitmask of ancestor dofs (incl. self) */ \
   X(mpair_i, d.nM) X(mpair_j, d.nM)                                            \
+  X(tri_i, d.ntri) X(tri_j, d.ntri)   /* lower-triangle entries sorted by (column, row) */ \
+  X(tri_col, d.nv + 1)                /* first entry of each column in tri_i/tri_j */ \
   X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
   X(pair_geom1, d.npair) X(pair_geom2, d.npair) X(pair_dim, d.npair)           \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \

@@ -98,6 +98,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   std::vector<int> mp_i, mp_j;
   for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) { mp_i.push_back(i); mp_j.push_back(j); }
   d.nM = (int)mp_i.size();
+  d.ntri = m.nv * (m.nv + 1) / 2;
   // contact / row caps
   int maxc = 0, maxr = 0, nlim = 0;
   for (int j = 0; j < m.njnt; j++) if (m.jnt_limited[j]) nlim++;
@@ -170,6 +171,11 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     mi[L.mi_dof_anc_hi + i] = (int)(uint32_t)(mask >> 32);
   }
   cpi(L.mi_mpair_i, mp_i); cpi(L.mi_mpair_j, mp_j);
+  {
+    int k = 0;
+    for (int j = 0; j < m.nv; j++) { mi[L.mi_tri_col + j] = k; for (int i = j; i < m.nv; i++) { mi[L.mi_tri_i + k] = i; mi[L.mi_tri_j + k] = j; k++; } }
+    mi[L.mi_tri_col + m.nv] = k;
+  }
   cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);
   cpi(L.mi_pair_geom1, m.pair_geom1); cpi(L.mi_pair_geom2, m.pair_geom2); cpi(L.mi_pair_dim, pdim);
   cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);

@@ -98,7 +98,8 @@ def test_forward_stages_fp64(cheetah, lanes):
     for name, ref in (('xpos', o.xpos), ('xmat', o.xmat), ('cdof', o.cdof), ('qM', o.qM),
                       ('qfrc_bias', o.qfrc_bias), ('efc_J', o.efc_J[:ne*m.nv]),
                       ('efc_D', o.efc_D[:ne]), ('efc_aref', o.efc_aref[:ne])):
-      np.testing.assert_array_equal(b.debug_get(name, e)[:ref.size], ref, err_msg='%s env %d' % (name, e))
+      np.testing.assert_allclose(b.debug_get(name, e)[:ref.size], ref, rtol=1e-9, atol=1e-11,
+                                 err_msg='%s env %d' % (name, e))
     np.testing.assert_allclose(b.debug_get('qacc', e), o.qacc, rtol=1e-10, atol=1e-8)
   # derived outputs through the public field API
   np.testing.assert_allclose(b.get('ncon')[:, 0], [int(b.debug_get('imisc', e)[0]) for e in range(NE)])

@@ -20,7 +20,7 @@ def _cheetah():
     return mc.compile_xml(f.read())
 
 
-def test_forward_stages_bit_exact_fp64():
+def test_forward_stages_fp64():
   m = _cheetah()
   rs = np.random.RandomState(0)
   for trial in range(4):
@@ -34,12 +34,14 @@ def test_forward_stages_bit_exact_fp64():
     o.forward()
     e.forward()
     assert o.ncon == e.ncon[0] and o.nefc == e.nefc[0]
+    # kinematics is re-associated in the kernel (parallel local poses + composition),
+    # so downstream stages agree to rounding, not bit for bit
     for name in ('xpos', 'xmat', 'subtree_com', 'qfrc_bias', 'sensordata'):
-      np.testing.assert_array_equal(getattr(o, name), getattr(e, name), err_msg=name)
+      np.testing.assert_allclose(getattr(o, name), getattr(e, name), rtol=1e-12, atol=1e-12, err_msg=name)
     ne = o.nefc
-    np.testing.assert_array_equal(o.qM, e.scratch('qM'))
-    np.testing.assert_array_equal(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv])
-    np.testing.assert_array_equal(o.efc_aref[:ne], e.scratch('efc_aref')[:ne])
+    np.testing.assert_allclose(o.qM, e.scratch('qM'), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(o.efc_aref[:ne], e.scratch('efc_aref')[:ne], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(o.qacc, e.qacc, rtol=1e-11, atol=1e-9)
 
 
