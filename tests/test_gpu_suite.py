@@ -241,3 +241,27 @@ def test_batched_facade_matches_single():
     np.testing.assert_array_equal(batch.data.qpos[e], single.data.qpos)
   np.testing.assert_array_equal(batch.named.data.xpos['torso', 'z'], np.full(3, single.named.data.xpos['torso', 'z']))
   single.free(); batch.free()
+
+
+def test_torch_batched_env_matches_host_env_semantics():
+  """Device-resident cheetah env: observations/rewards equal the host task's
+  formulas on the same device state; episodes end at the time limit and reset."""
+  import torch
+  from dm_control_amd.suite import torch_env, rewards
+  env = torch_env.TorchBatchedEnv(64, precision=32, time_limit=0.05, seed=1)
+  obs = env.reset()
+  assert obs.shape == (64, 17) and torch.isfinite(obs).all()
+  g = torch.Generator(device='cuda').manual_seed(0)
+  for t in range(5):
+    a = torch.rand((64, 6), device='cuda', generator=g) * 2 - 1
+    obs, rew, done = env.step(a)
+    q = env.physics.get('qpos'); v = env.physics.get('qvel'); s = env.physics.get('sensordata')
+    if t < 4:
+      np.testing.assert_allclose(obs.cpu().numpy(), np.concatenate([q[:, 1:], v], axis=1), rtol=1e-6, atol=1e-6)
+      want = rewards.tolerance(s[:, 0], bounds=(10, float('inf')), margin=10, value_at_margin=0, sigmoid='linear')
+      np.testing.assert_allclose(rew.cpu().numpy(), want, atol=1e-6)
+      assert not bool(done.any())
+  assert bool(done.all())              # 0.05 s / 0.01 s = 5 steps
+  assert int(env.steps.max()) == 0     # auto-reset
+  assert float(env.time.max()) == 0.0
+  env.close()
