@@ -1389,14 +1389,20 @@ struct StepCore {
 
   // ---- Newton solver on the primal (mj_fwdConstraint / mj_solNewton) -----------------
   // efc_state/efc_force from efc_jar; returns the constraint cost (group-uniform)
-  DMC_DEV T constraint_update(int nefc) {
+  // track != null: also record the active set and report whether it differs from
+  // the one H was last factored for (0/1, group-uniform)
+  DMC_DEV T constraint_update(int nefc, int* track = nullptr) {
     T cost = 0;
+    int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const T jar = S(efc_jar)[i];
-      if (jar < 0) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
+      const int act = jar < 0;
+      if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
       else S(efc_force)[i] = 0;
+      if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
     }
     cost = group_sum<LPE>(cost);
+    if (track) *track = group_max<LPE>(changed);
     DMC_WSYNC();
     return cost;
   }
@@ -1421,11 +1427,14 @@ struct StepCore {
       S(qfrc_constraint)[i] = f;
     }
   }
-  DMC_DEV void newton_gradient(int nefc) {
+  // refactor == 0: the active set is unchanged, so H and its factor (still in qLH)
+  // are reused -- identical values, none of the O(nv^3) work
+  DMC_DEV void newton_gradient(int nefc, int refactor) {
     const int nv = L.d.nv;
     constraint_force_to_joint(nefc);
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
+    if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
     for (int idx = lane; idx < L.d.ntri; idx += LPE) {
       const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
       T h = S(qM)[i*nv + j];
@@ -1527,11 +1536,13 @@ struct StepCore {
     mul_M(S(sv_Ma), S(qacc));
     jar_from(S(qacc), nefc);
     DMC_WSYNC();
-    T cc = constraint_update(nefc);
+    int changed = 1;
+    for (int i = lane; i < nefc; i += LPE) SI(efc_active)[i] = -1;   // no factor of H yet
+    T cc = constraint_update(nefc, &changed);
     T gauss = gauss_cost();
     T cost = cc + gauss;
     DMC_PROF(PROF_SOL_INIT);
-    newton_gradient(nefc);
+    newton_gradient(nefc, 1);
     FOR_LANES(i, nv) S(sv_search)[i] = -S(sv_Mgrad)[i];
     DMC_WSYNC();
     DMC_PROF(PROF_SOL_GRAD);
@@ -1544,11 +1555,11 @@ struct StepCore {
       for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
       DMC_WSYNC();
       const T oldcost = cost;
-      cc = constraint_update(nefc);
+      cc = constraint_update(nefc, &changed);
       gauss = gauss_cost();
       cost = cc + gauss;
       DMC_PROF(PROF_SOL_UPD);
-      newton_gradient(nefc);
+      newton_gradient(nefc, changed);
       DMC_PROF(PROF_SOL_GRAD);
       T g2 = 0, ma2 = 0;
       FOR_LANES(i, nv) { S(sv_search)[i] = -S(sv_Mgrad)[i]; g2 += S(sv_grad)[i]*S(sv_grad)[i]; ma2 += S(sv_Ma)[i]*S(sv_Ma)[i]; }

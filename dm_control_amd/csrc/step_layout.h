@@ -105,6 +105,7 @@ struct StepDims {
 #define STEP_SCRATCH_INT(X)                                                    \
   X(con_pair, d.nconmax) X(con_efc, d.nconmax)                                 \
   X(efc_tid, d.njmax)   /* (id << 2) | type */                                 \
+  X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch
