@@ -16,9 +16,9 @@
 #include "step_tables.h"
 
 namespace dmc {
-hipError_t launch_step_f32(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<float>& o,
+hipError_t launch_step_f32(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<float>& o,
                            const int* g_mi, const float* g_mr, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask, int nsub);
-hipError_t launch_step_f64(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<double>& o,
+hipError_t launch_step_f64(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<double>& o,
                            const int* g_mi, const double* g_mr, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask, int nsub);
 }  // namespace dmc
 
@@ -52,6 +52,7 @@ struct dmc_batch {
   LaunchGeom geom;
   int* d_mi;
   void* d_mr;
+  StepLayout* d_layout;
   std::vector<Field> fields;
   std::map<std::string, int> index;
   int outmask;
@@ -81,7 +82,8 @@ static Field* find_field(dmc_batch* b, const char* name) {
 
 static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   const StepLayout& L = b->tb.L;
-  const size_t tables = (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem;
+  const size_t tables = (size_t)(b->precision == 64 ? opts_lds_bytes<double>() : opts_lds_bytes<float>()) +
+                        (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem;
   const size_t env_bytes = (size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int);
   const size_t lds_cu = 160 * 1024;
   // automatic: small models (cheetah, nv = 9) leave most of a 64-lane group idle, so
@@ -138,7 +140,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr; b->d_prof = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
@@ -146,6 +148,8 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   const StepDims& d = L.d;
   hipError_t e = hipMalloc(&b->d_mi, (size_t)L.n_mi * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&b->d_mr, (size_t)L.n_mr * b->elem);
+  if (e == hipSuccess) e = hipMalloc((void**)&b->d_layout, sizeof(StepLayout));
+  if (e == hipSuccess) e = hipMemcpy(b->d_layout, &L, sizeof(StepLayout), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete b; return fail(std::string("hipMalloc: ") + hipGetErrorString(e), -2); }
   if (upload_tables(b)) { delete b; return -2; }
   struct Spec { const char* name; int rows; bool is_int; };
@@ -181,6 +185,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   for (Field& f : b->fields) if (f.owned) (void)hipFree(f.owned);
   if (b->d_mi) (void)hipFree(b->d_mi);
   if (b->d_mr) (void)hipFree(b->d_mr);
+  if (b->d_layout) (void)hipFree(b->d_layout);
   if (b->d_debug) (void)hipFree(b->d_debug);
   if (b->d_debug_i) (void)hipFree(b->d_debug_i);
   if (b->d_prof) (void)hipFree(b->d_prof);
@@ -213,12 +218,12 @@ static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, c
     StepIO<double> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (double*)sq->qvel : nullptr; io.sensor_seq = sq ? (double*)sq->sensor : nullptr;
-    e = launch_step_f64(b->geom, (hipStream_t)stream, b->tb.L, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
+    e = launch_step_f64(b->geom, (hipStream_t)stream, b->d_layout, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
   } else {
     StepIO<float> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const float*)sq->ctrl : nullptr; io.qpos_seq = sq ? (float*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (float*)sq->qvel : nullptr; io.sensor_seq = sq ? (float*)sq->sensor : nullptr;
-    e = launch_step_f32(b->geom, (hipStream_t)stream, b->tb.L, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
+    e = launch_step_f32(b->geom, (hipStream_t)stream, b->d_layout, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e), -2);
   return 0;

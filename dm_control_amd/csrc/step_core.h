@@ -373,8 +373,18 @@ DMC_FN void ls_eval_lds(LSPoint<T>* p, const DMC_LDS T* jar_, const DMC_LDS T* j
 // ---------------------------------------------------------------------------
 // the step
 // ---------------------------------------------------------------------------
-template <typename T, int LPE>
+// where a StepCore finds its layout: a runtime struct (generic kernel) or a
+// build-time constant (model-specialised kernels, see step_kernel.hip.h)
+struct DynLayoutSrc {
+  const StepLayout* p;
+  DMC_DEV const StepLayout& get() const { return *p; }
+};
+
+template <typename T, int LPE, typename LS> struct StageFns;   // out-of-line stage entry points (below)
+
+template <typename T, int LPE, typename LS = DynLayoutSrc>
 struct StepCore {
+  LS ls;
   const StepLayout& L;
   const StepOpts<T>& o;
   const int* mi;
@@ -387,8 +397,8 @@ struct StepCore {
   long long prof_[24]; long long prof_last_;
 #endif
 
-  DMC_DEV StepCore(const StepLayout& L_, const StepOpts<T>& o_, const int* mi_, const T* mr_, T* s_, int* si_, int lane_)
-      : L(L_), o(o_), mi(mi_), mr(mr_), s(s_), si(si_), lane(lane_) {}
+  DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, T* s_, int* si_, int lane_)
+      : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_), s(s_), si(si_), lane(lane_), time_(0) {}
 
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
@@ -1583,7 +1593,7 @@ struct StepCore {
   }
 
   // ---- integration (mj_Euler with implicit joint damping) ---------------------------------
-  DMC_DEV void euler() {
+  DMC_DEV void euler_state() {
     const int nv = L.d.nv;
     const T dt = o.timestep;
     const T* qacc = S(qacc);
@@ -1616,9 +1626,9 @@ struct StepCore {
         for (int k = 0; k < 4; k++) S(qpos)[qa + k] = q[k];
       } else S(qpos)[qa] += dt*S(qvel)[da];
     }
-    time_ += o.timestep_d;
     DMC_WSYNC();
   }
+  DMC_DEV void euler() { euler_state(); time_ += o.timestep_d; }
 
   // ---- RK4 (mj_RungeKutta, N = 4): stages run through the single forward() site ----------
   DMC_DEV void integrate_pos_from(const T* q0, const T* vel, T h) {
@@ -1720,6 +1730,28 @@ struct StepCore {
     (void)io; (void)env;
 #endif
   }
+  // The three heavy stages are entered through out-of-line functions (StageFns):
+  // each gets its own register allocation, so the peak pressure of one stage no
+  // longer forces spills in the others, and there is one copy of the code.
+#if !defined(DMC_HOST_EMU) && !defined(DMC_PROFILE) && !defined(DMC_INLINE_STAGES)
+  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor) {
+    StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+                                 (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0), outmask);
+  }
+  DMC_DEV void call_acc(bool disable_actuation, bool skipsensor) {
+    StageFns<T, LPE, LS>::acc(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+                              (DMC_LDS int*)si, lane, (disable_actuation ? 1 : 0) | (skipsensor ? 2 : 0));
+  }
+  DMC_DEV void call_euler() {
+    StageFns<T, LPE, LS>::euler(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+                                (DMC_LDS int*)si, lane);
+    time_ += o.timestep_d;
+  }
+#else
+  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor) { stage_posvel(partial, outmask, skipsensor); }
+  DMC_DEV void call_acc(bool disable_actuation, bool skipsensor) { stage_acc(disable_actuation, skipsensor); }
+  DMC_DEV void call_euler() { euler(); }
+#endif
   DMC_DEV void load_ctrl_seq(const StepIO<T>& io, int env, int t) {
     const int B = io.B, nu = L.d.nu;
     DMC_WSYNC();
@@ -1753,10 +1785,10 @@ struct StepCore {
       const int nstage = (stepping && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
       int stage = 0, retried = 0;
       while (stage < nstage) {
-        stage_posvel(partial, outmask, stage > 0);
+        call_posvel(partial, outmask, stage > 0);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
         if (partial) break;
-        stage_acc(mode == 2, stage > 0);
+        call_acc(mode == 2, stage > 0);
         if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
           if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
@@ -1766,7 +1798,7 @@ struct StepCore {
         stage++;
       }
       if (!stepping || partial) break;
-      if (nstage > 1) rk4_finish(); else euler();
+      if (nstage > 1) rk4_finish(); else call_euler();
       DMC_PROF(PROF_EULER);
     }
     if (!stepping) dump_debug(io, env);
@@ -1781,5 +1813,28 @@ struct StepCore {
 #undef SI
 #undef FOR_LANES
 };
+
+
+#ifndef DMC_HOST_EMU
+template <typename T, int LPE, typename LS>
+struct StageFns {
+  typedef StepCore<T, LPE, LS> Core;
+  static DMC_FN void posvel(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+                            DMC_LDS int* si, int lane, int flags, int outmask) {
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    c.stage_posvel(flags & 1, outmask, flags & 2);
+  }
+  static DMC_FN void acc(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+                         DMC_LDS int* si, int lane, int flags) {
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    c.stage_acc(flags & 1, flags & 2);
+  }
+  static DMC_FN void euler(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+                           DMC_LDS int* si, int lane) {
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    c.euler_state();
+  }
+};
+#endif
 
 }  // namespace dmc

@@ -32,15 +32,23 @@ struct LaunchGeom {
 #define DMC_NSTATIC 0
 #endif
 
-template <typename T, int LPE>
-__device__ __forceinline__ void step_kernel_body(const StepLayout& L, const StepOpts<T>& o, const int* __restrict__ g_mi,
+// bytes of the per-workgroup header in LDS that holds the scalar options (read by
+// the out-of-line stage functions, which cannot see kernel arguments)
+template <typename T> constexpr int opts_lds_bytes() { return (int)((sizeof(StepOpts<T>) + 15) / 16 * 16); }
+
+template <typename T, int LPE, typename LS>
+__device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg, const int* __restrict__ g_mi,
                                                  const T* __restrict__ g_mr, const StepIO<T>& io, int nstep, int legacy,
                                                  int mode, int outmask, int nsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* mi = reinterpret_cast<int*>(smem);
-  T* mr = reinterpret_cast<T*>(smem + (size_t)L.n_mi * sizeof(int));
+  const StepLayout& L = ls.get();
+  StepOpts<T>* o_lds = reinterpret_cast<StepOpts<T>*>(smem);
+  unsigned char* tables = smem + opts_lds_bytes<T>();
+  int* mi = reinterpret_cast<int*>(tables);
+  T* mr = reinterpret_cast<T*>(tables + (size_t)L.n_mi * sizeof(int));
   const int tid = threadIdx.x, nthr = blockDim.x;
   // stage the model constant tables once per workgroup (shared by all its envs)
+  if (tid == 0) *o_lds = o_arg;
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
   for (int i = tid; i < L.n_mr; i += nthr) mr[i] = g_mr[i];
   __syncthreads();
@@ -51,18 +59,21 @@ __device__ __forceinline__ void step_kernel_body(const StepLayout& L, const Step
   const int env = blockIdx.x * epb + g;
   if (env >= io.B) return;
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
-  unsigned char* base = smem + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
+  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
   T* s = reinterpret_cast<T*>(base);
   int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
-  StepCore<T, LPE> core(L, o, mi, mr, s, si, lane);
+  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, s, si, lane);
   core.run(io, env, nstep, legacy, mode, outmask, nsub);
 }
 
 template <typename T, int LPE>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
-step_kernel(StepLayout L, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
+step_kernel(const StepLayout* __restrict__ Lp, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
             StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
-  step_kernel_body<T, LPE>(L, o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
+  // generic kernel: the layout lives in device memory (uniform scalar loads); taking
+  // the address of a by-value kernel argument would copy it to scratch
+  DynLayoutSrc ls; ls.p = Lp;
+  step_kernel_body<T, LPE, DynLayoutSrc>(ls, o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
 }
 
 #if DMC_NSTATIC > 0
@@ -70,7 +81,7 @@ template <int SID> struct StaticLayout;
 #define DMC_DEF_STATIC(ID)                                                            \
   static __device__ const StepLayout kStaticLayout##ID = DMC_STATIC_LAYOUT_##ID;     \
   template <> struct StaticLayout<ID> {                                               \
-    static __device__ __forceinline__ const StepLayout& get() { return kStaticLayout##ID; } \
+    __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_DEF_STATIC(0)
 #if DMC_NSTATIC > 1
@@ -85,12 +96,12 @@ template <typename T, int LPE, int SID>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
                    StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
-  step_kernel_body<T, LPE>(StaticLayout<SID>::get(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
+  step_kernel_body<T, LPE, StaticLayout<SID> >(StaticLayout<SID>(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
 }
 #endif
 
 template <typename T>
-inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout& L, const StepOpts<T>& o,
+inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<T>& o,
                                 const int* g_mi, const T* g_mr, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
   const dim3 grid(g.grid), block(g.waves * 64);
 #define DMC_LAUNCH(LPE)                                                                                         \
@@ -98,7 +109,7 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, LPE>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, L, o, g_mi, g_mr, io, nstep,    \
+    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, d_layout, o, g_mi, g_mr, io, nstep,    \
                        legacy, mode, outmask, nsub);                                                                  \
   }
 #define DMC_LAUNCH_STATIC(LPE, SID)                                                                             \

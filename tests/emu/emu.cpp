@@ -67,7 +67,8 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.contact_dist = buf[21].data(); io.contact_pos = buf[22].data(); io.contact_frame = buf[23].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
-  StepCore<T, 1> core(L, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
+  DynLayoutSrc ls; ls.p = &L;
+  StepCore<T, 1> core(ls, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
   core.run(io, 0, nstep, legacy, mode, OUT_ALL, 1);
   for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
   f[5][0] = tm;
