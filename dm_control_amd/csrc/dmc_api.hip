@@ -351,7 +351,7 @@ extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) 
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
   if (!strcmp(name, "disableflags")) {
-    if (b->tb.has_unsupported_pairs && !(value & DMC_DSBL_CONTACT))
+    if (b->tb.has_unsupported_pairs && !(value & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)))
       return fail("cannot enable contacts: the model has geom pair types the collision kernel does not implement");
     o.disableflags = value;
   }

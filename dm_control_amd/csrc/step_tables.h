@@ -115,7 +115,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
                        (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE);
     if (!known) {
       // tolerated only while contacts are disabled (e.g. suite cartpole): the pair then never collides
-      if (m.opt_disableflags & DMC_DSBL_CONTACT) { t->has_unsupported_pairs = 1; nc = 0; }
+      if (m.opt_disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)) { t->has_unsupported_pairs = 1; nc = 0; }
       else { *err = "geom pair type not implemented in the HIP collision kernel (need plane/sphere/capsule, plane-box)"; return false; }
     }
     int dim;

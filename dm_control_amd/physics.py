@@ -167,9 +167,7 @@ class FieldIndexer:
       raise IndexError('too many indices')
     out = [self._rows.convert(key[0])]
     if len(key) == 2:
-      if self._cols is None:
-        raise IndexError('field has no named columns')
-      out.append(self._cols.convert(key[1]))
+      out.append(self._cols.convert(key[1]) if self._cols is not None else key[1])
     if self._batched:
       out = [slice(None)] + out
     if len(out) > 1 and all(isinstance(o, list) for o in out[-2:]):

@@ -16,7 +16,9 @@ def _oracle(model):
 
 
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'balance'), ('cartpole', 'swingup'),
-                                         ('humanoid', 'stand'), ('humanoid', 'run_pure_state')])
+                                         ('humanoid', 'stand'), ('humanoid', 'run_pure_state'), ('walker', 'walk'),
+                                         ('hopper', 'hop'), ('hopper', 'stand'), ('pendulum', 'swingup'),
+                                         ('acrobot', 'swingup'), ('acrobot', 'swingup_sparse')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -38,7 +40,8 @@ def test_suite_task_properties(domain, task):
   env.physics.free()
 
 
-@pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk')])
+@pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
+                                         ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -265,3 +268,43 @@ def test_torch_batched_env_matches_host_env_semantics():
   assert int(env.steps.max()) == 0     # auto-reset
   assert float(env.time.max()) == 0.0
   env.close()
+
+
+@pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1)])
+def test_more_domains_rollout_parity(name, nsub):
+  """Domains sharing the cheetah feature set: 60 env-steps from randomised starts
+  against the oracle (fp64 kernel), incl. hopper's touch sensors and acrobot's RK4."""
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  from oracle import oracle
+  m = mc.compile_xml(common.read_model(name + '.xml'))
+  NE = 8
+  rs = np.random.RandomState(5)
+  q = np.tile(m.qpos0, (NE, 1))
+  for j in range(m.njnt):
+    a = m.jnt_qposadr[j]
+    if m.jnt_type[j] == 3:
+      lo, hi = m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi)
+      q[:, a] = rs.uniform(lo, hi, NE)
+  b = BatchedPhysics(m, NE, precision=64)
+  b.set('qpos', q)
+  refs = []
+  for e in range(NE):
+    o = _oracle(m)
+    o.qpos[:] = q[e]
+    o.forward()
+    refs.append(o)
+  worst = 0.0
+  for t in range(60):
+    a = rs.uniform(-1, 1, (NE, m.nu))
+    b.set_control(a)
+    b.step(nsub)
+    oracle.rollout_legacy(refs, a[None], nsub=nsub)
+    qo = np.stack([o.qpos for o in refs])
+    worst = max(worst, float(np.abs(b.get('qpos') - qo).max()))
+  assert worst < 1e-7, worst
+  so = np.stack([o.sensordata for o in refs])
+  if m.nsensordata:
+    np.testing.assert_allclose(b.get('sensordata'), so, atol=1e-6 * max(1.0, np.abs(so).max()))
+  assert not b.get('warning').any()
+  b.close()
