@@ -288,23 +288,48 @@ template <typename T, int LPE>
 DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane, const DMC_LDS int* tri_i, const DMC_LDS int* tri_j,
                             const DMC_LDS int* tri_col) {
   const int ntri = tri_col[n];
+  // four entries per lane per trip: their index / matrix loads are issued together,
+  // so a column costs ~ntri_live/(4 LPE) LDS round trips instead of ntri_live/LPE
+  constexpr int U = 4;
   for (int k = 0; k < n; k++) {
     DMC_WSYNC();
     T akk = A[k*n + k];
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
     const T inv = 1 / t_sqrt(akk);
-    for (int idx = tri_col[k] + lane; idx < ntri; idx += LPE) {
-      const int i = tri_i[idx], j = tri_j[idx];
-      const T lik = A[i*n + k] * inv;
-      if (j > k) A[i*n + j] -= lik * (A[j*n + k] * inv);
-      else if (i > k) A[k*n + i] = lik;      // j == k: park L[i][k] in the upper triangle
-      else A[k*n + k] = inv;                 // the diagonal (all reads of it are already issued)
+    const int c0 = tri_col[k];
+    if (ntri - c0 <= 2*LPE) {      // small remainder: one entry per lane per trip
+      for (int idx = c0 + lane; idx < ntri; idx += LPE) {
+        const int i = tri_i[idx], j = tri_j[idx];
+        const T lik = A[i*n + k] * inv;
+        if (j > k) A[i*n + j] -= lik * (A[j*n + k] * inv);
+        else if (i > k) A[k*n + i] = lik;
+        else A[k*n + k] = inv;
+      }
+      continue;
+    }
+    for (int base = c0 + lane; base < ntri; base += U*LPE) {
+      int ii[U], jj[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int idx = base + u*LPE; ok[u] = idx < ntri; ii[u] = ok[u] ? tri_i[idx] : k; jj[u] = ok[u] ? tri_j[idx] : k; }
+      T aik[U], ajk[U], aij[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { aik[u] = A[ii[u]*n + k]; ajk[u] = A[jj[u]*n + k]; aij[u] = A[ii[u]*n + jj[u]]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) if (ok[u]) {
+        const T lik = aik[u] * inv;
+        if (jj[u] > k) A[ii[u]*n + jj[u]] = aij[u] - lik * (ajk[u] * inv);
+        else if (ii[u] > k) A[k*n + ii[u]] = lik;   // j == k: park L[i][k] in the upper triangle
+        else A[k*n + k] = inv;                      // the diagonal (all reads of it are already issued)
+      }
     }
   }
   DMC_WSYNC();
-  for (int idx = lane; idx < ntri; idx += LPE) {
-    const int i = tri_i[idx], j = tri_j[idx];
-    if (i > j) A[i*n + j] = A[j*n + i];
+  for (int base = lane; base < ntri; base += U*LPE) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int idx = base + u*LPE;
+      if (idx < ntri) { const int i = tri_i[idx], j = tri_j[idx]; if (i > j) A[i*n + j] = A[j*n + i]; }
+    }
   }
   DMC_WSYNC();
 }
@@ -1448,7 +1473,16 @@ struct StepCore {
     for (int idx = lane; idx < L.d.ntri; idx += LPE) {
       const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
       T h = S(qM)[i*nv + j];
-      for (int r = 0; r < nefc; r++) if (S(efc_jar)[r] < 0) {
+      int r = 0;
+      for (; r + 1 < nefc; r += 2) {      // two rows per trip (loads overlap); same accumulation order
+        const T jar0 = S(efc_jar)[r], jar1 = S(efc_jar)[r + 1];
+        const T ji0 = S(efc_J)[r*nv + i], ji1 = S(efc_J)[(r + 1)*nv + i];
+        const T jj0 = S(efc_J)[r*nv + j], jj1 = S(efc_J)[(r + 1)*nv + j];
+        const T d0 = S(efc_D)[r], d1 = S(efc_D)[r + 1];
+        if (jar0 < 0 && ji0 != 0) h += (d0*ji0) * jj0;
+        if (jar1 < 0 && ji1 != 0) h += (d1*ji1) * jj1;
+      }
+      if (r < nefc && S(efc_jar)[r] < 0) {
         const T ji = S(efc_J)[r*nv + i];
         if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
       }

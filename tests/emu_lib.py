@@ -24,7 +24,7 @@ def lib():
     csrc = os.path.join(os.path.dirname(_HERE), 'dm_control_amd', 'csrc')
     deps = [_SRC] + [os.path.join(csrc, f) for f in ('step_core.h', 'step_layout.h', 'step_tables.h')]
     if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in deps):
-      subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+      subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-unknown-pragmas',
                              '-o', _LIB, _SRC])
     L = ctypes.CDLL(_LIB)
     L.emu_last_error.restype = ctypes.c_char_p
