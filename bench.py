@@ -113,14 +113,20 @@ def main():
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  # DMC_BENCH_BACKEND=gloo + DMC_BENCH_SINGLE_DEVICE=1 exist only to exercise the N > 1
+  # code path on a one-GPU box (all ranks share cuda:0); the driver uses nccl (= RCCL).
+  backend = os.environ.get('DMC_BENCH_BACKEND', 'nccl')
+  if os.environ.get('DMC_BENCH_SINGLE_DEVICE'):
+    local_rank = 0
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs a GPU: the batched step has no CPU fallback')
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
+  red_dev = dev if backend == 'nccl' else torch.device('cpu')
   from dm_control_amd.batch import BatchedPhysics, OUT
 
   model = cheetah_model()
@@ -171,7 +177,7 @@ def main():
   elapsed = time.perf_counter() - t_start
   kernel_ms = ev0.elapsed_time(ev1) / K
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
   # ---- rollout leg: the same K env-steps, same resident action tensor, ONE launch per
@@ -193,7 +199,7 @@ def main():
   torch.cuda.synchronize()
   rollout_elapsed = time.perf_counter() - r0
   if world > 1:
-    t = torch.tensor([rollout_elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([rollout_elapsed], dtype=torch.float64, device=red_dev)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     rollout_elapsed = float(t.item())
   warn = phys.get('warning').sum(axis=0)

@@ -152,7 +152,7 @@ class BatchedPhysics:
 
   PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
                 'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
-                'euler', 'trailing_step1', 'store', 'kin_lev0', 'kin_lev1', 'kin_lev2', 'kin_lev3', 'kin_lev4+', 'x23']
+                'euler', 'trailing_step1', 'store']
 
   def prof_enable(self, on=True):
     _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))
@@ -161,7 +161,7 @@ class BatchedPhysics:
     buf = np.zeros(32)
     n = ctypes.c_int()
     _native.check(_native.lib().dmc_batch_prof_get(self._ptr, buf.ctypes.data, ctypes.byref(n)))
-    return dict(zip(self.PROF_NAMES, buf[:n.value]))
+    return dict(zip(self.PROF_NAMES, buf[:len(self.PROF_NAMES)]))
 
   # -- debug ----------------------------------------------------------------------------
   def debug_enable(self, n):

@@ -221,7 +221,6 @@ template <int CTRL> DMC_DEV double dpp_f(double v) {
   const int lo = dpp_i<CTRL>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL>((int)(b >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-DMC_DEV int dpp_v(int v, int) { return v; }
 #endif
 // Sum over the LPE lanes of a group; every lane receives the total.  Same
 // pairing tree as an xor butterfly (1, 2, 4, 8 inside a row via DPP quad_perm /
@@ -234,13 +233,6 @@ template <int LPE, typename V> DMC_DEV V group_sum(V v) {
   if (LPE >= 16) v += dpp_f<0x140>(v);  // row_mirror
   if (LPE >= 32) v += __shfl_xor(v, 16, 64);
   if (LPE >= 64) v += __shfl_xor(v, 32, 64);
-#endif
-  return v;
-}
-template <int LPE> DMC_DEV int group_sum_i(int v) {
-#ifndef DMC_HOST_EMU
-#pragma unroll
-  for (int o = LPE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPE);
 #endif
   return v;
 }
