@@ -145,10 +145,14 @@ template <typename T> DMC_DEV void mul_matT_vec3(T* r, const T* m, const T* v) {
 template <typename T> DMC_DEV void rot_vec_quat(T* r, const T* v, const T* q) {
   T m[9]; quat2mat(m, q); mul_mat_vec3(r, m, v);
 }
+// one range reduction for both values (bitwise the same results as sin / cos)
+DMC_DEV void t_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+DMC_DEV void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 template <typename T> DMC_DEV void axisangle2quat(T* q, const T* axis, T angle) {
   if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
-  T s = t_sin(angle * (T)0.5);
-  q[0] = t_cos(angle * (T)0.5); q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+  T s, c;
+  t_sincos(angle * (T)0.5, &s, &c);
+  q[0] = c; q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
 }
 template <typename T> DMC_DEV void quat_integrate(T* quat, const T* vel, T scale) {
   T tmp[3] = {vel[0], vel[1], vel[2]}, qrot[4];
