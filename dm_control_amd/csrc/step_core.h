@@ -893,6 +893,7 @@ struct StepCore {
     const unsigned m = (unsigned)(dofid < 32 ? MI(dof_anc_lo)[lastdof] : MI(dof_anc_hi)[lastdof]);
     return (m >> (dofid & 31)) & 1u;
   }
+  DMC_DEV int contact_rows(int dim) const { return dim == 1 ? 1 : (L.d.elliptic ? dim : 2*(dim - 1)); }
   DMC_DEV void make_constraint() {
     const int nv = L.d.nv, njmax = L.d.njmax;
     int nefc = 0, overflow = 0;
@@ -935,7 +936,7 @@ struct StepCore {
         const int p = SI(con_pair)[c];
         dim = MI(pair_dim)[p];
         incl = MR(pair_margin)[p] - MR(pair_gap)[p];
-        nrow = dim == 1 ? 1 : 2*(dim - 1);
+        nrow = contact_rows(dim);
         if (S(con_dist)[c] >= incl) nrow = 0;   // in the gap: excluded
       }
       int total;
@@ -945,9 +946,12 @@ struct StepCore {
         else if (off + nrow > njmax) { SI(con_efc)[c] = -1; overflow = 1; }
         else {
           SI(con_efc)[c] = off;
+          // pyramidal edges all carry (dist, margin); elliptic friction rows carry (0, 0)
+          const bool ell = L.d.elliptic && dim > 1;
           for (int r = off; r < off + nrow; r++) {
-            S(efc_aref)[r] = S(con_dist)[c]; S(efc_D)[r] = incl;
-            SI(efc_tid)[r] = EFC_TID(dim == 1 ? EFC_FRICTIONLESS : EFC_PYRAMIDAL, c);
+            const bool nrm = !ell || r == off;
+            S(efc_aref)[r] = nrm ? S(con_dist)[c] : (T)0; S(efc_D)[r] = nrm ? incl : (T)0;
+            SI(efc_tid)[r] = EFC_TID(dim == 1 ? EFC_FRICTIONLESS : (ell ? EFC_ELLIPTIC : EFC_PYRAMIDAL), c);
           }
         }
       }
@@ -960,7 +964,7 @@ struct StepCore {
       // the limit rows if no contact fit).
       int last = nefc_lim;
       for (int c = lane; c < ncon; c += LPE) if (SI(con_efc)[c] >= 0) {
-        const int dim = MI(pair_dim)[SI(con_pair)[c]]; const int e = SI(con_efc)[c] + (dim == 1 ? 1 : 2*(dim - 1));
+        const int e = SI(con_efc)[c] + contact_rows(MI(pair_dim)[SI(con_pair)[c]]);
         last = e > last ? e : last;
       }
       nefc = group_max<LPE>(last);
@@ -998,6 +1002,7 @@ struct StepCore {
         for (int a = 0; a < 3; a++) { jac[a] = dot3(fr + 3*a, dp); jac[3 + a] = dot3(fr + 3*a, dr); }
       }
       if (dim == 1) S(efc_J)[r0*nv + dd] = jac[0];
+      else if (L.d.elliptic) for (int k = 0; k < dim; k++) S(efc_J)[(r0 + k)*nv + dd] = jac[k];
       else for (int k = 1; k < dim; k++) {
         const T f = MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
         S(efc_J)[(r0 + 2*(k - 1))*nv + dd] = jac[0] + f*jac[k];
@@ -1011,6 +1016,7 @@ struct StepCore {
       const int type = EFC_TYPE(SI(efc_tid)[i]), id = EFC_ID(SI(efc_tid)[i]);
       const T pos = S(efc_aref)[i], margin = S(efc_D)[i];   // staged by the row headers above
       T mu = 0; T dA0 = 0;
+      int ell_row = 0; T ell_fj = 0, ell_imp0 = 0;
       if (type == EFC_LIMIT) {
         solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
         dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
@@ -1021,7 +1027,15 @@ struct StepCore {
         const T rot = MR(body_invweight0)[2*b1 + 1] + MR(body_invweight0)[2*b2 + 1];
         solref = MR(pair_solref) + 2*cp; solimp = MR(pair_solimp) + 5*cp;
         if (type == EFC_FRICTIONLESS) dA = tran;
-        else {
+        else if (type == EFC_ELLIPTIC) {
+          ell_row = i - SI(con_efc)[id];   // 0 normal, 1..2 slide, 3 torsion, 4..5 roll
+          dA = ell_row < 3 ? tran : rot;
+          if (ell_row > 0) {
+            mu = MR(pair_friction)[3*cp]; dA0 = tran;
+            ell_fj = MR(pair_friction)[3*cp + (ell_row < 3 ? 0 : (ell_row == 3 ? 1 : 2))];
+            ell_imp0 = get_impedance(solimp, S(con_dist)[id], MR(pair_margin)[cp] - MR(pair_gap)[cp]);
+          }
+        } else {
           const int j = i - SI(con_efc)[id];
           const int k = j/2;   // friction index 0,1: slide; 2: torsion; 3,4: roll
           const T fri = MR(pair_friction)[3*cp + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
@@ -1033,8 +1047,16 @@ struct StepCore {
       T ref0 = solref[0], ref1 = solref[1];
       if (!(o.disableflags & DMC_DSBL_REFSAFE) && ref0 > 0) ref0 = t_max(ref0, 2*o.timestep);
       const T imp = get_impedance(solimp, pos, margin);
-      if (type == EFC_PYRAMIDAL) { const T R0 = t_max((T)DMC_MINVAL, (1 - imp)*dA0/imp); R = 2*mu*mu*R0; }
-      else R = t_max((T)DMC_MINVAL, (1 - imp)*dA/imp);
+      // frictional rows: R(first friction) = R(normal)/impratio; regularised mu = mu*sqrt(R1/R0)
+      if (type == EFC_PYRAMIDAL) {
+        const T R0 = t_max((T)DMC_MINVAL, (1 - imp)*dA0/imp);
+        if (o.impratio != 1) { const T R1 = R0 / t_max((T)DMC_MINVAL, o.impratio); mu *= t_sqrt(R1/R0); }
+        R = 2*mu*mu*R0;
+      } else if (ell_row > 0) {
+        const T R0 = t_max((T)DMC_MINVAL, (1 - ell_imp0)*dA0/ell_imp0);
+        const T R1 = R0 / t_max((T)DMC_MINVAL, o.impratio);
+        R = ell_row == 1 ? R1 : R1*mu*mu/(ell_fj*ell_fj);
+      } else R = t_max((T)DMC_MINVAL, (1 - imp)*dA/imp);
       const T dmax = t_max((T)DMC_MINIMP, t_min((T)DMC_MAXIMP, solimp[1]));
       T K, Bd;
       if (ref0 > 0) { K = 1 / t_max((T)DMC_MINVAL, dmax*dmax*ref0*ref0*ref1*ref1); Bd = 2 / t_max((T)DMC_MINVAL, dmax*ref0); }
@@ -1174,6 +1196,7 @@ struct StepCore {
     const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
     const T* f = S(efc_force) + r0;
     if (dim == 1) { f6[0] = f[0]; return; }
+    if (L.d.elliptic) { for (int k = 0; k < dim; k++) f6[k] = f[k]; return; }
     for (int k = 0; k < 2*(dim - 1); k++) f6[0] += f[k];
     for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
   }
@@ -1422,7 +1445,152 @@ struct StepCore {
   // efc_state/efc_force from efc_jar; returns the constraint cost (group-uniform)
   // track != null: also record the active set and report whether it differs from
   // the one H was last factored for (0/1, group-uniform)
+  // elliptic cones: a frictional contact is one block of `dim` rows whose cost is
+  // the squared distance of the residual to the dual cone -- three zones
+  // (top: satisfied, bottom: per-row quadratic, middle: 0.5 Dm (N - mu T)^2).
+  // The lane that owns the block's first row handles the whole block.  For the
+  // middle zone it also leaves the rank structure of the block Hessian
+  //   Hc = Dm [ p p' + c (diag(g) - w w') ]   (p, w: combinations of the block's rows)
+  // in efc_ca / efc_cb / efc_cg for newton_gradient.
+  DMC_DEV T constraint_update_ell(int nefc, int* track) {
+    T cost = 0;
+    int changed = 0;
+    for (int i = lane; i < nefc; i += LPE) {
+      const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
+        const T jar = S(efc_jar)[i];
+        const int act = jar < 0;
+        if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
+        else S(efc_force)[i] = 0;
+        if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
+        continue;
+      }
+      const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
+      if (i != r0) continue;
+      const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
+      const T* fr = MR(pair_friction) + 3*cp;
+      const T D0 = S(efc_D)[r0];
+      const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);   // regularised cone: mu sqrt(R1/R0)
+      T U[6], fj[6], Tn = 0;
+      U[0] = S(efc_jar)[r0]*mu; fj[0] = mu;
+      for (int j = 1; j < dim; j++) {
+        fj[j] = fr[j < 3 ? 0 : (j == 3 ? 1 : 2)];
+        U[j] = S(efc_jar)[r0 + j]*fj[j]; Tn += U[j]*U[j];
+      }
+      Tn = t_sqrt(Tn);
+      const T N = U[0];
+      int st;
+      if (N >= mu*Tn || (Tn <= 0 && N >= 0)) {
+        st = EFC_ST_SATISFIED;
+        for (int j = 0; j < dim; j++) S(efc_force)[r0 + j] = 0;
+      } else if (mu*N + Tn <= 0 || (Tn <= 0 && N < 0)) {
+        st = EFC_ST_QUADRATIC;
+        for (int j = 0; j < dim; j++) {
+          const T jar = S(efc_jar)[r0 + j], D = S(efc_D)[r0 + j];
+          S(efc_force)[r0 + j] = -D*jar; cost += (T)0.5*D*jar*jar;
+        }
+      } else {
+        st = EFC_ST_CONE;
+        const T Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu)), NT = N - mu*Tn;
+        cost += (T)0.5*Dm*NT*NT;
+        const T f0 = -Dm*NT*mu;
+        S(efc_force)[r0] = f0;
+        const T cc = -NT*mu/Tn;   // > 0
+        S(efc_ca)[r0] = mu; S(efc_cb)[r0] = Dm*cc; S(efc_cg)[r0] = Dm;
+        for (int j = 1; j < dim; j++) {
+          const T uh = U[j]/Tn;
+          S(efc_force)[r0 + j] = -f0/Tn * U[j]*fj[j];
+          S(efc_ca)[r0 + j] = -mu*uh*fj[j]; S(efc_cb)[r0 + j] = uh*fj[j]; S(efc_cg)[r0 + j] = Dm*cc*fj[j]*fj[j];
+        }
+      }
+      if (track) {
+        // a cone-zone Hessian depends on the residual itself, not just on the zone
+        if (SI(efc_active)[r0] != st || st == EFC_ST_CONE) changed = 1;
+        for (int j = 0; j < dim; j++) SI(efc_active)[r0 + j] = st;
+      }
+    }
+    cost = group_sum<LPE>(cost);
+    if (track) *track = group_max<LPE>(changed);
+    DMC_WSYNC();
+    return cost;
+  }
+  // H(i, j) = M(i, j) + sum over active rows / cone blocks (elliptic models)
+  DMC_DEV T hess_entry_ell(int i, int j, int nefc) {
+    const int nv = L.d.nv;
+    T h = S(qM)[i*nv + j];
+    for (int r = 0; r < nefc; r++) {
+      const int st = SI(efc_active)[r];
+      if (st == EFC_ST_QUADRATIC) {
+        const T ji = S(efc_J)[r*nv + i];
+        if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
+      } else if (st == EFC_ST_CONE) {
+        const int dim = MI(pair_dim)[SI(con_pair)[EFC_ID(SI(efc_tid)[r])]];
+        T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+        for (int a = 0; a < dim; a++) {
+          const T ji = S(efc_J)[(r + a)*nv + i], jj = S(efc_J)[(r + a)*nv + j];
+          const T ca = S(efc_ca)[r + a];
+          Pi += ca*ji; Pj += ca*jj;
+          if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
+        }
+        h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
+        r += dim - 1;
+      }
+    }
+    return h;
+  }
+  // line-search point for elliptic models: quadratic rows as in ls_eval_lds, plus
+  // the non-quadratic middle-zone term of every frictional contact
+  DMC_DEV void ls_eval_ell(dmc::LSPoint<T>* p, const T* qg, int nefc) {
+    const T a = p->alpha;
+    T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
+    for (int i = lane; i < nefc; i += LPE) {
+      const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
+        const T jar = S(efc_jar)[i], jv = S(efc_jv)[i];
+        if (jar + a*jv < 0) { const T D = S(efc_D)[i], dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        continue;
+      }
+      const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
+      if (i != r0) continue;
+      const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
+      const T* fr = MR(pair_friction) + 3*cp;
+      const T D0 = S(efc_D)[r0];
+      const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);
+      const T U0 = S(efc_jar)[r0]*mu, V0 = S(efc_jv)[r0]*mu;
+      T UU = 0, UV = 0, VV = 0;
+      for (int j = 1; j < dim; j++) {
+        const T f = fr[j < 3 ? 0 : (j == 3 ? 1 : 2)];
+        const T u = S(efc_jar)[r0 + j]*f, v = S(efc_jv)[r0 + j]*f;
+        UU += u*u; UV += u*v; VV += v*v;
+      }
+      const T N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
+      bool bottom = false;
+      if (Tsqr <= 0) bottom = N < 0;
+      else {
+        const T Tn = t_sqrt(Tsqr);
+        if (N >= mu*Tn) {}
+        else if (mu*N + Tn <= 0) bottom = true;
+        else {
+          const T Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
+          const T N1 = V0, T1 = (UV + a*VV)/Tn, T2 = VV/Tn - (UV + a*VV)*T1/(Tn*Tn);
+          const T NT = N - mu*Tn, NT1 = N1 - mu*T1;
+          cc += (T)0.5*Dm*NT*NT; cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+        }
+      }
+      if (bottom) for (int j = 0; j < dim; j++) {
+        const T jar = S(efc_jar)[r0 + j], jv = S(efc_jv)[r0 + j], D = S(efc_D)[r0 + j], dj0 = D*jar;
+        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+      }
+    }
+    q0 = group_sum<LPE>(q0) + qg[0]; q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
+    cc = group_sum<LPE>(cc); cd0 = group_sum<LPE>(cd0); cd1 = group_sum<LPE>(cd1);
+    p->cost = a*a*q2 + a*q1 + q0 + cc;
+    p->d0 = 2*a*q2 + q1 + cd0;
+    p->d1 = 2*q2 + cd1;
+    if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+  }
   DMC_DEV T constraint_update(int nefc, int* track = nullptr) {
+    if (L.d.elliptic) return constraint_update_ell(nefc, track);
     T cost = 0;
     int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
@@ -1466,6 +1634,12 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
+    if (L.d.elliptic) {
+      for (int idx = lane; idx < L.d.ntri; idx += LPE) {
+        const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
+        S(qLH)[i*nv + j] = hess_entry_ell(i, j, nefc);
+      }
+    } else
     for (int idx = lane; idx < L.d.ntri; idx += LPE) {
       const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
       T h = S(qM)[i*nv + j];
@@ -1490,6 +1664,7 @@ struct StepCore {
   }
   typedef dmc::LSPoint<T> LSPoint;
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
+    if (L.d.elliptic) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
     ls_eval_lds<T, LPE>(p, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv), (const DMC_LDS T*)S(efc_D),
                         qg[0], qg[1], qg[2], nefc, lane);
     (*evals)++;

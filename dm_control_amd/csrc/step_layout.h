@@ -21,6 +21,7 @@ struct StepDims {
   int njmax;     // constraint-row cap per environment
   int rk4;       // 1: RK4 integrator (extra stage buffers)
   int ntri;      // nv (nv + 1) / 2: lower-triangle entries of an nv x nv matrix
+  int elliptic;  // 1: frictional contacts use elliptic cones (one row per contact-frame axis)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -97,7 +98,10 @@ struct StepDims {
   X(subtree_mom, 3 * d.nbody)
 #define STEP_SCRATCH_OVL_SOL(X)                                                \
   X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
-  X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)
+  X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)                    \
+  /* elliptic cones: per-row coefficients of the middle-zone Hessian (newton_gradient) */ \
+  X(efc_ca, d.elliptic * d.njmax) X(efc_cb, d.elliptic * d.njmax)              \
+  X(efc_cg, d.elliptic * d.njmax)
 #define STEP_SCRATCH_ALL_REAL(X) \
   STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 
@@ -114,7 +118,8 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..10: 8 warning cou
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8 };
-enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2 };
+enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3 };
+enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 2) | (type))
 #define EFC_TYPE(tid) ((tid) & 3)
 #define EFC_ID(tid) ((tid) >> 2)

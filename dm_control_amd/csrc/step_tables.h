@@ -75,11 +75,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   d.nsite = m.nsite; d.nsensor = m.nsensor; d.nsensordata = m.nsensordata; d.npair = m.npair;
   if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
   if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
-  if (m.opt_cone != DMC_CONE_PYRAMIDAL) {
-    bool fric = false;
-    for (int g = 0; g < m.ngeom; g++) if (m.geom_condim[g] > 1) fric = true;
-    if (fric && m.npair) { *err = "elliptic friction cones are not implemented in the HIP path yet"; return false; }
-  }
+  const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
   if (m.opt_solver != DMC_SOL_NEWTON) { *err = "only the Newton solver is implemented in the HIP path"; return false; }
   if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
   d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
@@ -123,16 +119,17 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (pr1 == pr2) dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
     else dim = m.geom_condim[pr1 > pr2 ? g1 : g2];
     pdim[p] = dim;
-    maxc += nc; maxr += nc * (dim == 1 ? 1 : 2*(dim - 1));
+    maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
   t->max_contacts = maxc; t->max_rows = maxr + nlim;
   int maxrow_per_contact = 1;
-  for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : 2*(pdim[p] - 1));
+  for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
   if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
   if (njmax <= 0) njmax = nlim + nconmax * maxrow_per_contact;
   njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim)));
   d.nconmax = nconmax; d.njmax = njmax;
+  d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
   step_layout_build(&t->L, d);
   const StepLayout& L = t->L;
   t->mi.assign(L.n_mi, 0);

@@ -60,10 +60,11 @@ typedef struct {
   int nconmax, njmax;
 } Model;
 
-enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2 };
+enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3 };
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
+  double H[36]; /* elliptic cone Hessian of the middle zone (dim x dim) */
   int dim, geom1, geom2, efc_address, exclude;
 } Contact;
 
@@ -798,8 +799,8 @@ static void make_constraint(const Model* m, Data* d) {
     Contact* c = d->contact + ci;
     if (c->exclude) continue;
     int dim = c->dim, b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
-    int nrow = dim == 1 ? 1 : 2*(dim - 1);
-    if (m->opt_cone != DMC_CONE_PYRAMIDAL && dim > 1) { g_err = "elliptic cones not restated"; nrow = 2*(dim - 1); }
+    int elliptic = m->opt_cone == DMC_CONE_ELLIPTIC && dim > 1;
+    int nrow = dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1));
     if (d->nefc + nrow > m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
     /* contact-frame Jacobian difference: rows 0..2 translational, 3..5 rotational */
     double* jac = d->w_tmp; /* 6*nv */
@@ -818,6 +819,14 @@ static void make_constraint(const Model* m, Data* d) {
       int r = d->nefc++;
       memcpy(d->efc_J + (size_t)r*nv, jac, sizeof(double) * (size_t)nv);
       d->efc_pos[r] = c->dist; d->efc_margin[r] = c->includemargin; d->efc_type[r] = CT_FRICTIONLESS; d->efc_id[r] = ci;
+    } else if (elliptic) {
+      /* one row per contact-frame axis: normal carries (dist, margin), friction rows (0, 0) */
+      for (int k = 0; k < dim; k++) {
+        int r = d->nefc++;
+        memcpy(d->efc_J + (size_t)r*nv, jac + (size_t)k*nv, sizeof(double) * (size_t)nv);
+        d->efc_pos[r] = k == 0 ? c->dist : 0; d->efc_margin[r] = k == 0 ? c->includemargin : 0;
+        d->efc_type[r] = CT_ELLIPTIC; d->efc_id[r] = ci;
+      }
     } else {
       for (int k = 1; k < dim; k++) for (int s = 0; s < 2; s++) {
         int r = d->nefc++;
@@ -842,6 +851,7 @@ static void make_constraint(const Model* m, Data* d) {
       double rot = m->body_invweight0[2*b1 + 1] + m->body_invweight0[2*b2 + 1];
       solref = c->solref; solimp = c->solimp;
       if (d->efc_type[i] == CT_FRICTIONLESS) dA = tran;
+      else if (d->efc_type[i] == CT_ELLIPTIC) dA = (i - c->efc_address) < 3 ? tran : rot;
       else { int j = i - c->efc_address; double fri = c->friction[j/2]; dA = tran + fri*fri*(j < 4 ? tran : rot); }
     }
     d->efc_diagApprox[i] = dA;
@@ -854,14 +864,25 @@ static void make_constraint(const Model* m, Data* d) {
     else { K = -ref[0] / mjMAX(MINVAL, dmax*dmax); B = -ref[1] / mjMAX(MINVAL, dmax); }
     d->efc_KBIP[4*i] = K; d->efc_KBIP[4*i + 1] = B; d->efc_KBIP[4*i + 2] = imp; d->efc_KBIP[4*i + 3] = 0;
   }
-  /* pyramidal contacts: all edges share Rpy = 2 mu^2 R(first edge) */
-  for (int i = 0; i < nefc; i++) if (d->efc_type[i] == CT_PYRAMIDAL) {
+  /* frictional contacts: the friction rows' regularisation is tied to the normal's.
+   * R(first friction) = R(normal)/impratio; regularised cone mu = friction[0]*sqrt(R1/R0);
+   * elliptic: R_j mu_j^2 is the same for every friction row; pyramidal: all edges
+   * share Rpy = 2 mu^2 R(first edge). */
+  for (int i = 0; i < nefc; i++) if (d->efc_type[i] == CT_PYRAMIDAL || d->efc_type[i] == CT_ELLIPTIC) {
     Contact* c = d->contact + d->efc_id[i];
-    int n = 2*(c->dim - 1);
-    c->mu = c->friction[0];
-    double Rpy = 2 * c->mu * c->mu * d->efc_R[i];
-    for (int j = 0; j < n; j++) d->efc_R[i + j] = Rpy;
-    i += n - 1;
+    double R1 = d->efc_R[i] / mjMAX(MINVAL, m->opt_impratio);
+    c->mu = c->friction[0] * sqrt(R1 / d->efc_R[i]);
+    if (d->efc_type[i] == CT_ELLIPTIC) {
+      d->efc_R[i + 1] = R1;
+      for (int j = 2; j < c->dim; j++)
+        d->efc_R[i + j] = R1 * c->friction[0]*c->friction[0] / (c->friction[j - 1]*c->friction[j - 1]);
+      i += c->dim - 1;
+    } else {
+      int n = 2*(c->dim - 1);
+      double Rpy = 2 * c->mu * c->mu * d->efc_R[i];
+      for (int j = 0; j < n; j++) d->efc_R[i + j] = Rpy;
+      i += n - 1;
+    }
   }
   for (int i = 0; i < nefc; i++) {
     d->efc_D[i] = 1 / d->efc_R[i];
@@ -1201,24 +1222,88 @@ static void fwd_acceleration(const Model* m, Data* d) {
 /* ------------------------------------------------------------------------- */
 /* constraint solver: Newton on the primal          */
 /* ------------------------------------------------------------------------- */
-enum { ST_SATISFIED = 0, ST_QUADRATIC = 1 };
+enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_CONE = 2 };
 static double constraint_update(const Model* m, Data* d, const double* jar, int flg_state_only) {
   (void)m; (void)flg_state_only;
   double cost = 0;
   for (int i = 0; i < d->nefc; i++) {
+    if (d->efc_type[i] == CT_ELLIPTIC) {
+      /* map the residual to the regular dual cone: U = diag(mu, friction) * jar */
+      Contact* c = d->contact + d->efc_id[i];
+      int dim = c->dim; double mu = c->mu, U[6], T = 0;
+      U[0] = jar[i]*mu;
+      for (int j = 1; j < dim; j++) { U[j] = jar[i + j]*c->friction[j - 1]; T += U[j]*U[j]; }
+      T = sqrt(T);
+      double N = U[0];
+      if (N >= mu*T || (T <= 0 && N >= 0)) {            /* top zone: inside the dual cone */
+        for (int j = 0; j < dim; j++) { d->efc_state[i + j] = ST_SATISFIED; d->efc_force[i + j] = 0; }
+      } else if (mu*N + T <= 0 || (T <= 0 && N < 0)) {  /* bottom zone: plain quadratic */
+        for (int j = 0; j < dim; j++) {
+          d->efc_state[i + j] = ST_QUADRATIC; d->efc_force[i + j] = -d->efc_D[i + j]*jar[i + j];
+          cost += 0.5*d->efc_D[i + j]*jar[i + j]*jar[i + j];
+        }
+      } else {                                          /* middle zone: distance to the cone surface */
+        double Dm = d->efc_D[i] / mjMAX(MINVAL, mu*mu*(1 + mu*mu)), NT = N - mu*T;
+        cost += 0.5*Dm*NT*NT;
+        d->efc_force[i] = -Dm*NT*mu;
+        for (int j = 1; j < dim; j++) d->efc_force[i + j] = -d->efc_force[i]/T * U[j]*c->friction[j - 1];
+        for (int j = 0; j < dim; j++) d->efc_state[i + j] = ST_CONE;
+        /* Hessian of 0.5 Dm (N - mu T)^2 w.r.t. jar */
+        double* H = c->H;
+        H[0] = 1;
+        for (int j = 1; j < dim; j++) H[j] = -mu*U[j]/T;
+        double s3 = mu*N/(T*T*T), dg = mu*mu - mu*N/T;
+        for (int k = 1; k < dim; k++) for (int j = k; j < dim; j++) H[k*dim + j] = s3*U[j]*U[k] + (j == k ? dg : 0);
+        for (int k = 0; k < dim; k++) for (int j = k; j < dim; j++) {
+          double sc = Dm * (j == 0 ? mu : c->friction[j - 1]) * (k == 0 ? mu : c->friction[k - 1]);
+          H[k*dim + j] *= sc; H[j*dim + k] = H[k*dim + j];
+        }
+      }
+      i += dim - 1;
+      continue;
+    }
     if (jar[i] < 0) { d->efc_state[i] = ST_QUADRATIC; d->efc_force[i] = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; }
     else { d->efc_state[i] = ST_SATISFIED; d->efc_force[i] = 0; }
   }
   return cost;
 }
 typedef struct { double alpha, cost, deriv[2]; } LSPoint;
-typedef struct { double quadGauss[3]; int nefc; const double *jar, *jv, *quad; int evals; } LSCtx;
+typedef struct { double quadGauss[3]; int nefc; const double *jar, *jv, *quad; int evals; const Data* d; } LSCtx;
 static void ls_eval(const LSCtx* c, LSPoint* p) {
   double a = p->alpha, qt[3] = {c->quadGauss[0], c->quadGauss[1], c->quadGauss[2]};
-  for (int i = 0; i < c->nefc; i++) if (c->jar[i] + a*c->jv[i] < 0) { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; }
-  p->cost = a*a*qt[2] + a*qt[1] + qt[0];
-  p->deriv[0] = 2*a*qt[2] + qt[1];
-  p->deriv[1] = 2*qt[2];
+  double ccost = 0, cd0 = 0, cd1 = 0; /* non-quadratic part: elliptic contacts in the middle zone */
+  for (int i = 0; i < c->nefc; i++) {
+    if (c->d->efc_type[i] == CT_ELLIPTIC) {
+      const Contact* con = c->d->contact + c->d->efc_id[i];
+      int dim = con->dim; double mu = con->mu;
+      double U0 = c->jar[i]*mu, V0 = c->jv[i]*mu, UU = 0, UV = 0, VV = 0;
+      for (int j = 1; j < dim; j++) {
+        double u = c->jar[i + j]*con->friction[j - 1], v = c->jv[i + j]*con->friction[j - 1];
+        UU += u*u; UV += u*v; VV += v*v;
+      }
+      double N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
+      int bottom = 0;
+      if (Tsqr <= 0) bottom = N < 0;
+      else {
+        double T = sqrt(Tsqr);
+        if (N >= mu*T) {}
+        else if (mu*N + T <= 0) bottom = 1;
+        else {
+          double Dm = c->d->efc_D[i] / mjMAX(MINVAL, mu*mu*(1 + mu*mu));
+          double N1 = V0, T1 = (UV + a*VV)/T, T2 = VV/T - (UV + a*VV)*T1/(T*T);
+          double NT = N - mu*T, NT1 = N1 - mu*T1;
+          ccost += 0.5*Dm*NT*NT; cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+        }
+      }
+      if (bottom) for (int j = 0; j < dim; j++) { qt[0] += c->quad[3*(i + j)]; qt[1] += c->quad[3*(i + j) + 1]; qt[2] += c->quad[3*(i + j) + 2]; }
+      i += dim - 1;
+      continue;
+    }
+    if (c->jar[i] + a*c->jv[i] < 0) { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; }
+  }
+  p->cost = a*a*qt[2] + a*qt[1] + qt[0] + ccost;
+  p->deriv[0] = 2*a*qt[2] + qt[1] + cd0;
+  p->deriv[1] = 2*qt[2] + cd1;
   if (p->deriv[1] <= 0) p->deriv[1] = MINVAL;
   ((LSCtx*)c)->evals++;
 }
@@ -1236,7 +1321,7 @@ static double primal_search(const Model* m, Data* d, double gauss, double scale)
   double *search = d->w_search, *Mv = d->w_Mv, *jv = d->w_Jv, *jar = d->w_Jaref, *quad = d->w_quad;
   for (int i = 0; i < nv; i++) Mv[i] = dot_n(d->qM + (size_t)i*nv, search, nv);
   for (int i = 0; i < nefc; i++) jv[i] = dot_n(d->efc_J + (size_t)i*nv, search, nv);
-  LSCtx c; c.nefc = nefc; c.jar = jar; c.jv = jv; c.quad = quad; c.evals = 0;
+  LSCtx c; c.d = d; c.nefc = nefc; c.jar = jar; c.jv = jv; c.quad = quad; c.evals = 0;
   c.quadGauss[0] = gauss;
   c.quadGauss[1] = dot_n(search, d->w_Ma, nv) - dot_n(d->qfrc_smooth, search, nv);
   c.quadGauss[2] = 0.5 * dot_n(search, Mv, nv);
@@ -1288,6 +1373,16 @@ static void newton_gradient(const Model* m, Data* d) {
   for (int r = 0; r < nefc; r++) if (d->efc_state[r] == ST_QUADRATIC) {
     const double* J = d->efc_J + (size_t)r*nv; double D = d->efc_D[r];
     for (int i = 0; i < nv; i++) { if (J[i] == 0) continue; double s = D*J[i]; for (int j = 0; j <= i; j++) H[i*nv + j] += s*J[j]; }
+  }
+  for (int r = 0; r < nefc; r++) if (d->efc_state[r] == ST_CONE) {
+    /* H += J_c^T Hcone J_c for a contact in the middle zone */
+    const Contact* c = d->contact + d->efc_id[r]; int dim = c->dim;
+    for (int a = 0; a < dim; a++) for (int b = 0; b < dim; b++) {
+      double h = c->H[a*dim + b]; if (h == 0) continue;
+      const double *Ja = d->efc_J + (size_t)(r + a)*nv, *Jb = d->efc_J + (size_t)(r + b)*nv;
+      for (int i = 0; i < nv; i++) { if (Ja[i] == 0) continue; double s = h*Ja[i]; for (int j = 0; j <= i; j++) H[i*nv + j] += s*Jb[j]; }
+    }
+    r += dim - 1;
   }
   for (int i = 0; i < nv; i++) for (int j = i + 1; j < nv; j++) H[i*nv + j] = H[j*nv + i];
   chol_factor(L, H, nv);
@@ -1354,6 +1449,7 @@ static void contact_force_local(const Model* m, const Data* d, int id, double* f
   if (c->efc_address < 0) return;
   const double* f = d->efc_force + c->efc_address;
   if (c->dim == 1) { f6[0] = f[0]; return; }
+  if (d->efc_type[c->efc_address] == CT_ELLIPTIC) { for (int k = 0; k < c->dim; k++) f6[k] = f[k]; return; }
   for (int k = 0; k < 2*(c->dim - 1); k++) f6[0] += f[k];
   for (int k = 1; k < c->dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * c->friction[k - 1];
 }

@@ -408,3 +408,75 @@ def test_rollout_equals_per_step_loop(cheetah, precision, nsub):
   np.testing.assert_array_equal(ro.get('sensordata'), loop.get('sensordata'))
   np.testing.assert_allclose(ro.get('time'), loop.get('time'), rtol=0, atol=0)
   loop.close(); ro.close()
+
+
+# ---- elliptic friction cones (cone="elliptic": suite finger / stacker / manipulator) ---------------
+_ELLIPTIC_SCENE = """
+<mujoco><option cone="elliptic" impratio="{impratio}" gravity="2 0.5 -9.81"/>
+<default><geom friction="0.7 0.02 0.003" condim="{condim}"/></default>
+<worldbody>
+  <geom name='floor' type='plane' size='5 5 1' conaffinity='5'/>
+  <body name='box' pos='0 0 .12'><freejoint/>
+    <geom name='box' type='box' size='.1 .08 .1' contype='4' conaffinity='4'/>
+    <body name='arm' pos='.1 0 .1'><joint name='h' type='hinge' axis='0 1 0' range='-60 60' limited='true'/>
+      <geom name='arm' type='capsule' fromto='0 0 0 .3 0 0' size='.04'/></body></body>
+  <body name='ball' pos='.5 .3 .1'><freejoint/><geom name='ball' size='.1'/></body>
+</worldbody></mujoco>"""
+
+
+@pytest.mark.parametrize('precision,condim,impratio,lanes', [(64, 3, 1.0, 64), (64, 4, 5.0, 32), (64, 6, 1.0, 16),
+                                                           (32, 3, 1.0, 0), (32, 6, 2.0, 0)])
+def test_elliptic_cones_match_oracle(precision, condim, impratio, lanes):
+  m = mc.compile_xml(_ELLIPTIC_SCENE.format(condim=condim, impratio=impratio))
+  B = 24
+  rs = np.random.RandomState(11)
+  q = np.tile(m.qpos0, (B, 1))
+  v = rs.uniform(-1, 1, (B, m.nv))
+  b = _batch(m, B, precision=precision, lanes_per_env=lanes)
+  b.set('qpos', q); b.set('qvel', v)
+  ora = _oracles(m, q, v)
+  b.forward()
+  np.testing.assert_array_equal(b.get('nefc')[:, 0], [o.nefc for o in ora])
+  nsteps = 300
+  if precision == 64:
+    for _ in range(nsteps // 50):
+      b.step(50)
+      for o in ora:
+        o.step(50)
+      err = _rel_err(b.get('qpos'), np.array([o.qpos for o in ora]))
+      assert err <= TOL_F64_1000, err
+  else:
+    # fp32: teacher-forced single steps from oracle states sampled along the trajectory
+    worst = 0.0
+    for k in range(20):
+      for o in ora:
+        o.step(10)
+      qo, vo = np.array([o.qpos for o in ora]), np.array([o.qvel for o in ora])
+      wo = np.array([o.qacc_warmstart for o in ora])
+      b.set('qpos', qo); b.set('qvel', vo); b.set('qacc_warmstart', wo)
+      b.step(1)
+      for o in ora:
+        o.step(1)
+      worst = max(worst, _rel_err(b.get('qpos'), np.array([o.qpos for o in ora])))
+    assert worst <= TOL_F32_ONE_STEP, worst
+  assert not b.get('warning').any()
+  b.close()
+
+
+def test_elliptic_contact_force_equals_weight_on_gpu():
+  # wrapper/core_test.py:393-416 with cone="elliptic", through touch (sums normal forces) and
+  # qfrc_constraint; fp64 kernel.
+  m = mc.compile_xml("""
+  <mujoco><option cone="elliptic"/><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='box' pos='0 0 .1'><freejoint/>
+      <geom name='box' type='box' size='.1 .1 .1'/>
+      <site name='s' type='box' size='.11 .11 .11'/></body>
+  </worldbody><sensor><touch name='t' site='s'/></sensor></mujoco>""")
+  b = _batch(m, 4, precision=64)
+  b.legacy_step = False
+  b.step(500)
+  b.forward()
+  np.testing.assert_allclose(b.get('sensordata')[:, 0], 9.81 * m.body_mass[1], rtol=0, atol=1e-6)
+  np.testing.assert_array_equal(b.get('nefc')[:, 0], 12)
+  b.close()

@@ -87,3 +87,45 @@ def test_contact_cap_raises_warning():
   e.forward()
   assert e.warning[mc.C['DMC_WARN_CONTACTFULL']] >= 1
   assert e.ncon[0] == 2
+
+
+_ELLIPTIC_SCENE = """
+<mujoco><option cone="elliptic" impratio="{impratio}" gravity="2 0.5 -9.81"/>
+<default><geom friction="0.7 0.02 0.003" condim="{condim}"/></default>
+<worldbody>
+  <geom name='floor' type='plane' size='5 5 1' conaffinity='5'/>
+  <body name='box' pos='0 0 .12'><freejoint/>
+    <geom name='box' type='box' size='.1 .08 .1' contype='4' conaffinity='4'/>
+    <body name='arm' pos='.1 0 .1'><joint name='h' type='hinge' axis='0 1 0' range='-60 60' limited='true'/>
+      <geom name='arm' type='capsule' fromto='0 0 0 .3 0 0' size='.04'/></body></body>
+  <body name='ball' pos='.5 .3 .1'><freejoint/><geom name='ball' size='.1'/></body>
+</worldbody></mujoco>"""
+
+
+@pytest.mark.parametrize('condim,impratio', [(3, 1.0), (4, 5.0), (6, 1.0)])
+def test_elliptic_cones_match_oracle(condim, impratio):
+  # cone="elliptic" (suite finger / stacker / manipulator): block rows, three-zone cost,
+  # cone Hessian and the non-quadratic line search, against the oracle's restatement.
+  m = mc.compile_xml(_ELLIPTIC_SCENE.format(condim=condim, impratio=impratio))
+  o, e = OraclePhysics(m), EmuPhysics(m, 64)
+  rs = np.random.RandomState(3)
+  v = rs.uniform(-1, 1, m.nv)
+  o.qvel[:] = v
+  e.qvel[:] = v
+  o.forward()
+  e.forward()
+  assert o.nefc == e.nefc[0] and o.ncon == e.ncon[0] and o.ncon > 0
+  ne = o.nefc
+  np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv], rtol=1e-11, atol=1e-13)
+  np.testing.assert_allclose(o.efc_D[:ne], e.scratch('efc_D')[:ne], rtol=1e-12)
+  np.testing.assert_allclose(o.efc_aref[:ne], e.scratch('efc_aref')[:ne], rtol=1e-9, atol=1e-9)
+  np.testing.assert_allclose(o.qacc, e.qacc, rtol=1e-8, atol=1e-8)
+  zones = set()
+  for _ in range(300):
+    o.step()
+    e.step()
+    zones |= set(e.scratch('efc_active')[:e.nefc[0]].tolist())
+    np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-8)
+  assert zones >= {0, 1, 2}    # top, bottom and cone zones were all exercised
+  np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-9)
+  assert not e.warning.any()

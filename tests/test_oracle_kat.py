@@ -272,3 +272,118 @@ def test_energy_conservation_free_pendulum():
   e0 = energy()
   p.step(500)
   assert abs(energy() - e0) < 1e-7
+
+
+# ---- elliptic friction cones (suite finger/stacker/manipulator use cone="elliptic") ----------------
+_BOX_ON_PLANE = """
+<mujoco><option cone="{cone}" gravity="{gx} 0 {gz}" impratio="{impratio}"/><worldbody>
+  <geom name='floor' type='plane' size='5 5 1' friction='{mu} .005 .0001'/>
+  <body name='box' pos='0 0 .1'>{joints}
+    <geom name='box' type='box' size='.1 .1 .1' friction='{mu} .005 .0001' condim='{condim}'/></body>
+</worldbody></mujoco>"""
+_PLANAR = "<joint type='slide' axis='1 0 0'/><joint type='slide' axis='0 1 0'/><joint type='slide' axis='0 0 1'/>"
+
+
+def _box(cone='elliptic', theta=0.0, mu=1.0, condim=3, impratio=1.0, free=False):
+  # `free=False`: translation only, so a tilted-gravity block slides without rocking on its corners
+  m = mc.compile_xml(_BOX_ON_PLANE.format(cone=cone, gx=G*np.sin(theta), gz=-G*np.cos(theta), mu=mu,
+                                          condim=condim, impratio=impratio,
+                                          joints='<freejoint/>' if free else _PLANAR))
+  return m, OraclePhysics(m, legacy_step=False)
+
+
+@pytest.mark.parametrize('condim', [3, 4, 6])
+def test_elliptic_contact_force_equals_weight(condim):
+  # wrapper/core_test.py:393-416 under cone="elliptic": one row per contact-frame axis, and
+  # mj_contactForce is the efc_force block itself.
+  m, p = _box(condim=condim, free=True)
+  for _ in range(500):
+    p.step()
+  assert p.ncon == 4 and p.nefc == 4 * condim
+  f = np.array([p.contact_force(i).ravel() for i in range(p.ncon)])
+  np.testing.assert_allclose(f[:, 0].sum(), G * m.body_mass[1], rtol=0, atol=1e-7)
+  np.testing.assert_allclose(f[:, 1:], 0, atol=1e-7)
+
+
+def test_elliptic_sliding_on_incline_matches_coulomb():
+  # mu < tan(theta): every loaded contact sits on the cone surface, |f_t| = mu f_n opposing the
+  # slip (MuJoCo computation chapter, "Friction cones").  The soft model couples slip speed into
+  # the normal force (the block chatters once mu*B*v exceeds g cos(theta)), so the Coulomb law is
+  # checked through the momentum identity that holds whether or not the block is airborne:
+  #   d(v_x + mu v_z)/dt = g (sin(theta) - mu cos(theta)).
+  theta, mu = 0.5, 0.3
+  m, p = _box(theta=theta, mu=mu)
+  for _ in range(20):
+    p.step()
+  v0, t0 = p.qvel.copy(), p.time
+  seen_contact = seen_air = False
+  for _ in range(400):
+    p.step()
+    f = np.array([p.contact_force(i).ravel() for i in range(p.ncon)]).reshape(-1, 6)
+    loaded = f[:, 0] > 1e-9
+    seen_contact |= bool(loaded.any())
+    seen_air |= p.ncon == 0
+    np.testing.assert_allclose(np.hypot(f[loaded, 1], f[loaded, 2]), mu * f[loaded, 0], rtol=1e-9)
+  assert seen_contact
+  dv, dt = p.qvel - v0, p.time - t0
+  np.testing.assert_allclose((dv[0] + mu * dv[2]) / dt, G * (np.sin(theta) - mu * np.cos(theta)), rtol=1e-9)
+
+
+def test_elliptic_sticking_on_incline_stays_inside_cone():
+  # mu > tan(theta): friction holds the block (soft-constraint creep only) and |f_t| < mu f_n.
+  theta, mu = 0.3, 1.0
+  m, p = _box(theta=theta, mu=mu)
+  for _ in range(500):
+    p.step()
+  assert abs(p.qvel[0]) < 2e-3
+  f = np.array([p.contact_force(i).ravel() for i in range(p.ncon)])
+  ft, fn = np.hypot(f[:, 1], f[:, 2]), f[:, 0]
+  assert np.all(ft <= mu * fn + 1e-9)
+  np.testing.assert_allclose(ft.sum(), G * np.sin(theta) * m.body_mass[1], rtol=2e-2)
+  np.testing.assert_allclose(fn.sum(), G * np.cos(theta) * m.body_mass[1], rtol=1e-3)
+
+
+def test_elliptic_impratio_hardens_friction():
+  # impratio scales the friction rows' regulariser: R_friction = R_normal / impratio, so the
+  # residual creep velocity of a stuck block shrinks roughly in proportion.
+  creep = []
+  for impratio in (1.0, 10.0):
+    _, p = _box(theta=0.3, mu=1.0, impratio=impratio)
+    for _ in range(500):
+      p.step()
+    creep.append(abs(p.qvel[0]))
+  assert creep[1] < 0.2 * creep[0]
+
+
+def test_elliptic_and_pyramidal_agree_at_rest():
+  # Without tangential load both cone models reduce to the same normal problem.
+  z = []
+  for cone in ('pyramidal', 'elliptic'):
+    _, p = _box(cone=cone, free=True)
+    for _ in range(300):
+      p.step()
+    z.append(p.qpos[2])
+  np.testing.assert_allclose(z[0], z[1], atol=2e-5)
+
+
+def test_elliptic_torsional_friction_stops_spin():
+  # condim 4: a ball spinning about the contact normal is braked by the torsional row only.
+  m = mc.compile_xml("""
+  <mujoco><option cone="elliptic"/><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='ball' pos='0 0 .1'><freejoint/>
+      <geom name='ball' size='.1' friction='1 .05 .001' condim='4'/></body>
+  </worldbody></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  for _ in range(100):
+    p.step()
+  p.qvel[5] = 5.0
+  p.step()
+  f = p.contact_force(0)
+  assert f[1, 0] != 0 and f[1, 1] == 0 and f[1, 2] == 0
+  # torsional torque saturates on the cone: |tau| = mu_torsion * f_n while spinning
+  np.testing.assert_allclose(abs(f[1, 0]), 0.05 * f[0, 0], rtol=1e-6)
+  w0 = p.qvel[5]
+  for _ in range(50):
+    p.step()
+  assert 0 <= p.qvel[5] < w0
