@@ -145,13 +145,11 @@ template <typename T> DMC_DEV void mul_matT_vec3(T* r, const T* m, const T* v) {
 template <typename T> DMC_DEV void rot_vec_quat(T* r, const T* v, const T* q) {
   T m[9]; quat2mat(m, q); mul_mat_vec3(r, m, v);
 }
-// one range reduction for both values (bitwise the same results as sin / cos)
-DMC_DEV void t_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
-DMC_DEV void t_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 template <typename T> DMC_DEV void axisangle2quat(T* q, const T* axis, T angle) {
-  if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
-  T s, c;
-  t_sincos(angle * (T)0.5, &s, &c);
+  // Straight-line on purpose: angle == 0 gives s = 0, c = 1, i.e. the identity MuJoCo
+  // returns early with; an early-out branch (or sincos()'s pointer outputs) makes the
+  // compiler route q through scratch memory.
+  const T s = t_sin(angle * (T)0.5), c = t_cos(angle * (T)0.5);
   q[0] = c; q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
 }
 template <typename T> DMC_DEV void quat_integrate(T* quat, const T* vel, T scale) {
@@ -372,10 +370,21 @@ DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b
 }
 // line-search evaluation: cost / derivatives of the piecewise quadratic at alpha
 template <typename T> struct LSPoint { T alpha, cost, d0, d1; };
+// Returned as a 4-vector {alpha, cost, d0, d1}: a pointer argument pins the caller's
+// points in scratch memory, and returning the struct itself by value measured 2x
+// slower on the whole kernel (MI355X, ROCm 7.2) -- the vector comes back in v0..v3.
+#ifdef DMC_HOST_EMU
+template <typename T> struct LSVec { T v[4]; DMC_DEV T operator[](int i) const { return v[i]; } };
+#define DMC_LSVEC(T) LSVec<T>
+#else
+#define DMC_LSVEC(T) T __attribute__((ext_vector_type(4)))
+#endif
 template <typename T, int LPE>
-DMC_FN void ls_eval_lds(LSPoint<T>* p, const DMC_LDS T* jar_, const DMC_LDS T* jv_, const DMC_LDS T* D_,
-                        T qg0, T qg1, T qg2, int nefc, int lane) {
-  const T a = p->alpha;
+DMC_FN DMC_LSVEC(T) ls_eval_lds(T a, const DMC_LDS T* jar_, const DMC_LDS T* jv_, const DMC_LDS T* D_,
+                                T qg0, T qg1, T qg2, int nefc, int lane) {
+  LSPoint<T> pt;
+  LSPoint<T>* p = &pt;
+  p->alpha = a;
   T q0 = 0, q1 = 0, q2 = 0;
   for (int i = lane; i < nefc; i += LPE) {
     const T jar = jar_[i], jv = jv_[i];
@@ -389,6 +398,8 @@ DMC_FN void ls_eval_lds(LSPoint<T>* p, const DMC_LDS T* jar_, const DMC_LDS T* j
   p->d0 = 2*a*q2 + q1;
   p->d1 = 2*q2;
   if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+  DMC_LSVEC(T) rv = {pt.alpha, pt.cost, pt.d0, pt.d1};
+  return rv;
 }
 
 // ---------------------------------------------------------------------------
@@ -746,8 +757,19 @@ struct StepCore {
     for (int k = 0; k < 3; k++) { h->pos[k] = p1[k] + n[k]*(r1 + dist*(T)0.5); h->nrm[k] = n[k]; }
     return 1;
   }
-  // narrow phase for one pair; returns number of hits (<= 4); tang = optional shared tangent
-  DMC_DEV int narrow_phase(int g1, int g2, T margin, Hit* h, T* tang, bool* has_tang) {
+  // h[n] = x with every slot index a compile-time constant, so that the hit
+  // buffer stays in registers (a dynamically indexed local array lives in scratch)
+  struct Hits { Hit s0, s1, s2, s3; };
+  DMC_DEV static void sel_hit(Hit& d, const Hit& x, bool c) {
+    d.dist = c ? x.dist : d.dist;
+    for (int k = 0; k < 3; k++) { d.pos[k] = c ? x.pos[k] : d.pos[k]; d.nrm[k] = c ? x.nrm[k] : d.nrm[k]; }
+  }
+  DMC_DEV static void put_hit(Hits* h, int n, const Hit& x) {
+    sel_hit(h->s0, x, n == 0); sel_hit(h->s1, x, n == 1); sel_hit(h->s2, x, n == 2); sel_hit(h->s3, x, n == 3);
+  }
+  // narrow phase for one pair; returns the mask of valid slots of h[0..3]
+  // (slot order = MuJoCo's contact order); tang = optional shared tangent
+  DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang) {
     const int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
     const T *m1 = S(geom_xmat) + 9*g1, *m2 = S(geom_xmat) + 9*g2;
@@ -757,7 +779,7 @@ struct StepCore {
       T nrm[3] = {m1[2], m1[5], m1[8]};
       T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       if (dot3(dif, nrm) > MR(geom_rbound)[g2] + margin) return 0;
-      if (t2 == DMC_GEOM_SPHERE) return plane_sphere(h, margin, p1, nrm, p2, s2[0]);
+      if (t2 == DMC_GEOM_SPHERE) return plane_sphere(&h->s0, margin, p1, nrm, p2, s2[0]);
       if (t2 == DMC_GEOM_CAPSULE) {
         T axis[3] = {m2[2], m2[5], m2[8]};
         T seg[3] = {axis[0]*s2[1], axis[1]*s2[1], axis[2]*s2[1]}, pos[3];
@@ -765,12 +787,12 @@ struct StepCore {
         for (int k = 0; k < 3; k++) tang[k] = axis[k] - nrm[k]*dp;
         normalize3(tang);
         *has_tang = true;
-        int n = 0;
+        int mask = 0;
         for (int k = 0; k < 3; k++) pos[k] = p2[k] + seg[k];
-        n += plane_sphere(h + n, margin, p1, nrm, pos, s2[0]);
+        mask |= plane_sphere(&h->s0, margin, p1, nrm, pos, s2[0]);
         for (int k = 0; k < 3; k++) pos[k] = p2[k] - seg[k];
-        n += plane_sphere(h + n, margin, p1, nrm, pos, s2[0]);
-        return n;
+        mask |= plane_sphere(&h->s1, margin, p1, nrm, pos, s2[0]) << 1;
+        return mask;
       }
       if (t2 == DMC_GEOM_BOX) {
         T dist = dot3(dif, nrm);
@@ -780,11 +802,13 @@ struct StepCore {
           mul_mat_vec3(corner, m2, vec);
           T ldist = dot3(nrm, corner);
           if (dist + ldist > margin || ldist > 0 || cnt >= 4) continue;
-          h[cnt].dist = dist + ldist;
-          for (int k = 0; k < 3; k++) { h[cnt].nrm[k] = nrm[k]; h[cnt].pos[k] = corner[k] + p2[k] - nrm[k]*h[cnt].dist*(T)0.5; }
+          Hit x;
+          x.dist = dist + ldist;
+          for (int k = 0; k < 3; k++) { x.nrm[k] = nrm[k]; x.pos[k] = corner[k] + p2[k] - nrm[k]*x.dist*(T)0.5; }
+          put_hit(h, cnt, x);
           cnt++;
         }
-        return cnt;
+        return (1 << cnt) - 1;
       }
       return 0;
     }
@@ -793,13 +817,13 @@ struct StepCore {
       T bound = MR(geom_rbound)[g1] + MR(geom_rbound)[g2] + margin;
       if (dot3(dif, dif) > bound*bound) return 0;
     }
-    if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) return sphere_sphere(h, margin, p1, s1[0], p2, s2[0]);
+    if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) return sphere_sphere(&h->s0, margin, p1, s1[0], p2, s2[0]);
     if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) {
       T axis[3] = {m2[2], m2[5], m2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
       T x = dot3(axis, vec);
       x = t_max(-s2[1], t_min(s2[1], x));
       T q[3] = {p2[0] + axis[0]*x, p2[1] + axis[1]*x, p2[2] + axis[2]*x};
-      return sphere_sphere(h, margin, p1, s1[0], q, s2[0]);
+      return sphere_sphere(&h->s0, margin, p1, s1[0], q, s2[0]);
     }
     if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) {
       T a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
@@ -814,24 +838,26 @@ struct StepCore {
         if (x2 > s2[1]) { x2 = s2[1]; x1 = (u - mb*s2[1]) / ma; x1 = t_max(-s1[1], t_min(s1[1], x1)); }
         else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = (u + mb*s2[1]) / ma; x1 = t_max(-s1[1], t_min(s1[1], x1)); }
         for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
-        return sphere_sphere(h, margin, v1, s1[0], v2, s2[0]);
+        return sphere_sphere(&h->s0, margin, v1, s1[0], v2, s2[0]);
       }
       int n = 0;
       for (int sg = 1; sg >= -1 && n < 2; sg -= 2) {
         T x1 = sg * s1[1], x2 = (v - mb*x1) / mc;
         if (x2 >= -s2[1] && x2 <= s2[1]) {
           for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
-          n += sphere_sphere(h + n, margin, v1, s1[0], v2, s2[0]);
+          Hit x;
+          if (sphere_sphere(&x, margin, v1, s1[0], v2, s2[0])) { put_hit(h, n, x); n++; }
         }
       }
       for (int sg = 1; sg >= -1 && n < 2; sg -= 2) {
         T x2 = sg * s2[1], x1 = (u - mb*x2) / ma;
         if (x1 > -s1[1] && x1 < s1[1]) {
           for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
-          n += sphere_sphere(h + n, margin, v1, s1[0], v2, s2[0]);
+          Hit x;
+          if (sphere_sphere(&x, margin, v1, s1[0], v2, s2[0])) { put_hit(h, n, x); n++; }
         }
       }
-      return n;
+      return (1 << n) - 1;
     }
     return 0;
   }
@@ -842,22 +868,24 @@ struct StepCore {
     int overflow = 0;
     for (int p0 = 0; p0 < npair; p0 += LPE) {
       const int p = p0 + lane;
-      Hit h[4]; T tang[3] = {0, 0, 0}; bool has_tang = false;
-      int n = 0, g1 = 0, g2 = 0;
+      Hits h = {}; T tang[3] = {0, 0, 0}; bool has_tang = false;
+      int mask = 0, g1 = 0, g2 = 0;
       if (p < npair) {
         g1 = MI(pair_geom1)[p]; g2 = MI(pair_geom2)[p];
-        n = narrow_phase(g1, g2, MR(pair_margin)[p], h, tang, &has_tang);
+        mask = narrow_phase(g1, g2, MR(pair_margin)[p], &h, tang, &has_tang);
       }
+      const int n = __builtin_popcount(mask);
       int total;
       int off = base + group_scan<LPE>(n, lane, &total);
-      for (int i = 0; i < 4; i++) if (i < n) {
-        const int c = off + i;
+      for (int i = 0; i < 4; i++) if ((mask >> i) & 1) {
+        const int c = off + __builtin_popcount(mask & ((1 << i) - 1));
         if (c >= L.d.nconmax) { overflow = 1; continue; }
+        const Hit& hi = i == 0 ? h.s0 : (i == 1 ? h.s1 : (i == 2 ? h.s2 : h.s3));   // i is a constant after unrolling
         T f[9];
-        for (int k = 0; k < 3; k++) { f[k] = h[i].nrm[k]; f[3 + k] = has_tang ? tang[k] : (T)0; }
+        for (int k = 0; k < 3; k++) { f[k] = hi.nrm[k]; f[3 + k] = has_tang ? tang[k] : (T)0; }
         if (has_tang) cross3(f + 6, f, f + 3); else make_frame(f);
-        S(con_dist)[c] = h[i].dist;
-        for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = h[i].pos[k];
+        S(con_dist)[c] = hi.dist;
+        for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = hi.pos[k];
         for (int k = 0; k < 9; k++) S(con_frame)[9*c + k] = f[k];
         SI(con_pair)[c] = p;
         SI(con_efc)[c] = -1;
@@ -901,26 +929,27 @@ struct StepCore {
     // joint limits
     if (enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int j0 = 0; j0 < L.d.njnt; j0 += LPE) {
       const int j = j0 + lane;
-      int cnt = 0; T dist[2] = {0, 0}; int side[2] = {0, 0}; T margin = 0;
+      // lower side first, then upper (locals indexed statically: no scratch memory)
+      bool act_lo = false, act_hi = false; T d_lo = 0, d_hi = 0, margin = 0;
       if (j < L.d.njnt && MI(jnt_limited)[j]) {
         const int t = MI(jnt_type)[j];
         if (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE) {
           const T value = S(qpos)[MI(jnt_qposadr)[j]];
           margin = MR(jnt_margin)[j];
-          for (int sd = -1; sd <= 1; sd += 2) {
-            T ds = sd * (MR(jnt_range)[2*j + (sd + 1)/2] - value);
-            if (ds < margin) { dist[cnt] = ds; side[cnt] = sd; cnt++; }
-          }
+          d_lo = -(MR(jnt_range)[2*j] - value); d_hi = MR(jnt_range)[2*j + 1] - value;
+          act_lo = d_lo < margin; act_hi = d_hi < margin;
         }
       }
+      const int cnt = (act_lo ? 1 : 0) + (act_hi ? 1 : 0);
       int total;
       const int off = nefc + group_scan<LPE>(cnt, lane, &total);
       for (int i = 0; i < 2; i++) if (i < cnt) {
         const int r = off + i;
         if (r >= njmax) { overflow = 1; continue; }
+        const bool lo = i == 0 && act_lo;
         for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
-        S(efc_J)[r*nv + MI(jnt_dofadr)[j]] = -(T)side[i];
-        S(efc_aref)[r] = dist[i]; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, j);
+        S(efc_J)[r*nv + MI(jnt_dofadr)[j]] = lo ? (T)1 : (T)-1;
+        S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, j);
       }
       nefc += total;
     }
@@ -1665,8 +1694,9 @@ struct StepCore {
   typedef dmc::LSPoint<T> LSPoint;
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
     if (L.d.elliptic) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
-    ls_eval_lds<T, LPE>(p, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv), (const DMC_LDS T*)S(efc_D),
-                        qg[0], qg[1], qg[2], nefc, lane);
+    const DMC_LSVEC(T) rv = ls_eval_lds<T, LPE>(p->alpha, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv),
+                                                (const DMC_LDS T*)S(efc_D), qg[0], qg[1], qg[2], nefc, lane);
+    p->alpha = rv[0]; p->cost = rv[1]; p->d0 = rv[2]; p->d1 = rv[3];
     (*evals)++;
   }
   DMC_DEV int ls_update_bracket(LSPoint* p, const LSPoint* cand, LSPoint* pnext, const T* qg, int nefc, int* evals) {
@@ -1715,9 +1745,11 @@ struct StepCore {
     while (evals < lsmax) {
       pmid.alpha = (T)0.5*(p1.alpha + p2.alpha); ls_eval(&pmid, qg, nefc, &evals);
       LSPoint cand[3] = {p1next, p2next, pmid};
-      int best = -1;
-      for (int i = 0; i < 3; i++) if (t_abs(cand[i].d0) < gtol && (best == -1 || cand[i].cost < cand[best].cost)) best = i;
-      if (best >= 0) return cand[best].alpha;
+      bool found = false; T best_cost = 0, best_alpha = 0;   // first candidate of lowest cost (no dynamic indexing)
+      for (int i = 0; i < 3; i++) if (t_abs(cand[i].d0) < gtol && (!found || cand[i].cost < best_cost)) {
+        found = true; best_cost = cand[i].cost; best_alpha = cand[i].alpha;
+      }
+      if (found) return best_alpha;
       const int b1 = ls_update_bracket(&p1, cand, &p1next, qg, nefc, &evals);
       const int b2 = ls_update_bracket(&p2, cand, &p2next, qg, nefc, &evals);
       if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : (T)0;

@@ -4,7 +4,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "step_core.h"
+#ifndef DMC_STEP_CORE_HEADER   // tuning studies build variants of the core from other files
+#define DMC_STEP_CORE_HEADER "step_core.h"
+#endif
+#include DMC_STEP_CORE_HEADER
 
 namespace dmc {
 

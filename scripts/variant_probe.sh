@@ -1,9 +1,11 @@
 #!/bin/bash
+# perf of experimental library variants (DMC_LIB_VARIANT): VARIANTS="a b c" bash scripts/variant_probe.sh
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-for v in "" mw4; do
+for v in ${VARIANTS:-""}; do
+  [ "$v" = "base" ] && v=""
   echo "=== variant '$v'"
-  DMC_LIB_VARIANT=$v CFGS='[[32,64,0,0,1,false],[32,32,0,0,1,false],[32,16,0,0,1,false],[32,16,0,0,10,false],[64,64,0,0,1,false]]' TAG=v$v timeout 600 python scripts/perf_probe.py 2>&1 | python -c "
+  DMC_LIB_VARIANT=$v CFGS=${CFGS:-'[[32,32,0,0,1,false],[32,32,0,0,10,false]]'} TAG=v$v timeout 600 python scripts/perf_probe.py 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     try: r=json.loads(l)
