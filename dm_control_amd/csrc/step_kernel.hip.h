@@ -57,9 +57,12 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   __syncthreads();
   const int epb = nthr / LPE;
   const int g = tid / LPE, lane = tid % LPE;
-  // consecutive workgroups land on different XCDs (block b -> XCD b % 8); envs of
-  // one workgroup stay contiguous so each SoA row is touched in epb-element segments
-  const int env = blockIdx.x * epb + g;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
+  // Give every XCD one contiguous range of environments, so that a 128-B line of
+  // an SoA row (32 fp32 envs = several workgroups) is fetched into one L2 only.
+  const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+  const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  const int env = lblk * epb + g;
   if (env >= io.B) return;
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
   unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
