@@ -116,6 +116,11 @@ class BatchedPhysics:
     else:
       _native.check(L.dmc_batch_set_opt_real(self._ptr, name.encode(), float(value)))
 
+  def set_model_real(self, name, values):
+    """Rewrites a model constant shared by the whole batch (see dmc_batch_set_model_real)."""
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
+    _native.check(_native.lib().dmc_batch_set_model_real(self._ptr, name.encode(), a.ctypes.data, a.size))
+
   # -- the hot path ---------------------------------------------------------------------
   def set_control(self, control):
     self.set('ctrl', control)

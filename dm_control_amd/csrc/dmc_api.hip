@@ -373,6 +373,38 @@ extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double val
   return 0;
 }
 
+// Model constants that tasks rewrite between episodes (straight copies of mjModel arrays
+// in the kernel's tables; anything the tables derive -- contact-pair mixing, inertias,
+// invweight0 -- is fixed at batch creation, as mj_setConst-dependent fields are in MuJoCo).
+extern "C" int dmc_batch_set_model_real(dmc_batch* b, const char* name, const double* values, int count) {
+  if (!b || !name || !values) return fail("null argument");
+  const StepLayout& L = b->tb.L;
+  const StepDims& d = L.d;
+  struct Slot { const char* name; int off, cnt, stride, ncopy; };   // stride: source elements per table element group
+  const Slot slots[] = {
+      {"dof_damping", L.mr_dof_damping, d.nv, 1, 1},   {"jnt_stiffness", L.mr_jnt_stiffness, d.njnt, 1, 1},
+      {"jnt_range", L.mr_jnt_range, 2 * d.njnt, 1, 1}, {"jnt_margin", L.mr_jnt_margin, d.njnt, 1, 1},
+      {"qpos_spring", L.mr_qpos_spring, d.nq, 1, 1},   {"site_pos", L.mr_site_pos, 3 * d.nsite, 1, 1},
+      {"site_quat", L.mr_site_quat, 4 * d.nsite, 1, 1}, {"site_size", L.mr_site_size, 3 * d.nsite, 1, 1},
+      {"actuator_ctrlrange", L.mr_act_ctrlrange, 2 * d.nu, 1, 1},
+      {"actuator_forcerange", L.mr_act_forcerange, 2 * d.nu, 1, 1},
+  };
+  for (const Slot& s : slots) {
+    if (strcmp(name, s.name)) continue;
+    if (count != s.cnt) return fail(std::string("wrong element count for model field ") + name);
+    for (int i = 0; i < count; i++) b->tb.mr[s.off + i] = values[i];
+    if (!strcmp(name, "dof_damping")) {
+      b->tb.opts.any_damping = 0;
+      for (int i = 0; i < count; i++) { if (values[i] < 0) return fail("negative dof_damping"); if (values[i] > 0) b->tb.opts.any_damping = 1; }
+    }
+    hipError_t e = hipSetDevice(b->device);
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    if (dmc_batch_sync(b)) return -2;
+    return upload_tables(b);
+  }
+  return fail(std::string("model field cannot be changed after batch creation: ") + name);
+}
+
 extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe) {
   if (!b) return fail("null batch");
   const HostModel& m = b->model->hm;

@@ -450,7 +450,7 @@ struct StepCore {
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
     time_ = io.time[env];
     if (lane == 0) {
-      for (int k = 0; k < 8; k++) SI(imisc)[IM_WARN + k] = 0;
+      for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
       SI(imisc)[IM_NCON] = 0; SI(imisc)[IM_NEFC] = 0; SI(imisc)[IM_ITER] = 0;
       // world body
       T* xp = S(xpos); T* xq = S(xquat); T* xm = S(xmat); T* xi = S(xipos);
@@ -473,7 +473,7 @@ struct StepCore {
     }
     if (lane == 0) {
       io.time[env] = time_;
-      for (int k = 0; k < 8; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
+      for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
     }
     // ctrl may have been zeroed by a BADCTRL warning (mj_fwdActuation semantics)
     if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) io.ctrl[(size_t)i*B + env] = S(ctrl)[i];
@@ -769,8 +769,13 @@ struct StepCore {
   }
   // narrow phase for one pair; returns the mask of valid slots of h[0..3]
   // (slot order = MuJoCo's contact order); tang = optional shared tangent
-  DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang) {
-    const int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+  DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang, bool* guard) {
+    int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+    // cylinders have no narrow phase here: they are tested as their enclosing capsule
+    // (same radius / half-length); a hit only raises DMC_WARN_COLLISION (see collision())
+    *guard = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
+    if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
     const T *m1 = S(geom_xmat) + 9*g1, *m2 = S(geom_xmat) + 9*g2;
     const T *s1 = MR(geom_size) + 3*g1, *s2 = MR(geom_size) + 3*g2;
@@ -865,14 +870,16 @@ struct StepCore {
     int base = 0;
     const bool enabled = !(o.disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT));
     const int npair = enabled ? L.d.npair : 0;
-    int overflow = 0;
+    int overflow = 0, unresolved = 0;
     for (int p0 = 0; p0 < npair; p0 += LPE) {
       const int p = p0 + lane;
       Hits h = {}; T tang[3] = {0, 0, 0}; bool has_tang = false;
       int mask = 0, g1 = 0, g2 = 0;
       if (p < npair) {
         g1 = MI(pair_geom1)[p]; g2 = MI(pair_geom2)[p];
-        mask = narrow_phase(g1, g2, MR(pair_margin)[p], &h, tang, &has_tang);
+        bool guard;
+        mask = narrow_phase(g1, g2, MR(pair_margin)[p], &h, tang, &has_tang, &guard);
+        if (guard) { if (mask) unresolved = 1; mask = 0; }
       }
       const int n = __builtin_popcount(mask);
       int total;
@@ -893,8 +900,13 @@ struct StepCore {
       base += total;
     }
     overflow = group_max<LPE>(overflow);
+    if (L.d.ncyl) unresolved = group_max<LPE>(unresolved);
     if (base > L.d.nconmax) base = L.d.nconmax;
-    if (lane == 0) { SI(imisc)[IM_NCON] = base; if (overflow) SI(imisc)[IM_WARN + DMC_WARN_CONTACTFULL]++; }
+    if (lane == 0) {
+      SI(imisc)[IM_NCON] = base;
+      if (overflow) SI(imisc)[IM_WARN + DMC_WARN_CONTACTFULL]++;
+      if (unresolved) SI(imisc)[IM_WARN + DMC_WARN_COLLISION]++;
+    }
     DMC_WSYNC();
   }
 
@@ -921,11 +933,24 @@ struct StepCore {
     const unsigned m = (unsigned)(dofid < 32 ? MI(dof_anc_lo)[lastdof] : MI(dof_anc_hi)[lastdof]);
     return (m >> (dofid & 31)) & 1u;
   }
+  // models with elliptic cones or dof friction loss take the general (per-row-type) solver paths
+  DMC_DEV bool general_rows() const { return L.d.elliptic || L.d.nfric; }
   DMC_DEV int contact_rows(int dim) const { return dim == 1 ? 1 : (L.d.elliptic ? dim : 2*(dim - 1)); }
   DMC_DEV void make_constraint() {
     const int nv = L.d.nv, njmax = L.d.njmax;
     int nefc = 0, overflow = 0;
     const bool enabled = !(o.disableflags & DMC_DSBL_CONSTRAINT);
+    // dof friction loss: one row per dof with frictionloss > 0 (MuJoCo order: friction, limit, contact)
+    if (L.d.nfric && enabled && !(o.disableflags & DMC_DSBL_FRICTIONLOSS)) {
+      for (int r = lane; r < L.d.nfric; r += LPE) {
+        if (r >= njmax) { overflow = 1; continue; }
+        const int dof = MI(fric_dof)[r];
+        for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
+        S(efc_J)[r*nv + dof] = 1;
+        S(efc_aref)[r] = 0; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_FRICTION, dof);
+      }
+      nefc = L.d.nfric < njmax ? L.d.nfric : njmax;
+    }
     // joint limits
     if (enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int j0 = 0; j0 < L.d.njnt; j0 += LPE) {
       const int j = j0 + lane;
@@ -1046,7 +1071,10 @@ struct StepCore {
       const T pos = S(efc_aref)[i], margin = S(efc_D)[i];   // staged by the row headers above
       T mu = 0; T dA0 = 0;
       int ell_row = 0; T ell_fj = 0, ell_imp0 = 0;
-      if (type == EFC_LIMIT) {
+      if (type == EFC_FRICTION) {
+        solref = MR(dof_solref) + 2*id; solimp = MR(dof_solimp) + 5*id;
+        dA = MR(dof_invweight0)[id];
+      } else if (type == EFC_LIMIT) {
         solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
         dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
       } else {
@@ -1322,6 +1350,15 @@ struct StepCore {
       }
       return best;
     }
+    if (type == DMC_GEOM_ELLIPSOID) {
+      T q[3] = {lp[0]/size[0], lp[1]/size[1], lp[2]/size[2]}, w[3] = {lv[0]/size[0], lv[1]/size[1], lv[2]/size[2]};
+      const T a = dot3(w, w), b = dot3(q, w), c = dot3(q, q) - 1;
+      if (a < (T)DMC_MINVAL) return -1;
+      const T det = b*b - a*c;
+      if (det < 0) return -1;
+      const T sq = t_sqrt(det), x0 = (-b - sq)/a, x1 = (-b + sq)/a;
+      return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : (T)-1);
+    }
     if (type == DMC_GEOM_BOX) {
       if (t_abs(lp[0]) <= size[0] && t_abs(lp[1]) <= size[1] && t_abs(lp[2]) <= size[2]) return 0;
       for (int ax = 0; ax < 3; ax++) {
@@ -1409,6 +1446,17 @@ struct StepCore {
       else if (t == DMC_SENS_JOINTVEL) out[0] = S(qvel)[MI(jnt_dofadr)[id]];
       else if (t == DMC_SENS_ACTUATORFRC) out[0] = S(actuator_force)[id];
       else if (t == DMC_SENS_SUBTREECOM) for (int k = 0; k < 3; k++) out[k] = S(subtree_com)[3*id + k];
+      else if (t == DMC_SENS_FRAMEPOS) {
+        const int ot = MI(sensor_objtype)[i];
+        if (ot == DMC_OBJ_SITE) {
+          const int b = MI(site_bodyid)[id]; T v[3];
+          mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+          for (int k = 0; k < 3; k++) out[k] = S(xpos)[3*b + k] + v[k];
+        } else {
+          const T* p = ot == DMC_OBJ_GEOM ? S(geom_xpos) + 3*id : (ot == DMC_OBJ_BODY ? S(xipos) + 3*id : S(xpos) + 3*id);
+          for (int k = 0; k < 3; k++) out[k] = p[k];
+        }
+      }
       else if (t == DMC_SENS_SUBTREELINVEL) for (int k = 0; k < 3; k++) out[k] = S(subtree_linvel)[3*id + k];
       else if (t == DMC_SENS_VELOCIMETER || t == DMC_SENS_GYRO) {
         const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
@@ -1486,6 +1534,16 @@ struct StepCore {
     int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) == EFC_FRICTION) {
+        // Huber cost: quadratic for |jar| < R*floss, linear (force saturated at +-floss) outside
+        const T jar = S(efc_jar)[i], D = S(efc_D)[i], f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D;
+        int st;
+        if (jar <= -rf) { st = EFC_ST_LINEARNEG; S(efc_force)[i] = f; cost += f*((T)-0.5*rf - jar); }
+        else if (jar >= rf) { st = EFC_ST_LINEARPOS; S(efc_force)[i] = -f; cost += f*((T)-0.5*rf + jar); }
+        else { st = EFC_ST_QUADRATIC; S(efc_force)[i] = -D*jar; cost += (T)0.5*D*jar*jar; }
+        if (track) { if (SI(efc_active)[i] != st) changed = 1; SI(efc_active)[i] = st; }
+        continue;
+      }
       if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
         const T jar = S(efc_jar)[i];
         const int act = jar < 0;
@@ -1574,6 +1632,14 @@ struct StepCore {
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) == EFC_FRICTION) {
+        const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i];
+        const T f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D, x = jar + a*jv;
+        if (x <= -rf) { q0 += f*((T)-0.5*rf - jar); q1 += -f*jv; }
+        else if (x >= rf) { q0 += f*((T)-0.5*rf + jar); q1 += f*jv; }
+        else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        continue;
+      }
       if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i];
         if (jar + a*jv < 0) { const T D = S(efc_D)[i], dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
@@ -1619,7 +1685,7 @@ struct StepCore {
     if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
   }
   DMC_DEV T constraint_update(int nefc, int* track = nullptr) {
-    if (L.d.elliptic) return constraint_update_ell(nefc, track);
+    if (general_rows()) return constraint_update_ell(nefc, track);
     T cost = 0;
     int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
@@ -1663,7 +1729,7 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
-    if (L.d.elliptic) {
+    if (general_rows()) {
       for (int idx = lane; idx < L.d.ntri; idx += LPE) {
         const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
         S(qLH)[i*nv + j] = hess_entry_ell(i, j, nefc);
@@ -1693,7 +1759,7 @@ struct StepCore {
   }
   typedef dmc::LSPoint<T> LSPoint;
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
-    if (L.d.elliptic) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
+    if (general_rows()) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
     const DMC_LSVEC(T) rv = ls_eval_lds<T, LPE>(p->alpha, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv),
                                                 (const DMC_LDS T*)S(efc_D), qg[0], qg[1], qg[2], nefc, lane);
     p->alpha = rv[0]; p->cost = rv[1]; p->d0 = rv[2]; p->d1 = rv[3];

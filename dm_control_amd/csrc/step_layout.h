@@ -22,6 +22,8 @@ struct StepDims {
   int rk4;       // 1: RK4 integrator (extra stage buffers)
   int ntri;      // nv (nv + 1) / 2: lower-triangle entries of an nv x nv matrix
   int elliptic;  // 1: frictional contacts use elliptic cones (one row per contact-frame axis)
+  int nfric;     // dofs with frictionloss > 0 (one Huber-cost row each)
+  int ncyl;      // candidate pairs involving a cylinder (guard test only, never a contact)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -43,7 +45,8 @@ struct StepDims {
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \
   X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
   X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
-  X(sensor_stage, d.nsensor)
+  X(sensor_stage, d.nsensor) X(sensor_objtype, d.nsensor)                      \
+  X(fric_dof, d.nfric)
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -56,6 +59,8 @@ struct StepDims {
   X(jnt_range, 2 * d.njnt) X(jnt_margin, d.njnt) X(jnt_solref, 2 * d.njnt)     \
   X(jnt_solimp, 5 * d.njnt)                                                    \
   X(dof_armature, d.nv) X(dof_damping, d.nv) X(dof_invweight0, d.nv)           \
+  X(dof_frictionloss, d.nfric ? d.nv : 0) X(dof_solref, d.nfric ? 2 * d.nv : 0) \
+  X(dof_solimp, d.nfric ? 5 * d.nv : 0)                                        \
   X(geom_size, 3 * d.ngeom) X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom) \
   X(geom_rbound, d.ngeom)                                                      \
   X(pair_margin, d.npair) X(pair_gap, d.npair) X(pair_friction, 3 * d.npair)   \
@@ -108,21 +113,21 @@ struct StepDims {
 // ---- per-environment scratch (ints) --------------------------------------------
 #define STEP_SCRATCH_INT(X)                                                    \
   X(con_pair, d.nconmax) X(con_efc, d.nconmax)                                 \
-  X(efc_tid, d.njmax)   /* (id << 2) | type */                                 \
+  X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch
 enum { MISC_TIME = 0 };
-enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..10: 8 warning counters */ };
+enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */ };
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8 };
-enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3 };
-enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2 };   /* efc_active values */
-#define EFC_TID(type, id) (((id) << 2) | (type))
-#define EFC_TYPE(tid) ((tid) & 3)
-#define EFC_ID(tid) ((tid) >> 2)
+enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4 };
+enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
+#define EFC_TID(type, id) (((id) << 3) | (type))
+#define EFC_TYPE(tid) ((tid) & 7)
+#define EFC_ID(tid) ((tid) >> 3)
 
 struct StepLayout {
   StepDims d;

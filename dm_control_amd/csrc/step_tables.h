@@ -80,7 +80,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
   d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
   if (m.opt_noslip_iterations > 0) { *err = "noslip iterations are not implemented in the HIP path"; return false; }
-  for (int i = 0; i < m.nv; i++) if (m.dof_frictionloss[i] != 0) { *err = "dof frictionloss is not implemented"; return false; }
+  std::vector<int> fric_dof;
+  for (int i = 0; i < m.nv; i++) {
+    if (m.dof_frictionloss[i] < 0) { *err = "negative dof frictionloss"; return false; }
+    if (m.dof_frictionloss[i] > 0) fric_dof.push_back(i);
+  }
+  d.nfric = (int)fric_dof.size();
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
@@ -101,7 +106,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   std::vector<int> pdim(m.npair);
   for (int p = 0; p < m.npair; p++) {
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-    const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    // cylinders: guard test as enclosing capsules (DMC_WARN_COLLISION), never a contact
+    const bool cyl = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
+    if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
+    if (cyl) d.ncyl++;
     int nc = 1;
     if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) nc = 2;
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) nc = 4;
@@ -119,15 +129,16 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (pr1 == pr2) dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
     else dim = m.geom_condim[pr1 > pr2 ? g1 : g2];
     pdim[p] = dim;
+    if (cyl) nc = 0;
     maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
-  t->max_contacts = maxc; t->max_rows = maxr + nlim;
+  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nfric;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
   if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
-  if (njmax <= 0) njmax = nlim + nconmax * maxrow_per_contact;
-  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim)));
+  if (njmax <= 0) njmax = d.nfric + nlim + nconmax * maxrow_per_contact;
+  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nfric)));
   d.nconmax = nconmax; d.njmax = njmax;
   d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
   step_layout_build(&t->L, d);
@@ -192,7 +203,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int k = 0; k < 3; k++) { mr[L.mr_act_gainprm + 3*i + k] = m.actuator_gainprm[10*i + k]; mr[L.mr_act_biasprm + 3*i + k] = m.actuator_biasprm[10*i + k]; }
   }
   cpi(L.mi_sensor_type, m.sensor_type); cpi(L.mi_sensor_objid, m.sensor_objid);
-  cpi(L.mi_sensor_adr, m.sensor_adr); cpi(L.mi_sensor_stage, m.sensor_needstage);
+  cpi(L.mi_sensor_adr, m.sensor_adr); cpi(L.mi_sensor_stage, m.sensor_needstage); cpi(L.mi_sensor_objtype, m.sensor_objtype);
   cpr(L.mr_qpos0, m.qpos0); cpr(L.mr_qpos_spring, m.qpos_spring);
   cpr(L.mr_body_pos, m.body_pos); cpr(L.mr_body_quat, m.body_quat); cpr(L.mr_body_ipos, m.body_ipos);
   cpr(L.mr_body_iquat, m.body_iquat); cpr(L.mr_body_mass, m.body_mass); cpr(L.mr_body_inertia, m.body_inertia);
@@ -226,6 +237,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int k = 0; k < 2; k++) mr[L.mr_pair_solref + 2*p + k] = (r1[0] > 0 && r2[0] > 0) ? mix*r1[k] + (1 - mix)*r2[k] : std::min(r1[k], r2[k]);
     for (int k = 0; k < 5; k++) mr[L.mr_pair_solimp + 5*p + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
   }
+  cpi(L.mi_fric_dof, fric_dof);
+  if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);
   // sensors the kernel can compute
   for (int i = 0; i < m.nsensor; i++) {
@@ -233,9 +246,9 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     const bool ok = st == DMC_SENS_JOINTPOS || st == DMC_SENS_JOINTVEL || st == DMC_SENS_ACTUATORFRC ||
                     st == DMC_SENS_SUBTREECOM || st == DMC_SENS_SUBTREELINVEL || st == DMC_SENS_VELOCIMETER ||
                     st == DMC_SENS_GYRO || st == DMC_SENS_ACCELEROMETER || st == DMC_SENS_FORCE ||
-                    st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH;
+                    st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH || st == DMC_SENS_FRAMEPOS;
     if (!ok) { *err = "sensor type not implemented"; return false; }
-    if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX) { *err = "touch sensor sites must be sphere, capsule or box"; return false; } }
+    if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX && tt != DMC_GEOM_ELLIPSOID) { *err = "touch sensor sites must be sphere, capsule, ellipsoid or box"; return false; } }
   }
   StepOpts<double>& o = t->opts;
   o.timestep = m.opt_timestep; o.timestep_d = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;

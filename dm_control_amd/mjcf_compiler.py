@@ -49,6 +49,8 @@ _SENSORS = {
     'actuatorfrc': (C['DMC_SENS_ACTUATORFRC'], 'actuator', C['DMC_OBJ_ACTUATOR'], 1, 3),
     'subtreecom': (C['DMC_SENS_SUBTREECOM'], 'body', C['DMC_OBJ_BODY'], 3, 1),
     'subtreelinvel': (C['DMC_SENS_SUBTREELINVEL'], 'body', C['DMC_OBJ_BODY'], 3, 2),
+    # object named by objtype/objname (body = inertial frame, xbody = body frame, geom, site)
+    'framepos': (C['DMC_SENS_FRAMEPOS'], 'objname', None, 3, 1),
 }
 
 
@@ -596,7 +598,9 @@ class _Compiler:
         armature=float(a.get('armature', 0)), frictionloss=float(a.get('frictionloss', 0)),
         margin=float(a.get('margin', 0)),
         solref=_vec(a.get('solreflimit', '0.02 1'), 2),
-        solimp=_solimp(a.get('solimplimit', '0.9 0.95 0.001 0.5 2')))
+        solimp=_solimp(a.get('solimplimit', '0.9 0.95 0.001 0.5 2')),
+        solreffriction=_vec(a.get('solreffriction', '0.02 1'), 2),
+        solimpfriction=_solimp(a.get('solimpfriction', '0.9 0.95 0.001 0.5 2')))
     if jtype == _JNT['free']:
       j['pos'] = np.zeros(3)
     if lim and jtype in (_JNT['hinge'], _JNT['slide']) and rng[0] >= rng[1]:
@@ -793,6 +797,8 @@ class _Compiler:
     m.dof_armature = np.zeros(nv)
     m.dof_damping = np.zeros(nv)
     m.dof_frictionloss = np.zeros(nv)
+    m.dof_solref = np.zeros((nv, 2))
+    m.dof_solimp = np.zeros((nv, 5))
     for jid, j in enumerate(self.joints):
       nd = {0: 6, 1: 3, 2: 1, 3: 1}[j['type']]
       for k in range(nd):
@@ -802,6 +808,8 @@ class _Compiler:
         m.dof_armature[d] = j['armature']
         m.dof_damping[d] = j['damping']
         m.dof_frictionloss[d] = j['frictionloss']
+        m.dof_solref[d] = j['solreffriction']
+        m.dof_solimp[d] = j['solimpfriction']
     last_dof = np.full(nbody, -1, dtype=np.int64)  # last dof on the path to root
     for bid in range(1, nbody):
       prev = last_dof[m.body_parentid[bid]]
@@ -1008,10 +1016,18 @@ class _Compiler:
     m.sensor_cutoff = np.zeros(ns)
     adr = 0
     names = []
-    kind = {C['DMC_OBJ_SITE']: 'site', C['DMC_OBJ_BODY']: 'body',
-            C['DMC_OBJ_JOINT']: 'joint', C['DMC_OBJ_ACTUATOR']: 'actuator'}
+    kind = {C['DMC_OBJ_SITE']: 'site', C['DMC_OBJ_BODY']: 'body', C['DMC_OBJ_XBODY']: 'body',
+            C['DMC_OBJ_GEOM']: 'geom', C['DMC_OBJ_JOINT']: 'joint', C['DMC_OBJ_ACTUATOR']: 'actuator'}
     for i, (tag, a) in enumerate(self.sensors):
       stype, attr, objtype, dim, stage = _SENSORS[tag]
+      if objtype is None:
+        if 'reftype' in a or 'refname' in a:
+          raise MjcfError('sensor %r: reference frames (reftype/refname) are not supported' % a.get('name'))
+        try:
+          objtype = {'body': C['DMC_OBJ_BODY'], 'xbody': C['DMC_OBJ_XBODY'], 'geom': C['DMC_OBJ_GEOM'],
+                     'site': C['DMC_OBJ_SITE']}[a.get('objtype')]
+        except KeyError:
+          raise MjcfError('sensor %r: unsupported objtype %r' % (a.get('name'), a.get('objtype')))
       names.append(a.get('name'))
       oname = a.get(attr)
       lst = m.names[kind[objtype]]

@@ -29,7 +29,12 @@ from dm_control_amd.envs.dm_env_api import specs
 
 mjMAXVAL = mjcf_compiler.C['DMC_MAXVAL']
 _WARNING_NAMES = ['mjWARN_INERTIA', 'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL', 'mjWARN_VGEOMFULL',
-                  'mjWARN_BADQPOS', 'mjWARN_BADQVEL', 'mjWARN_BADQACC', 'mjWARN_BADCTRL']
+                  'mjWARN_BADQPOS', 'mjWARN_BADQVEL', 'mjWARN_BADQACC', 'mjWARN_BADCTRL',
+                  'dmcWARN_COLLISION']
+# model arrays tasks may rewrite through physics.model / physics.named.model between
+# episodes; changes are pushed to the device tables before the next launch
+_MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margin', 'qpos_spring', 'site_pos',
+                         'site_quat', 'site_size', 'actuator_ctrlrange', 'actuator_forcerange')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
 _INPUT_FIELDS = ('qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')
@@ -98,6 +103,7 @@ class _Data:
 
   def _upload(self):
     p = self._p
+    p._push_model()
     for name in list(self._touched):
       a = np.asarray(self._cache[name], dtype=np.float64)
       p.batch.set(name, a.reshape(p.batch_size, -1))
@@ -233,9 +239,18 @@ class Physics(control.Physics):
     self.batch = BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, **batch_kwargs)
     self.data = _Data(self)
     self._warnings_cause_exception = True
-    self._warnings_seen = np.zeros((self.batch_size, 8), dtype=np.int64)
+    self._warnings_seen = np.zeros((self.batch_size, len(_WARNING_NAMES)), dtype=np.int64)
     self._build_named()
+    self._model_pushed = {f: np.array(getattr(model, f), dtype=np.float64, copy=True)
+                          for f in _MUTABLE_MODEL_FIELDS if hasattr(model, f)}
     self.after_reset()
+
+  def _push_model(self):
+    for f, old in self._model_pushed.items():
+      cur = np.asarray(getattr(self.model, f), dtype=np.float64)
+      if cur.shape != old.shape or not np.array_equal(cur, old):
+        self.batch.set_model_real(f, cur)
+        self._model_pushed[f] = cur.copy()
 
   # -- construction -----------------------------------------------------------------
   @classmethod

@@ -18,7 +18,7 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 3
+#define DMC_MODEL_VERSION 4
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
@@ -62,7 +62,7 @@
   X(jnt_range, 2*njnt) X(jnt_margin, njnt) X(jnt_solref, 2*njnt) \
   X(jnt_solimp, 5*njnt) \
   X(dof_armature, nv) X(dof_damping, nv) X(dof_invweight0, nv) \
-  X(dof_frictionloss, nv) \
+  X(dof_frictionloss, nv) X(dof_solref, 2*nv) X(dof_solimp, 5*nv) \
   X(geom_size, 3*ngeom) X(geom_pos, 3*ngeom) X(geom_quat, 4*ngeom) \
   X(geom_friction, 3*ngeom) X(geom_solmix, ngeom) X(geom_solref, 2*ngeom) \
   X(geom_solimp, 5*ngeom) X(geom_margin, ngeom) X(geom_gap, ngeom) \
@@ -88,7 +88,7 @@ enum { DMC_TRN_JOINT = 0 };
 enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2 };
 enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
 enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };
-enum { DMC_OBJ_BODY = 1, DMC_OBJ_JOINT = 3, DMC_OBJ_SITE = 6, DMC_OBJ_ACTUATOR = 19 };
+enum { DMC_OBJ_BODY = 1, DMC_OBJ_XBODY = 2, DMC_OBJ_JOINT = 3, DMC_OBJ_GEOM = 5, DMC_OBJ_SITE = 6, DMC_OBJ_ACTUATOR = 19 };
 enum { DMC_STAGE_NONE = 0, DMC_STAGE_POS = 1, DMC_STAGE_VEL = 2, DMC_STAGE_ACC = 3 };
 enum { DMC_SENS_TOUCH = 0, DMC_SENS_ACCELEROMETER = 1, DMC_SENS_VELOCIMETER = 2,
        DMC_SENS_GYRO = 3, DMC_SENS_FORCE = 4, DMC_SENS_TORQUE = 5,
@@ -109,7 +109,10 @@ enum { DMC_ENBL_OVERRIDE = 1 << 0, DMC_ENBL_ENERGY = 1 << 1 };
  * (dm_control/mujoco/engine.py:345-368) */
 enum { DMC_WARN_INERTIA = 0, DMC_WARN_CONTACTFULL = 1, DMC_WARN_CNSTRFULL = 2,
        DMC_WARN_VGEOMFULL = 3, DMC_WARN_BADQPOS = 4, DMC_WARN_BADQVEL = 5,
-       DMC_WARN_BADQACC = 6, DMC_WARN_BADCTRL = 7, DMC_NWARNING = 8 };
+       DMC_WARN_BADQACC = 6, DMC_WARN_BADCTRL = 7,
+       /* not a MuJoCo warning: a geom pair whose shapes the collision kernel cannot
+        * resolve (cylinders: tested as their enclosing capsules) came into contact range */
+       DMC_WARN_COLLISION = 8, DMC_NWARNING = 9 };
 
 #define DMC_MINVAL 1e-15
 #define DMC_MAXVAL 1e10

@@ -60,7 +60,7 @@ typedef struct {
   int nconmax, njmax;
 } Model;
 
-enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3 };
+enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3, CT_FRICTION_DOF = 4 };
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
@@ -290,7 +290,7 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
     g_err = "model blob size mismatch"; free(m->ibuf); free(m->rbuf); free(m); return NULL;
   }
   m->nconmax = 4 * npair + 4;
-  m->njmax = 2 * njnt + 10 * m->nconmax;
+  m->njmax = m->nv + 2 * njnt + 10 * m->nconmax;
   return m;
 }
 void ora_model_free(Model* m) { if (m) { free(m->ibuf); free(m->rbuf); free(m); } }
@@ -694,13 +694,19 @@ static void collision(const Model* m, Data* d) {
     if (d->ncon + 4 > m->nconmax) { d->warning[DMC_WARN_CONTACTFULL]++; break; }
     Contact* c = d->contact + d->ncon;
     int n = 0;
+    /* cylinders have no restated narrow phase: they are tested as their enclosing capsule
+     * (same radius / half-length) and a hit only raises DMC_WARN_COLLISION */
+    const int guard = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
+    if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_SPHERE) { double nrm[3] = {m1[2], m1[5], m1[8]}; n = raw_plane_sphere(c, margin, p1, nrm, p2, s2[0]); }
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) n = collide_plane_capsule(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) n = collide_plane_box(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) n = raw_sphere_sphere(c, margin, p1, s1[0], p2, s2[0]);
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) n = collide_sphere_capsule(c, margin, p1, s1, p2, m2, s2);
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) n = collide_capsule_capsule(c, margin, p1, m1, s1, p2, m2, s2);
-    else continue; /* pair type not restated (no such pair in the supported models) */
+    else { d->warning[DMC_WARN_COLLISION]++; continue; } /* pair type not restated and within bounding range */
+    if (guard) { if (n > 0) d->warning[DMC_WARN_COLLISION]++; continue; }
     /* contact parameters (max / priority / solmix) */
     for (int i = 0; i < n; i++) {
       Contact* ci = c + i;
@@ -777,6 +783,15 @@ static void make_constraint(const Model* m, Data* d) {
   d->nefc = 0;
   for (int i = 0; i < d->ncon; i++) d->contact[i].efc_address = -1;
   if (m->opt_disableflags & DMC_DSBL_CONSTRAINT) return;
+  /* dof friction loss (rows come first, as in MuJoCo: equality, friction, limit, contact) */
+  if (!(m->opt_disableflags & DMC_DSBL_FRICTIONLOSS)) for (int i = 0; i < nv; i++) {
+    if (m->dof_frictionloss[i] <= 0) continue;
+    if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+    int r = d->nefc++;
+    memset(d->efc_J + (size_t)r*nv, 0, sizeof(double) * (size_t)nv);
+    d->efc_J[(size_t)r*nv + i] = 1;
+    d->efc_pos[r] = 0; d->efc_margin[r] = 0; d->efc_type[r] = CT_FRICTION_DOF; d->efc_id[r] = i;
+  }
   /* joint limits */
   if (!(m->opt_disableflags & DMC_DSBL_LIMIT)) for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j]) continue;
@@ -840,7 +855,11 @@ static void make_constraint(const Model* m, Data* d) {
   int nefc = d->nefc;
   for (int i = 0; i < nefc; i++) {
     const double *solref, *solimp; double dA;
-    if (d->efc_type[i] == CT_LIMIT) {
+    if (d->efc_type[i] == CT_FRICTION_DOF) {
+      int k = d->efc_id[i];
+      solref = m->dof_solref + 2*k; solimp = m->dof_solimp + 5*k;
+      dA = m->dof_invweight0[k];
+    } else if (d->efc_type[i] == CT_LIMIT) {
       int j = d->efc_id[i];
       solref = m->jnt_solref + 2*j; solimp = m->jnt_solimp + 5*j;
       dA = m->dof_invweight0[m->jnt_dofadr[j]];
@@ -862,6 +881,7 @@ static void make_constraint(const Model* m, Data* d) {
     double dmax = mjMAX(DMC_MINIMP, mjMIN(DMC_MAXIMP, solimp[1])), K, B;
     if (ref[0] > 0) { K = 1 / mjMAX(MINVAL, dmax*dmax*ref[0]*ref[0]*ref[1]*ref[1]); B = 2 / mjMAX(MINVAL, dmax*ref[0]); }
     else { K = -ref[0] / mjMAX(MINVAL, dmax*dmax); B = -ref[1] / mjMAX(MINVAL, dmax); }
+    if (d->efc_type[i] == CT_FRICTION_DOF) K = 0; /* friction rows have no position term */
     d->efc_KBIP[4*i] = K; d->efc_KBIP[4*i + 1] = B; d->efc_KBIP[4*i + 2] = imp; d->efc_KBIP[4*i + 3] = 0;
   }
   /* frictional contacts: the friction rows' regularisation is tied to the normal's.
@@ -1016,6 +1036,11 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
       case DMC_SENS_JOINTVEL: out[0] = d->qvel[m->jnt_dofadr[id]]; break;
       case DMC_SENS_ACTUATORFRC: out[0] = d->actuator_force[id]; break;
       case DMC_SENS_SUBTREECOM: memcpy(out, d->subtree_com + 3*id, 3 * sizeof(double)); break;
+      case DMC_SENS_FRAMEPOS: { /* world-frame position of the object's frame origin (no reference frame) */
+        const double* p = m->sensor_objtype[i] == DMC_OBJ_SITE ? d->site_xpos + 3*id
+                        : m->sensor_objtype[i] == DMC_OBJ_GEOM ? d->geom_xpos + 3*id
+                        : m->sensor_objtype[i] == DMC_OBJ_BODY ? d->xipos + 3*id : d->xpos + 3*id;
+        memcpy(out, p, 3 * sizeof(double)); break; }
       case DMC_SENS_SUBTREELINVEL: memcpy(out, d->subtree_linvel + 3*id, 3 * sizeof(double)); break;
       case DMC_SENS_VELOCIMETER:
         object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, 1, v6);
@@ -1110,6 +1135,16 @@ static double ray_geom(const double* pos, const double* mat, const double* size,
     }
     /* point inside volume counts as hit at 0 */
     return best;
+  }
+  if (type == DMC_GEOM_ELLIPSOID) {
+    /* (lp + x lv)' diag(1/size^2) (lp + x lv) = 1: the unit-sphere test in scaled coordinates */
+    double q[3] = {lp[0]/size[0], lp[1]/size[1], lp[2]/size[2]}, w[3] = {lv[0]/size[0], lv[1]/size[1], lv[2]/size[2]};
+    double a = dot3(w, w), b = dot3(q, w), c = dot3(q, q) - 1;
+    if (a < MINVAL) return -1;
+    double det = b*b - a*c;
+    if (det < 0) return -1;
+    double sq = sqrt(det), x0 = (-b - sq)/a, x1 = (-b + sq)/a;
+    return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : -1);
   }
   if (type == DMC_GEOM_BOX) {
     int inside = fabs(lp[0]) <= size[0] && fabs(lp[1]) <= size[1] && fabs(lp[2]) <= size[2];
@@ -1222,7 +1257,7 @@ static void fwd_acceleration(const Model* m, Data* d) {
 /* ------------------------------------------------------------------------- */
 /* constraint solver: Newton on the primal          */
 /* ------------------------------------------------------------------------- */
-enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_CONE = 2 };
+enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_CONE = 2, ST_LINEARNEG = 3, ST_LINEARPOS = 4 };
 static double constraint_update(const Model* m, Data* d, const double* jar, int flg_state_only) {
   (void)m; (void)flg_state_only;
   double cost = 0;
@@ -1262,13 +1297,21 @@ static double constraint_update(const Model* m, Data* d, const double* jar, int 
       i += dim - 1;
       continue;
     }
+    if (d->efc_type[i] == CT_FRICTION_DOF) {
+      /* Huber cost: quadratic inside |jar| < R*floss, linear (force saturated at +-floss) outside */
+      double f = m->dof_frictionloss[d->efc_id[i]], rf = d->efc_R[i]*f;
+      if (jar[i] <= -rf) { d->efc_state[i] = ST_LINEARNEG; d->efc_force[i] = f; cost += f*(-0.5*rf - jar[i]); }
+      else if (jar[i] >= rf) { d->efc_state[i] = ST_LINEARPOS; d->efc_force[i] = -f; cost += f*(-0.5*rf + jar[i]); }
+      else { d->efc_state[i] = ST_QUADRATIC; d->efc_force[i] = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; }
+      continue;
+    }
     if (jar[i] < 0) { d->efc_state[i] = ST_QUADRATIC; d->efc_force[i] = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i]; }
     else { d->efc_state[i] = ST_SATISFIED; d->efc_force[i] = 0; }
   }
   return cost;
 }
 typedef struct { double alpha, cost, deriv[2]; } LSPoint;
-typedef struct { double quadGauss[3]; int nefc; const double *jar, *jv, *quad; int evals; const Data* d; } LSCtx;
+typedef struct { double quadGauss[3]; int nefc; const double *jar, *jv, *quad; int evals; const Data* d; const Model* m; } LSCtx;
 static void ls_eval(const LSCtx* c, LSPoint* p) {
   double a = p->alpha, qt[3] = {c->quadGauss[0], c->quadGauss[1], c->quadGauss[2]};
   double ccost = 0, cd0 = 0, cd1 = 0; /* non-quadratic part: elliptic contacts in the middle zone */
@@ -1299,6 +1342,13 @@ static void ls_eval(const LSCtx* c, LSPoint* p) {
       i += dim - 1;
       continue;
     }
+    if (c->d->efc_type[i] == CT_FRICTION_DOF) {
+      double f = c->m->dof_frictionloss[c->d->efc_id[i]], rf = c->d->efc_R[i]*f, x = c->jar[i] + a*c->jv[i];
+      if (x <= -rf) { qt[0] += f*(-0.5*rf - c->jar[i]); qt[1] += -f*c->jv[i]; }
+      else if (x >= rf) { qt[0] += f*(-0.5*rf + c->jar[i]); qt[1] += f*c->jv[i]; }
+      else { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; }
+      continue;
+    }
     if (c->jar[i] + a*c->jv[i] < 0) { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; }
   }
   p->cost = a*a*qt[2] + a*qt[1] + qt[0] + ccost;
@@ -1321,7 +1371,7 @@ static double primal_search(const Model* m, Data* d, double gauss, double scale)
   double *search = d->w_search, *Mv = d->w_Mv, *jv = d->w_Jv, *jar = d->w_Jaref, *quad = d->w_quad;
   for (int i = 0; i < nv; i++) Mv[i] = dot_n(d->qM + (size_t)i*nv, search, nv);
   for (int i = 0; i < nefc; i++) jv[i] = dot_n(d->efc_J + (size_t)i*nv, search, nv);
-  LSCtx c; c.d = d; c.nefc = nefc; c.jar = jar; c.jv = jv; c.quad = quad; c.evals = 0;
+  LSCtx c; c.d = d; c.m = m; c.nefc = nefc; c.jar = jar; c.jv = jv; c.quad = quad; c.evals = 0;
   c.quadGauss[0] = gauss;
   c.quadGauss[1] = dot_n(search, d->w_Ma, nv) - dot_n(d->qfrc_smooth, search, nv);
   c.quadGauss[2] = 0.5 * dot_n(search, Mv, nv);

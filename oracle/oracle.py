@@ -152,7 +152,7 @@ class OraclePhysics:
 
   @property
   def warning(self):
-    return np.ctypeslib.as_array(lib().ora_data_warning(self.ptr), shape=(8,))
+    return np.ctypeslib.as_array(lib().ora_data_warning(self.ptr), shape=(9,))
 
   def contact(self, i):
     out = np.zeros(30)

@@ -59,7 +59,7 @@ class EmuPhysics:
     self.f = {n: np.zeros(max(s, 1)) for n, s in zip(FIELDS, sizes)}
     self._sizes = dict(zip(FIELDS, sizes))
     self.fi = {'ncon': np.zeros(1, np.int32), 'nefc': np.zeros(1, np.int32),
-               'solver_iter': np.zeros(1, np.int32), 'warning': np.zeros(8, np.int32),
+               'solver_iter': np.zeros(1, np.int32), 'warning': np.zeros(9, np.int32),
                'contact_geom1': np.zeros(self.nconmax, np.int32),
                'contact_geom2': np.zeros(self.nconmax, np.int32)}
     self.f['qpos'][:m.nq] = m.qpos0

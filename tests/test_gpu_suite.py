@@ -18,7 +18,9 @@ def _oracle(model):
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'balance'), ('cartpole', 'swingup'),
                                          ('humanoid', 'stand'), ('humanoid', 'run_pure_state'), ('walker', 'walk'),
                                          ('hopper', 'hop'), ('hopper', 'stand'), ('pendulum', 'swingup'),
-                                         ('acrobot', 'swingup'), ('acrobot', 'swingup_sparse')])
+                                         ('acrobot', 'swingup'), ('acrobot', 'swingup_sparse'),
+                                         ('finger', 'spin'), ('finger', 'turn_easy'), ('finger', 'turn_hard'),
+                                         ('reacher', 'easy'), ('reacher', 'hard')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -41,7 +43,8 @@ def test_suite_task_properties(domain, task):
 
 
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
-                                         ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup')])
+                                         ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
+                                         ('finger', 'turn_hard'), ('reacher', 'hard')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -270,10 +273,12 @@ def test_torch_batched_env_matches_host_env_semantics():
   env.close()
 
 
-@pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1)])
+@pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1),
+                                       ('finger', 2), ('reacher', 1)])
 def test_more_domains_rollout_parity(name, nsub):
   """Domains sharing the cheetah feature set: 60 env-steps from randomised starts
-  against the oracle (fp64 kernel), incl. hopper's touch sensors and acrobot's RK4."""
+  against the oracle (fp64 kernel), incl. hopper's touch sensors, acrobot's RK4 and
+  finger's elliptic cones / dof friction loss / framepos + ellipsoid-site touch sensors."""
   from dm_control_amd.batch import BatchedPhysics
   from dm_control_amd.suite import common
   from oracle import oracle
@@ -307,4 +312,58 @@ def test_more_domains_rollout_parity(name, nsub):
   if m.nsensordata:
     np.testing.assert_allclose(b.get('sensordata'), so, atol=1e-6 * max(1.0, np.abs(so).max()))
   assert not b.get('warning').any()
+  b.close()
+
+
+def test_model_constants_rewritten_between_episodes():
+  """Tasks rewrite model arrays through physics.named.model (suite/finger.py:139
+  dof_damping); the change must reach the device tables before the next launch."""
+  from dm_control_amd.suite import finger
+  phys = finger.Physics.from_xml_string(*finger.get_model_and_assets())
+  o = _oracle(phys.model)
+
+  def spin_down(p_step, get_v):
+    for _ in range(20):
+      p_step()
+    return get_v()
+  phys.data.qvel[2] = 5.0
+  o.qvel[2] = 5.0
+  o.forward()
+  v_gpu = spin_down(phys.step, lambda: float(phys.data.qvel[2]))
+  v_ora = spin_down(o.step, lambda: float(o.qvel[2]))
+  np.testing.assert_allclose(v_gpu, v_ora, rtol=1e-9)
+  phys.named.model.dof_damping['hinge'] = .03
+  o.model.field('dof_damping')[2] = .03
+  phys.reset(); o.reset(); o.after_reset()
+  phys.data.qvel[2] = 5.0
+  o.qvel[2] = 5.0
+  phys.forward(); o.forward()
+  v_gpu2 = spin_down(phys.step, lambda: float(phys.data.qvel[2]))
+  v_ora2 = spin_down(o.step, lambda: float(o.qvel[2]))
+  np.testing.assert_allclose(v_gpu2, v_ora2, rtol=1e-9)
+  assert v_gpu2 > v_gpu          # less damping: spins down more slowly
+  with pytest.raises(Exception):
+    phys.batch.set_model_real('body_mass', phys.model.body_mass)
+  phys.free()
+
+
+def test_cylinder_pairs_are_guarded_not_silently_ignored():
+  """Cylinders have no narrow phase: a cylinder coming within range (tested as its
+  enclosing capsule) raises the dmcWARN_COLLISION counter instead of a contact."""
+  from dm_control_amd.batch import BatchedPhysics
+  m = mc.compile_xml("""
+  <mujoco><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='can' pos='0 0 .5'><freejoint/><geom type='cylinder' size='.1 .1'/></body>
+  </worldbody></mujoco>""")
+  b = BatchedPhysics(m, 2, precision=64)
+  o = _oracle(m)
+  o.forward()
+  b.step(100); [o.step() for _ in range(100)]
+  assert not b.get('warning').any() and not o.warning.any()       # still falling: out of range
+  b.step(100); [o.step() for _ in range(100)]
+  w = b.get('warning')
+  assert (w[:, mc.C['DMC_WARN_COLLISION']] > 0).all() and o.warning[mc.C['DMC_WARN_COLLISION']] > 0
+  assert (b.get('ncon') == 0).all() and o.ncon == 0
+  np.testing.assert_allclose(b.get('qpos')[0], o.qpos, atol=1e-9)
   b.close()

@@ -129,3 +129,27 @@ def test_elliptic_cones_match_oracle(condim, impratio):
   assert zones >= {0, 1, 2}    # top, bottom and cone zones were all exercised
   np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-9)
   assert not e.warning.any()
+
+
+def test_finger_domain_matches_oracle():
+  # suite finger: elliptic cones + dof friction loss (Huber rows) + framepos sensors +
+  # touch on ellipsoid sites + cylinder decorations (guard test only)
+  with open(os.path.join(ASSETS, 'finger.xml')) as f:
+    m = mc.compile_xml(f.read())
+  o, e = OraclePhysics(m), EmuPhysics(m, 64)
+  o.forward()
+  rs = np.random.RandomState(0)
+  states, touched = set(), 0.0
+  for _ in range(1000):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    states |= set(e.scratch('efc_active')[:e.nefc[0]].tolist())
+    touched = max(touched, o.sensordata[14], o.sensordata[15])
+  np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-10)
+  np.testing.assert_allclose(o.sensordata, e.sensordata, rtol=0, atol=1e-9)
+  assert states >= {0, 1, 2} and (3 in states or 4 in states)   # cone zones and the friction row's linear zone
+  assert touched > 0
+  assert not e.warning.any() and not o.warning.any()

@@ -387,3 +387,53 @@ def test_elliptic_torsional_friction_stops_spin():
   for _ in range(50):
     p.step()
   assert 0 <= p.qvel[5] < w0
+
+
+# ---- dof friction loss (suite finger: <joint frictionloss=".1">) ------------------------------------
+_FRICTION_HINGE = """
+<mujoco><option gravity="0 0 0"/><worldbody>
+  <body name='wheel'><joint name='h' type='hinge' axis='0 0 1' frictionloss='0.1'/>
+    <geom type='cylinder' size='.1 .02' mass='1'/></body>
+</worldbody><actuator><motor name='m' joint='h' gear='1'/></actuator></mujoco>"""
+
+
+def test_frictionloss_decelerates_at_constant_rate_then_holds():
+  # Dry friction: while sliding the constraint force saturates at -frictionloss, so the
+  # velocity falls linearly with slope frictionloss / M (Huber cost, linear zone).
+  m = mc.compile_xml(_FRICTION_HINGE)
+  p = OraclePhysics(m, legacy_step=False)
+  p.forward()
+  M = p.qM[0]
+  p.qvel[0] = 1.0
+  n = 10                                # stops after 1 / (0.1 / M) = 0.05 s = 25 steps
+  for _ in range(n):
+    p.step()
+  np.testing.assert_allclose(p.qvel[0], 1.0 - n * m.opt.timestep * 0.1 / M, rtol=1e-9)
+  np.testing.assert_allclose(p.qfrc_constraint[0], -0.1, rtol=1e-9)
+  while p.time < 0.2:
+    p.step()
+  assert abs(p.qvel[0]) < 1e-6          # came to rest and stays there (quadratic zone)
+
+
+def test_frictionloss_holds_against_subthreshold_torque():
+  m = mc.compile_xml(_FRICTION_HINGE)
+  p = OraclePhysics(m, legacy_step=False)
+  p.ctrl[0] = 0.05                       # below frictionloss: creeps at the soft-constraint rate only
+  for _ in range(200):
+    p.step()
+  np.testing.assert_allclose(p.qfrc_constraint[0], -0.05, rtol=1e-6)
+  # steady creep of the soft constraint: D (a + B v) = tau with a = 0  =>  v = R tau / B,
+  # R = (1 - d0)/d0 * dof_invweight0, B = 2 / (dmax * timeconst)   (defaults 0.9, 0.95, 0.02)
+  R, B = (0.1 / 0.9) * m.dof_invweight0[0], 2 / (0.95 * 0.02)
+  np.testing.assert_allclose(p.qvel[0], R * 0.05 / B, rtol=1e-6)
+  p.ctrl[0] = 0.3                        # above: net torque 0.3 - 0.1 accelerates the wheel
+  p.forward()
+  M = p.qM[0]
+  v0 = p.qvel[0]
+  for _ in range(50):
+    p.step()
+  np.testing.assert_allclose((p.qvel[0] - v0) / (50 * m.opt.timestep), 0.2 / M, rtol=1e-3)
+  # mjDSBL_FRICTIONLOSS removes the rows
+  p.model.opt_int('disableflags', p.model.opt_int('disableflags') | (1 << 2))
+  p.step()
+  assert p.nefc == 0
