@@ -1496,7 +1496,15 @@ struct StepCore {
         ctrl = t_max(MR(act_ctrlrange)[2*i], t_min(MR(act_ctrlrange)[2*i + 1], ctrl));
       const T* gp = MR(act_gainprm) + 3*i; const T* bp = MR(act_biasprm) + 3*i;
       const T gear = MR(act_gear)[i];
-      const T len = gear * S(qpos)[MI(act_qpos)[i]], vel = gear * S(qvel)[MI(act_dof)[i]];
+      T len, vel;
+      if (L.d.nwrap && (fl & ACTF_TENDON)) {   // fixed tendon: linear combination of joint coordinates
+        const int t = MI(act_dof)[i];
+        len = 0; vel = 0;
+        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+          len += MR(wrap_prm)[w] * S(qpos)[MI(wrap_qpos)[w]]; vel += MR(wrap_prm)[w] * S(qvel)[MI(wrap_dof)[w]];
+        }
+        len *= gear; vel *= gear;
+      } else { len = gear * S(qpos)[MI(act_qpos)[i]]; vel = gear * S(qvel)[MI(act_dof)[i]]; }
       T gain = gp[0], bias = 0;
       if (fl & ACTF_GAIN_AFFINE) gain = gp[0] + gp[1]*len + gp[2]*vel;
       if (fl & ACTF_BIAS_AFFINE) bias = bp[0] + bp[1]*len + bp[2]*vel;
@@ -1507,7 +1515,13 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(dd, nv) {
       T f = 0;
-      for (int i = 0; i < nu; i++) if (MI(act_dof)[i] == dd) f += MR(act_gear)[i] * S(actuator_force)[i];
+      for (int i = 0; i < nu; i++) {
+        if (L.d.nwrap && (MI(act_flags)[i] & ACTF_TENDON)) {
+          const int t = MI(act_dof)[i];
+          for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++)
+            if (MI(wrap_dof)[w] == dd) f += MR(act_gear)[i] * MR(wrap_prm)[w] * S(actuator_force)[i];
+        } else if (MI(act_dof)[i] == dd) f += MR(act_gear)[i] * S(actuator_force)[i];
+      }
       S(qfrc_actuator)[dd] = f;
     }
     DMC_WSYNC();

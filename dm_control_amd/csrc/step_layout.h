@@ -24,6 +24,7 @@ struct StepDims {
   int elliptic;  // 1: frictional contacts use elliptic cones (one row per contact-frame axis)
   int nfric;     // dofs with frictionloss > 0 (one Huber-cost row each)
   int ncyl;      // candidate pairs involving a cylinder (guard test only, never a contact)
+  int ntendon, nwrap;  // fixed tendons used as actuator transmissions
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -46,7 +47,8 @@ struct StepDims {
   X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
   X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
   X(sensor_stage, d.nsensor) X(sensor_objtype, d.nsensor)                      \
-  X(fric_dof, d.nfric)
+  X(fric_dof, d.nfric)                                                         \
+  X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap)
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -67,7 +69,7 @@ struct StepDims {
   X(pair_solref, 2 * d.npair) X(pair_solimp, 5 * d.npair)                      \
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
-  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
+  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -122,7 +124,8 @@ enum { MISC_TIME = 0 };
 enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */ };
 
 // act_flags bits
-enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8 };
+enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
+       ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */ };
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))

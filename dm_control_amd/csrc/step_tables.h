@@ -44,8 +44,8 @@ inline bool host_model_parse(HostModel* m, const int32_t* ints, int nints, const
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
-  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
+  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
+  (void)ntendon; (void)nwrap; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
 #define X(n, c) { long cnt = (c); if (cnt < 0 || !need_i(cnt)) { *err = "model blob truncated"; return false; } m->n.assign(ints + ip, ints + ip + cnt); ip += cnt; }
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -86,6 +86,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.dof_frictionloss[i] > 0) fric_dof.push_back(i);
   }
   d.nfric = (int)fric_dof.size();
+  d.ntendon = m.ntendon; d.nwrap = m.nwrap;
+  for (int w = 0; w < m.nwrap; w++) { const int j = m.wrap_objid[w]; if (j < 0 || j >= m.njnt || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "fixed tendons may only wrap hinge/slide joints"; return false; } }
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
@@ -189,10 +191,13 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);
   for (int i = 0; i < m.nu; i++) {
     const int j = m.actuator_trnid[2*i];
-    if (m.actuator_trntype[i] != DMC_TRN_JOINT || j < 0 || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "only hinge/slide joint transmissions are implemented"; return false; }
+    const bool tendon = m.actuator_trntype[i] == DMC_TRN_TENDON;
+    if (tendon) { if (j < 0 || j >= m.ntendon) { *err = "actuator refers to a missing tendon"; return false; } }
+    else if (m.actuator_trntype[i] != DMC_TRN_JOINT || j < 0 || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "only hinge/slide joint and fixed-tendon transmissions are implemented"; return false; }
     if (m.actuator_dyntype[i] != DMC_DYN_NONE) { *err = "actuator dynamics are not implemented"; return false; }
-    mi[L.mi_act_dof + i] = m.jnt_dofadr[j]; mi[L.mi_act_qpos + i] = m.jnt_qposadr[j];
-    int fl = 0;
+    if (tendon) { mi[L.mi_act_dof + i] = j; mi[L.mi_act_qpos + i] = 0; }
+    else { mi[L.mi_act_dof + i] = m.jnt_dofadr[j]; mi[L.mi_act_qpos + i] = m.jnt_qposadr[j]; }
+    int fl = tendon ? ACTF_TENDON : 0;
     if (m.actuator_ctrllimited[i]) fl |= ACTF_CTRLLIMITED;
     if (m.actuator_forcelimited[i]) fl |= ACTF_FORCELIMITED;
     if (m.actuator_gaintype[i] == DMC_GAIN_AFFINE) fl |= ACTF_GAIN_AFFINE;
@@ -238,6 +243,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int k = 0; k < 5; k++) mr[L.mr_pair_solimp + 5*p + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
   }
   cpi(L.mi_fric_dof, fric_dof);
+  cpi(L.mi_tendon_adr, m.tendon_adr); cpi(L.mi_tendon_num, m.tendon_num); cpr(L.mr_wrap_prm, m.wrap_prm);
+  for (int w = 0; w < m.nwrap; w++) { mi[L.mi_wrap_dof + w] = m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = m.jnt_qposadr[m.wrap_objid[w]]; }
   if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);
   // sensors the kernel can compute

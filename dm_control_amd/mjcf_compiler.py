@@ -275,7 +275,7 @@ class Model:
   def sizes(self):
     return {k: int(getattr(self, k)) for k in
             ('nq', 'nv', 'nu', 'na', 'nbody', 'njnt', 'ngeom', 'nsite',
-             'nsensor', 'nsensordata', 'npair', 'nkey')}
+             'nsensor', 'nsensordata', 'npair', 'nkey', 'ntendon', 'nwrap')}
 
   def pack(self):
     """Serialises into (ints int32[], reals float64[]) per dmc_model_layout.h."""
@@ -694,9 +694,40 @@ class _Compiler:
           raise MjcfError('unknown default class %r' % cname)
         a = dict(self.classes[cname].get('general'))
         a.update(_actuator_to_general(e.tag, dict(e.attrib)))
-        if 'joint' not in a:
-          raise MjcfError('only joint transmissions are supported')
+        if ('joint' in a) == ('tendon' in a):
+          raise MjcfError('actuator %r: exactly one of joint= / tendon= transmissions is supported'
+                          % a.get('name'))
         self.actuators.append(a)
+
+  def _parse_tendons(self):
+    """Fixed tendons (linear combinations of joint coordinates) used as actuator
+    transmissions; anything that would add forces or constraints is rejected."""
+    self.tendons = []
+    for sec in self.root.findall('tendon'):
+      for e in sec:
+        if e.tag != 'fixed':
+          raise MjcfError('unsupported tendon <%s> (only <fixed> tendons are supported)' % e.tag)
+        cname = e.attrib.get('class', 'main')
+        if cname not in self.classes:
+          raise MjcfError('unknown default class %r' % cname)
+        a = dict(self.classes[cname].get('tendon'))
+        a.update(e.attrib)
+        if a.get('limited', 'false') == 'true':
+          raise MjcfError('tendon %r: limits are not supported' % a.get('name'))
+        for k in ('stiffness', 'damping', 'frictionloss'):
+          if float(a.get(k, 0)) != 0:
+            raise MjcfError('tendon %r: %s is not supported' % (a.get('name'), k))
+        wraps = []
+        for w in e:
+          if w.tag != 'joint':
+            raise MjcfError('fixed tendon %r: unsupported element <%s>' % (a.get('name'), w.tag))
+          wraps.append((w.attrib['joint'], float(w.attrib['coef'])))
+        if not wraps:
+          raise MjcfError('tendon %r is empty' % a.get('name'))
+        self.tendons.append(dict(name=a.get('name'), wraps=wraps))
+    for sec in self.root.findall('equality'):
+      if len(sec):
+        raise MjcfError('equality constraints are not supported')
 
   def _parse_sensors(self):
     for sec in self.root.findall('sensor'):
@@ -734,6 +765,7 @@ class _Compiler:
         wb.append(c)
     self._parse_body(wb, -1, None)
     self._parse_actuators()
+    self._parse_tendons()
     self._parse_sensors()
     self._parse_contact()
     self._parse_keyframes()
@@ -973,16 +1005,42 @@ class _Compiler:
     m.actuator_gainprm = np.zeros((nu, 10))
     m.actuator_biasprm = np.zeros((nu, 10))
     m.actuator_dynprm = np.zeros((nu, 10))
+    # fixed tendons
+    m.ntendon = len(self.tendons)
+    m.tendon_adr = np.zeros(m.ntendon, dtype=np.int64)
+    m.tendon_num = np.zeros(m.ntendon, dtype=np.int64)
+    objid, prm = [], []
+    for t, td in enumerate(self.tendons):
+      m.tendon_adr[t] = len(objid)
+      m.tendon_num[t] = len(td['wraps'])
+      for jname, coef in td['wraps']:
+        if jname not in m.names['joint']:
+          raise MjcfError('tendon %r refers to unknown joint %r' % (td['name'], jname))
+        jid = m.names['joint'].index(jname)
+        if m.jnt_type[jid] not in (_JNT['hinge'], _JNT['slide']):
+          raise MjcfError('fixed tendons may only wrap hinge/slide joints')
+        objid.append(jid)
+        prm.append(coef)
+    m.nwrap = len(objid)
+    m.wrap_objid = np.asarray(objid, dtype=np.int64)
+    m.wrap_prm = np.asarray(prm, dtype=np.float64)
+    m.names['tendon'] = [td['name'] for td in self.tendons]
     names = []
     for i, a in enumerate(self.actuators):
       names.append(a.get('name'))
-      jname = a['joint']
-      if jname not in m.names['joint']:
-        raise MjcfError('actuator refers to unknown joint %r' % jname)
-      jid = m.names['joint'].index(jname)
-      if m.jnt_type[jid] not in (_JNT['hinge'], _JNT['slide']):
-        raise MjcfError('actuators on ball/free joints are not supported')
-      m.actuator_trnid[i, 0] = jid
+      if 'tendon' in a:
+        if a['tendon'] not in m.names['tendon']:
+          raise MjcfError('actuator refers to unknown tendon %r' % a['tendon'])
+        m.actuator_trntype[i] = C['DMC_TRN_TENDON']
+        m.actuator_trnid[i, 0] = m.names['tendon'].index(a['tendon'])
+      else:
+        jname = a['joint']
+        if jname not in m.names['joint']:
+          raise MjcfError('actuator refers to unknown joint %r' % jname)
+        jid = m.names['joint'].index(jname)
+        if m.jnt_type[jid] not in (_JNT['hinge'], _JNT['slide']):
+          raise MjcfError('actuators on ball/free joints are not supported')
+        m.actuator_trnid[i, 0] = jid
       dyn = a.get('dyntype', 'none')
       if dyn != 'none':
         raise MjcfError('actuator dyntype %r is not supported' % dyn)

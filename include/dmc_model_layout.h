@@ -18,12 +18,12 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 4
+#define DMC_MODEL_VERSION 5
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) \
-  X(nsensor) X(nsensordata) X(npair) X(nkey) \
+  X(nsensor) X(nsensordata) X(npair) X(nkey) X(ntendon) X(nwrap) \
   X(opt_integrator) X(opt_cone) X(opt_solver) X(opt_iterations) \
   X(opt_ls_iterations) X(opt_noslip_iterations) \
   X(opt_disableflags) X(opt_enableflags)
@@ -50,7 +50,9 @@
   X(actuator_ctrllimited, nu) X(actuator_forcelimited, nu) \
   X(sensor_type, nsensor) X(sensor_objtype, nsensor) X(sensor_objid, nsensor) \
   X(sensor_adr, nsensor) X(sensor_dim, nsensor) X(sensor_needstage, nsensor) \
-  X(pair_geom1, npair) X(pair_geom2, npair)
+  X(pair_geom1, npair) X(pair_geom2, npair) \
+  X(tendon_adr, ntendon) X(tendon_num, ntendon) /* fixed tendons: wraps [adr, adr + num) */ \
+  X(wrap_objid, nwrap)                           /* joint id of each wrap */
 
 /* ---- real fields: X(name, count_expr) ----------------------------------- */
 #define DMC_MODEL_REAL_FIELDS(X) \
@@ -71,7 +73,7 @@
   X(actuator_gear, 6*nu) X(actuator_ctrlrange, 2*nu) \
   X(actuator_forcerange, 2*nu) X(actuator_gainprm, 10*nu) \
   X(actuator_biasprm, 10*nu) X(actuator_dynprm, 10*nu) \
-  X(sensor_cutoff, nsensor) \
+  X(sensor_cutoff, nsensor) X(wrap_prm, nwrap) \
   X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
 
 /* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
@@ -84,7 +86,7 @@ enum { DMC_INT_EULER = 0, DMC_INT_RK4 = 1, DMC_INT_IMPLICIT = 2,
        DMC_INT_IMPLICITFAST = 3 };
 enum { DMC_CONE_PYRAMIDAL = 0, DMC_CONE_ELLIPTIC = 1 };
 enum { DMC_SOL_PGS = 0, DMC_SOL_CG = 1, DMC_SOL_NEWTON = 2 };
-enum { DMC_TRN_JOINT = 0 };
+enum { DMC_TRN_JOINT = 0, DMC_TRN_TENDON = 3 };
 enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2 };
 enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
 enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };

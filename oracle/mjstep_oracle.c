@@ -277,9 +277,9 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
 #define X(n, c) m->n = m->ibuf + ip; ip += (c);
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -308,9 +308,9 @@ double ora_model_opt_real(Model* m, const char* name, int set, double value) {
 }
 int* ora_model_int_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -318,9 +318,9 @@ int* ora_model_int_field(Model* m, const char* name, int* count) {
 }
 double* ora_model_real_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_REAL_FIELDS(X)
 #undef X
@@ -912,10 +912,20 @@ static void make_constraint(const Model* m, Data* d) {
   }
 }
 
+/* fixed tendon t: sum_k prm_k * v[index of wrapped joint k] (length from qpos, velocity from qvel) */
+static double tendon_dot(const Model* m, int t, const double* v, int use_dof) {
+  double s = 0;
+  for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) {
+    int j = m->wrap_objid[w];
+    s += m->wrap_prm[w] * v[use_dof ? m->jnt_dofadr[j] : m->jnt_qposadr[j]];
+  }
+  return s;
+}
 static void transmission(const Model* m, Data* d) {
   for (int i = 0; i < m->nu; i++) {
     int j = m->actuator_trnid[2*i];
-    d->actuator_length[i] = m->actuator_gear[6*i] * d->qpos[m->jnt_qposadr[j]];
+    if (m->actuator_trntype[i] == DMC_TRN_TENDON) d->actuator_length[i] = m->actuator_gear[6*i] * tendon_dot(m, j, d->qpos, 0);
+    else d->actuator_length[i] = m->actuator_gear[6*i] * d->qpos[m->jnt_qposadr[j]];
   }
 }
 
@@ -1238,7 +1248,11 @@ static void fwd_actuation(const Model* m, Data* d) {
     double force = gain*ctrl + bias;
     if (m->actuator_forcelimited[i]) force = mjMAX(m->actuator_forcerange[2*i], mjMIN(m->actuator_forcerange[2*i + 1], force));
     d->actuator_force[i] = force;
-    d->qfrc_actuator[m->jnt_dofadr[m->actuator_trnid[2*i]]] += m->actuator_gear[6*i] * force;
+    if (m->actuator_trntype[i] == DMC_TRN_TENDON) {
+      int t = m->actuator_trnid[2*i];
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+        d->qfrc_actuator[m->jnt_dofadr[m->wrap_objid[w]]] += m->actuator_gear[6*i] * m->wrap_prm[w] * force;
+    } else d->qfrc_actuator[m->jnt_dofadr[m->actuator_trnid[2*i]]] += m->actuator_gear[6*i] * force;
   }
 }
 static void fwd_acceleration(const Model* m, Data* d) {
@@ -1512,7 +1526,10 @@ static void fwd_position(const Model* m, Data* d) {
   kinematics(m, d); com_pos(m, d); crb(m, d); collision(m, d); make_constraint(m, d); transmission(m, d);
 }
 static void fwd_velocity(const Model* m, Data* d) {
-  for (int i = 0; i < m->nu; i++) d->actuator_velocity[i] = m->actuator_gear[6*i] * d->qvel[m->jnt_dofadr[m->actuator_trnid[2*i]]];
+  for (int i = 0; i < m->nu; i++) {
+    int j = m->actuator_trnid[2*i];
+    d->actuator_velocity[i] = m->actuator_gear[6*i] * (m->actuator_trntype[i] == DMC_TRN_TENDON ? tendon_dot(m, j, d->qvel, 1) : d->qvel[m->jnt_dofadr[j]]);
+  }
   com_vel(m, d); passive(m, d); rne(m, d);
 }
 static int bad_vec(const double* v, int n) { for (int i = 0; i < n; i++) if (isnan(v[i]) || v[i] > MAXVAL || v[i] < -MAXVAL) return 1; return 0; }

@@ -20,7 +20,8 @@ def _oracle(model):
                                          ('hopper', 'hop'), ('hopper', 'stand'), ('pendulum', 'swingup'),
                                          ('acrobot', 'swingup'), ('acrobot', 'swingup_sparse'),
                                          ('finger', 'spin'), ('finger', 'turn_easy'), ('finger', 'turn_hard'),
-                                         ('reacher', 'easy'), ('reacher', 'hard')])
+                                         ('reacher', 'easy'), ('reacher', 'hard'),
+                                         ('point_mass', 'easy'), ('point_mass', 'hard')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -44,7 +45,7 @@ def test_suite_task_properties(domain, task):
 
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
-                                         ('finger', 'turn_hard'), ('reacher', 'hard')])
+                                         ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -274,7 +275,7 @@ def test_torch_batched_env_matches_host_env_semantics():
 
 
 @pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1),
-                                       ('finger', 2), ('reacher', 1)])
+                                       ('finger', 2), ('reacher', 1), ('point_mass', 1)])
 def test_more_domains_rollout_parity(name, nsub):
   """Domains sharing the cheetah feature set: 60 env-steps from randomised starts
   against the oracle (fp64 kernel), incl. hopper's touch sensors, acrobot's RK4 and

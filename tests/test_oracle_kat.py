@@ -437,3 +437,29 @@ def test_frictionloss_holds_against_subthreshold_torque():
   p.model.opt_int('disableflags', p.model.opt_int('disableflags') | (1 << 2))
   p.step()
   assert p.nefc == 0
+
+
+# ---- fixed tendons as actuator transmissions (suite point_mass) ---------------------------------------
+def test_fixed_tendon_transmission_steady_state():
+  # A motor on a fixed tendon pushes every wrapped joint with gear * coef * force; against joint
+  # damping b the mass settles at v = gear * coef * ctrl / b, and actuator_length = gear * sum coef q.
+  m = mc.compile_xml("""
+  <mujoco><option timestep="0.02"><flag contact="disable"/></option>
+  <default><joint type="slide" damping="1"/><motor gear=".1"/></default>
+  <worldbody><body name="pm"><joint name="x" axis="1 0 0"/><joint name="y" axis="0 1 0"/>
+    <geom type="sphere" size=".01" mass=".3"/></body></worldbody>
+  <tendon><fixed name="t"><joint joint="x" coef="0.6"/><joint joint="y" coef="-0.8"/></fixed></tendon>
+  <actuator><motor name="a" tendon="t"/></actuator></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  p.ctrl[0] = 0.5
+  for _ in range(500):
+    p.step()
+  np.testing.assert_allclose(p.qvel, 0.1 * np.array([0.6, -0.8]) * 0.5 / 1.0, rtol=1e-9)
+  np.testing.assert_allclose(p.qfrc_actuator, 0.1 * np.array([0.6, -0.8]) * 0.5, rtol=1e-12)
+  p.forward()
+  np.testing.assert_allclose(p.actuator_length[0], 0.1 * (0.6 * p.qpos[0] - 0.8 * p.qpos[1]), rtol=1e-12)
+  for bad in ('<tendon><spatial name="s"><site site="a"/></spatial></tendon>',
+              '<equality><joint joint1="x"/></equality>'):
+    with pytest.raises(mc.MjcfError):
+      mc.compile_xml('<mujoco><worldbody><body><joint name="x" type="slide"/><geom size=".1"/>'
+                     '<site name="a"/></body></worldbody>%s</mujoco>' % bad)
