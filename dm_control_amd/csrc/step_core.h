@@ -1163,6 +1163,58 @@ struct StepCore {
       DMC_WSYNC();
     }
   }
+  // mj_passive fluid forces, inertia-box model: each body with mass is replaced by the box of
+  // equal inertia; Stokes (viscosity) and quadratic (density) drag on its local inertial-frame
+  // velocity; the wrench acts at the body COM.  Per-body wrenches are parked in cfrc_ext (free
+  // until mj_rnePostConstraint), then projected on the dofs.
+  DMC_DEV void fluid_forces() {
+    const int nb = L.d.nbody, nv = L.d.nv;
+    FOR_LANES(b, nb) {
+      T wr[6] = {0, 0, 0, 0, 0, 0};
+      const T mass = MR(body_mass)[b];
+      if (b > 0 && mass >= (T)DMC_MINVAL) {
+        const T* I = MR(body_inertia) + 3*b;
+        const T box[3] = {t_sqrt(t_max((T)DMC_MINVAL, I[1] + I[2] - I[0]) / mass * (T)6),
+                          t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[2] - I[1]) / mass * (T)6),
+                          t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[1] - I[2]) / mass * (T)6)};
+        T q[4], im[9], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
+        mul_quat(q, S(xquat) + 4*b, MR(body_iquat) + 4*b);
+        quat2mat(im, q);
+        object_velocity(b, S(xipos) + 3*b, im, lvel);
+        const T pi = (T)3.14159265358979323846;
+        if (o.viscosity > 0) {
+          const T diam = (box[0] + box[1] + box[2]) / (T)3;
+          for (int k = 0; k < 3; k++) { lfrc[k] = -pi*diam*diam*diam*o.viscosity * lvel[k]; lfrc[3 + k] = -(T)3*pi*diam*o.viscosity * lvel[3 + k]; }
+        }
+        if (o.density > 0) {
+          const T rho = o.density;
+          lfrc[3] -= (T)0.5*rho*box[1]*box[2]*t_abs(lvel[3])*lvel[3];
+          lfrc[4] -= (T)0.5*rho*box[0]*box[2]*t_abs(lvel[4])*lvel[4];
+          lfrc[5] -= (T)0.5*rho*box[0]*box[1]*t_abs(lvel[5])*lvel[5];
+          lfrc[0] -= rho*box[0]*(box[1]*box[1]*box[1]*box[1] + box[2]*box[2]*box[2]*box[2])*t_abs(lvel[0])*lvel[0]/(T)64;
+          lfrc[1] -= rho*box[1]*(box[0]*box[0]*box[0]*box[0] + box[2]*box[2]*box[2]*box[2])*t_abs(lvel[1])*lvel[1]/(T)64;
+          lfrc[2] -= rho*box[2]*(box[0]*box[0]*box[0]*box[0] + box[1]*box[1]*box[1]*box[1])*t_abs(lvel[2])*lvel[2]/(T)64;
+        }
+        mul_mat_vec3(wr, im, lfrc); mul_mat_vec3(wr + 3, im, lfrc + 3);   // [torque, force] in the world frame
+      }
+      for (int k = 0; k < 6; k++) S(cfrc_ext)[6*b + k] = wr[k];
+    }
+    DMC_WSYNC();
+    FOR_LANES(dd, nv) {
+      T f = 0;
+      const T* cd = S(cdof) + 6*dd;
+      for (int b = 1; b < nb; b++) {
+        if (!dof_in_chain(MI(body_lastdof)[b], dd)) continue;
+        const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
+        T off[3] = {S(xipos)[3*b] - rc[0], S(xipos)[3*b + 1] - rc[1], S(xipos)[3*b + 2] - rc[2]}, tmp[3];
+        cross3(tmp, cd, off);
+        const T* wr = S(cfrc_ext) + 6*b;
+        f += (cd[3] + tmp[0])*wr[3] + (cd[4] + tmp[1])*wr[4] + (cd[5] + tmp[2])*wr[5] + cd[0]*wr[0] + cd[1]*wr[1] + cd[2]*wr[2];
+      }
+      S(qfrc_passive)[dd] += f;
+    }
+    DMC_WSYNC();
+  }
   DMC_DEV void passive_and_rne() {
     const int nv = L.d.nv;
     FOR_LANES(i, nv) {
@@ -1174,8 +1226,23 @@ struct StepCore {
         f -= k * (S(qpos)[qa] - MR(qpos_spring)[qa]);
       }
       if (!(o.disableflags & DMC_DSBL_DAMPER)) f -= MR(dof_damping)[i] * S(qvel)[i];
+      // fixed-tendon springs / dampers (each lane re-derives the few tendon lengths it needs)
+      for (int t = 0; t < L.d.ntendon; t++) {
+        const T kt = MR(tendon_stiffness)[t], bt = MR(tendon_damping)[t];
+        if (kt == 0 && bt == 0) continue;
+        T len = 0, vel = 0, mine = 0;
+        for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++) {
+          len += MR(wrap_prm)[w] * S(qpos)[MI(wrap_qpos)[w]]; vel += MR(wrap_prm)[w] * S(qvel)[MI(wrap_dof)[w]];
+          if (MI(wrap_dof)[w] == i) mine += MR(wrap_prm)[w];
+        }
+        T ft = 0;
+        if (kt != 0 && !(o.disableflags & DMC_DSBL_SPRING)) ft -= kt * (len - MR(tendon_lengthspring)[t]);
+        if (bt != 0 && !(o.disableflags & DMC_DSBL_DAMPER)) ft -= bt * vel;
+        f += mine * ft;
+      }
       S(qfrc_passive)[i] = f;
     }
+    if (L.d.fluid) fluid_forces();
     if (lane == 0) {
       T* ca = S(cacc);
       ca[0] = ca[1] = ca[2] = 0; ca[3] = ca[4] = ca[5] = 0;
@@ -1446,6 +1513,15 @@ struct StepCore {
       else if (t == DMC_SENS_JOINTVEL) out[0] = S(qvel)[MI(jnt_dofadr)[id]];
       else if (t == DMC_SENS_ACTUATORFRC) out[0] = S(actuator_force)[id];
       else if (t == DMC_SENS_SUBTREECOM) for (int k = 0; k < 3; k++) out[k] = S(subtree_com)[3*id + k];
+      else if (t >= DMC_SENS_FRAMEXAXIS && t <= DMC_SENS_FRAMEZAXIS) {
+        const int ot = MI(sensor_objtype)[i], c = t - DMC_SENS_FRAMEXAXIS;
+        T q[4], R[9];
+        const T* Rp = R;
+        if (ot == DMC_OBJ_SITE) { mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id); quat2mat(R, q); }
+        else if (ot == DMC_OBJ_BODY) { mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id); quat2mat(R, q); }
+        else Rp = ot == DMC_OBJ_GEOM ? S(geom_xmat) + 9*id : S(xmat) + 9*id;
+        out[0] = Rp[c]; out[1] = Rp[3 + c]; out[2] = Rp[6 + c];
+      }
       else if (t == DMC_SENS_FRAMEPOS) {
         const int ot = MI(sensor_objtype)[i];
         if (ot == DMC_OBJ_SITE) {

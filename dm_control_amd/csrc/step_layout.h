@@ -24,7 +24,8 @@ struct StepDims {
   int elliptic;  // 1: frictional contacts use elliptic cones (one row per contact-frame axis)
   int nfric;     // dofs with frictionloss > 0 (one Huber-cost row each)
   int ncyl;      // candidate pairs involving a cylinder (guard test only, never a contact)
-  int ntendon, nwrap;  // fixed tendons used as actuator transmissions
+  int ntendon, nwrap;  // fixed tendons (actuator transmissions, springs / dampers)
+  int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -69,7 +70,8 @@ struct StepDims {
   X(pair_solref, 2 * d.npair) X(pair_solimp, 5 * d.npair)                      \
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
-  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)
+  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)       \
+  X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon)
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -154,7 +156,7 @@ struct StepLayout {
 // scalar options broadcast to every wave
 template <typename T>
 struct StepOpts {
-  T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia;
+  T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia, density, viscosity;
   int integrator, cone, iterations, ls_iterations, disableflags;
   int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
   double timestep_d; // fp64 copy for the time accumulator

@@ -87,6 +87,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   d.nfric = (int)fric_dof.size();
   d.ntendon = m.ntendon; d.nwrap = m.nwrap;
+  d.fluid = (m.opt_density > 0 || m.opt_viscosity > 0) ? 1 : 0;
   for (int w = 0; w < m.nwrap; w++) { const int j = m.wrap_objid[w]; if (j < 0 || j >= m.njnt || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "fixed tendons may only wrap hinge/slide joints"; return false; } }
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
@@ -244,6 +245,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   cpi(L.mi_fric_dof, fric_dof);
   cpi(L.mi_tendon_adr, m.tendon_adr); cpi(L.mi_tendon_num, m.tendon_num); cpr(L.mr_wrap_prm, m.wrap_prm);
+  cpr(L.mr_tendon_stiffness, m.tendon_stiffness); cpr(L.mr_tendon_damping, m.tendon_damping); cpr(L.mr_tendon_lengthspring, m.tendon_lengthspring);
   for (int w = 0; w < m.nwrap; w++) { mi[L.mi_wrap_dof + w] = m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = m.jnt_qposadr[m.wrap_objid[w]]; }
   if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);
@@ -253,14 +255,15 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     const bool ok = st == DMC_SENS_JOINTPOS || st == DMC_SENS_JOINTVEL || st == DMC_SENS_ACTUATORFRC ||
                     st == DMC_SENS_SUBTREECOM || st == DMC_SENS_SUBTREELINVEL || st == DMC_SENS_VELOCIMETER ||
                     st == DMC_SENS_GYRO || st == DMC_SENS_ACCELEROMETER || st == DMC_SENS_FORCE ||
-                    st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH || st == DMC_SENS_FRAMEPOS;
+                    st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH || st == DMC_SENS_FRAMEPOS ||
+                    st == DMC_SENS_FRAMEXAXIS || st == DMC_SENS_FRAMEYAXIS || st == DMC_SENS_FRAMEZAXIS;
     if (!ok) { *err = "sensor type not implemented"; return false; }
     if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX && tt != DMC_GEOM_ELLIPSOID) { *err = "touch sensor sites must be sphere, capsule, ellipsoid or box"; return false; } }
   }
   StepOpts<double>& o = t->opts;
   o.timestep = m.opt_timestep; o.timestep_d = m.opt_timestep; o.gravity[0] = m.opt_gravity_x; o.gravity[1] = m.opt_gravity_y; o.gravity[2] = m.opt_gravity_z;
   o.impratio = m.opt_impratio; o.tolerance = m.opt_tolerance; o.ls_tolerance = m.opt_ls_tolerance;
-  o.meaninertia = m.stat_meaninertia;
+  o.meaninertia = m.stat_meaninertia; o.density = m.opt_density; o.viscosity = m.opt_viscosity;
   o.integrator = m.opt_integrator; o.cone = m.opt_cone; o.iterations = m.opt_iterations;
   o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
   o.any_damping = 0;
@@ -273,7 +276,8 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   StepOpts<T> o;
   o.timestep = (T)s.timestep; for (int k = 0; k < 3; k++) o.gravity[k] = (T)s.gravity[k];
   o.impratio = (T)s.impratio; o.tolerance = (T)s.tolerance; o.ls_tolerance = (T)s.ls_tolerance;
-  o.meaninertia = (T)s.meaninertia; o.integrator = s.integrator; o.cone = s.cone;
+  o.meaninertia = (T)s.meaninertia; o.density = (T)s.density; o.viscosity = (T)s.viscosity;
+  o.integrator = s.integrator; o.cone = s.cone;
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
   o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
   return o;

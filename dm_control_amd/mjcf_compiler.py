@@ -51,6 +51,9 @@ _SENSORS = {
     'subtreelinvel': (C['DMC_SENS_SUBTREELINVEL'], 'body', C['DMC_OBJ_BODY'], 3, 2),
     # object named by objtype/objname (body = inertial frame, xbody = body frame, geom, site)
     'framepos': (C['DMC_SENS_FRAMEPOS'], 'objname', None, 3, 1),
+    'framexaxis': (C['DMC_SENS_FRAMEXAXIS'], 'objname', None, 3, 1),
+    'frameyaxis': (C['DMC_SENS_FRAMEYAXIS'], 'objname', None, 3, 1),
+    'framezaxis': (C['DMC_SENS_FRAMEZAXIS'], 'objname', None, 3, 1),
 }
 
 
@@ -237,6 +240,8 @@ class _Opt:
     self.timestep = 0.002
     self.gravity = np.array([0.0, 0.0, -9.81])
     self.impratio = 1.0
+    self.density = 0.0
+    self.viscosity = 0.0
     self.tolerance = 1e-8
     self.ls_tolerance = 0.01
     self.noslip_tolerance = 1e-6
@@ -293,6 +298,7 @@ class Model:
               opt_impratio=o.impratio, opt_tolerance=o.tolerance,
               opt_ls_tolerance=o.ls_tolerance,
               opt_noslip_tolerance=o.noslip_tolerance,
+              opt_density=o.density, opt_viscosity=o.viscosity,
               stat_meaninertia=self.stat_meaninertia)
     reals = [float(rh[k]) for k in _layout.HEADER_REALS]
     ints = [np.asarray(ints, dtype=np.int64)]
@@ -489,9 +495,13 @@ class _Compiler:
         o.cone = {'pyramidal': 0, 'elliptic': 1}[a['cone']]
       if 'solver' in a:
         o.solver = {'PGS': 0, 'CG': 1, 'Newton': 2}[a['solver']]
-      for k in ('density', 'viscosity'):
-        if k in a and float(a[k]) != 0:
-          raise MjcfError('fluid forces (option %s) are not supported' % k)
+      for k in ('density', 'viscosity'):   # fluid forces: inertia-box model (no geom fluidshape)
+        if k in a:
+          setattr(o, k, float(a[k]))
+          if getattr(o, k) < 0:
+            raise MjcfError('option %s must be non-negative' % k)
+      if 'wind' in a and np.any(_vec(a['wind'], 3) != 0):
+        raise MjcfError('option wind is not supported')
       for f in e.findall('flag'):
         for k, v in f.attrib.items():
           if k in _DISABLE_FLAGS:
@@ -714,9 +724,10 @@ class _Compiler:
         a.update(e.attrib)
         if a.get('limited', 'false') == 'true':
           raise MjcfError('tendon %r: limits are not supported' % a.get('name'))
-        for k in ('stiffness', 'damping', 'frictionloss'):
-          if float(a.get(k, 0)) != 0:
-            raise MjcfError('tendon %r: %s is not supported' % (a.get('name'), k))
+        if float(a.get('frictionloss', 0)) != 0:
+          raise MjcfError('tendon %r: frictionloss is not supported' % a.get('name'))
+        if 'springlength' in a:
+          raise MjcfError('tendon %r: explicit springlength is not supported' % a.get('name'))
         wraps = []
         for w in e:
           if w.tag != 'joint':
@@ -724,7 +735,8 @@ class _Compiler:
           wraps.append((w.attrib['joint'], float(w.attrib['coef'])))
         if not wraps:
           raise MjcfError('tendon %r is empty' % a.get('name'))
-        self.tendons.append(dict(name=a.get('name'), wraps=wraps))
+        self.tendons.append(dict(name=a.get('name'), wraps=wraps, stiffness=float(a.get('stiffness', 0)),
+                                 damping=float(a.get('damping', 0))))
     for sec in self.root.findall('equality'):
       if len(sec):
         raise MjcfError('equality constraints are not supported')
@@ -1024,6 +1036,11 @@ class _Compiler:
     m.nwrap = len(objid)
     m.wrap_objid = np.asarray(objid, dtype=np.int64)
     m.wrap_prm = np.asarray(prm, dtype=np.float64)
+    m.tendon_stiffness = np.array([td['stiffness'] for td in self.tendons], dtype=np.float64)
+    m.tendon_damping = np.array([td['damping'] for td in self.tendons], dtype=np.float64)
+    # spring rest length: the tendon's length at qpos0 (springlength = -1 default)
+    m.tendon_lengthspring = np.array([sum(c * m.qpos0[m.jnt_qposadr[m.names['joint'].index(j)]] for j, c in td['wraps'])
+                                      for td in self.tendons], dtype=np.float64)
     m.names['tendon'] = [td['name'] for td in self.tendons]
     names = []
     for i, a in enumerate(self.actuators):

@@ -1,0 +1,120 @@
+"""Fish domain (reference: dm_control/suite/fish.py): upright, swim.
+
+A free-floating body driven through fluid forces (option density, inertia-box model),
+position actuators on joints and on a fixed tendon, and a tendon spring.  The
+per-environment target of `swim` lives in the task (the reference rewrites
+model.geom_pos of the world-fixed target geom)."""
+import collections
+
+import numpy as np
+
+from dm_control_amd import physics as physics_lib
+from dm_control_amd.envs import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.suite import rewards
+
+_DEFAULT_TIME_LIMIT = 40
+_CONTROL_TIMESTEP = .04
+_JOINTS = ['tail1', 'tail_twist', 'tail2', 'finright_roll', 'finright_pitch', 'finleft_roll', 'finleft_pitch']
+TASKS = {}
+
+
+def get_model_and_assets():
+  return common.read_model('fish.xml'), None
+
+
+def _make(task_cls):
+  def factory(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None, physics_kwargs=None):
+    physics = Physics.from_xml_string(*get_model_and_assets(), **(physics_kwargs or {}))
+    return control.Environment(physics, task_cls(random=random), control_timestep=_CONTROL_TIMESTEP,
+                               time_limit=time_limit, **(environment_kwargs or {}))
+  return factory
+
+
+class Physics(physics_lib.Physics):
+  target_pos = None   # (B, 3) or (3,): per-environment target, set by the Swim task
+
+  def upright(self):
+    """Projection of the torso z axis on the world z axis."""
+    return self.named.data.xmat['torso'][..., 8]
+
+  def torso_velocity(self):
+    return self.data.sensordata
+
+  def joint_velocities(self):
+    return np.concatenate([self.named.data.qvel[j] for j in _JOINTS], axis=-1)
+
+  def joint_angles(self):
+    return np.concatenate([self.named.data.qpos[j] for j in _JOINTS], axis=-1)
+
+  def mouth_to_target(self):
+    """Vector from the mouth to the target in the mouth's local frame."""
+    data = self.named.data
+    target = self.target_pos if self.target_pos is not None else data.geom_xpos['target']
+    d = target - data.geom_xpos['mouth']
+    R = np.asarray(data.geom_xmat['mouth']).reshape(d.shape[:-1] + (3, 3))
+    return np.einsum('...i,...ij->...j', d, R)
+
+
+def _randomize_pose(physics, random):
+  B = physics.batch_size
+  nq = physics.model.nq
+  qpos = np.array(physics.data.qpos, dtype=np.float64, copy=True).reshape(B, nq)
+  adr = {j: physics.model.jnt_qposadr[physics.model.name2id(j, 'joint')] for j in _JOINTS}
+  root = physics.model.jnt_qposadr[physics.model.name2id('root', 'joint')]
+  for e in range(B):
+    quat = random.randn(4)
+    qpos[e, root + 3:root + 7] = quat / np.linalg.norm(quat)
+    for j in _JOINTS:
+      qpos[e, adr[j]] = random.uniform(-.2, .2)
+  physics.data.qpos = qpos.reshape(np.shape(physics.data.qpos))
+
+
+class Upright(base.Task):
+
+  def initialize_episode(self, physics):
+    _randomize_pose(physics, self.random)
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    obs = collections.OrderedDict()
+    obs['joint_angles'] = physics.joint_angles()
+    obs['upright'] = physics.upright()
+    obs['velocity'] = physics.velocity()
+    return obs
+
+  def get_reward(self, physics):
+    return rewards.tolerance(physics.upright(), bounds=(1, 1), margin=1)
+
+
+class Swim(base.Task):
+
+  def initialize_episode(self, physics):
+    _randomize_pose(physics, self.random)
+    B = physics.batch_size
+    t = np.zeros((B, 3))
+    for e in range(B):
+      t[e] = [self.random.uniform(-.4, .4), self.random.uniform(-.4, .4), self.random.uniform(.1, .3)]
+    physics.target_pos = t[0] if B == 1 else t
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    obs = collections.OrderedDict()
+    obs['joint_angles'] = physics.joint_angles()
+    obs['upright'] = physics.upright()
+    obs['target'] = physics.mouth_to_target()
+    obs['velocity'] = physics.velocity()
+    return obs
+
+  def get_reward(self, physics):
+    gs = physics.named.model.geom_size
+    radii = gs['mouth'][0] + gs['target'][0]
+    in_target = rewards.tolerance(np.linalg.norm(physics.mouth_to_target(), axis=-1), bounds=(0, radii),
+                                  margin=2 * radii)
+    is_upright = 0.5 * (physics.upright() + 1)
+    return (7 * in_target + is_upright) / 8
+
+
+upright, swim = _make(Upright), _make(Swim)
+TASKS.update(upright=(upright, 'benchmarking'), swim=(swim, 'benchmarking'))

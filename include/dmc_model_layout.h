@@ -18,7 +18,7 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 5
+#define DMC_MODEL_VERSION 6
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
@@ -32,7 +32,7 @@
 #define DMC_MODEL_HEADER_REALS(X) \
   X(opt_timestep) X(opt_gravity_x) X(opt_gravity_y) X(opt_gravity_z) \
   X(opt_impratio) X(opt_tolerance) X(opt_ls_tolerance) X(opt_noslip_tolerance) \
-  X(stat_meaninertia)
+  X(opt_density) X(opt_viscosity) X(stat_meaninertia)
 
 /* ---- int fields: X(name, count_expr) ------------------------------------ */
 #define DMC_MODEL_INT_FIELDS(X) \
@@ -74,6 +74,7 @@
   X(actuator_forcerange, 2*nu) X(actuator_gainprm, 10*nu) \
   X(actuator_biasprm, 10*nu) X(actuator_dynprm, 10*nu) \
   X(sensor_cutoff, nsensor) X(wrap_prm, nwrap) \
+  X(tendon_stiffness, ntendon) X(tendon_damping, ntendon) X(tendon_lengthspring, ntendon) \
   X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
 
 /* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
@@ -95,7 +96,8 @@ enum { DMC_STAGE_NONE = 0, DMC_STAGE_POS = 1, DMC_STAGE_VEL = 2, DMC_STAGE_ACC =
 enum { DMC_SENS_TOUCH = 0, DMC_SENS_ACCELEROMETER = 1, DMC_SENS_VELOCIMETER = 2,
        DMC_SENS_GYRO = 3, DMC_SENS_FORCE = 4, DMC_SENS_TORQUE = 5,
        DMC_SENS_JOINTPOS = 9, DMC_SENS_JOINTVEL = 10, DMC_SENS_ACTUATORFRC = 15,
-       DMC_SENS_FRAMEPOS = 26, DMC_SENS_SUBTREECOM = 37, DMC_SENS_SUBTREELINVEL = 38 };
+       DMC_SENS_FRAMEPOS = 26, DMC_SENS_FRAMEXAXIS = 28, DMC_SENS_FRAMEYAXIS = 29, DMC_SENS_FRAMEZAXIS = 30,
+       DMC_SENS_SUBTREECOM = 37, DMC_SENS_SUBTREELINVEL = 38 };
 /* mjtDisableBit, in the order of dm_control/mjcf/schema.xml:82-103 */
 enum { DMC_DSBL_CONSTRAINT = 1 << 0, DMC_DSBL_EQUALITY = 1 << 1,
        DMC_DSBL_FRICTIONLOSS = 1 << 2, DMC_DSBL_LIMIT = 1 << 3,

@@ -961,6 +961,8 @@ static void com_vel(const Model* m, Data* d) {
     memcpy(d->cvel + 6*i, cvel, sizeof cvel);
   }
 }
+#define DMC_PI 3.14159265358979323846
+static void object_velocity(const Model* m, const Data* d, int body, const double* pos, const double* mat, int local, double* res);
 static void passive(const Model* m, Data* d) {
   int nv = m->nv;
   memset(d->qfrc_passive, 0, sizeof(double) * (size_t)nv);
@@ -973,6 +975,51 @@ static void passive(const Model* m, Data* d) {
   }
   if (!(m->opt_disableflags & DMC_DSBL_DAMPER)) for (int i = 0; i < nv; i++)
     d->qfrc_passive[i] -= m->dof_damping[i] * d->qvel[i];
+  /* fixed-tendon spring / damper */
+  for (int t = 0; t < m->ntendon; t++) {
+    double f = 0;
+    if (m->tendon_stiffness[t] != 0 && !(m->opt_disableflags & DMC_DSBL_SPRING))
+      f -= m->tendon_stiffness[t] * (tendon_dot(m, t, d->qpos, 0) - m->tendon_lengthspring[t]);
+    if (m->tendon_damping[t] != 0 && !(m->opt_disableflags & DMC_DSBL_DAMPER))
+      f -= m->tendon_damping[t] * tendon_dot(m, t, d->qvel, 1);
+    if (f != 0) for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++)
+      d->qfrc_passive[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w] * f;
+  }
+  /* fluid forces, inertia-box model: every body with mass is replaced by the box with the
+   * same inertia; viscous (Stokes, sphere of the mean box size) and quadratic drag terms act
+   * on its local inertial-frame velocity; the wrench is applied at the body's COM */
+  if (m->opt_density > 0 || m->opt_viscosity > 0) for (int i = 1; i < m->nbody; i++) {
+    double mass = m->body_mass[i];
+    if (mass < MINVAL) continue;
+    const double* I = m->body_inertia + 3*i;
+    double box[3] = {sqrt(mjMAX(MINVAL, I[1] + I[2] - I[0]) / mass * 6.0),
+                     sqrt(mjMAX(MINVAL, I[0] + I[2] - I[1]) / mass * 6.0),
+                     sqrt(mjMAX(MINVAL, I[0] + I[1] - I[2]) / mass * 6.0)};
+    double lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0}, bf[3], bt[3];
+    object_velocity(m, d, i, d->xipos + 3*i, d->ximat + 9*i, 1, lvel);
+    if (m->opt_viscosity > 0) {
+      double diam = (box[0] + box[1] + box[2]) / 3.0;
+      for (int k = 0; k < 3; k++) {
+        lfrc[k] = -DMC_PI*diam*diam*diam*m->opt_viscosity * lvel[k];
+        lfrc[3 + k] = -3.0*DMC_PI*diam*m->opt_viscosity * lvel[3 + k];
+      }
+    }
+    if (m->opt_density > 0) {
+      double rho = m->opt_density;
+      lfrc[3] -= 0.5*rho*box[1]*box[2]*fabs(lvel[3])*lvel[3];
+      lfrc[4] -= 0.5*rho*box[0]*box[2]*fabs(lvel[4])*lvel[4];
+      lfrc[5] -= 0.5*rho*box[0]*box[1]*fabs(lvel[5])*lvel[5];
+      lfrc[0] -= rho*box[0]*(box[1]*box[1]*box[1]*box[1] + box[2]*box[2]*box[2]*box[2])*fabs(lvel[0])*lvel[0]/64.0;
+      lfrc[1] -= rho*box[1]*(box[0]*box[0]*box[0]*box[0] + box[2]*box[2]*box[2]*box[2])*fabs(lvel[1])*lvel[1]/64.0;
+      lfrc[2] -= rho*box[2]*(box[0]*box[0]*box[0]*box[0] + box[1]*box[1]*box[1]*box[1])*fabs(lvel[2])*lvel[2]/64.0;
+    }
+    mul_mat_vec3(bt, d->ximat + 9*i, lfrc); mul_mat_vec3(bf, d->ximat + 9*i, lfrc + 3);
+    for (int k = 0; k < nv; k++) {
+      double jp[3], jr[3];
+      jac_col(m, d, i, d->xipos + 3*i, k, jp, jr);
+      d->qfrc_passive[k] += dot3(jp, bf) + dot3(jr, bt);
+    }
+  }
 }
 /* mj_rne with flg_acc = 0 */
 static void rne(const Model* m, Data* d) {
@@ -1046,6 +1093,13 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
       case DMC_SENS_JOINTVEL: out[0] = d->qvel[m->jnt_dofadr[id]]; break;
       case DMC_SENS_ACTUATORFRC: out[0] = d->actuator_force[id]; break;
       case DMC_SENS_SUBTREECOM: memcpy(out, d->subtree_com + 3*id, 3 * sizeof(double)); break;
+      case DMC_SENS_FRAMEXAXIS: case DMC_SENS_FRAMEYAXIS: case DMC_SENS_FRAMEZAXIS: {
+        /* column of the object's world rotation matrix */
+        const double* R = m->sensor_objtype[i] == DMC_OBJ_SITE ? d->site_xmat + 9*id
+                        : m->sensor_objtype[i] == DMC_OBJ_GEOM ? d->geom_xmat + 9*id
+                        : m->sensor_objtype[i] == DMC_OBJ_BODY ? d->ximat + 9*id : d->xmat + 9*id;
+        int c = m->sensor_type[i] - DMC_SENS_FRAMEXAXIS;
+        out[0] = R[c]; out[1] = R[3 + c]; out[2] = R[6 + c]; break; }
       case DMC_SENS_FRAMEPOS: { /* world-frame position of the object's frame origin (no reference frame) */
         const double* p = m->sensor_objtype[i] == DMC_OBJ_SITE ? d->site_xpos + 3*id
                         : m->sensor_objtype[i] == DMC_OBJ_GEOM ? d->geom_xpos + 3*id

@@ -21,7 +21,9 @@ def _oracle(model):
                                          ('acrobot', 'swingup'), ('acrobot', 'swingup_sparse'),
                                          ('finger', 'spin'), ('finger', 'turn_easy'), ('finger', 'turn_hard'),
                                          ('reacher', 'easy'), ('reacher', 'hard'),
-                                         ('point_mass', 'easy'), ('point_mass', 'hard')])
+                                         ('point_mass', 'easy'), ('point_mass', 'hard'),
+                                         ('fish', 'upright'), ('fish', 'swim'), ('swimmer', 'swimmer6'),
+                                         ('swimmer', 'swimmer15')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -45,7 +47,8 @@ def test_suite_task_properties(domain, task):
 
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
-                                         ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard')])
+                                         ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
+                                         ('fish', 'swim'), ('swimmer', 'swimmer6')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -275,7 +278,8 @@ def test_torch_batched_env_matches_host_env_semantics():
 
 
 @pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1),
-                                       ('finger', 2), ('reacher', 1), ('point_mass', 1)])
+                                       ('finger', 2), ('reacher', 1), ('point_mass', 1), ('fish', 10),
+                                       ('swimmer6', 15)])
 def test_more_domains_rollout_parity(name, nsub):
   """Domains sharing the cheetah feature set: 60 env-steps from randomised starts
   against the oracle (fp64 kernel), incl. hopper's touch sensors, acrobot's RK4 and
@@ -283,7 +287,11 @@ def test_more_domains_rollout_parity(name, nsub):
   from dm_control_amd.batch import BatchedPhysics
   from dm_control_amd.suite import common
   from oracle import oracle
-  m = mc.compile_xml(common.read_model(name + '.xml'))
+  if name.startswith('swimmer'):
+    from dm_control_amd.suite import swimmer
+    m = mc.compile_xml(swimmer._make_model(int(name[7:])))
+  else:
+    m = mc.compile_xml(common.read_model(name + '.xml'))
   NE = 8
   rs = np.random.RandomState(5)
   q = np.tile(m.qpos0, (NE, 1))

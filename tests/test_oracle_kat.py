@@ -463,3 +463,66 @@ def test_fixed_tendon_transmission_steady_state():
     with pytest.raises(mc.MjcfError):
       mc.compile_xml('<mujoco><worldbody><body><joint name="x" type="slide"/><geom size=".1"/>'
                      '<site name="a"/></body></worldbody>%s</mujoco>' % bad)
+
+
+# ---- fluid forces, inertia-box model (suite swimmer / fish: <option density=...>) ------------------------
+def _sinking_box(density=0.0, viscosity=0.0):
+  m = mc.compile_xml("""
+  <mujoco><option density="%r" viscosity="%r" timestep="0.002"><flag contact="disable"/></option><worldbody>
+    <body name='b' pos='0 0 1'><joint type='slide' axis='0 0 1'/><joint name='spin' type='hinge' axis='1 0 0'/>
+      <geom type='box' size='.1 .2 .05' mass='2'/></body>
+  </worldbody></mujoco>""" % (density, viscosity))
+  return m, OraclePhysics(m, legacy_step=False)
+
+
+def test_fluid_quadratic_drag_terminal_velocity():
+  # the equivalent inertia box of a uniform box is the box itself: full sizes (.2, .4, .1);
+  # drag on the z faces: 0.5 rho b0 b1 v^2 = m g
+  m, p = _sinking_box(density=1000.0)
+  for _ in range(3000):
+    p.step()
+  vt = np.sqrt(2 * 2 * G / (1000.0 * 0.2 * 0.4))
+  np.testing.assert_allclose(p.qvel[0], -vt, rtol=1e-6)
+
+
+def test_fluid_viscous_drag_terminal_velocity():
+  # Stokes drag of the sphere whose diameter is the mean box size: 3 pi d mu v = m g
+  m, p = _sinking_box(viscosity=50.0)
+  for _ in range(3000):
+    p.step()
+  d = (0.2 + 0.4 + 0.1) / 3
+  np.testing.assert_allclose(p.qvel[0], -2 * G / (3 * np.pi * d * 50.0), rtol=1e-6)
+
+
+def test_fluid_angular_drag_one_step():
+  # torque about local x: rho b0 (b1^4 + b2^4) |w| w / 64 (+ pi d^3 mu w with viscosity)
+  m, p = _sinking_box(density=1000.0, viscosity=2.0)
+  p.model.opt_int('disableflags', p.model.opt_int('disableflags') | (1 << 7))   # no gravity
+  p.qvel[1] = 3.0
+  p.forward()
+  Ix = p.qM[3]                     # hinge about x through the COM: M[1, 1]
+  d = (0.2 + 0.4 + 0.1) / 3
+  tau = 1000.0 * 0.2 * (0.4**4 + 0.1**4) * 9.0 / 64 + np.pi * d**3 * 2.0 * 3.0
+  np.testing.assert_allclose(p.qfrc_passive[1], -tau, rtol=1e-12)
+  p.step()
+  np.testing.assert_allclose(p.qvel[1], 3.0 - m.opt.timestep * tau / Ix, rtol=1e-9)
+
+
+def test_tendon_spring_and_frame_axis_sensors():
+  m = mc.compile_xml("""
+  <mujoco><option><flag gravity="disable" contact="disable"/></option><worldbody>
+    <body name='a'><joint name='s' type='slide' axis='1 0 0' damping='5'/><joint name='h' type='hinge' axis='0 0 1' damping='1'/>
+      <geom name='g' size='.1' mass='1'/></body>
+  </worldbody>
+  <tendon><fixed name='t' stiffness='40'><joint joint='s' coef='0.5'/></fixed></tendon>
+  <sensor><framexaxis name='x' objtype='xbody' objname='a'/><frameyaxis name='y' objtype='geom' objname='g'/>
+          <framezaxis name='z' objtype='body' objname='a'/></sensor></mujoco>""")
+  p = OraclePhysics(m, legacy_step=False)
+  p.qfrc_applied[0] = 2.0
+  p.qpos[1] = np.pi / 2
+  for _ in range(5000):
+    p.step()
+  # equilibrium: F = k c^2 q
+  np.testing.assert_allclose(p.qpos[0], 2.0 / (40 * 0.25), rtol=1e-6)
+  p.forward()
+  np.testing.assert_allclose(p.sensordata, [0, 1, 0, -1, 0, 0, 0, 0, 1], atol=1e-9)
