@@ -715,13 +715,24 @@ class _Compiler:
     self.tendons = []
     for sec in self.root.findall('tendon'):
       for e in sec:
-        if e.tag != 'fixed':
-          raise MjcfError('unsupported tendon <%s> (only <fixed> tendons are supported)' % e.tag)
+        if e.tag not in ('fixed', 'spatial'):
+          raise MjcfError('unsupported tendon <%s>' % e.tag)
         cname = e.attrib.get('class', 'main')
         if cname not in self.classes:
           raise MjcfError('unknown default class %r' % cname)
         a = dict(self.classes[cname].get('tendon'))
         a.update(e.attrib)
+        if e.tag == 'spatial':
+          # A spatial tendon that exerts no force (no spring, damper, limit, friction; not an
+          # actuator transmission) only draws a line between sites (suite/lqr.py:174-180): skipped.
+          forceless = (a.get('limited', 'false') != 'true' and
+                       all(float(a.get(k, 0)) == 0 for k in ('stiffness', 'damping', 'frictionloss')) and
+                       all(w.tag == 'site' for w in e))
+          used = any(act.get('tendon') == a.get('name') for act in self.actuators)
+          if not forceless or used:
+            raise MjcfError('spatial tendon %r: only force-free spatial tendons (rendering aids) are supported'
+                            % a.get('name'))
+          continue
         if a.get('limited', 'false') == 'true':
           raise MjcfError('tendon %r: limits are not supported' % a.get('name'))
         if float(a.get('frictionloss', 0)) != 0:

@@ -48,7 +48,7 @@ def test_suite_task_properties(domain, task):
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
-                                         ('fish', 'swim'), ('swimmer', 'swimmer6')])
+                                         ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -376,3 +376,24 @@ def test_cylinder_pairs_are_guarded_not_silently_ignored():
   assert (b.get('ncon') == 0).all() and o.ncon == 0
   np.testing.assert_allclose(b.get('qpos')[0], o.qpos, atol=1e-9)
   b.close()
+
+
+def test_lqr_domain_linear_dynamics_and_reward():
+  """suite lqr: generated mass-spring chain; reward = 1 - (0.5 |q|^2 + 0.5 c |u|^2) (lqr.py:252-258);
+  the unforced chain conserves the discrete-time quadratic invariant of semi-implicit Euler closely."""
+  from dm_control_amd import suite
+  env = suite.load('lqr', 'lqr_6_2', task_kwargs=dict(random=3))
+  ts = env.reset()
+  q0 = np.asarray(ts.observation['position'])
+  np.testing.assert_allclose(np.linalg.norm(q0), np.sqrt(2), rtol=1e-12)
+  u = np.array([0.3, -0.2])
+  ts = env.step(u)
+  q = np.asarray(ts.observation['position'])
+  np.testing.assert_allclose(ts.reward, 1 - (0.5 * q @ q + 0.5 * 0.1 * u @ u), rtol=1e-12)
+  o = _oracle(env.physics.model)
+  o.qpos[:] = q0
+  o.forward()
+  o.ctrl[:] = u
+  o.step()
+  np.testing.assert_allclose(q, o.qpos, atol=1e-12)
+  env.physics.free()

@@ -458,7 +458,7 @@ def test_fixed_tendon_transmission_steady_state():
   np.testing.assert_allclose(p.qfrc_actuator, 0.1 * np.array([0.6, -0.8]) * 0.5, rtol=1e-12)
   p.forward()
   np.testing.assert_allclose(p.actuator_length[0], 0.1 * (0.6 * p.qpos[0] - 0.8 * p.qpos[1]), rtol=1e-12)
-  for bad in ('<tendon><spatial name="s"><site site="a"/></spatial></tendon>',
+  for bad in ('<tendon><spatial name="s" stiffness="3"><site site="a"/></spatial></tendon>',
               '<equality><joint joint1="x"/></equality>'):
     with pytest.raises(mc.MjcfError):
       mc.compile_xml('<mujoco><worldbody><body><joint name="x" type="slide"/><geom size=".1"/>'
