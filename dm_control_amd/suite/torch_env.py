@@ -1,81 +1,146 @@
 """Device-resident batched environments.
 
 `control.Environment` over the host mirror costs a PCIe round trip per field per
-step.  `TorchBatchedEnv` keeps everything on the GPU: the SoA arrays of the HIP
+step.  The environments here keep everything on the GPU: the SoA arrays of the HIP
 batch are rebound to torch tensors (zero copy, `dmc_batch_bind`), actions are
 written by the caller's policy directly into the `ctrl` tensor, observations /
-rewards are torch expressions over the `qpos` / `qvel` / `sensordata` tensors,
-and environments whose episode ended are re-initialised on device from a pool of
-pre-settled start states.  torch is plumbing here (memory + elementwise ops); the
-physics is the fused HIP kernel.
+rewards are torch expressions over the bound tensors, and environments whose
+episode ended are re-initialised on device from a pool of valid start states
+(cheetah: settled for 200 steps as suite/cheetah.py:63-76 does; humanoid: the
+collision-free configurations that suite/humanoid.py:160-165 finds by rejection).
+torch is plumbing here (memory + elementwise ops); the physics is the fused HIP
+kernel.
 
-Only the cheetah `run` task is provided in this form (BASELINE config 2).
+    env = torch_env.make('cheetah', 'run', batch_size=4096)
+    obs = env.reset()
+    obs, reward, done = env.step(policy(obs))      # all (B, ...) tensors on the GPU
 """
+import math
+
 import numpy as np
 
 from dm_control_amd import mjcf_compiler
 from dm_control_amd.batch import BatchedPhysics, OUT
 from dm_control_amd.suite import common
 
-_RUN_SPEED = 10.0
+
+def tolerance(torch, x, bounds=(0.0, 0.0), margin=0.0, sigmoid='gaussian', value_at_margin=0.1):
+  """rewards.tolerance (dm_control/utils/rewards.py:93-139) on torch tensors; the sigmoids the
+  device tasks use: gaussian, linear, quadratic."""
+  lower, upper = bounds
+  in_bounds = (x >= lower) & (x <= upper)
+  if margin == 0:
+    return in_bounds.to(x.dtype)
+  d = torch.where(x < lower, lower - x, x - upper) / margin
+  if sigmoid == 'gaussian':
+    s = torch.exp(-0.5 * (d * math.sqrt(-2 * math.log(value_at_margin)))**2)
+  elif sigmoid == 'linear':
+    sx = d * (1 - value_at_margin)
+    s = torch.where(sx.abs() < 1, 1 - sx, torch.zeros_like(sx))
+  elif sigmoid == 'quadratic':
+    sx = d * math.sqrt(1 - value_at_margin)
+    s = torch.where(sx.abs() < 1, 1 - sx**2, torch.zeros_like(sx))
+  else:
+    raise ValueError('sigmoid %r is not available on device' % sigmoid)
+  return torch.where(in_bounds, torch.ones_like(s), s)
 
 
 class TorchBatchedEnv:
-  """Cheetah run, B environments, all tensors (rows, B) on `device`."""
+  """B environments of one suite task; every tensor is (rows, B) on `device`.
 
-  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=1):
+  Subclasses define `_MODEL`, `_OUTPUTS` (extra derived arrays to bind), the start-state
+  pool, `observation()` and `reward()`.  The default (this class) is cheetah `run`."""
+
+  _MODEL = 'cheetah.xml'
+  _OUTPUTS = ()            # e.g. ('xpos', 'xmat'): derived arrays the task reads
+  _CONTROL_TIMESTEP = None  # None: one physics step per env step unless n_sub_steps is given
+  _RUN_SPEED = 10.0
+
+  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=None):
     import torch
     self.torch = torch
     self.device = torch.device('cuda', device_id)
-    self.model = mjcf_compiler.compile_xml(common.read_model('cheetah.xml'))
+    self.model = mjcf_compiler.compile_xml(common.read_model(self._MODEL))
     m = self.model
     self.B = int(batch_size)
+    if n_sub_steps is None:
+      n_sub_steps = 1 if self._CONTROL_TIMESTEP is None else int(round(self._CONTROL_TIMESTEP / m.opt.timestep))
     self.n_sub_steps = n_sub_steps
     self.dtype = torch.float32 if precision == 32 else torch.float64
     self.physics = BatchedPhysics(m, self.B, device_id=device_id, precision=precision)
-    self.physics.set_output_mask(OUT['sensor'])
+    mask = OUT['sensor']
+    for name in self._OUTPUTS:
+      mask |= OUT[{'subtree_com': 'subtree_com'}.get(name, name)]
+    self.physics.set_output_mask(mask)
     mk = lambda rows: torch.zeros((rows, self.B), dtype=self.dtype, device=self.device)
     self.qpos, self.qvel, self.ctrl = mk(m.nq), mk(m.nv), mk(m.nu)
     self.warm, self.sensordata = mk(m.nv), mk(m.nsensordata)
     self.time = torch.zeros((1, self.B), dtype=torch.float64, device=self.device)
-    for name, t in (('qpos', self.qpos), ('qvel', self.qvel), ('ctrl', self.ctrl),
-                    ('qacc_warmstart', self.warm), ('sensordata', self.sensordata), ('time', self.time)):
+    self.ncon = torch.zeros((1, self.B), dtype=torch.int32, device=self.device)
+    bound = [('qpos', self.qpos), ('qvel', self.qvel), ('ctrl', self.ctrl), ('qacc_warmstart', self.warm),
+             ('sensordata', self.sensordata), ('time', self.time), ('ncon', self.ncon)]
+    for name in self._OUTPUTS:
+      rows = self.physics._rows(name)[0]
+      t = mk(rows)
+      setattr(self, name, t)
+      bound.append((name, t))
+    for name, t in bound:
       self.physics.bind(name, t.data_ptr())
     self.step_limit = int(round(time_limit / (m.opt.timestep * n_sub_steps)))
     self.steps = torch.zeros(self.B, dtype=torch.int64, device=self.device)
     self._rs = np.random.RandomState(seed)
+    self._gen = torch.Generator(device=self.device).manual_seed(seed)
     self._make_start_pool()
     self.reset()
 
-  def _make_start_pool(self, pool=None):
+  # -- helpers -----------------------------------------------------------------------
+  def _stream(self):
+    return self.torch.cuda.current_stream().cuda_stream
+
+  def _body(self, name):
+    return self.model.name2id(name, 'body')
+
+  def _upload_qpos(self, q):
+    self.qpos.copy_(self.torch.from_numpy(np.ascontiguousarray(q.T)).to(self.dtype))
+
+  # -- start states ------------------------------------------------------------------
+  def _make_start_pool(self):
     """Cheetah.initialize_episode for a pool of start states (suite/cheetah.py:63-76):
     limited joints ~ U(range), 200 settle steps with zero control, on device."""
-    torch, m = self.torch, self.model
-    pool = pool or self.B
-    assert pool == self.B
+    m = self.model
     lim = m.jnt_limited == 1
     lo, hi = m.jnt_range[lim].T
     q = np.tile(m.qpos0, (self.B, 1))
     q[:, lim] = self._rs.uniform(lo, hi, (self.B, lo.size))
-    self.qpos.copy_(torch.from_numpy(q.T.copy()).to(self.dtype))
+    self._upload_qpos(q)
     self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_()
-    self.physics.step(200, stream=torch.cuda.current_stream().cuda_stream)
+    self.physics.step(200, stream=self._stream())
     self.pool_qpos, self.pool_qvel, self.pool_warm = self.qpos.clone(), self.qvel.clone(), self.warm.clone()
 
   def reset(self, mask=None):
-    """Re-initialises the selected environments (all if mask is None) from the pool."""
+    """Re-initialises the selected environments (all if mask is None) from the pool and
+    refreshes the derived arrays (mj_forward with actuation disabled, as Physics.reset does)."""
     torch = self.torch
     if mask is None:
       mask = torch.ones(self.B, dtype=torch.bool, device=self.device)
-    perm = torch.randperm(self.B, device=self.device)   # start state drawn from the pool
+    P = self.pool_qpos.shape[1]
+    pick = torch.randint(0, P, (self.B,), device=self.device, generator=self._gen)
     m2 = mask[None, :]
-    self.qpos.copy_(torch.where(m2, self.pool_qpos[:, perm], self.qpos))
-    self.qvel.copy_(torch.where(m2, self.pool_qvel[:, perm], self.qvel))
-    self.warm.copy_(torch.where(m2, self.pool_warm[:, perm], self.warm))
+    self.qpos.copy_(torch.where(m2, self.pool_qpos[:, pick], self.qpos))
+    self.qvel.copy_(torch.where(m2, self.pool_qvel[:, pick], self.qvel))
+    self.warm.copy_(torch.where(m2, self.pool_warm[:, pick], self.warm))
     self.time.copy_(torch.where(m2, torch.zeros_like(self.time), self.time))
     self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
+    if self._OUTPUTS:
+      # forward is a pure function of (qpos, qvel): recomputing it for the environments that
+      # were not reset reproduces the derived arrays they already hold; their solver warm start
+      # is put back so that their trajectories do not depend on who else was reset
+      warm = self.warm.clone()
+      self.physics.forward(disable_actuation=True, stream=self._stream())
+      self.warm.copy_(torch.where(m2, self.warm, warm))
     return self.observation()
 
+  # -- task ----------------------------------------------------------------------------
   def observation(self):
     """(B, 17): qpos[1:] and qvel (Cheetah.get_observation)."""
     return self.torch.cat([self.qpos[1:], self.qvel], dim=0).T
@@ -83,14 +148,13 @@ class TorchBatchedEnv:
   def reward(self):
     """rewards.tolerance(speed, bounds=(10, inf), margin=10, value_at_margin=0, 'linear')."""
     speed = self.sensordata[0]
-    return self.torch.clamp(speed / _RUN_SPEED, 0.0, 1.0)
+    return self.torch.clamp(speed / self._RUN_SPEED, 0.0, 1.0)
 
   def step(self, action):
     """action: (B, nu) tensor on device.  Returns (obs, reward, done) tensors; finished
     environments are auto-reset (their returned obs is the fresh start state)."""
-    torch = self.torch
     self.ctrl.copy_(action.T.to(self.dtype))
-    self.physics.step(self.n_sub_steps, stream=torch.cuda.current_stream().cuda_stream)
+    self.physics.step(self.n_sub_steps, stream=self._stream())
     self.steps += 1
     reward = self.reward().clone()
     done = self.steps >= self.step_limit
@@ -101,3 +165,129 @@ class TorchBatchedEnv:
 
   def close(self):
     self.physics.close()
+
+
+class CheetahRun(TorchBatchedEnv):
+  pass
+
+
+class Humanoid(TorchBatchedEnv):
+  """Humanoid stand / walk / run (suite/humanoid.py:132-207) on device."""
+
+  _MODEL = 'humanoid.xml'
+  _OUTPUTS = ('xpos', 'xmat')
+  _CONTROL_TIMESTEP = .025
+  _STAND_HEIGHT = 1.4
+  move_speed = 0.0
+
+  def __init__(self, batch_size, move_speed=0.0, time_limit=25.0, pool_size=None, **kw):
+    self.move_speed = float(move_speed)
+    self._pool_size = pool_size
+    super().__init__(batch_size, time_limit=time_limit, **kw)
+
+  def _make_start_pool(self):
+    """randomize_limited_and_rotational_joints + rejection of configurations in contact
+    (suite/humanoid.py:160-165), evaluated for whole batches with mj_forward until the pool
+    holds `pool_size` (default B) collision-free states."""
+    torch, m = self.torch, self.model
+    want = self._pool_size or self.B
+    keep = []
+    have = 0
+    for _ in range(1000):
+      q = np.tile(m.qpos0, (self.B, 1))
+      for j in range(m.njnt):
+        t, a = m.jnt_type[j], m.jnt_qposadr[j]
+        if m.jnt_limited[j] and t in (2, 3):
+          q[:, a] = self._rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], self.B)
+        elif t == 3:
+          q[:, a] = self._rs.uniform(-np.pi, np.pi, self.B)
+        elif t == 0:
+          quat = self._rs.rand(self.B, 4)
+          q[:, a + 3:a + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+      self._upload_qpos(q)
+      self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_()
+      self.physics.forward(disable_actuation=True, stream=self._stream())
+      ok = (self.ncon[0] == 0)
+      keep.append(self.qpos[:, ok].clone())
+      have += int(ok.sum())
+      if have >= want:
+        break
+    else:
+      raise RuntimeError('could not fill the pool of collision-free start states')
+    self.pool_qpos = torch.cat(keep, dim=1)[:, :want].contiguous()
+    P = self.pool_qpos.shape[1]
+    self.pool_qvel = torch.zeros((m.nv, P), dtype=self.dtype, device=self.device)
+    self.pool_warm = torch.zeros((m.nv, P), dtype=self.dtype, device=self.device)
+
+  # rows of the (3*nbody, B) / (9*nbody, B) arrays
+  def _xpos(self, body):
+    b = self._body(body)
+    return self.xpos[3*b:3*b + 3]
+
+  def _xmat(self, body):
+    b = self._body(body)
+    return self.xmat[9*b:9*b + 9]
+
+  def head_height(self):
+    return self._xpos('head')[2]
+
+  def torso_upright(self):
+    return self._xmat('torso')[8]
+
+  def center_of_mass_velocity(self):
+    adr = self.model.sensor_adr[self.model.name2id('torso_subtreelinvel', 'sensor')]
+    return self.sensordata[adr:adr + 3]
+
+  def extremities(self):
+    """(12, B): hands and feet relative to the torso, in the torso frame."""
+    R = self._xmat('torso').reshape(3, 3, self.B)      # R[i, j] = xmat[3 i + j]
+    torso = self._xpos('torso')
+    out = []
+    for side in ('left_', 'right_'):
+      for limb in ('hand', 'foot'):
+        d = self._xpos(side + limb) - torso
+        out.append((d[:, None, :] * R).sum(dim=0))      # d . frame  (row vector times matrix)
+    return self.torch.cat(out, dim=0)
+
+  def observation(self):
+    """(B, 67): joint_angles 21, head_height 1, extremities 12, torso_vertical 3, com_velocity 3,
+    velocity 27 -- the order of Humanoid.get_observation flattened."""
+    parts = [self.qpos[7:], self.head_height()[None], self.extremities(), self._xmat('torso')[6:9],
+             self.center_of_mass_velocity(), self.qvel]
+    return self.torch.cat(parts, dim=0).T
+
+  def reward(self):
+    torch = self.torch
+    standing = tolerance(torch, self.head_height(), bounds=(self._STAND_HEIGHT, float('inf')),
+                         margin=self._STAND_HEIGHT / 4)
+    upright = tolerance(torch, self.torso_upright(), bounds=(0.9, float('inf')), sigmoid='linear', margin=1.9,
+                        value_at_margin=0)
+    stand_reward = standing * upright
+    small_control = tolerance(torch, self.ctrl, margin=1, value_at_margin=0, sigmoid='quadratic').mean(dim=0)
+    small_control = (4 + small_control) / 5
+    horizontal = self.center_of_mass_velocity()[0:2]
+    if self.move_speed == 0:
+      dont_move = tolerance(torch, horizontal, margin=2).mean(dim=0)
+      return small_control * stand_reward * dont_move
+    speed = torch.linalg.norm(horizontal, dim=0)
+    move = tolerance(torch, speed, bounds=(self.move_speed, float('inf')), margin=self.move_speed,
+                     value_at_margin=0, sigmoid='linear')
+    return small_control * stand_reward * (5 * move + 1) / 6
+
+
+_TASKS = {
+    ('cheetah', 'run'): (CheetahRun, {}),
+    ('humanoid', 'stand'): (Humanoid, dict(move_speed=0)),
+    ('humanoid', 'walk'): (Humanoid, dict(move_speed=1)),
+    ('humanoid', 'run'): (Humanoid, dict(move_speed=10)),
+}
+
+
+def make(domain, task, batch_size, **kwargs):
+  """Device-resident batched version of `suite.load(domain, task)`."""
+  if (domain, task) not in _TASKS:
+    raise ValueError('no device-resident task for (%r, %r); available: %s' % (domain, task, sorted(_TASKS)))
+  cls, kw = _TASKS[(domain, task)]
+  kw = dict(kw)
+  kw.update(kwargs)
+  return cls(batch_size, **kw)
