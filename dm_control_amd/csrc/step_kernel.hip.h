@@ -87,6 +87,7 @@ template <int SID> struct StaticLayout;
 #define DMC_DEF_STATIC(ID)                                                            \
   static __device__ const StepLayout kStaticLayout##ID = DMC_STATIC_LAYOUT_##ID;     \
   template <> struct StaticLayout<ID> {                                               \
+    static constexpr int kNV = DMC_STATIC_NV_##ID;   /* compile-time nv: register-resident Cholesky */ \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_DEF_STATIC(0)
