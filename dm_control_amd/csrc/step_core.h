@@ -381,6 +381,36 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   DMC_WSYNC();
 }
 #endif
+// Substitution for model-specialised kernels: lane i loads its row and its column of L up
+// front (all loads in flight together), then both sweeps run on registers and v_readlane --
+// no LDS access inside the 2 N dependent steps.  Same operations as chol_solve_lds.
+#ifndef DMC_HOST_EMU
+template <typename T, int LPE, int N>
+DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b, int lane) {
+  static_assert(N >= 1 && N <= LPE, "one lane per unknown");
+  const int i = lane;
+  const bool own = i < N;
+  T row[N], col[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[i*N + k] : (T)0; col[k] = (own && k > i) ? Lm[k*N + i] : (T)0; }
+  const T dinv = own ? Lm[i*N + i] : (T)0;      // 1 / L[i][i]
+  T sreg = own ? b[i] : (T)0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
+    if (i == k) sreg = xk;
+    if (i > k && own) sreg -= row[k]*xk;
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
+    if (i == k) sreg = xk;
+    if (i < k) sreg -= col[k]*xk;
+  }
+  if (own) x[i] = sreg;
+  DMC_WSYNC();
+}
+#endif
 // x = (L L')^-1 b (x may alias b); Lm as produced by chol_factor_lds
 //   n <= LPE : lane i carries x[i] in a register; the pivot value travels by a
 //              cross-lane broadcast, no LDS round trip, no fence inside the loops.
@@ -745,6 +775,9 @@ struct StepCore {
                             (const DMC_LDS int*)MI(tri_col));
   }
   DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { chol_solve_rows<T, LPE, LS::kNV>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, lane); return; }
+#endif
     chol_solve_lds<T, LPE>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, n, lane);
   }
 
