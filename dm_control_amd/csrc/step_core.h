@@ -1374,24 +1374,22 @@ struct StepCore {
   }
 
   // ---- sensors (position / velocity stage) -------------------------------------------
-  DMC_DEV void subtree_vel() {
-    FOR_LANES(i, L.d.nbody) {
-      const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
-      T dif[3] = {S(xipos)[3*i] - rc[0], S(xipos)[3*i + 1] - rc[1], S(xipos)[3*i + 2] - rc[2]}, tmp[3];
-      cross3(tmp, dif, S(cvel) + 6*i);
-      for (int k = 0; k < 3; k++) S(subtree_mom)[3*i + k] = MR(body_mass)[i] * (S(cvel)[6*i + 3 + k] - tmp[k]);
-    }
-    DMC_WSYNC();
-    for (int lev = L.d.nlevel - 1; lev >= -1; lev--) {
-      const int a0 = lev >= 0 ? MI(level_adr)[lev] : 0, cnt = lev >= 0 ? MI(level_adr)[lev + 1] - a0 : 1;
-      for (int idx = lane; idx < cnt*3; idx += LPE) {
-        const int b = lev >= 0 ? MI(level_body)[a0 + idx/3] : 0, comp = idx % 3;
-        T v = S(subtree_mom)[3*b + comp];
-        for (int c = MI(child_adr)[b]; c < MI(child_adr)[b + 1]; c++) v += S(subtree_mom)[3*MI(child_list)[c] + comp];
-        S(subtree_mom)[3*b + comp] = v;
-        S(subtree_linvel)[3*b + comp] = v * (1 / t_max((T)DMC_MINVAL, MR(body_subtreemass)[b]));
+  // subtreelinvel sensors (mj_subtreeVel restricted to what is read): linear momentum of
+  // the bodies below `root` about their own COMs, summed by one reduction, over the subtree mass
+  DMC_DEV void subtree_linvel_sensors() {
+    for (int k = 0; k < L.d.nstv; k++) {
+      const int sidx = MI(stv_sensor)[k], root = MI(sensor_objid)[sidx];
+      T mom[3] = {0, 0, 0};
+      FOR_LANES(i, L.d.nbody) {
+        const unsigned m = (unsigned)(root < 32 ? MI(body_anc_lo)[i] : MI(body_anc_hi)[i]);
+        if (!((m >> (root & 31)) & 1u)) continue;
+        const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
+        T dif[3] = {S(xipos)[3*i] - rc[0], S(xipos)[3*i + 1] - rc[1], S(xipos)[3*i + 2] - rc[2]}, tmp[3];
+        cross3(tmp, dif, S(cvel) + 6*i);
+        for (int c = 0; c < 3; c++) mom[c] += MR(body_mass)[i] * (S(cvel)[6*i + 3 + c] - tmp[c]);
       }
-      DMC_WSYNC();
+      const T inv = 1 / t_max((T)DMC_MINVAL, MR(body_subtreemass)[root]);
+      for (int c = 0; c < 3; c++) { const T v = group_sum<LPE>(mom[c]) * inv; if (lane == 0) S(sensordata)[MI(sensor_adr)[sidx] + c] = v; }
     }
   }
   DMC_DEV void object_velocity(int body, const T* pos, const T* mat, T* res) {
@@ -1593,9 +1591,7 @@ struct StepCore {
   }
   DMC_DEV void sensors(int stage) {
     if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
-    int need = 0;
-    for (int i = 0; i < L.d.nsensor; i++) if (MI(sensor_stage)[i] == stage && MI(sensor_type)[i] == DMC_SENS_SUBTREELINVEL) need = 1;
-    if (need) subtree_vel();
+    if (L.d.nstv && stage == DMC_STAGE_VEL) subtree_linvel_sensors();
     FOR_LANES(i, L.d.nsensor) {
       if (MI(sensor_stage)[i] != stage) continue;
       T* out = S(sensordata) + MI(sensor_adr)[i];
@@ -1624,7 +1620,7 @@ struct StepCore {
           for (int k = 0; k < 3; k++) out[k] = p[k];
         }
       }
-      else if (t == DMC_SENS_SUBTREELINVEL) for (int k = 0; k < 3; k++) out[k] = S(subtree_linvel)[3*id + k];
+      else if (t == DMC_SENS_SUBTREELINVEL) {}   // written by subtree_linvel_sensors()
       else if (t == DMC_SENS_VELOCIMETER || t == DMC_SENS_GYRO) {
         const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
         mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);

@@ -26,6 +26,7 @@ struct StepDims {
   int ncyl;      // candidate pairs involving a cylinder (guard test only, never a contact)
   int ntendon, nwrap;  // fixed tendons (actuator transmissions, springs / dampers)
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
+  int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -33,6 +34,8 @@ struct StepDims {
   X(body_parentid, d.nbody) X(body_rootid, d.nbody) X(body_jntadr, d.nbody)    \
   X(body_jntnum, d.nbody) X(body_dofadr, d.nbody) X(body_dofnum, d.nbody)      \
   X(body_lastdof, d.nbody)     /* last dof on the path root->body, or -1 */    \
+  X(body_anc_lo, d.nstv ? d.nbody : 0) X(body_anc_hi, d.nstv ? d.nbody : 0) /* ancestor-or-self bodies */ \
+  X(stv_sensor, d.nstv)        /* the subtreelinvel sensors */                 \
   X(level_adr, d.nlevel + 1) X(level_body, d.nchild)                           \
   X(child_adr, d.nbody + 1) X(child_list, d.nchild)   /* children, descending */ \
   X(jnt_type, d.njnt) X(jnt_qposadr, d.njnt) X(jnt_dofadr, d.njnt)             \
@@ -88,7 +91,7 @@ struct StepDims {
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
-  X(subtree_linvel, 3 * d.nbody) X(sensordata, d.nsensordata)                  \
+  X(sensordata, d.nsensordata)                                                 \
   X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, 9 * d.nconmax) \
   X(efc_J, d.njmax * d.nv)                                                     \
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
@@ -103,8 +106,7 @@ struct StepDims {
   X(ximat, 9 * d.nbody) X(xanchor, 3 * d.njnt) X(xaxis, 3 * d.njnt)            \
   X(crb, 10 * d.nbody) X(mbuf, 6 * d.nv) X(subtree_usum, 3 * d.nbody)
 #define STEP_SCRATCH_OVL_VEL(X)                                                \
-  X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody) X(cfrc_ext, 6 * d.nbody)           \
-  X(subtree_mom, 3 * d.nbody)
+  X(cacc, 6 * d.nbody) X(cfrc, 6 * d.nbody) X(cfrc_ext, 6 * d.nbody)
 #define STEP_SCRATCH_OVL_SOL(X)                                                \
   X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
   X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)                    \

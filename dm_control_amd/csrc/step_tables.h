@@ -87,6 +87,10 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   d.nfric = (int)fric_dof.size();
   d.ntendon = m.ntendon; d.nwrap = m.nwrap;
+  std::vector<int> stv;
+  for (int i = 0; i < m.nsensor; i++) if (m.sensor_type[i] == DMC_SENS_SUBTREELINVEL) stv.push_back(i);
+  d.nstv = (int)stv.size();
+  if (d.nstv && m.nbody > 64) { *err = "subtreelinvel sensors need nbody <= 64"; return false; }
   d.fluid = (m.opt_density > 0 || m.opt_viscosity > 0) ? 1 : 0;
   for (int w = 0; w < m.nwrap; w++) { const int j = m.wrap_objid[w]; if (j < 0 || j >= m.njnt || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "fixed tendons may only wrap hinge/slide joints"; return false; } }
   for (int j = 0; j < m.njnt; j++) {
@@ -244,6 +248,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int k = 0; k < 5; k++) mr[L.mr_pair_solimp + 5*p + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
   }
   cpi(L.mi_fric_dof, fric_dof);
+  cpi(L.mi_stv_sensor, stv);
+  if (d.nstv) for (int b = 0; b < m.nbody; b++) {
+    uint64_t mask = 0;
+    for (int a = b; ; a = m.body_parentid[a]) { mask |= 1ull << a; if (a == 0) break; }
+    mi[L.mi_body_anc_lo + b] = (int)(uint32_t)(mask & 0xffffffffu); mi[L.mi_body_anc_hi + b] = (int)(uint32_t)(mask >> 32);
+  }
   cpi(L.mi_tendon_adr, m.tendon_adr); cpi(L.mi_tendon_num, m.tendon_num); cpr(L.mr_wrap_prm, m.wrap_prm);
   cpr(L.mr_tendon_stiffness, m.tendon_stiffness); cpr(L.mr_tendon_damping, m.tendon_damping); cpr(L.mr_tendon_lengthspring, m.tendon_lengthspring);
   for (int w = 0; w < m.nwrap; w++) { mi[L.mi_wrap_dof + w] = m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = m.jnt_qposadr[m.wrap_objid[w]]; }
