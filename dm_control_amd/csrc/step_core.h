@@ -1026,6 +1026,50 @@ struct StepCore {
   }
   // models with elliptic cones or dof friction loss take the general (per-row-type) solver paths
   DMC_DEV bool general_rows() const { return L.d.elliptic || L.d.nfric; }
+  // ---- tendons (mj_tendon for fixed and site-to-site spatial tendons) -----------------------
+  DMC_DEV void site_world_pos(int sid, T* p) {
+    const int b = MI(site_bodyid)[sid]; T v[3];
+    mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*sid);
+    for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
+  }
+  DMC_DEV T tendon_length(int t) {
+    const int w0 = MI(tendon_adr)[t], wn = MI(tendon_num)[t];
+    T len = 0;
+    if (MI(wrap_site)[w0] < 0) { for (int w = w0; w < w0 + wn; w++) len += MR(wrap_prm)[w] * S(qpos)[MI(wrap_qpos)[w]]; return len; }
+    for (int w = w0; w + 1 < w0 + wn; w++) {
+      T p0[3], p1[3];
+      site_world_pos(MI(wrap_site)[w], p0); site_world_pos(MI(wrap_site)[w + 1], p1);
+      const T dif[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+      len += t_sqrt(dot3(dif, dif));
+    }
+    return len;
+  }
+  // translational Jacobian column of a world point rigidly attached to `body`
+  DMC_DEV void point_jac(int body, const T* p, int dd, T* jp) {
+    jp[0] = jp[1] = jp[2] = 0;
+    if (!dof_in_chain(MI(body_lastdof)[body], dd)) return;
+    const T* cd = S(cdof) + 6*dd; const T* rc = S(subtree_com) + 3*MI(body_rootid)[body];
+    T off[3] = {p[0] - rc[0], p[1] - rc[1], p[2] - rc[2]}, tmp[3];
+    cross3(tmp, cd, off);
+    for (int k = 0; k < 3; k++) jp[k] = cd[3 + k] + tmp[k];
+  }
+  DMC_DEV T tendon_jac(int t, int dd) {
+    const int w0 = MI(tendon_adr)[t], wn = MI(tendon_num)[t];
+    T j = 0;
+    if (MI(wrap_site)[w0] < 0) { for (int w = w0; w < w0 + wn; w++) if (MI(wrap_dof)[w] == dd) j += MR(wrap_prm)[w]; return j; }
+    for (int w = w0; w + 1 < w0 + wn; w++) {
+      const int s0 = MI(wrap_site)[w], s1 = MI(wrap_site)[w + 1];
+      T p0[3], p1[3], j0[3], j1[3];
+      site_world_pos(s0, p0); site_world_pos(s1, p1);
+      T dif[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+      const T n = t_sqrt(dot3(dif, dif));
+      if (n < (T)DMC_MINVAL) continue;
+      for (int k = 0; k < 3; k++) dif[k] /= n;
+      point_jac(MI(site_bodyid)[s0], p0, dd, j0); point_jac(MI(site_bodyid)[s1], p1, dd, j1);
+      j += dif[0]*(j1[0] - j0[0]) + dif[1]*(j1[1] - j0[1]) + dif[2]*(j1[2] - j0[2]);
+    }
+    return j;
+  }
   DMC_DEV int contact_rows(int dim) const { return dim == 1 ? 1 : (L.d.elliptic ? dim : 2*(dim - 1)); }
   DMC_DEV void make_constraint() {
     const int nv = L.d.nv, njmax = L.d.njmax;
@@ -1070,6 +1114,20 @@ struct StepCore {
       nefc += total;
     }
     if (nefc > njmax) nefc = njmax;
+    // tendon length limits (after the joint limits, as in MuJoCo); every lane evaluates the few
+    // limited tendons' lengths itself, so the row count stays group-uniform without a fence
+    if (L.d.nlimten && enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int kt = 0; kt < L.d.nlimten; kt++) {
+      const int t = MI(limten)[kt];
+      const T value = tendon_length(t), margin = MR(tendon_margin)[t];
+      for (int sd = -1; sd <= 1; sd += 2) {
+        const T dist = sd * (MR(tendon_range)[2*t + (sd + 1)/2] - value);
+        if (!(dist < margin)) continue;
+        if (nefc >= njmax) { overflow = 1; continue; }
+        const int r = nefc++;
+        FOR_LANES(dd, nv) S(efc_J)[r*nv + dd] = -(T)sd * tendon_jac(t, dd);
+        if (lane == 0) { S(efc_aref)[r] = dist; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_TENDON_LIMIT, t); }
+      }
+    }
     const int nefc_lim = nefc;
     // contact rows: headers
     const int ncon = (enabled && !(o.disableflags & DMC_DSBL_CONTACT)) ? SI(imisc)[IM_NCON] : 0;
@@ -1168,6 +1226,9 @@ struct StepCore {
       } else if (type == EFC_LIMIT) {
         solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
         dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
+      } else if (type == EFC_TENDON_LIMIT) {
+        solref = MR(tendon_solref_lim) + 2*id; solimp = MR(tendon_solimp_lim) + 5*id;
+        dA = MR(tendon_invweight0)[id];
       } else {
         const int cp = SI(con_pair)[id];
         const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];

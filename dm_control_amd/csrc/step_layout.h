@@ -27,6 +27,7 @@ struct StepDims {
   int ntendon, nwrap;  // fixed tendons (actuator transmissions, springs / dampers)
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
+  int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -52,7 +53,9 @@ struct StepDims {
   X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
   X(sensor_stage, d.nsensor) X(sensor_objtype, d.nsensor)                      \
   X(fric_dof, d.nfric)                                                         \
-  X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap)
+  X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap) \
+  X(wrap_site, d.nwrap)        /* site id of a spatial-tendon wrap, -1 for joint wraps */ \
+  X(limten, d.nlimten)         /* the limited tendons */
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -74,7 +77,10 @@ struct StepDims {
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
   X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)       \
-  X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon)
+  X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon) \
+  X(tendon_range, d.nlimten ? 2 * d.ntendon : 0) X(tendon_margin, d.nlimten ? d.ntendon : 0) \
+  X(tendon_solref_lim, d.nlimten ? 2 * d.ntendon : 0) X(tendon_solimp_lim, d.nlimten ? 5 * d.ntendon : 0) \
+  X(tendon_invweight0, d.nlimten ? d.ntendon : 0)
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -130,7 +136,7 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
        ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */ };
-enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4 };
+enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))
 #define EFC_TYPE(tid) ((tid) & 7)

@@ -92,7 +92,18 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   d.nstv = (int)stv.size();
   if (d.nstv && m.nbody > 64) { *err = "subtreelinvel sensors need nbody <= 64"; return false; }
   d.fluid = (m.opt_density > 0 || m.opt_viscosity > 0) ? 1 : 0;
-  for (int w = 0; w < m.nwrap; w++) { const int j = m.wrap_objid[w]; if (j < 0 || j >= m.njnt || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "fixed tendons may only wrap hinge/slide joints"; return false; } }
+  for (int w = 0; w < m.nwrap; w++) {
+    const int j = m.wrap_objid[w];
+    if (m.wrap_type[w] == DMC_WRAP_SITE) { if (j < 0 || j >= m.nsite) { *err = "spatial tendon refers to a missing site"; return false; } continue; }
+    if (m.wrap_type[w] != DMC_WRAP_JOINT || j < 0 || j >= m.njnt || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "fixed tendons may only wrap hinge/slide joints"; return false; }
+  }
+  std::vector<int> limten;
+  for (int t = 0; t < m.ntendon; t++) {
+    const bool spatial = m.tendon_num[t] > 0 && m.wrap_type[m.tendon_adr[t]] == DMC_WRAP_SITE;
+    if (spatial && (m.tendon_stiffness[t] != 0 || m.tendon_damping[t] != 0)) { *err = "spatial tendon springs / dampers are not implemented"; return false; }
+    if (m.tendon_limited[t]) limten.push_back(t);
+  }
+  d.nlimten = (int)limten.size();
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
@@ -139,13 +150,13 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (cyl) nc = 0;
     maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
-  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nfric;
+  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
   if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
-  if (njmax <= 0) njmax = d.nfric + nlim + nconmax * maxrow_per_contact;
-  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nfric)));
+  if (njmax <= 0) njmax = d.nfric + nlim + d.nlimten + nconmax * maxrow_per_contact;
+  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric)));
   d.nconmax = nconmax; d.njmax = njmax;
   d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
   step_layout_build(&t->L, d);
@@ -256,7 +267,16 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   cpi(L.mi_tendon_adr, m.tendon_adr); cpi(L.mi_tendon_num, m.tendon_num); cpr(L.mr_wrap_prm, m.wrap_prm);
   cpr(L.mr_tendon_stiffness, m.tendon_stiffness); cpr(L.mr_tendon_damping, m.tendon_damping); cpr(L.mr_tendon_lengthspring, m.tendon_lengthspring);
-  for (int w = 0; w < m.nwrap; w++) { mi[L.mi_wrap_dof + w] = m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = m.jnt_qposadr[m.wrap_objid[w]]; }
+  for (int w = 0; w < m.nwrap; w++) {
+    const bool site = m.wrap_type[w] == DMC_WRAP_SITE;
+    mi[L.mi_wrap_dof + w] = site ? 0 : m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = site ? 0 : m.jnt_qposadr[m.wrap_objid[w]];
+    mi[L.mi_wrap_site + w] = site ? m.wrap_objid[w] : -1;
+  }
+  cpi(L.mi_limten, limten);
+  if (d.nlimten) {
+    cpr(L.mr_tendon_range, m.tendon_range); cpr(L.mr_tendon_margin, m.tendon_margin); cpr(L.mr_tendon_solref_lim, m.tendon_solref_lim);
+    cpr(L.mr_tendon_solimp_lim, m.tendon_solimp_lim); cpr(L.mr_tendon_invweight0, m.tendon_invweight0);
+  }
   if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);
   // sensors the kernel can compute

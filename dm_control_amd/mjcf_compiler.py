@@ -722,19 +722,23 @@ class _Compiler:
           raise MjcfError('unknown default class %r' % cname)
         a = dict(self.classes[cname].get('tendon'))
         a.update(e.attrib)
+        limited = a.get('limited', 'false') == 'true'
+        if a.get('limited') == 'auto' or (self.autolimits and 'limited' not in a and 'range' in a):
+          limited = 'range' in a
         if e.tag == 'spatial':
-          # A spatial tendon that exerts no force (no spring, damper, limit, friction; not an
-          # actuator transmission) only draws a line between sites (suite/lqr.py:174-180): skipped.
-          forceless = (a.get('limited', 'false') != 'true' and
-                       all(float(a.get(k, 0)) == 0 for k in ('stiffness', 'damping', 'frictionloss')) and
-                       all(w.tag == 'site' for w in e))
-          used = any(act.get('tendon') == a.get('name') for act in self.actuators)
-          if not forceless or used:
-            raise MjcfError('spatial tendon %r: only force-free spatial tendons (rendering aids) are supported'
-                            % a.get('name'))
+          # Spatial tendons: straight segments through sites.  A force-free one only draws a line
+          # (suite/lqr.py:174-180) and is skipped; a length limit (suite/ball_in_cup.xml) is supported.
+          if not all(w.tag == 'site' for w in e) or len(e) < 2:
+            raise MjcfError('spatial tendon %r: only site-to-site paths are supported' % a.get('name'))
+          if any(float(a.get(k, 0)) != 0 for k in ('stiffness', 'damping', 'frictionloss')):
+            raise MjcfError('spatial tendon %r: springs / dampers / friction are not supported' % a.get('name'))
+          if any(act.get('tendon') == a.get('name') for act in self.actuators):
+            raise MjcfError('spatial tendon %r: actuator transmissions are not supported' % a.get('name'))
+          if not limited:
+            continue
+          self.tendons.append(dict(name=a.get('name'), spatial=True, wraps=[(w.attrib['site'], 1.0) for w in e],
+                                   stiffness=0.0, damping=0.0, limited=True, attrs=a))
           continue
-        if a.get('limited', 'false') == 'true':
-          raise MjcfError('tendon %r: limits are not supported' % a.get('name'))
         if float(a.get('frictionloss', 0)) != 0:
           raise MjcfError('tendon %r: frictionloss is not supported' % a.get('name'))
         if 'springlength' in a:
@@ -746,8 +750,8 @@ class _Compiler:
           wraps.append((w.attrib['joint'], float(w.attrib['coef'])))
         if not wraps:
           raise MjcfError('tendon %r is empty' % a.get('name'))
-        self.tendons.append(dict(name=a.get('name'), wraps=wraps, stiffness=float(a.get('stiffness', 0)),
-                                 damping=float(a.get('damping', 0))))
+        self.tendons.append(dict(name=a.get('name'), spatial=False, wraps=wraps, stiffness=float(a.get('stiffness', 0)),
+                                 damping=float(a.get('damping', 0)), limited=limited, attrs=a))
     for sec in self.root.findall('equality'):
       if len(sec):
         raise MjcfError('equality constraints are not supported')
@@ -1032,11 +1036,20 @@ class _Compiler:
     m.ntendon = len(self.tendons)
     m.tendon_adr = np.zeros(m.ntendon, dtype=np.int64)
     m.tendon_num = np.zeros(m.ntendon, dtype=np.int64)
-    objid, prm = [], []
+    objid, prm, wtype = [], [], []
     for t, td in enumerate(self.tendons):
       m.tendon_adr[t] = len(objid)
       m.tendon_num[t] = len(td['wraps'])
+      if td['spatial']:
+        for sname, _ in td['wraps']:
+          if sname not in m.names['site']:
+            raise MjcfError('tendon %r refers to unknown site %r' % (td['name'], sname))
+          objid.append(m.names['site'].index(sname))
+          prm.append(0.0)
+          wtype.append(C['DMC_WRAP_SITE'])
+        continue
       for jname, coef in td['wraps']:
+        wtype.append(C['DMC_WRAP_JOINT'])
         if jname not in m.names['joint']:
           raise MjcfError('tendon %r refers to unknown joint %r' % (td['name'], jname))
         jid = m.names['joint'].index(jname)
@@ -1047,10 +1060,28 @@ class _Compiler:
     m.nwrap = len(objid)
     m.wrap_objid = np.asarray(objid, dtype=np.int64)
     m.wrap_prm = np.asarray(prm, dtype=np.float64)
+    m.wrap_type = np.asarray(wtype, dtype=np.int64)
+    nt = m.ntendon
+    m.tendon_limited = np.array([int(td['limited']) for td in self.tendons], dtype=np.int64)
+    m.tendon_range = np.zeros((nt, 2))
+    m.tendon_margin = np.zeros(nt)
+    m.tendon_solref_lim = np.zeros((nt, 2))
+    m.tendon_solimp_lim = np.zeros((nt, 5))
+    m.tendon_invweight0 = np.zeros(nt)     # filled by _set_const
+    for t, td in enumerate(self.tendons):
+      a = td['attrs']
+      if 'range' in a:
+        m.tendon_range[t] = _vec(a['range'], 2)
+      if td['limited'] and m.tendon_range[t, 0] >= m.tendon_range[t, 1]:
+        raise MjcfError('tendon %r: range[0] must be < range[1]' % td['name'])
+      m.tendon_margin[t] = float(a.get('margin', 0))
+      m.tendon_solref_lim[t] = _vec(a.get('solreflimit', '0.02 1'), 2)
+      m.tendon_solimp_lim[t] = _solimp(a.get('solimplimit', '0.9 0.95 0.001 0.5 2'))
     m.tendon_stiffness = np.array([td['stiffness'] for td in self.tendons], dtype=np.float64)
     m.tendon_damping = np.array([td['damping'] for td in self.tendons], dtype=np.float64)
     # spring rest length: the tendon's length at qpos0 (springlength = -1 default)
-    m.tendon_lengthspring = np.array([sum(c * m.qpos0[m.jnt_qposadr[m.names['joint'].index(j)]] for j, c in td['wraps'])
+    m.tendon_lengthspring = np.array([0.0 if td['spatial'] else
+                                      sum(c * m.qpos0[m.jnt_qposadr[m.names['joint'].index(j)]] for j, c in td['wraps'])
                                       for td in self.tendons], dtype=np.float64)
     m.names['tendon'] = [td['name'] for td in self.tendons]
     names = []
@@ -1279,6 +1310,36 @@ class _Compiler:
       m.body_invweight0[b, 0] = max(MINVAL, np.trace(ap) / 3)
       m.body_invweight0[b, 1] = max(MINVAL, np.trace(ar) / 3)
     m.stat_meaninertia = float(np.mean(np.diag(mass_matrix)))
+    # tendon_invweight0 = J M^-1 J' of the tendon length Jacobian at qpos0
+    for t in range(getattr(m, 'ntendon', 0)):
+      J = np.zeros(nv)
+      w0, wn = m.tendon_adr[t], m.tendon_num[t]
+      if wn and m.wrap_type[w0] == C['DMC_WRAP_JOINT']:
+        for w in range(w0, w0 + wn):
+          J[m.jnt_dofadr[m.wrap_objid[w]]] += m.wrap_prm[w]
+      else:
+        def point_jac(sid):
+          b = m.site_bodyid[sid]
+          p = xpos[b] + quat_to_mat(xquat[b]) @ m.site_pos[sid]
+          jp = np.zeros((3, nv))
+          d = -1
+          bb = b
+          while bb > 0 and d < 0:
+            if m.body_dofnum[bb]:
+              d = m.body_dofadr[bb] + m.body_dofnum[bb] - 1
+            bb = m.body_parentid[bb]
+          while d >= 0:
+            jp[:, d] = np.cross(dof_axis[d], p - dof_anchor[d]) if dof_rot[d] else dof_axis[d]
+            d = m.dof_parentid[d]
+          return p, jp
+        for w in range(w0, w0 + wn - 1):
+          p0, j0 = point_jac(m.wrap_objid[w])
+          p1, j1 = point_jac(m.wrap_objid[w + 1])
+          dvec = p1 - p0
+          n = np.linalg.norm(dvec)
+          if n > MINVAL:
+            J += (dvec / n) @ (j1 - j0)
+      m.tendon_invweight0[t] = max(MINVAL, float(J @ minv @ J))
 
 
 def _solimp(s):

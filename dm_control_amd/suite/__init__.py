@@ -3,13 +3,14 @@
 Mirrors dm_control/suite/__init__.py:93-150 (`load`, `build_environment`,
 ALL_TASKS / BENCHMARKING) for the domains whose models the BASELINE configs
 name (cartpole, cheetah, humanoid) plus the domains that share their feature set
-(acrobot, finger, fish, hopper, lqr, pendulum, point_mass, reacher, swimmer, walker).  Extra keyword: `physics_kwargs`
+(acrobot, ball_in_cup, finger, fish, hopper, lqr, pendulum, point_mass, reacher, swimmer, walker).  Extra keyword: `physics_kwargs`
 (batch_size, precision, device_id, ...) to run a whole batch behind the same
 `Environment` API.
 """
 import collections
 
 from dm_control_amd.suite import acrobot
+from dm_control_amd.suite import ball_in_cup
 from dm_control_amd.suite import cartpole
 from dm_control_amd.suite import cheetah
 from dm_control_amd.suite import finger
@@ -23,7 +24,7 @@ from dm_control_amd.suite import reacher
 from dm_control_amd.suite import swimmer
 from dm_control_amd.suite import walker
 
-_DOMAINS = collections.OrderedDict(acrobot=acrobot, cartpole=cartpole, cheetah=cheetah, finger=finger, fish=fish,
+_DOMAINS = collections.OrderedDict(acrobot=acrobot, ball_in_cup=ball_in_cup, cartpole=cartpole, cheetah=cheetah, finger=finger, fish=fish,
                                    hopper=hopper,
                                    humanoid=humanoid, lqr=lqr, pendulum=pendulum, point_mass=point_mass, reacher=reacher,
                                    swimmer=swimmer, walker=walker)

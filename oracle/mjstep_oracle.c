@@ -60,7 +60,7 @@ typedef struct {
   int nconmax, njmax;
 } Model;
 
-enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3, CT_FRICTION_DOF = 4 };
+enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3, CT_FRICTION_DOF = 4, CT_LIMIT_TENDON = 5 };
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
@@ -79,6 +79,7 @@ typedef struct {
   /* velocity-dependent */
   double *cvel, *cdof_dot, *qfrc_bias, *qfrc_passive, *subtree_linvel;
   double *actuator_length, *actuator_velocity;
+  double *ten_length, *ten_J; /* tendon lengths and their Jacobians (ntendon x nv) */
   /* acceleration */
   double *actuator_force, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc;
   double *qfrc_constraint, *cacc, *cfrc_int, *cfrc_ext;
@@ -290,7 +291,7 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
     g_err = "model blob size mismatch"; free(m->ibuf); free(m->rbuf); free(m); return NULL;
   }
   m->nconmax = 4 * npair + 4;
-  m->njmax = m->nv + 2 * njnt + 10 * m->nconmax;
+  m->njmax = m->nv + 2 * njnt + 2 * m->ntendon + 10 * m->nconmax;
   return m;
 }
 void ora_model_free(Model* m) { if (m) { free(m->ibuf); free(m->rbuf); free(m); } }
@@ -337,6 +338,7 @@ double* ora_model_real_field(Model* m, const char* name, int* count) {
   X(qM, m->nv*m->nv) X(qL, m->nv*m->nv) \
   X(cvel, 6*m->nbody) X(cdof_dot, 6*m->nv) X(qfrc_bias, m->nv) X(qfrc_passive, m->nv) \
   X(subtree_linvel, 3*m->nbody) X(actuator_length, m->nu) X(actuator_velocity, m->nu) \
+  X(ten_length, m->ntendon) X(ten_J, m->ntendon*m->nv) \
   X(actuator_force, m->nu) X(qfrc_actuator, m->nv) X(qfrc_smooth, m->nv) X(qacc_smooth, m->nv) \
   X(qacc, m->nv) X(qfrc_constraint, m->nv) X(cacc, 6*m->nbody) X(cfrc_int, 6*m->nbody) \
   X(cfrc_ext, 6*m->nbody) X(sensordata, m->nsensordata) \
@@ -778,6 +780,42 @@ static void get_impedance(const double* solimp_in, double pos, double margin, do
   *imp = s[0] + y*(s[1] - s[0]);
 }
 
+/* mj_tendon for the supported kinds: fixed (sum coef*q) and spatial site-to-site paths
+ * (sum of segment lengths; J = unit segment direction times the difference of the point Jacobians) */
+static void tendon_kinematics(const Model* m, Data* d) {
+  int nv = m->nv;
+  for (int t = 0; t < m->ntendon; t++) {
+    double* J = d->ten_J + (size_t)t*nv;
+    memset(J, 0, sizeof(double) * (size_t)nv);
+    int w0 = m->tendon_adr[t], wn = m->tendon_num[t];
+    double len = 0;
+    if (wn && m->wrap_type[w0] == DMC_WRAP_JOINT) {
+      for (int w = w0; w < w0 + wn; w++) {
+        int j = m->wrap_objid[w];
+        len += m->wrap_prm[w] * d->qpos[m->jnt_qposadr[j]];
+        J[m->jnt_dofadr[j]] += m->wrap_prm[w];
+      }
+    } else {
+      for (int w = w0; w + 1 < w0 + wn; w++) {
+        int s0 = m->wrap_objid[w], s1 = m->wrap_objid[w + 1];
+        const double *p0 = d->site_xpos + 3*s0, *p1 = d->site_xpos + 3*s1;
+        double dif[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+        double n = sqrt(dot3(dif, dif));
+        len += n;
+        if (n < MINVAL) continue;
+        for (int a = 0; a < 3; a++) dif[a] /= n;
+        for (int k = 0; k < nv; k++) {
+          double jp0[3], jp1[3], jr[3];
+          jac_col(m, d, m->site_bodyid[s0], p0, k, jp0, jr);
+          jac_col(m, d, m->site_bodyid[s1], p1, k, jp1, jr);
+          J[k] += dif[0]*(jp1[0] - jp0[0]) + dif[1]*(jp1[1] - jp0[1]) + dif[2]*(jp1[2] - jp0[2]);
+        }
+      }
+    }
+    d->ten_length[t] = len;
+  }
+}
+
 static void make_constraint(const Model* m, Data* d) {
   int nv = m->nv;
   d->nefc = 0;
@@ -806,6 +844,20 @@ static void make_constraint(const Model* m, Data* d) {
         memset(d->efc_J + (size_t)r*nv, 0, sizeof(double) * (size_t)nv);
         d->efc_J[(size_t)r*nv + m->jnt_dofadr[j]] = -(double)side;
         d->efc_pos[r] = dist; d->efc_margin[r] = margin; d->efc_type[r] = CT_LIMIT; d->efc_id[r] = j;
+      }
+    }
+  }
+  /* tendon limits (after the joint limits, as in MuJoCo) */
+  if (!(m->opt_disableflags & DMC_DSBL_LIMIT)) for (int t = 0; t < m->ntendon; t++) {
+    if (!m->tendon_limited[t]) continue;
+    double value = d->ten_length[t], margin = m->tendon_margin[t];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->tendon_range[2*t + (side + 1)/2] - value);
+      if (dist < margin) {
+        if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+        int r = d->nefc++;
+        for (int k = 0; k < nv; k++) d->efc_J[(size_t)r*nv + k] = -(double)side * d->ten_J[(size_t)t*nv + k];
+        d->efc_pos[r] = dist; d->efc_margin[r] = margin; d->efc_type[r] = CT_LIMIT_TENDON; d->efc_id[r] = t;
       }
     }
   }
@@ -863,6 +915,10 @@ static void make_constraint(const Model* m, Data* d) {
       int j = d->efc_id[i];
       solref = m->jnt_solref + 2*j; solimp = m->jnt_solimp + 5*j;
       dA = m->dof_invweight0[m->jnt_dofadr[j]];
+    } else if (d->efc_type[i] == CT_LIMIT_TENDON) {
+      int t = d->efc_id[i];
+      solref = m->tendon_solref_lim + 2*t; solimp = m->tendon_solimp_lim + 5*t;
+      dA = m->tendon_invweight0[t];
     } else {
       const Contact* c = d->contact + d->efc_id[i];
       int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
@@ -1577,7 +1633,7 @@ void ora_contact_force(const Model* m, const Data* d, int id, double* f6) { cont
 /* pipeline                                                                   */
 /* ------------------------------------------------------------------------- */
 static void fwd_position(const Model* m, Data* d) {
-  kinematics(m, d); com_pos(m, d); crb(m, d); collision(m, d); make_constraint(m, d); transmission(m, d);
+  kinematics(m, d); com_pos(m, d); tendon_kinematics(m, d); crb(m, d); collision(m, d); make_constraint(m, d); transmission(m, d);
 }
 static void fwd_velocity(const Model* m, Data* d) {
   for (int i = 0; i < m->nu; i++) {

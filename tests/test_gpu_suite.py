@@ -22,7 +22,7 @@ def _oracle(model):
                                          ('finger', 'spin'), ('finger', 'turn_easy'), ('finger', 'turn_hard'),
                                          ('reacher', 'easy'), ('reacher', 'hard'),
                                          ('point_mass', 'easy'), ('point_mass', 'hard'),
-                                         ('fish', 'upright'), ('fish', 'swim'), ('swimmer', 'swimmer6'),
+                                         ('ball_in_cup', 'catch'), ('fish', 'upright'), ('fish', 'swim'), ('swimmer', 'swimmer6'),
                                          ('swimmer', 'swimmer15')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
@@ -48,7 +48,8 @@ def test_suite_task_properties(domain, task):
 @pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('cartpole', 'swingup'), ('humanoid', 'walk'),
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
-                                         ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2')])
+                                         ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2'),
+                                         ('ball_in_cup', 'catch')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -278,7 +279,7 @@ def test_torch_batched_env_matches_host_env_semantics():
 
 
 @pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1),
-                                       ('finger', 2), ('reacher', 1), ('point_mass', 1), ('fish', 10),
+                                       ('finger', 2), ('reacher', 1), ('point_mass', 1), ('fish', 10), ('ball_in_cup', 10),
                                        ('swimmer6', 15)])
 def test_more_domains_rollout_parity(name, nsub):
   """Domains sharing the cheetah feature set: 60 env-steps from randomised starts

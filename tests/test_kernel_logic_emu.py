@@ -155,11 +155,11 @@ def test_finger_domain_matches_oracle():
   assert not e.warning.any() and not o.warning.any()
 
 
-@pytest.mark.parametrize('name', ['fish', 'swimmer6', 'point_mass'])
+@pytest.mark.parametrize('name', ['fish', 'swimmer6', 'point_mass', 'ball_in_cup'])
 def test_fluid_and_tendon_domains_match_oracle(name):
   # fish: free body in a fluid (inertia-box drag), tendon spring, position actuator on a fixed
   # tendon; swimmer: planar chain propelled by fluid forces, frame-axis sensors; point_mass:
-  # motors acting through fixed tendons
+  # motors acting through fixed tendons; ball_in_cup: length limit on a site-to-site spatial tendon
   if name.startswith('swimmer'):
     from dm_control_amd.suite import swimmer
     m = mc.compile_xml(swimmer._make_model(int(name[7:])))
@@ -176,13 +176,17 @@ def test_fluid_and_tendon_domains_match_oracle(name):
   o.qpos[:] = q
   e.qpos[:] = q
   o.forward()
-  for _ in range(300):
+  taut = 0
+  for _ in range(600 if name == 'ball_in_cup' else 300):
     c = rs.uniform(-1, 1, m.nu)
     o.ctrl[:] = c
     e.ctrl[:] = c
     o.step()
     e.step()
+    taut += int(e.nefc[0] > 0)
   assert np.abs(o.qpos - q).max() > 1e-3        # it moved
+  if name == 'ball_in_cup':
+    assert taut > 50                             # the string limit was active for a while
   np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-11)
   np.testing.assert_allclose(o.sensordata, e.sensordata, rtol=0, atol=1e-10)
   o.forward()

@@ -526,3 +526,33 @@ def test_tendon_spring_and_frame_axis_sensors():
   np.testing.assert_allclose(p.qpos[0], 2.0 / (40 * 0.25), rtol=1e-6)
   p.forward()
   np.testing.assert_allclose(p.sensordata, [0, 1, 0, -1, 0, 0, 0, 0, 1], atol=1e-9)
+
+
+# ---- tendon length limits on site-to-site spatial tendons (suite ball_in_cup) --------------------------
+def test_spatial_tendon_limit_carries_the_hanging_weight():
+  # A ball on a string (spatial tendon, range 0..0.3) hanging from a fixed point: at rest the limit row
+  # carries the weight, and the string is stretched by the soft-constraint penetration only.
+  m = mc.compile_xml("""
+  <mujoco><option timestep="0.002"/><worldbody>
+    <site name='hook' pos='0 0 1'/>
+    <body name='ball' pos='0 0 .8'><joint name='x' type='slide' axis='1 0 0' damping='.5'/>
+      <joint name='z' type='slide' axis='0 0 1' damping='.5'/>
+      <geom size='.025' mass='.2'/><site name='ball'/></body>
+  </worldbody>
+  <tendon><spatial name='string' limited='true' range='0 0.3'><site site='ball'/><site site='hook'/></spatial></tendon>
+  </mujoco>""")
+  np.testing.assert_allclose(m.tendon_invweight0[0], 1 / 0.2, rtol=1e-12)     # J M^-1 J' with J = -e_z
+  p = OraclePhysics(m, legacy_step=False)
+  p.qpos[0] = 0.05                    # start off-axis: swings, then settles under the joint damping
+  for _ in range(20000):
+    p.step()
+  assert p.nefc == 1
+  np.testing.assert_allclose(p.efc_force[0], 0.2 * G, rtol=1e-6)
+  length = np.linalg.norm(p.xpos.reshape(-1, 3)[1] - np.array([0, 0, 1.0]))
+  assert 0.3 < length < 0.3005
+  np.testing.assert_allclose(p.qpos[0], -0.0, atol=1e-4)
+  # slack string: no row
+  p.qpos[1] = 0.1
+  p.qvel[:] = 0
+  p.forward()
+  assert p.nefc == 0
