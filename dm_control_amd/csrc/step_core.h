@@ -2324,12 +2324,17 @@ struct StepCore {
       if (mode == 3 && !partial && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
       if (stepping) check_pos_vel();
       const int nstage = (stepping && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
+      // Sensor values are overwritten by every step, so only the passes whose sensordata can be
+      // read afterwards evaluate them: position/velocity sensors in the last pass of a launch and
+      // at env-step boundaries of a rollout, acceleration sensors in the pass before those.
+      const bool sens_pv = !stepping || it == npass - 1 || (mode == 3 && it % nsub == 0);
+      const bool sens_acc = !stepping || it == ntotal - 1 || (mode == 3 && (it + 1) % nsub == 0);
       int stage = 0, retried = 0;
       while (stage < nstage) {
-        call_posvel(partial, outmask, stage > 0);
+        call_posvel(partial, outmask, stage > 0 || !sens_pv);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
         if (partial) break;
-        call_acc(mode == 2, stage > 0);
+        call_acc(mode == 2, stage > 0 || !sens_acc);
         if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
           if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
