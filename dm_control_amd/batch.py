@@ -14,7 +14,7 @@ from dm_control_amd import mjcf_compiler
 
 OUT = dict(sensor=1 << 0, xpos=1 << 1, xquat=1 << 2, xmat=1 << 3, xipos=1 << 4,
            geom=1 << 5, site=1 << 6, subtree_com=1 << 7, qacc=1 << 8,
-           actuator=1 << 9, contact=1 << 10, qfrc=1 << 11)
+           actuator=1 << 9, contact=1 << 10, qfrc=1 << 11, cvel=1 << 12)
 OUT_ALL = 0x7fffffff
 
 

@@ -163,6 +163,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
       {"qacc", d.nv, false}, {"actuator_force", d.nu, false}, {"qfrc_actuator", d.nv, false},
       {"qfrc_bias", d.nv, false}, {"qfrc_constraint", d.nv, false},
       {"contact_dist", d.nconmax, false}, {"contact_pos", 3*d.nconmax, false}, {"contact_frame", 9*d.nconmax, false},
+      {"contact_force", 6*d.nconmax, false}, {"cvel", 6*nb, false},
       {"ncon", 1, true}, {"nefc", 1, true}, {"solver_iter", 1, true}, {"warning", DMC_NWARNING, true},
       {"contact_geom1", d.nconmax, true}, {"contact_geom2", d.nconmax, true}};
   for (const Spec& s : specs) {
@@ -204,6 +205,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->qacc = (T*)P("qacc"); io->actuator_force = (T*)P("actuator_force"); io->qfrc_actuator = (T*)P("qfrc_actuator");
   io->qfrc_bias = (T*)P("qfrc_bias"); io->qfrc_constraint = (T*)P("qfrc_constraint");
   io->contact_dist = (T*)P("contact_dist"); io->contact_pos = (T*)P("contact_pos"); io->contact_frame = (T*)P("contact_frame");
+  io->contact_force = (T*)P("contact_force"); io->cvel = (T*)P("cvel");
   io->ncon = (int*)P("ncon"); io->nefc = (int*)P("nefc"); io->solver_iter = (int*)P("solver_iter");
   io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;

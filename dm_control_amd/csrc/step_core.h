@@ -60,7 +60,7 @@ enum { PROF_LOAD = 0, PROF_KIN, PROF_COM, PROF_CRB, PROF_COLL, PROF_CONSTR, PROF
 enum {
   OUT_SENSOR = 1 << 0, OUT_XPOS = 1 << 1, OUT_XQUAT = 1 << 2, OUT_XMAT = 1 << 3,
   OUT_XIPOS = 1 << 4, OUT_GEOM = 1 << 5, OUT_SITE = 1 << 6, OUT_SUBTREE_COM = 1 << 7,
-  OUT_QACC = 1 << 8, OUT_ACTUATOR = 1 << 9, OUT_CONTACT = 1 << 10, OUT_QFRC = 1 << 11,
+  OUT_QACC = 1 << 8, OUT_ACTUATOR = 1 << 9, OUT_CONTACT = 1 << 10, OUT_QFRC = 1 << 11, OUT_CVEL = 1 << 12,
   OUT_ALL = 0x7fffffff
 };
 
@@ -73,6 +73,8 @@ struct StepIO {
   T *sensordata, *xpos, *xquat, *xmat, *xipos, *geom_xpos, *geom_xmat;
   T *site_xpos, *site_xmat, *subtree_com, *qacc, *actuator_force, *qfrc_actuator;
   T *qfrc_bias, *qfrc_constraint, *contact_dist, *contact_pos, *contact_frame;
+  T *contact_force;   // (6 nconmax): mj_contactForce of the rows solved in this launch's last full pass
+  T *cvel;            // (6 nbody): com-based body velocities, for mj_objectVelocity on the host
   int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
@@ -603,8 +605,12 @@ struct StepCore {
         io.contact_dist[(size_t)c*B + env] = live ? S(con_dist)[c] : (T)0;
         for (int k = 0; k < 3; k++) io.contact_pos[(size_t)(3*c + k)*B + env] = live ? S(con_pos)[3*c + k] : (T)0;
         for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? S(con_frame)[9*c + k] : (T)0;
+        T lf[6] = {0, 0, 0, 0, 0, 0};
+        if (live) contact_force_local(c, lf);
+        for (int k = 0; k < 6; k++) io.contact_force[(size_t)(6*c + k)*B + env] = lf[k];
       }
     }
+    if (mask & OUT_CVEL) FOR_LANES(i, 6*nb) io.cvel[(size_t)i*B + env] = S(cvel)[i];
   }
   DMC_DEV void dump_debug(const StepIO<T>& io, int env) {
     if (!io.debug || env >= io.ndebug) return;

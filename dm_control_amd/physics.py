@@ -129,6 +129,58 @@ class _Data:
     out['frame'] = self._get('contact_frame').reshape(-1, 9)[:n]
     return out
 
+  def contact_force(self, contact_id):
+    """(force, torque) of a contact in the contact frame, 2 x 3 (batch: B x 2 x 3), order
+    (normal, tangent, tangent).  Like the reference (wrapper/core.py:527-552) this re-solves the
+    constraints at the current state first (one mj_forward launch)."""
+    p = self._p
+    ncon = np.atleast_1d(self._get('ncon'))
+    if not 0 <= contact_id < int(ncon.min()):
+      raise ValueError('`contact_id` must be between 0 and {max_valid} (inclusive), got: {actual}.'
+                       .format(max_valid=int(ncon.min()) - 1, actual=contact_id))
+    self._upload()
+    warm = p.batch.get('qacc_warmstart')
+    p.batch.forward(False)
+    p.batch.set('qacc_warmstart', warm)      # a query must not move the solver's warm start
+    self._cache.clear()
+    w = p.batch.get('contact_force').reshape(p.batch_size, -1, 2, 3)[:, contact_id]
+    return w[0] if p.batch_size == 1 else w
+
+  def object_velocity(self, object_id, object_type, local_frame=False):
+    """6D velocity (linear, angular) of a body / xbody / geom / site, 2 x 3 (batch: B x 2 x 3);
+    mj_objectVelocity (wrapper/core.py:500-525) evaluated on the host from cvel / subtree_com."""
+    p = self._p
+    m = p.model
+    kinds = {'body': ('body', 'xipos', None), 'xbody': ('body', 'xpos', 'xmat'), 'geom': ('geom', 'geom_xpos', 'geom_xmat'),
+             'site': ('site', 'site_xpos', 'site_xmat'),
+             mjcf_compiler.C['DMC_OBJ_BODY']: ('body', 'xipos', None), mjcf_compiler.C['DMC_OBJ_XBODY']: ('body', 'xpos', 'xmat'),
+             mjcf_compiler.C['DMC_OBJ_GEOM']: ('geom', 'geom_xpos', 'geom_xmat'),
+             mjcf_compiler.C['DMC_OBJ_SITE']: ('site', 'site_xpos', 'site_xmat')}
+    if object_type not in kinds:
+      raise ValueError('{!r} is not a valid object type for object_velocity'.format(object_type))
+    kind, posf, matf = kinds[object_type]
+    if not isinstance(object_id, (int, np.integer)):
+      object_id = m.name2id(object_id, kind)
+    B = p.batch_size
+    body = {'body': object_id, 'geom': m.geom_bodyid[object_id] if kind == 'geom' else None,
+            'site': m.site_bodyid[object_id] if kind == 'site' else None}[kind]
+    pos = p.batch.get(posf).reshape(B, -1, 3)[:, object_id]
+    if matf is None:     # inertial frame of a body: orientation xquat * body_iquat
+      q = p.batch.get('xquat').reshape(B, -1, 4)[:, object_id]
+      mat = np.stack([mjcf_compiler.quat_to_mat(mjcf_compiler.quat_mul(q[e], m.body_iquat[object_id])) for e in range(B)])
+    else:
+      mat = p.batch.get(matf).reshape(B, -1, 3, 3)[:, object_id]
+    cvel = p.batch.get('cvel').reshape(B, -1, 6)[:, body]
+    root = m.body_rootid[body]
+    com = p.batch.get('subtree_com').reshape(B, -1, 3)[:, root]
+    ang = cvel[:, :3]
+    lin = cvel[:, 3:] - np.cross(pos - com, ang)
+    if local_frame:
+      ang = np.einsum('bij,bi->bj', mat, ang)
+      lin = np.einsum('bij,bi->bj', mat, lin)
+    out = np.stack([lin, ang], axis=1)
+    return out[0] if B == 1 else out
+
 
 class _Axis:
   """Row (or column) names -> indices; ragged rows span several entries."""

@@ -70,7 +70,8 @@ int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
  * "qfrc_applied", "sensordata", "xpos", "xquat", "xmat", "xipos", "geom_xpos",
  * "geom_xmat", "site_xpos", "site_xmat", "subtree_com", "qacc", "actuator_force",
  * "qfrc_actuator", "qfrc_bias", "qfrc_constraint", "contact_dist", "contact_pos",
- * "contact_frame"; int32: "ncon", "nefc", "solver_iter", "warning",
+ * "contact_frame", "contact_force" (mj_contactForce per contact, valid after dmc_batch_forward;
+ * wrapper/core.py:527-552), "cvel" (for mj_objectVelocity, wrapper/core.py:500-525); int32: "ncon", "nefc", "solver_iter", "warning",
  * "contact_geom1", "contact_geom2").  Replaces the numpy views MjData exposes
  * (wrapper/core.py:438-447).  Host buffers are env-major: (B, rows), float64 /
  * int32 regardless of the batch precision.  Synchronous. */

@@ -445,3 +445,54 @@ def test_torch_humanoid_env_matches_host_task_formulas(task, move_speed):
   assert bool(done.all()) and int(env.steps.max()) == 0       # time limit reached: auto-reset on device
   assert int(env.ncon.max()) == 0
   env.close()
+
+
+@pytest.mark.parametrize('qpos,linvel,angvel,local', [
+    ([0., 0.], [1.5, 0, 0], [0, 1, 0], False),
+    ([0., np.pi], [0.5, 0, 0], [0, 1, 0], False),
+    ([0., np.pi], [-0.5, 0, 0], [0, 1, 0], True)])
+def test_facade_object_velocity(qpos, linvel, angvel, local):
+  # wrapper/core_test.py:340-391 through physics.data.object_velocity, for the geom the reference
+  # queries and the site at the same pose
+  from dm_control_amd import physics as physics_lib
+  phys = physics_lib.Physics.from_xml_string("""
+  <mujoco><option><flag contact='disable'/></option><worldbody><body name='cart'>
+    <joint type='slide' axis='1 0 0'/>
+    <geom name='cart' type='box' size='0.2 0.2 0.2'/>
+    <body name='pole'><joint name='hinge' type='hinge' axis='0 1 0'/>
+      <geom name='mass' pos='0 0 .5' size='0.04'/>
+      <site name='mass' pos='0 0 .5'/></body></body></worldbody></mujoco>""")
+  phys.data.qpos[:] = qpos
+  phys.data.qvel[:] = [1., 1.]
+  phys.forward()
+  for kind in ('geom', 'site'):
+    v = phys.data.object_velocity('mass', kind, local_frame=local)
+    assert v.shape == (2, 3)
+    np.testing.assert_allclose(v[0], linvel, atol=1e-9)
+    np.testing.assert_allclose(v[1], angvel, atol=1e-9)
+  with pytest.raises(ValueError):
+    phys.data.object_velocity('mass', 'joint')
+  phys.free()
+
+
+def test_facade_contact_force_equals_weight():
+  # wrapper/core_test.py:393-416 through physics.data.contact_force; ids out of range raise
+  from dm_control_amd import physics as physics_lib
+  phys = physics_lib.Physics.from_xml_string("""
+  <mujoco><worldbody>
+    <geom name='floor' type='plane' size='1 1 1'/>
+    <body name='box' pos='0 0 .1'><freejoint/>
+      <geom name='box' type='box' size='.1 .1 .1'/></body>
+  </worldbody></mujoco>""")
+  phys.legacy_step = False
+  for _ in range(50):
+    phys.step(10)
+  assert int(phys.data.ncon) == 4
+  q_before = np.array(phys.data.qpos, copy=True)
+  normal = sum(phys.data.contact_force(i)[0, 0] for i in range(4))
+  np.testing.assert_allclose(normal, 9.81 * phys.model.body_mass[1], rtol=0, atol=1e-7)
+  np.testing.assert_array_equal(q_before, phys.data.qpos)     # a query does not advance the state
+  for bad in (-1, 4):
+    with pytest.raises(ValueError):
+      phys.data.contact_force(bad)
+  phys.free()
