@@ -408,7 +408,7 @@ class Physics(control.Physics):
 
   def copy(self, share_model=False):
     del share_model
-    other = Physics(self.model, batch_size=self.batch_size, precision=self.batch.precision)
+    other = type(self)(self.model, batch_size=self.batch_size, precision=self.batch.precision)
     for name in _INPUT_FIELDS:
       other.batch.set(name, np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1))
     other.legacy_step = self.legacy_step
@@ -419,6 +419,30 @@ class Physics(control.Physics):
     other.batch.set('qacc_warmstart', np.asarray(self.data._get('qacc_warmstart'), dtype=np.float64).reshape(self.batch_size, -1))
     other._warnings_seen = other.batch.get('warning').astype(np.int64)
     return other
+
+  __copy__ = copy
+
+  def __deepcopy__(self, memo):
+    del memo
+    return self.copy()
+
+  # pickling (engine_test.py:549-572): the compiled model plus the input state; the device batch
+  # is rebuilt on load and the derived arrays recomputed, exactly as copy() does
+  def __getstate__(self):
+    self.data._upload()
+    return dict(cls_model=self.model, batch_size=self.batch_size, precision=self.batch.precision,
+                legacy_step=self.legacy_step,
+                fields={n: self.batch.get(n) for n in _INPUT_FIELDS})
+
+  def __setstate__(self, st):
+    Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'])
+    for n, v in st['fields'].items():
+      self.batch.set(n, v)
+    self.legacy_step = st['legacy_step']
+    self.data._invalidate()
+    self.batch.forward(True)
+    self.batch.set('qacc_warmstart', st['fields']['qacc_warmstart'])
+    self._warnings_seen = self.batch.get('warning').astype(np.int64)
 
   def free(self):
     if getattr(self, 'batch', None) is not None:

@@ -496,3 +496,27 @@ def test_facade_contact_force_equals_weight():
     with pytest.raises(ValueError):
       phys.data.contact_force(bad)
   phys.free()
+
+
+def test_pickle_and_deepcopy_continue_identically():
+  # engine_test.py:549-572: copy / deepcopy / pickle, then ten more steps give identical states
+  import copy, pickle
+  from dm_control_amd.suite import cheetah
+  phys = cheetah.Physics.from_xml_string(*cheetah.get_model_and_assets())
+  rs = np.random.RandomState(0)
+  for _ in range(20):
+    phys.set_control(rs.uniform(-1, 1, 6))
+    phys.step()
+  clones = [copy.copy(phys), copy.deepcopy(phys), pickle.loads(pickle.dumps(phys))]
+  assert all(type(c) is type(phys) for c in clones)
+  for _ in range(10):
+    a = rs.uniform(-1, 1, 6)
+    for p in [phys] + clones:
+      p.set_control(a)
+      p.step()
+  for c in clones:
+    np.testing.assert_array_equal(c.data.qpos, phys.data.qpos)
+    np.testing.assert_array_equal(c.data.xpos, phys.data.xpos)
+    assert c.data.time == phys.data.time
+    c.free()
+  phys.free()
