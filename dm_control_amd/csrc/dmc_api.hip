@@ -391,6 +391,7 @@ extern "C" int dmc_batch_set_model_real(dmc_batch* b, const char* name, const do
       {"actuator_ctrlrange", L.mr_act_ctrlrange, 2 * d.nu, 1, 1},
       {"actuator_forcerange", L.mr_act_forcerange, 2 * d.nu, 1, 1},
       {"wrap_prm", L.mr_wrap_prm, d.nwrap, 1, 1},
+      {"body_pos", L.mr_body_pos, 3 * d.nbody, 1, 1}, {"body_quat", L.mr_body_quat, 4 * d.nbody, 1, 1},
   };
   for (const Slot& s : slots) {
     if (strcmp(name, s.name)) continue;

@@ -1031,7 +1031,7 @@ struct StepCore {
     return (m >> (dofid & 31)) & 1u;
   }
   // models with elliptic cones or dof friction loss take the general (per-row-type) solver paths
-  DMC_DEV bool general_rows() const { return L.d.elliptic || L.d.nfric; }
+  DMC_DEV bool general_rows() const { return L.d.elliptic || L.d.nfric || L.d.neq; }
   // ---- tendons (mj_tendon for fixed and site-to-site spatial tendons) -----------------------
   DMC_DEV void site_world_pos(int sid, T* p) {
     const int b = MI(site_bodyid)[sid]; T v[3];
@@ -1081,16 +1081,26 @@ struct StepCore {
     const int nv = L.d.nv, njmax = L.d.njmax;
     int nefc = 0, overflow = 0;
     const bool enabled = !(o.disableflags & DMC_DSBL_CONSTRAINT);
-    // dof friction loss: one row per dof with frictionloss > 0 (MuJoCo order: friction, limit, contact)
+    // equality constraints first (MuJoCo order: equality, friction, limit, contact): a fixed
+    // tendon held at its reference length; two-sided, always active
+    if (L.d.neq && enabled && !(o.disableflags & DMC_DSBL_EQUALITY)) for (int k = 0; k < L.d.neq; k++) {
+      if (nefc >= njmax) { overflow = 1; continue; }
+      const int r = nefc++, t = MI(eq_tendon)[k];
+      FOR_LANES(dd, nv) S(efc_J)[r*nv + dd] = tendon_jac(t, dd);
+      if (lane == 0) { S(efc_aref)[r] = tendon_length(t) - MR(eq_pos0)[k]; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_EQUALITY, k); }
+    }
+    // dof friction loss: one row per dof with frictionloss > 0
     if (L.d.nfric && enabled && !(o.disableflags & DMC_DSBL_FRICTIONLOSS)) {
-      for (int r = lane; r < L.d.nfric; r += LPE) {
+      const int base = nefc;
+      for (int k = lane; k < L.d.nfric; k += LPE) {
+        const int r = base + k;
         if (r >= njmax) { overflow = 1; continue; }
-        const int dof = MI(fric_dof)[r];
+        const int dof = MI(fric_dof)[k];
         for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
         S(efc_J)[r*nv + dof] = 1;
         S(efc_aref)[r] = 0; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_FRICTION, dof);
       }
-      nefc = L.d.nfric < njmax ? L.d.nfric : njmax;
+      nefc = base + L.d.nfric < njmax ? base + L.d.nfric : njmax;
     }
     // joint limits
     if (enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int j0 = 0; j0 < L.d.njnt; j0 += LPE) {
@@ -1226,7 +1236,10 @@ struct StepCore {
       const T pos = S(efc_aref)[i], margin = S(efc_D)[i];   // staged by the row headers above
       T mu = 0; T dA0 = 0;
       int ell_row = 0; T ell_fj = 0, ell_imp0 = 0;
-      if (type == EFC_FRICTION) {
+      if (type == EFC_EQUALITY) {
+        solref = MR(eq_solref) + 2*id; solimp = MR(eq_solimp) + 5*id;
+        dA = MR(tendon_invweight0)[MI(eq_tendon)[id]];
+      } else if (type == EFC_FRICTION) {
         solref = MR(dof_solref) + 2*id; solimp = MR(dof_solimp) + 5*id;
         dA = MR(dof_invweight0)[id];
       } else if (type == EFC_LIMIT) {
@@ -1778,6 +1791,12 @@ struct StepCore {
     int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) == EFC_EQUALITY) {   // two-sided: always quadratic
+        const T jar = S(efc_jar)[i], D = S(efc_D)[i];
+        S(efc_force)[i] = -D*jar; cost += (T)0.5*D*jar*jar;
+        if (track) { if (SI(efc_active)[i] != EFC_ST_QUADRATIC) changed = 1; SI(efc_active)[i] = EFC_ST_QUADRATIC; }
+        continue;
+      }
       if (EFC_TYPE(tid) == EFC_FRICTION) {
         // Huber cost: quadratic for |jar| < R*floss, linear (force saturated at +-floss) outside
         const T jar = S(efc_jar)[i], D = S(efc_D)[i], f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D;
@@ -1876,6 +1895,11 @@ struct StepCore {
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
+      if (EFC_TYPE(tid) == EFC_EQUALITY) {
+        const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i], dj0 = D*jar;
+        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+        continue;
+      }
       if (EFC_TYPE(tid) == EFC_FRICTION) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i];
         const T f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D, x = jar + a*jv;

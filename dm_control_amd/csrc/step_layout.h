@@ -28,6 +28,7 @@ struct StepDims {
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
   int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
+  int neq;       // active equality constraints (single fixed tendon held at its reference length)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -55,7 +56,8 @@ struct StepDims {
   X(fric_dof, d.nfric)                                                         \
   X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap) \
   X(wrap_site, d.nwrap)        /* site id of a spatial-tendon wrap, -1 for joint wraps */ \
-  X(limten, d.nlimten)         /* the limited tendons */
+  X(limten, d.nlimten)         /* the limited tendons */                       \
+  X(eq_tendon, d.neq)          /* tendon of each equality constraint */
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -80,7 +82,8 @@ struct StepDims {
   X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon) \
   X(tendon_range, d.nlimten ? 2 * d.ntendon : 0) X(tendon_margin, d.nlimten ? d.ntendon : 0) \
   X(tendon_solref_lim, d.nlimten ? 2 * d.ntendon : 0) X(tendon_solimp_lim, d.nlimten ? 5 * d.ntendon : 0) \
-  X(tendon_invweight0, d.nlimten ? d.ntendon : 0)
+  X(tendon_invweight0, (d.nlimten || d.neq) ? d.ntendon : 0)                   \
+  X(eq_solref, 2 * d.neq) X(eq_solimp, 5 * d.neq) X(eq_pos0, d.neq)  /* eq_pos0: reference length + polycoef[0] */
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -136,7 +139,7 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
        ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */ };
-enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5 };
+enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5, EFC_EQUALITY = 6 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))
 #define EFC_TYPE(tid) ((tid) & 7)

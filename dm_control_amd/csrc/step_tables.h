@@ -44,8 +44,8 @@ inline bool host_model_parse(HostModel* m, const int32_t* ints, int nints, const
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
-  (void)ntendon; (void)nwrap; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
+  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
+  (void)ntendon; (void)nwrap; (void)neq; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
 #define X(n, c) { long cnt = (c); if (cnt < 0 || !need_i(cnt)) { *err = "model blob truncated"; return false; } m->n.assign(ints + ip, ints + ip + cnt); ip += cnt; }
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -104,6 +104,14 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.tendon_limited[t]) limten.push_back(t);
   }
   d.nlimten = (int)limten.size();
+  std::vector<int> eq_tendon, eq_src;
+  for (int k = 0; k < m.neq; k++) {
+    if (m.eq_type[k] != DMC_EQ_TENDON) { *err = "only tendon equality constraints are implemented"; return false; }
+    const int t = m.eq_obj1id[k];
+    if (t < 0 || t >= m.ntendon || (m.tendon_num[t] > 0 && m.wrap_type[m.tendon_adr[t]] != DMC_WRAP_JOINT)) { *err = "equality constraints need a fixed tendon"; return false; }
+    if (m.eq_active0[k]) { eq_tendon.push_back(t); eq_src.push_back(k); }
+  }
+  d.neq = (int)eq_tendon.size();
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
@@ -150,13 +158,13 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (cyl) nc = 0;
     maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
-  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric;
+  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric + d.neq;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
   if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
-  if (njmax <= 0) njmax = d.nfric + nlim + d.nlimten + nconmax * maxrow_per_contact;
-  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric)));
+  if (njmax <= 0) njmax = d.neq + d.nfric + nlim + d.nlimten + nconmax * maxrow_per_contact;
+  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric + d.neq)));
   d.nconmax = nconmax; d.njmax = njmax;
   d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
   step_layout_build(&t->L, d);
@@ -275,7 +283,15 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   cpi(L.mi_limten, limten);
   if (d.nlimten) {
     cpr(L.mr_tendon_range, m.tendon_range); cpr(L.mr_tendon_margin, m.tendon_margin); cpr(L.mr_tendon_solref_lim, m.tendon_solref_lim);
-    cpr(L.mr_tendon_solimp_lim, m.tendon_solimp_lim); cpr(L.mr_tendon_invweight0, m.tendon_invweight0);
+    cpr(L.mr_tendon_solimp_lim, m.tendon_solimp_lim);
+  }
+  if (d.nlimten || d.neq) cpr(L.mr_tendon_invweight0, m.tendon_invweight0);
+  cpi(L.mi_eq_tendon, eq_tendon);
+  for (int k = 0; k < d.neq; k++) {
+    const int src = eq_src[k];
+    for (int a = 0; a < 2; a++) mr[L.mr_eq_solref + 2*k + a] = m.eq_solref[2*src + a];
+    for (int a = 0; a < 5; a++) mr[L.mr_eq_solimp + 5*k + a] = m.eq_solimp[5*src + a];
+    mr[L.mr_eq_pos0 + k] = m.tendon_length0[eq_tendon[k]] + m.eq_data[5*src];
   }
   if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);

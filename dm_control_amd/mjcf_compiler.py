@@ -280,7 +280,7 @@ class Model:
   def sizes(self):
     return {k: int(getattr(self, k)) for k in
             ('nq', 'nv', 'nu', 'na', 'nbody', 'njnt', 'ngeom', 'nsite',
-             'nsensor', 'nsensordata', 'npair', 'nkey', 'ntendon', 'nwrap')}
+             'nsensor', 'nsensordata', 'npair', 'nkey', 'ntendon', 'nwrap', 'neq')}
 
   def pack(self):
     """Serialises into (ints int32[], reals float64[]) per dmc_model_layout.h."""
@@ -752,9 +752,18 @@ class _Compiler:
           raise MjcfError('tendon %r is empty' % a.get('name'))
         self.tendons.append(dict(name=a.get('name'), spatial=False, wraps=wraps, stiffness=float(a.get('stiffness', 0)),
                                  damping=float(a.get('damping', 0)), limited=limited, attrs=a))
+    # equality constraints: a single fixed tendon held at its reference length (plus polycoef[0])
+    self.equalities = []
     for sec in self.root.findall('equality'):
-      if len(sec):
-        raise MjcfError('equality constraints are not supported')
+      for e in sec:
+        cname = e.attrib.get('class', 'main')
+        if cname not in self.classes:
+          raise MjcfError('unknown default class %r' % cname)
+        a = dict(self.classes[cname].get('equality'))
+        a.update(e.attrib)
+        if e.tag != 'tendon' or 'tendon2' in a:
+          raise MjcfError('unsupported equality constraint <%s> (only single-tendon equalities are supported)' % e.tag)
+        self.equalities.append(a)
 
   def _parse_sensors(self):
     for sec in self.root.findall('sensor'):
@@ -1077,6 +1086,31 @@ class _Compiler:
       m.tendon_margin[t] = float(a.get('margin', 0))
       m.tendon_solref_lim[t] = _vec(a.get('solreflimit', '0.02 1'), 2)
       m.tendon_solimp_lim[t] = _solimp(a.get('solimplimit', '0.9 0.95 0.001 0.5 2'))
+    m.tendon_length0 = np.zeros(nt)          # filled by _set_const (length at qpos0)
+    m.neq = len(self.equalities)
+    m.eq_type = np.full(m.neq, C['DMC_EQ_TENDON'], dtype=np.int64)
+    m.eq_obj1id = np.zeros(m.neq, dtype=np.int64)
+    m.eq_active0 = np.ones(m.neq, dtype=np.int64)
+    m.eq_solref = np.zeros((m.neq, 2))
+    m.eq_solimp = np.zeros((m.neq, 5))
+    m.eq_data = np.zeros((m.neq, 5))
+    eq_names = []
+    for k, a in enumerate(self.equalities):
+      eq_names.append(a.get('name'))
+      tname = a.get('tendon1')
+      names_t = [td['name'] for td in self.tendons]
+      if tname not in names_t:
+        raise MjcfError('equality refers to unknown tendon %r' % tname)
+      t = names_t.index(tname)
+      if self.tendons[t]['spatial']:
+        raise MjcfError('equality on a spatial tendon is not supported')
+      m.eq_obj1id[k] = t
+      m.eq_active0[k] = int(a.get('active', 'true') == 'true')
+      m.eq_solref[k] = _vec(a.get('solref', '0.02 1'), 2)
+      m.eq_solimp[k] = _solimp(a.get('solimp', '0.9 0.95 0.001 0.5 2'))
+      pc = _vec(a.get('polycoef', '0 1 0 0 0'))
+      m.eq_data[k, :pc.size] = pc
+    m.names['equality'] = eq_names
     m.tendon_stiffness = np.array([td['stiffness'] for td in self.tendons], dtype=np.float64)
     m.tendon_damping = np.array([td['damping'] for td in self.tendons], dtype=np.float64)
     # spring rest length: the tendon's length at qpos0 (springlength = -1 default)
@@ -1340,6 +1374,8 @@ class _Compiler:
           if n > MINVAL:
             J += (dvec / n) @ (j1 - j0)
       m.tendon_invweight0[t] = max(MINVAL, float(J @ minv @ J))
+      if wn and m.wrap_type[w0] == C['DMC_WRAP_JOINT']:
+        m.tendon_length0[t] = sum(m.wrap_prm[w] * m.qpos0[m.jnt_qposadr[m.wrap_objid[w]]] for w in range(w0, w0 + wn))
 
 
 def _solimp(s):

@@ -34,7 +34,8 @@ _WARNING_NAMES = ['mjWARN_INERTIA', 'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL', 'm
 # model arrays tasks may rewrite through physics.model / physics.named.model between
 # episodes; changes are pushed to the device tables before the next launch
 _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margin', 'qpos_spring', 'site_pos',
-                         'site_quat', 'site_size', 'actuator_ctrlrange', 'actuator_forcerange', 'wrap_prm')
+                         'site_quat', 'site_size', 'actuator_ctrlrange', 'actuator_forcerange', 'wrap_prm', 'body_pos',
+                         'body_quat')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
 _INPUT_FIELDS = ('qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')

@@ -18,12 +18,12 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 7
+#define DMC_MODEL_VERSION 8
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) \
-  X(nsensor) X(nsensordata) X(npair) X(nkey) X(ntendon) X(nwrap) \
+  X(nsensor) X(nsensordata) X(npair) X(nkey) X(ntendon) X(nwrap) X(neq) \
   X(opt_integrator) X(opt_cone) X(opt_solver) X(opt_iterations) \
   X(opt_ls_iterations) X(opt_noslip_iterations) \
   X(opt_disableflags) X(opt_enableflags)
@@ -53,7 +53,8 @@
   X(pair_geom1, npair) X(pair_geom2, npair) \
   X(tendon_adr, ntendon) X(tendon_num, ntendon) /* fixed tendons: wraps [adr, adr + num) */ \
   X(wrap_objid, nwrap)                           /* joint id (fixed) or site id (spatial) of each wrap */ \
-  X(wrap_type, nwrap) X(tendon_limited, ntendon)
+  X(wrap_type, nwrap) X(tendon_limited, ntendon) \
+  X(eq_type, neq) X(eq_obj1id, neq) X(eq_active0, neq)   /* equality constraints (tendon type only) */
 
 /* ---- real fields: X(name, count_expr) ----------------------------------- */
 #define DMC_MODEL_REAL_FIELDS(X) \
@@ -77,7 +78,8 @@
   X(sensor_cutoff, nsensor) X(wrap_prm, nwrap) \
   X(tendon_stiffness, ntendon) X(tendon_damping, ntendon) X(tendon_lengthspring, ntendon) \
   X(tendon_range, 2*ntendon) X(tendon_margin, ntendon) X(tendon_solref_lim, 2*ntendon) \
-  X(tendon_solimp_lim, 5*ntendon) X(tendon_invweight0, ntendon) \
+  X(tendon_solimp_lim, 5*ntendon) X(tendon_invweight0, ntendon) X(tendon_length0, ntendon) \
+  X(eq_solref, 2*neq) X(eq_solimp, 5*neq) X(eq_data, 5*neq) \
   X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
 
 /* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
@@ -92,6 +94,7 @@ enum { DMC_CONE_PYRAMIDAL = 0, DMC_CONE_ELLIPTIC = 1 };
 enum { DMC_SOL_PGS = 0, DMC_SOL_CG = 1, DMC_SOL_NEWTON = 2 };
 enum { DMC_TRN_JOINT = 0, DMC_TRN_TENDON = 3 };
 enum { DMC_WRAP_JOINT = 1, DMC_WRAP_SITE = 3 };
+enum { DMC_EQ_TENDON = 3 };
 enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2 };
 enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
 enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };

@@ -60,7 +60,7 @@ typedef struct {
   int nconmax, njmax;
 } Model;
 
-enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3, CT_FRICTION_DOF = 4, CT_LIMIT_TENDON = 5 };
+enum { CT_LIMIT = 0, CT_FRICTIONLESS = 1, CT_PYRAMIDAL = 2, CT_ELLIPTIC = 3, CT_FRICTION_DOF = 4, CT_LIMIT_TENDON = 5, CT_EQUALITY = 6 };
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
@@ -278,9 +278,9 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) m->n = m->ibuf + ip; ip += (c);
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -291,7 +291,7 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
     g_err = "model blob size mismatch"; free(m->ibuf); free(m->rbuf); free(m); return NULL;
   }
   m->nconmax = 4 * npair + 4;
-  m->njmax = m->nv + 2 * njnt + 2 * m->ntendon + 10 * m->nconmax;
+  m->njmax = m->neq + m->nv + 2 * njnt + 2 * m->ntendon + 10 * m->nconmax;
   return m;
 }
 void ora_model_free(Model* m) { if (m) { free(m->ibuf); free(m->rbuf); free(m); } }
@@ -309,9 +309,9 @@ double ora_model_opt_real(Model* m, const char* name, int set, double value) {
 }
 int* ora_model_int_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -319,9 +319,9 @@ int* ora_model_int_field(Model* m, const char* name, int* count) {
 }
 double* ora_model_real_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
   (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
-  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap;
+  (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_REAL_FIELDS(X)
 #undef X
@@ -821,6 +821,16 @@ static void make_constraint(const Model* m, Data* d) {
   d->nefc = 0;
   for (int i = 0; i < d->ncon; i++) d->contact[i].efc_address = -1;
   if (m->opt_disableflags & DMC_DSBL_CONSTRAINT) return;
+  /* equality constraints (first, as in MuJoCo): a fixed tendon held at its reference length,
+   * residual = (L - L0) - polycoef[0]; always active, two-sided */
+  if (!(m->opt_disableflags & DMC_DSBL_EQUALITY)) for (int k = 0; k < m->neq; k++) {
+    if (!m->eq_active0[k]) continue;
+    if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+    int r = d->nefc++, t = m->eq_obj1id[k];
+    memcpy(d->efc_J + (size_t)r*nv, d->ten_J + (size_t)t*nv, sizeof(double) * (size_t)nv);
+    d->efc_pos[r] = d->ten_length[t] - m->tendon_length0[t] - m->eq_data[5*k];
+    d->efc_margin[r] = 0; d->efc_type[r] = CT_EQUALITY; d->efc_id[r] = k;
+  }
   /* dof friction loss (rows come first, as in MuJoCo: equality, friction, limit, contact) */
   if (!(m->opt_disableflags & DMC_DSBL_FRICTIONLOSS)) for (int i = 0; i < nv; i++) {
     if (m->dof_frictionloss[i] <= 0) continue;
@@ -907,7 +917,11 @@ static void make_constraint(const Model* m, Data* d) {
   int nefc = d->nefc;
   for (int i = 0; i < nefc; i++) {
     const double *solref, *solimp; double dA;
-    if (d->efc_type[i] == CT_FRICTION_DOF) {
+    if (d->efc_type[i] == CT_EQUALITY) {
+      int k = d->efc_id[i];
+      solref = m->eq_solref + 2*k; solimp = m->eq_solimp + 5*k;
+      dA = m->tendon_invweight0[m->eq_obj1id[k]];
+    } else if (d->efc_type[i] == CT_FRICTION_DOF) {
       int k = d->efc_id[i];
       solref = m->dof_solref + 2*k; solimp = m->dof_solimp + 5*k;
       dA = m->dof_invweight0[k];
@@ -1421,6 +1435,10 @@ static double constraint_update(const Model* m, Data* d, const double* jar, int 
       i += dim - 1;
       continue;
     }
+    if (d->efc_type[i] == CT_EQUALITY) {   /* two-sided: always quadratic */
+      d->efc_state[i] = ST_QUADRATIC; d->efc_force[i] = -d->efc_D[i]*jar[i]; cost += 0.5*d->efc_D[i]*jar[i]*jar[i];
+      continue;
+    }
     if (d->efc_type[i] == CT_FRICTION_DOF) {
       /* Huber cost: quadratic inside |jar| < R*floss, linear (force saturated at +-floss) outside */
       double f = m->dof_frictionloss[d->efc_id[i]], rf = d->efc_R[i]*f;
@@ -1466,6 +1484,7 @@ static void ls_eval(const LSCtx* c, LSPoint* p) {
       i += dim - 1;
       continue;
     }
+    if (c->d->efc_type[i] == CT_EQUALITY) { qt[0] += c->quad[3*i]; qt[1] += c->quad[3*i + 1]; qt[2] += c->quad[3*i + 2]; continue; }
     if (c->d->efc_type[i] == CT_FRICTION_DOF) {
       double f = c->m->dof_frictionloss[c->d->efc_id[i]], rf = c->d->efc_R[i]*f, x = c->jar[i] + a*c->jv[i];
       if (x <= -rf) { qt[0] += f*(-0.5*rf - c->jar[i]); qt[1] += -f*c->jv[i]; }

@@ -22,7 +22,9 @@ def _oracle(model):
                                          ('finger', 'spin'), ('finger', 'turn_easy'), ('finger', 'turn_hard'),
                                          ('reacher', 'easy'), ('reacher', 'hard'),
                                          ('point_mass', 'easy'), ('point_mass', 'hard'),
-                                         ('ball_in_cup', 'catch'), ('fish', 'upright'), ('fish', 'swim'), ('swimmer', 'swimmer6'),
+                                         ('ball_in_cup', 'catch'), ('fish', 'upright'), ('fish', 'swim'),
+                                         ('manipulator', 'bring_ball'), ('manipulator', 'bring_peg'),
+                                         ('manipulator', 'insert_ball'), ('swimmer', 'swimmer6'),
                                          ('swimmer', 'swimmer15')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
@@ -49,7 +51,7 @@ def test_suite_task_properties(domain, task):
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
                                          ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2'),
-                                         ('ball_in_cup', 'catch')])
+                                         ('ball_in_cup', 'catch'), ('manipulator', 'bring_ball')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -520,3 +522,25 @@ def test_pickle_and_deepcopy_continue_identically():
     assert c.data.time == phys.data.time
     c.free()
   phys.free()
+
+
+def test_manipulator_batched_targets_and_receptacle():
+  """Batched manipulator: per-environment ghost targets live in the task, the colliding receptacle
+  pose is one model constant per episode pushed through dmc_batch_set_model_real."""
+  from dm_control_amd import suite
+  env = suite.load('manipulator', 'insert_ball', task_kwargs=dict(random=1), physics_kwargs=dict(batch_size=3))
+  ts = env.reset()
+  tp = np.asarray(ts.observation['target_pos'])
+  assert tp.shape == (3, 4)
+  np.testing.assert_allclose(tp[0], tp[1])             # insert: the shared receptacle / target pose
+  cup = env.physics.model.name2id('cup', 'body')
+  np.testing.assert_allclose(np.asarray(env.physics.data.xpos)[:, cup, [0, 2]], tp[:, :2], atol=1e-12)
+  assert (np.atleast_1d(env.physics.data.ncon) == 0).all()
+  for _ in range(5):
+    ts = env.step(np.zeros((3, 5)))
+  assert np.asarray(ts.reward).shape == (3,)
+  env.physics.free()
+  env = suite.load('manipulator', 'bring_ball', task_kwargs=dict(random=1), physics_kwargs=dict(batch_size=3))
+  tp = np.asarray(env.reset().observation['target_pos'])
+  assert not np.allclose(tp[0], tp[1])                 # bring: one target per environment
+  env.physics.free()

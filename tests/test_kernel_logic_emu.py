@@ -193,3 +193,26 @@ def test_fluid_and_tendon_domains_match_oracle(name):
   e.forward()   # the scratch dump is taken after a forward pass: compare like with like
   np.testing.assert_allclose(o.qfrc_passive, e.scratch('qfrc_passive'), rtol=1e-7, atol=1e-12)
   assert not e.warning.any()
+
+
+@pytest.mark.parametrize('use_peg,insert', [(False, False), (True, False), (False, True)])
+def test_manipulator_variants_match_oracle(use_peg, insert):
+  # suite manipulator: elliptic cones + tendon equality (finger / thumb coupling) + a motor on a
+  # fixed tendon + box touch sites; props removed per task as the reference does
+  from dm_control_amd.suite import manipulator
+  m = mc.compile_xml(manipulator.make_model(use_peg, insert)[0])
+  assert m.neq == 1 and m.ntendon == 2
+  o, e = OraclePhysics(m), EmuPhysics(m, 64)
+  o.forward()
+  rs = np.random.RandomState(0)
+  for t in range(800):
+    if t % 40 == 0:
+      c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+  np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-10)
+  np.testing.assert_allclose(o.sensordata, e.sensordata, rtol=0, atol=1e-8)
+  assert e.nefc[0] >= 1                      # the coupling row is always there
+  assert not e.warning.any() and not o.warning.any()

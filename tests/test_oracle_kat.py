@@ -556,3 +556,31 @@ def test_spatial_tendon_limit_carries_the_hanging_weight():
   p.qvel[:] = 0
   p.forward()
   assert p.nefc == 0
+
+
+# ---- tendon equality constraints (suite manipulator: finger / thumb coupling) ------------------------------
+def test_tendon_equality_couples_two_sliders():
+  # -0.5 a + 0.5 b held at its reference length: pushing a drags b along; the pair accelerates
+  # like one body of twice the mass, and the constraint force on b equals its inertial force.
+  m = mc.compile_xml("""
+  <mujoco><option timestep="0.001"><flag gravity="disable" contact="disable"/></option><worldbody>
+    <body name='a' pos='0 0 0'><joint name='a' type='slide' axis='1 0 0'/><geom size='.05' mass='2'/></body>
+    <body name='b' pos='0 1 0'><joint name='b' type='slide' axis='1 0 0'/><geom size='.05' mass='2'/></body>
+  </worldbody>
+  <tendon><fixed name='c'><joint joint='a' coef='-.5'/><joint joint='b' coef='.5'/></fixed></tendon>
+  <equality><tendon tendon1='c' solref='.005 1'/></equality></mujoco>""")
+  assert m.neq == 1
+  p = OraclePhysics(m, legacy_step=False)
+  p.qfrc_applied[0] = 4.0
+  for _ in range(1000):
+    p.step()
+  assert p.nefc == 1
+  np.testing.assert_allclose(p.qvel, [1.0, 1.0], rtol=2e-3)          # F t / (m_a + m_b) = 4 * 1 / 4
+  assert abs(p.qpos[0] - p.qpos[1]) < 2e-3
+  np.testing.assert_allclose(p.qfrc_constraint, [-2.0, 2.0], rtol=2e-3)
+  # mjDSBL_EQUALITY releases b
+  p.model.opt_int('disableflags', p.model.opt_int('disableflags') | (1 << 1))
+  v1 = p.qvel[1]
+  for _ in range(100):
+    p.step()
+  assert p.nefc == 0 and p.qvel[1] == v1
