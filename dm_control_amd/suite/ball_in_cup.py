@@ -61,7 +61,8 @@ class BallInCup(base.Task):
         qpos[e, ax] = self.random.uniform(-.2, .2)
         qpos[e, az] = self.random.uniform(.2, .5)
       physics.data.qpos = qpos.reshape(np.shape(physics.data.qpos))
-      physics.after_reset()
+      with physics.suppress_physics_errors():   # a rejected sample may overflow the contact cap
+        physics.after_reset()
       todo &= np.atleast_1d(physics.data.ncon) > 0
     super().initialize_episode(physics)
 

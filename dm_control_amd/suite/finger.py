@@ -79,7 +79,8 @@ def _set_random_joint_angles(physics, random, max_attempts=1000):
   todo = np.ones(physics.batch_size, dtype=bool)
   for _ in range(max_attempts):
     randomizers.randomize_limited_and_rotational_joints(physics, random, env_mask=todo)
-    physics.after_reset()
+    with physics.suppress_physics_errors():   # a rejected sample may overflow the contact cap
+      physics.after_reset()
     todo &= np.atleast_1d(physics.data.ncon) > 0
     if not todo.any():
       return

@@ -86,7 +86,8 @@ class Humanoid(base.Task):
     todo = np.ones(physics.batch_size, dtype=bool)
     while todo.any():
       randomizers.randomize_limited_and_rotational_joints(physics, self.random, env_mask=todo)
-      physics.after_reset()
+      with physics.suppress_physics_errors():   # a rejected sample may overflow the contact cap
+        physics.after_reset()
       todo &= np.atleast_1d(physics.data.ncon) > 0
     super().initialize_episode(physics)
 

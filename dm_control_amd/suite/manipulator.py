@@ -47,7 +47,9 @@ def make_model(use_peg, insert):
 def _make(use_peg, insert):
   def factory(fully_observable=True, time_limit=_TIME_LIMIT, random=None, environment_kwargs=None,
               physics_kwargs=None):
-    physics = Physics.from_xml_string(*make_model(use_peg, insert), **(physics_kwargs or {}))
+    kw = dict(nconmax=40)     # a folded arm touches itself in many places; the default cap is 16
+    kw.update(physics_kwargs or {})
+    physics = Physics.from_xml_string(*make_model(use_peg, insert), **kw)
     task = Bring(use_peg=use_peg, insert=insert, fully_observable=fully_observable, random=random)
     return control.Environment(physics, task, control_timestep=_CONTROL_TIMESTEP, time_limit=time_limit,
                                **(environment_kwargs or {}))
@@ -160,7 +162,8 @@ class Bring(base.Task):
         kinds[e] = choice(['in_hand', 'in_target', 'uniform'], p=[_P_IN_HAND, _P_IN_TARGET, 1 - _P_IN_HAND - _P_IN_TARGET])
       if any(k == 'in_hand' for k in kinds.values()):
         physics.data.qpos = qpos.reshape(np.shape(physics.data.qpos))
-        physics.after_reset()
+        with physics.suppress_physics_errors():
+          physics.after_reset()
         grasp_pos = np.asarray(physics.named.data.site_xpos['grasp']).reshape(B, 3)
         grasp_mat = np.asarray(physics.named.data.site_xmat['grasp']).reshape(B, 9)
       for e in idx:
@@ -176,7 +179,8 @@ class Bring(base.Task):
           qpos[e, qadr(n)] = v
       physics.data.qpos = qpos.reshape(np.shape(physics.data.qpos))
       physics.data.qvel = qvel.reshape(np.shape(physics.data.qvel))
-      physics.after_reset()
+      with physics.suppress_physics_errors():     # a rejected sample may overflow the contact cap
+        physics.after_reset()
       todo &= np.atleast_1d(physics.data.ncon) > 0
     physics.target_pose = target[0] if B == 1 else target
     super().initialize_episode(physics)

@@ -544,3 +544,66 @@ def test_manipulator_batched_targets_and_receptacle():
   tp = np.asarray(env.reset().observation['target_pos'])
   assert not np.allclose(tp[0], tp[1])                 # bring: one target per environment
   env.physics.free()
+
+
+@pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
+                                       ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4)])
+def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
+  """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
+  env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
+  median error of one env-step <= 1e-6, at least 98 % of the (env, step) samples <= 5e-5.  The
+  rest are contact on/off decisions that fall differently in fp32 (dist within rounding of the
+  margin) -- the fp64 kernel tracks the same runs to 1e-14 (test_more_domains_rollout_parity)."""
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  from oracle import oracle
+  if name.startswith('swimmer'):
+    from dm_control_amd.suite import swimmer
+    m = mc.compile_xml(swimmer._make_model(int(name[7:])))
+  elif name == 'manipulator':
+    from dm_control_amd.suite import manipulator
+    m = mc.compile_xml(manipulator.make_model(False, True)[0])
+  else:
+    m = mc.compile_xml(common.read_model(name + '.xml'))
+  NE = 16
+  rs = np.random.RandomState(11)
+  q = np.tile(m.qpos0, (NE, 1))
+  v = np.zeros((NE, m.nv))
+  if name == 'manipulator':
+    # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
+    # fp32; use the task's own collision-free start states (manipulator.py:183-239)
+    from dm_control_amd import suite
+    env = suite.load('manipulator', 'insert_ball', task_kwargs=dict(random=5), physics_kwargs=dict(batch_size=NE))
+    env.reset()
+    q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
+    m = env.physics.model
+    env.physics.free()
+  else:
+    for j in range(m.njnt):
+      a = m.jnt_qposadr[j]
+      if m.jnt_type[j] == 3 and m.jnt_limited[j]:
+        q[:, a] = rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], NE)
+  refs = []
+  for e in range(NE):
+    o = _oracle(m)
+    o.qpos[:] = q[e]
+    o.qvel[:] = v[e]
+    o.forward()
+    refs.append(o)
+  b = BatchedPhysics(m, NE, precision=32)
+  errs = []
+  for t in range(40):
+    a = rs.uniform(-1, 1, (NE, m.nu))
+    b.set('qpos', np.stack([o.qpos for o in refs]))
+    b.set('qvel', np.stack([o.qvel for o in refs]))
+    b.set('qacc_warmstart', np.stack([o.qacc_warmstart for o in refs]))
+    b.set_control(a)
+    b.step(nsub)
+    oracle.rollout_legacy(refs, a[None], nsub=nsub)
+    qo = np.stack([o.qpos for o in refs])
+    errs.append(np.abs(b.get('qpos') - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1)))
+  errs = np.concatenate(errs)
+  assert np.median(errs) <= 1e-6, np.median(errs)
+  assert (errs <= 5e-5).mean() >= 0.98, (errs <= 5e-5).mean()
+  assert not b.get('warning').any()
+  b.close()
