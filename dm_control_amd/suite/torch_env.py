@@ -88,6 +88,7 @@ class TorchBatchedEnv:
       self.physics.bind(name, t.data_ptr())
     self.step_limit = int(round(time_limit / (m.opt.timestep * n_sub_steps)))
     self.steps = torch.zeros(self.B, dtype=torch.int64, device=self.device)
+    self._host_steps = 0     # upper bound of `steps` known without a device sync
     self._rs = np.random.RandomState(seed)
     self._gen = torch.Generator(device=self.device).manual_seed(seed)
     self._make_start_pool()
@@ -123,6 +124,7 @@ class TorchBatchedEnv:
     torch = self.torch
     if mask is None:
       mask = torch.ones(self.B, dtype=torch.bool, device=self.device)
+      self._host_steps = 0
     P = self.pool_qpos.shape[1]
     pick = torch.randint(0, P, (self.B,), device=self.device, generator=self._gen)
     m2 = mask[None, :]
@@ -156,10 +158,16 @@ class TorchBatchedEnv:
     self.ctrl.copy_(action.T.to(self.dtype))
     self.physics.step(self.n_sub_steps, stream=self._stream())
     self.steps += 1
+    self._host_steps += 1
     reward = self.reward().clone()
     done = self.steps >= self.step_limit
     obs = self.observation()
-    if bool(done.any()):
+    # The time limit is the only termination, and no environment has taken more steps than the
+    # host-side count since the last reset of everything: before that count reaches the limit
+    # nothing can be done, so the device is not asked (no host sync in the steady state).
+    if self._host_steps >= self.step_limit and bool(done.any()):
+      if bool(done.all()):
+        self._host_steps = 0
       obs = self.reset(done)
     return obs, reward, done
 
