@@ -3,6 +3,18 @@ import os
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 
 
+# Contact / constraint-row caps per domain where the library default (16 contacts) is too tight;
+# the humanoid's are free: its LDS footprint puts 4 environments on a CU either way.  The
+# model-specialised kernels are baked for exactly these caps (dm_control_amd/build.py).
+DEFAULT_CAPS = {'humanoid': dict(nconmax=24)}
+
+
+def physics_kwargs(domain, user_kwargs):
+  kw = dict(DEFAULT_CAPS.get(domain, {}))
+  kw.update(user_kwargs or {})
+  return kw
+
+
 def read_model(filename):
   """Physics-only restatement of the reference model of the same name."""
   with open(os.path.join(_ASSETS, filename)) as f:

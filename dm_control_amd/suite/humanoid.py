@@ -25,7 +25,7 @@ def get_model_and_assets():
 
 def _make(move_speed, pure_state):
   def factory(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None, physics_kwargs=None):
-    physics = Physics.from_xml_string(*get_model_and_assets(), **(physics_kwargs or {}))
+    physics = Physics.from_xml_string(*get_model_and_assets(), **common.physics_kwargs('humanoid', physics_kwargs))
     task = Humanoid(move_speed=move_speed, pure_state=pure_state, random=random)
     return control.Environment(physics, task, time_limit=time_limit, control_timestep=_CONTROL_TIMESTEP,
                                **(environment_kwargs or {}))

@@ -67,7 +67,8 @@ class TorchBatchedEnv:
       n_sub_steps = 1 if self._CONTROL_TIMESTEP is None else int(round(self._CONTROL_TIMESTEP / m.opt.timestep))
     self.n_sub_steps = n_sub_steps
     self.dtype = torch.float32 if precision == 32 else torch.float64
-    self.physics = BatchedPhysics(m, self.B, device_id=device_id, precision=precision)
+    self.physics = BatchedPhysics(m, self.B, device_id=device_id, precision=precision,
+                                  **common.DEFAULT_CAPS.get(self._MODEL[:-4], {}))
     mask = OUT['sensor']
     for name in self._OUTPUTS:
       mask |= OUT[{'subtree_com': 'subtree_com'}.get(name, name)]

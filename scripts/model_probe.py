@@ -15,7 +15,8 @@ for name, nsub, lanes_list in (('humanoid', 5, (64, 32)), ('cartpole', 1, (32, 1
   for prec in (32, 64):
     for lanes in lanes_list:
       try:
-        b = BatchedPhysics(m, B, precision=prec, lanes_per_env=lanes)
+        from dm_control_amd.suite import common
+        b = BatchedPhysics(m, B, precision=prec, lanes_per_env=lanes, **common.DEFAULT_CAPS.get(name, {}))
         q = np.tile(m.qpos0, (B, 1))
         if name == 'humanoid':
           q[:, 7:] += rs.uniform(-0.2, 0.2, (B, m.nq - 7))

@@ -9,7 +9,8 @@ m = mc.compile_xml(open(os.path.join(ROOT, 'dm_control_amd/suite/assets/humanoid
 B = 2048
 rs = np.random.RandomState(5)
 q0 = np.tile(m.qpos0, (B, 1)); q0[:, 7:] += rs.uniform(-0.2, 0.2, (B, m.nq - 7))
-b = BatchedPhysics(m, B, precision=32, lanes_per_env=64)
+from dm_control_amd.suite import common
+b = BatchedPhysics(m, B, precision=32, lanes_per_env=64, **common.DEFAULT_CAPS['humanoid'])
 b.set('qpos', q0); b.set_output_mask(OUT['sensor'] | OUT['xpos'] | OUT['xmat'] | OUT['subtree_com'])
 for t in range(60):
   b.set_control(rs.uniform(-1, 1, (B, m.nu))); b.step(5)
