@@ -525,6 +525,15 @@ struct StepCore {
 #define SI(n) (si + L.si_##n)
 #define FOR_LANES(i, n) for (int i = lane; i < (n); i += LPE)
 
+  // Opaque copy of an env index: stops the compiler from forming HBM addresses long before
+  // they are used and carrying them across the out-of-line stage calls (callee-saved VGPRs,
+  // spilled to scratch once there are too many).
+  DMC_DEV static int late(int env) {
+#ifndef DMC_HOST_EMU
+    asm volatile("" : "+v"(env));
+#endif
+    return env;
+  }
   // ---- state I/O (SoA in HBM <-> LDS) --------------------------------------
   DMC_DEV void load_state(const StepIO<T>& io, int env) {
     const int B = io.B;
@@ -552,6 +561,7 @@ struct StepCore {
     DMC_WSYNC();
   }
   DMC_DEV void store_state(const StepIO<T>& io, int env) {
+    env = late(env);
     const int B = io.B;
     FOR_LANES(i, L.d.nq) io.qpos[(size_t)i*B + env] = S(qpos)[i];
     FOR_LANES(i, L.d.nv) {
@@ -566,6 +576,7 @@ struct StepCore {
     if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) io.ctrl[(size_t)i*B + env] = S(ctrl)[i];
   }
   DMC_DEV void store_outputs(const StepIO<T>& io, int env, int mask) {
+    env = late(env);
     const int B = io.B;
     const int nb = L.d.nbody;
     if (mask & OUT_SENSOR) FOR_LANES(i, L.d.nsensordata) io.sensordata[(size_t)i*B + env] = S(sensordata)[i];
@@ -613,6 +624,7 @@ struct StepCore {
     if (mask & OUT_CVEL) FOR_LANES(i, 6*nb) io.cvel[(size_t)i*B + env] = S(cvel)[i];
   }
   DMC_DEV void dump_debug(const StepIO<T>& io, int env) {
+    env = late(env);
     if (!io.debug || env >= io.ndebug) return;
     FOR_LANES(i, L.n_sr) io.debug[(size_t)i*io.ndebug + env] = s[i];
     FOR_LANES(i, L.n_si) io.debug_i[(size_t)i*io.ndebug + env] = si[i];
@@ -1682,12 +1694,18 @@ struct StepCore {
       else if (t == DMC_SENS_SUBTREECOM) for (int k = 0; k < 3; k++) out[k] = S(subtree_com)[3*id + k];
       else if (t >= DMC_SENS_FRAMEXAXIS && t <= DMC_SENS_FRAMEZAXIS) {
         const int ot = MI(sensor_objtype)[i], c = t - DMC_SENS_FRAMEXAXIS;
-        T q[4], R[9];
-        const T* Rp = R;
-        if (ot == DMC_OBJ_SITE) { mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id); quat2mat(R, q); }
-        else if (ot == DMC_OBJ_BODY) { mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id); quat2mat(R, q); }
-        else Rp = ot == DMC_OBJ_GEOM ? S(geom_xmat) + 9*id : S(xmat) + 9*id;
-        out[0] = Rp[c]; out[1] = Rp[3 + c]; out[2] = Rp[6 + c];
+        if (ot == DMC_OBJ_SITE || ot == DMC_OBJ_BODY) {
+          // column c of quat2mat(q) = q rotating the unit vector e_c (no matrix held in memory:
+          // selecting between a local array and an LDS array through a pointer pins it in scratch)
+          T q[4], e[3] = {c == 0 ? (T)1 : (T)0, c == 1 ? (T)1 : (T)0, c == 2 ? (T)1 : (T)0}, col[3];
+          if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
+          else mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id);
+          rot_vec_quat(col, e, q);
+          out[0] = col[0]; out[1] = col[1]; out[2] = col[2];
+        } else {
+          const T* Rp = ot == DMC_OBJ_GEOM ? S(geom_xmat) + 9*id : S(xmat) + 9*id;
+          out[0] = Rp[c]; out[1] = Rp[3 + c]; out[2] = Rp[6 + c];
+        }
       }
       else if (t == DMC_SENS_FRAMEPOS) {
         const int ot = MI(sensor_objtype)[i];
@@ -2324,12 +2342,14 @@ struct StepCore {
   DMC_DEV void call_euler() { euler(); }
 #endif
   DMC_DEV void load_ctrl_seq(const StepIO<T>& io, int env, int t) {
+    env = late(env);
     const int B = io.B, nu = L.d.nu;
     DMC_WSYNC();
     FOR_LANES(i, nu) S(ctrl)[i] = io.ctrl_seq[((size_t)t*nu + i)*B + env];
     DMC_WSYNC();
   }
   DMC_DEV void store_seq(const StepIO<T>& io, int env, int t) {
+    env = late(env);
     const int B = io.B;
     if (io.qpos_seq) FOR_LANES(i, L.d.nq) io.qpos_seq[((size_t)t*L.d.nq + i)*B + env] = S(qpos)[i];
     if (io.qvel_seq) FOR_LANES(i, L.d.nv) io.qvel_seq[((size_t)t*L.d.nv + i)*B + env] = S(qvel)[i];
