@@ -60,3 +60,21 @@ def test_product_never_imports_oracle():
           txt = f.read()
         assert 'import oracle' not in txt and 'from oracle' not in txt, fn
         assert 'mjstep_oracle' not in txt.replace('oracle/mjstep_oracle.c)', ''), fn
+
+
+def test_hot_kernel_keeps_its_locals_out_of_scratch(tmp_path):
+  """Regression guard for profiles/r01_hbm_traffic.json: dynamically indexed locals / spills in
+  the fused step kernel turn into HBM writes (17.8 MB per launch at one point).  The cheetah
+  instantiation the bench runs may only use the few bytes its out-of-line calls need."""
+  import subprocess
+  from dm_control_amd import build
+  build.generate_static_layouts()
+  src = os.path.join(build.CSRC, 'step_kernels_f32.hip')
+  out = str(tmp_path / 'f32.s')
+  subprocess.check_call([build.HIPCC] + build._COMMON + ['-S', '--cuda-device-only', src, '-o', out],
+                        stderr=subprocess.DEVNULL)
+  text = open(out).read()
+  sizes = dict(re.findall(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)', text))
+  bench_kernel = [k for k in sizes if 'step_kernel_staticIfLi32ELi0' in k]
+  assert bench_kernel, sorted(sizes)[:5]
+  assert int(sizes[bench_kernel[0]]) <= 32, sizes[bench_kernel[0]]
