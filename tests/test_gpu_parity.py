@@ -480,3 +480,43 @@ def test_elliptic_contact_force_equals_weight_on_gpu():
   np.testing.assert_allclose(b.get('sensordata')[:, 0], 9.81 * m.body_mass[1], rtol=0, atol=1e-6)
   np.testing.assert_array_equal(b.get('nefc')[:, 0], 12)
   b.close()
+
+
+@pytest.mark.parametrize('name,nsub', [('hopper', 4), ('humanoid', 5)])
+def test_rollout_with_acceleration_stage_sensors(name, nsub):
+  """Sensors are only evaluated in the passes whose values can be observed; with several
+  substeps per env-step and acceleration-stage sensors (touch, accelerometer, force / torque) the
+  one-launch rollout must still report exactly what the launch-per-step loop reports."""
+  import torch
+  m = _model(name)
+  B, T = 8, 12
+  rs = np.random.RandomState(4)
+  q = np.tile(m.qpos0, (B, 1))
+  if name == 'hopper':
+    q[:, 1] -= 0.35                      # start touching the ground: touch sensors fire
+  acts = rs.uniform(-1, 1, (T, B, m.nu))
+  loop = _batch(m, B, precision=64)
+  loop.set('qpos', q)
+  want_q, want_s = [], []
+  for t in range(T):
+    loop.set_control(acts[t])
+    loop.step(nsub)
+    want_q.append(loop.get('qpos')); want_s.append(loop.get('sensordata'))
+  assert np.abs(np.stack(want_s)).max() > 0
+  ro = _batch(m, B, precision=64)
+  ro.set('qpos', q)
+  ctrl = torch.from_numpy(np.ascontiguousarray(acts.transpose(0, 2, 1))).to('cuda').contiguous()
+  qs = torch.zeros((T, m.nq, B), dtype=torch.float64, device='cuda')
+  ss = torch.zeros((T, m.nsensordata, B), dtype=torch.float64, device='cuda')
+  ro.rollout(T, nsub, ctrl.data_ptr(), qs.data_ptr(), None, ss.data_ptr())
+  ro.sync()
+  np.testing.assert_array_equal(qs.cpu().numpy().transpose(0, 2, 1), np.stack(want_q))
+  np.testing.assert_array_equal(ss.cpu().numpy().transpose(0, 2, 1), np.stack(want_s))
+  # and against the oracle, which evaluates every sensor in every step
+  ora = _oracles(m, q)
+  from oracle import oracle
+  for t in range(T):
+    oracle.rollout_legacy(ora, acts[t][None], nsub=nsub)
+  so = np.stack([o.sensordata for o in ora])
+  np.testing.assert_allclose(want_s[-1], so, rtol=1e-7, atol=1e-7 * max(1.0, np.abs(so).max()))
+  loop.close(); ro.close()
