@@ -240,14 +240,6 @@ template <int LPE, typename V> DMC_DEV V group_sum(V v) {
 #endif
   return v;
 }
-// value held by lane `k` of the group (k group-uniform)
-template <int LPE, typename V> DMC_DEV V group_bcast(V v, int k) {
-#ifndef DMC_HOST_EMU
-  return __shfl(v, k, LPE);
-#else
-  (void)k; return v;
-#endif
-}
 // value held by lane `k` of each group when k is WAVE-uniform (a loop counter): v_readlane
 // into an SGPR (one per group of the wave) instead of a trip through the LDS crossbar
 #ifndef DMC_HOST_EMU
