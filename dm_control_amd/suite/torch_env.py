@@ -284,8 +284,110 @@ class Humanoid(TorchBatchedEnv):
     return small_control * stand_reward * (5 * move + 1) / 6
 
 
+class _RandomJointStart(TorchBatchedEnv):
+  """Start states = randomize_limited_and_rotational_joints (suite/utils/randomizers.py:35-88): limited
+  hinges / sliders ~ U(range), unlimited hinges ~ U(-pi, pi); a pool of B such states, drawn on reset."""
+
+  def _make_start_pool(self):
+    m = self.model
+    q = np.tile(m.qpos0, (self.B, 1))
+    for j in range(m.njnt):
+      t, a = m.jnt_type[j], m.jnt_qposadr[j]
+      if m.jnt_limited[j] and t in (2, 3):
+        q[:, a] = self._rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], self.B)
+      elif t == 3:
+        q[:, a] = self._rs.uniform(-np.pi, np.pi, self.B)
+    self._upload_qpos(q)
+    self.pool_qpos = self.qpos.clone()
+    self.pool_qvel = self.torch.zeros_like(self.qvel)
+    self.pool_warm = self.torch.zeros_like(self.warm)
+
+  def _sensor(self, name, n):
+    adr = self.model.sensor_adr[self.model.name2id(name, 'sensor')]
+    return self.sensordata[adr:adr + n]
+
+
+class Walker(_RandomJointStart):
+  """Planar walker stand / walk / run (suite/walker.py:41-132) on device."""
+
+  _MODEL = 'walker.xml'
+  _OUTPUTS = ('xpos', 'xmat')
+  _CONTROL_TIMESTEP = .025
+  _STAND_HEIGHT = 1.2
+
+  def __init__(self, batch_size, move_speed=0.0, time_limit=25.0, **kw):
+    self.move_speed = float(move_speed)
+    super().__init__(batch_size, time_limit=time_limit, **kw)
+
+  def torso_height(self):
+    b = self._body('torso')
+    return self.xpos[3*b + 2]
+
+  def torso_upright(self):
+    return self.xmat[9*self._body('torso') + 8]
+
+  def observation(self):
+    """(B, 2 (nbody-1) + 1 + nv): orientations (xx, xz of every body), height, velocity."""
+    nb = self.model.nbody
+    xm = self.xmat.reshape(nb, 9, self.B)[1:]
+    orient = self.torch.stack([xm[:, 0], xm[:, 2]], dim=1).reshape(2 * (nb - 1), self.B)
+    return self.torch.cat([orient, self.torso_height()[None], self.qvel], dim=0).T
+
+  def reward(self):
+    torch = self.torch
+    standing = tolerance(torch, self.torso_height(), bounds=(self._STAND_HEIGHT, float('inf')), margin=self._STAND_HEIGHT / 2)
+    upright = (1 + self.torso_upright()) / 2
+    stand_reward = (3 * standing + upright) / 4
+    if self.move_speed == 0:
+      return stand_reward
+    speed = self._sensor('torso_subtreelinvel', 3)[0]
+    move = tolerance(torch, speed, bounds=(self.move_speed, float('inf')), margin=self.move_speed / 2,
+                     value_at_margin=0.5, sigmoid='linear')
+    return stand_reward * (5 * move + 1) / 6
+
+
+class Hopper(_RandomJointStart):
+  """Hopper stand / hop (suite/hopper.py:62-140) on device."""
+
+  _MODEL = 'hopper.xml'
+  _OUTPUTS = ('xipos',)
+  _CONTROL_TIMESTEP = .02
+  _STAND_HEIGHT = 0.6
+  _HOP_SPEED = 2.0
+
+  def __init__(self, batch_size, hopping=False, time_limit=20.0, **kw):
+    self.hopping = bool(hopping)
+    super().__init__(batch_size, time_limit=time_limit, **kw)
+
+  def height(self):
+    return self.xipos[3*self._body('torso') + 2] - self.xipos[3*self._body('foot') + 2]
+
+  def touch(self):
+    return self.torch.log1p(self.torch.cat([self._sensor('touch_toe', 1), self._sensor('touch_heel', 1)], dim=0))
+
+  def observation(self):
+    """(B, nq-1 + nv + 2): position without the root x, velocity, touch."""
+    return self.torch.cat([self.qpos[1:], self.qvel, self.touch()], dim=0).T
+
+  def reward(self):
+    torch = self.torch
+    standing = tolerance(torch, self.height(), bounds=(self._STAND_HEIGHT, 2))
+    if self.hopping:
+      speed = self._sensor('torso_subtreelinvel', 3)[0]
+      hopping = tolerance(torch, speed, bounds=(self._HOP_SPEED, float('inf')), margin=self._HOP_SPEED / 2,
+                          value_at_margin=0.5, sigmoid='linear')
+      return standing * hopping
+    small_control = tolerance(torch, self.ctrl, margin=1, value_at_margin=0, sigmoid='quadratic').mean(dim=0)
+    return standing * (small_control + 4) / 5
+
+
 _TASKS = {
     ('cheetah', 'run'): (CheetahRun, {}),
+    ('walker', 'stand'): (Walker, dict(move_speed=0)),
+    ('walker', 'walk'): (Walker, dict(move_speed=1)),
+    ('walker', 'run'): (Walker, dict(move_speed=8)),
+    ('hopper', 'stand'): (Hopper, dict(hopping=False)),
+    ('hopper', 'hop'): (Hopper, dict(hopping=True)),
     ('humanoid', 'stand'): (Humanoid, dict(move_speed=0)),
     ('humanoid', 'walk'): (Humanoid, dict(move_speed=1)),
     ('humanoid', 'run'): (Humanoid, dict(move_speed=10)),

@@ -607,3 +607,33 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   assert (errs <= 5e-5).mean() >= 0.98, (errs <= 5e-5).mean()
   assert not b.get('warning').any()
   b.close()
+
+
+@pytest.mark.parametrize('domain,task', [('walker', 'run'), ('walker', 'stand'), ('hopper', 'hop'), ('hopper', 'stand')])
+def test_torch_env_matches_host_task(domain, task):
+  """Device-resident walker / hopper: observations and rewards equal the host task evaluated on the
+  same state (the host Physics is fed the device env's qpos / qvel / ctrl)."""
+  import torch
+  from dm_control_amd import suite
+  from dm_control_amd.suite import torch_env
+  B = 24
+  dev = torch_env.make(domain, task, B, precision=64, seed=3)
+  host = suite.load(domain, task, task_kwargs=dict(random=0), physics_kwargs=dict(batch_size=B, precision=64))
+  host.reset()
+  g = torch.Generator(device='cuda').manual_seed(1)
+  for t in range(6):
+    a = torch.rand((B, dev.model.nu), device='cuda', generator=g, dtype=torch.float64) * 2 - 1
+    q_before, v_before = dev.physics.get('qpos'), dev.physics.get('qvel')
+    w_before = dev.physics.get('qacc_warmstart')
+    obs, rew, done = dev.step(a)
+    # replay the same env-step on the host-facade physics from the same state
+    hp = host.physics
+    hp.data.qpos = q_before; hp.data.qvel = v_before; hp.data.qacc_warmstart = w_before
+    hp.forward()
+    hp.data.qacc_warmstart = w_before
+    host.task.before_step(a.cpu().numpy(), hp)
+    hp.step(dev.n_sub_steps)
+    want_obs = np.concatenate([np.asarray(v).reshape(B, -1) for v in host.task.get_observation(hp).values()], axis=1)
+    np.testing.assert_allclose(obs.cpu().numpy(), want_obs, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(rew.cpu().numpy(), host.task.get_reward(hp), rtol=1e-7, atol=1e-9)
+  dev.close(); host.physics.free()
