@@ -88,6 +88,8 @@ class BatchedPhysics:
 
   def set(self, name, value):
     rows, is_int = self._rows(name)
+    if not rows:
+      return
     dt = np.int32 if is_int else np.float64
     a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=dt).reshape(
         (-1, rows) if np.ndim(value) > 1 else (1, rows) if np.ndim(value) == 1 else (1, 1)),

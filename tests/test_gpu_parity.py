@@ -520,3 +520,35 @@ def test_rollout_with_acceleration_stage_sensors(name, nsub):
   so = np.stack([o.sensordata for o in ora])
   np.testing.assert_allclose(want_s[-1], so, rtol=1e-7, atol=1e-7 * max(1.0, np.abs(so).max()))
   loop.close(); ro.close()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_models_match_oracle(seed):
+  """Parity fuzzing (tests/random_models.py): random articulated models -- free / ball / hinge / slide
+  joints, several roots, capsule / sphere contacts, pyramidal and elliptic cones of every condim, Euler and
+  RK4, fluid drag, motors / servos, random sensors -- fp64 kernel vs oracle, lane widths rotating with
+  the seed.  Tolerance: the two solvers stop at MuJoCo's 1e-8 tolerance and may stop ~1e-8 apart in
+  qacc where their iteration paths differ in the last bits (see tests/test_random_models.py)."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from random_models import random_model_xml
+  m = mc.compile_xml(random_model_xml(seed))
+  B = 4
+  rs = np.random.RandomState(1000 + seed)
+  q = np.tile(m.qpos0, (B, 1))
+  v = rs.uniform(-.5, .5, (B, m.nv))
+  b = _batch(m, B, precision=64, lanes_per_env=(64, 32, 16)[seed % 3])
+  b.set('qpos', q); b.set('qvel', v)
+  ora = _oracles(m, q, v)
+  from oracle import oracle
+  for t in range(15):
+    a = rs.uniform(-1, 1, (B, m.nu))
+    b.set_control(a)
+    b.step(10)
+    oracle.rollout_legacy(ora, a[None], nsub=10)
+  qo = np.stack([o.qpos for o in ora])
+  assert _rel_err(b.get('qpos'), qo) <= 1e-6
+  so = np.stack([o.sensordata for o in ora])
+  np.testing.assert_allclose(b.get('sensordata'), so, rtol=0, atol=1e-5 * max(1.0, np.abs(so).max()))
+  np.testing.assert_array_equal(b.get('warning').sum(axis=0), np.sum([o.warning for o in ora], axis=0))
+  b.close()
