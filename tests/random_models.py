@@ -60,7 +60,8 @@ def random_model_xml(seed):
       else:
         ax = rs.choice(['0 1 0', '0 0 1', '1 1 0'])
         lim = rs.rand() < .6
-        lines.append('<joint name="j%d" type="hinge" axis="%s"%s/>' % (k, ax, ' range="-70 70" limited="true"' if lim else ''))
+        fl = ' frictionloss="%g"' % rs.uniform(.01, .2) if rs.rand() < .25 else ''
+        lines.append('<joint name="j%d" type="hinge" axis="%s"%s%s/>' % (k, ax, ' range="-70 70" limited="true"' if lim else '', fl))
         joints.append('j%d' % k)
     if rs.rand() < .7:
       lines.append('<geom name="g%d" type="capsule" fromto="0 0 0 %g %g %g" size="%g"/>' % (
@@ -80,6 +81,22 @@ def random_model_xml(seed):
   for _ in range(nroots):
     out += body(0, 0.0)
   out.append('</worldbody>')
+  tendons, eqs = [], []
+  hinges = [j for j in joints]
+  if len(hinges) >= 2 and rs.rand() < .5:
+    j1, j2 = rs.choice(hinges, 2, replace=False)
+    tendons.append('<fixed name="tf"%s><joint joint="%s" coef="%g"/><joint joint="%s" coef="%g"/></fixed>' % (
+        ' stiffness="%g" damping="%g"' % (rs.uniform(0, 3), rs.uniform(0, .2)) if rs.rand() < .5 else '',
+        j1, rs.uniform(.3, 1), j2, -rs.uniform(.3, 1)))
+    if rs.rand() < .3:
+      eqs.append('<tendon tendon1="tf" solref=".01 1"/>')
+  if len(sites) >= 2 and rs.rand() < .4:
+    tendons.append('<spatial name="ts" limited="true" range="0 %g"><site site="%s"/><site site="%s"/></spatial>' % (
+        rs.uniform(.3, .8), sites[0], sites[-1]))
+  if tendons:
+    out += ['<tendon>'] + tendons + ['</tendon>']
+  if eqs:
+    out += ['<equality>'] + eqs + ['</equality>']
   if joints:
     acts = []
     for j in joints:
@@ -90,6 +107,8 @@ def random_model_xml(seed):
           acts.append('<position name="a_%s" joint="%s" kp="%g" ctrllimited="true" ctrlrange="-1 1"/>' % (j, j, rs.uniform(1, 10)))
     if not acts:
       acts.append('<motor name="a0" joint="%s" gear="1"/>' % joints[0])
+    if any('name="tf"' in t for t in tendons) and not eqs:
+      acts.append('<motor name="a_tf" tendon="tf" gear="%g"/>' % rs.uniform(.5, 3))
     out += ['<actuator>'] + acts + ['</actuator>']
   sens = []
   for s in sites:
@@ -106,6 +125,14 @@ def random_model_xml(seed):
       sens.append('<framepos objtype="site" objname="%s"/>' % s)
     elif r < .78:
       sens.append('<force site="%s"/>' % s)
+    elif r < .84:
+      sens.append('<torque site="%s"/>' % s)
+    elif r < .9:
+      sens.append('<frame%saxis objtype="site" objname="%s"/>' % (rs.choice(['x', 'y', 'z']), s))
   sens.append('<subtreelinvel body="%s"/>' % bodies[0])
+  sens.append('<subtreecom body="%s"/>' % bodies[-1])
+  if joints:
+    sens.append('<jointpos joint="%s"/>' % joints[0])
+    sens.append('<jointvel joint="%s"/>' % joints[-1])
   out += ['<sensor>'] + sens + ['</sensor>', '</mujoco>']
   return '\n'.join(out)
