@@ -90,13 +90,7 @@ template <int SID> struct StaticLayout;
     static constexpr int kNV = DMC_STATIC_NV_##ID;   /* compile-time nv: register-resident Cholesky */ \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
-DMC_DEF_STATIC(0)
-#if DMC_NSTATIC > 1
-DMC_DEF_STATIC(1)
-#endif
-#if DMC_NSTATIC > 2
-DMC_DEF_STATIC(2)
-#endif
+DMC_STATIC_IDS(DMC_DEF_STATIC)
 #undef DMC_DEF_STATIC
 
 template <typename T, int LPE, int SID>

@@ -9,7 +9,10 @@ from dm_control_amd.batch import BatchedPhysics, OUT
 import torch
 B = int(os.environ.get('B', 4096))
 out = []
-for name, nsub, lanes_list in (('humanoid', 5, (64, 32)), ('cartpole', 1, (32, 16)), ('cheetah', 1, (32,))):
+_ALL = (('humanoid', 5, (64, 32)), ('cartpole', 1, (32, 16)), ('cheetah', 1, (32,)),
+        ('walker', 10, (32,)), ('hopper', 4, (32,)))
+_SEL = os.environ.get('MODELS')
+for name, nsub, lanes_list in [x for x in _ALL if not _SEL or x[0] in _SEL.split(',')]:
   m = mc.compile_xml(open(os.path.join(ROOT, 'dm_control_amd/suite/assets/%s.xml' % name)).read())
   rs = np.random.RandomState(0)
   for prec in (32, 64):
@@ -40,4 +43,4 @@ for name, nsub, lanes_list in (('humanoid', 5, (64, 32)), ('cartpole', 1, (32, 1
         r = dict(model=name, prec=prec, lanes=lanes, error=repr(ex))
       print(json.dumps(r), flush=True)
       out.append(r)
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'model_probe.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', os.environ.get('OUTNAME', 'model_probe.json')), 'w'), indent=1)
