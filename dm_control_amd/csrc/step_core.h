@@ -868,6 +868,138 @@ struct StepCore {
   DMC_DEV static void put_hit(Hits* h, int n, const Hit& x) {
     sel_hit(h->s0, x, n == 0); sel_hit(h->s1, x, n == 1); sel_hit(h->s2, x, n == 2); sel_hit(h->s3, x, n == 3);
   }
+  // ---- ellipsoid pairs: signed distance = max over unit n of the support-function gap F(n),
+  // Newton iteration on the unit sphere; a capsule is its swept sphere minimised over the axis
+  // parameter (regula falsi on n.axis).  Same iteration, same operation order as the oracle's
+  // "ellipsoid pairs" section; everything lives in registers (constant indexing only).
+  struct Quadric { T c[3], R[9], s[3]; };
+  DMC_DEV static constexpr T ccd_tol() { return sizeof(T) == 8 ? (T)1e-10 : (T)1e-4; }
+  DMC_DEV static constexpr int ccd_maxit() { return sizeof(T) == 8 ? 30 : 12; }
+  DMC_DEV static T quadric_support(const Quadric& q, const T* n, T* g, T* wh) {
+    T w[3];
+    for (int k = 0; k < 3; k++) w[k] = q.s[k]*(q.R[k]*n[0] + q.R[3 + k]*n[1] + q.R[6 + k]*n[2]);
+    const T wn = t_sqrt(dot3(w, w));
+    if (wn < (T)DMC_MINVAL) { g[0] = g[1] = g[2] = 0; wh[0] = wh[1] = wh[2] = 0; return 0; }
+    T v[3];
+    for (int k = 0; k < 3; k++) { wh[k] = w[k]/wn; v[k] = q.s[k]*wh[k]; }
+    mul_mat_vec3(g, q.R, v);
+    return wn;
+  }
+  DMC_DEV static void quadric_curv(const Quadric& q, const T* wh, T wn, const T* t1, const T* t2, T* K) {
+    if (wn < (T)DMC_MINVAL) return;
+    T y1[3], y2[3];
+    for (int k = 0; k < 3; k++) {
+      y1[k] = q.s[k]*(q.R[k]*t1[0] + q.R[3 + k]*t1[1] + q.R[6 + k]*t1[2]);
+      y2[k] = q.s[k]*(q.R[k]*t2[0] + q.R[3 + k]*t2[1] + q.R[6 + k]*t2[2]);
+    }
+    const T a1 = dot3(y1, wh), a2 = dot3(y2, wh);
+    K[0] += (dot3(y1, y1) - a1*a1)/wn; K[1] += (dot3(y1, y2) - a1*a2)/wn; K[2] += (dot3(y2, y2) - a2*a2)/wn;
+  }
+  DMC_DEV static T quadric_gap_value(const Quadric& A, const Quadric& B, const T* n) {
+    T g[3], wh[3], d[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
+    const T hA = quadric_support(A, n, g, wh), hB = quadric_support(B, n, g, wh);
+    return dot3(n, d) - hA - hB;
+  }
+  DMC_DEV static T quadric_gap(const Quadric& A, const Quadric& B, T* n, T* gA, T* gB) {
+    const T d[3] = {B.c[0] - A.c[0], B.c[1] - A.c[1], B.c[2] - A.c[2]};
+    T F = 0;
+    for (int it = 0; ; it++) {
+      T wA[3], wB[3];
+      const T hA = quadric_support(A, n, gA, wA), hB = quadric_support(B, n, gB, wB);
+      F = dot3(n, d) - hA - hB;
+      if (it >= ccd_maxit()) break;
+      T f[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+      make_frame(f);
+      const T *t1 = f + 3, *t2 = f + 6;
+      const T grad[3] = {d[0] - gA[0] - gB[0], d[1] - gA[1] - gB[1], d[2] - gA[2] - gB[2]};
+      const T g1 = dot3(t1, grad), g2 = dot3(t2, grad);
+      T K[3] = {F, 0, F};
+      quadric_curv(A, wA, hA, t1, t2, K); quadric_curv(B, wB, hB, t1, t2, K);
+      const T tr = K[0] + K[2];
+      T det = K[0]*K[2] - K[1]*K[1];
+      const T floor_ = (T)1e-3*(hA + hB) + (T)DMC_MINVAL;
+      const T lmin = (T)0.5*(tr - t_sqrt(t_max((T)0, tr*tr - 4*det)));
+      if (lmin < floor_) { const T sh = floor_ - lmin; K[0] += sh; K[2] += sh; det = K[0]*K[2] - K[1]*K[1]; }
+      T d1 = (K[2]*g1 - K[1]*g2)/det, d2 = (K[0]*g2 - K[1]*g1)/det;
+      if (d1*d1 + d2*d2 < ccd_tol()*ccd_tol()) break;
+      T nn[3];
+      for (int ls = 0; ; ls++) {
+        for (int k = 0; k < 3; k++) nn[k] = n[k] + t1[k]*d1 + t2[k]*d2;
+        normalize3(nn);
+        if (ls >= 8 || quadric_gap_value(A, B, nn) >= F) break;
+        d1 *= (T)0.5; d2 *= (T)0.5;
+      }
+      n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
+    }
+    return F;
+  }
+  DMC_DEV static void quadric_init_dir(const Quadric& A, const Quadric& B, T* n) {
+    for (int k = 0; k < 3; k++) n[k] = B.c[k] - A.c[k];
+    if (dot3(n, n) < (T)DMC_MINVAL*(T)DMC_MINVAL) { n[0] = 1; n[1] = n[2] = 0; }
+    normalize3(n);
+  }
+  DMC_DEV static int quadric_contact(Hit* h, T margin, const Quadric& A, const Quadric& B, T* n) {
+    T gA[3], gB[3];
+    const T dist = quadric_gap(A, B, n, gA, gB);
+    if (dist > margin) return 0;
+    h->dist = dist;
+    for (int k = 0; k < 3; k++) { h->pos[k] = (T)0.5*((A.c[k] + gA[k]) + (B.c[k] - gB[k])); h->nrm[k] = n[k]; }
+    return 1;
+  }
+  DMC_DEV static Quadric make_quadric(int type, const T* pos, const T* mat, const T* size) {
+    Quadric q;
+    for (int k = 0; k < 3; k++) { q.c[k] = pos[k]; q.s[k] = type == DMC_GEOM_ELLIPSOID ? size[k] : size[0]; }
+    for (int k = 0; k < 9; k++) q.R[k] = mat[k];
+    return q;
+  }
+  // geom 2 is an ellipsoid; geom 1 a plane-less partner (sphere, capsule or ellipsoid)
+  DMC_DEV static int ellipsoid_pair(Hit* h, T margin, int t1, const T* p1, const T* m1, const T* s1,
+                                    const T* p2, const T* m2, const T* s2) {
+    Quadric A = make_quadric(t1 == DMC_GEOM_CAPSULE ? DMC_GEOM_SPHERE : t1, p1, m1, s1);
+    const Quadric B = make_quadric(DMC_GEOM_ELLIPSOID, p2, m2, s2);
+    T n[3];
+    if (t1 != DMC_GEOM_CAPSULE) { quadric_init_dir(A, B, n); return quadric_contact(h, margin, A, B, n); }
+    const T u[3] = {m1[2], m1[5], m1[8]};
+    const T hl = s1[1];
+    T gA[3], gB[3];
+    T tlo = -hl, thi = hl, plo, phi = 0, t;
+    for (int k = 0; k < 3; k++) A.c[k] = p1[k] + u[k]*tlo;
+    quadric_init_dir(A, B, n);
+    quadric_gap(A, B, n, gA, gB); plo = dot3(n, u);
+    if (plo <= 0) t = tlo;
+    else {
+      for (int k = 0; k < 3; k++) A.c[k] = p1[k] + u[k]*thi;
+      quadric_gap(A, B, n, gA, gB); phi = dot3(n, u);
+      if (phi >= 0) t = thi;
+      else {
+        t = 0;
+        int side = 0;
+        for (int it = 0; it < 40; it++) {
+          t = (tlo*phi - thi*plo)/(phi - plo);
+          for (int k = 0; k < 3; k++) A.c[k] = p1[k] + u[k]*t;
+          quadric_gap(A, B, n, gA, gB);
+          const T pt = dot3(n, u);
+          if (t_abs(pt) < ccd_tol() || thi - tlo < ccd_tol()*hl) break;
+          if (pt > 0) { tlo = t; plo = pt; if (side == 1) phi *= (T)0.5; side = 1; }
+          else { thi = t; phi = pt; if (side == -1) plo *= (T)0.5; side = -1; }
+        }
+      }
+    }
+    for (int k = 0; k < 3; k++) A.c[k] = p1[k] + u[k]*t;
+    return quadric_contact(h, margin, A, B, n);
+  }
+  DMC_DEV static int plane_ellipsoid(Hit* h, T margin, const T* p1, const T* nrm, const T* p2, const T* m2, const T* s2) {
+    const Quadric q = make_quadric(DMC_GEOM_ELLIPSOID, p2, m2, s2);
+    T g[3], wh[3];
+    quadric_support(q, nrm, g, wh);
+    const T pt[3] = {p2[0] - g[0], p2[1] - g[1], p2[2] - g[2]};
+    const T dif[3] = {pt[0] - p1[0], pt[1] - p1[1], pt[2] - p1[2]};
+    const T dist = dot3(dif, nrm);
+    if (dist > margin) return 0;
+    h->dist = dist;
+    for (int k = 0; k < 3; k++) { h->pos[k] = pt[k] - nrm[k]*dist*(T)0.5; h->nrm[k] = nrm[k]; }
+    return 1;
+  }
   // narrow phase for one pair; returns the mask of valid slots of h[0..3]
   // (slot order = MuJoCo's contact order); tang = optional shared tangent
   DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang, bool* guard) {
@@ -916,6 +1048,7 @@ struct StepCore {
         }
         return (1 << cnt) - 1;
       }
+      if (L.d.nell && t2 == DMC_GEOM_ELLIPSOID) return plane_ellipsoid(&h->s0, margin, p1, nrm, p2, m2, s2);
       return 0;
     }
     {
@@ -923,6 +1056,7 @@ struct StepCore {
       T bound = MR(geom_rbound)[g1] + MR(geom_rbound)[g2] + margin;
       if (dot3(dif, dif) > bound*bound) return 0;
     }
+    if (L.d.nell && t2 == DMC_GEOM_ELLIPSOID) return ellipsoid_pair(&h->s0, margin, t1, p1, m1, s1, p2, m2, s2);
     if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) return sphere_sphere(&h->s0, margin, p1, s1[0], p2, s2[0]);
     if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) {
       T axis[3] = {m2[2], m2[5], m2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
@@ -967,6 +1101,9 @@ struct StepCore {
     }
     return 0;
   }
+  // contact-parameter tuple of a candidate pair; a model whose pairs all share one tuple (cheetah,
+  // walker, ... in their specialised kernels) needs no lookup at all
+  DMC_DEV int prm_of(int pair) const { return L.d.nprm == 1 ? 0 : MI(pair_prm)[pair]; }
   DMC_DEV void collision() {
     int base = 0;
     const bool enabled = !(o.disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT));
@@ -979,7 +1116,7 @@ struct StepCore {
       if (p < npair) {
         g1 = MI(pair_geom1)[p]; g2 = MI(pair_geom2)[p];
         bool guard;
-        mask = narrow_phase(g1, g2, MR(pair_margin)[p], &h, tang, &has_tang, &guard);
+        mask = narrow_phase(g1, g2, MR(prm_margin)[prm_of(p)], &h, tang, &has_tang, &guard);
         if (guard) { if (mask) unresolved = 1; mask = 0; }
       }
       const int n = __builtin_popcount(mask);
@@ -1158,7 +1295,7 @@ struct StepCore {
       if (c < ncon) {
         const int p = SI(con_pair)[c];
         dim = MI(pair_dim)[p];
-        incl = MR(pair_margin)[p] - MR(pair_gap)[p];
+        incl = MR(prm_margin)[prm_of(p)] - MR(prm_gap)[prm_of(p)];
         nrow = contact_rows(dim);
         if (S(con_dist)[c] >= incl) nrow = 0;   // in the gap: excluded
       }
@@ -1227,7 +1364,7 @@ struct StepCore {
       if (dim == 1) S(efc_J)[r0*nv + dd] = jac[0];
       else if (L.d.elliptic) for (int k = 0; k < dim; k++) S(efc_J)[(r0 + k)*nv + dd] = jac[k];
       else for (int k = 1; k < dim; k++) {
-        const T f = MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+        const T f = MR(prm_friction)[3*prm_of(cp) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
         S(efc_J)[(r0 + 2*(k - 1))*nv + dd] = jac[0] + f*jac[k];
         S(efc_J)[(r0 + 2*(k - 1) + 1)*nv + dd] = jac[0] + (-f)*jac[k];
       }
@@ -1257,22 +1394,22 @@ struct StepCore {
         const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
         const T tran = MR(body_invweight0)[2*b1] + MR(body_invweight0)[2*b2];
         const T rot = MR(body_invweight0)[2*b1 + 1] + MR(body_invweight0)[2*b2 + 1];
-        solref = MR(pair_solref) + 2*cp; solimp = MR(pair_solimp) + 5*cp;
+        solref = MR(prm_solref) + 2*prm_of(cp); solimp = MR(prm_solimp) + 5*prm_of(cp);
         if (type == EFC_FRICTIONLESS) dA = tran;
         else if (type == EFC_ELLIPTIC) {
           ell_row = i - SI(con_efc)[id];   // 0 normal, 1..2 slide, 3 torsion, 4..5 roll
           dA = ell_row < 3 ? tran : rot;
           if (ell_row > 0) {
-            mu = MR(pair_friction)[3*cp]; dA0 = tran;
-            ell_fj = MR(pair_friction)[3*cp + (ell_row < 3 ? 0 : (ell_row == 3 ? 1 : 2))];
-            ell_imp0 = get_impedance(solimp, S(con_dist)[id], MR(pair_margin)[cp] - MR(pair_gap)[cp]);
+            mu = MR(prm_friction)[3*prm_of(cp)]; dA0 = tran;
+            ell_fj = MR(prm_friction)[3*prm_of(cp) + (ell_row < 3 ? 0 : (ell_row == 3 ? 1 : 2))];
+            ell_imp0 = get_impedance(solimp, S(con_dist)[id], MR(prm_margin)[prm_of(cp)] - MR(prm_gap)[prm_of(cp)]);
           }
         } else {
           const int j = i - SI(con_efc)[id];
           const int k = j/2;   // friction index 0,1: slide; 2: torsion; 3,4: roll
-          const T fri = MR(pair_friction)[3*cp + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
+          const T fri = MR(prm_friction)[3*prm_of(cp) + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
           dA = tran + fri*fri*(j < 4 ? tran : rot);
-          mu = MR(pair_friction)[3*cp];
+          mu = MR(prm_friction)[3*prm_of(cp)];
           dA0 = tran + mu*mu*tran;
         }
       }
@@ -1495,7 +1632,7 @@ struct StepCore {
     if (dim == 1) { f6[0] = f[0]; return; }
     if (L.d.elliptic) { for (int k = 0; k < dim; k++) f6[k] = f[k]; return; }
     for (int k = 0; k < 2*(dim - 1); k++) f6[0] += f[k];
-    for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(pair_friction)[3*cp + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+    for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(prm_friction)[3*prm_of(cp) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
   }
   DMC_DEV void rne_post_constraint() {
     const int nb = L.d.nbody, ncon = SI(imisc)[IM_NCON];
@@ -1828,7 +1965,7 @@ struct StepCore {
       const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
       if (i != r0) continue;
       const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
-      const T* fr = MR(pair_friction) + 3*cp;
+      const T* fr = MR(prm_friction) + 3*prm_of(cp);
       const T D0 = S(efc_D)[r0];
       const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);   // regularised cone: mu sqrt(R1/R0)
       T U[6], fj[6], Tn = 0;
@@ -1926,7 +2063,7 @@ struct StepCore {
       const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
       if (i != r0) continue;
       const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
-      const T* fr = MR(pair_friction) + 3*cp;
+      const T* fr = MR(prm_friction) + 3*prm_of(cp);
       const T D0 = S(efc_D)[r0];
       const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);
       const T U0 = S(efc_jar)[r0]*mu, V0 = S(efc_jv)[r0]*mu;

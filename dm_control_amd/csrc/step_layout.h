@@ -29,6 +29,8 @@ struct StepDims {
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
   int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
   int neq;       // active equality constraints (single fixed tendon held at its reference length)
+  int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
+  int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
 };
 
 // ---- model tables (ints) -----------------------------------------------------
@@ -49,6 +51,7 @@ struct StepDims {
   X(tri_col, d.nv + 1)                /* first entry of each column in tri_i/tri_j */ \
   X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
   X(pair_geom1, d.npair) X(pair_geom2, d.npair) X(pair_dim, d.npair)           \
+  X(pair_prm, d.npair)         /* contact-parameter tuple of each pair */      \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \
   X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
   X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
@@ -74,8 +77,8 @@ struct StepDims {
   X(dof_solimp, d.nfric ? 5 * d.nv : 0)                                        \
   X(geom_size, 3 * d.ngeom) X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom) \
   X(geom_rbound, d.ngeom)                                                      \
-  X(pair_margin, d.npair) X(pair_gap, d.npair) X(pair_friction, 3 * d.npair)   \
-  X(pair_solref, 2 * d.npair) X(pair_solimp, 5 * d.npair)                      \
+  X(prm_margin, d.nprm) X(prm_gap, d.nprm) X(prm_friction, 3 * d.nprm)         \
+  X(prm_solref, 2 * d.nprm) X(prm_solimp, 5 * d.nprm)  /* distinct contact-parameter tuples */ \
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
   X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)       \

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -138,13 +139,15 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     if (cyl) d.ncyl++;
+    const bool ell = t2 == DMC_GEOM_ELLIPSOID && (t1 == DMC_GEOM_PLANE || t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE || t1 == DMC_GEOM_ELLIPSOID) && !cyl;
+    if (ell) d.nell++;
     int nc = 1;
     if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) nc = 2;
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) nc = 4;
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) nc = 1;   // 2 only for exactly parallel axes
     const bool known = (t1 == DMC_GEOM_PLANE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE || t2 == DMC_GEOM_BOX)) ||
                        (t1 == DMC_GEOM_SPHERE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE)) ||
-                       (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE);
+                       (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) || ell;
     if (!known) {
       // tolerated only while contacts are disabled (e.g. suite cartpole): the pair then never collides
       if (m.opt_disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)) { t->has_unsupported_pairs = 1; nc = 0; }
@@ -158,6 +161,38 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (cyl) nc = 0;
     maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
+  // contact parameters (mixing rules: max / priority / solmix).  Most pairs of a
+  // model share one parameter tuple (all geoms at their defaults), so the tuples are stored once and the
+  // pairs index them: humanoid_CMU has 1118 candidate pairs but 2 distinct tuples
+  std::vector<std::array<double, 12> > prm;
+  std::vector<int> pair_prm(m.npair);
+  for (int p = 0; p < m.npair; p++) {
+    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
+    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    std::array<double, 12> v;
+    v[0] = std::max(m.geom_margin[g1], m.geom_margin[g2]);
+    v[1] = std::max(m.geom_gap[g1], m.geom_gap[g2]);
+    double fr[3];
+    if (pr1 == pr2) for (int k = 0; k < 3; k++) fr[k] = std::max(m.geom_friction[3*g1 + k], m.geom_friction[3*g2 + k]);
+    else { const int gp = pr1 > pr2 ? g1 : g2; for (int k = 0; k < 3; k++) fr[k] = m.geom_friction[3*gp + k]; }
+    for (int k = 0; k < 3; k++) v[2 + k] = std::max((double)DMC_MINMU, fr[k]);
+    double mix;
+    if (pr1 != pr2) mix = pr1 > pr2 ? 1 : 0;
+    else {
+      const double sm1 = m.geom_solmix[g1], sm2 = m.geom_solmix[g2];
+      if (sm1 >= DMC_MINVAL && sm2 >= DMC_MINVAL) mix = sm1 / (sm1 + sm2);
+      else if (sm1 < DMC_MINVAL && sm2 < DMC_MINVAL) mix = 0.5;
+      else mix = sm1 < DMC_MINVAL ? 0.0 : 1.0;
+    }
+    const double *r1 = &m.geom_solref[2*g1], *r2 = &m.geom_solref[2*g2];
+    for (int k = 0; k < 2; k++) v[5 + k] = (r1[0] > 0 && r2[0] > 0) ? mix*r1[k] + (1 - mix)*r2[k] : std::min(r1[k], r2[k]);
+    for (int k = 0; k < 5; k++) v[7 + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
+    int q = 0;
+    while (q < (int)prm.size() && std::memcmp(prm[q].data(), v.data(), sizeof(double)*12)) q++;
+    if (q == (int)prm.size()) prm.push_back(v);
+    pair_prm[p] = q;
+  }
+  d.nprm = (int)prm.size();
   t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric + d.neq;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
@@ -244,27 +279,13 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   cpr(L.mr_dof_armature, m.dof_armature); cpr(L.mr_dof_damping, m.dof_damping); cpr(L.mr_dof_invweight0, m.dof_invweight0);
   cpr(L.mr_geom_size, m.geom_size); cpr(L.mr_geom_pos, m.geom_pos); cpr(L.mr_geom_quat, m.geom_quat);
   cpr(L.mr_geom_rbound, m.geom_rbound);
-  // per-pair contact parameters (mixing rules: max / priority / solmix), SURVEY.md Appendix A.5
-  for (int p = 0; p < m.npair; p++) {
-    const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
-    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
-    mr[L.mr_pair_margin + p] = std::max(m.geom_margin[g1], m.geom_margin[g2]);
-    mr[L.mr_pair_gap + p] = std::max(m.geom_gap[g1], m.geom_gap[g2]);
-    double fr[3];
-    if (pr1 == pr2) for (int k = 0; k < 3; k++) fr[k] = std::max(m.geom_friction[3*g1 + k], m.geom_friction[3*g2 + k]);
-    else { const int gp = pr1 > pr2 ? g1 : g2; for (int k = 0; k < 3; k++) fr[k] = m.geom_friction[3*gp + k]; }
-    for (int k = 0; k < 3; k++) mr[L.mr_pair_friction + 3*p + k] = std::max((double)DMC_MINMU, fr[k]);
-    double mix;
-    if (pr1 != pr2) mix = pr1 > pr2 ? 1 : 0;
-    else {
-      const double sm1 = m.geom_solmix[g1], sm2 = m.geom_solmix[g2];
-      if (sm1 >= DMC_MINVAL && sm2 >= DMC_MINVAL) mix = sm1 / (sm1 + sm2);
-      else if (sm1 < DMC_MINVAL && sm2 < DMC_MINVAL) mix = 0.5;
-      else mix = sm1 < DMC_MINVAL ? 0.0 : 1.0;
-    }
-    const double *r1 = &m.geom_solref[2*g1], *r2 = &m.geom_solref[2*g2];
-    for (int k = 0; k < 2; k++) mr[L.mr_pair_solref + 2*p + k] = (r1[0] > 0 && r2[0] > 0) ? mix*r1[k] + (1 - mix)*r2[k] : std::min(r1[k], r2[k]);
-    for (int k = 0; k < 5; k++) mr[L.mr_pair_solimp + 5*p + k] = mix*m.geom_solimp[5*g1 + k] + (1 - mix)*m.geom_solimp[5*g2 + k];
+  cpi(L.mi_pair_prm, pair_prm);
+  for (int q = 0; q < d.nprm; q++) {
+    const double* v = prm[q].data();
+    mr[L.mr_prm_margin + q] = v[0]; mr[L.mr_prm_gap + q] = v[1];
+    for (int k = 0; k < 3; k++) mr[L.mr_prm_friction + 3*q + k] = v[2 + k];
+    for (int k = 0; k < 2; k++) mr[L.mr_prm_solref + 2*q + k] = v[5 + k];
+    for (int k = 0; k < 5; k++) mr[L.mr_prm_solimp + 5*q + k] = v[7 + k];
   }
   cpi(L.mi_fric_dof, fric_dof);
   cpi(L.mi_stv_sensor, stv);

@@ -289,6 +289,7 @@ class Physics(control.Physics):
       raise TypeError('model must be a compiled Model; use Physics.from_xml_string')
     self.model = model
     self.batch_size = int(batch_size)
+    self._batch_kwargs = dict(batch_kwargs, device_id=device_id)   # contact caps etc.: copies / pickles keep them
     self.batch = BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, **batch_kwargs)
     self.data = _Data(self)
     self._warnings_cause_exception = True
@@ -409,7 +410,7 @@ class Physics(control.Physics):
 
   def copy(self, share_model=False):
     del share_model
-    other = type(self)(self.model, batch_size=self.batch_size, precision=self.batch.precision)
+    other = type(self)(self.model, batch_size=self.batch_size, precision=self.batch.precision, **self._batch_kwargs)
     for name in _INPUT_FIELDS:
       other.batch.set(name, np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1))
     other.legacy_step = self.legacy_step
@@ -432,11 +433,12 @@ class Physics(control.Physics):
   def __getstate__(self):
     self.data._upload()
     return dict(cls_model=self.model, batch_size=self.batch_size, precision=self.batch.precision,
-                legacy_step=self.legacy_step,
+                legacy_step=self.legacy_step, batch_kwargs=self._batch_kwargs,
                 fields={n: self.batch.get(n) for n in _INPUT_FIELDS})
 
   def __setstate__(self, st):
-    Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'])
+    Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'],
+                     **st.get('batch_kwargs', {}))
     for n, v in st['fields'].items():
       self.batch.set(n, v)
     self.legacy_step = st['legacy_step']

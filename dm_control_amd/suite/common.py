@@ -6,7 +6,9 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # Contact / constraint-row caps per domain where the library default (16 contacts) is too tight;
 # the humanoid's are free: its LDS footprint puts 4 environments on a CU either way.  The
 # model-specialised kernels are baked for exactly these caps (dm_control_amd/build.py).
-DEFAULT_CAPS = {'humanoid': dict(nconmax=24)}
+# humanoid_CMU (nv = 62): one environment fills a CU's LDS in fp32 (98 KiB of scratch + 58 KiB of
+# tables at 32 contacts); the fp64 scratch does not fit, so the domain runs the fp32 kernel.
+DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=32, precision=32)}
 
 
 def physics_kwargs(domain, user_kwargs):

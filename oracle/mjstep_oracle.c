@@ -672,6 +672,152 @@ static int collide_capsule_capsule(Contact* c, double margin, const double* p1, 
   return n;
 }
 
+
+/* ---- ellipsoid pairs ------------------------------------------------------
+ * MuJoCo routes every pair that involves an ellipsoid (other than plane-ellipsoid)
+ * through its general convex collider (mjc_Convex: MPR / GJK+EPA, tolerance 1e-6,
+ * one contact per pair).  Source not available here; this restates the quantity that
+ * collider converges to.  For convex A, B with support functions h_A, h_B the signed
+ * distance is  max_{|n|=1} F(n),  F(n) = -h_A(n) - h_B(-n)  (n from A to B): positive =
+ * separation, negative = penetration depth.  Spheres and ellipsoids are smooth and
+ * centrally symmetric, h_X(n) = n.c_X + |S_X R_X^T n|, so F is maximised by a Newton
+ * iteration on the unit sphere; a capsule is a sphere swept along its axis segment and
+ * the distance is minimised over the sweep parameter.  The contact reports
+ * dist = F(n*), frame normal n*, position = midpoint of the two witness points
+ * (PARITY_ASSUMPTIONS.md row 29). */
+typedef struct { const double* c; const double* R; double s[3]; } Quadric;
+/* support offset g = R S w/|w|, w = S R^T n; returns |w| and the unit w */
+static double quadric_support(const Quadric* q, const double* n, double* g, double* wh) {
+  double w[3];
+  for (int k = 0; k < 3; k++) w[k] = q->s[k]*(q->R[k]*n[0] + q->R[3 + k]*n[1] + q->R[6 + k]*n[2]);
+  double wn = sqrt(dot3(w, w));
+  if (wn < MINVAL) { g[0] = g[1] = g[2] = 0; wh[0] = wh[1] = wh[2] = 0; return 0; }
+  double v[3];
+  for (int k = 0; k < 3; k++) { wh[k] = w[k]/wn; v[k] = q->s[k]*wh[k]; }
+  mul_mat_vec3(g, q->R, v);
+  return wn;
+}
+/* t_i^T H t_j for the support-function Hessian H = R S (I - wh wh^T) S R^T / |w| */
+static void quadric_curv(const Quadric* q, const double* wh, double wn, const double* t1, const double* t2, double* K) {
+  if (wn < MINVAL) return;
+  double y1[3], y2[3];
+  for (int k = 0; k < 3; k++) {
+    y1[k] = q->s[k]*(q->R[k]*t1[0] + q->R[3 + k]*t1[1] + q->R[6 + k]*t1[2]);
+    y2[k] = q->s[k]*(q->R[k]*t2[0] + q->R[3 + k]*t2[1] + q->R[6 + k]*t2[2]);
+  }
+  double a1 = dot3(y1, wh), a2 = dot3(y2, wh);
+  K[0] += (dot3(y1, y1) - a1*a1)/wn; K[1] += (dot3(y1, y2) - a1*a2)/wn; K[2] += (dot3(y2, y2) - a2*a2)/wn;
+}
+static double quadric_gap_value(const Quadric* A, const Quadric* B, const double* n) {
+  double g[3], wh[3], d[3] = {B->c[0] - A->c[0], B->c[1] - A->c[1], B->c[2] - A->c[2]};
+  double hA = quadric_support(A, n, g, wh), hB = quadric_support(B, n, g, wh);
+  return dot3(n, d) - hA - hB;
+}
+#define CCD_MAXIT 30
+#define CCD_TOL 1e-10
+/* maximise F over the unit sphere starting from n (in/out); gA, gB = support offsets at the optimum */
+static double quadric_gap(const Quadric* A, const Quadric* B, double* n, double* gA, double* gB) {
+  double d[3] = {B->c[0] - A->c[0], B->c[1] - A->c[1], B->c[2] - A->c[2]};
+  double F = 0;
+  for (int it = 0; ; it++) {
+    double wA[3], wB[3];
+    double hA = quadric_support(A, n, gA, wA), hB = quadric_support(B, n, gB, wB);
+    F = dot3(n, d) - hA - hB;
+    if (it >= CCD_MAXIT) break;
+    double f[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+    make_frame(f);
+    const double *t1 = f + 3, *t2 = f + 6;
+    double grad[3] = {d[0] - gA[0] - gB[0], d[1] - gA[1] - gB[1], d[2] - gA[2] - gB[2]};
+    double g1 = dot3(t1, grad), g2 = dot3(t2, grad);
+    double K[3] = {F, 0, F};
+    quadric_curv(A, wA, hA, t1, t2, K); quadric_curv(B, wB, hB, t1, t2, K);
+    double tr = K[0] + K[2], det = K[0]*K[2] - K[1]*K[1];
+    double floor_ = 1e-3*(hA + hB) + MINVAL;
+    double lmin = 0.5*(tr - sqrt(mjMAX(0.0, tr*tr - 4*det)));
+    if (lmin < floor_) { double sh = floor_ - lmin; K[0] += sh; K[2] += sh; det = K[0]*K[2] - K[1]*K[1]; }
+    double d1 = (K[2]*g1 - K[1]*g2)/det, d2 = (K[0]*g2 - K[1]*g1)/det;
+    if (d1*d1 + d2*d2 < CCD_TOL*CCD_TOL) break;
+    double nn[3];
+    for (int ls = 0; ; ls++) {
+      for (int k = 0; k < 3; k++) nn[k] = n[k] + t1[k]*d1 + t2[k]*d2;
+      normalize3(nn);
+      if (ls >= 8 || quadric_gap_value(A, B, nn) >= F) break;
+      d1 *= 0.5; d2 *= 0.5;
+    }
+    n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
+  }
+  return F;
+}
+static void quadric_init_dir(const Quadric* A, const Quadric* B, double* n) {
+  for (int k = 0; k < 3; k++) n[k] = B->c[k] - A->c[k];
+  if (dot3(n, n) < MINVAL*MINVAL) { n[0] = 1; n[1] = n[2] = 0; }
+  normalize3(n);
+}
+static int quadric_contact(Contact* c, double margin, const Quadric* A, const Quadric* B, double* n) {
+  double gA[3], gB[3];
+  double dist = quadric_gap(A, B, n, gA, gB);
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) {
+    c->pos[k] = 0.5*((A->c[k] + gA[k]) + (B->c[k] - gB[k]));
+    c->frame[k] = n[k]; c->frame[3 + k] = 0;
+  }
+  return 1;
+}
+static Quadric make_quadric(int type, const double* pos, const double* mat, const double* size) {
+  Quadric q; q.c = pos; q.R = mat;
+  if (type == DMC_GEOM_ELLIPSOID) { q.s[0] = size[0]; q.s[1] = size[1]; q.s[2] = size[2]; }
+  else q.s[0] = q.s[1] = q.s[2] = size[0];   /* sphere, or the swept sphere of a capsule */
+  return q;
+}
+static int collide_plane_ellipsoid(Contact* c, double margin, const double* p1, const double* m1,
+                                   const double* p2, const double* m2, const double* s2) {
+  /* plane vs smooth convex: the support point of the ellipsoid along -normal */
+  double nrm[3] = {m1[2], m1[5], m1[8]}, g[3], wh[3];
+  Quadric q = make_quadric(DMC_GEOM_ELLIPSOID, p2, m2, s2);
+  quadric_support(&q, nrm, g, wh);
+  double pt[3] = {p2[0] - g[0], p2[1] - g[1], p2[2] - g[2]};
+  double dif[3] = {pt[0] - p1[0], pt[1] - p1[1], pt[2] - p1[2]};
+  double dist = dot3(dif, nrm);
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->pos[k] = pt[k] - nrm[k]*dist*0.5; c->frame[k] = nrm[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
+/* capsule (geom 1) vs ellipsoid (geom 2): minimise the swept-sphere gap over the axis parameter */
+static int collide_capsule_ellipsoid(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
+                                     const double* p2, const double* m2, const double* s2) {
+  double u[3] = {m1[2], m1[5], m1[8]}, cc[3], n[3], gA[3], gB[3];
+  const double h = s1[1];
+  Quadric A = make_quadric(DMC_GEOM_SPHERE, cc, m1, s1), B = make_quadric(DMC_GEOM_ELLIPSOID, p2, m2, s2);
+  /* psi(t) = n*(t).u is decreasing in t; the minimising t is its root clamped to [-h, h] */
+  double tlo = -h, thi = h, plo, phi, t;
+  for (int k = 0; k < 3; k++) cc[k] = p1[k] + u[k]*tlo;
+  quadric_init_dir(&A, &B, n);
+  quadric_gap(&A, &B, n, gA, gB); plo = dot3(n, u);
+  if (plo <= 0) t = tlo;
+  else {
+    for (int k = 0; k < 3; k++) cc[k] = p1[k] + u[k]*thi;
+    quadric_gap(&A, &B, n, gA, gB); phi = dot3(n, u);
+    if (phi >= 0) t = thi;
+    else {
+      t = 0;
+      int side = 0;   /* Illinois variant of regula falsi */
+      for (int it = 0; it < 40; it++) {
+        t = (tlo*phi - thi*plo)/(phi - plo);
+        for (int k = 0; k < 3; k++) cc[k] = p1[k] + u[k]*t;
+        quadric_gap(&A, &B, n, gA, gB);
+        double pt = dot3(n, u);
+        if (fabs(pt) < CCD_TOL || thi - tlo < CCD_TOL*h) break;
+        if (pt > 0) { tlo = t; plo = pt; if (side == 1) phi *= 0.5; side = 1; }
+        else { thi = t; phi = pt; if (side == -1) plo *= 0.5; side = -1; }
+      }
+    }
+  }
+  for (int k = 0; k < 3; k++) cc[k] = p1[k] + u[k]*t;
+  return quadric_contact(c, margin, &A, &B, n);
+}
+
 static void collision(const Model* m, Data* d) {
   d->ncon = 0;
   if (m->opt_disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)) return;
@@ -707,6 +853,13 @@ static void collision(const Model* m, Data* d) {
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) n = raw_sphere_sphere(c, margin, p1, s1[0], p2, s2[0]);
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) n = collide_sphere_capsule(c, margin, p1, s1, p2, m2, s2);
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) n = collide_capsule_capsule(c, margin, p1, m1, s1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_ELLIPSOID) n = collide_plane_ellipsoid(c, margin, p1, m1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_ELLIPSOID) n = collide_capsule_ellipsoid(c, margin, p1, m1, s1, p2, m2, s2);
+    else if ((t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_ELLIPSOID) && t2 == DMC_GEOM_ELLIPSOID) {
+      Quadric A = make_quadric(t1, p1, m1, s1), B = make_quadric(t2, p2, m2, s2);
+      double nn[3]; quadric_init_dir(&A, &B, nn);
+      n = quadric_contact(c, margin, &A, &B, nn);
+    }
     else { d->warning[DMC_WARN_COLLISION]++; continue; } /* pair type not restated and within bounding range */
     if (guard) { if (n > 0) d->warning[DMC_WARN_COLLISION]++; continue; }
     /* contact parameters (max / priority / solmix) */

@@ -3,8 +3,9 @@ with a random mix of the features both implementations support."""
 import numpy as np
 
 
-def random_model_xml(seed):
+def random_model_xml(seed, ellipsoids=False):
   rs = np.random.RandomState(seed)
+  rs2 = np.random.RandomState(7919 + seed)   # separate stream: the base models keep their seeds
   cone = rs.choice(['pyramidal', 'elliptic'])
   integrator = rs.choice(['Euler', 'RK4'], p=[.75, .25])
   condim = int(rs.choice([1, 3, 3, 4, 6]))
@@ -68,6 +69,11 @@ def random_model_xml(seed):
           k, length, rs.uniform(-.04, .04), rs.uniform(-.04, .04), radius))
     else:
       lines.append('<geom name="g%d" type="sphere" pos="%g 0 0" size="%g"/>' % (k, length / 2, radius * 1.5))
+    if ellipsoids and rs2.rand() < .6:
+      # an ellipsoid "hand" past the end of the link (ellipsoid-plane / -sphere / -capsule / -ellipsoid pairs)
+      q = rs2.normal(size=4)
+      lines.append('<geom name="e%d" type="ellipsoid" pos="%g %g 0" quat="%g %g %g %g" size="%g %g %g"/>' % (
+          (k, length + .03, rs2.uniform(-.03, .03)) + tuple(q / np.linalg.norm(q)) + tuple(rs2.uniform(.02, .07, 3))))
     lines.append('<site name="s%d" pos="%g 0 0" size=".01"/>' % (k, length / 2))
     sites.append('s%d' % k)
     nchild = 0 if depth >= 3 else int(rs.choice([0, 1, 1, 2]))

@@ -17,7 +17,8 @@ def _load(name):
 
 
 @pytest.mark.parametrize('name,nq,nv,nu,nbody,ngeom,nsd', [
-    ('cartpole', 2, 2, 1, 3, 5, 0), ('cheetah', 9, 9, 6, 8, 9, 3), ('humanoid', 28, 27, 21, 17, 20, 66)])
+    ('cartpole', 2, 2, 1, 3, 5, 0), ('cheetah', 9, 9, 6, 8, 9, 3), ('humanoid', 28, 27, 21, 17, 20, 66),
+    ('humanoid_CMU', 63, 62, 56, 32, 50, 16)])
 def test_sizes_match_survey_table(name, nq, nv, nu, nbody, ngeom, nsd):
   # SURVEY.md 8(a) size table (hand-derived from the reference XML)
   m = _load(name)

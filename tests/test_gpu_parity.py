@@ -522,17 +522,17 @@ def test_rollout_with_acceleration_stage_sensors(name, nsub):
   loop.close(); ro.close()
 
 
-@pytest.mark.parametrize('seed', range(24))
-def test_random_models_match_oracle(seed):
+@pytest.mark.parametrize('seed,ellipsoids', [(s, False) for s in range(24)] + [(s, True) for s in range(8)])
+def test_random_models_match_oracle(seed, ellipsoids):
   """Parity fuzzing (tests/random_models.py): random articulated models -- free / ball / hinge / slide
-  joints, several roots, capsule / sphere contacts, pyramidal and elliptic cones of every condim, Euler and
+  joints, several roots, capsule / sphere / ellipsoid contacts, pyramidal and elliptic cones of every condim, Euler and
   RK4, fluid drag, motors / servos, random sensors -- fp64 kernel vs oracle, lane widths rotating with
   the seed.  Tolerance: the two solvers stop at MuJoCo's 1e-8 tolerance and may stop ~1e-8 apart in
   qacc where their iteration paths differ in the last bits (see tests/test_random_models.py)."""
   import sys
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from random_models import random_model_xml
-  m = mc.compile_xml(random_model_xml(seed))
+  m = mc.compile_xml(random_model_xml(seed, ellipsoids))
   B = 4
   rs = np.random.RandomState(1000 + seed)
   q = np.tile(m.qpos0, (B, 1))

@@ -25,7 +25,7 @@ def _oracle(model):
                                          ('ball_in_cup', 'catch'), ('fish', 'upright'), ('fish', 'swim'),
                                          ('manipulator', 'bring_ball'), ('manipulator', 'bring_peg'),
                                          ('manipulator', 'insert_ball'), ('swimmer', 'swimmer6'),
-                                         ('swimmer', 'swimmer15')])
+                                         ('swimmer', 'swimmer15'), ('humanoid_CMU', 'stand'), ('humanoid_CMU', 'run')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -51,7 +51,8 @@ def test_suite_task_properties(domain, task):
                                          ('walker', 'run'), ('hopper', 'hop'), ('acrobot', 'swingup'),
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
                                          ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2'),
-                                         ('ball_in_cup', 'catch'), ('manipulator', 'bring_ball')])
+                                         ('ball_in_cup', 'catch'), ('manipulator', 'bring_ball'),
+                                         ('humanoid_CMU', 'walk')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -547,7 +548,8 @@ def test_manipulator_batched_targets_and_receptacle():
 
 
 @pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
-                                       ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4)])
+                                       ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4),
+                                       ('humanoid_CMU', 10)])
 def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
   env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
@@ -569,11 +571,12 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   rs = np.random.RandomState(11)
   q = np.tile(m.qpos0, (NE, 1))
   v = np.zeros((NE, m.nv))
-  if name == 'manipulator':
+  if name in ('manipulator', 'humanoid_CMU'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
-    # fp32; use the task's own collision-free start states (manipulator.py:183-239)
+    # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
     from dm_control_amd import suite
-    env = suite.load('manipulator', 'insert_ball', task_kwargs=dict(random=5), physics_kwargs=dict(batch_size=NE))
+    env = suite.load(name, 'insert_ball' if name == 'manipulator' else 'stand', task_kwargs=dict(random=5),
+                     physics_kwargs=dict(batch_size=NE))
     env.reset()
     q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
     m = env.physics.model
@@ -590,7 +593,7 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     o.qvel[:] = v[e]
     o.forward()
     refs.append(o)
-  b = BatchedPhysics(m, NE, precision=32)
+  b = BatchedPhysics(m, NE, **dict(common.DEFAULT_CAPS.get(name, {}), precision=32))
   errs = []
   for t in range(40):
     a = rs.uniform(-1, 1, (NE, m.nu))

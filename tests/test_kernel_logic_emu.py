@@ -216,3 +216,32 @@ def test_manipulator_variants_match_oracle(use_peg, insert):
   np.testing.assert_allclose(o.sensordata, e.sensordata, rtol=0, atol=1e-8)
   assert e.nefc[0] >= 1                      # the coupling row is always there
   assert not e.warning.any() and not o.warning.any()
+
+
+def test_humanoid_cmu_rollout_fp64():
+  """62 dofs, 1118 candidate pairs (ellipsoid hands against capsules, spheres and the floor): the
+  fp64 scratch of this model does not fit in a CU's LDS, so the fp64 comparison of the kernel core
+  with the oracle lives here; the GPU test is the fp32 teacher-forced one (test_gpu_suite.py)."""
+  with open(os.path.join(ASSETS, 'humanoid_CMU.xml')) as f:
+    m = mc.compile_xml(f.read())
+  o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=32)
+  rs = np.random.RandomState(0)
+  q = m.qpos0.copy()
+  q[7:] += rs.uniform(-.3, .3, m.nq - 7)
+  o.qpos[:] = q
+  e.qpos[:] = q
+  o.forward()
+  maxcon, worst = 0, 0.0
+  for _ in range(500):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    assert o.ncon == e.ncon[0]
+    maxcon = max(maxcon, o.ncon)
+    worst = max(worst, np.abs(e.qpos - o.qpos).max())
+  assert maxcon >= 4 and o.qpos[2] < 0.5      # it fell and lies on the floor
+  assert worst < 1e-9
+  np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
+  assert not o.warning.any() and not e.warning.any()

@@ -1,6 +1,6 @@
 """Parity fuzzing on the CPU: the kernel core (host emulation, one lane per environment) against the
-oracle on random articulated models -- free / ball / hinge / slide joints, several roots, capsule and
-sphere contacts, pyramidal and elliptic cones of every condim, Euler and RK4, fluid drag, motors and
+oracle on random articulated models -- free / ball / hinge / slide joints, several roots, capsule, sphere
+and ellipsoid contacts, pyramidal and elliptic cones of every condim, Euler and RK4, fluid drag, motors and
 position servos, a random set of sensors.  The same generator drives the GPU version in
 test_gpu_parity.py."""
 import numpy as np
@@ -12,9 +12,9 @@ from oracle.oracle import OraclePhysics
 from random_models import random_model_xml
 
 
-@pytest.mark.parametrize('seed', range(40))
-def test_random_model_emulation_matches_oracle(seed):
-  m = mc.compile_xml(random_model_xml(seed))
+@pytest.mark.parametrize('seed,ellipsoids', [(s, False) for s in range(40)] + [(s, True) for s in range(16)])
+def test_random_model_emulation_matches_oracle(seed, ellipsoids):
+  m = mc.compile_xml(random_model_xml(seed, ellipsoids))
   o, e = OraclePhysics(m), EmuPhysics(m, 64)
   rs = np.random.RandomState(1000 + seed)
   v = rs.uniform(-.5, .5, m.nv)
