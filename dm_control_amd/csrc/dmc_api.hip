@@ -359,6 +359,10 @@ extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) 
   }
   else if (!strcmp(name, "iterations")) o.iterations = value;
   else if (!strcmp(name, "ls_iterations")) o.ls_iterations = value;
+  else if (!strcmp(name, "noslip_iterations")) {
+    if (value > 0 && !b->tb.L.d.nslip) return fail("noslip needs scratch the batch was created without: compile the model with noslip_iterations > 0");
+    o.noslip_iterations = value;
+  }
   else return fail(std::string("unknown int option: ") + name);
   return 0;
 }
@@ -368,6 +372,7 @@ extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double val
   if (!strcmp(name, "timestep")) o.timestep = value;
   else if (!strcmp(name, "tolerance")) o.tolerance = value;
   else if (!strcmp(name, "ls_tolerance")) o.ls_tolerance = value;
+  else if (!strcmp(name, "noslip_tolerance")) o.noslip_tolerance = value;
   else if (!strcmp(name, "gravity_x")) o.gravity[0] = value;
   else if (!strcmp(name, "gravity_y")) o.gravity[1] = value;
   else if (!strcmp(name, "gravity_z")) o.gravity[2] = value;

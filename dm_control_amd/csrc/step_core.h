@@ -2239,6 +2239,147 @@ struct StepCore {
     if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
     return 0;
   }
+  // ---- noslip post-solver (mj_solNoSlip; same algorithm and operation order as the oracle's
+  // "noslip" section).  Gauss-Seidel in force space over the friction dimensions with R removed:
+  // A = J_F M^-1 J_F^T is built once (one substitution per friction row), the residual vector
+  // res = J qacc - aref is kept up to date lane-parallel, the per-block scalar maths runs
+  // redundantly on every lane (uniform values, no divergence).
+  DMC_DEV static int qcqp(T* res, const T* Ain, const T* bin, const T* dd, T r, int n) {
+    T A[25], b[5], Lc[25], v[5], pv[5], la = 0;
+    for (int i = 0; i < 5; i++) { v[i] = 0; pv[i] = 0; b[i] = 0; }
+    for (int i = 0; i < n; i++) { b[i] = bin[i]*dd[i]; for (int j = 0; j < n; j++) A[i*n + j] = Ain[i*n + j]*dd[i]*dd[j]; }
+    for (int iter = 0; iter < 20; iter++) {
+      for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
+        T t = A[i*n + j] + (i == j ? la : (T)0);
+        for (int k = 0; k < j; k++) t -= Lc[i*n + k]*Lc[j*n + k];
+        if (i == j) { if (t < (T)1e-10) { for (int k = 0; k < n; k++) res[k] = 0; return 0; } Lc[i*n + i] = t_sqrt(t); }
+        else Lc[i*n + j] = t/Lc[j*n + j];
+      }
+      for (int i = 0; i < n; i++) { T t = -b[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*v[k]; v[i] = t/Lc[i*n + i]; }
+      for (int i = n - 1; i >= 0; i--) { T t = v[i]; for (int k = i + 1; k < n; k++) t -= Lc[k*n + i]*v[k]; v[i] = t/Lc[i*n + i]; }
+      T val = -r*r;
+      for (int i = 0; i < n; i++) val += v[i]*v[i];
+      if (val < (T)1e-10) break;
+      for (int i = 0; i < n; i++) { T t = v[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*pv[k]; pv[i] = t/Lc[i*n + i]; }
+      T deriv = 0;
+      for (int i = 0; i < n; i++) deriv += pv[i]*pv[i];
+      deriv *= -2;
+      const T delta = -val/deriv;
+      if (delta < (T)1e-10) break;
+      la += delta;
+    }
+    for (int i = 0; i < n; i++) res[i] = v[i]*dd[i];
+    return la != 0;
+  }
+  // A is symmetric: packed lower triangle, entry (i, j) with i >= j computed as J_i . (M^-1 J_j^T)
+  DMC_DEV static int ns_idx(int i, int j) { return i >= j ? i*(i + 1)/2 + j : j*(j + 1)/2 + i; }
+  DMC_DEV void noslip(int nefc) {
+    const int nv = L.d.nv, cap = L.d.nslip;
+    int nf = 0, over = 0;
+    for (int i = 0; i < nefc; i++) {
+      const int tid = SI(efc_tid)[i], t = EFC_TYPE(tid);
+      bool take = t == EFC_FRICTION || t == EFC_PYRAMIDAL;
+      if (t == EFC_ELLIPTIC) take = i != SI(con_efc)[EFC_ID(tid)];
+      if (take) { if (nf < cap) { if (lane == 0) SI(ns_row)[nf] = i; nf++; } else over = 1; }
+    }
+    if (over) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++; return; }   // more friction rows than the cap: step without noslip
+    if (!nf) return;
+    // factor of M (qLH held the factor of H)
+    FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
+    DMC_WSYNC();
+    chol_factor_inplace(S(qLH), nv);
+    for (int b = 0; b < nf; b++) {
+      const int rb = SI(ns_row)[b];
+      FOR_LANES(i, nv) S(sv_grad)[i] = S(efc_J)[rb*nv + i];
+      DMC_WSYNC();
+      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+      for (int a = b + lane; a < nf; a += LPE) S(ns_A)[ns_idx(a, b)] = dot_n(S(efc_J) + SI(ns_row)[a]*nv, S(sv_Mgrad), nv);
+      DMC_WSYNC();
+    }
+    for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = dot_n(S(efc_J) + ra*nv, S(qacc), nv) - S(efc_aref)[ra]; }
+    DMC_WSYNC();
+    const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
+    int iter = 0;
+    while (iter < o.noslip_iterations) {
+      T improvement = 0;
+      if (iter == 0) {
+        for (int i = lane; i < nefc; i += LPE) { const T f = S(efc_force)[i]; improvement += (T)0.5*f*f / S(efc_D)[i]; }
+        improvement = group_sum<LPE>(improvement);
+      }
+      for (int a = 0; a < nf; ) {
+        const int i = SI(ns_row)[a], tid = SI(efc_tid)[i], t = EFC_TYPE(tid), id = EFC_ID(tid);
+        int n = 1;
+        if (t == EFC_PYRAMIDAL) n = 2;
+        else if (t == EFC_ELLIPTIC) n = MI(pair_dim)[SI(con_pair)[id]] - 1;
+        T Ac[25], old[5], bres[5], fnew[5];
+        for (int p = 0; p < 5; p++) { old[p] = 0; bres[p] = 0; fnew[p] = 0; }
+        for (int p = 0; p < n; p++) {
+          old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p];
+          for (int q = 0; q < n; q++) Ac[p*n + q] = S(ns_A)[ns_idx(a + p, a + q)];
+        }
+        if (t == EFC_FRICTION) {
+          const T fl = MR(dof_frictionloss)[id];
+          fnew[0] = old[0] - bres[0]/Ac[0];
+          if (fnew[0] < -fl) fnew[0] = -fl; else if (fnew[0] > fl) fnew[0] = fl;
+        } else if (t == EFC_PYRAMIDAL) {
+          const T bc0 = bres[0] - Ac[0]*old[0] - Ac[1]*old[1], bc1 = bres[1] - Ac[2]*old[0] - Ac[3]*old[1];
+          const T mid = (T)0.5*(old[0] + old[1]);
+          const T K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid*(Ac[0] - Ac[3]) + bc0 - bc1;
+          if (K1 < (T)DMC_MINVAL) fnew[0] = fnew[1] = mid;
+          else {
+            const T y = -K0/K1;
+            if (y < -mid) { fnew[0] = 0; fnew[1] = 2*mid; }
+            else if (y > mid) { fnew[0] = 2*mid; fnew[1] = 0; }
+            else { fnew[0] = mid + y; fnew[1] = mid - y; }
+          }
+        } else {
+          const int cp = SI(con_pair)[id];
+          const T* fr3 = MR(prm_friction) + 3*prm_of(cp);
+          const T fri[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
+          const T fn = S(efc_force)[SI(con_efc)[id]];
+          T bc[5];
+          for (int p = 0; p < 5; p++) bc[p] = 0;
+          for (int p = 0; p < n; p++) { bc[p] = bres[p]; for (int q = 0; q < n; q++) bc[p] -= Ac[p*n + q]*old[q]; }
+          if (fn < (T)DMC_MINVAL) { for (int p = 0; p < n; p++) fnew[p] = 0; }
+          else {
+            const int active = qcqp(fnew, Ac, bc, fri, fn, n);
+            if (active) {
+              T ss = 0;
+              for (int p = 0; p < n; p++) ss += (fnew[p]/fri[p])*(fnew[p]/fri[p]);
+              ss = t_sqrt(fn*fn / t_max((T)DMC_MINVAL, ss));
+              for (int p = 0; p < n; p++) fnew[p] *= ss;
+            }
+          }
+        }
+        // cost change of the block; an update that increases the cost is undone
+        T change = 0;
+        for (int p = 0; p < n; p++) {
+          T tq = 0;
+          for (int q = 0; q < n; q++) tq += Ac[p*n + q]*(fnew[q] - old[q]);
+          change += (T)0.5*(fnew[p] - old[p])*tq + (fnew[p] - old[p])*bres[p];
+        }
+        if (change > (T)1e-10) { for (int p = 0; p < n; p++) fnew[p] = old[p]; change = 0; }
+        improvement -= change;
+        DMC_WSYNC();
+        for (int p = 0; p < n; p++) {
+          const T delta = fnew[p] - old[p];
+          if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
+          if (delta != 0) for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += S(ns_A)[ns_idx(b, a + p)]*delta;
+        }
+        DMC_WSYNC();
+        a += n;
+      }
+      improvement *= scale;
+      iter++;
+      if (improvement < o.noslip_tolerance) break;
+    }
+    constraint_force_to_joint(nefc);
+    DMC_WSYNC();
+    FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
+    DMC_WSYNC();
+    chol_solve(S(qacc), S(qLH), S(sv_grad), nv);
+    DMC_WSYNC();
+  }
   DMC_DEV void fwd_constraint() {
     const int nv = L.d.nv, nefc = SI(imisc)[IM_NEFC];
     if (!nefc) {
@@ -2307,6 +2448,8 @@ struct StepCore {
     FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
     DMC_WSYNC();
+    // the warm start keeps the main solver's solution; noslip then edits qacc / efc_force
+    if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
     DMC_PROF(PROF_SOL_UPD);
   }
 

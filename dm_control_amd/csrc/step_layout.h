@@ -30,6 +30,7 @@ struct StepDims {
   int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
   int neq;       // active equality constraints (single fixed tendon held at its reference length)
   int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
+  int nslip;     // cap on the friction rows the noslip post-solver handles (0: model has noslip_iterations = 0)
   int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
 };
 
@@ -124,7 +125,9 @@ struct StepDims {
   X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)                    \
   /* elliptic cones: per-row coefficients of the middle-zone Hessian (newton_gradient) */ \
   X(efc_ca, d.elliptic * d.njmax) X(efc_cb, d.elliptic * d.njmax)              \
-  X(efc_cg, d.elliptic * d.njmax)
+  X(efc_cg, d.elliptic * d.njmax)                                              \
+  /* noslip: A = J_F M^-1 J_F^T over the friction rows (packed lower triangle) and the running residual */ \
+  X(ns_A, d.nslip * (d.nslip + 1) / 2) X(ns_res, d.nslip)
 #define STEP_SCRATCH_ALL_REAL(X) \
   STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 
@@ -133,6 +136,7 @@ struct StepDims {
   X(con_pair, d.nconmax) X(con_efc, d.nconmax)                                 \
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
+  X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch
@@ -170,8 +174,8 @@ struct StepLayout {
 // scalar options broadcast to every wave
 template <typename T>
 struct StepOpts {
-  T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia, density, viscosity;
-  int integrator, cone, iterations, ls_iterations, disableflags;
+  T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia, density, viscosity, noslip_tolerance;
+  int integrator, cone, iterations, ls_iterations, disableflags, noslip_iterations;
   int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
   double timestep_d; // fp64 copy for the time accumulator
 };

@@ -80,7 +80,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   if (m.opt_solver != DMC_SOL_NEWTON) { *err = "only the Newton solver is implemented in the HIP path"; return false; }
   if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
   d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
-  if (m.opt_noslip_iterations > 0) { *err = "noslip iterations are not implemented in the HIP path"; return false; }
   std::vector<int> fric_dof;
   for (int i = 0; i < m.nv; i++) {
     if (m.dof_frictionloss[i] < 0) { *err = "negative dof frictionloss"; return false; }
@@ -202,6 +201,14 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric + d.neq)));
   d.nconmax = nconmax; d.njmax = njmax;
   d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
+  if (m.opt_noslip_iterations > 0) {
+    // friction dimensions: every dof friction row, all rows of a pyramidal contact, all but the normal of an elliptic one
+    int maxfr = 0;
+    for (int p = 0; p < m.npair; p++) if (pdim[p] > 1) maxfr = std::max(maxfr, elliptic ? pdim[p] - 1 : 2*(pdim[p] - 1));
+    // at most 64 friction dimensions per environment (A is 64 x 65 / 2 reals of LDS); a step with more
+    // raises DMC_WARN_CNSTRFULL and keeps the main solver's result
+    d.nslip = std::min(std::min(njmax, d.nfric + nconmax * maxfr), 64);
+  }
   step_layout_build(&t->L, d);
   const StepLayout& L = t->L;
   t->mi.assign(L.n_mi, 0);
@@ -333,6 +340,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   o.meaninertia = m.stat_meaninertia; o.density = m.opt_density; o.viscosity = m.opt_viscosity;
   o.integrator = m.opt_integrator; o.cone = m.opt_cone; o.iterations = m.opt_iterations;
   o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
+  o.noslip_iterations = m.opt_noslip_iterations; o.noslip_tolerance = m.opt_noslip_tolerance;
   o.any_damping = 0;
   for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
   return true;
@@ -346,6 +354,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.meaninertia = (T)s.meaninertia; o.density = (T)s.density; o.viscosity = (T)s.viscosity;
   o.integrator = s.integrator; o.cone = s.cone;
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
+  o.noslip_iterations = s.noslip_iterations; o.noslip_tolerance = (T)s.noslip_tolerance;
   o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
   return o;
 }

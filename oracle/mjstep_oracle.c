@@ -1740,6 +1740,135 @@ static double total_cost(const Model* m, Data* d, double constraint_cost, double
   g *= 0.5; *gauss_out = g;
   return constraint_cost + g;
 }
+
+/* ---- noslip post-solver (mj_solNoSlip, engine_solver.c; restated from the documented algorithm) ----
+ * Gauss-Seidel sweeps in force space over the friction dimensions only (dof friction loss, the edge
+ * pairs of pyramidal contacts, the tangential rows of elliptic contacts) with the regulariser R removed,
+ * so that the residual slip velocity goes to zero; normal forces and limit / equality forces stay.
+ *   A = J M^-1 J^T (no R),  res = b + A f = J qacc - aref
+ *   dof friction:  f -= res/A_ii, clamped to [-floss, floss]
+ *   pyramid edge pair (f0, f1): f0 + f1 is kept; y = (f0 - f1)/2 minimises the 2x2 quadratic, |y| <= mid
+ *   elliptic: min 1/2 x'A x + x'bc over the tangential forces s.t. sum (x_k/mu_k)^2 <= f_n^2 (QCQP,
+ *   Newton on the multiplier), rescaled onto the cone when the constraint is active
+ * a block update that increases the cost by more than 1e-10 is undone.  PARITY_ASSUMPTIONS.md row 30. */
+static int qcqp(double* res, const double* Ain, const double* bin, const double* dd, double r, int n) {
+  double A[25], b[5], Lc[25], v[5], pv[5], la = 0;
+  for (int i = 0; i < n; i++) { b[i] = bin[i]*dd[i]; for (int j = 0; j < n; j++) A[i*n + j] = Ain[i*n + j]*dd[i]*dd[j]; }
+  for (int iter = 0; iter < 20; iter++) {
+    /* Cholesky of A + la I; not positive definite -> give up with zero forces */
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
+      double t = A[i*n + j] + (i == j ? la : 0);
+      for (int k = 0; k < j; k++) t -= Lc[i*n + k]*Lc[j*n + k];
+      if (i == j) { if (t < 1e-10) { for (int k = 0; k < n; k++) res[k] = 0; return 0; } Lc[i*n + i] = sqrt(t); }
+      else Lc[i*n + j] = t/Lc[j*n + j];
+    }
+    for (int i = 0; i < n; i++) { double t = -b[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*v[k]; v[i] = t/Lc[i*n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double t = v[i]; for (int k = i + 1; k < n; k++) t -= Lc[k*n + i]*v[k]; v[i] = t/Lc[i*n + i]; }
+    double val = -r*r;
+    for (int i = 0; i < n; i++) val += v[i]*v[i];
+    if (val < 1e-10) break;
+    /* deriv = -2 v' (A + la)^-1 v */
+    for (int i = 0; i < n; i++) { double t = v[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*pv[k]; pv[i] = t/Lc[i*n + i]; }
+    double deriv = 0;
+    for (int i = 0; i < n; i++) deriv += pv[i]*pv[i];
+    deriv *= -2;
+    double delta = -val/deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] = v[i]*dd[i];
+  return la != 0;
+}
+/* cost change of a block update; an update that increases the cost is undone */
+static double noslip_cost_change(const double* Ac, double* force, const double* oldforce, const double* res, int n) {
+  double delta[5], change = 0;
+  for (int i = 0; i < n; i++) delta[i] = force[i] - oldforce[i];
+  for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += Ac[i*n + j]*delta[j]; change += 0.5*delta[i]*t + delta[i]*res[i]; }
+  if (change > 1e-10) { for (int i = 0; i < n; i++) force[i] = oldforce[i]; change = 0; }
+  return change;
+}
+static void noslip(const Model* m, Data* d) {
+  const int nv = m->nv, nefc = d->nefc;
+  int* rows = (int*)malloc(sizeof(int) * (size_t)(nefc + 1));
+  int nf = 0;
+  for (int i = 0; i < nefc; i++) {
+    const int t = d->efc_type[i];
+    if (t == CT_FRICTION_DOF || t == CT_PYRAMIDAL) rows[nf++] = i;
+    else if (t == CT_ELLIPTIC && i != d->contact[d->efc_id[i]].efc_address) rows[nf++] = i;
+  }
+  if (!nf) { free(rows); return; }
+  double* W = (double*)malloc(sizeof(double) * (size_t)nf * (size_t)nv);   /* M^-1 J_F^T */
+  double* A = (double*)malloc(sizeof(double) * (size_t)nf * (size_t)nf);
+  double* res = (double*)malloc(sizeof(double) * (size_t)nf);
+  for (int a = 0; a < nf; a++) { chol_solve(W + (size_t)a*nv, d->qL, d->efc_J + (size_t)rows[a]*nv, nv); }
+  /* symmetric by construction: entry (a, b), a >= b, is J_a . (M^-1 J_b^T), mirrored */
+  for (int a = 0; a < nf; a++) for (int b = 0; b <= a; b++) A[a*nf + b] = A[b*nf + a] = dot_n(d->efc_J + (size_t)rows[a]*nv, W + (size_t)b*nv, nv);
+  for (int a = 0; a < nf; a++) res[a] = dot_n(d->efc_J + (size_t)rows[a]*nv, d->qacc, nv) - d->efc_aref[rows[a]];
+  double* force = d->efc_force;
+  const double scale = 1 / (m->stat_meaninertia * mjMAX(1, nv));
+  int iter = 0;
+  while (iter < m->opt_noslip_iterations) {
+    double improvement = 0;
+    if (iter == 0) for (int i = 0; i < nefc; i++) improvement += 0.5*force[i]*force[i]*d->efc_R[i];
+    for (int a = 0; a < nf; ) {
+      const int i = rows[a], t = d->efc_type[i];
+      int n;   /* block size */
+      double Ac[25], old[5], bres[5], fnew[5];
+      if (t == CT_FRICTION_DOF) n = 1;
+      else if (t == CT_PYRAMIDAL) n = 2;
+      else n = d->contact[d->efc_id[i]].dim - 1;
+      for (int p = 0; p < n; p++) { old[p] = force[rows[a + p]]; bres[p] = res[a + p]; for (int q = 0; q < n; q++) Ac[p*n + q] = A[(a + p)*nf + a + q]; }
+      if (t == CT_FRICTION_DOF) {
+        const double fl = m->dof_frictionloss[d->efc_id[i]];
+        fnew[0] = old[0] - bres[0]/Ac[0];
+        if (fnew[0] < -fl) fnew[0] = -fl; else if (fnew[0] > fl) fnew[0] = fl;
+      } else if (t == CT_PYRAMIDAL) {
+        const double bc0 = bres[0] - Ac[0]*old[0] - Ac[1]*old[1], bc1 = bres[1] - Ac[2]*old[0] - Ac[3]*old[1];
+        const double mid = 0.5*(old[0] + old[1]);
+        const double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid*(Ac[0] - Ac[3]) + bc0 - bc1;
+        if (K1 < MINVAL) fnew[0] = fnew[1] = mid;
+        else {
+          const double y = -K0/K1;
+          if (y < -mid) { fnew[0] = 0; fnew[1] = 2*mid; }
+          else if (y > mid) { fnew[0] = 2*mid; fnew[1] = 0; }
+          else { fnew[0] = mid + y; fnew[1] = mid - y; }
+        }
+      } else {
+        const Contact* c = d->contact + d->efc_id[i];
+        const double fn = force[c->efc_address];
+        double bc[5];
+        for (int p = 0; p < n; p++) { bc[p] = bres[p]; for (int q = 0; q < n; q++) bc[p] -= Ac[p*n + q]*old[q]; }
+        if (fn < MINVAL) for (int p = 0; p < n; p++) fnew[p] = 0;
+        else {
+          const int active = qcqp(fnew, Ac, bc, c->friction, fn, n);
+          if (active) {
+            double ss = 0;
+            for (int p = 0; p < n; p++) ss += (fnew[p]/c->friction[p])*(fnew[p]/c->friction[p]);
+            ss = sqrt(fn*fn / mjMAX(MINVAL, ss));
+            for (int p = 0; p < n; p++) fnew[p] *= ss;
+          }
+        }
+      }
+      improvement -= noslip_cost_change(Ac, fnew, old, bres, n);
+      for (int p = 0; p < n; p++) {
+        const double delta = fnew[p] - old[p];
+        force[rows[a + p]] = fnew[p];
+        if (delta != 0) for (int b = 0; b < nf; b++) res[b] += A[b*nf + a + p]*delta;
+      }
+      a += n;
+    }
+    improvement *= scale;
+    iter++;
+    if (improvement < m->opt_noslip_tolerance) break;
+  }
+  /* accelerations from the updated forces */
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*force[r];
+  double* tmp = (double*)malloc(sizeof(double) * (size_t)nv);
+  for (int i = 0; i < nv; i++) tmp[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+  chol_solve(d->qacc, d->qL, tmp, nv);
+  free(tmp); free(res); free(A); free(W); free(rows);
+}
 static void fwd_constraint(const Model* m, Data* d) {
   int nv = m->nv, nefc = d->nefc;
   d->solver_iter = 0;
@@ -1786,6 +1915,8 @@ static void fwd_constraint(const Model* m, Data* d) {
   for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
   for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * (size_t)nv);
+  /* the warm start keeps the main solver's solution; noslip then edits qacc / efc_force */
+  if (m->opt_noslip_iterations > 0) noslip(m, d);
 }
 /* mj_contactForce in the contact frame: [normal, tangent1, tangent2, torsion, roll1, roll2] */
 static void contact_force_local(const Model* m, const Data* d, int id, double* f6) {

@@ -1,4 +1,6 @@
-"""humanoid_CMU (nv = 62) on the GPU: LDS geometry and throughput for several contact caps."""
+"""The two 62-dof CMU humanoid models on the GPU (suite humanoid_CMU: 10 substeps per env-step; BASELINE
+config 4 physics -- position-controlled 2019 model on the Floor arena, elliptic cones + 5 noslip sweeps,
+6 substeps): LDS geometry, throughput at B = 4096, contact statistics."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,17 +10,19 @@ from dm_control_amd.batch import BatchedPhysics, OUT
 from dm_control_amd.suite import common
 import torch
 B = int(os.environ.get('B', 4096))
-m = mc.compile_xml(common.read_model('humanoid_CMU.xml'))
 rs = np.random.RandomState(0)
 out = []
-for prec, ncon in ((32, 32),):
+for name, nsub in (('humanoid_CMU', 10), ('cmu_2019_position_floor', 6)):
+  m = mc.compile_xml(common.read_model(name + '.xml'))
+  caps = dict(common.DEFAULT_CAPS[name])
+  prec, ncon = caps['precision'], caps['nconmax']
   try:
     b = BatchedPhysics(m, B, precision=prec, nconmax=ncon)
     q = np.tile(m.qpos0, (B, 1))
     q[:, 7:] += rs.uniform(-0.2, 0.2, (B, m.nq - 7))
     b.set('qpos', q)
     b.set_output_mask(OUT['sensor'] | OUT['xpos'] | OUT['xmat'] | OUT['subtree_com'])
-    T, nsub = 50, 10
+    T = 50
     td = torch.float32 if prec == 32 else torch.float64
     ctrl = (torch.rand((T, m.nu, B), device='cuda', dtype=td) * 2 - 1)
     b.rollout(T, nsub, ctrl.data_ptr(), None, None, None); b.sync()   # fall to the floor
@@ -26,12 +30,12 @@ for prec, ncon in ((32, 32),):
     ms = b.time_steps(nsub, 5)
     t0 = time.perf_counter(); b.rollout(T, nsub, ctrl.data_ptr(), None, None, None); b.sync(); dt = time.perf_counter() - t0
     ncon_now = b.get('ncon')
-    r = dict(prec=prec, nconmax=ncon, ms_per_env_step=ms, env_steps_per_s=B / (ms * 1e-3), physics_steps_per_s=B * nsub / (ms * 1e-3),
+    r = dict(model=name, nsub=nsub, prec=prec, nconmax=ncon, ms_per_env_step=ms, env_steps_per_s=B / (ms * 1e-3), physics_steps_per_s=B * nsub / (ms * 1e-3),
              rollout_env_steps_per_s=B * T / dt, info=b.info(), mean_ncon=float(ncon_now.mean()), max_ncon=int(ncon_now.max()),
              mean_iter=float(b.get('solver_iter').mean()), warnings=b.get('warning').sum(axis=0).tolist())
     b.close()
   except Exception as ex:  # pylint: disable=broad-except
-    r = dict(prec=prec, nconmax=ncon, error=repr(ex))
+    r = dict(model=name, nsub=nsub, prec=prec, nconmax=ncon, error=repr(ex))
   print(json.dumps(r), flush=True)
   out.append(r)
 json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'cmu_probe.json'), 'w'), indent=1)

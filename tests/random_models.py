@@ -3,7 +3,7 @@ with a random mix of the features both implementations support."""
 import numpy as np
 
 
-def random_model_xml(seed, ellipsoids=False):
+def random_model_xml(seed, ellipsoids=False, noslip=0):
   rs = np.random.RandomState(seed)
   rs2 = np.random.RandomState(7919 + seed)   # separate stream: the base models keep their seeds
   cone = rs.choice(['pyramidal', 'elliptic'])
@@ -141,4 +141,7 @@ def random_model_xml(seed, ellipsoids=False):
     sens.append('<jointpos joint="%s"/>' % joints[0])
     sens.append('<jointvel joint="%s"/>' % joints[-1])
   out += ['<sensor>'] + sens + ['</sensor>', '</mujoco>']
-  return '\n'.join(out)
+  xml = '\n'.join(out)
+  if noslip:
+    xml = xml.replace('<option ', '<option noslip_iterations="%d" ' % noslip, 1)
+  return xml

@@ -463,6 +463,43 @@ def test_elliptic_cones_match_oracle(precision, condim, impratio, lanes):
   b.close()
 
 
+@pytest.mark.parametrize('precision,cone,condim', [(64, 'pyramidal', 3), (64, 'elliptic', 3), (64, 'elliptic', 6),
+                                                   (64, 'pyramidal', 4), (32, 'elliptic', 4), (32, 'pyramidal', 3)])
+def test_noslip_matches_oracle(precision, cone, condim):
+  """noslip post-solver (composer/arena.xml:4: 5 sweeps) on the scene above: fp64 tracks the oracle over
+  300 steps, fp32 one step at a time from the oracle's states."""
+  xml = _ELLIPTIC_SCENE.format(condim=condim, impratio=1.0).replace('cone="elliptic"', 'cone="%s" noslip_iterations="5"' % cone)
+  m = mc.compile_xml(xml)
+  B = 16
+  rs = np.random.RandomState(12)
+  q = np.tile(m.qpos0, (B, 1))
+  v = rs.uniform(-1, 1, (B, m.nv))
+  b = _batch(m, B, precision=precision)
+  b.set('qpos', q); b.set('qvel', v)
+  ora = _oracles(m, q, v)
+  if precision == 64:
+    for _ in range(6):
+      b.step(50)
+      for o in ora:
+        o.step(50)
+      assert _rel_err(b.get('qpos'), np.array([o.qpos for o in ora])) <= TOL_F64_1000
+    np.testing.assert_allclose(b.get('qacc'), np.array([o.qacc for o in ora]), rtol=0, atol=1e-6)
+  else:
+    worst = 0.0
+    for k in range(20):
+      for o in ora:
+        o.step(10)
+      b.set('qpos', np.array([o.qpos for o in ora])); b.set('qvel', np.array([o.qvel for o in ora]))
+      b.set('qacc_warmstart', np.array([o.qacc_warmstart for o in ora]))
+      b.step(1)
+      for o in ora:
+        o.step(1)
+      worst = max(worst, _rel_err(b.get('qpos'), np.array([o.qpos for o in ora])))
+    assert worst <= TOL_F32_ONE_STEP, worst
+  assert not b.get('warning').any()
+  b.close()
+
+
 def test_elliptic_contact_force_equals_weight_on_gpu():
   # wrapper/core_test.py:393-416 with cone="elliptic", through touch (sums normal forces) and
   # qfrc_constraint; fp64 kernel.
@@ -522,8 +559,9 @@ def test_rollout_with_acceleration_stage_sensors(name, nsub):
   loop.close(); ro.close()
 
 
-@pytest.mark.parametrize('seed,ellipsoids', [(s, False) for s in range(24)] + [(s, True) for s in range(8)])
-def test_random_models_match_oracle(seed, ellipsoids):
+@pytest.mark.parametrize('seed,ellipsoids,noslip', [(s, False, 0) for s in range(24)] + [(s, True, 0) for s in range(8)] +
+                         [(s, s % 2 == 1, 3) for s in range(8)])
+def test_random_models_match_oracle(seed, ellipsoids, noslip):
   """Parity fuzzing (tests/random_models.py): random articulated models -- free / ball / hinge / slide
   joints, several roots, capsule / sphere / ellipsoid contacts, pyramidal and elliptic cones of every condim, Euler and
   RK4, fluid drag, motors / servos, random sensors -- fp64 kernel vs oracle, lane widths rotating with
@@ -532,7 +570,7 @@ def test_random_models_match_oracle(seed, ellipsoids):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from random_models import random_model_xml
-  m = mc.compile_xml(random_model_xml(seed, ellipsoids))
+  m = mc.compile_xml(random_model_xml(seed, ellipsoids, noslip))
   B = 4
   rs = np.random.RandomState(1000 + seed)
   q = np.tile(m.qpos0, (B, 1))

@@ -549,7 +549,7 @@ def test_manipulator_batched_targets_and_receptacle():
 
 @pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
                                        ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4),
-                                       ('humanoid_CMU', 10)])
+                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6)])
 def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
   env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
@@ -571,6 +571,9 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   rs = np.random.RandomState(11)
   q = np.tile(m.qpos0, (NE, 1))
   v = np.zeros((NE, m.nv))
+  if name == 'cmu_2019_position_floor':
+    # BASELINE config 4 physics: start upright with perturbed joints (qpos0 is the upright pose)
+    q[:, 7:] += rs.uniform(-.15, .15, (NE, m.nq - 7))
   if name in ('manipulator', 'humanoid_CMU'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
     # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
@@ -581,7 +584,7 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
     m = env.physics.model
     env.physics.free()
-  else:
+  elif name != 'cmu_2019_position_floor':
     for j in range(m.njnt):
       a = m.jnt_qposadr[j]
       if m.jnt_type[j] == 3 and m.jnt_limited[j]:
@@ -607,7 +610,12 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     errs.append(np.abs(b.get('qpos') - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1)))
   errs = np.concatenate(errs)
   assert np.median(errs) <= 1e-6, np.median(errs)
-  assert (errs <= 5e-5).mean() >= 0.98, (errs <= 5e-5).mean()
+  # config 4 (62 dofs, servo gains up to 150 against 0.01 armature, 6 substeps, noslip): the error is a
+  # continuous rounding tail, not contact flips -- 95 % within 5e-5 and nothing beyond 1e-3
+  frac = 0.95 if name == 'cmu_2019_position_floor' else 0.98
+  assert (errs <= 5e-5).mean() >= frac, (errs <= 5e-5).mean()
+  if name == 'cmu_2019_position_floor':
+    assert errs.max() <= 1e-3, errs.max()
   assert not b.get('warning').any()
   b.close()
 

@@ -245,3 +245,53 @@ def test_humanoid_cmu_rollout_fp64():
   assert worst < 1e-9
   np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
   assert not o.warning.any() and not e.warning.any()
+
+
+@pytest.mark.parametrize('cone', ['pyramidal', 'elliptic'])
+@pytest.mark.parametrize('condim', [3, 4, 6])
+@pytest.mark.parametrize('prec,tol', [(64, 1e-12), (32, 2e-6)])
+def test_noslip_matches_oracle(cone, condim, prec, tol):
+  # composer arenas run 5 noslip sweeps after the Newton solve (composer/arena.xml:4)
+  xml = _ELLIPTIC_SCENE.format(condim=condim, impratio=1.0).replace('cone="elliptic"', 'cone="%s" noslip_iterations="5"' % cone)
+  m = mc.compile_xml(xml)
+  o, e = OraclePhysics(m), EmuPhysics(m, prec)
+  rs = np.random.RandomState(3)
+  v = rs.uniform(-1, 1, m.nv)
+  o.qvel[:] = v
+  e.qvel[:] = v
+  o.forward()
+  for _ in range(200):
+    o.step()
+    e.step()
+  np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol * 200)
+  np.testing.assert_allclose(e.qacc, o.qacc, rtol=0, atol=max(tol * 1e4, 1e-8) * max(1.0, np.abs(o.qacc).max()))
+  assert not e.warning.any()
+
+
+def test_config4_cmu_position_floor_rollout_fp64():
+  """BASELINE config 4 physics (assets/cmu_2019_position_floor.xml: CMU 2019 humanoid, scaled position
+  actuators with force limits, elliptic cones, 5 noslip sweeps, dt = 0.005): kernel core vs oracle in
+  fp64 from the upright pose through the fall under random targets."""
+  with open(os.path.join(ASSETS, 'cmu_2019_position_floor.xml')) as f:
+    m = mc.compile_xml(f.read())
+  assert (m.nq, m.nv, m.nu, m.nsensordata) == (63, 62, 56, 25)        # SURVEY.md 8(a), config 4 row
+  assert m.opt.noslip_iterations == 5 and m.opt.timestep == 0.005
+  o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=24)
+  rs = np.random.RandomState(0)
+  o.forward()
+  head = m.names['body'].index('head')
+  assert abs(o.xpos[3*head + 2] - 1.455) < 5e-3                         # upright (cmu_humanoid.py:174-176)
+  maxcon, worst = 0, 0.0
+  for i in range(360):
+    c = rs.uniform(-1, 1, m.nu) * (0.3 if i < 150 else 1.0)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    maxcon = max(maxcon, o.ncon)
+    worst = max(worst, np.abs(e.qpos - o.qpos).max())
+  assert maxcon >= 4 and o.qpos[2] < 0.3
+  assert worst < 1e-9
+  np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
+  assert np.abs(o.actuator_force).max() <= 150 + 1e-9                 # forcerange clamps (largest: lowerback, 150)
+  assert not o.warning.any() and not e.warning.any()

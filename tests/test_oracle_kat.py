@@ -584,3 +584,55 @@ def test_tendon_equality_couples_two_sliders():
   for _ in range(100):
     p.step()
   assert p.nefc == 0 and p.qvel[1] == v1
+
+
+# ---- noslip post-solver (composer/arena.xml:4 sets noslip_iterations="5") ------------------------------
+def _incline_scene(cone, noslip, condim=3, angle=10.0):
+  g = 9.81
+  return ('<mujoco><option cone="%s" noslip_iterations="%d" gravity="%r 0 %r" timestep="0.002"/>'
+          '<worldbody><geom type="plane" size="5 5 .1" friction="1 .005 .0001" condim="%d"/>'
+          '<body pos="0 0 .1"><freejoint/><geom type="box" size=".1 .1 .1" friction="1 .005 .0001"/></body>'
+          '</worldbody></mujoco>') % (cone, noslip, float(g*np.sin(np.radians(angle))), float(-g*np.cos(np.radians(angle))), condim)
+
+
+@pytest.mark.parametrize('cone', ['pyramidal', 'elliptic'])
+def test_noslip_removes_the_soft_constraint_creep(cone):
+  """A box on a 10 degree incline with friction 1 (friction angle 45 degrees) must not slide.  The soft
+  contact model lets it creep at ~0.5 mm/s; the noslip sweeps solve the friction dimensions without the
+  regulariser, which removes the creep but leaves the normal forces (= weight) alone."""
+  creep = {}
+  for ns in (0, 5):
+    p = OraclePhysics(mc.compile_xml(_incline_scene(cone, ns)), legacy_step=False)
+    for _ in range(500):
+      p.step()
+    creep[ns] = abs(p.qvel[0])
+    normal = sum(p.contact_force(i)[0, 0] for i in range(p.ncon))
+    np.testing.assert_allclose(normal, p.model.compiled.body_mass[1] * 9.81 * np.cos(np.radians(10)), rtol=1e-4)
+    # tangential force balances the gravity component along the slope
+    fx = sum((p.contact(i)['frame'].T @ p.contact_force(i)[0])[0] for i in range(p.ncon))
+    np.testing.assert_allclose(abs(fx), p.model.compiled.body_mass[1] * 9.81 * np.sin(np.radians(10)), rtol=2e-3)
+  assert creep[0] > 2e-4
+  assert creep[5] < 1e-3 * creep[0]
+
+
+def test_noslip_keeps_sliding_friction_on_the_cone():
+  # steeper than the friction angle (friction 0.3 on a 30 degree slope): the box slides, and the
+  # tangential force stays at mu * normal (noslip projects onto the cone, it does not add friction)
+  xml = _incline_scene('elliptic', 5, angle=30.0).replace('friction="1 ', 'friction="0.3 ')
+  p = OraclePhysics(mc.compile_xml(xml), legacy_step=False)
+  for _ in range(100):
+    p.step()
+  a = (p.qvel[0] - 0.0) / p.time
+  np.testing.assert_allclose(a, 9.81 * (np.sin(np.radians(30)) - 0.3 * np.cos(np.radians(30))), rtol=2e-2)
+  for i in range(p.ncon):
+    f = p.contact_force(i)[0]
+    assert np.hypot(f[1], f[2]) <= 0.3 * f[0] * (1 + 1e-9)
+
+
+def test_noslip_dof_frictionloss_holds_exactly():
+  p = OraclePhysics(mc.compile_xml(_FRICTION_HINGE.replace('<option', '<option noslip_iterations="5"')), legacy_step=False)
+  p.ctrl[0] = 0.05                       # below frictionloss: without noslip it creeps at R tau / B (test above)
+  for _ in range(200):
+    p.step()
+  assert abs(p.qvel[0]) < 1e-12
+  np.testing.assert_allclose(p.qfrc_constraint[0], -0.05, rtol=1e-9)

@@ -12,9 +12,10 @@ from oracle.oracle import OraclePhysics
 from random_models import random_model_xml
 
 
-@pytest.mark.parametrize('seed,ellipsoids', [(s, False) for s in range(40)] + [(s, True) for s in range(16)])
-def test_random_model_emulation_matches_oracle(seed, ellipsoids):
-  m = mc.compile_xml(random_model_xml(seed, ellipsoids))
+@pytest.mark.parametrize('seed,ellipsoids,noslip', [(s, False, 0) for s in range(40)] + [(s, True, 0) for s in range(16)] +
+                         [(s, s % 2 == 1, 3) for s in range(16)])
+def test_random_model_emulation_matches_oracle(seed, ellipsoids, noslip):
+  m = mc.compile_xml(random_model_xml(seed, ellipsoids, noslip))
   o, e = OraclePhysics(m), EmuPhysics(m, 64)
   rs = np.random.RandomState(1000 + seed)
   v = rs.uniform(-.5, .5, m.nv)
