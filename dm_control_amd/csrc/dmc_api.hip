@@ -156,7 +156,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   const int nb = d.nbody;
   const Spec specs[] = {
       {"qpos", d.nq, false}, {"qvel", d.nv, false}, {"ctrl", d.nu, false}, {"qacc_warmstart", d.nv, false},
-      {"qfrc_applied", d.nv, false}, {"time", 1, false},
+      {"qfrc_applied", d.nv, false}, {"time", 1, false}, {"act", d.na, false},
       {"sensordata", d.nsensordata, false}, {"xpos", 3*nb, false}, {"xquat", 4*nb, false}, {"xmat", 9*nb, false},
       {"xipos", 3*nb, false}, {"geom_xpos", 3*d.ngeom, false}, {"geom_xmat", 9*d.ngeom, false},
       {"site_xpos", 3*d.nsite, false}, {"site_xmat", 9*d.nsite, false}, {"subtree_com", 3*nb, false},
@@ -198,7 +198,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   auto P = [&](const char* n) { return find_field(b, n)->dev; };
   io->B = b->B;
   io->qpos = (T*)P("qpos"); io->qvel = (T*)P("qvel"); io->ctrl = (T*)P("ctrl");
-  io->qacc_warmstart = (T*)P("qacc_warmstart"); io->qfrc_applied = (T*)P("qfrc_applied"); io->time = (double*)P("time"); io->prof = b->d_prof;
+  io->qacc_warmstart = (T*)P("qacc_warmstart"); io->qfrc_applied = (T*)P("qfrc_applied"); io->time = (double*)P("time"); io->act = (T*)P("act"); io->prof = b->d_prof;
   io->sensordata = (T*)P("sensordata"); io->xpos = (T*)P("xpos"); io->xquat = (T*)P("xquat"); io->xmat = (T*)P("xmat");
   io->xipos = (T*)P("xipos"); io->geom_xpos = (T*)P("geom_xpos"); io->geom_xmat = (T*)P("geom_xmat");
   io->site_xpos = (T*)P("site_xpos"); io->site_xmat = (T*)P("site_xmat"); io->subtree_com = (T*)P("subtree_com");
@@ -436,6 +436,7 @@ extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyfra
   if (reset_real("qacc_warmstart", nullptr, m.nv)) return -2;
   if (reset_real("qfrc_applied", nullptr, m.nv)) return -2;
   if (reset_real("time", nullptr, 1)) return -2;
+  if (reset_real("act", nullptr, m.na)) return -2;
   // mj_resetData clears warnings as well
   Field* w = find_field(b, "warning");
   std::vector<int32_t> wh((size_t)B * DMC_NWARNING, 0);

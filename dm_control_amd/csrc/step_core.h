@@ -69,6 +69,7 @@ template <typename T>
 struct StepIO {
   int B;
   T *qpos, *qvel, *ctrl, *qacc_warmstart, *qfrc_applied;
+  T *act;   // (na): activation states of actuators with dynamics
   double* time;   // always fp64: 1000 x 0.01 s must not drift in fp32 batches
   T *sensordata, *xpos, *xquat, *xmat, *xipos, *geom_xpos, *geom_xmat;
   T *site_xpos, *site_xmat, *subtree_com, *qacc, *actuator_force, *qfrc_actuator;
@@ -95,6 +96,8 @@ template <typename T> DMC_DEV T t_cos(T x) { return (T)cos((double)x); }
 template <> DMC_DEV float t_cos<float>(float x) { return cosf(x); }
 template <typename T> DMC_DEV T t_pow(T x, T y) { return (T)pow((double)x, (double)y); }
 template <> DMC_DEV float t_pow<float>(float x, float y) { return powf(x, y); }
+template <typename T> DMC_DEV T t_exp(T x) { return (T)exp((double)x); }
+template <> DMC_DEV float t_exp<float>(float x) { return expf(x); }
 template <typename T> DMC_DEV T t_abs(T x) { return x < 0 ? -x : x; }
 template <typename T> DMC_DEV T t_max(T a, T b) { return a > b ? a : b; }
 template <typename T> DMC_DEV T t_min(T a, T b) { return a < b ? a : b; }
@@ -536,6 +539,7 @@ struct StepCore {
       S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;
     }
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
+    if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = io.act[(size_t)i*B + env]; S(act_dot)[i] = 0; }
     time_ = io.time[env];
     if (lane == 0) {
       for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
@@ -560,6 +564,7 @@ struct StepCore {
       io.qvel[(size_t)i*B + env] = S(qvel)[i];
       io.qacc_warmstart[(size_t)i*B + env] = S(qacc_warmstart)[i];
     }
+    if (L.d.na) FOR_LANES(i, L.d.na) io.act[(size_t)i*B + env] = S(act)[i];
     if (lane == 0) {
       io.time[env] = time_;
       for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
@@ -1006,7 +1011,8 @@ struct StepCore {
     int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
     // cylinders have no narrow phase here: they are tested as their enclosing capsule
     // (same radius / half-length); a hit only raises DMC_WARN_COLLISION (see collision())
-    *guard = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    const bool plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;
+    *guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && !plane_cyl;
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
@@ -1017,6 +1023,45 @@ struct StepCore {
       T nrm[3] = {m1[2], m1[5], m1[8]};
       T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       if (dot3(dif, nrm) > MR(geom_rbound)[g2] + margin) return 0;
+      if (plane_cyl) {
+        // mjc_PlaneCylinder: deepest rim point of the near cap, the matching point of the far cap, two
+        // more points of the near disc at +-120 degrees (same order as the oracle)
+        T axis[3] = {m2[2], m2[5], m2[8]};
+        T prjaxis = dot3(nrm, axis);
+        if (prjaxis > 0) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
+        const T dist0 = dot3(dif, nrm);
+        T vec[3] = {axis[0]*prjaxis - nrm[0], axis[1]*prjaxis - nrm[1], axis[2]*prjaxis - nrm[2]};
+        const T len2 = dot3(vec, vec);
+        if (len2 >= (T)DMC_MINVAL*(T)DMC_MINVAL) { const T sc = s2[0]/t_sqrt(len2); vec[0] *= sc; vec[1] *= sc; vec[2] *= sc; }
+        else { vec[0] = m2[0]*s2[0]; vec[1] = m2[3]*s2[0]; vec[2] = m2[6]*s2[0]; }
+        const T prjvec = dot3(vec, nrm);
+        axis[0] *= s2[1]; axis[1] *= s2[1]; axis[2] *= s2[1]; prjaxis *= s2[1];
+        if (dist0 + prjaxis + prjvec > margin) return 0;
+        int cnt = 0;
+        Hit x;
+        for (int k = 0; k < 3; k++) x.nrm[k] = nrm[k];
+        x.dist = dist0 + prjaxis + prjvec;
+        for (int k = 0; k < 3; k++) x.pos[k] = p2[k] + vec[k] + axis[k] - nrm[k]*x.dist*(T)0.5;
+        put_hit(h, cnt, x); cnt++;
+        if (dist0 - prjaxis + prjvec <= margin) {
+          x.dist = dist0 - prjaxis + prjvec;
+          for (int k = 0; k < 3; k++) x.pos[k] = p2[k] + vec[k] - axis[k] - nrm[k]*x.dist*(T)0.5;
+          put_hit(h, cnt, x); cnt++;
+        }
+        const T prjvec1 = -prjvec*(T)0.5;
+        if (dist0 + prjaxis + prjvec1 <= margin) {
+          T vec1[3];
+          cross3(vec1, vec, axis);
+          normalize3(vec1);
+          const T sc = s2[0]*t_sqrt((T)3)/2;
+          x.dist = dist0 + prjaxis + prjvec1;
+          for (int k = 0; k < 3; k++) x.pos[k] = p2[k] + sc*vec1[k] + axis[k] - vec[k]*(T)0.5 - nrm[k]*x.dist*(T)0.5;
+          put_hit(h, cnt, x); cnt++;
+          for (int k = 0; k < 3; k++) x.pos[k] = p2[k] - sc*vec1[k] + axis[k] - vec[k]*(T)0.5 - nrm[k]*x.dist*(T)0.5;
+          put_hit(h, cnt, x); cnt++;
+        }
+        return (1 << cnt) - 1;
+      }
       if (t2 == DMC_GEOM_SPHERE) return plane_sphere(&h->s0, margin, p1, nrm, p2, s2[0]);
       if (t2 == DMC_GEOM_CAPSULE) {
         T axis[3] = {m2[2], m2[5], m2[8]};
@@ -1867,6 +1912,7 @@ struct StepCore {
     if (disable_actuation || (o.disableflags & DMC_DSBL_ACTUATION)) {
       FOR_LANES(i, nv) S(qfrc_actuator)[i] = 0;
       FOR_LANES(i, nu) S(actuator_force)[i] = 0;
+      if (L.d.na) FOR_LANES(i, L.d.na) S(act_dot)[i] = 0;
       DMC_WSYNC();
       return;
     }
@@ -1898,7 +1944,16 @@ struct StepCore {
       T gain = gp[0], bias = 0;
       if (fl & ACTF_GAIN_AFFINE) gain = gp[0] + gp[1]*len + gp[2]*vel;
       if (fl & ACTF_BIAS_AFFINE) bias = bp[0] + bp[1]*len + bp[2]*vel;
-      T force = gain*ctrl + bias;
+      // actuators with dynamics: the activation drives the gain; integrator: act_dot = ctrl,
+      // filter / filterexact: act_dot = (ctrl - act) / tau
+      T input = ctrl;
+      if (L.d.na) { if (fl & ACTF_DYN_ANY) {
+        const int k = MI(act_adr)[i];
+        const T act = S(act)[k];
+        S(act_dot)[k] = (fl & ACTF_DYN_INTEGRATOR) ? ctrl : (ctrl - act) / t_max((T)DMC_MINVAL, MR(act_dynprm)[i]);
+        input = act;
+      } }
+      T force = gain*input + bias;
       if (fl & ACTF_FORCELIMITED) force = t_max(MR(act_forcerange)[2*i], t_min(MR(act_forcerange)[2*i + 1], force));
       S(actuator_force)[i] = force;
     }
@@ -2458,6 +2513,15 @@ struct StepCore {
     const int nv = L.d.nv;
     const T dt = o.timestep;
     const T* qacc = S(qacc);
+    // activations first (mj_advance): explicit Euler, or the exact exponential for filterexact
+    if (L.d.na) FOR_LANES(i, L.d.nu) {
+      const int fl = MI(act_flags)[i];
+      if (fl & ACTF_DYN_ANY) {
+        const int k = MI(act_adr)[i];
+        if (fl & ACTF_DYN_FILTEREXACT) { const T tau = t_max((T)DMC_MINVAL, MR(act_dynprm)[i]); S(act)[k] += S(act_dot)[k] * tau * (1 - t_exp(-dt/tau)); }
+        else S(act)[k] += dt*S(act_dot)[k];
+      }
+    }
     if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {
       FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
@@ -2539,6 +2603,7 @@ struct StepCore {
     FOR_LANES(i, L.d.nq) S(qpos)[i] = MR(qpos0)[i];
     FOR_LANES(i, L.d.nv) { S(qvel)[i] = 0; S(qacc_warmstart)[i] = 0; S(qfrc_applied)[i] = 0; }
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = 0;
+    if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = 0; S(act_dot)[i] = 0; }
     time_ = 0;
     DMC_WSYNC();
   }

@@ -31,6 +31,7 @@ struct StepDims {
   int neq;       // active equality constraints (single fixed tendon held at its reference length)
   int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
   int nslip;     // cap on the friction rows the noslip post-solver handles (0: model has noslip_iterations = 0)
+  int na;        // activation states (actuators with integrator / filter dynamics)
   int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
 };
 
@@ -55,6 +56,7 @@ struct StepDims {
   X(pair_prm, d.npair)         /* contact-parameter tuple of each pair */      \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \
   X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
+  X(act_adr, d.na ? d.nu : 0)  /* activation index of a stateful actuator, -1 otherwise */ \
   X(sensor_type, d.nsensor) X(sensor_objid, d.nsensor) X(sensor_adr, d.nsensor) \
   X(sensor_stage, d.nsensor) X(sensor_objtype, d.nsensor)                      \
   X(fric_dof, d.nfric)                                                         \
@@ -83,6 +85,7 @@ struct StepDims {
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
   X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)       \
+  X(act_dynprm, d.na ? d.nu : 0)  /* time constant of filter dynamics */          \
   X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon) \
   X(tendon_range, d.nlimten ? 2 * d.ntendon : 0) X(tendon_margin, d.nlimten ? d.ntendon : 0) \
   X(tendon_solref_lim, d.nlimten ? 2 * d.ntendon : 0) X(tendon_solimp_lim, d.nlimten ? 5 * d.ntendon : 0) \
@@ -93,6 +96,7 @@ struct StepDims {
 // Persistent arrays (live across the whole substep) ...
 #define STEP_SCRATCH_REAL(X)                                                   \
   X(qpos, d.nq) X(qvel, d.nv) X(ctrl, d.nu) X(qacc_warmstart, d.nv)            \
+  X(act, d.na) X(act_dot, d.na)                                                \
   X(qfrc_applied, d.nv)                                                        \
   X(xpos, 3 * d.nbody) X(xquat, 4 * d.nbody) X(xmat, 9 * d.nbody)              \
   X(xipos, 3 * d.nbody)                                                        \
@@ -145,7 +149,8 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING 
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
-       ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */ };
+       ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */,
+       ACTF_DYN_INTEGRATOR = 32, ACTF_DYN_FILTER = 64, ACTF_DYN_FILTEREXACT = 128, ACTF_DYN_ANY = 32 | 64 | 128 };
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5, EFC_EQUALITY = 6 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))

@@ -74,6 +74,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   std::memset(&d, 0, sizeof d);
   d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom;
   d.nsite = m.nsite; d.nsensor = m.nsensor; d.nsensordata = m.nsensordata; d.npair = m.npair;
+  for (int i = 0; i < m.nu; i++) {
+    if (m.actuator_dyntype[i] < DMC_DYN_NONE || m.actuator_dyntype[i] > DMC_DYN_FILTEREXACT) { *err = "actuator dyntype not implemented (none / integrator / filter / filterexact)"; return false; }
+    if (m.actuator_dyntype[i] != DMC_DYN_NONE) d.na++;
+  }
+  if (d.na != m.na) { *err = "model na does not match the number of actuators with dynamics"; return false; }
+  if (d.na && m.opt_integrator != DMC_INT_EULER) { *err = "actuator dynamics are only implemented with the Euler integrator"; return false; }
   if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
   if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
   const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
@@ -134,7 +140,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
     // cylinders: guard test as enclosing capsules (DMC_WARN_COLLISION), never a contact
-    const bool cyl = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    const bool plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;   // analytic, up to 4 contacts
+    const bool cyl = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && !plane_cyl;
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     if (cyl) d.ncyl++;
@@ -143,6 +150,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     int nc = 1;
     if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) nc = 2;
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) nc = 4;
+    if (plane_cyl) nc = 4;
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) nc = 1;   // 2 only for exactly parallel axes
     const bool known = (t1 == DMC_GEOM_PLANE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE || t2 == DMC_GEOM_BOX)) ||
                        (t1 == DMC_GEOM_SPHERE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE)) ||
@@ -255,12 +263,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);
   cpi(L.mi_pair_geom1, m.pair_geom1); cpi(L.mi_pair_geom2, m.pair_geom2); cpi(L.mi_pair_dim, pdim);
   cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);
+  int nact = 0;
   for (int i = 0; i < m.nu; i++) {
     const int j = m.actuator_trnid[2*i];
     const bool tendon = m.actuator_trntype[i] == DMC_TRN_TENDON;
     if (tendon) { if (j < 0 || j >= m.ntendon) { *err = "actuator refers to a missing tendon"; return false; } }
     else if (m.actuator_trntype[i] != DMC_TRN_JOINT || j < 0 || (m.jnt_type[j] != DMC_JNT_HINGE && m.jnt_type[j] != DMC_JNT_SLIDE)) { *err = "only hinge/slide joint and fixed-tendon transmissions are implemented"; return false; }
-    if (m.actuator_dyntype[i] != DMC_DYN_NONE) { *err = "actuator dynamics are not implemented"; return false; }
     if (tendon) { mi[L.mi_act_dof + i] = j; mi[L.mi_act_qpos + i] = 0; }
     else { mi[L.mi_act_dof + i] = m.jnt_dofadr[j]; mi[L.mi_act_qpos + i] = m.jnt_qposadr[j]; }
     int fl = tendon ? ACTF_TENDON : 0;
@@ -268,6 +276,10 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.actuator_forcelimited[i]) fl |= ACTF_FORCELIMITED;
     if (m.actuator_gaintype[i] == DMC_GAIN_AFFINE) fl |= ACTF_GAIN_AFFINE;
     if (m.actuator_biastype[i] == DMC_BIAS_AFFINE) fl |= ACTF_BIAS_AFFINE;
+    if (m.actuator_dyntype[i] == DMC_DYN_INTEGRATOR) fl |= ACTF_DYN_INTEGRATOR;
+    else if (m.actuator_dyntype[i] == DMC_DYN_FILTER) fl |= ACTF_DYN_FILTER;
+    else if (m.actuator_dyntype[i] == DMC_DYN_FILTEREXACT) fl |= ACTF_DYN_FILTEREXACT;
+    if (d.na) { mi[L.mi_act_adr + i] = (fl & ACTF_DYN_ANY) ? nact++ : -1; mr[L.mr_act_dynprm + i] = m.actuator_dynprm[10*i]; }
     mi[L.mi_act_flags + i] = fl;
     mr[L.mr_act_gear + i] = m.actuator_gear[6*i];
     for (int k = 0; k < 2; k++) { mr[L.mr_act_ctrlrange + 2*i + k] = m.actuator_ctrlrange[2*i + k]; mr[L.mr_act_forcerange + 2*i + k] = m.actuator_forcerange[2*i + k]; }

@@ -1135,8 +1135,11 @@ class _Compiler:
           raise MjcfError('actuators on ball/free joints are not supported')
         m.actuator_trnid[i, 0] = jid
       dyn = a.get('dyntype', 'none')
-      if dyn != 'none':
+      if dyn not in ('none', 'integrator', 'filter', 'filterexact'):
         raise MjcfError('actuator dyntype %r is not supported' % dyn)
+      m.actuator_dyntype[i] = {'none': 0, 'integrator': 1, 'filter': 2, 'filterexact': 3}[dyn]
+      if a.get('actlimited', 'false') == 'true' or (a.get('actlimited', 'auto') == 'auto' and self.autolimits and 'actrange' in a):
+        raise MjcfError('actuator %r: actlimited / actrange is not supported' % a.get('name'))
       m.actuator_gaintype[i] = {'fixed': 0, 'affine': 1}[a.get('gaintype', 'fixed')]
       m.actuator_biastype[i] = {'none': 0, 'affine': 1}[a.get('biastype', 'none')]
       g = _vec(a.get('gear', '1'))
@@ -1146,6 +1149,9 @@ class _Compiler:
       bp = _vec(a.get('biasprm', '0'))
       m.actuator_biasprm[i, :bp.size] = bp
       m.actuator_dynprm[i, 0] = 1
+      if 'dynprm' in a:
+        dp = _vec(a['dynprm'])
+        m.actuator_dynprm[i, :dp.size] = dp
       for key, lim, rng in (('ctrl', m.actuator_ctrllimited, m.actuator_ctrlrange),
                             ('force', m.actuator_forcelimited, m.actuator_forcerange)):
         has = (key + 'range') in a
@@ -1154,6 +1160,10 @@ class _Compiler:
         flag = a.get(key + 'limited', 'auto')
         lim[i] = int((self.autolimits and has) if flag == 'auto' else flag == 'true')
     m.names['actuator'] = names
+    # one activation state per actuator with dynamics, in actuator order (mjModel.actuator_actadr)
+    m.na = int(np.count_nonzero(m.actuator_dyntype))
+    if m.na and m.opt.integrator != 0:
+      raise MjcfError('actuator dynamics are only supported with the Euler integrator')
 
   def _sensors(self, m):
     ns = len(self.sensors)

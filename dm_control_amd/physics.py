@@ -13,7 +13,7 @@ drop-in.  batch_size == B > 1: every data array gains a leading batch dimension.
 
 `physics.data` is a host mirror of the device arrays: reads fetch lazily (and
 are cached until the next step/forward/reset), writes to the input fields
-(`qpos qvel ctrl qacc_warmstart qfrc_applied time`) are uploaded before the
+(`qpos qvel act ctrl qacc_warmstart qfrc_applied time`) are uploaded before the
 next kernel launch.  High-throughput callers use `physics.batch`
 (`BatchedPhysics`: device pointers, zero-copy binds) instead of the mirror.
 """
@@ -38,7 +38,7 @@ _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margi
                          'body_quat')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
-_INPUT_FIELDS = ('qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')
+_INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')
 _INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
 # field -> (row object kind for named access, columns per row)
 _FIELD_AXES = {
@@ -397,16 +397,18 @@ class Physics(control.Physics):
 
   # -- state -------------------------------------------------------------------------------
   def get_state(self):
-    """Concatenated [qpos, qvel] (na == 0 in the supported models)."""
-    return np.concatenate([np.asarray(self.data.qpos), np.asarray(self.data.qvel)], axis=-1)
+    """Concatenated [qpos, qvel, act] (engine.py:235-285)."""
+    return np.concatenate([np.asarray(self.data.qpos), np.asarray(self.data.qvel), np.asarray(self.data.act)], axis=-1)
 
   def set_state(self, physics_state):
     s = np.asarray(physics_state, dtype=np.float64)
-    nq, nv = self.model.nq, self.model.nv
-    if s.shape[-1] != nq + nv:
-      raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (nq + nv,)))
+    nq, nv, na = self.model.nq, self.model.nv, self.model.na
+    if s.shape[-1] != nq + nv + na:
+      raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (nq + nv + na,)))
     self.data.qpos = s[..., :nq]
-    self.data.qvel = s[..., nq:]
+    self.data.qvel = s[..., nq:nq + nv]
+    if na:
+      self.data.act = s[..., nq + nv:]
 
   def copy(self, share_model=False):
     del share_model
@@ -469,7 +471,7 @@ class Physics(control.Physics):
     return np.array(self.data.ctrl)
 
   def activation(self):
-    return np.zeros((0,)) if self.batch_size == 1 else np.zeros((self.batch_size, 0))
+    return np.array(self.data.act)
 
   def state(self):
     return self.get_state()

@@ -1,0 +1,235 @@
+"""Quadruped domain (reference: dm_control/suite/quadruped.py): walk, run, fetch.
+
+Tendon-coupled legs (fixed tendons as transmissions + tendon equalities), position servos behind
+first-order filters (`dyntype="filter"`: 12 activation states), an ellipsoid torso, toe spheres, and
+-- fetch -- four tilted wall planes and a condim-6 ball with contact priority.  `escape` needs the
+heightfield terrain and rangefinders and is not provided."""
+import collections
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from dm_control_amd import physics as physics_lib
+from dm_control_amd.envs import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.suite import rewards
+
+_DEFAULT_TIME_LIMIT = 20
+_CONTROL_TIMESTEP = .02
+_RUN_SPEED = 5
+_WALK_SPEED = 0.5
+_TOES = ['toe_front_left', 'toe_back_left', 'toe_back_right', 'toe_front_right']
+_WALLS = ['wall_px', 'wall_py', 'wall_nx', 'wall_ny']
+_SENS_ACCELEROMETER, _SENS_GYRO, _SENS_FORCE, _SENS_TORQUE = 1, 3, 4, 5   # mjtSensor values
+TASKS = {}
+
+
+def _remove(root, tag, name):
+  for parent in root.iter():
+    for c in list(parent):
+      if c.tag == tag and c.get('name') == name:
+        parent.remove(c)
+        return
+  raise ValueError('%s %r not found' % (tag, name))
+
+
+def make_model(floor_size=None, walls_and_ball=False):
+  """Model XML for the task (quadruped.py:55-93; terrain and rangefinders are never present here)."""
+  root = ET.fromstring(common.read_model('quadruped.xml'))
+  if floor_size is not None:
+    for g in root.iter('geom'):
+      if g.get('name') == 'floor':
+        g.set('size', '%r %r .5' % (floor_size, floor_size))
+  if not walls_and_ball:
+    for wall in _WALLS:
+      _remove(root, 'geom', wall)
+    _remove(root, 'body', 'ball')
+    _remove(root, 'site', 'target')
+  return ET.tostring(root, encoding='unicode')
+
+
+def get_model_and_assets():
+  return make_model(), None
+
+
+def _make(kind, speed=None):
+  def factory(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None, physics_kwargs=None):
+    if kind == 'move':
+      xml = make_model(floor_size=_DEFAULT_TIME_LIMIT * speed)
+      task = Move(desired_speed=speed, random=random)
+    else:
+      xml = make_model(walls_and_ball=True)
+      task = Fetch(random=random)
+    physics = Physics.from_xml_string(xml, None, **common.physics_kwargs('quadruped', physics_kwargs))
+    return control.Environment(physics, task, time_limit=time_limit, control_timestep=_CONTROL_TIMESTEP,
+                               **(environment_kwargs or {}))
+  return factory
+
+
+walk = _make('move', _WALK_SPEED)
+run = _make('move', _RUN_SPEED)
+fetch = _make('fetch')
+TASKS.update(walk=(walk, None), run=(run, None), fetch=(fetch, None))
+
+
+def _to_frame(vec, frame):
+  """vec . frame per environment (the reference's `v.dot(torso_frame)`)."""
+  return np.einsum('...i,...ij->...j', vec, frame)
+
+
+class Physics(physics_lib.Physics):
+
+  def _torso_frame(self):
+    xmat = self.named.data.xmat['torso']
+    return xmat.reshape(xmat.shape[:-1] + (3, 3))
+
+  def _sensor_names(self, *types):
+    st = np.asarray(self.model.sensor_type)
+    return [self.model.id2name(i, 'sensor') for i in np.nonzero(np.isin(st, types))[0]]
+
+  def torso_upright(self):
+    return np.asarray(self.named.data.xmat['torso', 'zz'])
+
+  def torso_velocity(self):
+    return self.named.data.sensordata['velocimeter'].copy()
+
+  def egocentric_state(self):
+    hinges = [self.model.id2name(j, 'joint') for j in np.nonzero(np.asarray(self.model.jnt_type) == 3)[0]]
+    return np.concatenate([self.named.data.qpos[hinges], self.named.data.qvel[hinges], np.asarray(self.data.act)], axis=-1)
+
+  def toe_positions(self):
+    d = self.named.data.xpos[_TOES] - self.named.data.xpos['torso'][..., None, :]
+    return np.einsum('...ti,...ij->...tj', d, self._torso_frame())
+
+  def force_torque(self):
+    return np.arcsinh(self.named.data.sensordata[self._sensor_names(_SENS_FORCE, _SENS_TORQUE)])
+
+  def imu(self):
+    return self.named.data.sensordata[self._sensor_names(_SENS_GYRO, _SENS_ACCELEROMETER)]
+
+  def origin_distance(self):
+    return np.asarray(np.linalg.norm(self.named.data.site_xpos['workspace'], axis=-1))
+
+  def origin(self):
+    return _to_frame(-self.named.data.xpos['torso'], self._torso_frame())
+
+  def ball_state(self):
+    data = self.named.data
+    frame = self._torso_frame()
+    rel_pos = data.xpos['ball'] - data.xpos['torso']
+    rel_vel = data.qvel['ball_root'][..., :3] - data.qvel['root'][..., :3]
+    rot_vel = data.qvel['ball_root'][..., 3:]
+    return np.concatenate([_to_frame(v, frame) for v in (rel_pos, rel_vel, rot_vel)], axis=-1)
+
+  def target_position(self):
+    return _to_frame(self.named.data.site_xpos['target'] - self.named.data.xpos['torso'], self._torso_frame())
+
+  def ball_to_target_distance(self):
+    d = self.named.data.site_xpos['target'] - self.named.data.xpos['ball']
+    return np.linalg.norm(d[..., :2], axis=-1)
+
+  def self_to_ball_distance(self):
+    d = self.named.data.site_xpos['workspace'] - self.named.data.xpos['ball']
+    return np.linalg.norm(d[..., :2], axis=-1)
+
+
+def _find_non_contacting_height(physics, orientation, x_pos=0.0, y_pos=0.0):
+  """Raises the root in 1 cm steps from the floor until nothing touches (quadruped.py:249-278); in a
+  batch every environment stops at its own height."""
+  B = physics.batch_size
+  orientation = np.broadcast_to(orientation, (B, 4))
+  z = np.zeros(B)
+  todo = np.ones(B, dtype=bool)
+  root = physics.named.data.qpos['root']
+  attempts = 0
+  while todo.any():
+    with physics.suppress_physics_errors():        # a buried start may fill the contact buffer
+      with physics.reset_context():
+        pose = np.concatenate([np.broadcast_to(x_pos, (B,))[:, None], np.broadcast_to(y_pos, (B,))[:, None],
+                               z[:, None], orientation], axis=1)
+        physics.named.data.qpos['root'] = pose if B > 1 else pose[0]
+    todo = np.atleast_1d(physics.data.ncon) > 0
+    z[todo] += 0.01
+    attempts += 1
+    if attempts > 10000:
+      raise RuntimeError('Failed to find a non-contacting configuration.')
+  del root
+
+
+def _common_observations(physics):
+  obs = collections.OrderedDict()
+  obs['egocentric_state'] = physics.egocentric_state()
+  obs['torso_velocity'] = physics.torso_velocity()
+  obs['torso_upright'] = physics.torso_upright()
+  obs['imu'] = physics.imu()
+  obs['force_torque'] = physics.force_torque()
+  return obs
+
+
+def _upright_reward(physics, deviation_angle=0):
+  deviation = np.cos(np.deg2rad(deviation_angle))
+  return rewards.tolerance(physics.torso_upright(), bounds=(deviation, float('inf')), sigmoid='linear',
+                           margin=1 + deviation, value_at_margin=0)
+
+
+def _random_orientation(random, B):
+  q = random.randn(4) if B == 1 else random.randn(B, 4)
+  return q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+
+class Move(base.Task):
+
+  def __init__(self, desired_speed, random=None):
+    self._desired_speed = desired_speed
+    super().__init__(random=random)
+
+  def initialize_episode(self, physics):
+    _find_non_contacting_height(physics, _random_orientation(self.random, physics.batch_size))
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    return _common_observations(physics)
+
+  def get_reward(self, physics):
+    move_reward = rewards.tolerance(physics.torso_velocity()[..., 0], bounds=(self._desired_speed, float('inf')),
+                                    margin=self._desired_speed, value_at_margin=0.5, sigmoid='linear')
+    return _upright_reward(physics) * move_reward
+
+
+class Fetch(base.Task):
+
+  def initialize_episode(self, physics):
+    B = physics.batch_size
+    shape = () if B == 1 else (B,)
+    azimuth = self.random.uniform(0, 2*np.pi, size=shape)
+    zero = np.zeros_like(azimuth)
+    orientation = np.stack([np.cos(azimuth/2), zero, zero, np.sin(azimuth/2)], axis=-1)
+    spawn_radius = 0.9 * physics.named.model.geom_size['floor', 0]
+    xy = self.random.uniform(-spawn_radius, spawn_radius, size=shape + (2,))
+    _find_non_contacting_height(physics, orientation, xy[..., 0], xy[..., 1])
+    ball = np.array(physics.named.data.qpos['ball_root'])
+    ball[..., :2] = self.random.uniform(-spawn_radius, spawn_radius, size=shape + (2,))
+    ball[..., 2] = 2
+    physics.named.data.qpos['ball_root'] = ball
+    vel = np.array(physics.named.data.qvel['ball_root'])
+    vel[..., :2] = 5*self.random.randn(*(shape + (2,)))
+    physics.named.data.qvel['ball_root'] = vel
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    obs = _common_observations(physics)
+    obs['ball_state'] = physics.ball_state()
+    obs['target_position'] = physics.target_position()
+    return obs
+
+  def get_reward(self, physics):
+    arena_radius = physics.named.model.geom_size['floor', 0] * np.sqrt(2)
+    workspace_radius = physics.named.model.site_size['workspace', 0]
+    ball_radius = physics.named.model.geom_size['ball', 0]
+    reach_reward = rewards.tolerance(physics.self_to_ball_distance(), bounds=(0, workspace_radius + ball_radius),
+                                     sigmoid='linear', margin=arena_radius, value_at_margin=0)
+    target_radius = physics.named.model.site_size['target', 0]
+    fetch_reward = rewards.tolerance(physics.ball_to_target_distance(), bounds=(0, target_radius),
+                                     sigmoid='linear', margin=arena_radius, value_at_margin=0)
+    return _upright_reward(physics) * reach_reward * (0.5 + 0.5*fetch_reward)

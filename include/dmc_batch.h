@@ -66,7 +66,7 @@ int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);
  * envs whose mask byte is non-zero (mask == NULL: all).  keyframe < 0: qpos0. */
 int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
 
-/* Field access by mjData name ("qpos", "qvel", "ctrl", "qacc_warmstart", "time",
+/* Field access by mjData name ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "time",
  * "qfrc_applied", "sensordata", "xpos", "xquat", "xmat", "xipos", "geom_xpos",
  * "geom_xmat", "site_xpos", "site_xmat", "subtree_com", "qacc", "actuator_force",
  * "qfrc_actuator", "qfrc_bias", "qfrc_constraint", "contact_dist", "contact_pos",

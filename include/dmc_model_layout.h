@@ -95,7 +95,7 @@ enum { DMC_SOL_PGS = 0, DMC_SOL_CG = 1, DMC_SOL_NEWTON = 2 };
 enum { DMC_TRN_JOINT = 0, DMC_TRN_TENDON = 3 };
 enum { DMC_WRAP_JOINT = 1, DMC_WRAP_SITE = 3 };
 enum { DMC_EQ_TENDON = 3 };
-enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2 };
+enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2, DMC_DYN_FILTEREXACT = 3 };
 enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
 enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };
 enum { DMC_OBJ_BODY = 1, DMC_OBJ_XBODY = 2, DMC_OBJ_JOINT = 3, DMC_OBJ_GEOM = 5, DMC_OBJ_SITE = 6, DMC_OBJ_ACTUATOR = 19 };

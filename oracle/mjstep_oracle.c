@@ -71,7 +71,7 @@ typedef struct {
 typedef struct {
   /* state */
   double time;
-  double *qpos, *qvel, *act, *qacc_warmstart, *ctrl, *qfrc_applied, *xfrc_applied;
+  double *qpos, *qvel, *act, *act_dot, *qacc_warmstart, *ctrl, *qfrc_applied, *xfrc_applied;
   /* position-dependent */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
   double *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
@@ -329,7 +329,7 @@ double* ora_model_real_field(Model* m, const char* name, int* count) {
 }
 
 #define DATA_REAL_FIELDS(X) \
-  X(qpos, m->nq) X(qvel, m->nv) X(act, m->na) X(qacc_warmstart, m->nv) X(ctrl, m->nu) \
+  X(qpos, m->nq) X(qvel, m->nv) X(act, m->na) X(act_dot, m->na) X(qacc_warmstart, m->nv) X(ctrl, m->nu) \
   X(qfrc_applied, m->nv) X(xfrc_applied, 6*m->nbody) \
   X(xpos, 3*m->nbody) X(xquat, 4*m->nbody) X(xmat, 9*m->nbody) X(xipos, 3*m->nbody) \
   X(ximat, 9*m->nbody) X(xanchor, 3*m->njnt) X(xaxis, 3*m->njnt) \
@@ -784,6 +784,46 @@ static int collide_plane_ellipsoid(Contact* c, double margin, const double* p1, 
   for (int k = 0; k < 3; k++) { c->pos[k] = pt[k] - nrm[k]*dist*0.5; c->frame[k] = nrm[k]; c->frame[3 + k] = 0; }
   return 1;
 }
+/* plane (geom 1) vs cylinder (mjc_PlaneCylinder): the deepest rim point of the cap facing the plane,
+ * the matching rim point of the other cap, and two more points of the near disc at +-120 degrees */
+static int collide_plane_cylinder(Contact* c, double margin, const double* p1, const double* m1,
+                                  const double* p2, const double* m2, const double* s2) {
+  double nrm[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
+  double prjaxis = dot3(nrm, axis);
+  if (prjaxis > 0) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  const double dist0 = dot3(dif, nrm);
+  /* direction on the disc that points most towards the plane */
+  double vec[3] = {axis[0]*prjaxis - nrm[0], axis[1]*prjaxis - nrm[1], axis[2]*prjaxis - nrm[2]};
+  const double len2 = dot3(vec, vec);
+  if (len2 >= MINVAL*MINVAL) { const double sc = s2[0]/sqrt(len2); vec[0] *= sc; vec[1] *= sc; vec[2] *= sc; }
+  else { vec[0] = m2[0]*s2[0]; vec[1] = m2[3]*s2[0]; vec[2] = m2[6]*s2[0]; }   /* disc parallel to the plane */
+  const double prjvec = dot3(vec, nrm);
+  axis[0] *= s2[1]; axis[1] *= s2[1]; axis[2] *= s2[1]; prjaxis *= s2[1];
+  int n = 0;
+  if (dist0 + prjaxis + prjvec > margin) return 0;
+  c[n].dist = dist0 + prjaxis + prjvec;
+  for (int k = 0; k < 3; k++) { c[n].pos[k] = p2[k] + vec[k] + axis[k] - nrm[k]*c[n].dist*0.5; c[n].frame[k] = nrm[k]; c[n].frame[3 + k] = 0; }
+  n++;
+  if (dist0 - prjaxis + prjvec <= margin) {
+    c[n].dist = dist0 - prjaxis + prjvec;
+    for (int k = 0; k < 3; k++) { c[n].pos[k] = p2[k] + vec[k] - axis[k] - nrm[k]*c[n].dist*0.5; c[n].frame[k] = nrm[k]; c[n].frame[3 + k] = 0; }
+    n++;
+  }
+  const double prjvec1 = -prjvec*0.5;
+  if (dist0 + prjaxis + prjvec1 <= margin) {
+    double vec1[3];
+    cross3(vec1, vec, axis);
+    normalize3(vec1);
+    const double sc = s2[0]*sqrt(3.0)/2;
+    for (int sg = 1; sg >= -1; sg -= 2) {
+      c[n].dist = dist0 + prjaxis + prjvec1;
+      for (int k = 0; k < 3; k++) { c[n].pos[k] = p2[k] + sg*sc*vec1[k] + axis[k] - vec[k]*0.5 - nrm[k]*c[n].dist*0.5; c[n].frame[k] = nrm[k]; c[n].frame[3 + k] = 0; }
+      n++;
+    }
+  }
+  return n;
+}
 /* capsule (geom 1) vs ellipsoid (geom 2): minimise the swept-sphere gap over the axis parameter */
 static int collide_capsule_ellipsoid(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
                                      const double* p2, const double* m2, const double* s2) {
@@ -844,10 +884,12 @@ static void collision(const Model* m, Data* d) {
     int n = 0;
     /* cylinders have no restated narrow phase: they are tested as their enclosing capsule
      * (same radius / half-length) and a hit only raises DMC_WARN_COLLISION */
-    const int guard = t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER;
+    const int guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && t1 != DMC_GEOM_PLANE;
+    const int plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
-    if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_SPHERE) { double nrm[3] = {m1[2], m1[5], m1[8]}; n = raw_plane_sphere(c, margin, p1, nrm, p2, s2[0]); }
+    if (plane_cyl) n = collide_plane_cylinder(c, margin, p1, m1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_SPHERE) { double nrm[3] = {m1[2], m1[5], m1[8]}; n = raw_plane_sphere(c, margin, p1, nrm, p2, s2[0]); }
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) n = collide_plane_capsule(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) n = collide_plane_box(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) n = raw_sphere_sphere(c, margin, p1, s1[0], p2, s2[0]);
@@ -1508,12 +1550,14 @@ static void fwd_actuation(const Model* m, Data* d) {
   int nv = m->nv, nu = m->nu;
   memset(d->qfrc_actuator, 0, sizeof(double) * (size_t)nv);
   memset(d->actuator_force, 0, sizeof(double) * (size_t)nu);
+  memset(d->act_dot, 0, sizeof(double) * (size_t)m->na);
   if (m->opt_disableflags & DMC_DSBL_ACTUATION) return;
   for (int i = 0; i < nu; i++) if (isnan(d->ctrl[i]) || fabs(d->ctrl[i]) > MAXVAL) {
     d->warning[DMC_WARN_BADCTRL]++;
     memset(d->ctrl, 0, sizeof(double) * (size_t)nu);
     break;
   }
+  int kact = 0;
   for (int i = 0; i < nu; i++) {
     double ctrl = d->ctrl[i];
     if (m->actuator_ctrllimited[i] && !(m->opt_disableflags & DMC_DSBL_CLAMPCTRL))
@@ -1522,7 +1566,17 @@ static void fwd_actuation(const Model* m, Data* d) {
     double gain = gp[0], bias = 0;
     if (m->actuator_gaintype[i] == DMC_GAIN_AFFINE) gain = gp[0] + gp[1]*d->actuator_length[i] + gp[2]*d->actuator_velocity[i];
     if (m->actuator_biastype[i] == DMC_BIAS_AFFINE) bias = bp[0] + bp[1]*d->actuator_length[i] + bp[2]*d->actuator_velocity[i];
-    double force = gain*ctrl + bias;
+    /* actuators with dynamics: activation state act[k] (k-th stateful actuator) drives the gain;
+     * integrator: act_dot = ctrl; filter / filterexact: act_dot = (ctrl - act) / tau */
+    double input = ctrl;
+    if (m->actuator_dyntype[i] != DMC_DYN_NONE) {
+      const double act = d->act[kact];
+      if (m->actuator_dyntype[i] == DMC_DYN_INTEGRATOR) d->act_dot[kact] = ctrl;
+      else d->act_dot[kact] = (ctrl - act) / mjMAX(MINVAL, m->actuator_dynprm[10*i]);
+      input = act;
+      kact++;
+    }
+    double force = gain*input + bias;
     if (m->actuator_forcelimited[i]) force = mjMAX(m->actuator_forcerange[2*i], mjMIN(m->actuator_forcerange[2*i + 1], force));
     d->actuator_force[i] = force;
     if (m->actuator_trntype[i] == DMC_TRN_TENDON) {
@@ -1982,6 +2036,14 @@ static void integrate_pos(const Model* m, double* qpos, const double* qvel, doub
 }
 static void advance(const Model* m, Data* d, const double* qacc, const double* qvel_for_pos) {
   double dt = m->opt_timestep;
+  /* activations first (mj_advance): explicit Euler, or the exact exponential for filterexact */
+  for (int i = 0, k = 0; i < m->nu; i++) if (m->actuator_dyntype[i] != DMC_DYN_NONE) {
+    if (m->actuator_dyntype[i] == DMC_DYN_FILTEREXACT) {
+      const double tau = mjMAX(MINVAL, m->actuator_dynprm[10*i]);
+      d->act[k] += d->act_dot[k] * tau * (1 - exp(-dt/tau));
+    } else d->act[k] += dt*d->act_dot[k];
+    k++;
+  }
   for (int i = 0; i < m->nv; i++) d->qvel[i] += dt*qacc[i];
   integrate_pos(m, d->qpos, qvel_for_pos ? qvel_for_pos : d->qvel, dt);
   d->time += dt;

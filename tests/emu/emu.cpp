@@ -50,7 +50,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   const int sizes[] = {L.d.nq, L.d.nv, L.d.nu, L.d.nv, L.d.nv, 1,
                        L.d.nsensordata, 3*nb, 4*nb, 9*nb, 3*nb, 3*L.d.ngeom, 9*L.d.ngeom,
                        3*L.d.nsite, 9*L.d.nsite, 3*nb, L.d.nv, L.d.nu, L.d.nv, L.d.nv, L.d.nv,
-                       L.d.nconmax, 3*L.d.nconmax, 9*L.d.nconmax, 6*L.d.nconmax, 6*nb};
+                       L.d.nconmax, 3*L.d.nconmax, 9*L.d.nconmax, 6*L.d.nconmax, 6*nb, L.d.na};
   const int NF = sizeof(sizes)/sizeof(int);
   std::vector<std::vector<T>> buf(NF);
   for (int k = 0; k < NF; k++) { buf[k].resize(sizes[k] + 1); for (int i = 0; i < sizes[k]; i++) buf[k][i] = (T)f[k][i]; }
@@ -65,7 +65,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.qacc = buf[16].data(); io.actuator_force = buf[17].data(); io.qfrc_actuator = buf[18].data();
   io.qfrc_bias = buf[19].data(); io.qfrc_constraint = buf[20].data();
   io.contact_dist = buf[21].data(); io.contact_pos = buf[22].data(); io.contact_frame = buf[23].data();
-  io.contact_force = buf[24].data(); io.cvel = buf[25].data();
+  io.contact_force = buf[24].data(); io.cvel = buf[25].data(); io.act = buf[26].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   DynLayoutSrc ls; ls.p = &L;

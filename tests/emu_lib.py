@@ -14,7 +14,7 @@ FIELDS = ['qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time',
           'sensordata', 'xpos', 'xquat', 'xmat', 'xipos', 'geom_xpos', 'geom_xmat',
           'site_xpos', 'site_xmat', 'subtree_com', 'qacc', 'actuator_force',
           'qfrc_actuator', 'qfrc_bias', 'qfrc_constraint',
-          'contact_dist', 'contact_pos', 'contact_frame', 'contact_force', 'cvel']
+          'contact_dist', 'contact_pos', 'contact_frame', 'contact_force', 'cvel', 'act']
 IFIELDS = ['ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2']
 
 
@@ -55,7 +55,7 @@ class EmuPhysics:
     nb = m.nbody
     sizes = [m.nq, m.nv, m.nu, m.nv, m.nv, 1, m.nsensordata, 3*nb, 4*nb, 9*nb, 3*nb,
              3*m.ngeom, 9*m.ngeom, 3*m.nsite, 9*m.nsite, 3*nb, m.nv, m.nu, m.nv, m.nv, m.nv,
-             self.nconmax, 3*self.nconmax, 9*self.nconmax, 6*self.nconmax, 6*nb]
+             self.nconmax, 3*self.nconmax, 9*self.nconmax, 6*self.nconmax, 6*nb, m.na]
     self.f = {n: np.zeros(max(s, 1)) for n, s in zip(FIELDS, sizes)}
     self._sizes = dict(zip(FIELDS, sizes))
     self.fi = {'ncon': np.zeros(1, np.int32), 'nefc': np.zeros(1, np.int32),

@@ -500,6 +500,29 @@ def test_noslip_matches_oracle(precision, cone, condim):
   b.close()
 
 
+@pytest.mark.parametrize('precision,tol', [(64, 1e-10), (32, 5e-4)])
+def test_plane_cylinder_contacts_match_oracle(precision, tol):
+  # mjc_PlaneCylinder restated (up to 4 contacts); short horizon: a wobbling disc is chaotic
+  m = mc.compile_xml("""<mujoco><option timestep="0.002"/><worldbody><geom type="plane" size="2 2 .1"/>
+    <body pos="0 0 .2" quat="0.9 0.3 0.2 0.1"><freejoint/><geom type="cylinder" size=".1 .05" density="800"/></body>
+    <body pos=".5 0 .06"><freejoint/><geom type="cylinder" size=".1 .05" density="800"/></body>
+    <body pos="1 0 .11" quat="0.70710678118 0.70710678118 0 0"><freejoint/><geom type="cylinder" size=".1 .05" density="800"/></body>
+  </worldbody></mujoco>""")
+  B = 4
+  q = np.tile(m.qpos0, (B, 1))
+  b = _batch(m, B, precision=precision)
+  b.set('qpos', q)
+  ora = _oracles(m, q)
+  b.step(250)
+  for o in ora:
+    o.step(250)
+  np.testing.assert_array_equal(b.get('ncon')[:, 0], [o.ncon for o in ora])
+  assert ora[0].ncon >= 5                      # 3 under the flat disc, 2 under the one on its side
+  np.testing.assert_allclose(b.get('qpos'), np.array([o.qpos for o in ora]), rtol=0, atol=tol)
+  assert not b.get('warning').any()
+  b.close()
+
+
 def test_elliptic_contact_force_equals_weight_on_gpu():
   # wrapper/core_test.py:393-416 with cone="elliptic", through touch (sums normal forces) and
   # qfrc_constraint; fp64 kernel.

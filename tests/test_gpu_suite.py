@@ -25,7 +25,8 @@ def _oracle(model):
                                          ('ball_in_cup', 'catch'), ('fish', 'upright'), ('fish', 'swim'),
                                          ('manipulator', 'bring_ball'), ('manipulator', 'bring_peg'),
                                          ('manipulator', 'insert_ball'), ('swimmer', 'swimmer6'),
-                                         ('swimmer', 'swimmer15'), ('humanoid_CMU', 'stand'), ('humanoid_CMU', 'run')])
+                                         ('swimmer', 'swimmer15'), ('humanoid_CMU', 'stand'), ('humanoid_CMU', 'run'),
+                                         ('quadruped', 'walk'), ('quadruped', 'fetch')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -52,7 +53,7 @@ def test_suite_task_properties(domain, task):
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
                                          ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2'),
                                          ('ball_in_cup', 'catch'), ('manipulator', 'bring_ball'),
-                                         ('humanoid_CMU', 'walk')])
+                                         ('humanoid_CMU', 'walk'), ('quadruped', 'run')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -361,13 +362,13 @@ def test_model_constants_rewritten_between_episodes():
 
 
 def test_cylinder_pairs_are_guarded_not_silently_ignored():
-  """Cylinders have no narrow phase: a cylinder coming within range (tested as its
-  enclosing capsule) raises the dmcWARN_COLLISION counter instead of a contact."""
+  """Only plane-cylinder has a narrow phase: a cylinder coming within range of any other geom
+  (tested as its enclosing capsule) raises the dmcWARN_COLLISION counter instead of a contact."""
   from dm_control_amd.batch import BatchedPhysics
   m = mc.compile_xml("""
   <mujoco><worldbody>
-    <geom name='floor' type='plane' size='1 1 1'/>
-    <body name='can' pos='0 0 .5'><freejoint/><geom type='cylinder' size='.1 .1'/></body>
+    <geom name='post' type='sphere' size='.1'/>
+    <body name='can' pos='0 0 .6'><freejoint/><geom type='cylinder' size='.1 .1'/></body>
   </worldbody></mujoco>""")
   b = BatchedPhysics(m, 2, precision=64)
   o = _oracle(m)
@@ -549,7 +550,7 @@ def test_manipulator_batched_targets_and_receptacle():
 
 @pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
                                        ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4),
-                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6)])
+                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('quadruped', 4)])
 def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
   env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
@@ -574,11 +575,11 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   if name == 'cmu_2019_position_floor':
     # BASELINE config 4 physics: start upright with perturbed joints (qpos0 is the upright pose)
     q[:, 7:] += rs.uniform(-.15, .15, (NE, m.nq - 7))
-  if name in ('manipulator', 'humanoid_CMU'):
+  if name in ('manipulator', 'humanoid_CMU', 'quadruped'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
     # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
     from dm_control_amd import suite
-    env = suite.load(name, 'insert_ball' if name == 'manipulator' else 'stand', task_kwargs=dict(random=5),
+    env = suite.load(name, dict(manipulator='insert_ball', quadruped='fetch').get(name, 'stand'), task_kwargs=dict(random=5),
                      physics_kwargs=dict(batch_size=NE))
     env.reset()
     q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
@@ -603,6 +604,8 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     b.set('qpos', np.stack([o.qpos for o in refs]))
     b.set('qvel', np.stack([o.qvel for o in refs]))
     b.set('qacc_warmstart', np.stack([o.qacc_warmstart for o in refs]))
+    if m.na:
+      b.set('act', np.stack([o.act for o in refs]))
     b.set_control(a)
     b.step(nsub)
     oracle.rollout_legacy(refs, a[None], nsub=nsub)

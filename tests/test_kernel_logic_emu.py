@@ -295,3 +295,59 @@ def test_config4_cmu_position_floor_rollout_fp64():
   np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
   assert np.abs(o.actuator_force).max() <= 150 + 1e-9                 # forcerange clamps (largest: lowerback, 150)
   assert not o.warning.any() and not e.warning.any()
+
+
+@pytest.mark.parametrize('walls_and_ball', [False, True])
+def test_quadruped_rollout_fp64(walls_and_ball):
+  """suite quadruped (walk / run model, fetch model): filtered position servos (12 activation states),
+  tendon transmissions and tendon equalities, ellipsoid torso, condim-6 priority ball, wall planes."""
+  from dm_control_amd.suite import quadruped
+  m = mc.compile_xml(quadruped.make_model(walls_and_ball=walls_and_ball))
+  assert m.na == 12 and m.nu == 12
+  o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=24)
+  rs = np.random.RandomState(0)
+  q = m.qpos0.copy()
+  q[2] = 0.7
+  q[3:7] = rs.randn(4)
+  q[3:7] /= np.linalg.norm(q[3:7])
+  o.qpos[:] = q
+  e.qpos[:] = q
+  o.forward()
+  worst, maxcon = 0.0, 0
+  for _ in range(400):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    maxcon = max(maxcon, o.ncon)
+    worst = max(worst, np.abs(e.qpos - o.qpos).max())
+  assert maxcon >= 3 and worst < 1e-9
+  np.testing.assert_allclose(e.act, o.act, rtol=0, atol=1e-12)
+  assert np.abs(o.act).max() > 0.05
+  assert not o.warning.any() and not e.warning.any()
+
+
+def test_actuator_dynamics_closed_forms():
+  # integrator: act = integral of ctrl; filter (explicit Euler): act_n = 1 - (1 - dt/tau)^n;
+  # filterexact: act = 1 - exp(-t/tau); the force is gain * act + bias
+  xml = """<mujoco><option timestep="0.005" gravity="0 0 0"/><worldbody>
+  <body><joint name="a" type="hinge" axis="0 1 0" damping="1"/><geom type="capsule" fromto="0 0 0 .4 0 0" size=".04"/></body>
+  </worldbody><actuator>
+   <general name="f" joint="a" dyntype="filter" dynprm="0.1" gainprm="50" biastype="affine" biasprm="0 -50"/>
+   <general name="i" joint="a" dyntype="integrator" gainprm="5" ctrllimited="true" ctrlrange="-1 0.5"/>
+   <motor name="m" joint="a" gear="2"/>
+   <general name="fe" joint="a" dyntype="filterexact" dynprm="0.05" gainprm="3"/>
+  </actuator></mujoco>"""
+  m = mc.compile_xml(xml)
+  assert m.na == 3
+  for P in (lambda: OraclePhysics(m, legacy_step=False), lambda: EmuPhysics(m, 64)):
+    p = P()
+    p.ctrl[:] = [1, 2, 0, 1]            # the integrator's ctrl is clamped to 0.5 first
+    for _ in range(40):
+      p.step(1, False) if isinstance(p, EmuPhysics) else p.step()
+    np.testing.assert_allclose(p.act, [1 - (1 - 0.005/0.1)**40, 0.5*40*0.005, 1 - np.exp(-40*0.005/0.05)], rtol=1e-12)
+    p.forward()
+    np.testing.assert_allclose(p.actuator_force, [50*p.act[0] - 50*p.qpos[0], 5*p.act[1], 0, 3*p.act[2]], rtol=1e-12, atol=1e-12)
+  with pytest.raises(mc.MjcfError):
+    mc.compile_xml(xml.replace('timestep="0.005"', 'timestep="0.005" integrator="RK4"'))
