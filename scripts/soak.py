@@ -8,7 +8,8 @@ from dm_control_amd import suite
 B = 256
 T = int(os.environ.get('T', 300))
 out = []
-for domain, task in suite.ALL_TASKS:
+_ONLY = os.environ.get('DOMAINS')
+for domain, task in [dt for dt in suite.ALL_TASKS if not _ONLY or dt[0] in _ONLY.split(',')]:
   try:
     env = suite.load(domain, task, task_kwargs=dict(random=0), physics_kwargs=dict(batch_size=B, precision=32))
     spec = env.action_spec()
