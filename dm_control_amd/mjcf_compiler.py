@@ -16,6 +16,9 @@ own copy of MuJoCo's schema, e.g. option :51-80, geom :311-347, joint :285-310).
 Output: `Model` with numpy arrays named like mjModel fields, plus `pack()` which
 serialises them into the blob described by include/dmc_model_layout.h.
 """
+import collections
+import copy
+import hashlib
 import math
 import xml.etree.ElementTree as ET
 
@@ -1395,9 +1398,32 @@ def _solimp(s):
   return out
 
 
-def compile_xml(xml_string, assets=None):
+_COMPILE_CACHE = collections.OrderedDict()
+_COMPILE_CACHE_SIZE = 16
+
+
+def compile_xml(xml_string, assets=None, cache=True):
   """MJCF string (+ include assets) -> Model.  Mirrors
-  `MjModel.from_xml_string(xml_string, assets)` (wrapper/core.py:289)."""
+  `MjModel.from_xml_string(xml_string, assets)` (wrapper/core.py:289).
+
+  Compiled models are cached by the hash of the XML and its assets: composer environments
+  recompile their model at every episode (composer/environment.py:377-383), mostly to the very
+  same XML.  A cache hit returns a private deep copy (tasks write into model fields)."""
   if isinstance(xml_string, bytes):
     xml_string = xml_string.decode()
-  return _Compiler(xml_string, assets).compile()
+  if not cache:
+    return _Compiler(xml_string, assets).compile()
+  h = hashlib.sha1(xml_string.encode())
+  for k in sorted(assets or {}):
+    v = assets[k]
+    h.update(b'\0' + k.encode() + b'\0' + (v if isinstance(v, bytes) else v.encode()))
+  key = h.digest()
+  hit = _COMPILE_CACHE.get(key)
+  if hit is None:
+    hit = _Compiler(xml_string, assets).compile()
+    _COMPILE_CACHE[key] = hit
+    while len(_COMPILE_CACHE) > _COMPILE_CACHE_SIZE:
+      _COMPILE_CACHE.popitem(last=False)
+  else:
+    _COMPILE_CACHE.move_to_end(key)
+  return copy.deepcopy(hit)

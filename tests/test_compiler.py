@@ -122,3 +122,64 @@ def test_bad_models_raise_value_error():
     mc.compile_xml('<notmujoco/>')
   with pytest.raises(ValueError):
     mc.compile_xml('<mujoco><worldbody><geom type="mesh"/></worldbody></mujoco>')
+
+
+def _pymjcf_shape(xml, prefix='walker/'):
+  """Rewrites a single-model MJCF file into the shape PyMJCF's to_xml_string() emits for a model attached
+  to an arena (mjcf/README.md:356-421): the attached model's global defaults live in a default class
+  named `<prefix>`, its named classes become `<prefix><name>`, every named element is prefixed, the
+  arena's own (empty) global defaults are the class `/`, and elements that relied on the global defaults
+  carry `class="<prefix>"` / `childclass="<prefix>"` explicitly."""
+  import xml.etree.ElementTree as ET
+  root = ET.fromstring(xml)
+  dflt = root.find('default')
+  scoped = ET.Element('default', {'class': prefix})
+  for c in list(dflt):
+    dflt.remove(c)
+    scoped.append(c)
+  for d in scoped.iter('default'):
+    if d is not scoped:
+      d.set('class', prefix + d.get('class'))
+  dflt.append(ET.Element('default', {'class': '/'}))
+  dflt.append(scoped)
+  wb = root.find('worldbody')
+  floor = wb.find('geom')
+  floor.set('class', '/')
+  frame = wb.find('body')
+  frame.set('childclass', prefix)
+  NAME_REFS = ('name', 'joint', 'site', 'body', 'body1', 'body2', 'tendon', 'objname', 'geom')
+  for section in (frame, root.find('contact'), root.find('actuator'), root.find('sensor')):
+    for e in section.iter():
+      for k in NAME_REFS:
+        if k in e.attrib and e is not floor:
+          e.set(k, prefix + e.get(k))
+      for k in ('class', 'childclass'):
+        if k in e.attrib and e is not frame:
+          e.set(k, prefix + e.get(k))
+  for section in (root.find('actuator'), root.find('sensor')):
+    for e in section:
+      e.attrib.setdefault('class', prefix)
+  return ET.tostring(root, encoding='unicode')
+
+
+def test_pymjcf_style_default_scoping_compiles_to_the_same_model():
+  """a composer model reaches the compiler as PyMJCF output -- prefixed names, the
+  attached model's defaults in a class named `walker/`, nothing in the global default context.  The
+  config 4 asset rewritten into that shape must compile to the same numbers."""
+  flat = open(os.path.join(ASSETS, 'cmu_2019_position_floor.xml')).read()
+  a, b = mc.compile_xml(flat), mc.compile_xml(_pymjcf_shape(flat))
+  assert b.names['body'][1:4] == ['walker/walker', 'walker/root', 'walker/lhipjoint']
+  assert b.names['actuator'][0] == 'walker/headrx'
+  (ia, ra), (ib, rb) = a.pack(), b.pack()
+  np.testing.assert_array_equal(ia, ib)
+  np.testing.assert_array_equal(ra, rb)
+
+
+def test_compile_cache_returns_private_copies():
+  xml = open(os.path.join(ASSETS, 'cheetah.xml')).read()
+  a = mc.compile_xml(xml)
+  a.dof_damping[3] = 123.0                      # a task writing into its model ...
+  b = mc.compile_xml(xml)
+  assert b.dof_damping[3] != 123.0              # ... never reaches the next environment's model
+  c = mc.compile_xml(xml, cache=False)
+  np.testing.assert_array_equal(b.pack()[1], c.pack()[1])
