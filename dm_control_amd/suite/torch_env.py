@@ -60,15 +60,17 @@ class TorchBatchedEnv:
     import torch
     self.torch = torch
     self.device = torch.device('cuda', device_id)
-    self.model = mjcf_compiler.compile_xml(common.read_model(self._MODEL))
+    self.model = mjcf_compiler.compile_xml(self._model_xml())
     m = self.model
     self.B = int(batch_size)
     if n_sub_steps is None:
       n_sub_steps = 1 if self._CONTROL_TIMESTEP is None else int(round(self._CONTROL_TIMESTEP / m.opt.timestep))
     self.n_sub_steps = n_sub_steps
     self.dtype = torch.float32 if precision == 32 else torch.float64
-    self.physics = BatchedPhysics(m, self.B, device_id=device_id, precision=precision,
-                                  **common.DEFAULT_CAPS.get(self._MODEL[:-4], {}))
+    caps = dict(common.DEFAULT_CAPS.get(self._MODEL[:-4], {}))
+    if caps.pop('precision', precision) != precision:
+      raise ValueError('%s only runs in fp%d (its fp64 scratch does not fit in LDS)' % (self._MODEL, common.DEFAULT_CAPS[self._MODEL[:-4]]['precision']))
+    self.physics = BatchedPhysics(m, self.B, device_id=device_id, precision=precision, **caps)
     mask = OUT['sensor']
     for name in self._OUTPUTS:
       mask |= OUT[{'subtree_com': 'subtree_com'}.get(name, name)]
@@ -80,6 +82,9 @@ class TorchBatchedEnv:
     self.ncon = torch.zeros((1, self.B), dtype=torch.int32, device=self.device)
     bound = [('qpos', self.qpos), ('qvel', self.qvel), ('ctrl', self.ctrl), ('qacc_warmstart', self.warm),
              ('sensordata', self.sensordata), ('time', self.time), ('ncon', self.ncon)]
+    if m.na:
+      self.act = mk(m.na)      # activation states (filtered servos): zero at every reset
+      bound.append(('act', self.act))
     for name in self._OUTPUTS:
       rows = self.physics._rows(name)[0]
       t = mk(rows)
@@ -94,6 +99,9 @@ class TorchBatchedEnv:
     self._gen = torch.Generator(device=self.device).manual_seed(seed)
     self._make_start_pool()
     self.reset()
+
+  def _model_xml(self):
+    return common.read_model(self._MODEL)
 
   # -- helpers -----------------------------------------------------------------------
   def _stream(self):
@@ -134,6 +142,8 @@ class TorchBatchedEnv:
     self.warm.copy_(torch.where(m2, self.pool_warm[:, pick], self.warm))
     self.time.copy_(torch.where(m2, torch.zeros_like(self.time), self.time))
     self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
+    if self.model.na:
+      self.act.copy_(torch.where(m2, torch.zeros_like(self.act), self.act))
     if self._OUTPUTS:
       # forward is a pure function of (qpos, qvel): recomputing it for the environments that
       # were not reset reproduces the derived arrays they already hold; their solver warm start
@@ -187,6 +197,10 @@ class Humanoid(TorchBatchedEnv):
   _OUTPUTS = ('xpos', 'xmat')
   _CONTROL_TIMESTEP = .025
   _STAND_HEIGHT = 1.4
+  _TORSO = 'torso'
+  _UPRIGHT = 8              # xmat entry of the torso that measures uprightness ('zz')
+  _SIDES = ('left_', 'right_')
+  _COM_VEL_SENSOR = 'torso_subtreelinvel'
   move_speed = 0.0
 
   def __init__(self, batch_size, move_speed=0.0, time_limit=25.0, pool_size=None, **kw):
@@ -241,18 +255,18 @@ class Humanoid(TorchBatchedEnv):
     return self._xpos('head')[2]
 
   def torso_upright(self):
-    return self._xmat('torso')[8]
+    return self._xmat(self._TORSO)[self._UPRIGHT]
 
   def center_of_mass_velocity(self):
-    adr = self.model.sensor_adr[self.model.name2id('torso_subtreelinvel', 'sensor')]
+    adr = self.model.sensor_adr[self.model.name2id(self._COM_VEL_SENSOR, 'sensor')]
     return self.sensordata[adr:adr + 3]
 
   def extremities(self):
     """(12, B): hands and feet relative to the torso, in the torso frame."""
-    R = self._xmat('torso').reshape(3, 3, self.B)      # R[i, j] = xmat[3 i + j]
-    torso = self._xpos('torso')
+    R = self._xmat(self._TORSO).reshape(3, 3, self.B)      # R[i, j] = xmat[3 i + j]
+    torso = self._xpos(self._TORSO)
     out = []
-    for side in ('left_', 'right_'):
+    for side in self._SIDES:
       for limb in ('hand', 'foot'):
         d = self._xpos(side + limb) - torso
         out.append((d[:, None, :] * R).sum(dim=0))      # d . frame  (row vector times matrix)
@@ -261,7 +275,7 @@ class Humanoid(TorchBatchedEnv):
   def observation(self):
     """(B, 67): joint_angles 21, head_height 1, extremities 12, torso_vertical 3, com_velocity 3,
     velocity 27 -- the order of Humanoid.get_observation flattened."""
-    parts = [self.qpos[7:], self.head_height()[None], self.extremities(), self._xmat('torso')[6:9],
+    parts = [self.qpos[7:], self.head_height()[None], self.extremities(), self._xmat(self._TORSO)[6:9],
              self.center_of_mass_velocity(), self.qvel]
     return self.torch.cat(parts, dim=0).T
 
@@ -282,6 +296,21 @@ class Humanoid(TorchBatchedEnv):
     move = tolerance(torch, speed, bounds=(self.move_speed, float('inf')), margin=self.move_speed,
                      value_at_margin=0, sigmoid='linear')
     return small_control * stand_reward * (5 * move + 1) / 6
+
+
+class HumanoidCMU(Humanoid):
+  """Humanoid_CMU stand / walk / run (suite/humanoid_CMU.py:132-190) on device: the same task as the
+  humanoid with the thorax as torso, uprightness = thorax y axis on world z, 137 observations."""
+
+  _MODEL = 'humanoid_CMU.xml'
+  _CONTROL_TIMESTEP = .02
+  _TORSO = 'thorax'
+  _UPRIGHT = 7              # 'zy'
+  _SIDES = ('l', 'r')
+  _COM_VEL_SENSOR = 'thorax_subtreelinvel'
+
+  def __init__(self, batch_size, move_speed=0.0, time_limit=20.0, **kw):
+    super().__init__(batch_size, move_speed=move_speed, time_limit=time_limit, **kw)
 
 
 class _RandomJointStart(TorchBatchedEnv):
@@ -381,6 +410,74 @@ class Hopper(_RandomJointStart):
     return standing * (small_control + 4) / 5
 
 
+class Quadruped(TorchBatchedEnv):
+  """Quadruped walk / run (suite/quadruped.py:281-342) on device.  Start states: a random orientation,
+  raised in 1 cm steps from the floor until nothing touches (`_find_non_contacting_height`), evaluated for
+  the whole pool at once."""
+
+  _MODEL = 'quadruped.xml'
+  _OUTPUTS = ('xmat',)
+  _CONTROL_TIMESTEP = .02
+
+  def __init__(self, batch_size, desired_speed=0.5, time_limit=20.0, **kw):
+    self.desired_speed = float(desired_speed)
+    super().__init__(batch_size, time_limit=time_limit, **kw)
+
+  def _model_xml(self):
+    from dm_control_amd.suite import quadruped
+    return quadruped.make_model(floor_size=20 * self.desired_speed)
+
+  def _make_start_pool(self):
+    torch, m = self.torch, self.model
+    q = np.tile(m.qpos0, (self.B, 1))
+    quat = self._rs.randn(self.B, 4)
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 2] = 0.0
+    self._upload_qpos(q)
+    self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_(); self.act.zero_()
+    for _ in range(10000):
+      self.physics.forward(disable_actuation=True, stream=self._stream())
+      touching = self.ncon[0] > 0
+      if not bool(touching.any()):
+        break
+      self.qpos[2] += 0.01 * touching.to(self.dtype)
+    else:
+      raise RuntimeError('Failed to find a non-contacting configuration.')
+    self.pool_qpos = self.qpos.clone()
+    self.pool_qvel = torch.zeros_like(self.qvel)
+    self.pool_warm = torch.zeros_like(self.warm)
+    m = self.model
+    hinge = [j for j in range(m.njnt) if m.jnt_type[j] == 3]
+    self._hq = torch.tensor([m.jnt_qposadr[j] for j in hinge], device=self.device)
+    self._hv = torch.tensor([m.jnt_dofadr[j] for j in hinge], device=self.device)
+    rows = lambda types: torch.tensor([m.sensor_adr[i] + k for i in range(m.nsensor) if m.sensor_type[i] in types
+                                       for k in range(3)], device=self.device)
+    self._imu_rows = rows((1, 3))          # accelerometer, gyro -- in sensor order, as Physics.imu
+    self._ft_rows = rows((4, 5))           # force, torque
+    adr = m.sensor_adr[m.name2id('velocimeter', 'sensor')]
+    self._vel_rows = slice(adr, adr + 3)
+    self._torso = self._body('torso')
+
+  def torso_upright(self):
+    return self.xmat[9*self._torso + 8]
+
+  def observation(self):
+    """(B, 78): egocentric_state 44 (hinge qpos, hinge qvel, act), torso_velocity 3, torso_upright 1,
+    imu 6, force_torque 24 (arcsinh) -- the order of `_common_observations`."""
+    torch = self.torch
+    parts = [self.qpos[self._hq], self.qvel[self._hv], self.act, self.sensordata[self._vel_rows],
+             self.torso_upright()[None], self.sensordata[self._imu_rows], torch.asinh(self.sensordata[self._ft_rows])]
+    return torch.cat(parts, dim=0).T
+
+  def reward(self):
+    torch = self.torch
+    upright = tolerance(torch, self.torso_upright(), bounds=(1.0, float('inf')), sigmoid='linear', margin=2.0,
+                        value_at_margin=0)
+    move = tolerance(torch, self.sensordata[self._vel_rows][0], bounds=(self.desired_speed, float('inf')),
+                     margin=self.desired_speed, value_at_margin=0.5, sigmoid='linear')
+    return upright * move
+
+
 _TASKS = {
     ('cheetah', 'run'): (CheetahRun, {}),
     ('walker', 'stand'): (Walker, dict(move_speed=0)),
@@ -391,6 +488,11 @@ _TASKS = {
     ('humanoid', 'stand'): (Humanoid, dict(move_speed=0)),
     ('humanoid', 'walk'): (Humanoid, dict(move_speed=1)),
     ('humanoid', 'run'): (Humanoid, dict(move_speed=10)),
+    ('quadruped', 'walk'): (Quadruped, dict(desired_speed=0.5)),
+    ('quadruped', 'run'): (Quadruped, dict(desired_speed=5)),
+    ('humanoid_CMU', 'stand'): (HumanoidCMU, dict(move_speed=0)),
+    ('humanoid_CMU', 'walk'): (HumanoidCMU, dict(move_speed=1)),
+    ('humanoid_CMU', 'run'): (HumanoidCMU, dict(move_speed=10)),
 }
 
 

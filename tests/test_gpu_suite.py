@@ -404,18 +404,21 @@ def test_lqr_domain_linear_dynamics_and_reward():
   env.physics.free()
 
 
-@pytest.mark.parametrize('task,move_speed', [('stand', 0), ('run', 10)])
-def test_torch_humanoid_env_matches_host_task_formulas(task, move_speed):
+@pytest.mark.parametrize('domain,task,move_speed', [('humanoid', 'stand', 0), ('humanoid', 'run', 10),
+                                                   ('humanoid_CMU', 'stand', 0), ('humanoid_CMU', 'walk', 1)])
+def test_torch_humanoid_env_matches_host_task_formulas(domain, task, move_speed):
   """Device-resident humanoid: start states are collision-free, observations
   and rewards equal Humanoid.get_observation / get_reward evaluated on the same device state."""
   import torch
   from dm_control_amd.suite import torch_env, rewards
   B = 48
-  env = torch_env.make('humanoid', task, B, precision=32, time_limit=0.1, seed=2)
+  cmu = domain == 'humanoid_CMU'
+  env = torch_env.make(domain, task, B, precision=32, time_limit=0.08 if cmu else 0.1, seed=2)
   m = env.model
-  assert env.n_sub_steps == 5 and env.step_limit == 4
+  assert env.n_sub_steps == (10 if cmu else 5) and env.step_limit == 4
+  torso, sides, upright_idx = ('thorax', ('l', 'r'), (2, 1)) if cmu else ('torso', ('left_', 'right_'), (2, 2))
   obs = env.reset()
-  assert obs.shape == (B, 67) and torch.isfinite(obs).all()
+  assert obs.shape == (B, 137 if cmu else 67) and torch.isfinite(obs).all()
   assert int(env.ncon.max()) == 0                       # rejection-sampled: no initial contacts
   g = torch.Generator(device='cuda').manual_seed(0)
   bid = lambda n: m.name2id(n, 'body')
@@ -427,16 +430,16 @@ def test_torch_humanoid_env_matches_host_task_formulas(task, move_speed):
     q, v, s = env.physics.get('qpos'), env.physics.get('qvel'), env.physics.get('sensordata')
     xpos = env.physics.get('xpos').reshape(B, -1, 3)
     xmat = env.physics.get('xmat').reshape(B, -1, 3, 3)
-    R, torso = xmat[:, bid('torso')], xpos[:, bid('torso')]
-    ext = np.concatenate([np.einsum('bi,bij->bj', xpos[:, bid(sd + lb)] - torso, R)
-                          for sd in ('left_', 'right_') for lb in ('hand', 'foot')], axis=1)
-    adr = m.sensor_adr[m.name2id('torso_subtreelinvel', 'sensor')]
+    R, tpos = xmat[:, bid(torso)], xpos[:, bid(torso)]
+    ext = np.concatenate([np.einsum('bi,bij->bj', xpos[:, bid(sd + lb)] - tpos, R)
+                          for sd in sides for lb in ('hand', 'foot')], axis=1)
+    adr = m.sensor_adr[m.name2id(torso + '_subtreelinvel', 'sensor')]
     com_vel = s[:, adr:adr + 3]
     head = xpos[:, bid('head'), 2]
     want_obs = np.concatenate([q[:, 7:], head[:, None], ext, R[:, 2, :], com_vel, v], axis=1)
     np.testing.assert_allclose(obs.cpu().numpy(), want_obs, rtol=1e-5, atol=1e-5)
     standing = rewards.tolerance(head, bounds=(1.4, float('inf')), margin=1.4 / 4)
-    upright = rewards.tolerance(R[:, 2, 2], bounds=(0.9, float('inf')), sigmoid='linear', margin=1.9, value_at_margin=0)
+    upright = rewards.tolerance(R[:, upright_idx[0], upright_idx[1]], bounds=(0.9, float('inf')), sigmoid='linear', margin=1.9, value_at_margin=0)
     sc = (4 + rewards.tolerance(a.cpu().numpy(), margin=1, value_at_margin=0, sigmoid='quadratic').mean(axis=1)) / 5
     if move_speed == 0:
       want = sc * standing * upright * rewards.tolerance(com_vel[:, :2], margin=2).mean(axis=1)
@@ -623,7 +626,8 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   b.close()
 
 
-@pytest.mark.parametrize('domain,task', [('walker', 'run'), ('walker', 'stand'), ('hopper', 'hop'), ('hopper', 'stand')])
+@pytest.mark.parametrize('domain,task', [('walker', 'run'), ('walker', 'stand'), ('hopper', 'hop'), ('hopper', 'stand'),
+                                         ('quadruped', 'walk'), ('quadruped', 'run')])
 def test_torch_env_matches_host_task(domain, task):
   """Device-resident walker / hopper: observations and rewards equal the host task evaluated on the
   same state (the host Physics is fed the device env's qpos / qvel / ctrl)."""
@@ -639,10 +643,13 @@ def test_torch_env_matches_host_task(domain, task):
     a = torch.rand((B, dev.model.nu), device='cuda', generator=g, dtype=torch.float64) * 2 - 1
     q_before, v_before = dev.physics.get('qpos'), dev.physics.get('qvel')
     w_before = dev.physics.get('qacc_warmstart')
+    act_before = dev.physics.get('act')
     obs, rew, done = dev.step(a)
     # replay the same env-step on the host-facade physics from the same state
     hp = host.physics
     hp.data.qpos = q_before; hp.data.qvel = v_before; hp.data.qacc_warmstart = w_before
+    if dev.model.na:
+      hp.data.act = act_before
     hp.forward()
     hp.data.qacc_warmstart = w_before
     host.task.before_step(a.cpu().numpy(), hp)
