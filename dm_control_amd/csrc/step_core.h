@@ -97,6 +97,10 @@ template <> DMC_DEV float t_cos<float>(float x) { return cosf(x); }
 template <typename T> DMC_DEV T t_pow(T x, T y) { return (T)pow((double)x, (double)y); }
 template <> DMC_DEV float t_pow<float>(float x, float y) { return powf(x, y); }
 template <typename T> DMC_DEV T t_exp(T x) { return (T)exp((double)x); }
+template <typename T> DMC_DEV T t_atan2(T y, T x) { return (T)atan2((double)y, (double)x); }
+template <> DMC_DEV float t_atan2<float>(float y, float x) { return atan2f(y, x); }
+template <typename T> DMC_DEV T t_fmod(T x, T y) { return (T)fmod((double)x, (double)y); }
+template <> DMC_DEV float t_fmod<float>(float x, float y) { return fmodf(x, y); }
 template <> DMC_DEV float t_exp<float>(float x) { return expf(x); }
 template <typename T> DMC_DEV T t_abs(T x) { return x < 0 ? -x : x; }
 template <typename T> DMC_DEV T t_max(T a, T b) { return a > b ? a : b; }
@@ -1005,6 +1009,181 @@ struct StepCore {
     for (int k = 0; k < 3; k++) { h->pos[k] = pt[k] - nrm[k]*dist*(T)0.5; h->nrm[k] = nrm[k]; }
     return 1;
   }
+  // ---- box pairs (sphere-box, capsule-box, box-box): same constructions, same operation order as the
+  // oracle's "box pairs" section.  The clipping polygon is a dynamically indexed local array (scratch
+  // memory); the code is compiled out of models without such pairs (d.nbox == 0).
+  DMC_DEV static int sphere_box_core(Hit* h, T margin, const T* ps, T r, const T* pb, const T* mb, const T* sb) {
+    T dif[3] = {ps[0] - pb[0], ps[1] - pb[1], ps[2] - pb[2]}, cl[3], q[3], nb[3] = {0, 0, 0};
+    mul_matT_vec3(cl, mb, dif);
+    bool outside = false;
+    for (int k = 0; k < 3; k++) { q[k] = t_max(-sb[k], t_min(sb[k], cl[k])); if (q[k] != cl[k]) outside = true; }
+    T dist;
+    if (outside) {
+      const T d[3] = {cl[0] - q[0], cl[1] - q[1], cl[2] - q[2]};
+      const T dn = t_sqrt(dot3(d, d));
+      dist = dn - r;
+      if (dist > margin) return 0;
+      for (int k = 0; k < 3; k++) nb[k] = d[k]/dn;
+    } else {
+      const T d0 = sb[0] - t_abs(cl[0]), d1 = sb[1] - t_abs(cl[1]), d2 = sb[2] - t_abs(cl[2]);
+      int best = 0; T depth = d0;
+      if (d1 < depth) { depth = d1; best = 1; }
+      if (d2 < depth) { depth = d2; best = 2; }
+      for (int k = 0; k < 3; k++) if (k == best) { nb[k] = cl[k] >= 0 ? (T)1 : (T)-1; q[k] = nb[k]*sb[k]; }
+      dist = -depth - r;
+    }
+    T nw[3], qw[3];
+    mul_mat_vec3(nw, mb, nb); mul_mat_vec3(qw, mb, q);
+    h->dist = dist;
+    for (int k = 0; k < 3; k++) { h->pos[k] = pb[k] + qw[k] + nw[k]*dist*(T)0.5; h->nrm[k] = -nw[k]; }
+    return 1;
+  }
+  DMC_DEV static T seg_box_dd(const T* p0, const T* u, const T* sb, T t, T* deriv) {
+    T f = 0, g = 0;
+    for (int k = 0; k < 3; k++) {
+      const T x = p0[k] + t*u[k], e = x - t_max(-sb[k], t_min(sb[k], x));
+      f += e*e; g += 2*e*u[k];
+    }
+    *deriv = g;
+    return f;
+  }
+  DMC_DEV static int capsule_box(Hits* hs, T margin, const T* p1, const T* m1, const T* s1, const T* p2, const T* m2, const T* s2) {
+    const T axw[3] = {m1[2], m1[5], m1[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    T p0[3], u[3];
+    mul_matT_vec3(p0, m2, dif); mul_matT_vec3(u, m2, axw);
+    const T hl = s1[1];
+    T lo = -hl, hi = hl, g, t;
+    seg_box_dd(p0, u, s2, lo, &g);
+    if (g >= 0) t = lo;
+    else {
+      seg_box_dd(p0, u, s2, hi, &g);
+      if (g <= 0) t = hi;
+      else {
+        for (int it = 0; it < (sizeof(T) == 8 ? 60 : 30); it++) { t = (T)0.5*(lo + hi); seg_box_dd(p0, u, s2, t, &g); if (g > 0) hi = t; else lo = t; }
+        t = (T)0.5*(lo + hi);
+      }
+    }
+    int mask = 0;
+    T ps[3];
+    for (int k = 0; k < 3; k++) ps[k] = p1[k] + axw[k]*t;
+    mask |= sphere_box_core(&hs->s0, margin, ps, s1[0], p2, m2, s2);
+    const T t2 = t <= 0 ? hl : -hl;
+    if (t_abs(t2 - t) > (T)1e-3*hl) {
+      for (int k = 0; k < 3; k++) ps[k] = p1[k] + axw[k]*t2;
+      Hit x;
+      if (sphere_box_core(&x, margin, ps, s1[0], p2, m2, s2)) { put_hit(hs, mask & 1, x); mask = (mask << 1) | 1; }
+    }
+    return mask;
+  }
+  DMC_DEV static int box_box(Hits* hs, T margin, const T* pA, const T* RA, const T* sA, const T* pB, const T* RB, const T* sB) {
+    const T d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]};
+    T colA[3][3], colB[3][3];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { colA[i][k] = RA[3*k + i]; colB[i][k] = RB[3*k + i]; }
+    T best = (T)-1e30; int code = -1; T bestn[3] = {0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      T L[3];
+      for (int k = 0; k < 3; k++) L[k] = i < 3 ? colA[i % 3][k] : colB[i % 3][k];
+      T ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += sA[k]*t_abs(dot3(L, colA[k])); rb += sB[k]*t_abs(dot3(L, colB[k])); }
+      const T proj = dot3(L, d), sep = t_abs(proj) - ra - rb;
+      if (sep > margin) return 0;
+      if (sep > best) { best = sep; code = i; for (int k = 0; k < 3; k++) bestn[k] = proj >= 0 ? L[k] : -L[k]; }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      T L[3];
+      cross3(L, colA[i], colB[j]);
+      const T ln = t_sqrt(dot3(L, L));
+      if (ln < (T)1e-6) continue;
+      for (int k = 0; k < 3; k++) L[k] /= ln;
+      T ra = 0, rb = 0;
+      for (int k = 0; k < 3; k++) { ra += sA[k]*t_abs(dot3(L, colA[k])); rb += sB[k]*t_abs(dot3(L, colB[k])); }
+      const T proj = dot3(L, d), sep = t_abs(proj) - ra - rb;
+      if (sep > margin) return 0;
+      if (sep > 0 ? sep > best : sep*(T)1.05 > best) {
+        if (!(sep > 0) && !(best < 0)) continue;
+        best = sep; code = 6 + 3*i + j; for (int k = 0; k < 3; k++) bestn[k] = proj >= 0 ? L[k] : -L[k];
+      }
+    }
+    if (code >= 6) {
+      const int i = (code - 6)/3, j = (code - 6) % 3;
+      T pa[3] = {pA[0], pA[1], pA[2]}, pb[3] = {pB[0], pB[1], pB[2]};
+      for (int k = 0; k < 3; k++) if (k != i) { const T sg = dot3(bestn, colA[k]) > 0 ? (T)1 : (T)-1; for (int a = 0; a < 3; a++) pa[a] += sg*sA[k]*colA[k][a]; }
+      for (int k = 0; k < 3; k++) if (k != j) { const T sg = dot3(bestn, colB[k]) > 0 ? (T)-1 : (T)1; for (int a = 0; a < 3; a++) pb[a] += sg*sB[k]*colB[k][a]; }
+      T ua[3], ub[3];
+      for (int k = 0; k < 3; k++) { ua[k] = colA[i][k]; ub[k] = colB[j][k]; }
+      const T w[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+      const T uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub*uaub;
+      T alpha = 0, beta = 0;
+      if (den > (T)1e-12) { alpha = (q1 + uaub*q2)/den; beta = (uaub*q1 + q2)/den; }
+      alpha = t_max(-sA[i], t_min(sA[i], alpha)); beta = t_max(-sB[j], t_min(sB[j], beta));
+      hs->s0.dist = best;
+      for (int k = 0; k < 3; k++) { hs->s0.pos[k] = (T)0.5*((pa[k] + alpha*ua[k]) + (pb[k] + beta*ub[k])); hs->s0.nrm[k] = bestn[k]; }
+      return 1;
+    }
+    const bool refA = code < 3;
+    T pR[3], sR[3], pI[3], sI[3], cR[3][3], cI[3][3], nref[3];
+    for (int k = 0; k < 3; k++) {
+      pR[k] = refA ? pA[k] : pB[k]; sR[k] = refA ? sA[k] : sB[k]; pI[k] = refA ? pB[k] : pA[k]; sI[k] = refA ? sB[k] : sA[k];
+      nref[k] = refA ? bestn[k] : -bestn[k];
+      for (int a = 0; a < 3; a++) { cR[k][a] = refA ? colA[k][a] : colB[k][a]; cI[k][a] = refA ? colB[k][a] : colA[k][a]; }
+    }
+    const int ax = refA ? code : code - 3;
+    int inc = 0; T incdot = (T)1e30;
+    for (int k = 0; k < 3; k++) { const T dk = dot3(nref, cI[k]); if (-t_abs(dk) < incdot) { incdot = -t_abs(dk); inc = k; } }
+    const T incsign = dot3(nref, cI[inc]) > 0 ? (T)-1 : (T)1;
+    const int i1 = (inc + 1) % 3, i2 = (inc + 2) % 3, r1 = (ax + 1) % 3, r2 = (ax + 2) % 3;
+    T poly[16][3], tmp[16][3];
+    int np_ = 4;
+    for (int v = 0; v < 4; v++) {
+      const T a = (v == 0 || v == 3) ? (T)1 : (T)-1, b = v < 2 ? (T)1 : (T)-1;
+      T pt[3];
+      for (int k = 0; k < 3; k++) pt[k] = pI[k] + incsign*sI[inc]*cI[inc][k] + a*sI[i1]*cI[i1][k] + b*sI[i2]*cI[i2][k] - pR[k];
+      poly[v][0] = dot3(pt, cR[r1]); poly[v][1] = dot3(pt, cR[r2]); poly[v][2] = dot3(pt, nref) - sR[ax];
+    }
+    for (int side = 0; side < 4 && np_ > 0; side++) {
+      const int coord = side >> 1; const T sg = (side & 1) ? (T)-1 : (T)1, lim = coord ? sR[r2] : sR[r1];
+      int nn = 0;
+      for (int v = 0; v < np_; v++) {
+        const T* P = poly[v]; const T* Q = poly[(v + 1) % np_];
+        const T dp = lim - sg*P[coord], dq = lim - sg*Q[coord];
+        if (dp >= 0) { tmp[nn][0] = P[0]; tmp[nn][1] = P[1]; tmp[nn][2] = P[2]; nn++; }
+        if ((dp >= 0) != (dq >= 0)) { const T f = dp/(dp - dq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f*(Q[k] - P[k]); nn++; }
+      }
+      np_ = nn;
+      for (int v = 0; v < np_; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];
+    }
+    int nk = 0;
+    for (int v = 0; v < np_; v++) if (poly[v][2] <= margin) { for (int k = 0; k < 3; k++) poly[nk][k] = poly[v][k]; nk++; }
+    if (!nk) return 0;
+    int pick[4] = {0, 0, 0, 0}, npick = 0;
+    if (nk <= 4) { for (int v = 0; v < nk; v++) pick[npick++] = v; }
+    else {
+      T cx = 0, cy = 0; int deep = 0;
+      for (int v = 0; v < nk; v++) { cx += poly[v][0]; cy += poly[v][1]; if (poly[v][2] < poly[deep][2]) deep = v; }
+      cx /= nk; cy /= nk;
+      const T PI = (T)3.14159265358979323846;
+      const T a0 = t_atan2(poly[deep][1] - cy, poly[deep][0] - cx);
+      int used = 1 << deep;
+      pick[npick++] = deep;
+      for (int q = 1; q < 4; q++) {
+        const T target = a0 + q*(PI/2);
+        int bv = -1; T bd = (T)1e30;
+        for (int v = 0; v < nk; v++) if (!((used >> v) & 1)) {
+          const T da = t_abs(t_fmod(t_atan2(poly[v][1] - cy, poly[v][0] - cx) - target + 5*PI, 2*PI) - PI);
+          if (da < bd) { bd = da; bv = v; }
+        }
+        pick[npick++] = bv; used |= 1 << bv;
+      }
+    }
+    for (int q = 0; q < npick; q++) {
+      const T* P = poly[pick[q]];
+      Hit x;
+      x.dist = P[2];
+      for (int k = 0; k < 3; k++) { x.pos[k] = pR[k] + P[0]*cR[r1][k] + P[1]*cR[r2][k] + (sR[ax] + (T)0.5*P[2])*nref[k]; x.nrm[k] = bestn[k]; }
+      put_hit(hs, q, x);
+    }
+    return (1 << npick) - 1;
+  }
   // narrow phase for one pair; returns the mask of valid slots of h[0..3]
   // (slot order = MuJoCo's contact order); tang = optional shared tangent
   DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang, bool* guard) {
@@ -1102,6 +1281,11 @@ struct StepCore {
       if (dot3(dif, dif) > bound*bound) return 0;
     }
     if (L.d.nell && t2 == DMC_GEOM_ELLIPSOID) return ellipsoid_pair(&h->s0, margin, t1, p1, m1, s1, p2, m2, s2);
+    if (L.d.nbox && t2 == DMC_GEOM_BOX) {
+      if (t1 == DMC_GEOM_SPHERE) return sphere_box_core(&h->s0, margin, p1, s1[0], p2, m2, s2);
+      if (t1 == DMC_GEOM_CAPSULE) return capsule_box(h, margin, p1, m1, s1, p2, m2, s2);
+      if (t1 == DMC_GEOM_BOX) return box_box(h, margin, p1, m1, s1, p2, m2, s2);
+    }
     if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) return sphere_sphere(&h->s0, margin, p1, s1[0], p2, s2[0]);
     if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) {
       T axis[3] = {m2[2], m2[5], m2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};

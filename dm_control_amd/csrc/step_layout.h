@@ -32,6 +32,7 @@ struct StepDims {
   int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
   int nslip;     // cap on the friction rows the noslip post-solver handles (0: model has noslip_iterations = 0)
   int na;        // activation states (actuators with integrator / filter dynamics)
+  int nbox;      // candidate pairs sphere-box / capsule-box / box-box
   int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
 };
 

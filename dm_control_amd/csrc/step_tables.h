@@ -147,18 +147,21 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (cyl) d.ncyl++;
     const bool ell = t2 == DMC_GEOM_ELLIPSOID && (t1 == DMC_GEOM_PLANE || t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE || t1 == DMC_GEOM_ELLIPSOID) && !cyl;
     if (ell) d.nell++;
+    // (a cylinder against a box is guard-tested as its enclosing capsule like every other cylinder pair)
+    const bool boxp = t2 == DMC_GEOM_BOX && (t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE || t1 == DMC_GEOM_BOX);
     int nc = 1;
+    if (boxp) { d.nbox++; if (t1 == DMC_GEOM_CAPSULE) nc = 2; else if (t1 == DMC_GEOM_BOX) nc = 4; }
     if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) nc = 2;
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) nc = 4;
     if (plane_cyl) nc = 4;
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) nc = 1;   // 2 only for exactly parallel axes
     const bool known = (t1 == DMC_GEOM_PLANE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE || t2 == DMC_GEOM_BOX)) ||
                        (t1 == DMC_GEOM_SPHERE && (t2 == DMC_GEOM_SPHERE || t2 == DMC_GEOM_CAPSULE)) ||
-                       (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) || ell;
+                       (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) || ell || boxp;
     if (!known) {
       // tolerated only while contacts are disabled (e.g. suite cartpole): the pair then never collides
       if (m.opt_disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)) { t->has_unsupported_pairs = 1; nc = 0; }
-      else { *err = "geom pair type not implemented in the HIP collision kernel (need plane/sphere/capsule, plane-box)"; return false; }
+      else { *err = "geom pair type not implemented in the HIP collision kernel (mesh / hfield, cylinder or ellipsoid against a box)"; return false; }
     }
     int dim;
     const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];

@@ -3,7 +3,7 @@
 Mirrors dm_control/suite/__init__.py:93-150 (`load`, `build_environment`,
 ALL_TASKS / BENCHMARKING) for the domains whose models the BASELINE configs
 name (cartpole, cheetah, humanoid) plus the domains that share their feature set
-(acrobot, ball_in_cup, finger, fish, hopper, humanoid_CMU, lqr, manipulator, pendulum, point_mass, quadruped, reacher, swimmer, walker).  Extra keyword: `physics_kwargs`
+(acrobot, ball_in_cup, finger, fish, hopper, humanoid_CMU, lqr, manipulator, pendulum, point_mass, quadruped, reacher, stacker, swimmer, walker).  Extra keyword: `physics_kwargs`
 (batch_size, precision, device_id, ...) to run a whole batch behind the same
 `Environment` API.
 """
@@ -24,13 +24,14 @@ from dm_control_amd.suite import pendulum
 from dm_control_amd.suite import point_mass
 from dm_control_amd.suite import quadruped
 from dm_control_amd.suite import reacher
+from dm_control_amd.suite import stacker
 from dm_control_amd.suite import swimmer
 from dm_control_amd.suite import walker
 
 _DOMAINS = collections.OrderedDict(acrobot=acrobot, ball_in_cup=ball_in_cup, cartpole=cartpole, cheetah=cheetah, finger=finger, fish=fish,
                                    hopper=hopper,
                                    humanoid=humanoid, humanoid_CMU=humanoid_CMU, lqr=lqr, manipulator=manipulator, pendulum=pendulum, point_mass=point_mass, quadruped=quadruped, reacher=reacher,
-                                   swimmer=swimmer, walker=walker)
+                                   stacker=stacker, swimmer=swimmer, walker=walker)
 
 ALL_TASKS = tuple((d, t) for d, mod in _DOMAINS.items() for t in mod.TASKS)
 BENCHMARKING = tuple((d, t) for d, mod in _DOMAINS.items() for t, (_, tag) in mod.TASKS.items()

@@ -9,7 +9,8 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # humanoid_CMU (nv = 62): one environment fills a CU's LDS in fp32 (98 KiB of scratch + 58 KiB of
 # tables at 32 contacts); the fp64 scratch does not fit, so the domain runs the fp32 kernel.
 DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=32, precision=32),
-                'cmu_2019_position_floor': dict(nconmax=32, precision=32)}   # BASELINE config 4 physics (assets/)
+                'cmu_2019_position_floor': dict(nconmax=32, precision=32),
+                'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts   # BASELINE config 4 physics (assets/)
 
 
 def physics_kwargs(domain, user_kwargs):

@@ -1,9 +1,8 @@
 """Planar manipulator domain (reference: dm_control/suite/manipulator.py): bring_ball, bring_peg,
-insert_ball.
+insert_ball, insert_peg.
 
 Elliptic cones, a fixed-tendon transmission (grasp), a tendon equality constraint (finger / thumb
-coupling), box touch sites.  `insert_peg` needs capsule-box collisions against the slot and is not
-provided.  Model constants are shared by a batch: the ghost target's pose is kept per environment
+coupling), box touch sites, capsule-box contacts between the peg / arm and the slot.  Model constants are shared by a batch: the ghost target's pose is kept per environment
 in the task (it has no physics); the receptacle of `insert_ball` collides, so its pose is drawn once
 per episode for the whole batch."""
 import collections
@@ -56,8 +55,9 @@ def _make(use_peg, insert):
   return factory
 
 
-bring_ball, bring_peg, insert_ball = _make(False, False), _make(True, False), _make(False, True)
-TASKS.update(bring_ball=(bring_ball, 'benchmarking'), bring_peg=(bring_peg, None), insert_ball=(insert_ball, None))
+bring_ball, bring_peg, insert_ball, insert_peg = _make(False, False), _make(True, False), _make(False, True), _make(True, True)
+TASKS.update(bring_ball=(bring_ball, 'benchmarking'), bring_peg=(bring_peg, None), insert_ball=(insert_ball, None),
+             insert_peg=(insert_peg, None))
 
 
 def _quat_y(angle):

@@ -784,6 +784,199 @@ static int collide_plane_ellipsoid(Contact* c, double margin, const double* p1, 
   for (int k = 0; k < 3; k++) { c->pos[k] = pt[k] - nrm[k]*dist*0.5; c->frame[k] = nrm[k]; c->frame[3 + k] = 0; }
   return 1;
 }
+#define DMC_PI 3.14159265358979323846
+/* ---- box pairs -----------------------------------------------------------
+ * MuJoCo has dedicated routines (mjc_SphereBox, mjc_CapsuleBox, mjc_BoxBox); their source is not
+ * available here.  These are restatements of the same geometric problems (PARITY_ASSUMPTIONS.md row 33):
+ *   sphere-box   closest point of the box to the centre (inside: the nearest face), one contact
+ *   capsule-box  the axis point nearest to the box, plus the far end cap when it is in range too
+ *   box-box      separating-axis test over the 15 axes; a face axis gives the incident face clipped
+ *                against the reference face (at most 4 points kept, spread around the deepest one),
+ *                an edge axis gives the closest points of the two edges */
+static int sphere_box_core(Contact* c, double margin, const double* ps, double r,
+                           const double* pb, const double* mb, const double* sb) {
+  double dif[3] = {ps[0] - pb[0], ps[1] - pb[1], ps[2] - pb[2]}, cl[3], q[3], nb[3] = {0, 0, 0};
+  mul_matT_vec3(cl, mb, dif);
+  int outside = 0;
+  for (int k = 0; k < 3; k++) { q[k] = mjMAX(-sb[k], mjMIN(sb[k], cl[k])); if (q[k] != cl[k]) outside = 1; }
+  double dist;
+  if (outside) {
+    double d[3] = {cl[0] - q[0], cl[1] - q[1], cl[2] - q[2]};
+    const double dn = sqrt(dot3(d, d));
+    dist = dn - r;
+    if (dist > margin) return 0;
+    for (int k = 0; k < 3; k++) nb[k] = d[k]/dn;
+  } else {
+    int best = 0; double depth = sb[0] - fabs(cl[0]);
+    for (int k = 1; k < 3; k++) { const double dk = sb[k] - fabs(cl[k]); if (dk < depth) { depth = dk; best = k; } }
+    nb[best] = cl[best] >= 0 ? 1 : -1;
+    q[best] = nb[best]*sb[best];
+    dist = -depth - r;
+  }
+  double nw[3], qw[3];
+  mul_mat_vec3(nw, mb, nb); mul_mat_vec3(qw, mb, q);
+  c->dist = dist;
+  /* frame normal: from the sphere (geom 1) to the box (geom 2) */
+  for (int k = 0; k < 3; k++) { c->pos[k] = pb[k] + qw[k] + nw[k]*dist*0.5; c->frame[k] = -nw[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
+/* squared distance from the point p0 + t u (box frame) to the box, and its derivative in t */
+static double seg_box_dd(const double* p0, const double* u, const double* sb, double t, double* deriv) {
+  double f = 0, g = 0;
+  for (int k = 0; k < 3; k++) {
+    const double x = p0[k] + t*u[k], e = x - mjMAX(-sb[k], mjMIN(sb[k], x));
+    f += e*e; g += 2*e*u[k];
+  }
+  *deriv = g;
+  return f;
+}
+static int collide_capsule_box(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
+                               const double* p2, const double* m2, const double* s2) {
+  double axw[3] = {m1[2], m1[5], m1[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, p0[3], u[3];
+  mul_matT_vec3(p0, m2, dif); mul_matT_vec3(u, m2, axw);
+  const double h = s1[1];
+  /* convex in t: bisection on the derivative */
+  double lo = -h, hi = h, g, t;
+  seg_box_dd(p0, u, s2, lo, &g);
+  if (g >= 0) t = lo;
+  else {
+    seg_box_dd(p0, u, s2, hi, &g);
+    if (g <= 0) t = hi;
+    else {
+      for (int it = 0; it < 60; it++) { t = 0.5*(lo + hi); seg_box_dd(p0, u, s2, t, &g); if (g > 0) hi = t; else lo = t; }
+      t = 0.5*(lo + hi);
+    }
+  }
+  int n = 0;
+  double ps[3];
+  for (int k = 0; k < 3; k++) ps[k] = p1[k] + axw[k]*t;
+  n += sphere_box_core(c + n, margin, ps, s1[0], p2, m2, s2);
+  /* second contact: the end cap farther from t, when it is in range as well (capsule lying on a face) */
+  const double t2 = t <= 0 ? h : -h;
+  if (fabs(t2 - t) > 1e-3*h) {
+    for (int k = 0; k < 3; k++) ps[k] = p1[k] + axw[k]*t2;
+    n += sphere_box_core(c + n, margin, ps, s1[0], p2, m2, s2);
+  }
+  return n;
+}
+static int collide_box_box(Contact* c, double margin, const double* pA, const double* RA, const double* sA,
+                           const double* pB, const double* RB, const double* sB) {
+  double d[3] = {pB[0] - pA[0], pB[1] - pA[1], pB[2] - pA[2]};
+  double colA[3][3], colB[3][3];
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { colA[i][k] = RA[3*k + i]; colB[i][k] = RB[3*k + i]; }
+  /* face axes */
+  double best = -1e300; int code = -1; double bestn[3] = {0, 0, 0};
+  for (int i = 0; i < 6; i++) {
+    const double* L = i < 3 ? colA[i] : colB[i - 3];
+    double ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += sA[k]*fabs(dot3(L, colA[k])); rb += sB[k]*fabs(dot3(L, colB[k])); }
+    const double proj = dot3(L, d), sep = fabs(proj) - ra - rb;
+    if (sep > margin) return 0;
+    if (sep > best) { best = sep; code = i; for (int k = 0; k < 3; k++) bestn[k] = proj >= 0 ? L[k] : -L[k]; }
+  }
+  /* edge axes: preferred only when clearly less penetrating than the best face (factor 1.05 on the depth) */
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double L[3];
+    cross3(L, colA[i], colB[j]);
+    const double ln = sqrt(dot3(L, L));
+    if (ln < 1e-6) continue;
+    for (int k = 0; k < 3; k++) L[k] /= ln;
+    double ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += sA[k]*fabs(dot3(L, colA[k])); rb += sB[k]*fabs(dot3(L, colB[k])); }
+    const double proj = dot3(L, d), sep = fabs(proj) - ra - rb;
+    if (sep > margin) return 0;
+    if (sep > 0 ? sep > best : sep*1.05 > best) {
+      if (!(sep > 0) && !(best < 0)) continue;
+      best = sep; code = 6 + 3*i + j; for (int k = 0; k < 3; k++) bestn[k] = proj >= 0 ? L[k] : -L[k];
+    }
+  }
+  if (code >= 6) {
+    /* edge-edge: the edges of A and B that face each other along n, closest points of their lines */
+    const int i = (code - 6)/3, j = (code - 6) % 3;
+    double pa[3] = {pA[0], pA[1], pA[2]}, pb[3] = {pB[0], pB[1], pB[2]};
+    for (int k = 0; k < 3; k++) if (k != i) { const double sg = dot3(bestn, colA[k]) > 0 ? 1 : -1; for (int a = 0; a < 3; a++) pa[a] += sg*sA[k]*colA[k][a]; }
+    for (int k = 0; k < 3; k++) if (k != j) { const double sg = dot3(bestn, colB[k]) > 0 ? -1 : 1; for (int a = 0; a < 3; a++) pb[a] += sg*sB[k]*colB[k][a]; }
+    const double *ua = colA[i], *ub = colB[j];
+    double w[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double uaub = dot3(ua, ub), q1 = dot3(ua, w), q2 = -dot3(ub, w), den = 1 - uaub*uaub;
+    double alpha = 0, beta = 0;
+    if (den > 1e-12) { alpha = (q1 + uaub*q2)/den; beta = (uaub*q1 + q2)/den; }
+    alpha = mjMAX(-sA[i], mjMIN(sA[i], alpha)); beta = mjMAX(-sB[j], mjMIN(sB[j], beta));
+    c->dist = best;
+    for (int k = 0; k < 3; k++) {
+      c->pos[k] = 0.5*((pa[k] + alpha*ua[k]) + (pb[k] + beta*ub[k]));
+      c->frame[k] = bestn[k]; c->frame[3 + k] = 0;
+    }
+    return 1;
+  }
+  /* face contact: reference box = owner of the axis, incident face = the face of the other box most
+   * opposed to n; Sutherland-Hodgman clipping of the incident face against the reference face sides */
+  const int refA = code < 3;
+  const double *pR = refA ? pA : pB, *sR = refA ? sA : sB, *pI = refA ? pB : pA, *sI = refA ? sB : sA;
+  double (*cR)[3] = refA ? colA : colB, (*cI)[3] = refA ? colB : colA;
+  const int ax = refA ? code : code - 3;
+  double nref[3];                              /* outward normal of the reference face, towards the other box */
+  for (int k = 0; k < 3; k++) nref[k] = refA ? bestn[k] : -bestn[k];
+  int inc = 0; double incdot = 1e300;
+  for (int k = 0; k < 3; k++) { const double dk = dot3(nref, cI[k]); if (-fabs(dk) < incdot) { incdot = -fabs(dk); inc = k; } }
+  const double incsign = dot3(nref, cI[inc]) > 0 ? -1 : 1;
+  const int i1 = (inc + 1) % 3, i2 = (inc + 2) % 3, r1 = (ax + 1) % 3, r2 = (ax + 2) % 3;
+  /* incident face vertices in the 2-D frame (r1, r2) of the reference face, plus their height above it */
+  double poly[16][3], tmp[16][3];
+  int np_ = 4;
+  for (int v = 0; v < 4; v++) {
+    const double a = (v == 0 || v == 3) ? 1 : -1, b = v < 2 ? 1 : -1;
+    double pt[3];
+    for (int k = 0; k < 3; k++) pt[k] = pI[k] + incsign*sI[inc]*cI[inc][k] + a*sI[i1]*cI[i1][k] + b*sI[i2]*cI[i2][k] - pR[k];
+    poly[v][0] = dot3(pt, cR[r1]); poly[v][1] = dot3(pt, cR[r2]); poly[v][2] = dot3(pt, nref) - sR[ax];
+  }
+  for (int side = 0; side < 4 && np_ > 0; side++) {
+    const int coord = side >> 1; const double sg = (side & 1) ? -1 : 1, lim = coord ? sR[r2] : sR[r1];
+    int nn = 0;
+    for (int v = 0; v < np_; v++) {
+      const double* P = poly[v]; const double* Q = poly[(v + 1) % np_];
+      const double dp = lim - sg*P[coord], dq = lim - sg*Q[coord];
+      if (dp >= 0) { tmp[nn][0] = P[0]; tmp[nn][1] = P[1]; tmp[nn][2] = P[2]; nn++; }
+      if ((dp >= 0) != (dq >= 0)) { const double f = dp/(dp - dq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f*(Q[k] - P[k]); nn++; }
+    }
+    np_ = nn;
+    for (int v = 0; v < np_; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];
+  }
+  /* keep the points at or below the margin */
+  int nk = 0;
+  for (int v = 0; v < np_; v++) if (poly[v][2] <= margin) { for (int k = 0; k < 3; k++) poly[nk][k] = poly[v][k]; nk++; }
+  if (!nk) return 0;
+  /* at most 4: the deepest point, then the candidates nearest to +90, 180, 270 degrees around the centroid */
+  int pick[4], npick = 0;
+  if (nk <= 4) { for (int v = 0; v < nk; v++) pick[npick++] = v; }
+  else {
+    double cx = 0, cy = 0; int deep = 0;
+    for (int v = 0; v < nk; v++) { cx += poly[v][0]; cy += poly[v][1]; if (poly[v][2] < poly[deep][2]) deep = v; }
+    cx /= nk; cy /= nk;
+    const double a0 = atan2(poly[deep][1] - cy, poly[deep][0] - cx);
+    int used[16] = {0};
+    pick[npick++] = deep; used[deep] = 1;
+    for (int q = 1; q < 4; q++) {
+      const double target = a0 + q*(DMC_PI/2);
+      int bv = -1; double bd = 1e300;
+      for (int v = 0; v < nk; v++) if (!used[v]) {
+        double da = fabs(fmod(atan2(poly[v][1] - cy, poly[v][0] - cx) - target + 5*DMC_PI, 2*DMC_PI) - DMC_PI);
+        if (da < bd) { bd = da; bv = v; }
+      }
+      pick[npick++] = bv; used[bv] = 1;
+    }
+  }
+  for (int q = 0; q < npick; q++) {
+    const double* P = poly[pick[q]];
+    c[q].dist = P[2];
+    for (int k = 0; k < 3; k++) {
+      /* midpoint between the incident point and its projection on the reference face */
+      c[q].pos[k] = pR[k] + P[0]*cR[r1][k] + P[1]*cR[r2][k] + (sR[ax] + 0.5*P[2])*nref[k];
+      c[q].frame[k] = bestn[k]; c[q].frame[3 + k] = 0;
+    }
+  }
+  return npick;
+}
 /* plane (geom 1) vs cylinder (mjc_PlaneCylinder): the deepest rim point of the cap facing the plane,
  * the matching rim point of the other cap, and two more points of the near disc at +-120 degrees */
 static int collide_plane_cylinder(Contact* c, double margin, const double* p1, const double* m1,
@@ -895,6 +1088,9 @@ static void collision(const Model* m, Data* d) {
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_SPHERE) n = raw_sphere_sphere(c, margin, p1, s1[0], p2, s2[0]);
     else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_CAPSULE) n = collide_sphere_capsule(c, margin, p1, s1, p2, m2, s2);
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_CAPSULE) n = collide_capsule_capsule(c, margin, p1, m1, s1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_SPHERE && t2 == DMC_GEOM_BOX) n = sphere_box_core(c, margin, p1, s1[0], p2, m2, s2);
+    else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_BOX) n = collide_capsule_box(c, margin, p1, m1, s1, p2, m2, s2);
+    else if (t1 == DMC_GEOM_BOX && t2 == DMC_GEOM_BOX) n = collide_box_box(c, margin, p1, m1, s1, p2, m2, s2);
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_ELLIPSOID) n = collide_plane_ellipsoid(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_CAPSULE && t2 == DMC_GEOM_ELLIPSOID) n = collide_capsule_ellipsoid(c, margin, p1, m1, s1, p2, m2, s2);
     else if ((t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_ELLIPSOID) && t2 == DMC_GEOM_ELLIPSOID) {

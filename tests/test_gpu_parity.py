@@ -523,6 +523,39 @@ def test_plane_cylinder_contacts_match_oracle(precision, tol):
   b.close()
 
 
+@pytest.mark.parametrize('precision,tol,lanes', [(64, 1e-9, 64), (64, 1e-9, 32), (32, 1e-3, 16)])
+def test_box_piles_match_oracle(precision, tol, lanes):
+  """sphere-box, capsule-box and box-box contacts (tests/test_box_collision.py): random piles, one per
+  environment, while they form."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_box_collision import _scene
+  rs = np.random.RandomState(5)
+  bodies = []
+  for k in range(5):
+    gtype = ['box', 'box', 'capsule', 'sphere', 'box'][k]
+    size = {'box': rs.uniform(.04, .12, 3), 'capsule': (rs.uniform(.03, .05), rs.uniform(.05, .1)), 'sphere': (rs.uniform(.04, .07),)}[gtype]
+    bodies.append((gtype, size, (0, 0, .15 + .22*k), (1, 0, 0, 0)))
+  m = mc.compile_xml(_scene(bodies, 'cone="elliptic"'))
+  B = 8
+  q = np.tile(m.qpos0, (B, 1))
+  for e in range(B):
+    for k in range(5):
+      quat = rs.randn(4)
+      q[e, 7*k + 3:7*k + 7] = quat / np.linalg.norm(quat)
+      q[e, 7*k:7*k + 2] = rs.uniform(-.08, .08, 2)
+  b = _batch(m, B, precision=precision, lanes_per_env=lanes, nconmax=32)
+  b.set('qpos', q)
+  ora = _oracles(m, q)
+  b.step(300)
+  for o in ora:
+    o.step(300)
+  np.testing.assert_array_equal(b.get('ncon')[:, 0] > 0, [o.ncon > 0 for o in ora])
+  np.testing.assert_allclose(b.get('qpos'), np.array([o.qpos for o in ora]), rtol=0, atol=tol)
+  assert not b.get('warning').any()
+  b.close()
+
+
 def test_elliptic_contact_force_equals_weight_on_gpu():
   # wrapper/core_test.py:393-416 with cone="elliptic", through touch (sums normal forces) and
   # qfrc_constraint; fp64 kernel.

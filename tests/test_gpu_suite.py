@@ -26,7 +26,8 @@ def _oracle(model):
                                          ('manipulator', 'bring_ball'), ('manipulator', 'bring_peg'),
                                          ('manipulator', 'insert_ball'), ('swimmer', 'swimmer6'),
                                          ('swimmer', 'swimmer15'), ('humanoid_CMU', 'stand'), ('humanoid_CMU', 'run'),
-                                         ('quadruped', 'walk'), ('quadruped', 'fetch')])
+                                         ('quadruped', 'walk'), ('quadruped', 'fetch'), ('stacker', 'stack_2'),
+                                         ('stacker', 'stack_4'), ('manipulator', 'insert_peg')])
 def test_suite_task_properties(domain, task):
   from dm_control_amd import suite
   env = suite.load(domain, task, task_kwargs=dict(random=0))
@@ -53,7 +54,7 @@ def test_suite_task_properties(domain, task):
                                          ('finger', 'turn_hard'), ('reacher', 'hard'), ('point_mass', 'hard'),
                                          ('fish', 'swim'), ('swimmer', 'swimmer6'), ('lqr', 'lqr_6_2'),
                                          ('ball_in_cup', 'catch'), ('manipulator', 'bring_ball'),
-                                         ('humanoid_CMU', 'walk'), ('quadruped', 'run')])
+                                         ('humanoid_CMU', 'walk'), ('quadruped', 'run'), ('stacker', 'stack_2')])
 def test_same_seed_same_trajectory(domain, task):
   from dm_control_amd import suite
 
@@ -553,7 +554,7 @@ def test_manipulator_batched_targets_and_receptacle():
 
 @pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
                                        ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4),
-                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('quadruped', 4)])
+                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('quadruped', 4), ('stacker', 10)])
 def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
   env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
@@ -578,11 +579,11 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   if name == 'cmu_2019_position_floor':
     # BASELINE config 4 physics: start upright with perturbed joints (qpos0 is the upright pose)
     q[:, 7:] += rs.uniform(-.15, .15, (NE, m.nq - 7))
-  if name in ('manipulator', 'humanoid_CMU', 'quadruped'):
+  if name in ('manipulator', 'humanoid_CMU', 'quadruped', 'stacker'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
     # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
     from dm_control_amd import suite
-    env = suite.load(name, dict(manipulator='insert_ball', quadruped='fetch').get(name, 'stand'), task_kwargs=dict(random=5),
+    env = suite.load(name, dict(manipulator='insert_ball', quadruped='fetch', stacker='stack_4').get(name, 'stand'), task_kwargs=dict(random=5),
                      physics_kwargs=dict(batch_size=NE))
     env.reset()
     q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
@@ -618,10 +619,12 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   assert np.median(errs) <= 1e-6, np.median(errs)
   # config 4 (62 dofs, servo gains up to 150 against 0.01 armature, 6 substeps, noslip): the error is a
   # continuous rounding tail, not contact flips -- 95 % within 5e-5 and nothing beyond 1e-3
-  frac = 0.95 if name == 'cmu_2019_position_floor' else 0.98
+  # stacker (box piles, 10 substeps): box-box manifolds are discrete decisions (face vs edge axis, which clipped
+  # points survive); in fp32 a few per cent of the env-steps take another branch -- median 6e-8, tail below 5e-3
+  frac = 0.95 if name in ('cmu_2019_position_floor', 'stacker') else 0.98
   assert (errs <= 5e-5).mean() >= frac, (errs <= 5e-5).mean()
-  if name == 'cmu_2019_position_floor':
-    assert errs.max() <= 1e-3, errs.max()
+  if name in ('cmu_2019_position_floor', 'stacker'):
+    assert errs.max() <= (1e-3 if name == 'cmu_2019_position_floor' else 5e-3), errs.max()
   assert not b.get('warning').any()
   b.close()
 

@@ -351,3 +351,40 @@ def test_actuator_dynamics_closed_forms():
     np.testing.assert_allclose(p.actuator_force, [50*p.act[0] - 50*p.qpos[0], 5*p.act[1], 0, 3*p.act[2]], rtol=1e-12, atol=1e-12)
   with pytest.raises(mc.MjcfError):
     mc.compile_xml(xml.replace('timestep="0.005"', 'timestep="0.005" integrator="RK4"'))
+
+
+def test_stacker_and_insert_peg_rollouts_fp64():
+  """suite stacker (4 boxes) and manipulator insert_peg: box-box / capsule-box / sphere-box contacts with
+  elliptic cones behind the manipulator arm; boxes dropped in a heap next to the arm, random torques."""
+  from dm_control_amd.suite import stacker, manipulator
+  for xml, movers in ((stacker.make_model(4)[0], ['box0', 'box1', 'box2', 'box3']), (manipulator.make_model(True, True)[0], ['peg'])):
+    m = mc.compile_xml(xml)
+    o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=48)
+    rs = np.random.RandomState(0)
+    q = m.qpos0.copy()
+    for k, name in enumerate(movers):
+      jx, jz, jy = (m.jnt_qposadr[m.names['joint'].index(name + s)] for s in ('_x', '_z', '_y'))
+      if name == 'peg':
+        q[jx], q[jz], q[jy] = -.405, .42, 0.3      # above the slot (manipulator.xml: slot at x = -.405, z = .2)
+      else:
+        q[jx], q[jz], q[jy] = 0.1*rs.uniform(-1, 1), 0.1 + 0.07*k, rs.uniform(0, 6.28)
+    o.qpos[:] = q
+    e.qpos[:] = q
+    o.forward()
+    kinds, worst = set(), 0.0
+    for t in range(700):
+      c = rs.uniform(-1, 1, m.nu)
+      o.ctrl[:] = c
+      e.ctrl[:] = c
+      o.step()
+      e.step()
+      worst = max(worst, np.abs(e.qpos - o.qpos).max())
+      for i in range(o.ncon):
+        ci = o.contact(i)
+        kinds.add((int(m.geom_type[ci['geom1']]), int(m.geom_type[ci['geom2']])))
+    assert worst < 1e-8, worst
+    if len(movers) > 1:
+      assert (0, 6) in kinds and (6, 6) in kinds             # boxes on the floor and on each other
+    else:
+      assert (3, 6) in kinds                                 # the peg's capsules against the slot boxes
+    assert not o.warning.any() and not e.warning.any()
