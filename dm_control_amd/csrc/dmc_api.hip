@@ -98,7 +98,9 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
     long blocks = (long)(lds_cu / bytes);
     if (blocks * w > 32) blocks = 32 / w;           // 32 waves per CU
     const long score = blocks * w * epw;            // resident envs per CU
-    if (score > best_score) { best_score = score; best_w = w; }
+    // fewer waves per workgroup only for a clear gain in residency: 4-wave groups give grids that divide the
+    // batch evenly (cartpole, B = 4096: 3-wave groups = 683 workgroups ran 1.8x slower than 4-wave = 512)
+    if (best_score < 0 || score * 100 > best_score * 115) { best_score = score; best_w = w; }
   }
   if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
   LaunchGeom& g = b->geom;
