@@ -285,11 +285,12 @@ def test_torch_batched_env_matches_host_env_semantics():
 
 @pytest.mark.parametrize('name,nsub', [('walker', 10), ('hopper', 4), ('pendulum', 1), ('acrobot', 1),
                                        ('finger', 2), ('reacher', 1), ('point_mass', 1), ('fish', 10), ('ball_in_cup', 10),
-                                       ('swimmer6', 15)])
+                                       ('swimmer6', 15), ('quadruped', 4), ('stacker', 10), ('manipulator', 10)])
 def test_more_domains_rollout_parity(name, nsub):
   """Domains sharing the cheetah feature set: 60 env-steps from randomised starts
-  against the oracle (fp64 kernel), incl. hopper's touch sensors, acrobot's RK4 and
-  finger's elliptic cones / dof friction loss / framepos + ellipsoid-site touch sensors."""
+  against the oracle (fp64 kernel), incl. hopper's touch sensors, acrobot's RK4,
+  finger's elliptic cones / dof friction loss / framepos + ellipsoid-site touch sensors, quadruped's filtered
+  servos + tendon equalities + ellipsoid torso, and the box contacts of stacker and of the full manipulator model."""
   from dm_control_amd.batch import BatchedPhysics
   from dm_control_amd.suite import common
   from oracle import oracle
@@ -306,7 +307,7 @@ def test_more_domains_rollout_parity(name, nsub):
     if m.jnt_type[j] == 3:
       lo, hi = m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi)
       q[:, a] = rs.uniform(lo, hi, NE)
-  b = BatchedPhysics(m, NE, precision=64)
+  b = BatchedPhysics(m, NE, precision=64, **dict(dict(manipulator=dict(nconmax=40)).get(name, common.DEFAULT_CAPS.get(name, {}))))
   b.set('qpos', q)
   refs = []
   for e in range(NE):
