@@ -1981,6 +1981,53 @@ struct StepCore {
     }
     return -1;
   }
+  // rays of rangefinder sensors: every geom type (planes are front-side only and finite where their
+  // half-sizes are positive; a ray that starts inside a box leaves through a face)
+  DMC_DEV static T ray_geom_any(const T* pos, const T* mat, const T* size, const T* pnt, const T* vec, int type) {
+    if (type != DMC_GEOM_PLANE && type != DMC_GEOM_CYLINDER && type != DMC_GEOM_BOX) return ray_geom(pos, mat, size, pnt, vec, type);
+    T dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, lp[3], lv[3];
+    mul_matT_vec3(lp, mat, dif); mul_matT_vec3(lv, mat, vec);
+    T best = -1;
+    if (type == DMC_GEOM_PLANE) {
+      if (lv[2] > -(T)DMC_MINVAL) return -1;
+      const T x = -lp[2]/lv[2];
+      if (x < 0) return -1;
+      const T px = lp[0] + x*lv[0], py = lp[1] + x*lv[1];
+      if ((size[0] <= 0 || t_abs(px) <= size[0]) && (size[1] <= 0 || t_abs(py) <= size[1])) return x;
+      return -1;
+    }
+    if (type == DMC_GEOM_CYLINDER) {
+      const T a = lv[0]*lv[0] + lv[1]*lv[1], b = lp[0]*lv[0] + lp[1]*lv[1], c = lp[0]*lp[0] + lp[1]*lp[1] - size[0]*size[0];
+      if (a >= (T)DMC_MINVAL) {
+        const T det = b*b - a*c;
+        if (det >= 0) {
+          const T sq = t_sqrt(det);
+          for (int k = 0; k < 2; k++) {
+            const T x = k == 0 ? (-b - sq)/a : (-b + sq)/a;
+            if (x >= 0 && t_abs(lp[2] + x*lv[2]) <= size[1]) if (best < 0 || x < best) best = x;
+          }
+        }
+      }
+      if (t_abs(lv[2]) >= (T)DMC_MINVAL) for (int sg = -1; sg <= 1; sg += 2) {
+        const T x = (sg*size[1] - lp[2]) / lv[2];
+        if (x < 0) continue;
+        const T px = lp[0] + x*lv[0], py = lp[1] + x*lv[1];
+        if (px*px + py*py <= size[0]*size[0]) if (best < 0 || x < best) best = x;
+      }
+      return best;
+    }
+    for (int ax = 0; ax < 3; ax++) {
+      if (t_abs(lv[ax]) < (T)DMC_MINVAL) continue;
+      for (int sg = -1; sg <= 1; sg += 2) {
+        const T x = (sg*size[ax] - lp[ax]) / lv[ax];
+        if (x < 0) continue;
+        const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        if (t_abs(lp[a1] + x*lv[a1]) <= size[a1] && t_abs(lp[a2] + x*lv[a2]) <= size[a2])
+          if (best < 0 || x < best) best = x;
+      }
+    }
+    return best;
+  }
   DMC_DEV void sensors_acc() {
     if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
     int need = 0;
@@ -2077,6 +2124,50 @@ struct StepCore {
         }
       }
       else if (t == DMC_SENS_SUBTREELINVEL) {}   // written by subtree_linvel_sensors()
+      else if (L.d.nrf && t == DMC_SENS_RANGEFINDER) {
+        // mj_ray along the site's z axis: nearest visible geom that is not on the site's own body
+        const int sb = MI(site_bodyid)[id];
+        T v[3], sp[3], q[4], e[3] = {0, 0, 1}, vec[3];
+        mul_mat_vec3(v, S(xmat) + 9*sb, MR(site_pos) + 3*id);
+        for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*sb + k] + v[k];
+        mul_quat(q, S(xquat) + 4*sb, MR(site_quat) + 4*id);
+        rot_vec_quat(vec, e, q);
+        T best = -1;
+        for (int g = 0; g < L.d.ngeom; g++) {
+          if (MI(geom_bodyid)[g] == sb || MI(geom_invisible)[g]) continue;
+          const T x = ray_geom_any(S(geom_xpos) + 3*g, S(geom_xmat) + 9*g, MR(geom_size) + 3*g, sp, vec, MI(geom_type)[g]);
+          if (x >= 0 && (best < 0 || x < best)) best = x;
+        }
+        out[0] = best;
+      }
+      else if (t == DMC_SENS_FRAMEQUAT) {
+        const int ot = MI(sensor_objtype)[i];
+        T q[4];
+        if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
+        else if (ot == DMC_OBJ_GEOM) mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[id], MR(geom_quat) + 4*id);
+        else if (ot == DMC_OBJ_BODY) mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id);
+        else for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*id + k];
+        for (int k = 0; k < 4; k++) out[k] = q[k];
+      }
+      else if (t == DMC_SENS_FRAMELINVEL || t == DMC_SENS_FRAMEANGVEL) {
+        // mj_objectVelocity in world orientation at the object's frame origin
+        const int ot = MI(sensor_objtype)[i];
+        const int b = ot == DMC_OBJ_SITE ? MI(site_bodyid)[id] : (ot == DMC_OBJ_GEOM ? MI(geom_bodyid)[id] : id);
+        T p[3];
+        if (ot == DMC_OBJ_SITE) {
+          T v[3]; mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+          for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
+        } else {
+          const T* pp = ot == DMC_OBJ_GEOM ? S(geom_xpos) + 3*id : (ot == DMC_OBJ_BODY ? S(xipos) + 3*id : S(xpos) + 3*id);
+          for (int k = 0; k < 3; k++) p[k] = pp[k];
+        }
+        const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
+        const T dif[3] = {p[0] - rc[0], p[1] - rc[1], p[2] - rc[2]};
+        const T* cv = S(cvel) + 6*b;
+        T tmp[3];
+        cross3(tmp, dif, cv);
+        for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_FRAMEANGVEL ? cv[k] : cv[3 + k] - tmp[k];
+      }
       else if (t == DMC_SENS_VELOCIMETER || t == DMC_SENS_GYRO) {
         const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
         mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);

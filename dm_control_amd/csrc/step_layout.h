@@ -33,6 +33,7 @@ struct StepDims {
   int nslip;     // cap on the friction rows the noslip post-solver handles (0: model has noslip_iterations = 0)
   int na;        // activation states (actuators with integrator / filter dynamics)
   int nbox;      // candidate pairs sphere-box / capsule-box / box-box
+  int nrf;       // rangefinder sensors (ray casts against every geom)
   int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
 };
 
@@ -53,6 +54,7 @@ struct StepDims {
   X(tri_i, d.ntri) X(tri_j, d.ntri)   /* lower-triangle entries sorted by (column, row) */ \
   X(tri_col, d.nv + 1)                /* first entry of each column in tri_i/tri_j */ \
   X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
+  X(geom_invisible, d.nrf ? d.ngeom : 0)  /* rays skip geoms with alpha 0 */   \
   X(pair_geom1, d.npair) X(pair_geom2, d.npair) X(pair_dim, d.npair)           \
   X(pair_prm, d.npair)         /* contact-parameter tuple of each pair */      \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \

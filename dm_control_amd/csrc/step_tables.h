@@ -96,6 +96,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   std::vector<int> stv;
   for (int i = 0; i < m.nsensor; i++) if (m.sensor_type[i] == DMC_SENS_SUBTREELINVEL) stv.push_back(i);
   d.nstv = (int)stv.size();
+  for (int i = 0; i < m.nsensor; i++) if (m.sensor_type[i] == DMC_SENS_RANGEFINDER) d.nrf++;
   if (d.nstv && m.nbody > 64) { *err = "subtreelinvel sensors need nbody <= 64"; return false; }
   d.fluid = (m.opt_density > 0 || m.opt_viscosity > 0) ? 1 : 0;
   for (int w = 0; w < m.nwrap; w++) {
@@ -264,6 +265,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     mi[L.mi_tri_col + m.nv] = k;
   }
   cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);
+  if (d.nrf) cpi(L.mi_geom_invisible, m.geom_invisible);
   cpi(L.mi_pair_geom1, m.pair_geom1); cpi(L.mi_pair_geom2, m.pair_geom2); cpi(L.mi_pair_dim, pdim);
   cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);
   int nact = 0;
@@ -345,7 +347,9 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
                     st == DMC_SENS_SUBTREECOM || st == DMC_SENS_SUBTREELINVEL || st == DMC_SENS_VELOCIMETER ||
                     st == DMC_SENS_GYRO || st == DMC_SENS_ACCELEROMETER || st == DMC_SENS_FORCE ||
                     st == DMC_SENS_TORQUE || st == DMC_SENS_TOUCH || st == DMC_SENS_FRAMEPOS ||
-                    st == DMC_SENS_FRAMEXAXIS || st == DMC_SENS_FRAMEYAXIS || st == DMC_SENS_FRAMEZAXIS;
+                    st == DMC_SENS_FRAMEXAXIS || st == DMC_SENS_FRAMEYAXIS || st == DMC_SENS_FRAMEZAXIS ||
+                    st == DMC_SENS_FRAMEQUAT || st == DMC_SENS_FRAMELINVEL || st == DMC_SENS_FRAMEANGVEL ||
+                    st == DMC_SENS_RANGEFINDER;
     if (!ok) { *err = "sensor type not implemented"; return false; }
     if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX && tt != DMC_GEOM_ELLIPSOID) { *err = "touch sensor sites must be sphere, capsule, ellipsoid or box"; return false; } }
   }

@@ -57,6 +57,10 @@ _SENSORS = {
     'framexaxis': (C['DMC_SENS_FRAMEXAXIS'], 'objname', None, 3, 1),
     'frameyaxis': (C['DMC_SENS_FRAMEYAXIS'], 'objname', None, 3, 1),
     'framezaxis': (C['DMC_SENS_FRAMEZAXIS'], 'objname', None, 3, 1),
+    'rangefinder': (C['DMC_SENS_RANGEFINDER'], 'site', C['DMC_OBJ_SITE'], 1, 1),
+    'framequat': (C['DMC_SENS_FRAMEQUAT'], 'objname', None, 4, 1),
+    'framelinvel': (C['DMC_SENS_FRAMELINVEL'], 'objname', None, 3, 2),
+    'frameangvel': (C['DMC_SENS_FRAMEANGVEL'], 'objname', None, 3, 2),
 }
 
 
@@ -673,6 +677,11 @@ class _Compiler:
         solimp=_solimp(a.get('solimp', '0.9 0.95 0.001 0.5 2')),
         margin=float(a.get('margin', 0)), gap=float(a.get('gap', 0)),
         mass=mass, inertia=inertia)
+    if a.get('material') in getattr(self, 'material_alpha', {}):
+      g['invisible'] = int(self.material_alpha[a['material']] == 0)
+    else:
+      rgba = _vec(a.get('rgba', '0.5 0.5 0.5 1'))
+      g['invisible'] = int(rgba.size == 4 and rgba[3] == 0)
     if g['condim'] not in (1, 3, 4, 6):
       raise MjcfError('geom condim must be 1, 3, 4 or 6')
     self.bodies[bid]['geoms'].append(len(self.geoms))
@@ -802,6 +811,12 @@ class _Compiler:
     for extra in wbs[1:]:
       for c in list(extra):
         wb.append(c)
+    # material alpha: rays (rangefinder sensors) skip invisible geoms (rgba alpha 0, or a material with alpha 0)
+    self.material_alpha = {}
+    for asset in self.root.findall('asset'):
+      for mat in asset.findall('material'):
+        rgba = _vec(mat.get('rgba', '1 1 1 1'))
+        self.material_alpha[mat.get('name')] = float(rgba[3]) if rgba.size == 4 else 1.0
     self._parse_body(wb, -1, None)
     self._parse_actuators()
     self._parse_tendons()
@@ -920,6 +935,7 @@ class _Compiler:
     m.geom_condim = np.array([g['condim'] for g in self.geoms], dtype=np.int64)
     m.geom_bodyid = np.array([g['body'] for g in self.geoms], dtype=np.int64)
     m.geom_priority = np.array([g['priority'] for g in self.geoms], dtype=np.int64)
+    m.geom_invisible = np.array([g['invisible'] for g in self.geoms], dtype=np.int64)
     m.geom_size = np.array([g['size'] for g in self.geoms]).reshape(ngeom, 3)
     m.geom_pos = np.array([g['pos'] for g in self.geoms]).reshape(ngeom, 3)
     m.geom_quat = np.array([g['quat'] for g in self.geoms]).reshape(ngeom, 4)

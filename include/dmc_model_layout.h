@@ -18,7 +18,7 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 8
+#define DMC_MODEL_VERSION 9
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
@@ -43,7 +43,7 @@
   X(jnt_bodyid, njnt) X(jnt_limited, njnt) \
   X(dof_bodyid, nv) X(dof_jntid, nv) X(dof_parentid, nv) \
   X(geom_type, ngeom) X(geom_contype, ngeom) X(geom_conaffinity, ngeom) \
-  X(geom_condim, ngeom) X(geom_bodyid, ngeom) X(geom_priority, ngeom) \
+  X(geom_condim, ngeom) X(geom_bodyid, ngeom) X(geom_priority, ngeom) X(geom_invisible, ngeom) \
   X(site_bodyid, nsite) X(site_type, nsite) \
   X(actuator_trntype, nu) X(actuator_dyntype, nu) X(actuator_gaintype, nu) \
   X(actuator_biastype, nu) X(actuator_trnid, 2*nu) \
@@ -103,7 +103,9 @@ enum { DMC_STAGE_NONE = 0, DMC_STAGE_POS = 1, DMC_STAGE_VEL = 2, DMC_STAGE_ACC =
 enum { DMC_SENS_TOUCH = 0, DMC_SENS_ACCELEROMETER = 1, DMC_SENS_VELOCIMETER = 2,
        DMC_SENS_GYRO = 3, DMC_SENS_FORCE = 4, DMC_SENS_TORQUE = 5,
        DMC_SENS_JOINTPOS = 9, DMC_SENS_JOINTVEL = 10, DMC_SENS_ACTUATORFRC = 15,
-       DMC_SENS_FRAMEPOS = 26, DMC_SENS_FRAMEXAXIS = 28, DMC_SENS_FRAMEYAXIS = 29, DMC_SENS_FRAMEZAXIS = 30,
+       DMC_SENS_RANGEFINDER = 7,
+       DMC_SENS_FRAMEPOS = 26, DMC_SENS_FRAMEQUAT = 27, DMC_SENS_FRAMEXAXIS = 28, DMC_SENS_FRAMEYAXIS = 29, DMC_SENS_FRAMEZAXIS = 30,
+       DMC_SENS_FRAMELINVEL = 31, DMC_SENS_FRAMEANGVEL = 32,
        DMC_SENS_SUBTREECOM = 37, DMC_SENS_SUBTREELINVEL = 38 };
 /* mjtDisableBit, in the order of dm_control/mjcf/schema.xml:82-103 */
 enum { DMC_DSBL_CONSTRAINT = 1 << 0, DMC_DSBL_EQUALITY = 1 << 1,

@@ -1539,6 +1539,7 @@ void ora_object_velocity(const Model* m, const Data* d, int objtype, int id, int
   if (objtype == DMC_OBJ_SITE) object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, local, res);
   else object_velocity(m, d, id, d->xpos + 3*id, d->xmat + 9*id, local, res);
 }
+static double ray_geom(const double* pos, const double* mat, const double* size, const double* pnt, const double* vec, int type);
 static void sensor_stage(const Model* m, Data* d, int stage) {
   if (m->opt_disableflags & DMC_DSBL_SENSOR) return;
   int need_subtree = 0;
@@ -1567,6 +1568,30 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
                         : m->sensor_objtype[i] == DMC_OBJ_BODY ? d->xipos + 3*id : d->xpos + 3*id;
         memcpy(out, p, 3 * sizeof(double)); break; }
       case DMC_SENS_SUBTREELINVEL: memcpy(out, d->subtree_linvel + 3*id, 3 * sizeof(double)); break;
+      case DMC_SENS_RANGEFINDER: { /* mj_ray along the site's z axis: nearest visible geom not on the site's body, -1 if none */
+        const double* R = d->site_xmat + 9*id;
+        const double vec[3] = {R[2], R[5], R[8]};
+        double best = -1;
+        for (int g = 0; g < m->ngeom; g++) {
+          if (m->geom_bodyid[g] == m->site_bodyid[id] || m->geom_invisible[g]) continue;
+          const double x = ray_geom(d->geom_xpos + 3*g, d->geom_xmat + 9*g, m->geom_size + 3*g, d->site_xpos + 3*id, vec, m->geom_type[g]);
+          if (x >= 0 && (best < 0 || x < best)) best = x;
+        }
+        out[0] = best; break; }
+      case DMC_SENS_FRAMEQUAT: { /* orientation of the object's frame: body quaternion times the local one */
+        const int ot = m->sensor_objtype[i];
+        if (ot == DMC_OBJ_SITE) mul_quat(out, d->xquat + 4*m->site_bodyid[id], m->site_quat + 4*id);
+        else if (ot == DMC_OBJ_GEOM) mul_quat(out, d->xquat + 4*m->geom_bodyid[id], m->geom_quat + 4*id);
+        else if (ot == DMC_OBJ_BODY) mul_quat(out, d->xquat + 4*id, m->body_iquat + 4*id);
+        else memcpy(out, d->xquat + 4*id, 4 * sizeof(double));
+        break; }
+      case DMC_SENS_FRAMELINVEL: case DMC_SENS_FRAMEANGVEL: { /* mj_objectVelocity, world orientation */
+        const int ot = m->sensor_objtype[i];
+        const int body = ot == DMC_OBJ_SITE ? m->site_bodyid[id] : ot == DMC_OBJ_GEOM ? m->geom_bodyid[id] : id;
+        const double* p = ot == DMC_OBJ_SITE ? d->site_xpos + 3*id : ot == DMC_OBJ_GEOM ? d->geom_xpos + 3*id
+                        : ot == DMC_OBJ_BODY ? d->xipos + 3*id : d->xpos + 3*id;
+        object_velocity(m, d, body, p, NULL, 0, v6);
+        memcpy(out, m->sensor_type[i] == DMC_SENS_FRAMELINVEL ? v6 + 3 : v6, 3 * sizeof(double)); break; }
       case DMC_SENS_VELOCIMETER:
         object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, 1, v6);
         memcpy(out, v6 + 3, 3 * sizeof(double)); break;
@@ -1671,9 +1696,35 @@ static double ray_geom(const double* pos, const double* mat, const double* size,
     double sq = sqrt(det), x0 = (-b - sq)/a, x1 = (-b + sq)/a;
     return x0 >= 0 ? x0 : (x1 >= 0 ? x1 : -1);
   }
+  if (type == DMC_GEOM_PLANE) {
+    /* front side only; a plane with positive half-sizes is finite for rays */
+    if (lv[2] > -MINVAL) return -1;
+    const double x = -lp[2]/lv[2];
+    if (x < 0) return -1;
+    const double px = lp[0] + x*lv[0], py = lp[1] + x*lv[1];
+    if ((size[0] <= 0 || fabs(px) <= size[0]) && (size[1] <= 0 || fabs(py) <= size[1])) return x;
+    return -1;
+  }
+  if (type == DMC_GEOM_CYLINDER) {
+    /* side wall, then the two caps */
+    const double a = lv[0]*lv[0] + lv[1]*lv[1], b = lp[0]*lv[0] + lp[1]*lv[1], c = lp[0]*lp[0] + lp[1]*lp[1] - size[0]*size[0];
+    if (a >= MINVAL) {
+      const double det = b*b - a*c;
+      if (det >= 0) {
+        const double sq = sqrt(det), xs[2] = {(-b - sq)/a, (-b + sq)/a};
+        for (int k = 0; k < 2; k++) if (xs[k] >= 0 && fabs(lp[2] + xs[k]*lv[2]) <= size[1]) if (best < 0 || xs[k] < best) best = xs[k];
+      }
+    }
+    if (fabs(lv[2]) >= MINVAL) for (int s = -1; s <= 1; s += 2) {
+      const double x = (s*size[1] - lp[2]) / lv[2];
+      if (x < 0) continue;
+      const double px = lp[0] + x*lv[0], py = lp[1] + x*lv[1];
+      if (px*px + py*py <= size[0]*size[0]) if (best < 0 || x < best) best = x;
+    }
+    return best;
+  }
   if (type == DMC_GEOM_BOX) {
-    int inside = fabs(lp[0]) <= size[0] && fabs(lp[1]) <= size[1] && fabs(lp[2]) <= size[2];
-    if (inside) return 0;
+    /* nearest face crossing with x >= 0 (from inside: the exit face) */
     for (int ax = 0; ax < 3; ax++) {
       if (fabs(lv[ax]) < MINVAL) continue;
       for (int s = -1; s <= 1; s += 2) {

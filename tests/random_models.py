@@ -135,6 +135,14 @@ def random_model_xml(seed, ellipsoids=False, noslip=0):
       sens.append('<torque site="%s"/>' % s)
     elif r < .9:
       sens.append('<frame%saxis objtype="site" objname="%s"/>' % (rs.choice(['x', 'y', 'z']), s))
+    elif r < .925:
+      sens.append('<framequat objtype="site" objname="%s"/>' % s)
+    elif r < .95:
+      sens.append('<framelinvel objtype="site" objname="%s"/>' % s)
+    elif r < .975:
+      sens.append('<frameangvel objtype="site" objname="%s"/>' % s)
+    else:
+      sens.append('<rangefinder site="%s"/>' % s)
   sens.append('<subtreelinvel body="%s"/>' % bodies[0])
   sens.append('<subtreecom body="%s"/>' % bodies[-1])
   if joints:

@@ -636,3 +636,63 @@ def test_noslip_dof_frictionloss_holds_exactly():
     p.step()
   assert abs(p.qvel[0]) < 1e-12
   np.testing.assert_allclose(p.qfrc_constraint[0], -0.05, rtol=1e-9)
+
+
+# ---- frame and rangefinder sensors (composer props / walkers: entities/props/primitive.py, third_party/ant) -------
+def test_frame_velocity_and_orientation_sensors_are_consistent():
+  xml = """<mujoco><worldbody>
+  <body name="b" pos="0 0 .5" quat=".9 .1 .3 .2"><freejoint/><geom name="g" type="box" size=".1 .05 .02" pos=".02 0 0" quat=".8 .2 0 .1"/>
+   <site name="s" pos=".1 .02 .03" quat=".7 0 .5 .1"/>
+   <body name="c" pos=".2 0 0"><joint type="hinge" axis="0 1 0"/><geom type="capsule" size=".02 .1"/><site name="s2" pos="0 0 .1"/></body></body>
+  </worldbody><sensor>
+  <framequat objtype="site" objname="s"/><framequat objtype="body" objname="b"/><framequat objtype="xbody" objname="c"/><framequat objtype="geom" objname="g"/>
+  <framelinvel objtype="site" objname="s2"/><frameangvel objtype="site" objname="s2"/><velocimeter site="s2"/><gyro site="s2"/>
+  <framepos objtype="site" objname="s2"/></sensor></mujoco>"""
+  m = mc.compile_xml(xml)
+  p = OraclePhysics(m, legacy_step=False)
+  p.qvel[:] = np.random.RandomState(0).uniform(-1, 1, m.nv)
+  for _ in range(20):
+    p.step()
+  p.forward()
+  sd = p.sensordata
+
+  def mat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y)], [2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x)],
+                     [2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)]])
+  np.testing.assert_allclose(mat(sd[0:4]), p.site_xmat[0:9].reshape(3, 3), atol=1e-12)
+  np.testing.assert_allclose(mat(sd[4:8]), p.ximat[9:18].reshape(3, 3), atol=1e-12)       # body = inertial frame
+  np.testing.assert_allclose(mat(sd[8:12]), p.xmat[18:27].reshape(3, 3), atol=1e-12)     # xbody = body frame
+  np.testing.assert_allclose(mat(sd[12:16]), p.geom_xmat[0:9].reshape(3, 3), atol=1e-12)
+  R = p.site_xmat[9:18].reshape(3, 3)
+  np.testing.assert_allclose(R.T @ sd[16:19], sd[22:25], atol=1e-12)      # world linear velocity -> velocimeter frame
+  np.testing.assert_allclose(R.T @ sd[19:22], sd[25:28], atol=1e-12)      # world angular velocity -> gyro frame
+  # framelinvel is the time derivative of framepos
+  pos0, v0 = sd[28:31].copy(), sd[16:19].copy()
+  p.step()
+  p.forward()
+  # (semi-implicit Euler moves positions with the new velocity)
+  del v0
+  np.testing.assert_allclose((p.sensordata[28:31] - pos0) / m.opt.timestep, p.sensordata[16:19], atol=3e-3)
+
+
+def test_rangefinder_closed_forms():
+  xml = """<mujoco><worldbody><geom type="plane" size="1 1 .1"/>
+  <geom name="cyl" type="cylinder" size=".1 .2" pos="1 0 .5"/><geom name="box" type="box" size=".1 .1 .1" pos="0 1 .5"/>
+  <geom name="ghost" type="sphere" size=".2" pos="0 0 .2" rgba="1 0 0 0"/>
+  <geom name="ell" type="ellipsoid" size=".1 .2 .3" pos="-1 0 .5"/><geom name="cap" type="capsule" size=".05 .2" pos="0 -1 .5"/>
+  <body pos="0 0 .5"><freejoint/><geom type="sphere" size=".05"/>
+  <site name="down" quat="0 1 0 0"/><site name="px" quat="0.70710678 0 0.70710678 0"/><site name="py" quat="0.70710678 -0.70710678 0 0"/>
+  <site name="up"/><site name="nx" quat="0.70710678 0 -0.70710678 0"/><site name="ny" quat="0.70710678 0.70710678 0 0"/>
+  <site name="far" pos="0 0 0" quat="0.9238795 0 0.3826834 0"/></body>
+  </worldbody><sensor><rangefinder site="down"/><rangefinder site="px"/><rangefinder site="py"/><rangefinder site="up"/>
+  <rangefinder site="nx"/><rangefinder site="ny"/><rangefinder site="far"/></sensor></mujoco>"""
+  p = OraclePhysics(mc.compile_xml(xml))
+  p.forward()
+  # floor below (the invisible ghost sphere and the site's own body are skipped), cylinder side, box face, nothing above,
+  # ellipsoid along its x semi-axis, capsule side; the 45-degree ray leaves the finite plane (|x| <= 1) before z = 0
+  np.testing.assert_allclose(p.sensordata, [0.5, 0.9, 0.9, -1, 0.9, 0.95, -1], atol=1e-7)
+  # move over the cylinder's top cap and look down: 0.3 above the cap at z = 0.7
+  p.qpos[:3] = [1.05, 0, 1.0]
+  p.forward()
+  np.testing.assert_allclose(p.sensordata[0], 0.3, atol=1e-12)
