@@ -10,6 +10,7 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # tables at 32 contacts); the fp64 scratch does not fit, so the domain runs the fp32 kernel.
 DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=32, precision=32),
                 'cmu_2019_position_floor': dict(nconmax=32, precision=32),
+                'soccer_2v2_boxhead': dict(nconmax=24),   # BASELINE config 5 physics (assets/)
                 'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts   # BASELINE config 4 physics (assets/)
 
 

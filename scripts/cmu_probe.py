@@ -1,6 +1,6 @@
-"""The two 62-dof CMU humanoid models on the GPU (suite humanoid_CMU: 10 substeps per env-step; BASELINE
+"""The large BASELINE models on the GPU: the two 62-dof CMU humanoids (suite humanoid_CMU: 10 substeps per env-step; BASELINE
 config 4 physics -- position-controlled 2019 model on the Floor arena, elliptic cones + 5 noslip sweeps,
-6 substeps): LDS geometry, throughput at B = 4096, contact statistics."""
+6 substeps) and BASELINE config 5 physics (soccer 2v2 BoxHead, 5 substeps): LDS geometry, throughput at B = 4096, contact statistics."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,14 +12,18 @@ import torch
 B = int(os.environ.get('B', 4096))
 rs = np.random.RandomState(0)
 out = []
-for name, nsub in (('humanoid_CMU', 10), ('cmu_2019_position_floor', 6)):
+for name, nsub in (('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('soccer_2v2_boxhead', 5)):
   m = mc.compile_xml(common.read_model(name + '.xml'))
   caps = dict(common.DEFAULT_CAPS[name])
-  prec, ncon = caps['precision'], caps['nconmax']
+  prec, ncon = caps.get('precision', 32), caps['nconmax']
   try:
     b = BatchedPhysics(m, B, precision=prec, nconmax=ncon)
     q = np.tile(m.qpos0, (B, 1))
-    q[:, 7:] += rs.uniform(-0.2, 0.2, (B, m.nq - 7))
+    if name.startswith('soccer'):
+      q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-8, 8, (B, 8))     # players anywhere around their kick-off spots
+      q[:, 24:26] += rs.uniform(-15, 15, (B, 2))
+    else:
+      q[:, 7:] += rs.uniform(-0.2, 0.2, (B, m.nq - 7))
     b.set('qpos', q)
     b.set_output_mask(OUT['sensor'] | OUT['xpos'] | OUT['xmat'] | OUT['subtree_com'])
     T = 50

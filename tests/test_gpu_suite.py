@@ -555,7 +555,8 @@ def test_manipulator_batched_targets_and_receptacle():
 
 @pytest.mark.parametrize('name,nsub', [('finger', 2), ('fish', 10), ('swimmer6', 15), ('ball_in_cup', 10),
                                        ('manipulator', 10), ('point_mass', 1), ('walker', 10), ('hopper', 4),
-                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('quadruped', 4), ('stacker', 10)])
+                                       ('humanoid_CMU', 10), ('cmu_2019_position_floor', 6), ('quadruped', 4), ('stacker', 10),
+                                       ('soccer_2v2_boxhead', 5)])
 def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   """The production (fp32) kernel on the other domains, restarted from the oracle's state at every
   env-step (random, partly interpenetrating joint configurations; up to 15 substeps per env-step):
@@ -580,6 +581,11 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
   if name == 'cmu_2019_position_floor':
     # BASELINE config 4 physics: start upright with perturbed joints (qpos0 is the upright pose)
     q[:, 7:] += rs.uniform(-.15, .15, (NE, m.nq - 7))
+  if name == 'soccer_2v2_boxhead':
+    # BASELINE config 5 physics: players spread around their kick-off spots, ball somewhere in midfield
+    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-6, 6, (NE, 8))
+    q[:, 24:26] += rs.uniform(-8, 8, (NE, 2))
+    q[:, [2, 8, 14, 20]] = 0.01      # at qpos0 the wheels touch the pitch at exactly dist = 0: an fp32 coin flip
   if name in ('manipulator', 'humanoid_CMU', 'quadruped', 'stacker'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
     # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
@@ -590,7 +596,7 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     q, v = np.array(env.physics.data.qpos), np.array(env.physics.data.qvel)
     m = env.physics.model
     env.physics.free()
-  elif name != 'cmu_2019_position_floor':
+  elif name not in ('cmu_2019_position_floor', 'soccer_2v2_boxhead'):
     for j in range(m.njnt):
       a = m.jnt_qposadr[j]
       if m.jnt_type[j] == 3 and m.jnt_limited[j]:

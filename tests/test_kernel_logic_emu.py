@@ -388,3 +388,36 @@ def test_stacker_and_insert_peg_rollouts_fp64():
     else:
       assert (3, 6) in kinds                                 # the peg's capsules against the slot boxes
     assert not o.warning.any() and not e.warning.any()
+
+
+def test_config5_soccer_boxhead_rollout_fp64():
+  """BASELINE config 5 physics (assets/soccer_2v2_boxhead.xml): four BoxHead walkers (root slides, steer,
+  kick, rolling ball), the condim-6 priority-1 soccer ball, pitch walls and goal posts; elliptic cones + noslip.
+  Players are driven into the ball and into each other."""
+  with open(os.path.join(ASSETS, 'soccer_2v2_boxhead.xml')) as f:
+    m = mc.compile_xml(f.read())
+  assert (m.nq, m.nv, m.nu) == (31, 30, 12)                   # SURVEY.md 8(a), config 5 row
+  o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=24)
+  q = m.qpos0.copy()
+  # frames are at x = -+10, y = +-5: move the four players to (-+1, +-1.5), around the ball on the centre spot
+  q[0:2], q[6:8] = (9, -3.5), (9, 3.5)
+  q[12:14], q[18:20] = (-9, -3.5), (-9, 3.5)
+  o.qpos[:] = q
+  e.qpos[:] = q
+  o.forward()
+  rs = np.random.RandomState(0)
+  kinds, worst = set(), 0.0
+  for t in range(500):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    worst = max(worst, np.abs(e.qpos - o.qpos).max())
+    for k in range(o.ncon):
+      ci = o.contact(k)
+      kinds.add((m.names['geom'][ci['geom1']].split('/')[-1], m.names['geom'][ci['geom2']].split('/')[-1]))
+  assert worst < 1e-9, worst
+  assert ('ground', 'shell') in kinds and ('ground', 'geom') in kinds     # wheels and the soccer ball on the pitch
+  np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
+  assert not o.warning.any() and not e.warning.any()
