@@ -2574,32 +2574,148 @@ struct StepCore {
   // A = J_F M^-1 J_F^T is built once (one substitution per friction row), the residual vector
   // res = J qacc - aref is kept up to date lane-parallel, the per-block scalar maths runs
   // redundantly on every lane (uniform values, no divergence).
-  DMC_DEV static int qcqp(T* res, const T* Ain, const T* bin, const T* dd, T r, int n) {
-    T A[25], b[5], Lc[25], v[5], pv[5], la = 0;
-    for (int i = 0; i < 5; i++) { v[i] = 0; pv[i] = 0; b[i] = 0; }
-    for (int i = 0; i < n; i++) { b[i] = bin[i]*dd[i]; for (int j = 0; j < n; j++) A[i*n + j] = Ain[i*n + j]*dd[i]*dd[j]; }
+  // N is a compile-time constant: every array below is indexed statically and lives in registers (with a
+  // run-time size the 20 Newton iterations ran out of scratch memory: 2.5 M cycles per step on the soccer model)
+  template <int N>
+  DMC_DEV static int qcqp(T* res, const T* Ain, const T* bin, const T* dd, T r) {
+    T A[N*N], b[N], Lc[N*N], v[N], pv[N], la = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { v[i] = 0; pv[i] = 0; b[i] = bin[i]*dd[i]; }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++) { A[i*N + j] = Ain[i*N + j]*dd[i]*dd[j]; Lc[i*N + j] = 0; }
+    bool fail = false;
     for (int iter = 0; iter < 20; iter++) {
-      for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
-        T t = A[i*n + j] + (i == j ? la : (T)0);
-        for (int k = 0; k < j; k++) t -= Lc[i*n + k]*Lc[j*n + k];
-        if (i == j) { if (t < (T)1e-10) { for (int k = 0; k < n; k++) res[k] = 0; return 0; } Lc[i*n + i] = t_sqrt(t); }
-        else Lc[i*n + j] = t/Lc[j*n + j];
+#pragma unroll
+      for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+          T t = A[i*N + j] + (i == j ? la : (T)0);
+#pragma unroll
+          for (int k = 0; k < j; k++) t -= Lc[i*N + k]*Lc[j*N + k];
+          if (i == j) { if (t < (T)1e-10) fail = true; Lc[i*N + i] = t_sqrt(t_max(t, (T)1e-30)); }
+          else Lc[i*N + j] = t/Lc[j*N + j];
+        }
+      if (fail) break;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        T t = -b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t -= Lc[i*N + k]*v[k];
+        v[i] = t/Lc[i*N + i];
       }
-      for (int i = 0; i < n; i++) { T t = -b[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*v[k]; v[i] = t/Lc[i*n + i]; }
-      for (int i = n - 1; i >= 0; i--) { T t = v[i]; for (int k = i + 1; k < n; k++) t -= Lc[k*n + i]*v[k]; v[i] = t/Lc[i*n + i]; }
+#pragma unroll
+      for (int i = N - 1; i >= 0; i--) {
+        T t = v[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) t -= Lc[k*N + i]*v[k];
+        v[i] = t/Lc[i*N + i];
+      }
       T val = -r*r;
-      for (int i = 0; i < n; i++) val += v[i]*v[i];
+#pragma unroll
+      for (int i = 0; i < N; i++) val += v[i]*v[i];
       if (val < (T)1e-10) break;
-      for (int i = 0; i < n; i++) { T t = v[i]; for (int k = 0; k < i; k++) t -= Lc[i*n + k]*pv[k]; pv[i] = t/Lc[i*n + i]; }
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        T t = v[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t -= Lc[i*N + k]*pv[k];
+        pv[i] = t/Lc[i*N + i];
+      }
       T deriv = 0;
-      for (int i = 0; i < n; i++) deriv += pv[i]*pv[i];
+#pragma unroll
+      for (int i = 0; i < N; i++) deriv += pv[i]*pv[i];
       deriv *= -2;
       const T delta = -val/deriv;
       if (delta < (T)1e-10) break;
       la += delta;
     }
-    for (int i = 0; i < n; i++) res[i] = v[i]*dd[i];
+    if (fail) {
+#pragma unroll
+      for (int i = 0; i < N; i++) res[i] = 0;
+      return 0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) res[i] = v[i]*dd[i];
     return la != 0;
+  }
+  // one Gauss-Seidel block of N friction dimensions starting at slot a; returns the cost change (<= 0)
+  template <int N>
+  DMC_DEV T noslip_block(int a, int nf, int t, int id) {
+    T Ac[N*N], old[N], bres[N], fnew[N];
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) Ac[p*N + q] = S(ns_A)[ns_idx(a + p, a + q)];
+    }
+    if (N == 1) {
+      const T fl = MR(dof_frictionloss)[id];
+      fnew[0] = old[0] - bres[0]/Ac[0];
+      if (fnew[0] < -fl) fnew[0] = -fl; else if (fnew[0] > fl) fnew[0] = fl;
+    } else if (t == EFC_PYRAMIDAL) {
+      const T bc0 = bres[0] - Ac[0]*old[0] - Ac[1]*old[N > 1 ? 1 : 0], bc1 = bres[N > 1 ? 1 : 0] - Ac[N > 1 ? N : 0]*old[0] - Ac[N > 1 ? N + 1 : 0]*old[N > 1 ? 1 : 0];
+      const T mid = (T)0.5*(old[0] + old[N > 1 ? 1 : 0]);
+      const T K1 = Ac[0] + Ac[N > 1 ? N + 1 : 0] - Ac[N > 1 ? 1 : 0] - Ac[N > 1 ? N : 0], K0 = mid*(Ac[0] - Ac[N > 1 ? N + 1 : 0]) + bc0 - bc1;
+      T f0, f1;
+      if (K1 < (T)DMC_MINVAL) f0 = f1 = mid;
+      else {
+        const T y = -K0/K1;
+        if (y < -mid) { f0 = 0; f1 = 2*mid; }
+        else if (y > mid) { f0 = 2*mid; f1 = 0; }
+        else { f0 = mid + y; f1 = mid - y; }
+      }
+      fnew[0] = f0; fnew[N > 1 ? 1 : 0] = f1;
+    } else {
+      const int cp = SI(con_pair)[id];
+      const T* fr3 = MR(prm_friction) + 3*prm_of(cp);
+      const T fri5[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
+      T fri[N], bc[N];
+#pragma unroll
+      for (int p = 0; p < N; p++) fri[p] = fri5[p < 5 ? p : 4];
+      const T fn = S(efc_force)[SI(con_efc)[id]];
+#pragma unroll
+      for (int p = 0; p < N; p++) {
+        bc[p] = bres[p];
+#pragma unroll
+        for (int q = 0; q < N; q++) bc[p] -= Ac[p*N + q]*old[q];
+      }
+      if (fn >= (T)DMC_MINVAL) {
+        const int active = qcqp<N>(fnew, Ac, bc, fri, fn);
+        if (active) {
+          T ss = 0;
+#pragma unroll
+          for (int p = 0; p < N; p++) ss += (fnew[p]/fri[p])*(fnew[p]/fri[p]);
+          ss = t_sqrt(fn*fn / t_max((T)DMC_MINVAL, ss));
+#pragma unroll
+          for (int p = 0; p < N; p++) fnew[p] *= ss;
+        }
+      }
+    }
+    // cost change of the block; an update that increases the cost is undone
+    T change = 0;
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      T tq = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) tq += Ac[p*N + q]*(fnew[q] - old[q]);
+      change += (T)0.5*(fnew[p] - old[p])*tq + (fnew[p] - old[p])*bres[p];
+    }
+    if (change > (T)1e-10) {
+#pragma unroll
+      for (int p = 0; p < N; p++) fnew[p] = old[p];
+      change = 0;
+    }
+    DMC_WSYNC();
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      const T delta = fnew[p] - old[p];
+      if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
+      if (delta != 0) for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += S(ns_A)[ns_idx(b, a + p)]*delta;
+    }
+    DMC_WSYNC();
+    return change;
   }
   // A is symmetric: packed lower triangle, entry (i, j) with i >= j computed as J_i . (M^-1 J_j^T)
   DMC_DEV static int ns_idx(int i, int j) { return i >= j ? i*(i + 1)/2 + j : j*(j + 1)/2 + i; }
@@ -2641,62 +2757,12 @@ struct StepCore {
         int n = 1;
         if (t == EFC_PYRAMIDAL) n = 2;
         else if (t == EFC_ELLIPTIC) n = MI(pair_dim)[SI(con_pair)[id]] - 1;
-        T Ac[25], old[5], bres[5], fnew[5];
-        for (int p = 0; p < 5; p++) { old[p] = 0; bres[p] = 0; fnew[p] = 0; }
-        for (int p = 0; p < n; p++) {
-          old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p];
-          for (int q = 0; q < n; q++) Ac[p*n + q] = S(ns_A)[ns_idx(a + p, a + q)];
-        }
-        if (t == EFC_FRICTION) {
-          const T fl = MR(dof_frictionloss)[id];
-          fnew[0] = old[0] - bres[0]/Ac[0];
-          if (fnew[0] < -fl) fnew[0] = -fl; else if (fnew[0] > fl) fnew[0] = fl;
-        } else if (t == EFC_PYRAMIDAL) {
-          const T bc0 = bres[0] - Ac[0]*old[0] - Ac[1]*old[1], bc1 = bres[1] - Ac[2]*old[0] - Ac[3]*old[1];
-          const T mid = (T)0.5*(old[0] + old[1]);
-          const T K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid*(Ac[0] - Ac[3]) + bc0 - bc1;
-          if (K1 < (T)DMC_MINVAL) fnew[0] = fnew[1] = mid;
-          else {
-            const T y = -K0/K1;
-            if (y < -mid) { fnew[0] = 0; fnew[1] = 2*mid; }
-            else if (y > mid) { fnew[0] = 2*mid; fnew[1] = 0; }
-            else { fnew[0] = mid + y; fnew[1] = mid - y; }
-          }
-        } else {
-          const int cp = SI(con_pair)[id];
-          const T* fr3 = MR(prm_friction) + 3*prm_of(cp);
-          const T fri[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
-          const T fn = S(efc_force)[SI(con_efc)[id]];
-          T bc[5];
-          for (int p = 0; p < 5; p++) bc[p] = 0;
-          for (int p = 0; p < n; p++) { bc[p] = bres[p]; for (int q = 0; q < n; q++) bc[p] -= Ac[p*n + q]*old[q]; }
-          if (fn < (T)DMC_MINVAL) { for (int p = 0; p < n; p++) fnew[p] = 0; }
-          else {
-            const int active = qcqp(fnew, Ac, bc, fri, fn, n);
-            if (active) {
-              T ss = 0;
-              for (int p = 0; p < n; p++) ss += (fnew[p]/fri[p])*(fnew[p]/fri[p]);
-              ss = t_sqrt(fn*fn / t_max((T)DMC_MINVAL, ss));
-              for (int p = 0; p < n; p++) fnew[p] *= ss;
-            }
-          }
-        }
-        // cost change of the block; an update that increases the cost is undone
-        T change = 0;
-        for (int p = 0; p < n; p++) {
-          T tq = 0;
-          for (int q = 0; q < n; q++) tq += Ac[p*n + q]*(fnew[q] - old[q]);
-          change += (T)0.5*(fnew[p] - old[p])*tq + (fnew[p] - old[p])*bres[p];
-        }
-        if (change > (T)1e-10) { for (int p = 0; p < n; p++) fnew[p] = old[p]; change = 0; }
+        T change;
+        if (n == 1) change = noslip_block<1>(a, nf, t, id);
+        else if (n == 2) change = noslip_block<2>(a, nf, t, id);
+        else if (n == 3) change = noslip_block<3>(a, nf, t, id);
+        else change = noslip_block<5>(a, nf, t, id);
         improvement -= change;
-        DMC_WSYNC();
-        for (int p = 0; p < n; p++) {
-          const T delta = fnew[p] - old[p];
-          if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
-          if (delta != 0) for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += S(ns_A)[ns_idx(b, a + p)]*delta;
-        }
-        DMC_WSYNC();
         a += n;
       }
       improvement *= scale;
