@@ -16,3 +16,15 @@ def pytest_configure(config):
 def oracle_lib():
   from oracle import oracle
   return oracle.lib()
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+  """Runs the host stack (Physics facade, Environment, suite tasks) on the CPU oracle for one test:
+  `dm_control_amd.physics.BatchedPhysics` is replaced by tests/oracle_backend.OracleBatch.  Test
+  infrastructure only -- the product has no CPU path."""
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import oracle_backend as ob
+  from dm_control_amd import physics
+  monkeypatch.setattr(physics, 'BatchedPhysics', ob.OracleBatch)
+  return ob

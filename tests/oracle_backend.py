@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE: a stand-in for `dm_control_amd.batch.BatchedPhysics` backed by the CPU oracle.
+
+It lets the host stack (Physics facade, named indexing, Environment, every suite task) run in the
+`-m "not gpu"` tests.  It is reachable only through the `oracle_backend` pytest fixture
+(tests/conftest.py), which monkeypatches the name inside `dm_control_amd.physics` for one test; the
+product never imports it and still fails loudly without a GPU."""
+import numpy as np
+
+from oracle.oracle import OracleModel, OraclePhysics
+
+_NWARN = 9
+_DSBL_ACTUATION = 1 << 11
+
+
+class OracleBatch:
+
+  def __init__(self, model, batch_size, device_id=0, precision=64, nconmax=0, njmax=0, lanes_per_env=0):
+    del device_id, njmax, lanes_per_env
+    self.model = model
+    self.batch_size = int(batch_size)
+    self.precision = precision
+    self.legacy_step = True
+    self._om = OracleModel(model)
+    self._envs = [OraclePhysics(self._om) for _ in range(self.batch_size)]
+    self.nconmax = nconmax or 16
+    m = model
+    nb = m.nbody
+    self._rows = dict(qpos=m.nq, qvel=m.nv, act=m.na, ctrl=m.nu, qacc_warmstart=m.nv, qfrc_applied=m.nv, time=1,
+                      sensordata=m.nsensordata, xpos=3*nb, xquat=4*nb, xmat=9*nb, xipos=3*nb, geom_xpos=3*m.ngeom,
+                      geom_xmat=9*m.ngeom, site_xpos=3*m.nsite, site_xmat=9*m.nsite, subtree_com=3*nb, qacc=m.nv,
+                      actuator_force=m.nu, qfrc_actuator=m.nv, qfrc_bias=m.nv, qfrc_constraint=m.nv, cvel=6*nb)
+
+  def close(self):
+    self._envs = []
+
+  def info(self):
+    return dict(B=self.batch_size, precision=self.precision, nconmax=self.nconmax, static_id=-1)
+
+  # -- fields ---------------------------------------------------------------------------
+  def get(self, name):
+    B = self.batch_size
+    if name == 'warning':
+      return np.stack([np.array(o.warning, dtype=np.int32) for o in self._envs])
+    if name in ('ncon', 'nefc', 'solver_iter'):
+      return np.array([[getattr(o, name)] for o in self._envs], dtype=np.int32)
+    if name.startswith('contact_'):
+      what = name[len('contact_'):]
+      width = dict(dist=1, pos=3, frame=9, force=6, geom1=1, geom2=1)[what]
+      out = np.zeros((B, self.nconmax * width), dtype=np.int32 if what.startswith('geom') else np.float64)
+      if what.startswith('geom'):
+        out[:] = -1
+      for e, o in enumerate(self._envs):
+        for i in range(min(o.ncon, self.nconmax)):
+          c = o.contact(i)
+          v = o.contact_force(i).ravel() if what == 'force' else np.ravel(c[what])
+          out[e, i*width:(i + 1)*width] = v
+      return out
+    if name == 'time':
+      return np.array([[o.time] for o in self._envs])
+    return np.stack([np.array(o.field(name), dtype=np.float64).reshape(-1)[:self._rows[name]] for o in self._envs]).reshape(B, self._rows[name])
+
+  def set(self, name, value):
+    rows = self._rows[name]
+    if not rows:
+      return
+    a = np.broadcast_to(np.asarray(value, dtype=np.float64).reshape((-1, rows) if np.ndim(value) > 1 else (1, rows)),
+                        (self.batch_size, rows))
+    for e, o in enumerate(self._envs):
+      if name == 'time':
+        o.time = float(a[e, 0])
+      else:
+        o.field(name)[:rows] = a[e]
+
+  def set_control(self, control):
+    self.set('ctrl', control)
+
+  def set_model_real(self, name, values):
+    self._om.field(name)[:] = np.asarray(values, dtype=np.float64).ravel()
+
+  # -- pipeline -------------------------------------------------------------------------
+  def step(self, nstep=1, stream=None):
+    del stream
+    for o in self._envs:
+      o.legacy_step = bool(self.legacy_step)
+      o.step(int(nstep))
+
+  def forward(self, disable_actuation=False, stream=None):
+    del stream
+    flags = self._om.opt_int('disableflags')
+    if disable_actuation:
+      self._om.opt_int('disableflags', flags | _DSBL_ACTUATION)
+    for o in self._envs:
+      o.forward()
+    self._om.opt_int('disableflags', flags)
+
+  def reset(self, env_mask=None, keyframe_id=None):
+    from oracle.oracle import lib
+    for e, o in enumerate(self._envs):
+      if env_mask is None or env_mask[e]:
+        lib().ora_reset(self._om.ptr, o.ptr, -1 if keyframe_id is None else int(keyframe_id))
+
+  def sync(self):
+    pass

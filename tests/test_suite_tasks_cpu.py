@@ -1,0 +1,71 @@
+"""Host stack without a GPU: `suite.load`, the Physics facade, named indexing, the Environment loop and every
+suite task run on the oracle-backed stand-in batch (tests/oracle_backend.py).  Mirrors the reference's
+suite-level properties (dm_control/suite/suite_test.py: spec conformance :149, determinism :170, finite
+observations :81, reward range :94).  The `-m gpu` suite runs the same checks on the HIP backend."""
+import numpy as np
+import pytest
+
+from dm_control_amd import suite
+
+_SLOW = {'humanoid_CMU'}          # a 62-dof oracle step is ~2 ms: fewer env-steps there
+
+
+@pytest.mark.parametrize('domain,task', suite.ALL_TASKS)
+def test_task_runs_and_respects_its_specs(oracle_backend, domain, task):
+  env = suite.load(domain, task, task_kwargs=dict(random=0))
+  aspec, ospec = env.action_spec(), env.observation_spec()
+  rs = np.random.RandomState(1)
+  ts = env.reset()
+  assert ts.first() and ts.reward is None
+  assert set(ts.observation) == set(ospec)
+  for _ in range(3 if domain in _SLOW else 8):
+    lo, hi = np.maximum(aspec.minimum, -1), np.minimum(aspec.maximum, 1)      # lqr's action spec is unbounded
+    ts = env.step(rs.uniform(lo, hi, aspec.shape))
+    for k, v in ts.observation.items():
+      v = np.asarray(v)
+      assert v.shape == ospec[k].shape and np.all(np.isfinite(v)), (k, v.shape, ospec[k].shape)
+    assert float(ts.reward) <= 1.0 and (domain == 'lqr' or float(ts.reward) >= 0.0)   # lqr: 1 - quadratic cost
+  env.physics.free()
+
+
+@pytest.mark.parametrize('domain,task', [('cheetah', 'run'), ('humanoid', 'walk'), ('quadruped', 'run'), ('stacker', 'stack_2'),
+                                         ('manipulator', 'insert_peg'), ('finger', 'turn_hard'), ('fish', 'swim')])
+def test_same_seed_same_trajectory_and_batches_agree_with_single_envs(oracle_backend, domain, task):
+  def rollout(batch):
+    env = suite.load(domain, task, task_kwargs=dict(random=42), physics_kwargs=dict(batch_size=batch))
+    aspec = env.action_spec()
+    rs = np.random.RandomState(7)
+    ts = env.reset()
+    out = [np.concatenate([np.reshape(v, (batch, -1)) for v in ts.observation.values()], axis=1)]
+    for _ in range(5):
+      ts = env.step(rs.uniform(aspec.minimum, aspec.maximum, aspec.shape))
+      out.append(np.concatenate([np.reshape(v, (batch, -1)) for v in ts.observation.values()] + [np.reshape(ts.reward, (batch, 1))], axis=1))
+    env.physics.free()
+    return out
+  a, b = rollout(1), rollout(1)
+  for x, y in zip(a, b):
+    np.testing.assert_array_equal(x, y)
+  # a batch of 3 produces well-formed (3, ...) observations and rewards in [0, 1]
+  c = rollout(3)
+  assert c[0].shape[0] == 3 and c[0].shape[1] == a[0].shape[1]
+  assert all(np.isfinite(x).all() for x in c)
+  assert ((c[-1][:, -1] >= 0) & (c[-1][:, -1] <= 1)).all()
+
+
+def test_humanoid_cmu_observation_formulas(oracle_backend):
+  env = suite.load('humanoid_CMU', 'walk', task_kwargs=dict(random=3))
+  ts = env.reset()
+  p = env.physics
+  m = p.model
+  bid = lambda n: m.name2id(n, 'body')
+  xpos = np.asarray(p.data.xpos).reshape(-1, 3)
+  xmat = np.asarray(p.data.xmat).reshape(-1, 3, 3)
+  R, t = xmat[bid('thorax')], xpos[bid('thorax')]
+  ext = np.concatenate([(xpos[bid(s + l)] - t) @ R for s in ('l', 'r') for l in ('hand', 'foot')])
+  np.testing.assert_allclose(ts.observation['extremities'], ext, atol=1e-12)
+  np.testing.assert_allclose(ts.observation['head_height'], xpos[bid('head'), 2], atol=1e-12)
+  np.testing.assert_allclose(ts.observation['torso_vertical'], R[2], atol=1e-12)
+  np.testing.assert_allclose(p.thorax_upright(), R[2, 1], atol=1e-12)
+  np.testing.assert_allclose(ts.observation['joint_angles'], np.asarray(p.data.qpos)[7:], atol=0)
+  assert np.asarray(p.data.ncon) == 0                      # rejection-sampled start: nothing touches
+  env.physics.free()
