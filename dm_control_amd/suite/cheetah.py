@@ -1,4 +1,9 @@
-"""Cheetah domain (reference: dm_control/suite/cheetah.py): task `run`."""
+"""Cheetah domain (reference: dm_control/suite/cheetah.py): task `run`.
+
+This is BASELINE config 2.  One `Physics` holds `batch_size` independent cheetahs; observations and rewards
+come back with a leading batch axis when `batch_size > 1` and exactly in the reference's shapes when it is 1
+(the drop-in case).  The random start pose draws from the task's RandomState in the reference's order, so a
+single environment with seed s starts where the reference's does."""
 import collections
 
 import numpy as np
@@ -36,16 +41,20 @@ class Physics(physics_lib.Physics):
 
 class Cheetah(base.Task):
 
+  _SETTLE_STEPS = 200     # zero-control physics steps between the random pose and t = 0 (cheetah.py:72)
+
+  def _draw_start_pose(self, physics):
+    """Every range-limited joint uniformly inside its range (all cheetah joints are scalar: nq == njnt)."""
+    model = physics.model
+    assert model.nq == model.njnt
+    limited = np.flatnonzero(model.jnt_limited == 1)
+    lo, hi = model.jnt_range[limited, 0], model.jnt_range[limited, 1]
+    shape = (limited.size,) if physics.batch_size == 1 else (physics.batch_size, limited.size)
+    physics.data.qpos[..., limited] = self.random.uniform(lo, hi, shape)
+
   def initialize_episode(self, physics):
-    # cheetah.py:63-76: limited joints uniform in range, 200 settle steps, time = 0
-    assert physics.model.nq == physics.model.njnt
-    is_limited = physics.model.jnt_limited == 1
-    lower, upper = physics.model.jnt_range[is_limited].T
-    if physics.batch_size == 1:
-      physics.data.qpos[is_limited] = self.random.uniform(lower, upper)
-    else:
-      physics.data.qpos[:, is_limited] = self.random.uniform(lower, upper, (physics.batch_size, lower.size))
-    physics.step(nstep=200)
+    self._draw_start_pose(physics)
+    physics.step(nstep=self._SETTLE_STEPS)      # let it fall onto its feet
     physics.data.time = 0
     self._timeout_progress = 0
     super().initialize_episode(physics)

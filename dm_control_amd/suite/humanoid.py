@@ -41,32 +41,38 @@ TASKS.update(stand=(stand, 'benchmarking'), walk=(walk, 'benchmarking'), run=(ru
 
 
 class Physics(physics_lib.Physics):
+  # body / sensor names of the model; the CMU humanoid (suite/humanoid_CMU.py) reuses everything below
+  # with its own names
+  TORSO = 'torso'
+  UPRIGHT_AXIS = 'zz'                      # torso axis whose world-z component measures uprightness
+  SIDES = ('left_', 'right_')
+  COM_VELOCITY_SENSOR = 'torso_subtreelinvel'
 
   def torso_upright(self):
-    return self.named.data.xmat['torso', 'zz']
+    return self.named.data.xmat[self.TORSO, self.UPRIGHT_AXIS]
 
   def head_height(self):
     return self.named.data.xpos['head', 'z']
 
   def center_of_mass_position(self):
-    return self.named.data.subtree_com['torso'].copy()
+    return self.named.data.subtree_com[self.TORSO].copy()
 
   def center_of_mass_velocity(self):
-    return self.named.data.sensordata['torso_subtreelinvel'].copy()
+    return self.named.data.sensordata[self.COM_VELOCITY_SENSOR].copy()
 
   def torso_vertical_orientation(self):
-    return self.named.data.xmat['torso', ['zx', 'zy', 'zz']]
+    return self.named.data.xmat[self.TORSO, ['zx', 'zy', 'zz']]
 
   def joint_angles(self):
     return self.data.qpos[..., 7:].copy()
 
   def extremities(self):
     """Hand / foot positions in the egocentric torso frame."""
-    xmat = self.named.data.xmat['torso']
+    xmat = self.named.data.xmat[self.TORSO]
     frame = xmat.reshape(xmat.shape[:-1] + (3, 3))
-    torso_pos = self.named.data.xpos['torso']
+    torso_pos = self.named.data.xpos[self.TORSO]
     out = []
-    for side in ('left_', 'right_'):
+    for side in self.SIDES:
       for limb in ('hand', 'foot'):
         d = self.named.data.xpos[side + limb] - torso_pos
         out.append(np.einsum('...i,...ij->...j', d, frame))

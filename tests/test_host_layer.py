@@ -171,3 +171,28 @@ def test_named_axes():
   np.testing.assert_array_equal(fi[1:, 'zz'], data[1:, 8])
   with pytest.raises(KeyError):
     fi['nope']
+
+
+def test_tolerance_values_against_closed_forms():
+  # distance d = (x - upper) / margin; every sigmoid returns value_at_margin at d = 1 and its closed form elsewhere
+  d = np.array([0.25, 0.5, 1.0, 1.5])
+  x = 1.0 + 2.0 * d
+  v = 0.2
+  want = {
+      'gaussian': np.exp(np.log(v) * d**2),
+      'hyperbolic': 1 / np.cosh(d * np.arccosh(1 / v)),
+      'long_tail': 1 / (d**2 * (1 / v - 1) + 1),
+      'reciprocal': 1 / (d * (1 / v - 1) + 1),
+      'tanh_squared': 1 - np.tanh(d * np.arctanh(np.sqrt(1 - v)))**2,
+      'cosine': np.where(d * np.arccos(2*v - 1) / np.pi < 1, (1 + np.cos(d * np.arccos(2*v - 1))) / 2, 0),
+      'linear': np.where(d * (1 - v) < 1, 1 - d * (1 - v), 0),
+      'quadratic': np.where(d * np.sqrt(1 - v) < 1, 1 - d**2 * (1 - v), 0),
+  }
+  for name, w in want.items():
+    got = rewards.tolerance(x, bounds=(0, 1), margin=2, sigmoid=name, value_at_margin=v)
+    np.testing.assert_allclose(got, w, rtol=1e-12, atol=1e-15, err_msg=name)
+    assert abs(got[2] - v) < 1e-12
+  with pytest.raises(ValueError):
+    rewards.tolerance(2.0, bounds=(0, 1), margin=1, sigmoid='nope')
+  with pytest.raises(ValueError):
+    rewards.tolerance(2.0, bounds=(0, 1), margin=1, sigmoid='gaussian', value_at_margin=0)
