@@ -449,6 +449,26 @@ class Physics(control.Physics):
     self.batch.set('qacc_warmstart', st['fields']['qacc_warmstart'])
     self._warnings_seen = self.batch.get('warning').astype(np.int64)
 
+  def reload_from_xml_string(self, xml_string, assets=None):
+    """Swaps in a new model, keeping this object (engine.py:500-515): composer environments do this at
+    every episode when their MJCF changed (composer/environment.py:377-383).  The device batch is rebuilt
+    with the same batch size, precision and caps; the state is that of a freshly constructed Physics.
+    Recompiling an unchanged XML costs a hash lookup (`mjcf_compiler.compile_xml` cache)."""
+    model = mjcf_compiler.compile_xml(xml_string, assets)
+    kwargs = dict(self._batch_kwargs)
+    batch_size, precision, legacy = self.batch_size, self.batch.precision, self.legacy_step
+    self.free()
+    Physics.__init__(self, model, batch_size=batch_size, precision=precision, **kwargs)
+    self.legacy_step = legacy
+
+  def reload_from_xml_path(self, file_path):
+    with open(file_path) as f:
+      self.reload_from_xml_string(f.read())
+
+  def render(self, *args, **kwargs):
+    """Rendering (engine.py:178-233) is outside this backend's scope: there is no GL context here."""
+    raise NotImplementedError('rendering is not part of the MI355X physics backend (DESIGN.md, out of scope)')
+
   def free(self):
     if getattr(self, 'batch', None) is not None:
       self.batch.close()

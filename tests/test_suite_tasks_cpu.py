@@ -69,3 +69,23 @@ def test_humanoid_cmu_observation_formulas(oracle_backend):
   np.testing.assert_allclose(ts.observation['joint_angles'], np.asarray(p.data.qpos)[7:], atol=0)
   assert np.asarray(p.data.ncon) == 0                      # rejection-sampled start: nothing touches
   env.physics.free()
+
+
+def test_reload_from_xml_string_keeps_the_object_and_its_settings(oracle_backend):
+  # composer/environment.py:377-383 recompiles and reloads at episode boundaries
+  from dm_control_amd.suite import cheetah, walker
+  p = cheetah.Physics.from_xml_string(*cheetah.get_model_and_assets(), batch_size=2, nconmax=20)
+  p.legacy_step = False
+  p.set_control(np.ones((2, 6)))
+  p.step(5)
+  assert p.model.nq == 9 and np.asarray(p.data.time).max() > 0
+  p.reload_from_xml_string(walker.get_model_and_assets()[0])
+  assert type(p) is cheetah.Physics and p.batch_size == 2 and p.legacy_step is False
+  assert p.batch.nconmax == 20                        # caps travel with the object
+  assert p.model.nq == 9 and p.model.nu == 6 and 'right_hip' in p.model.names['joint']
+  assert np.asarray(p.data.time).max() == 0           # fresh state, named indexing rebuilt for the new model
+  assert np.asarray(p.named.data.qpos['right_hip']).shape == (2, 1)
+  p.step(3)
+  with pytest.raises(NotImplementedError):
+    p.render()
+  p.free()
