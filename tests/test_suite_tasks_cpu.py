@@ -89,3 +89,37 @@ def test_reload_from_xml_string_keeps_the_object_and_its_settings(oracle_backend
   with pytest.raises(NotImplementedError):
     p.render()
   p.free()
+
+
+def test_gather_table_reproduces_task_observations(oracle_backend):
+  """named-field observations resolved once into row indices; evaluated for a batch with one
+  gather per field.  The cheetah and humanoid observations that are plain field slices come out identical."""
+  from dm_control_amd.observation import GatherTable
+  env = suite.load('cheetah', 'run', task_kwargs=dict(random=1), physics_kwargs=dict(batch_size=3))
+  ts = env.reset()
+  m = env.physics.model
+  joints = [n for n in m.names['joint'] if n != 'rootx']
+  table = GatherTable(m, [('qpos', joints), ('qvel', None), ('sensordata', ['torso_subtreelinvel']), ('xpos', ['torso'], 'z')])
+  env.physics.data._upload()
+  got = table.gather(env.physics)
+  assert got.shape == (3, 8 + 9 + 3 + 1)
+  np.testing.assert_array_equal(got[:, :8], ts.observation['position'])
+  np.testing.assert_array_equal(got[:, 8:17], ts.observation['velocity'])
+  np.testing.assert_array_equal(got[:, 17], env.physics.speed())
+  np.testing.assert_array_equal(got[:, 20], np.asarray(env.physics.named.data.xpos['torso', 'z']))
+  assert list(table.rows['xpos']) == [3 * m.name2id('torso', 'body') + 2]
+  env.physics.free()
+  env = suite.load('humanoid', 'stand', task_kwargs=dict(random=1))
+  ts = env.reset()
+  m = env.physics.model
+  table = GatherTable(m, [('qpos', [n for n in m.names['joint'] if n != 'root']), ('xpos', ['head'], 'z'),
+                          ('xmat', ['torso'], ['zx', 'zy', 'zz']), ('sensordata', ['torso_subtreelinvel']), ('qvel', None)])
+  got = table.gather(env.physics)
+  want = np.concatenate([ts.observation['joint_angles'], [ts.observation['head_height']], ts.observation['torso_vertical'],
+                         ts.observation['com_velocity'], ts.observation['velocity']])
+  np.testing.assert_array_equal(got, want)
+  with pytest.raises(KeyError):
+    GatherTable(m, [('qpos', ['no_such_joint'])])
+  with pytest.raises(ValueError):
+    GatherTable(m, [('efc_J', None)])
+  env.physics.free()
