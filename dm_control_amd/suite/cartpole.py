@@ -1,6 +1,7 @@
-"""Cartpole domain (reference: dm_control/suite/cartpole.py): balance,
-balance_sparse, swingup, swingup_sparse (single pole)."""
+"""Cartpole domain (reference: dm_control/suite/cartpole.py): balance, balance_sparse, swingup,
+swingup_sparse (one pole), two_poles, three_poles (chains generated from the one-pole model)."""
 import collections
+import xml.etree.ElementTree as etree
 
 import numpy as np
 
@@ -14,13 +15,30 @@ _DEFAULT_TIME_LIMIT = 10
 TASKS = {}
 
 
-def get_model_and_assets():
-  return common.read_model('cartpole.xml'), None
+def _make_model(n_poles):
+  """One-pole model with n_poles - 1 further poles hinged end to end, floor lowered to clear the hanging
+  chain (cartpole.py:105-127; the cameras the reference also moves do not exist here)."""
+  xml_string = common.read_model('cartpole.xml')
+  if n_poles == 1:
+    return xml_string
+  mjcf = etree.fromstring(xml_string)
+  parent = mjcf.find('./worldbody/body/body')          # the first pole
+  for k in range(2, n_poles + 1):
+    child = etree.SubElement(parent, 'body', name='pole_%d' % k, pos='0 0 1', childclass='pole')
+    etree.SubElement(child, 'joint', name='hinge_%d' % k)
+    etree.SubElement(child, 'geom', name='pole_%d' % k)
+    parent = child
+  mjcf.find('./worldbody/geom').set('pos', '0 0 %r' % (1 - n_poles - .05))
+  return etree.tostring(mjcf, encoding='unicode')
 
 
-def _make(swing_up, sparse):
+def get_model_and_assets(num_poles=1):
+  return _make_model(num_poles), None
+
+
+def _make(swing_up, sparse, num_poles=1):
   def factory(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None, physics_kwargs=None):
-    physics = Physics.from_xml_string(*get_model_and_assets(), **(physics_kwargs or {}))
+    physics = Physics.from_xml_string(*get_model_and_assets(num_poles), **(physics_kwargs or {}))
     task = Balance(swing_up=swing_up, sparse=sparse, random=random)
     return control.Environment(physics, task, time_limit=time_limit, **(environment_kwargs or {}))
   return factory
@@ -32,6 +50,9 @@ swingup = _make(True, False)
 swingup_sparse = _make(True, True)
 for _n in ('balance', 'balance_sparse', 'swingup', 'swingup_sparse'):
   TASKS[_n] = (globals()[_n], 'benchmarking')
+two_poles = _make(True, False, num_poles=2)
+three_poles = _make(True, False, num_poles=3)
+TASKS.update(two_poles=(two_poles, None), three_poles=(three_poles, None))
 
 
 class Physics(physics_lib.Physics):
