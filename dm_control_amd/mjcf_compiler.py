@@ -1355,7 +1355,7 @@ class _Compiler:
       iw = imat @ np.diag(m.body_inertia[b]) @ imat.T
       mass_matrix += m.body_mass[b] * jacp[b].T @ jacp[b] + jacr[b].T @ iw @ jacr[b]
     self.mass_matrix0 = mass_matrix
-    minv = np.linalg.inv(mass_matrix)
+    minv = _robust_inverse(mass_matrix)
     diag = np.diag(minv).copy()
     for j in range(m.njnt):
       d = m.jnt_dofadr[j]
@@ -1412,6 +1412,24 @@ def _solimp(s):
   out = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
   out[:min(5, v.size)] = v[:5]
   return out
+
+
+def _robust_inverse(mat):
+  """Inverse of the mass matrix at qpos0.  A model may legitimately have a singular one (three hinges with the
+  same axis on one body and no armature: suite/utils/randomizers_test.py); MuJoCo's factorisation clamps the
+  pivots at mjMINVAL instead of failing, so does this fallback (Cholesky with clamped pivots)."""
+  try:
+    return np.linalg.inv(mat)
+  except np.linalg.LinAlgError:
+    n = mat.shape[0]
+    low = np.zeros_like(mat)
+    for j in range(n):
+      d = mat[j, j] - low[j, :j] @ low[j, :j]
+      low[j, j] = np.sqrt(max(d, MINVAL))
+      for i in range(j + 1, n):
+        low[i, j] = (mat[i, j] - low[i, :j] @ low[j, :j]) / low[j, j]
+    linv = np.linalg.inv(low)
+    return linv.T @ linv
 
 
 _COMPILE_CACHE = collections.OrderedDict()

@@ -123,3 +123,57 @@ def test_gather_table_reproduces_task_observations(oracle_backend):
   with pytest.raises(ValueError):
     GatherTable(m, [('efc_J', None)])
   env.physics.free()
+
+
+# ---- suite/utils/randomizers_test.py mirrored on the oracle-backed facade -----------------------------------
+def _physics(xml, **kw):
+  from dm_control_amd import physics as physics_lib
+  return physics_lib.Physics.from_xml_string(xml, **kw)
+
+
+def test_randomizer_single_joint_of_each_type(oracle_backend):
+  from dm_control_amd.suite import randomizers
+  p = _physics("""<mujoco><default><joint range="0 90" armature="1"/></default><worldbody>
+      <body><geom type="box" size="1 1 1"/><joint name="free" type="free"/></body>
+      <body><geom type="box" size="1 1 1"/><joint name="limited_hinge" type="hinge" limited="true"/>
+        <joint name="slide" type="slide" limited="false"/><joint name="limited_slide" type="slide" limited="true"/>
+        <joint name="hinge" type="hinge" limited="false"/></body>
+      <body><geom type="box" size="1 1 1"/><joint name="ball" type="ball" limited="false"/></body>
+    </worldbody></mujoco>""")
+  randomizers.randomize_limited_and_rotational_joints(p, np.random.RandomState(100))
+  q = p.named.data.qpos
+  assert q['hinge'] != 0 and q['limited_hinge'] != 0 and q['limited_slide'] != 0
+  assert np.sum(q['ball']) != 0 and np.sum(q['free'][3:]) != 0
+  np.testing.assert_allclose(np.linalg.norm(q['ball']), 1, atol=1e-12)
+  np.testing.assert_allclose(np.linalg.norm(q['free'][3:]), 1, atol=1e-12)
+  # the unlimited slide and the translation of the free joint are left alone
+  assert q['slide'] == 0 and np.sum(q['free'][:3]) == 0
+  p.free()
+
+
+def test_randomizer_ranges_and_distinct_draws(oracle_backend):
+  from dm_control_amd.suite import randomizers
+  rand = np.random.RandomState(100)
+  p = _physics("""<mujoco><worldbody><body><geom type="box" size="1 1 1"/>
+      <joint name="hinge_1" type="hinge"/><joint name="hinge_2" type="hinge"/><joint name="hinge_3" type="hinge"/></body>
+    </worldbody></mujoco>""")
+  for _ in range(10):
+    randomizers.randomize_limited_and_rotational_joints(p, rand)
+    a, b, c = (float(p.named.data.qpos[n][0]) for n in ('hinge_1', 'hinge_2', 'hinge_3'))
+    assert len({a, b, c}) == 3 and all(-np.pi <= v <= np.pi and v != 0 for v in (a, b, c))
+  p.free()
+  p = _physics("""<mujoco><default><joint limited="true"/></default><worldbody><body><geom type="box" size="1 1 1"/>
+      <joint name="hinge" type="hinge" range="0 10"/><joint name="slide" type="slide" range="30 50"/></body>
+    </worldbody></mujoco>""")
+  for _ in range(10):
+    randomizers.randomize_limited_and_rotational_joints(p, rand)
+    assert 0 <= p.named.data.qpos['hinge'][0] <= np.deg2rad(10)
+    assert 30 <= p.named.data.qpos['slide'][0] <= 50
+  p.free()
+  # batch: only the masked environments are re-drawn
+  p = _physics("""<mujoco><worldbody><body><geom type="box" size="1 1 1"/><joint name="h" type="hinge"/></body>
+    </worldbody></mujoco>""", batch_size=4)
+  randomizers.randomize_limited_and_rotational_joints(p, rand, env_mask=[True, False, True, False])
+  q = np.asarray(p.data.qpos)[:, 0]
+  assert q[0] != 0 and q[2] != 0 and q[1] == 0 and q[3] == 0
+  p.free()
