@@ -1,0 +1,160 @@
+"""dm_control/mujoco/engine_test.py (the cases that do not render) against the Physics facade, run on the
+oracle-backed stand-in batch (tests/oracle_backend.py) so that they are part of the `-m "not gpu"` tier."""
+import copy
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from dm_control_amd import physics as physics_lib
+from dm_control_amd.envs import control
+
+CARTPOLE = """<mujoco model="cart-pole"><option timestep="0.01"/>
+<worldbody>
+  <geom name="floor" type="plane" pos="0 0 -.05" size="4 4 .2"/>
+  <body name="cart" pos="0 0 1">
+    <joint name="slider" type="slide" limited="true" axis="1 0 0" range="-1.8 1.8" damping="5e-4"/>
+    <geom name="cart" type="box" size="0.2 0.15 0.1" mass="1"/>
+    <body name="pole"><joint name="hinge_1" type="hinge" axis="0 1 0" damping="2e-6"/>
+      <geom name="pole" type="capsule" fromto="0 0 0 0 0 1" size="0.045" mass=".1"/>
+      <site name="tip" pos="0 0 1"/></body></body>
+</worldbody>
+<actuator><motor name="slide" joint="slider" gear="10" ctrllimited="true" ctrlrange="-1 1"/></actuator>
+<sensor><accelerometer name="accelerometer" site="tip"/></sensor>
+<keyframe><key name="hanging_down" qpos="0 1.57"/><key qpos="0.1 3.14" qvel="0.5 0"/></keyframe>
+</mujoco>"""
+
+
+@pytest.fixture
+def physics(oracle_backend):
+  p = physics_lib.Physics.from_xml_string(CARTPOLE)
+  yield p
+  p.free()
+
+
+def test_named_views(physics):
+  assert physics.control().shape == (1,) and physics.position().shape == (2,) and physics.velocity().shape == (2,)
+  assert physics.activation().shape == (0,) and physics.state().shape == (4,)
+  assert physics.time() == 0.0 and physics.timestep() == 0.01
+  assert physics.named.data.xpos['cart'].shape == (3,)
+  assert physics.named.data.xpos[['cart', 'pole']].shape == (2, 3)
+
+
+def test_set_get_physics_state(physics):
+  state = physics.get_state()
+  physics.set_state(state)
+  new = np.random.RandomState(0).random_sample(state.shape)
+  physics.set_state(new)
+  np.testing.assert_allclose(physics.get_state(), new)
+  with pytest.raises(ValueError):
+    physics.set_state(np.repeat(state, 2))
+
+
+def test_reload_from_path_and_string(physics, tmp_path):
+  path = os.path.join(str(tmp_path), 'cartpole.xml')
+  with open(path, 'w') as f:
+    f.write(CARTPOLE)
+  physics.step(3)
+  physics.reload_from_xml_path(path)
+  assert physics.time() == 0 and physics.model.nq == 2
+  physics.reload_from_xml_string(CARTPOLE)
+  other = physics_lib.Physics.from_xml_path(path)
+  np.testing.assert_array_equal(other.data.qpos, physics.data.qpos)
+  other.free()
+
+
+def test_reset_and_keyframes(physics):
+  physics.step(5)
+  physics.reset()
+  assert physics.data.qpos[1] == 0 and physics.time() == 0
+  physics.reset(keyframe_id=0)
+  assert physics.data.qpos[1] == physics.model.key_qpos[0, 1] == 1.57
+  physics.reset(keyframe_id=1)
+  np.testing.assert_array_equal(physics.data.qvel, [0.5, 0])
+  for bad in (-1, 2):
+    with pytest.raises(ValueError):
+      physics.reset(keyframe_id=bad)
+
+
+@pytest.mark.parametrize('bad_value', [float('inf'), float('nan'), 1e15])
+def test_bad_qpos_raises_physics_error(physics, bad_value):
+  with pytest.raises(control.PhysicsError, match='mjWARN_BADQPOS'):
+    with physics.reset_context():
+      pass
+    physics.data.qpos[0] = bad_value
+    physics.step()
+  physics.reset()
+  physics.step()                     # a reset physics is valid again
+
+
+def test_nan_control_and_suppression(physics):
+  with physics.reset_context():
+    pass
+  physics.data.ctrl[0] = float('nan')
+  with pytest.raises(control.PhysicsError, match='mjWARN_BADCTRL'):
+    physics.step()
+  physics.data.ctrl[0] = float('nan')
+  with physics.suppress_physics_errors():
+    physics.forward()                # warns instead of raising
+  physics.data.ctrl[0] = float('nan')
+  with pytest.raises(control.PhysicsError, match='mjWARN_BADCTRL'):
+    physics.forward()
+
+
+@pytest.mark.parametrize('clone', [copy.copy, copy.deepcopy, lambda p: pickle.loads(pickle.dumps(p))])
+def test_copy_or_pickle_continues_identically(physics, clone):
+  for _ in range(10):
+    physics.set_control([0.3])
+    physics.step()
+  other = clone(physics)
+  assert other is not physics and type(other) is type(physics)
+  for _ in range(10):
+    for p in (physics, other):
+      p.set_control([-0.2])
+      p.step()
+  np.testing.assert_array_equal(other.get_state(), physics.get_state())
+  np.testing.assert_array_equal(other.data.xpos, physics.data.xpos)
+  assert other.time() == physics.time()
+  # warnings seen before the copy do not raise in the copy (engine_test.py:578-584)
+  other.free()
+
+
+def test_forward_dynamics_after_reset_and_actuation_disabled_in_after_reset(physics):
+  with physics.reset_context():
+    pass
+  # the accelerometer at the pole tip reads +g along z after a reset (forward was run)
+  np.testing.assert_allclose(physics.named.data.sensordata['accelerometer'][2], 9.81, rtol=1e-6)
+  physics.data.ctrl[0] = 1.0
+  physics.after_reset()              # forward with actuation disabled
+  assert physics.data.actuator_force[0] == 0.0
+  physics.forward()
+  assert physics.data.actuator_force[0] == 1.0
+
+
+def test_action_spec_limits(oracle_backend):
+  p = physics_lib.Physics.from_xml_string("""<mujoco><worldbody><body><geom type="sphere" size="0.1"/>
+      <joint type="hinge" name="hinge"/></body></worldbody><actuator>
+      <motor joint="hinge" ctrllimited="false"/><motor joint="hinge" ctrllimited="true" ctrlrange="-1 2"/>
+    </actuator></mujoco>""")
+  spec = physics_lib.action_spec(p)
+  assert spec.dtype == float
+  np.testing.assert_array_equal(spec.minimum, [-1e10, -1.0])       # mjMAXVAL
+  np.testing.assert_array_equal(spec.maximum, [1e10, 2.0])
+  p.free()
+
+
+@pytest.mark.parametrize('integrator', ['Euler', 'RK4'])
+def test_nstep_equals_repeated_single_steps(oracle_backend, integrator):
+  xml = CARTPOLE.replace('timestep="0.01"', 'timestep="0.01" integrator="%s"' % integrator)
+  a, b = physics_lib.Physics.from_xml_string(xml), physics_lib.Physics.from_xml_string(xml)
+  for p in (a, b):
+    with p.reset_context():
+      p.data.qpos[1] = 0.3
+    p.set_control([0.5])
+  a.step(4)
+  for _ in range(4):
+    b.step()
+  np.testing.assert_array_equal(a.get_state(), b.get_state())
+  assert a.time() == b.time()
+  a.free(); b.free()
