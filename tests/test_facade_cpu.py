@@ -158,3 +158,37 @@ def test_nstep_equals_repeated_single_steps(oracle_backend, integrator):
   np.testing.assert_array_equal(a.get_state(), b.get_state())
   assert a.time() == b.time()
   a.free(); b.free()
+
+
+# ---- dm_control/mujoco/index_test.py: named indexing semantics ------------------------------------------------
+def test_named_indexing_keys_match_numeric_indexing(physics):
+  physics.step(3)
+  d, n = physics.data, physics.named.data
+  xpos, xmat, sd = np.asarray(d.xpos), np.asarray(d.xmat), np.asarray(d.sensordata)
+  np.testing.assert_array_equal(n.xpos['pole'], xpos[2])
+  np.testing.assert_array_equal(n.xpos[['pole', 'cart']], xpos[[2, 1]])
+  np.testing.assert_array_equal(n.sensordata['accelerometer'], sd[0:3])
+  np.testing.assert_array_equal(n.xpos['pole', 'y'], xpos[2, 1])
+  np.testing.assert_array_equal(n.xmat['cart', ['yy', 'zz']], xmat[1, [4, 8]])
+  np.testing.assert_array_equal(n.xpos[['pole', 'cart'], ['x', 'z']], xpos[[[2], [1]], [0, 2]])   # outer product
+  np.testing.assert_array_equal(n.xpos[:, 0], xpos[:, 0])                                          # plain slices pass through
+  np.testing.assert_array_equal(n.qpos['slider'], np.asarray(d.qpos)[0:1])                         # ragged rows are slices
+  np.testing.assert_array_equal(n.qvel[['slider', 'hinge_1']], np.asarray(d.qvel)[[0, 1]])
+  m = physics.named.model
+  np.testing.assert_array_equal(m.actuator_gear['slide'], physics.model.actuator_gear[0])
+  np.testing.assert_array_equal(m.dof_armature[['slider', 'hinge_1']], physics.model.dof_armature[[0, 1]])
+  with pytest.raises(KeyError):
+    n.xpos['no_such_body']
+
+
+@pytest.mark.parametrize('field,key', [('qpos', 'slider'), ('qvel', ['slider', 'hinge_1']), ('ctrl', 'slide')])
+def test_named_assignment_reaches_the_state(physics, field, key):
+  indexer = getattr(physics.named.data, field)
+  shape = np.shape(indexer[key])
+  new = 0.25 + np.arange(int(np.prod(shape))).reshape(shape) if shape else 0.25
+  indexer[key] = new
+  np.testing.assert_array_equal(indexer[key], new)
+  physics.forward()                          # uploaded with the next pipeline call and still there afterwards
+  np.testing.assert_array_equal(getattr(physics.named.data, field)[key], new)
+  with pytest.raises(AttributeError):
+    physics.data.xpos = 0                    # derived arrays are read-only
