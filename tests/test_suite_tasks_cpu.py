@@ -177,3 +177,26 @@ def test_randomizer_ranges_and_distinct_draws(oracle_backend):
   q = np.asarray(p.data.qpos)[:, 0]
   assert q[0] != 0 and q[2] != 0 and q[1] == 0 and q[3] == 0
   p.free()
+
+
+@pytest.mark.parametrize('domain,task', suite.ALL_TASKS)
+def test_every_task_runs_as_a_batch(oracle_backend, domain, task):
+  """batch_size = 2: observations gain a leading batch axis, rewards come back as (2,), both environments evolve
+  (different random starts) and the first one equals... nothing in particular: only shapes and ranges are checked."""
+  single = suite.load(domain, task, task_kwargs=dict(random=0))
+  ospec = single.observation_spec()
+  single.physics.free()
+  env = suite.load(domain, task, task_kwargs=dict(random=0), physics_kwargs=dict(batch_size=2))
+  aspec = env.action_spec()
+  assert aspec.shape[0] == 2
+  rs = np.random.RandomState(3)
+  ts = env.reset()
+  for _ in range(2 if domain == 'humanoid_CMU' else 4):
+    lo, hi = np.maximum(aspec.minimum, -1), np.minimum(aspec.maximum, 1)
+    ts = env.step(rs.uniform(lo, hi, aspec.shape))
+    for k, v in ts.observation.items():
+      v = np.asarray(v)
+      assert v.shape == (2,) + ospec[k].shape and np.all(np.isfinite(v)), (k, v.shape, ospec[k].shape)
+    r = np.asarray(ts.reward)
+    assert r.shape == (2,) and np.all(r <= 1.0) and (domain == 'lqr' or np.all(r >= 0.0))
+  env.physics.free()
