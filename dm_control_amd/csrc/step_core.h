@@ -1451,13 +1451,66 @@ struct StepCore {
     const int nv = L.d.nv, njmax = L.d.njmax;
     int nefc = 0, overflow = 0;
     const bool enabled = !(o.disableflags & DMC_DSBL_CONSTRAINT);
-    // equality constraints first (MuJoCo order: equality, friction, limit, contact): a fixed
-    // tendon held at its reference length; two-sided, always active
+    // equality constraints first (MuJoCo order: equality, friction, limit, contact), two-sided, always
+    // active; residuals and Jacobians as in the oracle's make_constraint (tendon, joint, connect, weld)
     if (L.d.neq && enabled && !(o.disableflags & DMC_DSBL_EQUALITY)) for (int k = 0; k < L.d.neq; k++) {
-      if (nefc >= njmax) { overflow = 1; continue; }
-      const int r = nefc++, t = MI(eq_tendon)[k];
-      FOR_LANES(dd, nv) S(efc_J)[r*nv + dd] = tendon_jac(t, dd);
-      if (lane == 0) { S(efc_aref)[r] = tendon_length(t) - MR(eq_pos0)[k]; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_EQUALITY, k); }
+      const int et = MI(eq_type)[k], o1 = MI(eq_obj1)[k], o2 = MI(eq_obj2)[k];
+      const int nrow = et == DMC_EQ_CONNECT ? 3 : (et == DMC_EQ_WELD ? 6 : 1);
+      if (nefc + nrow > njmax) { overflow = 1; continue; }
+      const int r0 = nefc;
+      nefc += nrow;
+      const T* data = MR(eq_data) + 13*k;
+      if (lane == 0) for (int a = 0; a < nrow; a++) { S(efc_D)[r0 + a] = 0; SI(efc_tid)[r0 + a] = EFC_TID(EFC_EQUALITY, k); }
+      if (et == DMC_EQ_TENDON) {
+        FOR_LANES(dd, nv) S(efc_J)[r0*nv + dd] = tendon_jac(o1, dd);
+        if (lane == 0) S(efc_aref)[r0] = tendon_length(o1) - data[11] - data[0];
+      } else if (et == DMC_EQ_JOINT) {
+        const int q1 = MI(jnt_qposadr)[o1], d1 = MI(jnt_dofadr)[o1];
+        T pos = S(qpos)[q1] - data[11], deriv = 0;
+        int d2 = -1;
+        if (o2 >= 0) {
+          d2 = MI(jnt_dofadr)[o2];
+          const T dif = S(qpos)[MI(jnt_qposadr)[o2]] - data[12];
+          T pw = 1, poly = 0;
+          for (int p = 0; p < 5; p++) { poly += data[p]*pw; if (p < 4) deriv += (p + 1)*data[p + 1]*pw; pw *= dif; }
+          pos -= poly;
+        } else pos -= data[0];
+        FOR_LANES(dd, nv) { T j = dd == d2 ? -deriv : (T)0; if (dd == d1) j += 1; S(efc_J)[r0*nv + dd] = j; }
+        if (lane == 0) S(efc_aref)[r0] = pos;
+      } else {
+        // connect: data[0:3] on body 1, data[3:6] on body 2; weld: data[3:6] on body 1, data[0:3] on body 2
+        const T *l1 = et == DMC_EQ_CONNECT ? data : data + 3, *l2 = et == DMC_EQ_CONNECT ? data + 3 : data;
+        T p1[3], p2[3], tmp[3];
+        mul_mat_vec3(tmp, S(xmat) + 9*o1, l1); for (int a = 0; a < 3; a++) p1[a] = S(xpos)[3*o1 + a] + tmp[a];
+        mul_mat_vec3(tmp, S(xmat) + 9*o2, l2); for (int a = 0; a < 3; a++) p2[a] = S(xpos)[3*o2 + a] + tmp[a];
+        T quat[4] = {1, 0, 0, 0}, q2inv[4] = {1, 0, 0, 0}, err[4] = {1, 0, 0, 0};
+        if (et == DMC_EQ_WELD) {
+          T rel[4] = {data[6], data[7], data[8], data[9]}, q1[4], q2[4];
+          for (int a = 0; a < 4; a++) { q1[a] = S(xquat)[4*o1 + a]; q2[a] = S(xquat)[4*o2 + a]; }
+          mul_quat(quat, q1, rel);
+          q2inv[0] = q2[0]; q2inv[1] = -q2[1]; q2inv[2] = -q2[2]; q2inv[3] = -q2[3];
+          mul_quat(err, q2inv, quat);
+        }
+        if (lane == 0) {
+          for (int a = 0; a < 3; a++) S(efc_aref)[r0 + a] = p1[a] - p2[a];
+          if (et == DMC_EQ_WELD) for (int a = 0; a < 3; a++) S(efc_aref)[r0 + 3 + a] = data[10]*err[1 + a];
+        }
+        FOR_LANES(dd, nv) {
+          T jp1[3], jp2[3];
+          point_jac(o1, p1, dd, jp1); point_jac(o2, p2, dd, jp2);
+          for (int a = 0; a < 3; a++) S(efc_J)[(r0 + a)*nv + dd] = jp1[a] - jp2[a];
+          if (et == DMC_EQ_WELD) {
+            const bool in1 = dof_in_chain(MI(body_lastdof)[o1], dd), in2 = dof_in_chain(MI(body_lastdof)[o2], dd);
+            const T* cd = S(cdof) + 6*dd;
+            T w[4] = {0, 0, 0, 0};
+            for (int a = 0; a < 3; a++) w[1 + a] = (in1 ? cd[a] : (T)0) - (in2 ? cd[a] : (T)0);
+            T t1[4], t2[4];
+            mul_quat(t1, q2inv, w);
+            mul_quat(t2, t1, quat);
+            for (int a = 0; a < 3; a++) S(efc_J)[(r0 + 3 + a)*nv + dd] = data[10]*(T)0.5*t2[1 + a];
+          }
+        }
+      }
     }
     // dof friction loss: one row per dof with frictionloss > 0
     if (L.d.nfric && enabled && !(o.disableflags & DMC_DSBL_FRICTIONLOSS)) {
@@ -1608,7 +1661,15 @@ struct StepCore {
       int ell_row = 0; T ell_fj = 0, ell_imp0 = 0;
       if (type == EFC_EQUALITY) {
         solref = MR(eq_solref) + 2*id; solimp = MR(eq_solimp) + 5*id;
-        dA = MR(tendon_invweight0)[MI(eq_tendon)[id]];
+        const int et = MI(eq_type)[id], o1 = MI(eq_obj1)[id], o2 = MI(eq_obj2)[id];
+        if (et == DMC_EQ_TENDON) dA = MR(tendon_invweight0)[o1];
+        else if (et == DMC_EQ_JOINT) {
+          dA = MR(dof_invweight0)[MI(jnt_dofadr)[o1]];
+          if (o2 >= 0) dA += MR(dof_invweight0)[MI(jnt_dofadr)[o2]];
+        } else {
+          const int col = (i - MI(eq_rowadr)[id]) < 3 ? 0 : 1;     // translational rows, then (weld) rotational ones
+          dA = MR(body_invweight0)[2*o1 + col] + MR(body_invweight0)[2*o2 + col];
+        }
       } else if (type == EFC_FRICTION) {
         solref = MR(dof_solref) + 2*id; solimp = MR(dof_solimp) + 5*id;
         dA = MR(dof_invweight0)[id];

@@ -28,7 +28,8 @@ struct StepDims {
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
   int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
-  int neq;       // active equality constraints (single fixed tendon held at its reference length)
+  int neq;       // active equality constraints (tendon, joint: 1 row; connect: 3; weld: 6)
+  int neqrow;    // their rows
   int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
   int nslip;     // cap on the friction rows the noslip post-solver handles (0: model has noslip_iterations = 0)
   int na;        // activation states (actuators with integrator / filter dynamics)
@@ -66,7 +67,8 @@ struct StepDims {
   X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap) \
   X(wrap_site, d.nwrap)        /* site id of a spatial-tendon wrap, -1 for joint wraps */ \
   X(limten, d.nlimten)         /* the limited tendons */                       \
-  X(eq_tendon, d.neq)          /* tendon of each equality constraint */
+  X(eq_type, d.neq) X(eq_obj1, d.neq) X(eq_obj2, d.neq)   /* mjtEq, tendon / joint / body ids (-1: none) */ \
+  X(eq_rowadr, d.neq)          /* first constraint row of each equality (equality rows come first) */
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -93,7 +95,8 @@ struct StepDims {
   X(tendon_range, d.nlimten ? 2 * d.ntendon : 0) X(tendon_margin, d.nlimten ? d.ntendon : 0) \
   X(tendon_solref_lim, d.nlimten ? 2 * d.ntendon : 0) X(tendon_solimp_lim, d.nlimten ? 5 * d.ntendon : 0) \
   X(tendon_invweight0, (d.nlimten || d.neq) ? d.ntendon : 0)                   \
-  X(eq_solref, 2 * d.neq) X(eq_solimp, 5 * d.neq) X(eq_pos0, d.neq)  /* eq_pos0: reference length + polycoef[0] */
+  X(eq_solref, 2 * d.neq) X(eq_solimp, 5 * d.neq)                             \
+  X(eq_data, 13 * d.neq)  /* mjModel.eq_data (11) + reference coordinates: tendon length0, or the joints' qpos0 */
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...

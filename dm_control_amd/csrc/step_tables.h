@@ -111,14 +111,21 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.tendon_limited[t]) limten.push_back(t);
   }
   d.nlimten = (int)limten.size();
-  std::vector<int> eq_tendon, eq_src;
+  std::vector<int> eq_src, eq_rowadr;
   for (int k = 0; k < m.neq; k++) {
-    if (m.eq_type[k] != DMC_EQ_TENDON) { *err = "only tendon equality constraints are implemented"; return false; }
-    const int t = m.eq_obj1id[k];
-    if (t < 0 || t >= m.ntendon || (m.tendon_num[t] > 0 && m.wrap_type[m.tendon_adr[t]] != DMC_WRAP_JOINT)) { *err = "equality constraints need a fixed tendon"; return false; }
-    if (m.eq_active0[k]) { eq_tendon.push_back(t); eq_src.push_back(k); }
+    const int et = m.eq_type[k], o1 = m.eq_obj1id[k], o2 = m.eq_obj2id[k];
+    if (et == DMC_EQ_TENDON) {
+      if (o1 < 0 || o1 >= m.ntendon || (m.tendon_num[o1] > 0 && m.wrap_type[m.tendon_adr[o1]] != DMC_WRAP_JOINT)) { *err = "tendon equality constraints need a fixed tendon"; return false; }
+    } else if (et == DMC_EQ_JOINT) {
+      if (o1 < 0 || o1 >= m.njnt || o2 >= m.njnt) { *err = "joint equality refers to a missing joint"; return false; }
+    } else if (et == DMC_EQ_CONNECT || et == DMC_EQ_WELD) {
+      if (o1 < 0 || o1 >= m.nbody || o2 < 0 || o2 >= m.nbody) { *err = "connect / weld equality refers to a missing body"; return false; }
+    } else { *err = "equality constraint type not implemented (connect, weld, joint, tendon)"; return false; }
+    if (!m.eq_active0[k]) continue;
+    eq_src.push_back(k); eq_rowadr.push_back(d.neqrow);
+    d.neqrow += et == DMC_EQ_CONNECT ? 3 : (et == DMC_EQ_WELD ? 6 : 1);
   }
-  d.neq = (int)eq_tendon.size();
+  d.neq = (int)eq_src.size();
   for (int j = 0; j < m.njnt; j++) {
     if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
@@ -204,13 +211,13 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     pair_prm[p] = q;
   }
   d.nprm = (int)prm.size();
-  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric + d.neq;
+  t->max_contacts = maxc; t->max_rows = maxr + nlim + d.nlimten + d.nfric + d.neqrow;
   int maxrow_per_contact = 1;
   for (int p = 0; p < m.npair; p++) maxrow_per_contact = std::max(maxrow_per_contact, pdim[p] == 1 ? 1 : (elliptic ? pdim[p] : 2*(pdim[p] - 1)));
   if (nconmax <= 0) nconmax = std::min(maxc, 16);
   nconmax = std::max(1, std::min(nconmax, std::max(1, maxc)));
-  if (njmax <= 0) njmax = d.neq + d.nfric + nlim + d.nlimten + nconmax * maxrow_per_contact;
-  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric + d.neq)));
+  if (njmax <= 0) njmax = d.neqrow + d.nfric + nlim + d.nlimten + nconmax * maxrow_per_contact;
+  njmax = std::max(1, std::min(njmax, std::max(1, maxr + nlim + d.nlimten + d.nfric + d.neqrow)));
   d.nconmax = nconmax; d.njmax = njmax;
   d.elliptic = (elliptic && maxrow_per_contact > 1) ? 1 : 0;
   if (m.opt_noslip_iterations > 0) {
@@ -331,12 +338,18 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     cpr(L.mr_tendon_solimp_lim, m.tendon_solimp_lim);
   }
   if (d.nlimten || d.neq) cpr(L.mr_tendon_invweight0, m.tendon_invweight0);
-  cpi(L.mi_eq_tendon, eq_tendon);
+  cpi(L.mi_eq_rowadr, eq_rowadr);
   for (int k = 0; k < d.neq; k++) {
-    const int src = eq_src[k];
+    const int src = eq_src[k], et = m.eq_type[src];
+    mi[L.mi_eq_type + k] = et; mi[L.mi_eq_obj1 + k] = m.eq_obj1id[src]; mi[L.mi_eq_obj2 + k] = m.eq_obj2id[src];
     for (int a = 0; a < 2; a++) mr[L.mr_eq_solref + 2*k + a] = m.eq_solref[2*src + a];
     for (int a = 0; a < 5; a++) mr[L.mr_eq_solimp + 5*k + a] = m.eq_solimp[5*src + a];
-    mr[L.mr_eq_pos0 + k] = m.tendon_length0[eq_tendon[k]] + m.eq_data[5*src];
+    for (int a = 0; a < 11; a++) mr[L.mr_eq_data + 13*k + a] = m.eq_data[11*src + a];
+    if (et == DMC_EQ_TENDON) mr[L.mr_eq_data + 13*k + 11] = m.tendon_length0[m.eq_obj1id[src]];
+    if (et == DMC_EQ_JOINT) {
+      mr[L.mr_eq_data + 13*k + 11] = m.qpos0[m.jnt_qposadr[m.eq_obj1id[src]]];
+      if (m.eq_obj2id[src] >= 0) mr[L.mr_eq_data + 13*k + 12] = m.qpos0[m.jnt_qposadr[m.eq_obj2id[src]]];
+    }
   }
   if (d.nfric) { cpr(L.mr_dof_frictionloss, m.dof_frictionloss); cpr(L.mr_dof_solref, m.dof_solref); cpr(L.mr_dof_solimp, m.dof_solimp); }
   cpr(L.mr_site_pos, m.site_pos); cpr(L.mr_site_quat, m.site_quat); cpr(L.mr_site_size, m.site_size);

@@ -773,8 +773,9 @@ class _Compiler:
           raise MjcfError('unknown default class %r' % cname)
         a = dict(self.classes[cname].get('equality'))
         a.update(e.attrib)
-        if e.tag != 'tendon' or 'tendon2' in a:
-          raise MjcfError('unsupported equality constraint <%s> (only single-tendon equalities are supported)' % e.tag)
+        if e.tag not in ('tendon', 'connect', 'weld', 'joint') or 'tendon2' in a:
+          raise MjcfError('unsupported equality constraint <%s> (connect, weld, joint and single-tendon equalities are supported)' % e.tag)
+        a['_tag'] = e.tag
         self.equalities.append(a)
 
   def _parse_sensors(self):
@@ -1109,26 +1110,74 @@ class _Compiler:
     m.neq = len(self.equalities)
     m.eq_type = np.full(m.neq, C['DMC_EQ_TENDON'], dtype=np.int64)
     m.eq_obj1id = np.zeros(m.neq, dtype=np.int64)
+    m.eq_obj2id = np.full(m.neq, -1, dtype=np.int64)
     m.eq_active0 = np.ones(m.neq, dtype=np.int64)
     m.eq_solref = np.zeros((m.neq, 2))
     m.eq_solimp = np.zeros((m.neq, 5))
-    m.eq_data = np.zeros((m.neq, 5))
+    m.eq_data = np.zeros((m.neq, 11))
     eq_names = []
+    self._eq_auto = {}      # weld / connect: which parts of eq_data _set_const derives from the pose at qpos0
     for k, a in enumerate(self.equalities):
       eq_names.append(a.get('name'))
-      tname = a.get('tendon1')
-      names_t = [td['name'] for td in self.tendons]
-      if tname not in names_t:
-        raise MjcfError('equality refers to unknown tendon %r' % tname)
-      t = names_t.index(tname)
-      if self.tendons[t]['spatial']:
-        raise MjcfError('equality on a spatial tendon is not supported')
-      m.eq_obj1id[k] = t
+      tag = a['_tag']
       m.eq_active0[k] = int(a.get('active', 'true') == 'true')
       m.eq_solref[k] = _vec(a.get('solref', '0.02 1'), 2)
       m.eq_solimp[k] = _solimp(a.get('solimp', '0.9 0.95 0.001 0.5 2'))
-      pc = _vec(a.get('polycoef', '0 1 0 0 0'))
-      m.eq_data[k, :pc.size] = pc
+      if tag == 'tendon':
+        tname = a.get('tendon1')
+        names_t = [td['name'] for td in self.tendons]
+        if tname not in names_t:
+          raise MjcfError('equality refers to unknown tendon %r' % tname)
+        t = names_t.index(tname)
+        if self.tendons[t]['spatial']:
+          raise MjcfError('equality on a spatial tendon is not supported')
+        m.eq_obj1id[k] = t
+        pc = _vec(a.get('polycoef', '0 1 0 0 0'))
+        m.eq_data[k, :pc.size] = pc
+      elif tag == 'joint':
+        m.eq_type[k] = C['DMC_EQ_JOINT']
+        for key, dst in (('joint1', m.eq_obj1id), ('joint2', m.eq_obj2id)):
+          if key in a:
+            if a[key] not in m.names['joint']:
+              raise MjcfError('equality refers to unknown joint %r' % a[key])
+            j = m.names['joint'].index(a[key])
+            if m.jnt_type[j] not in (_JNT['hinge'], _JNT['slide']):
+              raise MjcfError('joint equalities need hinge / slide joints')
+            dst[k] = j
+          elif key == 'joint1':
+            raise MjcfError('joint equality needs joint1')
+        pc = _vec(a.get('polycoef', '0 1 0 0 0'))
+        m.eq_data[k, :pc.size] = pc
+      else:
+        m.eq_type[k] = C['DMC_EQ_CONNECT'] if tag == 'connect' else C['DMC_EQ_WELD']
+        if 'body1' not in a:
+          raise MjcfError('%s equality needs body1 (site-based definitions are not supported)' % tag)
+        for key, dst in (('body1', m.eq_obj1id), ('body2', m.eq_obj2id)):
+          name = a.get(key)
+          if name is None:
+            dst[k] = 0                         # the world
+          elif name not in m.names['body']:
+            raise MjcfError('equality refers to unknown body %r' % name)
+          else:
+            dst[k] = m.names['body'].index(name)
+        anchor = _vec(a['anchor'], 3) if 'anchor' in a else np.zeros(3)
+        if tag == 'connect':
+          if 'anchor' not in a:
+            raise MjcfError('connect equality needs an anchor')
+          m.eq_data[k, 0:3] = anchor           # in the body1 frame; the body2 one follows from qpos0
+          self._eq_auto[k] = 'connect'
+        else:
+          m.eq_data[k, 0:3] = anchor           # in the body2 frame
+          m.eq_data[k, 10] = float(a.get('torquescale', 1))
+          rel = _vec(a.get('relpose', '0 1 0 0 0 0 0'), 7)
+          if np.any(rel[3:] != 0):
+            q = rel[3:] / np.linalg.norm(rel[3:])
+            m.eq_data[k, 6:10] = q
+            # anchor expressed in body1: relpose maps body2 coordinates into body1's frame
+            m.eq_data[k, 3:6] = rel[:3] + quat_to_mat(q) @ anchor
+            self._eq_auto[k] = None
+          else:
+            self._eq_auto[k] = 'weld'          # pose of body2 in body1 taken from qpos0
     m.names['equality'] = eq_names
     m.tendon_stiffness = np.array([td['stiffness'] for td in self.tendons], dtype=np.float64)
     m.tendon_damping = np.array([td['damping'] for td in self.tendons], dtype=np.float64)
@@ -1405,6 +1454,18 @@ class _Compiler:
       m.tendon_invweight0[t] = max(MINVAL, float(J @ minv @ J))
       if wn and m.wrap_type[w0] == C['DMC_WRAP_JOINT']:
         m.tendon_length0[t] = sum(m.wrap_prm[w] * m.qpos0[m.jnt_qposadr[m.wrap_objid[w]]] for w in range(w0, w0 + wn))
+    # connect / weld equalities: the parts of eq_data that follow from the reference pose (qpos0)
+    for k, kind in getattr(self, '_eq_auto', {}).items():
+      b1, b2 = int(m.eq_obj1id[k]), int(m.eq_obj2id[k])
+      R1, R2 = quat_to_mat(xquat[b1]), quat_to_mat(xquat[b2])
+      if kind == 'connect':
+        world = xpos[b1] + R1 @ m.eq_data[k, 0:3]
+        m.eq_data[k, 3:6] = R2.T @ (world - xpos[b2])
+      elif kind == 'weld':
+        world = xpos[b2] + R2 @ m.eq_data[k, 0:3]
+        m.eq_data[k, 3:6] = R1.T @ (world - xpos[b1])
+        q1 = xquat[b1]
+        m.eq_data[k, 6:10] = quat_mul(np.array([q1[0], -q1[1], -q1[2], -q1[3]]), xquat[b2])
 
 
 def _solimp(s):

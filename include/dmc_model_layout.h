@@ -18,7 +18,7 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 9
+#define DMC_MODEL_VERSION 10
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
@@ -54,7 +54,7 @@
   X(tendon_adr, ntendon) X(tendon_num, ntendon) /* fixed tendons: wraps [adr, adr + num) */ \
   X(wrap_objid, nwrap)                           /* joint id (fixed) or site id (spatial) of each wrap */ \
   X(wrap_type, nwrap) X(tendon_limited, ntendon) \
-  X(eq_type, neq) X(eq_obj1id, neq) X(eq_active0, neq)   /* equality constraints (tendon type only) */
+  X(eq_type, neq) X(eq_obj1id, neq) X(eq_obj2id, neq) X(eq_active0, neq)   /* equality constraints: bodies (connect, weld), joints, a fixed tendon; obj2 = -1: none / world = 0 */
 
 /* ---- real fields: X(name, count_expr) ----------------------------------- */
 #define DMC_MODEL_REAL_FIELDS(X) \
@@ -79,7 +79,7 @@
   X(tendon_stiffness, ntendon) X(tendon_damping, ntendon) X(tendon_lengthspring, ntendon) \
   X(tendon_range, 2*ntendon) X(tendon_margin, ntendon) X(tendon_solref_lim, 2*ntendon) \
   X(tendon_solimp_lim, 5*ntendon) X(tendon_invweight0, ntendon) X(tendon_length0, ntendon) \
-  X(eq_solref, 2*neq) X(eq_solimp, 5*neq) X(eq_data, 5*neq) \
+  X(eq_solref, 2*neq) X(eq_solimp, 5*neq) X(eq_data, 11*neq) /* mjModel.eq_data rows: connect anchor1(3) anchor2(3); weld anchor2(3) anchor1(3) relquat(4) torquescale; joint / tendon polycoef(5) */ \
   X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
 
 /* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
@@ -94,7 +94,7 @@ enum { DMC_CONE_PYRAMIDAL = 0, DMC_CONE_ELLIPTIC = 1 };
 enum { DMC_SOL_PGS = 0, DMC_SOL_CG = 1, DMC_SOL_NEWTON = 2 };
 enum { DMC_TRN_JOINT = 0, DMC_TRN_TENDON = 3 };
 enum { DMC_WRAP_JOINT = 1, DMC_WRAP_SITE = 3 };
-enum { DMC_EQ_TENDON = 3 };
+enum { DMC_EQ_CONNECT = 0, DMC_EQ_WELD = 1, DMC_EQ_JOINT = 2, DMC_EQ_TENDON = 3 };   /* mjtEq */
 enum { DMC_DYN_NONE = 0, DMC_DYN_INTEGRATOR = 1, DMC_DYN_FILTER = 2, DMC_DYN_FILTEREXACT = 3 };
 enum { DMC_GAIN_FIXED = 0, DMC_GAIN_AFFINE = 1 };
 enum { DMC_BIAS_NONE = 0, DMC_BIAS_AFFINE = 1 };

@@ -1212,15 +1212,68 @@ static void make_constraint(const Model* m, Data* d) {
   d->nefc = 0;
   for (int i = 0; i < d->ncon; i++) d->contact[i].efc_address = -1;
   if (m->opt_disableflags & DMC_DSBL_CONSTRAINT) return;
-  /* equality constraints (first, as in MuJoCo): a fixed tendon held at its reference length,
-   * residual = (L - L0) - polycoef[0]; always active, two-sided */
+  /* equality constraints (first, as in MuJoCo; mj_instantiateEquality), always active, two-sided:
+   *   tendon   (L - L0) - polycoef[0], J = tendon Jacobian
+   *   joint    (q1 - q1_0) - poly(q2 - q2_0), J = e_dof1 - poly'(q2 - q2_0) e_dof2
+   *   connect  pos1 - pos2 of the two anchor points (3 rows), J = point Jacobian difference
+   *   weld     3 rows as connect (anchor of body2, its image in body1), 3 rows torquescale * vec(q2^-1 q1 relquat),
+   *            J_rot column = torquescale * 0.5 * vec(q2^-1 (0, w1 - w2) q1 relquat) */
   if (!(m->opt_disableflags & DMC_DSBL_EQUALITY)) for (int k = 0; k < m->neq; k++) {
     if (!m->eq_active0[k]) continue;
-    if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
-    int r = d->nefc++, t = m->eq_obj1id[k];
-    memcpy(d->efc_J + (size_t)r*nv, d->ten_J + (size_t)t*nv, sizeof(double) * (size_t)nv);
-    d->efc_pos[r] = d->ten_length[t] - m->tendon_length0[t] - m->eq_data[5*k];
-    d->efc_margin[r] = 0; d->efc_type[r] = CT_EQUALITY; d->efc_id[r] = k;
+    const int type = m->eq_type[k];
+    const int nrow = type == DMC_EQ_CONNECT ? 3 : type == DMC_EQ_WELD ? 6 : 1;
+    if (d->nefc + nrow > m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+    const int r0 = d->nefc;
+    d->nefc += nrow;
+    const double* data = m->eq_data + 11*k;
+    for (int a = 0; a < nrow; a++) { d->efc_margin[r0 + a] = 0; d->efc_type[r0 + a] = CT_EQUALITY; d->efc_id[r0 + a] = k; }
+    if (type == DMC_EQ_TENDON) {
+      const int t = m->eq_obj1id[k];
+      memcpy(d->efc_J + (size_t)r0*nv, d->ten_J + (size_t)t*nv, sizeof(double) * (size_t)nv);
+      d->efc_pos[r0] = d->ten_length[t] - m->tendon_length0[t] - data[0];
+    } else if (type == DMC_EQ_JOINT) {
+      const int j1 = m->eq_obj1id[k], j2 = m->eq_obj2id[k];
+      memset(d->efc_J + (size_t)r0*nv, 0, sizeof(double) * (size_t)nv);
+      double pos = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]], deriv = 0;
+      if (j2 >= 0) {
+        const double dif = d->qpos[m->jnt_qposadr[j2]] - m->qpos0[m->jnt_qposadr[j2]];
+        double pw = 1, poly = 0;
+        for (int p = 0; p < 5; p++) { poly += data[p]*pw; if (p < 4) deriv += (p + 1)*data[p + 1]*pw; pw *= dif; }
+        pos -= poly;
+        d->efc_J[(size_t)r0*nv + m->jnt_dofadr[j2]] = -deriv;
+      } else pos -= data[0];
+      d->efc_J[(size_t)r0*nv + m->jnt_dofadr[j1]] += 1;
+      d->efc_pos[r0] = pos;
+    } else {
+      const int b1 = m->eq_obj1id[k], b2 = m->eq_obj2id[k];
+      /* connect: data[0:3] on body1, data[3:6] on body2; weld: data[3:6] on body1, data[0:3] on body2 */
+      const double *l1 = type == DMC_EQ_CONNECT ? data : data + 3, *l2 = type == DMC_EQ_CONNECT ? data + 3 : data;
+      double p1[3], p2[3], tmp[3];
+      mul_mat_vec3(tmp, d->xmat + 9*b1, l1); for (int a = 0; a < 3; a++) p1[a] = d->xpos[3*b1 + a] + tmp[a];
+      mul_mat_vec3(tmp, d->xmat + 9*b2, l2); for (int a = 0; a < 3; a++) p2[a] = d->xpos[3*b2 + a] + tmp[a];
+      for (int a = 0; a < 3; a++) d->efc_pos[r0 + a] = p1[a] - p2[a];
+      double quat[4] = {1, 0, 0, 0}, q2inv[4] = {1, 0, 0, 0};
+      if (type == DMC_EQ_WELD) {
+        double err[4];
+        mul_quat(quat, d->xquat + 4*b1, data + 6);                       /* q1 * relquat */
+        q2inv[0] = d->xquat[4*b2]; for (int a = 1; a < 4; a++) q2inv[a] = -d->xquat[4*b2 + a];
+        mul_quat(err, q2inv, quat);
+        for (int a = 0; a < 3; a++) d->efc_pos[r0 + 3 + a] = data[10]*err[1 + a];
+      }
+      for (int dof = 0; dof < nv; dof++) {
+        double jp1[3], jr1[3], jp2[3], jr2[3];
+        jac_col(m, d, b1, p1, dof, jp1, jr1);
+        jac_col(m, d, b2, p2, dof, jp2, jr2);
+        for (int a = 0; a < 3; a++) d->efc_J[(size_t)(r0 + a)*nv + dof] = jp1[a] - jp2[a];
+        if (type == DMC_EQ_WELD) {
+          const double w[4] = {0, jr1[0] - jr2[0], jr1[1] - jr2[1], jr1[2] - jr2[2]};
+          double t1[4], t2[4];
+          mul_quat(t1, q2inv, w);
+          mul_quat(t2, t1, quat);
+          for (int a = 0; a < 3; a++) d->efc_J[(size_t)(r0 + 3 + a)*nv + dof] = data[10]*0.5*t2[1 + a];
+        }
+      }
+    }
   }
   /* dof friction loss (rows come first, as in MuJoCo: equality, friction, limit, contact) */
   if (!(m->opt_disableflags & DMC_DSBL_FRICTIONLOSS)) for (int i = 0; i < nv; i++) {
@@ -1311,7 +1364,17 @@ static void make_constraint(const Model* m, Data* d) {
     if (d->efc_type[i] == CT_EQUALITY) {
       int k = d->efc_id[i];
       solref = m->eq_solref + 2*k; solimp = m->eq_solimp + 5*k;
-      dA = m->tendon_invweight0[m->eq_obj1id[k]];
+      const int et = m->eq_type[k];
+      if (et == DMC_EQ_TENDON) dA = m->tendon_invweight0[m->eq_obj1id[k]];
+      else if (et == DMC_EQ_JOINT) {
+        dA = m->dof_invweight0[m->jnt_dofadr[m->eq_obj1id[k]]];
+        if (m->eq_obj2id[k] >= 0) dA += m->dof_invweight0[m->jnt_dofadr[m->eq_obj2id[k]]];
+      } else {
+        /* rows 0..2 translational, 3..5 (weld) rotational: sums of the two bodies' inverse weights */
+        int first = i; while (first > 0 && d->efc_type[first - 1] == CT_EQUALITY && d->efc_id[first - 1] == k) first--;
+        const int col = (i - first) < 3 ? 0 : 1;
+        dA = m->body_invweight0[2*m->eq_obj1id[k] + col] + m->body_invweight0[2*m->eq_obj2id[k] + col];
+      }
     } else if (d->efc_type[i] == CT_FRICTION_DOF) {
       int k = d->efc_id[i];
       solref = m->dof_solref + 2*k; solimp = m->dof_solimp + 5*k;

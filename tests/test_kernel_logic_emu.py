@@ -421,3 +421,33 @@ def test_config5_soccer_boxhead_rollout_fp64():
   assert ('ground', 'shell') in kinds and ('ground', 'geom') in kinds     # wheels and the soccer ball on the pitch
   np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
   assert not o.warning.any() and not e.warning.any()
+
+
+@pytest.mark.parametrize('prec,tol', [(64, 1e-12), (32, 2e-5)])
+def test_connect_weld_joint_equalities_match_oracle(prec, tol):
+  """Equality constraints between bodies (connect: 3 rows, weld: 6 rows incl. the quaternion-error rows) and
+  joints (polynomial coupling), next to the tendon equalities of the suite models."""
+  import test_oracle_kat as kat
+  scenes = [kat._EQ_CHAIN,
+            """<mujoco><option timestep="0.002"/><worldbody><geom type="plane" size="2 2 .1"/>
+               <body name="box" pos=".3 .1 .7" quat=".8 .2 .4 .1"><freejoint/><geom type="box" size=".1 .05 .02" mass="2"/></body>
+               <body name="b2" pos=".6 .1 .7"><freejoint/><geom type="sphere" size=".05"/></body>
+               <body name="bob" pos="0 0 1"><freejoint/><geom type="sphere" size=".02" mass="1"/></body></worldbody>
+               <equality><weld body1="box" body2="b2" anchor="-.15 0 0"/><connect body1="bob" anchor="0 0 .5" solref="0.004 1"/></equality></mujoco>"""]
+  for xml in scenes:
+    m = mc.compile_xml(xml)
+    o, e = OraclePhysics(m), EmuPhysics(m, prec)
+    v = np.random.RandomState(1).uniform(-.5, .5, m.nv)
+    o.qvel[:] = v
+    e.qvel[:] = v
+    o.forward()
+    e.forward()
+    assert o.nefc == e.nefc[0] and o.nefc >= 9
+    if prec == 64:
+      ne = o.nefc
+      np.testing.assert_allclose(e.scratch('efc_J')[:ne*m.nv], np.array(o.efc_J[:ne*m.nv]), atol=1e-13)
+    for _ in range(400):
+      o.step()
+      e.step()
+    np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol)
+    assert not o.warning.any() and not e.warning.any()

@@ -459,7 +459,7 @@ def test_fixed_tendon_transmission_steady_state():
   p.forward()
   np.testing.assert_allclose(p.actuator_length[0], 0.1 * (0.6 * p.qpos[0] - 0.8 * p.qpos[1]), rtol=1e-12)
   for bad in ('<tendon><spatial name="s" stiffness="3"><site site="a"/></spatial></tendon>',
-              '<equality><joint joint1="x"/></equality>'):
+              '<equality><distance geom1="a" geom2="b"/></equality>'):
     with pytest.raises(mc.MjcfError):
       mc.compile_xml('<mujoco><worldbody><body><joint name="x" type="slide"/><geom size=".1"/>'
                      '<site name="a"/></body></worldbody>%s</mujoco>' % bad)
@@ -696,3 +696,99 @@ def test_rangefinder_closed_forms():
   p.qpos[:3] = [1.05, 0, 1.0]
   p.forward()
   np.testing.assert_allclose(p.sensordata[0], 0.3, atol=1e-12)
+
+
+# ---- connect / weld / joint equality constraints ------------------------------------------------------------------
+_EQ_CHAIN = """<mujoco><option gravity="0 0 -9.81" timestep="0.002"/><worldbody>
+  <body name="a" pos="0 0 1"><joint name="a1" type="hinge" axis="0 1 0"/><joint name="a2" type="hinge" axis="1 0 0"/>
+    <geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/>
+    <body name="b" pos=".3 0 0"><joint name="b1" type="hinge" axis="0 0 1"/><joint name="b2" type="slide" axis="1 0 0"/>
+      <geom type="capsule" fromto="0 0 0 .25 0 0" size=".03"/></body></body>
+  <body name="c" pos=".1 .4 1" quat=".9 .1 .3 .2"><joint name="c1" type="hinge" axis="0 1 0"/><joint name="c2" type="hinge" axis="0 0 1"/>
+    <joint name="c3" type="slide" axis="0 0 1"/><geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/></body>
+</worldbody><equality>
+  <connect body1="b" body2="c" anchor=".25 0 0"/>
+  <weld body1="a" body2="c" anchor=".05 .02 0"/>
+  <weld body1="b" relpose=".1 0 1 .9 .2 0 .1" torquescale="0.5"/>
+  <joint joint1="a1" joint2="c1" polycoef="0.1 2 0.5 0 0"/>
+  <joint joint1="b2" polycoef="0.05 0 0 0 0"/>
+</equality></mujoco>"""
+
+
+def test_equality_jacobians_are_the_derivatives_of_their_residuals():
+  m = mc.compile_xml(_EQ_CHAIN)
+  assert m.neq == 5 and m.nv == 7
+  rs = np.random.RandomState(0)
+  q = rs.uniform(-.4, .4, m.nq)
+  p = OraclePhysics(m)
+  p.qpos[:] = q
+  p.forward()
+  ne = p.nefc
+  assert ne == 3 + 6 + 6 + 1 + 1
+  J = np.array(p.efc_J[:ne*m.nv]).reshape(ne, m.nv)
+  pos0 = np.array(p.efc_pos[:ne])
+  eps = 1e-6
+  for dof in range(m.nv):           # hinges and slides: qpos and qvel coordinates coincide
+    dq = np.zeros(m.nq); dq[dof] = eps
+    p.qpos[:] = q + dq
+    p.forward()
+    plus = np.array(p.efc_pos[:ne])
+    p.qpos[:] = q - dq
+    p.forward()
+    minus = np.array(p.efc_pos[:ne])
+    np.testing.assert_allclose((plus - minus) / (2*eps), J[:, dof], atol=2e-8, err_msg='dof %d' % dof)
+  # residuals vanish at the reference pose for everything defined from qpos0 (rows 0..8)
+  p.qpos[:] = m.qpos0
+  p.forward()
+  np.testing.assert_allclose(np.array(p.efc_pos[:9]), 0, atol=1e-12)
+  del pos0
+
+
+def test_connect_makes_a_pendulum_and_weld_holds_a_body():
+  # a free ball connected to the world 0.5 m above it swings like a pendulum of that length
+  xml = """<mujoco><option timestep="0.001"/><worldbody>
+    <body name="bob" pos="0 0 1"><freejoint/><geom type="sphere" size=".02" mass="1"/></body>
+  </worldbody><equality><connect body1="bob" anchor="0 0 .5" solref="0.002 1"/></equality></mujoco>"""
+  m = mc.compile_xml(xml)
+  p = OraclePhysics(m, legacy_step=False)
+  p.qvel[0] = 0.2                      # small push: amplitude ~ 0.2 / omega = 4.5 cm
+  zero_crossings, prev = [], 0.0
+  for _ in range(4000):
+    p.step()
+    x = p.qpos[0]
+    if prev < 0 <= x or prev > 0 >= x:
+      zero_crossings.append(p.time)
+    prev = x
+  period = 2 * np.mean(np.diff(zero_crossings))
+  np.testing.assert_allclose(period, 2*np.pi*np.sqrt(0.5/9.81), rtol=2e-2)
+  assert abs(np.linalg.norm(np.array(p.qpos[:3]) - [0, 0, 1.5]) - 0.5) < 2e-3      # stays on the sphere around the anchor
+  # a free box welded to the world: hangs in place, the constraint carries its weight, orientation kept
+  xml = """<mujoco><option timestep="0.002"/><worldbody>
+    <body name="box" pos=".3 .1 .7" quat=".8 .2 .4 .1"><freejoint/><geom type="box" size=".1 .05 .02" mass="2"/></body>
+  </worldbody><equality><weld body1="box" anchor=".3 .1 .7"/></equality></mujoco>"""     # anchor (world frame) at the box
+  m = mc.compile_xml(xml)
+  p = OraclePhysics(m, legacy_step=False)
+  q0 = np.array(p.qpos).copy()
+  p.qvel[3:6] = [0.5, -0.3, 0.2]       # a spin that the weld has to absorb
+  for _ in range(1500):
+    p.step()
+  assert np.abs(p.qvel).max() < 1e-4
+  np.testing.assert_allclose(p.qpos[:3], q0[:3], atol=2e-3)
+  assert abs(abs(np.dot(p.qpos[3:7], q0[3:7] / np.linalg.norm(q0[3:7]))) - 1) < 1e-5
+  np.testing.assert_allclose(p.qfrc_constraint[2], 2 * 9.81, rtol=1e-4)
+
+
+def test_joint_equality_couples_two_hinges():
+  xml = """<mujoco><option gravity="0 0 0"/><worldbody>
+    <body><joint name="j1" type="hinge" axis="0 0 1" damping=".1"/><geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/></body>
+    <body pos="0 1 0"><joint name="j2" type="hinge" axis="0 0 1" damping=".1"/><geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/></body>
+  </worldbody><equality><joint joint1="j1" joint2="j2" polycoef="0 2 0 0 0" solref="0.004 1"/></equality>
+  <actuator><motor joint="j2" gear="1"/></actuator></mujoco>"""
+  m = mc.compile_xml(xml)
+  p = OraclePhysics(m, legacy_step=False)
+  p.ctrl[0] = 0.05
+  for _ in range(500):
+    p.step()
+  assert abs(p.qpos[1]) > 0.05
+  np.testing.assert_allclose(p.qpos[0], 2 * p.qpos[1], atol=2e-3)
+  np.testing.assert_allclose(p.qvel[0], 2 * p.qvel[1], atol=2e-3)
