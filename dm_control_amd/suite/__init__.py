@@ -36,6 +36,12 @@ _DOMAINS = collections.OrderedDict(acrobot=acrobot, ball_in_cup=ball_in_cup, car
 ALL_TASKS = tuple((d, t) for d, mod in _DOMAINS.items() for t in mod.TASKS)
 BENCHMARKING = tuple((d, t) for d, mod in _DOMAINS.items() for t, (_, tag) in mod.TASKS.items()
                      if tag == 'benchmarking')
+# difficulty tags of the reference's `@SUITE.add(...)` decorators (suite/__init__.py:79-86)
+EASY = (('ball_in_cup', 'catch'), ('point_mass', 'easy'), ('reacher', 'easy'))
+HARD = tuple((d, t) for d, t in ALL_TASKS if d in ('manipulator', 'stacker'))
+EXTRA = tuple(sorted(set(ALL_TASKS) - set(BENCHMARKING)))
+NO_REWARD_VIZ = ()                       # the dog tasks in the reference; none of them is provided here
+REWARD_VIZ = tuple(sorted(ALL_TASKS))
 TASKS_BY_DOMAIN = collections.OrderedDict((d, tuple(mod.TASKS)) for d, mod in _DOMAINS.items())
 
 

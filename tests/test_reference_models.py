@@ -53,3 +53,20 @@ def test_every_suite_xml_except_mesh_and_hfield_models_compiles():
   assert set(refused) == {'dog.xml', 'quadruped.xml'}, refused         # meshes; height field (escape task only)
   assert all('mesh/hfield' in v for v in refused.values())
   assert len(ok) == 17
+
+
+def test_task_registry_and_tags_match_the_reference():
+  import re
+  from dm_control_amd import suite
+  tags = {}
+  for path in glob.glob(os.path.join(REF, 'suite/*.py')):
+    src = open(path).read()
+    for mm in re.finditer(r"@SUITE\.add\(([^)]*)\)\s*\ndef (\w+)", src):
+      tags[(os.path.basename(path)[:-3], mm.group(2))] = [t.strip(" '\"") for t in mm.group(1).split(',') if t.strip()]
+  missing = set(tags) - set(suite.ALL_TASKS)
+  assert all(d == 'dog' or (d, t) == ('quadruped', 'escape') for d, t in missing), missing      # meshes; height field
+  assert set(suite.ALL_TASKS) <= set(tags)
+  have = lambda tag: {k for k, v in tags.items() if tag in v and k in suite.ALL_TASKS}
+  assert set(suite.BENCHMARKING) == have('benchmarking')
+  assert set(suite.EASY) == have('easy') and set(suite.HARD) == have('hard')
+  assert set(suite.EXTRA) == set(suite.ALL_TASKS) - set(suite.BENCHMARKING)
