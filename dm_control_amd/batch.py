@@ -62,10 +62,11 @@ class BatchedPhysics:
 
   # -- info ---------------------------------------------------------------------
   def info(self):
-    a = np.zeros(11, dtype=np.int32)
+    a = np.zeros(16, dtype=np.int32)
     _native.check(_native.lib().dmc_batch_info(self._ptr, a.ctypes.data))
     keys = ['B', 'precision', 'lanes_per_env', 'waves_per_block', 'envs_per_block',
-            'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes', 'static_id']
+            'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes', 'static_id',
+            'jac_kmax', 'table_lds_bytes', 'envs_per_cu', 'njdense', 'njcon']
     return dict(zip(keys, (int(x) for x in a)))
 
   def _rows(self, name):

@@ -17,9 +17,9 @@
 
 namespace dmc {
 hipError_t launch_step_f32(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<float>& o,
-                           const int* g_mi, const float* g_mr, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask, int nsub);
+                           const int* g_mi, const float* g_mr, const int* g_mc, const StepIO<float>& io, int nstep, int legacy, int mode, int outmask, int nsub);
 hipError_t launch_step_f64(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<double>& o,
-                           const int* g_mi, const double* g_mr, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask, int nsub);
+                           const int* g_mi, const double* g_mr, const int* g_mc, const StepIO<double>& io, int nstep, int legacy, int mode, int outmask, int nsub);
 }  // namespace dmc
 
 using namespace dmc;
@@ -51,6 +51,7 @@ struct dmc_batch {
   StepTables tb;
   LaunchGeom geom;
   int* d_mi;
+  int* d_mc;      // cold int tables (stay in global memory)
   void* d_mr;
   StepLayout* d_layout;
   std::vector<Field> fields;
@@ -121,6 +122,7 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
 static int upload_tables(dmc_batch* b) {
   const StepLayout& L = b->tb.L;
   HIP_TRY(hipMemcpy(b->d_mi, b->tb.mi.data(), (size_t)L.n_mi * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_mc, b->tb.mc.data(), b->tb.mc.size() * sizeof(int), hipMemcpyHostToDevice));
   if (b->precision == 64) {
     HIP_TRY(hipMemcpy(b->d_mr, b->tb.mr.data(), (size_t)L.n_mr * sizeof(double), hipMemcpyHostToDevice));
   } else {
@@ -142,13 +144,14 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mr = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
   const StepLayout& L = b->tb.L;
   const StepDims& d = L.d;
   hipError_t e = hipMalloc(&b->d_mi, (size_t)L.n_mi * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&b->d_mc, b->tb.mc.size() * sizeof(int));
   if (e == hipSuccess) e = hipMalloc(&b->d_mr, (size_t)L.n_mr * b->elem);
   if (e == hipSuccess) e = hipMalloc((void**)&b->d_layout, sizeof(StepLayout));
   if (e == hipSuccess) e = hipMemcpy(b->d_layout, &L, sizeof(StepLayout), hipMemcpyHostToDevice);
@@ -187,6 +190,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   (void)hipSetDevice(b->device);
   for (Field& f : b->fields) if (f.owned) (void)hipFree(f.owned);
   if (b->d_mi) (void)hipFree(b->d_mi);
+  if (b->d_mc) (void)hipFree(b->d_mc);
   if (b->d_mr) (void)hipFree(b->d_mr);
   if (b->d_layout) (void)hipFree(b->d_layout);
   if (b->d_debug) (void)hipFree(b->d_debug);
@@ -222,12 +226,12 @@ static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, c
     StepIO<double> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (double*)sq->qvel : nullptr; io.sensor_seq = sq ? (double*)sq->sensor : nullptr;
-    e = launch_step_f64(b->geom, (hipStream_t)stream, b->d_layout, b->tb.opts, b->d_mi, (const double*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
+    e = launch_step_f64(b->geom, (hipStream_t)stream, b->d_layout, b->tb.opts, b->d_mi, (const double*)b->d_mr, b->d_mc, io, nstep, legacy, mode, b->outmask, nsub);
   } else {
     StepIO<float> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const float*)sq->ctrl : nullptr; io.qpos_seq = sq ? (float*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (float*)sq->qvel : nullptr; io.sensor_seq = sq ? (float*)sq->sensor : nullptr;
-    e = launch_step_f32(b->geom, (hipStream_t)stream, b->d_layout, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, io, nstep, legacy, mode, b->outmask, nsub);
+    e = launch_step_f32(b->geom, (hipStream_t)stream, b->d_layout, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, b->d_mc, io, nstep, legacy, mode, b->outmask, nsub);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e), -2);
   return 0;
@@ -454,6 +458,10 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[5] = b->geom.lds_bytes; info[6] = b->geom.grid; info[7] = L.d.nconmax; info[8] = L.d.njmax;
   info[9] = (int)((size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int));
   info[10] = b->geom.static_id;
+  info[11] = L.d.kmax;
+  info[12] = b->geom.lds_bytes - b->geom.envs_per_block * info[9];
+  { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 32) blocks = 32 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }
+  info[14] = L.d.njdense; info[15] = L.d.njcon;
   return 0;
 }
 

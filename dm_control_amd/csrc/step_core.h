@@ -294,60 +294,40 @@ template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 // ---------------------------------------------------------------------------
 // out-of-line LDS routines shared by several call sites
 // ---------------------------------------------------------------------------
-// In-place Cholesky of the lower triangle of A (n x n), same operation order as
-// the oracle.  On exit: strict lower part = L, diagonal = 1/L[k][k] (the strict
-// upper part is scratch).  Entry-parallel right-looking form with ONE wave fence
-// per column: in column step k every remaining lower-triangle entry (i, j), j > k,
-// is updated by one lane with  A[i][j] -= (A[i][k] inv) (A[j][k] inv)  -- column k
-// is read UNSCALED and scaled redundantly by each reader (same rounding as scaling
-// once), while the scaled L[i][k] is parked in the upper triangle (A[k][i]) so that
-// nothing a concurrent reader needs is overwritten.  tri_*: lower-triangle entries
-// sorted by column (step_tables.h), so the live entries of step k are a suffix.
+// Symmetric n x n matrices (the factor of M, H = M + J'DJ and its factor) are stored as their lower
+// triangle packed BY COLUMNS: entry (i, j), i >= j, lives at tri_c0(j, n) + i - j.  Column k is
+// contiguous, and the entries a right-looking Cholesky still has to touch at step k are a suffix.
+DMC_DEV int tri_c0(int j, int n) { return j*n - ((j*(j - 1)) >> 1); }
+DMC_DEV int tri_at(int i, int j, int n) { return tri_c0(j, n) + i - j; }
+// inverse of tri_at for a packed index t of an m x m triangle: column j and row i
+DMC_DEV void tri_unrank(int t, int m, int* i, int* j) {
+  const float b = (float)(2*m + 1);
+  int c = (int)((b - sqrtf(b*b - 8.0f*(float)t)) * 0.5f);
+  c = c < 0 ? 0 : (c > m - 1 ? m - 1 : c);
+  if (tri_c0(c, m) > t) c--;
+  else if (c + 1 < m && tri_c0(c + 1, m) <= t) c++;
+  *j = c; *i = c + (t - tri_c0(c, m));
+}
+// In-place Cholesky of a packed lower triangle, same operation order as the oracle.  On exit: strict
+// lower part = L, diagonal = 1/L[k][k].  Two wave fences per column: scale column k, then every
+// remaining entry (i, j), j > k, is updated by one lane with  A[i][j] -= L[i][k] L[j][k].
 template <typename T, int LPE>
-DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane, const DMC_LDS int* tri_i, const DMC_LDS int* tri_j,
-                            const DMC_LDS int* tri_col) {
-  const int ntri = tri_col[n];
-  // four entries per lane per trip: their index / matrix loads are issued together,
-  // so a column costs ~ntri_live/(4 LPE) LDS round trips instead of ntri_live/LPE
-  constexpr int U = 4;
+DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
+  const int ntri = (n*(n + 1)) >> 1;
   for (int k = 0; k < n; k++) {
     DMC_WSYNC();
-    T akk = A[k*n + k];
+    const int ck = tri_c0(k, n);
+    T akk = A[ck];
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
     const T inv = 1 / t_sqrt(akk);
-    const int c0 = tri_col[k];
-    if (ntri - c0 <= 2*LPE) {      // small remainder: one entry per lane per trip
-      for (int idx = c0 + lane; idx < ntri; idx += LPE) {
-        const int i = tri_i[idx], j = tri_j[idx];
-        const T lik = A[i*n + k] * inv;
-        if (j > k) A[i*n + j] -= lik * (A[j*n + k] * inv);
-        else if (i > k) A[k*n + i] = lik;
-        else A[k*n + k] = inv;
-      }
-      continue;
-    }
-    for (int base = c0 + lane; base < ntri; base += U*LPE) {
-      int ii[U], jj[U]; bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) { const int idx = base + u*LPE; ok[u] = idx < ntri; ii[u] = ok[u] ? tri_i[idx] : k; jj[u] = ok[u] ? tri_j[idx] : k; }
-      T aik[U], ajk[U], aij[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) { aik[u] = A[ii[u]*n + k]; ajk[u] = A[jj[u]*n + k]; aij[u] = A[ii[u]*n + jj[u]]; }
-#pragma unroll
-      for (int u = 0; u < U; u++) if (ok[u]) {
-        const T lik = aik[u] * inv;
-        if (jj[u] > k) A[ii[u]*n + jj[u]] = aij[u] - lik * (ajk[u] * inv);
-        else if (ii[u] > k) A[k*n + ii[u]] = lik;   // j == k: park L[i][k] in the upper triangle
-        else A[k*n + k] = inv;                      // the diagonal (all reads of it are already issued)
-      }
-    }
-  }
-  DMC_WSYNC();
-  for (int base = lane; base < ntri; base += U*LPE) {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int idx = base + u*LPE;
-      if (idx < ntri) { const int i = tri_i[idx], j = tri_j[idx]; if (i > j) A[i*n + j] = A[j*n + i]; }
+    for (int i = k + 1 + lane; i < n; i += LPE) A[ck + i - k] *= inv;
+    DMC_WSYNC();
+    if (lane == 0) A[ck] = inv;
+    const int c1 = ck + n - k, m = n - k - 1;   // trailing (n-k-1) x (n-k-1) triangle starts at c1
+    for (int t = lane; t < ntri - c1; t += LPE) {
+      int ii, jj;
+      tri_unrank(t, m, &ii, &jj);
+      A[c1 + t] -= A[ck + 1 + ii] * A[ck + 1 + jj];
     }
   }
   DMC_WSYNC();
@@ -364,7 +344,7 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   T a[N];
   const bool own = lane < N;
 #pragma unroll
-  for (int j = 0; j < N; j++) a[j] = own ? A[lane*N + j] : (T)0;
+  for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? A[tri_c0(j, N) + lane - j] : (T)0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
     T akk = wave_bcast<LPE>(a[k], k);
@@ -377,7 +357,7 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   }
   if (own) {
 #pragma unroll
-    for (int j = 0; j < N; j++) if (j <= lane) A[lane*N + j] = a[j];
+    for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
   }
   DMC_WSYNC();
 }
@@ -391,10 +371,11 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   static_assert(N >= 1 && N <= LPE, "one lane per unknown");
   const int i = lane;
   const bool own = i < N;
+  const int ci = tri_c0(own ? i : 0, N);
   T row[N], col[N];
 #pragma unroll
-  for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[i*N + k] : (T)0; col[k] = (own && k > i) ? Lm[k*N + i] : (T)0; }
-  const T dinv = own ? Lm[i*N + i] : (T)0;      // 1 / L[i][i]
+  for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
+  const T dinv = own ? Lm[ci] : (T)0;      // 1 / L[i][i]
   T sreg = own ? b[i] : (T)0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -419,16 +400,18 @@ template <typename T, int LPE>
 DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b, int n, int lane) {
   if (n <= LPE && LPE > 1) {
     const int i = lane;
+    const int ci = tri_c0(i < n ? i : 0, n);
     T sreg = i < n ? b[i] : (T)0;
     for (int k = 0; k < n; k++) {
-      const T lik = (i > k && i < n) ? Lm[i*n + k] : (T)0;
-      const T xk = wave_bcast<LPE>(sreg, k) * Lm[k*n + k];
+      const int ck = tri_c0(k, n);
+      const T lik = (i > k && i < n) ? Lm[ck + i - k] : (T)0;
+      const T xk = wave_bcast<LPE>(sreg, k) * Lm[ck];
       if (i == k) sreg = xk;
       if (i > k && i < n) sreg -= lik*xk;
     }
     for (int k = n - 1; k >= 0; k--) {
-      const T lki = i < k ? Lm[k*n + i] : (T)0;
-      const T xk = wave_bcast<LPE>(sreg, k) * Lm[k*n + k];
+      const T lki = i < k ? Lm[ci + k - i] : (T)0;
+      const T xk = wave_bcast<LPE>(sreg, k) * Lm[tri_c0(k, n)];
       if (i == k) sreg = xk;
       if (i < k) sreg -= lki*xk;
     }
@@ -439,17 +422,18 @@ DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b
   for (int i = lane; i < n; i += LPE) x[i] = b[i];
   DMC_WSYNC();
   for (int k = 0; k < n; k++) {
-    const T xk = x[k] * Lm[k*n + k];
+    const int ck = tri_c0(k, n);
+    const T xk = x[k] * Lm[ck];
     DMC_WSYNC();
     if (lane == 0) x[k] = xk;
-    for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[i*n + k]*xk;
+    for (int i = k + 1 + lane; i < n; i += LPE) x[i] -= Lm[ck + i - k]*xk;
     DMC_WSYNC();
   }
   for (int k = n - 1; k >= 0; k--) {
-    const T xk = x[k] * Lm[k*n + k];
+    const T xk = x[k] * Lm[tri_c0(k, n)];
     DMC_WSYNC();
     if (lane == 0) x[k] = xk;
-    for (int i = lane; i < k; i += LPE) x[i] -= Lm[k*n + i]*xk;
+    for (int i = lane; i < k; i += LPE) x[i] -= Lm[tri_c0(i, n) + k - i]*xk;
     DMC_WSYNC();
   }
 }
@@ -507,6 +491,7 @@ struct StepCore {
   const StepOpts<T>& o;
   const int* mi;
   const T* mr;
+  const int* gc;          // cold int tables, global memory (STEP_MODEL_COLD_TABLES)
   T* s;
   int* si;
   int lane;
@@ -515,11 +500,12 @@ struct StepCore {
   long long prof_[24]; long long prof_last_;
 #endif
 
-  DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, T* s_, int* si_, int lane_)
-      : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_), s(s_), si(si_), lane(lane_), time_(0) {}
+  DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
+      : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_), gc(gc_), s(s_), si(si_), lane(lane_), time_(0) {}
 
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
+#define GC(n) (gc + L.mc_##n)
 #define S(n) (s + L.s_##n)
 #define SI(n) (si + L.si_##n)
 #define FOR_LANES(i, n) for (int i = lane; i < (n); i += LPE)
@@ -556,7 +542,6 @@ struct StepCore {
       for (int k = 0; k < 10; k++) S(cinert)[k] = 0;
       for (int k = 0; k < 6; k++) S(cvel)[k] = 0;
     }
-    FOR_LANES(i, L.d.nv * L.d.nv) { S(qM)[i] = 0; }
     FOR_LANES(i, L.d.nsensordata) S(sensordata)[i] = 0;
     DMC_WSYNC();
   }
@@ -612,8 +597,8 @@ struct StepCore {
       const int nc = SI(imisc)[IM_NCON];
       FOR_LANES(c, L.d.nconmax) {
         bool live = c < nc;
-        io.contact_geom1[(size_t)c*B + env] = live ? MI(pair_geom1)[SI(con_pair)[c]] : -1;
-        io.contact_geom2[(size_t)c*B + env] = live ? MI(pair_geom2)[SI(con_pair)[c]] : -1;
+        io.contact_geom1[(size_t)c*B + env] = live ? con_g1(c) : -1;
+        io.contact_geom2[(size_t)c*B + env] = live ? con_g2(c) : -1;
         io.contact_dist[(size_t)c*B + env] = live ? S(con_dist)[c] : (T)0;
         for (int k = 0; k < 3; k++) io.contact_pos[(size_t)(3*c + k)*B + env] = live ? S(con_pos)[3*c + k] : (T)0;
         for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? S(con_frame)[9*c + k] : (T)0;
@@ -790,8 +775,7 @@ struct StepCore {
 #ifndef DMC_HOST_EMU
     if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { chol_factor_rows<T, LPE, LS::kNV>((DMC_LDS T*)A, lane); return; }
 #endif
-    chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane, (const DMC_LDS int*)MI(tri_i), (const DMC_LDS int*)MI(tri_j),
-                            (const DMC_LDS int*)MI(tri_col));
+    chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane);
   }
   DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
 #ifndef DMC_HOST_EMU
@@ -824,13 +808,39 @@ struct StepCore {
     }
     DMC_WSYNC();
     FOR_LANES(p, L.d.nM) {
-      const int i = MI(mpair_i)[p], j = MI(mpair_j)[p];
+      const int pk = GC(mpair)[p], i = pk & 0xffff, j = pk >> 16;
       T v = dot_n(S(cdof) + 6*j, S(mbuf) + 6*i, 6);
       if (i == j) v += MR(dof_armature)[i];
-      S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v;
+      S(qM)[p] = v;
     }
     DMC_WSYNC();
-    FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
+    factor_M(false);
+  }
+  // ---- sparse mass matrix helpers ------------------------------------------------
+  // M(i, j) for i >= j: entry k of row i is the k-th dof on the way from i to the root
+  DMC_DEV int anc_above(int i, int j) const {   // ancestors-or-self of i with index > j
+    const unsigned lo = (unsigned)MI(dof_anc_lo)[i];
+    if (L.d.nv <= 32) return j >= 31 ? 0 : __builtin_popcount(lo >> (j + 1));
+    const unsigned hi = (unsigned)MI(dof_anc_hi)[i];
+    if (j < 31) return __builtin_popcount(lo >> (j + 1)) + __builtin_popcount(hi);
+    if (j == 31) return __builtin_popcount(hi);
+    return j >= 63 ? 0 : __builtin_popcount(hi >> (j - 31));
+  }
+  DMC_DEV T M_at(int i, int j) const {
+    if (!dof_in_chain(i, j)) return 0;
+    return S(qM)[MI(dof_madr)[i] + anc_above(i, j)];
+  }
+  // qLH <- M (+ timestep * damping on the diagonal), then its Cholesky factor
+  DMC_DEV void factor_M(bool with_damping) {
+    const int nv = L.d.nv;
+    FOR_LANES(i, L.d.ntri) S(qLH)[i] = 0;
+    DMC_WSYNC();
+    FOR_LANES(p, L.d.nM) {
+      const int pk = GC(mpair)[p], i = pk & 0xffff, j = pk >> 16;
+      T v = S(qM)[p];
+      if (with_damping && i == j) v += o.timestep*MR(dof_damping)[i];
+      S(qLH)[tri_at(i, j, nv)] = v;
+    }
     DMC_WSYNC();
     chol_factor_inplace(S(qLH), nv);
   }
@@ -1332,7 +1342,14 @@ struct StepCore {
   }
   // contact-parameter tuple of a candidate pair; a model whose pairs all share one tuple (cheetah,
   // walker, ... in their specialised kernels) needs no lookup at all
-  DMC_DEV int prm_of(int pair) const { return L.d.nprm == 1 ? 0 : MI(pair_prm)[pair]; }
+  DMC_DEV int prm_of_info(int info) const { return L.d.nprm == 1 ? 0 : (int)((unsigned)info >> 8); }
+  // per-contact copies of the candidate pair's entries (the pair tables themselves stay in global memory)
+  DMC_DEV int con_g1(int c) const { return SI(con_geom)[c] & 0xffff; }
+  DMC_DEV int con_g2(int c) const { return (int)((unsigned)SI(con_geom)[c] >> 16); }
+  DMC_DEV int con_b1(int c) const { return MI(geom_bodyid)[con_g1(c)]; }
+  DMC_DEV int con_b2(int c) const { return MI(geom_bodyid)[con_g2(c)]; }
+  DMC_DEV int con_dim(int c) const { return SI(con_info)[c] & 0xff; }
+  DMC_DEV int con_prm(int c) const { return prm_of_info(SI(con_info)[c]); }
   DMC_DEV void collision() {
     int base = 0;
     const bool enabled = !(o.disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT));
@@ -1341,11 +1358,11 @@ struct StepCore {
     for (int p0 = 0; p0 < npair; p0 += LPE) {
       const int p = p0 + lane;
       Hits h = {}; T tang[3] = {0, 0, 0}; bool has_tang = false;
-      int mask = 0, g1 = 0, g2 = 0;
+      int mask = 0, pgeom = 0, pinfo = 0;
       if (p < npair) {
-        g1 = MI(pair_geom1)[p]; g2 = MI(pair_geom2)[p];
+        pgeom = GC(pair_geom)[p]; pinfo = GC(pair_info)[p];
         bool guard;
-        mask = narrow_phase(g1, g2, MR(prm_margin)[prm_of(p)], &h, tang, &has_tang, &guard);
+        mask = narrow_phase(pgeom & 0xffff, (int)((unsigned)pgeom >> 16), MR(prm_margin)[prm_of_info(pinfo)], &h, tang, &has_tang, &guard);
         if (guard) { if (mask) unresolved = 1; mask = 0; }
       }
       const int n = __builtin_popcount(mask);
@@ -1361,7 +1378,7 @@ struct StepCore {
         S(con_dist)[c] = hi.dist;
         for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = hi.pos[k];
         for (int k = 0; k < 9; k++) S(con_frame)[9*c + k] = f[k];
-        SI(con_pair)[c] = p;
+        SI(con_geom)[c] = pgeom; SI(con_info)[c] = pinfo;
         SI(con_efc)[c] = -1;
       }
       base += total;
@@ -1447,22 +1464,66 @@ struct StepCore {
     return j;
   }
   DMC_DEV int contact_rows(int dim) const { return dim == 1 ? 1 : (L.d.elliptic ? dim : 2*(dim - 1)); }
+  // ---- constraint Jacobian access (three storage classes, see step_layout.h) -------------------
+  struct RowMap { int s0, tl0, c0; };   // first simple / tendon-limit / contact row (group-uniform)
+  DMC_DEV RowMap row_map() const { RowMap rm = {SI(imisc)[IM_ROW_S0], SI(imisc)[IM_ROW_TL0], SI(imisc)[IM_ROW_C0]}; return rm; }
+  // the one nonzero of a dof-friction / joint-limit row
+  DMC_DEV int simple_dof(int tid) const { return EFC_TYPE(tid) == EFC_FRICTION ? EFC_ID(tid) : MI(jnt_dofadr)[EFC_ID(tid) >> 1]; }
+  DMC_DEV T simple_sign(int tid) const { return (EFC_TYPE(tid) == EFC_LIMIT && (EFC_ID(tid) & 1)) ? (T)-1 : (T)1; }
+  DMC_DEV const T* dense_row(int r, const RowMap& rm) const { return S(efc_Jd) + (r < rm.s0 ? r : rm.s0 + (r - rm.tl0))*L.d.nv; }
+  DMC_DEV unsigned con_mask_lo(int c) const { return (unsigned)SI(con_mlo)[c]; }
+  DMC_DEV unsigned con_mask_hi(int c) const { return L.d.nv > 32 ? (unsigned)SI(con_mhi)[c] : 0u; }
+  // slot of dof dd in the compressed rows of a contact with mask (lo, hi), or -1
+  DMC_DEV int mask_slot(unsigned lo, unsigned hi, int dd) const {
+    if (L.d.nv <= 32 || dd < 32) {
+      if (!((lo >> dd) & 1u)) return -1;
+      return __builtin_popcount(lo & ((1u << dd) - 1u));
+    }
+    const int d2 = dd - 32;
+    if (!((hi >> d2) & 1u)) return -1;
+    return __builtin_popcount(lo) + __builtin_popcount(hi & ((1u << d2) - 1u));
+  }
+  // J[r, :] . x for any row class (x: nv reals)
+  DMC_DEV T row_dot(int r, const T* x, const RowMap& rm) const {
+    if (r >= rm.c0) {
+      const int c = EFC_ID(SI(efc_tid)[r]);
+      const T* jr = S(efc_Jc) + (r - rm.c0)*L.d.kmax;
+      T acc = 0;
+      int k = 0;
+      for (unsigned m = con_mask_lo(c); m; m &= m - 1) acc += jr[k++] * x[__builtin_ctz(m)];
+      if (L.d.nv > 32) for (unsigned m = con_mask_hi(c); m; m &= m - 1) acc += jr[k++] * x[32 + __builtin_ctz(m)];
+      return acc;
+    }
+    if (r >= rm.s0 && r < rm.tl0) { const int tid = SI(efc_tid)[r]; return simple_sign(tid) * x[simple_dof(tid)]; }
+    return dot_n(dense_row(r, rm), x, L.d.nv);
+  }
+  // J[r, dd] for any row class
+  DMC_DEV T row_entry(int r, int dd, const RowMap& rm) const {
+    if (r >= rm.c0) {
+      const int c = EFC_ID(SI(efc_tid)[r]);
+      const int k = mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
+      return k < 0 ? (T)0 : S(efc_Jc)[(r - rm.c0)*L.d.kmax + k];
+    }
+    if (r >= rm.s0 && r < rm.tl0) { const int tid = SI(efc_tid)[r]; return simple_dof(tid) == dd ? simple_sign(tid) : (T)0; }
+    return dense_row(r, rm)[dd];
+  }
   DMC_DEV void make_constraint() {
     const int nv = L.d.nv, njmax = L.d.njmax;
-    int nefc = 0, overflow = 0;
+    int nefc = 0, overflow = 0, ndense = 0;
     const bool enabled = !(o.disableflags & DMC_DSBL_CONSTRAINT);
     // equality constraints first (MuJoCo order: equality, friction, limit, contact), two-sided, always
     // active; residuals and Jacobians as in the oracle's make_constraint (tendon, joint, connect, weld)
     if (L.d.neq && enabled && !(o.disableflags & DMC_DSBL_EQUALITY)) for (int k = 0; k < L.d.neq; k++) {
       const int et = MI(eq_type)[k], o1 = MI(eq_obj1)[k], o2 = MI(eq_obj2)[k];
       const int nrow = et == DMC_EQ_CONNECT ? 3 : (et == DMC_EQ_WELD ? 6 : 1);
-      if (nefc + nrow > njmax) { overflow = 1; continue; }
+      if (nefc + nrow > njmax || ndense + nrow > L.d.njdense) { overflow = 1; continue; }
       const int r0 = nefc;
-      nefc += nrow;
+      nefc += nrow; ndense += nrow;
       const T* data = MR(eq_data) + 13*k;
+      T* Jd = S(efc_Jd);
       if (lane == 0) for (int a = 0; a < nrow; a++) { S(efc_D)[r0 + a] = 0; SI(efc_tid)[r0 + a] = EFC_TID(EFC_EQUALITY, k); }
       if (et == DMC_EQ_TENDON) {
-        FOR_LANES(dd, nv) S(efc_J)[r0*nv + dd] = tendon_jac(o1, dd);
+        FOR_LANES(dd, nv) Jd[r0*nv + dd] = tendon_jac(o1, dd);
         if (lane == 0) S(efc_aref)[r0] = tendon_length(o1) - data[11] - data[0];
       } else if (et == DMC_EQ_JOINT) {
         const int q1 = MI(jnt_qposadr)[o1], d1 = MI(jnt_dofadr)[o1];
@@ -1475,7 +1536,7 @@ struct StepCore {
           for (int p = 0; p < 5; p++) { poly += data[p]*pw; if (p < 4) deriv += (p + 1)*data[p + 1]*pw; pw *= dif; }
           pos -= poly;
         } else pos -= data[0];
-        FOR_LANES(dd, nv) { T j = dd == d2 ? -deriv : (T)0; if (dd == d1) j += 1; S(efc_J)[r0*nv + dd] = j; }
+        FOR_LANES(dd, nv) { T j = dd == d2 ? -deriv : (T)0; if (dd == d1) j += 1; Jd[r0*nv + dd] = j; }
         if (lane == 0) S(efc_aref)[r0] = pos;
       } else {
         // connect: data[0:3] on body 1, data[3:6] on body 2; weld: data[3:6] on body 1, data[0:3] on body 2
@@ -1498,7 +1559,7 @@ struct StepCore {
         FOR_LANES(dd, nv) {
           T jp1[3], jp2[3];
           point_jac(o1, p1, dd, jp1); point_jac(o2, p2, dd, jp2);
-          for (int a = 0; a < 3; a++) S(efc_J)[(r0 + a)*nv + dd] = jp1[a] - jp2[a];
+          for (int a = 0; a < 3; a++) Jd[(r0 + a)*nv + dd] = jp1[a] - jp2[a];
           if (et == DMC_EQ_WELD) {
             const bool in1 = dof_in_chain(MI(body_lastdof)[o1], dd), in2 = dof_in_chain(MI(body_lastdof)[o2], dd);
             const T* cd = S(cdof) + 6*dd;
@@ -1507,25 +1568,23 @@ struct StepCore {
             T t1[4], t2[4];
             mul_quat(t1, q2inv, w);
             mul_quat(t2, t1, quat);
-            for (int a = 0; a < 3; a++) S(efc_J)[(r0 + 3 + a)*nv + dd] = data[10]*(T)0.5*t2[1 + a];
+            for (int a = 0; a < 3; a++) Jd[(r0 + 3 + a)*nv + dd] = data[10]*(T)0.5*t2[1 + a];
           }
         }
       }
     }
-    // dof friction loss: one row per dof with frictionloss > 0
+    const int row_s0 = nefc;
+    // dof friction loss: one row per dof with frictionloss > 0 (simple rows: no Jacobian storage)
     if (L.d.nfric && enabled && !(o.disableflags & DMC_DSBL_FRICTIONLOSS)) {
       const int base = nefc;
       for (int k = lane; k < L.d.nfric; k += LPE) {
         const int r = base + k;
         if (r >= njmax) { overflow = 1; continue; }
-        const int dof = MI(fric_dof)[k];
-        for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
-        S(efc_J)[r*nv + dof] = 1;
-        S(efc_aref)[r] = 0; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_FRICTION, dof);
+        S(efc_aref)[r] = 0; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_FRICTION, MI(fric_dof)[k]);
       }
       nefc = base + L.d.nfric < njmax ? base + L.d.nfric : njmax;
     }
-    // joint limits
+    // joint limits (simple rows)
     if (enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int j0 = 0; j0 < L.d.njnt; j0 += LPE) {
       const int j = j0 + lane;
       // lower side first, then upper (locals indexed statically: no scratch memory)
@@ -1546,13 +1605,12 @@ struct StepCore {
         const int r = off + i;
         if (r >= njmax) { overflow = 1; continue; }
         const bool lo = i == 0 && act_lo;
-        for (int k = 0; k < nv; k++) S(efc_J)[r*nv + k] = 0;
-        S(efc_J)[r*nv + MI(jnt_dofadr)[j]] = lo ? (T)1 : (T)-1;
-        S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, j);
+        S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, (j << 1) | (lo ? 0 : 1));
       }
       nefc += total;
     }
     if (nefc > njmax) nefc = njmax;
+    const int row_tl0 = nefc;
     // tendon length limits (after the joint limits, as in MuJoCo); every lane evaluates the few
     // limited tendons' lengths itself, so the row count stays group-uniform without a fence
     if (L.d.nlimten && enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int kt = 0; kt < L.d.nlimten; kt++) {
@@ -1561,23 +1619,23 @@ struct StepCore {
       for (int sd = -1; sd <= 1; sd += 2) {
         const T dist = sd * (MR(tendon_range)[2*t + (sd + 1)/2] - value);
         if (!(dist < margin)) continue;
-        if (nefc >= njmax) { overflow = 1; continue; }
-        const int r = nefc++;
-        FOR_LANES(dd, nv) S(efc_J)[r*nv + dd] = -(T)sd * tendon_jac(t, dd);
+        if (nefc >= njmax || ndense >= L.d.njdense) { overflow = 1; continue; }
+        const int r = nefc++, jr = ndense++;
+        FOR_LANES(dd, nv) S(efc_Jd)[jr*nv + dd] = -(T)sd * tendon_jac(t, dd);
         if (lane == 0) { S(efc_aref)[r] = dist; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_TENDON_LIMIT, t); }
       }
     }
     const int nefc_lim = nefc;
-    // contact rows: headers
+    // contact rows: headers, and the dof mask of each contact's Jacobian rows (the dofs on exactly one of
+    // the two bodies' chains: on a shared ancestor dof the two bodies move together and the entry is 0)
     const int ncon = (enabled && !(o.disableflags & DMC_DSBL_CONTACT)) ? SI(imisc)[IM_NCON] : 0;
     for (int c0 = 0; c0 < ncon; c0 += LPE) {
       const int c = c0 + lane;
       int nrow = 0, dim = 0;
       T incl = 0;
       if (c < ncon) {
-        const int p = SI(con_pair)[c];
-        dim = MI(pair_dim)[p];
-        incl = MR(prm_margin)[prm_of(p)] - MR(prm_gap)[prm_of(p)];
+        dim = con_dim(c);
+        incl = MR(prm_margin)[con_prm(c)] - MR(prm_gap)[con_prm(c)];
         nrow = contact_rows(dim);
         if (S(con_dist)[c] >= incl) nrow = 0;   // in the gap: excluded
       }
@@ -1585,9 +1643,12 @@ struct StepCore {
       const int off = nefc + group_scan<LPE>(nrow, lane, &total);
       if (c < ncon) {
         if (nrow == 0) SI(con_efc)[c] = -1;
-        else if (off + nrow > njmax) { SI(con_efc)[c] = -1; overflow = 1; }
+        else if (off + nrow > njmax || off - nefc_lim + nrow > L.d.njcon) { SI(con_efc)[c] = -1; overflow = 1; }
         else {
           SI(con_efc)[c] = off;
+          const int l1 = MI(body_lastdof)[con_b1(c)], l2 = MI(body_lastdof)[con_b2(c)];
+          SI(con_mlo)[c] = (l1 >= 0 ? MI(dof_anc_lo)[l1] : 0) ^ (l2 >= 0 ? MI(dof_anc_lo)[l2] : 0);
+          if (nv > 32) SI(con_mhi)[c] = (l1 >= 0 ? MI(dof_anc_hi)[l1] : 0) ^ (l2 >= 0 ? MI(dof_anc_hi)[l2] : 0);
           // pyramidal edges all carry (dist, margin); elliptic friction rows carry (0, 0)
           const bool ell = L.d.elliptic && dim > 1;
           for (int r = off; r < off + nrow; r++) {
@@ -1606,25 +1667,27 @@ struct StepCore {
       // the limit rows if no contact fit).
       int last = nefc_lim;
       for (int c = lane; c < ncon; c += LPE) if (SI(con_efc)[c] >= 0) {
-        const int e = SI(con_efc)[c] + contact_rows(MI(pair_dim)[SI(con_pair)[c]]);
+        const int e = SI(con_efc)[c] + contact_rows(con_dim(c));
         last = e > last ? e : last;
       }
       nefc = group_max<LPE>(last);
       if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++;
     }
-    if (lane == 0) SI(imisc)[IM_NEFC] = nefc;
+    if (lane == 0) { SI(imisc)[IM_NEFC] = nefc; SI(imisc)[IM_ROW_S0] = row_s0; SI(imisc)[IM_ROW_TL0] = row_tl0; SI(imisc)[IM_ROW_C0] = nefc_lim; }
     DMC_WSYNC();
-    // contact Jacobian columns: item = (contact, dof)
+    const RowMap rm = {row_s0, row_tl0, nefc_lim};
+    // contact Jacobian entries: item = (contact, dof); dofs outside the contact's mask are skipped
     for (int idx = lane; idx < ncon*nv; idx += LPE) {
       const int c = idx / nv, dd = idx - c*nv;
       const int r0 = SI(con_efc)[c];
       if (r0 < 0) continue;
-      const int cp = SI(con_pair)[c];
-      const int dim = MI(pair_dim)[cp];
-      const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+      const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
+      if (slot < 0) continue;
+      const int dim = con_dim(c);
+      const int b1 = con_b1(c), b2 = con_b2(c);
       const bool in1 = dof_in_chain(MI(body_lastdof)[b1], dd), in2 = dof_in_chain(MI(body_lastdof)[b2], dd);
       T jac[6] = {0, 0, 0, 0, 0, 0};
-      if (in1 || in2) {
+      {
         const T* cd = S(cdof) + 6*dd; const T* pos = S(con_pos) + 3*c;
         T jp1[3] = {0, 0, 0}, jr1[3] = {0, 0, 0}, jp2[3] = {0, 0, 0}, jr2[3] = {0, 0, 0}, off[3], tmp[3], dp[3], dr[3];
         if (in1) {
@@ -1643,12 +1706,14 @@ struct StepCore {
         const T* fr = S(con_frame) + 9*c;
         for (int a = 0; a < 3; a++) { jac[a] = dot3(fr + 3*a, dp); jac[3 + a] = dot3(fr + 3*a, dr); }
       }
-      if (dim == 1) S(efc_J)[r0*nv + dd] = jac[0];
-      else if (L.d.elliptic) for (int k = 0; k < dim; k++) S(efc_J)[(r0 + k)*nv + dd] = jac[k];
+      T* Jc = S(efc_Jc) + (r0 - nefc_lim)*L.d.kmax + slot;
+      const int K = L.d.kmax;
+      if (dim == 1) Jc[0] = jac[0];
+      else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jc[k*K] = jac[k];
       else for (int k = 1; k < dim; k++) {
-        const T f = MR(prm_friction)[3*prm_of(cp) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
-        S(efc_J)[(r0 + 2*(k - 1))*nv + dd] = jac[0] + f*jac[k];
-        S(efc_J)[(r0 + 2*(k - 1) + 1)*nv + dd] = jac[0] + (-f)*jac[k];
+        const T f = MR(prm_friction)[3*con_prm(c) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+        Jc[2*(k - 1)*K] = jac[0] + f*jac[k];
+        Jc[(2*(k - 1) + 1)*K] = jac[0] + (-f)*jac[k];
       }
     }
     DMC_WSYNC();
@@ -1674,32 +1739,32 @@ struct StepCore {
         solref = MR(dof_solref) + 2*id; solimp = MR(dof_solimp) + 5*id;
         dA = MR(dof_invweight0)[id];
       } else if (type == EFC_LIMIT) {
-        solref = MR(jnt_solref) + 2*id; solimp = MR(jnt_solimp) + 5*id;
-        dA = MR(dof_invweight0)[MI(jnt_dofadr)[id]];
+        const int jn = id >> 1;
+        solref = MR(jnt_solref) + 2*jn; solimp = MR(jnt_solimp) + 5*jn;
+        dA = MR(dof_invweight0)[MI(jnt_dofadr)[jn]];
       } else if (type == EFC_TENDON_LIMIT) {
         solref = MR(tendon_solref_lim) + 2*id; solimp = MR(tendon_solimp_lim) + 5*id;
         dA = MR(tendon_invweight0)[id];
       } else {
-        const int cp = SI(con_pair)[id];
-        const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+        const int b1 = con_b1(id), b2 = con_b2(id), prm = con_prm(id);
         const T tran = MR(body_invweight0)[2*b1] + MR(body_invweight0)[2*b2];
         const T rot = MR(body_invweight0)[2*b1 + 1] + MR(body_invweight0)[2*b2 + 1];
-        solref = MR(prm_solref) + 2*prm_of(cp); solimp = MR(prm_solimp) + 5*prm_of(cp);
+        solref = MR(prm_solref) + 2*prm; solimp = MR(prm_solimp) + 5*prm;
         if (type == EFC_FRICTIONLESS) dA = tran;
         else if (type == EFC_ELLIPTIC) {
           ell_row = i - SI(con_efc)[id];   // 0 normal, 1..2 slide, 3 torsion, 4..5 roll
           dA = ell_row < 3 ? tran : rot;
           if (ell_row > 0) {
-            mu = MR(prm_friction)[3*prm_of(cp)]; dA0 = tran;
-            ell_fj = MR(prm_friction)[3*prm_of(cp) + (ell_row < 3 ? 0 : (ell_row == 3 ? 1 : 2))];
-            ell_imp0 = get_impedance(solimp, S(con_dist)[id], MR(prm_margin)[prm_of(cp)] - MR(prm_gap)[prm_of(cp)]);
+            mu = MR(prm_friction)[3*prm]; dA0 = tran;
+            ell_fj = MR(prm_friction)[3*prm + (ell_row < 3 ? 0 : (ell_row == 3 ? 1 : 2))];
+            ell_imp0 = get_impedance(solimp, S(con_dist)[id], MR(prm_margin)[prm] - MR(prm_gap)[prm]);
           }
         } else {
           const int j = i - SI(con_efc)[id];
           const int k = j/2;   // friction index 0,1: slide; 2: torsion; 3,4: roll
-          const T fri = MR(prm_friction)[3*prm_of(cp) + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
+          const T fri = MR(prm_friction)[3*prm + (k < 2 ? 0 : (k == 2 ? 1 : 2))];
           dA = tran + fri*fri*(j < 4 ? tran : rot);
-          mu = MR(prm_friction)[3*prm_of(cp)];
+          mu = MR(prm_friction)[3*prm];
           dA0 = tran + mu*mu*tran;
         }
       }
@@ -1721,7 +1786,7 @@ struct StepCore {
       if (ref0 > 0) { K = 1 / t_max((T)DMC_MINVAL, dmax*dmax*ref0*ref0*ref1*ref1); Bd = 2 / t_max((T)DMC_MINVAL, dmax*ref0); }
       else { K = -ref0 / t_max((T)DMC_MINVAL, dmax*dmax); Bd = -ref1 / t_max((T)DMC_MINVAL, dmax); }
       S(efc_D)[i] = 1 / R;
-      const T vel = dot_n(S(efc_J) + i*nv, S(qvel), nv);
+      const T vel = row_dot(i, S(qvel), rm);
       S(efc_aref)[i] = -Bd*vel - K*imp*(pos - margin);
     }
     DMC_WSYNC();
@@ -1917,12 +1982,12 @@ struct StepCore {
     for (int k = 0; k < 6; k++) f6[k] = 0;
     const int r0 = SI(con_efc)[c];
     if (r0 < 0) return;
-    const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
+    const int dim = con_dim(c);
     const T* f = S(efc_force) + r0;
     if (dim == 1) { f6[0] = f[0]; return; }
     if (L.d.elliptic) { for (int k = 0; k < dim; k++) f6[k] = f[k]; return; }
     for (int k = 0; k < 2*(dim - 1); k++) f6[0] += f[k];
-    for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(prm_friction)[3*prm_of(cp) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+    for (int k = 1; k < dim; k++) f6[k] = (f[2*(k - 1)] - f[2*(k - 1) + 1]) * MR(prm_friction)[3*con_prm(c) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
   }
   DMC_DEV void rne_post_constraint() {
     const int nb = L.d.nbody, ncon = SI(imisc)[IM_NCON];
@@ -1931,8 +1996,7 @@ struct StepCore {
       T acc[6] = {0, 0, 0, 0, 0, 0};
       if (b > 0) for (int c = 0; c < ncon; c++) {
         if (SI(con_efc)[c] < 0) continue;
-        const int cp = SI(con_pair)[c];
-        const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+        const int b1 = con_b1(c), b2 = con_b2(c);
         if (b1 != b && b2 != b) continue;
         T lf[6], gf[3], gt[3], dif[3], t[3];
         contact_force_local(c, lf);
@@ -2114,8 +2178,7 @@ struct StepCore {
         T tot = 0;
         for (int c = 0; c < ncon; c++) {
           if (SI(con_efc)[c] < 0) continue;
-          const int cp = SI(con_pair)[c];
-          const int b1 = MI(geom_bodyid)[MI(pair_geom1)[cp]], b2 = MI(geom_bodyid)[MI(pair_geom2)[cp]];
+          const int b1 = con_b1(c), b2 = con_b2(c);
           if (b1 != body && b2 != body) continue;
           T lf[6]; contact_force_local(c, lf);
           if (lf[0] <= 0) continue;
@@ -2355,8 +2418,8 @@ struct StepCore {
       }
       const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
       if (i != r0) continue;
-      const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
-      const T* fr = MR(prm_friction) + 3*prm_of(cp);
+      const int dim = con_dim(c);
+      const T* fr = MR(prm_friction) + 3*con_prm(c);
       const T D0 = S(efc_D)[r0];
       const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);   // regularised cone: mu sqrt(R1/R0)
       T U[6], fj[6], Tn = 0;
@@ -2402,27 +2465,51 @@ struct StepCore {
     DMC_WSYNC();
     return cost;
   }
-  // H(i, j) = M(i, j) + sum over active rows / cone blocks (elliptic models)
-  DMC_DEV T hess_entry_ell(int i, int j, int nefc) {
-    const int nv = L.d.nv;
-    T h = S(qM)[i*nv + j];
-    for (int r = 0; r < nefc; r++) {
-      const int st = SI(efc_active)[r];
-      if (st == EFC_ST_QUADRATIC) {
-        const T ji = S(efc_J)[r*nv + i];
-        if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
-      } else if (st == EFC_ST_CONE) {
-        const int dim = MI(pair_dim)[SI(con_pair)[EFC_ID(SI(efc_tid)[r])]];
-        T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
-        for (int a = 0; a < dim; a++) {
-          const T ji = S(efc_J)[(r + a)*nv + i], jj = S(efc_J)[(r + a)*nv + j];
-          const T ca = S(efc_ca)[r + a];
-          Pi += ca*ji; Pj += ca*jj;
-          if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
+  // H(i, j) = M(i, j) + sum over the active rows / cone blocks, rows visited in order: dense equality
+  // rows, the one-nonzero friction / limit rows (diagonal only), dense tendon-limit rows, then the
+  // contacts through their dof masks.  efc_active holds the state constraint_update recorded.
+  DMC_DEV T hess_entry(int i, int j, int nefc, const RowMap& rm) {
+    const int nv = L.d.nv, K = L.d.kmax;
+    T h = M_at(i, j);
+    if (L.d.njdense) for (int r = 0; r < rm.s0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
+      const T* jr = S(efc_Jd) + r*nv;
+      const T ji = jr[i];
+      if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];
+    }
+    if (i == j) for (int r = rm.s0; r < rm.tl0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
+      if (simple_dof(SI(efc_tid)[r]) == i) h += S(efc_D)[r];
+    }
+    if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
+      const T* jr = S(efc_Jd) + (rm.s0 + r - rm.tl0)*nv;
+      const T ji = jr[i];
+      if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];
+    }
+    for (int r = rm.c0; r < nefc; ) {
+      const int c = EFC_ID(SI(efc_tid)[r]);
+      const int nrow = contact_rows(con_dim(c));
+      const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
+      const int si_ = mask_slot(lo, hi, i), sj = si_ < 0 ? -1 : mask_slot(lo, hi, j);
+      if (sj >= 0) {
+        const T* ji_ = S(efc_Jc) + (r - rm.c0)*K + si_;
+        const T* jj_ = S(efc_Jc) + (r - rm.c0)*K + sj;
+        const int st = SI(efc_active)[r];
+        if (L.d.elliptic && st == EFC_ST_CONE) {
+          T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+          for (int a = 0; a < nrow; a++) {
+            const T ji = ji_[a*K], jj = jj_[a*K];
+            const T ca = S(efc_ca)[r + a];
+            Pi += ca*ji; Pj += ca*jj;
+            if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
+          }
+          h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
+        } else {
+          for (int a = 0; a < nrow; a++) if (SI(efc_active)[r + a] == EFC_ST_QUADRATIC) {
+            const T ji = ji_[a*K];
+            if (ji != 0) h += (S(efc_D)[r + a]*ji) * jj_[a*K];
+          }
         }
-        h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
-        r += dim - 1;
       }
+      r += nrow;
     }
     return h;
   }
@@ -2453,8 +2540,8 @@ struct StepCore {
       }
       const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
       if (i != r0) continue;
-      const int cp = SI(con_pair)[c], dim = MI(pair_dim)[cp];
-      const T* fr = MR(prm_friction) + 3*prm_of(cp);
+      const int dim = con_dim(c);
+      const T* fr = MR(prm_friction) + 3*con_prm(c);
       const T D0 = S(efc_D)[r0];
       const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);
       const T U0 = S(efc_jar)[r0]*mu, V0 = S(efc_jv)[r0]*mu;
@@ -2511,19 +2598,46 @@ struct StepCore {
     FOR_LANES(i, L.d.nv) g += (S(sv_Ma)[i] - S(qfrc_smooth)[i]) * (S(qacc)[i] - S(qacc_smooth)[i]);
     return (T)0.5 * group_sum<LPE>(g);
   }
+  // res = M v on the sparse M: row i holds M(i, ancestors of i); the transposed part comes from the
+  // dofs below i (dof_subend: end of the subtree's dof range)
   DMC_DEV void mul_M(T* res, const T* v) {
     const int nv = L.d.nv;
-    FOR_LANES(i, nv) res[i] = dot_n(S(qM) + i*nv, v, nv);
+    FOR_LANES(i, nv) {
+      const T* row = S(qM) + MI(dof_madr)[i];
+      T acc = 0;
+      int k = 0;
+      for (int j = i; j >= 0; j = MI(dof_parentid)[j]) acc += row[k++] * v[j];
+      const int end = MI(dof_subend)[i];
+      for (int dd = i + 1; dd < end; dd++) if (dof_in_chain(dd, i)) acc += S(qM)[MI(dof_madr)[dd] + anc_above(dd, i)] * v[dd];
+      res[i] = acc;
+    }
   }
   DMC_DEV void jar_from(const T* qacc, int nefc) {
-    const int nv = L.d.nv;
-    for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] = dot_n(S(efc_J) + i*nv, qacc, nv) - S(efc_aref)[i];
+    const RowMap rm = row_map();
+    for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] = row_dot(i, qacc, rm) - S(efc_aref)[i];
   }
+  // qfrc_constraint = J' efc_force, rows visited in order
   DMC_DEV void constraint_force_to_joint(int nefc) {
-    const int nv = L.d.nv;
+    const int nv = L.d.nv, K = L.d.kmax;
+    const RowMap rm = row_map();
     FOR_LANES(i, nv) {
       T f = 0;
-      for (int r = 0; r < nefc; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_J)[r*nv + i]*fr; }
+      if (L.d.njdense) for (int r = 0; r < rm.s0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
+      for (int r = rm.s0; r < rm.tl0; r++) {
+        const T fr = S(efc_force)[r];
+        if (fr != 0) { const int tid = SI(efc_tid)[r]; if (simple_dof(tid) == i) f += simple_sign(tid)*fr; }
+      }
+      if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[(rm.s0 + r - rm.tl0)*nv + i]*fr; }
+      for (int r = rm.c0; r < nefc; ) {
+        const int c = EFC_ID(SI(efc_tid)[r]);
+        const int nrow = contact_rows(con_dim(c));
+        const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), i);
+        if (slot >= 0) {
+          const T* jc = S(efc_Jc) + (r - rm.c0)*K + slot;
+          for (int a = 0; a < nrow; a++) { const T fr = S(efc_force)[r + a]; if (fr != 0) f += jc[a*K]*fr; }
+        }
+        r += nrow;
+      }
       S(qfrc_constraint)[i] = f;
     }
   }
@@ -2535,29 +2649,11 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
-    if (general_rows()) {
-      for (int idx = lane; idx < L.d.ntri; idx += LPE) {
-        const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
-        S(qLH)[i*nv + j] = hess_entry_ell(i, j, nefc);
-      }
-    } else
+    const RowMap rm = row_map();
     for (int idx = lane; idx < L.d.ntri; idx += LPE) {
-      const int i = MI(tri_i)[idx], j = MI(tri_j)[idx];
-      T h = S(qM)[i*nv + j];
-      int r = 0;
-      for (; r + 1 < nefc; r += 2) {      // two rows per trip (loads overlap); same accumulation order
-        const T jar0 = S(efc_jar)[r], jar1 = S(efc_jar)[r + 1];
-        const T ji0 = S(efc_J)[r*nv + i], ji1 = S(efc_J)[(r + 1)*nv + i];
-        const T jj0 = S(efc_J)[r*nv + j], jj1 = S(efc_J)[(r + 1)*nv + j];
-        const T d0 = S(efc_D)[r], d1 = S(efc_D)[r + 1];
-        if (jar0 < 0 && ji0 != 0) h += (d0*ji0) * jj0;
-        if (jar1 < 0 && ji1 != 0) h += (d1*ji1) * jj1;
-      }
-      if (r < nefc && S(efc_jar)[r] < 0) {
-        const T ji = S(efc_J)[r*nv + i];
-        if (ji != 0) h += (S(efc_D)[r]*ji) * S(efc_J)[r*nv + j];
-      }
-      S(qLH)[i*nv + j] = h;
+      int i, j;
+      tri_unrank(idx, nv, &i, &j);
+      S(qLH)[idx] = hess_entry(i, j, nefc, rm);
     }
     DMC_WSYNC();
     chol_factor_inplace(S(qLH), nv);
@@ -2583,7 +2679,7 @@ struct StepCore {
   DMC_DEV T primal_search(int nefc, T gauss, T scale) {
     const int nv = L.d.nv;
     mul_M(S(sv_Mv), S(sv_search));
-    for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = dot_n(S(efc_J) + i*nv, S(sv_search), nv);
+    { const RowMap rm = row_map(); for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = row_dot(i, S(sv_search), rm); }
     DMC_WSYNC();
     T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     FOR_LANES(i, nv) {
@@ -2729,8 +2825,7 @@ struct StepCore {
       }
       fnew[0] = f0; fnew[N > 1 ? 1 : 0] = f1;
     } else {
-      const int cp = SI(con_pair)[id];
-      const T* fr3 = MR(prm_friction) + 3*prm_of(cp);
+      const T* fr3 = MR(prm_friction) + 3*con_prm(id);
       const T fri5[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
       T fri[N], bc[N];
 #pragma unroll
@@ -2792,18 +2887,18 @@ struct StepCore {
     if (over) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++; return; }   // more friction rows than the cap: step without noslip
     if (!nf) return;
     // factor of M (qLH held the factor of H)
-    FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
     DMC_WSYNC();
-    chol_factor_inplace(S(qLH), nv);
+    factor_M(false);
+    const RowMap rm = row_map();
     for (int b = 0; b < nf; b++) {
       const int rb = SI(ns_row)[b];
-      FOR_LANES(i, nv) S(sv_grad)[i] = S(efc_J)[rb*nv + i];
+      FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(rb, i, rm);
       DMC_WSYNC();
       chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
-      for (int a = b + lane; a < nf; a += LPE) S(ns_A)[ns_idx(a, b)] = dot_n(S(efc_J) + SI(ns_row)[a]*nv, S(sv_Mgrad), nv);
+      for (int a = b + lane; a < nf; a += LPE) S(ns_A)[ns_idx(a, b)] = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm);
       DMC_WSYNC();
     }
-    for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = dot_n(S(efc_J) + ra*nv, S(qacc), nv) - S(efc_aref)[ra]; }
+    for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = row_dot(ra, S(qacc), rm) - S(efc_aref)[ra]; }
     DMC_WSYNC();
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
     int iter = 0;
@@ -2817,7 +2912,7 @@ struct StepCore {
         const int i = SI(ns_row)[a], tid = SI(efc_tid)[i], t = EFC_TYPE(tid), id = EFC_ID(tid);
         int n = 1;
         if (t == EFC_PYRAMIDAL) n = 2;
-        else if (t == EFC_ELLIPTIC) n = MI(pair_dim)[SI(con_pair)[id]] - 1;
+        else if (t == EFC_ELLIPTIC) n = con_dim(id) - 1;
         T change;
         if (n == 1) change = noslip_block<1>(a, nf, t, id);
         else if (n == 2) change = noslip_block<2>(a, nf, t, id);
@@ -2925,12 +3020,9 @@ struct StepCore {
       }
     }
     if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {
-      FOR_LANES(i, nv*nv) S(qLH)[i] = S(qM)[i];
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
       DMC_WSYNC();
-      FOR_LANES(i, nv) S(qLH)[i*nv + i] += dt*MR(dof_damping)[i];
-      DMC_WSYNC();
-      chol_factor_inplace(S(qLH), nv);
+      factor_M(true);
       chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
       qacc = S(sv_Mgrad);
     }
@@ -3063,15 +3155,15 @@ struct StepCore {
   // longer forces spills in the others, and there is one copy of the code.
 #if !defined(DMC_HOST_EMU) && !defined(DMC_PROFILE) && !defined(DMC_INLINE_STAGES)
   DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor) {
-    StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+    StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
                                  (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0), outmask);
   }
   DMC_DEV void call_acc(bool disable_actuation, bool skipsensor) {
-    StageFns<T, LPE, LS>::acc(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+    StageFns<T, LPE, LS>::acc(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
                               (DMC_LDS int*)si, lane, (disable_actuation ? 1 : 0) | (skipsensor ? 2 : 0));
   }
   DMC_DEV void call_euler() {
-    StageFns<T, LPE, LS>::euler(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, (DMC_LDS T*)s,
+    StageFns<T, LPE, LS>::euler(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
                                 (DMC_LDS int*)si, lane);
     time_ += o.timestep_d;
   }
@@ -3144,6 +3236,7 @@ struct StepCore {
   }
 #undef MI
 #undef MR
+#undef GC
 #undef S
 #undef SI
 #undef FOR_LANES
@@ -3154,19 +3247,19 @@ struct StepCore {
 template <typename T, int LPE, typename LS>
 struct StageFns {
   typedef StepCore<T, LPE, LS> Core;
-  static DMC_FN void posvel(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+  static DMC_FN void posvel(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                             DMC_LDS int* si, int lane, int flags, int outmask) {
-    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
     c.stage_posvel(flags & 1, outmask, flags & 2);
   }
-  static DMC_FN void acc(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+  static DMC_FN void acc(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                          DMC_LDS int* si, int lane, int flags) {
-    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
     c.stage_acc(flags & 1, flags & 2);
   }
-  static DMC_FN void euler(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, DMC_LDS T* s,
+  static DMC_FN void euler(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                            DMC_LDS int* si, int lane) {
-    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, (T*)s, (int*)si, lane);
+    Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
     c.euler_state();
   }
 };

@@ -41,7 +41,7 @@ template <typename T> constexpr int opts_lds_bytes() { return (int)((sizeof(Step
 
 template <typename T, int LPE, typename LS>
 __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg, const int* __restrict__ g_mi,
-                                                 const T* __restrict__ g_mr, const StepIO<T>& io, int nstep, int legacy,
+                                                 const T* __restrict__ g_mr, const int* __restrict__ g_mc, const StepIO<T>& io, int nstep, int legacy,
                                                  int mode, int outmask, int nsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepLayout& L = ls.get();
@@ -68,18 +68,18 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
   T* s = reinterpret_cast<T*>(base);
   int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
-  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, s, si, lane);
+  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, g_mc, s, si, lane);
   core.run(io, env, nstep, legacy, mode, outmask, nsub);
 }
 
 template <typename T, int LPE>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel(const StepLayout* __restrict__ Lp, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
-            StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
+            const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   // generic kernel: the layout lives in device memory (uniform scalar loads); taking
   // the address of a by-value kernel argument would copy it to scratch
   DynLayoutSrc ls; ls.p = Lp;
-  step_kernel_body<T, LPE, DynLayoutSrc>(ls, o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
+  step_kernel_body<T, LPE, DynLayoutSrc>(ls, o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
 }
 
 #if DMC_NSTATIC > 0
@@ -96,21 +96,21 @@ DMC_STATIC_IDS(DMC_DEF_STATIC)
 template <typename T, int LPE, int SID>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
-                   StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
-  step_kernel_body<T, LPE, StaticLayout<SID> >(StaticLayout<SID>(), o, g_mi, g_mr, io, nstep, legacy, mode, outmask, nsub);
+                   const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
+  step_kernel_body<T, LPE, StaticLayout<SID> >(StaticLayout<SID>(), o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
 }
 #endif
 
 template <typename T>
 inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<T>& o,
-                                const int* g_mi, const T* g_mr, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
+                                const int* g_mi, const T* g_mr, const int* g_mc, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
   const dim3 grid(g.grid), block(g.waves * 64);
 #define DMC_LAUNCH(LPE)                                                                                         \
   {                                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, LPE>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, d_layout, o, g_mi, g_mr, io, nstep,    \
+    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, d_layout, o, g_mi, g_mr, g_mc, io, nstep,    \
                        legacy, mode, outmask, nsub);                                                                  \
   }
 #define DMC_LAUNCH_STATIC(LPE, SID)                                                                             \
@@ -118,7 +118,7 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_static<T, LPE, SID>),         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((step_kernel_static<T, LPE, SID>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, io,  \
+    hipLaunchKernelGGL((step_kernel_static<T, LPE, SID>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, g_mc, io,  \
                        nstep, legacy, mode, outmask, nsub);                                                           \
     return hipGetLastError();                                                                                   \
   }

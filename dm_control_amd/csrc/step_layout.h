@@ -36,8 +36,20 @@ struct StepDims {
   int nbox;      // candidate pairs sphere-box / capsule-box / box-box
   int nrf;       // rangefinder sensors (ray casts against every geom)
   int nell;      // candidate pairs involving an ellipsoid (iterative support-function narrow phase)
+  int kmax;      // max over the candidate pairs of the dofs a contact Jacobian row can touch (chain symmetric difference)
+  int njdense;   // cap on the constraint rows stored as dense Jacobian rows (equalities, tendon limits)
+  int njcon;     // cap on the contact rows (stored compressed: kmax entries per row)
 };
 
+// Constraint Jacobian storage.  Rows come in MuJoCo's order (equality, dof friction, joint limit,
+// tendon limit, contact) and in three classes:
+//   dense      equality and tendon-limit rows: nv entries each, in efc_Jd;
+//   simple     dof-friction and joint-limit rows: ONE nonzero (+-1 at a dof) -- never stored;
+//   contact    a contact's rows touch only the dofs in the symmetric difference of its two bodies'
+//              chains: per contact a 64-bit dof mask (con_mlo / con_mhi), per row kmax entries in efc_Jc
+//              (entry k belongs to the k-th set bit of the mask).
+// imisc[IM_ROW_S0 / TL0 / C0] hold the first simple, first tendon-limit and first contact row.
+//
 // ---- model tables (ints) -----------------------------------------------------
 #define STEP_MODEL_INT_TABLES(X)                                               \
   X(body_parentid, d.nbody) X(body_rootid, d.nbody) X(body_jntadr, d.nbody)    \
@@ -51,13 +63,10 @@ struct StepDims {
   X(jnt_bodyid, d.njnt) X(jnt_limited, d.njnt)                                 \
   X(dof_bodyid, d.nv) X(dof_jntid, d.nv) X(dof_parentid, d.nv)                 \
   X(dof_anc_lo, d.nv) X(dof_anc_hi, d.nv)  /* bitmask of ancestor dofs (incl. self) */ \
-  X(mpair_i, d.nM) X(mpair_j, d.nM)                                            \
-  X(tri_i, d.ntri) X(tri_j, d.ntri)   /* lower-triangle entries sorted by (column, row) */ \
-  X(tri_col, d.nv + 1)                /* first entry of each column in tri_i/tri_j */ \
+  X(dof_madr, d.nv + 1)        /* first entry of row i of the sparse M (entries: i, parent(i), ...) */ \
+  X(dof_subend, d.nv)          /* 1 + last dof of the subtree below dof i */   \
   X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
   X(geom_invisible, d.nrf ? d.ngeom : 0)  /* rays skip geoms with alpha 0 */   \
-  X(pair_geom1, d.npair) X(pair_geom2, d.npair) X(pair_dim, d.npair)           \
-  X(pair_prm, d.npair)         /* contact-parameter tuple of each pair */      \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \
   X(act_dof, d.nu) X(act_qpos, d.nu) X(act_flags, d.nu)                        \
   X(act_adr, d.na ? d.nu : 0)  /* activation index of a stateful actuator, -1 otherwise */ \
@@ -69,6 +78,13 @@ struct StepDims {
   X(limten, d.nlimten)         /* the limited tendons */                       \
   X(eq_type, d.neq) X(eq_obj1, d.neq) X(eq_obj2, d.neq)   /* mjtEq, tendon / joint / body ids (-1: none) */ \
   X(eq_rowadr, d.neq)          /* first constraint row of each equality (equality rows come first) */
+
+// ---- cold model tables (ints): stay in global memory (L2-resident), read coalesced ----
+// once per step: the candidate pair list and the (i, j) list of the sparse mass matrix
+#define STEP_MODEL_COLD_TABLES(X)                                              \
+  X(mpair, d.nM)               /* i | j << 16 : entry p of the sparse M is M(i, j), j an ancestor dof of i */ \
+  X(pair_geom, d.npair)        /* geom1 | geom2 << 16 */                       \
+  X(pair_info, d.npair)        /* condim | contact-parameter tuple << 8 */
 
 // ---- model tables (reals) ----------------------------------------------------
 #define STEP_MODEL_REAL_TABLES(X)                                              \
@@ -110,13 +126,14 @@ struct StepDims {
   X(subtree_com, 3 * d.nbody)                                                  \
   X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv)              \
   X(cvel, 6 * d.nbody)                                                         \
-  X(qM, d.nv * d.nv) X(qLH, d.nv * d.nv)  /* Cholesky of M, later of H / M+hB */ \
+  X(qM, d.nM)           /* sparse: row i holds M(i, i), M(i, parent(i)), ... (dof_madr) */ \
+  X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
   X(sensordata, d.nsensordata)                                                 \
   X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, 9 * d.nconmax) \
-  X(efc_J, d.njmax * d.nv)                                                     \
+  X(efc_Jd, d.njdense * d.nv) X(efc_Jc, d.njcon * d.kmax)                      \
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
   X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
   X(efc_force, d.njmax)                                                        \
@@ -143,7 +160,10 @@ struct StepDims {
 
 // ---- per-environment scratch (ints) --------------------------------------------
 #define STEP_SCRATCH_INT(X)                                                    \
-  X(con_pair, d.nconmax) X(con_efc, d.nconmax)                                 \
+  X(con_geom, d.nconmax)  /* geom1 | geom2 << 16 */                            \
+  X(con_info, d.nconmax)  /* condim | contact-parameter tuple << 8 */          \
+  X(con_efc, d.nconmax)                                                        \
+  X(con_mlo, d.nconmax) X(con_mhi, d.nv > 32 ? d.nconmax : 0)  /* dof mask of the contact's Jacobian rows */ \
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
@@ -151,12 +171,14 @@ struct StepDims {
 
 // indices into the `misc` / `imisc` scratch
 enum { MISC_TIME = 0 };
-enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */ };
+enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */,
+       IM_ROW_S0 = 12, IM_ROW_TL0 = 13, IM_ROW_C0 = 14 /* first simple / tendon-limit / contact row */ };
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
        ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */,
        ACTF_DYN_INTEGRATOR = 32, ACTF_DYN_FILTER = 64, ACTF_DYN_FILTEREXACT = 128, ACTF_DYN_ANY = 32 | 64 | 128 };
+// EFC_LIMIT rows carry id = (joint << 1) | upper_side
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5, EFC_EQUALITY = 6 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))
@@ -172,13 +194,16 @@ struct StepLayout {
 #define X(name, cnt) int mr_##name;
   STEP_MODEL_REAL_TABLES(X)
 #undef X
+#define X(name, cnt) int mc_##name;
+  STEP_MODEL_COLD_TABLES(X)
+#undef X
 #define X(name, cnt) int s_##name;
   STEP_SCRATCH_ALL_REAL(X)
 #undef X
 #define X(name, cnt) int si_##name;
   STEP_SCRATCH_INT(X)
 #undef X
-  int n_mi, n_mr;          // table sizes (elements)
+  int n_mi, n_mr, n_mc;    // table sizes (elements)
   int n_sr, n_si;          // per-env scratch sizes (elements)
 };
 
@@ -203,6 +228,11 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
   STEP_MODEL_REAL_TABLES(X)
 #undef X
   L->n_mr = (o + 3) & ~3;
+  o = 0;
+#define X(name, cnt) L->mc_##name = o; o += (cnt);
+  STEP_MODEL_COLD_TABLES(X)
+#undef X
+  L->n_mc = (o + 3) & ~3;
   o = 0;
 #define X(name, cnt) L->s_##name = o; o += (cnt);
   STEP_SCRATCH_REAL(X)

@@ -62,6 +62,7 @@ inline bool host_model_parse(HostModel* m, const int32_t* ints, int nints, const
 struct StepTables {
   StepLayout L;
   std::vector<int> mi;       // int tables, laid out per L.mi_*
+  std::vector<int> mc;       // cold int tables (global memory), per L.mc_*
   std::vector<double> mr;    // real tables (fp64 master copy), per L.mr_*
   StepOpts<double> opts;
   int max_contacts, max_rows;  // upper bounds if no cap applied
@@ -81,6 +82,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   if (d.na != m.na) { *err = "model na does not match the number of actuators with dynamics"; return false; }
   if (d.na && m.opt_integrator != DMC_INT_EULER) { *err = "actuator dynamics are only implemented with the Euler integrator"; return false; }
   if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
+  if (m.ngeom > 65535) { *err = "kernel supports ngeom <= 65535"; return false; }
   if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
   const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
   if (m.opt_solver != DMC_SOL_NEWTON) { *err = "only the Newton solver is implemented in the HIP path"; return false; }
@@ -228,9 +230,30 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     // raises DMC_WARN_CNSTRFULL and keeps the main solver's result
     d.nslip = std::min(std::min(njmax, d.nfric + nconmax * maxfr), 64);
   }
+  // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
+  // one-nonzero friction / joint-limit rows, kmax entries per contact row
+  d.njdense = std::min(njmax, d.neqrow + 2 * d.nlimten);
+  d.njcon = std::min(njmax, nconmax * maxrow_per_contact);
+  {
+    std::vector<uint64_t> anc(m.nv, 0);
+    for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) anc[i] |= (uint64_t)1 << j;
+    std::vector<int> lastd(m.nbody, -1);
+    for (int b = 1; b < m.nbody; b++) {
+      lastd[b] = lastd[m.body_parentid[b]];
+      if (m.body_dofnum[b]) lastd[b] = m.body_dofadr[b] + m.body_dofnum[b] - 1;
+    }
+    int kmax = 1;
+    for (int p = 0; p < m.npair; p++) {
+      const int b1 = m.geom_bodyid[m.pair_geom1[p]], b2 = m.geom_bodyid[m.pair_geom2[p]];
+      const uint64_t mk = (lastd[b1] >= 0 ? anc[lastd[b1]] : 0) ^ (lastd[b2] >= 0 ? anc[lastd[b2]] : 0);
+      kmax = std::max(kmax, __builtin_popcountll(mk));
+    }
+    d.kmax = kmax;
+  }
   step_layout_build(&t->L, d);
   const StepLayout& L = t->L;
   t->mi.assign(L.n_mi, 0);
+  t->mc.assign(std::max(L.n_mc, 4), 0);
   t->mr.assign(L.n_mr, 0.0);
   int* mi = t->mi.data(); double* mr = t->mr.data();
   auto cpi = [&](int off, const std::vector<int>& v) { std::copy(v.begin(), v.end(), mi + off); };
@@ -265,15 +288,25 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     mi[L.mi_dof_anc_lo + i] = (int)(uint32_t)(mask & 0xffffffffu);
     mi[L.mi_dof_anc_hi + i] = (int)(uint32_t)(mask >> 32);
   }
-  cpi(L.mi_mpair_i, mp_i); cpi(L.mi_mpair_j, mp_j);
   {
+    int* mc = t->mc.data();
+    for (int p = 0; p < d.nM; p++) mc[L.mc_mpair + p] = mp_i[p] | (mp_j[p] << 16);
+    for (int p = 0; p < m.npair; p++) {
+      mc[L.mc_pair_geom + p] = m.pair_geom1[p] | (m.pair_geom2[p] << 16);
+      mc[L.mc_pair_info + p] = pdim[p] | (pair_prm[p] << 8);
+    }
+    // sparse M: row i = entries (i, i), (i, parent(i)), ... in mpair order
     int k = 0;
-    for (int j = 0; j < m.nv; j++) { mi[L.mi_tri_col + j] = k; for (int i = j; i < m.nv; i++) { mi[L.mi_tri_i + k] = i; mi[L.mi_tri_j + k] = j; k++; } }
-    mi[L.mi_tri_col + m.nv] = k;
+    for (int i = 0; i < m.nv; i++) { mi[L.mi_dof_madr + i] = k; for (int j = i; j >= 0; j = m.dof_parentid[j]) k++; }
+    mi[L.mi_dof_madr + m.nv] = k;
+    for (int i = 0; i < m.nv; i++) {
+      int end = i + 1;
+      for (int dd = i + 1; dd < m.nv; dd++) for (int j = dd; j >= 0; j = m.dof_parentid[j]) if (j == i) { end = dd + 1; break; }
+      mi[L.mi_dof_subend + i] = end;
+    }
   }
   cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);
   if (d.nrf) cpi(L.mi_geom_invisible, m.geom_invisible);
-  cpi(L.mi_pair_geom1, m.pair_geom1); cpi(L.mi_pair_geom2, m.pair_geom2); cpi(L.mi_pair_dim, pdim);
   cpi(L.mi_site_bodyid, m.site_bodyid); cpi(L.mi_site_type, m.site_type);
   int nact = 0;
   for (int i = 0; i < m.nu; i++) {
@@ -310,7 +343,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   cpr(L.mr_dof_armature, m.dof_armature); cpr(L.mr_dof_damping, m.dof_damping); cpr(L.mr_dof_invweight0, m.dof_invweight0);
   cpr(L.mr_geom_size, m.geom_size); cpr(L.mr_geom_pos, m.geom_pos); cpr(L.mr_geom_quat, m.geom_quat);
   cpr(L.mr_geom_rbound, m.geom_rbound);
-  cpi(L.mi_pair_prm, pair_prm);
   for (int q = 0; q < d.nprm; q++) {
     const double* v = prm[q].data();
     mr[L.mr_prm_margin + q] = v[0]; mr[L.mr_prm_gap + q] = v[1];

@@ -107,9 +107,12 @@ int dmc_batch_set_model_real(dmc_batch* b, const char* name, const double* value
 
 int dmc_batch_sync(dmc_batch* b);
 
-/* info[0..10] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
- * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id}
- * (static_id >= 0: a model-specialised kernel instantiation is in use). */
+/* info[0..15] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
+ * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id,
+ * jac_kmax, table_lds_bytes, envs_per_cu, njdense, njcon}
+ * (static_id >= 0: a model-specialised kernel instantiation is in use; jac_kmax: entries per
+ * compressed contact Jacobian row; envs_per_cu: environments resident on one CU under the
+ * 160 KiB LDS budget). */
 int dmc_batch_info(const dmc_batch* b, int* info);
 
 /* Time `reps` back-to-back step launches with hipEvents on `hip_stream`;

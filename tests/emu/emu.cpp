@@ -32,7 +32,7 @@ void* emu_create(const int32_t* ints, int ni, const double* reals, int nr, int n
 void emu_free(void* h) { delete (Emu*)h; }
 int emu_dims(void* h, int* out) {
   Emu* e = (Emu*)h; const StepLayout& L = e->tb.L;
-  out[0] = L.n_sr; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr;
+  out[0] = L.n_sr; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr; out[6] = L.d.kmax; out[7] = L.n_mc;
   return 0;
 }
 int emu_find(void* h, const char* name, int* off, int* cnt, int* kind) { return step_layout_find(&((Emu*)h)->tb.L, name, off, cnt, kind); }
@@ -69,7 +69,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   DynLayoutSrc ls; ls.p = &L;
-  StepCore<T, 1> core(ls, o, e->tb.mi.data(), mr, s.data(), si.data(), 0);
+  StepCore<T, 1> core(ls, o, e->tb.mi.data(), mr, e->tb.mc.data(), s.data(), si.data(), 0);
   core.run(io, 0, nstep, legacy, mode, OUT_ALL, 1);
   for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
   f[5][0] = tm;

@@ -48,9 +48,10 @@ class EmuPhysics:
     self.h = lib().emu_create(ints.ctypes.data, ints.size, reals.ctypes.data, reals.size, nconmax, njmax)
     if not self.h:
       raise ValueError(lib().emu_last_error().decode())
-    dims = np.zeros(6, dtype=np.int32)
+    dims = np.zeros(8, dtype=np.int32)
     lib().emu_dims(self.h, dims.ctypes.data)
     self.n_sr, self.n_si, self.nconmax, self.njmax = [int(x) for x in dims[:4]]
+    self.kmax = int(dims[6])
     m = compiled
     nb = m.nbody
     sizes = [m.nq, m.nv, m.nu, m.nv, m.nv, 1, m.nsensordata, 3*nb, 4*nb, 9*nb, 3*nb,
@@ -88,6 +89,14 @@ class EmuPhysics:
 
   def forward(self, disable_actuation=False):
     self._run(0, 0, 2 if disable_actuation else 1)
+
+  def dense_M(self):
+    import scratch_decode
+    return scratch_decode.dense_M(self.m, self.scratch)
+
+  def dense_J(self):
+    import scratch_decode
+    return scratch_decode.dense_J(self.m, self.scratch, self.kmax)
 
   def scratch(self, name):
     off, cnt, kind = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -1,0 +1,76 @@
+"""TEST INFRASTRUCTURE: dense views of the kernel's packed scratch arrays.
+
+The kernel keeps the mass matrix sparse (row i = M(i, i), M(i, parent(i)), ...), the Cholesky buffer as
+a column-packed lower triangle, and the constraint Jacobian in three classes (dense equality /
+tendon-limit rows, implicit one-nonzero friction / joint-limit rows, mask-compressed contact rows) --
+see dm_control_amd/csrc/step_layout.h.  The oracle holds dense matrices; these helpers expand the
+kernel's form so that the two can be compared entry by entry.
+
+`get(name)` returns one environment's scratch array (EmuPhysics.scratch, or
+lambda n: batch.debug_get(n, env)).
+"""
+import numpy as np
+
+IM_NCON, IM_NEFC, IM_ROW_S0, IM_ROW_TL0, IM_ROW_C0 = 0, 1, 12, 13, 14
+EFC_LIMIT, EFC_FRICTION = 0, 4
+
+
+def dense_M(m, get):
+  """(nv*nv,) dense symmetric mass matrix from the sparse qM scratch."""
+  nv = m.nv
+  qM = np.asarray(get('qM'))
+  M = np.zeros((nv, nv))
+  p = 0
+  for i in range(nv):
+    j = i
+    while j >= 0:
+      M[i, j] = M[j, i] = qM[p]
+      p += 1
+      j = int(m.dof_parentid[j])
+  return M.ravel()
+
+
+def _anc_mask(m, dof):
+  mask = 0
+  while dof >= 0:
+    mask |= 1 << dof
+    dof = int(m.dof_parentid[dof])
+  return mask
+
+
+def dense_J(m, get, kmax):
+  """(nefc*nv,) dense constraint Jacobian from efc_Jd / efc_Jc / efc_tid / the contact masks.
+
+  kmax: row stride of efc_Jc (EmuPhysics.kmax, BatchedPhysics.info()['jac_kmax'])."""
+  nv = m.nv
+  im = np.asarray(get('imisc')).astype(np.int64)
+  nefc, s0, tl0, c0 = int(im[IM_NEFC]), int(im[IM_ROW_S0]), int(im[IM_ROW_TL0]), int(im[IM_ROW_C0])
+  tid = np.asarray(get('efc_tid')).astype(np.int64)
+  Jd = np.asarray(get('efc_Jd'))
+  Jc = np.asarray(get('efc_Jc'))
+  mlo = np.asarray(get('con_mlo')).astype(np.int64) & 0xffffffff
+  mhi = (np.asarray(get('con_mhi')).astype(np.int64) & 0xffffffff) if nv > 32 else np.zeros_like(mlo)
+  J = np.zeros((nefc, nv))
+  for r in range(nefc):
+    t, ident = int(tid[r]) & 7, int(tid[r]) >> 3
+    if r < s0:
+      J[r] = Jd[r*nv:(r + 1)*nv]
+    elif r < tl0:
+      if t == EFC_FRICTION:
+        J[r, ident] = 1.0
+      else:
+        assert t == EFC_LIMIT
+        J[r, int(m.jnt_dofadr[ident >> 1])] = -1.0 if ident & 1 else 1.0
+    elif r < c0:
+      k = s0 + (r - tl0)
+      J[r] = Jd[k*nv:(k + 1)*nv]
+    else:
+      c = ident
+      mask = int(mlo[c]) | (int(mhi[c]) << 32)
+      base = (r - c0)*kmax
+      k = 0
+      for dd in range(nv):
+        if (mask >> dd) & 1:
+          J[r, dd] = Jc[base + k]
+          k += 1
+  return J.ravel()

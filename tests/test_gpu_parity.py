@@ -5,6 +5,7 @@ track the oracle to 1e-9."""
 import os
 
 import numpy as np
+import scratch_decode
 import pytest
 
 from dm_control_amd import mjcf_compiler as mc
@@ -95,11 +96,16 @@ def test_forward_stages_fp64(cheetah, lanes):
     im = b.debug_get('imisc', e)
     assert int(im[0]) == o.ncon and int(im[1]) == o.nefc
     ne = o.nefc
-    for name, ref in (('xpos', o.xpos), ('xmat', o.xmat), ('cdof', o.cdof), ('qM', o.qM),
-                      ('qfrc_bias', o.qfrc_bias), ('efc_J', o.efc_J[:ne*m.nv]),
+    for name, ref in (('xpos', o.xpos), ('xmat', o.xmat), ('cdof', o.cdof),
+                      ('qfrc_bias', o.qfrc_bias),
                       ('efc_D', o.efc_D[:ne]), ('efc_aref', o.efc_aref[:ne])):
       np.testing.assert_allclose(b.debug_get(name, e)[:ref.size], ref, rtol=1e-9, atol=1e-11,
                                  err_msg='%s env %d' % (name, e))
+    # the kernel's sparse M and class-compressed Jacobian, expanded to the oracle's dense form
+    get = lambda n, e=e: b.debug_get(n, e)
+    np.testing.assert_allclose(scratch_decode.dense_M(m, get), o.qM, rtol=1e-9, atol=1e-11, err_msg='qM env %d' % e)
+    np.testing.assert_allclose(scratch_decode.dense_J(m, get, b.info()['jac_kmax']), o.efc_J[:ne*m.nv], rtol=1e-9, atol=1e-11,
+                               err_msg='efc_J env %d' % e)
     np.testing.assert_allclose(b.debug_get('qacc', e), o.qacc, rtol=1e-10, atol=1e-8)
   # derived outputs through the public field API
   np.testing.assert_allclose(b.get('ncon')[:, 0], [int(b.debug_get('imisc', e)[0]) for e in range(NE)])

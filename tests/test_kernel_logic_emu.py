@@ -39,8 +39,8 @@ def test_forward_stages_fp64():
     for name in ('xpos', 'xmat', 'subtree_com', 'qfrc_bias', 'sensordata'):
       np.testing.assert_allclose(getattr(o, name), getattr(e, name), rtol=1e-12, atol=1e-12, err_msg=name)
     ne = o.nefc
-    np.testing.assert_allclose(o.qM, e.scratch('qM'), rtol=1e-12, atol=1e-13)
-    np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(o.qM, e.dense_M(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.dense_J(), rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(o.efc_aref[:ne], e.scratch('efc_aref')[:ne], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(o.qacc, e.qacc, rtol=1e-11, atol=1e-9)
 
@@ -116,7 +116,7 @@ def test_elliptic_cones_match_oracle(condim, impratio):
   e.forward()
   assert o.nefc == e.nefc[0] and o.ncon == e.ncon[0] and o.ncon > 0
   ne = o.nefc
-  np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.scratch('efc_J')[:ne*m.nv], rtol=1e-11, atol=1e-13)
+  np.testing.assert_allclose(o.efc_J[:ne*m.nv], e.dense_J(), rtol=1e-11, atol=1e-13)
   np.testing.assert_allclose(o.efc_D[:ne], e.scratch('efc_D')[:ne], rtol=1e-12)
   np.testing.assert_allclose(o.efc_aref[:ne], e.scratch('efc_aref')[:ne], rtol=1e-9, atol=1e-9)
   np.testing.assert_allclose(o.qacc, e.qacc, rtol=1e-8, atol=1e-8)
@@ -445,7 +445,7 @@ def test_connect_weld_joint_equalities_match_oracle(prec, tol):
     assert o.nefc == e.nefc[0] and o.nefc >= 9
     if prec == 64:
       ne = o.nefc
-      np.testing.assert_allclose(e.scratch('efc_J')[:ne*m.nv], np.array(o.efc_J[:ne*m.nv]), atol=1e-13)
+      np.testing.assert_allclose(e.dense_J(), np.array(o.efc_J[:ne*m.nv]), atol=1e-13)
     for _ in range(400):
       o.step()
       e.step()
