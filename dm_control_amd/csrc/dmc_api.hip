@@ -84,7 +84,7 @@ static Field* find_field(dmc_batch* b, const char* name) {
 static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   const StepLayout& L = b->tb.L;
   const size_t tables = (size_t)(b->precision == 64 ? opts_lds_bytes<double>() : opts_lds_bytes<float>()) +
-                        (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem;
+                        (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem + (L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0);
   const size_t env_bytes = (size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int);
   const size_t lds_cu = 160 * 1024;
   // automatic: small models (cheetah, nv = 9) leave most of a 64-lane group idle, so

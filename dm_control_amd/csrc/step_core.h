@@ -501,7 +501,15 @@ struct StepCore {
 #endif
 
   DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
-      : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_), gc(gc_), s(s_), si(si_), lane(lane_), time_(0) {}
+      : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_),
+        // small models stage the cold tables in LDS right behind the real tables (step_kernel.hip.h): derive the
+        // pointer from `mr` so that the loads compile to LDS reads
+#ifndef DMC_HOST_EMU
+        gc(ls_.get().d.coldlds ? reinterpret_cast<const int*>(mr_ + ls_.get().n_mr) : gc_),
+#else
+        gc(gc_),
+#endif
+        s(s_), si(si_), lane(lane_), time_(0) {}
 
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
@@ -542,6 +550,7 @@ struct StepCore {
       for (int k = 0; k < 10; k++) S(cinert)[k] = 0;
       for (int k = 0; k < 6; k++) S(cvel)[k] = 0;
     }
+    if (!L.d.msparse) FOR_LANES(i, L.d.nv * L.d.nv) S(qM)[i] = 0;
     FOR_LANES(i, L.d.nsensordata) S(sensordata)[i] = 0;
     DMC_WSYNC();
   }
@@ -811,7 +820,7 @@ struct StepCore {
       const int pk = GC(mpair)[p], i = pk & 0xffff, j = pk >> 16;
       T v = dot_n(S(cdof) + 6*j, S(mbuf) + 6*i, 6);
       if (i == j) v += MR(dof_armature)[i];
-      S(qM)[p] = v;
+      if (L.d.msparse) S(qM)[p] = v; else { S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v; }
     }
     DMC_WSYNC();
     factor_M(false);
@@ -827,22 +836,30 @@ struct StepCore {
     return j >= 63 ? 0 : __builtin_popcount(hi >> (j - 31));
   }
   DMC_DEV T M_at(int i, int j) const {
+    if (!L.d.msparse) return S(qM)[i*L.d.nv + j];
     if (!dof_in_chain(i, j)) return 0;
     return S(qM)[MI(dof_madr)[i] + anc_above(i, j)];
   }
-  // qLH <- M (+ timestep * damping on the diagonal), then its Cholesky factor
-  DMC_DEV void factor_M(bool with_damping) {
-    const int nv = L.d.nv;
+  // qLH <- M (+ diag), packed by columns: zero fill, then the nonzeros (i, j) of the (i, j) list; the list is
+  // read from global memory one trip ahead of its use
+  DMC_DEV void scatter_M(const T* diag, T diag_scale) {
+    const int nv = L.d.nv, nM = L.d.nM;
     FOR_LANES(i, L.d.ntri) S(qLH)[i] = 0;
     DMC_WSYNC();
-    FOR_LANES(p, L.d.nM) {
-      const int pk = GC(mpair)[p], i = pk & 0xffff, j = pk >> 16;
-      T v = S(qM)[p];
-      if (with_damping && i == j) v += o.timestep*MR(dof_damping)[i];
+    int pk = lane < nM ? GC(mpair)[lane] : 0;
+    for (int p = lane; p < nM; p += LPE) {
+      const int i = pk & 0xffff, j = pk >> 16;
+      if (p + LPE < nM) pk = GC(mpair)[p + LPE];
+      T v = L.d.msparse ? S(qM)[p] : S(qM)[i*nv + j];
+      if (diag && i == j) v += diag_scale*diag[i];
       S(qLH)[tri_at(i, j, nv)] = v;
     }
     DMC_WSYNC();
-    chol_factor_inplace(S(qLH), nv);
+  }
+  // qLH <- M (+ timestep * damping on the diagonal), then its Cholesky factor
+  DMC_DEV void factor_M(bool with_damping) {
+    scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep);
+    chol_factor_inplace(S(qLH), L.d.nv);
   }
 
   // ---- collision (mj_collision over the static candidate pair list) -------------
@@ -1355,12 +1372,15 @@ struct StepCore {
     const bool enabled = !(o.disableflags & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT));
     const int npair = enabled ? L.d.npair : 0;
     int overflow = 0, unresolved = 0;
+    // the candidate pair list lives in global memory: each trip's entries are fetched one trip ahead
+    int nxt_geom = lane < npair ? GC(pair_geom)[lane] : 0, nxt_info = lane < npair ? GC(pair_info)[lane] : 0;
     for (int p0 = 0; p0 < npair; p0 += LPE) {
       const int p = p0 + lane;
       Hits h = {}; T tang[3] = {0, 0, 0}; bool has_tang = false;
-      int mask = 0, pgeom = 0, pinfo = 0;
+      int mask = 0;
+      const int pgeom = nxt_geom, pinfo = nxt_info;
+      if (p + LPE < npair) { nxt_geom = GC(pair_geom)[p + LPE]; nxt_info = GC(pair_info)[p + LPE]; }
       if (p < npair) {
-        pgeom = GC(pair_geom)[p]; pinfo = GC(pair_info)[p];
         bool guard;
         mask = narrow_phase(pgeom & 0xffff, (int)((unsigned)pgeom >> 16), MR(prm_margin)[prm_of_info(pinfo)], &h, tang, &has_tang, &guard);
         if (guard) { if (mask) unresolved = 1; mask = 0; }
@@ -1468,9 +1488,11 @@ struct StepCore {
   struct RowMap { int s0, tl0, c0; };   // first simple / tendon-limit / contact row (group-uniform)
   DMC_DEV RowMap row_map() const { RowMap rm = {SI(imisc)[IM_ROW_S0], SI(imisc)[IM_ROW_TL0], SI(imisc)[IM_ROW_C0]}; return rm; }
   // the one nonzero of a dof-friction / joint-limit row
-  DMC_DEV int simple_dof(int tid) const { return EFC_TYPE(tid) == EFC_FRICTION ? EFC_ID(tid) : MI(jnt_dofadr)[EFC_ID(tid) >> 1]; }
+  DMC_DEV int simple_dof(int tid) const { return EFC_TYPE(tid) == EFC_FRICTION ? EFC_ID(tid) : (EFC_ID(tid) >> 1); }
   DMC_DEV T simple_sign(int tid) const { return (EFC_TYPE(tid) == EFC_LIMIT && (EFC_ID(tid) & 1)) ? (T)-1 : (T)1; }
   DMC_DEV const T* dense_row(int r, const RowMap& rm) const { return S(efc_Jd) + (r < rm.s0 ? r : rm.s0 + (r - rm.tl0))*L.d.nv; }
+  DMC_DEV const unsigned char* con_dof_list(int c) const { return (const unsigned char*)(SI(con_dofs) + c*L.d.kwords); }
+  DMC_DEV int con_ndof(int c) const { return __builtin_popcount(con_mask_lo(c)) + (L.d.nv > 32 ? __builtin_popcount(con_mask_hi(c)) : 0); }
   DMC_DEV unsigned con_mask_lo(int c) const { return (unsigned)SI(con_mlo)[c]; }
   DMC_DEV unsigned con_mask_hi(int c) const { return L.d.nv > 32 ? (unsigned)SI(con_mhi)[c] : 0u; }
   // slot of dof dd in the compressed rows of a contact with mask (lo, hi), or -1
@@ -1486,12 +1508,14 @@ struct StepCore {
   // J[r, :] . x for any row class (x: nv reals)
   DMC_DEV T row_dot(int r, const T* x, const RowMap& rm) const {
     if (r >= rm.c0) {
+      // entry k of the row belongs to dof con_dofs[c][k]; the loop runs to the compile-time bound kmax in the
+      // model-specialised kernels, so all its loads are in flight together
       const int c = EFC_ID(SI(efc_tid)[r]);
       const T* jr = S(efc_Jc) + (r - rm.c0)*L.d.kmax;
+      const unsigned char* dofs = con_dof_list(c);
+      const int kc = con_ndof(c);
       T acc = 0;
-      int k = 0;
-      for (unsigned m = con_mask_lo(c); m; m &= m - 1) acc += jr[k++] * x[__builtin_ctz(m)];
-      if (L.d.nv > 32) for (unsigned m = con_mask_hi(c); m; m &= m - 1) acc += jr[k++] * x[32 + __builtin_ctz(m)];
+      for (int k = 0; k < L.d.kmax; k++) if (k < kc) acc += jr[k] * x[dofs[k]];
       return acc;
     }
     if (r >= rm.s0 && r < rm.tl0) { const int tid = SI(efc_tid)[r]; return simple_sign(tid) * x[simple_dof(tid)]; }
@@ -1605,7 +1629,7 @@ struct StepCore {
         const int r = off + i;
         if (r >= njmax) { overflow = 1; continue; }
         const bool lo = i == 0 && act_lo;
-        S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, (j << 1) | (lo ? 0 : 1));
+        S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, (MI(jnt_dofadr)[j] << 1) | (lo ? 0 : 1));
       }
       nefc += total;
     }
@@ -1708,6 +1732,7 @@ struct StepCore {
       }
       T* Jc = S(efc_Jc) + (r0 - nefc_lim)*L.d.kmax + slot;
       const int K = L.d.kmax;
+      ((unsigned char*)(SI(con_dofs) + c*L.d.kwords))[slot] = (unsigned char)dd;
       if (dim == 1) Jc[0] = jac[0];
       else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jc[k*K] = jac[k];
       else for (int k = 1; k < dim; k++) {
@@ -1739,9 +1764,9 @@ struct StepCore {
         solref = MR(dof_solref) + 2*id; solimp = MR(dof_solimp) + 5*id;
         dA = MR(dof_invweight0)[id];
       } else if (type == EFC_LIMIT) {
-        const int jn = id >> 1;
+        const int jn = MI(dof_jntid)[id >> 1];
         solref = MR(jnt_solref) + 2*jn; solimp = MR(jnt_solimp) + 5*jn;
-        dA = MR(dof_invweight0)[MI(jnt_dofadr)[jn]];
+        dA = MR(dof_invweight0)[id >> 1];
       } else if (type == EFC_TENDON_LIMIT) {
         solref = MR(tendon_solref_lim) + 2*id; solimp = MR(tendon_solimp_lim) + 5*id;
         dA = MR(tendon_invweight0)[id];
@@ -2465,53 +2490,86 @@ struct StepCore {
     DMC_WSYNC();
     return cost;
   }
-  // H(i, j) = M(i, j) + sum over the active rows / cone blocks, rows visited in order: dense equality
-  // rows, the one-nonzero friction / limit rows (diagonal only), dense tendon-limit rows, then the
-  // contacts through their dof masks.  efc_active holds the state constraint_update recorded.
-  DMC_DEV T hess_entry(int i, int j, int nefc, const RowMap& rm) {
+  // H = M + J' D_active J (+ the cone blocks of elliptic contacts) into qLH, packed by columns.  Assembled by
+  // storage class: M scattered from its (i, j) list with the one-nonzero friction / limit rows already on the
+  // diagonal; dense equality / tendon-limit rows entry by entry; then ONE CONTACT AT A TIME: a contact's rows
+  // only touch the kc x kc block of its own dofs, so its lanes run over the kc (kc + 1) / 2 dof pairs of that
+  // block (no two lanes on the same entry; a wave fence between contacts).  efc_active holds the state
+  // constraint_update recorded.
+  DMC_DEV void hess_assemble(int nefc, const RowMap& rm) {
     const int nv = L.d.nv, K = L.d.kmax;
-    T h = M_at(i, j);
-    if (L.d.njdense) for (int r = 0; r < rm.s0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
-      const T* jr = S(efc_Jd) + r*nv;
-      const T ji = jr[i];
-      if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];
-    }
-    if (i == j) for (int r = rm.s0; r < rm.tl0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
-      if (simple_dof(SI(efc_tid)[r]) == i) h += S(efc_D)[r];
-    }
-    if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) if (SI(efc_active)[r] == EFC_ST_QUADRATIC) {
-      const T* jr = S(efc_Jd) + (rm.s0 + r - rm.tl0)*nv;
-      const T ji = jr[i];
-      if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];
-    }
-    for (int r = rm.c0; r < nefc; ) {
-      const int c = EFC_ID(SI(efc_tid)[r]);
-      const int nrow = contact_rows(con_dim(c));
-      const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
-      const int si_ = mask_slot(lo, hi, i), sj = si_ < 0 ? -1 : mask_slot(lo, hi, j);
-      if (sj >= 0) {
-        const T* ji_ = S(efc_Jc) + (r - rm.c0)*K + si_;
-        const T* jj_ = S(efc_Jc) + (r - rm.c0)*K + sj;
-        const int st = SI(efc_active)[r];
-        if (L.d.elliptic && st == EFC_ST_CONE) {
-          T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
-          for (int a = 0; a < nrow; a++) {
-            const T ji = ji_[a*K], jj = jj_[a*K];
-            const T ca = S(efc_ca)[r + a];
-            Pi += ca*ji; Pj += ca*jj;
-            if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
-          }
-          h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
-        } else {
-          for (int a = 0; a < nrow; a++) if (SI(efc_active)[r + a] == EFC_ST_QUADRATIC) {
-            const T ji = ji_[a*K];
-            if (ji != 0) h += (S(efc_D)[r + a]*ji) * jj_[a*K];
-          }
+    FOR_LANES(i, nv) {
+      T dsum = 0;
+      for (int r = rm.s0; r < rm.tl0; r += 4) {      // four rows per trip: their loads are issued together
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool in = r + u < rm.tl0;
+          const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
+          const T dd = in ? S(efc_D)[r + u] : (T)0;
+          if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
         }
       }
-      r += nrow;
+      S(sv_Mgrad)[i] = dsum;
     }
-    return h;
+    scatter_M(S(sv_Mgrad), (T)1);      // (fences inside: sv_Mgrad is complete before it is read)
+    if (L.d.njdense && (rm.s0 > 0 || rm.c0 > rm.tl0)) {
+      for (int idx = lane; idx < L.d.ntri; idx += LPE) {
+        int i, j;
+        tri_unrank(idx, nv, &i, &j);
+        T h = S(qLH)[idx];
+        for (int r = 0; r < rm.c0; r++) {
+          if (r >= rm.s0 && r < rm.tl0) continue;
+          if (SI(efc_active)[r] != EFC_ST_QUADRATIC) continue;
+          const T* jr = dense_row(r, rm);
+          const T ji = jr[i];
+          if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];
+        }
+        S(qLH)[idx] = h;
+      }
+      DMC_WSYNC();
+    }
+    const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
+    for (int c = 0; c < ncon; c++) {
+      const int r0 = SI(con_efc)[c];
+      if (r0 < 0) continue;
+      const int nrow = contact_rows(con_dim(c));
+      const int st0 = SI(efc_active)[r0];
+      const bool cone = L.d.elliptic && st0 == EFC_ST_CONE;
+      // the row loops run to the compile-time bound maxrow (model-specialised kernels) under a predicate, so
+      // that the loads of all rows are in flight together
+      bool any = cone;
+      for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) any = any || SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC;
+      if (!any) continue;               // group-uniform: a contact whose rows are all inactive adds nothing
+      const int kc = con_ndof(c), npair = (kc*(kc + 1)) >> 1;
+      const unsigned char* dofs = con_dof_list(c);
+      const T* J = S(efc_Jc) + (r0 - rm.c0)*K;
+      for (int t = lane; t < npair; t += LPE) {
+        // slot pair (a >= b) of the block, row-major
+        int a = (int)((sqrtf(8.0f*(float)t + 1.0f) - 1.0f)*0.5f);
+        if (((a + 1)*(a + 2)) >> 1 <= t) a++;
+        else if ((a*(a + 1)) >> 1 > t) a--;
+        const int b2 = t - ((a*(a + 1)) >> 1);
+        const int i = dofs[a], j = dofs[b2];
+        T acc = 0;
+        if (cone) {
+          T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+          for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) {
+            const T ji = J[q*K + a], jj = J[q*K + b2];
+            const T ca = S(efc_ca)[r0 + q];
+            Pi += ca*ji; Pj += ca*jj;
+            if (q) { const T cb = S(efc_cb)[r0 + q]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r0 + q]*ji*jj; }
+          }
+          acc = S(efc_cg)[r0]*(Pi*Pj) - S(efc_cb)[r0]*(Wi*Wj) + g;
+        } else {
+          for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
+            const T ji = J[q*K + a];
+            if (ji != 0) acc += (S(efc_D)[r0 + q]*ji) * J[q*K + b2];
+          }
+        }
+        S(qLH)[tri_at(i, j, nv)] += acc;
+      }
+      DMC_WSYNC();
+    }
   }
   // line-search point for elliptic models: quadratic rows as in ls_eval_lds, plus
   // the non-quadratic middle-zone term of every frictional contact
@@ -2598,17 +2656,18 @@ struct StepCore {
     FOR_LANES(i, L.d.nv) g += (S(sv_Ma)[i] - S(qfrc_smooth)[i]) * (S(qacc)[i] - S(qacc_smooth)[i]);
     return (T)0.5 * group_sum<LPE>(g);
   }
-  // res = M v on the sparse M: row i holds M(i, ancestors of i); the transposed part comes from the
-  // dofs below i (dof_subend: end of the subtree's dof range)
+  // res = M v.  Sparse M: lane i walks j = 0 .. nv-1 like a dense row product, the entry (max, min) being
+  // looked up through the ancestor masks (present iff min is an ancestor dof of max) -- independent
+  // iterations, same summation order as the dense product.
   DMC_DEV void mul_M(T* res, const T* v) {
     const int nv = L.d.nv;
+    if (!L.d.msparse) { FOR_LANES(i, nv) res[i] = dot_n(S(qM) + i*nv, v, nv); return; }
     FOR_LANES(i, nv) {
-      const T* row = S(qM) + MI(dof_madr)[i];
       T acc = 0;
-      int k = 0;
-      for (int j = i; j >= 0; j = MI(dof_parentid)[j]) acc += row[k++] * v[j];
-      const int end = MI(dof_subend)[i];
-      for (int dd = i + 1; dd < end; dd++) if (dof_in_chain(dd, i)) acc += S(qM)[MI(dof_madr)[dd] + anc_above(dd, i)] * v[dd];
+      for (int j = 0; j < nv; j++) {
+        const int a = j <= i ? i : j, b2 = j <= i ? j : i;
+        if (dof_in_chain(a, b2)) acc += S(qM)[MI(dof_madr)[a] + anc_above(a, b2)] * v[j];
+      }
       res[i] = acc;
     }
   }
@@ -2620,23 +2679,24 @@ struct StepCore {
   DMC_DEV void constraint_force_to_joint(int nefc) {
     const int nv = L.d.nv, K = L.d.kmax;
     const RowMap rm = row_map();
+    const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
     FOR_LANES(i, nv) {
       T f = 0;
       if (L.d.njdense) for (int r = 0; r < rm.s0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
       for (int r = rm.s0; r < rm.tl0; r++) {
         const T fr = S(efc_force)[r];
-        if (fr != 0) { const int tid = SI(efc_tid)[r]; if (simple_dof(tid) == i) f += simple_sign(tid)*fr; }
+        const int tid = SI(efc_tid)[r];
+        if (fr != 0 && simple_dof(tid) == i) f += simple_sign(tid)*fr;
       }
       if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[(rm.s0 + r - rm.tl0)*nv + i]*fr; }
-      for (int r = rm.c0; r < nefc; ) {
-        const int c = EFC_ID(SI(efc_tid)[r]);
-        const int nrow = contact_rows(con_dim(c));
+      for (int c = 0; c < ncon; c++) {
+        const int r0 = SI(con_efc)[c];
+        if (r0 < 0) continue;
         const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), i);
-        if (slot >= 0) {
-          const T* jc = S(efc_Jc) + (r - rm.c0)*K + slot;
-          for (int a = 0; a < nrow; a++) { const T fr = S(efc_force)[r + a]; if (fr != 0) f += jc[a*K]*fr; }
-        }
-        r += nrow;
+        if (slot < 0) continue;
+        const int nrow = contact_rows(con_dim(c));
+        const T* jc = S(efc_Jc) + (r0 - rm.c0)*K + slot;
+        for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q]; if (fr != 0) f += jc[q*K]*fr; }
       }
       S(qfrc_constraint)[i] = f;
     }
@@ -2649,13 +2709,7 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
-    const RowMap rm = row_map();
-    for (int idx = lane; idx < L.d.ntri; idx += LPE) {
-      int i, j;
-      tri_unrank(idx, nv, &i, &j);
-      S(qLH)[idx] = hess_entry(i, j, nefc, rm);
-    }
-    DMC_WSYNC();
+    hess_assemble(nefc, row_map());
     chol_factor_inplace(S(qLH), nv);
     chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
   }

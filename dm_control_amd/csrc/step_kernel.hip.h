@@ -54,6 +54,10 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   if (tid == 0) *o_lds = o_arg;
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
   for (int i = tid; i < L.n_mr; i += nthr) mr[i] = g_mr[i];
+  // small models: the cold tables ride along in LDS (after the real tables); large ones read them from global memory
+  int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T));
+  const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
+  if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
   __syncthreads();
   const int epb = nthr / LPE;
   const int g = tid / LPE, lane = tid % LPE;
@@ -65,10 +69,10 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   const int env = lblk * epb + g;
   if (env >= io.B) return;
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
-  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + (size_t)g * env_bytes;
+  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + cold_bytes + (size_t)g * env_bytes;
   T* s = reinterpret_cast<T*>(base);
   int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
-  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, g_mc, s, si, lane);
+  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, L.d.coldlds ? (const int*)mc_lds : g_mc, s, si, lane);
   core.run(io, env, nstep, legacy, mode, outmask, nsub);
 }
 

@@ -39,6 +39,10 @@ struct StepDims {
   int kmax;      // max over the candidate pairs of the dofs a contact Jacobian row can touch (chain symmetric difference)
   int njdense;   // cap on the constraint rows stored as dense Jacobian rows (equalities, tendon limits)
   int njcon;     // cap on the contact rows (stored compressed: kmax entries per row)
+  int msparse;   // 1: qM holds the nM tree-sparse entries (nv > 16); 0: dense nv x nv (small models: no index arithmetic)
+  int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
+  int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
+  int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
 };
 
 // Constraint Jacobian storage.  Rows come in MuJoCo's order (equality, dof friction, joint limit,
@@ -46,8 +50,8 @@ struct StepDims {
 //   dense      equality and tendon-limit rows: nv entries each, in efc_Jd;
 //   simple     dof-friction and joint-limit rows: ONE nonzero (+-1 at a dof) -- never stored;
 //   contact    a contact's rows touch only the dofs in the symmetric difference of its two bodies'
-//              chains: per contact a 64-bit dof mask (con_mlo / con_mhi), per row kmax entries in efc_Jc
-//              (entry k belongs to the k-th set bit of the mask).
+//              chains: per contact a 64-bit dof mask (con_mlo / con_mhi) and the same dofs as a byte list
+//              (con_dofs, ascending), per row kmax entries in efc_Jc (entry k belongs to the k-th dof).
 // imisc[IM_ROW_S0 / TL0 / C0] hold the first simple, first tendon-limit and first contact row.
 //
 // ---- model tables (ints) -----------------------------------------------------
@@ -126,7 +130,7 @@ struct StepDims {
   X(subtree_com, 3 * d.nbody)                                                  \
   X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv)              \
   X(cvel, 6 * d.nbody)                                                         \
-  X(qM, d.nM)           /* sparse: row i holds M(i, i), M(i, parent(i)), ... (dof_madr) */ \
+  X(qM, d.msparse ? d.nM : d.nv * d.nv)  /* sparse: row i holds M(i, i), M(i, parent(i)), ... (dof_madr) */ \
   X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
@@ -164,6 +168,7 @@ struct StepDims {
   X(con_info, d.nconmax)  /* condim | contact-parameter tuple << 8 */          \
   X(con_efc, d.nconmax)                                                        \
   X(con_mlo, d.nconmax) X(con_mhi, d.nv > 32 ? d.nconmax : 0)  /* dof mask of the contact's Jacobian rows */ \
+  X(con_dofs, d.nconmax * d.kwords)  /* the mask's dofs in ascending order, one byte each */ \
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
@@ -178,7 +183,7 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING 
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
        ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */,
        ACTF_DYN_INTEGRATOR = 32, ACTF_DYN_FILTER = 64, ACTF_DYN_FILTEREXACT = 128, ACTF_DYN_ANY = 32 | 64 | 128 };
-// EFC_LIMIT rows carry id = (joint << 1) | upper_side
+// EFC_LIMIT rows carry id = (dof << 1) | upper_side
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5, EFC_EQUALITY = 6 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */
 #define EFC_TID(type, id) (((id) << 3) | (type))

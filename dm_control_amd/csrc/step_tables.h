@@ -249,7 +249,11 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
       kmax = std::max(kmax, __builtin_popcountll(mk));
     }
     d.kmax = kmax;
+    d.kwords = (kmax + 3) / 4;
   }
+  d.msparse = m.nv > 16 ? 1 : 0;
+  d.maxrow = maxrow_per_contact;
+  d.coldlds = (d.nM + 2 * m.npair) <= 256 ? 1 : 0;
   step_layout_build(&t->L, d);
   const StepLayout& L = t->L;
   t->mi.assign(L.n_mi, 0);

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-2 GPU session D: tests + bench + probes + fp32 parity distribution
+set -x
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu.log
+tail -8 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; python -c "
+import json; d=json.load(open('gpurun_out/bench.json')); print(d['value'], d['ms_per_step'], d['rollout']['value'], d['max_rel_qpos_err_vs_cpu'], d['config']['info'])"
+MODELS=humanoid timeout 600 python scripts/model_probe.py > gpurun_out/model_probe.log 2>&1; echo "probe rc=$?"; grep -v "^\s*$" gpurun_out/model_probe.log | cut -c1-330 | tail -6
+timeout 900 python scripts/cmu_probe.py > gpurun_out/cmu_probe.log 2>&1; echo "cmu rc=$?"; cut -c1-330 gpurun_out/cmu_probe.log | tail -4
+timeout 900 python scripts/parity_dist.py > gpurun_out/parity_dist.log 2>&1; echo "parity rc=$?"; tail -2 gpurun_out/parity_dist.log | cut -c1-1500

@@ -1,0 +1,98 @@
+"""Distribution of the fp32 kernel's qpos error against the fp64 oracle (BASELINE config 2 workload).
+
+NE environments (default 256) of suite cheetah: task initialisation (random limited joints, 200 settle
+steps), then T = 1000 random-action steps.  Two statistics per environment:
+  * open loop: max over t of |qpos_gpu - qpos_cpu|_inf / max(1, |qpos_cpu|_inf);
+  * teacher forced: the same after ONE step from the oracle's state, max over t.
+Writes gpurun_out/parity_dist_<model>.json with the percentiles and the per-environment tail.
+Oracle use here is the checker role (scripts/ are measurement tools, not product)."""
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dm_control_amd import mjcf_compiler as mc   # noqa: E402
+from dm_control_amd.batch import BatchedPhysics  # noqa: E402
+from dm_control_amd.suite import common          # noqa: E402
+from oracle import oracle                        # noqa: E402
+
+NE = int(os.environ.get('NE', 256))
+T = int(os.environ.get('T', 1000))
+PREC = int(os.environ.get('PREC', 32))
+name = os.environ.get('MODEL', 'cheetah')
+nsub = int(os.environ.get('NSUB', 1))
+m = mc.compile_xml(common.read_model(name + '.xml'))
+caps = dict(common.DEFAULT_CAPS.get(name, {}))
+caps.pop('precision', None)
+
+
+def rel(qg, qo):
+  return np.abs(qg - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))
+
+
+q = np.tile(m.qpos0, (NE, 1))
+if name == 'cheetah':
+  lim = m.jnt_limited == 1
+  lo, hi = m.jnt_range[lim].T
+  for e in range(NE):
+    q[e, lim] = np.random.RandomState(e).uniform(lo, hi)
+else:
+  rs0 = np.random.RandomState(7)
+  q[:, 7:] += rs0.uniform(-0.1, 0.1, (NE, m.nq - 7))
+b = BatchedPhysics(m, NE, precision=PREC, **caps)
+tf = BatchedPhysics(m, NE, precision=PREC, **caps)
+b.set('qpos', q)
+refs = []
+for e in range(NE):
+  p = oracle.OraclePhysics(m)
+  p.qpos[:] = q[e]
+  p.forward()
+  refs.append(p)
+nthreads = min(os.cpu_count() or 1, NE)
+shards = [list(range(i, NE, nthreads)) for i in range(nthreads)]
+
+
+def cpu_steps(acts):
+  def work(idx):
+    oracle.rollout_legacy([refs[i] for i in idx], np.ascontiguousarray(acts[:, idx]), nsub)
+  with ThreadPoolExecutor(nthreads) as ex:
+    list(ex.map(work, shards))
+
+
+settle = 200 if name == 'cheetah' else 0
+if settle:
+  b.step(settle)
+  cpu_steps(np.zeros((settle, NE, m.nu)))
+  b.set('time', np.zeros((NE, 1)))
+rs = np.random.RandomState(0)
+acts = rs.uniform(-1, 1, (T, NE, m.nu)).astype(np.float32).astype(np.float64)
+open_loop = rel(b.get('qpos'), np.stack([p.qpos for p in refs]))
+forced = np.zeros(NE)
+first_over = np.full(NE, -1)
+for t in range(T):
+  qo = np.stack([p.qpos for p in refs]); vo = np.stack([p.qvel for p in refs]); wo = np.stack([p.qacc_warmstart for p in refs])
+  tf.set('qpos', qo); tf.set('qvel', vo); tf.set('qacc_warmstart', wo)
+  if m.na:
+    tf.set('act', np.stack([p.act for p in refs]))
+  tf.set_control(acts[t]); tf.step(nsub)
+  b.set_control(acts[t]); b.step(nsub)
+  cpu_steps(acts[t:t + 1])
+  qo = np.stack([p.qpos for p in refs])
+  forced = np.maximum(forced, rel(tf.get('qpos'), qo))
+  err = rel(b.get('qpos'), qo)
+  open_loop = np.maximum(open_loop, err)
+  newly = (open_loop > 1e-4) & (first_over < 0)
+  first_over[newly] = t
+pct = lambda a: {str(p): float(np.percentile(a, p)) for p in (50, 90, 95, 99, 100)}
+tail = [dict(env=int(e), open_loop=float(open_loop[e]), teacher_forced=float(forced[e]), first_step_over_1e4=int(first_over[e]))
+        for e in np.argsort(-open_loop)[:16]]
+out = dict(model=name, precision=PREC, envs=NE, steps=T, nsub=nsub, open_loop=pct(open_loop), teacher_forced=pct(forced),
+           frac_open_loop_le_1e4=float(np.mean(open_loop <= 1e-4)), worst_envs=tail,
+           warnings=b.get('warning').sum(axis=0).tolist(), info=b.info())
+print(json.dumps(out))
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'parity_dist_%s_f%d.json' % (name, PREC)), 'w'), indent=1)

@@ -19,6 +19,8 @@ def dense_M(m, get):
   """(nv*nv,) dense symmetric mass matrix from the sparse qM scratch."""
   nv = m.nv
   qM = np.asarray(get('qM'))
+  if nv <= 16:      # small models keep M dense (StepDims.msparse == 0)
+    return qM[:nv*nv].copy()
   M = np.zeros((nv, nv))
   p = 0
   for i in range(nv):
@@ -60,7 +62,7 @@ def dense_J(m, get, kmax):
         J[r, ident] = 1.0
       else:
         assert t == EFC_LIMIT
-        J[r, int(m.jnt_dofadr[ident >> 1])] = -1.0 if ident & 1 else 1.0
+        J[r, ident >> 1] = -1.0 if ident & 1 else 1.0
     elif r < c0:
       k = s0 + (r - tl0)
       J[r] = Jd[k*nv:(k + 1)*nv]
