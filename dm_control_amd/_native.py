@@ -14,7 +14,7 @@ EXPORTS = [
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
     'dmc_batch_set_model_real',
-    'dmc_batch_sync', 'dmc_batch_info', 'dmc_batch_time_steps',
+    'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_info', 'dmc_batch_time_steps',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get',
 ]
@@ -65,6 +65,7 @@ def lib():
   L.dmc_batch_set_opt_real.argtypes = [vp, cs, cd]
   L.dmc_batch_set_model_real.argtypes = [vp, cs, vp, ci]
   L.dmc_batch_sync.argtypes = [vp]
+  L.dmc_batch_invalidate.argtypes = [vp]
   L.dmc_batch_info.argtypes = [vp, vp]
   L.dmc_batch_time_steps.argtypes = [vp, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
   L.dmc_batch_debug_enable.argtypes = [vp, ci]

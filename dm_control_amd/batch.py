@@ -62,11 +62,11 @@ class BatchedPhysics:
 
   # -- info ---------------------------------------------------------------------
   def info(self):
-    a = np.zeros(16, dtype=np.int32)
+    a = np.zeros(18, dtype=np.int32)
     _native.check(_native.lib().dmc_batch_info(self._ptr, a.ctypes.data))
     keys = ['B', 'precision', 'lanes_per_env', 'waves_per_block', 'envs_per_block',
             'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes', 'static_id',
-            'jac_kmax', 'table_lds_bytes', 'envs_per_cu', 'njdense', 'njcon']
+            'jac_kmax', 'table_lds_bytes', 'envs_per_cu', 'njdense', 'njcon', 'stash', 'stash_bytes_per_env']
     return dict(zip(keys, (int(x) for x in a)))
 
   def _rows(self, name):
@@ -114,7 +114,7 @@ class BatchedPhysics:
 
   def set_opt(self, name, value):
     L = _native.lib()
-    if isinstance(value, (int, np.integer)) and name in ('disableflags', 'iterations', 'ls_iterations'):
+    if isinstance(value, (int, np.integer, bool)) and name in ('disableflags', 'iterations', 'ls_iterations', 'noslip_iterations', 'stash'):
       _native.check(L.dmc_batch_set_opt_int(self._ptr, name.encode(), int(value)))
     else:
       _native.check(L.dmc_batch_set_opt_real(self._ptr, name.encode(), float(value)))
@@ -151,6 +151,10 @@ class BatchedPhysics:
 
   def sync(self):
     _native.check(_native.lib().dmc_batch_sync(self._ptr))
+
+  def invalidate(self):
+    """Call after writing qpos / qvel / act through memory bound with `bind` (see dmc_batch_invalidate)."""
+    _native.check(_native.lib().dmc_batch_invalidate(self._ptr))
 
   def time_steps(self, nstep, reps, stream=None):
     ms = ctypes.c_float()

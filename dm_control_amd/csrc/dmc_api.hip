@@ -62,6 +62,9 @@ struct dmc_batch {
   int* d_debug_i;
   long long* d_prof;
   size_t elem;  // sizeof(T)
+  // per-env stash of the position / velocity stage between legacy steps (StepIO::stash_*); epoch: bumped by every
+  // host-side edit that can change what the stage depends on, which invalidates all stashes at once
+  void* d_stash_r; int* d_stash_i; int stash_epoch; int stash_on;
 };
 
 extern "C" const char* dmc_last_error(void) { return g_err.c_str(); }
@@ -144,7 +147,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
@@ -182,6 +185,8 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
     b->fields.push_back(f);
   }
   *out = b;
+  // small models: keep the position / velocity stage between legacy steps in HBM (auto; "stash" option overrides)
+  if (L.n_keep + L.n_si <= 4096 && !getenv("DMC_NO_STASH")) { if (dmc_batch_set_opt_int(b, "stash", 1)) { dmc_batch_destroy(b); *out = nullptr; return -2; } }
   return dmc_batch_reset(b, nullptr, -1);
 }
 
@@ -196,6 +201,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_debug) (void)hipFree(b->d_debug);
   if (b->d_debug_i) (void)hipFree(b->d_debug_i);
   if (b->d_prof) (void)hipFree(b->d_prof);
+  if (b->d_stash_r) (void)hipFree(b->d_stash_r);
+  if (b->d_stash_i) (void)hipFree(b->d_stash_i);
   delete b;
 }
 
@@ -215,6 +222,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->ncon = (int*)P("ncon"); io->nefc = (int*)P("nefc"); io->solver_iter = (int*)P("solver_iter");
   io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
+  io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
 }
 
 struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsub; };
@@ -280,6 +288,7 @@ static int get_real(dmc_batch* b, Field* f, double* dst) {
 static int set_real(dmc_batch* b, Field* f, const double* src) {
   const size_t n = (size_t)f->rows * b->B;
   if (!n) return 0;
+  if (f->name != "ctrl" && f->name != "qfrc_applied") b->stash_epoch++;   // inputs of the acceleration stage only
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
   if (b->precision == 64 || f->is_f64) {
@@ -348,16 +357,36 @@ extern "C" int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr) 
   Field* f = find_field(b, name);
   if (!f) return fail(std::string("unknown field: ") + name);
   f->dev = device_ptr ? device_ptr : f->owned;
+  if (f->name != "ctrl" && f->name != "qfrc_applied") b->stash_epoch++;
+  return 0;
+}
+extern "C" int dmc_batch_invalidate(dmc_batch* b) {
+  if (!b) return fail("null batch");
+  b->stash_epoch++;
   return 0;
 }
 extern "C" int dmc_batch_set_output_mask(dmc_batch* b, int mask) {
   if (!b) return fail("null batch");
+  b->stash_epoch++;
   b->outmask = mask;
   return 0;
 }
 extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) {
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
+  b->stash_epoch++;
+  if (!strcmp(name, "stash")) {
+    if (value && !b->d_stash_r) {
+      const StepLayout& L = b->tb.L;
+      HIP_TRY(hipSetDevice(b->device));
+      const size_t nr = (size_t)std::max(1, L.n_keep) * b->B * b->elem, ni = (size_t)(L.n_si + 4) * b->B * sizeof(int);
+      HIP_TRY(hipMalloc(&b->d_stash_r, nr));
+      HIP_TRY(hipMalloc((void**)&b->d_stash_i, ni));
+      HIP_TRY(hipMemset(b->d_stash_i, 0, ni));
+    }
+    b->stash_on = value ? 1 : 0;
+    return 0;
+  }
   if (!strcmp(name, "disableflags")) {
     if (b->tb.has_unsupported_pairs && !(value & (DMC_DSBL_CONTACT | DMC_DSBL_CONSTRAINT)))
       return fail("cannot enable contacts: the model has geom pair types the collision kernel does not implement");
@@ -375,6 +404,7 @@ extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) 
 extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value) {
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
+  b->stash_epoch++;
   if (!strcmp(name, "timestep")) o.timestep = value;
   else if (!strcmp(name, "tolerance")) o.tolerance = value;
   else if (!strcmp(name, "ls_tolerance")) o.ls_tolerance = value;
@@ -408,6 +438,7 @@ extern "C" int dmc_batch_set_model_real(dmc_batch* b, const char* name, const do
     if (strcmp(name, s.name)) continue;
     if (count != s.cnt) return fail(std::string("wrong element count for model field ") + name);
     for (int i = 0; i < count; i++) b->tb.mr[s.off + i] = values[i];
+    b->stash_epoch++;
     if (!strcmp(name, "dof_damping")) {
       b->tb.opts.any_damping = 0;
       for (int i = 0; i < count; i++) { if (values[i] < 0) return fail("negative dof_damping"); if (values[i] > 0) b->tb.opts.any_damping = 1; }
@@ -461,7 +492,7 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[11] = L.d.kmax;
   info[12] = b->geom.lds_bytes - b->geom.envs_per_block * info[9];
   { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 32) blocks = 32 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }
-  info[14] = L.d.njdense; info[15] = L.d.njcon;
+  info[14] = L.d.njdense; info[15] = L.d.njcon; info[16] = b->stash_on; info[17] = (int)((size_t)L.n_keep * b->elem + (size_t)(L.n_si + 4) * sizeof(int));
   return 0;
 }
 

@@ -79,6 +79,10 @@ struct StepIO {
   int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
+  // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
+  // legacy Physics.step() and the mj_step2 that begins the next): env-major, (B, n_keep) reals and (B, n_si + 4)
+  // ints whose first word is the epoch the stash was written in (valid iff equal to stash_epoch)
+  T* stash_r; int* stash_i; int stash_epoch;
   long long* prof;   // optional (DMC_PROFILE builds): (PROF_N, B) cycle counters
   T* debug;      // optional: (n_sr, ndebug) dump of the env scratch after forward
   int* debug_i;  // optional: (n_si, ndebug)
@@ -528,7 +532,28 @@ struct StepCore {
     return env;
   }
   // ---- state I/O (SoA in HBM <-> LDS) --------------------------------------
-  DMC_DEV void load_state(const StepIO<T>& io, int env) {
+  // the per-env stash: everything the stages keep in LDS (persistent reals + all ints), env-major in HBM
+  DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
+    env = late(env);
+    const int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
+    if (hi[0] != io.stash_epoch) return false;      // group-uniform: never written, or written before the last host edit
+    const T* hr = io.stash_r + (size_t)env*L.n_keep;
+    FOR_LANES(i, L.n_keep) s[i] = hr[i];
+    FOR_LANES(i, L.n_si) si[i] = hi[4 + i];
+    DMC_WSYNC();
+    return true;
+  }
+  DMC_DEV void store_stash(const StepIO<T>& io, int env, bool valid) {
+    env = late(env);
+    int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
+    if (valid) {
+      T* hr = io.stash_r + (size_t)env*L.n_keep;
+      FOR_LANES(i, L.n_keep) hr[i] = s[i];
+      FOR_LANES(i, L.n_si) hi[4 + i] = si[i];
+    }
+    if (lane == 0) hi[0] = valid ? io.stash_epoch : 0;
+  }
+  DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash) {
     const int B = io.B;
     FOR_LANES(i, L.d.nq) S(qpos)[i] = io.qpos[(size_t)i*B + env];
     FOR_LANES(i, L.d.nv) {
@@ -539,6 +564,11 @@ struct StepCore {
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
     if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = io.act[(size_t)i*B + env]; S(act_dot)[i] = 0; }
     time_ = io.time[env];
+    if (have_stash) {      // the derived arrays come from the stash; only this launch's warning counters start at zero
+      if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
+      DMC_WSYNC();
+      return;
+    }
     if (lane == 0) {
       for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
       SI(imisc)[IM_NCON] = 0; SI(imisc)[IM_NEFC] = 0; SI(imisc)[IM_ITER] = 0;
@@ -3155,7 +3185,7 @@ struct StepCore {
     time_ = 0;
     DMC_WSYNC();
   }
-  DMC_DEV void check_pos_vel() {
+  DMC_DEV bool check_pos_vel() {
     int badp = 0, badv = 0;
     FOR_LANES(i, L.d.nq) if (t_bad(S(qpos)[i])) badp = 1;
     badp = group_max<LPE>(badp);
@@ -3163,6 +3193,7 @@ struct StepCore {
     FOR_LANES(i, L.d.nv) if (t_bad(S(qvel)[i])) badv = 1;
     badv = group_max<LPE>(badv);
     if (badv) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQVEL]++; if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); } }
+    return (badp || badv) && !(o.disableflags & DMC_DSBL_AUTORESET);
   }
   DMC_DEV bool bad_acc() {
     int bad = 0;
@@ -3245,9 +3276,16 @@ struct StepCore {
   //           per-step results written to (T, rows, B) sequence buffers -- legacy ordering
   //           (mj_step2 ... mj_step1) with NO redundant pass: the mj_step1 that closes
   //           env-step t is the position/velocity stage that opens env-step t+1.
+  // With a stash (io.stash_r != null) a legacy Physics.step() does exactly the reference's work split
+  // (engine.py:147-162): mj_step2 on the position / velocity stage the previous call's mj_step1 left behind
+  // (reloaded from HBM instead of recomputed), ..., then a FULL mj_step1 whose results are stashed for the next
+  // call.  Without one the opening stage is recomputed and the trailing mj_step1 only evaluates the outputs.
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub) {
     prof_begin();
-    load_state(io, env);
+    const bool stash = io.stash_r != nullptr;
+    bool have = false;
+    if (stash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) have = load_stash(io, env);
+    load_state(io, env, have);
     DMC_PROF(PROF_LOAD);
     const bool stepping = mode == 0 || mode == 3;
     const int ntotal = mode == 3 ? nstep*nsub : nstep;
@@ -3255,10 +3293,11 @@ struct StepCore {
     // passes (+ the trailing mj_step1 pass for legacy_step), or one pass for mj_forward
     const int npass = !stepping ? 1 : ntotal + ((legacy || mode == 3) ? 1 : 0);
     for (int it = 0; it < npass; it++) {
-      const bool partial = stepping && it == ntotal;
-      if (mode == 3 && !partial && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
-      if (stepping) check_pos_vel();
-      const int nstage = (stepping && !partial && o.integrator == DMC_INT_RK4) ? 4 : 1;
+      const bool trailing = stepping && it == ntotal;
+      const bool partial = trailing && !(stash && mode == 0);
+      if (mode == 3 && !trailing && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
+      if (stepping) { if (check_pos_vel()) have = false; }
+      const int nstage = (stepping && !trailing && o.integrator == DMC_INT_RK4) ? 4 : 1;
       // Sensor values are overwritten by every step, so only the passes whose sensordata can be
       // read afterwards evaluate them: position/velocity sensors in the last pass of a launch and
       // at env-step boundaries of a rollout, acceleration sensors in the pass before those.
@@ -3266,9 +3305,9 @@ struct StepCore {
       const bool sens_acc = !stepping || it == ntotal - 1 || (mode == 3 && (it + 1) % nsub == 0);
       int stage = 0, retried = 0;
       while (stage < nstage) {
-        call_posvel(partial, outmask, stage > 0 || !sens_pv);
+        if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
-        if (partial) break;
+        if (trailing) break;
         call_acc(mode == 2, stage > 0 || !sens_acc);
         if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
@@ -3278,12 +3317,15 @@ struct StepCore {
         if (nstage > 1) rk4_stage(stage);
         stage++;
       }
-      if (!stepping || partial) break;
+      if (!stepping || trailing) break;
       if (nstage > 1) rk4_finish(); else call_euler();
       DMC_PROF(PROF_EULER);
     }
     if (!stepping) dump_debug(io, env);
     if (!stepping || legacy || mode == 3) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
+    // the stash holds a complete position / velocity stage at the CURRENT state only after a legacy step (after an
+    // mj_forward the Cholesky buffer holds the factor of H, not of M; a non-legacy mj_step ends before mj_step1)
+    if (stash) store_stash(io, env, mode == 0 && legacy);
     store_state(io, env);
     DMC_PROF(PROF_STORE);
     prof_end(io, env);

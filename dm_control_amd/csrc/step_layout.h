@@ -210,6 +210,7 @@ struct StepLayout {
 #undef X
   int n_mi, n_mr, n_mc;    // table sizes (elements)
   int n_sr, n_si;          // per-env scratch sizes (elements)
+  int n_keep;              // reals before the overlay region: what survives a stage (the per-env stash in HBM)
 };
 
 // scalar options broadcast to every wave
@@ -242,6 +243,8 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #define X(name, cnt) L->s_##name = o; o += (cnt);
   STEP_SCRATCH_REAL(X)
 #undef X
+  o = (o + 3) & ~3;
+  L->n_keep = o;
   {
     const int base = o;
     int top = base;

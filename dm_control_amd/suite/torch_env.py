@@ -144,6 +144,7 @@ class TorchBatchedEnv:
     self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
     if self.model.na:
       self.act.copy_(torch.where(m2, torch.zeros_like(self.act), self.act))
+    self.physics.invalidate()      # qpos / qvel were edited through the bound tensors
     if self._OUTPUTS:
       # forward is a pure function of (qpos, qvel): recomputing it for the environments that
       # were not reset reproduces the derived arrays they already hold; their solver warm start

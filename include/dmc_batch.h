@@ -107,9 +107,18 @@ int dmc_batch_set_model_real(dmc_batch* b, const char* name, const double* value
 
 int dmc_batch_sync(dmc_batch* b);
 
-/* info[0..15] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
+/* Between the mj_step1 that ends one legacy Physics.step() and the mj_step2 that begins the next
+ * (dm_control/mujoco/engine.py:147-162) the reference keeps the position / velocity stage in mjData.
+ * The batch keeps it in a per-environment stash in HBM (option "stash": dmc_batch_set_opt_int; on by
+ * default for small models), so that a legacy step launch does not recompute it.  Every entry point of this
+ * library that edits state, model or options invalidates the stash itself.  A caller that writes qpos / qvel /
+ * act through memory it bound with dmc_batch_bind must call this afterwards (the reference's equivalent:
+ * derived quantities are stale until mj_forward is run). */
+int dmc_batch_invalidate(dmc_batch* b);
+
+/* info[0..17] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
  * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id,
- * jac_kmax, table_lds_bytes, envs_per_cu, njdense, njcon}
+ * jac_kmax, table_lds_bytes, envs_per_cu, njdense, njcon, stash_on, stash_bytes_per_env}
  * (static_id >= 0: a model-specialised kernel instantiation is in use; jac_kmax: entries per
  * compressed contact Jacobian row; envs_per_cu: environments resident on one CU under the
  * 160 KiB LDS budget). */

@@ -16,6 +16,9 @@ struct Emu {
   HostModel hm;
   StepTables tb;
   std::vector<float> mr32;
+  // optional stash of the position / velocity stage between legacy steps (one environment)
+  int stash_on = 0, stash_epoch = 1;
+  std::vector<double> stash_r64; std::vector<float> stash_r32; std::vector<int> stash_i;
 };
 
 static std::string g_err;
@@ -35,6 +38,8 @@ int emu_dims(void* h, int* out) {
   out[0] = L.n_sr; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr; out[6] = L.d.kmax; out[7] = L.n_mc;
   return 0;
 }
+void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
+void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
 int emu_find(void* h, const char* name, int* off, int* cnt, int* kind) { return step_layout_find(&((Emu*)h)->tb.L, name, off, cnt, kind); }
 
 }  // extern "C"
@@ -68,6 +73,8 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.contact_force = buf[24].data(); io.cvel = buf[25].data(); io.act = buf[26].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
+  io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
+  if (e->stash_on) { io.stash_r = sizeof(T) == 8 ? (T*)e->stash_r64.data() : (T*)e->stash_r32.data(); io.stash_i = e->stash_i.data(); }
   DynLayoutSrc ls; ls.p = &L;
   StepCore<T, 1> core(ls, o, e->tb.mi.data(), mr, e->tb.mc.data(), s.data(), si.data(), 0);
   core.run(io, 0, nstep, legacy, mode, OUT_ALL, 1);

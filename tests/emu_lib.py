@@ -31,6 +31,8 @@ def lib():
     L.emu_create.restype = ctypes.c_void_p
     L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.emu_free.argtypes = [ctypes.c_void_p]
+    L.emu_stash.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.emu_invalidate.argtypes = [ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
     L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -83,6 +85,13 @@ class EmuPhysics:
     pf = (ctypes.c_void_p * len(FIELDS))(*[self.f[n].ctypes.data for n in FIELDS])
     pi = (ctypes.c_void_p * len(IFIELDS))(*[self.fi[n].ctypes.data for n in IFIELDS])
     lib().emu_run(self.h, self.prec, pf, pi, nstep, legacy, mode, self.dbg.ctypes.data, self.dbgi.ctypes.data)
+
+  def stash(self, on=True):
+    """Keeps the position / velocity stage between legacy steps (the HBM stash of the GPU batch)."""
+    lib().emu_stash(self.h, int(on))
+
+  def invalidate(self):
+    lib().emu_invalidate(self.h)
 
   def step(self, nstep=1, legacy=True):
     self._run(nstep, int(legacy), 0)

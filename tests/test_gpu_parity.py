@@ -652,3 +652,91 @@ def test_random_models_match_oracle(seed, ellipsoids, noslip):
   np.testing.assert_allclose(b.get('sensordata'), so, rtol=0, atol=1e-5 * max(1.0, np.abs(so).max()))
   np.testing.assert_array_equal(b.get('warning').sum(axis=0), np.sum([o.warning for o in ora], axis=0))
   b.close()
+
+
+# ---- the HBM stash of the position / velocity stage between legacy steps --------------------------
+@pytest.mark.parametrize('name,precision,lanes', [('cheetah', 32, 32), ('cheetah', 64, 16), ('cartpole', 32, 32),
+                                                  ('hopper', 32, 32), ('humanoid', 32, 64)])
+def test_stash_between_legacy_steps_is_bit_identical_on_gpu(name, precision, lanes):
+  """What mjData keeps between the mj_step1 that ends one legacy Physics.step() and the mj_step2 that begins
+  the next (engine.py:147-162) is kept in a per-env HBM stash; a launch that reloads it must produce the very
+  same bits as one that recomputes the stage, and every state edit must invalidate it."""
+  import torch
+  m = _model(name)
+  B, T = 37, 60
+  rs = np.random.RandomState(3)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, -3:] += rs.uniform(-.2, .2, (B, 3))
+  a, b = _batch(m, B, precision=precision, lanes_per_env=lanes), _batch(m, B, precision=precision, lanes_per_env=lanes)
+  a.set_opt('stash', 0)
+  b.set_opt('stash', 1)
+  assert a.info()['stash'] == 0 and b.info()['stash'] == 1
+  td = torch.float32 if precision == 32 else torch.float64
+  qdev = torch.zeros((m.nq, B), dtype=td, device='cuda')
+  for e in (a, b):
+    e.set('qpos', q)
+  for t in range(T):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    for e in (a, b):
+      e.set_control(c)
+      e.step(1 + t % 3)
+    for f in ('qpos', 'qvel', 'sensordata', 'xpos', 'qacc_warmstart', 'time'):
+      np.testing.assert_array_equal(a.get(f), b.get(f), err_msg='%s at step %d' % (f, t))
+    if t == 20:        # edit through the C-ABI: invalidates by itself
+      for e in (a, b):
+        e.set('qvel', np.zeros((B, m.nv)))
+    if t == 30:        # masked reset of some environments
+      mask = (np.arange(B) % 3 == 0).astype(np.int32)
+      for e in (a, b):
+        e.reset(mask)
+    if t == 40:        # edit through bound device memory: the caller must invalidate
+      qdev.copy_(torch.from_numpy(np.ascontiguousarray(q.T)).to(td))
+      for e in (a, b):
+        e.sync()
+        e.bind('qpos', qdev.data_ptr())
+        e.invalidate()
+        e.step()
+        e.sync()
+        got = e.get('qpos')
+        e.bind('qpos', 0)
+        e.set('qpos', got)
+  assert np.abs(a.get('qpos') - q).max() > 1e-3
+  a.close(); b.close()
+
+
+# ---- equality constraints between bodies and joints on the HIP path --------------------------------
+@pytest.mark.parametrize('precision,tol,lanes', [(64, 1e-10, 64), (64, 1e-10, 16), (32, 5e-4, 32)])
+def test_connect_weld_joint_equalities_match_oracle_on_gpu(precision, tol, lanes):
+  """connect (3 rows), weld (6 rows incl. the quaternion-error rows) and joint-coupling equalities through the
+  C-ABI against the oracle (the host-build twin of this test: tests/test_kernel_logic_emu.py)."""
+  import test_oracle_kat as kat
+  from oracle.oracle import OraclePhysics
+  scenes = [kat._EQ_CHAIN,
+            """<mujoco><option timestep="0.002"/><worldbody><geom type="plane" size="2 2 .1"/>
+               <body name="box" pos=".3 .1 .7" quat=".8 .2 .4 .1"><freejoint/><geom type="box" size=".1 .05 .02" mass="2"/></body>
+               <body name="b2" pos=".6 .1 .7"><freejoint/><geom type="sphere" size=".05"/></body>
+               <body name="bob" pos="0 0 1"><freejoint/><geom type="sphere" size=".02" mass="1"/></body></worldbody>
+               <equality><weld body1="box" body2="b2" anchor="-.15 0 0"/><connect body1="bob" anchor="0 0 .5" solref="0.004 1"/></equality></mujoco>"""]
+  for xml in scenes:
+    m = mc.compile_xml(xml)
+    B = 5
+    rs = np.random.RandomState(1)
+    v = rs.uniform(-.5, .5, (B, m.nv))
+    b = _batch(m, B, precision=precision, lanes_per_env=lanes)
+    b.set('qvel', v)
+    refs = []
+    for e in range(B):
+      o = OraclePhysics(m)
+      o.qvel[:] = v[e]
+      o.forward()
+      refs.append(o)
+    b.forward()
+    assert (b.get('nefc')[:, 0] == [o.nefc for o in refs]).all() and refs[0].nefc >= 9
+    for _ in range(300):
+      b.step()
+      for o in refs:
+        o.step()
+    qo = np.stack([o.qpos for o in refs])
+    np.testing.assert_allclose(b.get('qpos'), qo, rtol=0, atol=tol)
+    assert not b.get('warning').any()
+    b.close()

@@ -451,3 +451,35 @@ def test_connect_weld_joint_equalities_match_oracle(prec, tol):
       e.step()
     np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol)
     assert not o.warning.any() and not e.warning.any()
+
+
+@pytest.mark.parametrize('asset', ['cheetah', 'humanoid', 'cartpole', 'quadruped'])
+def test_stash_between_legacy_steps_is_bit_identical(asset):
+  """The stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one legacy
+  Physics.step() and the mj_step2 that begins the next, engine.py:147-162) must not change a single bit of
+  the trajectory; editing the state invalidates it."""
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    m = mc.compile_xml(f.read())
+  a, b = EmuPhysics(m, 64), EmuPhysics(m, 64)
+  b.stash(True)
+  rs = np.random.RandomState(2)
+  q = m.qpos0.copy()
+  if asset != 'cartpole':
+    q[-4:] += rs.uniform(-.2, .2, 4)
+  for e in (a, b):
+    e.qpos[:] = q
+  for t in range(60):
+    c = rs.uniform(-1, 1, m.nu)
+    for e in (a, b):
+      e.ctrl[:] = c
+      e.step(1 + t % 3)
+    np.testing.assert_array_equal(a.qpos, b.qpos, err_msg='step %d' % t)
+    np.testing.assert_array_equal(a.qvel, b.qvel)
+    np.testing.assert_array_equal(a.sensordata, b.sensordata)
+    np.testing.assert_array_equal(a.xpos, b.xpos)
+    if t == 30:      # a host edit of the state: the stash is stale and must be ignored
+      for e in (a, b):
+        e.qpos[:] = q
+        e.qvel[:] = 0
+      b.invalidate()
+  assert np.abs(a.qpos - q).max() > 1e-3
