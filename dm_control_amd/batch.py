@@ -164,7 +164,7 @@ class BatchedPhysics:
 
   PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
                 'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
-                'euler', 'trailing_step1', 'store']
+                'euler', 'trailing_step1', 'store', 'noslip', 'sol_hess', 'sol_factor', 'sol_solve', 'ls_setup']
 
   def prof_enable(self, on=True):
     _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))

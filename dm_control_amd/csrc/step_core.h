@@ -54,7 +54,8 @@ namespace dmc {
 #define DMC_PROF(id) ((void)0)
 #endif
 enum { PROF_LOAD = 0, PROF_KIN, PROF_COM, PROF_CRB, PROF_COLL, PROF_CONSTR, PROF_COMVEL, PROF_RNE, PROF_SENS, PROF_ACT,
-       PROF_ACC, PROF_SOL_INIT, PROF_SOL_GRAD, PROF_SOL_LS, PROF_SOL_UPD, PROF_EULER, PROF_TRAIL, PROF_STORE, PROF_N };
+       PROF_ACC, PROF_SOL_INIT, PROF_SOL_GRAD, PROF_SOL_LS, PROF_SOL_UPD, PROF_EULER, PROF_TRAIL, PROF_STORE,
+       PROF_NOSLIP, PROF_HESS, PROF_FACTOR, PROF_SOLVE, PROF_LS_SETUP, PROF_N };
 
 // output selection bits (which derived arrays a launch writes back to HBM)
 enum {
@@ -2738,10 +2739,14 @@ struct StepCore {
     constraint_force_to_joint(nefc);
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
-    if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); return; }
+    DMC_PROF(PROF_SOL_GRAD);
+    if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
     hess_assemble(nefc, row_map());
+    DMC_PROF(PROF_HESS);
     chol_factor_inplace(S(qLH), nv);
+    DMC_PROF(PROF_FACTOR);
     chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+    DMC_PROF(PROF_SOLVE);
   }
   typedef dmc::LSPoint<T> LSPoint;
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
@@ -2777,6 +2782,7 @@ struct StepCore {
     const T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
     const int lsmax = o.ls_iterations;
     int evals = 0;
+    DMC_PROF(PROF_LS_SETUP);
     LSPoint p0, p1, p2, pmid, p1next, p2next;
     p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals);
     p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals);
@@ -3085,8 +3091,9 @@ struct StepCore {
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
     DMC_WSYNC();
     // the warm start keeps the main solver's solution; noslip then edits qacc / efc_force
-    if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
     DMC_PROF(PROF_SOL_UPD);
+    if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
+    DMC_PROF(PROF_NOSLIP);
   }
 
   // ---- integration (mj_Euler with implicit joint damping) ---------------------------------

@@ -109,8 +109,9 @@ int dmc_batch_sync(dmc_batch* b);
 
 /* Between the mj_step1 that ends one legacy Physics.step() and the mj_step2 that begins the next
  * (dm_control/mujoco/engine.py:147-162) the reference keeps the position / velocity stage in mjData.
- * The batch keeps it in a per-environment stash in HBM (option "stash": dmc_batch_set_opt_int; on by
- * default for small models), so that a legacy step launch does not recompute it.  Every entry point of this
+ * The batch keeps it in a per-environment stash in HBM (option "stash": dmc_batch_set_opt_int; off by
+ * default: on MI355X recomputing the outputs of that stage is cheaper than the stash traffic), so that a legacy
+ * step launch does not recompute it.  Every entry point of this
  * library that edits state, model or options invalidates the stash itself.  A caller that writes qpos / qvel /
  * act through memory it bound with dmc_batch_bind must call this afterwards (the reference's equivalent:
  * derived quantities are stale until mj_forward is run). */

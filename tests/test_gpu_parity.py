@@ -666,13 +666,14 @@ def test_stash_between_legacy_steps_is_bit_identical_on_gpu(name, precision, lan
   B, T = 37, 60
   rs = np.random.RandomState(3)
   q = np.tile(m.qpos0, (B, 1))
-  q[:, -3:] += rs.uniform(-.2, .2, (B, 3))
+  k = min(3, m.nq)
+  q[:, -k:] += rs.uniform(-.2, .2, (B, k))
   a, b = _batch(m, B, precision=precision, lanes_per_env=lanes), _batch(m, B, precision=precision, lanes_per_env=lanes)
   a.set_opt('stash', 0)
   b.set_opt('stash', 1)
   assert a.info()['stash'] == 0 and b.info()['stash'] == 1
   td = torch.float32 if precision == 32 else torch.float64
-  qdev = torch.zeros((m.nq, B), dtype=td, device='cuda')
+  qdevs = [torch.zeros((m.nq, B), dtype=td, device='cuda') for _ in range(2)]
   for e in (a, b):
     e.set('qpos', q)
   for t in range(T):
@@ -690,8 +691,8 @@ def test_stash_between_legacy_steps_is_bit_identical_on_gpu(name, precision, lan
       for e in (a, b):
         e.reset(mask)
     if t == 40:        # edit through bound device memory: the caller must invalidate
-      qdev.copy_(torch.from_numpy(np.ascontiguousarray(q.T)).to(td))
-      for e in (a, b):
+      for e, qdev in zip((a, b), qdevs):
+        qdev.copy_(torch.from_numpy(np.ascontiguousarray(q.T)).to(td))
         e.sync()
         e.bind('qpos', qdev.data_ptr())
         e.invalidate()
