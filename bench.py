@@ -1,17 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the batched physics step (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2): suite 'cheetah run',
-batch 4096 per GPU, fp32, random actions U(-1,1)^6 generated once and resident
-in HBM.  One "step" = one `Physics.step()` over the whole batch = ONE launch of
-the fused HIP kernel (n_sub_steps = 1 for cheetah, suite/cheetah.py:48), with
-legacy_step semantics (engine.py:147-162).  Initial states follow
-Cheetah.initialize_episode (suite/cheetah.py:63-76): limited joints ~ U(range),
-200 settle steps with zero control, time = 0 (untimed).
+    python bench.py [--config {2,3,4,5}] [--gpus N] [--steps K] [--warmup W]
 
-N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and
-the max-over-ranks timing; environments are independent, so there is no
-data-path collective) -- weak scaling, 4096 envs per GPU.
+Workloads = BASELINE.json configs; the default is config 2, the one the metric is quoted on:
+
+  2  suite 'cheetah run', batch 4096, fp32, 1 physics step per env-step (suite/cheetah.py:48); start states as
+     Cheetah.initialize_episode (suite/cheetah.py:63-76): limited joints ~ U(range), 200 settle steps, time = 0
+  3  suite 'humanoid stand', batch 4096, 5 physics steps per env-step (suite/humanoid.py:30,55); start states by
+     rejection until ncon == 0 (suite/humanoid.py:160-165)
+  4  locomotion CMU humanoid (2019, position-controlled) on the Floor arena, 6 physics steps per env-step
+     (locomotion/examples/basic_cmu_2019.py:110-111), batch 4096 PER GPU (32768 over 8); upright start pose at a
+     uniform position of the arena (tasks/go_to_target.py:139-165)
+  5  locomotion.soccer 2v2 BoxHead, 5 physics steps per env-step (soccer/task.py:105-106), batch 256 PER GPU
+     (2048 over 8); players and ball spread over the pitch (soccer/initializers.py)
+
+Actions are U(-1, 1)^nu, generated once and resident in HBM.  One "step" = one `Physics.step(n_sub_steps)` over the
+whole batch = ONE launch of the fused HIP kernel with legacy_step semantics (engine.py:147-162).
+
+N > 1: one process per GPU, environments sharded in contiguous ranges (dm_control_amd/sharding.py); the physics has
+no data-path collective, `value` is measured with every rank stepping its shard from actions resident on its own
+GPU (weak scaling).  The agent-interface exchange (actions scattered from rank 0, observations gathered to every
+rank over RCCL) is timed as a separate leg and reported under "collectives".
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,89 +36,238 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_STEP = 260          # cheetah fp32 SoA, state + ctrl in, state + sensordata out
-PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
-BATCH_PER_GPU = 4096
+SIMDS = 1024                       # 256 CUs x 4 SIMDs
+METRIC = 'env-steps/s (whole node) at batch 4096; max rel qpos error vs CPU'
+
+# algo_bytes: SURVEY.md 8(d) compulsory bytes per env per launch, fp32 SoA with the state kept on chip across the
+# substeps: 4 [ (nq + nv + nv_warm + nu) read + (nq + nv + nv_warm + nsensordata) written ] + 8 (time)
+CONFIGS = {
+    2: dict(asset='cheetah', nsub=1, batch=4096, algo_bytes=260, outputs=('sensor',), parity_envs=64, parity_steps=200,
+            workload="suite 'cheetah run'"),
+    3: dict(asset='humanoid', nsub=5, batch=4096, algo_bytes=1012, outputs=('sensor', 'xpos', 'xmat', 'subtree_com'),
+            parity_envs=64, parity_steps=100, workload="suite 'humanoid stand'"),
+    4: dict(asset='cmu_2019_position_floor', nsub=6, batch=4096, algo_bytes=1828, outputs=('sensor', 'xpos', 'xmat'),
+            parity_envs=64, parity_steps=50, workload='locomotion CMU humanoid (2019, position-controlled) on the Floor arena'),
+    5: dict(asset='soccer_2v2_boxhead', nsub=5, batch=256, algo_bytes=928, outputs=('sensor', 'xpos', 'xmat'),
+            parity_envs=64, parity_steps=100, workload='locomotion.soccer 2v2 BoxHead'),
+}
 
 
 def parse():
   ap = argparse.ArgumentParser()
+  ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=1000)
-  ap.add_argument('--warmup', type=int, default=50)
-  ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='envs per GPU')
+  ap.add_argument('--steps', type=int, default=None)
+  ap.add_argument('--warmup', type=int, default=None)
+  ap.add_argument('--batch', type=int, default=None, help='envs per GPU')
   ap.add_argument('--lanes', type=int, default=int(os.environ.get('DMC_LANES', '0')))
   ap.add_argument('--precision', type=int, default=32)
-  ap.add_argument('--parity-envs', type=int, default=32)
-  ap.add_argument('--parity-steps', type=int, default=200)
+  ap.add_argument('--parity-envs', type=int, default=None)
+  ap.add_argument('--parity-steps', type=int, default=None)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-envs', type=int, default=4096)
+  ap.add_argument('--cpu-seconds', type=float, default=10.0)
   return ap.parse_args()
 
 
-def cheetah_model():
+def load_model(asset):
   from dm_control_amd import mjcf_compiler
-  with open(os.path.join(ROOT, 'dm_control_amd', 'suite', 'assets', 'cheetah.xml')) as f:
-    return mjcf_compiler.compile_xml(f.read())
+  from dm_control_amd.suite import common
+  return mjcf_compiler.compile_xml(common.read_model(asset + '.xml'))
 
 
-def initial_qpos(model, n, seed0):
-  """Cheetah.initialize_episode: qpos[is_limited] ~ U(lower, upper), per-env seed."""
-  q = np.tile(model.qpos0, (n, 1))
-  lim = model.jnt_limited == 1
-  lo, hi = model.jnt_range[lim].T
-  for e in range(n):
-    q[e, lim] = np.random.RandomState(seed0 + e).uniform(lo, hi)
+def initial_qpos(cfg, model, n, seed0, phys=None):
+  """Per-env start configurations (host array (n, nq)); `phys` (a BatchedPhysics of n envs) evaluates the
+  humanoid's contact-free rejection test for the whole batch at once."""
+  m = model
+  q = np.tile(m.qpos0, (n, 1))
+  asset = cfg['asset']
+  if asset == 'cheetah':
+    lim = m.jnt_limited == 1
+    lo, hi = m.jnt_range[lim].T
+    for e in range(n):
+      q[e, lim] = np.random.RandomState(seed0 + e).uniform(lo, hi)
+  elif asset == 'humanoid':
+    rs = np.random.RandomState(seed0)
+    todo = np.ones(n, bool)
+    for _ in range(200):
+      k = int(todo.sum())
+      if not k:
+        break
+      for j in range(m.njnt):      # randomize_limited_and_rotational_joints (suite/utils/randomizers.py:35-88)
+        t, a = m.jnt_type[j], m.jnt_qposadr[j]
+        if m.jnt_limited[j] and t in (2, 3):
+          q[todo, a] = rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], k)
+        elif t == 3:
+          q[todo, a] = rs.uniform(-np.pi, np.pi, k)
+        elif t == 0:
+          quat = rs.randn(k, 4)
+          q[todo, a + 3:a + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+      phys.set('qpos', q)
+      phys.forward(disable_actuation=True)
+      todo = phys.get('ncon')[:, 0] > 0
+    else:
+      raise RuntimeError('could not find collision-free humanoid start states')
+  elif asset == 'cmu_2019_position_floor':
+    rs = np.random.RandomState(seed0)
+    q[:, 0:2] += rs.uniform(-4, 4, (n, 2))       # arena_position: U(-size/2, size/2), Floor size 8 x 8
+  elif asset == 'soccer_2v2_boxhead':
+    rs = np.random.RandomState(seed0)
+    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-8, 8, (n, 8))      # players around their kick-off spots
+    q[:, 24:26] += rs.uniform(-15, 15, (n, 2))                           # ball
   return q
 
 
-def cpu_baseline(model, q0, action_fn, nthreads, target_s=8.0, max_steps=1000):
-  """Times the fp64 oracle (oracle/, test infrastructure) on host cores over a
-  bounded sample of the same workload (~target_s seconds of wall clock on all
-  host cores).  kind = 'port': MuJoCo itself is not installable here."""
+def make_oracles(model, q, v=None, w=None, step1=True):
+  from oracle import oracle
+  om = oracle.OracleModel(model)
+  out = []
+  for e in range(q.shape[0]):
+    p = oracle.OraclePhysics(om)
+    p.qpos[:] = q[e]
+    if v is not None:
+      p.qvel[:] = v[e]
+    if w is not None:
+      p.qacc_warmstart[:] = w[e]
+    if step1:
+      p.step1()
+    out.append(p)
+  return out
+
+
+def threaded_rollout(phys, acts, nsub, nthreads):
+  """oracle.rollout_legacy over `phys` split across host threads (ctypes releases the GIL)."""
   from concurrent.futures import ThreadPoolExecutor
   from oracle import oracle
-  B = q0.shape[0]
-  phys = []
-  for e in range(B):
-    p = oracle.OraclePhysics(model)
-    p.qpos[:] = q0[e]
-    p.forward()
-    phys.append(p)
-  shards = [list(range(i, B, nthreads)) for i in range(nthreads)]
-  shards = [s for s in shards if s]
+  n = len(phys)
+  shards = [list(range(i, n, nthreads)) for i in range(min(nthreads, n))]
+
+  def work(idx):
+    oracle.rollout_legacy([phys[i] for i in idx], np.ascontiguousarray(acts[:, idx]), nsub)
+  with ThreadPoolExecutor(len(shards)) as ex:
+    list(ex.map(work, shards))
+  return len(shards)
+
+
+def cpu_baseline(model, nsub, q0, v0, w0, action_fn, nthreads, target_s):
+  """Times the fp64 oracle (oracle/, test infrastructure) on the host cores over a bounded sample of the same
+  workload (~target_s seconds of wall clock).  kind = 'port': MuJoCo itself is not installable here."""
+  n = q0.shape[0]
+  phys = make_oracles(model, q0, v0, w0)
+  Tc = 2
+  while True:                                   # calibration: double the chunk until it takes >= 0.3 s
+    t0 = time.time()
+    cores = threaded_rollout(phys, action_fn(0, Tc), nsub, nthreads)
+    dtc = time.time() - t0
+    if dtc >= 0.3 or Tc >= 256:
+      break
+    Tc *= 2
+  rate = Tc * n / max(dtc, 1e-6)
+  T = int(min(2000, max(3, target_s * rate / n)))
+  acts = action_fn(2, T)
+  t0 = time.time()
+  threaded_rollout(phys, acts, nsub, nthreads)
+  dt = time.time() - t0
+  return dict(value=T * n / dt, unit='env-steps/s', cores=cores, kind='port',
+              physics_steps_per_s=T * n * nsub / dt,
+              sample='%d envs x %d env-steps x %d substeps (%.1f s wall), fp64 C restatement of mj_step (oracle/), one '
+                     'thread per core' % (n, T, nsub, dt))
+
+
+def mujoco_baseline(asset, nsub, q0, action_fn, nthreads, target_s):
+  """cpu_baseline.kind = 'mujoco' (BASELINE.md 3.2): real MuJoCo through its Python bindings, one MjData per
+  thread (the pattern of mujoco/thread_safety_test.py:56-73).  Only when `import mujoco` works."""
+  import mujoco      # noqa: raises ImportError where the wheel is absent (this image)
+  from concurrent.futures import ThreadPoolExecutor
+  from dm_control_amd.suite import common
+  m = mujoco.MjModel.from_xml_string(common.read_model(asset + '.xml'))
+  n = q0.shape[0]
+  datas = []
+  for e in range(n):
+    d = mujoco.MjData(m)
+    d.qpos[:] = q0[e]
+    mujoco.mj_forward(m, d)
+    datas.append(d)
+  shards = [list(range(i, n, nthreads)) for i in range(min(nthreads, n))]
 
   def run(acts):
     def work(idx):
-      oracle.rollout_legacy([phys[i] for i in idx], np.ascontiguousarray(acts[:, idx]))
+      for t in range(acts.shape[0]):
+        for i in idx:
+          datas[i].ctrl[:] = acts[t, i]
+          mujoco.mj_step(m, datas[i], nsub)
     with ThreadPoolExecutor(len(shards)) as ex:
       list(ex.map(work, shards))
-  run(np.zeros((200, B, model.nu)))   # settle (untimed)
-  t0 = time.time()
-  run(action_fn(0, 20))               # calibration chunk
-  rate = 20 * B / max(time.time() - t0, 1e-6)
-  T = int(min(max_steps, max(50, target_s * rate / B)))
-  acts = action_fn(20, T)
+  Tc = 2
+  while True:
+    t0 = time.time()
+    run(action_fn(0, Tc))
+    dtc = time.time() - t0
+    if dtc >= 0.3 or Tc >= 256:
+      break
+    Tc *= 2
+  rate = Tc * n / max(dtc, 1e-6)
+  T = int(min(2000, max(3, target_s * rate / n)))
+  acts = action_fn(2, T)
   t0 = time.time()
   run(acts)
   dt = time.time() - t0
-  return dict(value=T * B / dt, unit='env-steps/s', cores=len(shards), kind='port',
-              sample='%d envs x %d steps (%.1f s wall), fp64 C restatement of mj_step (oracle/), one thread per core'
-                     % (B, T, dt))
+  return dict(value=T * n / dt, unit='env-steps/s', cores=len(shards), kind='mujoco',
+              sample='%d envs x %d env-steps x %d substeps (%.1f s wall), mujoco %s mj_step, one MjData per thread'
+                     % (n, T, nsub, dt, mujoco.__version__))
 
 
-def _pmc_traffic():
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+def _committed_pmc(config):
+  """Counters of the committed rocprofv3 PMC passes for this config (profiles/r02_pmc_cfg<N>.json), or None."""
   try:
-    with open(PMC_TRAFFIC_FILE) as f:
-      return json.load(f)['hbm_bytes_per_launch']
+    with open(os.path.join(ROOT, 'profiles', 'r02_pmc_cfg%d.json' % config)) as f:
+      return json.load(f)
   except Exception:  # pylint: disable=broad-except
     return None
 
 
+def rel_err(qg, qo):
+  return np.abs(qg - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))
+
+
+def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads):
+  """GPU vs the fp64 oracle on the first envs, same states and actions: open loop (both integrate on their own)
+  and teacher-forced (the GPU state is overwritten by the oracle's before every env-step)."""
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  nsub = cfg['nsub']
+  ne, T = q.shape[0], acts.shape[0]
+  caps = dict(common.DEFAULT_CAPS.get(cfg['asset'], {}))
+  caps.pop('precision', None)
+  ops = make_oracles(model, q, v, w)
+  res = {}
+  for mode in ('open-loop', 'teacher-forced'):
+    chk = BatchedPhysics(model, ne, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes, **caps)
+    chk.set('qpos', q); chk.set('qvel', v); chk.set('qacc_warmstart', w)
+    refs = [p.copy() for p in ops]
+    worst = np.zeros(ne)
+    for t in range(T):
+      a = acts[t].astype(np.float64)
+      if mode == 'teacher-forced' and t:
+        chk.set('qpos', np.stack([p.qpos for p in refs]))
+        chk.set('qvel', np.stack([p.qvel for p in refs]))
+        chk.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+      chk.set_control(a)
+      chk.step(nsub)
+      threaded_rollout(refs, a[None], nsub, nthreads)
+      worst = np.maximum(worst, rel_err(chk.get('qpos'), np.stack([p.qpos for p in refs])))
+    res[mode] = dict(max=float(worst.max()), median=float(np.median(worst)), p90=float(np.percentile(worst, 90)),
+                     frac_le_1e4=float((worst <= 1e-4).mean()))
+    res['gpu_warnings'] = [int(x) for x in chk.get('warning').sum(axis=0)]
+    res['oracle_warnings'] = [int(x) for x in np.sum([p.warning for p in refs], axis=0)]
+    chk.close()
+  return res
+
+
 def main():
   args = parse()
+  cfg = CONFIGS[args.config]
   import torch
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -118,6 +277,7 @@ def main():
   backend = os.environ.get('DMC_BENCH_BACKEND', 'nccl')
   if os.environ.get('DMC_BENCH_SINGLE_DEVICE'):
     local_rank = 0
+  dist = None
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -128,12 +288,22 @@ def main():
   dev = torch.device('cuda', local_rank)
   red_dev = dev if backend == 'nccl' else torch.device('cpu')
   from dm_control_amd.batch import BatchedPhysics, OUT
+  from dm_control_amd.suite import common
+  from dm_control_amd import sharding
 
-  model = cheetah_model()
-  B, K, W = args.batch, args.steps, args.warmup
+  model = load_model(cfg['asset'])
+  nsub = cfg['nsub']
+  B = args.batch or cfg['batch']
+  K = args.steps if args.steps is not None else (1000 if args.config == 2 else 100)
+  W = args.warmup if args.warmup is not None else (50 if args.config == 2 else 5)
   tdtype = torch.float32 if args.precision == 32 else torch.float64
-  phys = BatchedPhysics(model, B, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes)
-  q0 = initial_qpos(model, B, seed0=rank * B)
+  caps = dict(common.DEFAULT_CAPS.get(cfg['asset'], {}))
+  if caps.pop('precision', args.precision) != args.precision:
+    raise SystemExit('%s runs in fp32 only' % cfg['asset'])
+  shard = sharding.ShardedEnvBatch(B * world, dist, device=red_dev)      # contiguous env range of this rank
+  assert shard.local_batch == B
+  phys = BatchedPhysics(model, B, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes, **caps)
+  q0 = initial_qpos(cfg, model, B, seed0=shard.lo, phys=phys)
   phys.set('qpos', q0)
   stream = torch.cuda.current_stream().cuda_stream
   # random actions, generated once, resident in HBM, SoA (T, nu, B)
@@ -141,26 +311,37 @@ def main():
   rs = np.random.RandomState(1234 + rank)
   actions_host = rs.uniform(-1, 1, (nact, B, model.nu)).astype(np.float32)
   actions = torch.from_numpy(np.ascontiguousarray(actions_host.transpose(0, 2, 1))).to(dev).to(tdtype).contiguous()
-  zero_ctrl = torch.zeros((model.nu, B), dtype=tdtype, device=dev)
-  # outputs the cheetah task reads: qpos, qvel (state) + sensordata (speed)
-  phys.set_output_mask(OUT['sensor'])
-  # settle 200 steps with zero control (Cheetah.initialize_episode), time = 0
-  phys.bind('ctrl', zero_ctrl.data_ptr())
-  phys.step(200, stream=stream)
-  torch.cuda.synchronize()
-  phys.set('time', np.zeros((B, 1)))
-  q_settled = phys.get('qpos')
-  v_settled = phys.get('qvel')
-  w_settled = phys.get('qacc_warmstart')
+  mask = 0
+  for name in cfg['outputs']:
+    mask |= OUT[name]
+  phys.set_output_mask(mask)
+  if cfg['asset'] == 'cheetah':
+    # settle 200 steps with zero control (Cheetah.initialize_episode), time = 0
+    zero_ctrl = torch.zeros((model.nu, B), dtype=tdtype, device=dev)
+    phys.bind('ctrl', zero_ctrl.data_ptr())
+    phys.step(200, stream=stream)
+    torch.cuda.synchronize()
+    phys.set('time', np.zeros((B, 1)))
+  else:
+    phys.forward()
+    torch.cuda.synchronize()
+  q_start, v_start, w_start = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
 
   def run(t0, n):
     for t in range(t0, t0 + n):
       phys.bind('ctrl', actions[t].data_ptr())
-      phys.step(1, stream=stream)
+      phys.step(nsub, stream=stream)
 
   def barrier():
     if world > 1:
-      torch.distributed.barrier()
+      dist.barrier()
+
+  def max_over_ranks(x):
+    if world == 1:
+      return x
+    t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
   run(0, W)
   torch.cuda.synchronize()
@@ -174,52 +355,77 @@ def main():
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t_start
-  kernel_ms = ev0.elapsed_time(ev1) / K
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+  elapsed = max_over_ranks(time.perf_counter() - t_start)
+  kernel_ms = ev0.elapsed_time(ev1) / K      # HIP events on the stream the kernel is launched on
+  q_end, v_end, w_end = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
+  warn = phys.get('warning').sum(axis=0)
+  stats = dict(mean_ncon=float(phys.get('ncon').mean()), max_ncon=int(phys.get('ncon').max()),
+               mean_nefc=float(phys.get('nefc').mean()), mean_solver_iter=float(phys.get('solver_iter').mean()))
+
   # ---- rollout leg: the same K env-steps, same resident action tensor, ONE launch per
   # chunk of <= 250 steps, per-step qpos/qvel/sensordata written to HBM (dmc_batch_rollout)
   chunk = min(250, K)
   nchunks = max(1, K // chunk)
   qs = torch.empty((chunk, model.nq, B), dtype=tdtype, device=dev)
   vs = torch.empty((chunk, model.nv, B), dtype=tdtype, device=dev)
-  ss = torch.empty((chunk, model.nsensordata, B), dtype=tdtype, device=dev)
-  phys.rollout(min(W, chunk) or 1, 1, actions[0:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
+  ss = torch.empty((chunk, max(1, model.nsensordata), B), dtype=tdtype, device=dev)
+  phys.rollout(min(W, chunk) or 1, nsub, actions[0:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
   r0 = time.perf_counter()
   for c in range(nchunks):
-    phys.rollout(chunk, 1, actions[W + c*chunk:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
+    phys.rollout(chunk, nsub, actions[W + c*chunk:].data_ptr(), qs.data_ptr(), vs.data_ptr(), ss.data_ptr(), stream=stream)
   torch.cuda.synchronize()
   barrier()
   torch.cuda.synchronize()
-  rollout_elapsed = time.perf_counter() - r0
+  rollout_elapsed = max_over_ranks(time.perf_counter() - r0)
+
+  # ---- agent-interface collectives (N > 1): actions scattered from rank 0, observations gathered to all ranks
+  coll = None
   if world > 1:
-    t = torch.tensor([rollout_elapsed], dtype=torch.float64, device=red_dev)
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    rollout_elapsed = float(t.item())
-  warn = phys.get('warning').sum(axis=0)
+    nobs = model.nq + model.nv + model.nsensordata
+    glob_act = torch.rand((B * world, model.nu), device=red_dev) if rank == 0 else None
+    obs = torch.cat([phys_t for phys_t in (torch.zeros((B, nobs), device=red_dev),)], dim=0)
+    for _ in range(3):
+      shard.scatter_actions(glob_act); shard.gather(obs)
+    torch.cuda.synchronize(); barrier()
+    c0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+      a_loc = shard.scatter_actions(glob_act)
+      shard.gather(obs)
+    torch.cuda.synchronize(); barrier()
+    coll_ms = max_over_ranks((time.perf_counter() - c0) / reps * 1e3)
+    coll = dict(ms_per_env_step=coll_ms, backend=backend, n_ranks_seen=dist.get_world_size(),
+                action_bytes=int(B * world * model.nu * 4), observation_bytes=int(B * world * nobs * 4),
+                env_steps_per_s_with_exchange=world * B / (elapsed / K + coll_ms * 1e-3),
+                note='scatter of (B, nu) fp32 actions from rank 0 + all_gather of (B, nq+nv+nsensordata) fp32 '
+                     'observations, serialised with the step (no overlap): the agent-interface cost when the policy '
+                     'lives on one rank; `value` is the no-collective number (policy co-located with each shard)')
 
   if rank == 0:
     value = world * B * K / elapsed
-    achieved = ALGO_BYTES_PER_STEP * B / (kernel_ms * 1e-3) / 1e9
+    algo = cfg['algo_bytes']
+    achieved = algo * B / (kernel_ms * 1e-3) / 1e9
+    pmc = _committed_pmc(args.config)
+    roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
+            'kernel_ms_avg': kernel_ms, 'algorithmic_bytes_per_launch': algo * B,
+            'note': 'nominal bound (SURVEY 8(d)): compulsory HBM traffic is %d B per env per launch; the kernel is '
+                    'VALU-issue / latency bound, see roofline_issue' % algo}
     out = {
-        'metric': 'env-steps/s (whole node) at batch 4096; max rel qpos error vs CPU',
+        'metric': METRIC,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
         'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32' if args.precision == 32 else 'f64', 'data': 'synthetic',
-        'config': {'workload': "suite 'cheetah run', batch %d per GPU, random actions U(-1,1)^6, "
-                               "legacy Physics.step(1), one fused kernel launch per step" % B,
-                   'batch_per_gpu': B, 'n_sub_steps': 1, 'info': phys.info()},
-        'physics_steps_per_s': value,
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc_traffic(),
-                     'kernel_ms_avg': kernel_ms, 'algorithmic_bytes_per_launch': ALGO_BYTES_PER_STEP * B,
-                     'note': 'latency/LDS/VALU-bound kernel: compulsory HBM traffic is 260 B per env-step'},
+        'config': {'workload': "BASELINE config %d: %s, batch %d per GPU, random actions U(-1,1)^%d, legacy "
+                               "Physics.step(%d), one fused kernel launch per env-step" % (args.config, cfg['workload'], B, model.nu, nsub),
+                   'baseline_config': args.config, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_steps': nsub,
+                   'sharding': 'contiguous env ranges, ranks %d' % world, 'info': phys.info()},
+        'physics_steps_per_s': value * nsub,
+        'roofline': roof,
+        'workload_stats': stats,
         'warnings_after_run': [int(x) for x in warn],
         'rollout': {'value': world * B * nchunks * chunk / rollout_elapsed, 'unit': 'env-steps/s',
                     'steps': nchunks * chunk, 'launches': nchunks,
@@ -227,50 +433,49 @@ def main():
                             'qpos,qvel,sensordata written to HBM, no launch per step; `value` above is the '
                             'host-in-the-loop mode (one Physics.step() launch per env-step)'},
     }
+    if pmc and pmc.get('SQ_INSTS_VALU') and pmc.get('kernel_us'):
+      # what actually limits the kernel: VALU issue slots.  One wave64 VALU instruction occupies its SIMD for one
+      # quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on this kernel), so issue utilisation =
+      # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x kernel time); counters from the committed PMC passes.
+      clk = pmc.get('clock_ghz', 2.4)
+      issue = pmc['SQ_INSTS_VALU'] * 4 / (SIMDS * clk * 1e9 * pmc['kernel_us'] * 1e-6)
+      out['roofline_issue'] = {'bound': 'valu_issue', 'achieved': issue, 'peak': 1.0, 'unit': 'fraction of VALU issue slots',
+                               'frac': issue, 'valu_insts_per_launch': pmc['SQ_INSTS_VALU'], 'kernel_us_profiled': pmc['kernel_us'],
+                               'source': 'profiles/r02_pmc_cfg%d.json' % args.config}
+    if coll:
+      out['collectives'] = coll
+    nthreads = os.cpu_count() or 1
     # ---- parity vs the CPU oracle on the first envs (checker only, untimed) -------
     try:
-      ne, T = min(args.parity_envs, B), min(args.parity_steps, K)
-      from oracle import oracle
-      ops = []
-      for e in range(ne):
-        p = oracle.OraclePhysics(model)
-        p.qpos[:] = q_settled[e]; p.qvel[:] = v_settled[e]; p.qacc_warmstart[:] = w_settled[e]
-        p.step1()
-        ops.append(p)
-      chk = BatchedPhysics(model, ne, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes)
-      chk.set('qpos', q_settled[:ne]); chk.set('qvel', v_settled[:ne]); chk.set('qacc_warmstart', w_settled[:ne])
-      err = 0.0
-      for t in range(T):
-        a = actions_host[t, :ne].astype(np.float64)
-        chk.set_control(a)
-        chk.step()
-        oracle.rollout_legacy(ops, a[None])
-        qg = chk.get('qpos')
-        qo = np.stack([p.qpos for p in ops])
-        err = max(err, float((np.abs(qg - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))).max()))
-      out['max_rel_qpos_err_vs_cpu'] = err
-      out['parity'] = {'envs': ne, 'steps': T, 'mode': 'open-loop', 'oracle': 'fp64 C restatement (parity unpinned vs real MuJoCo)'}
-      chk.close()
+      ne = min(args.parity_envs if args.parity_envs is not None else cfg['parity_envs'], B)
+      T = args.parity_steps if args.parity_steps is not None else cfg['parity_steps']
+      if T > 0 and ne > 0:
+        pa = np.random.RandomState(77).uniform(-1, 1, (T, ne, model.nu)).astype(np.float32)
+        res = parity(model, cfg, args, local_rank, q_start[:ne], v_start[:ne], w_start[:ne], pa, nthreads)
+        out['max_rel_qpos_err_vs_cpu'] = res['open-loop']['max']
+        out['parity'] = dict(res, envs=ne, steps=T, n_sub_steps=nsub,
+                             oracle='fp64 C restatement (oracle/); pinned on the reference KATs, unpinned vs real MuJoCo trajectories')
     except Exception as ex:  # pylint: disable=broad-except
       out['max_rel_qpos_err_vs_cpu'] = None
       out['parity_error'] = repr(ex)
     # ---- CPU baseline (rank 0, N = 1 only; bounded sample) ----------------------------
     if world == 1 and not args.no_cpu_baseline:
-      try:
-        nthreads = os.cpu_count() or 1
-        nb = min(args.cpu_envs, B)
+      nb = min(args.cpu_envs, B)
 
-        def action_fn(t0, n):
-          return np.random.RandomState(99 + t0).uniform(-1, 1, (n, nb, model.nu))
-        cb = cpu_baseline(model, q0[:nb], action_fn, nthreads)
-        out['cpu_baseline'] = cb
+      def action_fn(t0, n):
+        return np.random.RandomState(99 + t0).uniform(-1, 1, (n, nb, model.nu))
+      try:
+        try:
+          out['cpu_baseline'] = mujoco_baseline(cfg['asset'], nsub, q_end[:nb], action_fn, nthreads, args.cpu_seconds)
+        except ImportError:
+          out['cpu_baseline'] = cpu_baseline(model, nsub, q_end[:nb], v_end[:nb], w_end[:nb], action_fn, nthreads, args.cpu_seconds)
       except Exception as ex:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'value': None, 'error': repr(ex)}
     print(json.dumps(out), flush=True)
   phys.close()
   if world > 1:
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -14,9 +14,9 @@ EXPORTS = [
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
     'dmc_batch_set_model_real',
-    'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_info', 'dmc_batch_time_steps',
+    'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_info', 'dmc_batch_time_steps',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
-    'dmc_batch_prof_get',
+    'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
 ]
 
 _lib = None
@@ -66,6 +66,12 @@ def lib():
   L.dmc_batch_set_model_real.argtypes = [vp, cs, vp, ci]
   L.dmc_batch_sync.argtypes = [vp]
   L.dmc_batch_invalidate.argtypes = [vp]
+  L.dmc_batch_step1.argtypes = [vp, vp]
+  L.dmc_gather_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), vp, vp, vp, ctypes.POINTER(vp)]
+  L.dmc_gather_destroy.argtypes = [vp]
+  L.dmc_gather_destroy.restype = None
+  L.dmc_gather_run.argtypes = [vp, vp, vp]
+  L.dmc_batch_step2.argtypes = [vp, vp]
   L.dmc_batch_info.argtypes = [vp, vp]
   L.dmc_batch_time_steps.argtypes = [vp, ci, ci, ci, vp, ctypes.POINTER(ctypes.c_float)]
   L.dmc_batch_debug_enable.argtypes = [vp, ci]

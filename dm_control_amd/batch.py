@@ -14,7 +14,7 @@ from dm_control_amd import mjcf_compiler
 
 OUT = dict(sensor=1 << 0, xpos=1 << 1, xquat=1 << 2, xmat=1 << 3, xipos=1 << 4,
            geom=1 << 5, site=1 << 6, subtree_com=1 << 7, qacc=1 << 8,
-           actuator=1 << 9, contact=1 << 10, qfrc=1 << 11, cvel=1 << 12)
+           actuator=1 << 9, contact=1 << 10, qfrc=1 << 11, cvel=1 << 12, contact_ids=1 << 13)
 OUT_ALL = 0x7fffffff
 
 
@@ -28,6 +28,7 @@ class BatchedPhysics:
     self.model = model
     self.batch_size = int(batch_size)
     self.precision = precision
+    self.device_id = device_id
     ints, reals = model.pack()
     self._model_ptr = ctypes.c_void_p()
     _native.check(L.dmc_model_create(ints.ctypes.data, ints.size, reals.ctypes.data,
@@ -137,6 +138,14 @@ class BatchedPhysics:
     arrays in batch precision (None: skip)."""
     _native.check(_native.lib().dmc_batch_rollout(self._ptr, int(nsteps), int(n_sub_steps), ctrl_seq, qpos_seq,
                                                   qvel_seq, sensordata_seq, stream))
+
+  def step1(self, stream=None):
+    """mujoco.mj_step1 on its own (engine.py:160): position / velocity stage, state unchanged."""
+    _native.check(_native.lib().dmc_batch_step1(self._ptr, stream))
+
+  def step2(self, stream=None):
+    """mujoco.mj_step2 on its own (engine.py:156): acceleration stage + Euler integration."""
+    _native.check(_native.lib().dmc_batch_step2(self._ptr, stream))
 
   def forward(self, disable_actuation=False, stream=None):
     _native.check(_native.lib().dmc_batch_forward(self._ptr, int(disable_actuation), stream))

@@ -1,0 +1,301 @@
+"""Batch-aware composer environment loop on device.
+
+Mirrors `composer.Environment.step / _substep` (dm_control/composer/environment.py:412-465) and the hook dispatcher
+`_EnvironmentHooks` (:74-162) for B environments at once:
+
+    before_step(physics, action)            -- task, then entities
+    for each of n_sub_steps:
+      before_substep -> physics.step() -> after_substep
+    after_step
+    reward / discount / should_terminate_episode or time limit
+
+Every hook receives the batch physics and works on (.., B) tensors; per-env quantities the reference keeps as Python
+scalars on the task (`_failure_termination`, `_reward_step_counter`) are (B,) tensors.  Like the reference, hooks that
+are no-ops are found once at construction (`_callable_is_trivial`, environment.py:44-58) and never called; when no
+substep hook is left, the n_sub_steps physics steps of a control step fuse into ONE launch of the step kernel
+(`Physics.step(n_sub_steps)`), otherwise each substep is its own launch with the hooks in between, in the
+reference's order.  `legacy_base.Walker.after_substep` (legacy_base.py:179-186: `mj_subtreeVel`, needed so that
+`subtree_linvel` is fresh) has no work left here: the kernel evaluates subtree velocities whenever a
+`subtreelinvel` sensor or output asks for them.
+
+An environment whose episode ended is re-initialised at the start of the NEXT `step` call, which returns its FIRST
+time step (reward / discount of that step are zero / one and `step_type == 0`), as the reference does with
+`_reset_next_step` (environment.py:414-416) -- per environment.  Nothing in the steady state synchronises with the
+host.
+"""
+import collections
+
+import numpy as np
+
+HOOK_NAMES = ('initialize_episode', 'before_step', 'before_substep', 'after_substep', 'after_step')
+FIRST, MID, LAST = 0, 1, 2
+
+TimeStep = collections.namedtuple('TimeStep', ['step_type', 'reward', 'discount', 'observation'])
+
+
+def _empty_function():
+  pass
+
+
+def _empty_function_with_docstring():
+  """Some docstring."""
+
+
+_EMPTY_CODE = _empty_function.__code__.co_code
+_EMPTY_WITH_DOCSTRING_CODE = _empty_function_with_docstring.__code__.co_code
+
+
+def _callable_is_trivial(f):
+  """environment.py:44-58: a hook whose body is empty (or only a docstring) is never dispatched."""
+  try:
+    code = f.__code__.co_code
+  except AttributeError:
+    return False
+  return code in (_EMPTY_CODE, _EMPTY_WITH_DOCSTRING_CODE)
+
+
+class Entity:
+  """The slice of `composer.Entity` the loop needs: named, with optional hooks (all trivial by default)."""
+
+  def initialize_episode(self, physics, random_state, mask):
+    pass
+
+  def before_step(self, physics, random_state):
+    pass
+
+  def before_substep(self, physics, random_state):
+    pass
+
+  def after_substep(self, physics, random_state):
+    pass
+
+  def after_step(self, physics, random_state):
+    pass
+
+
+class Task:
+  """`composer.Task` for a batch (composer/task.py): hooks default to no-ops; subclasses override what they use.
+
+  Differences forced by the batch: `initialize_episode` gets the (B,) bool mask of the environments being
+  re-initialised; `get_reward` / `get_discount` / `should_terminate_episode` return (B,) tensors (rewards may be
+  (n_agents, B))."""
+
+  physics_timestep = 0.005
+  control_timestep = 0.025
+
+  @property
+  def entities(self):
+    return ()
+
+  def set_timesteps(self, control_timestep, physics_timestep):
+    n = control_timestep / physics_timestep
+    if abs(n - round(n)) > 1e-6:
+      raise ValueError('control timestep must be an integer multiple of the physics timestep')
+    self.control_timestep, self.physics_timestep = control_timestep, physics_timestep
+
+  @property
+  def physics_steps_per_control_step(self):
+    return int(round(self.control_timestep / self.physics_timestep))
+
+  def initialize_episode(self, physics, random_state, mask):
+    pass
+
+  def before_step(self, physics, action, random_state):
+    pass
+
+  def before_substep(self, physics, action, random_state):
+    pass
+
+  def after_substep(self, physics, random_state):
+    pass
+
+  def after_step(self, physics, random_state):
+    pass
+
+  def get_reward(self, physics):
+    raise NotImplementedError
+
+  def get_discount(self, physics):
+    return physics.torch.ones(physics.B, dtype=physics.dtype, device=physics.device)
+
+  def should_terminate_episode(self, physics):
+    return physics.torch.zeros(physics.B, dtype=physics.torch.bool, device=physics.device)
+
+  def get_observation(self, physics):
+    raise NotImplementedError
+
+
+class _EnvironmentHooks:
+  """environment.py:74-162: scans the task and its entities once, keeps the non-trivial hooks."""
+
+  def __init__(self, task):
+    self._task = task
+    self._entity_hooks = {n: [] for n in HOOK_NAMES}
+    self._extra = {n: [] for n in HOOK_NAMES}
+    self._task_hooks = {}
+    for name in HOOK_NAMES:
+      h = getattr(task, name)
+      self._task_hooks[name] = None if _callable_is_trivial(h) else h
+      for entity in task.entities:
+        eh = getattr(entity, name, None)
+        if eh is not None and not _callable_is_trivial(eh):
+          self._entity_hooks[name].append(eh)
+
+  def add_extra_hook(self, hook_name, hook_callable):
+    if hook_name not in HOOK_NAMES:
+      raise ValueError('{!r} is not a valid hook name'.format(hook_name))
+    if not callable(hook_callable):
+      raise ValueError('{!r} is not a callable'.format(hook_callable))
+    self._extra[hook_name].append(hook_callable)
+
+  def has_substep_hooks(self):
+    return any(self._task_hooks[n] or self._entity_hooks[n] or self._extra[n] for n in ('before_substep', 'after_substep'))
+
+  def initialize_episode(self, physics, random_state, mask):
+    if self._task_hooks['initialize_episode']:
+      self._task_hooks['initialize_episode'](physics, random_state, mask)
+    for h in self._entity_hooks['initialize_episode']:
+      h(physics, random_state, mask)
+    for h in self._extra['initialize_episode']:
+      h(physics, random_state, mask)
+
+  def before_step(self, physics, action, random_state):
+    if self._task_hooks['before_step']:
+      self._task_hooks['before_step'](physics, action, random_state)
+    for h in self._entity_hooks['before_step']:
+      h(physics, random_state)
+    for h in self._extra['before_step']:
+      h(physics, action, random_state)
+
+  def before_substep(self, physics, action, random_state):
+    if self._task_hooks['before_substep']:
+      self._task_hooks['before_substep'](physics, action, random_state)
+    for h in self._entity_hooks['before_substep']:
+      h(physics, random_state)
+    for h in self._extra['before_substep']:
+      h(physics, action, random_state)
+
+  def after_substep(self, physics, random_state):
+    if self._task_hooks['after_substep']:
+      self._task_hooks['after_substep'](physics, random_state)
+    for h in self._entity_hooks['after_substep']:
+      h(physics, random_state)
+    for h in self._extra['after_substep']:
+      h(physics, random_state)
+
+  def after_step(self, physics, random_state):
+    if self._task_hooks['after_step']:
+      self._task_hooks['after_step'](physics, random_state)
+    for h in self._entity_hooks['after_step']:
+      h(physics, random_state)
+    for h in self._extra['after_step']:
+      h(physics, random_state)
+
+
+class Environment:
+  """B composer-style environments of one task on one GPU."""
+
+  def __init__(self, task, physics, time_limit=float('inf'), random_state=None, n_sub_steps=None, fuse_substeps=None):
+    self.task = task
+    self.physics = physics
+    self._time_limit = time_limit
+    self._rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    self._n_sub_steps = n_sub_steps or task.physics_steps_per_control_step
+    self._hooks = _EnvironmentHooks(task)
+    self._fuse = fuse_substeps
+    torch = physics.torch
+    self._reset_next = torch.ones(physics.B, dtype=torch.bool, device=physics.device)
+    self._host_all_reset = True     # known without a device sync: every env is waiting for its reset
+    self.launches = 0               # physics launches issued (tests / profiling)
+
+  @property
+  def n_sub_steps(self):
+    return self._n_sub_steps
+
+  @property
+  def fused(self):
+    return (not self._hooks.has_substep_hooks()) if self._fuse is None else bool(self._fuse)
+
+  def add_extra_hook(self, hook_name, hook_callable):
+    self._hooks.add_extra_hook(hook_name, hook_callable)
+
+  def control_timestep(self):
+    return self.task.physics_timestep * self._n_sub_steps
+
+  # -- episode initialisation (environment.py:366-395) ------------------------------------------------
+  def _initialize(self, mask):
+    """`with physics.reset_context(): hooks.initialize_episode(...)` for the masked environments: mj_resetData,
+    then the task's initialisation; the closing mj_forward with actuation disabled (engine.py:326-333) is the
+    caller's launch."""
+    p = self.physics
+    p.reset(mask)
+    self._hooks.initialize_episode(p, self._rs, mask)
+
+  def reset(self):
+    torch = self.physics.torch
+    mask = torch.ones(self.physics.B, dtype=torch.bool, device=self.physics.device)
+    self._initialize(mask)
+    self.physics.field('env_mode').zero_()
+    self.physics.forward(disable_actuation=True)
+    self.launches += 1
+    self._reset_next = torch.zeros_like(mask)
+    self._host_all_reset = False
+    B = self.physics.B
+    return TimeStep(step_type=torch.full((B,), FIRST, dtype=torch.int32, device=self.physics.device),
+                    reward=torch.zeros(B, dtype=self.physics.dtype, device=self.physics.device),
+                    discount=torch.ones(B, dtype=self.physics.dtype, device=self.physics.device),
+                    observation=self.task.get_observation(self.physics))
+
+  # -- one control step (environment.py:412-465) --------------------------------------------------------
+  def step(self, action):
+    p, torch = self.physics, self.physics.torch
+    if self._host_all_reset:
+      return self.reset()
+    first = self._reset_next
+    # environments whose episode ended last step start a new one now; the others take a regular step.  The
+    # re-initialisation is data-dependent but needs no host decision: the state edits are applied under the mask,
+    # and the SAME launch that steps the others runs mj_forward with actuation disabled for these (env_mode 1).
+    self._initialize(first)
+    p.field('env_mode').copy_(first[None, :].to(torch.int32))
+    self._hooks.before_step(p, action, self._rs)
+    if self.fused:
+      # no substep hook (or fusion forced): the substep hooks, if any, see the control step as ONE substep
+      self._hooks.before_substep(p, action, self._rs)
+      p.step(self._n_sub_steps)
+      self.launches += 1
+      self._hooks.after_substep(p, self._rs)
+    else:
+      for _ in range(self._n_sub_steps):
+        self._hooks.before_substep(p, action, self._rs)
+        p.step()
+        self.launches += 1
+        self._hooks.after_substep(p, self._rs)
+    self._hooks.after_step(p, self._rs)
+    task = self.task
+    reward = task.get_reward(p)
+    discount = task.get_discount(p)
+    # mjWARN_BADQPOS / BADQVEL / BADQACC since the last look = PhysicsError in the reference (engine.py:345-368):
+    # reward 0, discount 0, episode over (environment.py:449-452)
+    diverged = self._divergence(p)
+    terminating = task.should_terminate_episode(p) | (p.field('time')[0] >= self._time_limit - 1e-9) | diverged
+    zero = torch.zeros_like(discount)
+    reward = torch.where(diverged if reward.dim() == 1 else diverged[None, :], torch.zeros_like(reward), reward)
+    discount = torch.where(diverged, zero, discount)
+    obs = task.get_observation(p)
+    step_type = torch.where(first, torch.full_like(first, FIRST, dtype=torch.int32),
+                            torch.where(terminating, torch.full_like(first, LAST, dtype=torch.int32),
+                                        torch.full_like(first, MID, dtype=torch.int32)))
+    # an environment that was (re)started this call reports FIRST with no reward, and cannot end on it
+    reward = torch.where(first if reward.dim() == 1 else first[None, :], torch.zeros_like(reward), reward)
+    discount = torch.where(first, torch.ones_like(discount), discount)
+    self._reset_next = terminating & ~first
+    return TimeStep(step_type=step_type, reward=reward, discount=discount, observation=obs)
+
+  def _divergence(self, physics):
+    w = physics.field('warning')
+    bad = (w[4] + w[5] + w[6]) > 0            # BADQPOS, BADQVEL, BADQACC (include/dmc_model_layout.h order)
+    w[4:7].zero_()
+    return bad
+
+  def close(self):
+    self.physics.close()

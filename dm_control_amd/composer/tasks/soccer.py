@@ -1,0 +1,306 @@
+"""BASELINE config 5 as an environment: locomotion.soccer 2-vs-2 with BoxHead walkers, for a batch on device.
+
+Task layer of `dm_control.locomotion.soccer.load(team_size=2, walker_type=BOXHEAD)` (soccer/__init__.py:92-148,
+soccer/task.py:36-230) over the restated physics asset `suite/assets/soccer_2v2_boxhead.xml`
+(scripts/make_soccer_model.py):
+
+  * 4 agents: the action is (B, 4, 3) = per player (roll, steer, kick), written to the players' actuators
+    (`walker.apply_action`, task.py:211-213);
+  * `UniformInitializer` (soccer/initializers.py:33-127): ball and players uniform over `spawn_ratio` of the pitch,
+    players with a uniform yaw; placements with two entities closer than their bounding radii are redrawn (the
+    reference redraws on detected contacts);
+  * goal / out-of-court detection by `PositionDetector` volumes on the ball position (entities/props/
+    position_detector.py; pitch.py:426-456), evaluated AFTER EVERY SUBSTEP and retained until the end of the control
+    step (`retain_substep_detections=True`, pitch.py:262): the detectors are entities with an `after_substep`
+    hook, so by default the control step runs as n_sub_steps launches with the hook in between -- the reference's
+    order.  `Environment(..., fuse_substeps=True)` checks at the end of the control step only (one launch);
+  * reward +1 / -1 per player when a team scores, discount 0 and termination on a goal (task.py:160-209);
+    throw-in when the ball left the court (task.py:215-217, :128-135);
+  * observations per player (soccer/observables.py CoreObservablesAdder): proprioception (kick joint position /
+    velocity, body height, end effector, world z axis, prev_action), kinematic sensors, ball / teammate / opponent
+    positions and velocities and goal / field corners in the player's egocentric frame, and the stats_* scalars.
+    Observation tensors are (B, 4, n).
+
+Pitch randomisation (`RandomizedPitch`, pitch.py:612-690) needs per-environment geom positions: see
+`DevicePhysics` per-env model deltas; the default here is the fixed 40 x 30 pitch of the asset.
+"""
+import numpy as np
+
+from dm_control_amd import mjcf_compiler
+from dm_control_amd.composer import environment
+from dm_control_amd.composer.physics import DevicePhysics
+from dm_control_amd.suite import common
+
+_ASSET = 'soccer_2v2_boxhead'
+_PLAYERS = ('home0', 'home1', 'away0', 'away1')
+_TEAM = (0, 0, 1, 1)                                   # 0 = HOME (defends -x), 1 = AWAY
+_SPOTS = np.array([(-10., 5.), (-10., -5.), (10., 5.), (10., -5.)])      # attachment frames of the asset
+_SIZE = np.array([40.0, 30.0])
+_SIDE_WIDTH = 32. / 6.
+_GOAL_SIZE = np.array([_SIDE_WIDTH / 2, _SIZE[1] * 0.33, _SIDE_WIDTH / 2])       # pitch.py _get_goal_size
+_INIT_BALL_Z, _SPAWN_RATIO, _THROW_IN_BALL_Z = 0.5, 0.6, 0.5
+
+
+class PositionDetector(environment.Entity):
+  """Axis-aligned detection volume on the ball's geom position (position_detector.py:42-260)."""
+
+  def __init__(self, lower, upper, inverted=False, retain_substep_detections=False):
+    self.lower, self.upper = np.asarray(lower, float), np.asarray(upper, float)
+    self.mid = (self.lower + self.upper) / 2
+    self.inverted = inverted
+    self.retain = retain_substep_detections
+    self.detected = None      # (B,) bool
+    self._ball_rows = None
+
+  def bind_ball(self, task):
+    self._task = task
+
+  def _inside(self, physics):
+    torch = physics.torch
+    p = self._task.ball_xpos(physics)
+    d = self.lower.size
+    lo = torch.as_tensor(self.lower, dtype=physics.dtype, device=physics.device)[:, None]
+    hi = torch.as_tensor(self.upper, dtype=physics.dtype, device=physics.device)[:, None]
+    inside = ((p[:d] > lo) & (p[:d] < hi)).all(dim=0)
+    return ~inside if self.inverted else inside
+
+  def initialize_episode(self, physics, random_state, mask):
+    torch = physics.torch
+    if self.detected is None:
+      self.detected = torch.zeros(physics.B, dtype=torch.bool, device=physics.device)
+    self.detected = self.detected & ~mask
+
+  def before_step(self, physics, random_state):
+    # position_detector.py before_step: a retained detection is cleared at the start of the next control step
+    if self.retain:
+      self.detected = physics.torch.zeros_like(self.detected)
+
+  def after_substep(self, physics, random_state):
+    now = self._inside(physics)
+    self.detected = (self.detected | now) if self.retain else now
+
+
+class Soccer2v2(environment.Task):
+
+  def __init__(self, model=None, control_timestep=0.025, spawn_ratio=_SPAWN_RATIO):
+    self.model = model or mjcf_compiler.compile_xml(common.read_model(_ASSET + '.xml'))
+    self.set_timesteps(control_timestep=control_timestep, physics_timestep=0.005)      # task.py:105-106
+    self._spawn = _SIZE * spawn_ratio
+    gs = _GOAL_SIZE
+    home_pos = np.array([-_SIZE[0] + gs[0], 0, gs[2]])
+    away_pos = np.array([_SIZE[0] - gs[0], 0, gs[2]])
+    self.home_goal = PositionDetector(home_pos - gs, home_pos + gs, retain_substep_detections=True)
+    self.away_goal = PositionDetector(away_pos - gs, away_pos + gs, retain_substep_detections=True)
+    fs = np.array([_SIZE[0] - 2 * gs[0], _SIZE[1] - 2 * gs[0]])
+    self.field = PositionDetector(-fs, fs, inverted=True)
+    for d in (self.home_goal, self.away_goal, self.field):
+      d.bind_ball(self)
+    m = self.model
+    self._ball_geom = m.name2id('soccer_ball/geom', 'geom')
+    self._ball_body = m.name2id('soccer_ball', 'body')
+    self._root = [m.name2id(p + '/head_body', 'body') for p in _PLAYERS]
+    jq = lambda n: int(m.jnt_qposadr[m.name2id(n, 'joint')])
+    jv = lambda n: int(m.jnt_dofadr[m.name2id(n, 'joint')])
+    self._q = {p: {k: jq('%s/%s' % (p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
+    self._v = {p: {k: jv('%s/%s' % (p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
+    self._ball_q, self._ball_v = jq('soccer_ball'), jv('soccer_ball')
+    self._ctrl_rows = [[m.name2id('%s/%s' % (p, a), 'actuator') for a in ('roll', 'steer', 'kick')] for p in _PLAYERS]
+    sadr = lambda n: int(m.sensor_adr[m.name2id(n, 'sensor')])
+    self._sens = {p: {k: sadr('%s/sensor_torso_%s' % (p, k)) for k in ('vel', 'gyro', 'accel')} for p in _PLAYERS}
+    self._ball_linvel = sadr('soccer_ball/linear_velocity')
+    self._ball_angvel = sadr('soccer_ball/angular_velocity')
+    self._prev_action = None
+    self._gen = None
+
+  @property
+  def entities(self):
+    return (self.home_goal, self.away_goal, self.field)
+
+  def make_physics(self, batch_size, device_id=0, precision=32):
+    caps = dict(common.DEFAULT_CAPS.get(_ASSET, {}))
+    caps.pop('precision', None)
+    return DevicePhysics(self.model, batch_size, device_id=device_id, precision=precision,
+                         outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), **caps)
+
+  # -- helpers -----------------------------------------------------------------------------------------
+  def ball_xpos(self, physics):
+    g = self._ball_geom
+    return physics.field('geom_xpos')[3*g:3*g + 3]
+
+  def _uniform(self, physics, lo, hi):
+    torch = physics.torch
+    lo = torch.as_tensor(np.asarray(lo, float), dtype=physics.dtype, device=physics.device).reshape(-1, 1)
+    hi = torch.as_tensor(np.asarray(hi, float), dtype=physics.dtype, device=physics.device).reshape(-1, 1)
+    u = torch.rand((lo.shape[0], physics.B), generator=self._gen, device=physics.device, dtype=physics.dtype)
+    return lo + (hi - lo) * u
+
+  def _place(self, physics, mask):
+    """UniformInitializer._initialize_entities for the masked environments: returns nothing, edits qpos."""
+    torch = physics.torch
+    q = physics.field('qpos')
+    m2 = mask[None, :]
+    ball = self._uniform(physics, -self._spawn, self._spawn)
+    pos = [ball]
+    bq = self._ball_q
+    q[bq:bq + 2] = torch.where(m2, ball, q[bq:bq + 2])
+    q[bq + 2] = torch.where(mask, torch.full_like(q[bq + 2], _INIT_BALL_Z - 0.35), q[bq + 2])      # geom centre at z = 0.5 (body + 0.35)
+    for k, p in enumerate(_PLAYERS):
+      xy = self._uniform(physics, -self._spawn, self._spawn)
+      pos.append(xy)
+      spot = torch.as_tensor(_SPOTS[k], dtype=physics.dtype, device=physics.device)[:, None]
+      a = self._q[p]
+      q[a['root_x']] = torch.where(mask, xy[0] - spot[0], q[a['root_x']])      # slides are relative to the frame
+      q[a['root_y']] = torch.where(mask, xy[1] - spot[1], q[a['root_y']])
+      yaw = self._uniform(physics, [-np.pi], [np.pi])[0]
+      q[a['steer']] = torch.where(mask, yaw, q[a['steer']])
+    return torch.stack(pos)            # (5, 2, B)
+
+  # -- hooks -------------------------------------------------------------------------------------------
+  def initialize_episode(self, physics, random_state, mask):
+    torch = physics.torch
+    if self._gen is None:
+      self._gen = torch.Generator(device=physics.device)
+      self._gen.manual_seed(int(random_state.randint(2**31 - 1)))
+      self._prev_action = torch.zeros((4, 3, physics.B), dtype=physics.dtype, device=physics.device)
+    todo = mask
+    for _ in range(4):                 # redraw placements whose entities overlap (initializers.py:96-127)
+      pos = self._place(physics, todo)
+      d = torch.linalg.norm(pos[:, None] - pos[None, :], dim=2)                    # (5, 5, B)
+      eye = torch.eye(5, dtype=torch.bool, device=physics.device)[:, :, None]
+      close = ((d < 1.5) & ~eye).any(dim=0).any(dim=0)
+      todo = todo & close
+    self._prev_action = torch.where(mask[None, None, :], torch.zeros_like(self._prev_action), self._prev_action)
+    physics.mark_as_dirty()
+
+  def before_step(self, physics, action, random_state):
+    """action: (B, 4, 3).  task.py:211-217: apply the players' actions, then throw the ball in if it left the court."""
+    torch = physics.torch
+    a = action.permute(1, 2, 0).to(physics.dtype)              # (4, 3, B)
+    ctrl = physics.field('ctrl')
+    for k in range(4):
+      for j in range(3):
+        ctrl[self._ctrl_rows[k][j]] = a[k, j]
+    self._prev_action = a
+    off = self.field.detected
+    if off is not None:
+      # _throw_in (task.py:128-135): ball back at a shrunk position, at rest
+      q, v = physics.field('qpos'), physics.field('qvel')
+      xy = self.ball_xpos(physics)[:2]
+      shrink = self._uniform(physics, [0.7, 0.7], [0.9, 0.9])
+      bq, bv = self._ball_q, self._ball_v
+      q[bq:bq + 2] = torch.where(off[None, :], xy * shrink, q[bq:bq + 2])
+      q[bq + 2] = torch.where(off, torch.full_like(q[bq + 2], _THROW_IN_BALL_Z - 0.35), q[bq + 2])
+      v[bv:bv + 6] = torch.where(off[None, :], torch.zeros_like(v[bv:bv + 6]), v[bv:bv + 6])
+      physics.mark_as_dirty()
+
+  def _scoring_team(self, physics):
+    """+1 where AWAY scored (ball in the home goal), -1 ... as two masks: (home_scored, away_scored)."""
+    return self.away_goal.detected, self.home_goal.detected
+
+  def get_reward(self, physics):
+    torch = physics.torch
+    home_scored, away_scored = self._scoring_team(physics)
+    # arena.detected_goal: the home goal is looked at first (pitch.py:574-580)
+    away_scored = away_scored
+    home_scored = home_scored & ~away_scored
+    r_home = home_scored.to(physics.dtype) - away_scored.to(physics.dtype)
+    return torch.stack([r_home, r_home, -r_home, -r_home])                           # (4, B)
+
+  def get_discount(self, physics):
+    return (~(self.home_goal.detected | self.away_goal.detected)).to(physics.dtype)
+
+  def should_terminate_episode(self, physics):
+    return self.home_goal.detected | self.away_goal.detected
+
+  # -- observations --------------------------------------------------------------------------------------
+  def _frame(self, physics, k):
+    b = self._root[k]
+    R = physics.field('xmat')[9*b:9*b + 9].reshape(3, 3, physics.B)
+    return physics.field('xpos')[3*b:3*b + 3], R
+
+  @staticmethod
+  def _ego(vec, R):
+    """world (n, B) vector in the frame R (3, 3, B): v . R restricted to the first n components."""
+    n = vec.shape[0]
+    return (vec[:, None, :] * R[:n, :n]).sum(dim=0)
+
+  def get_observation(self, physics):
+    torch = physics.torch
+    B = physics.B
+    sd, q, v = physics.field('sensordata'), physics.field('qpos'), physics.field('qvel')
+    ball = self.ball_xpos(physics)
+    blin = sd[self._ball_linvel:self._ball_linvel + 3]
+    bang = sd[self._ball_angvel:self._ball_angvel + 3]
+    frames = [self._frame(physics, k) for k in range(4)]
+    cvel = physics.field('cvel')
+    out = {}
+    gs = _GOAL_SIZE
+
+    def put(name, t):
+      out.setdefault(name, []).append(t.T if t.dim() == 2 else t[:, None])
+
+    home_lo = torch.as_tensor(self.home_goal.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    home_hi = torch.as_tensor(self.home_goal.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    home_mid = torch.as_tensor(self.home_goal.mid, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    away_lo = torch.as_tensor(self.away_goal.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    away_hi = torch.as_tensor(self.away_goal.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    away_mid = torch.as_tensor(self.away_goal.mid, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
+    f_lo = torch.as_tensor(self.field.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(2, B)
+    f_hi = torch.as_tensor(self.field.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(2, B)
+    corners = [home_lo[:2], home_mid, home_hi[:2], f_hi, away_hi[:2], away_mid, away_lo[:2], f_lo]
+    corner_names = ['team_goal_back_right', 'team_goal_mid', 'team_goal_front_left', 'field_front_left',
+                    'opponent_goal_back_left', 'opponent_goal_mid', 'opponent_goal_front_right', 'field_back_right']
+    dist_to_ball = [torch.linalg.norm(ball - frames[k][0], dim=0) for k in range(4)]
+    for k, p in enumerate(_PLAYERS):
+      pos, R = frames[k]
+      a, av, s = self._q[p], self._v[p], self._sens[p]
+      put('joints_pos', q[a['kick']]); put('joints_vel', v[av['kick']])
+      put('body_height', pos[2])
+      put('end_effectors_pos', torch.zeros((3, B), dtype=physics.dtype, device=physics.device))      # head_body w.r.t. itself
+      put('world_zaxis', physics.field('xmat')[9*self._root[k] + 6:9*self._root[k] + 9])
+      put('sensors_gyro', sd[s['gyro']:s['gyro'] + 3]); put('sensors_velocimeter', sd[s['vel']:s['vel'] + 3])
+      put('sensors_accelerometer', sd[s['accel']:s['accel'] + 3])
+      put('prev_action', self._prev_action[k])
+      put('ball_ego_position', self._ego(ball - pos, R))
+      put('ball_ego_linear_velocity', self._ego(blin - cvel[6*self._root[k] + 3:6*self._root[k] + 6], R))
+      put('ball_ego_angular_velocity', self._ego(bang, R))
+      mates = [j for j in range(4) if j != k and _TEAM[j] == _TEAM[k]]
+      opps = [j for j in range(4) if _TEAM[j] != _TEAM[k]]
+      for prefix, others in (('teammate', mates), ('opponent', opps)):
+        for n, j in enumerate(others):
+          opos, oR = frames[j]
+          put('%s_%d_ego_position' % (prefix, n), self._ego(opos - pos, R))
+          put('%s_%d_ego_linear_velocity' % (prefix, n),
+              self._ego(cvel[6*self._root[j] + 3:6*self._root[j] + 6] - cvel[6*self._root[k] + 3:6*self._root[k] + 6], R))
+          # the other's axes in this player's frame (framexaxis / frameyaxis / framezaxis sensors with reftype)
+          rel = torch.einsum('ijb,ikb->jkb', R, oR)            # R^T oR : columns = other's axes
+          put('%s_%d_ego_orientation' % (prefix, n), rel.permute(1, 0, 2).reshape(9, B))
+      feats = corners if _TEAM[k] == 0 else corners[4:] + corners[:4]
+      for name, c in zip(corner_names, feats):
+        n = c.shape[0]
+        put(name, self._ego(c - pos[:n], R))
+      # stats (observables.py:262-330)
+      dir_ = ball - pos
+      unit = dir_[:2] / (torch.linalg.norm(dir_[:2], dim=0) + 1e-7)
+      # cvel[3:5] of the root body: the reference dots the planar direction with the body's com-frame linear velocity
+      vel_to_ball = (unit * cvel[6*self._root[k] + 3:6*self._root[k] + 5]).sum(dim=0)
+      put('stats_vel_to_ball', vel_to_ball)
+      closest = torch.ones(B, dtype=torch.bool, device=physics.device)
+      for j in mates:
+        closest = closest & (dist_to_ball[k] <= dist_to_ball[j])
+      put('stats_closest_vel_to_ball', torch.where(closest, vel_to_ball, torch.zeros_like(vel_to_ball)))
+      put('stats_veloc_forward', sd[s['vel']])
+      goal_mid = away_mid if _TEAM[k] == 0 else home_mid
+      direction = goal_mid - ball
+      nrm = torch.linalg.norm(direction, dim=0)
+      ndir = torch.where(nrm[None, :] > 0, direction / nrm.clamp_min(1e-30), direction)
+      put('stats_vel_ball_to_goal', (ndir * blin).sum(dim=0))
+    return {name: torch.stack(v, dim=1) for name, v in out.items()}            # (B, 4, n)
+
+
+def make(batch_size, device_id=0, precision=32, time_limit=45.0, random_state=0, fuse_substeps=None, **task_kwargs):
+  """`soccer.load(team_size=2, time_limit=45., walker_type=WalkerType.BOXHEAD)` (soccer/__init__.py:92-148) for a
+  batch, on the fixed pitch of the asset."""
+  task = Soccer2v2(**task_kwargs)
+  physics = task.make_physics(batch_size, device_id=device_id, precision=precision)
+  return environment.Environment(task, physics, time_limit=time_limit, random_state=random_state, fuse_substeps=fuse_substeps)

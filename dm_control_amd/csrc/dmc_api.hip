@@ -173,7 +173,7 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
       {"contact_dist", d.nconmax, false}, {"contact_pos", 3*d.nconmax, false}, {"contact_frame", 9*d.nconmax, false},
       {"contact_force", 6*d.nconmax, false}, {"cvel", 6*nb, false},
       {"ncon", 1, true}, {"nefc", 1, true}, {"solver_iter", 1, true}, {"warning", DMC_NWARNING, true},
-      {"contact_geom1", d.nconmax, true}, {"contact_geom2", d.nconmax, true}};
+      {"contact_geom1", d.nconmax, true}, {"contact_geom2", d.nconmax, true}, {"env_mode", 1, true}};
   for (const Spec& s : specs) {
     Field f; f.name = s.name; f.rows = s.rows; f.is_int = s.is_int; f.is_f64 = !strcmp(s.name, "time"); f.dev = nullptr; f.owned = nullptr;
     const size_t bytes = (size_t)std::max(1, s.rows) * b->B * (s.is_int ? sizeof(int) : (f.is_f64 ? sizeof(double) : b->elem));
@@ -223,6 +223,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->contact_force = (T*)P("contact_force"); io->cvel = (T*)P("cvel");
   io->ncon = (int*)P("ncon"); io->nefc = (int*)P("nefc"); io->solver_iter = (int*)P("solver_iter");
   io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
+  io->env_mode = (const int*)P("env_mode");
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
 }
@@ -252,6 +253,26 @@ extern "C" int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hi
   if (nstep < 1) return fail("nstep must be >= 1");
   return launch(b, nstep, legacy_step ? 1 : 0, 0, hip_stream);
 }
+// mj_step1 / mj_step2 as separate launches: the stage mj_step1 computes travels to mj_step2 through the per-env
+// stash in HBM (allocated on first use)
+static int ensure_stash(dmc_batch* b) {
+  if (b->stash_on) return 0;
+  const int epoch = b->stash_epoch;
+  if (dmc_batch_set_opt_int(b, "stash", 1)) return -2;
+  b->stash_epoch = epoch + 1;
+  return 0;
+}
+extern "C" int dmc_batch_step1(dmc_batch* b, void* hip_stream) {
+  if (!b) return fail("null batch");
+  if (ensure_stash(b)) return -2;
+  return launch(b, 1, 0, 4, hip_stream);
+}
+extern "C" int dmc_batch_step2(dmc_batch* b, void* hip_stream) {
+  if (!b) return fail("null batch");
+  if (b->tb.opts.integrator == DMC_INT_RK4) return fail("mj_step2 integrates with Euler only; RK4 models step through dmc_batch_step");
+  if (ensure_stash(b)) return -2;
+  return launch(b, 1, 0, 5, hip_stream);
+}
 extern "C" int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream) {
   if (!b) return fail("null batch");
   return launch(b, 0, 0, disable_actuation ? 2 : 1, hip_stream);
@@ -263,6 +284,92 @@ extern "C" int dmc_batch_rollout(dmc_batch* b, int nsteps, int n_sub_steps, cons
   SeqArgs sq = {ctrl_seq, qpos_seq, qvel_seq, sensordata_seq, n_sub_steps};
   return launch(b, nsteps, 1, 3, hip_stream, &sq);
 }
+// ---- observation gather table (composer/observation/updater.py:285-295, observable/mjcf.py:43) ---------------
+// An MJCFFeature observable is a named slice of an mjData field; a task's enabled observables resolve once into a
+// table of (field, row, corruptor) triples, and every control step ONE launch gathers them out of the SoA field
+// arrays into the (B, nobs) env-major observation matrix a policy consumes.  Reads are coalesced along the env
+// index (SoA rows), writes along the observation index (a 64 x 64 tile transposed through LDS).
+enum { GOP_NONE = 0, GOP_GREATER = 1, GOP_TANH2 = 2, GOP_LOG1P = 3, GOP_ASINH = 4 };
+struct GatherRow { int field, row, op; float prm; };
+struct GatherPtrs { const void* p[16]; };
+struct dmc_gather {
+  dmc_batch* batch;
+  int nrows;
+  std::vector<std::string> field_names;   // distinct fields, slot order
+  GatherRow* d_rows;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) gather_kernel(GatherPtrs ptrs, const GatherRow* __restrict__ rows, int nrows, int B, T* __restrict__ out) {
+  __shared__ T tile[64][65];
+  const int tx = threadIdx.x, ty = threadIdx.y;      // (64, 4)
+  const int env0 = blockIdx.x * 64;
+  for (int k0 = 0; k0 < nrows; k0 += 64) {
+    for (int kk = ty; kk < 64; kk += 4) {
+      const int k = k0 + kk, env = env0 + tx;
+      T v = 0;
+      if (k < nrows && env < B) {
+        const GatherRow r = rows[k];
+        v = ((const T*)ptrs.p[r.field])[(size_t)r.row * B + env];
+        if (r.op == GOP_GREATER) v = v > (T)r.prm ? (T)1 : (T)0;
+        else if (r.op == GOP_TANH2) v = (T)tanh((double)(2 * v / (T)r.prm));
+        else if (r.op == GOP_LOG1P) v = (T)log1p((double)v);
+        else if (r.op == GOP_ASINH) v = (T)asinh((double)v);
+      }
+      tile[kk][tx] = v;
+    }
+    __syncthreads();
+    for (int ee = ty; ee < 64; ee += 4) {
+      const int env = env0 + ee, k = k0 + tx;
+      if (env < B && k < nrows) out[(size_t)env * nrows + k] = tile[tx][ee];
+    }
+    __syncthreads();
+  }
+}
+extern "C" int dmc_gather_create(dmc_batch* b, int nrows, const char* const* field_names, const int* rows, const int* ops,
+                                 const double* params, dmc_gather** out) {
+  if (!b || !out || nrows < 1 || !field_names || !rows) return fail("null argument");
+  dmc_gather* g = new dmc_gather();
+  g->batch = b; g->nrows = nrows; g->d_rows = nullptr;
+  std::vector<GatherRow> h(nrows);
+  for (int k = 0; k < nrows; k++) {
+    Field* f = field_names[k] ? find_field(b, field_names[k]) : nullptr;
+    if (!f) { delete g; return fail(std::string("unknown field: ") + (field_names[k] ? field_names[k] : "(null)")); }
+    if (f->is_int || f->is_f64) { delete g; return fail(std::string("field cannot be gathered (not in batch precision): ") + f->name); }
+    if (rows[k] < 0 || rows[k] >= f->rows) { delete g; return fail(std::string("row out of range for field ") + f->name); }
+    int slot = -1;
+    for (size_t q = 0; q < g->field_names.size(); q++) if (g->field_names[q] == f->name) slot = (int)q;
+    if (slot < 0) { slot = (int)g->field_names.size(); g->field_names.push_back(f->name); }
+    if (slot >= 16) { delete g; return fail("at most 16 distinct fields per gather table"); }
+    const int op = ops ? ops[k] : GOP_NONE;
+    if (op < GOP_NONE || op > GOP_ASINH) { delete g; return fail("unknown gather op"); }
+    h[k].field = slot; h[k].row = rows[k]; h[k].op = op; h[k].prm = params ? (float)params[k] : 0.f;
+  }
+  hipError_t e = hipSetDevice(b->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&g->d_rows, sizeof(GatherRow) * nrows);
+  if (e == hipSuccess) e = hipMemcpy(g->d_rows, h.data(), sizeof(GatherRow) * nrows, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (g->d_rows) (void)hipFree(g->d_rows); delete g; return fail(hipGetErrorString(e), -2); }
+  *out = g;
+  return 0;
+}
+extern "C" void dmc_gather_destroy(dmc_gather* g) {
+  if (!g) return;
+  if (g->d_rows) (void)hipFree(g->d_rows);
+  delete g;
+}
+extern "C" int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream) {
+  if (!g || !out) return fail("null argument");
+  dmc_batch* b = g->batch;
+  GatherPtrs ptrs;
+  for (int q = 0; q < 16; q++) ptrs.p[q] = nullptr;
+  for (size_t q = 0; q < g->field_names.size(); q++) ptrs.p[q] = find_field(b, g->field_names[q].c_str())->dev;   // honours rebinding
+  HIP_TRY(hipSetDevice(b->device));
+  const dim3 grid((b->B + 63) / 64), block(64, 4);
+  if (b->precision == 64) hipLaunchKernelGGL(gather_kernel<double>, grid, block, 0, (hipStream_t)hip_stream, ptrs, g->d_rows, g->nrows, b->B, (double*)out);
+  else hipLaunchKernelGGL(gather_kernel<float>, grid, block, 0, (hipStream_t)hip_stream, ptrs, g->d_rows, g->nrows, b->B, (float*)out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dmc_batch_sync(dmc_batch* b) {
   if (!b) return fail("null batch");
   HIP_TRY(hipSetDevice(b->device));

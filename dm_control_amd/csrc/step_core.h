@@ -62,6 +62,7 @@ enum {
   OUT_SENSOR = 1 << 0, OUT_XPOS = 1 << 1, OUT_XQUAT = 1 << 2, OUT_XMAT = 1 << 3,
   OUT_XIPOS = 1 << 4, OUT_GEOM = 1 << 5, OUT_SITE = 1 << 6, OUT_SUBTREE_COM = 1 << 7,
   OUT_QACC = 1 << 8, OUT_ACTUATOR = 1 << 9, OUT_CONTACT = 1 << 10, OUT_QFRC = 1 << 11, OUT_CVEL = 1 << 12,
+  OUT_CONTACT_IDS = 1 << 13,   // contact_geom1 / contact_geom2 only (contact scans of task layers)
   OUT_ALL = 0x7fffffff
 };
 
@@ -78,6 +79,9 @@ struct StepIO {
   T *contact_force;   // (6 nconmax): mj_contactForce of the rows solved in this launch's last full pass
   T *cvel;            // (6 nbody): com-based body velocities, for mj_objectVelocity on the host
   int *ncon, *nefc, *solver_iter, *warning, *contact_geom1, *contact_geom2;
+  // per-env override of a step launch: 0 = as launched, 1 = mj_forward with actuation disabled instead (an
+  // environment that was just re-initialised: reset_context's after_reset), 2 = leave the environment untouched
+  const int* env_mode;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
@@ -632,6 +636,13 @@ struct StepCore {
     if (mask & OUT_ACTUATOR) FOR_LANES(i, L.d.nu) io.actuator_force[(size_t)i*B + env] = S(actuator_force)[i];
     if (lane == 0) {
       io.ncon[env] = SI(imisc)[IM_NCON]; io.nefc[env] = SI(imisc)[IM_NEFC]; io.solver_iter[env] = SI(imisc)[IM_ITER];
+    }
+    if ((mask & OUT_CONTACT_IDS) && !(mask & OUT_CONTACT)) {
+      const int nc = SI(imisc)[IM_NCON];
+      FOR_LANES(c, L.d.nconmax) {
+        io.contact_geom1[(size_t)c*B + env] = c < nc ? con_g1(c) : -1;
+        io.contact_geom2[(size_t)c*B + env] = c < nc ? con_g2(c) : -1;
+      }
     }
     if (mask & OUT_CONTACT) {
       const int nc = SI(imisc)[IM_NCON];
@@ -3214,7 +3225,7 @@ struct StepCore {
   DMC_DEV void stage_posvel(bool partial, int outmask, bool skipsensor) {
     kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM);
     if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
-    if (!partial || (outmask & OUT_CONTACT)) { collision(); DMC_PROF(PROF_COLL); }
+    if (!partial || (outmask & (OUT_CONTACT | OUT_CONTACT_IDS))) { collision(); DMC_PROF(PROF_COLL); }
     if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); }
     if (!skipsensor) sensors(DMC_STAGE_POS);
     DMC_PROF(PROF_SENS);
@@ -3287,7 +3298,45 @@ struct StepCore {
   // (engine.py:147-162): mj_step2 on the position / velocity stage the previous call's mj_step1 left behind
   // (reloaded from HBM instead of recomputed), ..., then a FULL mj_step1 whose results are stashed for the next
   // call.  Without one the opening stage is recomputed and the trailing mj_step1 only evaluates the outputs.
+  // mode 4 / 5 = mj_step1 / mj_step2 as separate entry points (engine.py:156-162 calls them one after the other with
+  // Python in between): mj_step1 leaves its stage in the stash, mj_step2 picks it up (and recomputes it when the
+  // state was edited in between, where MuJoCo would integrate on stale derived arrays).
+  DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask) {
+    const bool stash = io.stash_r != nullptr;
+    bool have = false;
+    if (mode == 5 && stash) have = load_stash(io, env);
+    load_state(io, env, have);
+    if (mode == 4) {
+      check_pos_vel();
+      call_posvel(false, outmask, false);
+      store_outputs(io, env, outmask);
+      if (stash) store_stash(io, env, true);
+      store_state(io, env);
+      return;
+    }
+    int retried = 0;
+    for (;;) {
+      if (!have || retried) call_posvel(false, outmask, true);
+      call_acc(false, false);
+      if (!retried && bad_acc()) {
+        if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
+        if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
+      }
+      break;
+    }
+    // acceleration-stage results; the position-stage arrays keep the values mj_step1 wrote
+    store_outputs(io, env, outmask & (OUT_SENSOR | OUT_QACC | OUT_ACTUATOR | OUT_QFRC | OUT_CONTACT));
+    call_euler();
+    if (stash) store_stash(io, env, false);
+    store_state(io, env);
+  }
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub) {
+    if (io.env_mode) {
+      const int em = io.env_mode[late(env)];
+      if (em == 2) return;
+      if (em == 1 && (mode == 0 || mode >= 4)) mode = 2;
+    }
+    if (mode >= 4) { run_split(io, env, mode, outmask); return; }
     prof_begin();
     const bool stash = io.stash_r != nullptr;
     bool have = false;

@@ -11,10 +11,28 @@ gather per field and works for the whole batch at once.
   table = GatherTable(model, [('qpos', ['bthigh', 'bshin']), ('xpos', ['torso'], 'z'), ('sensordata', None)])
   obs = table.gather(physics)             # (B, table.size) float64 (B == 1: (table.size,))
   rows = table.rows['xpos']               # the row indices, e.g. to index a device tensor of that field
+
+On the device the same table is ONE launch of the library's gather kernel (include/dmc_batch.h dmc_gather_*):
+
+  dg = table.on_device(batch)             # a BatchedPhysics
+  obs = dg(out=None, stream=None)         # (B, table.size) torch tensor in batch precision, env-major
+
+An entry may carry a corruptor, the per-value transform some of the reference's observables apply
+(`corruptor=` of MJCFFeature): ('sensordata', touch_sensor_names, None, ('greater', 1e-3)).
 """
 import collections
+import ctypes
 
 import numpy as np
+
+# corruptors the gather kernel implements (csrc/dmc_api.hip GOP_*): name -> (op code, host function of (v, p))
+OPS = {
+    None: (0, lambda v, p: v),
+    'greater': (1, lambda v, p: (v > p).astype(np.float64)),      # walkers' touch sensors (legacy_base.py:262-265)
+    'tanh2': (2, lambda v, p: np.tanh(2 * v / p)),                # torque sensors (cmu_humanoid.py:462-465)
+    'log1p': (3, lambda v, p: np.log1p(v)),
+    'asinh': (4, lambda v, p: np.arcsinh(v)),
+}
 
 # field -> (kind of named object, entries per object, column names)
 _FIELDS = {
@@ -49,10 +67,14 @@ class GatherTable:
     self.model = model
     self.rows = collections.OrderedDict()
     self.slices = []                      # (field, first output column, count), in entry order
+    self.flat = []                        # per output column: (field, row, op name, op parameter)
     out = 0
     for entry in entries:
       field, names = entry[0], entry[1]
       columns = entry[2] if len(entry) > 2 else None
+      op, prm = entry[3] if len(entry) > 3 and entry[3] else (None, 0.0)
+      if op not in OPS:
+        raise ValueError('unknown corruptor %r' % (op,))
       if field not in _FIELDS:
         raise ValueError('field %r cannot be observed through a GatherTable' % field)
       kind, width, colnames = _FIELDS[field]
@@ -60,6 +82,7 @@ class GatherTable:
       self.rows.setdefault(field, [])
       self.rows[field].extend(idx)
       self.slices.append((field, out, len(idx)))
+      self.flat.extend((field, int(r), op, float(prm)) for r in idx)
       out += len(idx)
     self.size = out
     # per field: the rows to fetch and where each entry's values go in the flat observation
@@ -105,4 +128,50 @@ class GatherTable:
     out = np.zeros((B, self.size))
     for field, src, dst, count in self._plan:
       out[:, dst:dst + count] = fetched[field][:, src:src + count]
+    for k, (_, _, op, prm) in enumerate(self.flat):
+      if op is not None:
+        out[:, k] = OPS[op][1](out[:, k], prm)
     return out[0] if B == 1 else out
+
+  def on_device(self, batch):
+    """The table as a device gather over `batch` (a BatchedPhysics)."""
+    return DeviceGather(self, batch)
+
+
+class DeviceGather:
+  """One HIP launch per evaluation: (B, size) env-major observation matrix in batch precision."""
+
+  def __init__(self, table, batch):
+    from dm_control_amd import _native
+    self._native = _native
+    self.table, self.batch = table, batch
+    n = table.size
+    names = (ctypes.c_char_p * n)(*[f.encode() for f, _, _, _ in table.flat])
+    rows = np.array([r for _, r, _, _ in table.flat], dtype=np.int32)
+    ops = np.array([OPS[o][0] for _, _, o, _ in table.flat], dtype=np.int32)
+    prm = np.array([p for _, _, _, p in table.flat], dtype=np.float64)
+    self._ptr = ctypes.c_void_p()
+    _native.check(_native.lib().dmc_gather_create(batch._ptr, n, names, rows.ctypes.data, ops.ctypes.data,
+                                                  prm.ctypes.data, ctypes.byref(self._ptr)))
+
+  def __call__(self, out=None, stream=None):
+    import torch
+    B = self.batch.batch_size
+    if out is None:
+      dt = torch.float32 if self.batch.precision == 32 else torch.float64
+      out = torch.empty((B, self.table.size), dtype=dt, device=torch.device('cuda', self.batch.device_id))
+    if stream is None:
+      stream = torch.cuda.current_stream().cuda_stream
+    self._native.check(self._native.lib().dmc_gather_run(self._ptr, out.data_ptr(), stream))
+    return out
+
+  def close(self):
+    if self._ptr:
+      self._native.lib().dmc_gather_destroy(self._ptr)
+      self._ptr = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass

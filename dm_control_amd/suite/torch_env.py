@@ -80,8 +80,9 @@ class TorchBatchedEnv:
     self.warm, self.sensordata = mk(m.nv), mk(m.nsensordata)
     self.time = torch.zeros((1, self.B), dtype=torch.float64, device=self.device)
     self.ncon = torch.zeros((1, self.B), dtype=torch.int32, device=self.device)
+    self.env_mode = torch.zeros((1, self.B), dtype=torch.int32, device=self.device)
     bound = [('qpos', self.qpos), ('qvel', self.qvel), ('ctrl', self.ctrl), ('qacc_warmstart', self.warm),
-             ('sensordata', self.sensordata), ('time', self.time), ('ncon', self.ncon)]
+             ('sensordata', self.sensordata), ('time', self.time), ('ncon', self.ncon), ('env_mode', self.env_mode)]
     if m.na:
       self.act = mk(m.na)      # activation states (filtered servos): zero at every reset
       bound.append(('act', self.act))
@@ -146,12 +147,12 @@ class TorchBatchedEnv:
       self.act.copy_(torch.where(m2, torch.zeros_like(self.act), self.act))
     self.physics.invalidate()      # qpos / qvel were edited through the bound tensors
     if self._OUTPUTS:
-      # forward is a pure function of (qpos, qvel): recomputing it for the environments that
-      # were not reset reproduces the derived arrays they already hold; their solver warm start
-      # is put back so that their trajectories do not depend on who else was reset
-      warm = self.warm.clone()
+      # refresh the derived arrays of the environments that were reset, and of those only: the others are left
+      # untouched by the launch (env_mode 2), so their acceleration-stage sensors, warm starts and observations
+      # do not depend on who else was reset
+      self.env_mode.copy_(torch.where(m2, torch.zeros_like(self.env_mode), torch.full_like(self.env_mode, 2)))
       self.physics.forward(disable_actuation=True, stream=self._stream())
-      self.warm.copy_(torch.where(m2, self.warm, warm))
+      self.env_mode.zero_()
     return self.observation()
 
   # -- task ----------------------------------------------------------------------------

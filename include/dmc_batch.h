@@ -58,6 +58,15 @@ int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream);
 int dmc_batch_rollout(dmc_batch* b, int nsteps, int n_sub_steps, const void* ctrl_seq, void* qpos_seq,
                       void* qvel_seq, void* sensordata_seq, void* hip_stream);
 
+/* Replace mujoco.mj_step1 / mujoco.mj_step2 called on their own (engine.py:156-162; composer hooks that read or
+ * write between the two halves of a step).  dmc_batch_step1: position / velocity stage at the current state
+ * (derived arrays and position / velocity sensors written, state unchanged); dmc_batch_step2: actuation,
+ * acceleration, constraint solve, acceleration-stage sensors, mj_checkAcc, Euler integration.  The stage travels
+ * from one call to the other through the per-environment stash (see dmc_batch_invalidate); if the state was
+ * edited in between, dmc_batch_step2 recomputes it first.  dmc_batch_step2 rejects RK4 models. */
+int dmc_batch_step1(dmc_batch* b, void* hip_stream);
+int dmc_batch_step2(dmc_batch* b, void* hip_stream);
+
 /* Replaces mujoco.mj_forward (engine.py:343); disable_actuation != 0 mirrors the
  * mjDSBL_ACTUATION context used by Physics.reset/after_reset (engine.py:326-333). */
 int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);
@@ -72,7 +81,11 @@ int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
  * "qfrc_actuator", "qfrc_bias", "qfrc_constraint", "contact_dist", "contact_pos",
  * "contact_frame", "contact_force" (mj_contactForce per contact, valid after dmc_batch_forward;
  * wrapper/core.py:527-552), "cvel" (for mj_objectVelocity, wrapper/core.py:500-525); int32: "ncon", "nefc", "solver_iter", "warning",
- * "contact_geom1", "contact_geom2").  Replaces the numpy views MjData exposes
+ * "contact_geom1", "contact_geom2", "env_mode").  "env_mode" (one int per environment, default 0) overrides what a
+ * dmc_batch_step / step1 / step2 launch does to that environment: 0 = step, 1 = mj_forward with actuation
+ * disabled instead (an environment re-initialised under the reference's reset_context, rl/control.py:232-253,
+ * while the rest of the batch steps), 2 = leave it untouched (also honoured by dmc_batch_forward: refresh only
+ * the environments that were reset).  Replaces the numpy views MjData exposes
  * (wrapper/core.py:438-447).  Host buffers are env-major: (B, rows), float64 /
  * int32 regardless of the batch precision.  Synchronous. */
 int dmc_batch_field_rows(const dmc_batch* b, const char* name, int* rows, int* is_int);
@@ -116,6 +129,19 @@ int dmc_batch_sync(dmc_batch* b);
  * act through memory it bound with dmc_batch_bind must call this afterwards (the reference's equivalent:
  * derived quantities are stale until mj_forward is run). */
 int dmc_batch_invalidate(dmc_batch* b);
+
+/* Observation gather table: what composer's observation.Updater does per control step for MJCFFeature observables
+ * (composer/observation/updater.py:285-295, composer/observation/observable/mjcf.py:43), for the whole batch in one
+ * launch.  Row k of the table names element `rows[k]` of the mjData field `field_names[k]` (real-valued fields in
+ * batch precision), optionally passed through a corruptor `ops[k]` with parameter `params[k]`:
+ * 0 none, 1 (v > p ? 1 : 0) (walkers' touch sensors, legacy_base.py:262-265), 2 tanh(2 v / p) (torque sensors,
+ * cmu_humanoid.py:462-465), 3 log1p(v), 4 asinh(v).  dmc_gather_run writes out[env * nrows + k], a (B, nrows)
+ * env-major matrix in batch precision, on `hip_stream`; fields rebound with dmc_batch_bind are followed. */
+typedef struct dmc_gather dmc_gather;
+int dmc_gather_create(dmc_batch* b, int nrows, const char* const* field_names, const int* rows, const int* ops,
+                      const double* params, dmc_gather** out);
+void dmc_gather_destroy(dmc_gather* g);
+int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream);
 
 /* info[0..17] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
  * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id,

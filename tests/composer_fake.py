@@ -1,0 +1,140 @@
+"""TEST INFRASTRUCTURE: `composer.physics.DevicePhysics` on CPU tensors with the oracle doing the stepping.
+
+Same surface as the product class (fields as (rows, B) torch tensors, bind, gather, env_mode, step / forward / reset),
+so that the composer-side layer -- the environment loop, hooks, the go-to-target and soccer tasks -- runs in the
+`-m "not gpu"` tier.  Nothing under dm_control_amd/ can reach this module."""
+import numpy as np
+import torch
+
+from dm_control_amd.composer.physics import Binding, _DERIVED
+from oracle.oracle import OracleModel, OraclePhysics, lib
+
+_DSBL_ACTUATION = 1 << 11
+
+
+class OracleDevicePhysics:
+
+  def __init__(self, model, batch_size, outputs=('sensordata', 'xpos', 'xmat'), nconmax=32, **unused):
+    self.torch = torch
+    self.model = model
+    self.B = int(batch_size)
+    self.device = torch.device('cpu')
+    self.dtype = torch.float64
+    self._om = OracleModel(model)
+    self._envs = [OraclePhysics(self._om) for _ in range(self.B)]
+    self.nconmax = nconmax
+    m, nb = model, model.nbody
+    rows = dict(qpos=m.nq, qvel=m.nv, ctrl=m.nu, act=m.na, qacc_warmstart=m.nv, time=1, sensordata=m.nsensordata,
+                xpos=3*nb, xquat=4*nb, xmat=9*nb, xipos=3*nb, subtree_com=3*nb, geom_xpos=3*m.ngeom, geom_xmat=9*m.ngeom,
+                site_xpos=3*m.nsite, site_xmat=9*m.nsite, qacc=m.nv, actuator_force=m.nu, qfrc_actuator=m.nv, cvel=6*nb)
+    self._rows = rows
+    self._fields = {}
+    names = ['qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'time'] + (['act'] if m.na else []) + [f for f in outputs if f in rows]
+    for n in names:
+      self._fields[n] = torch.zeros((max(rows[n], 1), self.B), dtype=torch.float64)
+    for n in ('ncon',):
+      self._fields[n] = torch.zeros((1, self.B), dtype=torch.int32)
+    self._fields['warning'] = torch.zeros((9, self.B), dtype=torch.int32)
+    self._fields['env_mode'] = torch.zeros((1, self.B), dtype=torch.int32)
+    if 'contact_geom1' in outputs:
+      self._fields['contact_geom1'] = torch.full((nconmax, self.B), -1, dtype=torch.int32)
+      self._fields['contact_geom2'] = torch.full((nconmax, self.B), -1, dtype=torch.int32)
+    self._state = [n for n in ('qpos', 'qvel', 'ctrl', 'act', 'qacc_warmstart') if n in self._fields]
+    self._derived = [n for n in outputs if n in rows]
+    self.launches = []
+    self.reset()
+
+  def field(self, name):
+    return self._fields[name]
+
+  def bind(self, kind, names):
+    return Binding(self, kind, names)
+
+  def stream(self):
+    return None
+
+  def mark_as_dirty(self):
+    pass
+
+  def gather(self, table):
+    out = torch.zeros((self.B, table.size), dtype=torch.float64)
+    from dm_control_amd.observation import OPS
+    for k, (f, r, op, prm) in enumerate(table.flat):
+      out[:, k] = torch.from_numpy(OPS[op][1](self._fields[f][r].numpy(), prm))
+    return out
+
+  def timestep(self):
+    return float(self.model.opt.timestep)
+
+  # -- oracle <-> tensors ----------------------------------------------------------------------------
+  def _push(self, e):
+    o = self._envs[e]
+    for n in self._state:
+      r = self._rows[n]
+      if r:
+        o.field(n)[:r] = self._fields[n][:r, e].numpy()
+    o.time = float(self._fields['time'][0, e])
+
+  def _pull(self, e, state=True):
+    o = self._envs[e]
+    for n in (self._state if state else []) + self._derived:
+      r = self._rows[n]
+      if r:
+        self._fields[n][:r, e] = torch.from_numpy(np.array(o.field(n))[:r])
+    self._fields['time'][0, e] = o.time
+    self._fields['ncon'][0, e] = o.ncon
+    if 'contact_geom1' in self._fields:
+      self._fields['contact_geom1'][:, e] = -1
+      self._fields['contact_geom2'][:, e] = -1
+      for i in range(min(o.ncon, self.nconmax)):
+        c = o.contact(i)
+        self._fields['contact_geom1'][i, e] = c['geom1']
+        self._fields['contact_geom2'][i, e] = c['geom2']
+    w = np.array(o.warning, dtype=np.int32)
+    self._fields['warning'][:, e] += torch.from_numpy(w)
+    o.warning[:] = 0
+
+  def _forward(self, e, disable_actuation):
+    flags = self._om.opt_int('disableflags')
+    if disable_actuation:
+      self._om.opt_int('disableflags', flags | _DSBL_ACTUATION)
+    self._envs[e].forward()
+    self._om.opt_int('disableflags', flags)
+
+  def forward(self, disable_actuation=False):
+    self.launches.append('forward')
+    for e in range(self.B):
+      if int(self._fields['env_mode'][0, e]) == 2:
+        continue
+      self._push(e)
+      self._forward(e, disable_actuation)
+      self._pull(e, state=False)
+
+  def step(self, nstep=1):
+    self.launches.append('step%d' % nstep)
+    for e in range(self.B):
+      mode = int(self._fields['env_mode'][0, e])
+      if mode == 2:
+        continue
+      self._push(e)
+      if mode == 1:
+        self._forward(e, True)
+        self._pull(e, state=False)
+      else:
+        self._envs[e].step1()        # derived arrays of the (possibly edited) state, as the kernel recomputes them
+        self._envs[e].step(int(nstep))
+        self._pull(e)
+
+  def reset(self, mask=None):
+    q0 = torch.from_numpy(np.asarray(self.model.qpos0, dtype=np.float64))[:, None]
+    m2 = torch.ones((1, self.B), dtype=torch.bool) if mask is None else mask[None, :]
+    f = self._fields
+    f['qpos'].copy_(torch.where(m2, q0, f['qpos']))
+    for n in ('qvel', 'ctrl', 'qacc_warmstart', 'time') + (('act',) if 'act' in f else ()):
+      f[n].copy_(torch.where(m2, torch.zeros_like(f[n]), f[n]))
+    for e in range(self.B):
+      if mask is None or bool(mask[e]):
+        lib().ora_reset(self._om.ptr, self._envs[e].ptr, -1)
+
+  def close(self):
+    self._envs = []

@@ -73,6 +73,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.contact_force = buf[24].data(); io.cvel = buf[25].data(); io.act = buf[26].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
+  io.env_mode = nullptr;
   io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
   if (e->stash_on) { io.stash_r = sizeof(T) == 8 ? (T*)e->stash_r64.data() : (T*)e->stash_r32.data(); io.stash_i = e->stash_i.data(); }
   DynLayoutSrc ls; ls.p = &L;

@@ -96,6 +96,12 @@ class EmuPhysics:
   def step(self, nstep=1, legacy=True):
     self._run(nstep, int(legacy), 0)
 
+  def step1(self):
+    self._run(1, 0, 4)
+
+  def step2(self):
+    self._run(1, 0, 5)
+
   def forward(self, disable_actuation=False):
     self._run(0, 0, 2 if disable_actuation else 1)
 

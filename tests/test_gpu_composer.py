@@ -1,0 +1,184 @@
+"""GPU tier of the composer-side layer: the device observation gather, per-env launch modes, and the BASELINE
+config 4 / 5 environments against a host evaluation of the same state (the reference's per-env numpy formulas)."""
+import numpy as np
+import pytest
+
+from dm_control_amd import mjcf_compiler as mc, observation
+from dm_control_amd.suite import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name):
+  return mc.compile_xml(common.read_model(name + '.xml'))
+
+
+@pytest.mark.parametrize('precision', [32, 64])
+def test_device_gather_matches_host_gather(precision):
+  """dmc_gather_* (composer/observation/updater.py:285-295 for a batch): one launch, (B, nobs) env-major, with the
+  corruptors of the walkers' touch / torque observables, against the host evaluation of the same table."""
+  import torch
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.physics import Physics
+  m = _model('humanoid')
+  B = 77                                   # not a multiple of the 64-env tile
+  b = BatchedPhysics(m, B, precision=precision, nconmax=24)
+  rs = np.random.RandomState(0)
+  q = np.tile(m.qpos0, (B, 1)); q[:, 7:] += rs.uniform(-.3, .3, (B, m.nq - 7)); q[:, 2] = rs.uniform(0.2, 1.5, B)
+  b.set('qpos', q); b.set('qvel', rs.uniform(-1, 1, (B, m.nv)))
+  b.forward()
+  touch = [n for i, n in enumerate(m.names['sensor']) if m.sensor_type[i] == 0]
+  table = observation.GatherTable(m, [
+      ('qpos', ['right_knee', 'left_knee', 'root']), ('qvel', None), ('xpos', ['head', 'torso'], 'z'),
+      ('xmat', ['torso'], ['zx', 'zy', 'zz']), ('sensordata', touch, None, ('greater', 1e-3)),
+      ('sensordata', ['torso_accel'], None, ('tanh2', 60.0)), ('sensordata', ['torso_gyro'], None, ('asinh', 0.0)),
+      ('subtree_com', ['torso']), ('sensordata', touch, None, ('log1p', 0.0))] * 3)       # > 64 rows: several tiles
+  assert table.size > 128
+  dg = table.on_device(b)
+  out = dg()
+  torch.cuda.synchronize()
+  assert tuple(out.shape) == (B, table.size)
+
+  class _Host:      # the host mirror's surface GatherTable.gather needs
+    batch_size = B
+    batch = b
+  want = table.gather(_Host)
+  tol = 1e-12 if precision == 64 else 2e-6
+  np.testing.assert_allclose(out.cpu().numpy(), want, rtol=tol, atol=tol)
+  # a rebound field is followed
+  qdev = torch.from_numpy(np.ascontiguousarray((q + 1.0).T)).to('cuda').to(out.dtype)
+  b.sync(); b.bind('qpos', qdev.data_ptr())
+  out2 = dg()
+  np.testing.assert_allclose(out2[:, 0].cpu().numpy(), q[:, m.jnt_qposadr[m.name2id('right_knee', 'joint')]] + 1.0, rtol=tol, atol=tol)
+  with pytest.raises(Exception):
+    observation.GatherTable(m, [('qpos', ['no_such_joint'])])
+  dg.close(); b.close()
+
+
+def test_env_mode_per_environment_launch_override():
+  """"env_mode": 0 = step, 1 = mj_forward with actuation disabled instead (reset_context while the batch steps),
+  2 = untouched."""
+  from dm_control_amd.batch import BatchedPhysics, OUT
+  m = _model('hopper')
+  B = 6
+  rs = np.random.RandomState(1)
+  q = np.tile(m.qpos0, (B, 1)); q[:, 1] += 0.3; q[:, 3:] += rs.uniform(-.2, .2, (B, m.nq - 3))
+  c = rs.uniform(-1, 1, (B, m.nu))
+  a, b = BatchedPhysics(m, B, precision=64), BatchedPhysics(m, B, precision=64)
+  for e in (a, b):
+    e.set('qpos', q); e.set_control(c); e.set_output_mask(OUT['sensor'] | OUT['xpos'] | OUT['actuator'])
+    e.step(3)
+  mode = np.array([0, 1, 2, 0, 2, 1], dtype=np.int32)[:, None]
+  before = {f: b.get(f) for f in ('qpos', 'qvel', 'xpos', 'sensordata', 'time', 'actuator_force')}
+  b.set_int('env_mode', mode)
+  a.step(2); b.step(2)
+  fwd = BatchedPhysics(m, B, precision=64)
+  fwd.set('qpos', before['qpos']); fwd.set('qvel', before['qvel']); fwd.set_control(c)
+  fwd.set('qacc_warmstart', a.get('qacc_warmstart') * 0 + b.get('qacc_warmstart'))
+  fwd.forward(disable_actuation=True)
+  for e in range(B):
+    if mode[e, 0] == 0:
+      for f in before:
+        np.testing.assert_array_equal(b.get(f)[e], a.get(f)[e], err_msg='%s env %d' % (f, e))
+    else:
+      for f in ('qpos', 'qvel', 'time'):
+        np.testing.assert_array_equal(b.get(f)[e], before[f][e], err_msg='%s env %d' % (f, e))
+      if mode[e, 0] == 2:
+        for f in ('xpos', 'sensordata', 'actuator_force'):
+          np.testing.assert_array_equal(b.get(f)[e], before[f][e])
+      else:
+        np.testing.assert_allclose(b.get('xpos')[e], fwd.get('xpos')[e], atol=1e-13)
+        assert np.abs(b.get('actuator_force')[e]).max() == 0.0 and np.abs(before['actuator_force'][e]).max() > 0
+  a.close(); b.close(); fwd.close()
+
+
+def test_go_to_target_environment_on_gpu():
+  """BASELINE config 4 as an environment (tasks/go_to_target.py): observations / reward / contact-scan termination
+  of the device task against the per-env host evaluation of the same device state; auto-reset without host sync."""
+  import torch
+  from dm_control_amd import composer
+  from dm_control_amd.composer import environment
+  from test_composer_cpu import _reference_observation
+  B = 48
+  env = composer.make('cmu_go_to_target', B, random_state=5)
+  task, phys, m = env.task, env.physics, env.task.model
+  assert env.fused and env.n_sub_steps == 6
+  ts = env.reset()
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  nonfoot = {m.name2id(n, 'geom') for n in task.walker.nonfoot_geoms}
+  seen_last = seen_first = 0
+  launches0 = env.launches
+  for t in range(60):
+    a = torch.rand((B, m.nu), device='cuda', generator=gen) * 2 - 1
+    prev_reset = env._reset_next.clone()
+    ts = env.step(a)
+    torch.cuda.synchronize()
+
+    class _Host:      # CPU copies of the device fields for the per-env reference formulas
+      B = 0
+      def __init__(s): s.f = {n: phys.field(n).cpu().double() for n in ('qpos', 'qvel', 'xpos', 'xmat', 'sensordata')}
+      def field(s, n): return s.f[n]
+    host = _Host()
+    tgt = task.target_position(phys).cpu().double()
+    task_view = type('T', (), {'walker': task.walker, 'target_position': staticmethod(lambda p: tgt)})
+    g1 = phys.field('contact_geom1').cpu().numpy(); g2 = phys.field('contact_geom2').cpu().numpy()
+    for e in (0, 7, B - 1):
+      want = _reference_observation(m, task_view, host, e)
+      for k, v in want.items():
+        np.testing.assert_allclose(ts.observation[k][e].cpu().numpy(), v, rtol=0, atol=2e-5, err_msg='%s step %d' % (k, t))
+    # termination = the reference's contact scan (go_to_target.py:189-193), per env in Python
+    scan = np.array([any((x in nonfoot and y == 0) or (y in nonfoot and x == 0) for x, y in zip(g1[:, e], g2[:, e]) if x >= 0)
+                     for e in range(B)])
+    first = prev_reset.cpu().numpy()
+    st = ts.step_type.cpu().numpy()
+    assert (st[first] == environment.FIRST).all()
+    assert ((st == environment.LAST) == (scan & ~first)).all(), t
+    assert (ts.discount.cpu().numpy()[scan & ~first] == 0).all()
+    root = phys.field('xpos')[3*m.name2id('root', 'body'):][:2].cpu().numpy()
+    want_r = (np.linalg.norm(tgt.numpy() - root, axis=0) < 1.0) & ~first
+    np.testing.assert_array_equal(ts.reward.cpu().numpy() > 0, want_r)
+    seen_last += int((st == environment.LAST).sum()); seen_first += int(first.sum())
+  assert env.launches - launches0 == 60              # one launch per control step, resets included
+  assert seen_last > 0 and seen_first > 0            # random actions make the humanoid fall: episodes end and restart
+  assert int(phys.field('warning').sum()) == 0
+  env.close()
+
+
+def test_soccer_environment_on_gpu():
+  """BASELINE config 5 as an environment (tasks/soccer.py): per-substep goal detectors, 4-agent rewards, throw-in."""
+  import torch
+  from dm_control_amd import composer
+  from dm_control_amd.composer import environment
+  B = 16
+  env = composer.make('soccer_2v2', B, random_state=2)
+  task, phys, m = env.task, env.physics, env.task.model
+  assert not env.fused and env.n_sub_steps == 5
+  ts = env.reset()
+  assert tuple(ts.observation['ball_ego_position'].shape) == (B, 4, 3)
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  l0 = env.launches
+  for t in range(10):
+    ts = env.step(torch.rand((B, 4, 3), device='cuda', generator=gen) * 2 - 1)
+  assert env.launches - l0 == 50
+  torch.cuda.synchronize()
+  hb = m.name2id('away1/head_body', 'body')
+  pos = phys.field('xpos')[3*hb:3*hb + 3, 3].cpu().double().numpy()
+  R = phys.field('xmat')[9*hb:9*hb + 9, 3].cpu().double().numpy().reshape(3, 3)
+  ball = task.ball_xpos(phys)[:, 3].cpu().double().numpy()
+  np.testing.assert_allclose(ts.observation['ball_ego_position'][3, 3].cpu().numpy(), (ball - pos) @ R, atol=2e-5)
+  assert float(ts.reward.abs().max()) == 0.0
+  bq = task._ball_q
+  q = phys.field('qpos')
+  q[bq:bq + 3, 0] = torch.tensor([-37.0, 0.0, 1.0], device='cuda', dtype=q.dtype)       # in the home goal: AWAY scores
+  q[bq:bq + 3, 5] = torch.tensor([0.0, -27.5, 0.2], device='cuda', dtype=q.dtype)       # off the court
+  phys.field('qvel')[task._ball_v:task._ball_v + 6] = 0
+  phys.mark_as_dirty()
+  ts = env.step(torch.zeros((B, 4, 3), device='cuda'))
+  assert ts.reward[:, 0].tolist() == [-1.0, -1.0, 1.0, 1.0]
+  st = ts.step_type.cpu().numpy()
+  assert st[0] == environment.LAST and (st[1:] == environment.MID).all() and float(ts.discount[0]) == 0.0
+  assert bool(task.field.detected[5])
+  ts = env.step(torch.zeros((B, 4, 3), device='cuda'))
+  assert int(ts.step_type[0]) == environment.FIRST and not bool(task.field.detected[5])
+  assert int(phys.field('warning').sum()) == 0
+  env.close()

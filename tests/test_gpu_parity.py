@@ -741,3 +741,56 @@ def test_connect_weld_joint_equalities_match_oracle_on_gpu(precision, tol, lanes
     np.testing.assert_allclose(b.get('qpos'), qo, rtol=0, atol=tol)
     assert not b.get('warning').any()
     b.close()
+
+
+@pytest.mark.parametrize('name,precision,lanes', [('cheetah', 64, 32), ('cheetah', 32, 32), ('humanoid', 32, 64)])
+def test_step1_step2_entry_points_on_gpu(name, precision, lanes):
+  """dmc_batch_step1 / dmc_batch_step2 (mujoco.mj_step1 / mj_step2 on their own, engine.py:156-162): the pair is
+  bit-identical to one non-legacy mj_step launch, the arrays step1 writes are those of the current state (vs the
+  oracle's mj_step1), and a state edit between the two makes step2 recompute the stage."""
+  from oracle.oracle import OraclePhysics, OracleModel
+  m = _model(name)
+  B, T = 9, 40
+  rs = np.random.RandomState(8)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, -3:] += rs.uniform(-.2, .2, (B, 3))
+  a, b = _batch(m, B, precision=precision, lanes_per_env=lanes), _batch(m, B, precision=precision, lanes_per_env=lanes)
+  a.legacy_step = False
+  om = OracleModel(m)
+  refs = [OraclePhysics(om) for _ in range(B)]
+  for e in (a, b):
+    e.set('qpos', q)
+  for k, o in enumerate(refs):
+    o.qpos[:] = q[k]
+  tol = 1e-10 if precision == 64 else 2e-4
+  for t in range(T):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    for e in (a, b):
+      e.set_control(c)
+    a.step()
+    b.step1()
+    xg = b.get('xpos')
+    for k, o in enumerate(refs):
+      o.ctrl[:] = c[k]
+      if precision == 32 and t:      # teacher-forced: the fp32 trajectory drifts from the fp64 one
+        o.qpos[:] = qprev[k]; o.qvel[:] = vprev[k]; o.qacc_warmstart[:] = wprev[k]
+      o.step1()
+      np.testing.assert_allclose(xg[k], np.array(o.xpos), rtol=0, atol=tol)
+    b.step2()
+    for o in refs:
+      o.step2()
+    qprev, vprev, wprev = b.get('qpos'), b.get('qvel'), b.get('qacc_warmstart')
+    np.testing.assert_array_equal(a.get('qpos'), qprev, err_msg='step %d' % t)
+    np.testing.assert_array_equal(a.get('qvel'), vprev)
+    np.testing.assert_allclose(qprev, np.stack([o.qpos for o in refs]), rtol=0, atol=tol)
+    if t == 20:
+      b.step1()
+      for e in (a, b):
+        e.set('qvel', np.zeros((B, m.nv)))
+      a.step()
+      b.step2()
+      np.testing.assert_array_equal(a.get('qpos'), b.get('qpos'))
+      qprev, vprev, wprev = b.get('qpos'), b.get('qvel'), b.get('qacc_warmstart')
+      for k, o in enumerate(refs):
+        o.qpos[:] = qprev[k]; o.qvel[:] = vprev[k]; o.qacc_warmstart[:] = wprev[k]
+  a.close(); b.close()

@@ -483,3 +483,42 @@ def test_stash_between_legacy_steps_is_bit_identical(asset):
         e.qvel[:] = 0
       b.invalidate()
   assert np.abs(a.qpos - q).max() > 1e-3
+
+
+@pytest.mark.parametrize('asset', ['cheetah', 'humanoid', 'hopper'])
+def test_step1_step2_entry_points(asset):
+  """mj_step1 and mj_step2 as separate calls (engine.py:156-162): step1; step2 is exactly mj_step, the derived
+  arrays after step1 are those of the current state, and the pair tracks the oracle's step1 / step2."""
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    m = mc.compile_xml(f.read())
+  a, b, o = EmuPhysics(m, 64), EmuPhysics(m, 64), OraclePhysics(m)
+  b.stash(True)
+  rs = np.random.RandomState(4)
+  q = m.qpos0.copy()
+  q[-3:] += rs.uniform(-.2, .2, 3)
+  for e in (a, b, o):
+    e.qpos[:] = q
+  for t in range(80):
+    c = rs.uniform(-1, 1, m.nu)
+    for e in (a, b, o):
+      e.ctrl[:] = c
+    a.step(1, legacy=False)
+    b.step1()
+    o.step1()
+    np.testing.assert_allclose(b.xpos, np.array(o.xpos), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.sensordata[:3], np.array(o.sensordata)[:3], rtol=0, atol=1e-9)
+    b.step2()
+    o.step2()
+    np.testing.assert_array_equal(a.qpos, b.qpos, err_msg='step %d' % t)
+    np.testing.assert_array_equal(a.qvel, b.qvel)
+    np.testing.assert_allclose(b.qpos, np.array(o.qpos), rtol=0, atol=1e-9)
+    if t == 40:      # an edit between step1 and step2: step2 recomputes the stage for the edited state
+      b.step1()
+      for e in (a, b):
+        e.qvel[:] = 0
+      b.invalidate()
+      a.step(1, legacy=False)
+      b.step2()
+      np.testing.assert_array_equal(a.qpos, b.qpos)
+      o.qpos[:] = b.qpos; o.qvel[:] = b.qvel; o.qacc_warmstart[:] = b.qacc_warmstart
+  assert np.abs(a.qpos - q).max() > 1e-3

@@ -19,7 +19,7 @@ def native():
 def test_header_symbols_are_exported(native):
   with open(os.path.join(ROOT, 'include', 'dmc_batch.h')) as f:
     hdr = f.read()
-  declared = set(re.findall(r'\b(dmc_[a-z_]+)\s*\(', hdr))
+  declared = set(re.findall(r'\b(dmc_[a-z0-9_]+)\s*\(', hdr))
   assert declared, 'no declarations parsed'
   lib = native.lib()
   missing = [n for n in sorted(declared) if not hasattr(lib, n)]
