@@ -345,6 +345,10 @@ def main():
 
   run(0, W)
   torch.cuda.synchronize()
+  if cfg['asset'] != 'cheetah':
+    # parity starts where the timed run starts (after the warm-up: the t = 0 drop of the start pose onto the floor,
+    # |qacc| ~ 1e4, is a one-step transient that says nothing about the steady state)
+    q_start, v_start, w_start = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
   barrier()
   torch.cuda.synchronize()
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

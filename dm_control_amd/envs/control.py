@@ -138,27 +138,23 @@ def _spec_from_observation(observation):
 
 
 class Environment(dm_env.Environment):
-  """Physics-based RL environment: before_step -> physics.step(n_sub_steps) ->
-  after_step -> reward / observation / termination -> TimeStep."""
+  """The agent-facing loop of the reference (rl/control.py:40-176) over any `control.Physics`: a control step is
+  task.before_step -> physics.step(n_sub_steps) -> task.after_step, then reward, observation and the episode-end
+  test (time budget first, then the task's termination).  Works unchanged for a batch physics: the task then
+  returns (B,) rewards and (B, ...) observations."""
 
   def __init__(self, physics, task, time_limit=float('inf'), control_timestep=None,
                n_sub_steps=None, flat_observation=False, legacy_step=True):
-    self._task = task
-    self._physics = physics
-    self._physics.legacy_step = legacy_step
-    self._flat_observation = flat_observation
     if n_sub_steps is not None and control_timestep is not None:
       raise ValueError('Both n_sub_steps and control_timestep were supplied.')
-    if n_sub_steps is not None:
-      self._n_sub_steps = n_sub_steps
-    elif control_timestep is not None:
-      self._n_sub_steps = compute_n_steps(control_timestep, self._physics.timestep())
-    else:
-      self._n_sub_steps = 1
-    if time_limit == float('inf'):
-      self._step_limit = float('inf')
-    else:
-      self._step_limit = time_limit / (self._physics.timestep() * self._n_sub_steps)
+    physics.legacy_step = legacy_step
+    if n_sub_steps is None:
+      n_sub_steps = 1 if control_timestep is None else compute_n_steps(control_timestep, physics.timestep())
+    self._physics, self._task = physics, task
+    self._n_sub_steps = n_sub_steps
+    self._flat_observation = flat_observation
+    # control steps an episode may take (fractional: the comparison below is >=)
+    self._step_limit = time_limit if time_limit == float('inf') else time_limit / (physics.timestep() * n_sub_steps)
     self._step_count = 0
     self._reset_next_step = True
 
@@ -167,29 +163,25 @@ class Environment(dm_env.Environment):
     return flatten_observation(obs) if self._flat_observation else obs
 
   def reset(self):
-    self._reset_next_step = False
-    self._step_count = 0
+    self._step_count, self._reset_next_step = 0, False
     with self._physics.reset_context():
       self._task.initialize_episode(self._physics)
-    return dm_env.TimeStep(dm_env.StepType.FIRST, None, None, self._observe())
+    return dm_env.restart(self._observe())
 
   def step(self, action):
-    if self._reset_next_step:
+    if self._reset_next_step:      # the call after an episode's last step starts the next episode
       return self.reset()
-    self._task.before_step(action, self._physics)
-    self._physics.step(self._n_sub_steps)
-    self._task.after_step(self._physics)
-    reward = self._task.get_reward(self._physics)
-    observation = self._observe()
+    task, physics = self._task, self._physics
+    task.before_step(action, physics)
+    physics.step(self._n_sub_steps)
+    task.after_step(physics)
     self._step_count += 1
-    if self._step_count >= self._step_limit:
-      discount = 1.0
-    else:
-      discount = self._task.get_termination(self._physics)
-    if discount is not None:
-      self._reset_next_step = True
-      return dm_env.TimeStep(dm_env.StepType.LAST, reward, discount, observation)
-    return dm_env.TimeStep(dm_env.StepType.MID, reward, 1.0, observation)
+    reward, observation = task.get_reward(physics), self._observe()
+    final_discount = 1.0 if self._step_count >= self._step_limit else task.get_termination(physics)
+    if final_discount is None:
+      return dm_env.transition(reward, observation)
+    self._reset_next_step = True
+    return dm_env.TimeStep(dm_env.StepType.LAST, reward, final_discount, observation)
 
   def action_spec(self):
     return self._task.action_spec(self._physics)
@@ -201,10 +193,7 @@ class Environment(dm_env.Environment):
     try:
       return self._task.observation_spec(self._physics)
     except NotImplementedError:
-      obs = self._task.get_observation(self._physics)
-      if self._flat_observation:
-        obs = flatten_observation(obs)
-      return _spec_from_observation(obs)
+      return _spec_from_observation(self._observe())
 
   @property
   def physics(self):

@@ -6,12 +6,13 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # Contact / constraint-row caps per domain where the library default (16 contacts) is too tight;
 # the humanoid's are free: its LDS footprint puts 4 environments on a CU either way.  The
 # model-specialised kernels are baked for exactly these caps (dm_control_amd/build.py).
-# humanoid_CMU (nv = 62): one environment fills a CU's LDS in fp32 (98 KiB of scratch + 58 KiB of
-# tables at 32 contacts); the fp64 scratch does not fit, so the domain runs the fp32 kernel.
-DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=32, precision=32),
-                'cmu_2019_position_floor': dict(nconmax=32, precision=32),
+# humanoid_CMU / the config-4 CMU model (nv = 62): two environments per CU in fp32 either way (tables 18 KiB + 54 ..
+# 62 KiB of scratch per environment), so the contact cap is the one that never overflowed in the soak runs (48: a
+# ragdoll lying on the floor reaches 27 .. 40 contacts; 32 raised mjWARN_CONTACTFULL 15 times in 0.4 M env-steps).
+DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=48, precision=32),
+                'cmu_2019_position_floor': dict(nconmax=48, precision=32),   # BASELINE config 4 physics (assets/)
                 'soccer_2v2_boxhead': dict(nconmax=24),   # BASELINE config 5 physics (assets/)
-                'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts   # BASELINE config 4 physics (assets/)
+                'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts
 
 
 def physics_kwargs(domain, user_kwargs):

@@ -70,7 +70,7 @@ def test_env_mode_per_environment_launch_override():
     e.step(3)
   mode = np.array([0, 1, 2, 0, 2, 1], dtype=np.int32)[:, None]
   before = {f: b.get(f) for f in ('qpos', 'qvel', 'xpos', 'sensordata', 'time', 'actuator_force')}
-  b.set_int('env_mode', mode)
+  b.set('env_mode', mode)
   a.step(2); b.step(2)
   fwd = BatchedPhysics(m, B, precision=64)
   fwd.set('qpos', before['qpos']); fwd.set('qvel', before['qvel']); fwd.set_control(c)

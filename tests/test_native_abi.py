@@ -68,12 +68,17 @@ def test_hot_kernel_keeps_its_locals_out_of_scratch(tmp_path):
   instantiation the bench runs may only use the few bytes its out-of-line calls need."""
   import subprocess
   from dm_control_amd import build
-  build.generate_static_layouts()
-  src = os.path.join(build.CSRC, 'step_kernels_f32.hip')
-  out = str(tmp_path / 'f32.s')
-  subprocess.check_call([build.HIPCC] + build._COMMON + ['-S', '--cuda-device-only', src, '-o', out],
-                        stderr=subprocess.DEVNULL)
-  text = open(out).read()
+  build.build()
+  # kernel metadata of the device code object inside the built (bundled) object file -- no recompilation
+  blob = open(os.path.join(build.CSRC, 'step_kernels_f32.o'), 'rb').read()
+  text, pos = '', blob.find(b'\x7fELF')
+  while pos >= 0:
+    elf = tmp_path / ('obj%d.elf' % pos)
+    elf.write_bytes(blob[pos:])
+    r = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', str(elf)], capture_output=True, text=True)
+    if 'amdhsa.kernels' in r.stdout:
+      text += r.stdout
+    pos = blob.find(b'\x7fELF', pos + 4)
   sizes = dict(re.findall(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)', text))
   bench_kernel = [k for k in sizes if 'step_kernel_staticIfLi32ELi0' in k]
   assert bench_kernel, sorted(sizes)[:5]
