@@ -8,7 +8,7 @@ _VARIANT = 'prof' if os.environ.get('DMC_USE_PROF') else os.environ.get('DMC_LIB
 LIB_PATH = os.path.join(_HERE, 'libdmc_hip_%s.so' % _VARIANT if _VARIANT else 'libdmc_hip.so')
 
 EXPORTS = [
-    'dmc_last_error', 'dmc_model_create', 'dmc_model_destroy', 'dmc_batch_create',
+    'dmc_last_error', 'dmc_model_create', 'dmc_model_destroy', 'dmc_batch_create', 'dmc_batch_create_caps',
     'dmc_batch_destroy', 'dmc_batch_step', 'dmc_batch_rollout', 'dmc_batch_forward', 'dmc_batch_reset',
     'dmc_batch_field_rows', 'dmc_batch_get', 'dmc_batch_set', 'dmc_batch_get_int',
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
@@ -17,6 +17,7 @@ EXPORTS = [
     'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_info', 'dmc_batch_time_steps',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
+    'dmc_batch_set_env_geoms', 'dmc_env_geom_pack',
 ]
 
 _lib = None
@@ -67,6 +68,9 @@ def lib():
   L.dmc_batch_sync.argtypes = [vp]
   L.dmc_batch_invalidate.argtypes = [vp]
   L.dmc_batch_step1.argtypes = [vp, vp]
+  L.dmc_batch_create_caps.argtypes = [vp, ci, ci, ci, vp, ci, ctypes.POINTER(vp)]
+  L.dmc_batch_set_env_geoms.argtypes = [vp, ci, vp]
+  L.dmc_env_geom_pack.argtypes = [ci, vp, vp, vp, vp]
   L.dmc_gather_create.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), vp, vp, vp, ctypes.POINTER(vp)]
   L.dmc_gather_destroy.argtypes = [vp]
   L.dmc_gather_destroy.restype = None

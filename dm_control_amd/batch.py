@@ -21,7 +21,7 @@ OUT_ALL = 0x7fffffff
 class BatchedPhysics:
 
   def __init__(self, model, batch_size, device_id=0, precision=32, nconmax=0,
-               njmax=0, lanes_per_env=0):
+               njmax=0, lanes_per_env=0, njcon=0):
     if not isinstance(model, mjcf_compiler.Model):
       raise TypeError('model must be a compiled mjcf_compiler.Model')
     L = _native.lib()
@@ -34,8 +34,9 @@ class BatchedPhysics:
     _native.check(L.dmc_model_create(ints.ctypes.data, ints.size, reals.ctypes.data,
                                      reals.size, ctypes.byref(self._model_ptr)))
     self._ptr = ctypes.c_void_p()
-    rc = L.dmc_batch_create(self._model_ptr, self.batch_size, device_id, precision,
-                            nconmax, njmax, lanes_per_env, ctypes.byref(self._ptr))
+    caps = np.array([nconmax, njmax, lanes_per_env, njcon], dtype=np.int32)
+    rc = L.dmc_batch_create_caps(self._model_ptr, self.batch_size, device_id, precision,
+                                 caps.ctypes.data, caps.size, ctypes.byref(self._ptr))
     if rc != 0:
       L.dmc_model_destroy(self._model_ptr)
       self._model_ptr = None
@@ -124,6 +125,35 @@ class BatchedPhysics:
     """Rewrites a model constant shared by the whole batch (see dmc_batch_set_model_real)."""
     a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
     _native.check(_native.lib().dmc_batch_set_model_real(self._ptr, name.encode(), a.ctypes.data, a.size))
+
+  # -- per-environment model deltas ---------------------------------------------------------
+  def set_env_geoms(self, names):
+    """Declares world-fixed geoms whose pose / size differ between environments (dmc_batch_set_env_geoms); their
+    values live in the field 'env_geom' ((B, 16 n): pos 3, xmat 9, size 3, rbound 1 per geom)."""
+    ids = np.array([self.model.name2id(n, 'geom') for n in names], dtype=np.int32)
+    _native.check(_native.lib().dmc_batch_set_env_geoms(self._ptr, ids.size, ids.ctypes.data))
+    self.env_geoms = list(names)
+
+  def pack_env_geom(self, name, pos, quat, size):
+    """(B, 16) rows of one declared geom from per-env pos (B, 3) / quat (B, 4) / size (B, 3)."""
+    g = self.model.name2id(name, 'geom')
+    pos, quat, size = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.batch_size, n)))
+                       for a, n in ((pos, 3), (quat, 4), (size, 3)))
+    out = np.zeros((self.batch_size, 16))
+    for e in range(self.batch_size):
+      _native.check(_native.lib().dmc_env_geom_pack(int(self.model.geom_type[g]), pos[e].ctypes.data, quat[e].ctypes.data,
+                                                    size[e].ctypes.data, out[e].ctypes.data))
+    return out
+
+  def set_env_geom(self, name, pos=None, quat=None, size=None):
+    """Writes one declared geom's per-env values; arguments left None keep the model's."""
+    g, k = self.model.name2id(name, 'geom'), self.env_geoms.index(name)
+    m = self.model
+    rows = self.pack_env_geom(name, m.geom_pos[g] if pos is None else pos, m.geom_quat[g] if quat is None else quat,
+                              m.geom_size[g] if size is None else size)
+    cur = self.get('env_geom')
+    cur[:, 16*k:16*k + 16] = rows
+    self.set('env_geom', cur)
 
   # -- the hot path ---------------------------------------------------------------------
   def set_control(self, control):

@@ -186,6 +186,20 @@ class DevicePhysics:
     """physics.bind(elements) of the reference, elements given as (kind, name or names)."""
     return Binding(self, kind, names)
 
+  def declare_env_geoms(self, names):
+    """Per-environment model deltas (dmc_batch_set_env_geoms): the world-fixed geoms `names` get their pose and
+    size from the (16 n, B) tensor field 'env_geom' -- rows of geom k: pos 3, xmat 9 (row-major), size 3, bounding
+    radius 1 -- initialised from the model.  What the reference does by editing the MJCF and recompiling."""
+    torch = self.torch
+    self.batch.set_env_geoms(names)
+    init = self.batch.get('env_geom')                     # (B, 16 n) host
+    t = torch.from_numpy(np.ascontiguousarray(init.T)).to(self.device).to(self.dtype).contiguous()
+    self.batch.sync()
+    self.batch.bind('env_geom', t.data_ptr())
+    self._fields['env_geom'] = t
+    self.env_geoms = list(names)
+    return t
+
   def stream(self):
     return self.torch.cuda.current_stream().cuda_stream
 

@@ -21,8 +21,12 @@ soccer/task.py:36-230) over the restated physics asset `suite/assets/soccer_2v2_
     positions and velocities and goal / field corners in the player's egocentric frame, and the stats_* scalars.
     Observation tensors are (B, 4, n).
 
-Pitch randomisation (`RandomizedPitch`, pitch.py:612-690) needs per-environment geom positions: see
-`DevicePhysics` per-env model deltas; the default here is the fixed 40 x 30 pitch of the asset.
+`randomize_pitch=(min_size, max_size)` is `RandomizedPitch` (pitch.py:604-669; `soccer.load` uses (32, 24) ..
+(48, 36), soccer/__init__.py:140-148): every episode draws its own pitch size; walls, goal posts (positions,
+lengths, radii), goal / field detectors and spawn ranges follow per environment.  The reference edits the MJCF and
+recompiles; a batch shares one compiled model, so the 4 walls and 20 goal posts are declared per-environment geoms
+(`DevicePhysics.declare_env_geoms`, dmc_batch_set_env_geoms) and their rows of the 'env_geom' tensor are rewritten on
+device under the reset mask.  Default: the fixed 40 x 30 pitch of the asset.
 """
 import numpy as np
 
@@ -39,6 +43,12 @@ _SIZE = np.array([40.0, 30.0])
 _SIDE_WIDTH = 32. / 6.
 _GOAL_SIZE = np.array([_SIDE_WIDTH / 2, _SIZE[1] * 0.33, _SIDE_WIDTH / 2])       # pitch.py _get_goal_size
 _INIT_BALL_Z, _SPAWN_RATIO, _THROW_IN_BALL_Z = 0.5, 0.6, 0.5
+_GOALPOST_RELATIVE_SIZE, _SUPPORT_POST_RATIO = 0.07, 0.75                          # pitch.py:40-41
+# unit from / to of the goal posts in goal coordinates (pitch.py:165-230), the table scripts/make_soccer_model.py used
+_GOALPOSTS = {'right_post': (1, -1, -1, 1, -1, 1), 'left_post': (1, 1, -1, 1, 1, 1), 'top_post': (1, -1, 1, 1, 1, 1),
+              'right_base': (1, -1, -1, -1, -1, -1), 'left_base': (1, 1, -1, -1, 1, -1), 'back_base': (-1, -1, -1, -1, 1, -1),
+              'right_support': (-1, -1, -1, .2, -1, 1), 'right_top_support': (.2, -1, 1, 1, -1, 1),
+              'left_support': (-1, 1, -1, .2, 1, 1), 'left_top_support': (.2, 1, 1, 1, 1, 1)}
 
 
 class PositionDetector(environment.Entity):
@@ -55,12 +65,25 @@ class PositionDetector(environment.Entity):
   def bind_ball(self, task):
     self._task = task
 
-  def _inside(self, physics):
+  def bounds(self, physics):
+    """(lower, upper) as (d, B) tensors: per-environment once the pitch is randomised (`resize`)."""
     torch = physics.torch
+    if getattr(self, '_lo_t', None) is None:
+      self._lo_t = torch.as_tensor(self.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(-1, physics.B).clone()
+      self._hi_t = torch.as_tensor(self.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(-1, physics.B).clone()
+    return self._lo_t, self._hi_t
+
+  def resize(self, physics, pos, size, mask):
+    """position_detector.py:149-160 for the masked environments; pos / size: (d, B) tensors."""
+    lo, hi = self.bounds(physics)
+    m2 = mask[None, :]
+    self._lo_t = physics.torch.where(m2, pos - size, lo)
+    self._hi_t = physics.torch.where(m2, pos + size, hi)
+
+  def _inside(self, physics):
     p = self._task.ball_xpos(physics)
-    d = self.lower.size
-    lo = torch.as_tensor(self.lower, dtype=physics.dtype, device=physics.device)[:, None]
-    hi = torch.as_tensor(self.upper, dtype=physics.dtype, device=physics.device)[:, None]
+    lo, hi = self.bounds(physics)
+    d = lo.shape[0]
     inside = ((p[:d] > lo) & (p[:d] < hi)).all(dim=0)
     return ~inside if self.inverted else inside
 
@@ -82,10 +105,12 @@ class PositionDetector(environment.Entity):
 
 class Soccer2v2(environment.Task):
 
-  def __init__(self, model=None, control_timestep=0.025, spawn_ratio=_SPAWN_RATIO):
+  def __init__(self, model=None, control_timestep=0.025, spawn_ratio=_SPAWN_RATIO, randomize_pitch=None):
     self.model = model or mjcf_compiler.compile_xml(common.read_model(_ASSET + '.xml'))
     self.set_timesteps(control_timestep=control_timestep, physics_timestep=0.005)      # task.py:105-106
-    self._spawn = _SIZE * spawn_ratio
+    self._spawn_ratio = spawn_ratio
+    self._randomize = None if randomize_pitch is None else (np.asarray(randomize_pitch[0], float), np.asarray(randomize_pitch[1], float))
+    self._size_t = None                      # (2, B) pitch half-sizes per environment
     gs = _GOAL_SIZE
     home_pos = np.array([-_SIZE[0] + gs[0], 0, gs[2]])
     away_pos = np.array([_SIZE[0] - gs[0], 0, gs[2]])
@@ -119,8 +144,48 @@ class Soccer2v2(environment.Task):
   def make_physics(self, batch_size, device_id=0, precision=32):
     caps = dict(common.DEFAULT_CAPS.get(_ASSET, {}))
     caps.pop('precision', None)
-    return DevicePhysics(self.model, batch_size, device_id=device_id, precision=precision,
-                         outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), **caps)
+    physics = DevicePhysics(self.model, batch_size, device_id=device_id, precision=precision,
+                            outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), **caps)
+    if self._randomize is not None:
+      physics.declare_env_geoms(self.pitch_geoms())
+    return physics
+
+  def pitch_geoms(self):
+    """The geoms a pitch resize moves: 4 walls, then the 10 posts of each goal."""
+    return ['wall%d' % k for k in range(4)] + ['%s/%s' % (g, p) for g in ('home_goal', 'away_goal') for p in _GOALPOSTS]
+
+  def _resize_pitch(self, physics, size, mask):
+    """RandomizedPitch.initialize_episode_mjcf (pitch.py:645-669) for the masked environments; size: (2, B)."""
+    torch = physics.torch
+    B = physics.B
+    eg = physics.field('env_geom')
+    m2 = mask[None, :]
+    z = torch.zeros(B, dtype=physics.dtype, device=physics.device)
+    one = torch.ones_like(z)
+    sx, sy = size[0], size[1]
+    gs = torch.stack([one * (_SIDE_WIDTH / 2), sy * 0.33, one * (_SIDE_WIDTH / 2)])           # _get_goal_size
+    # walls (_wall_pos_xyaxes): orientation fixed, position follows the size
+    for k, pos in enumerate((torch.stack([z, -sy, z]), torch.stack([z, sy, z]), torch.stack([-sx, z, z]), torch.stack([sx, z, z]))):
+      eg[16*k:16*k + 3] = torch.where(m2, pos, eg[16*k:16*k + 3])
+    radius = _GOALPOST_RELATIVE_SIZE * gs.sum(dim=0) / 3
+    k = 4
+    for direction, gx in ((1.0, -sx + gs[0]), (-1.0, sx - gs[0])):
+      gpos = torch.stack([gx, z, gs[2]])
+      d3 = torch.tensor([direction, direction, 1.0], dtype=physics.dtype, device=physics.device)[:, None]
+      for pname, unit in _GOALPOSTS.items():
+        u = torch.tensor(unit, dtype=physics.dtype, device=physics.device)
+        frm = u[:3, None] * d3 * gs + gpos
+        to = u[3:, None] * d3 * gs + gpos
+        half = 0.5 * torch.linalg.norm(to - frm, dim=0)
+        r = radius * (1.01 if 'top' in pname else 1.0) * (_SUPPORT_POST_RATIO if 'support' in pname else 1.0)
+        rows = torch.cat([0.5 * (frm + to), eg[16*k + 3:16*k + 12], torch.stack([r, half, z]), (r + half)[None]])
+        eg[16*k:16*k + 16] = torch.where(m2, rows, eg[16*k:16*k + 16])
+        k += 1
+    home = torch.stack([-sx + gs[0], z, gs[2]]); away = torch.stack([sx - gs[0], z, gs[2]])
+    self.home_goal.resize(physics, home, gs, mask)
+    self.away_goal.resize(physics, away, gs, mask)
+    self.field.resize(physics, torch.zeros((2, B), dtype=physics.dtype, device=physics.device),
+                      torch.stack([sx - 2 * gs[0], sy - 2 * gs[0]]), mask)
 
   # -- helpers -----------------------------------------------------------------------------------------
   def ball_xpos(self, physics):
@@ -139,13 +204,15 @@ class Soccer2v2(environment.Task):
     torch = physics.torch
     q = physics.field('qpos')
     m2 = mask[None, :]
-    ball = self._uniform(physics, -self._spawn, self._spawn)
+    spawn = self._size_t * self._spawn_ratio                      # (2, B): spawn_range = arena.size * spawn_ratio
+    unit = lambda: self._uniform(physics, [-1.0, -1.0], [1.0, 1.0]) * spawn
+    ball = unit()
     pos = [ball]
     bq = self._ball_q
     q[bq:bq + 2] = torch.where(m2, ball, q[bq:bq + 2])
     q[bq + 2] = torch.where(mask, torch.full_like(q[bq + 2], _INIT_BALL_Z - 0.35), q[bq + 2])      # geom centre at z = 0.5 (body + 0.35)
     for k, p in enumerate(_PLAYERS):
-      xy = self._uniform(physics, -self._spawn, self._spawn)
+      xy = unit()
       pos.append(xy)
       spot = torch.as_tensor(_SPOTS[k], dtype=physics.dtype, device=physics.device)[:, None]
       a = self._q[p]
@@ -162,6 +229,12 @@ class Soccer2v2(environment.Task):
       self._gen = torch.Generator(device=physics.device)
       self._gen.manual_seed(int(random_state.randint(2**31 - 1)))
       self._prev_action = torch.zeros((4, 3, physics.B), dtype=physics.dtype, device=physics.device)
+      self._size_t = torch.as_tensor(_SIZE, dtype=physics.dtype, device=physics.device)[:, None].expand(2, physics.B).clone()
+    if self._randomize is not None:
+      lo, hi = self._randomize
+      size = self._uniform(physics, lo, hi)                    # one ratio per axis (keep_aspect_ratio=False)
+      self._size_t = torch.where(mask[None, :], size, self._size_t)
+      self._resize_pitch(physics, self._size_t, mask)
     todo = mask
     for _ in range(4):                 # redraw placements whose entities overlap (initializers.py:96-127)
       pos = self._place(physics, todo)
@@ -239,14 +312,10 @@ class Soccer2v2(environment.Task):
     def put(name, t):
       out.setdefault(name, []).append(t.T if t.dim() == 2 else t[:, None])
 
-    home_lo = torch.as_tensor(self.home_goal.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    home_hi = torch.as_tensor(self.home_goal.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    home_mid = torch.as_tensor(self.home_goal.mid, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    away_lo = torch.as_tensor(self.away_goal.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    away_hi = torch.as_tensor(self.away_goal.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    away_mid = torch.as_tensor(self.away_goal.mid, dtype=physics.dtype, device=physics.device)[:, None].expand(3, B)
-    f_lo = torch.as_tensor(self.field.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(2, B)
-    f_hi = torch.as_tensor(self.field.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(2, B)
+    home_lo, home_hi = self.home_goal.bounds(physics)
+    away_lo, away_hi = self.away_goal.bounds(physics)
+    home_mid, away_mid = (home_lo + home_hi) / 2, (away_lo + away_hi) / 2
+    f_lo, f_hi = self.field.bounds(physics)
     corners = [home_lo[:2], home_mid, home_hi[:2], f_hi, away_hi[:2], away_mid, away_lo[:2], f_lo]
     corner_names = ['team_goal_back_right', 'team_goal_mid', 'team_goal_front_left', 'field_front_left',
                     'opponent_goal_back_left', 'opponent_goal_mid', 'opponent_goal_front_right', 'field_back_right']

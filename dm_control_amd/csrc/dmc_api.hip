@@ -65,6 +65,8 @@ struct dmc_batch {
   // per-env stash of the position / velocity stage between legacy steps (StepIO::stash_*); epoch: bumped by every
   // host-side edit that can change what the stage depends on, which invalidates all stashes at once
   void* d_stash_r; int* d_stash_i; int stash_epoch; int stash_on;
+  void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
+  int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
 
 extern "C" const char* dmc_last_error(void) { return g_err.c_str(); }
@@ -96,15 +98,21 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   if (lpe != 64 && lpe != 32 && lpe != 16) return fail("lanes_per_env must be 64, 32 or 16");
   const int epw = 64 / lpe;
   int best_w = 0; long best_score = -1;
-  for (int w = 4; w >= 1; w--) {
+  // workgroups of up to 8 waves (512 threads): one big workgroup shares the model tables among more environments
+  // than two smaller ones can (humanoid: 7 instead of 2 x 3 per CU).  The kernels are built for 2 waves per SIMD
+  // (256 VGPRs), i.e. at most 8 resident waves per CU whatever the LDS would allow.
+  const int order[8] = {4, 8, 7, 6, 5, 3, 2, 1};
+  for (int k = 0; k < 8; k++) {
+    const int w = order[k];
     const size_t bytes = tables + (size_t)w * epw * env_bytes;
     if (bytes > lds_cu) continue;
     long blocks = (long)(lds_cu / bytes);
-    if (blocks * w > 32) blocks = 32 / w;           // 32 waves per CU
+    if (blocks * w > 8) blocks = 8 / w;             // VGPR-limited: 2 waves per SIMD
+    if (blocks < 1) continue;
     const long score = blocks * w * epw;            // resident envs per CU
-    // fewer waves per workgroup only for a clear gain in residency: 4-wave groups give grids that divide the
+    // another shape than 4 waves only for a clear gain in residency: 4-wave groups give grids that divide the
     // batch evenly (cartpole, B = 4096: 3-wave groups = 683 workgroups ran 1.8x slower than 4-wave = 512)
-    if (best_score < 0 || score * 100 > best_score * 115) { best_score = score; best_w = w; }
+    if (best_score < 0 || score * 100 >= best_score * 115) { best_score = score; best_w = w; }
   }
   if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
   LaunchGeom& g = b->geom;
@@ -137,6 +145,14 @@ static int upload_tables(dmc_batch* b) {
 
 extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
                                 int nconmax, int njmax, int lanes_per_env, dmc_batch** out) {
+  const int caps[3] = {nconmax, njmax, lanes_per_env};
+  return dmc_batch_create_caps(m, batch_size, device_id, precision, caps, 3, out);
+}
+extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int device_id, int precision,
+                                     const int* caps, int ncaps, dmc_batch** out) {
+  if (ncaps < 0 || (ncaps > 0 && !caps)) return fail("null argument");
+  const int nconmax = ncaps > 0 ? caps[0] : 0, njmax = ncaps > 1 ? caps[1] : 0, lanes_per_env = ncaps > 2 ? caps[2] : 0;
+  const int njcon = ncaps > 3 ? caps[3] : 0;
   if (!m || !out) return fail("null argument");
   if (batch_size < 1) return fail("batch_size must be >= 1");
   if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
@@ -147,9 +163,9 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->d_ns_A = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
-  if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err)) { delete b; return fail(err); }
+  if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
   const StepLayout& L = b->tb.L;
   const StepDims& d = L.d;
@@ -160,6 +176,11 @@ extern "C" int dmc_batch_create(const dmc_model* m, int batch_size, int device_i
   if (e == hipSuccess) e = hipMemcpy(b->d_layout, &L, sizeof(StepLayout), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete b; return fail(std::string("hipMalloc: ") + hipGetErrorString(e), -2); }
   if (upload_tables(b)) { delete b; return -2; }
+  if (d.nslip) {
+    e = hipMalloc(&b->d_ns_A, (size_t)b->B * d.nslip * d.nslip * b->elem);
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc noslip matrix: ") + hipGetErrorString(e), -2); }
+    b->tb.opts.ns_A = b->d_ns_A;
+  }
   struct Spec { const char* name; int rows; bool is_int; };
   const int nb = d.nbody;
   const Spec specs[] = {
@@ -205,6 +226,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_stash_r) (void)hipFree(b->d_stash_r);
   if (b->d_stash_i) (void)hipFree(b->d_stash_i);
+  if (b->d_eg_slot) (void)hipFree(b->d_eg_slot);
+  if (b->d_ns_A) (void)hipFree(b->d_ns_A);
   delete b;
 }
 
@@ -231,6 +254,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
 struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsub; };
 static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq = nullptr) {
   HIP_TRY(hipSetDevice(b->device));
+  if (b->tb.opts.eg_n) b->tb.opts.eg_data = find_field(b, "env_geom")->dev;      // follows dmc_batch_bind
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
   if (b->precision == 64) {
@@ -253,6 +277,78 @@ extern "C" int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hi
   if (nstep < 1) return fail("nstep must be >= 1");
   return launch(b, nstep, legacy_step ? 1 : 0, 0, hip_stream);
 }
+struct Field;
+static int set_real(dmc_batch* b, Field* f, const double* src);
+// ---- per-environment model deltas: world-fixed geoms with per-env pose / size ---------------------------------
+// The reference randomises scenery per episode by editing the MJCF and recompiling (soccer RandomizedPitch,
+// locomotion/soccer/pitch.py:612-690 through composer's initialize_episode_mjcf); a batch shares one compiled model,
+// so the geoms that differ between environments get their pose and size from a per-env array instead of the tables.
+static double geom_rbound_of(int type, const double* size) {
+  switch (type) {
+    case DMC_GEOM_SPHERE: return size[0];
+    case DMC_GEOM_CAPSULE: return size[0] + size[1];
+    case DMC_GEOM_CYLINDER: return sqrt(size[0]*size[0] + size[1]*size[1]);
+    case DMC_GEOM_ELLIPSOID: return std::max(size[0], std::max(size[1], size[2]));
+    case DMC_GEOM_BOX: return sqrt(size[0]*size[0] + size[1]*size[1] + size[2]*size[2]);
+    default: return 0;
+  }
+}
+extern "C" int dmc_batch_set_env_geoms(dmc_batch* b, int n, const int* geom_ids) {
+  if (!b || n < 1 || !geom_ids) return fail("null argument");
+  if (find_field(b, "env_geom")) return fail("per-environment geoms were already declared for this batch");
+  const HostModel& m = b->model->hm;
+  std::vector<int> slot(m.ngeom, -1);
+  for (int k = 0; k < n; k++) {
+    const int g = geom_ids[k];
+    if (g < 0 || g >= m.ngeom) return fail("geom id out of range");
+    if (m.geom_bodyid[g] != 0) return fail("only world-fixed geoms (children of the worldbody) can differ between environments");
+    if (slot[g] >= 0) return fail("geom listed twice");
+    slot[g] = k;
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  Field f; f.name = "env_geom"; f.rows = 16*n; f.is_int = false; f.is_f64 = false; f.dev = nullptr; f.owned = nullptr;
+  HIP_TRY(hipMalloc(&f.owned, (size_t)f.rows * b->B * b->elem));
+  f.dev = f.owned;
+  b->index[f.name] = (int)b->fields.size();
+  b->fields.push_back(f);
+  HIP_TRY(hipMalloc((void**)&b->d_eg_slot, sizeof(int) * m.ngeom));
+  HIP_TRY(hipMemcpy(b->d_eg_slot, slot.data(), sizeof(int) * m.ngeom, hipMemcpyHostToDevice));
+  // initial values: the model's own
+  std::vector<double> host((size_t)b->B * f.rows);
+  for (int k = 0; k < n; k++) {
+    const int g = geom_ids[k];
+    const double* q = &m.geom_quat[4*g];
+    double mat[9];
+    { const double w = q[0], x = q[1], y = q[2], z = q[3];
+      mat[0] = w*w + x*x - y*y - z*z; mat[4] = w*w - x*x + y*y - z*z; mat[8] = w*w - x*x - y*y + z*z;
+      mat[1] = 2*(x*y - w*z); mat[2] = 2*(x*z + w*y); mat[3] = 2*(x*y + w*z); mat[5] = 2*(y*z - w*x); mat[6] = 2*(x*z - w*y); mat[7] = 2*(y*z + w*x); }
+    double row[16];
+    for (int j = 0; j < 3; j++) row[j] = m.geom_pos[3*g + j];
+    for (int j = 0; j < 9; j++) row[3 + j] = mat[j];
+    for (int j = 0; j < 3; j++) row[12 + j] = m.geom_size[3*g + j];
+    row[15] = m.geom_rbound[g];
+    for (int e = 0; e < b->B; e++) for (int j = 0; j < 16; j++) host[(size_t)e * f.rows + 16*k + j] = row[j];
+  }
+  b->tb.opts.eg_slot = b->d_eg_slot; b->tb.opts.eg_n = n; b->tb.opts.eg_B = b->B;
+  b->stash_epoch++;
+  return set_real(b, find_field(b, "env_geom"), host.data());
+}
+// rows of one geom slot from (pos, quat, size): what a caller writes into "env_geom" (host helper, no device work)
+extern "C" int dmc_env_geom_pack(int geom_type, const double* pos, const double* quat, const double* size, double* out16) {
+  if (!pos || !quat || !size || !out16) return fail("null argument");
+  const double n = sqrt(quat[0]*quat[0] + quat[1]*quat[1] + quat[2]*quat[2] + quat[3]*quat[3]);
+  if (!(n > 0)) return fail("zero quaternion");
+  const double w = quat[0]/n, x = quat[1]/n, y = quat[2]/n, z = quat[3]/n;
+  for (int j = 0; j < 3; j++) out16[j] = pos[j];
+  double* mat = out16 + 3;
+  mat[0] = w*w + x*x - y*y - z*z; mat[4] = w*w - x*x + y*y - z*z; mat[8] = w*w - x*x - y*y + z*z;
+  mat[1] = 2*(x*y - w*z); mat[2] = 2*(x*z + w*y); mat[3] = 2*(x*y + w*z); mat[5] = 2*(y*z - w*x); mat[6] = 2*(x*z - w*y); mat[7] = 2*(y*z + w*x);
+  for (int j = 0; j < 3; j++) out16[12 + j] = size[j];
+  out16[15] = geom_rbound_of(geom_type, size);
+  return 0;
+}
+
 // mj_step1 / mj_step2 as separate launches: the stage mj_step1 computes travels to mj_step2 through the per-env
 // stash in HBM (allocated on first use)
 static int ensure_stash(dmc_batch* b) {
@@ -600,7 +696,7 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[10] = b->geom.static_id;
   info[11] = L.d.kmax;
   info[12] = b->geom.lds_bytes - b->geom.envs_per_block * info[9];
-  { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 32) blocks = 32 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }
+  { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 8) blocks = 8 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }
   info[14] = L.d.njdense; info[15] = L.d.njcon; info[16] = b->stash_on; info[17] = (int)((size_t)L.n_keep * b->elem + (size_t)(L.n_si + 4) * sizeof(int));
   return 0;
 }

@@ -1,6 +1,6 @@
 // lds_report.cpp -- build-time / tuning tool (host only, g++): prints the LDS footprint of a
 // model array by array (tables and per-environment scratch).  Input: <name> <ints.bin> <reals.bin>
-// [nconmax njmax].  scripts/lds_report.py drives it over the BASELINE models.
+// [nconmax njmax njcon].  scripts/lds_report.py drives it over the BASELINE models.
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -19,13 +19,13 @@ static std::vector<char> slurp(const char* path) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 4) { fprintf(stderr, "usage: %s name ints.bin reals.bin [nconmax njmax]\n", argv[0]); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: %s name ints.bin reals.bin [nconmax njmax njcon]\n", argv[0]); return 2; }
   std::vector<char> bi = slurp(argv[2]), br = slurp(argv[3]);
   dmc::HostModel hm; std::string err;
   if (!dmc::host_model_parse(&hm, (const int32_t*)bi.data(), (int)(bi.size()/4), (const double*)br.data(), (int)(br.size()/8), &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
   dmc::StepTables tb;
-  const int nconmax = argc > 4 ? atoi(argv[4]) : 0, njmax = argc > 5 ? atoi(argv[5]) : 0;
-  if (!dmc::step_tables_build(&tb, hm, nconmax, njmax, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+  const int nconmax = argc > 4 ? atoi(argv[4]) : 0, njmax = argc > 5 ? atoi(argv[5]) : 0, njcon = argc > 6 ? atoi(argv[6]) : 0;
+  if (!dmc::step_tables_build(&tb, hm, nconmax, njmax, &err, njcon)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
   const StepLayout& L = tb.L;
   const StepDims& d = L.d;
   printf("{\"name\": \"%s\", \"nq\": %d, \"nv\": %d, \"nu\": %d, \"nbody\": %d, \"njnt\": %d, \"ngeom\": %d, \"npair\": %d, \"nM\": %d, \"ntri\": %d, "

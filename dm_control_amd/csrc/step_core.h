@@ -569,6 +569,7 @@ struct StepCore {
     FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
     if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = io.act[(size_t)i*B + env]; S(act_dot)[i] = 0; }
     time_ = io.time[env];
+    if (lane == 0) SI(imisc)[IM_ENV] = env;
     if (have_stash) {      // the derived arrays come from the stash; only this launch's warning counters start at zero
       if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
       DMC_WSYNC();
@@ -755,6 +756,13 @@ struct StepCore {
       for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = m[k];
     }
     FOR_LANES(g, L.d.ngeom) {
+      const int k = o.eg_n ? o.eg_slot[g] : -1;
+      if (k >= 0) {      // a world-fixed geom with a per-environment pose: its world frame IS that pose
+        const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
+        for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
+        for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
+        continue;
+      }
       const int b = MI(geom_bodyid)[g]; T v[3], q[4], m[9];
       mul_mat_vec3(v, S(xmat) + 9*b, MR(geom_pos) + 3*g);
       for (int k = 0; k < 3; k++) S(geom_xpos)[3*g + k] = S(xpos)[3*b + k] + v[k];
@@ -1265,12 +1273,20 @@ struct StepCore {
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
     const T *m1 = S(geom_xmat) + 9*g1, *m2 = S(geom_xmat) + 9*g2;
-    const T *s1 = MR(geom_size) + 3*g1, *s2 = MR(geom_size) + 3*g2;
+    // sizes and bounding radii as private copies: shared model tables, or the environment's own values
+    T s1[3], s2[3], rb1 = MR(geom_rbound)[g1], rb2 = MR(geom_rbound)[g2];
+    for (int k = 0; k < 3; k++) { s1[k] = MR(geom_size)[3*g1 + k]; s2[k] = MR(geom_size)[3*g2 + k]; }
+    if (o.eg_n) {
+      const int k1 = o.eg_slot[g1], k2 = o.eg_slot[g2];
+      const T* eg = (const T*)o.eg_data + SI(imisc)[IM_ENV];
+      if (k1 >= 0) { for (int k = 0; k < 3; k++) s1[k] = eg[(size_t)(16*k1 + 12 + k)*o.eg_B]; rb1 = eg[(size_t)(16*k1 + 15)*o.eg_B]; }
+      if (k2 >= 0) { for (int k = 0; k < 3; k++) s2[k] = eg[(size_t)(16*k2 + 12 + k)*o.eg_B]; rb2 = eg[(size_t)(16*k2 + 15)*o.eg_B]; }
+    }
     *has_tang = false;
     if (t1 == DMC_GEOM_PLANE) {
       T nrm[3] = {m1[2], m1[5], m1[8]};
       T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      if (dot3(dif, nrm) > MR(geom_rbound)[g2] + margin) return 0;
+      if (dot3(dif, nrm) > rb2 + margin) return 0;
       if (plane_cyl) {
         // mjc_PlaneCylinder: deepest rim point of the near cap, the matching point of the far cap, two
         // more points of the near disc at +-120 degrees (same order as the oracle)
@@ -1346,7 +1362,7 @@ struct StepCore {
     }
     {
       T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      T bound = MR(geom_rbound)[g1] + MR(geom_rbound)[g2] + margin;
+      T bound = rb1 + rb2 + margin;
       if (dot3(dif, dif) > bound*bound) return 0;
     }
     if (L.d.nell && t2 == DMC_GEOM_ELLIPSOID) return ellipsoid_pair(&h->s0, margin, t1, p1, m1, s1, p2, m2, s2);
@@ -2906,7 +2922,7 @@ struct StepCore {
     for (int p = 0; p < N; p++) {
       old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
 #pragma unroll
-      for (int q = 0; q < N; q++) Ac[p*N + q] = S(ns_A)[ns_idx(a + p, a + q)];
+      for (int q = 0; q < N; q++) Ac[p*N + q] = ns_A()[(a + p)*L.d.nslip + a + q];
     }
     if (N == 1) {
       const T fl = MR(dof_frictionloss)[id];
@@ -2969,13 +2985,14 @@ struct StepCore {
     for (int p = 0; p < N; p++) {
       const T delta = fnew[p] - old[p];
       if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
-      if (delta != 0) for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += S(ns_A)[ns_idx(b, a + p)]*delta;
+      if (delta != 0) { const T* Ap = ns_A() + (a + p)*L.d.nslip; for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += Ap[b]*delta; }
     }
     DMC_WSYNC();
     return change;
   }
-  // A is symmetric: packed lower triangle, entry (i, j) with i >= j computed as J_i . (M^-1 J_j^T)
-  DMC_DEV static int ns_idx(int i, int j) { return i >= j ? i*(i + 1)/2 + j : j*(j + 1)/2 + i; }
+  // A is symmetric and stored in full, (nslip, nslip) per environment in global memory: entry (i, j), i >= j, is
+  // computed once as J_i . (M^-1 J_j^T) and written to both places, so that every later read runs along a row
+  DMC_DEV T* ns_A() const { return (T*)o.ns_A + (size_t)SI(imisc)[IM_ENV] * L.d.nslip * L.d.nslip; }
   DMC_DEV void noslip(int nefc) {
     const int nv = L.d.nv, cap = L.d.nslip;
     int nf = 0, over = 0;
@@ -2996,7 +3013,8 @@ struct StepCore {
       FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(rb, i, rm);
       DMC_WSYNC();
       chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
-      for (int a = b + lane; a < nf; a += LPE) S(ns_A)[ns_idx(a, b)] = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm);
+      { T* A = ns_A(); const int cap = L.d.nslip;
+        for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
     }
     for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = row_dot(ra, S(qacc), rm) - S(efc_aref)[ra]; }

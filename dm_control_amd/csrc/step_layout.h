@@ -157,8 +157,8 @@ struct StepDims {
   /* elliptic cones: per-row coefficients of the middle-zone Hessian (newton_gradient) */ \
   X(efc_ca, d.elliptic * d.njmax) X(efc_cb, d.elliptic * d.njmax)              \
   X(efc_cg, d.elliptic * d.njmax)                                              \
-  /* noslip: A = J_F M^-1 J_F^T over the friction rows (packed lower triangle) and the running residual */ \
-  X(ns_A, d.nslip * (d.nslip + 1) / 2) X(ns_res, d.nslip)
+  /* noslip: the running residual (A = J_F M^-1 J_F^T itself lives in global memory, StepOpts::ns_A) */ \
+  X(ns_res, d.nslip)
 #define STEP_SCRATCH_ALL_REAL(X) \
   STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 
@@ -177,7 +177,8 @@ struct StepDims {
 // indices into the `misc` / `imisc` scratch
 enum { MISC_TIME = 0 };
 enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */,
-       IM_ROW_S0 = 12, IM_ROW_TL0 = 13, IM_ROW_C0 = 14 /* first simple / tendon-limit / contact row */ };
+       IM_ROW_S0 = 12, IM_ROW_TL0 = 13, IM_ROW_C0 = 14 /* first simple / tendon-limit / contact row */,
+       IM_ENV = 15 /* the environment's index in the batch (per-env model deltas) */ };
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
@@ -220,6 +221,13 @@ struct StepOpts {
   int integrator, cone, iterations, ls_iterations, disableflags, noslip_iterations;
   int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
   double timestep_d; // fp64 copy for the time accumulator
+  // per-environment model deltas: world-fixed geoms whose pose / size differ between environments (soccer pitch
+  // randomisation, per-env targets).  eg_data: (16 eg_n, eg_B) SoA in batch precision, rows of geom slot k:
+  // pos(3) mat(9) size(3) rbound(1); eg_slot: (ngeom) slot of a geom or -1.  Both in global memory.
+  const void* eg_data; const int* eg_slot; int eg_n, eg_B;
+  // noslip: A = J_F M^-1 J_F^T of every environment, (B, nslip, nslip) full symmetric storage in global memory
+  // (L2-resident for the environments in flight; 8 .. 36 KB per environment is LDS the solver needs elsewhere)
+  void* ns_A;
 };
 
 static inline void step_layout_build(StepLayout* L, const StepDims& d) {

@@ -70,7 +70,7 @@ struct StepTables {
 };
 
 // returns false + err for models the kernel does not support
-inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, int njmax, std::string* err) {
+inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, int njmax, std::string* err, int njcon = 0) {
   StepDims d;
   std::memset(&d, 0, sizeof d);
   d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom;
@@ -226,14 +226,15 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     // friction dimensions: every dof friction row, all rows of a pyramidal contact, all but the normal of an elliptic one
     int maxfr = 0;
     for (int p = 0; p < m.npair; p++) if (pdim[p] > 1) maxfr = std::max(maxfr, elliptic ? pdim[p] - 1 : 2*(pdim[p] - 1));
-    // at most 64 friction dimensions per environment (A is 64 x 65 / 2 reals of LDS); a step with more
-    // raises DMC_WARN_CNSTRFULL and keeps the main solver's result
-    d.nslip = std::min(std::min(njmax, d.nfric + nconmax * maxfr), 64);
+    d.nslip = std::min(njmax, d.nfric + nconmax * maxfr);
   }
   // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
   // one-nonzero friction / joint-limit rows, kmax entries per contact row
   d.njdense = std::min(njmax, d.neqrow + 2 * d.nlimten);
+  // contact rows with a stored Jacobian: by default every contact slot may use its maximum number of rows; a
+  // smaller pool (njcon > 0) trades LDS for a DMC_WARN_CNSTRFULL when the live contacts need more rows than that
   d.njcon = std::min(njmax, nconmax * maxrow_per_contact);
+  if (njcon > 0) d.njcon = std::max(maxrow_per_contact, std::min(d.njcon, njcon));
   {
     std::vector<uint64_t> anc(m.nv, 0);
     for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) anc[i] |= (uint64_t)1 << j;
@@ -410,6 +411,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
   o.noslip_iterations = m.opt_noslip_iterations; o.noslip_tolerance = m.opt_noslip_tolerance;
   o.any_damping = 0;
+  o.eg_data = nullptr; o.eg_slot = nullptr; o.eg_n = 0; o.eg_B = 0; o.ns_A = nullptr;
   for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
   return true;
 }
@@ -424,6 +426,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
   o.noslip_iterations = s.noslip_iterations; o.noslip_tolerance = (T)s.noslip_tolerance;
   o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
+  o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A;
   return o;
 }
 

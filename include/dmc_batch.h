@@ -40,6 +40,13 @@ void dmc_model_destroy(dmc_model* m);
  * counters like MuJoCo's own caps.  lanes_per_env: 64, 32 or 16 (0 = automatic: 32 for nv <= 12, else 64). */
 int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
                      int nconmax, int njmax, int lanes_per_env, dmc_batch** out);
+/* The same with the capacity knobs as a list: caps = {nconmax, njmax, lanes_per_env, njcon} (missing or 0 = automatic).
+ * njcon: contact rows with a stored Jacobian.  The default lets every contact slot use the most rows a contact of
+ * the model can have (nconmax x that); a smaller pool keeps LDS for a second / third resident environment and
+ * raises DMC_WARN_CNSTRFULL (the contact is dropped, as MuJoCo does when njmax is hit) when the live contacts of one
+ * environment need more. */
+int dmc_batch_create_caps(const dmc_model* m, int batch_size, int device_id, int precision,
+                          const int* caps, int ncaps, dmc_batch** out);
 void dmc_batch_destroy(dmc_batch* b);
 
 /* Replaces Physics.step(nstep) = mj_step2; mj_step(nstep-1); mj_step1 when
@@ -117,6 +124,17 @@ int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value);
  * (suite/point_mass.py:113-114), "body_pos", "body_quat" (suite/manipulator.py:201-208).  `values` is the
  * whole mjModel array (count elements).  Shared by every env of the batch.  Synchronous. */
 int dmc_batch_set_model_real(dmc_batch* b, const char* name, const double* values, int count);
+
+/* Per-environment model deltas.  The reference randomises scenery per episode by editing the MJCF and recompiling
+ * (composer initialize_episode_mjcf; soccer RandomizedPitch, locomotion/soccer/pitch.py:612-690).  A batch shares ONE
+ * compiled model; dmc_batch_set_env_geoms declares the world-fixed geoms (children of the worldbody) whose pose and
+ * size differ between environments.  It creates the field "env_geom": 16 rows per declared geom, in declaration
+ * order -- pos(3), rotation matrix (9, row-major), size(3), bounding radius(1) -- initialised from the model for
+ * every environment, readable / writable / bindable like any other field (dmc_batch_set "env_geom": (B, 16 n)).
+ * dmc_env_geom_pack fills the 16 values of one geom from (pos, quat, size).  Contact parameters, masses and
+ * everything else stay shared. */
+int dmc_batch_set_env_geoms(dmc_batch* b, int n, const int* geom_ids);
+int dmc_env_geom_pack(int geom_type, const double* pos, const double* quat, const double* size, double* out16);
 
 int dmc_batch_sync(dmc_batch* b);
 

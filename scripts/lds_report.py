@@ -20,7 +20,7 @@ DEFAULT = ['cheetah', 'humanoid:24', 'humanoid_CMU:32', 'cmu_2019_position_floor
 def report(spec):
   parts = spec.split(':')
   name = parts[0]
-  caps = [int(x) for x in parts[1:]] + [0, 0]
+  caps = [int(x) for x in parts[1:]] + [0, 0, 0]
   tool = os.path.join(CSRC, 'lds_report')
   src = tool + '.cpp'
   deps = [src, os.path.join(CSRC, 'step_tables.h'), os.path.join(CSRC, 'step_layout.h')]
@@ -33,7 +33,7 @@ def report(spec):
     fi, fr = os.path.join(td, 'i.bin'), os.path.join(td, 'r.bin')
     ints.tofile(fi)
     reals.tofile(fr)
-    out = subprocess.check_output([tool, name, fi, fr, str(caps[0]), str(caps[1])]).decode()
+    out = subprocess.check_output([tool, name, fi, fr, str(caps[0]), str(caps[1]), str(caps[2])]).decode()
   return json.loads(out)
 
 

@@ -19,16 +19,19 @@ struct Emu {
   // optional stash of the position / velocity stage between legacy steps (one environment)
   int stash_on = 0, stash_epoch = 1;
   std::vector<double> stash_r64; std::vector<float> stash_r32; std::vector<int> stash_i;
+  // per-environment world geoms (one environment here): slot table + the 16 values per declared geom
+  std::vector<int> eg_slot; std::vector<double> eg64; std::vector<float> eg32;
+  std::vector<double> nsA;      // noslip matrix (global memory on the device)
 };
 
 static std::string g_err;
 
 extern "C" {
 const char* emu_last_error() { return g_err.c_str(); }
-void* emu_create(const int32_t* ints, int ni, const double* reals, int nr, int nconmax, int njmax) {
+void* emu_create(const int32_t* ints, int ni, const double* reals, int nr, int nconmax, int njmax, int njcon) {
   Emu* e = new Emu;
   if (!host_model_parse(&e->hm, ints, ni, reals, nr, &g_err)) { delete e; return nullptr; }
-  if (!step_tables_build(&e->tb, e->hm, nconmax, njmax, &g_err)) { delete e; return nullptr; }
+  if (!step_tables_build(&e->tb, e->hm, nconmax, njmax, &g_err, njcon)) { delete e; return nullptr; }
   e->mr32.assign(e->tb.mr.begin(), e->tb.mr.end());
   return e;
 }
@@ -40,6 +43,12 @@ int emu_dims(void* h, int* out) {
 }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
+void emu_set_env_geoms(void* h, int n, const int* ids, const double* data) {
+  Emu* e = (Emu*)h;
+  e->eg_slot.assign(e->hm.ngeom, -1);
+  for (int k = 0; k < n; k++) e->eg_slot[ids[k]] = k;
+  e->eg64.assign(data, data + 16*n); e->eg32.assign(data, data + 16*n);
+}
 int emu_find(void* h, const char* name, int* off, int* cnt, int* kind) { return step_layout_find(&((Emu*)h)->tb.L, name, off, cnt, kind); }
 
 }  // extern "C"
@@ -74,6 +83,8 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   io.env_mode = nullptr;
+  if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }
+  if (!e->eg_slot.empty()) { o.eg_slot = e->eg_slot.data(); o.eg_n = (int)e->eg64.size() / 16; o.eg_B = 1; o.eg_data = sizeof(T) == 8 ? (const void*)e->eg64.data() : (const void*)e->eg32.data(); }
   io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
   if (e->stash_on) { io.stash_r = sizeof(T) == 8 ? (T*)e->stash_r64.data() : (T*)e->stash_r32.data(); io.stash_i = e->stash_i.data(); }
   DynLayoutSrc ls; ls.p = &L;

@@ -29,10 +29,11 @@ def lib():
     L = ctypes.CDLL(_LIB)
     L.emu_last_error.restype = ctypes.c_char_p
     L.emu_create.restype = ctypes.c_void_p
-    L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.emu_free.argtypes = [ctypes.c_void_p]
     L.emu_stash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_invalidate.argtypes = [ctypes.c_void_p]
+    L.emu_set_env_geoms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
     L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
@@ -43,11 +44,11 @@ def lib():
 
 class EmuPhysics:
 
-  def __init__(self, compiled, prec=64, nconmax=0, njmax=0):
+  def __init__(self, compiled, prec=64, nconmax=0, njmax=0, njcon=0):
     self.m = compiled
     self.prec = prec
     ints, reals = compiled.pack()
-    self.h = lib().emu_create(ints.ctypes.data, ints.size, reals.ctypes.data, reals.size, nconmax, njmax)
+    self.h = lib().emu_create(ints.ctypes.data, ints.size, reals.ctypes.data, reals.size, nconmax, njmax, njcon)
     if not self.h:
       raise ValueError(lib().emu_last_error().decode())
     dims = np.zeros(8, dtype=np.int32)
@@ -92,6 +93,13 @@ class EmuPhysics:
 
   def invalidate(self):
     lib().emu_invalidate(self.h)
+
+  def set_env_geoms(self, geom_ids, rows):
+    """Per-environment world geoms of this (single) environment: rows = (n, 16) pos / xmat / size / rbound."""
+    ids = np.ascontiguousarray(geom_ids, dtype=np.int32)
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    assert rows.shape == (ids.size, 16)
+    lib().emu_set_env_geoms(self.h, ids.size, ids.ctypes.data, rows.ctypes.data)
 
   def step(self, nstep=1, legacy=True):
     self._run(nstep, int(legacy), 0)

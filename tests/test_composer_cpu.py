@@ -261,3 +261,42 @@ def test_soccer_fused_checks_detectors_once_per_control_step():
 def test_make_names():
   with pytest.raises(ValueError):
     composer.make('nope', 1)
+
+
+def test_soccer_pitch_resize_rows_reproduce_the_compiled_pitch():
+  """RandomizedPitch (pitch.py:645-669) on per-environment geom rows: resizing to the asset's own 40 x 30 must
+  reproduce, for every wall and goal post, exactly the pose / size / bounding radius the MJCF compiler derived
+  from the reference's goal-post geometry (scripts/make_soccer_model.py); another size moves walls and goals."""
+  task = soccer.Soccer2v2(randomize_pitch=((32, 24), (48, 36)))
+  m = task.model
+  names = task.pitch_geoms()
+  B = 3
+
+  def quat2mat(q):
+    w, x, y, z = q
+    return np.array([[w*w+x*x-y*y-z*z, 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), w*w-x*x+y*y-z*z, 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), w*w-x*x-y*y+z*z]])
+  rows = []
+  for n in names:
+    g = m.name2id(n, 'geom')
+    rows.append(np.r_[m.geom_pos[g], quat2mat(m.geom_quat[g]).ravel(), m.geom_size[g], m.geom_rbound[g]])
+  init = np.concatenate(rows)
+
+  class _P:
+    pass
+  p = _P()
+  p.torch, p.B, p.dtype, p.device = torch, B, torch.float64, torch.device('cpu')
+  eg = torch.from_numpy(np.tile(init[:, None], (1, B))).clone()
+  p.field = lambda name: eg
+  mask = torch.tensor([True, True, False])
+  size = torch.tensor([[40.0, 32.0, 48.0], [30.0, 24.0, 36.0]], dtype=torch.float64)
+  task._resize_pitch(p, size, mask)
+  np.testing.assert_allclose(eg[:, 0].numpy(), init, rtol=0, atol=1e-12)            # same size: the compiled pitch
+  np.testing.assert_array_equal(eg[:, 2].numpy(), init)                               # not in the mask: untouched
+  e1 = eg[:, 1].numpy().reshape(len(names), 16)
+  assert e1[0, 1] == -24.0 and e1[1, 1] == 24.0 and e1[2, 0] == -32.0 and e1[3, 0] == 32.0        # walls at the new size
+  k = names.index('home_goal/top_post')
+  assert abs(e1[k, 13] - 24 * 0.33) < 1e-12 and abs(e1[k, 0] - (-32.0 + 32. / 6.)) < 1e-12       # half-length, goal line
+  lo, hi = task.home_goal.bounds(p)
+  assert abs(float(lo[0, 1]) + 32.0) < 1e-12 and abs(float(hi[1, 1]) - 24 * 0.33) < 1e-12
+  flo, fhi = task.field.bounds(p)
+  assert abs(float(fhi[0, 1]) - (32.0 - 32. / 6.)) < 1e-12 and float(fhi[0, 2]) == 40.0 - 32. / 6.      # masked-out env keeps 40 x 30

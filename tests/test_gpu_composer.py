@@ -182,3 +182,97 @@ def test_soccer_environment_on_gpu():
   assert int(ts.step_type[0]) == environment.FIRST and not bool(task.field.detected[5])
   assert int(phys.field('warning').sum()) == 0
   env.close()
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 2e-4)])
+def test_per_env_world_geoms_two_pitch_sizes_in_one_launch(precision, tol):
+  """Per-environment model deltas (dmc_batch_set_env_geoms; soccer/pitch.py:612-690 RandomizedPitch): a batch whose
+  environments have DIFFERENT wall positions and goal-post sizes, stepped in one launch, matches per-environment
+  oracles whose models were edited accordingly."""
+  from dm_control_amd.batch import BatchedPhysics
+  from oracle.oracle import OraclePhysics
+  m = _model('soccer_2v2_boxhead')
+  names = ['wall0', 'wall1', 'wall2', 'wall3', 'home_goal/right_post', 'away_goal/top_post']
+  B = 6
+  scales = np.array([0.3, 0.27, 0.33, 0.3, 0.27, 0.36])
+  b = BatchedPhysics(m, B, precision=precision, nconmax=24)
+  b.set_env_geoms(names)
+  rs = np.random.RandomState(0)
+  refs = [OraclePhysics(m) for _ in range(B)]
+  for n in names:
+    g = m.name2id(n, 'geom')
+    wall = n.startswith('wall')
+    pos = np.array([np.array(m.geom_pos[g]) * (scales[e] if wall else 1.0) + (0 if wall else rs.uniform(-1, 1, 3) * [2, 2, 0]) for e in range(B)])
+    size = np.tile(np.array(m.geom_size[g]) * (1.0 if wall else 1.5), (B, 1))
+    b.set_env_geom(n, pos=pos, size=size)
+    rows = b.pack_env_geom(n, pos, m.geom_quat[g], size)
+    for e, o in enumerate(refs):
+      o.model.field('geom_pos')[3*g:3*g + 3] = pos[e]
+      o.model.field('geom_size')[3*g:3*g + 3] = size[e]
+      o.model.field('geom_rbound')[g] = rows[e, 15]
+  q = np.tile(m.qpos0, (B, 1)); q[:, 24:26] = (6.0, 3.0)
+  v = np.zeros((B, m.nv)); v[:, 24:27] = (40.0, 25.0, 1.0)
+  b.set('qpos', q); b.set('qvel', v)
+  for e, o in enumerate(refs):
+    o.qpos[:] = q[e]; o.qvel[:] = v[e]
+    o.forward()
+  hit = np.zeros(B, bool)
+  for t in range(300):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    if precision == 32 and t:
+      b.set('qpos', np.stack([o.qpos for o in refs])); b.set('qvel', np.stack([o.qvel for o in refs]))
+      b.set('qacc_warmstart', np.stack([o.qacc_warmstart for o in refs]))
+    b.set_control(c)
+    b.step()
+    for e, o in enumerate(refs):
+      o.ctrl[:] = c[e]
+      o.step()
+      for k in range(o.ncon):
+        if m.names['geom'][o.contact(k)['geom1']].startswith('wall'):
+          hit[e] = True
+    if precision == 32 and t < 3:
+      continue
+    qo = np.stack([o.qpos for o in refs])
+    np.testing.assert_allclose(b.get('qpos'), qo, rtol=0, atol=tol * max(1.0, np.abs(qo).max()), err_msg='step %d' % t)
+  assert hit.all() and not b.get('warning').any()
+  ball = b.get('qpos')[:, 24:26]
+  assert (np.abs(ball[:, 0]) < 40 * scales + 1).all() and len(set(np.round(ball[:, 0], 3))) > 2       # different pitches, different games
+  b.close()
+
+
+def test_soccer_randomized_pitch_on_gpu():
+  """soccer.load's RandomizedPitch ((32, 24) .. (48, 36), soccer/__init__.py:140-148) per environment: every env
+  plays on its own pitch -- walls contain its ball, goals sit on its goal lines -- and a reset draws a new one."""
+  import torch
+  from dm_control_amd import composer
+  B = 24
+  env = composer.make('soccer_2v2', B, random_state=4, randomize_pitch=((32, 24), (48, 36)), fuse_substeps=True)
+  task, phys = env.task, env.physics
+  env.reset()
+  size = task._size_t.cpu().numpy()
+  assert (size[0] >= 32).all() and (size[0] <= 48).all() and (size[1] >= 24).all() and (size[1] <= 36).all()
+  assert len(set(np.round(size[0], 3))) > B // 2
+  eg = phys.field('env_geom').cpu().numpy().reshape(24, 16, B)
+  np.testing.assert_allclose(eg[0, 1], -size[1], rtol=1e-6); np.testing.assert_allclose(eg[3, 0], size[0], rtol=1e-6)
+  # shoot every ball hard at the +x wall: it must come back from ITS wall
+  q, v = phys.field('qpos'), phys.field('qvel')
+  bq, bv = task._ball_q, task._ball_v
+  q[bq:bq + 3] = torch.tensor([0.0, 20.0, 0.3], device='cuda', dtype=q.dtype)[:, None]      # y = 20: beside the goal mouth
+  v[bv:bv + 6] = 0
+  v[bv] = 60.0
+  phys.mark_as_dirty()
+  xmax = torch.zeros(B, device='cuda', dtype=q.dtype)
+  for t in range(60):
+    ts = env.step(torch.zeros((B, 4, 3), device='cuda'))
+    xmax = torch.maximum(xmax, task.ball_xpos(phys)[0])
+  xmax = xmax.cpu().numpy()
+  assert (xmax <= size[0] + 0.05).all() and (xmax >= size[0] - 0.8).all(), (xmax - size[0])
+  assert int(phys.field('warning').sum()) == 0
+  # a reset draws a new pitch for the environments that restart
+  task.home_goal.detected[:] = False
+  old = size.copy()
+  env._reset_next[:5] = True
+  env.step(torch.zeros((B, 4, 3), device='cuda'))
+  new = task._size_t.cpu().numpy()
+  assert (new[:, 5:] == old[:, 5:]).all() and (new[:, :5] != old[:, :5]).any()
+  env.close()

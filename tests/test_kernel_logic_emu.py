@@ -522,3 +522,59 @@ def test_step1_step2_entry_points(asset):
       np.testing.assert_array_equal(a.qpos, b.qpos)
       o.qpos[:] = b.qpos; o.qvel[:] = b.qvel; o.qacc_warmstart[:] = b.qacc_warmstart
   assert np.abs(a.qpos - q).max() > 1e-3
+
+
+def _env_geom_rows(m, g, pos, quat, size):
+  """pos(3) xmat(9) size(3) rbound(1) of one geom, computed here from the definitions (not via the library)."""
+  w, x, y, z = np.asarray(quat, float) / np.linalg.norm(quat)
+  mat = np.array([[1-2*(y*y+z*z), 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), 1-2*(x*x+z*z), 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), 1-2*(x*x+y*y)]])
+  t = int(m.geom_type[g])
+  rb = {2: size[0], 3: size[0] + size[1], 6: float(np.linalg.norm(size))}.get(t, 0.0)
+  return np.r_[pos, mat.ravel(), size, rb]
+
+
+@pytest.mark.parametrize('prec,tol', [(64, 1e-10), (32, 2e-4)])
+def test_per_env_world_geoms_match_single_model_oracles(prec, tol):
+  """Per-environment model deltas (soccer pitch randomisation, soccer/pitch.py:612-690): walls and a goal post moved /
+  resized per environment through the per-env geom table must give exactly what an oracle whose MODEL was edited
+  that way gives -- the batch shares one compiled model, the reference would have recompiled."""
+  m = mc.compile_xml(open(os.path.join(ASSETS, 'soccer_2v2_boxhead.xml')).read())
+  names = ['wall0', 'wall1', 'wall2', 'wall3', 'home_goal/right_post', 'away_goal/top_post']
+  ids = [m.name2id(n, 'geom') for n in names]
+  rs = np.random.RandomState(0)
+  for variant in range(2):
+    scale = (0.3, 0.27)[variant]                       # two pitch sizes, both small enough for the ball to reach the walls
+    o = OraclePhysics(m)
+    om, e = o.model, EmuPhysics(m, prec, nconmax=24)
+    rows = []
+    for n, g in zip(names, ids):
+      pos = np.array(m.geom_pos[g]) * (scale if n.startswith('wall') else 1.0) + (0 if n.startswith('wall') else rs.uniform(-1, 1, 3) * [2, 2, 0])
+      size = np.array(m.geom_size[g]) * (1.0 if n.startswith('wall') else 1.5)
+      quat = np.array(m.geom_quat[g])
+      om.field('geom_pos')[3*g:3*g + 3] = pos
+      om.field('geom_size')[3*g:3*g + 3] = size
+      om.field('geom_rbound')[g] = _env_geom_rows(m, g, pos, quat, size)[15]
+      rows.append(_env_geom_rows(m, g, pos, quat, size))
+    e.set_env_geoms(ids, np.stack(rows))
+    q = m.qpos0.copy()
+    q[24:26] = (6.0, 3.0)
+    v = np.zeros(m.nv); v[24:27] = (40.0, 25.0, 1.0)        # a hard shot: the ball bounces off the (moved) walls
+    for p in (o, e):
+      p.qpos[:] = q; p.qvel[:] = v
+    o.forward()
+    hit_wall = False
+    for t in range(300):
+      c = rs.uniform(-1, 1, m.nu)
+      o.ctrl[:] = c; e.ctrl[:] = c
+      if prec == 32 and t:
+        e.qpos[:] = o.qpos; e.qvel[:] = o.qvel; e.qacc_warmstart[:] = o.qacc_warmstart
+      o.step(); e.step()
+      if prec == 32 and t < 3:
+        continue                     # the players' drop onto the pitch at t = 0: |qacc| ~ 1e4, a one-step fp32 transient
+      np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol * max(1.0, np.abs(o.qpos).max()), err_msg='variant %d step %d' % (variant, t))
+      for k in range(o.ncon):
+        ci = o.contact(k)
+        if m.names['geom'][ci['geom1']].startswith('wall'):
+          hit_wall = True
+    assert hit_wall and np.abs(o.qpos[24:26]).max() < 40 * scale + 1.0       # the ball stayed inside the smaller pitch
+    assert not o.warning.any() and not e.warning.any()
