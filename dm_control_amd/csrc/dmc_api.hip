@@ -65,6 +65,7 @@ struct dmc_batch {
   // per-env stash of the position / velocity stage between legacy steps (StepIO::stash_*); epoch: bumped by every
   // host-side edit that can change what the stage depends on, which invalidates all stashes at once
   void* d_stash_r; int* d_stash_i; int stash_epoch; int stash_on;
+  int xfrc_on;         // xfrc_applied was written / bound / exposed: the kernel reads it from now on
   void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
@@ -98,21 +99,25 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   if (lpe != 64 && lpe != 32 && lpe != 16) return fail("lanes_per_env must be 64, 32 or 16");
   const int epw = 64 / lpe;
   int best_w = 0; long best_score = -1;
-  // workgroups of up to 8 waves (512 threads): one big workgroup shares the model tables among more environments
-  // than two smaller ones can (humanoid: 7 instead of 2 x 3 per CU).  The kernels are built for 2 waves per SIMD
-  // (256 VGPRs), i.e. at most 8 resident waves per CU whatever the LDS would allow.
-  const int order[8] = {4, 8, 7, 6, 5, 3, 2, 1};
-  for (int k = 0; k < 8; k++) {
-    const int w = order[k];
+  // The kernels are built for 2 waves per SIMD (256 VGPRs): at most 8 resident waves per CU whatever the LDS would
+  // allow.  Workgroups of more than 4 waves were tried (512 threads: humanoid 7 environments in one workgroup instead
+  // of 2 x 3) and measured slower (1.20 M vs 1.29 M env-steps/s), so 4 waves stays the largest shape.
+  for (int w = 4; w >= 1; w--) {
     const size_t bytes = tables + (size_t)w * epw * env_bytes;
     if (bytes > lds_cu) continue;
     long blocks = (long)(lds_cu / bytes);
     if (blocks * w > 8) blocks = 8 / w;             // VGPR-limited: 2 waves per SIMD
     if (blocks < 1) continue;
     const long score = blocks * w * epw;            // resident envs per CU
-    // another shape than 4 waves only for a clear gain in residency: 4-wave groups give grids that divide the
+    // fewer waves per workgroup only for a clear gain in residency: 4-wave groups give grids that divide the
     // batch evenly (cartpole, B = 4096: 3-wave groups = 683 workgroups ran 1.8x slower than 4-wave = 512)
-    if (best_score < 0 || score * 100 >= best_score * 115) { best_score = score; best_w = w; }
+    if (best_score < 0 || score * 100 > best_score * 115) { best_score = score; best_w = w; }
+  }
+  // a batch too small to fill the chip (soccer: 256 environments per GPU): spread it over as many CUs as possible --
+  // the smallest workgroup that still holds the batch in one round (one wave alone on a CU shares nothing)
+  if (best_w) {
+    const long cus = 256, need = ((long)b->B + cus * epw - 1) / (cus * epw);      // waves per CU to hold B at once
+    if (need < best_w) best_w = (int)std::max(1L, need);
   }
   if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
   LaunchGeom& g = b->geom;
@@ -163,7 +168,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->d_ns_A = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
@@ -185,7 +190,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   const int nb = d.nbody;
   const Spec specs[] = {
       {"qpos", d.nq, false}, {"qvel", d.nv, false}, {"ctrl", d.nu, false}, {"qacc_warmstart", d.nv, false},
-      {"qfrc_applied", d.nv, false}, {"time", 1, false}, {"act", d.na, false},
+      {"qfrc_applied", d.nv, false}, {"xfrc_applied", 6*nb, false}, {"time", 1, false}, {"act", d.na, false},
       {"sensordata", d.nsensordata, false}, {"xpos", 3*nb, false}, {"xquat", 4*nb, false}, {"xmat", 9*nb, false},
       {"xipos", 3*nb, false}, {"geom_xpos", 3*d.ngeom, false}, {"geom_xmat", 9*d.ngeom, false},
       {"site_xpos", 3*d.nsite, false}, {"site_xmat", 9*d.nsite, false}, {"subtree_com", 3*nb, false},
@@ -255,6 +260,7 @@ struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsu
 static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq = nullptr) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->tb.opts.eg_n) b->tb.opts.eg_data = find_field(b, "env_geom")->dev;      // follows dmc_batch_bind
+  b->tb.opts.xfrc = b->xfrc_on ? find_field(b, "xfrc_applied")->dev : nullptr; b->tb.opts.xfrc_B = b->B;
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
   if (b->precision == 64) {
@@ -493,7 +499,8 @@ static int get_real(dmc_batch* b, Field* f, double* dst) {
 static int set_real(dmc_batch* b, Field* f, const double* src) {
   const size_t n = (size_t)f->rows * b->B;
   if (!n) return 0;
-  if (f->name != "ctrl" && f->name != "qfrc_applied") b->stash_epoch++;   // inputs of the acceleration stage only
+  if (f->name != "ctrl" && f->name != "qfrc_applied" && f->name != "xfrc_applied") b->stash_epoch++;   // inputs of the acceleration stage only
+  if (f->name == "xfrc_applied") b->xfrc_on = 1;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
   if (b->precision == 64 || f->is_f64) {
@@ -555,6 +562,7 @@ extern "C" void* dmc_batch_device_ptr(dmc_batch* b, const char* name) {
   if (!b || !name) { fail("null argument"); return nullptr; }
   Field* f = find_field(b, name);
   if (!f) { fail(std::string("unknown field: ") + name); return nullptr; }
+  if (f->name == "xfrc_applied") b->xfrc_on = 1;
   return f->dev;
 }
 extern "C" int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr) {
@@ -562,6 +570,7 @@ extern "C" int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr) 
   Field* f = find_field(b, name);
   if (!f) return fail(std::string("unknown field: ") + name);
   f->dev = device_ptr ? device_ptr : f->owned;
+  if (f->name == "xfrc_applied") b->xfrc_on = 1;
   if (f->name != "ctrl" && f->name != "qfrc_applied") b->stash_epoch++;
   return 0;
 }
@@ -677,6 +686,7 @@ extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyfra
   if (reset_real("ctrl", c0, m.nu)) return -2;
   if (reset_real("qacc_warmstart", nullptr, m.nv)) return -2;
   if (reset_real("qfrc_applied", nullptr, m.nv)) return -2;
+  if (b->xfrc_on && reset_real("xfrc_applied", nullptr, 6*m.nbody)) return -2;
   if (reset_real("time", nullptr, 1)) return -2;
   if (reset_real("act", nullptr, m.na)) return -2;
   // mj_resetData clears warnings as well

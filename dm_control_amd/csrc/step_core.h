@@ -2090,6 +2090,13 @@ struct StepCore {
         if (b1 == b) for (int k = 0; k < 3; k++) { acc[k] += -(gt[k] + t[k]); acc[3 + k] += -gf[k]; }
         if (b2 == b) for (int k = 0; k < 3; k++) { acc[k] += (gt[k] + t[k]); acc[3 + k] += gf[k]; }
       }
+      if (b > 0 && o.xfrc) {      // applied Cartesian wrench, about the root's subtree COM like the contact wrenches
+        T xf[6], dif[3], t[3]; load_xfrc(b, xf);
+        const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
+        for (int k = 0; k < 3; k++) dif[k] = S(xipos)[3*b + k] - rc[k];
+        cross3(t, dif, xf);
+        for (int k = 0; k < 3; k++) { acc[k] += xf[3 + k] + t[k]; acc[3 + k] += xf[k]; }
+      }
       for (int k = 0; k < 6; k++) S(cfrc_ext)[6*b + k] = acc[k];
     }
     if (lane == 0) {
@@ -2453,8 +2460,30 @@ struct StepCore {
     }
     DMC_WSYNC();
   }
+  // xfrc_applied[b] = [force, torque] at the COM of body b, from global memory (group-uniform address per b)
+  DMC_DEV void load_xfrc(int b, T* xf) const {
+    const T* p = (const T*)o.xfrc + (size_t)6*b*o.xfrc_B + SI(imisc)[IM_ENV];
+    for (int k = 0; k < 6; k++) xf[k] = p[(size_t)k*o.xfrc_B];
+  }
   DMC_DEV void fwd_acceleration() {
     FOR_LANES(i, L.d.nv) S(qfrc_smooth)[i] = S(qfrc_passive)[i] - S(qfrc_bias)[i] + S(qfrc_applied)[i] + S(qfrc_actuator)[i];
+    if (o.xfrc) {
+      // mj_xfrcAccumulate: qfrc_smooth += J_b' [f; tau] with the body Jacobian at xipos, through the com-based motion
+      // axes: column k of J at point p is (cdof_lin + cdof_ang x (p - com_root), cdof_ang) for dofs above body b
+      FOR_LANES(i, L.d.nv) {
+        T acc = 0;
+        for (int b = 1; b < L.d.nbody; b++) {
+          if (!dof_in_chain(MI(body_lastdof)[b], i)) continue;
+          T xf[6]; load_xfrc(b, xf);
+          const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
+          const T dif[3] = {S(xipos)[3*b] - rc[0], S(xipos)[3*b + 1] - rc[1], S(xipos)[3*b + 2] - rc[2]};
+          T t[3]; cross3(t, dif, xf);                      // (p - c) x f
+          const T* cd = S(cdof) + 6*i;
+          acc += cd[0]*(xf[3] + t[0]) + cd[1]*(xf[4] + t[1]) + cd[2]*(xf[5] + t[2]) + cd[3]*xf[0] + cd[4]*xf[1] + cd[5]*xf[2];
+        }
+        S(qfrc_smooth)[i] += acc;
+      }
+    }
     DMC_WSYNC();
     chol_solve(S(qacc_smooth), S(qLH), S(qfrc_smooth), L.d.nv);
   }

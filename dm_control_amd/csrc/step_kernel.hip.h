@@ -77,7 +77,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
 }
 
 template <typename T, int LPE>
-__global__ void __launch_bounds__(512, DMC_MIN_WAVES)
+__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel(const StepLayout* __restrict__ Lp, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
             const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   // generic kernel: the layout lives in device memory (uniform scalar loads); taking
@@ -98,7 +98,7 @@ DMC_STATIC_IDS(DMC_DEF_STATIC)
 #undef DMC_DEF_STATIC
 
 template <typename T, int LPE, int SID>
-__global__ void __launch_bounds__(512, DMC_MIN_WAVES)
+__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
                    const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   step_kernel_body<T, LPE, StaticLayout<SID> >(StaticLayout<SID>(), o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);

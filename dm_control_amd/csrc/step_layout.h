@@ -228,6 +228,9 @@ struct StepOpts {
   // noslip: A = J_F M^-1 J_F^T of every environment, (B, nslip, nslip) full symmetric storage in global memory
   // (L2-resident for the environments in flight; 8 .. 36 KB per environment is LDS the solver needs elsewhere)
   void* ns_A;
+  // mjData.xfrc_applied: Cartesian [force(3), torque(3)] per body at its COM, (6 nbody, B) SoA in global memory; null
+  // until the caller touches the field (almost every batch): read only where it enters (mj_fwdAcceleration, cfrc_ext)
+  const void* xfrc; int xfrc_B;
 };
 
 static inline void step_layout_build(StepLayout* L, const StepDims& d) {

@@ -13,7 +13,7 @@ drop-in.  batch_size == B > 1: every data array gains a leading batch dimension.
 
 `physics.data` is a host mirror of the device arrays: reads fetch lazily (and
 are cached until the next step/forward/reset), writes to the input fields
-(`qpos qvel act ctrl qacc_warmstart qfrc_applied time`) are uploaded before the
+(`qpos qvel act ctrl qacc_warmstart qfrc_applied xfrc_applied time`) are uploaded before the
 next kernel launch.  High-throughput callers use `physics.batch`
 (`BatchedPhysics`: device pointers, zero-copy binds) instead of the mirror.
 """
@@ -38,12 +38,12 @@ _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margi
                          'body_quat')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
-_INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'time')
+_INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time')
 _INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
 # field -> (row object kind for named access, columns per row)
 _FIELD_AXES = {
     'qpos': ('joint_q', None), 'qvel': ('joint_v', None), 'qacc': ('joint_v', None),
-    'qacc_warmstart': ('joint_v', None), 'qfrc_applied': ('joint_v', None),
+    'qacc_warmstart': ('joint_v', None), 'qfrc_applied': ('joint_v', None), 'xfrc_applied': ('body', 6),
     'qfrc_actuator': ('joint_v', None), 'qfrc_bias': ('joint_v', None),
     'qfrc_constraint': ('joint_v', None),
     'ctrl': ('actuator', None), 'actuator_force': ('actuator', None),
@@ -52,7 +52,7 @@ _FIELD_AXES = {
     'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
     'site_xpos': ('site', 3), 'site_xmat': ('site', 9),
 }
-_COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'],
+_COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'], 6: ['fx', 'fy', 'fz', 'tx', 'ty', 'tz'],
          9: ['xx', 'xy', 'xz', 'yx', 'yy', 'yz', 'zx', 'zy', 'zz']}
 
 

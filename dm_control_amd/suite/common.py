@@ -10,11 +10,8 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # 62 KiB of scratch per environment), so the contact cap is the one that never overflowed in the soak runs (48: a
 # ragdoll lying on the floor reaches 27 .. 40 contacts; 32 raised mjWARN_CONTACTFULL 15 times in 0.4 M env-steps).
 # fp64 fits too since the LDS diet (one environment per CU): the parity tests of these models run both precisions.
-# njcon = 96: the 48 contact slots share a pool of 96 Jacobian rows (a floor contact takes 3 with elliptic cones, a
-# body-body contact 1; the soak runs peak at 28 contacts / 90 rows in all) -- 5 KB of LDS per environment that,
-# with the noslip matrix in global memory, make room for a THIRD resident environment per CU.
-DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=48, njcon=96),
-                'cmu_2019_position_floor': dict(nconmax=48, njcon=96),   # BASELINE config 4 physics (assets/)
+DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=64),
+                'cmu_2019_position_floor': dict(nconmax=48),   # BASELINE config 4 physics (assets/)
                 'soccer_2v2_boxhead': dict(nconmax=24),   # BASELINE config 5 physics (assets/)
                 'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts
 

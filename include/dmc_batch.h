@@ -83,7 +83,8 @@ int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);
 int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
 
 /* Field access by mjData name ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "time",
- * "qfrc_applied", "sensordata", "xpos", "xquat", "xmat", "xipos", "geom_xpos",
+ * "qfrc_applied", "xfrc_applied" (6 per body: Cartesian force, torque at the body COM; read by the kernel once it has been
+ * written, bound or exposed through dmc_batch_device_ptr), "sensordata", "xpos", "xquat", "xmat", "xipos", "geom_xpos",
  * "geom_xmat", "site_xpos", "site_xmat", "subtree_com", "qacc", "actuator_force",
  * "qfrc_actuator", "qfrc_bias", "qfrc_constraint", "contact_dist", "contact_pos",
  * "contact_frame", "contact_force" (mj_contactForce per contact, valid after dmc_batch_forward;

@@ -14,12 +14,15 @@ for domain, task in [dt for dt in suite.ALL_TASKS if not _ONLY or dt[0] in _ONLY
     env = suite.load(domain, task, task_kwargs=dict(random=0), physics_kwargs=dict(batch_size=B, precision=32))
     spec = env.action_spec()
     rs = np.random.RandomState(0)
+    # unbounded action specs (lqr: no ctrlrange, engine.py:1093-1103 gives +-mjMAXVAL) are sampled in [-1, 1]: U(-1e10, 1e10)
+    # forces drive the state past mjMAXVAL within a few hundred steps and raise BADQACC by construction
+    lo, hi = np.maximum(spec.minimum, -1.0), np.minimum(spec.maximum, 1.0)
     ts = env.reset()
     rmin, rmax, n = np.inf, -np.inf, 0
     t0 = time.perf_counter()
     with env.physics.suppress_physics_errors():
       for t in range(T):
-        ts = env.step(rs.uniform(spec.minimum, spec.maximum, spec.shape))
+        ts = env.step(rs.uniform(lo, hi, spec.shape))
         n += 1
         if ts.reward is not None:
           r = np.asarray(ts.reward); rmin = min(rmin, float(r.min())); rmax = max(rmax, float(r.max()))

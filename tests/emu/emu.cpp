@@ -22,6 +22,7 @@ struct Emu {
   // per-environment world geoms (one environment here): slot table + the 16 values per declared geom
   std::vector<int> eg_slot; std::vector<double> eg64; std::vector<float> eg32;
   std::vector<double> nsA;      // noslip matrix (global memory on the device)
+  std::vector<double> xfrc64; std::vector<float> xfrc32;      // xfrc_applied (6 nbody), empty = not set
 };
 
 static std::string g_err;
@@ -43,6 +44,7 @@ int emu_dims(void* h, int* out) {
 }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
+void emu_set_xfrc(void* h, const double* x) { Emu* e = (Emu*)h; e->xfrc64.assign(x, x + 6*e->hm.nbody); e->xfrc32.assign(x, x + 6*e->hm.nbody); }
 void emu_set_env_geoms(void* h, int n, const int* ids, const double* data) {
   Emu* e = (Emu*)h;
   e->eg_slot.assign(e->hm.ngeom, -1);
@@ -83,6 +85,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   io.env_mode = nullptr;
+  if (!e->xfrc64.empty()) { o.xfrc = sizeof(T) == 8 ? (const void*)e->xfrc64.data() : (const void*)e->xfrc32.data(); o.xfrc_B = 1; }
   if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }
   if (!e->eg_slot.empty()) { o.eg_slot = e->eg_slot.data(); o.eg_n = (int)e->eg64.size() / 16; o.eg_B = 1; o.eg_data = sizeof(T) == 8 ? (const void*)e->eg64.data() : (const void*)e->eg32.data(); }
   io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;

@@ -33,6 +33,7 @@ def lib():
     L.emu_free.argtypes = [ctypes.c_void_p]
     L.emu_stash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_invalidate.argtypes = [ctypes.c_void_p]
+    L.emu_set_xfrc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_set_env_geoms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
@@ -93,6 +94,12 @@ class EmuPhysics:
 
   def invalidate(self):
     lib().emu_invalidate(self.h)
+
+  def set_xfrc(self, xfrc):
+    """mjData.xfrc_applied: (nbody, 6) [force, torque] at the body COMs."""
+    a = np.ascontiguousarray(xfrc, dtype=np.float64).reshape(-1)
+    assert a.size == 6 * self.m.nbody
+    lib().emu_set_xfrc(self.h, a.ctypes.data)
 
   def set_env_geoms(self, geom_ids, rows):
     """Per-environment world geoms of this (single) environment: rows = (n, 16) pos / xmat / size / rbound."""

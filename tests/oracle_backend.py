@@ -25,7 +25,7 @@ class OracleBatch:
     self.nconmax = nconmax or 16
     m = model
     nb = m.nbody
-    self._rows = dict(qpos=m.nq, qvel=m.nv, act=m.na, ctrl=m.nu, qacc_warmstart=m.nv, qfrc_applied=m.nv, time=1,
+    self._rows = dict(qpos=m.nq, qvel=m.nv, act=m.na, ctrl=m.nu, qacc_warmstart=m.nv, qfrc_applied=m.nv, xfrc_applied=6*nb, time=1,
                       sensordata=m.nsensordata, xpos=3*nb, xquat=4*nb, xmat=9*nb, xipos=3*nb, geom_xpos=3*m.ngeom,
                       geom_xmat=9*m.ngeom, site_xpos=3*m.nsite, site_xmat=9*m.nsite, subtree_com=3*nb, qacc=m.nv,
                       actuator_force=m.nu, qfrc_actuator=m.nv, qfrc_bias=m.nv, qfrc_constraint=m.nv, cvel=6*nb)

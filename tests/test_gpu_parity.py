@@ -794,3 +794,43 @@ def test_step1_step2_entry_points_on_gpu(name, precision, lanes):
       for k, o in enumerate(refs):
         o.qpos[:] = qprev[k]; o.qvel[:] = vprev[k]; o.qacc_warmstart[:] = wprev[k]
   a.close(); b.close()
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-10), (32, 2e-4)])
+def test_xfrc_applied_on_gpu(precision, tol):
+  """mjData.xfrc_applied through the C-ABI field: per-env Cartesian wrenches on three bodies of the humanoid against
+  the oracle (the host-build twin: tests/test_kernel_logic_emu.py::test_xfrc_applied_matches_oracle)."""
+  from oracle.oracle import OraclePhysics, OracleModel
+  m = _model('humanoid')
+  B = 4
+  rs = np.random.RandomState(3)
+  x = np.zeros((B, m.nbody, 6))
+  for e in range(B):
+    for bd in rs.choice(np.arange(1, m.nbody), 3, replace=False):
+      x[e, bd] = rs.uniform(-1, 1, 6) * [30, 30, 60, 3, 3, 3]
+  x[3] = 0                                  # one env without any wrench
+  b = _batch(m, B, precision=precision, nconmax=24)
+  b.set('xfrc_applied', x.reshape(B, -1))
+  om = OracleModel(m)
+  refs = [OraclePhysics(om) for _ in range(B)]
+  for e, o in enumerate(refs):
+    o.xfrc_applied[:] = x[e].ravel()
+    o.forward()
+  for t in range(120):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    if precision == 32 and t:
+      b.set('qpos', np.stack([o.qpos for o in refs])); b.set('qvel', np.stack([o.qvel for o in refs]))
+      b.set('qacc_warmstart', np.stack([o.qacc_warmstart for o in refs]))
+    b.set_control(c)
+    b.step()
+    for e, o in enumerate(refs):
+      o.ctrl[:] = c[e]
+      o.step()
+    qo = np.stack([o.qpos for o in refs])
+    np.testing.assert_allclose(b.get('qpos'), qo, rtol=0, atol=tol * max(1.0, np.abs(qo).max()), err_msg='step %d' % t)
+  if precision == 64:
+    so = np.stack([o.sensordata for o in refs])
+    np.testing.assert_allclose(b.get('sensordata'), so, rtol=0, atol=1e-7 * max(1.0, np.abs(so).max()))
+  b.reset()
+  assert not b.get('xfrc_applied').any()            # mj_resetData zeroes it
+  b.close()

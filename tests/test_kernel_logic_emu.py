@@ -578,3 +578,37 @@ def test_per_env_world_geoms_match_single_model_oracles(prec, tol):
           hit_wall = True
     assert hit_wall and np.abs(o.qpos[24:26]).max() < 40 * scale + 1.0       # the ball stayed inside the smaller pitch
     assert not o.warning.any() and not e.warning.any()
+
+
+@pytest.mark.parametrize('asset,prec,tol', [('humanoid', 64, 1e-10), ('cheetah', 64, 1e-10), ('humanoid', 32, 2e-4)])
+def test_xfrc_applied_matches_oracle(asset, prec, tol):
+  """mjData.xfrc_applied (Cartesian force / torque at body COMs, SURVEY 8(b) state inputs): enters qfrc_smooth through
+  the body Jacobians and cfrc_ext of the force / torque sensors."""
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    m = mc.compile_xml(f.read())
+  o, e = OraclePhysics(m), EmuPhysics(m, prec)
+  rs = np.random.RandomState(3)
+  x = np.zeros((m.nbody, 6))
+  for b in rs.choice(np.arange(1, m.nbody), 3, replace=False):
+    x[b] = rs.uniform(-1, 1, 6) * [30, 30, 60, 3, 3, 3]
+  o.xfrc_applied[:] = x.ravel()
+  e.set_xfrc(x)
+  free = np.zeros(m.nq); free[:] = m.qpos0
+  for p in (o, e):
+    p.qpos[:] = free
+  o.forward()
+  for t in range(150):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c; e.ctrl[:] = c
+    if prec == 32 and t:
+      e.qpos[:] = o.qpos; e.qvel[:] = o.qvel; e.qacc_warmstart[:] = o.qacc_warmstart
+    o.step(); e.step()
+    np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol * max(1, np.abs(o.qpos).max()), err_msg='step %d' % t)
+  if prec == 64 and m.nsensordata:
+    np.testing.assert_allclose(e.sensordata, o.sensordata, rtol=0, atol=1e-7 * max(1.0, np.abs(o.sensordata).max()))
+  # and it matters: without the wrench the trajectory is another one
+  o2 = OraclePhysics(m); o2.qpos[:] = free; o2.forward()
+  rs = np.random.RandomState(3); rs.choice(np.arange(1, m.nbody), 3, replace=False); [rs.uniform(-1, 1, 6) for _ in range(3)]
+  for t in range(150):
+    o2.ctrl[:] = rs.uniform(-1, 1, m.nu); o2.step()
+  assert np.abs(np.array(o2.qpos) - np.array(o.qpos)).max() > 1e-2
