@@ -421,7 +421,11 @@ def main():
     achieved = algo * B / (kernel_ms * 1e-3) / 1e9
     pmc = _committed_pmc(args.config)
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
+            'frac': achieved / HBM_PEAK_GBS,
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs; reads x 2
+            # as MI355X_MICROARCH.md prescribes for gfx950), profiles/r02_pmc_cfg<N>.json
+            'traffic': (pmc.get('hbm_bytes_per_launch') or {}).get('total_corrected') if pmc else None,
+            'traffic_detail': pmc.get('hbm_bytes_per_launch') if pmc else None,
             'kernel_ms_avg': kernel_ms, 'algorithmic_bytes_per_launch': algo * B,
             'note': 'nominal bound (SURVEY 8(d)): compulsory HBM traffic is %d B per env per launch; the kernel is '
                     'VALU-issue / latency bound, see roofline_issue' % algo}

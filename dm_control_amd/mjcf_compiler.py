@@ -1325,6 +1325,15 @@ class _Compiler:
         m.key_qvel[i] = _vec(k['qvel'], m.nv)
       if 'ctrl' in k:
         m.key_ctrl[i] = _vec(k['ctrl'], m.nu)
+      # mj_resetDataKeyframe also restores key_time and key_act; the batch reset zeroes both, so a keyframe that
+      # asks for anything else is refused instead of silently resetting to the wrong activation state / time
+      if 'time' in k and float(k['time']) != 0.0:
+        raise MjcfError('keyframe %r: a non-zero `time` is not supported' % k.get('name'))
+      if 'act' in k and np.any(np.asarray(_vec(k['act'], m.na) if m.na else [float(x) for x in k['act'].split()]) != 0):
+        raise MjcfError('keyframe %r: non-zero `act` is not supported' % k.get('name'))
+      for unsupported in ('mpos', 'mquat'):
+        if unsupported in k:
+          raise MjcfError('keyframe %r: mocap data (`%s`) is not supported' % (k.get('name'), unsupported))
     m.names['key'] = names
 
   # -- constants evaluated at qpos0 -------------------------------------------

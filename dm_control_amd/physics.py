@@ -297,6 +297,12 @@ class Physics(control.Physics):
     self._build_named()
     self._model_pushed = {f: np.array(getattr(model, f), dtype=np.float64, copy=True)
                           for f in _MUTABLE_MODEL_FIELDS if hasattr(model, f)}
+    # Every other model array feeds tables that are derived once at batch creation (contact-pair mixing, inertias,
+    # invweight0, ...): a write would be silently ignored by the device, so it is made to fail instead
+    # (ValueError: assignment destination is read-only).  The writable ones are _MUTABLE_MODEL_FIELDS.
+    for name, value in vars(model).items():
+      if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS:
+        value.setflags(write=False)
     self.after_reset()
 
   def _push_model(self):
@@ -396,23 +402,79 @@ class Physics(control.Physics):
     pass
 
   # -- state -------------------------------------------------------------------------------
-  def get_state(self):
-    """Concatenated [qpos, qvel, act] (engine.py:235-285)."""
-    return np.concatenate([np.asarray(self.data.qpos), np.asarray(self.data.qvel), np.asarray(self.data.act)], axis=-1)
+  # mjtState bits (mujoco 3.x), in the order mj_getState concatenates them
+  _STATE_BITS = (('time', 1 << 0), ('qpos', 1 << 1), ('qvel', 1 << 2), ('act', 1 << 3), ('qacc_warmstart', 1 << 4),
+                 ('ctrl', 1 << 5), ('qfrc_applied', 1 << 6), ('xfrc_applied', 1 << 7), ('eq_active', 1 << 8),
+                 ('mocap_pos', 1 << 9), ('mocap_quat', 1 << 10), ('userdata', 1 << 11), ('plugin_state', 1 << 12))
 
-  def set_state(self, physics_state):
+  def _state_components(self, sig):
+    if not isinstance(sig, (int, np.integer)) or sig <= 0 or sig >= (1 << 13):
+      raise ValueError('invalid state signature: {!r}'.format(sig))
+    out = []
+    for name, bit in self._STATE_BITS:
+      if not sig & bit:
+        continue
+      if name == 'eq_active':
+        n = len(getattr(self.model, 'eq_active0', ()))
+        out.append((name, n))
+      elif name in ('mocap_pos', 'mocap_quat', 'userdata', 'plugin_state'):
+        out.append((name, 0))            # no mocap bodies / user data / plugins in a compiled Model
+      else:
+        out.append((name, int(np.asarray(self.data._get(name)).reshape(self.batch_size, -1).shape[1])))
+    return out
+
+  def get_state(self, sig=None):
+    """sig None: concatenated [qpos, qvel, act] (engine.py:235-249); otherwise what `mj_getState(sig)` returns
+    (engine.py:246-249): the components selected by the mjtState bits of `sig`, in bit order."""
+    if sig is None:
+      return np.concatenate([np.asarray(self.data.qpos), np.asarray(self.data.qvel), np.asarray(self.data.act)], axis=-1)
+    parts = []
+    for name, n in self._state_components(sig):
+      if name == 'eq_active':
+        a = np.tile(np.asarray(self.model.eq_active0, dtype=np.float64), (self.batch_size, 1))
+      elif n == 0:
+        a = np.zeros((self.batch_size, 0))
+      else:
+        a = np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1)
+      parts.append(a)
+    out = np.concatenate(parts, axis=1) if parts else np.zeros((self.batch_size, 0))
+    return out[0] if self.batch_size == 1 else out
+
+  def set_state(self, physics_state, sig=None):
     s = np.asarray(physics_state, dtype=np.float64)
-    nq, nv, na = self.model.nq, self.model.nv, self.model.na
-    if s.shape[-1] != nq + nv + na:
-      raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (nq + nv + na,)))
-    self.data.qpos = s[..., :nq]
-    self.data.qvel = s[..., nq:nq + nv]
-    if na:
-      self.data.act = s[..., nq + nv:]
+    if sig is None:
+      nq, nv, na = self.model.nq, self.model.nv, self.model.na
+      if s.shape[-1] != nq + nv + na:
+        raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (nq + nv + na,)))
+      self.data.qpos = s[..., :nq]
+      self.data.qvel = s[..., nq:nq + nv]
+      if na:
+        self.data.act = s[..., nq + nv:]
+      return
+    comps = self._state_components(sig)
+    total = sum(n for _, n in comps)
+    if s.shape[-1] != total:
+      raise ValueError('Input physics state has shape {}. Expected {}.'.format(s.shape, (total,)))
+    start = 0
+    for name, n in comps:
+      chunk = s[..., start:start + n]
+      start += n
+      if name == 'eq_active':
+        if n and not np.array_equal(np.broadcast_to(chunk, (self.batch_size, n)) != 0,
+                                    np.tile(np.asarray(self.model.eq_active0) != 0, (self.batch_size, 1))):
+          raise ValueError('eq_active cannot be changed at run time on this backend')
+      elif n:
+        setattr(self.data, name, chunk[..., 0] if name == 'time' else chunk.reshape(np.shape(self.data._get(name))))
 
   def copy(self, share_model=False):
-    del share_model
-    other = type(self)(self.model, batch_size=self.batch_size, precision=self.batch.precision, **self._batch_kwargs)
+    """engine.py:287-304: an independent Physics in the same state; the model is copied unless share_model."""
+    import copy as _copy
+    model = self.model if share_model else _copy.deepcopy(self.model)
+    other = type(self)(model, batch_size=self.batch_size, precision=self.batch.precision, **self._batch_kwargs)
+    # per-episode state that suite Physics subclasses keep on the instance (reacher / finger / manipulator targets)
+    for k, v in vars(self).items():
+      if not k.startswith('_') and k not in ('model', 'batch', 'data', 'named', 'batch_size'):
+        setattr(other, k, _copy.deepcopy(v))
     for name in _INPUT_FIELDS:
       other.batch.set(name, np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1))
     other.legacy_step = self.legacy_step
@@ -436,7 +498,9 @@ class Physics(control.Physics):
     self.data._upload()
     return dict(cls_model=self.model, batch_size=self.batch_size, precision=self.batch.precision,
                 legacy_step=self.legacy_step, batch_kwargs=self._batch_kwargs,
-                fields={n: self.batch.get(n) for n in _INPUT_FIELDS})
+                fields={n: self.batch.get(n) for n in _INPUT_FIELDS},
+                attrs={k: v for k, v in vars(self).items()
+                       if not k.startswith('_') and k not in ('model', 'batch', 'data', 'named', 'batch_size', 'legacy_step')})
 
   def __setstate__(self, st):
     Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'],
@@ -444,6 +508,8 @@ class Physics(control.Physics):
     for n, v in st['fields'].items():
       self.batch.set(n, v)
     self.legacy_step = st['legacy_step']
+    for k, v in st.get('attrs', {}).items():
+      setattr(self, k, v)
     self.data._invalidate()
     self.batch.forward(True)
     self.batch.set('qacc_warmstart', st['fields']['qacc_warmstart'])

@@ -12,6 +12,23 @@ def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+def pytest_collection_modifyitems(config, items):
+  """`gpu` tests need a HIP device and the built library: skip (not fail) where either is missing, so that a plain
+  `pytest tests` works on a CPU-only box."""
+  lib = os.path.join(ROOT, 'dm_control_amd', 'libdmc_hip.so')
+  try:
+    import torch
+    have = torch.cuda.is_available() and os.path.exists(lib)
+  except Exception:  # pylint: disable=broad-except
+    have = False
+  if have:
+    return
+  skip = pytest.mark.skip(reason='needs an MI355X and dm_control_amd/libdmc_hip.so')
+  for item in items:
+    if 'gpu' in item.keywords:
+      item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def oracle_lib():
   from oracle import oracle

@@ -70,6 +70,8 @@ class OracleBatch:
         o.time = float(a[e, 0])
       else:
         o.field(name)[:rows] = a[e]
+    if name in ('qpos', 'qvel', 'act'):
+      self._stale = True      # the HIP launch recomputes the position / velocity stage from the state it is given
 
   def set_control(self, control):
     self.set('ctrl', control)
@@ -82,7 +84,10 @@ class OracleBatch:
     del stream
     for o in self._envs:
       o.legacy_step = bool(self.legacy_step)
+      if getattr(self, '_stale', False) and self.legacy_step:
+        o.step1()
       o.step(int(nstep))
+    self._stale = False
 
   def forward(self, disable_actuation=False, stream=None):
     del stream

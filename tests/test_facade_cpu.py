@@ -192,3 +192,64 @@ def test_named_assignment_reaches_the_state(physics, field, key):
   np.testing.assert_array_equal(getattr(physics.named.data, field)[key], new)
   with pytest.raises(AttributeError):
     physics.data.xpos = 0                    # derived arrays are read-only
+
+
+# ---- round-2 advisor findings -------------------------------------------------------------------------
+def test_model_arrays_the_device_cannot_follow_are_read_only(oracle_backend):
+  """Writes to model arrays outside the pushed set used to be silently ignored by the device (body_mass *= 100 gave a
+  bit-identical trajectory): they now fail loudly; the pushed set stays writable."""
+  from dm_control_amd import suite
+  env = suite.load('cheetah', 'run', task_kwargs=dict(random=0))
+  p = env.physics
+  with pytest.raises(ValueError):
+    p.model.body_mass[1] = 100.0
+  with pytest.raises(ValueError):
+    p.named.model.geom_friction['torso', 0] = 0.0
+  p.model.dof_damping[3] = 2.5                     # in the pushed set
+  p.forward()
+
+
+def test_get_set_state_with_signature(oracle_backend):
+  """engine.py:235-285 with `sig`: mj_getState / mj_setState component order (mjtState bits)."""
+  from dm_control_amd import suite
+  env = suite.load('cheetah', 'run', task_kwargs=dict(random=1))
+  p = env.physics
+  env.reset()
+  env.step(np.full(6, 0.3))
+  m = p.model
+  TIME, QPOS, QVEL, ACT, WARM, CTRL, QFRC, XFRC = (1 << k for k in range(8))
+  s = p.get_state(QPOS | QVEL)
+  np.testing.assert_array_equal(s, np.r_[p.data.qpos, p.data.qvel])
+  np.testing.assert_array_equal(s, p.get_state())                      # no activations: same as the legacy form
+  full = p.get_state(TIME | QPOS | QVEL | ACT | WARM | CTRL | QFRC | XFRC)
+  assert full.shape == (1 + m.nq + m.nv + 0 + m.nv + m.nu + m.nv + 6 * m.nbody,)
+  assert full[0] == p.data.time and np.array_equal(full[1 + m.nq + 2 * m.nv:][:m.nu], p.data.ctrl)
+  q = p.copy()
+  for _ in range(5):
+    p.step()
+  p.set_state(full, TIME | QPOS | QVEL | ACT | WARM | CTRL | QFRC | XFRC)      # (no forward: it would overwrite the warm start)
+  for _ in range(5):
+    p.step(); q.step()
+  np.testing.assert_array_equal(p.data.qpos, q.data.qpos)             # state complete: continues identically
+  with pytest.raises(ValueError):
+    p.set_state(full[:-1], TIME | QPOS | QVEL | ACT | WARM | CTRL | QFRC | XFRC)
+  with pytest.raises(ValueError):
+    p.get_state(0)
+
+
+def test_copy_keeps_subclass_episode_state_and_owns_its_model(oracle_backend):
+  """copy() / pickle of a suite Physics subclass keep its per-episode attributes (reacher target) and do not share the
+  mutable model unless share_model=True (engine.py:287-304)."""
+  import pickle
+  from dm_control_amd import suite
+  env = suite.load('reacher', 'easy', task_kwargs=dict(random=3))
+  env.reset()
+  p = env.physics
+  want = np.array(p.finger_to_target())
+  c = p.copy()
+  np.testing.assert_array_equal(np.array(c.finger_to_target()), want)
+  u = pickle.loads(pickle.dumps(p))
+  np.testing.assert_array_equal(np.array(u.finger_to_target()), want)
+  assert c.model is not p.model and p.copy(share_model=True).model is p.model
+  c.model.dof_damping[0] = 9.0
+  assert p.model.dof_damping[0] != 9.0
