@@ -2743,20 +2743,46 @@ struct StepCore {
     FOR_LANES(i, L.d.nv) g += (S(sv_Ma)[i] - S(qfrc_smooth)[i]) * (S(qacc)[i] - S(qacc_smooth)[i]);
     return (T)0.5 * group_sum<LPE>(g);
   }
-  // res = M v.  Sparse M: lane i walks j = 0 .. nv-1 like a dense row product, the entry (max, min) being
-  // looked up through the ancestor masks (present iff min is an ancestor dof of max) -- independent
-  // iterations, same summation order as the dense product.
+  // res = M v.  Small models keep the dense M: a row product.  Tree-sparse models (nv > 16) never touch M: M v is the
+  // joint-space force that produces acceleration v at zero velocity without gravity, so it is evaluated the way
+  // mj_rne would (composite-inertia identity  M_ij = cdof_i . (sum_{d in subtree(i) & subtree(j)} cinert_d) cdof_j):
+  //   A. every body b in parallel: spatial acceleration a_b = sum of cdof_j v_j over the dofs j on the path to b
+  //      (the ancestor bit mask of its last dof), then its inertial force f_b = cinert_b a_b;
+  //   B. leaves to root, one tree level per fence: f_b += f_children (descending child order, as crb_mass_matrix);
+  //   C. every dof in parallel: res_i = cdof_i . f_body(i) + armature_i v_i.
+  // Cost: nlevel fences and O(depth) work per lane, instead of nv serial look-ups through the ancestor masks per row
+  // (root rows of a humanoid are dense): on the 62-dof model 6.6 products per physics step were 11 % of the step.
   DMC_DEV void mul_M(T* res, const T* v) {
     const int nv = L.d.nv;
     if (!L.d.msparse) { FOR_LANES(i, nv) res[i] = dot_n(S(qM) + i*nv, v, nv); return; }
-    FOR_LANES(i, nv) {
-      T acc = 0;
-      for (int j = 0; j < nv; j++) {
-        const int a = j <= i ? i : j, b2 = j <= i ? j : i;
-        if (dof_in_chain(a, b2)) acc += S(qM)[MI(dof_madr)[a] + anc_above(a, b2)] * v[j];
+    const int nb = L.d.nbody;
+    T* bf = S(sv_bf);
+    FOR_LANES(b, nb) {
+      T a[6] = {0, 0, 0, 0, 0, 0}, f[6] = {0, 0, 0, 0, 0, 0};
+      const int ld = b > 0 ? MI(body_lastdof)[b] : -1;
+      if (ld >= 0) {
+        unsigned lo = (unsigned)MI(dof_anc_lo)[ld], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[ld] : 0u;
+        while (lo) { const int j = __builtin_ctz(lo); lo &= lo - 1; const T vj = v[j]; const T* cd = S(cdof) + 6*j; for (int k = 0; k < 6; k++) a[k] += cd[k]*vj; }
+        while (hi) { const int j = 32 + __builtin_ctz(hi); hi &= hi - 1; const T vj = v[j]; const T* cd = S(cdof) + 6*j; for (int k = 0; k < 6; k++) a[k] += cd[k]*vj; }
+        mul_inert_vec(f, S(cinert) + 10*b, a);
       }
-      res[i] = acc;
+      for (int k = 0; k < 6; k++) bf[6*b + k] = f[k];
     }
+    DMC_WSYNC();
+    for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
+      const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
+      for (int idx = lane; idx < cnt*6; idx += LPE) {
+        const int b = MI(level_body)[a0 + idx/6], comp = idx % 6;
+        const int c0 = MI(child_adr)[b], c1 = MI(child_adr)[b + 1];
+        if (c1 > c0) {
+          T acc = bf[6*b + comp];
+          for (int c = c0; c < c1; c++) acc += bf[6*MI(child_list)[c] + comp];
+          bf[6*b + comp] = acc;
+        }
+      }
+      DMC_WSYNC();
+    }
+    FOR_LANES(i, nv) res[i] = dot_n(S(cdof) + 6*i, bf + 6*MI(dof_bodyid)[i], 6) + MR(dof_armature)[i]*v[i];
   }
   DMC_DEV void jar_from(const T* qacc, int nefc) {
     const RowMap rm = row_map();

@@ -154,6 +154,8 @@ struct StepDims {
 #define STEP_SCRATCH_OVL_SOL(X)                                                \
   X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
   X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)                    \
+  /* M v through the tree (mul_M, sparse-M models): per-body spatial force of the acceleration field of v */ \
+  X(sv_bf, d.msparse * 6 * d.nbody)                                            \
   /* elliptic cones: per-row coefficients of the middle-zone Hessian (newton_gradient) */ \
   X(efc_ca, d.elliptic * d.njmax) X(efc_cb, d.elliptic * d.njmax)              \
   X(efc_cg, d.elliptic * d.njmax)                                              \
