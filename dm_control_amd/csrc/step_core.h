@@ -892,9 +892,9 @@ struct StepCore {
   }
   // qLH <- M (+ diag), packed by columns: zero fill, then the nonzeros (i, j) of the (i, j) list; the list is
   // read from global memory one trip ahead of its use
-  DMC_DEV void scatter_M(const T* diag, T diag_scale) {
+  DMC_DEV void scatter_M(const T* diag, T diag_scale, T* dst) {
     const int nv = L.d.nv, nM = L.d.nM;
-    FOR_LANES(i, L.d.ntri) S(qLH)[i] = 0;
+    FOR_LANES(i, L.d.ntri) dst[i] = 0;
     DMC_WSYNC();
     int pk = lane < nM ? GC(mpair)[lane] : 0;
     for (int p = lane; p < nM; p += LPE) {
@@ -902,14 +902,17 @@ struct StepCore {
       if (p + LPE < nM) pk = GC(mpair)[p + LPE];
       T v = L.d.msparse ? S(qM)[p] : S(qM)[i*nv + j];
       if (diag && i == j) v += diag_scale*diag[i];
-      S(qLH)[tri_at(i, j, nv)] = v;
+      dst[tri_at(i, j, nv)] = v;
     }
     DMC_WSYNC();
   }
   // qLH <- M (+ timestep * damping on the diagonal), then its Cholesky factor
+  // the factor of M lives in qLM where a model runs noslip (it is needed again after H's factor took qLH), else in qLH
+  DMC_DEV T* M_factor() { return S(qLM); }      // aliases qLH when the model does not run noslip (step_layout_build)
   DMC_DEV void factor_M(bool with_damping) {
-    scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep);
-    chol_factor_inplace(S(qLH), L.d.nv);
+    T* dst = with_damping ? S(qLH) : M_factor();
+    scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
+    chol_factor_inplace(dst, L.d.nv);
   }
 
   // ---- collision (mj_collision over the static candidate pair list) -------------
@@ -2485,7 +2488,7 @@ struct StepCore {
       }
     }
     DMC_WSYNC();
-    chol_solve(S(qacc_smooth), S(qLH), S(qfrc_smooth), L.d.nv);
+    chol_solve(S(qacc_smooth), M_factor(), S(qfrc_smooth), L.d.nv);
   }
 
   // ---- Newton solver on the primal (mj_fwdConstraint / mj_solNewton) -----------------
@@ -2598,7 +2601,7 @@ struct StepCore {
       }
       S(sv_Mgrad)[i] = dsum;
     }
-    scatter_M(S(sv_Mgrad), (T)1);      // (fences inside: sv_Mgrad is complete before it is read)
+    scatter_M(S(sv_Mgrad), (T)1, S(qLH));      // (fences inside: sv_Mgrad is complete before it is read)
     if (L.d.njdense && (rm.s0 > 0 || rm.c0 > rm.tl0)) {
       for (int idx = lane; idx < L.d.ntri; idx += LPE) {
         int i, j;
@@ -3059,15 +3062,14 @@ struct StepCore {
     }
     if (over) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++; return; }   // more friction rows than the cap: step without noslip
     if (!nf) return;
-    // factor of M (qLH held the factor of H)
+    // M^-1 through the factor of M computed in the position stage (kept in qLM beside H's factor in qLH)
     DMC_WSYNC();
-    factor_M(false);
     const RowMap rm = row_map();
     for (int b = 0; b < nf; b++) {
       const int rb = SI(ns_row)[b];
       FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(rb, i, rm);
       DMC_WSYNC();
-      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv);
       { T* A = ns_A(); const int cap = L.d.nslip;
         for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
@@ -3103,7 +3105,7 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
     DMC_WSYNC();
-    chol_solve(S(qacc), S(qLH), S(sv_grad), nv);
+    chol_solve(S(qacc), M_factor(), S(sv_grad), nv);
     DMC_WSYNC();
   }
   DMC_DEV void fwd_constraint() {

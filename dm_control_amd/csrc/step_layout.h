@@ -132,6 +132,7 @@ struct StepDims {
   X(cvel, 6 * d.nbody)                                                         \
   X(qM, d.msparse ? d.nM : d.nv * d.nv)  /* sparse: row i holds M(i, i), M(i, parent(i)), ... (dof_madr) */ \
   X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
+  X(qLM, d.nslip ? d.ntri : 0)   /* noslip models: the factor of M kept beside that of H (noslip needs M^-1 after the solve) */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
@@ -256,6 +257,7 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #define X(name, cnt) L->s_##name = o; o += (cnt);
   STEP_SCRATCH_REAL(X)
 #undef X
+  if (!d.nslip) L->s_qLM = L->s_qLH;      // no noslip: M's factor is not needed after H's took the buffer -- one buffer
   o = (o + 3) & ~3;
   L->n_keep = o;
   {

@@ -668,3 +668,46 @@ def test_torch_env_matches_host_task(domain, task):
     np.testing.assert_allclose(obs.cpu().numpy(), want_obs, rtol=1e-7, atol=1e-7)
     np.testing.assert_allclose(rew.cpu().numpy(), host.task.get_reward(hp), rtol=1e-7, atol=1e-9)
   dev.close(); host.physics.free()
+
+
+@pytest.mark.parametrize('name,nsub,caps', [('cmu_2019_position_floor', 6, dict(nconmax=32)), ('soccer_2v2_boxhead', 5, dict(nconmax=24)),
+                                            ('humanoid_CMU', 10, dict(nconmax=32))])
+def test_baseline_62dof_and_soccer_models_fp64_open_loop(name, nsub, caps):
+  """BASELINE configs 4 / 5 (and the suite's humanoid_CMU) on the fp64 instantiation of the kernel, OPEN LOOP against
+  the oracle: since the LDS diet the fp64 scratch of the 62-dof models fits (one environment per CU, up to 32 .. 40
+  contacts), so these configs have the same fp64 GPU parity as the small ones."""
+  from dm_control_amd import mjcf_compiler as mc
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  from oracle.oracle import OraclePhysics, OracleModel
+  m = mc.compile_xml(common.read_model(name + '.xml'))
+  B, T = 6, 25
+  rs = np.random.RandomState(11)
+  q = np.tile(m.qpos0, (B, 1))
+  if name.startswith('soccer'):
+    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-8, 8, (B, 8))
+    q[:, 24:26] += rs.uniform(-15, 15, (B, 2))
+  else:
+    q[:, 7:] += rs.uniform(-0.15, 0.15, (B, m.nq - 7))
+    q[:, 2] -= 0.25 if name == 'humanoid_CMU' else 0.0
+  b = BatchedPhysics(m, B, precision=64, **caps)
+  assert b.info()['precision'] == 64
+  b.set('qpos', q)
+  om = OracleModel(m)
+  refs = [OraclePhysics(om) for _ in range(B)]
+  for e, o in enumerate(refs):
+    o.qpos[:] = q[e]
+    o.forward()
+  worst = 0.0
+  for t in range(T):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    b.set_control(c)
+    b.step(nsub)
+    for e, o in enumerate(refs):
+      o.ctrl[:] = c[e]
+      o.step(nsub)
+    qo = np.stack([o.qpos for o in refs])
+    worst = max(worst, float((np.abs(b.get('qpos') - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))).max()))
+  assert worst < 1e-8, worst
+  assert b.get('ncon').max() > 0 and not b.get('warning').any()
+  b.close()
