@@ -238,7 +238,7 @@ class Environment:
     self.physics.field('env_mode').zero_()
     self.physics.forward(disable_actuation=True)
     self.launches += 1
-    self._reset_next = torch.zeros_like(mask)
+    self._reset_next.zero_()
     self._host_all_reset = False
     B = self.physics.B
     return TimeStep(step_type=torch.full((B,), FIRST, dtype=torch.int32, device=self.physics.device),
@@ -251,7 +251,7 @@ class Environment:
     p, torch = self.physics, self.physics.torch
     if self._host_all_reset:
       return self.reset()
-    first = self._reset_next
+    first = self._reset_next.clone()
     # environments whose episode ended last step start a new one now; the others take a regular step.  The
     # re-initialisation is data-dependent but needs no host decision: the state edits are applied under the mask,
     # and the SAME launch that steps the others runs mj_forward with actuation disabled for these (env_mode 1).
@@ -288,8 +288,40 @@ class Environment:
     # an environment that was (re)started this call reports FIRST with no reward, and cannot end on it
     reward = torch.where(first if reward.dim() == 1 else first[None, :], torch.zeros_like(reward), reward)
     discount = torch.where(first, torch.ones_like(discount), discount)
-    self._reset_next = terminating & ~first
+    self._reset_next.copy_(terminating & ~first)      # in place: carried state must keep its address (graph replay)
     return TimeStep(step_type=step_type, reward=reward, discount=discount, observation=obs)
+
+  # -- HIP graph: one control step as ONE replayable graph ----------------------------------------------------
+  def capture(self, example_action):
+    """Captures `step` -- hooks, the physics launch(es), reward, termination, observation gather: a few hundred
+    small device operations with no host decision in between -- into a HIP graph (torch.cuda.CUDAGraph; the
+    library's kernels are launched on the capturing stream like any other).  `step_graph(action)` then replays it:
+    the per-operation launch overhead, which dominates small batches (soccer at 256 environments: 10 ms of host
+    time around 3.4 ms of physics), is paid once.  Every tensor the step carries over (reset flags, task state,
+    detector state) is updated in place, so a replay continues where the previous one ended."""
+    torch = self.physics.torch
+    if self._host_all_reset:
+      self.reset()
+    self._g_action = example_action.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):              # warm-up off the default stream, as graph capture requires
+      for _ in range(2):
+        self.step(self._g_action)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    for gen in getattr(self.task, 'generators', lambda: ())():
+      graph.register_generator_state(gen)
+    with torch.cuda.graph(graph):
+      self._g_out = self.step(self._g_action)
+    self._graph = graph
+    return self._g_out
+
+  def step_graph(self, action):
+    """Replays the captured control step on `action`; returns the SAME TimeStep tensors, refreshed."""
+    self._g_action.copy_(action)
+    self._graph.replay()
+    return self._g_out
 
   def _divergence(self, physics):
     w = physics.field('warning')

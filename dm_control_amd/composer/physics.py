@@ -145,6 +145,7 @@ class DevicePhysics:
     self.batch = BatchedPhysics(model, self.B, device_id=device_id, precision=precision, **caps)
     self._fields = {}
     self._gathers = {}
+    self._consts = {}
     mask = 0
     names = ['qpos', 'qvel', 'ctrl', 'qacc_warmstart', 'time', 'ncon', 'warning', 'env_mode'] + (['act'] if model.na else [])
     for f in outputs:
@@ -200,6 +201,16 @@ class DevicePhysics:
     self.env_geoms = list(names)
     return t
 
+  def const(self, values):
+    """Device tensor of a small host constant, uploaded ONCE per distinct value: tasks call this inside their hooks, and
+    a host-to-device copy inside a captured HIP graph is not allowed (nor wanted on every control step)."""
+    a = np.asarray(values, dtype=np.float64)
+    key = (a.shape, a.tobytes())
+    t = self._consts.get(key)
+    if t is None:
+      t = self._consts[key] = self.torch.from_numpy(a).to(self.device).to(self.dtype)
+    return t
+
   def stream(self):
     return self.torch.cuda.current_stream().cuda_stream
 
@@ -238,7 +249,7 @@ class DevicePhysics:
     activation / warm start / time; derived arrays refreshed by the caller's forward (reset_context order)."""
     torch = self.torch
     f = self._fields
-    q0 = torch.as_tensor(np.asarray(self.model.qpos0), dtype=self.dtype, device=self.device)[:, None]
+    q0 = self.const(self.model.qpos0)[:, None]
     if mask is None:
       f['qpos'].copy_(q0.expand_as(f['qpos']))
       for n in ('qvel', 'ctrl', 'qacc_warmstart', 'time') + (('act',) if 'act' in f else ()):

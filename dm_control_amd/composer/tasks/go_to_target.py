@@ -114,9 +114,12 @@ class GoToTarget(environment.Task):
       self._gen = torch.Generator(device=physics.device)
       self._gen.manual_seed(int(self._seed))
     u = torch.rand((n, physics.B), generator=self._gen, device=physics.device, dtype=physics.dtype)
-    lo = torch.as_tensor(lo, dtype=physics.dtype, device=physics.device).reshape(-1, 1)
-    hi = torch.as_tensor(hi, dtype=physics.dtype, device=physics.device).reshape(-1, 1)
+    lo, hi = physics.const(lo).reshape(-1, 1), physics.const(hi).reshape(-1, 1)
     return lo + (hi - lo) * u
+
+  def generators(self):
+    """Device RNG streams of the task (registered with a capturing HIP graph)."""
+    return [self._gen] if getattr(self, '_gen', None) is not None else []
 
   def target_position(self, physics):
     return self._target
@@ -126,6 +129,8 @@ class GoToTarget(environment.Task):
     torch = physics.torch
     if getattr(self, '_seed', None) is None:
       self._seed = random_state.randint(2**31 - 1)
+      self._gen = torch.Generator(device=physics.device)
+      self._gen.manual_seed(int(self._seed))
       self._target = torch.zeros((2, physics.B), dtype=physics.dtype, device=physics.device)
       self._failure = torch.zeros(physics.B, dtype=torch.bool, device=physics.device)
       self._reward_steps = torch.zeros(physics.B, dtype=torch.int32, device=physics.device)
@@ -137,7 +142,7 @@ class GoToTarget(environment.Task):
     # initialize_episode_mjcf: target ~ U(arena); initialize_episode: reinitialize_pose (qpos0 of the asset is the
     # upright pose, already restored by the reset) + shift_pose to a uniform arena position (+ optional yaw)
     tgt = self._uniform(physics, -self._arena_half, self._arena_half, 2)
-    self._target = torch.where(m2, tgt, self._target)
+    self._target.copy_(torch.where(m2, tgt, self._target))
     spawn = self._uniform(physics, -self._arena_half, self._arena_half, 2)
     q = physics.field('qpos')
     q[0:2] = torch.where(m2, q[0:2] + spawn, q[0:2])
@@ -150,8 +155,8 @@ class GoToTarget(environment.Task):
                          rot[0]*cur[2] + rot[3]*cur[1], rot[0]*cur[3] + rot[3]*cur[0]])      # rot (x) cur, rot = (w,0,0,z)
       q[3:7] = torch.where(m2, new, cur)
     physics.mark_as_dirty()
-    self._failure = self._failure & ~mask
-    self._reward_steps = torch.where(mask, torch.zeros_like(self._reward_steps), self._reward_steps)
+    self._failure.copy_(self._failure & ~mask)
+    self._reward_steps.copy_(torch.where(mask, torch.zeros_like(self._reward_steps), self._reward_steps))
 
   def before_step(self, physics, action, random_state):
     self.walker.apply_action(physics, action, random_state)
@@ -164,7 +169,7 @@ class GoToTarget(environment.Task):
     ng = self.model.ngeom
     g1, g2 = torch.where(g1 < 0, ng, g1), torch.where(g2 < 0, ng, g2)
     bad = (self._is_nonfoot[g1] & self._is_ground[g2]) | (self._is_ground[g1] & self._is_nonfoot[g2])
-    self._failure = bad.any(dim=0)
+    self._failure.copy_(bad.any(dim=0))
     if self._moving_target:
       move = self._reward_steps >= self._steps_before_moving_target
       if self._target_relative:
@@ -172,8 +177,8 @@ class GoToTarget(environment.Task):
         new = physics.field('xpos')[3*self._root:3*self._root + 2] + self._uniform(physics, [-d, -d], [d, d], 2)
       else:
         new = self._uniform(physics, -self._arena_half, self._arena_half, 2)
-      self._target = torch.where(move[None, :], new, self._target)
-      self._reward_steps = torch.where(move, torch.zeros_like(self._reward_steps), self._reward_steps)
+      self._target.copy_(torch.where(move[None, :], new, self._target))
+      self._reward_steps.copy_(torch.where(move, torch.zeros_like(self._reward_steps), self._reward_steps))
 
   def should_terminate_episode(self, physics):
     return self._failure
@@ -187,7 +192,7 @@ class GoToTarget(environment.Task):
     distance = torch.linalg.norm(self._target - root, dim=0)
     hit = distance < self._distance_tolerance
     if self._moving_target:
-      self._reward_steps = self._reward_steps + hit.to(torch.int32)
+      self._reward_steps += hit.to(torch.int32)
     return hit.to(physics.dtype)
 
   # -- observations --------------------------------------------------------------------------------------

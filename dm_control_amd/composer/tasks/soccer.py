@@ -77,8 +77,8 @@ class PositionDetector(environment.Entity):
     """position_detector.py:149-160 for the masked environments; pos / size: (d, B) tensors."""
     lo, hi = self.bounds(physics)
     m2 = mask[None, :]
-    self._lo_t = physics.torch.where(m2, pos - size, lo)
-    self._hi_t = physics.torch.where(m2, pos + size, hi)
+    lo.copy_(physics.torch.where(m2, pos - size, lo))
+    hi.copy_(physics.torch.where(m2, pos + size, hi))
 
   def _inside(self, physics):
     p = self._task.ball_xpos(physics)
@@ -91,16 +91,16 @@ class PositionDetector(environment.Entity):
     torch = physics.torch
     if self.detected is None:
       self.detected = torch.zeros(physics.B, dtype=torch.bool, device=physics.device)
-    self.detected = self.detected & ~mask
+    self.detected.copy_(self.detected & ~mask)
 
   def before_step(self, physics, random_state):
     # position_detector.py before_step: a retained detection is cleared at the start of the next control step
     if self.retain:
-      self.detected = physics.torch.zeros_like(self.detected)
+      self.detected.zero_()
 
   def after_substep(self, physics, random_state):
     now = self._inside(physics)
-    self.detected = (self.detected | now) if self.retain else now
+    self.detected.copy_((self.detected | now) if self.retain else now)
 
 
 class Soccer2v2(environment.Task):
@@ -141,6 +141,9 @@ class Soccer2v2(environment.Task):
   def entities(self):
     return (self.home_goal, self.away_goal, self.field)
 
+  def generators(self):
+    return [self._gen] if self._gen is not None else []
+
   def make_physics(self, batch_size, device_id=0, precision=32):
     caps = dict(common.DEFAULT_CAPS.get(_ASSET, {}))
     caps.pop('precision', None)
@@ -171,9 +174,9 @@ class Soccer2v2(environment.Task):
     k = 4
     for direction, gx in ((1.0, -sx + gs[0]), (-1.0, sx - gs[0])):
       gpos = torch.stack([gx, z, gs[2]])
-      d3 = torch.tensor([direction, direction, 1.0], dtype=physics.dtype, device=physics.device)[:, None]
+      d3 = physics.const([direction, direction, 1.0])[:, None]
       for pname, unit in _GOALPOSTS.items():
-        u = torch.tensor(unit, dtype=physics.dtype, device=physics.device)
+        u = physics.const(unit)
         frm = u[:3, None] * d3 * gs + gpos
         to = u[3:, None] * d3 * gs + gpos
         half = 0.5 * torch.linalg.norm(to - frm, dim=0)
@@ -194,8 +197,7 @@ class Soccer2v2(environment.Task):
 
   def _uniform(self, physics, lo, hi):
     torch = physics.torch
-    lo = torch.as_tensor(np.asarray(lo, float), dtype=physics.dtype, device=physics.device).reshape(-1, 1)
-    hi = torch.as_tensor(np.asarray(hi, float), dtype=physics.dtype, device=physics.device).reshape(-1, 1)
+    lo, hi = physics.const(lo).reshape(-1, 1), physics.const(hi).reshape(-1, 1)
     u = torch.rand((lo.shape[0], physics.B), generator=self._gen, device=physics.device, dtype=physics.dtype)
     return lo + (hi - lo) * u
 
@@ -214,7 +216,7 @@ class Soccer2v2(environment.Task):
     for k, p in enumerate(_PLAYERS):
       xy = unit()
       pos.append(xy)
-      spot = torch.as_tensor(_SPOTS[k], dtype=physics.dtype, device=physics.device)[:, None]
+      spot = physics.const(_SPOTS[k])[:, None]
       a = self._q[p]
       q[a['root_x']] = torch.where(mask, xy[0] - spot[0], q[a['root_x']])      # slides are relative to the frame
       q[a['root_y']] = torch.where(mask, xy[1] - spot[1], q[a['root_y']])
@@ -233,7 +235,7 @@ class Soccer2v2(environment.Task):
     if self._randomize is not None:
       lo, hi = self._randomize
       size = self._uniform(physics, lo, hi)                    # one ratio per axis (keep_aspect_ratio=False)
-      self._size_t = torch.where(mask[None, :], size, self._size_t)
+      self._size_t.copy_(torch.where(mask[None, :], size, self._size_t))
       self._resize_pitch(physics, self._size_t, mask)
     todo = mask
     for _ in range(4):                 # redraw placements whose entities overlap (initializers.py:96-127)
@@ -242,7 +244,7 @@ class Soccer2v2(environment.Task):
       eye = torch.eye(5, dtype=torch.bool, device=physics.device)[:, :, None]
       close = ((d < 1.5) & ~eye).any(dim=0).any(dim=0)
       todo = todo & close
-    self._prev_action = torch.where(mask[None, None, :], torch.zeros_like(self._prev_action), self._prev_action)
+    self._prev_action.copy_(torch.where(mask[None, None, :], torch.zeros_like(self._prev_action), self._prev_action))
     physics.mark_as_dirty()
 
   def before_step(self, physics, action, random_state):
@@ -253,7 +255,7 @@ class Soccer2v2(environment.Task):
     for k in range(4):
       for j in range(3):
         ctrl[self._ctrl_rows[k][j]] = a[k, j]
-    self._prev_action = a
+    self._prev_action.copy_(a)
     off = self.field.detected
     if off is not None:
       # _throw_in (task.py:128-135): ball back at a shrunk position, at rest

@@ -19,19 +19,24 @@ for name, B, kw in (('cmu_go_to_target', 4096, {}), ('soccer_2v2', 256, {}), ('s
   for t in range(5):
     env.step(acts[t % 16])
   torch.cuda.synchronize()
-  nlast = torch.zeros((), device='cuda', dtype=torch.int64)
-  rsum = torch.zeros((), device='cuda', dtype=torch.float64)
-  t0 = time.perf_counter()
-  for t in range(T):
-    ts = env.step(acts[t % 16])
-    nlast += (ts.step_type == composer.LAST).sum()
-    rsum += ts.reward.sum()
-  torch.cuda.synchronize()
-  dt = time.perf_counter() - t0
-  r = dict(env=name, B=B, kwargs=kw, steps=T, n_sub_steps=env.n_sub_steps, fused=env.fused, seconds=dt,
+  for mode in (('eager', 'graph') if os.environ.get('GRAPH') else ('eager',)):
+   nlast = torch.zeros((), device='cuda', dtype=torch.int64)
+   rsum = torch.zeros((), device='cuda', dtype=torch.float64)
+   if mode == 'graph':
+     env.capture(acts[0])
+   stepfn = env.step_graph if mode == 'graph' else env.step
+   torch.cuda.synchronize()
+   t0 = time.perf_counter()
+   for t in range(T):
+     ts = stepfn(acts[t % 16])
+     nlast += (ts.step_type == composer.LAST).sum()
+     rsum += ts.reward.sum()
+   torch.cuda.synchronize()
+   dt = time.perf_counter() - t0
+   r = dict(env=name, B=B, kwargs=kw, mode=mode, steps=T, n_sub_steps=env.n_sub_steps, fused=env.fused, seconds=dt,
            env_steps_per_s=B * T / dt, physics_steps_per_s=B * T * env.n_sub_steps / dt, episodes_ended=int(nlast),
            reward_sum=float(rsum), warnings=env.physics.field('warning').sum(dim=1).tolist(), info=env.physics.batch.info())
-  print(json.dumps(r), flush=True)
-  out.append(r)
+   print(json.dumps(r), flush=True)
+   out.append(r)
   env.close()
 json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'composer_runs.json'), 'w'), indent=1)

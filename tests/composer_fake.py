@@ -53,6 +53,9 @@ class OracleDevicePhysics:
   def stream(self):
     return None
 
+  def const(self, values):
+    return torch.from_numpy(np.asarray(values, dtype=np.float64))
+
   def mark_as_dirty(self):
     pass
 

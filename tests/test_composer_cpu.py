@@ -287,6 +287,7 @@ def test_soccer_pitch_resize_rows_reproduce_the_compiled_pitch():
   p.torch, p.B, p.dtype, p.device = torch, B, torch.float64, torch.device('cpu')
   eg = torch.from_numpy(np.tile(init[:, None], (1, B))).clone()
   p.field = lambda name: eg
+  p.const = lambda v: torch.from_numpy(np.asarray(v, dtype=np.float64))
   mask = torch.tensor([True, True, False])
   size = torch.tensor([[40.0, 32.0, 48.0], [30.0, 24.0, 36.0]], dtype=torch.float64)
   task._resize_pitch(p, size, mask)

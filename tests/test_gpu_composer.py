@@ -283,3 +283,38 @@ def test_soccer_randomized_pitch_on_gpu():
   new = task._size_t.cpu().numpy()
   assert (new[:, 5:] == old[:, 5:]).all() and (new[:, :5] != old[:, :5]).any()
   env.close()
+
+
+@pytest.mark.parametrize('name,shape', [('soccer_2v2', (4, 3)), ('cmu_go_to_target', None)])
+def test_environment_step_as_hip_graph(name, shape):
+  """Environment.capture / step_graph: the whole control step (hooks, physics launches, reward, termination, observation
+  gather) replayed as ONE HIP graph produces the same time steps as the eager loop, including auto-resets."""
+  import torch
+  from dm_control_amd import composer
+  B = 32
+  envs = [composer.make(name, B, random_state=9) for _ in range(2)]
+  m = envs[0].task.model
+  ashape = (B,) + (shape if shape else (m.nu,))
+  gen = torch.Generator(device='cuda').manual_seed(1)
+  acts = torch.rand((40,) + ashape, device='cuda', generator=gen) * 2 - 1
+  eager, graph = envs
+  eager.reset(); graph.reset()
+  for t in range(2):                       # the warm-up steps capture() takes, mirrored on the eager environment
+    eager.step(acts[0])
+  graph.capture(acts[0])                   # (capturing records the step, it does not run it)
+  l0 = graph.launches
+  n_last = 0
+  for t in range(1, 40):
+    a = eager.step(acts[t])
+    b = graph.step_graph(acts[t])
+    torch.cuda.synchronize()
+    assert torch.equal(a.step_type, b.step_type), t
+    assert torch.equal(a.reward, b.reward) and torch.equal(a.discount, b.discount)
+    for k in a.observation:
+      assert torch.equal(a.observation[k], b.observation[k]), (k, t)
+    n_last += int((a.step_type == composer.LAST).sum())
+  assert graph.launches == l0              # no Python-side launch happened during the replays
+  if name == 'cmu_go_to_target':
+    assert n_last > 0                      # falls happened and the graph re-initialised those environments itself
+  for e in envs:
+    e.close()
