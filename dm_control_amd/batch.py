@@ -64,11 +64,12 @@ class BatchedPhysics:
 
   # -- info ---------------------------------------------------------------------
   def info(self):
-    a = np.zeros(18, dtype=np.int32)
+    a = np.zeros(20, dtype=np.int32)
     _native.check(_native.lib().dmc_batch_info(self._ptr, a.ctypes.data))
     keys = ['B', 'precision', 'lanes_per_env', 'waves_per_block', 'envs_per_block',
             'lds_bytes_per_block', 'grid', 'nconmax', 'njmax', 'env_scratch_bytes', 'static_id',
-            'jac_kmax', 'table_lds_bytes', 'envs_per_cu', 'njdense', 'njcon', 'stash', 'stash_bytes_per_env']
+            'jac_kmax', 'table_lds_bytes', 'envs_per_cu', 'njdense', 'njcon', 'stash', 'stash_bytes_per_env',
+            'global_scratch_bytes_per_env', 'work_queue']
     return dict(zip(keys, (int(x) for x in a)))
 
   def _rows(self, name):

@@ -67,6 +67,9 @@ struct dmc_batch {
   void* d_stash_r; int* d_stash_i; int stash_epoch; int stash_on;
   int xfrc_on;         // xfrc_applied was written / bound / exposed: the kernel reads it from now on
   void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
+  int* d_work;         // work queue of launches with a resident-only grid: {next item, finished waves} (StepIO::work)
+  int ncu;             // compute units of the device
+  void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
 
@@ -90,7 +93,7 @@ static Field* find_field(dmc_batch* b, const char* name) {
 static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   const StepLayout& L = b->tb.L;
   const size_t tables = (size_t)(b->precision == 64 ? opts_lds_bytes<double>() : opts_lds_bytes<float>()) +
-                        (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * b->elem + (L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0);
+                        (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * b->elem + (L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0);
   const size_t env_bytes = (size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int);
   const size_t lds_cu = 160 * 1024;
   // automatic: small models (cheetah, nv = 9) leave most of a 64-lane group idle, so
@@ -98,11 +101,13 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   int lpe = lanes_per_env ? lanes_per_env : (b->tb.L.d.nv <= 12 ? 32 : 64);
   if (lpe != 64 && lpe != 32 && lpe != 16) return fail("lanes_per_env must be 64, 32 or 16");
   const int epw = 64 / lpe;
-  int best_w = 0; long best_score = -1;
+  int best_w = 0; long best_score = -1, best_blocks = 1;
   // The kernels are built for 2 waves per SIMD (256 VGPRs): at most 8 resident waves per CU whatever the LDS would
   // allow.  Workgroups of more than 4 waves were tried (512 threads: humanoid 7 environments in one workgroup instead
   // of 2 x 3) and measured slower (1.20 M vs 1.29 M env-steps/s), so 4 waves stays the largest shape.
+  const int force_w = getenv("DMC_WAVES") ? atoi(getenv("DMC_WAVES")) : 0;      // tuning studies only
   for (int w = 4; w >= 1; w--) {
+    if (force_w && w != force_w) continue;
     const size_t bytes = tables + (size_t)w * epw * env_bytes;
     if (bytes > lds_cu) continue;
     long blocks = (long)(lds_cu / bytes);
@@ -111,19 +116,24 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
     const long score = blocks * w * epw;            // resident envs per CU
     // fewer waves per workgroup only for a clear gain in residency: 4-wave groups give grids that divide the
     // batch evenly (cartpole, B = 4096: 3-wave groups = 683 workgroups ran 1.8x slower than 4-wave = 512)
-    if (best_score < 0 || score * 100 > best_score * 115) { best_score = score; best_w = w; }
+    if (best_score < 0 || score * 100 > best_score * 115) { best_score = score; best_w = w; best_blocks = blocks; }
   }
   // a batch too small to fill the chip (soccer: 256 environments per GPU): spread it over as many CUs as possible --
   // the smallest workgroup that still holds the batch in one round (one wave alone on a CU shares nothing)
   if (best_w) {
     const long cus = 256, need = ((long)b->B + cus * epw - 1) / (cus * epw);      // waves per CU to hold B at once
-    if (need < best_w) best_w = (int)std::max(1L, need);
+    if (need < best_w && !force_w) { best_w = (int)std::max(1L, need); best_blocks = std::min(8L / best_w, (long)(lds_cu / (tables + (size_t)best_w * epw * env_bytes))); }
   }
   if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
   LaunchGeom& g = b->geom;
   g.lpe = lpe; g.waves = best_w; g.envs_per_block = best_w * epw;
   g.lds_bytes = (int)(tables + (size_t)g.envs_per_block * env_bytes);
   g.grid = (b->B + g.envs_per_block - 1) / g.envs_per_block;
+  g.blocks_per_cu = (int)std::max(1L, best_blocks);
+  // a batch of more workgroups than the chip holds at once: launch the resident ones, their waves claim the rest
+  // from the work queue as they finish (step_kernel_body)
+  g.queue = 0;
+  if (g.grid > b->ncu * g.blocks_per_cu && !getenv("DMC_NO_QUEUE")) { g.grid = b->ncu * g.blocks_per_cu; g.queue = 1; }
   g.static_id = -1;
 #if DMC_NSTATIC > 0
   {
@@ -168,9 +178,10 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
   const StepLayout& L = b->tb.L;
   const StepDims& d = L.d;
@@ -181,10 +192,21 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   if (e == hipSuccess) e = hipMemcpy(b->d_layout, &L, sizeof(StepLayout), hipMemcpyHostToDevice);
   if (e != hipSuccess) { delete b; return fail(std::string("hipMalloc: ") + hipGetErrorString(e), -2); }
   if (upload_tables(b)) { delete b; return -2; }
+  b->tb.opts.g_mr = b->d_mr;
   if (d.nslip) {
     e = hipMalloc(&b->d_ns_A, (size_t)b->B * d.nslip * d.nslip * b->elem);
     if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc noslip matrix: ") + hipGetErrorString(e), -2); }
     b->tb.opts.ns_A = b->d_ns_A;
+  }
+  e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
+  if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
+  if (L.n_gs) {
+    const size_t bytes = (size_t)b->B * L.n_gs * b->elem;
+    e = hipMalloc(&b->d_gscr, bytes);
+    if (e == hipSuccess) e = hipMemset(b->d_gscr, 0, bytes);
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc global scratch: ") + hipGetErrorString(e), -2); }
+    b->tb.opts.gscr = b->d_gscr;
   }
   struct Spec { const char* name; int rows; bool is_int; };
   const int nb = d.nbody;
@@ -233,6 +255,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_stash_i) (void)hipFree(b->d_stash_i);
   if (b->d_eg_slot) (void)hipFree(b->d_eg_slot);
   if (b->d_ns_A) (void)hipFree(b->d_ns_A);
+  if (b->d_gscr) (void)hipFree(b->d_gscr);
+  if (b->d_work) (void)hipFree(b->d_work);
   delete b;
 }
 
@@ -252,6 +276,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->ncon = (int*)P("ncon"); io->nefc = (int*)P("nefc"); io->solver_iter = (int*)P("solver_iter");
   io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
   io->env_mode = (const int*)P("env_mode");
+  io->work = b->geom.queue ? b->d_work : nullptr;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
 }
@@ -708,6 +733,8 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[12] = b->geom.lds_bytes - b->geom.envs_per_block * info[9];
   { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 8) blocks = 8 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }
   info[14] = L.d.njdense; info[15] = L.d.njcon; info[16] = b->stash_on; info[17] = (int)((size_t)L.n_keep * b->elem + (size_t)(L.n_si + 4) * sizeof(int));
+  info[18] = (int)((size_t)L.n_gs * b->elem);
+  info[19] = b->geom.queue;
   return 0;
 }
 
@@ -737,9 +764,9 @@ extern "C" int dmc_batch_debug_enable(dmc_batch* b, int n) {
   if (n <= 0) return 0;
   if (n > b->B) n = b->B;
   const StepLayout& L = b->tb.L;
-  HIP_TRY(hipMalloc(&b->d_debug, (size_t)L.n_sr * n * b->elem));
+  HIP_TRY(hipMalloc(&b->d_debug, (size_t)(L.n_sr + L.n_gs) * n * b->elem));
   HIP_TRY(hipMalloc((void**)&b->d_debug_i, (size_t)L.n_si * n * sizeof(int)));
-  HIP_TRY(hipMemset(b->d_debug, 0, (size_t)L.n_sr * n * b->elem));
+  HIP_TRY(hipMemset(b->d_debug, 0, (size_t)(L.n_sr + L.n_gs) * n * b->elem));
   HIP_TRY(hipMemset(b->d_debug_i, 0, (size_t)L.n_si * n * sizeof(int)));
   b->ndebug = n;
   return 0;

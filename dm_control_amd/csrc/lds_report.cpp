@@ -29,15 +29,16 @@ int main(int argc, char** argv) {
   const StepLayout& L = tb.L;
   const StepDims& d = L.d;
   printf("{\"name\": \"%s\", \"nq\": %d, \"nv\": %d, \"nu\": %d, \"nbody\": %d, \"njnt\": %d, \"ngeom\": %d, \"npair\": %d, \"nM\": %d, \"ntri\": %d, "
-         "\"nconmax\": %d, \"njmax\": %d, \"nslip\": %d, \"max_contacts\": %d, \"max_rows\": %d, \"n_mi\": %d, \"n_mr\": %d, \"n_sr\": %d, \"n_si\": %d,\n",
+         "\"nconmax\": %d, \"njmax\": %d, \"nslip\": %d, \"max_contacts\": %d, \"max_rows\": %d, \"n_mi\": %d, \"n_mr\": %d, \"n_mr_lds\": %d, \"n_gs\": %d, \"n_sr\": %d, \"n_si\": %d,\n",
          argv[1], d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.npair, d.nM, d.ntri, d.nconmax, d.njmax, d.nslip, tb.max_contacts, tb.max_rows,
-         L.n_mi, L.n_mr, L.n_sr, L.n_si);
+         L.n_mi, L.n_mr, L.n_mr_lds, L.n_gs, L.n_sr, L.n_si);
   printf(" \"int_tables\": {");
   { bool first = true;
 #define X(n, c) { int cnt = (c); if (cnt) { printf("%s\"%s\": %d", first ? "" : ", ", #n, cnt); first = false; } }
     STEP_MODEL_INT_TABLES(X)
     printf("},\n \"real_tables\": {"); first = true;
-    STEP_MODEL_REAL_TABLES(X)
+    STEP_MODEL_HOT_REAL_TABLES(X)
+    if (d.jglobal < 2) { STEP_MODEL_COLD_REAL_TABLES(X) }
     printf("},\n \"scratch_real\": {"); first = true;
     STEP_SCRATCH_REAL(X)
     printf("},\n \"ovl_pos\": {"); first = true;

@@ -31,6 +31,7 @@
 #define DMC_DEV inline
 #define DMC_FN inline
 #define DMC_LDS
+#define DMC_GLB
 #define DMC_WSYNC() ((void)0)
 #else
 #define DMC_DEV __device__ __forceinline__
@@ -38,6 +39,7 @@
 // explicitly LDS-qualified pointers so that they still compile to ds_* ops
 #define DMC_FN __device__ __attribute__((noinline))
 #define DMC_LDS __attribute__((address_space(3)))
+#define DMC_GLB __attribute__((address_space(1)))   // the per-env global scratch: global_load / global_store, not flat
 #define DMC_WSYNC()                                             \
   do {                                                          \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      \
@@ -82,6 +84,9 @@ struct StepIO {
   // per-env override of a step launch: 0 = as launched, 1 = mj_forward with actuation disabled instead (an
   // environment that was just re-initialised: reset_context's after_reset), 2 = leave the environment untouched
   const int* env_mode;
+  // Work queue of a launch whose grid is smaller than the batch (resident workgroups only): work[0] hands out the
+  // next wave-sized item, work[1] counts finished waves (the last one re-arms both).  Null: one item per wave.
+  int* work;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
@@ -487,6 +492,7 @@ DMC_FN DMC_LSVEC(T) ls_eval_lds(T a, const DMC_LDS T* jar_, const DMC_LDS T* jv_
 // build-time constant (model-specialised kernels, see step_kernel.hip.h)
 struct DynLayoutSrc {
   static constexpr int kNV = 0;   // nv only known at run time
+  static constexpr int kJGlobal = -1;   // so is StepDims::jglobal
   const StepLayout* p;
   DMC_DEV const StepLayout& get() const { return *p; }
 };
@@ -514,7 +520,7 @@ struct StepCore {
         // small models stage the cold tables in LDS right behind the real tables (step_kernel.hip.h): derive the
         // pointer from `mr` so that the loads compile to LDS reads
 #ifndef DMC_HOST_EMU
-        gc(ls_.get().d.coldlds ? reinterpret_cast<const int*>(mr_ + ls_.get().n_mr) : gc_),
+        gc(ls_.get().d.coldlds ? reinterpret_cast<const int*>(mr_ + ls_.get().n_mr_lds) : gc_),
 #else
         gc(gc_),
 #endif
@@ -522,11 +528,22 @@ struct StepCore {
 
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
+#define MRC(n) (mrc() + L.mr_##n)   // a cold real table (STEP_MODEL_COLD_REAL_TABLES)
 #define GC(n) (gc + L.mc_##n)
 #define S(n) (s + L.s_##n)
 #define SI(n) (si + L.si_##n)
 #define FOR_LANES(i, n) for (int i = lane; i < (n); i += LPE)
 
+  // Cold real tables: in LDS with the others, or (large models) in global memory.  The model-specialised kernels know
+  // which at compile time; the round trip through the global address space lets the compiler emit global_load.
+  DMC_DEV const T* mrc() const {
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kJGlobal == 2) return (const T*)(const DMC_GLB T*)o.g_mr;
+    else if constexpr (LS::kJGlobal >= 0) return mr;
+    else
+#endif
+    return L.d.jglobal == 2 ? (const T*)o.g_mr : mr;
+  }
   // Opaque copy of an env index: stops the compiler from forming HBM addresses long before
   // they are used and carrying them across the out-of-line stage calls (callee-saved VGPRs,
   // spilled to scratch once there are too many).
@@ -653,7 +670,7 @@ struct StepCore {
         io.contact_geom2[(size_t)c*B + env] = live ? con_g2(c) : -1;
         io.contact_dist[(size_t)c*B + env] = live ? S(con_dist)[c] : (T)0;
         for (int k = 0; k < 3; k++) io.contact_pos[(size_t)(3*c + k)*B + env] = live ? S(con_pos)[3*c + k] : (T)0;
-        for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? S(con_frame)[9*c + k] : (T)0;
+        for (int k = 0; k < 9; k++) io.contact_frame[(size_t)(9*c + k)*B + env] = live ? conF()[9*c + k] : (T)0;
         T lf[6] = {0, 0, 0, 0, 0, 0};
         if (live) contact_force_local(c, lf);
         for (int k = 0; k < 6; k++) io.contact_force[(size_t)(6*c + k)*B + env] = lf[k];
@@ -666,6 +683,7 @@ struct StepCore {
     if (!io.debug || env >= io.ndebug) return;
     FOR_LANES(i, L.n_sr) io.debug[(size_t)i*io.ndebug + env] = s[i];
     FOR_LANES(i, L.n_si) io.debug_i[(size_t)i*io.ndebug + env] = si[i];
+    if (L.n_gs) { const T* g = gscr(); FOR_LANES(i, L.n_gs) io.debug[(size_t)(L.n_sr + i)*io.ndebug + env] = g[i]; }
   }
 
   // ---- kinematics (mj_kinematics) --------------------------------------------
@@ -687,8 +705,8 @@ struct StepCore {
       normalize4(q);
       for (int k = 0; k < 3; k++) { S(xanchor)[3*jntadr + k] = p[k]; S(xaxis)[3*jntadr + k] = MR(jnt_axis)[3*jntadr + k]; }
     } else {
-      for (int k = 0; k < 3; k++) p[k] = MR(body_pos)[3*i + k];
-      for (int k = 0; k < 4; k++) q[k] = MR(body_quat)[4*i + k];
+      for (int k = 0; k < 3; k++) p[k] = MRC(body_pos)[3*i + k];
+      for (int k = 0; k < 4; k++) q[k] = MRC(body_quat)[4*i + k];
       for (int j = jntadr; j < jntadr + jntnum; j++) {
         const int qa = MI(jnt_qposadr)[j], t = MI(jnt_type)[j];
         T R[9], axis[3], anchor[3];
@@ -749,9 +767,9 @@ struct StepCore {
     }
     for (int i = 1 + lane; i < L.d.nbody; i += LPE) {
       T v[3], q[4], m[9];
-      mul_mat_vec3(v, S(xmat) + 9*i, MR(body_ipos) + 3*i);
+      mul_mat_vec3(v, S(xmat) + 9*i, MRC(body_ipos) + 3*i);
       for (int k = 0; k < 3; k++) S(xipos)[3*i + k] = S(xpos)[3*i + k] + v[k];
-      mul_quat(q, S(xquat) + 4*i, MR(body_iquat) + 4*i);
+      mul_quat(q, S(xquat) + 4*i, MRC(body_iquat) + 4*i);
       quat2mat(m, q);
       for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = m[k];
     }
@@ -764,9 +782,9 @@ struct StepCore {
         continue;
       }
       const int b = MI(geom_bodyid)[g]; T v[3], q[4], m[9];
-      mul_mat_vec3(v, S(xmat) + 9*b, MR(geom_pos) + 3*g);
+      mul_mat_vec3(v, S(xmat) + 9*b, MRC(geom_pos) + 3*g);
       for (int k = 0; k < 3; k++) S(geom_xpos)[3*g + k] = S(xpos)[3*b + k] + v[k];
-      mul_quat(q, S(xquat) + 4*b, MR(geom_quat) + 4*g);
+      mul_quat(q, S(xquat) + 4*b, MRC(geom_quat) + 4*g);
       quat2mat(m, q);
       for (int k = 0; k < 9; k++) S(geom_xmat)[9*g + k] = m[k];
     }
@@ -797,7 +815,7 @@ struct StepCore {
     for (int i = 1 + lane; i < L.d.nbody; i += LPE) {
       T off[3], ci[10]; const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
       for (int k = 0; k < 3; k++) off[k] = S(xipos)[3*i + k] - rc[k];
-      inert_com(ci, MR(body_inertia) + 3*i, S(ximat) + 9*i, off, MR(body_mass)[i]);
+      inert_com(ci, MRC(body_inertia) + 3*i, S(ximat) + 9*i, off, MR(body_mass)[i]);
       for (int k = 0; k < 10; k++) S(cinert)[10*i + k] = ci[k];
     }
     FOR_LANES(j, L.d.njnt) {
@@ -842,6 +860,9 @@ struct StepCore {
 #endif
     chol_solve_lds<T, LPE>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, n, lane);
   }
+  // ---- per-environment global scratch (StepOpts::gscr, StepLayout::gs_*) -------------------------
+  DMC_DEV T* gscr() const { return (T*)o.gscr + (size_t)SI(imisc)[IM_ENV] * L.n_gs; }
+  DMC_DEV T* gLM() const { return gscr() + L.gs_LM; }
 
   // ---- CRB mass matrix + factor (mj_crb, mj_factorM) ----------------------------
   DMC_DEV void crb_mass_matrix() {
@@ -870,25 +891,29 @@ struct StepCore {
       const int pk = GC(mpair)[p], i = pk & 0xffff, j = pk >> 16;
       T v = dot_n(S(cdof) + 6*j, S(mbuf) + 6*i, 6);
       if (i == j) v += MR(dof_armature)[i];
-      if (L.d.msparse) S(qM)[p] = v; else { S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v; }
+      if (L.d.msparse) qMs()[p] = v; else { S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v; }
     }
     DMC_WSYNC();
     factor_M(false);
   }
-  // ---- sparse mass matrix helpers ------------------------------------------------
-  // M(i, j) for i >= j: entry k of row i is the k-th dof on the way from i to the root
-  DMC_DEV int anc_above(int i, int j) const {   // ancestors-or-self of i with index > j
-    const unsigned lo = (unsigned)MI(dof_anc_lo)[i];
-    if (L.d.nv <= 32) return j >= 31 ? 0 : __builtin_popcount(lo >> (j + 1));
-    const unsigned hi = (unsigned)MI(dof_anc_hi)[i];
-    if (j < 31) return __builtin_popcount(lo >> (j + 1)) + __builtin_popcount(hi);
-    if (j == 31) return __builtin_popcount(hi);
-    return j >= 63 ? 0 : __builtin_popcount(hi >> (j - 31));
+  // contact frames (9 reals per contact): LDS, or the global scratch of a large model
+  DMC_DEV T* conF() const {
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kJGlobal == 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_cf);
+    else if constexpr (LS::kJGlobal >= 0) return S(con_frame);
+    else
+#endif
+    return L.d.jglobal == 2 ? gscr() + L.gs_cf : S(con_frame);
   }
-  DMC_DEV T M_at(int i, int j) const {
-    if (!L.d.msparse) return S(qM)[i*L.d.nv + j];
-    if (!dof_in_chain(i, j)) return 0;
-    return S(qM)[MI(dof_madr)[i] + anc_above(i, j)];
+  // ---- sparse mass matrix ------------------------------------------------------------
+  // the nM tree-sparse entries (msparse models): LDS, or the global scratch of a large model
+  DMC_DEV T* qMs() const {
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kJGlobal == 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_M);
+    else if constexpr (LS::kJGlobal >= 0) return S(qM);
+    else
+#endif
+    return L.d.jglobal == 2 ? gscr() + L.gs_M : S(qM);
   }
   // qLH <- M (+ diag), packed by columns: zero fill, then the nonzeros (i, j) of the (i, j) list; the list is
   // read from global memory one trip ahead of its use
@@ -900,7 +925,7 @@ struct StepCore {
     for (int p = lane; p < nM; p += LPE) {
       const int i = pk & 0xffff, j = pk >> 16;
       if (p + LPE < nM) pk = GC(mpair)[p + LPE];
-      T v = L.d.msparse ? S(qM)[p] : S(qM)[i*nv + j];
+      T v = L.d.msparse ? qMs()[p] : S(qM)[i*nv + j];
       if (diag && i == j) v += diag_scale*diag[i];
       dst[tri_at(i, j, nv)] = v;
     }
@@ -908,11 +933,17 @@ struct StepCore {
   }
   // qLH <- M (+ timestep * damping on the diagonal), then its Cholesky factor
   // the factor of M lives in qLM where a model runs noslip (it is needed again after H's factor took qLH), else in qLH
-  DMC_DEV T* M_factor() { return S(qLM); }      // aliases qLH when the model does not run noslip (step_layout_build)
+  // Large noslip models (jglobal): factored in qLH, where mj_fwdAcceleration still finds it, and copied to the global
+  // scratch, from where the noslip pass brings it back once H's factor is done with qLH.
+  DMC_DEV T* M_factor() { return S(qLM); }      // aliases qLH when the model does not run noslip or keeps the copy in global memory
   DMC_DEV void factor_M(bool with_damping) {
     T* dst = with_damping ? S(qLH) : M_factor();
     scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
     chol_factor_inplace(dst, L.d.nv);
+    if (!with_damping && L.d.jglobal && L.d.nslip) {
+      DMC_GLB T* g = (DMC_GLB T*)gLM();
+      FOR_LANES(i, L.d.ntri) g[i] = dst[i];
+    }
   }
 
   // ---- collision (mj_collision over the static candidate pair list) -------------
@@ -1458,7 +1489,7 @@ struct StepCore {
         if (has_tang) cross3(f + 6, f, f + 3); else make_frame(f);
         S(con_dist)[c] = hi.dist;
         for (int k = 0; k < 3; k++) S(con_pos)[3*c + k] = hi.pos[k];
-        for (int k = 0; k < 9; k++) S(con_frame)[9*c + k] = f[k];
+        for (int k = 0; k < 9; k++) conF()[9*c + k] = f[k];
         SI(con_geom)[c] = pgeom; SI(con_info)[c] = pinfo;
         SI(con_efc)[c] = -1;
       }
@@ -1551,6 +1582,13 @@ struct StepCore {
   // the one nonzero of a dof-friction / joint-limit row
   DMC_DEV int simple_dof(int tid) const { return EFC_TYPE(tid) == EFC_FRICTION ? EFC_ID(tid) : (EFC_ID(tid) >> 1); }
   DMC_DEV T simple_sign(int tid) const { return (EFC_TYPE(tid) == EFC_LIMIT && (EFC_ID(tid) & 1)) ? (T)-1 : (T)1; }
+  // the compressed contact rows: LDS, or the global scratch of a large model.  Model-specialised kernels know which
+  // at compile time and get an address-space-qualified pointer (ds_* or global_* instead of flat_* accesses).
+  DMC_DEV auto Jc() const {
+    if constexpr (LS::kJGlobal >= 1) return (DMC_GLB T*)(gscr() + L.gs_Jc);
+    else if constexpr (LS::kJGlobal == 0) return (DMC_LDS T*)S(efc_Jc);
+    else return L.d.jglobal ? gscr() + L.gs_Jc : S(efc_Jc);
+  }
   DMC_DEV const T* dense_row(int r, const RowMap& rm) const { return S(efc_Jd) + (r < rm.s0 ? r : rm.s0 + (r - rm.tl0))*L.d.nv; }
   DMC_DEV const unsigned char* con_dof_list(int c) const { return (const unsigned char*)(SI(con_dofs) + c*L.d.kwords); }
   DMC_DEV int con_ndof(int c) const { return __builtin_popcount(con_mask_lo(c)) + (L.d.nv > 32 ? __builtin_popcount(con_mask_hi(c)) : 0); }
@@ -1572,7 +1610,7 @@ struct StepCore {
       // entry k of the row belongs to dof con_dofs[c][k]; the loop runs to the compile-time bound kmax in the
       // model-specialised kernels, so all its loads are in flight together
       const int c = EFC_ID(SI(efc_tid)[r]);
-      const T* jr = S(efc_Jc) + (r - rm.c0)*L.d.kmax;
+      const auto jr = Jc() + (r - rm.c0)*L.d.kmax;
       const unsigned char* dofs = con_dof_list(c);
       const int kc = con_ndof(c);
       T acc = 0;
@@ -1587,7 +1625,7 @@ struct StepCore {
     if (r >= rm.c0) {
       const int c = EFC_ID(SI(efc_tid)[r]);
       const int k = mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
-      return k < 0 ? (T)0 : S(efc_Jc)[(r - rm.c0)*L.d.kmax + k];
+      return k < 0 ? (T)0 : Jc()[(r - rm.c0)*L.d.kmax + k];
     }
     if (r >= rm.s0 && r < rm.tl0) { const int tid = SI(efc_tid)[r]; return simple_dof(tid) == dd ? simple_sign(tid) : (T)0; }
     return dense_row(r, rm)[dd];
@@ -1678,8 +1716,8 @@ struct StepCore {
         const int t = MI(jnt_type)[j];
         if (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE) {
           const T value = S(qpos)[MI(jnt_qposadr)[j]];
-          margin = MR(jnt_margin)[j];
-          d_lo = -(MR(jnt_range)[2*j] - value); d_hi = MR(jnt_range)[2*j + 1] - value;
+          margin = MRC(jnt_margin)[j];
+          d_lo = -(MRC(jnt_range)[2*j] - value); d_hi = MRC(jnt_range)[2*j + 1] - value;
           act_lo = d_lo < margin; act_hi = d_hi < margin;
         }
       }
@@ -1761,6 +1799,7 @@ struct StepCore {
     if (lane == 0) { SI(imisc)[IM_NEFC] = nefc; SI(imisc)[IM_ROW_S0] = row_s0; SI(imisc)[IM_ROW_TL0] = row_tl0; SI(imisc)[IM_ROW_C0] = nefc_lim; }
     DMC_WSYNC();
     const RowMap rm = {row_s0, row_tl0, nefc_lim};
+    const auto Jc_base = Jc();
     // contact Jacobian entries: item = (contact, dof); dofs outside the contact's mask are skipped
     for (int idx = lane; idx < ncon*nv; idx += LPE) {
       const int c = idx / nv, dd = idx - c*nv;
@@ -1788,18 +1827,18 @@ struct StepCore {
           for (int k = 0; k < 3; k++) { jr2[k] = cd[k]; jp2[k] = cd[3 + k] + tmp[k]; }
         }
         for (int k = 0; k < 3; k++) { dp[k] = jp2[k] - jp1[k]; dr[k] = jr2[k] - jr1[k]; }
-        const T* fr = S(con_frame) + 9*c;
+        const T* fr = conF() + 9*c;
         for (int a = 0; a < 3; a++) { jac[a] = dot3(fr + 3*a, dp); jac[3 + a] = dot3(fr + 3*a, dr); }
       }
-      T* Jc = S(efc_Jc) + (r0 - nefc_lim)*L.d.kmax + slot;
+      const auto Jw = Jc_base + (r0 - nefc_lim)*L.d.kmax + slot;
       const int K = L.d.kmax;
       ((unsigned char*)(SI(con_dofs) + c*L.d.kwords))[slot] = (unsigned char)dd;
-      if (dim == 1) Jc[0] = jac[0];
-      else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jc[k*K] = jac[k];
+      if (dim == 1) Jw[0] = jac[0];
+      else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jw[k*K] = jac[k];
       else for (int k = 1; k < dim; k++) {
         const T f = MR(prm_friction)[3*con_prm(c) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
-        Jc[2*(k - 1)*K] = jac[0] + f*jac[k];
-        Jc[(2*(k - 1) + 1)*K] = jac[0] + (-f)*jac[k];
+        Jw[2*(k - 1)*K] = jac[0] + f*jac[k];
+        Jw[(2*(k - 1) + 1)*K] = jac[0] + (-f)*jac[k];
       }
     }
     DMC_WSYNC();
@@ -1826,7 +1865,7 @@ struct StepCore {
         dA = MR(dof_invweight0)[id];
       } else if (type == EFC_LIMIT) {
         const int jn = MI(dof_jntid)[id >> 1];
-        solref = MR(jnt_solref) + 2*jn; solimp = MR(jnt_solimp) + 5*jn;
+        solref = MRC(jnt_solref) + 2*jn; solimp = MRC(jnt_solimp) + 5*jn;
         dA = MR(dof_invweight0)[id >> 1];
       } else if (type == EFC_TENDON_LIMIT) {
         solref = MR(tendon_solref_lim) + 2*id; solimp = MR(tendon_solimp_lim) + 5*id;
@@ -1926,12 +1965,12 @@ struct StepCore {
       T wr[6] = {0, 0, 0, 0, 0, 0};
       const T mass = MR(body_mass)[b];
       if (b > 0 && mass >= (T)DMC_MINVAL) {
-        const T* I = MR(body_inertia) + 3*b;
+        const T* I = MRC(body_inertia) + 3*b;
         const T box[3] = {t_sqrt(t_max((T)DMC_MINVAL, I[1] + I[2] - I[0]) / mass * (T)6),
                           t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[2] - I[1]) / mass * (T)6),
                           t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[1] - I[2]) / mass * (T)6)};
         T q[4], im[9], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-        mul_quat(q, S(xquat) + 4*b, MR(body_iquat) + 4*b);
+        mul_quat(q, S(xquat) + 4*b, MRC(body_iquat) + 4*b);
         quat2mat(im, q);
         object_velocity(b, S(xipos) + 3*b, im, lvel);
         const T pi = (T)3.14159265358979323846;
@@ -1973,7 +2012,7 @@ struct StepCore {
     FOR_LANES(i, nv) {
       T f = 0;
       const int j = MI(dof_jntid)[i], t = MI(jnt_type)[j];
-      const T k = MR(jnt_stiffness)[j];
+      const T k = MRC(jnt_stiffness)[j];
       if (!(o.disableflags & DMC_DSBL_SPRING) && k != 0 && (t == DMC_JNT_SLIDE || t == DMC_JNT_HINGE)) {
         const int qa = MI(jnt_qposadr)[j];
         f -= k * (S(qpos)[qa] - MR(qpos_spring)[qa]);
@@ -2086,7 +2125,7 @@ struct StepCore {
         if (b1 != b && b2 != b) continue;
         T lf[6], gf[3], gt[3], dif[3], t[3];
         contact_force_local(c, lf);
-        mul_matT_vec3(gf, S(con_frame) + 9*c, lf); mul_matT_vec3(gt, S(con_frame) + 9*c, lf + 3);
+        mul_matT_vec3(gf, conF() + 9*c, lf); mul_matT_vec3(gt, conF() + 9*c, lf + 3);
         const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
         for (int k = 0; k < 3; k++) dif[k] = S(con_pos)[3*c + k] - rc[k];
         cross3(t, dif, gf);
@@ -2275,7 +2314,7 @@ struct StepCore {
           if (b1 != body && b2 != body) continue;
           T lf[6]; contact_force_local(c, lf);
           if (lf[0] <= 0) continue;
-          const T* fr = S(con_frame) + 9*c;
+          const T* fr = conF() + 9*c;
           T ray[3] = {fr[0]*lf[0], fr[1]*lf[0], fr[2]*lf[0]};
           normalize3(ray);
           if (b2 == body) { ray[0] = -ray[0]; ray[1] = -ray[1]; ray[2] = -ray[2]; }
@@ -2321,7 +2360,7 @@ struct StepCore {
           // selecting between a local array and an LDS array through a pointer pins it in scratch)
           T q[4], e[3] = {c == 0 ? (T)1 : (T)0, c == 1 ? (T)1 : (T)0, c == 2 ? (T)1 : (T)0}, col[3];
           if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
-          else mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id);
+          else mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
           rot_vec_quat(col, e, q);
           out[0] = col[0]; out[1] = col[1]; out[2] = col[2];
         } else {
@@ -2361,8 +2400,8 @@ struct StepCore {
         const int ot = MI(sensor_objtype)[i];
         T q[4];
         if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
-        else if (ot == DMC_OBJ_GEOM) mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[id], MR(geom_quat) + 4*id);
-        else if (ot == DMC_OBJ_BODY) mul_quat(q, S(xquat) + 4*id, MR(body_iquat) + 4*id);
+        else if (ot == DMC_OBJ_GEOM) mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[id], MRC(geom_quat) + 4*id);
+        else if (ot == DMC_OBJ_BODY) mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
         else for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*id + k];
         for (int k = 0; k < 4; k++) out[k] = q[k];
       }
@@ -2421,9 +2460,9 @@ struct StepCore {
       T ctrl = S(ctrl)[i];
       const int fl = MI(act_flags)[i];
       if ((fl & ACTF_CTRLLIMITED) && !(o.disableflags & DMC_DSBL_CLAMPCTRL))
-        ctrl = t_max(MR(act_ctrlrange)[2*i], t_min(MR(act_ctrlrange)[2*i + 1], ctrl));
-      const T* gp = MR(act_gainprm) + 3*i; const T* bp = MR(act_biasprm) + 3*i;
-      const T gear = MR(act_gear)[i];
+        ctrl = t_max(MRC(act_ctrlrange)[2*i], t_min(MRC(act_ctrlrange)[2*i + 1], ctrl));
+      const T* gp = MRC(act_gainprm) + 3*i; const T* bp = MRC(act_biasprm) + 3*i;
+      const T gear = MRC(act_gear)[i];
       T len, vel;
       if (L.d.nwrap && (fl & ACTF_TENDON)) {   // fixed tendon: linear combination of joint coordinates
         const int t = MI(act_dof)[i];
@@ -2446,7 +2485,7 @@ struct StepCore {
         input = act;
       } }
       T force = gain*input + bias;
-      if (fl & ACTF_FORCELIMITED) force = t_max(MR(act_forcerange)[2*i], t_min(MR(act_forcerange)[2*i + 1], force));
+      if (fl & ACTF_FORCELIMITED) force = t_max(MRC(act_forcerange)[2*i], t_min(MRC(act_forcerange)[2*i + 1], force));
       S(actuator_force)[i] = force;
     }
     DMC_WSYNC();
@@ -2456,8 +2495,8 @@ struct StepCore {
         if (L.d.nwrap && (MI(act_flags)[i] & ACTF_TENDON)) {
           const int t = MI(act_dof)[i];
           for (int w = MI(tendon_adr)[t]; w < MI(tendon_adr)[t] + MI(tendon_num)[t]; w++)
-            if (MI(wrap_dof)[w] == dd) f += MR(act_gear)[i] * MR(wrap_prm)[w] * S(actuator_force)[i];
-        } else if (MI(act_dof)[i] == dd) f += MR(act_gear)[i] * S(actuator_force)[i];
+            if (MI(wrap_dof)[w] == dd) f += MRC(act_gear)[i] * MR(wrap_prm)[w] * S(actuator_force)[i];
+        } else if (MI(act_dof)[i] == dd) f += MRC(act_gear)[i] * S(actuator_force)[i];
       }
       S(qfrc_actuator)[dd] = f;
     }
@@ -2619,6 +2658,7 @@ struct StepCore {
       DMC_WSYNC();
     }
     const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
+    const auto Jc_base = Jc();
     for (int c = 0; c < ncon; c++) {
       const int r0 = SI(con_efc)[c];
       if (r0 < 0) continue;
@@ -2632,7 +2672,7 @@ struct StepCore {
       if (!any) continue;               // group-uniform: a contact whose rows are all inactive adds nothing
       const int kc = con_ndof(c), npair = (kc*(kc + 1)) >> 1;
       const unsigned char* dofs = con_dof_list(c);
-      const T* J = S(efc_Jc) + (r0 - rm.c0)*K;
+      const auto J = Jc_base + (r0 - rm.c0)*K;
       for (int t = lane; t < npair; t += LPE) {
         // slot pair (a >= b) of the block, row-major
         int a = (int)((sqrtf(8.0f*(float)t + 1.0f) - 1.0f)*0.5f);
@@ -2796,6 +2836,7 @@ struct StepCore {
     const int nv = L.d.nv, K = L.d.kmax;
     const RowMap rm = row_map();
     const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
+    const auto Jc_base = Jc();
     FOR_LANES(i, nv) {
       T f = 0;
       if (L.d.njdense) for (int r = 0; r < rm.s0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
@@ -2811,7 +2852,7 @@ struct StepCore {
         const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), i);
         if (slot < 0) continue;
         const int nrow = contact_rows(con_dim(c));
-        const T* jc = S(efc_Jc) + (r0 - rm.c0)*K + slot;
+        const auto jc = Jc_base + (r0 - rm.c0)*K + slot;
         for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q]; if (fr != 0) f += jc[q*K]*fr; }
       }
       S(qfrc_constraint)[i] = f;
@@ -3051,6 +3092,40 @@ struct StepCore {
   // A is symmetric and stored in full, (nslip, nslip) per environment in global memory: entry (i, j), i >= j, is
   // computed once as J_i . (M^-1 J_j^T) and written to both places, so that every later read runs along a row
   DMC_DEV T* ns_A() const { return (T*)o.ns_A + (size_t)SI(imisc)[IM_ENV] * L.d.nslip * L.d.nslip; }
+#ifndef DMC_HOST_EMU
+  // A = J_F M^-1 J_F^T for model-specialised kernels: lane i loads row i and column i of M's factor ONCE and keeps
+  // them in registers over all nf solves; each solve is chol_solve_rows' two register sweeps, operation for operation.
+  template <int N>
+  DMC_DEV void noslip_build_A_rows(const DMC_LDS T* Lm, int nf, const RowMap& rm) {
+    const int i = lane;
+    const bool own = i < N;
+    const int ci = tri_c0(own ? i : 0, N);
+    T row[N], col[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
+    const T dinv = own ? Lm[ci] : (T)0;
+    T* A = ns_A(); const int cap = L.d.nslip;
+    for (int b = 0; b < nf; b++) {
+      T sreg = own ? row_entry(SI(ns_row)[b], i, rm) : (T)0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
+        if (i == k) sreg = xk;
+        if (i > k && own) sreg -= row[k]*xk;
+      }
+#pragma unroll
+      for (int k = N - 1; k >= 0; k--) {
+        const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
+        if (i == k) sreg = xk;
+        if (i < k) sreg -= col[k]*xk;
+      }
+      if (own) S(sv_Mgrad)[i] = sreg;
+      DMC_WSYNC();
+      for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; }
+      DMC_WSYNC();
+    }
+  }
+#endif
   DMC_DEV void noslip(int nefc) {
     const int nv = L.d.nv, cap = L.d.nslip;
     int nf = 0, over = 0;
@@ -3062,10 +3137,20 @@ struct StepCore {
     }
     if (over) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++; return; }   // more friction rows than the cap: step without noslip
     if (!nf) return;
-    // M^-1 through the factor of M computed in the position stage (kept in qLM beside H's factor in qLH)
+    // M^-1 through the factor of M computed in the position stage and kept beside H's factor: in qLM, or (large
+    // models) in the global scratch, from where it returns to qLH now that the solver is done with H
     DMC_WSYNC();
+    if (L.d.jglobal) {
+      const DMC_GLB T* g = (const DMC_GLB T*)gLM();
+      FOR_LANES(i, L.d.ntri) S(qLH)[i] = g[i];
+      DMC_WSYNC();
+    }
     const RowMap rm = row_map();
-    for (int b = 0; b < nf; b++) {
+    bool built = false;
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { noslip_build_A_rows<LS::kNV>((const DMC_LDS T*)M_factor(), nf, rm); built = true; }
+#endif
+    if (!built) for (int b = 0; b < nf; b++) {
       const int rb = SI(ns_row)[b];
       FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(rb, i, rm);
       DMC_WSYNC();

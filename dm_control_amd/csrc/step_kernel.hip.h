@@ -16,7 +16,9 @@ struct LaunchGeom {
   int waves;           // wavefronts per workgroup (1..4)
   int envs_per_block;  // waves * 64 / lpe
   int lds_bytes;       // dynamic LDS per workgroup
-  int grid;            // workgroups
+  int grid;            // workgroups: one per envs_per_block environments, or (queue != 0) only the resident ones
+  int queue;           // 1: the batch is larger than what is resident at once -- waves claim further items from StepIO::work
+  int blocks_per_cu;   // workgroups of this shape resident on one CU (LDS- and VGPR-limited)
   int static_id;       // >= 0: layout equals the baked layout with this id (specialised kernel)
 };
 
@@ -53,27 +55,44 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   // stage the model constant tables once per workgroup (shared by all its envs)
   if (tid == 0) *o_lds = o_arg;
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
-  for (int i = tid; i < L.n_mr; i += nthr) mr[i] = g_mr[i];
+  for (int i = tid; i < L.n_mr_lds; i += nthr) mr[i] = g_mr[i];   // large models: only the hot tables (StepLayout::n_mr_lds)
   // small models: the cold tables ride along in LDS (after the real tables); large ones read them from global memory
-  int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T));
+  int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T));
   const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
   if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
   __syncthreads();
-  const int epb = nthr / LPE;
   const int g = tid / LPE, lane = tid % LPE;
   // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
   // Give every XCD one contiguous range of environments, so that a 128-B line of
   // an SoA row (32 fp32 envs = several workgroups) is fetched into one L2 only.
   const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
   const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
-  const int env = lblk * epb + g;
-  if (env >= io.B) return;
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
-  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr * sizeof(T) + cold_bytes + (size_t)g * env_bytes;
+  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T) + cold_bytes + (size_t)g * env_bytes;
   T* s = reinterpret_cast<T*>(base);
   int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
   StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, L.d.coldlds ? (const int*)mc_lds : g_mc, s, si, lane);
-  core.run(io, env, nstep, legacy, mode, outmask, nsub);
+  // An item is the 64 / LPE environments one wave steps together.  Every wave starts on the item of its position in
+  // the grid.  When the grid is only the RESIDENT workgroups of a larger batch (io.work != null), a wave that finishes
+  // takes the next unclaimed item from the queue: the waves of a workgroup do not wait for its slowest environment,
+  // and a launch is not a whole number of rounds (a fallen 62-dof humanoid steps several times longer than a
+  // standing one; with 4-wave workgroups handed out whole, one launch per env-step ran 1.5x longer than the rollout).
+  constexpr int epw = 64 / LPE;
+  const int wave = tid >> 6, wpb = nthr >> 6;
+  const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
+  for (int item = lblk * wpb + wave; item < nitems; ) {
+    const int env = item * epw + (g - wave * epw);
+    if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub);
+    if (!io.work) break;
+    int nx = 0;
+    if ((tid & 63) == 0) nx = atomicAdd(io.work, 1);
+    item = nwaves + __builtin_amdgcn_readfirstlane(nx);
+  }
+  if (io.work && (tid & 63) == 0) {
+    // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
+    // last wave to arrive can re-arm the queue for the next launch on the stream
+    if (atomicAdd(io.work + 1, 1) == nwaves - 1) { atomicExch(io.work, 0); atomicExch(io.work + 1, 0); }
+  }
 }
 
 template <typename T, int LPE>
@@ -92,6 +111,7 @@ template <int SID> struct StaticLayout;
   static __device__ const StepLayout kStaticLayout##ID = DMC_STATIC_LAYOUT_##ID;     \
   template <> struct StaticLayout<ID> {                                               \
     static constexpr int kNV = DMC_STATIC_NV_##ID;   /* compile-time nv: register-resident Cholesky */ \
+    static constexpr int kJGlobal = DMC_JGLOBAL_LEVEL(DMC_STATIC_NV_##ID);   /* StepDims::jglobal */ \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_STATIC_IDS(DMC_DEF_STATIC)

@@ -12,6 +12,9 @@
 #pragma once
 #include <stdint.h>
 
+// StepDims::jglobal of a model with nv dofs
+#define DMC_JGLOBAL_LEVEL(nv) ((nv) > 32 ? 2 : ((nv) > 16 ? 1 : 0))
+
 struct StepDims {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;
   int nlevel;    // number of tree depths >= 1
@@ -43,6 +46,12 @@ struct StepDims {
   int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
   int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
   int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
+  int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
+                 //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
+                 //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables.
+                 // The residency per CU of these models is bounded by LDS and their step is long enough that a few L2
+                 // round trips do not show: level 1 took humanoid 6 -> 8 and the 62-dof models 2 -> 3 environments per
+                 // CU, level 2 the 62-dof models to 4; on the 27 / 30-dof models level 2 gains no residency and costs 1-2 %.
 };
 
 // Constraint Jacobian storage.  Rows come in MuJoCo's order (equality, dof friction, joint limit,
@@ -91,25 +100,24 @@ struct StepDims {
   X(pair_info, d.npair)        /* condim | contact-parameter tuple << 8 */
 
 // ---- model tables (reals) ----------------------------------------------------
-#define STEP_MODEL_REAL_TABLES(X)                                              \
+// Hot tables are staged in LDS by every workgroup.  The cold ones -- each read once per step, one element per lane, in
+// a loop over bodies / joints / geoms / actuators -- are staged with them for the small models, and left in global
+// memory (L2-resident, StepOpts::g_mr) for the large ones (StepDims::jglobal == 2), whose residency LDS bounds.
+#define STEP_MODEL_HOT_REAL_TABLES(X)                                          \
   X(qpos0, d.nq) X(qpos_spring, d.nq)                                          \
-  X(body_pos, 3 * d.nbody) X(body_quat, 4 * d.nbody) X(body_ipos, 3 * d.nbody) \
-  X(body_iquat, 4 * d.nbody) X(body_mass, d.nbody) X(body_inertia, 3 * d.nbody) \
+  X(body_mass, d.nbody)                                                        \
   X(body_subtreemass, d.nbody) X(body_invsubtreemass, d.nbody)                 \
   X(body_invweight0, 2 * d.nbody)                                              \
-  X(jnt_pos, 3 * d.njnt) X(jnt_axis, 3 * d.njnt) X(jnt_stiffness, d.njnt)      \
-  X(jnt_range, 2 * d.njnt) X(jnt_margin, d.njnt) X(jnt_solref, 2 * d.njnt)     \
-  X(jnt_solimp, 5 * d.njnt)                                                    \
+  X(jnt_pos, 3 * d.njnt) X(jnt_axis, 3 * d.njnt)                               \
   X(dof_armature, d.nv) X(dof_damping, d.nv) X(dof_invweight0, d.nv)           \
   X(dof_frictionloss, d.nfric ? d.nv : 0) X(dof_solref, d.nfric ? 2 * d.nv : 0) \
   X(dof_solimp, d.nfric ? 5 * d.nv : 0)                                        \
-  X(geom_size, 3 * d.ngeom) X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom) \
+  X(geom_size, 3 * d.ngeom)                                                    \
   X(geom_rbound, d.ngeom)                                                      \
   X(prm_margin, d.nprm) X(prm_gap, d.nprm) X(prm_friction, 3 * d.nprm)         \
   X(prm_solref, 2 * d.nprm) X(prm_solimp, 5 * d.nprm)  /* distinct contact-parameter tuples */ \
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
-  X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
-  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu) X(wrap_prm, d.nwrap)       \
+  X(wrap_prm, d.nwrap)                                                         \
   X(act_dynprm, d.na ? d.nu : 0)  /* time constant of filter dynamics */          \
   X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon) \
   X(tendon_range, d.nlimten ? 2 * d.ntendon : 0) X(tendon_margin, d.nlimten ? d.ntendon : 0) \
@@ -117,6 +125,16 @@ struct StepDims {
   X(tendon_invweight0, (d.nlimten || d.neq) ? d.ntendon : 0)                   \
   X(eq_solref, 2 * d.neq) X(eq_solimp, 5 * d.neq)                             \
   X(eq_data, 13 * d.neq)  /* mjModel.eq_data (11) + reference coordinates: tendon length0, or the joints' qpos0 */
+#define STEP_MODEL_COLD_REAL_TABLES(X)                                         \
+  X(body_pos, 3 * d.nbody) X(body_quat, 4 * d.nbody) X(body_ipos, 3 * d.nbody) \
+  X(body_iquat, 4 * d.nbody) X(body_inertia, 3 * d.nbody)                      \
+  X(jnt_stiffness, d.njnt)                                                     \
+  X(jnt_range, 2 * d.njnt) X(jnt_margin, d.njnt) X(jnt_solref, 2 * d.njnt)     \
+  X(jnt_solimp, 5 * d.njnt)                                                    \
+  X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom)                           \
+  X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
+  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
+#define STEP_MODEL_REAL_TABLES(X) STEP_MODEL_HOT_REAL_TABLES(X) STEP_MODEL_COLD_REAL_TABLES(X)
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -130,15 +148,15 @@ struct StepDims {
   X(subtree_com, 3 * d.nbody)                                                  \
   X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv)              \
   X(cvel, 6 * d.nbody)                                                         \
-  X(qM, d.msparse ? d.nM : d.nv * d.nv)  /* sparse: row i holds M(i, i), M(i, parent(i)), ... (dof_madr) */ \
+  X(qM, d.jglobal == 2 ? 0 : (d.msparse ? d.nM : d.nv * d.nv))  /* sparse: entry p is M(i, j) of the (i, j) list (mpair); global scratch if jglobal */ \
   X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
-  X(qLM, d.nslip ? d.ntri : 0)   /* noslip models: the factor of M kept beside that of H (noslip needs M^-1 after the solve) */ \
+  X(qLM, (d.nslip && !d.jglobal) ? d.ntri : 0)   /* noslip models: the factor of M kept beside that of H (noslip needs M^-1 after the solve); global scratch if jglobal */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
   X(sensordata, d.nsensordata)                                                 \
-  X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, 9 * d.nconmax) \
-  X(efc_Jd, d.njdense * d.nv) X(efc_Jc, d.njcon * d.kmax)                      \
+  X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, d.jglobal == 2 ? 0 : 9 * d.nconmax) \
+  X(efc_Jd, d.njdense * d.nv) X(efc_Jc, d.jglobal ? 0 : d.njcon * d.kmax)                      \
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
   X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
   X(efc_force, d.njmax)                                                        \
@@ -213,8 +231,10 @@ struct StepLayout {
   STEP_SCRATCH_INT(X)
 #undef X
   int n_mi, n_mr, n_mc;    // table sizes (elements)
+  int n_mr_lds;            // reals staged in LDS: n_mr, or only the hot tables (d.jglobal)
   int n_sr, n_si;          // per-env scratch sizes (elements)
   int n_keep;              // reals before the overlay region: what survives a stage (the per-env stash in HBM)
+  int n_gs, gs_Jc, gs_LM, gs_M, gs_cf;  // per-env global scratch (reals; 0 unless d.jglobal): size, offsets of efc_Jc, the factor of M, sparse M, con_frame
 };
 
 // scalar options broadcast to every wave
@@ -234,6 +254,10 @@ struct StepOpts {
   // mjData.xfrc_applied: Cartesian [force(3), torque(3)] per body at its COM, (6 nbody, B) SoA in global memory; null
   // until the caller touches the field (almost every batch): read only where it enters (mj_fwdAcceleration, cfrc_ext)
   const void* xfrc; int xfrc_B;
+  // per-environment global scratch, (B, n_gs) reals (StepLayout::gs_*): arrays of the large models that LDS has no room for
+  void* gscr;
+  // the real model tables in global memory (batch precision): where the large models read the cold ones from
+  const void* g_mr;
 };
 
 static inline void step_layout_build(StepLayout* L, const StepDims& d) {
@@ -245,9 +269,13 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
   L->n_mi = (o + 3) & ~3;
   o = 0;
 #define X(name, cnt) L->mr_##name = o; o += (cnt);
-  STEP_MODEL_REAL_TABLES(X)
+  STEP_MODEL_HOT_REAL_TABLES(X)
+  o = (o + 3) & ~3;
+  L->n_mr_lds = o;
+  STEP_MODEL_COLD_REAL_TABLES(X)
 #undef X
   L->n_mr = (o + 3) & ~3;
+  if (d.jglobal < 2) L->n_mr_lds = L->n_mr;
   o = 0;
 #define X(name, cnt) L->mc_##name = o; o += (cnt);
   STEP_MODEL_COLD_TABLES(X)
@@ -257,7 +285,18 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #define X(name, cnt) L->s_##name = o; o += (cnt);
   STEP_SCRATCH_REAL(X)
 #undef X
-  if (!d.nslip) L->s_qLM = L->s_qLH;      // no noslip: M's factor is not needed after H's took the buffer -- one buffer
+  if (!d.nslip || d.jglobal) L->s_qLM = L->s_qLH;   // no noslip: M's factor is not needed after H's took the buffer -- one buffer
+  L->n_gs = L->gs_Jc = L->gs_LM = L->gs_M = L->gs_cf = 0;
+  if (d.jglobal) {
+    int g = (d.njcon * d.kmax + 31) & ~31;     // 128-byte granules: an environment's arrays never share a cache line
+    L->gs_LM = g;
+    if (d.nslip) g += (d.ntri + 31) & ~31;
+    L->gs_M = g;
+    if (d.jglobal == 2) g += (d.nM + 31) & ~31;
+    L->gs_cf = g;
+    if (d.jglobal == 2) g += (9 * d.nconmax + 31) & ~31;
+    L->n_gs = g;
+  }
   o = (o + 3) & ~3;
   L->n_keep = o;
   {
@@ -289,6 +328,10 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #include <string.h>
 static inline int step_layout_find(const StepLayout* L, const char* name, int* off, int* cnt, int* kind) {
   const StepDims& d = L->d;
+  // the debug dump appends the environment's global scratch after its n_sr LDS reals
+  if (d.jglobal && !strcmp(name, "efc_Jc")) { *off = L->n_sr + L->gs_Jc; *cnt = d.njcon * d.kmax; *kind = 0; return 1; }
+  if (d.jglobal == 2 && !strcmp(name, "qM")) { *off = L->n_sr + L->gs_M; *cnt = d.nM; *kind = 0; return 1; }
+  if (d.jglobal == 2 && !strcmp(name, "con_frame")) { *off = L->n_sr + L->gs_cf; *cnt = 9 * d.nconmax; *kind = 0; return 1; }
 #define X(n, c) if (!strcmp(name, #n)) { *off = L->s_##n; *cnt = (c); *kind = 0; return 1; }
   STEP_SCRATCH_ALL_REAL(X)
 #undef X

@@ -253,6 +253,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     d.kwords = (kmax + 3) / 4;
   }
   d.msparse = m.nv > 16 ? 1 : 0;
+  d.jglobal = DMC_JGLOBAL_LEVEL(m.nv);
   d.maxrow = maxrow_per_contact;
   d.coldlds = (d.nM + 2 * m.npair) <= 256 ? 1 : 0;
   step_layout_build(&t->L, d);
@@ -411,7 +412,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
   o.noslip_iterations = m.opt_noslip_iterations; o.noslip_tolerance = m.opt_noslip_tolerance;
   o.any_damping = 0;
-  o.eg_data = nullptr; o.eg_slot = nullptr; o.eg_n = 0; o.eg_B = 0; o.ns_A = nullptr; o.xfrc = nullptr; o.xfrc_B = 0;
+  o.eg_data = nullptr; o.eg_slot = nullptr; o.eg_n = 0; o.eg_B = 0; o.ns_A = nullptr; o.xfrc = nullptr; o.xfrc_B = 0; o.gscr = nullptr; o.g_mr = nullptr;
   for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
   return true;
 }
@@ -426,7 +427,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
   o.noslip_iterations = s.noslip_iterations; o.noslip_tolerance = (T)s.noslip_tolerance;
   o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
-  o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A; o.xfrc = s.xfrc; o.xfrc_B = s.xfrc_B;
+  o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A; o.xfrc = s.xfrc; o.xfrc_B = s.xfrc_B; o.gscr = s.gscr; o.g_mr = s.g_mr;
   return o;
 }
 

@@ -162,12 +162,16 @@ int dmc_gather_create(dmc_batch* b, int nrows, const char* const* field_names, c
 void dmc_gather_destroy(dmc_gather* g);
 int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream);
 
-/* info[0..17] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
+/* info[0..19] = {B, precision, lanes_per_env, waves_per_block, envs_per_block,
  * lds_bytes_per_block, grid, nconmax, njmax, env_scratch_bytes, static_id,
- * jac_kmax, table_lds_bytes, envs_per_cu, njdense, njcon, stash_on, stash_bytes_per_env}
+ * jac_kmax, table_lds_bytes, envs_per_cu, njdense, njcon, stash_on, stash_bytes_per_env,
+ * global_scratch_bytes_per_env, work_queue}
  * (static_id >= 0: a model-specialised kernel instantiation is in use; jac_kmax: entries per
  * compressed contact Jacobian row; envs_per_cu: environments resident on one CU under the
- * 160 KiB LDS budget). */
+ * 160 KiB LDS budget; global_scratch_bytes_per_env: what a tree-sparse model (nv > 16) keeps in
+ * device memory instead of LDS -- the compressed contact rows and, with noslip, the factor of M; work_queue: 1 when
+ * the batch is larger than what the chip holds at once, so `grid` is only the resident workgroups and their waves
+ * claim the remaining environments from a device-side queue as they finish). */
 int dmc_batch_info(const dmc_batch* b, int* info);
 
 /* Time `reps` back-to-back step launches with hipEvents on `hip_stream`;

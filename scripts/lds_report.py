@@ -47,9 +47,9 @@ def main():
       items = sorted(r[sect].items(), key=lambda kv: -kv[1])
       tot = sum(v for _, v in items)
       print('  %-12s %6d words (%5.1f KiB fp32): %s' % (sect, tot, tot*4/1024.0, ', '.join('%s=%d' % kv for kv in items[:10])))
-    tables = (r['n_mi'] + r['n_mr'])*4
+    tables = (r['n_mi'] + r['n_mr_lds'])*4
     env = (r['n_sr'] + r['n_si'])*4
-    print('  fp32: tables %.1f KiB, env %.1f KiB -> %d envs per 160 KiB CU' % (tables/1024.0, env/1024.0, (160*1024 - tables)//env))
+    print('  fp32: tables %.1f KiB, env %.1f KiB -> %d envs per 160 KiB CU; global scratch %.1f KiB per env' % (tables/1024.0, env/1024.0, (160*1024 - tables)//env, r['n_gs']*4/1024.0))
 
 
 if __name__ == '__main__':

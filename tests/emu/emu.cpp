@@ -22,6 +22,7 @@ struct Emu {
   // per-environment world geoms (one environment here): slot table + the 16 values per declared geom
   std::vector<int> eg_slot; std::vector<double> eg64; std::vector<float> eg32;
   std::vector<double> nsA;      // noslip matrix (global memory on the device)
+  std::vector<double> gs;       // the environment's global scratch (persists between launches, like the device buffer)
   std::vector<double> xfrc64; std::vector<float> xfrc32;      // xfrc_applied (6 nbody), empty = not set
 };
 
@@ -39,7 +40,7 @@ void* emu_create(const int32_t* ints, int ni, const double* reals, int nr, int n
 void emu_free(void* h) { delete (Emu*)h; }
 int emu_dims(void* h, int* out) {
   Emu* e = (Emu*)h; const StepLayout& L = e->tb.L;
-  out[0] = L.n_sr; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr; out[6] = L.d.kmax; out[7] = L.n_mc;
+  out[0] = L.n_sr + L.n_gs; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr; out[6] = L.d.kmax; out[7] = L.n_mc;
   return 0;
 }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
@@ -70,7 +71,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   const int NF = sizeof(sizes)/sizeof(int);
   std::vector<std::vector<T>> buf(NF);
   for (int k = 0; k < NF; k++) { buf[k].resize(sizes[k] + 1); for (int i = 0; i < sizes[k]; i++) buf[k][i] = (T)f[k][i]; }
-  std::vector<T> dbuf(L.n_sr); std::vector<int> dibuf(L.n_si);
+  std::vector<T> dbuf(L.n_sr + L.n_gs); std::vector<int> dibuf(L.n_si);
   StepIO<T> io;
   io.B = 1;
   io.qpos = buf[0].data(); io.qvel = buf[1].data(); io.ctrl = buf[2].data(); io.qacc_warmstart = buf[3].data();
@@ -86,6 +87,8 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
   io.env_mode = nullptr;
   if (!e->xfrc64.empty()) { o.xfrc = sizeof(T) == 8 ? (const void*)e->xfrc64.data() : (const void*)e->xfrc32.data(); o.xfrc_B = 1; }
+  o.g_mr = mr;
+  e->gs.resize(L.n_gs + 2); o.gscr = e->gs.data();   // doubles: room for either precision
   if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }
   if (!e->eg_slot.empty()) { o.eg_slot = e->eg_slot.data(); o.eg_n = (int)e->eg64.size() / 16; o.eg_B = 1; o.eg_data = sizeof(T) == 8 ? (const void*)e->eg64.data() : (const void*)e->eg32.data(); }
   io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
@@ -95,7 +98,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   core.run(io, 0, nstep, legacy, mode, OUT_ALL, 1);
   for (int k = 0; k < NF; k++) for (int i = 0; i < sizes[k]; i++) f[k][i] = (double)buf[k][i];
   f[5][0] = tm;
-  if (dbg) { for (int i = 0; i < L.n_sr; i++) dbg[i] = (double)dbuf[i]; for (int i = 0; i < L.n_si; i++) dbgi[i] = dibuf[i]; }
+  if (dbg) { for (int i = 0; i < L.n_sr + L.n_gs; i++) dbg[i] = (double)dbuf[i]; for (int i = 0; i < L.n_si; i++) dbgi[i] = dibuf[i]; }
 }
 extern "C" {
 int emu_run(void* h, int prec, double** f, int** fi, int nstep, int legacy, int mode, double* dbg, int* dbgi) {

@@ -18,12 +18,18 @@ ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 # stated fp64/fp32 tolerance.  The fp64 kernel holds 1e-9 for every environment.
 # The fp32 kernel seeds ~1e-7 rounding differences which contact events amplify
 # (the reference itself demonstrates this sensitivity,
-# dm_control/mujoco/tutorial.ipynb:1122-1160), so open loop over 1000 steps it is
-# held to: median <= 1e-5, at least 90 % of environments <= 1e-4, all <= 2e-3;
-# the per-step (teacher-forced) fp32 error is held to 5e-5 separately (stiff
-# contacts: |qacc| ~ 1e3..1e4 with ~1e-5 relative error, times dt^2).
+# dm_control/mujoco/tutorial.ipynb:1122-1160).  Measured over 256 environments x 1000 steps
+# (profiles/r02_parity_dist_cheetah_f32.json): median 1.6e-6, 95 % <= 4.6e-6, 98.8 % <= 1e-4; the three
+# environments above 1e-4 stay below it for 650+ steps and then diverge through a contact that
+# closes one step earlier or later (their per-step, teacher-forced error never exceeds 1e-5).  Held to:
+# median <= 5e-6, at least 95 % of environments <= 1e-4 (north_star; 2 of 64 happens), and every environment above 1e-4 is justified
+# individually: replayed teacher-forced (the kernel restarted from the oracle's state at every one of its 1000
+# steps, same actions) its per-step error must stay below 5e-5 -- the open-loop gap is then amplification of
+# rounding by the dynamics, not a defect of the step (stiff contacts: |qacc| ~ 1e3..1e4 with ~1e-5 relative
+# error, times dt^2) -- except on the rare steps where a contact is just touching (|dist| < 1e-6) and fp32 / fp64
+# disagree about activating it, which the replay identifies and reports (_teacher_forced_replay).
 TOL_F64_1000 = 1e-9
-TOL_F32_MEDIAN, TOL_F32_FRAC_1E4, TOL_F32_MAX = 1e-5, 0.9, 2e-3
+TOL_F32_MEDIAN, TOL_F32_FRAC_1E4 = 5e-6, 0.95
 TOL_F32_ONE_STEP = 5e-5
 
 
@@ -112,13 +118,58 @@ def test_forward_stages_fp64(cheetah, lanes):
   b.close()
 
 
-@pytest.mark.parametrize('precision,lanes', [(64, 64), (64, 16), (32, 64), (32, 32), (32, 16)])
-def test_cheetah_1000_step_rollout(cheetah, precision, lanes):
-  """BASELINE config 2 on a 32-env subset: task initialisation (random limited
-  joints + 200 settle steps), then 1000 random-action steps, open loop."""
+def _teacher_forced_replay(m, q0, acts, lanes):
+  """Per-env max over the steps of the fp32 kernel's one-step error when it is restarted from the oracle's state at
+  every step of the same episode (q0: (n, nq) initial configurations, acts: (T, n, nu)).
+
+  Steps on which the two DISAGREE ABOUT A CONTACT THAT IS JUST TOUCHING are reported separately: MuJoCo activates a
+  contact when dist < margin, and an activated contact pushes back at once through the damping term of solref, so
+  the dynamics are discontinuous there; with |dist - margin| below fp32 resolution (positions ~1 m: 1e-7) the last
+  bit decides, and a one-step gap of ~1e-2 follows (measured: cheetah's back foot grazing the ground at dist =
+  -6e-8 in fp32, >= 0 in fp64).  Returns (per-env max over the other steps, list of (env, step, dist) events)."""
+  from oracle import oracle
+  n = len(q0)
+  refs = _oracles(m, q0)
+  oracle.rollout_legacy(refs, np.zeros((200, n, m.nu)))
+  b = _batch(m, n, precision=32, lanes_per_env=lanes)
+  worst = np.zeros(n)
+  events = []
+  for t in range(acts.shape[0]):
+    b.set('qpos', np.stack([p.qpos for p in refs]))
+    b.set('qvel', np.stack([p.qvel for p in refs]))
+    b.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+    b.set_control(acts[t])
+    b.forward()          # the contact set the kernel sees at the oracle's state
+    ncon, dist = b.get('ncon')[:, 0], b.get('contact_dist')
+    g1, g2 = b.get('contact_geom1'), b.get('contact_geom2')
+    edge = np.zeros(n, bool)
+    for e, p in enumerate(refs):
+      mine = {(int(g1[e, c]), int(g2[e, c])): float(dist[e, c]) for c in range(int(ncon[e]))}
+      theirs = {}
+      for c in range(p.ncon):
+        cc = p.contact(c)
+        theirs[(cc['geom1'], cc['geom2'])] = cc['dist']
+      only = [(k, d) for k, d in mine.items() if k not in theirs] + [(k, d) for k, d in theirs.items() if k not in mine]
+      if only:
+        assert all(abs(d) < 1e-6 for _, d in only), ('contact sets differ beyond rounding', e, t, only)   # margin = 0
+        edge[e] = True
+        events.append((e, t, only[0][1]))
+    b.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))      # mj_forward left its own solution there
+    b.step()
+    oracle.rollout_legacy(refs, acts[t:t + 1])
+    err = _rel_err_env(b.get('qpos'), np.stack([p.qpos for p in refs]))
+    worst = np.maximum(worst, np.where(edge, 0.0, err))
+  b.close()
+  return worst, events
+
+
+@pytest.mark.parametrize('precision,lanes,NE', [(64, 64, 32), (64, 16, 32), (32, 64, 64), (32, 32, 256), (32, 16, 64)])
+def test_cheetah_1000_step_rollout(cheetah, precision, lanes, NE):
+  """BASELINE config 2 on a subset of environments (256 for the production shape): task initialisation (random
+  limited joints + 200 settle steps), then 1000 random-action steps, open loop."""
   from oracle import oracle
   m = cheetah
-  NE, T = 32, 1000
+  T = 1000
   q = _cheetah_init(m, NE)
   b = _batch(m, NE, precision=precision, lanes_per_env=lanes)
   b.set('qpos', q)
@@ -141,8 +192,16 @@ def test_cheetah_1000_step_rollout(cheetah, precision, lanes):
     assert worst.max() < TOL_F64_1000, worst.max()
   else:
     assert np.median(worst) < TOL_F32_MEDIAN, np.median(worst)
-    assert np.mean(worst < 1e-4) >= TOL_F32_FRAC_1E4, np.sort(worst)[-5:]
-    assert worst.max() < TOL_F32_MAX, worst.max()
+    assert np.mean(worst <= 1e-4) >= TOL_F32_FRAC_1E4, np.sort(worst)[-5:]
+    tail = np.nonzero(worst > 1e-4)[0]
+    if tail.size:
+      step_err, events = _teacher_forced_replay(m, q[tail], acts[:, tail], lanes)
+      print('  environments above 1e-4: %s open-loop %s, teacher-forced per-step max %s; just-touching contacts decided '
+            'by the last bit (env, step, dist): %s'
+            % (tail.tolist(), np.array2string(worst[tail], precision=2), np.array2string(step_err, precision=2),
+               [(int(tail[e]), t, float('%.2g' % d)) for e, t, d in events]))
+      assert step_err.max() < TOL_F32_ONE_STEP, (tail, step_err)
+      assert len(events) <= 2 * tail.size, events
   assert not b.get('warning').any()
   ok = worst < 1e-4
   sens = b.get('sensordata')
@@ -163,7 +222,7 @@ def test_teacher_forced_single_step_fp32(cheetah, lanes):
   oracle.rollout_legacy(refs, np.zeros((200, NE, m.nu)))
   b = _batch(m, NE, precision=32, lanes_per_env=lanes)
   rs = np.random.RandomState(9)
-  worst = 0.0
+  worst = worst_dv = 0.0
   for t in range(T):
     a = rs.uniform(-1, 1, (NE, m.nu))
     b.set('qpos', np.stack([p.qpos for p in refs]))
@@ -174,7 +233,9 @@ def test_teacher_forced_single_step_fp32(cheetah, lanes):
     oracle.rollout_legacy(refs, a[None])
     worst = max(worst, _rel_err(b.get('qpos'), np.stack([p.qpos for p in refs])))
     dv = np.abs(b.get('qvel') - np.stack([p.qvel for p in refs])).max()
-    assert dv < 2e-3, dv
+    worst_dv = max(worst_dv, dv)
+    assert dv < 4e-4, dv      # measured 8.4e-5 (|qvel| ~ 10, contact impulses)
+  print('measured: teacher_forced_single_step_fp32 max rel dqpos=%.3g max|dqvel|=%.3g' % (worst, worst_dv))
   assert worst < TOL_F32_ONE_STEP, worst
   b.close()
 

@@ -169,7 +169,7 @@ def test_humanoid_forward_all_sensors_match_oracle():
   b.close()
 
 
-@pytest.mark.parametrize('precision,tol', [(64, 1e-8), (32, 2e-3)])
+@pytest.mark.parametrize('precision,tol', [(64, 1e-10), (32, 2e-4)])   # measured 2.8e-13 / 3.8e-5
 def test_humanoid_short_rollout(precision, tol):
   """Humanoid is strongly chaotic (error grows ~10x per 0.5 s), so open-loop parity
   is asserted over 100 physics steps (20 env-steps of 5 substeps)."""
@@ -198,6 +198,7 @@ def test_humanoid_short_rollout(precision, tol):
   qg = b.get('qpos')
   qo = np.stack([o.qpos for o in refs])
   err = np.abs(qg - qo).max()
+  print('measured: humanoid_short_rollout precision=%d max|dqpos|=%.3g' % (precision, err))
   assert err < tol, err
   assert not b.get('warning').any()
   b.close()
