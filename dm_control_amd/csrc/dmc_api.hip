@@ -69,6 +69,7 @@ struct dmc_batch {
   void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
   int* d_work;         // work queue of launches with a resident-only grid: {next item, finished waves} (StepIO::work)
   int ncu;             // compute units of the device
+  int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
@@ -178,7 +179,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -201,6 +202,14 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
   if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
+  if (b->geom.queue && !getenv("DMC_NO_LPT")) {
+    b->nitems = (b->B * b->geom.lpe + 63) / 64;
+    e = hipMalloc((void**)&b->d_cost, (size_t)b->nitems * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(b->d_cost, 0, (size_t)b->nitems * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->d_order, (size_t)b->nitems * sizeof(int));
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc schedule: ") + hipGetErrorString(e), -2); }
+    b->lpt = 1;
+  }
   if (L.n_gs) {
     const size_t bytes = (size_t)b->B * L.n_gs * b->elem;
     e = hipMalloc(&b->d_gscr, bytes);
@@ -257,6 +266,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_ns_A) (void)hipFree(b->d_ns_A);
   if (b->d_gscr) (void)hipFree(b->d_gscr);
   if (b->d_work) (void)hipFree(b->d_work);
+  if (b->d_cost) (void)hipFree(b->d_cost);
+  if (b->d_order) (void)hipFree(b->d_order);
   delete b;
 }
 
@@ -277,8 +288,32 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->warning = (int*)P("warning"); io->contact_geom1 = (int*)P("contact_geom1"); io->contact_geom2 = (int*)P("contact_geom2");
   io->env_mode = (const int*)P("env_mode");
   io->work = b->geom.queue ? b->d_work : nullptr;
+  io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
+}
+
+// order[k] = the item handed out k-th: items by DESCENDING cost of the previous launch (1024 linear buckets of the
+// largest cost; the order inside a bucket does not matter).  One workgroup; a few microseconds for 4096 items.
+__global__ void __launch_bounds__(1024) order_kernel(const int* __restrict__ cost, int* __restrict__ order, int n) {
+  __shared__ int hist[1024];
+  __shared__ int mx;
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  if (tid == 0) mx = 0;
+  __syncthreads();
+  int m = 0;
+  for (int i = tid; i < n; i += 1024) m = max(m, cost[i]);
+  atomicMax(&mx, m);
+  __syncthreads();
+  const int top = mx;
+  if (top <= 0) { for (int i = tid; i < n; i += 1024) order[i] = i; return; }      // first launch: nothing measured yet
+  const float sc = 1023.0f / (float)top;
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[1023 - min(1023, (int)((float)cost[i] * sc))], 1);   // bucket 0 = costliest
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int k = 0; k < 1024; k++) { const int c = hist[k]; hist[k] = acc; acc += c; } }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) order[atomicAdd(&hist[1023 - min(1023, (int)((float)cost[i] * sc))], 1)] = i;
 }
 
 struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsub; };
@@ -288,6 +323,7 @@ static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, c
   b->tb.opts.xfrc = b->xfrc_on ? find_field(b, "xfrc_applied")->dev : nullptr; b->tb.opts.xfrc_B = b->B;
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
+  if (b->lpt) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)b->d_cost, b->d_order, b->nitems);
   if (b->precision == 64) {
     StepIO<double> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;

@@ -87,6 +87,10 @@ struct StepIO {
   // Work queue of a launch whose grid is smaller than the batch (resident workgroups only): work[0] hands out the
   // next wave-sized item, work[1] counts finished waves (the last one re-arms both).  Null: one item per wave.
   int* work;
+  // Longest-first scheduling of those launches: cost[item] = wave time (cycles / 64) the item took in the previous
+  // launch, written by the step kernel; order[k] = the item handed out k-th, built from it before every launch
+  // (order_kernel, dmc_api.hip).  Null: items in index order.
+  int* cost; const int* order;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one

@@ -80,13 +80,21 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   constexpr int epw = 64 / LPE;
   const int wave = tid >> 6, wpb = nthr >> 6;
   const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
-  for (int item = lblk * wpb + wave; item < nitems; ) {
+  for (int slot = lblk * wpb + wave; slot < nitems; ) {
+    // longest first: an environment that took long last time (a fallen humanoid with 20 contacts) is started early,
+    // so that the launch does not end waiting for one that was started last
+    const int item = io.order ? io.order[slot] : slot;
+    const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     const int env = item * epw + (g - wave * epw);
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub);
+    if (io.cost && (tid & 63) == 0) {
+      const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
+      io.cost[item] = (int)(dt < 1 ? 1 : (dt > 0x3fffffff ? 0x3fffffff : dt));
+    }
     if (!io.work) break;
     int nx = 0;
     if ((tid & 63) == 0) nx = atomicAdd(io.work, 1);
-    item = nwaves + __builtin_amdgcn_readfirstlane(nx);
+    slot = nwaves + __builtin_amdgcn_readfirstlane(nx);
   }
   if (io.work && (tid & 63) == 0) {
     // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
