@@ -1708,6 +1708,7 @@ struct StepCore {
         const int r = base + k;
         if (r >= njmax) { overflow = 1; continue; }
         S(efc_aref)[r] = 0; S(efc_D)[r] = 0; SI(efc_tid)[r] = EFC_TID(EFC_FRICTION, MI(fric_dof)[k]);
+        if (L.d.jfull) for (int k2 = 0; k2 < nv; k2++) S(efc_Jd)[r*nv + k2] = k2 == MI(fric_dof)[k] ? (T)1 : (T)0;
       }
       nefc = base + L.d.nfric < njmax ? base + L.d.nfric : njmax;
     }
@@ -1733,10 +1734,12 @@ struct StepCore {
         if (r >= njmax) { overflow = 1; continue; }
         const bool lo = i == 0 && act_lo;
         S(efc_aref)[r] = lo ? d_lo : d_hi; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_LIMIT, (MI(jnt_dofadr)[j] << 1) | (lo ? 0 : 1));
+        if (L.d.jfull) for (int k2 = 0; k2 < nv; k2++) S(efc_Jd)[r*nv + k2] = k2 == MI(jnt_dofadr)[j] ? (lo ? (T)1 : (T)-1) : (T)0;
       }
       nefc += total;
     }
     if (nefc > njmax) nefc = njmax;
+    if (L.d.jfull) ndense = nefc;      // every row so far is a dense row: row r lives at efc_Jd[r * nv]
     const int row_tl0 = nefc;
     // tendon length limits (after the joint limits, as in MuJoCo); every lane evaluates the few
     // limited tendons' lengths itself, so the row count stays group-uniform without a fence
@@ -1774,7 +1777,7 @@ struct StepCore {
         else {
           SI(con_efc)[c] = off;
           const int l1 = MI(body_lastdof)[con_b1(c)], l2 = MI(body_lastdof)[con_b2(c)];
-          SI(con_mlo)[c] = (l1 >= 0 ? MI(dof_anc_lo)[l1] : 0) ^ (l2 >= 0 ? MI(dof_anc_lo)[l2] : 0);
+          if (!L.d.jfull) SI(con_mlo)[c] = (l1 >= 0 ? MI(dof_anc_lo)[l1] : 0) ^ (l2 >= 0 ? MI(dof_anc_lo)[l2] : 0);
           if (nv > 32) SI(con_mhi)[c] = (l1 >= 0 ? MI(dof_anc_hi)[l1] : 0) ^ (l2 >= 0 ? MI(dof_anc_hi)[l2] : 0);
           // pyramidal edges all carry (dist, margin); elliptic friction rows carry (0, 0)
           const bool ell = L.d.elliptic && dim > 1;
@@ -1800,16 +1803,17 @@ struct StepCore {
       nefc = group_max<LPE>(last);
       if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++;
     }
-    if (lane == 0) { SI(imisc)[IM_NEFC] = nefc; SI(imisc)[IM_ROW_S0] = row_s0; SI(imisc)[IM_ROW_TL0] = row_tl0; SI(imisc)[IM_ROW_C0] = nefc_lim; }
+    // all-dense models: every row belongs to the first (dense) class
+    const RowMap rm = {L.d.jfull ? nefc : row_s0, L.d.jfull ? nefc : row_tl0, L.d.jfull ? nefc : nefc_lim};
+    if (lane == 0) { SI(imisc)[IM_NEFC] = nefc; SI(imisc)[IM_ROW_S0] = rm.s0; SI(imisc)[IM_ROW_TL0] = rm.tl0; SI(imisc)[IM_ROW_C0] = rm.c0; }
     DMC_WSYNC();
-    const RowMap rm = {row_s0, row_tl0, nefc_lim};
     const auto Jc_base = Jc();
     // contact Jacobian entries: item = (contact, dof); dofs outside the contact's mask are skipped
     for (int idx = lane; idx < ncon*nv; idx += LPE) {
       const int c = idx / nv, dd = idx - c*nv;
       const int r0 = SI(con_efc)[c];
       if (r0 < 0) continue;
-      const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
+      const int slot = L.d.jfull ? dd : mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
       if (slot < 0) continue;
       const int dim = con_dim(c);
       const int b1 = con_b1(c), b2 = con_b2(c);
@@ -1834,15 +1838,19 @@ struct StepCore {
         const T* fr = conF() + 9*c;
         for (int a = 0; a < 3; a++) { jac[a] = dot3(fr + 3*a, dp); jac[3 + a] = dot3(fr + 3*a, dr); }
       }
-      const auto Jw = Jc_base + (r0 - nefc_lim)*L.d.kmax + slot;
-      const int K = L.d.kmax;
-      ((unsigned char*)(SI(con_dofs) + c*L.d.kwords))[slot] = (unsigned char)dd;
-      if (dim == 1) Jw[0] = jac[0];
-      else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jw[k*K] = jac[k];
-      else for (int k = 1; k < dim; k++) {
-        const T f = MR(prm_friction)[3*con_prm(c) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
-        Jw[2*(k - 1)*K] = jac[0] + f*jac[k];
-        Jw[(2*(k - 1) + 1)*K] = jac[0] + (-f)*jac[k];
+      auto put = [&](auto Jw, int K) {      // the contact's rows, entry of this dof (row stride K)
+        if (dim == 1) Jw[0] = jac[0];
+        else if (L.d.elliptic) for (int k = 0; k < dim; k++) Jw[k*K] = jac[k];
+        else for (int k = 1; k < dim; k++) {
+          const T f = MR(prm_friction)[3*con_prm(c) + (k < 3 ? 0 : (k == 3 ? 1 : 2))];
+          Jw[2*(k - 1)*K] = jac[0] + f*jac[k];
+          Jw[(2*(k - 1) + 1)*K] = jac[0] + (-f)*jac[k];
+        }
+      };
+      if (L.d.jfull) put(S(efc_Jd) + r0*nv + dd, nv);      // dofs on neither or both chains come out as exact zeros
+      else {
+        ((unsigned char*)(SI(con_dofs) + c*L.d.kwords))[slot] = (unsigned char)dd;
+        put(Jc_base + (r0 - nefc_lim)*L.d.kmax + slot, L.d.kmax);
       }
     }
     DMC_WSYNC();
@@ -2652,7 +2660,21 @@ struct StepCore {
         T h = S(qLH)[idx];
         for (int r = 0; r < rm.c0; r++) {
           if (r >= rm.s0 && r < rm.tl0) continue;
-          if (SI(efc_active)[r] != EFC_ST_QUADRATIC) continue;
+          const int st = SI(efc_active)[r];
+          if (L.d.jfull && L.d.elliptic && st == EFC_ST_CONE) {      // all-dense models: the cone block of an elliptic contact
+            const int dim = con_dim(EFC_ID(SI(efc_tid)[r]));
+            T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+            for (int a = 0; a < dim; a++) {
+              const T ji = S(efc_Jd)[(r + a)*nv + i], jj = S(efc_Jd)[(r + a)*nv + j];
+              const T ca = S(efc_ca)[r + a];
+              Pi += ca*ji; Pj += ca*jj;
+              if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
+            }
+            h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
+            r += dim - 1;
+            continue;
+          }
+          if (st != EFC_ST_QUADRATIC) continue;
           const T* jr = dense_row(r, rm);
           const T ji = jr[i];
           if (ji != 0) h += (S(efc_D)[r]*ji) * jr[j];

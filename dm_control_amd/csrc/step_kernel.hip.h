@@ -78,7 +78,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   // and a launch is not a whole number of rounds (a fallen 62-dof humanoid steps several times longer than a
   // standing one; with 4-wave workgroups handed out whole, one launch per env-step ran 1.5x longer than the rollout).
   constexpr int epw = 64 / LPE;
-  const int wave = tid >> 6, wpb = nthr >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave-uniform: the loop state lives in SGPRs
   const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
   for (int slot = lblk * wpb + wave; slot < nitems; ) {
     // longest first: an environment that took long last time (a fallen humanoid with 20 contacts) is started early,

@@ -46,6 +46,8 @@ struct StepDims {
   int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
   int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
   int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
+  int jfull;     // 1 (nv <= 16): EVERY constraint row is stored as a dense row of nv entries in efc_Jd (row classes and
+                 //   compression pay off for long chains; on a 9-dof model their index arithmetic cost 10 % of the step)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
                  //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables.
@@ -156,7 +158,7 @@ struct StepDims {
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
   X(sensordata, d.nsensordata)                                                 \
   X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, d.jglobal == 2 ? 0 : 9 * d.nconmax) \
-  X(efc_Jd, d.njdense * d.nv) X(efc_Jc, d.jglobal ? 0 : d.njcon * d.kmax)                      \
+  X(efc_Jd, d.njdense * d.nv) X(efc_Jc, (d.jglobal || d.jfull) ? 0 : d.njcon * d.kmax)                      \
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
   X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
   X(efc_force, d.njmax)                                                        \
@@ -189,7 +191,7 @@ struct StepDims {
   X(con_info, d.nconmax)  /* condim | contact-parameter tuple << 8 */          \
   X(con_efc, d.nconmax)                                                        \
   X(con_mlo, d.nconmax) X(con_mhi, d.nv > 32 ? d.nconmax : 0)  /* dof mask of the contact's Jacobian rows */ \
-  X(con_dofs, d.nconmax * d.kwords)  /* the mask's dofs in ascending order, one byte each */ \
+  X(con_dofs, d.jfull ? 0 : d.nconmax * d.kwords)  /* the mask's dofs in ascending order, one byte each */ \
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \

@@ -230,7 +230,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
   // one-nonzero friction / joint-limit rows, kmax entries per contact row
-  d.njdense = std::min(njmax, d.neqrow + 2 * d.nlimten);
+  d.jfull = m.nv <= 16 ? 1 : 0;
+  d.njdense = d.jfull ? njmax : std::min(njmax, d.neqrow + 2 * d.nlimten);
   // contact rows with a stored Jacobian: by default every contact slot may use its maximum number of rows; a
   // smaller pool (njcon > 0) trades LDS for a DMC_WARN_CNSTRFULL when the live contacts need more rows than that
   d.njcon = std::min(njmax, nconmax * maxrow_per_contact);
