@@ -458,10 +458,14 @@ def main():
       # what actually limits the kernel: VALU issue slots.  One wave64 VALU instruction occupies its SIMD for one
       # quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on this kernel), so issue utilisation =
       # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x kernel time); counters from the committed PMC passes.
+      # The instruction count per launch comes from the PMC pass (it does not depend on how fast the launch ran), the
+      # kernel time from THIS run's HIP events: counter collection itself slows the launch down (config 2: 203 us
+      # under --pmc, 138 us under --kernel-trace alone).
       clk = pmc.get('clock_ghz', 2.4)
-      issue = pmc['SQ_INSTS_VALU'] * 4 / (SIMDS * clk * 1e9 * pmc['kernel_us'] * 1e-6)
+      issue = pmc['SQ_INSTS_VALU'] * 4 / (SIMDS * clk * 1e9 * kernel_ms * 1e-3)
       out['roofline_issue'] = {'bound': 'valu_issue', 'achieved': issue, 'peak': 1.0, 'unit': 'fraction of VALU issue slots',
                                'frac': issue, 'valu_insts_per_launch': pmc['SQ_INSTS_VALU'], 'kernel_us_profiled': pmc['kernel_us'],
+                               'kernel_us_live': kernel_ms * 1e3,
                                'source': 'profiles/r02_pmc_cfg%d.json' % args.config}
     if coll:
       out['collectives'] = coll

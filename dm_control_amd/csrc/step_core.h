@@ -108,6 +108,13 @@ struct StepIO {
 // ---------------------------------------------------------------------------
 template <typename T> DMC_DEV T t_sqrt(T x) { return (T)sqrt((double)x); }
 template <> DMC_DEV float t_sqrt<float>(float x) { return sqrtf(x); }
+// 1 / sqrt(x) for the Cholesky pivots.  fp32: the hardware reciprocal square root (v_rsq_f32, 1 ulp) instead of a
+// correctly rounded sqrt followed by a correctly rounded division -- ~25 instructions less on the dependent chain of
+// every column (a fifth of the 62 x 62 factorisation); fp64 keeps the exact sequence the oracle uses.
+template <typename T> DMC_DEV T t_rsqrt(T x) { return 1 / t_sqrt(x); }
+#ifndef DMC_HOST_EMU
+template <> DMC_DEV float t_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
 template <typename T> DMC_DEV T t_sin(T x) { return (T)sin((double)x); }
 template <> DMC_DEV float t_sin<float>(float x) { return sinf(x); }
 template <typename T> DMC_DEV T t_cos(T x) { return (T)cos((double)x); }
@@ -337,7 +344,7 @@ DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
     const int ck = tri_c0(k, n);
     T akk = A[ck];
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-    const T inv = 1 / t_sqrt(akk);
+    const T inv = t_rsqrt(akk);
     for (int i = k + 1 + lane; i < n; i += LPE) A[ck + i - k] *= inv;
     DMC_WSYNC();
     if (lane == 0) A[ck] = inv;
@@ -367,7 +374,7 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   for (int k = 0; k < N; k++) {
     T akk = wave_bcast<LPE>(a[k], k);
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-    const T inv = 1 / t_sqrt(akk);
+    const T inv = t_rsqrt(akk);
     const T lik = a[k] * inv;
 #pragma unroll
     for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }

@@ -61,17 +61,12 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
   if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
   __syncthreads();
-  const int g = tid / LPE, lane = tid % LPE;
   // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
   // Give every XCD one contiguous range of environments, so that a 128-B line of
   // an SoA row (32 fp32 envs = several workgroups) is fetched into one L2 only.
   const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
   const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
-  unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T) + cold_bytes + (size_t)g * env_bytes;
-  T* s = reinterpret_cast<T*>(base);
-  int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
-  StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, L.d.coldlds ? (const int*)mc_lds : g_mc, s, si, lane);
   // An item is the 64 / LPE environments one wave steps together.  Every wave starts on the item of its position in
   // the grid.  When the grid is only the RESIDENT workgroups of a larger batch (io.work != null), a wave that finishes
   // takes the next unclaimed item from the queue: the waves of a workgroup do not wait for its slowest environment,
@@ -81,22 +76,32 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave-uniform: the loop state lives in SGPRs
   const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
   for (int slot = lblk * wpb + wave; slot < nitems; ) {
+    // The per-lane pointers are re-derived from the thread index on every trip (behind an opaque copy, so that the
+    // compiler does not hoist them): otherwise they stay live across the out-of-line stage calls of run() and are
+    // spilled to scratch memory there -- 11 VGPRs on the cheetah kernel, 6 x the algorithmic HBM writes of a launch.
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int g = t / LPE, lane = t % LPE;
+    unsigned char* base = tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T) + cold_bytes + (size_t)g * env_bytes;
+    T* s = reinterpret_cast<T*>(base);
+    int* si = reinterpret_cast<int*>(base + (size_t)L.n_sr * sizeof(T));
+    StepCore<T, LPE, LS> core(ls, *o_lds, mi, mr, L.d.coldlds ? (const int*)mc_lds : g_mc, s, si, lane);
     // longest first: an environment that took long last time (a fallen humanoid with 20 contacts) is started early,
     // so that the launch does not end waiting for one that was started last
     const int item = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
-    const int env = item * epw + (g - wave * epw);
+    const int env = item * epw + (g & (epw - 1));
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub);
-    if (io.cost && (tid & 63) == 0) {
+    if (io.cost && (threadIdx.x & 63) == 0) {
       const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
       io.cost[item] = (int)(dt < 1 ? 1 : (dt > 0x3fffffff ? 0x3fffffff : dt));
     }
     if (!io.work) break;
     int nx = 0;
-    if ((tid & 63) == 0) nx = atomicAdd(io.work, 1);
+    if ((threadIdx.x & 63) == 0) nx = atomicAdd(io.work, 1);
     slot = nwaves + __builtin_amdgcn_readfirstlane(nx);
   }
-  if (io.work && (tid & 63) == 0) {
+  if (io.work && (threadIdx.x & 63) == 0) {
     // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
     // last wave to arrive can re-arm the queue for the next launch on the stream
     if (atomicAdd(io.work + 1, 1) == nwaves - 1) { atomicExch(io.work, 0); atomicExch(io.work + 1, 0); }
