@@ -2984,13 +2984,20 @@ struct StepCore {
   // run-time size the 20 Newton iterations ran out of scratch memory: 2.5 M cycles per step on the soccer model)
   template <int N>
   DMC_DEV static int qcqp(T* res, const T* Ain, const T* bin, const T* dd, T r) {
-    T A[N*N], b[N], Lc[N*N], v[N], pv[N], la = 0;
+    // Every lane of the group runs this scalar Newton iteration redundantly (Gauss-Seidel is sequential), so its
+    // instruction count IS the noslip time (31 % of the soccer step).  fp32: one hardware reciprocal square root per
+    // pivot serves both L[i][i] and every division by it (the exact form costs ~10 correctly rounded divisions /
+    // roots per trip), and the stopping tests are floored at what fp32 resolves (|v|^2 - r^2 cannot get within
+    // 1e-10 of zero when r^2 ~ 1e4); fp64 keeps MuJoCo's sequence operation for operation.
+    constexpr bool fast = sizeof(T) == 4;
+    T A[N*N], b[N], Lc[N*N], inv[N], v[N], pv[N], la = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) { v[i] = 0; pv[i] = 0; b[i] = bin[i]*dd[i]; }
+    for (int i = 0; i < N; i++) { v[i] = 0; pv[i] = 0; inv[i] = 0; b[i] = bin[i]*dd[i]; }
 #pragma unroll
     for (int i = 0; i < N; i++)
 #pragma unroll
       for (int j = 0; j < N; j++) { A[i*N + j] = Ain[i*N + j]*dd[i]*dd[j]; Lc[i*N + j] = 0; }
+    const T val_floor = fast ? t_max((T)1e-10, (T)(16*1.1920929e-7)*r*r) : (T)1e-10;
     bool fail = false;
     for (int iter = 0; iter < 20; iter++) {
 #pragma unroll
@@ -3000,8 +3007,12 @@ struct StepCore {
           T t = A[i*N + j] + (i == j ? la : (T)0);
 #pragma unroll
           for (int k = 0; k < j; k++) t -= Lc[i*N + k]*Lc[j*N + k];
-          if (i == j) { if (t < (T)1e-10) fail = true; Lc[i*N + i] = t_sqrt(t_max(t, (T)1e-30)); }
-          else Lc[i*N + j] = t/Lc[j*N + j];
+          if (i == j) {
+            if (t < (T)1e-10) fail = true;
+            const T tc = t_max(t, (T)1e-30);
+            if (fast) { inv[i] = t_rsqrt(tc); Lc[i*N + i] = tc*inv[i]; }
+            else Lc[i*N + i] = t_sqrt(tc);
+          } else Lc[i*N + j] = fast ? t*inv[j] : t/Lc[j*N + j];
         }
       if (fail) break;
 #pragma unroll
@@ -3009,32 +3020,32 @@ struct StepCore {
         T t = -b[i];
 #pragma unroll
         for (int k = 0; k < i; k++) t -= Lc[i*N + k]*v[k];
-        v[i] = t/Lc[i*N + i];
+        v[i] = fast ? t*inv[i] : t/Lc[i*N + i];
       }
 #pragma unroll
       for (int i = N - 1; i >= 0; i--) {
         T t = v[i];
 #pragma unroll
         for (int k = i + 1; k < N; k++) t -= Lc[k*N + i]*v[k];
-        v[i] = t/Lc[i*N + i];
+        v[i] = fast ? t*inv[i] : t/Lc[i*N + i];
       }
       T val = -r*r;
 #pragma unroll
       for (int i = 0; i < N; i++) val += v[i]*v[i];
-      if (val < (T)1e-10) break;
+      if (val < val_floor) break;
 #pragma unroll
       for (int i = 0; i < N; i++) {
         T t = v[i];
 #pragma unroll
         for (int k = 0; k < i; k++) t -= Lc[i*N + k]*pv[k];
-        pv[i] = t/Lc[i*N + i];
+        pv[i] = fast ? t*inv[i] : t/Lc[i*N + i];
       }
       T deriv = 0;
 #pragma unroll
       for (int i = 0; i < N; i++) deriv += pv[i]*pv[i];
       deriv *= -2;
       const T delta = -val/deriv;
-      if (delta < (T)1e-10) break;
+      if (delta < (fast ? t_max((T)1e-10, (T)(4*1.1920929e-7)*la) : (T)1e-10)) break;
       la += delta;
     }
     if (fail) {
