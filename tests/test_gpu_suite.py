@@ -712,3 +712,39 @@ def test_baseline_62dof_and_soccer_models_fp64_open_loop(name, nsub, caps):
   assert worst < 1e-8, worst
   assert b.get('ncon').max() > 0 and not b.get('warning').any()
   b.close()
+
+
+@pytest.mark.parametrize('name,nsub,B', [('humanoid', 5, 4096), ('cmu_2019_position_floor', 6, 2048)])
+def test_work_queue_and_schedule_do_not_change_results(name, nsub, B, monkeypatch):
+  """A batch larger than the chip holds runs a resident-only grid whose waves claim environments from a device queue,
+  longest first (include/dmc_batch.h: work_queue).  Which wave steps an environment, and when, must not matter: the
+  trajectories equal those of the static one-workgroup-per-4-environments grid bit for bit."""
+  from dm_control_amd import mjcf_compiler as mc
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  m = mc.compile_xml(common.read_model(name + '.xml'))
+  caps = dict(common.DEFAULT_CAPS.get(name, {}))
+  caps['precision'] = 32
+  rs = np.random.RandomState(3)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, 7:] += rs.uniform(-0.3, 0.3, (B, m.nq - 7))
+  q[:B // 8, 2] -= 0.6          # some start in the ground: many contacts, long steps
+  acts = rs.uniform(-1, 1, (6, B, m.nu))
+  out = {}
+  for mode, env in (('queue', {}), ('index_order', {'DMC_NO_LPT': '1'}), ('static', {'DMC_NO_QUEUE': '1'})):
+    for k in ('DMC_NO_LPT', 'DMC_NO_QUEUE'):
+      monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+      monkeypatch.setenv(k, v)
+    b = BatchedPhysics(m, B, **caps)
+    assert b.info()['work_queue'] == (0 if mode == 'static' else 1), b.info()
+    b.set('qpos', q)
+    for a in acts:
+      b.set_control(a)
+      b.step(nsub)
+    out[mode] = (b.get('qpos'), b.get('qvel'), b.get('sensordata'), b.get('ncon'), b.get('warning'))
+    b.close()
+  for mode in ('index_order', 'static'):
+    for x, y in zip(out['queue'], out[mode]):
+      np.testing.assert_array_equal(x, y, err_msg=mode)
+  assert out['queue'][3].max() > 8
