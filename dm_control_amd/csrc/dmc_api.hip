@@ -69,6 +69,7 @@ struct dmc_batch {
   void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
   int* d_work;         // work queue of launches with a resident-only grid: {next item, finished waves} (StepIO::work)
   int ncu;             // compute units of the device
+  void* d_kstash; int* d_kstash_i;      // kinematic stash (StepIO::kstash), on unless DMC_NO_KSTASH
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
@@ -179,7 +180,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -202,6 +203,13 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
   if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
+  if (!getenv("DMC_NO_KSTASH")) {
+    const size_t nk = (size_t)d.nq + d.nv + (L.s_qM - L.s_xpos);
+    e = hipMalloc(&b->d_kstash, (size_t)b->B * nk * b->elem);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->d_kstash_i, (size_t)b->B * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(b->d_kstash_i, 0, (size_t)b->B * sizeof(int));      // epoch 0: never valid
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc kinematic stash: ") + hipGetErrorString(e), -2); }
+  }
   if (b->geom.queue && !getenv("DMC_NO_LPT")) {
     b->nitems = (b->B * b->geom.lpe + 63) / 64;
     e = hipMalloc((void**)&b->d_cost, (size_t)b->nitems * sizeof(int));
@@ -266,6 +274,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_ns_A) (void)hipFree(b->d_ns_A);
   if (b->d_gscr) (void)hipFree(b->d_gscr);
   if (b->d_work) (void)hipFree(b->d_work);
+  if (b->d_kstash) (void)hipFree(b->d_kstash);
+  if (b->d_kstash_i) (void)hipFree(b->d_kstash_i);
   if (b->d_cost) (void)hipFree(b->d_cost);
   if (b->d_order) (void)hipFree(b->d_order);
   delete b;
@@ -290,6 +300,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->work = b->geom.queue ? b->d_work : nullptr;
   io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
+  io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
 }
 

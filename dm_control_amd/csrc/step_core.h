@@ -97,6 +97,9 @@ struct StepIO {
   // legacy Physics.step() and the mj_step2 that begins the next): env-major, (B, n_keep) reals and (B, n_si + 4)
   // ints whose first word is the epoch the stash was written in (valid iff equal to stash_epoch)
   T* stash_r; int* stash_i; int stash_epoch;
+  // kinematic stash (on by default): what mj_kinematics / mj_comPos / mj_comVel derive from (qpos, qvel), kept per env
+  // between legacy steps; (nq + nv + n_kin, ...) reals env-major and one epoch int per env (StepCore::load_kstash)
+  T* kstash; int* kstash_i;
   long long* prof;   // optional (DMC_PROFILE builds): (PROF_N, B) cycle counters
   T* debug;      // optional: (n_sr, ndebug) dump of the env scratch after forward
   int* debug_i;  // optional: (n_si, ndebug)
@@ -586,6 +589,36 @@ struct StepCore {
     }
     if (lane == 0) hi[0] = valid ? io.stash_epoch : 0;
   }
+  // ---- kinematic stash ------------------------------------------------------------------------------------------
+  // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
+  // results (engine.py:147-162).  Across launches LDS is lost, so the opening position / velocity stage is recomputed
+  // -- except for what depends on (qpos, qvel) ALONE: body / geom poses, the COM frame (subtree_com, cinert, cdof)
+  // and the velocities (cvel, cdof_dot), one contiguous range of the scratch.  The trailing stage leaves them in
+  // global memory together with the (qpos, qvel) they belong to; the next launch takes them back iff its state is
+  // bit-equal (and no model constant was edited: the epoch), so writes to bound tensors need no notification.
+  DMC_DEV int kin_count() const { return L.s_qM - L.s_xpos; }
+  DMC_DEV bool load_kstash(const StepIO<T>& io, int env) {
+    env = late(env);
+    if (io.kstash_i[env] != io.stash_epoch) return false;
+    const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
+    const T* h = io.kstash + (size_t)env*(nq + nv + nk);
+    int bad = 0;
+    FOR_LANES(i, nq) if (!(h[i] == S(qpos)[i])) bad = 1;
+    FOR_LANES(i, nv) if (!(h[nq + i] == S(qvel)[i])) bad = 1;
+    if (group_max<LPE>(bad)) return false;
+    FOR_LANES(i, nk) S(xpos)[i] = h[nq + nv + i];
+    DMC_WSYNC();
+    return true;
+  }
+  DMC_DEV void store_kstash(const StepIO<T>& io, int env) {
+    env = late(env);
+    const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
+    T* h = io.kstash + (size_t)env*(nq + nv + nk);
+    FOR_LANES(i, nq) h[i] = S(qpos)[i];
+    FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
+    FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
+    if (lane == 0) io.kstash_i[env] = io.stash_epoch;
+  }
   DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash) {
     const int B = io.B;
     FOR_LANES(i, L.d.nq) S(qpos)[i] = io.qpos[(size_t)i*B + env];
@@ -930,6 +963,18 @@ struct StepCore {
   // read from global memory one trip ahead of its use
   DMC_DEV void scatter_M(const T* diag, T diag_scale, T* dst) {
     const int nv = L.d.nv, nM = L.d.nM;
+    if (!L.d.msparse) {
+      // dense M (small models): every packed entry is written from its (i, j) -- no zero fill, one fence
+      FOR_LANES(idx, L.d.ntri) {
+        int i, j;
+        tri_unrank(idx, nv, &i, &j);
+        T v = S(qM)[i*nv + j];
+        if (diag && i == j) v += diag_scale*diag[i];
+        dst[idx] = v;
+      }
+      DMC_WSYNC();
+      return;
+    }
     FOR_LANES(i, L.d.ntri) dst[i] = 0;
     DMC_WSYNC();
     int pk = lane < nM ? GC(mpair)[lane] : 0;
@@ -1617,6 +1662,7 @@ struct StepCore {
   }
   // J[r, :] . x for any row class (x: nv reals)
   DMC_DEV T row_dot(int r, const T* x, const RowMap& rm) const {
+    if (L.d.jfull) return dot_n(S(efc_Jd) + r*L.d.nv, x, L.d.nv);
     if (r >= rm.c0) {
       // entry k of the row belongs to dof con_dofs[c][k]; the loop runs to the compile-time bound kmax in the
       // model-specialised kernels, so all its loads are in flight together
@@ -1633,6 +1679,7 @@ struct StepCore {
   }
   // J[r, dd] for any row class
   DMC_DEV T row_entry(int r, int dd, const RowMap& rm) const {
+    if (L.d.jfull) return S(efc_Jd)[r*L.d.nv + dd];
     if (r >= rm.c0) {
       const int c = EFC_ID(SI(efc_tid)[r]);
       const int k = mask_slot(con_mask_lo(c), con_mask_hi(c), dd);
@@ -2646,6 +2693,36 @@ struct StepCore {
   // constraint_update recorded.
   DMC_DEV void hess_assemble(int nefc, const RowMap& rm) {
     const int nv = L.d.nv, K = L.d.kmax;
+    if (L.d.jfull && !L.d.msparse) {
+      // small models (dense M, every row dense): ONE pass over the packed triangle, entry (i, j) = M(i, j) + the rows in
+      // order -- no zero fill, no scatter, no fence before the factorisation's own
+      for (int idx = lane; idx < L.d.ntri; idx += LPE) {
+        int i, j;
+        tri_unrank(idx, nv, &i, &j);
+        T h = S(qM)[i*nv + j];
+        for (int r = 0; r < nefc; r++) {
+          const int st = SI(efc_active)[r];
+          if (L.d.elliptic && st == EFC_ST_CONE) {
+            const int dim = con_dim(EFC_ID(SI(efc_tid)[r]));
+            T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+            for (int a = 0; a < dim; a++) {
+              const T ji = S(efc_Jd)[(r + a)*nv + i], jj = S(efc_Jd)[(r + a)*nv + j];
+              const T ca = S(efc_ca)[r + a];
+              Pi += ca*ji; Pj += ca*jj;
+              if (a) { const T cb = S(efc_cb)[r + a]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r + a]*ji*jj; }
+            }
+            h += S(efc_cg)[r]*(Pi*Pj) - S(efc_cb)[r]*(Wi*Wj) + g;
+            r += dim - 1;
+            continue;
+          }
+          const T ji = S(efc_Jd)[r*nv + i], jj = S(efc_Jd)[r*nv + j], dd = S(efc_D)[r];
+          if (st == EFC_ST_QUADRATIC && ji != 0) h += (dd*ji) * jj;
+        }
+        S(qLH)[idx] = h;
+      }
+      DMC_WSYNC();
+      return;
+    }
     FOR_LANES(i, nv) {
       T dsum = 0;
       for (int r = rm.s0; r < rm.tl0; r += 4) {      // four rows per trip: their loads are issued together
@@ -2868,6 +2945,14 @@ struct StepCore {
   DMC_DEV void constraint_force_to_joint(int nefc) {
     const int nv = L.d.nv, K = L.d.kmax;
     const RowMap rm = row_map();
+    if (L.d.jfull) {      // every row dense: one loop, rows in order
+      FOR_LANES(i, nv) {
+        T f = 0;
+        for (int r = 0; r < nefc; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
+        S(qfrc_constraint)[i] = f;
+      }
+      return;
+    }
     const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
     const auto Jc_base = Jc();
     FOR_LANES(i, nv) {
@@ -3426,14 +3511,14 @@ struct StepCore {
   // ---- pipeline -----------------------------------------------------------------------------
   // Position + velocity stage (mj_step1 without the checks).  partial = only what
   // the outputs need (the trailing mj_step1 of a legacy Physics.step()).
-  DMC_DEV void stage_posvel(bool partial, int outmask, bool skipsensor) {
-    kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM);
+  DMC_DEV void stage_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) {
+    if (!havekin) { kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM); }
     if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
     if (!partial || (outmask & (OUT_CONTACT | OUT_CONTACT_IDS))) { collision(); DMC_PROF(PROF_COLL); }
     if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); }
     if (!skipsensor) sensors(DMC_STAGE_POS);
     DMC_PROF(PROF_SENS);
-    com_vel(); DMC_PROF(PROF_COMVEL);
+    if (!havekin) { com_vel(); DMC_PROF(PROF_COMVEL); }
     if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); }
     if (!skipsensor) sensors(DMC_STAGE_VEL);
     DMC_PROF(PROF_SENS);
@@ -3461,9 +3546,9 @@ struct StepCore {
   // each gets its own register allocation, so the peak pressure of one stage no
   // longer forces spills in the others, and there is one copy of the code.
 #if !defined(DMC_HOST_EMU) && !defined(DMC_PROFILE) && !defined(DMC_INLINE_STAGES)
-  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor) {
+  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) {
     StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
-                                 (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0), outmask);
+                                 (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0) | (havekin ? 4 : 0), outmask);
   }
   DMC_DEV void call_acc(bool disable_actuation, bool skipsensor) {
     StageFns<T, LPE, LS>::acc(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
@@ -3475,7 +3560,7 @@ struct StepCore {
     time_ += o.timestep_d;
   }
 #else
-  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor) { stage_posvel(partial, outmask, skipsensor); }
+  DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) { stage_posvel(partial, outmask, skipsensor, havekin); }
   DMC_DEV void call_acc(bool disable_actuation, bool skipsensor) { stage_acc(disable_actuation, skipsensor); }
   DMC_DEV void call_euler() { euler(); }
 #endif
@@ -3546,6 +3631,8 @@ struct StepCore {
     bool have = false;
     if (stash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) have = load_stash(io, env);
     load_state(io, env, have);
+    bool havekin = false;
+    if (io.kstash && mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) havekin = load_kstash(io, env);
     DMC_PROF(PROF_LOAD);
     const bool stepping = mode == 0 || mode == 3;
     const int ntotal = mode == 3 ? nstep*nsub : nstep;
@@ -3556,7 +3643,7 @@ struct StepCore {
       const bool trailing = stepping && it == ntotal;
       const bool partial = trailing && !(stash && mode == 0);
       if (mode == 3 && !trailing && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
-      if (stepping) { if (check_pos_vel()) have = false; }
+      if (stepping) { if (check_pos_vel()) { have = false; havekin = false; } }
       const int nstage = (stepping && !trailing && o.integrator == DMC_INT_RK4) ? 4 : 1;
       // Sensor values are overwritten by every step, so only the passes whose sensordata can be
       // read afterwards evaluate them: position/velocity sensors in the last pass of a launch and
@@ -3565,7 +3652,7 @@ struct StepCore {
       const bool sens_acc = !stepping || it == ntotal - 1 || (mode == 3 && (it + 1) % nsub == 0);
       int stage = 0, retried = 0;
       while (stage < nstage) {
-        if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv);
+        if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv, havekin && it == 0 && !retried && !trailing);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
         if (trailing) break;
         call_acc(mode == 2, stage > 0 || !sens_acc);
@@ -3586,6 +3673,8 @@ struct StepCore {
     // the stash holds a complete position / velocity stage at the CURRENT state only after a legacy step (after an
     // mj_forward the Cholesky buffer holds the factor of H, not of M; a non-legacy mj_step ends before mj_step1)
     if (stash) store_stash(io, env, mode == 0 && legacy);
+    // the trailing stage (partial or full) evaluated kinematics / COM frame / velocities at the state being stored
+    if (io.kstash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) store_kstash(io, env);
     store_state(io, env);
     DMC_PROF(PROF_STORE);
     prof_end(io, env);
@@ -3606,7 +3695,7 @@ struct StageFns {
   static DMC_FN void posvel(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                             DMC_LDS int* si, int lane, int flags, int outmask) {
     Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
-    c.stage_posvel(flags & 1, outmask, flags & 2);
+    c.stage_posvel(flags & 1, outmask, flags & 2, flags & 4);
   }
   static DMC_FN void acc(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                          DMC_LDS int* si, int lane, int flags) {

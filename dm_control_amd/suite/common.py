@@ -6,11 +6,12 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 # Contact / constraint-row caps per domain where the library default (16 contacts) is too tight;
 # the humanoid's are free: its LDS footprint puts 4 environments on a CU either way.  The
 # model-specialised kernels are baked for exactly these caps (dm_control_amd/build.py).
-# humanoid_CMU / the config-4 CMU model (nv = 62): two environments per CU in fp32 either way (tables 18 KiB + 54 ..
-# 62 KiB of scratch per environment), so the contact cap is the one that never overflowed in the soak runs (48: a
-# ragdoll lying on the floor reaches 27 .. 40 contacts; 32 raised mjWARN_CONTACTFULL 15 times in 0.4 M env-steps).
-# fp64 fits too since the LDS diet (one environment per CU): the parity tests of these models run both precisions.
-DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=64, precision=32),      # 64 contacts: fp32 only (the fp64 scratch fits up to 48)
+# humanoid_CMU / the config-4 CMU model (nv = 62): four environments per CU in fp32 (tables 10 KiB + 34 .. 37 KiB of LDS
+# scratch per environment; the contact rows, the sparse M and the cold tables live in global memory), so the contact
+# cap is the one that never overflowed in the soak runs (48: a ragdoll lying on the floor reaches 27 .. 40 contacts;
+# 32 raised mjWARN_CONTACTFULL 15 times in 0.4 M env-steps).  fp64 fits too (two environments per CU): the parity
+# tests of these models run both precisions.
+DEFAULT_CAPS = {'humanoid': dict(nconmax=24), 'humanoid_CMU': dict(nconmax=64),
                 'cmu_2019_position_floor': dict(nconmax=48),   # BASELINE config 4 physics (assets/)
                 'soccer_2v2_boxhead': dict(nconmax=24),   # BASELINE config 5 physics (assets/)
                 'stacker': dict(nconmax=48)}   # four boxes in a heap + a folded arm: many simultaneous contacts

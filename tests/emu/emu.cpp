@@ -22,6 +22,7 @@ struct Emu {
   // per-environment world geoms (one environment here): slot table + the 16 values per declared geom
   std::vector<int> eg_slot; std::vector<double> eg64; std::vector<float> eg32;
   std::vector<double> nsA;      // noslip matrix (global memory on the device)
+  int kstash_on = 0; std::vector<double> kstash; std::vector<int> kstash_i;      // kinematic stash (doubles: room for either precision)
   std::vector<double> gs;       // the environment's global scratch (persists between launches, like the device buffer)
   std::vector<double> xfrc64; std::vector<float> xfrc32;      // xfrc_applied (6 nbody), empty = not set
 };
@@ -45,6 +46,7 @@ int emu_dims(void* h, int* out) {
 }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
+void emu_kstash(void* h, int on) { Emu* e = (Emu*)h; const StepLayout& L = e->tb.L; e->kstash_on = on; e->kstash.assign(L.d.nq + L.d.nv + (L.s_qM - L.s_xpos) + 4, 0.0); e->kstash_i.assign(2, 0); }
 void emu_set_xfrc(void* h, const double* x) { Emu* e = (Emu*)h; e->xfrc64.assign(x, x + 6*e->hm.nbody); e->xfrc32.assign(x, x + 6*e->hm.nbody); }
 void emu_set_env_geoms(void* h, int n, const int* ids, const double* data) {
   Emu* e = (Emu*)h;
@@ -92,6 +94,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }
   if (!e->eg_slot.empty()) { o.eg_slot = e->eg_slot.data(); o.eg_n = (int)e->eg64.size() / 16; o.eg_B = 1; o.eg_data = sizeof(T) == 8 ? (const void*)e->eg64.data() : (const void*)e->eg32.data(); }
   io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
+  io.kstash = e->kstash_on ? (T*)e->kstash.data() : nullptr; io.kstash_i = e->kstash_on ? e->kstash_i.data() : nullptr;
   if (e->stash_on) { io.stash_r = sizeof(T) == 8 ? (T*)e->stash_r64.data() : (T*)e->stash_r32.data(); io.stash_i = e->stash_i.data(); }
   DynLayoutSrc ls; ls.p = &L;
   StepCore<T, 1> core(ls, o, e->tb.mi.data(), mr, e->tb.mc.data(), s.data(), si.data(), 0);

@@ -33,6 +33,7 @@ def lib():
     L.emu_free.argtypes = [ctypes.c_void_p]
     L.emu_stash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_invalidate.argtypes = [ctypes.c_void_p]
+    L.emu_kstash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_set_xfrc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_set_env_geoms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -91,6 +92,11 @@ class EmuPhysics:
   def stash(self, on=True):
     """Keeps the position / velocity stage between legacy steps (the HBM stash of the GPU batch)."""
     lib().emu_stash(self.h, int(on))
+
+  def kstash(self, on=True):
+    """Keeps kinematics / COM frame / velocities between legacy steps (the kinematic stash of the GPU batch, on by
+    default there)."""
+    lib().emu_kstash(self.h, int(on))
 
   def invalidate(self):
     lib().emu_invalidate(self.h)

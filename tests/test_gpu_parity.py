@@ -895,3 +895,42 @@ def test_xfrc_applied_on_gpu(precision, tol):
   b.reset()
   assert not b.get('xfrc_applied').any()            # mj_resetData zeroes it
   b.close()
+
+
+@pytest.mark.parametrize('asset,nsub', [('cheetah', 1), ('humanoid', 2)])
+def test_kinematic_stash_bit_identical_and_notices_silent_edits(asset, nsub, monkeypatch):
+  """The kinematic stash (on by default) keeps poses / COM frame / velocities between legacy steps together with the
+  (qpos, qvel) they belong to.  Same trajectories bit for bit as without it, including after the state was rewritten
+  directly in device memory (a torch tensor, no dmc_batch_set, no invalidate)."""
+  import torch
+  m = _model(asset)
+  B = 64
+  rs = np.random.RandomState(1)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, -4:] += rs.uniform(-0.2, 0.2, (B, 4))
+  acts = rs.uniform(-1, 1, (12, B, m.nu))
+  out = {}
+  for mode in ('on', 'off'):
+    monkeypatch.delenv('DMC_NO_KSTASH', raising=False)
+    if mode == 'off':
+      monkeypatch.setenv('DMC_NO_KSTASH', '1')
+    b = _batch(m, B, precision=32)
+    b.set('qpos', q)
+    rows = []
+    qdev = torch.empty((m.nq, B), dtype=torch.float32, device='cuda')      # SoA: (rows, B)
+    for t, a in enumerate(acts):
+      if t == 5:
+        # from here on qpos lives in a torch tensor; its first write is a silent edit of the state
+        qdev.copy_(torch.as_tensor(b.get('qpos').T.copy(), device='cuda'))
+        b.bind('qpos', qdev.data_ptr())
+      if t == 8:
+        qdev[-1, :] += 0.05
+        torch.cuda.synchronize()
+      b.set_control(a)
+      b.step(nsub)
+      rows.append((b.get('qpos').copy(), b.get('qvel').copy(), b.get('sensordata').copy(), b.get('xpos').copy()))
+    out[mode] = rows
+    b.close()
+  for t, (x, y) in enumerate(zip(out['on'], out['off'])):
+    for u, v in zip(x, y):
+      np.testing.assert_array_equal(u, v, err_msg='step %d' % t)

@@ -485,6 +485,39 @@ def test_stash_between_legacy_steps_is_bit_identical(asset):
   assert np.abs(a.qpos - q).max() > 1e-3
 
 
+@pytest.mark.parametrize('asset,prec', [('cheetah', 64), ('cheetah', 32), ('humanoid', 64), ('cartpole', 64), ('quadruped', 64),
+                                        ('cmu_2019_position_floor', 64)])
+def test_kinematic_stash_is_bit_identical_and_self_validating(asset, prec):
+  """The kinematic stash (poses, COM frame, velocities kept between legacy steps together with the (qpos, qvel) they
+  belong to) must not change a single bit of the trajectory, and must notice by itself when the state was edited
+  behind its back (writes to bound device tensors are not announced to the library)."""
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    m = mc.compile_xml(f.read())
+  a, b = EmuPhysics(m, prec), EmuPhysics(m, prec)
+  b.kstash(True)
+  rs = np.random.RandomState(2)
+  q = m.qpos0.copy()
+  if asset != 'cartpole':
+    q[-4:] += rs.uniform(-.2, .2, 4)
+  for e in (a, b):
+    e.qpos[:] = q
+  for t in range(40):
+    c = rs.uniform(-1, 1, m.nu)
+    for e in (a, b):
+      e.ctrl[:] = c
+      e.step(1 + t % 3)
+    for name in ('qpos', 'qvel', 'sensordata', 'xpos', 'xmat', 'geom_xpos', 'subtree_com', 'qacc', 'contact_dist'):
+      np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg='%s step %d' % (name, t))
+    if t == 20:      # a silent edit of the state (no invalidate): the stored (qpos, qvel) no longer match
+      for e in (a, b):
+        e.qpos[:] = q
+        e.qvel[:] = 0.1
+    if t == 30:      # velocities only
+      for e in (a, b):
+        e.qvel[:] *= 0.5
+  assert np.abs(a.qpos - q).max() > 1e-3
+
+
 @pytest.mark.parametrize('asset', ['cheetah', 'humanoid', 'hopper'])
 def test_step1_step2_entry_points(asset):
   """mj_step1 and mj_step2 as separate calls (engine.py:156-162): step1; step2 is exactly mj_step, the derived
