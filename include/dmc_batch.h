@@ -146,7 +146,11 @@ int dmc_batch_sync(dmc_batch* b);
  * step launch does not recompute it.  Every entry point of this
  * library that edits state, model or options invalidates the stash itself.  A caller that writes qpos / qvel /
  * act through memory it bound with dmc_batch_bind must call this afterwards (the reference's equivalent:
- * derived quantities are stale until mj_forward is run). */
+ * derived quantities are stale until mj_forward is run).
+ * Independently of that option every batch keeps a small KINEMATIC stash (poses, COM frame, velocities -- what
+ * mj_kinematics / mj_comPos / mj_comVel derive from qpos and qvel) between legacy steps; it is stored with the
+ * (qpos, qvel) it was computed at and reused only when the next launch finds exactly that state, so it needs no
+ * invalidation by the caller (DMC_NO_KSTASH=1 in the environment disables it). */
 int dmc_batch_invalidate(dmc_batch* b);
 
 /* Observation gather table: what composer's observation.Updater does per control step for MJCFFeature observables
