@@ -3169,33 +3169,11 @@ struct StepCore {
   template <int N>
   DMC_DEV T noslip_block(int a, int nf, int t, int id) {
     T Ac[N*N], old[N], bres[N], fnew[N];
-    // One wave per environment and at most 128 friction dimensions: the rows a .. a+N-1 of A, which the residual
-    // update needs AFTER the block is solved, are requested from global memory now (lane b holds columns b, b + 64),
-    // so that their round trip overlaps the solve; the N x N diagonal block itself comes from the LDS band.  (Loading
-    // block and rows one after the other cost two dependent L2 round trips per block: most of the noslip time once
-    // the QCQP was cheap.)
-#ifndef DMC_HOST_EMU
-    const bool rows = LPE == 64 && nf <= 128;
-#else
-    const bool rows = false;
-#endif
-    T r0[N], r1[N];
-#pragma unroll
-    for (int p = 0; p < N; p++) { r0[p] = 0; r1[p] = 0; }
-    if (rows) {
-      const DMC_GLB T* A = (const DMC_GLB T*)ns_A();
-#pragma unroll
-      for (int p = 0; p < N; p++) {
-        const DMC_GLB T* Ap = A + (a + p)*L.d.nslip;
-        if (lane < nf) r0[p] = Ap[lane];
-        if (lane + 64 < nf) r1[p] = Ap[lane + 64];
-      }
-    }
 #pragma unroll
     for (int p = 0; p < N; p++) {
       old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
 #pragma unroll
-      for (int q = 0; q < N; q++) Ac[p*N + q] = S(ns_band)[(a + (p < q ? p : q))*L.d.nsblk + (p < q ? q - p : p - q)];
+      for (int q = 0; q < N; q++) Ac[p*N + q] = ns_A()[(a + p)*L.d.nslip + a + q];
     }
     if (N == 1) {
       const T fl = MR(dof_frictionloss)[id];
@@ -3254,24 +3232,11 @@ struct StepCore {
       change = 0;
     }
     DMC_WSYNC();
-    if (rows) {
-      // same operations per entry as the loop below (res += A[a+p][b] * delta for p in order, zero deltas skipped)
-      T acc0 = lane < nf ? S(ns_res)[lane] : (T)0, acc1 = lane + 64 < nf ? S(ns_res)[lane + 64] : (T)0;
 #pragma unroll
-      for (int p = 0; p < N; p++) {
-        const T delta = fnew[p] - old[p];
-        if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
-        if (delta != 0) { acc0 += r0[p]*delta; acc1 += r1[p]*delta; }
-      }
-      if (lane < nf) S(ns_res)[lane] = acc0;
-      if (lane + 64 < nf) S(ns_res)[lane + 64] = acc1;
-    } else {
-#pragma unroll
-      for (int p = 0; p < N; p++) {
-        const T delta = fnew[p] - old[p];
-        if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
-        if (delta != 0) { const T* Ap = ns_A() + (a + p)*L.d.nslip; for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += Ap[b]*delta; }
-      }
+    for (int p = 0; p < N; p++) {
+      const T delta = fnew[p] - old[p];
+      if (lane == 0) S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
+      if (delta != 0) { const T* Ap = ns_A() + (a + p)*L.d.nslip; for (int b = lane; b < nf; b += LPE) S(ns_res)[b] += Ap[b]*delta; }
     }
     DMC_WSYNC();
     return change;
@@ -3308,10 +3273,7 @@ struct StepCore {
       }
       if (own) S(sv_Mgrad)[i] = sreg;
       DMC_WSYNC();
-      for (int a = b + lane; a < nf; a += LPE) {
-        const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v;
-        if (a - b < L.d.nsblk) S(ns_band)[b*L.d.nsblk + a - b] = v;
-      }
+      for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; }
       DMC_WSYNC();
     }
   }
@@ -3346,10 +3308,7 @@ struct StepCore {
       DMC_WSYNC();
       chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv);
       { T* A = ns_A(); const int cap = L.d.nslip;
-        for (int a = b + lane; a < nf; a += LPE) {
-          const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v;
-          if (a - b < L.d.nsblk) S(ns_band)[b*L.d.nsblk + a - b] = v;
-        } }
+        for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
     }
     for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = row_dot(ra, S(qacc), rm) - S(efc_aref)[ra]; }

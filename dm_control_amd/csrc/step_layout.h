@@ -46,7 +46,6 @@ struct StepDims {
   int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
   int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
   int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
-  int nsblk;     // noslip: widest Gauss-Seidel block (friction dimensions solved together: 1, 2, 3 or 5)
   int jfull;     // 1 (nv <= 16): EVERY constraint row is stored as a dense row of nv entries in efc_Jd (row classes and
                  //   compression pay off for long chains; on a 9-dof model their index arithmetic cost 10 % of the step)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
@@ -182,9 +181,7 @@ struct StepDims {
   X(efc_ca, d.elliptic * d.njmax) X(efc_cb, d.elliptic * d.njmax)              \
   X(efc_cg, d.elliptic * d.njmax)                                              \
   /* noslip: the running residual (A = J_F M^-1 J_F^T itself lives in global memory, StepOpts::ns_A) */ \
-  X(ns_res, d.nslip)                                                           \
-  /* noslip: the band A[i][i + d], d < nsblk -- the diagonal blocks the Gauss-Seidel sweeps read (the rest of A: global) */ \
-  X(ns_band, d.nslip * d.nsblk)
+  X(ns_res, d.nslip)
 #define STEP_SCRATCH_ALL_REAL(X) \
   STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 

@@ -227,10 +227,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     int maxfr = 0;
     for (int p = 0; p < m.npair; p++) if (pdim[p] > 1) maxfr = std::max(maxfr, elliptic ? pdim[p] - 1 : 2*(pdim[p] - 1));
     d.nslip = std::min(njmax, d.nfric + nconmax * maxfr);
-    // widest Gauss-Seidel block: an elliptic contact's friction dimensions together, a pyramidal edge pair, a dof row
-    int blk = d.nfric ? 1 : 0;
-    for (int p = 0; p < m.npair; p++) if (pdim[p] > 1) blk = std::max(blk, elliptic ? pdim[p] - 1 : 2);
-    d.nsblk = std::max(1, blk);
   }
   // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
   // one-nonzero friction / joint-limit rows, kmax entries per contact row
