@@ -35,6 +35,14 @@ for mn in cheetah:1 humanoid:5 cmu_2019_position_floor:6 soccer_2v2_boxhead:5; d
   cp gpurun_out/phase_${mn%%:*}.json gpurun_out/profiles_new/r02_phase_${mn%%:*}.json
 done
 GRAPH=1 T=300 timeout 900 python scripts/composer_runs.py > gpurun_out/composer_runs.log 2>&1; echo "composer rc=$?"; cut -c1-330 gpurun_out/composer_runs.log | tail -8
+T=300 timeout 1500 python scripts/soak.py > gpurun_out/soak.log 2>&1; echo "soak rc=$?"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/soak.json'))
+print('soak tasks', len(d), 'errors', [r for r in d if 'error' in r][:3], 'nonzero warnings', [(r['task'], r['warnings']) for r in d if 'warnings' in r and sum(r['warnings'])])
+PY
+cp gpurun_out/soak.json gpurun_out/profiles_new/r02_soak_all_tasks.json
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()"; echo "smoke rc=$?"
 cp profiles/r02_bench_cfg*.json profiles/r02_kernel_stats_cfg*.json profiles/r02_pmc_cfg*.json gpurun_out/profiles_new/
 cp gpurun_out/composer_runs.json gpurun_out/profiles_new/r02_composer_runs.json 2>/dev/null
 ls gpurun_out/profiles_new
