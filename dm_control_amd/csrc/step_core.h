@@ -3006,6 +3006,9 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(sv_Ma)[i] - S(qfrc_smooth)[i] - S(qfrc_constraint)[i];
     DMC_PROF(PROF_SOL_GRAD);
+    // CG (mj_solPrimal with flg_Newton = 0): the gradient preconditioned with M^-1 -- the factor mj_factorM left
+    // (no Hessian is ever assembled, so it is still in place)
+    if (L.d.cg) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
     hess_assemble(nefc, row_map());
     DMC_PROF(PROF_HESS);
@@ -3389,14 +3392,27 @@ struct StepCore {
       for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
       DMC_WSYNC();
       const T oldcost = cost;
+      if (L.d.cg) FOR_LANES(i, nv) { S(sv_gold)[i] = S(sv_grad)[i]; S(sv_Mgold)[i] = S(sv_Mgrad)[i]; }
       cc = constraint_update(nefc, &changed);
       gauss = gauss_cost();
       cost = cc + gauss;
       DMC_PROF(PROF_SOL_UPD);
       newton_gradient(nefc, changed);
       DMC_PROF(PROF_SOL_GRAD);
+      T beta = 0;
+      if (L.d.cg) {      // Polak-Ribiere, restarted when negative
+        T num = 0, den = 0;
+        FOR_LANES(i, nv) { num += S(sv_grad)[i]*(S(sv_Mgrad)[i] - S(sv_Mgold)[i]); den += S(sv_gold)[i]*S(sv_Mgold)[i]; }
+        num = group_sum<LPE>(num); den = group_sum<LPE>(den);
+        beta = num / t_max((T)DMC_MINVAL, den);
+        if (beta < 0) beta = 0;
+      }
       T g2 = 0, ma2 = 0;
-      FOR_LANES(i, nv) { S(sv_search)[i] = -S(sv_Mgrad)[i]; g2 += S(sv_grad)[i]*S(sv_grad)[i]; ma2 += S(sv_Ma)[i]*S(sv_Ma)[i]; }
+      FOR_LANES(i, nv) {
+        T sr = -S(sv_Mgrad)[i];
+        if (L.d.cg) sr += beta*S(sv_search)[i];
+        S(sv_search)[i] = sr; g2 += S(sv_grad)[i]*S(sv_grad)[i]; ma2 += S(sv_Ma)[i]*S(sv_Ma)[i];
+      }
       g2 = group_sum<LPE>(g2); ma2 = group_sum<LPE>(ma2);
       DMC_WSYNC();
       const T improvement = scale*(oldcost - cost), gradient = scale*t_sqrt(g2);

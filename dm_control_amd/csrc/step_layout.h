@@ -46,6 +46,7 @@ struct StepDims {
   int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
   int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
   int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
+  int cg;        // 1: option solver="CG" (conjugate gradient on the same primal problem, preconditioned with M^-1)
   int jfull;     // 1 (nv <= 16): EVERY constraint row is stored as a dense row of nv entries in efc_Jd (row classes and
                  //   compression pay off for long chains; on a 9-dof model their index arithmetic cost 10 % of the step)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
@@ -175,6 +176,7 @@ struct StepDims {
 #define STEP_SCRATCH_OVL_SOL(X)                                                \
   X(sv_Ma, d.nv) X(sv_Mv, d.nv) X(sv_grad, d.nv) X(sv_Mgrad, d.nv)             \
   X(sv_search, d.nv) X(efc_jar, d.njmax) X(efc_jv, d.njmax)                    \
+  X(sv_gold, d.cg * d.nv) X(sv_Mgold, d.cg * d.nv)  /* CG: gradient and M^-1 gradient of the previous iterate */                    \
   /* M v through the tree (mul_M, sparse-M models): per-body spatial force of the acceleration field of v */ \
   X(sv_bf, d.msparse * 6 * d.nbody)                                            \
   /* elliptic cones: per-row coefficients of the middle-zone Hessian (newton_gradient) */ \

@@ -2098,6 +2098,15 @@ static void newton_gradient(const Model* m, Data* d) {
   chol_factor(L, H, nv);
   chol_solve(d->w_Mgrad, L, d->w_grad, nv);
 }
+/* CG (mjSOL_CG, engine_solver.c mj_solPrimal with flg_Newton = 0): same cost, line search and stopping tests as
+ * Newton; the gradient is preconditioned with M^-1 (mj_solveM on the factor mj_factorM left in qL) instead of H^-1. */
+static void cg_gradient(const Model* m, Data* d) {
+  int nv = m->nv, nefc = d->nefc;
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
+  for (int i = 0; i < nv; i++) d->w_grad[i] = d->w_Ma[i] - d->qfrc_smooth[i] - d->qfrc_constraint[i];
+  chol_solve(d->w_Mgrad, d->qL, d->w_grad, nv);
+}
 static double total_cost(const Model* m, Data* d, double constraint_cost, double* gauss_out) {
   int nv = m->nv; double g = 0;
   for (int i = 0; i < nv; i++) g += (d->w_Ma[i] - d->qfrc_smooth[i]) * (d->qacc[i] - d->qacc_smooth[i]);
@@ -2257,7 +2266,9 @@ static void fwd_constraint(const Model* m, Data* d) {
   for (int i = 0; i < nv; i++) Ma[i] = dot_n(d->qM + (size_t)i*nv, d->qacc, nv);
   for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc, nv) - d->efc_aref[i];
   double gauss, cost = total_cost(m, d, constraint_update(m, d, jar, 0), &gauss);
-  newton_gradient(m, d);
+  const int cg = m->opt_solver == DMC_SOL_CG;
+  double *gradold = d->w_H, *Mgradold = d->w_H + nv;      /* CG only: w_H is free (no Hessian) */
+  if (cg) cg_gradient(m, d); else newton_gradient(m, d);
   for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i];
   int iter = 0;
   while (iter < m->opt_iterations) {
@@ -2266,9 +2277,20 @@ static void fwd_constraint(const Model* m, Data* d) {
     for (int i = 0; i < nv; i++) { d->qacc[i] += alpha*d->w_search[i]; Ma[i] += alpha*d->w_Mv[i]; }
     for (int i = 0; i < nefc; i++) jar[i] += alpha*d->w_Jv[i];
     double oldcost = cost;
+    if (cg) { memcpy(gradold, d->w_grad, sizeof(double) * (size_t)nv); memcpy(Mgradold, d->w_Mgrad, sizeof(double) * (size_t)nv); }
     cost = total_cost(m, d, constraint_update(m, d, jar, 0), &gauss);
-    newton_gradient(m, d);
-    for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i];
+    if (cg) {
+      cg_gradient(m, d);
+      /* Polak-Ribiere, restarted when negative */
+      double num = 0, den = 0;
+      for (int i = 0; i < nv; i++) { num += d->w_grad[i]*(d->w_Mgrad[i] - Mgradold[i]); den += gradold[i]*Mgradold[i]; }
+      double beta = num / mjMAX(MINVAL, den);
+      if (beta < 0) beta = 0;
+      for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i] + beta*d->w_search[i];
+    } else {
+      newton_gradient(m, d);
+      for (int i = 0; i < nv; i++) d->w_search[i] = -d->w_Mgrad[i];
+    }
     double improvement = scale*(oldcost - cost);
     double gradient = scale*sqrt(dot_n(d->w_grad, d->w_grad, nv));
     iter++;

@@ -934,3 +934,44 @@ def test_kinematic_stash_bit_identical_and_notices_silent_edits(asset, nsub, mon
   for t, (x, y) in enumerate(zip(out['on'], out['off'])):
     for u, v in zip(x, y):
       np.testing.assert_array_equal(u, v, err_msg='step %d' % t)
+
+
+@pytest.mark.parametrize('asset,precision,teacher,tol', [('cheetah', 64, False, 1e-9), ('humanoid', 64, False, 1e-5),
+                                                         ('cheetah', 32, True, 1e-3), ('humanoid', 32, True, 2e-3)])
+def test_cg_solver_on_device(asset, precision, teacher, tol):
+  """option solver="CG" on the device (generic kernel: the baked layouts are Newton's) against the oracle.  CG stops at
+  the solver tolerance instead of converging quadratically, so two implementations agree per step to ~1e-8 of the
+  acceleration scale, not to rounding: fp64 open loop over 60 steps (measured 8e-15 cheetah, 1.6e-6 humanoid), fp32
+  teacher-forced (measured 1.1e-4 / 5.6e-4 per step: in fp32 the conjugate directions lose orthogonality to rounding
+  and the iteration stops on its floors; the production solver is Newton).  PGS is refused at batch creation."""
+  from dm_control_amd import _native
+  from oracle import oracle
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    xml = f.read()
+  m = mc.compile_xml(xml.replace('<option', '<option solver="CG" iterations="100"', 1))
+  B, T = 16, 60
+  rs = np.random.RandomState(5)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, -3:] += rs.uniform(-0.3, 0.3, (B, 3))
+  b = _batch(m, B, precision=precision)
+  assert b.info()['static_id'] == -1
+  b.set('qpos', q)
+  refs = _oracles(m, q)
+  worst, iters = 0.0, 0
+  for t in range(T):
+    a = rs.uniform(-1, 1, (B, m.nu))
+    if teacher:
+      b.set('qpos', np.stack([p.qpos for p in refs]))
+      b.set('qvel', np.stack([p.qvel for p in refs]))
+      b.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+    b.set_control(a)
+    b.step()
+    oracle.rollout_legacy(refs, a[None])
+    worst = max(worst, _rel_err(b.get('qpos'), np.stack([p.qpos for p in refs])))
+    iters = max(iters, int(b.get('solver_iter').max()))
+  print('measured: cg %s fp%d %s max rel dqpos=%.3g, max iterations %d' % (asset, precision, 'teacher-forced' if teacher else 'open loop', worst, iters))
+  assert worst < tol, worst
+  assert iters > 4 and not b.get('warning').any()
+  b.close()
+  with pytest.raises(_native.NativeError, match='PGS'):
+    _batch(mc.compile_xml(xml.replace('<option', '<option solver="PGS"', 1)), 4)

@@ -126,6 +126,28 @@ def test_newton_answer_minimises_the_documented_cost_pyramidal(asset, seed):
   assert checked >= 5
 
 
+@pytest.mark.parametrize('asset', ['cheetah', 'hopper'])
+def test_cg_answer_minimises_the_documented_cost(asset):
+  """option solver="CG": a different iteration on the SAME documented cost -- the generic minimiser must land on
+  its answer too (the restated Polak-Ribiere / M^-1 preconditioning is otherwise pinned only against itself)."""
+  xml = common.read_model(asset + '.xml').replace('<option', '<option solver="CG" iterations="200" tolerance="1e-10"', 1)
+  m = mc.compile_xml(xml)
+  assert m.opt.solver == 1
+  o = OraclePhysics(m)
+  rs = np.random.RandomState(3)
+  o.qpos[:] = m.qpos0
+  o.qpos[-4:] += rs.uniform(-.3, .3, 4)
+  checked = 0
+  for t in range(120):
+    o.ctrl[:] = rs.uniform(-1, 1, m.nu)
+    o.step()
+    if t % 15 == 14 and o.nefc > 0:
+      o.forward()
+      _check_minimiser(m, o, 2e-5)
+      checked += 1
+  assert checked >= 4
+
+
 _ELL = """<mujoco><option cone="elliptic" impratio="{imp}" gravity="1.5 .4 -9.81"/>
 <default><geom friction=".8 .03 .002" condim="{cd}"/></default><worldbody>
  <geom type="plane" size="3 3 .1"/>

@@ -645,3 +645,62 @@ def test_xfrc_applied_matches_oracle(asset, prec, tol):
   for t in range(150):
     o2.ctrl[:] = rs.uniform(-1, 1, m.nu); o2.step()
   assert np.abs(np.array(o2.qpos) - np.array(o.qpos)).max() > 1e-2
+
+
+def _with_option(asset, **attrs):
+  with open(os.path.join(ASSETS, asset + '.xml')) as f:
+    xml = f.read()
+  return xml.replace('<option', '<option ' + ' '.join('%s="%s"' % kv for kv in attrs.items()), 1)
+
+
+@pytest.mark.parametrize('asset,prec,tol', [('cheetah', 64, 1e-10), ('cheetah', 32, 5e-4), ('humanoid', 64, 1e-9), ('hopper', 64, 1e-10)])
+def test_cg_solver_matches_oracle(asset, prec, tol):
+  """option solver="CG" (mj_solPrimal with flg_Newton = 0: gradient preconditioned with M^-1, Polak-Ribiere
+  directions, the same line search and stopping tests): kernel core vs oracle, open loop."""
+  m = mc.compile_xml(_with_option(asset, solver='CG', iterations='100'))
+  assert m.opt.solver == 1
+  o, e = OraclePhysics(m), EmuPhysics(m, prec)
+  rs = np.random.RandomState(5)
+  q = m.qpos0.copy()
+  q[-3:] += rs.uniform(-0.3, 0.3, 3)
+  o.qpos[:] = q
+  e.qpos[:] = q
+  o.forward()
+  e.forward()
+  iters = []
+  for t in range(60):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    iters.append(int(e.solver_iter[0]))
+    err = np.abs(o.qpos - e.qpos).max() / max(1.0, np.abs(o.qpos).max())
+    assert err < tol, (t, err)
+    if prec == 64:
+      assert o.solver_iter == e.solver_iter[0], (t, o.solver_iter, e.solver_iter)
+  assert max(iters) > 4      # CG takes more iterations than Newton ever does on these models
+
+
+def test_cg_reaches_the_newton_solution_and_pgs_is_rejected():
+  """Both solvers minimise the same convex cost: at a tight tolerance their accelerations agree; PGS (the dual
+  solver) is not implemented and is refused, never silently replaced."""
+  mN = mc.compile_xml(_with_option('cheetah', iterations='200', tolerance='1e-12'))
+  mC = mc.compile_xml(_with_option('cheetah', solver='CG', iterations='200', tolerance='1e-12'))
+  rs = np.random.RandomState(0)
+  for k in range(10):
+    q = mN.qpos0.copy()
+    q[1] = rs.uniform(-0.65, -0.3)
+    q[2] = rs.uniform(-1, 1)
+    q[3:] += rs.uniform(-0.4, 0.4, 6)
+    v = rs.uniform(-2, 2, mN.nv)
+    a, b, e = OraclePhysics(mN), OraclePhysics(mC), EmuPhysics(mC, 64)
+    for p in (a, b, e):
+      p.qpos[:], p.qvel[:], p.ctrl[:] = q, v, 0.3
+      p.forward()
+    scale = max(1.0, np.abs(a.qacc).max())
+    assert a.nefc > 0
+    assert np.abs(a.qacc - b.qacc).max() / scale < 1e-6
+    assert np.abs(b.qacc - e.qacc).max() / scale < 1e-6      # at this tolerance the kernel's rounding floor on the stopping tests ends CG a few iterations earlier
+  with pytest.raises(Exception, match='PGS'):
+    EmuPhysics(mc.compile_xml(_with_option('cheetah', solver='PGS')), 64)
