@@ -3356,27 +3356,38 @@ struct StepCore {
       DMC_WSYNC();
       return;
     }
+    // Warm start (mj_solPrimal / warmstart()): keep qacc_warmstart only if its cost beats qacc_smooth's.  qacc_smooth is
+    // evaluated first, so that when the warm start wins -- the usual case -- its M a, J a - aref, forces, active set and
+    // cost are already those the solver starts from (they used to be recomputed: a third of the solver's set-up).
+    int changed = 1;
+    T cc = 0, gauss = 0;
+    bool evaluated = false;
     if (!(o.disableflags & DMC_DSBL_WARMSTART)) {
+      jar_from(S(qacc_smooth), nefc);
+      DMC_WSYNC();
+      const T cs = constraint_update(nefc);      // Gauss term is zero at qacc_smooth
       FOR_LANES(i, nv) S(qacc)[i] = S(qacc_warmstart)[i];
       DMC_WSYNC();
       jar_from(S(qacc), nefc);
       mul_M(S(sv_Ma), S(qacc));
       DMC_WSYNC();
-      const T cw = constraint_update(nefc) + gauss_cost();
-      jar_from(S(qacc_smooth), nefc);
-      DMC_WSYNC();
-      const T cs = constraint_update(nefc);
-      if (cw > cs) FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
+      for (int i = lane; i < nefc; i += LPE) SI(efc_active)[i] = -1;   // no factor of H yet
+      cc = constraint_update(nefc, &changed);
+      gauss = gauss_cost();
+      if (cc + gauss > cs) FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
+      else evaluated = true;
     } else FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
     DMC_WSYNC();
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
-    mul_M(S(sv_Ma), S(qacc));
-    jar_from(S(qacc), nefc);
-    DMC_WSYNC();
-    int changed = 1;
-    for (int i = lane; i < nefc; i += LPE) SI(efc_active)[i] = -1;   // no factor of H yet
-    T cc = constraint_update(nefc, &changed);
-    T gauss = gauss_cost();
+    if (!evaluated) {
+      mul_M(S(sv_Ma), S(qacc));
+      jar_from(S(qacc), nefc);
+      DMC_WSYNC();
+      changed = 1;
+      for (int i = lane; i < nefc; i += LPE) SI(efc_active)[i] = -1;   // no factor of H yet
+      cc = constraint_update(nefc, &changed);
+      gauss = gauss_cost();
+    }
     T cost = cc + gauss;
     DMC_PROF(PROF_SOL_INIT);
     newton_gradient(nefc, 1);
