@@ -38,3 +38,30 @@ def test_random_model_emulation_matches_oracle(seed, ellipsoids, noslip):
   np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-6 * scale)
   np.testing.assert_allclose(o.sensordata, e.sensordata, rtol=0, atol=1e-6 * max(1.0, np.abs(o.sensordata).max()))
   np.testing.assert_array_equal(o.warning, e.warning)
+
+
+@pytest.mark.parametrize('seed,ellipsoids,noslip', [(s, s % 3 == 0, 0) for s in range(100, 112)] + [(s, False, 3) for s in range(112, 116)])
+def test_random_model_cg_solver_matches_oracle(seed, ellipsoids, noslip):
+  """The same fuzzing with option solver="CG": elliptic and pyramidal cones, several trees, noslip after CG."""
+  xml = random_model_xml(seed, ellipsoids, noslip)
+  assert '<option' in xml
+  m = mc.compile_xml(xml.replace('<option', '<option solver="CG"', 1))
+  assert m.opt.solver == 1
+  o, e = OraclePhysics(m), EmuPhysics(m, 64)
+  rs = np.random.RandomState(2000 + seed)
+  v = rs.uniform(-.5, .5, m.nv)
+  o.qvel[:] = v
+  e.qvel[:] = v
+  o.forward()
+  for t in range(100):
+    c = rs.uniform(-1, 1, m.nu)
+    o.ctrl[:] = c
+    e.ctrl[:] = c
+    o.step()
+    e.step()
+    assert o.ncon == e.ncon[0], (t, o.ncon, e.ncon)
+  # CG stops at the solver tolerance instead of converging quadratically: the two restatements agree per step to ~1e-8
+  # of the acceleration scale, and contacts amplify that
+  scale = max(1.0, np.abs(o.qpos).max())
+  np.testing.assert_allclose(o.qpos, e.qpos, rtol=0, atol=1e-4 * scale)
+  np.testing.assert_array_equal(o.warning, e.warning)
