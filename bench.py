@@ -23,12 +23,27 @@ no data-path collective, `value` is measured with every rank stepping its shard 
 GPU (weak scaling).  The agent-interface exchange (actions scattered from rank 0, observations gathered to every
 rank over RCCL) is timed as a separate leg and reported under "collectives".
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this file under `torch.distributed.run` with N
+ranks on 127.0.0.1 (one GPU each); under a launcher the world size must equal --gpus or the run fails.  On a box with
+fewer than N GPUs the run fails too, unless DMC_BENCH_SINGLE_DEVICE=1 (+ DMC_BENCH_BACKEND=gloo) asks for all ranks on
+cuda:0 -- a harness check, not a measurement.
+
+roofline.traffic and roofline_issue are measured IN THE RUN when rocprofv3 is on the PATH (N = 1): the bench re-runs
+itself (`--pmc-child`: same workload, 30 steps, nothing else) under `rocprofv3 --kernel-trace --pmc <counters>` once per
+counter group -- FETCH_SIZE and WRITE_SIZE in separate passes, reads x 2 as MI355X_MICROARCH.md prescribes for gfx950
+-- and reads the timed launches' rows from the csv.  DMC_BENCH_NO_PMC=1 (or an enclosing rocprofv3) skips the passes;
+the line then carries the committed counters of profiles/ and says so in `traffic_source`.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -38,12 +53,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024                       # 256 CUs x 4 SIMDs
+# issue cost of one wave64 fp32 VALU instruction on a CDNA4 SIMD: 2 cycles (MI355X_MICROARCH.md "Wave scheduling" and the
+# measured v_fma_f32 row of "Per-instruction cycle constants": 157 TF fp32 = 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz).
+# The SQ counters tick in quad-cycles (same table, s_memtime row); round 2 priced an instruction at one quad-cycle = 4.
+VALU_CYCLES_PER_INST = 2
+PMC_PASSES = (('FETCH_SIZE',), ('WRITE_SIZE',),
+              ('SQ_INSTS_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'))
 METRIC = 'env-steps/s (whole node) at batch 4096; max rel qpos error vs CPU'
 
 # algo_bytes: SURVEY.md 8(d) compulsory bytes per env per launch, fp32 SoA with the state kept on chip across the
 # substeps: 4 [ (nq + nv + nv_warm + nu) read + (nq + nv + nv_warm + nsensordata) written ] + 8 (time)
 CONFIGS = {
-    2: dict(asset='cheetah', nsub=1, batch=4096, algo_bytes=260, outputs=('sensor',), parity_envs=64, parity_steps=200,
+    2: dict(asset='cheetah', nsub=1, batch=4096, algo_bytes=260, outputs=('sensor',), parity_envs=64, parity_steps=1000,
             workload="suite 'cheetah run'"),
     3: dict(asset='humanoid', nsub=5, batch=4096, algo_bytes=1012, outputs=('sensor', 'xpos', 'xmat', 'subtree_com'),
             parity_envs=64, parity_steps=100, workload="suite 'humanoid stand'"),
@@ -54,7 +75,7 @@ CONFIGS = {
 }
 
 
-def parse():
+def parse(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
   ap.add_argument('--gpus', type=int, default=1)
@@ -68,7 +89,79 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-envs', type=int, default=4096)
   ap.add_argument('--cpu-seconds', type=float, default=10.0)
-  return ap.parse_args()
+  ap.add_argument('--pmc-child', action='store_true', help='internal: only the timed launches (run under rocprofv3 by the parent)')
+  return ap.parse_args(argv)
+
+
+def launch_command(args, argv, port):
+  """The command `--gpus N` (N > 1, no launcher in the environment) re-executes: N ranks of this file on 127.0.0.1."""
+  return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(args, world, n_devices, single_device):
+  """--gpus is a contract, not a hint: the world must be exactly N ranks and (outside the single-device harness
+  mode) the box must have N GPUs."""
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+  if not single_device and n_devices < args.gpus:
+    raise SystemExit('bench.py: --gpus %d but only %d GPU(s) are visible (DMC_BENCH_SINGLE_DEVICE=1 with '
+                     'DMC_BENCH_BACKEND=gloo runs all ranks on cuda:0 as a harness check)' % (args.gpus, n_devices))
+
+
+def free_port():
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    return sk.getsockname()[1]
+
+
+def collect_pmc(args, K):
+  """HBM bytes and SQ counters per timed launch, measured now: this file re-run as `--pmc-child` under rocprofv3, one
+  pass per counter group (separate --pmc passes, --kernel-trace only beside them).  Returns (dict, why-not)."""
+  exe = shutil.which('rocprofv3')
+  if os.environ.get('DMC_BENCH_NO_PMC'):
+    return None, 'DMC_BENCH_NO_PMC set'
+  if exe is None:
+    return None, 'rocprofv3 not on PATH'
+  if any(k.startswith('ROCPROF') or k.startswith('ROCP_') for k in os.environ):
+    return None, 'already running under a profiler'
+  import csv
+  import glob
+  import statistics
+  out = {}
+  child = [sys.executable, os.path.abspath(__file__), '--pmc-child', '--config', str(args.config), '--steps', str(K),
+           '--warmup', '5', '--precision', str(args.precision), '--lanes', str(args.lanes)]
+  if args.batch:
+    child += ['--batch', str(args.batch)]
+  env = dict(os.environ, TMPDIR='/tmp')
+  for counters in PMC_PASSES:
+    with tempfile.TemporaryDirectory(dir='/tmp') as td:
+      cmd = [exe, '--kernel-trace', '--pmc'] + list(counters) + ['-d', td, '-o', 'p', '--output-format', 'csv', '--'] + child
+      try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+      except subprocess.TimeoutExpired:
+        return (out or None), 'rocprofv3 pass %s timed out' % (counters,)
+      if r.returncode != 0:
+        return (out or None), 'rocprofv3 pass %s rc=%d: %s' % (counters, r.returncode, r.stderr.decode()[-200:])
+      dur = {}
+      for f in glob.glob(os.path.join(td, '**', '*kernel_trace.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+          dur[row.get('Dispatch_Id')] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
+      per = {}
+      for f in glob.glob(os.path.join(td, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+          if 'step_kernel' in row.get('Kernel_Name', ''):
+            d = per.setdefault(int(row['Dispatch_Id']), {})
+            d[row['Counter_Name']] = d.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
+      ids = sorted(per)[-K:]                       # the child's last K step_kernel dispatches are the timed launches
+      if len(ids) < K:
+        return (out or None), 'rocprofv3 pass %s: %d step_kernel dispatches, expected >= %d' % (counters, len(ids), K)
+      for c in counters:
+        out[c] = statistics.median(per[i].get(c, 0.0) for i in ids)
+      us = [dur[str(i)] for i in ids if str(i) in dur]
+      if us:
+        out['kernel_us_under_pmc:' + counters[0]] = statistics.median(us)
+  return out, None
 
 
 def load_model(asset):
@@ -281,14 +374,25 @@ def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads):
 def main():
   args = parse()
   cfg = CONFIGS[args.config]
-  import torch
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # bare `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and hand their exit code back
+    cmd = launch_command(args, sys.argv[1:], free_port())
+    print('bench.py: spawning %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1')))
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  single_device = bool(os.environ.get('DMC_BENCH_SINGLE_DEVICE'))
+  if os.environ.get('DMC_BENCH_DRYRUN'):      # harness test hook: the rank layout only, before anything touches a GPU
+    check_world(args, world, args.gpus, single_device)
+    print(json.dumps({'dryrun': True, 'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': args.gpus}), flush=True)
+    return
+  import torch
+  check_world(args, world, torch.cuda.device_count(), single_device)
   # DMC_BENCH_BACKEND=gloo + DMC_BENCH_SINGLE_DEVICE=1 exist only to exercise the N > 1
   # code path on a one-GPU box (all ranks share cuda:0); the driver uses nccl (= RCCL).
   backend = os.environ.get('DMC_BENCH_BACKEND', 'nccl')
-  if os.environ.get('DMC_BENCH_SINGLE_DEVICE'):
+  if single_device:
     local_rank = 0
   dist = None
   if world > 1:
@@ -374,6 +478,9 @@ def main():
   torch.cuda.synchronize()
   elapsed = max_over_ranks(time.perf_counter() - t_start)
   kernel_ms = ev0.elapsed_time(ev1) / K      # HIP events on the stream the kernel is launched on
+  if args.pmc_child:                         # the parent reads the last K step_kernel dispatches from rocprofv3's csv
+    phys.close()
+    return
   q_end, v_end, w_end = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
   warn = phys.get('warning').sum(axis=0)
   stats = dict(mean_ncon=float(phys.get('ncon').mean()), max_ncon=int(phys.get('ncon').max()),
@@ -425,13 +532,27 @@ def main():
     value = world * B * K / elapsed
     algo = cfg['algo_bytes']
     achieved = algo * B / (kernel_ms * 1e-3) / 1e9
-    pmc = _committed_pmc(args.config)
+    live, why = (None, 'N > 1') if world > 1 else collect_pmc(args, 30)
+    pmc_source = 'live: rocprofv3 --pmc passes of this run (bench.py --pmc-child, 30 launches per pass)'
+    if live and 'FETCH_SIZE' in live and 'WRITE_SIZE' in live:
+      pmc = dict(live)
+      # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM): x 2 on reads
+      pmc['hbm_bytes_per_launch'] = dict(fetch_raw=live['FETCH_SIZE'] * 1024, fetch_corrected=2 * live['FETCH_SIZE'] * 1024,
+                                         write=live['WRITE_SIZE'] * 1024,
+                                         total_corrected=(2 * live['FETCH_SIZE'] + live['WRITE_SIZE']) * 1024)
+      if live.get('GRBM_GUI_ACTIVE') and live.get('kernel_us_under_pmc:SQ_INSTS_VALU'):
+        pmc['clock_ghz'] = live['GRBM_GUI_ACTIVE'] / 8 / (live['kernel_us_under_pmc:SQ_INSTS_VALU'] * 1e3)   # summed over the 8 XCDs
+      pmc['kernel_us'] = live.get('kernel_us_under_pmc:SQ_INSTS_VALU')
+    else:
+      pmc = _committed_pmc(args.config)
+      pmc_source = 'committed: profiles/r02_pmc_cfg%d.json (not measured in this run: %s)' % (args.config, why)
     roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs; reads x 2
-            # as MI355X_MICROARCH.md prescribes for gfx950), profiles/r02_pmc_cfg<N>.json
+            # HBM bytes per launch: separate --pmc FETCH_SIZE / WRITE_SIZE passes, reads x 2 as MI355X_MICROARCH.md prescribes
             'traffic': (pmc.get('hbm_bytes_per_launch') or {}).get('total_corrected') if pmc else None,
+            'traffic_source': pmc_source if pmc else None,
             'traffic_detail': pmc.get('hbm_bytes_per_launch') if pmc else None,
+            'traffic_over_algorithmic': ((pmc.get('hbm_bytes_per_launch') or {}).get('total_corrected', 0) / (algo * B)) if pmc else None,
             'kernel_ms_avg': kernel_ms, 'algorithmic_bytes_per_launch': algo * B,
             'note': 'nominal bound (SURVEY 8(d)): compulsory HBM traffic is %d B per env per launch; the kernel is '
                     'VALU-issue / latency bound, see roofline_issue' % algo}
@@ -454,19 +575,22 @@ def main():
                             'qpos,qvel,sensordata written to HBM, no launch per step; `value` above is the '
                             'host-in-the-loop mode (one Physics.step() launch per env-step)'},
     }
-    if pmc and pmc.get('SQ_INSTS_VALU') and pmc.get('kernel_us'):
-      # what actually limits the kernel: VALU issue slots.  One wave64 VALU instruction occupies its SIMD for one
-      # quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU on this kernel), so issue utilisation =
-      # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x kernel time); counters from the committed PMC passes.
-      # The instruction count per launch comes from the PMC pass (it does not depend on how fast the launch ran), the
-      # kernel time from THIS run's HIP events: counter collection itself slows the launch down (config 2: 203 us
-      # under --pmc, 138 us under --kernel-trace alone).
-      clk = pmc.get('clock_ghz', 2.4)
-      issue = pmc['SQ_INSTS_VALU'] * 4 / (SIMDS * clk * 1e9 * kernel_ms * 1e-3)
-      out['roofline_issue'] = {'bound': 'valu_issue', 'achieved': issue, 'peak': 1.0, 'unit': 'fraction of VALU issue slots',
-                               'frac': issue, 'valu_insts_per_launch': pmc['SQ_INSTS_VALU'], 'kernel_us_profiled': pmc['kernel_us'],
-                               'kernel_us_live': kernel_ms * 1e3,
-                               'source': 'profiles/r02_pmc_cfg%d.json' % args.config}
+    if pmc and pmc.get('SQ_INSTS_VALU'):
+      # what actually limits the kernel: VALU issue.  achieved = wave64 VALU instructions per launch (counter) x the issue
+      # cost of one instruction / (1024 SIMDs x clock x kernel time of THIS run's HIP events: counter collection slows
+      # the launch down, the instruction count does not depend on it).  Primary convention: 2 cycles per fp32 wave64
+      # instruction (MI355X_MICROARCH.md); `frac_quad_cycle` is round 2's convention (one SQ quad-cycle = 4 cycles).
+      clk = pmc.get('clock_ghz') or 2.4
+      slots = SIMDS * clk * 1e9 * kernel_ms * 1e-3
+      issue = pmc['SQ_INSTS_VALU'] * VALU_CYCLES_PER_INST / slots
+      out['roofline_issue'] = {'bound': 'valu_issue', 'achieved': issue, 'peak': 1.0, 'unit': 'fraction of VALU issue cycles',
+                               'frac': issue, 'cycles_per_wave64_valu_inst': VALU_CYCLES_PER_INST,
+                               'frac_quad_cycle': pmc['SQ_INSTS_VALU'] * 4 / slots,
+                               'valu_insts_per_launch': pmc['SQ_INSTS_VALU'], 'clock_ghz': clk,
+                               'kernel_us_under_pmc': pmc.get('kernel_us'), 'kernel_us_live': kernel_ms * 1e3,
+                               'wait_any_over_wave_cycles': (pmc['SQ_WAIT_ANY'] / pmc['SQ_WAVE_CYCLES'])
+                               if pmc.get('SQ_WAIT_ANY') and pmc.get('SQ_WAVE_CYCLES') else None,
+                               'source': pmc_source}
     if coll:
       out['collectives'] = coll
     nthreads = os.cpu_count() or 1
@@ -479,7 +603,8 @@ def main():
         res = parity(model, cfg, args, local_rank, q_start[:ne], v_start[:ne], w_start[:ne], pa, nthreads)
         out['max_rel_qpos_err_vs_cpu'] = res['open-loop']['max']
         out['parity'] = dict(res, envs=ne, steps=T, n_sub_steps=nsub,
-                             oracle='fp64 C restatement (oracle/); pinned on the reference KATs, unpinned vs real MuJoCo trajectories')
+                             oracle='fp64 C restatement (oracle/); kinematics pinned on reference-held MuJoCo output (tests/golden/cmu2019_mocap.json), '
+                                    'dynamics on the reference KATs + independent solver-optimum pins; trajectories unpinned vs real MuJoCo')
     except Exception as ex:  # pylint: disable=broad-except
       out['max_rel_qpos_err_vs_cpu'] = None
       out['parity_error'] = repr(ex)

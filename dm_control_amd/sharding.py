@@ -24,7 +24,12 @@ def shard_sizes(batch_size, world_size):
 
 
 class ShardedEnvBatch:
-  """Agent-interface collectives for an env-sharded batch (one instance per rank)."""
+  """Agent-interface collectives for an env-sharded batch (one instance per rank).
+
+  Per-step calls allocate nothing: the padded staging / receive buffers are created on the first call for a given
+  (width, dtype) and reused; when every rank owns the same number of environments (the BASELINE shardings:
+  4096 or 256 per GPU) the collectives work directly on views of the caller's tensors -- `scatter` from row
+  blocks of the global action matrix, `all_gather_into_tensor` into one (B, n) result buffer."""
 
   def __init__(self, global_batch, dist=None, device='cpu'):
     import torch
@@ -35,44 +40,73 @@ class ShardedEnvBatch:
     self.global_batch = global_batch
     self.lo, self.hi = shard_bounds(global_batch, self.world, self.rank)
     self.sizes = shard_sizes(global_batch, self.world)
+    self.bounds = [shard_bounds(global_batch, self.world, r) for r in range(self.world)]
+    self.even = len(set(self.sizes)) == 1
+    self.pad = max(self.sizes)
     self.device = device
+    self._buffers = {}
+    self._nu = None
 
   @property
   def local_batch(self):
     return self.hi - self.lo
 
+  def _buffer(self, tag, shape, dtype):
+    key = (tag, tuple(shape), dtype)
+    b = self._buffers.get(key)
+    if b is None:
+      b = self._buffers[key] = self._torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+    return b
+
   def scatter_actions(self, actions_global, src=0):
-    """actions_global: (B, nu) tensor on rank `src` (ignored elsewhere) ->
-    this rank's (local_batch, nu) slice."""
+    """actions_global: (B, nu) tensor on rank `src` (ignored elsewhere) -> this rank's (local_batch, nu) slice
+    (a view of a persistent receive buffer: valid until the next call)."""
     torch = self._torch
     if self.world == 1:
       return actions_global[self.lo:self.hi]
-    nu = torch.tensor([actions_global.shape[1] if self.rank == src else 0], device=self.device)
-    self.dist.broadcast(nu, src)
-    pad = max(self.sizes)
-    out = torch.empty((pad, int(nu.item())), dtype=torch.float32, device=self.device)
+    if self._nu is None:        # once: the action width travels with the first exchange
+      nu = torch.tensor([actions_global.shape[1] if self.rank == src else 0], device=self.device)
+      self.dist.broadcast(nu, src)
+      self._nu = int(nu.item())
+    nu = self._nu
+    out = self._buffer('act_recv', (self.pad, nu), torch.float32)
     chunks = None
     if self.rank == src:
-      chunks = []
-      for r in range(self.world):
-        lo, hi = shard_bounds(self.global_batch, self.world, r)
-        c = torch.zeros((pad, int(nu.item())), dtype=torch.float32, device=self.device)
-        c[:hi - lo] = actions_global[lo:hi].to(torch.float32)
-        chunks.append(c)
+      a = actions_global
+      if a.dtype != torch.float32 or not a.is_contiguous():
+        stage = self._buffer('act_cast', (self.global_batch, nu), torch.float32)
+        stage.copy_(a)
+        a = stage
+      if self.even:
+        chunks = [a[lo:hi] for lo, hi in self.bounds]                 # views, no copy
+      else:
+        stage = self._buffer('act_stage', (self.world, self.pad, nu), torch.float32)
+        for r, (lo, hi) in enumerate(self.bounds):
+          stage[r, :hi - lo].copy_(a[lo:hi])
+        chunks = list(stage.unbind(0))
     self.dist.scatter(out, chunks, src=src)
     return out[:self.local_batch]
 
   def gather(self, local, dst=None):
-    """local: (local_batch, n) tensor -> (B, n) on every rank (all_gather)."""
+    """local: (local_batch, n) tensor -> (B, n) on every rank (one all_gather_into_tensor; the result is a
+    persistent buffer, valid until the next call with the same shape)."""
     torch = self._torch
     if self.world == 1:
       return local
-    pad = max(self.sizes)
-    buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=self.device)
-    buf[:self.local_batch] = local
-    outs = [torch.empty_like(buf) for _ in range(self.world)]
-    self.dist.all_gather(outs, buf)
-    return torch.cat([o[:n] for o, n in zip(outs, self.sizes)], dim=0)
+    tail = tuple(local.shape[1:])
+    recv = self._buffer('obs_recv', (self.world * self.pad,) + tail, local.dtype)
+    if self.even:
+      send = local if local.is_contiguous() else local.contiguous()
+    else:
+      send = self._buffer('obs_send', (self.pad,) + tail, local.dtype)
+      send[:self.local_batch].copy_(local)
+    self.dist.all_gather_into_tensor(recv, send)
+    if self.even:
+      return recv
+    out = self._buffer('obs_out', (self.global_batch,) + tail, local.dtype)
+    for r, (lo, hi) in enumerate(self.bounds):
+      out[lo:hi].copy_(recv[r * self.pad:r * self.pad + hi - lo])
+    return out
 
   def max_over_ranks(self, value):
     """Slowest rank's elapsed time (bench.py contract)."""

@@ -41,17 +41,25 @@ def _worker(rank, world, port, B, nu, nobs):
     assert torch.equal(full[:, 1], torch.arange(B, dtype=torch.float32))
     assert torch.allclose(full[:, 0], torch.arange(B * nu, dtype=torch.float32).reshape(B, nu).sum(dim=1))
     assert sb.max_over_ranks(1.0 + rank) == float(world)
+    # per-step calls reuse their buffers (no allocation after the first exchange)
+    nbuf = len(sb._buffers)
+    ptrs = (local.data_ptr(), full.data_ptr())
+    local2 = sb.scatter_actions(actions)
+    full2 = sb.gather(obs)
+    assert len(sb._buffers) == nbuf and (local2.data_ptr(), full2.data_ptr()) == ptrs
+    assert torch.equal(local2, want) and torch.equal(full2[:, 1], torch.arange(B, dtype=torch.float32))
     dist.barrier()
   finally:
     dist.destroy_process_group()
 
 
-def test_two_rank_scatter_gather_gloo():
+@pytest.mark.parametrize('B', [11, 12])       # ragged and even shardings (the even one works on views, no staging)
+def test_two_rank_scatter_gather_gloo(B):
   import torch.multiprocessing as mp
   with socket.socket() as s:
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
-  mp.spawn(_worker, args=(2, port, 11, 6, 4), nprocs=2, join=True)
+  mp.spawn(_worker, args=(2, port, B, 6, 4), nprocs=2, join=True)
 
 
 def _step_worker(rank, world, port, B, T, out_path):
