@@ -216,6 +216,19 @@ class BatchedPhysics:
     return dict(zip(self.PROF_NAMES, buf[:len(self.PROF_NAMES)]))
 
   # -- debug ----------------------------------------------------------------------------
+  def wave_trace(self, enable=None):
+    """enable=True/False switches the trace; no argument: (3, nitems) int array of the last launch (start, end of
+    every wave item on the 100 MHz constant clock, workgroup index)."""
+    L = _native.lib()
+    n = ctypes.c_int(0)
+    if enable is not None:
+      _native.check(L.dmc_batch_wave_trace(self._ptr, int(bool(enable)), None, ctypes.byref(n)))
+      return None
+    info = self.info()
+    out = np.zeros((3, (info['B'] * info['lanes_per_env'] + 63) // 64), dtype=np.int32)
+    _native.check(L.dmc_batch_wave_trace(self._ptr, 1, out.ctypes.data, ctypes.byref(n)))
+    return out
+
   def debug_enable(self, n):
     _native.check(_native.lib().dmc_batch_debug_enable(self._ptr, int(n)))
 

@@ -72,6 +72,7 @@ struct dmc_batch {
   void* d_kstash; int* d_kstash_i;      // kinematic stash (StepIO::kstash), on unless DMC_NO_KSTASH
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
+  int* d_trace;        // wave trace (dmc_batch_wave_trace): (3, nitems) ints, or null
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
 
@@ -180,7 +181,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -278,6 +279,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_kstash_i) (void)hipFree(b->d_kstash_i);
   if (b->d_cost) (void)hipFree(b->d_cost);
   if (b->d_order) (void)hipFree(b->d_order);
+  if (b->d_trace) (void)hipFree(b->d_trace);
   delete b;
 }
 
@@ -299,6 +301,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->env_mode = (const int*)P("env_mode");
   io->work = b->geom.queue ? b->d_work : nullptr;
   io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
+  io->trace = b->d_trace;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
@@ -841,6 +844,27 @@ extern "C" int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int e
     for (int i = 0; i < cnt; i++) dst[i] = tmp[(size_t)i * n + env];
   }
   *count = cnt;
+  return 0;
+}
+
+// ---- wave trace: when every wave of the LAST launch started / finished its item (100 MHz constant clock) -------
+extern "C" int dmc_batch_wave_trace(dmc_batch* b, int enable, int32_t* dst, int* nitems) {
+  if (!b) return fail("null batch");
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = (b->B * b->geom.lpe + 63) / 64;
+  if (nitems) *nitems = n;
+  if (dst) {
+    if (!b->d_trace) return fail("wave trace not enabled");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, b->d_trace, (size_t)3 * n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  if (b->d_trace) { (void)hipFree(b->d_trace); b->d_trace = nullptr; }
+  if (enable) {
+    HIP_TRY(hipMalloc((void**)&b->d_trace, (size_t)3 * n * sizeof(int)));
+    HIP_TRY(hipMemset(b->d_trace, 0, (size_t)3 * n * sizeof(int)));
+  }
   return 0;
 }
 

@@ -23,6 +23,10 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#ifdef DMC_HOST_EMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #include "../../include/dmc_model_layout.h"
 #include "step_layout.h"
@@ -91,6 +95,9 @@ struct StepIO {
   // launch, written by the step kernel; order[k] = the item handed out k-th, built from it before every launch
   // (order_kernel, dmc_api.hip).  Null: items in index order.
   int* cost; const int* order;
+  // optional wave trace (dmc_batch_wave_trace): trace[item] / trace[nitems + item] = constant-rate clock (100 MHz) at which
+  // the item's wave started / finished it, trace[2 nitems + item] = XCD id << 16 | CU-local info; null: no trace
+  int* trace;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
@@ -115,7 +122,7 @@ template <> DMC_DEV float t_sqrt<float>(float x) { return sqrtf(x); }
 // correctly rounded sqrt followed by a correctly rounded division -- ~25 instructions less on the dependent chain of
 // every column (a fifth of the 62 x 62 factorisation); fp64 keeps the exact sequence the oracle uses.
 template <typename T> DMC_DEV T t_rsqrt(T x) { return 1 / t_sqrt(x); }
-#ifndef DMC_HOST_EMU
+#if !defined(DMC_HOST_EMU) && !defined(DMC_EXACT_RSQ)
 template <> DMC_DEV float t_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
 #endif
 template <typename T> DMC_DEV T t_sin(T x) { return (T)sin((double)x); }
@@ -3100,7 +3107,11 @@ struct StepCore {
     // pivot serves both L[i][i] and every division by it (the exact form costs ~10 correctly rounded divisions /
     // roots per trip), and the stopping tests are floored at what fp32 resolves (|v|^2 - r^2 cannot get within
     // 1e-10 of zero when r^2 ~ 1e4); fp64 keeps MuJoCo's sequence operation for operation.
+#ifdef DMC_EXACT_QCQP
+    constexpr bool fast = false;
+#else
     constexpr bool fast = sizeof(T) == 4;
+#endif
     T A[N*N], b[N], Lc[N*N], inv[N], v[N], pv[N], la = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) { v[i] = 0; pv[i] = 0; inv[i] = 0; b[i] = bin[i]*dd[i]; }
@@ -3434,6 +3445,10 @@ struct StepCore {
       const T eps8 = 8 * (sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16);
       const T tol_imp = t_max(o.tolerance, eps8*scale*t_abs(cost));
       const T tol_grad = t_max(o.tolerance, eps8*scale*t_sqrt(ma2));
+#ifdef DMC_HOST_EMU
+      if (getenv("DMC_EMU_TRACE")) fprintf(stderr, "  newton iter %d alpha %.6e cost %.9e improvement %.3e (tol %.3e) gradient %.3e (tol %.3e) changed %d\n",
+                                            iter, (double)alpha, (double)cost, (double)improvement, (double)tol_imp, (double)gradient, (double)tol_grad, changed);
+#endif
       if (improvement < tol_imp || gradient < tol_grad) break;
     }
     constraint_force_to_joint(nefc);

@@ -91,7 +91,12 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const int item = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     const int env = item * epw + (g & (epw - 1));
+    if (io.trace && (threadIdx.x & 63) == 0) io.trace[item] = (int)(wall_clock64() & 0x7fffffffll);
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub);
+    if (io.trace && (threadIdx.x & 63) == 0) {
+      io.trace[nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
+      io.trace[2*nitems + item] = (int)blockIdx.x;
+    }
     if (io.cost && (threadIdx.x & 63) == 0) {
       const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
       io.cost[item] = (int)(dt < 1 ? 1 : (dt > 0x3fffffff ? 0x3fffffff : dt));

@@ -87,7 +87,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.contact_force = buf[24].data(); io.cvel = buf[25].data(); io.act = buf[26].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
-  io.env_mode = nullptr; io.work = nullptr; io.cost = nullptr; io.order = nullptr;
+  io.env_mode = nullptr; io.work = nullptr; io.cost = nullptr; io.order = nullptr; io.trace = nullptr;
   if (!e->xfrc64.empty()) { o.xfrc = sizeof(T) == 8 ? (const void*)e->xfrc64.data() : (const void*)e->xfrc32.data(); o.xfrc_B = 1; }
   o.g_mr = mr;
   e->gs.resize(L.n_gs + 2); o.gscr = e->gs.data();   // doubles: room for either precision
