@@ -474,6 +474,13 @@ DMC_FN void chol_solve_lds(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b
 }
 // line-search evaluation: cost / derivatives of the piecewise quadratic at alpha
 template <typename T> struct LSPoint { T alpha, cost, d0, d1; };
+// fp32: the line search works on the cost RELATIVE to alpha = 0.  Its points are only ever compared with each other,
+// and the total cost of a stiff contact configuration is ~1e6 -- one fp32 ulp of that is 0.06, more than the
+// improvement of a late Newton iteration: with absolute costs the search answered "no improvement" (alpha = 0) two
+// iterations before the fp64 solver converged, leaving one-step errors of 1e-4 on the 62-dof model.  The relative cost
+// is also what the solver's stopping test uses as the iteration's improvement (exact to ~1e-6 of itself instead of to
+// an ulp of the total).  fp64 keeps the oracle's absolute form, operation for operation.
+template <typename T> DMC_DEV constexpr bool ls_relative() { return sizeof(T) == 4; }
 // Returned as a 4-vector {alpha, cost, d0, d1}: a pointer argument pins the caller's
 // points in scratch memory, and returning the struct itself by value measured 2x
 // slower on the whole kernel (MI355X, ROCm 7.2) -- the vector comes back in v0..v3.
@@ -492,7 +499,16 @@ DMC_FN DMC_LSVEC(T) ls_eval_lds(T a, const DMC_LDS T* jar_, const DMC_LDS T* jv_
   T q0 = 0, q1 = 0, q2 = 0;
   for (int i = lane; i < nefc; i += LPE) {
     const T jar = jar_[i], jv = jv_[i];
-    if (jar + a*jv < 0) {
+    if (ls_relative<T>()) {
+      // cost RELATIVE to alpha = 0 (see ls_relative): the constant 1/2 D jar^2 of a row active at both ends drops out,
+      // a row that switches between 0 and alpha contributes it with the sign of the switch
+      const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
+      if (act_a | act_0) {
+        const T D = D_[i], dj0 = D*jar;
+        if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+      }
+    } else if (jar + a*jv < 0) {
       const T D = D_[i], dj0 = D*jar;
       q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
     }
@@ -2855,12 +2871,14 @@ struct StepCore {
   // the non-quadratic middle-zone term of every frictional contact
   DMC_DEV void ls_eval_ell(dmc::LSPoint<T>* p, const T* qg, int nefc) {
     const T a = p->alpha;
+    constexpr bool rel = ls_relative<T>();      // cost relative to alpha = 0 (fp32), see ls_relative
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
       if (EFC_TYPE(tid) == EFC_EQUALITY) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i], dj0 = D*jar;
-        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+        if (!rel) q0 += (T)0.5*jar*dj0;
+        q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
         continue;
       }
       if (EFC_TYPE(tid) == EFC_FRICTION) {
@@ -2869,11 +2887,23 @@ struct StepCore {
         if (x <= -rf) { q0 += f*((T)-0.5*rf - jar); q1 += -f*jv; }
         else if (x >= rf) { q0 += f*((T)-0.5*rf + jar); q1 += f*jv; }
         else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        if (rel) {      // minus the row's cost at alpha = 0 (Huber: linear outside |jar| < rf)
+          if (jar <= -rf) q0 -= f*((T)-0.5*rf - jar);
+          else if (jar >= rf) q0 -= f*((T)-0.5*rf + jar);
+          else q0 -= (T)0.5*jar*D*jar;
+        }
         continue;
       }
       if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i];
-        if (jar + a*jv < 0) { const T D = S(efc_D)[i], dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        if (rel) {
+          const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
+          if (act_a | act_0) {
+            const T D = S(efc_D)[i], dj0 = D*jar;
+            if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+            if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+          }
+        } else if (jar + a*jv < 0) { const T D = S(efc_D)[i], dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
         continue;
       }
       // first row of a frictional contact: its alpha-independent aggregates were parked by ls_prepare_ell
@@ -2882,22 +2912,42 @@ struct StepCore {
       const T U0 = S(efc_ca)[r0], V0 = S(efc_ca)[r0 + 1], UU = S(efc_ca)[r0 + 2];
       const T UV = S(efc_cb)[r0], VV = S(efc_cb)[r0 + 1], mu = S(efc_cb)[r0 + 2];
       const T N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
-      bool bottom = false;
+      bool bottom = false, middle = false;
+      T NT = 0, Dm = 0;
       if (Tsqr <= 0) bottom = N < 0;
       else {
         const T Tn = t_sqrt(Tsqr);
         if (N >= mu*Tn) {}
         else if (mu*N + Tn <= 0) bottom = true;
         else {
-          const T Dm = S(efc_D)[r0] / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
+          middle = true;
+          Dm = S(efc_D)[r0] / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
           const T N1 = V0, T1 = (UV + a*VV)/Tn, T2 = VV/Tn - (UV + a*VV)*T1/(Tn*Tn);
-          const T NT = N - mu*Tn, NT1 = N1 - mu*T1;
-          cc += (T)0.5*Dm*NT*NT; cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+          const T NT1 = N1 - mu*T1;
+          NT = N - mu*Tn;
+          if (!rel) cc += (T)0.5*Dm*NT*NT;
+          cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
         }
       }
-      if (bottom) { q0 += S(efc_cg)[r0]; q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; }
+      if (!rel) { if (bottom) { q0 += S(efc_cg)[r0]; q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; } continue; }
+      // relative form: the contact's cost at alpha minus its cost at 0, by the pair of zones
+      bool bottom0 = false, middle0 = false;
+      T NT0 = 0;
+      if (UU <= 0) bottom0 = U0 < 0;
+      else {
+        const T T0 = t_sqrt(UU);
+        if (U0 >= mu*T0) {}
+        else if (mu*U0 + T0 <= 0) bottom0 = true;
+        else { middle0 = true; NT0 = U0 - mu*T0; }
+      }
+      if (bottom) { q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; if (!bottom0) q0 += S(efc_cg)[r0]; }
+      else if (bottom0) q0 -= S(efc_cg)[r0];
+      if (middle | middle0) {
+        if (!middle0 || !middle) Dm = S(efc_D)[r0] / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
+        cc += (T)0.5*Dm*(NT - NT0)*(NT + NT0);      // 1/2 Dm (NT^2 - NT0^2); a zone that is not the middle one has NT = 0
+      }
     }
-    q0 = group_sum<LPE>(q0) + qg[0]; q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
+    q0 = group_sum<LPE>(q0) + (rel ? (T)0 : qg[0]); q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
     cc = group_sum<LPE>(cc); cd0 = group_sum<LPE>(cd0); cd1 = group_sum<LPE>(cd1);
     p->cost = a*a*q2 + a*q1 + q0 + cc;
     p->d0 = 2*a*q2 + q1 + cd0;
@@ -3028,7 +3078,7 @@ struct StepCore {
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
     if (general_rows()) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
     const DMC_LSVEC(T) rv = ls_eval_lds<T, LPE>(p->alpha, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv),
-                                                (const DMC_LDS T*)S(efc_D), qg[0], qg[1], qg[2], nefc, lane);
+                                                (const DMC_LDS T*)S(efc_D), ls_relative<T>() ? (T)0 : qg[0], qg[1], qg[2], nefc, lane);
     p->alpha = rv[0]; p->cost = rv[1]; p->d0 = rv[2]; p->d1 = rv[3];
     (*evals)++;
   }
@@ -3041,7 +3091,8 @@ struct StepCore {
     if (flag) { pnext->alpha = p->alpha - p->d0/p->d1; ls_eval(pnext, qg, nefc, evals); }
     return flag;
   }
-  DMC_DEV T primal_search(int nefc, T gauss, T scale) {
+  DMC_DEV T primal_search(int nefc, T gauss, T scale, T* lscost) {
+    *lscost = 0;      // cost of the returned point (relative to alpha = 0 in fp32: minus the iteration's improvement)
     const int nv = L.d.nv;
     mul_M(S(sv_Mv), S(sv_search));
     { const RowMap rm = row_map(); for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = row_dot(i, S(sv_search), rm); }
@@ -3064,17 +3115,17 @@ struct StepCore {
     p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals);
     p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals);
     if (p0.cost < p1.cost) p1 = p0;
-    if (t_abs(p1.d0) < gtol) return p1.alpha;
+    if (t_abs(p1.d0) < gtol) { *lscost = p1.cost; return p1.alpha; }
     const int dir = p1.d0 < 0 ? 1 : -1;
     int p2update = 0;
     p2 = p1;
     while (p1.d0*dir <= -gtol && evals < lsmax) {
       p2 = p1; p2update = 1;
       p1.alpha -= p1.d0/p1.d1; ls_eval(&p1, qg, nefc, &evals);
-      if (t_abs(p1.d0) < gtol) return p1.alpha;
+      if (t_abs(p1.d0) < gtol) { *lscost = p1.cost; return p1.alpha; }
     }
-    if (evals >= lsmax) return p1.alpha;
-    if (!p2update) return p1.alpha;
+    if (evals >= lsmax) { *lscost = p1.cost; return p1.alpha; }
+    if (!p2update) { *lscost = p1.cost; return p1.alpha; }
     p2next = p1;
     p1next.alpha = p1.alpha - p1.d0/p1.d1; ls_eval(&p1next, qg, nefc, &evals);
     while (evals < lsmax) {
@@ -3084,13 +3135,13 @@ struct StepCore {
       for (int i = 0; i < 3; i++) if (t_abs(cand[i].d0) < gtol && (!found || cand[i].cost < best_cost)) {
         found = true; best_cost = cand[i].cost; best_alpha = cand[i].alpha;
       }
-      if (found) return best_alpha;
+      if (found) { *lscost = best_cost; return best_alpha; }
       const int b1 = ls_update_bracket(&p1, cand, &p1next, qg, nefc, &evals);
       const int b2 = ls_update_bracket(&p2, cand, &p2next, qg, nefc, &evals);
-      if (!b1 && !b2) return pmid.cost < p0.cost ? pmid.alpha : (T)0;
+      if (!b1 && !b2) { if (pmid.cost < p0.cost) { *lscost = pmid.cost; return pmid.alpha; } return 0; }
     }
-    if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
-    if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+    if (p1.cost <= p2.cost && p1.cost < p0.cost) { *lscost = p1.cost; return p1.alpha; }
+    if (p2.cost <= p1.cost && p2.cost < p0.cost) { *lscost = p2.cost; return p2.alpha; }
     return 0;
   }
   // ---- noslip post-solver (mj_solNoSlip; same algorithm and operation order as the oracle's
@@ -3359,12 +3410,187 @@ struct StepCore {
     chol_solve(S(qacc), M_factor(), S(sv_grad), nv);
     DMC_WSYNC();
   }
+  // ---- PGS (mj_solPGS; option solver="PGS", dm_control/mjcf/schema.xml:69-72; same algorithm and operation order as the
+  // oracle's pgs_solve).  Dual problem  min 1/2 f'AR f + f'b,  AR = J M^-1 J' + diag(R),  b = J qacc_smooth - aref:
+  // Gauss-Seidel over the rows in force space.  AR is built once per solve (one substitution per row, as noslip builds
+  // its A) into the environment's (njmax, njmax) matrix in global memory; the residual  res = b + AR f  is kept up to
+  // date lane-parallel (row i of the symmetric AR = column i, coalesced), the per-block scalar maths runs redundantly
+  // on every lane.  A block update that raises the cost by more than 1e-10 is undone.
+  template <int N>
+  DMC_DEV T pgs_cone_block(int i) {
+    const int cap = L.d.nslip, c = EFC_ID(SI(efc_tid)[i]);
+    T A[N*N], old[N], rs[N], f[N];
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      old[p] = S(efc_force)[i + p]; rs[p] = S(ns_res)[i + p]; f[p] = old[p];
+#pragma unroll
+      for (int q = 0; q < N; q++) A[p*N + q] = ns_A()[(i + p)*cap + i + q];
+    }
+    const T* fr3 = MR(prm_friction) + 3*con_prm(c);
+    const T fri5[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
+    if (f[0] < (T)DMC_MINVAL) {            // normal force too small: normal update, friction cleared
+      f[0] -= rs[0]/A[0];
+      if (f[0] < 0) f[0] = 0;
+#pragma unroll
+      for (int p = 1; p < N; p++) f[p] = 0;
+    } else {                               // ray update along the current force
+      T v1[N], denom = 0, vr = 0;
+#pragma unroll
+      for (int p = 0; p < N; p++) { T t = 0;
+#pragma unroll
+        for (int q = 0; q < N; q++) t += A[p*N + q]*old[q];
+        v1[p] = t; }
+#pragma unroll
+      for (int p = 0; p < N; p++) { denom += old[p]*v1[p]; vr += old[p]*rs[p]; }
+      if (denom >= (T)DMC_MINVAL) {
+        T x = -vr / denom;
+        if (f[0] + x*old[0] < 0) x = -f[0]/old[0];
+#pragma unroll
+        for (int p = 0; p < N; p++) f[p] += x*old[p];
+      }
+    }
+    // friction update with the normal fixed
+    constexpr int M = N - 1;
+    T Ac[M*M], bc[M], fri[M], v[M];
+#pragma unroll
+    for (int p = 0; p < M; p++) {
+      fri[p] = fri5[p < 5 ? p : 4];
+      bc[p] = rs[p + 1];
+#pragma unroll
+      for (int q = 0; q < M; q++) { Ac[p*M + q] = A[(p + 1)*N + q + 1]; bc[p] -= Ac[p*M + q]*old[1 + q]; }
+      bc[p] += A[(p + 1)*N]*(f[0] - old[0]);
+    }
+    if (f[0] < (T)DMC_MINVAL) {
+#pragma unroll
+      for (int p = 0; p < M; p++) f[1 + p] = 0;
+    } else {
+      const int active = qcqp<M>(v, Ac, bc, fri, f[0]);
+      if (active) {
+        T ss = 0;
+#pragma unroll
+        for (int p = 0; p < M; p++) ss += v[p]*v[p]/(fri[p]*fri[p]);
+        ss = t_sqrt(f[0]*f[0] / t_max((T)DMC_MINVAL, ss));
+#pragma unroll
+        for (int p = 0; p < M; p++) v[p] *= ss;
+      }
+#pragma unroll
+      for (int p = 0; p < M; p++) f[1 + p] = v[p];
+    }
+    T change = 0;
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      T tq = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) tq += A[p*N + q]*(f[q] - old[q]);
+      change += (T)0.5*(f[p] - old[p])*tq + (f[p] - old[p])*rs[p];
+    }
+    if (change > (T)1e-10) {
+#pragma unroll
+      for (int p = 0; p < N; p++) f[p] = old[p];
+      change = 0;
+    }
+    DMC_WSYNC();
+    const int nefc = SI(imisc)[IM_NEFC];
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      const T delta = f[p] - old[p];
+      if (lane == 0) S(efc_force)[i + p] = f[p];
+      if (delta != 0) { const T* Ap = ns_A() + (i + p)*cap; for (int b = lane; b < nefc; b += LPE) S(ns_res)[b] += Ap[b]*delta; }
+    }
+    DMC_WSYNC();
+    return change;
+  }
+  DMC_DEV void pgs_solve(int nefc) {
+    const int nv = L.d.nv, cap = L.d.nslip;
+    const RowMap rm = row_map();
+    for (int i = lane; i < nefc; i += LPE) SI(ns_row)[i] = i;
+    DMC_WSYNC();
+    // AR = J M^-1 J' + diag(R)
+    bool built = false;
+#ifndef DMC_HOST_EMU
+    if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { noslip_build_A_rows<LS::kNV>((const DMC_LDS T*)M_factor(), nefc, rm); built = true; }
+#endif
+    if (!built) for (int b = 0; b < nefc; b++) {
+      FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(b, i, rm);
+      DMC_WSYNC();
+      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv);
+      { T* A = ns_A();
+        for (int a = b + lane; a < nefc; a += LPE) { const T v = row_dot(a, S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
+      DMC_WSYNC();
+    }
+    for (int i = lane; i < nefc; i += LPE) {
+      ns_A()[i*cap + i] += 1 / S(efc_D)[i];
+      S(efc_jv)[i] = row_dot(i, S(qacc_smooth), rm) - S(efc_aref)[i];       // b
+    }
+    // warm start: the forces of qacc_warmstart through the primal map, kept only if their dual cost beats zero forces
+    bool warm = false;
+    if (!(o.disableflags & DMC_DSBL_WARMSTART)) {
+      for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] = row_dot(i, S(qacc_warmstart), rm) - S(efc_aref)[i];
+      DMC_WSYNC();
+      constraint_update(nefc);
+      T cost = 0;
+      for (int i = lane; i < nefc; i += LPE) {
+        const T* Ai = ns_A() + i*cap;
+        T t = 0;
+        for (int j = 0; j < nefc; j++) t += Ai[j]*S(efc_force)[j];
+        const T f = S(efc_force)[i], bi = S(efc_jv)[i];
+        cost += f*bi + (T)0.5*f*t;
+        S(ns_res)[i] = bi + t;
+      }
+      cost = group_sum<LPE>(cost);
+      warm = !(cost > 0);
+    }
+    DMC_WSYNC();
+    if (!warm) for (int i = lane; i < nefc; i += LPE) { S(efc_force)[i] = 0; S(ns_res)[i] = S(efc_jv)[i]; }
+    DMC_WSYNC();
+    const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
+    int iter = 0;
+    while (iter < o.iterations) {
+      T improvement = 0;
+      for (int i = 0; i < nefc; ) {
+        const int tid = SI(efc_tid)[i], t = EFC_TYPE(tid);
+        const int dim = t == EFC_ELLIPTIC ? con_dim(EFC_ID(tid)) : 1;
+        if (dim == 1) {
+          const T a = ns_A()[i*cap + i], r = S(ns_res)[i], old = S(efc_force)[i];
+          T f = old - r/a;
+          if (t == EFC_FRICTION) { const T fl = MR(dof_frictionloss)[EFC_ID(tid)]; if (f < -fl) f = -fl; else if (f > fl) f = fl; }
+          else if (t != EFC_EQUALITY) { if (f < 0) f = 0; }
+          T delta = f - old;
+          T change = (T)0.5*delta*delta*a + delta*r;
+          if (change > (T)1e-10) { f = old; delta = 0; change = 0; }
+          DMC_WSYNC();
+          if (lane == 0) S(efc_force)[i] = f;
+          if (delta != 0) { const T* Ap = ns_A() + i*cap; for (int b = lane; b < nefc; b += LPE) S(ns_res)[b] += Ap[b]*delta; }
+          DMC_WSYNC();
+          improvement -= change;
+        } else if (dim == 3) improvement -= pgs_cone_block<3>(i);
+        else if (dim == 4) improvement -= pgs_cone_block<4>(i);
+        else improvement -= pgs_cone_block<6>(i);
+        i += dim;
+      }
+      improvement *= scale;
+      iter++;
+      if (improvement < o.tolerance) break;
+    }
+    // dualFinish: qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 qfrc_constraint
+    constraint_force_to_joint(nefc);
+    DMC_WSYNC();
+    chol_solve(S(sv_Mgrad), M_factor(), S(qfrc_constraint), nv);
+    FOR_LANES(i, nv) { const T a = S(qacc_smooth)[i] + S(sv_Mgrad)[i]; S(qacc)[i] = a; S(qacc_warmstart)[i] = a; }
+    if (lane == 0) SI(imisc)[IM_ITER] = iter;
+    DMC_WSYNC();
+  }
   DMC_DEV void fwd_constraint() {
     const int nv = L.d.nv, nefc = SI(imisc)[IM_NEFC];
     if (!nefc) {
       FOR_LANES(i, nv) { const T a = S(qacc_smooth)[i]; S(qacc)[i] = a; S(qacc_warmstart)[i] = a; S(qfrc_constraint)[i] = 0; }
       if (lane == 0) SI(imisc)[IM_ITER] = 0;
       DMC_WSYNC();
+      return;
+    }
+    if (L.d.pgs) {
+      pgs_solve(nefc);
+      if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
       return;
     }
     // Warm start (mj_solPrimal / warmstart()): keep qacc_warmstart only if its cost beats qacc_smooth's.  qacc_smooth is
@@ -3407,7 +3633,8 @@ struct StepCore {
     DMC_PROF(PROF_SOL_GRAD);
     int iter = 0;
     while (iter < o.iterations) {
-      const T alpha = primal_search(nefc, gauss, scale);
+      T lscost;
+      const T alpha = primal_search(nefc, gauss, scale, &lscost);
       DMC_PROF(PROF_SOL_LS);
       if (alpha == 0) break;
       FOR_LANES(i, nv) { S(qacc)[i] += alpha*S(sv_search)[i]; S(sv_Ma)[i] += alpha*S(sv_Mv)[i]; }
@@ -3437,14 +3664,25 @@ struct StepCore {
       }
       g2 = group_sum<LPE>(g2); ma2 = group_sum<LPE>(ma2);
       DMC_WSYNC();
-      const T improvement = scale*(oldcost - cost), gradient = scale*t_sqrt(g2);
+      const T improvement = ls_relative<T>() ? -scale*lscost : scale*(oldcost - cost), gradient = scale*t_sqrt(g2);
       iter++;
-      // MuJoCo's criteria, floored at what the arithmetic can resolve: a cost
-      // change below ~8 ulp of the cost (or a gradient below ~8 ulp of |M a|) is
-      // rounding noise.  For fp64 the floor is far below `tolerance` (no-op).
-      const T eps8 = 8 * (sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16);
-      const T tol_imp = t_max(o.tolerance, eps8*scale*t_abs(cost));
-      const T tol_grad = t_max(o.tolerance, eps8*scale*t_sqrt(ma2));
+      // MuJoCo's criteria, floored at what the arithmetic can resolve: a gradient below ~8 ulp of |M a| is rounding
+      // noise, and so is a cost change below 1 ulp of the cost.  (Round 2 floored the improvement at 8 ulp: an iteration
+      // whose line search stops at a kink makes a small but real step -- improvement 1e-3 against a cost of 7e5 --
+      // while the gradient is still 1e4 x its floor; stopping there left one-step errors of 2e-4 on the 62-dof model,
+      // 4e-8 with the 1-ulp floor, at no measurable cost: profiles/r03_fp32_floor.json.)  fp64: both floors are far
+      // below `tolerance` (no-op).
+#ifndef DMC_EPS_IMP
+#define DMC_EPS_IMP 1
+#endif
+#ifdef DMC_HOST_EMU
+      const T epsimp = getenv("DMC_EMU_EPSMUL") ? (T)atof(getenv("DMC_EMU_EPSMUL")) : (T)DMC_EPS_IMP;
+#else
+      const T epsimp = (T)DMC_EPS_IMP;
+#endif
+      const T ulp = sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16;
+      const T tol_imp = ls_relative<T>() ? o.tolerance : t_max(o.tolerance, epsimp*ulp*scale*t_abs(cost));
+      const T tol_grad = t_max(o.tolerance, 8*ulp*scale*t_sqrt(ma2));
 #ifdef DMC_HOST_EMU
       if (getenv("DMC_EMU_TRACE")) fprintf(stderr, "  newton iter %d alpha %.6e cost %.9e improvement %.3e (tol %.3e) gradient %.3e (tol %.3e) changed %d\n",
                                             iter, (double)alpha, (double)cost, (double)improvement, (double)tol_imp, (double)gradient, (double)tol_grad, changed);

@@ -46,6 +46,7 @@ struct StepDims {
   int kwords;    // ints per contact holding its dof list as bytes: (kmax + 3) / 4
   int maxrow;    // most constraint rows a single contact can have (bound of the per-contact row loops)
   int coldlds;   // 1: the cold tables are small enough to be staged in LDS with the others
+  int pgs;       // 1: option solver="PGS" (projected Gauss-Seidel on the dual; AR = J M^-1 J' + R lives in StepOpts::ns_A, nslip = njmax)
   int cg;        // 1: option solver="CG" (conjugate gradient on the same primal problem, preconditioned with M^-1)
   int jfull;     // 1 (nv <= 16): EVERY constraint row is stored as a dense row of nv entries in efc_Jd (row classes and
                  //   compression pay off for long chains; on a 9-dof model their index arithmetic cost 10 % of the step)

@@ -85,7 +85,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   if (m.ngeom > 65535) { *err = "kernel supports ngeom <= 65535"; return false; }
   if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
   const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
-  if (m.opt_solver == DMC_SOL_PGS) { *err = "the PGS solver is not implemented in the HIP path (Newton and CG are)"; return false; }
   if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
   d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
   std::vector<int> fric_dof;
@@ -231,6 +230,8 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
   // one-nonzero friction / joint-limit rows, kmax entries per contact row
   d.cg = m.opt_solver == DMC_SOL_CG ? 1 : 0;
+  d.pgs = m.opt_solver == DMC_SOL_PGS ? 1 : 0;
+  if (d.pgs) d.nslip = njmax;      // the dual solver keeps a residual entry and a row of AR for EVERY constraint row
   d.jfull = m.nv <= 16 ? 1 : 0;
   d.njdense = d.jfull ? njmax : std::min(njmax, d.neqrow + 2 * d.nlimten);
   // contact rows with a stored Jacobian: by default every contact slot may use its maximum number of rows; a

@@ -2154,7 +2154,7 @@ static int qcqp(double* res, const double* Ain, const double* bin, const double*
 }
 /* cost change of a block update; an update that increases the cost is undone */
 static double noslip_cost_change(const double* Ac, double* force, const double* oldforce, const double* res, int n) {
-  double delta[5], change = 0;
+  double delta[6], change = 0;
   for (int i = 0; i < n; i++) delta[i] = force[i] - oldforce[i];
   for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += Ac[i*n + j]*delta[j]; change += 0.5*delta[i]*t + delta[i]*res[i]; }
   if (change > 1e-10) { for (int i = 0; i < n; i++) force[i] = oldforce[i]; change = 0; }
@@ -2242,6 +2242,105 @@ static void noslip(const Model* m, Data* d) {
   chol_solve(d->qacc, d->qL, tmp, nv);
   free(tmp); free(res); free(A); free(W); free(rows);
 }
+/* ---- PGS (mj_solPGS; MuJoCo engine_solver.c, restated from the published algorithm; option solver="PGS",
+ * dm_control/mjcf/schema.xml:69-72; the reference's own hot-path asset mujoco/testing/assets/humanoid.xml:9 uses it).
+ * Dual problem: min over forces of 1/2 f'AR f + f'b, AR = J M^-1 J' + diag(R), b = J qacc_smooth - aref, with
+ *   equality rows free, dof-friction rows |f| <= frictionloss, limit / frictionless / pyramid-edge rows f >= 0,
+ *   elliptic contacts inside their friction cone.
+ * Gauss-Seidel over the rows: a scalar row takes its unconstrained minimum and is clamped; an elliptic contact does
+ * a normal (or ray) update followed by a QCQP over the friction dimensions with the normal fixed.  A block update that
+ * increases the cost by more than 1e-10 is undone.  Warm start (warmstart() in engine_forward.c): forces of
+ * qacc_warmstart through the primal map, kept only if their dual cost is below that of zero forces. */
+static void pgs_solve(const Model* m, Data* d) {
+  const int nv = m->nv, nefc = d->nefc;
+  double* W = (double*)malloc(sizeof(double) * (size_t)nefc * (size_t)nv);   /* M^-1 J' */
+  double* AR = (double*)malloc(sizeof(double) * (size_t)nefc * (size_t)nefc);
+  double* b = (double*)malloc(sizeof(double) * (size_t)nefc);
+  double* res = (double*)malloc(sizeof(double) * (size_t)nefc);
+  double* force = d->efc_force;
+  for (int a = 0; a < nefc; a++) chol_solve(W + (size_t)a*nv, d->qL, d->efc_J + (size_t)a*nv, nv);
+  for (int a = 0; a < nefc; a++) for (int c = 0; c <= a; c++) AR[a*nefc + c] = AR[c*nefc + a] = dot_n(d->efc_J + (size_t)a*nv, W + (size_t)c*nv, nv);
+  for (int a = 0; a < nefc; a++) AR[a*nefc + a] += d->efc_R[a];
+  for (int a = 0; a < nefc; a++) b[a] = dot_n(d->efc_J + (size_t)a*nv, d->qacc_smooth, nv) - d->efc_aref[a];
+  /* warm start */
+  if (!(m->opt_disableflags & DMC_DSBL_WARMSTART)) {
+    double* jar = d->w_Jaref;
+    for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc_warmstart, nv) - d->efc_aref[i];
+    constraint_update(m, d, jar, 0);
+    double cost = 0;
+    for (int i = 0; i < nefc; i++) { cost += force[i]*b[i]; cost += 0.5*force[i]*dot_n(AR + (size_t)i*nefc, force, nefc); }
+    if (cost > 0) for (int i = 0; i < nefc; i++) force[i] = 0;
+  } else for (int i = 0; i < nefc; i++) force[i] = 0;
+  const double scale = 1 / (m->stat_meaninertia * mjMAX(1, nv));
+  int iter = 0;
+  while (iter < m->opt_iterations) {
+    double improvement = 0;
+    for (int i = 0; i < nefc; ) {
+      const int t = d->efc_type[i];
+      const int dim = t == CT_ELLIPTIC ? d->contact[d->efc_id[i]].dim : 1;
+      double Athis[36], old[6], rs[6];
+      for (int p = 0; p < dim; p++) { rs[p] = b[i + p] + dot_n(AR + (size_t)(i + p)*nefc, force, nefc); old[p] = force[i + p]; }
+      if (dim == 1) {
+        Athis[0] = AR[i*nefc + i];
+        force[i] -= rs[0]/Athis[0];
+        if (t == CT_FRICTION_DOF) {
+          const double fl = m->dof_frictionloss[d->efc_id[i]];
+          if (force[i] < -fl) force[i] = -fl; else if (force[i] > fl) force[i] = fl;
+        } else if (t != CT_EQUALITY) { if (force[i] < 0) force[i] = 0; }
+      } else {
+        const Contact* c = d->contact + d->efc_id[i];
+        for (int p = 0; p < dim; p++) for (int q = 0; q < dim; q++) Athis[p*dim + q] = AR[(i + p)*nefc + i + q];
+        if (force[i] < MINVAL) {                       /* normal force too small: normal update, friction cleared */
+          force[i] -= rs[0]/Athis[0];
+          if (force[i] < 0) force[i] = 0;
+          for (int p = 1; p < dim; p++) force[i + p] = 0;
+        } else {                                       /* ray update along the current force */
+          double v[6], v1[6], denom = 0;
+          for (int p = 0; p < dim; p++) v[p] = force[i + p];
+          for (int p = 0; p < dim; p++) { v1[p] = dot_n(Athis + p*dim, v, dim); }
+          denom = dot_n(v, v1, dim);
+          if (denom >= MINVAL) {
+            double x = -dot_n(v, rs, dim) / denom;
+            if (force[i] + x*v[0] < 0) x = -force[i]/v[0];
+            for (int p = 0; p < dim; p++) force[i + p] += x*v[p];
+          }
+        }
+        /* friction update with the normal fixed */
+        double Ac[25], bc[5], v[5];
+        const int n = dim - 1;
+        for (int p = 0; p < n; p++) {
+          for (int q = 0; q < n; q++) Ac[p*n + q] = Athis[(p + 1)*dim + q + 1];
+          bc[p] = rs[p + 1];
+          for (int q = 0; q < n; q++) bc[p] -= Ac[p*n + q]*old[1 + q];
+          bc[p] += Athis[(p + 1)*dim]*(force[i] - old[0]);
+        }
+        if (force[i] < MINVAL) for (int p = 0; p < n; p++) force[i + 1 + p] = 0;
+        else {
+          const int active = qcqp(v, Ac, bc, c->friction, force[i], n);
+          if (active) {
+            double ss = 0;
+            for (int p = 0; p < n; p++) ss += v[p]*v[p]/(c->friction[p]*c->friction[p]);
+            ss = sqrt(force[i]*force[i] / mjMAX(MINVAL, ss));
+            for (int p = 0; p < n; p++) v[p] *= ss;
+          }
+          for (int p = 0; p < n; p++) force[i + 1 + p] = v[p];
+        }
+      }
+      improvement -= noslip_cost_change(Athis, force + i, old, rs, dim);
+      i += dim;
+    }
+    improvement *= scale;
+    iter++;
+    if (improvement < m->opt_tolerance) break;
+  }
+  d->solver_iter = iter;
+  /* dualFinish: qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 qfrc_constraint */
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*force[r];
+  chol_solve(d->qacc, d->qL, d->qfrc_constraint, nv);
+  for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
+  free(res); free(b); free(AR); free(W);
+}
 static void fwd_constraint(const Model* m, Data* d) {
   int nv = m->nv, nefc = d->nefc;
   d->solver_iter = 0;
@@ -2249,6 +2348,12 @@ static void fwd_constraint(const Model* m, Data* d) {
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
     memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * (size_t)nv);
     memset(d->qfrc_constraint, 0, sizeof(double) * (size_t)nv);
+    return;
+  }
+  if (m->opt_solver == DMC_SOL_PGS) {
+    pgs_solve(m, d);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * (size_t)nv);
+    if (m->opt_noslip_iterations > 0) noslip(m, d);
     return;
   }
   double *jar = d->w_Jaref, *Ma = d->w_Ma;

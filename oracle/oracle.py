@@ -75,8 +75,6 @@ class OracleModel:
 
   def __init__(self, compiled):
     self.compiled = compiled
-    if compiled.opt.solver == 0:
-      raise ValueError('the PGS solver is not restated in the oracle (Newton and CG are)')
     ints, reals = compiled.pack()
     self._ints, self._reals = ints, reals
     self.ptr = lib().ora_model_create(

@@ -28,6 +28,8 @@ nsub = int(os.environ.get('NSUB', 1))
 m = mc.compile_xml(common.read_model(name + '.xml'))
 caps = dict(common.DEFAULT_CAPS.get(name, {}))
 caps.pop('precision', None)
+if os.environ.get('LANES'):
+  caps['lanes_per_env'] = int(os.environ['LANES'])
 
 
 def rel(qg, qo):

@@ -22,14 +22,17 @@ ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 # (profiles/r02_parity_dist_cheetah_f32.json): median 1.6e-6, 95 % <= 4.6e-6, 98.8 % <= 1e-4; the three
 # environments above 1e-4 stay below it for 650+ steps and then diverge through a contact that
 # closes one step earlier or later (their per-step, teacher-forced error never exceeds 1e-5).  Held to:
-# median <= 5e-6, at least 95 % of environments <= 1e-4 (north_star; 2 of 64 happens), and every environment above 1e-4 is justified
+# (Round 3, relative line-search cost in fp32, 512 environments x 1000 steps, profiles/r03_parity_dist_cheetah_f32_lanes{16,32,64}.json:
+# 99.4 % <= 1e-4 at 16 / 32 lanes, 98.4 % at 64 lanes -- a different summation order, other environments in the tail;
+# teacher-forced per-step error median 3e-7, 99 % <= 9.5e-7 for all three.)
+# median <= 5e-6, at least 98 % of environments <= 1e-4 on the production shape (north_star), and every environment above 1e-4 is justified
 # individually: replayed teacher-forced (the kernel restarted from the oracle's state at every one of its 1000
 # steps, same actions) its per-step error must stay below 5e-5 -- the open-loop gap is then amplification of
 # rounding by the dynamics, not a defect of the step (stiff contacts: |qacc| ~ 1e3..1e4 with ~1e-5 relative
 # error, times dt^2) -- except on the rare steps where a contact is just touching (|dist| < 1e-6) and fp32 / fp64
 # disagree about activating it, which the replay identifies and reports (_teacher_forced_replay).
 TOL_F64_1000 = 1e-9
-TOL_F32_MEDIAN, TOL_F32_FRAC_1E4 = 5e-6, 0.95
+TOL_F32_MEDIAN, TOL_F32_FRAC_1E4 = 5e-6, 0.98      # production shape (32 lanes, 256 envs); the 64-env shapes: at most 5 environments
 TOL_F32_ONE_STEP = 5e-5
 
 
@@ -192,7 +195,7 @@ def test_cheetah_1000_step_rollout(cheetah, precision, lanes, NE):
     assert worst.max() < TOL_F64_1000, worst.max()
   else:
     assert np.median(worst) < TOL_F32_MEDIAN, np.median(worst)
-    assert np.mean(worst <= 1e-4) >= TOL_F32_FRAC_1E4, np.sort(worst)[-5:]
+    assert np.sum(worst > 1e-4) <= (5 if NE < 256 else int(round((1 - TOL_F32_FRAC_1E4) * NE))), np.sort(worst)[-8:]
     tail = np.nonzero(worst > 1e-4)[0]
     if tail.size:
       step_err, events = _teacher_forced_replay(m, q[tail], acts[:, tail], lanes)
@@ -943,8 +946,7 @@ def test_cg_solver_on_device(asset, precision, teacher, tol):
   the solver tolerance instead of converging quadratically, so two implementations agree per step to ~1e-8 of the
   acceleration scale, not to rounding: fp64 open loop over 60 steps (measured 8e-15 cheetah, 1.6e-6 humanoid), fp32
   teacher-forced (measured 1.1e-4 / 5.6e-4 per step: in fp32 the conjugate directions lose orthogonality to rounding
-  and the iteration stops on its floors; the production solver is Newton).  PGS is refused at batch creation."""
-  from dm_control_amd import _native
+  and the iteration stops on its floors; the production solver is Newton)."""
   from oracle import oracle
   with open(os.path.join(ASSETS, asset + '.xml')) as f:
     xml = f.read()
@@ -973,5 +975,43 @@ def test_cg_solver_on_device(asset, precision, teacher, tol):
   assert worst < tol, worst
   assert iters > 4 and not b.get('warning').any()
   b.close()
-  with pytest.raises(_native.NativeError, match='PGS'):
-    _batch(mc.compile_xml(xml.replace('<option', '<option solver="PGS"', 1)), 4)
+
+
+@pytest.mark.parametrize('cone,condim,precision,tol', [('pyramidal', 3, 64, 1e-9), ('elliptic', 3, 64, 1e-9), ('elliptic', 4, 64, 1e-9),
+                                                       ('elliptic', 6, 64, 1e-9), ('pyramidal', 3, 32, 1e-4), ('elliptic', 4, 32, 1e-4)])
+def test_pgs_solver_on_device(cone, condim, precision, tol):
+  """option solver="PGS" (north_star "PGS/Newton"; the reference's own hot-path test asset
+  mujoco/testing/assets/humanoid.xml:9 = suite/assets/testing_humanoid_pgs.xml: PGS + RK4) on the device against the
+  oracle, teacher-forced including the warm start (PGS stops at its 50-iteration cap, far from convergence: its answer
+  depends on the warm start and open-loop runs separate by chaos).  Pyramidal and elliptic cones, condim 3 / 4 / 6."""
+  from oracle import oracle
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from test_pgs import _xml
+  m = mc.compile_xml(_xml(cone=cone, floor_condim=condim))
+  assert m.opt.solver == 0 and m.opt.integrator == 1
+  B, T = 16, 120
+  rs = np.random.RandomState(9)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, 2] = rs.uniform(0.5, 1.0, B)
+  q[:, 7:] += rs.uniform(-0.3, 0.3, (B, m.nq - 7))
+  b = _batch(m, B, precision=precision)
+  refs = _oracles(m, q)
+  worst, iters, nefc = 0.0, 0, 0
+  for t in range(T):
+    a = rs.uniform(-1, 1, (B, m.nu)).astype(np.float32).astype(np.float64)
+    b.set('qpos', np.stack([p.qpos for p in refs]))
+    b.set('qvel', np.stack([p.qvel for p in refs]))
+    b.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+    b.set_control(a)
+    b.step()
+    oracle.rollout_legacy(refs, a[None])
+    worst = max(worst, _rel_err(b.get('qpos'), np.stack([p.qpos for p in refs])))
+    iters = max(iters, int(b.get('solver_iter').max()))
+    nefc = max(nefc, int(b.get('nefc').max()))
+    if precision == 64:
+      np.testing.assert_array_equal(b.get('solver_iter')[:, 0], [p.solver_iter for p in refs])
+  print('measured: pgs %s condim %d fp%d teacher-forced max rel dqpos=%.3g, max iterations %d, max nefc %d' % (cone, condim, precision, worst, iters, nefc))
+  assert worst < tol, worst
+  assert iters >= 10 and nefc >= 12 and not b.get('warning').any()
+  b.close()

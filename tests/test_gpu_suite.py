@@ -721,7 +721,11 @@ def test_baseline_62dof_and_soccer_fp32_error_of_one_physics_step(cfgid):
   the GPU state is overwritten by the oracle's before EVERY physics step (legacy Physics.step(1)), so each of the
   64 x 50 x n_sub_steps comparisons is the arithmetic error of one mj_step from identical state.  (Forced only every
   env-step, 0.2 % of the env-steps exceed 1e-4 -- bench.py `parity.teacher-forced.per_step`: a contact that fp32 and
-  fp64 activate one physics step apart changes the following substeps; the per-physics-step figure has no such tail.)"""
+  fp64 activate one physics step apart changes the following substeps; the per-physics-step figure has no such tail.)
+  Steps on which the two disagree about a contact that is JUST TOUCHING (|dist| below fp32 resolution; margin 0) are
+  identified by comparing the contact sets at the forced state, counted and excluded, as in
+  test_gpu_parity._teacher_forced_replay: MuJoCo's dynamics are discontinuous there.  Config 5 starts that way (the
+  players' feet rest exactly on the pitch: dist = 0 in fp64, -1e-7 in fp32)."""
   import os
   import sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -742,19 +746,36 @@ def test_baseline_62dof_and_soccer_fp32_error_of_one_physics_step(cfgid):
   rs = np.random.RandomState(77)
   nth = os.cpu_count() or 1
   errs = []
+  events = []
   for t in range(T):
     a = rs.uniform(-1, 1, (NE, m.nu)).astype(np.float32).astype(np.float64)
     g.set_control(a)
     for k in range(nsub):
       g.set('qpos', np.stack([p.qpos for p in refs])); g.set('qvel', np.stack([p.qvel for p in refs]))
-      g.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+      g.forward()      # the contact set the fp32 kernel sees at the oracle's state
+      ncon, dist, g1, g2 = g.get('ncon')[:, 0], g.get('contact_dist'), g.get('contact_geom1'), g.get('contact_geom2')
+      edge = np.zeros(NE, bool)
+      for e, p in enumerate(refs):
+        if int(ncon[e]) == p.ncon:
+          continue
+        mine = {(int(g1[e, c]), int(g2[e, c])): float(dist[e, c]) for c in range(int(ncon[e]))}
+        theirs = {(cc['geom1'], cc['geom2']): cc['dist'] for cc in (p.contact(c) for c in range(p.ncon))}
+        only = [d for kk, d in mine.items() if kk not in theirs] + [d for kk, d in theirs.items() if kk not in mine]
+        # margin = 0: a contact exists iff dist < 0; positions reach ~30 m on the pitch (fp32 ulp 2e-6)
+        assert only and all(abs(d) < 1e-5 for d in only), ('contact sets differ beyond rounding', e, t, k, only)
+        edge[e] = True
+        events.append((e, t, k, only[0]))
+      g.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))      # mj_forward left its own solution there
       g.step(1)
       bench.threaded_rollout(refs, a[None], 1, nth)
-      errs.append(bench.rel_err(g.get('qpos'), np.stack([p.qpos for p in refs])))
+      errs.append(np.where(edge, 0.0, bench.rel_err(g.get('qpos'), np.stack([p.qpos for p in refs]))))
   e = np.concatenate(errs)
+  print('measured: config %d fp32 one-physics-step error over %d steps: median %.2e p99 %.2e max %.2e; %d steps excluded '
+        'for a just-touching contact decided by the last bit: %s' % (cfgid, e.size, np.median(e), np.percentile(e, 99), e.max(), len(events), events[:6]))
   assert e.size == NE * T * nsub
   assert np.median(e) < 1e-6, np.median(e)
   assert e.max() <= 1e-4, (e.max(), np.sort(e)[-5:])
+  assert len(events) <= 0.01 * e.size + NE, len(events)      # config 5 starts with every foot resting exactly on the pitch: the first step of each environment
   assert max(p.ncon for p in refs) > 0 and not g.get('warning').any()
   g.close()
 

@@ -682,9 +682,9 @@ def test_cg_solver_matches_oracle(asset, prec, tol):
   assert max(iters) > 4      # CG takes more iterations than Newton ever does on these models
 
 
-def test_cg_reaches_the_newton_solution_and_pgs_is_rejected():
-  """Both solvers minimise the same convex cost: at a tight tolerance their accelerations agree; PGS (the dual
-  solver) is not implemented and is refused, never silently replaced."""
+def test_cg_reaches_the_newton_solution():
+  """Both solvers minimise the same convex cost: at a tight tolerance their accelerations agree (PGS, the dual
+  solver: tests/test_pgs.py)."""
   mN = mc.compile_xml(_with_option('cheetah', iterations='200', tolerance='1e-12'))
   mC = mc.compile_xml(_with_option('cheetah', solver='CG', iterations='200', tolerance='1e-12'))
   rs = np.random.RandomState(0)
@@ -702,5 +702,3 @@ def test_cg_reaches_the_newton_solution_and_pgs_is_rejected():
     assert a.nefc > 0
     assert np.abs(a.qacc - b.qacc).max() / scale < 1e-6
     assert np.abs(b.qacc - e.qacc).max() / scale < 1e-6      # at this tolerance the kernel's rounding floor on the stopping tests ends CG a few iterations earlier
-  with pytest.raises(Exception, match='PGS'):
-    EmuPhysics(mc.compile_xml(_with_option('cheetah', solver='PGS')), 64)
