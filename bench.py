@@ -206,9 +206,12 @@ def initial_qpos(cfg, model, n, seed0, phys=None):
     rs = np.random.RandomState(seed0)
     q[:, 0:2] += rs.uniform(-4, 4, (n, 2))       # arena_position: U(-size/2, size/2), Floor size 8 x 8
   elif asset == 'soccer_2v2_boxhead':
+    from dm_control_amd.composer.tasks import soccer
     rs = np.random.RandomState(seed0)
-    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-8, 8, (n, 8))      # players around their kick-off spots
-    q[:, 24:26] += rs.uniform(-15, 15, (n, 2))                           # ball
+    q = np.tile(soccer.kickoff_qpos(m), (n, 1))      # PyMJCF's qpos0 has every entity at the origin
+    adr = soccer.addresses(m)
+    q[:, [a for xy in adr['players'] for a in xy]] += rs.uniform(-8, 8, (n, 8))      # players around their kick-off spots
+    q[:, adr['ball_q']:adr['ball_q'] + 2] += rs.uniform(-15, 15, (n, 2))            # ball
   return q
 
 

@@ -1,8 +1,9 @@
 """BASELINE config 5 as an environment: locomotion.soccer 2-vs-2 with BoxHead walkers, for a batch on device.
 
 Task layer of `dm_control.locomotion.soccer.load(team_size=2, walker_type=BOXHEAD)` (soccer/__init__.py:92-148,
-soccer/task.py:36-230) over the restated physics asset `suite/assets/soccer_2v2_boxhead.xml`
-(scripts/make_soccer_model.py):
+soccer/task.py:36-230) over `suite/assets/soccer_2v2_boxhead.xml`, which is the XML the reference's own PyMJCF
+composition produces for that call (scripts/make_pymjcf_goldens.py; element names are PyMJCF's: `home0/root_x/`,
+`soccer_ball/`, `//unnamed_geom_1..4` for the four walls):
 
   * 4 agents: the action is (B, 4, 3) = per player (roll, steer, kick), written to the players' actuators
     (`walker.apply_action`, task.py:211-213);
@@ -38,7 +39,7 @@ from dm_control_amd.suite import common
 _ASSET = 'soccer_2v2_boxhead'
 _PLAYERS = ('home0', 'home1', 'away0', 'away1')
 _TEAM = (0, 0, 1, 1)                                   # 0 = HOME (defends -x), 1 = AWAY
-_SPOTS = np.array([(-10., 5.), (-10., -5.), (10., 5.), (10., -5.)])      # attachment frames of the asset
+_SPOTS = np.zeros((4, 2))      # attachment frames of the players: PyMJCF attaches every walker at the origin
 _SIZE = np.array([40.0, 30.0])
 _SIDE_WIDTH = 32. / 6.
 _GOAL_SIZE = np.array([_SIDE_WIDTH / 2, _SIZE[1] * 0.33, _SIDE_WIDTH / 2])       # pitch.py _get_goal_size
@@ -49,6 +50,29 @@ _GOALPOSTS = {'right_post': (1, -1, -1, 1, -1, 1), 'left_post': (1, 1, -1, 1, 1,
               'right_base': (1, -1, -1, -1, -1, -1), 'left_base': (1, 1, -1, -1, 1, -1), 'back_base': (-1, -1, -1, -1, 1, -1),
               'right_support': (-1, -1, -1, .2, -1, 1), 'right_top_support': (.2, -1, 1, 1, -1, 1),
               'left_support': (-1, 1, -1, .2, 1, 1), 'left_top_support': (.2, 1, 1, 1, 1, 1)}
+
+
+def addresses(model):
+  """qpos / qvel addresses of the composed model by PyMJCF element name: {'players': [(qx, qy) x 4 in _PLAYERS order],
+  'ball_q': first qpos of the ball's free joint, 'ball_v': first dof} -- for callers that place entities directly
+  (bench.py, tests) instead of through the task's initializer."""
+  jq = lambda n: int(model.jnt_qposadr[model.name2id(n, 'joint')])
+  return dict(players=[(jq(p + '/root_x/'), jq(p + '/root_y/')) for p in _PLAYERS], ball_q=jq('soccer_ball/'),
+              ball_v=int(model.jnt_dofadr[model.name2id('soccer_ball/', 'joint')]))
+
+
+KICKOFF_SPOTS = np.array([(-10., 5.), (-10., -5.), (10., 5.), (10., -5.)])      # where bench / tests stand the players
+
+
+def kickoff_qpos(model):
+  """qpos0 with the players on KICKOFF_SPOTS and the ball above the centre spot at the initializer's height
+  (soccer/initializers.py:31 `_INIT_BALL_Z`): PyMJCF's own qpos0 has all five entities at the origin."""
+  q = np.array(model.qpos0, dtype=float)
+  a = addresses(model)
+  for (qx, qy), xy in zip(a['players'], KICKOFF_SPOTS):
+    q[qx], q[qy] = xy
+  q[a['ball_q'] + 2] = 0.5
+  return q
 
 
 class PositionDetector(environment.Entity):
@@ -122,13 +146,14 @@ class Soccer2v2(environment.Task):
       d.bind_ball(self)
     m = self.model
     self._ball_geom = m.name2id('soccer_ball/geom', 'geom')
-    self._ball_body = m.name2id('soccer_ball', 'body')
+    self._ball_body = m.name2id('soccer_ball/', 'body')
     self._root = [m.name2id(p + '/head_body', 'body') for p in _PLAYERS]
     jq = lambda n: int(m.jnt_qposadr[m.name2id(n, 'joint')])
     jv = lambda n: int(m.jnt_dofadr[m.name2id(n, 'joint')])
-    self._q = {p: {k: jq('%s/%s' % (p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
-    self._v = {p: {k: jv('%s/%s' % (p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
-    self._ball_q, self._ball_v = jq('soccer_ball'), jv('soccer_ball')
+    jn = lambda p, k: '%s/%s%s' % (p, k, '/' if k.startswith('root_') else '')      # attachment-frame joints: `home0/root_x/`
+    self._q = {p: {k: jq(jn(p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
+    self._v = {p: {k: jv(jn(p, k)) for k in ('root_x', 'root_y', 'root_z', 'steer', 'kick', 'roll')} for p in _PLAYERS}
+    self._ball_q, self._ball_v = jq('soccer_ball/'), jv('soccer_ball/')
     self._ctrl_rows = [[m.name2id('%s/%s' % (p, a), 'actuator') for a in ('roll', 'steer', 'kick')] for p in _PLAYERS]
     sadr = lambda n: int(m.sensor_adr[m.name2id(n, 'sensor')])
     self._sens = {p: {k: sadr('%s/sensor_torso_%s' % (p, k)) for k in ('vel', 'gyro', 'accel')} for p in _PLAYERS}
@@ -155,7 +180,7 @@ class Soccer2v2(environment.Task):
 
   def pitch_geoms(self):
     """The geoms a pitch resize moves: 4 walls, then the 10 posts of each goal."""
-    return ['wall%d' % k for k in range(4)] + ['%s/%s' % (g, p) for g in ('home_goal', 'away_goal') for p in _GOALPOSTS]
+    return ['//unnamed_geom_%d' % (k + 1) for k in range(4)] + ['%s/%s' % (g, p) for g in ('home_goal', 'away_goal') for p in _GOALPOSTS]
 
   def _resize_pitch(self, physics, size, mask):
     """RandomizedPitch.initialize_episode_mjcf (pitch.py:645-669) for the masked environments; size: (2, B)."""

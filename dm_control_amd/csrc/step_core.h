@@ -566,6 +566,7 @@ struct StepCore {
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
 #define MRC(n) (mrc() + L.mr_##n)   // a cold real table (STEP_MODEL_COLD_REAL_TABLES)
+#define MRS(n) ((L.d.sitegl ? (const T*)o.g_mr : (const T*)mr) + L.mr_##n)   // a site table (STEP_MODEL_SITE_REAL_TABLES)
 #define GC(n) (gc + L.mc_##n)
 #define S(n) (s + L.s_##n)
 #define SI(n) (si + L.si_##n)
@@ -706,9 +707,9 @@ struct StepCore {
     }
     if (mask & OUT_SITE) FOR_LANES(sid, L.d.nsite) {
       int b = MI(site_bodyid)[sid]; T v[3], q[4], m[9];
-      mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*sid);
+      mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*sid);
       for (int k = 0; k < 3; k++) io.site_xpos[(size_t)(3*sid + k)*B + env] = S(xpos)[3*b + k] + v[k];
-      mul_quat(q, S(xquat) + 4*b, MR(site_quat) + 4*sid);
+      mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*sid);
       quat2mat(m, q);
       for (int k = 0; k < 9; k++) io.site_xmat[(size_t)(9*sid + k)*B + env] = m[k];
     }
@@ -1613,7 +1614,7 @@ struct StepCore {
   // ---- tendons (mj_tendon for fixed and site-to-site spatial tendons) -----------------------
   DMC_DEV void site_world_pos(int sid, T* p) {
     const int b = MI(site_bodyid)[sid]; T v[3];
-    mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*sid);
+    mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*sid);
     for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
   }
   DMC_DEV T tendon_length(int t) {
@@ -2390,9 +2391,9 @@ struct StepCore {
       if (t == DMC_SENS_ACTUATORFRC) { out[0] = S(actuator_force)[id]; continue; }
       const int body = MI(site_bodyid)[id];
       T v[3], q[4], smat[9], spos[3];
-      mul_mat_vec3(v, S(xmat) + 9*body, MR(site_pos) + 3*id);
+      mul_mat_vec3(v, S(xmat) + 9*body, MRS(site_pos) + 3*id);
       for (int k = 0; k < 3; k++) spos[k] = S(xpos)[3*body + k] + v[k];
-      mul_quat(q, S(xquat) + 4*body, MR(site_quat) + 4*id);
+      mul_quat(q, S(xquat) + 4*body, MRS(site_quat) + 4*id);
       quat2mat(smat, q);
       const T* rc = S(subtree_com) + 3*MI(body_rootid)[body];
       if (t == DMC_SENS_TOUCH) {
@@ -2407,7 +2408,7 @@ struct StepCore {
           T ray[3] = {fr[0]*lf[0], fr[1]*lf[0], fr[2]*lf[0]};
           normalize3(ray);
           if (b2 == body) { ray[0] = -ray[0]; ray[1] = -ray[1]; ray[2] = -ray[2]; }
-          if (ray_geom(spos, smat, MR(site_size) + 3*id, S(con_pos) + 3*c, ray, MI(site_type)[id]) >= 0) tot += lf[0];
+          if (ray_geom(spos, smat, MRS(site_size) + 3*id, S(con_pos) + 3*c, ray, MI(site_type)[id]) >= 0) tot += lf[0];
         }
         out[0] = tot;
       } else if (t == DMC_SENS_ACCELEROMETER) {
@@ -2431,6 +2432,24 @@ struct StepCore {
     }
     DMC_WSYNC();
   }
+  // pose (origin, quaternion) of a sensor's reference frame (mj_sensorPos)
+  DMC_DEV void sensor_ref_pose(int rt, int rid, T* p, T* q) {
+    if (rt == DMC_OBJ_SITE) {
+      const int b = MI(site_bodyid)[rid]; T v[3];
+      mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*rid);
+      for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
+      mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*rid);
+    } else if (rt == DMC_OBJ_GEOM) {
+      for (int k = 0; k < 3; k++) p[k] = S(geom_xpos)[3*rid + k];
+      mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[rid], MRC(geom_quat) + 4*rid);
+    } else if (rt == DMC_OBJ_BODY) {
+      for (int k = 0; k < 3; k++) p[k] = S(xipos)[3*rid + k];
+      mul_quat(q, S(xquat) + 4*rid, MRC(body_iquat) + 4*rid);
+    } else {
+      for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*rid + k];
+      for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*rid + k];
+    }
+  }
   DMC_DEV void sensors(int stage) {
     if ((o.disableflags & DMC_DSBL_SENSOR) || L.d.nsensor == 0) return;
     if (L.d.nstv && stage == DMC_STAGE_VEL) subtree_linvel_sensors();
@@ -2443,12 +2462,12 @@ struct StepCore {
       else if (t == DMC_SENS_ACTUATORFRC) out[0] = S(actuator_force)[id];
       else if (t == DMC_SENS_SUBTREECOM) for (int k = 0; k < 3; k++) out[k] = S(subtree_com)[3*id + k];
       else if (t >= DMC_SENS_FRAMEXAXIS && t <= DMC_SENS_FRAMEZAXIS) {
-        const int ot = MI(sensor_objtype)[i], c = t - DMC_SENS_FRAMEXAXIS;
+        const int otr = MI(sensor_objtype)[i], ot = otr & 255, c = t - DMC_SENS_FRAMEXAXIS;
         if (ot == DMC_OBJ_SITE || ot == DMC_OBJ_BODY) {
           // column c of quat2mat(q) = q rotating the unit vector e_c (no matrix held in memory:
           // selecting between a local array and an LDS array through a pointer pins it in scratch)
           T q[4], e[3] = {c == 0 ? (T)1 : (T)0, c == 1 ? (T)1 : (T)0, c == 2 ? (T)1 : (T)0}, col[3];
-          if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
+          if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
           else mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
           rot_vec_quat(col, e, q);
           out[0] = col[0]; out[1] = col[1]; out[2] = col[2];
@@ -2456,16 +2475,31 @@ struct StepCore {
           const T* Rp = ot == DMC_OBJ_GEOM ? S(geom_xmat) + 9*id : S(xmat) + 9*id;
           out[0] = Rp[c]; out[1] = Rp[3 + c]; out[2] = Rp[6 + c];
         }
+        if (otr >> 16) {      // the axis in the reference frame: conj(q_ref) rotates it
+          T qr[4], pr[3], ax[3] = {out[0], out[1], out[2]}, r[3];
+          sensor_ref_pose((otr >> 8) & 255, (otr >> 16) - 1, pr, qr);
+          qr[1] = -qr[1]; qr[2] = -qr[2]; qr[3] = -qr[3];
+          rot_vec_quat(r, ax, qr);
+          out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+        }
       }
       else if (t == DMC_SENS_FRAMEPOS) {
-        const int ot = MI(sensor_objtype)[i];
+        const int otr = MI(sensor_objtype)[i], ot = otr & 255;
         if (ot == DMC_OBJ_SITE) {
           const int b = MI(site_bodyid)[id]; T v[3];
-          mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+          mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*id);
           for (int k = 0; k < 3; k++) out[k] = S(xpos)[3*b + k] + v[k];
         } else {
           const T* p = ot == DMC_OBJ_GEOM ? S(geom_xpos) + 3*id : (ot == DMC_OBJ_BODY ? S(xipos) + 3*id : S(xpos) + 3*id);
           for (int k = 0; k < 3; k++) out[k] = p[k];
+        }
+        if (otr >> 16) {      // R_ref' (p - p_ref)
+          T qr[4], pr[3], r[3];
+          sensor_ref_pose((otr >> 8) & 255, (otr >> 16) - 1, pr, qr);
+          const T df[3] = {out[0] - pr[0], out[1] - pr[1], out[2] - pr[2]};
+          qr[1] = -qr[1]; qr[2] = -qr[2]; qr[3] = -qr[3];
+          rot_vec_quat(r, df, qr);
+          out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
         }
       }
       else if (t == DMC_SENS_SUBTREELINVEL) {}   // written by subtree_linvel_sensors()
@@ -2473,9 +2507,9 @@ struct StepCore {
         // mj_ray along the site's z axis: nearest visible geom that is not on the site's own body
         const int sb = MI(site_bodyid)[id];
         T v[3], sp[3], q[4], e[3] = {0, 0, 1}, vec[3];
-        mul_mat_vec3(v, S(xmat) + 9*sb, MR(site_pos) + 3*id);
+        mul_mat_vec3(v, S(xmat) + 9*sb, MRS(site_pos) + 3*id);
         for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*sb + k] + v[k];
-        mul_quat(q, S(xquat) + 4*sb, MR(site_quat) + 4*id);
+        mul_quat(q, S(xquat) + 4*sb, MRS(site_quat) + 4*id);
         rot_vec_quat(vec, e, q);
         T best = -1;
         for (int g = 0; g < L.d.ngeom; g++) {
@@ -2486,21 +2520,28 @@ struct StepCore {
         out[0] = best;
       }
       else if (t == DMC_SENS_FRAMEQUAT) {
-        const int ot = MI(sensor_objtype)[i];
+        const int otr = MI(sensor_objtype)[i], ot = otr & 255;
         T q[4];
-        if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MR(site_quat) + 4*id);
+        if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
         else if (ot == DMC_OBJ_GEOM) mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[id], MRC(geom_quat) + 4*id);
         else if (ot == DMC_OBJ_BODY) mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
         else for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*id + k];
+        if (otr >> 16) {      // conj(q_ref) q
+          T qr[4], pr[3], qq[4];
+          sensor_ref_pose((otr >> 8) & 255, (otr >> 16) - 1, pr, qr);
+          qr[1] = -qr[1]; qr[2] = -qr[2]; qr[3] = -qr[3];
+          mul_quat(qq, qr, q);
+          for (int k = 0; k < 4; k++) q[k] = qq[k];
+        }
         for (int k = 0; k < 4; k++) out[k] = q[k];
       }
       else if (t == DMC_SENS_FRAMELINVEL || t == DMC_SENS_FRAMEANGVEL) {
         // mj_objectVelocity in world orientation at the object's frame origin
-        const int ot = MI(sensor_objtype)[i];
+        const int otr = MI(sensor_objtype)[i], ot = otr & 255;
         const int b = ot == DMC_OBJ_SITE ? MI(site_bodyid)[id] : (ot == DMC_OBJ_GEOM ? MI(geom_bodyid)[id] : id);
         T p[3];
         if (ot == DMC_OBJ_SITE) {
-          T v[3]; mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+          T v[3]; mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*id);
           for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
         } else {
           const T* pp = ot == DMC_OBJ_GEOM ? S(geom_xpos) + 3*id : (ot == DMC_OBJ_BODY ? S(xipos) + 3*id : S(xpos) + 3*id);
@@ -2509,15 +2550,36 @@ struct StepCore {
         const T* rc = S(subtree_com) + 3*MI(body_rootid)[b];
         const T dif[3] = {p[0] - rc[0], p[1] - rc[1], p[2] - rc[2]};
         const T* cv = S(cvel) + 6*b;
-        T tmp[3];
+        T tmp[3], w[3], v[3];
         cross3(tmp, dif, cv);
-        for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_FRAMEANGVEL ? cv[k] : cv[3 + k] - tmp[k];
+        for (int k = 0; k < 3; k++) { w[k] = cv[k]; v[k] = cv[3 + k] - tmp[k]; }
+        if (otr >> 16) {
+          // relative to a moving reference frame (mj_sensorVel): R_ref' (v - v_ref + r x w_ref), R_ref' (w - w_ref)
+          const int rt = (otr >> 8) & 255, rid = (otr >> 16) - 1;
+          const int rb = rt == DMC_OBJ_SITE ? MI(site_bodyid)[rid] : (rt == DMC_OBJ_GEOM ? MI(geom_bodyid)[rid] : rid);
+          T qr[4], pr[3], cr[3], rel[3], res[3];
+          sensor_ref_pose(rt, rid, pr, qr);
+          const T* rcr = S(subtree_com) + 3*MI(body_rootid)[rb];
+          const T difr[3] = {pr[0] - rcr[0], pr[1] - rcr[1], pr[2] - rcr[2]};
+          const T* cvr = S(cvel) + 6*rb;
+          if (t == DMC_SENS_FRAMEANGVEL) for (int k = 0; k < 3; k++) rel[k] = w[k] - cvr[k];
+          else {
+            const T r[3] = {p[0] - pr[0], p[1] - pr[1], p[2] - pr[2]};
+            cross3(tmp, difr, cvr);
+            cross3(cr, r, cvr);
+            for (int k = 0; k < 3; k++) rel[k] = v[k] - (cvr[3 + k] - tmp[k]) + cr[k];
+          }
+          qr[1] = -qr[1]; qr[2] = -qr[2]; qr[3] = -qr[3];
+          rot_vec_quat(res, rel, qr);
+          for (int k = 0; k < 3; k++) { w[k] = res[k]; v[k] = res[k]; }
+        }
+        for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_FRAMEANGVEL ? w[k] : v[k];
       }
       else if (t == DMC_SENS_VELOCIMETER || t == DMC_SENS_GYRO) {
         const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
-        mul_mat_vec3(v, S(xmat) + 9*b, MR(site_pos) + 3*id);
+        mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*id);
         for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*b + k] + v[k];
-        mul_quat(q, S(xquat) + 4*b, MR(site_quat) + 4*id);
+        mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*id);
         quat2mat(m, q);
         object_velocity(b, sp, m, v6);
         for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_GYRO ? v6[k] : v6[3 + k];

@@ -50,6 +50,9 @@ struct StepDims {
   int cg;        // 1: option solver="CG" (conjugate gradient on the same primal problem, preconditioned with M^-1)
   int jfull;     // 1 (nv <= 16): EVERY constraint row is stored as a dense row of nv entries in efc_Jd (row classes and
                  //   compression pay off for long chains; on a 9-dof model their index arithmetic cost 10 % of the step)
+  int sitegl;    // 1 (nsite > 32): the real site tables (pos, quat, size) stay in global memory (StepOpts::g_mr) -- composed
+                 //   scenes carry render-only sites (soccer: 120 hoarding boards of 136 sites) that only an output
+                 //   pass over ALL sites ever reads; sensors touch a handful, one per lane
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
                  //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables.
@@ -120,7 +123,6 @@ struct StepDims {
   X(geom_rbound, d.ngeom)                                                      \
   X(prm_margin, d.nprm) X(prm_gap, d.nprm) X(prm_friction, 3 * d.nprm)         \
   X(prm_solref, 2 * d.nprm) X(prm_solimp, 5 * d.nprm)  /* distinct contact-parameter tuples */ \
-  X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite) \
   X(wrap_prm, d.nwrap)                                                         \
   X(act_dynprm, d.na ? d.nu : 0)  /* time constant of filter dynamics */          \
   X(tendon_stiffness, d.ntendon) X(tendon_damping, d.ntendon) X(tendon_lengthspring, d.ntendon) \
@@ -138,7 +140,10 @@ struct StepDims {
   X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom)                           \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
   X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
-#define STEP_MODEL_REAL_TABLES(X) STEP_MODEL_HOT_REAL_TABLES(X) STEP_MODEL_COLD_REAL_TABLES(X)
+// site tables: hot (LDS) for ordinary models, behind the cold tables and left in global memory when StepDims::sitegl
+#define STEP_MODEL_SITE_REAL_TABLES(X)                                         \
+  X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite)
+#define STEP_MODEL_REAL_TABLES(X) STEP_MODEL_HOT_REAL_TABLES(X) STEP_MODEL_COLD_REAL_TABLES(X) STEP_MODEL_SITE_REAL_TABLES(X)
 
 // ---- per-environment scratch (reals) -------------------------------------------
 // Persistent arrays (live across the whole substep) ...
@@ -275,12 +280,15 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
   o = 0;
 #define X(name, cnt) L->mr_##name = o; o += (cnt);
   STEP_MODEL_HOT_REAL_TABLES(X)
+  if (!d.sitegl) { STEP_MODEL_SITE_REAL_TABLES(X) }
   o = (o + 3) & ~3;
   L->n_mr_lds = o;
   STEP_MODEL_COLD_REAL_TABLES(X)
+  o = (o + 3) & ~3;
+  if (d.jglobal < 2) L->n_mr_lds = o;
+  if (d.sitegl) { STEP_MODEL_SITE_REAL_TABLES(X) }
 #undef X
   L->n_mr = (o + 3) & ~3;
-  if (d.jglobal < 2) L->n_mr_lds = L->n_mr;
   o = 0;
 #define X(name, cnt) L->mc_##name = o; o += (cnt);
   STEP_MODEL_COLD_TABLES(X)

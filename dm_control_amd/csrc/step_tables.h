@@ -257,6 +257,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   d.msparse = m.nv > 16 ? 1 : 0;
   d.jglobal = DMC_JGLOBAL_LEVEL(m.nv);
+  d.sitegl = m.nsite > 32 ? 1 : 0;
   d.maxrow = maxrow_per_contact;
   d.coldlds = (d.nM + 2 * m.npair) <= 256 ? 1 : 0;
   step_layout_build(&t->L, d);
@@ -340,7 +341,10 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int k = 0; k < 3; k++) { mr[L.mr_act_gainprm + 3*i + k] = m.actuator_gainprm[10*i + k]; mr[L.mr_act_biasprm + 3*i + k] = m.actuator_biasprm[10*i + k]; }
   }
   cpi(L.mi_sensor_type, m.sensor_type); cpi(L.mi_sensor_objid, m.sensor_objid);
-  cpi(L.mi_sensor_adr, m.sensor_adr); cpi(L.mi_sensor_stage, m.sensor_needstage); cpi(L.mi_sensor_objtype, m.sensor_objtype);
+  cpi(L.mi_sensor_adr, m.sensor_adr); cpi(L.mi_sensor_stage, m.sensor_needstage);
+  // object type in the low byte; a reference frame (frame{pos,quat,?axis}) as reftype << 8 | (refid + 1) << 16
+  for (int i = 0; i < m.nsensor; i++)
+    mi[L.mi_sensor_objtype + i] = m.sensor_objtype[i] | (m.sensor_refid[i] >= 0 ? (m.sensor_reftype[i] << 8) | ((m.sensor_refid[i] + 1) << 16) : 0);
   cpr(L.mr_qpos0, m.qpos0); cpr(L.mr_qpos_spring, m.qpos_spring);
   cpr(L.mr_body_pos, m.body_pos); cpr(L.mr_body_quat, m.body_quat); cpr(L.mr_body_ipos, m.body_ipos);
   cpr(L.mr_body_iquat, m.body_iquat); cpr(L.mr_body_mass, m.body_mass); cpr(L.mr_body_inertia, m.body_inertia);
@@ -405,6 +409,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
                     st == DMC_SENS_FRAMEQUAT || st == DMC_SENS_FRAMELINVEL || st == DMC_SENS_FRAMEANGVEL ||
                     st == DMC_SENS_RANGEFINDER;
     if (!ok) { *err = "sensor type not implemented"; return false; }
+    if (m.sensor_refid[i] >= 0 && (m.sensor_refid[i] > 32766 || !(st == DMC_SENS_FRAMEPOS || st == DMC_SENS_FRAMEQUAT || (st >= DMC_SENS_FRAMEXAXIS && st <= DMC_SENS_FRAMEZAXIS) || st == DMC_SENS_FRAMELINVEL || st == DMC_SENS_FRAMEANGVEL))) { *err = "sensor reference frames are implemented for the frame* sensors"; return false; }
     if (st == DMC_SENS_TOUCH) { const int tt = m.site_type[m.sensor_objid[i]]; if (tt != DMC_GEOM_SPHERE && tt != DMC_GEOM_CAPSULE && tt != DMC_GEOM_BOX && tt != DMC_GEOM_ELLIPSOID) { *err = "touch sensor sites must be sphere, capsule, ellipsoid or box"; return false; } }
   }
   StepOpts<double>& o = t->opts;

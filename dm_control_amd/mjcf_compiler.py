@@ -1242,6 +1242,8 @@ class _Compiler:
     m.sensor_adr = np.zeros(ns, dtype=np.int64)
     m.sensor_dim = np.zeros(ns, dtype=np.int64)
     m.sensor_needstage = np.zeros(ns, dtype=np.int64)
+    m.sensor_reftype = np.zeros(ns, dtype=np.int64)
+    m.sensor_refid = np.full(ns, -1, dtype=np.int64)
     m.sensor_cutoff = np.zeros(ns)
     adr = 0
     names = []
@@ -1249,14 +1251,21 @@ class _Compiler:
             C['DMC_OBJ_GEOM']: 'geom', C['DMC_OBJ_JOINT']: 'joint', C['DMC_OBJ_ACTUATOR']: 'actuator'}
     for i, (tag, a) in enumerate(self.sensors):
       stype, attr, objtype, dim, stage = _SENSORS[tag]
+      reftype = refname = None
       if objtype is None:
-        if 'reftype' in a or 'refname' in a:
-          raise MjcfError('sensor %r: reference frames (reftype/refname) are not supported' % a.get('name'))
+        frames = {'body': C['DMC_OBJ_BODY'], 'xbody': C['DMC_OBJ_XBODY'], 'geom': C['DMC_OBJ_GEOM'], 'site': C['DMC_OBJ_SITE']}
         try:
-          objtype = {'body': C['DMC_OBJ_BODY'], 'xbody': C['DMC_OBJ_XBODY'], 'geom': C['DMC_OBJ_GEOM'],
-                     'site': C['DMC_OBJ_SITE']}[a.get('objtype')]
+          objtype = frames[a.get('objtype')]
         except KeyError:
           raise MjcfError('sensor %r: unsupported objtype %r' % (a.get('name'), a.get('objtype')))
+        if 'reftype' in a or 'refname' in a:
+          # the object's frame expressed in a reference frame (mj_sensorPos: R_ref' (p - p_ref), R_ref' axis,
+          # conj(q_ref) q; mj_sensorVel: R_ref' (v - v_ref + r x w_ref), R_ref' (w - w_ref))
+          try:
+            reftype = frames[a.get('reftype')]
+          except KeyError:
+            raise MjcfError('sensor %r: unsupported reftype %r' % (a.get('name'), a.get('reftype')))
+          refname = a.get('refname')
       names.append(a.get('name'))
       oname = a.get(attr)
       lst = m.names[kind[objtype]]
@@ -1268,6 +1277,12 @@ class _Compiler:
       m.sensor_adr[i] = adr
       m.sensor_dim[i] = dim
       m.sensor_needstage[i] = stage
+      if reftype is not None:
+        rl = m.names[kind[reftype]]
+        if refname not in rl:
+          raise MjcfError('sensor %r refers to unknown reference %r' % (a.get('name'), refname))
+        m.sensor_reftype[i] = reftype
+        m.sensor_refid[i] = rl.index(refname)
       m.sensor_cutoff[i] = float(a.get('cutoff', 0))
       adr += dim
     m.nsensordata = adr

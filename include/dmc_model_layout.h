@@ -50,6 +50,7 @@
   X(actuator_ctrllimited, nu) X(actuator_forcelimited, nu) \
   X(sensor_type, nsensor) X(sensor_objtype, nsensor) X(sensor_objid, nsensor) \
   X(sensor_adr, nsensor) X(sensor_dim, nsensor) X(sensor_needstage, nsensor) \
+  X(sensor_reftype, nsensor) X(sensor_refid, nsensor)   /* reference frame of frame{pos,quat,?axis} sensors (mjtObj, id); refid = -1: world */ \
   X(pair_geom1, npair) X(pair_geom2, npair) \
   X(tendon_adr, ntendon) X(tendon_num, ntendon) /* fixed tendons: wraps [adr, adr + num) */ \
   X(wrap_objid, nwrap)                           /* joint id (fixed) or site id (spatial) of each wrap */ \

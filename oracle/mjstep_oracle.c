@@ -1603,6 +1603,13 @@ void ora_object_velocity(const Model* m, const Data* d, int objtype, int id, int
   else object_velocity(m, d, id, d->xpos + 3*id, d->xmat + 9*id, local, res);
 }
 static double ray_geom(const double* pos, const double* mat, const double* size, const double* pnt, const double* vec, int type);
+/* pose of a sensor's reference frame (mj_sensorPos: get_xpos_xmat / get_xquat of the reference object) */
+static void sensor_ref_pose(const Model* m, const Data* d, int rt, int rid, const double** p, const double** R, double* q) {
+  if (rt == DMC_OBJ_SITE) { *p = d->site_xpos + 3*rid; *R = d->site_xmat + 9*rid; mul_quat(q, d->xquat + 4*m->site_bodyid[rid], m->site_quat + 4*rid); }
+  else if (rt == DMC_OBJ_GEOM) { *p = d->geom_xpos + 3*rid; *R = d->geom_xmat + 9*rid; mul_quat(q, d->xquat + 4*m->geom_bodyid[rid], m->geom_quat + 4*rid); }
+  else if (rt == DMC_OBJ_BODY) { *p = d->xipos + 3*rid; *R = d->ximat + 9*rid; mul_quat(q, d->xquat + 4*rid, m->body_iquat + 4*rid); }
+  else { *p = d->xpos + 3*rid; *R = d->xmat + 9*rid; memcpy(q, d->xquat + 4*rid, 4 * sizeof(double)); }
+}
 static void sensor_stage(const Model* m, Data* d, int stage) {
   if (m->opt_disableflags & DMC_DSBL_SENSOR) return;
   int need_subtree = 0;
@@ -1624,12 +1631,25 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
                         : m->sensor_objtype[i] == DMC_OBJ_GEOM ? d->geom_xmat + 9*id
                         : m->sensor_objtype[i] == DMC_OBJ_BODY ? d->ximat + 9*id : d->xmat + 9*id;
         int c = m->sensor_type[i] - DMC_SENS_FRAMEXAXIS;
-        out[0] = R[c]; out[1] = R[3 + c]; out[2] = R[6 + c]; break; }
-      case DMC_SENS_FRAMEPOS: { /* world-frame position of the object's frame origin (no reference frame) */
+        out[0] = R[c]; out[1] = R[3 + c]; out[2] = R[6 + c];
+        if (m->sensor_refid[i] >= 0) {      /* the axis in the reference frame: R_ref' axis */
+          const double *pr, *Rr; double qr[4], ax[3] = {out[0], out[1], out[2]};
+          sensor_ref_pose(m, d, m->sensor_reftype[i], m->sensor_refid[i], &pr, &Rr, qr);
+          for (int k = 0; k < 3; k++) out[k] = Rr[k]*ax[0] + Rr[3 + k]*ax[1] + Rr[6 + k]*ax[2];
+        }
+        break; }
+      case DMC_SENS_FRAMEPOS: { /* position of the object's frame origin: world frame, or R_ref' (p - p_ref) */
         const double* p = m->sensor_objtype[i] == DMC_OBJ_SITE ? d->site_xpos + 3*id
                         : m->sensor_objtype[i] == DMC_OBJ_GEOM ? d->geom_xpos + 3*id
                         : m->sensor_objtype[i] == DMC_OBJ_BODY ? d->xipos + 3*id : d->xpos + 3*id;
-        memcpy(out, p, 3 * sizeof(double)); break; }
+        memcpy(out, p, 3 * sizeof(double));
+        if (m->sensor_refid[i] >= 0) {
+          const double *pr, *Rr; double qr[4], df[3];
+          sensor_ref_pose(m, d, m->sensor_reftype[i], m->sensor_refid[i], &pr, &Rr, qr);
+          for (int k = 0; k < 3; k++) df[k] = p[k] - pr[k];
+          for (int k = 0; k < 3; k++) out[k] = Rr[k]*df[0] + Rr[3 + k]*df[1] + Rr[6 + k]*df[2];
+        }
+        break; }
       case DMC_SENS_SUBTREELINVEL: memcpy(out, d->subtree_linvel + 3*id, 3 * sizeof(double)); break;
       case DMC_SENS_RANGEFINDER: { /* mj_ray along the site's z axis: nearest visible geom not on the site's body, -1 if none */
         const double* R = d->site_xmat + 9*id;
@@ -1647,6 +1667,12 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
         else if (ot == DMC_OBJ_GEOM) mul_quat(out, d->xquat + 4*m->geom_bodyid[id], m->geom_quat + 4*id);
         else if (ot == DMC_OBJ_BODY) mul_quat(out, d->xquat + 4*id, m->body_iquat + 4*id);
         else memcpy(out, d->xquat + 4*id, 4 * sizeof(double));
+        if (m->sensor_refid[i] >= 0) {      /* conj(q_ref) q */
+          const double *pr, *Rr; double qr[4], qo[4] = {out[0], out[1], out[2], out[3]};
+          sensor_ref_pose(m, d, m->sensor_reftype[i], m->sensor_refid[i], &pr, &Rr, qr);
+          qr[1] = -qr[1]; qr[2] = -qr[2]; qr[3] = -qr[3];
+          mul_quat(out, qr, qo);
+        }
         break; }
       case DMC_SENS_FRAMELINVEL: case DMC_SENS_FRAMEANGVEL: { /* mj_objectVelocity, world orientation */
         const int ot = m->sensor_objtype[i];
@@ -1654,6 +1680,23 @@ static void sensor_stage(const Model* m, Data* d, int stage) {
         const double* p = ot == DMC_OBJ_SITE ? d->site_xpos + 3*id : ot == DMC_OBJ_GEOM ? d->geom_xpos + 3*id
                         : ot == DMC_OBJ_BODY ? d->xipos + 3*id : d->xpos + 3*id;
         object_velocity(m, d, body, p, NULL, 0, v6);
+        if (m->sensor_refid[i] >= 0) {
+          /* relative to a moving reference frame (mj_sensorVel): the time derivative of the pose the position-stage
+           * sensor reports, R_ref' (v - v_ref + r x w_ref) with r = p - p_ref, and R_ref' (w - w_ref) */
+          const int rt = m->sensor_reftype[i], rid = m->sensor_refid[i];
+          const int rbody = rt == DMC_OBJ_SITE ? m->site_bodyid[rid] : rt == DMC_OBJ_GEOM ? m->geom_bodyid[rid] : rid;
+          const double *pr, *Rr; double qr[4], vr[6], rel[6], r[3], cr[3];
+          sensor_ref_pose(m, d, rt, rid, &pr, &Rr, qr);
+          object_velocity(m, d, rbody, pr, NULL, 0, vr);
+          for (int k = 0; k < 6; k++) rel[k] = v6[k] - vr[k];
+          for (int k = 0; k < 3; k++) r[k] = p[k] - pr[k];
+          cross3(cr, r, vr);
+          for (int k = 0; k < 3; k++) rel[3 + k] += cr[k];
+          for (int k = 0; k < 3; k++) {
+            v6[k] = Rr[k]*rel[0] + Rr[3 + k]*rel[1] + Rr[6 + k]*rel[2];
+            v6[3 + k] = Rr[k]*rel[3] + Rr[3 + k]*rel[4] + Rr[6 + k]*rel[5];
+          }
+        }
         memcpy(out, m->sensor_type[i] == DMC_SENS_FRAMELINVEL ? v6 + 3 : v6, 3 * sizeof(double)); break; }
       case DMC_SENS_VELOCIMETER:
         object_velocity(m, d, m->site_bodyid[id], d->site_xpos + 3*id, d->site_xmat + 9*id, 1, v6);

@@ -19,16 +19,17 @@ def load():
   return out
 
 
-def qpos_of_frames(model, g, root_joint):
+def qpos_of_frames(model, g, root_joint, prefix=''):
   """(nframes, nq): root free joint <- position / quaternion, hinge joints by name <- joints
-  (reference_pose/utils.py:103-117 `set_walker` via walker.set_pose + bind(mocap_joints).qpos)."""
+  (reference_pose/utils.py:103-117 `set_walker` via walker.set_pose + bind(mocap_joints).qpos); `prefix`: PyMJCF's
+  name scope of the walker in a composed model ('walker/')."""
   n = g['position'].shape[0]
   q = np.tile(np.asarray(model.qpos0, dtype=np.float64), (n, 1))
   adr = int(model.jnt_qposadr[model.name2id(root_joint, 'joint')])
   q[:, adr:adr + 3] = g['position']
   q[:, adr + 3:adr + 7] = g['quaternion']
   for k, name in enumerate(g['joint_order']):
-    q[:, int(model.jnt_qposadr[model.name2id(name, 'joint')])] = g['joints'][:, k]
+    q[:, int(model.jnt_qposadr[model.name2id(prefix + name, 'joint')])] = g['joints'][:, k]
   return q
 
 

@@ -192,7 +192,10 @@ def test_per_env_world_geoms_two_pitch_sizes_in_one_launch(precision, tol):
   from dm_control_amd.batch import BatchedPhysics
   from oracle.oracle import OraclePhysics
   m = _model('soccer_2v2_boxhead')
-  names = ['wall0', 'wall1', 'wall2', 'wall3', 'home_goal/right_post', 'away_goal/top_post']
+  from dm_control_amd.composer.tasks import soccer
+  adr = soccer.addresses(m)
+  bq, bv = adr['ball_q'], adr['ball_v']
+  names = ['//unnamed_geom_%d' % k for k in (1, 2, 3, 4)] + ['home_goal/right_post', 'away_goal/top_post']      # the four wall planes are unnamed in pitch.py:410-420
   B = 6
   scales = np.array([0.3, 0.27, 0.33, 0.3, 0.27, 0.36])
   b = BatchedPhysics(m, B, precision=precision, nconmax=24)
@@ -201,7 +204,7 @@ def test_per_env_world_geoms_two_pitch_sizes_in_one_launch(precision, tol):
   refs = [OraclePhysics(m) for _ in range(B)]
   for n in names:
     g = m.name2id(n, 'geom')
-    wall = n.startswith('wall')
+    wall = n.startswith('//unnamed_geom')
     pos = np.array([np.array(m.geom_pos[g]) * (scales[e] if wall else 1.0) + (0 if wall else rs.uniform(-1, 1, 3) * [2, 2, 0]) for e in range(B)])
     size = np.tile(np.array(m.geom_size[g]) * (1.0 if wall else 1.5), (B, 1))
     b.set_env_geom(n, pos=pos, size=size)
@@ -210,8 +213,8 @@ def test_per_env_world_geoms_two_pitch_sizes_in_one_launch(precision, tol):
       o.model.field('geom_pos')[3*g:3*g + 3] = pos[e]
       o.model.field('geom_size')[3*g:3*g + 3] = size[e]
       o.model.field('geom_rbound')[g] = rows[e, 15]
-  q = np.tile(m.qpos0, (B, 1)); q[:, 24:26] = (6.0, 3.0)
-  v = np.zeros((B, m.nv)); v[:, 24:27] = (40.0, 25.0, 1.0)
+  q = np.tile(soccer.kickoff_qpos(m), (B, 1)); q[:, bq:bq + 2] = (6.0, 3.0)
+  v = np.zeros((B, m.nv)); v[:, bv:bv + 3] = (40.0, 25.0, 1.0)
   b.set('qpos', q); b.set('qvel', v)
   for e, o in enumerate(refs):
     o.qpos[:] = q[e]; o.qvel[:] = v[e]
@@ -228,14 +231,14 @@ def test_per_env_world_geoms_two_pitch_sizes_in_one_launch(precision, tol):
       o.ctrl[:] = c[e]
       o.step()
       for k in range(o.ncon):
-        if m.names['geom'][o.contact(k)['geom1']].startswith('wall'):
+        if m.names['geom'][o.contact(k)['geom1']].startswith('//unnamed_geom'):
           hit[e] = True
     if precision == 32 and t < 3:
       continue
     qo = np.stack([o.qpos for o in refs])
     np.testing.assert_allclose(b.get('qpos'), qo, rtol=0, atol=tol * max(1.0, np.abs(qo).max()), err_msg='step %d' % t)
   assert hit.all() and not b.get('warning').any()
-  ball = b.get('qpos')[:, 24:26]
+  ball = b.get('qpos')[:, bq:bq + 2]
   assert (np.abs(ball[:, 0]) < 40 * scales + 1).all() and len(set(np.round(ball[:, 0], 3))) > 2       # different pitches, different games
   b.close()
 

@@ -58,3 +58,84 @@ def test_go_to_target_egocentric_observables_match_mujoco_goldens(precision, tol
   np.testing.assert_allclose(obs['end_effectors_pos'].cpu().double().numpy(), g['end_effectors'], rtol=0, atol=tol)
   np.testing.assert_allclose(obs['appendages_pos'].cpu().double().numpy(), g['appendages'], rtol=0, atol=tol)
   env.close()
+
+
+def _read_golden(name):
+  import os
+  with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name)) as f:
+    return f.read()
+
+
+@pytest.mark.parametrize('precision,tol', [(64, 1e-12), (32, 1e-5)])
+def test_pymjcf_composed_walker_end_effector_sensors_match_mujoco_goldens(precision, tol):
+  """The XML the reference's own PyMJCF composition emits for config 4 (tests/golden/pymjcf_cmu2019_go_to_target.xml,
+  scripts/make_pymjcf_goldens.py) on the device: its four `*_end_effector` sensors -- framepos with reftype / refname,
+  walkers/legacy_base.py -- on the 20 golden poses against the values real MuJoCo gave for those sensors; the whole
+  sensordata vector against the oracle."""
+  from dm_control_amd.batch import BatchedPhysics
+  from oracle.oracle import OraclePhysics
+  m = mc.compile_xml(_read_golden('pymjcf_cmu2019_go_to_target.xml'))
+  g = mocap_golden.load()
+  q = mocap_golden.qpos_of_frames(m, g, 'walker/', prefix='walker/')
+  B = q.shape[0]
+  b = BatchedPhysics(m, B, precision=precision, nconmax=48)
+  b.set('qpos', q)
+  b.forward()
+  sd = b.get('sensordata')
+  adr = [int(m.sensor_adr[m.name2id('walker/%s_end_effector' % n, 'sensor')]) for n in g['end_effector_bodies']]
+  got = np.concatenate([sd[:, a:a + 3] for a in adr], axis=1)
+  np.testing.assert_allclose(got, g['end_effectors'], rtol=0, atol=tol)
+  o = OraclePhysics(m)
+  for k in range(B):
+    o.qpos[:] = q[k]
+    o.forward()
+    so = np.array(o.sensordata)
+    np.testing.assert_allclose(sd[k], so, rtol=0, atol=(1e-10 if precision == 64 else 2e-4) * max(1.0, np.abs(so).max()))
+  b.close()
+
+
+@pytest.mark.parametrize('precision,tol,stol', [(64, 1e-9, 1e-8), (32, 1e-4, 5e-3)])
+def test_pymjcf_composed_soccer_model_with_all_113_sensors(precision, tol, stol):
+  """suite/assets/soccer_2v2_boxhead.xml is the reference's composed config-5 model (soccer.load(team_size=2) through
+  PyMJCF, scripts/make_pymjcf_goldens.py): 25 bodies, 62 geoms, 136 sites, 113 sensors of which 76 are expressed in
+  a moving reference frame (soccer/observables.py).  State and every sensor against the oracle, fp64 open loop /
+  fp32 teacher-forced."""
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.composer.tasks import soccer
+  from oracle import oracle
+  m = mc.compile_xml(common.read_model('soccer_2v2_boxhead.xml'))
+  assert (m.nbody, m.ngeom, m.nsite, m.nsensor, m.nsensordata) == (25, 62, 136, 113, 340)
+  assert int((np.asarray(m.sensor_refid) >= 0).sum()) == 76
+  B, T = 16, 120
+  rs = np.random.RandomState(5)
+  adr = soccer.addresses(m)
+  q = np.tile(soccer.kickoff_qpos(m), (B, 1))
+  q[:, [a for xy in adr['players'] for a in xy]] += rs.uniform(-6, 6, (B, 8))
+  q[:, adr['ball_q']:adr['ball_q'] + 2] = rs.uniform(-4, 4, (B, 2))
+  v = np.zeros((B, m.nv)); v[:, adr['ball_v']:adr['ball_v'] + 6] = rs.uniform(-3, 3, (B, 6))
+  b = BatchedPhysics(m, B, precision=precision, nconmax=24)
+  b.set('qpos', q); b.set('qvel', v)
+  refs = []
+  for e in range(B):
+    p = oracle.OraclePhysics(m)
+    p.qpos[:] = q[e]; p.qvel[:] = v[e]
+    p.forward()
+    refs.append(p)
+  worst = worst_s = 0.0
+  for t in range(T):
+    a = rs.uniform(-1, 1, (B, m.nu)).astype(np.float32).astype(np.float64)
+    if precision == 32 and t:
+      b.set('qpos', np.stack([p.qpos for p in refs])); b.set('qvel', np.stack([p.qvel for p in refs]))
+      b.set('qacc_warmstart', np.stack([p.qacc_warmstart for p in refs]))
+    b.set_control(a)
+    b.step()
+    oracle.rollout_legacy(refs, a[None])
+    if precision == 32 and t < 3:
+      continue      # the drop onto the pitch: feet at dist = 0 exactly, see test_gpu_suite
+    qo, so = np.stack([p.qpos for p in refs]), np.stack([p.sensordata for p in refs])
+    worst = max(worst, (np.abs(b.get('qpos') - qo).max(axis=1) / np.maximum(1, np.abs(qo).max(axis=1))).max())
+    worst_s = max(worst_s, (np.abs(b.get('sensordata') - so).max(axis=1) / np.maximum(1, np.abs(so).max(axis=1))).max())
+  print('measured: composed soccer model fp%d: max rel qpos err %.3g, max rel sensordata err %.3g' % (precision, worst, worst_s))
+  assert worst < tol and worst_s < stol, (worst, worst_s)
+  assert max(p.ncon for p in refs) > 0 and not b.get('warning').any()
+  b.close()

@@ -584,9 +584,12 @@ def test_fp32_kernel_teacher_forced_on_more_domains(name, nsub):
     q[:, 7:] += rs.uniform(-.15, .15, (NE, m.nq - 7))
   if name == 'soccer_2v2_boxhead':
     # BASELINE config 5 physics: players spread around their kick-off spots, ball somewhere in midfield
-    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-6, 6, (NE, 8))
-    q[:, 24:26] += rs.uniform(-8, 8, (NE, 2))
-    q[:, [2, 8, 14, 20]] = 0.01      # at qpos0 the wheels touch the pitch at exactly dist = 0: an fp32 coin flip
+    from dm_control_amd.composer.tasks import soccer
+    adr = soccer.addresses(m)
+    q = np.tile(soccer.kickoff_qpos(m), (NE, 1))
+    q[:, [a for xy in adr['players'] for a in xy]] += rs.uniform(-6, 6, (NE, 8))
+    q[:, adr['ball_q']:adr['ball_q'] + 2] += rs.uniform(-8, 8, (NE, 2))
+    q[:, [qy + 1 for _, qy in adr['players']]] = 0.01      # root_z: at 0 the wheels touch the pitch at exactly dist = 0, an fp32 coin flip
   if name in ('manipulator', 'humanoid_CMU', 'quadruped', 'stacker'):
     # stiff (solref 5 ms), gram-scale fingertips: interpenetrating starts are ill-conditioned beyond
     # fp32; use the task's own collision-free start states (manipulator.py:183-239, humanoid_CMU.py:137-145)
@@ -687,8 +690,11 @@ def test_baseline_62dof_and_soccer_models_fp64_open_loop(name, nsub, caps):
   rs = np.random.RandomState(11)
   q = np.tile(m.qpos0, (B, 1))
   if name.startswith('soccer'):
-    q[:, [0, 1, 6, 7, 12, 13, 18, 19]] += rs.uniform(-8, 8, (B, 8))
-    q[:, 24:26] += rs.uniform(-15, 15, (B, 2))
+    from dm_control_amd.composer.tasks import soccer
+    adr = soccer.addresses(m)
+    q = np.tile(soccer.kickoff_qpos(m), (B, 1))
+    q[:, [a for xy in adr['players'] for a in xy]] += rs.uniform(-8, 8, (B, 8))
+    q[:, adr['ball_q']:adr['ball_q'] + 2] += rs.uniform(-15, 15, (B, 2))
   else:
     q[:, 7:] += rs.uniform(-0.15, 0.15, (B, m.nq - 7))
     q[:, 2] -= 0.25 if name == 'humanoid_CMU' else 0.0

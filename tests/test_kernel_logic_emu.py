@@ -398,10 +398,11 @@ def test_config5_soccer_boxhead_rollout_fp64():
     m = mc.compile_xml(f.read())
   assert (m.nq, m.nv, m.nu) == (31, 30, 12)
   o, e = OraclePhysics(m), EmuPhysics(m, 64, nconmax=24)
-  q = m.qpos0.copy()
-  # frames are at x = -+10, y = +-5: move the four players to (-+1, +-1.5), around the ball on the centre spot
-  q[0:2], q[6:8] = (9, -3.5), (9, 3.5)
-  q[12:14], q[18:20] = (-9, -3.5), (-9, 3.5)
+  from dm_control_amd.composer.tasks import soccer
+  q = soccer.kickoff_qpos(m)
+  # PyMJCF attaches every player at the origin: move the four to (-+1, +-1.5), around the ball on the centre spot
+  for (qx, qy), xy in zip(soccer.addresses(m)['players'], ((-1, 1.5), (-1, -1.5), (1, 1.5), (1, -1.5))):
+    q[qx], q[qy] = xy
   o.qpos[:] = q
   e.qpos[:] = q
   o.forward()
@@ -572,7 +573,11 @@ def test_per_env_world_geoms_match_single_model_oracles(prec, tol):
   resized per environment through the per-env geom table must give exactly what an oracle whose MODEL was edited
   that way gives -- the batch shares one compiled model, the reference would have recompiled."""
   m = mc.compile_xml(open(os.path.join(ASSETS, 'soccer_2v2_boxhead.xml')).read())
-  names = ['wall0', 'wall1', 'wall2', 'wall3', 'home_goal/right_post', 'away_goal/top_post']
+  from dm_control_amd.composer.tasks import soccer
+  adr = soccer.addresses(m)
+  bq, bv = adr['ball_q'], adr['ball_v']
+  names = ['//unnamed_geom_1', '//unnamed_geom_2', '//unnamed_geom_3', '//unnamed_geom_4', 'home_goal/right_post', 'away_goal/top_post']
+  wall = lambda n: n.startswith('//unnamed_geom')      # the four wall planes (soccer/pitch.py:410-420 adds them unnamed)
   ids = [m.name2id(n, 'geom') for n in names]
   rs = np.random.RandomState(0)
   for variant in range(2):
@@ -581,17 +586,17 @@ def test_per_env_world_geoms_match_single_model_oracles(prec, tol):
     om, e = o.model, EmuPhysics(m, prec, nconmax=24)
     rows = []
     for n, g in zip(names, ids):
-      pos = np.array(m.geom_pos[g]) * (scale if n.startswith('wall') else 1.0) + (0 if n.startswith('wall') else rs.uniform(-1, 1, 3) * [2, 2, 0])
-      size = np.array(m.geom_size[g]) * (1.0 if n.startswith('wall') else 1.5)
+      pos = np.array(m.geom_pos[g]) * (scale if wall(n) else 1.0) + (0 if wall(n) else rs.uniform(-1, 1, 3) * [2, 2, 0])
+      size = np.array(m.geom_size[g]) * (1.0 if wall(n) else 1.5)
       quat = np.array(m.geom_quat[g])
       om.field('geom_pos')[3*g:3*g + 3] = pos
       om.field('geom_size')[3*g:3*g + 3] = size
       om.field('geom_rbound')[g] = _env_geom_rows(m, g, pos, quat, size)[15]
       rows.append(_env_geom_rows(m, g, pos, quat, size))
     e.set_env_geoms(ids, np.stack(rows))
-    q = m.qpos0.copy()
-    q[24:26] = (6.0, 3.0)
-    v = np.zeros(m.nv); v[24:27] = (40.0, 25.0, 1.0)        # a hard shot: the ball bounces off the (moved) walls
+    q = soccer.kickoff_qpos(m)
+    q[bq:bq + 2] = (6.0, 3.0)
+    v = np.zeros(m.nv); v[bv:bv + 3] = (40.0, 25.0, 1.0)        # a hard shot: the ball bounces off the (moved) walls
     for p in (o, e):
       p.qpos[:] = q; p.qvel[:] = v
     o.forward()
@@ -607,9 +612,9 @@ def test_per_env_world_geoms_match_single_model_oracles(prec, tol):
       np.testing.assert_allclose(e.qpos, o.qpos, rtol=0, atol=tol * max(1.0, np.abs(o.qpos).max()), err_msg='variant %d step %d' % (variant, t))
       for k in range(o.ncon):
         ci = o.contact(k)
-        if m.names['geom'][ci['geom1']].startswith('wall'):
+        if wall(m.names['geom'][ci['geom1']]):
           hit_wall = True
-    assert hit_wall and np.abs(o.qpos[24:26]).max() < 40 * scale + 1.0       # the ball stayed inside the smaller pitch
+    assert hit_wall and np.abs(o.qpos[bq:bq + 2]).max() < 40 * scale + 1.0       # the ball stayed inside the smaller pitch
     assert not o.warning.any() and not e.warning.any()
 
 
