@@ -382,7 +382,15 @@ extern "C" int dmc_batch_set_env_geoms(dmc_batch* b, int n, const int* geom_ids)
   for (int k = 0; k < n; k++) {
     const int g = geom_ids[k];
     if (g < 0 || g >= m.ngeom) return fail("geom id out of range");
-    if (m.geom_bodyid[g] != 0) return fail("only world-fixed geoms (children of the worldbody) can differ between environments");
+    // world-fixed: on the worldbody, or on a jointless child of it whose frame is the world frame (PyMJCF attaches a
+    // static entity -- a goal -- as such a body; the per-environment row holds the geom's WORLD pose either way)
+    const int gb = m.geom_bodyid[g];
+    bool fixed = gb == 0;
+    if (!fixed && m.body_weldid[gb] == 0 && m.body_parentid[gb] == 0) {
+      const double* bp = &m.body_pos[3*gb]; const double* bq = &m.body_quat[4*gb];
+      fixed = bp[0] == 0 && bp[1] == 0 && bp[2] == 0 && bq[0] == 1 && bq[1] == 0 && bq[2] == 0 && bq[3] == 0;
+    }
+    if (!fixed) return fail("only world-fixed geoms (on the worldbody or on a jointless body at the world frame) can differ between environments");
     if (slot[g] >= 0) return fail("geom listed twice");
     slot[g] = k;
   }
