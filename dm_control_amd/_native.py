@@ -14,7 +14,7 @@ EXPORTS = [
     'dmc_batch_set_int', 'dmc_batch_device_ptr', 'dmc_batch_bind',
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
     'dmc_batch_set_model_real',
-    'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_info', 'dmc_batch_time_steps',
+    'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_invalidate_async', 'dmc_batch_info', 'dmc_batch_time_steps',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
     'dmc_batch_set_env_geoms', 'dmc_env_geom_pack', 'dmc_batch_wave_trace',
@@ -67,6 +67,7 @@ def lib():
   L.dmc_batch_set_model_real.argtypes = [vp, cs, vp, ci]
   L.dmc_batch_sync.argtypes = [vp]
   L.dmc_batch_invalidate.argtypes = [vp]
+  L.dmc_batch_invalidate_async.argtypes = [vp, vp]
   L.dmc_batch_step1.argtypes = [vp, vp]
   L.dmc_batch_create_caps.argtypes = [vp, ci, ci, ci, vp, ci, ctypes.POINTER(vp)]
   L.dmc_batch_set_env_geoms.argtypes = [vp, ci, vp]

@@ -192,9 +192,13 @@ class BatchedPhysics:
   def sync(self):
     _native.check(_native.lib().dmc_batch_sync(self._ptr))
 
-  def invalidate(self):
-    """Call after writing qpos / qvel / act through memory bound with `bind` (see dmc_batch_invalidate)."""
-    _native.check(_native.lib().dmc_batch_invalidate(self._ptr))
+  def invalidate(self, stream=None):
+    """Call after writing qpos / qvel / act through memory bound with `bind` (see dmc_batch_invalidate).  With a HIP
+    stream handle the invalidation is ordered on that stream (capturable into a HIP graph) instead of synchronous."""
+    if stream is None:
+      _native.check(_native.lib().dmc_batch_invalidate(self._ptr))
+    else:
+      _native.check(_native.lib().dmc_batch_invalidate_async(self._ptr, ctypes.c_void_p(stream)))
 
   def time_steps(self, nstep, reps, stream=None):
     ms = ctypes.c_float()

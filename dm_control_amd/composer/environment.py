@@ -274,8 +274,9 @@ class Environment:
     task = self.task
     reward = task.get_reward(p)
     discount = task.get_discount(p)
-    # mjWARN_BADQPOS / BADQVEL / BADQACC since the last look = PhysicsError in the reference (engine.py:345-368):
-    # reward 0, discount 0, episode over (environment.py:449-452)
+    # ANY new mjWARN_* since the last look = PhysicsError in the reference (engine.py:345-368 compares the warning
+    # counters before / after; BADQPOS / BADQVEL / BADQACC but also CONTACTFULL / CNSTRFULL / INERTIA): reward 0,
+    # discount 0, episode over (environment.py:449-452)
     diverged = self._divergence(p)
     terminating = task.should_terminate_episode(p) | (p.field('time')[0] >= self._time_limit - 1e-9) | diverged
     zero = torch.zeros_like(discount)
@@ -325,8 +326,8 @@ class Environment:
 
   def _divergence(self, physics):
     w = physics.field('warning')
-    bad = (w[4] + w[5] + w[6]) > 0            # BADQPOS, BADQVEL, BADQACC (include/dmc_model_layout.h order)
-    w[4:7].zero_()
+    bad = w[:8].sum(dim=0) > 0                # the eight mjtWarning counters (include/dmc_model_layout.h order); row 8 is this backend's own
+    w[:8].zero_()
     return bad
 
   def close(self):

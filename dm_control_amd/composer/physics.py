@@ -225,7 +225,7 @@ class DevicePhysics:
   def mark_as_dirty(self):
     """State was edited through a tensor: derived arrays are stale until the next forward / step."""
     self._dirty = True
-    self.batch.invalidate()
+    self.batch.invalidate(stream=self.stream())      # on the current stream: part of a captured control step
 
   def forward(self, disable_actuation=False):
     self.batch.forward(disable_actuation=disable_actuation, stream=self.stream())

@@ -64,7 +64,7 @@ struct dmc_batch {
   size_t elem;  // sizeof(T)
   // per-env stash of the position / velocity stage between legacy steps (StepIO::stash_*); epoch: bumped by every
   // host-side edit that can change what the stage depends on, which invalidates all stashes at once
-  void* d_stash_r; int* d_stash_i; int stash_epoch; int stash_on;
+  void* d_stash_r; int* d_stash_i; int* d_epoch; int stash_on; int stash_auto;
   int xfrc_on;         // xfrc_applied was written / bound / exposed: the kernel reads it from now on
   void* d_ns_A;        // noslip: (B, nslip, nslip) reals in global memory (StepOpts::ns_A)
   int* d_work;         // work queue of launches with a resident-only grid: {next item, finished waves} (StepIO::work)
@@ -124,7 +124,7 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   // a batch too small to fill the chip (soccer: 256 environments per GPU): spread it over as many CUs as possible --
   // the smallest workgroup that still holds the batch in one round (one wave alone on a CU shares nothing)
   if (best_w) {
-    const long cus = 256, need = ((long)b->B + cus * epw - 1) / (cus * epw);      // waves per CU to hold B at once
+    const long cus = b->ncu > 0 ? b->ncu : 256, need = ((long)b->B + cus * epw - 1) / (cus * epw);      // waves per CU to hold B at once
     if (need < best_w && !force_w) { best_w = (int)std::max(1L, need); best_blocks = std::min(8L / best_w, (long)(lds_cu / (tables + (size_t)best_w * epw * env_bytes))); }
   }
   if (!best_w) return fail("environment scratch does not fit in 160 KiB of LDS; lower nconmax/njmax");
@@ -181,7 +181,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->stash_epoch = 1; b->stash_on = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -201,6 +201,10 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
     if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc noslip matrix: ") + hipGetErrorString(e), -2); }
     b->tb.opts.ns_A = b->d_ns_A;
   }
+  { const int one = 1;
+    e = hipMalloc((void**)&b->d_epoch, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(b->d_epoch, &one, sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc stash epoch: ") + hipGetErrorString(e), -2); } }
   e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
   if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
@@ -271,6 +275,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_stash_r) (void)hipFree(b->d_stash_r);
   if (b->d_stash_i) (void)hipFree(b->d_stash_i);
+  if (b->d_epoch) (void)hipFree(b->d_epoch);
   if (b->d_eg_slot) (void)hipFree(b->d_eg_slot);
   if (b->d_ns_A) (void)hipFree(b->d_ns_A);
   if (b->d_gscr) (void)hipFree(b->d_gscr);
@@ -304,7 +309,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->trace = b->d_trace;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
-  io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->stash_epoch = b->stash_epoch;
+  io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->epoch = b->d_epoch;
 }
 
 // order[k] = the item handed out k-th: items by DESCENDING cost of the previous launch (1024 linear buckets of the
@@ -374,6 +379,17 @@ static double geom_rbound_of(int type, const double* size) {
     default: return 0;
   }
 }
+// The stash epoch (StepIO::epoch) is a device int: every edit that can change what the stashed stages depend on bumps
+// it with a one-thread kernel.  Host-synchronous entry points bump on the null stream and wait; dmc_batch_invalidate_async
+// bumps on the caller's stream, which makes the invalidation capturable into a HIP graph together with the edit.
+__global__ void epoch_bump_kernel(int* epoch) { *epoch = (*epoch == 0x7ffffff0) ? 1 : *epoch + 1; }
+static int bump_epoch(dmc_batch* b, hipStream_t stream, bool wait) {
+  HIP_TRY(hipSetDevice(b->device));
+  hipLaunchKernelGGL(epoch_bump_kernel, dim3(1), dim3(1), 0, stream, b->d_epoch);
+  HIP_TRY(hipGetLastError());
+  if (wait) HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
 extern "C" int dmc_batch_set_env_geoms(dmc_batch* b, int n, const int* geom_ids) {
   if (!b || n < 1 || !geom_ids) return fail("null argument");
   if (find_field(b, "env_geom")) return fail("per-environment geoms were already declared for this batch");
@@ -420,7 +436,7 @@ extern "C" int dmc_batch_set_env_geoms(dmc_batch* b, int n, const int* geom_ids)
     for (int e = 0; e < b->B; e++) for (int j = 0; j < 16; j++) host[(size_t)e * f.rows + 16*k + j] = row[j];
   }
   b->tb.opts.eg_slot = b->d_eg_slot; b->tb.opts.eg_n = n; b->tb.opts.eg_B = b->B;
-  b->stash_epoch++;
+  if (bump_epoch(b, 0, true)) return -2;
   return set_real(b, find_field(b, "env_geom"), host.data());
 }
 // rows of one geom slot from (pos, quat, size): what a caller writes into "env_geom" (host helper, no device work)
@@ -442,9 +458,8 @@ extern "C" int dmc_env_geom_pack(int geom_type, const double* pos, const double*
 // stash in HBM (allocated on first use)
 static int ensure_stash(dmc_batch* b) {
   if (b->stash_on) return 0;
-  const int epoch = b->stash_epoch;
   if (dmc_batch_set_opt_int(b, "stash", 1)) return -2;
-  b->stash_epoch = epoch + 1;
+  b->stash_auto = 1;      // switched on by a step1 / step2 call, not by the caller's option: the step2 that consumes it switches it off again
   return 0;
 }
 extern "C" int dmc_batch_step1(dmc_batch* b, void* hip_stream) {
@@ -456,7 +471,10 @@ extern "C" int dmc_batch_step2(dmc_batch* b, void* hip_stream) {
   if (!b) return fail("null batch");
   if (b->tb.opts.integrator == DMC_INT_RK4) return fail("mj_step2 integrates with Euler only; RK4 models step through dmc_batch_step");
   if (ensure_stash(b)) return -2;
-  return launch(b, 1, 0, 5, hip_stream);
+  const int rc = launch(b, 1, 0, 5, hip_stream);
+  // a stash this pair switched on is not left on for every later launch (2 x n_keep reals per env of traffic each)
+  if (b->stash_auto) { b->stash_on = 0; b->stash_auto = 0; }
+  return rc;
 }
 extern "C" int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream) {
   if (!b) return fail("null batch");
@@ -582,7 +600,7 @@ static int get_real(dmc_batch* b, Field* f, double* dst) {
 static int set_real(dmc_batch* b, Field* f, const double* src) {
   const size_t n = (size_t)f->rows * b->B;
   if (!n) return 0;
-  if (f->name != "ctrl" && f->name != "qfrc_applied" && f->name != "xfrc_applied") b->stash_epoch++;   // inputs of the acceleration stage only
+  if (f->name != "ctrl" && f->name != "qfrc_applied" && f->name != "xfrc_applied") { if (bump_epoch(b, 0, true)) return -2; }   // (the others are inputs of the acceleration stage only)
   if (f->name == "xfrc_applied") b->xfrc_on = 1;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
@@ -654,24 +672,27 @@ extern "C" int dmc_batch_bind(dmc_batch* b, const char* name, void* device_ptr) 
   if (!f) return fail(std::string("unknown field: ") + name);
   f->dev = device_ptr ? device_ptr : f->owned;
   if (f->name == "xfrc_applied") b->xfrc_on = 1;
-  if (f->name != "ctrl" && f->name != "qfrc_applied") b->stash_epoch++;
+  if (f->name != "ctrl" && f->name != "qfrc_applied") { if (bump_epoch(b, 0, true)) return -2; }
   return 0;
 }
 extern "C" int dmc_batch_invalidate(dmc_batch* b) {
   if (!b) return fail("null batch");
-  b->stash_epoch++;
-  return 0;
+  return bump_epoch(b, 0, true);
+}
+extern "C" int dmc_batch_invalidate_async(dmc_batch* b, void* hip_stream) {
+  if (!b) return fail("null batch");
+  return bump_epoch(b, (hipStream_t)hip_stream, false);
 }
 extern "C" int dmc_batch_set_output_mask(dmc_batch* b, int mask) {
   if (!b) return fail("null batch");
-  b->stash_epoch++;
+  if (bump_epoch(b, 0, true)) return -2;
   b->outmask = mask;
   return 0;
 }
 extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) {
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
-  b->stash_epoch++;
+  if (bump_epoch(b, 0, true)) return -2;
   if (!strcmp(name, "stash")) {
     if (value && !b->d_stash_r) {
       const StepLayout& L = b->tb.L;
@@ -701,7 +722,7 @@ extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) 
 extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value) {
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
-  b->stash_epoch++;
+  if (bump_epoch(b, 0, true)) return -2;
   if (!strcmp(name, "timestep")) o.timestep = value;
   else if (!strcmp(name, "tolerance")) o.tolerance = value;
   else if (!strcmp(name, "ls_tolerance")) o.ls_tolerance = value;
@@ -735,7 +756,7 @@ extern "C" int dmc_batch_set_model_real(dmc_batch* b, const char* name, const do
     if (strcmp(name, s.name)) continue;
     if (count != s.cnt) return fail(std::string("wrong element count for model field ") + name);
     for (int i = 0; i < count; i++) b->tb.mr[s.off + i] = values[i];
-    b->stash_epoch++;
+    if (bump_epoch(b, 0, true)) return -2;
     if (!strcmp(name, "dof_damping")) {
       b->tb.opts.any_damping = 0;
       for (int i = 0; i < count; i++) { if (values[i] < 0) return fail("negative dof_damping"); if (values[i] > 0) b->tb.opts.any_damping = 1; }

@@ -102,8 +102,10 @@ struct StepIO {
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
   // legacy Physics.step() and the mj_step2 that begins the next): env-major, (B, n_keep) reals and (B, n_si + 4)
-  // ints whose first word is the epoch the stash was written in (valid iff equal to stash_epoch)
-  T* stash_r; int* stash_i; int stash_epoch;
+  // ints whose first word is the epoch the stash was written in (valid iff equal to *epoch).  The epoch lives in
+  // device memory and is bumped by a kernel on the caller's stream (dmc_batch_invalidate_async), so an invalidation
+  // recorded into a HIP graph is replayed with it -- a by-value epoch would be frozen at capture time.
+  T* stash_r; int* stash_i; const int* epoch;
   // kinematic stash (on by default): what mj_kinematics / mj_comPos / mj_comVel derive from (qpos, qvel), kept per env
   // between legacy steps; (nq + nv + n_kin, ...) reals env-major and one epoch int per env (StepCore::load_kstash)
   T* kstash; int* kstash_i;
@@ -596,7 +598,7 @@ struct StepCore {
   DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
     env = late(env);
     const int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
-    if (hi[0] != io.stash_epoch) return false;      // group-uniform: never written, or written before the last host edit
+    if (hi[0] != *io.epoch) return false;      // group-uniform: never written, or written before the last host edit
     const T* hr = io.stash_r + (size_t)env*L.n_keep;
     FOR_LANES(i, L.n_keep) s[i] = hr[i];
     FOR_LANES(i, L.n_si) si[i] = hi[4 + i];
@@ -611,7 +613,7 @@ struct StepCore {
       FOR_LANES(i, L.n_keep) hr[i] = s[i];
       FOR_LANES(i, L.n_si) hi[4 + i] = si[i];
     }
-    if (lane == 0) hi[0] = valid ? io.stash_epoch : 0;
+    if (lane == 0) hi[0] = valid ? *io.epoch : 0;
   }
   // ---- kinematic stash ------------------------------------------------------------------------------------------
   // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
@@ -623,7 +625,7 @@ struct StepCore {
   DMC_DEV int kin_count() const { return L.s_qM - L.s_xpos; }
   DMC_DEV bool load_kstash(const StepIO<T>& io, int env) {
     env = late(env);
-    if (io.kstash_i[env] != io.stash_epoch) return false;
+    if (io.kstash_i[env] != *io.epoch) return false;
     const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
     const T* h = io.kstash + (size_t)env*(nq + nv + nk);
     int bad = 0;
@@ -632,6 +634,17 @@ struct StepCore {
     if (group_max<LPE>(bad)) return false;
     FOR_LANES(i, nk) S(xpos)[i] = h[nq + nv + i];
     DMC_WSYNC();
+    // per-environment geoms are inputs the stash does not compare: their world poses are taken from the rows again
+    if (o.eg_n) {
+      FOR_LANES(g, L.d.ngeom) {
+        const int k = o.eg_slot[g];
+        if (k < 0) continue;
+        const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
+        for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
+        for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
+      }
+      DMC_WSYNC();
+    }
     return true;
   }
   DMC_DEV void store_kstash(const StepIO<T>& io, int env) {
@@ -641,7 +654,7 @@ struct StepCore {
     FOR_LANES(i, nq) h[i] = S(qpos)[i];
     FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
-    if (lane == 0) io.kstash_i[env] = io.stash_epoch;
+    if (lane == 0) io.kstash_i[env] = *io.epoch;
   }
   DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash) {
     const int B = io.B;

@@ -300,9 +300,17 @@ class Physics(control.Physics):
     # Every other model array feeds tables that are derived once at batch creation (contact-pair mixing, inertias,
     # invweight0, ...): a write would be silently ignored by the device, so it is made to fail instead
     # (ValueError: assignment destination is read-only).  The writable ones are _MUTABLE_MODEL_FIELDS.
-    for name, value in vars(model).items():
-      if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS:
-        value.setflags(write=False)
+    # The freeze is applied to a PRIVATE shallow copy of the model whose immutable arrays are read-only views: the
+    # caller's compiled Model stays writable (it may be edited and used to build another Physics, as the reference allows).
+    import copy as _copy
+    if not (getattr(model, '_frozen_private', False) and not np.asarray(model.body_mass).flags.writeable):      # (copy(share_model=True) hands this Physics' own frozen copy on)
+      self.model = _copy.copy(model)
+      self.model._frozen_private = True
+      for name, value in vars(model).items():
+        if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS:
+          view = value.view()
+          view.setflags(write=False)
+          setattr(self.model, name, view)
     self.after_reset()
 
   def _push_model(self):
@@ -470,6 +478,8 @@ class Physics(control.Physics):
     """engine.py:287-304: an independent Physics in the same state; the model is copied unless share_model."""
     import copy as _copy
     model = self.model if share_model else _copy.deepcopy(self.model)
+    if not share_model:
+      model.__dict__.pop('_frozen_private', None)      # an independent model: frozen afresh by the new Physics
     other = type(self)(model, batch_size=self.batch_size, precision=self.batch.precision, **self._batch_kwargs)
     # per-episode state that suite Physics subclasses keep on the instance (reacher / finger / manipulator targets)
     for k, v in vars(self).items():

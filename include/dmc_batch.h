@@ -152,6 +152,10 @@ int dmc_batch_sync(dmc_batch* b);
  * (qpos, qvel) it was computed at and reused only when the next launch finds exactly that state, so it needs no
  * invalidation by the caller (DMC_NO_KSTASH=1 in the environment disables it). */
 int dmc_batch_invalidate(dmc_batch* b);
+/* The same, ordered on `hip_stream` instead of waiting for the device: the stash epoch lives in device memory and is
+ * bumped by a one-thread kernel, so an invalidation issued while a HIP graph is being captured (a composer hook that
+ * edits qpos through a bound tensor inside a captured control step) is part of the graph and replays with it. */
+int dmc_batch_invalidate_async(dmc_batch* b, void* hip_stream);
 
 /* Observation gather table: what composer's observation.Updater does per control step for MJCFFeature observables
  * (composer/observation/updater.py:285-295, composer/observation/observable/mjcf.py:43), for the whole batch in one

@@ -93,7 +93,7 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   e->gs.resize(L.n_gs + 2); o.gscr = e->gs.data();   // doubles: room for either precision
   if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }
   if (!e->eg_slot.empty()) { o.eg_slot = e->eg_slot.data(); o.eg_n = (int)e->eg64.size() / 16; o.eg_B = 1; o.eg_data = sizeof(T) == 8 ? (const void*)e->eg64.data() : (const void*)e->eg32.data(); }
-  io.stash_r = nullptr; io.stash_i = nullptr; io.stash_epoch = e->stash_epoch;
+  io.stash_r = nullptr; io.stash_i = nullptr; io.epoch = &e->stash_epoch;
   io.kstash = e->kstash_on ? (T*)e->kstash.data() : nullptr; io.kstash_i = e->kstash_on ? e->kstash_i.data() : nullptr;
   if (e->stash_on) { io.stash_r = sizeof(T) == 8 ? (T*)e->stash_r64.data() : (T*)e->stash_r32.data(); io.stash_i = e->stash_i.data(); }
   DynLayoutSrc ls; ls.p = &L;

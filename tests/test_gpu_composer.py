@@ -321,3 +321,49 @@ def test_environment_step_as_hip_graph(name, shape):
     assert n_last > 0                      # falls happened and the graph re-initialised those environments itself
   for e in envs:
     e.close()
+
+
+def test_invalidation_inside_a_captured_graph_reaches_the_kernel():
+  """The stash epoch lives in device memory (StepIO::epoch) and `mark_as_dirty` bumps it on the current stream
+  (dmc_batch_invalidate_async): a captured sequence [edit qvel through the bound tensor, mark_as_dirty, step] replays
+  with its invalidation.  With the FULL position / velocity-stage stash on (option 'stash'), a by-value epoch frozen
+  at capture time made every replay continue from the stage stashed before the edit."""
+  import torch
+  from dm_control_amd.composer.physics import DevicePhysics
+  m = _model('cheetah')
+  B = 64
+  rs = np.random.RandomState(1)
+  q0 = np.tile(m.qpos0, (B, 1)); q0[:, 3:] += rs.uniform(-.3, .3, (B, m.nq - 3))
+  acts = torch.as_tensor(rs.uniform(-1, 1, (12, m.nu, B)), device='cuda', dtype=torch.float32)
+  kick = torch.as_tensor(rs.uniform(-2, 2, (m.nv, B)), device='cuda', dtype=torch.float32)
+  out = []
+  for mode in ('eager', 'graph'):
+    phys = DevicePhysics(m, B, precision=32)
+    phys.batch.set_opt('stash', 1)
+    phys.field('qpos').copy_(torch.as_tensor(q0.T, device='cuda', dtype=torch.float32))
+    phys.mark_as_dirty()
+    phys.forward()
+    ctrl = phys.field('ctrl')
+
+    def body():
+      phys.field('qvel').add_(kick)      # the throw-in of the advisor's scenario: state edited through a tensor
+      phys.mark_as_dirty()
+      phys.step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for t in range(2):
+        ctrl.copy_(acts[t]); body()
+    torch.cuda.current_stream().wait_stream(side)
+    if mode == 'graph':
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        body()
+    for t in range(2, 12):
+      ctrl.copy_(acts[t])
+      g.replay() if mode == 'graph' else body()
+    torch.cuda.synchronize()
+    out.append(phys.field('qpos').clone())
+    assert phys.batch.info()['stash'] == 1
+    phys.close()
+  assert torch.equal(out[0], out[1])
