@@ -221,15 +221,16 @@ class BatchedPhysics:
 
   # -- debug ----------------------------------------------------------------------------
   def wave_trace(self, enable=None):
-    """enable=True/False switches the trace; no argument: (3, nitems) int array of the last launch (start, end of
-    every wave item on the 100 MHz constant clock, workgroup index)."""
+    """enable=True/False switches the trace; no argument: (8, 4, nitems) int array, a ring of the last 8 launches
+    (slot = launch % 8 since enabling): kernel entry, start and end of every wave item on the 100 MHz constant clock,
+    workgroup index."""
     L = _native.lib()
     n = ctypes.c_int(0)
     if enable is not None:
       _native.check(L.dmc_batch_wave_trace(self._ptr, int(bool(enable)), None, ctypes.byref(n)))
       return None
     info = self.info()
-    out = np.zeros((3, (info['B'] * info['lanes_per_env'] + 63) // 64), dtype=np.int32)
+    out = np.zeros((8, 4, (info['B'] * info['lanes_per_env'] + 63) // 64), dtype=np.int32)
     _native.check(L.dmc_batch_wave_trace(self._ptr, 1, out.ctypes.data, ctypes.byref(n)))
     return out
 

@@ -72,7 +72,8 @@ struct dmc_batch {
   void* d_kstash; int* d_kstash_i;      // kinematic stash (StepIO::kstash), on unless DMC_NO_KSTASH
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
-  int* d_trace;        // wave trace (dmc_batch_wave_trace): (3, nitems) ints, or null
+  int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (4, nitems) ints, or null
+  int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
 
@@ -181,7 +182,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr; b->trace_launch = 0;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -306,7 +307,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->env_mode = (const int*)P("env_mode");
   io->work = b->geom.queue ? b->d_work : nullptr;
   io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
-  io->trace = b->d_trace;
+  io->trace = b->d_trace; io->trace_slot = b->d_trace ? b->trace_launch++ : 0;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->epoch = b->d_epoch;
@@ -885,14 +886,15 @@ extern "C" int dmc_batch_wave_trace(dmc_batch* b, int enable, int32_t* dst, int*
   if (dst) {
     if (!b->d_trace) return fail("wave trace not enabled");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(dst, b->d_trace, (size_t)3 * n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, b->d_trace, (size_t)32 * n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
   }
   HIP_TRY(hipDeviceSynchronize());
   if (b->d_trace) { (void)hipFree(b->d_trace); b->d_trace = nullptr; }
+  b->trace_launch = 0;
   if (enable) {
-    HIP_TRY(hipMalloc((void**)&b->d_trace, (size_t)3 * n * sizeof(int)));
-    HIP_TRY(hipMemset(b->d_trace, 0, (size_t)3 * n * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&b->d_trace, (size_t)32 * n * sizeof(int)));
+    HIP_TRY(hipMemset(b->d_trace, 0, (size_t)32 * n * sizeof(int)));
   }
   return 0;
 }

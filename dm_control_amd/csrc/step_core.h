@@ -95,9 +95,10 @@ struct StepIO {
   // launch, written by the step kernel; order[k] = the item handed out k-th, built from it before every launch
   // (order_kernel, dmc_api.hip).  Null: items in index order.
   int* cost; const int* order;
-  // optional wave trace (dmc_batch_wave_trace): trace[item] / trace[nitems + item] = constant-rate clock (100 MHz) at which
-  // the item's wave started / finished it, trace[2 nitems + item] = XCD id << 16 | CU-local info; null: no trace
-  int* trace;
+  // optional wave trace (dmc_batch_wave_trace): a ring of the last 8 launches, (8, 4, nitems) ints; per launch the rows
+  // are the constant-rate clock (100 MHz) at which the item's wave entered the kernel (before the tables are staged),
+  // started and finished the item, and its workgroup index; null: no trace
+  int* trace; int trace_slot;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
@@ -532,6 +533,7 @@ DMC_FN DMC_LSVEC(T) ls_eval_lds(T a, const DMC_LDS T* jar_, const DMC_LDS T* jv_
 struct DynLayoutSrc {
   static constexpr int kNV = 0;   // nv only known at run time
   static constexpr int kJGlobal = -1;   // so is StepDims::jglobal
+  static constexpr int kNKin = 0;       // and the size of the kinematic stash
   const StepLayout* p;
   DMC_DEV const StepLayout& get() const { return *p; }
 };
@@ -634,17 +636,7 @@ struct StepCore {
     if (group_max<LPE>(bad)) return false;
     FOR_LANES(i, nk) S(xpos)[i] = h[nq + nv + i];
     DMC_WSYNC();
-    // per-environment geoms are inputs the stash does not compare: their world poses are taken from the rows again
-    if (o.eg_n) {
-      FOR_LANES(g, L.d.ngeom) {
-        const int k = o.eg_slot[g];
-        if (k < 0) continue;
-        const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
-        for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
-        for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
-      }
-      DMC_WSYNC();
-    }
+    kstash_env_geoms();
     return true;
   }
   DMC_DEV void store_kstash(const StepIO<T>& io, int env) {
@@ -656,17 +648,101 @@ struct StepCore {
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
     if (lane == 0) io.kstash_i[env] = *io.epoch;
   }
-  DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash) {
-    const int B = io.B;
-    FOR_LANES(i, L.d.nq) S(qpos)[i] = io.qpos[(size_t)i*B + env];
-    FOR_LANES(i, L.d.nv) {
-      S(qvel)[i] = io.qvel[(size_t)i*B + env];
-      S(qacc_warmstart)[i] = io.qacc_warmstart[(size_t)i*B + env];
-      S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;
+  // ---- launch-entry loads ------------------------------------------------------------------------------------------
+  // Everything a launch reads from HBM before it can start -- the env's launch override, its state, the tag of its
+  // kinematic stash, the (qpos, qvel) the stash belongs to and the stash itself -- is requested in ONE batch of
+  // independent loads (issued by the kernel before it stages the model tables, so that one HBM round trip covers
+  // tables, state and stash) and written to the env's LDS scratch, which nobody else touches; what is left for run()
+  // is a few flags.  Loading them where they are consumed cost four dependent round trips at the head of every launch
+  // (override -> state -> tag -> compare -> data).  The stash is copied SPECULATIVELY: when it turns out stale the
+  // kinematics pass overwrites it.  Lane i carries element i of every field: models with more than LPE coordinates,
+  // and launches that use the full stash (whose copy of the state would overwrite this one), keep the in-place loads.
+  static constexpr int kPFKin = LS::kNKin > 0 ? ((LS::kNKin + LPE - 1) / LPE < 24 ? (LS::kNKin + LPE - 1) / LPE : 24) : 0;
+  struct Entry { int em, fast, kvalid; };
+  struct EntryRegs {
+    T qpos, qvel, warm, qfrc, ctrl, act, kq, kv;
+    int ktag, epoch;
+    T kd[kPFKin ? kPFKin : 1];
+  };
+  DMC_DEV static bool kstash_applies(const StepOpts<T>& o, const StepIO<T>& io, int mode, int legacy) {
+    return io.kstash && mode == 0 && legacy && o.integrator != DMC_INT_RK4 && !io.stash_r;
+  }
+  DMC_DEV static void entry_issue(const StepLayout& L, const StepOpts<T>& o, const StepIO<T>& io, int env, int lane, int mode,
+                                  int legacy, Entry* e, EntryRegs* r) {
+    e->em = io.env_mode ? io.env_mode[env] : 0;
+    e->kvalid = 0;
+#if defined(DMC_HOST_EMU) || defined(DMC_NO_ENTRY_LOADS)
+    e->fast = 0;
+#else
+    e->fast = (L.d.nq <= LPE && L.d.nv <= LPE && L.d.nu <= LPE && L.d.na <= LPE && !io.stash_r) ? 1 : 0;
+#endif
+    r->ktag = 0; r->epoch = 1;
+    if (!e->fast) return;
+    const size_t B = (size_t)io.B;
+    const int nq = L.d.nq, nv = L.d.nv;
+    r->qpos = lane < nq ? io.qpos[lane*B + env] : (T)0;
+    r->qvel = lane < nv ? io.qvel[lane*B + env] : (T)0;
+    r->warm = lane < nv ? io.qacc_warmstart[lane*B + env] : (T)0;
+    r->qfrc = (io.qfrc_applied && lane < nv) ? io.qfrc_applied[lane*B + env] : (T)0;
+    r->ctrl = lane < L.d.nu ? io.ctrl[lane*B + env] : (T)0;
+    r->act = (L.d.na && lane < L.d.na) ? io.act[lane*B + env] : (T)0;
+    if (!kstash_applies(o, io, mode, legacy)) return;
+    r->ktag = io.kstash_i[env]; r->epoch = *io.epoch;
+    const int nk = L.s_qM - L.s_xpos;
+    const T* h = io.kstash + (size_t)env*(nq + nv + nk);
+    r->kq = lane < nq ? h[lane] : (T)0;
+    r->kv = lane < nv ? h[nq + lane] : (T)0;
+#pragma unroll
+    for (int k = 0; k < kPFKin; k++) { const int i = lane + k*LPE; r->kd[k] = i < nk ? h[nq + nv + i] : (T)0; }
+  }
+  // s: the LDS scratch of the env (of this lane's group)
+  DMC_DEV static void entry_commit(const StepLayout& L, const StepIO<T>& io, int env, int lane, Entry* e, const EntryRegs& r, T* s) {
+    if (!e->fast) return;
+    const int nq = L.d.nq, nv = L.d.nv;
+    if (lane < nq) s[L.s_qpos + lane] = r.qpos;
+    if (lane < nv) { s[L.s_qvel + lane] = r.qvel; s[L.s_qacc_warmstart + lane] = r.warm; s[L.s_qfrc_applied + lane] = r.qfrc; }
+    if (lane < L.d.nu) s[L.s_ctrl + lane] = r.ctrl;
+    if (L.d.na && lane < L.d.na) s[L.s_act + lane] = r.act;
+    if (r.ktag != r.epoch) return;
+    const int bad = ((lane < nq && !(r.kq == r.qpos)) || (lane < nv && !(r.kv == r.qvel))) ? 1 : 0;
+    if (group_max<LPE>(bad)) return;
+    const int nk = L.s_qM - L.s_xpos;
+#pragma unroll
+    for (int k = 0; k < kPFKin; k++) { const int i = lane + k*LPE; if (i < nk) s[L.s_xpos + i] = r.kd[k]; }
+    if (kPFKin*LPE < nk) {
+      const T* h = io.kstash + (size_t)env*(nq + nv + nk) + nq + nv;
+      for (int i = lane + kPFKin*LPE; i < nk; i += LPE) s[L.s_xpos + i] = h[i];
     }
-    FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
-    if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = io.act[(size_t)i*B + env]; S(act_dot)[i] = 0; }
-    time_ = io.time[env];
+    e->kvalid = 1;
+  }
+  // per-environment geoms are inputs the stash does not compare: their world poses are taken from the rows again
+  DMC_DEV void kstash_env_geoms() {
+    if (!o.eg_n) return;
+    FOR_LANES(g, L.d.ngeom) {
+      const int k = o.eg_slot[g];
+      if (k < 0) continue;
+      const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
+      for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
+      for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
+    }
+    DMC_WSYNC();
+  }
+  DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash, const Entry& en) {
+    const int B = io.B;
+    if (en.fast) {      // the state is in LDS already (entry_commit)
+      if (L.d.na && lane < L.d.na) S(act_dot)[lane] = 0;
+      time_ = io.time[env];      // (not needed before the state is stored: nothing waits for it here)
+    } else {
+      FOR_LANES(i, L.d.nq) S(qpos)[i] = io.qpos[(size_t)i*B + env];
+      FOR_LANES(i, L.d.nv) {
+        S(qvel)[i] = io.qvel[(size_t)i*B + env];
+        S(qacc_warmstart)[i] = io.qacc_warmstart[(size_t)i*B + env];
+        S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;
+      }
+      FOR_LANES(i, L.d.nu) S(ctrl)[i] = io.ctrl[(size_t)i*B + env];
+      if (L.d.na) FOR_LANES(i, L.d.na) { S(act)[i] = io.act[(size_t)i*B + env]; S(act_dot)[i] = 0; }
+      time_ = io.time[env];
+    }
     if (lane == 0) SI(imisc)[IM_ENV] = env;
     if (have_stash) {      // the derived arrays come from the stash; only this launch's warning counters start at zero
       if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
@@ -3968,11 +4044,11 @@ struct StepCore {
   // mode 4 / 5 = mj_step1 / mj_step2 as separate entry points (engine.py:156-162 calls them one after the other with
   // Python in between): mj_step1 leaves its stage in the stash, mj_step2 picks it up (and recomputes it when the
   // state was edited in between, where MuJoCo would integrate on stale derived arrays).
-  DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask) {
+  DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask, const Entry& en) {
     const bool stash = io.stash_r != nullptr;
     bool have = false;
     if (mode == 5 && stash) have = load_stash(io, env);
-    load_state(io, env, have);
+    load_state(io, env, have, en);
     if (mode == 4) {
       check_pos_vel();
       call_posvel(false, outmask, false);
@@ -3998,19 +4074,31 @@ struct StepCore {
     store_state(io, env);
   }
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub) {
+    Entry en; EntryRegs er;
+    entry_issue(L, o, io, env, lane, mode, legacy, &en, &er);
+    entry_commit(L, io, env, lane, &en, er, s);
+    run(io, env, nstep, legacy, mode, outmask, nsub, en);
+  }
+  // en: what entry_issue / entry_commit left for this env and the launch's (mode, legacy)
+  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en) {
+    const int launch_mode = mode;
     if (io.env_mode) {
-      const int em = io.env_mode[late(env)];
+      const int em = en.em;
       if (em == 2) return;
       if (em == 1 && (mode == 0 || mode >= 4)) mode = 2;
     }
-    if (mode >= 4) { run_split(io, env, mode, outmask); return; }
+    if (mode >= 4) { run_split(io, env, mode, outmask, en); return; }
     prof_begin();
     const bool stash = io.stash_r != nullptr;
     bool have = false;
     if (stash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) have = load_stash(io, env);
-    load_state(io, env, have);
+    load_state(io, env, have, en);
     bool havekin = false;
-    if (io.kstash && mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) havekin = load_kstash(io, env);
+    // (the stash was only prefetched for a launch that steps: an env switched to mj_forward by env_mode has none)
+    if (io.kstash && mode == 0 && launch_mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) {
+      if (!en.fast) havekin = load_kstash(io, env);
+      else if (en.kvalid) { havekin = true; DMC_WSYNC(); kstash_env_geoms(); }
+    }
     DMC_PROF(PROF_LOAD);
     const bool stepping = mode == 0 || mode == 3;
     const int ntotal = mode == 3 ? nstep*nsub : nstep;

@@ -52,6 +52,30 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   int* mi = reinterpret_cast<int*>(tables);
   T* mr = reinterpret_cast<T*>(tables + (size_t)L.n_mi * sizeof(int));
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int t_entry = io.trace ? (int)(wall_clock64() & 0x7fffffffll) : 0;
+  typedef StepCore<T, LPE, LS> Core;
+  constexpr int epw = 64 / LPE;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
+  // Give every XCD one contiguous range of environments, so that a 128-B line of
+  // an SoA row (32 fp32 envs = several workgroups) is fetched into one L2 only.
+  const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+  const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave-uniform: the loop state lives in SGPRs
+  const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
+  // The first item's state and kinematic stash are requested before the tables are staged and written to the env's
+  // LDS scratch before the barrier: one HBM round trip for tables, state and stash.
+  const size_t tables_bytes = (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T) + (L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0);
+  const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
+  typename Core::Entry en;
+  typename Core::EntryRegs er;
+  int slot = lblk * wpb + wave;
+  int env0 = 0;
+  if (slot < nitems) {
+    const int item = io.order ? io.order[slot] : slot;
+    env0 = item * epw + ((tid / LPE) & (epw - 1));
+    if (env0 >= io.B) env0 = io.B - 1;      // ragged last wave: loads the last environment, runs nothing
+    Core::entry_issue(L, o_arg, io, env0, tid % LPE, mode, legacy, &en, &er);
+  }
   // stage the model constant tables once per workgroup (shared by all its envs)
   if (tid == 0) *o_lds = o_arg;
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
@@ -60,22 +84,14 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T));
   const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
   if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
+  if (slot < nitems) Core::entry_commit(L, io, env0, tid % LPE, &en, er, reinterpret_cast<T*>(tables + tables_bytes + (size_t)(tid / LPE) * env_bytes));
   __syncthreads();
-  // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
-  // Give every XCD one contiguous range of environments, so that a 128-B line of
-  // an SoA row (32 fp32 envs = several workgroups) is fetched into one L2 only.
-  const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
-  const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
-  const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
   // An item is the 64 / LPE environments one wave steps together.  Every wave starts on the item of its position in
   // the grid.  When the grid is only the RESIDENT workgroups of a larger batch (io.work != null), a wave that finishes
   // takes the next unclaimed item from the queue: the waves of a workgroup do not wait for its slowest environment,
   // and a launch is not a whole number of rounds (a fallen 62-dof humanoid steps several times longer than a
   // standing one; with 4-wave workgroups handed out whole, one launch per env-step ran 1.5x longer than the rollout).
-  constexpr int epw = 64 / LPE;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave-uniform: the loop state lives in SGPRs
-  const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
-  for (int slot = lblk * wpb + wave; slot < nitems; ) {
+  if (slot < nitems) for (;;) {
     // The per-lane pointers are re-derived from the thread index on every trip (behind an opaque copy, so that the
     // compiler does not hoist them): otherwise they stay live across the out-of-line stage calls of run() and are
     // spilled to scratch memory there -- 11 VGPRs on the cheetah kernel, 6 x the algorithmic HBM writes of a launch.
@@ -91,11 +107,12 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const int item = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     const int env = item * epw + (g & (epw - 1));
-    if (io.trace && (threadIdx.x & 63) == 0) io.trace[item] = (int)(wall_clock64() & 0x7fffffffll);
-    if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub);
-    if (io.trace && (threadIdx.x & 63) == 0) {
-      io.trace[nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
-      io.trace[2*nitems + item] = (int)blockIdx.x;
+    int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 4 * nitems : nullptr;
+    if (tr && (threadIdx.x & 63) == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
+    if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en);
+    if (tr && (threadIdx.x & 63) == 0) {
+      tr[2*nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
+      tr[3*nitems + item] = (int)blockIdx.x;
     }
     if (io.cost && (threadIdx.x & 63) == 0) {
       const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
@@ -105,6 +122,12 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     int nx = 0;
     if ((threadIdx.x & 63) == 0) nx = atomicAdd(io.work, 1);
     slot = nwaves + __builtin_amdgcn_readfirstlane(nx);
+    if (slot >= nitems) break;
+    const int nitem = io.order ? io.order[slot] : slot;
+    int nenv = nitem * epw + ((threadIdx.x / LPE) & (epw - 1));
+    if (nenv >= io.B) nenv = io.B - 1;
+    // (later items load in place, inside run(): up here the registers are full of what the loop keeps alive)
+    en.em = io.env_mode ? io.env_mode[nenv] : 0; en.fast = 0; en.kvalid = 0;
   }
   if (io.work && (threadIdx.x & 63) == 0) {
     // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
@@ -130,6 +153,8 @@ template <int SID> struct StaticLayout;
   template <> struct StaticLayout<ID> {                                               \
     static constexpr int kNV = DMC_STATIC_NV_##ID;   /* compile-time nv: register-resident Cholesky */ \
     static constexpr int kJGlobal = DMC_JGLOBAL_LEVEL(DMC_STATIC_NV_##ID);   /* StepDims::jglobal */ \
+    static constexpr StepLayout kL = DMC_STATIC_LAYOUT_##ID;                                      \
+    static constexpr int kNKin = kL.s_qM - kL.s_xpos;   /* reals of the kinematic stash */       \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_STATIC_IDS(DMC_DEF_STATIC)

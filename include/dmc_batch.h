@@ -191,9 +191,11 @@ int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, voi
 int dmc_batch_debug_enable(dmc_batch* b, int n);
 int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int env, double* dst, int* count);
 
-/* Wave trace of the last launch (tuning: the tail of a launch whose environments all run at once is its slowest
- * wave).  dst == NULL: enable / disable.  dst != NULL: copies (3, nitems) ints -- start and end of every wave item on
- * the 100 MHz constant clock (low 31 bits) and its workgroup index; *nitems = ceil(B * lanes_per_env / 64). */
+/* Wave trace of the last 8 launches (tuning: the tail of a launch whose environments all run at once is its slowest
+ * wave; the time between the launches is what is left of a launch once its waves are accounted for).  dst == NULL:
+ * enable / disable.  dst != NULL: copies the ring, (8, 4, nitems) ints -- slot (launch % 8), rows = when the item's
+ * wave entered the kernel, started and finished the item on the 100 MHz constant clock (low 31 bits), and its
+ * workgroup index; *nitems = ceil(B * lanes_per_env / 64). */
 int dmc_batch_wave_trace(dmc_batch* b, int enable, int32_t* dst, int* nitems);
 
 /* Per-phase shader-cycle profile of the fused kernel (libraries built with
