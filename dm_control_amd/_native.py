@@ -17,7 +17,7 @@ EXPORTS = [
     'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_invalidate_async', 'dmc_batch_info', 'dmc_batch_time_steps',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
-    'dmc_batch_set_env_geoms', 'dmc_env_geom_pack', 'dmc_batch_wave_trace',
+    'dmc_batch_set_env_geoms', 'dmc_env_geom_pack', 'dmc_batch_wave_trace', 'dmc_batch_randomize_joints',
 ]
 
 _lib = None
@@ -84,6 +84,7 @@ def lib():
   L.dmc_batch_prof_enable.argtypes = [vp, ci]
   L.dmc_batch_prof_get.argtypes = [vp, vp, ctypes.POINTER(ci)]
   L.dmc_batch_wave_trace.argtypes = [vp, ci, vp, ctypes.POINTER(ci)]
+  L.dmc_batch_randomize_joints.argtypes = [vp, ctypes.c_uint64, vp, vp, ci, vp]
   _lib = L
   return L
 

@@ -200,6 +200,16 @@ class BatchedPhysics:
     else:
       _native.check(_native.lib().dmc_batch_invalidate_async(self._ptr, ctypes.c_void_p(stream)))
 
+  RAND_LIMITED, RAND_UNLIMITED_HINGE, RAND_QUATERNION, RAND_FREE_NORMAL, RAND_ALL = 1, 2, 4, 8, 7
+
+  def randomize_joints(self, seed, draw_ptr, env_mask_ptr=None, flags=7, stream=None):
+    """randomize_limited_and_rotational_joints (suite/utils/randomizers.py:35-88) on the device for the environments
+    whose entry of the (B,) int32 device array at `env_mask_ptr` is non-zero (None: all); `draw_ptr`: (B,) int32 device
+    array of per-environment draw counters, incremented for the environments drawn (dmc_batch_randomize_joints)."""
+    _native.check(_native.lib().dmc_batch_randomize_joints(self._ptr, ctypes.c_uint64(int(seed) & (2**64 - 1)),
+                                                           ctypes.c_void_p(draw_ptr), ctypes.c_void_p(env_mask_ptr), int(flags),
+                                                           ctypes.c_void_p(stream) if stream else None))
+
   def time_steps(self, nstep, reps, stream=None):
     ms = ctypes.c_float()
     _native.check(_native.lib().dmc_batch_time_steps(self._ptr, int(nstep), int(self.legacy_step),

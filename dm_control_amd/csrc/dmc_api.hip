@@ -74,6 +74,7 @@ struct dmc_batch {
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (4, nitems) ints, or null
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
+  int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
 };
 
@@ -182,7 +183,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   dmc_batch* b = new dmc_batch();
   b->model = m; b->B = batch_size; b->device = device_id; b->precision = precision;
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
-  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr; b->trace_launch = 0;
+  b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr; b->trace_launch = 0; b->d_rj_i = nullptr; b->d_rj_r = nullptr;
   std::string err;
   if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
@@ -286,6 +287,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_cost) (void)hipFree(b->d_cost);
   if (b->d_order) (void)hipFree(b->d_order);
   if (b->d_trace) (void)hipFree(b->d_trace);
+  if (b->d_rj_i) (void)hipFree(b->d_rj_i);
+  if (b->d_rj_r) (void)hipFree(b->d_rj_r);
   delete b;
 }
 
@@ -875,6 +878,99 @@ extern "C" int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int e
   }
   *count = cnt;
   return 0;
+}
+
+// ---- per-episode joint randomisation on the device -------------------------------------------------------------
+// suite/utils/randomizers.py:35-88 (randomize_limited_and_rotational_joints) and the draws of
+// suite/cheetah.py:66-69 / suite/quadruped.py:_find_non_contacting_height for a whole batch, without a host round
+// trip and without a finite pool of start states: a counter-based generator (Philox4x32-10, Salmon et al. 2011) keyed
+// by (seed, env) with counter (draw number of the env, joint, block) -- every (env, episode, joint) has its own
+// stream whatever the batch size, launch order or mask.
+struct Philox { uint32_t c[4]; };
+__host__ __device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox o = {{c0, c1, c2, c3}};
+  return o;
+}
+__device__ inline double philox_u01(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }      // in (0, 1)
+__device__ inline void box_muller(double u0, double u1, double* n0, double* n1) {
+  const double r = sqrt(-2.0 * log(u0)), a = 6.283185307179586476925286766559 * u1;
+  *n0 = r * cos(a); *n1 = r * sin(a);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) randomize_joints_kernel(T* __restrict__ qpos, int B, int njnt, const int* __restrict__ ji,
+                                                               const double* __restrict__ jr, uint32_t seed_lo, uint32_t seed_hi,
+                                                               int* __restrict__ draw, const int* __restrict__ mask, int flags) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= B || (mask && !mask[env])) return;
+  const uint32_t k = (uint32_t)draw[env];
+  draw[env] = (int)(k + 1);
+  const uint32_t key0 = seed_lo ^ (uint32_t)env, key1 = seed_hi;
+  for (int j = 0; j < njnt; j++) {
+    const int type = ji[j], adr = ji[njnt + j], limited = ji[2*njnt + j];
+    const double lo = jr[2*j], hi = jr[2*j + 1];
+    const Philox x = philox4x32_10(k, (uint32_t)j, 0u, 0u, key0, key1);
+    if (type == DMC_JNT_HINGE || type == DMC_JNT_SLIDE) {
+      if (limited) { if (flags & DMC_RAND_LIMITED) qpos[(size_t)adr*B + env] = (T)(lo + (hi - lo) * philox_u01(x.c[0])); }
+      else if (type == DMC_JNT_HINGE && (flags & DMC_RAND_UNLIMITED_HINGE))
+        qpos[(size_t)adr*B + env] = (T)(-3.14159265358979323846 + 6.283185307179586476925286766559 * philox_u01(x.c[0]));
+    } else if (type == DMC_JNT_BALL && limited) {
+      if (!(flags & DMC_RAND_LIMITED)) continue;
+      // random_limited_quaternion: axis ~ normalised N(0, I), angle ~ U(0, range max)
+      const Philox y = philox4x32_10(k, (uint32_t)j, 1u, 0u, key0, key1);
+      double n[4];
+      box_muller(philox_u01(x.c[0]), philox_u01(x.c[1]), &n[0], &n[1]);
+      box_muller(philox_u01(x.c[2]), philox_u01(x.c[3]), &n[2], &n[3]);
+      const double nn = sqrt(n[0]*n[0] + n[1]*n[1] + n[2]*n[2]), ang = philox_u01(y.c[0]) * hi, sn = sin(0.5 * ang) / nn;
+      qpos[(size_t)adr*B + env] = (T)cos(0.5 * ang);
+      for (int c = 0; c < 3; c++) qpos[(size_t)(adr + 1 + c)*B + env] = (T)(n[c] * sn);
+    } else if (type == DMC_JNT_BALL || type == DMC_JNT_FREE) {
+      if (!(flags & DMC_RAND_QUATERNION)) continue;
+      // ball joints: normalised N(0, I) (uniform on the 3-sphere); free joints: normalised U(0, 1)^4 as the reference
+      // draws them (randomizers.py:84-88 keeps `rand` on purpose) unless DMC_RAND_FREE_NORMAL asks for the sphere
+      double q[4];
+      if (type == DMC_JNT_BALL || (flags & DMC_RAND_FREE_NORMAL)) {
+        box_muller(philox_u01(x.c[0]), philox_u01(x.c[1]), &q[0], &q[1]);
+        box_muller(philox_u01(x.c[2]), philox_u01(x.c[3]), &q[2], &q[3]);
+      } else {
+        for (int c = 0; c < 4; c++) q[c] = philox_u01(x.c[c]);
+      }
+      const double inv = 1.0 / sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+      const int a0 = adr + (type == DMC_JNT_FREE ? 3 : 0);
+      for (int c = 0; c < 4; c++) qpos[(size_t)(a0 + c)*B + env] = (T)(q[c] * inv);
+    }
+  }
+}
+extern "C" int dmc_batch_randomize_joints(dmc_batch* b, uint64_t seed, int32_t* d_draw, const int32_t* d_env_mask, int flags,
+                                          void* hip_stream) {
+  if (!b || !d_draw) return fail("null argument");
+  HIP_TRY(hipSetDevice(b->device));
+  const HostModel& m = b->model->hm;
+  const int nj = m.njnt;
+  if (!b->d_rj_i) {
+    std::vector<int> ji(3 * (size_t)std::max(1, nj));
+    for (int j = 0; j < nj; j++) { ji[j] = m.jnt_type[j]; ji[nj + j] = m.jnt_qposadr[j]; ji[2*nj + j] = m.jnt_limited[j]; }
+    HIP_TRY(hipMalloc((void**)&b->d_rj_i, ji.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&b->d_rj_r, 2 * (size_t)std::max(1, nj) * sizeof(double)));
+    HIP_TRY(hipMemcpy(b->d_rj_i, ji.data(), ji.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (nj) HIP_TRY(hipMemcpy(b->d_rj_r, m.jnt_range.data(), 2 * (size_t)nj * sizeof(double), hipMemcpyHostToDevice));
+  }
+  const dim3 grid((b->B + 255) / 256), block(256);
+  void* q = find_field(b, "qpos")->dev;
+  if (b->precision == 64)
+    hipLaunchKernelGGL(randomize_joints_kernel<double>, grid, block, 0, (hipStream_t)hip_stream, (double*)q, b->B, nj, (const int*)b->d_rj_i,
+                       (const double*)b->d_rj_r, (uint32_t)seed, (uint32_t)(seed >> 32), d_draw, d_env_mask, flags);
+  else
+    hipLaunchKernelGGL(randomize_joints_kernel<float>, grid, block, 0, (hipStream_t)hip_stream, (float*)q, b->B, nj, (const int*)b->d_rj_i,
+                       (const double*)b->d_rj_r, (uint32_t)seed, (uint32_t)(seed >> 32), d_draw, d_env_mask, flags);
+  HIP_TRY(hipGetLastError());
+  // qpos was edited behind the stashes' back
+  return dmc_batch_invalidate_async(b, hip_stream);
 }
 
 // ---- wave trace: when every wave of the LAST launch started / finished its item (100 MHz constant clock) -------

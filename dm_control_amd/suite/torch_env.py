@@ -5,9 +5,12 @@ step.  The environments here keep everything on the GPU: the SoA arrays of the H
 batch are rebound to torch tensors (zero copy, `dmc_batch_bind`), actions are
 written by the caller's policy directly into the `ctrl` tensor, observations /
 rewards are torch expressions over the bound tensors, and environments whose
-episode ended are re-initialised on device from a pool of valid start states
-(cheetah: settled for 200 steps as suite/cheetah.py:63-76 does; humanoid: the
-collision-free configurations that suite/humanoid.py:160-165 finds by rejection).
+episode ended are re-initialised on device with a fresh draw per episode
+(`dmc_batch_randomize_joints`: a counter-based Philox stream per environment and
+draw, suite/utils/randomizers.py:35-88 -- cheetah: limited joints ~ U(range), then
+200 settle steps as suite/cheetah.py:63-76 does; humanoid: redrawn until nothing is
+in contact, suite/humanoid.py:160-165, the rejection loop running for the whole
+batch at once on the environments still pending).
 torch is plumbing here (memory + elementwise ops); the physics is the fused HIP
 kernel.
 
@@ -48,8 +51,8 @@ def tolerance(torch, x, bounds=(0.0, 0.0), margin=0.0, sigmoid='gaussian', value
 class TorchBatchedEnv:
   """B environments of one suite task; every tensor is (rows, B) on `device`.
 
-  Subclasses define `_MODEL`, `_OUTPUTS` (extra derived arrays to bind), the start-state
-  pool, `observation()` and `reward()`.  The default (this class) is cheetah `run`."""
+  Subclasses define `_MODEL`, `_OUTPUTS` (extra derived arrays to bind), `_initialize_episode()`,
+  `observation()` and `reward()`.  The default (this class) is cheetah `run`."""
 
   _MODEL = 'cheetah.xml'
   _OUTPUTS = ()            # e.g. ('xpos', 'xmat'): derived arrays the task reads
@@ -96,9 +99,12 @@ class TorchBatchedEnv:
     self.step_limit = int(round(time_limit / (m.opt.timestep * n_sub_steps)))
     self.steps = torch.zeros(self.B, dtype=torch.int64, device=self.device)
     self._host_steps = 0     # upper bound of `steps` known without a device sync
-    self._rs = np.random.RandomState(seed)
-    self._gen = torch.Generator(device=self.device).manual_seed(seed)
-    self._make_start_pool()
+    self._seed = int(seed)
+    self._draw = torch.zeros(self.B, dtype=torch.int32, device=self.device)      # per-environment draw counters
+    self._mask_i = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+    self._q0 = torch.from_numpy(np.ascontiguousarray(m.qpos0, dtype=np.float64)).to(self.device, self.dtype)[:, None]
+    self.reset_rounds = 0      # launches the last reset needed (rejection / raising loops)
+    self._setup()
     self.reset()
 
   def _model_xml(self):
@@ -111,48 +117,54 @@ class TorchBatchedEnv:
   def _body(self, name):
     return self.model.name2id(name, 'body')
 
-  def _upload_qpos(self, q):
-    self.qpos.copy_(self.torch.from_numpy(np.ascontiguousarray(q.T)).to(self.dtype))
+  def _setup(self):
+    """Index tensors a task needs, before the first reset."""
+
+  def _randomize(self, mask, flags):
+    """randomize_limited_and_rotational_joints for the masked environments, drawn on the device."""
+    self._mask_i.copy_(mask)
+    self.physics.randomize_joints(self._seed, self._draw.data_ptr(), self._mask_i.data_ptr(), flags, stream=self._stream())
+
+  def _launch_only(self, mask, fn):
+    """Runs a launch for the masked environments and leaves the others untouched (env_mode 2)."""
+    torch = self.torch
+    self.env_mode.copy_(torch.where(mask[None, :], torch.zeros_like(self.env_mode), torch.full_like(self.env_mode, 2)))
+    fn()
+    self.env_mode.zero_()
+
+  def _zero_rows(self, t, mask):
+    t.copy_(self.torch.where(mask[None, :], self.torch.zeros_like(t), t))
 
   # -- start states ------------------------------------------------------------------
-  def _make_start_pool(self):
-    """Cheetah.initialize_episode for a pool of start states (suite/cheetah.py:63-76):
-    limited joints ~ U(range), 200 settle steps with zero control, on device."""
-    m = self.model
-    lim = m.jnt_limited == 1
-    lo, hi = m.jnt_range[lim].T
-    q = np.tile(m.qpos0, (self.B, 1))
-    q[:, lim] = self._rs.uniform(lo, hi, (self.B, lo.size))
-    self._upload_qpos(q)
-    self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_()
-    self.physics.step(200, stream=self._stream())
-    self.pool_qpos, self.pool_qvel, self.pool_warm = self.qpos.clone(), self.qvel.clone(), self.warm.clone()
+  def _initialize_episode(self, mask):
+    """Cheetah.initialize_episode for the masked environments (suite/cheetah.py:63-76): limited joints ~ U(range),
+    then 200 settle steps with zero control; the other environments sit the launch out."""
+    torch = self.torch
+    self.qpos.copy_(torch.where(mask[None, :], self._q0, self.qpos))
+    self._randomize(mask, BatchedPhysics.RAND_LIMITED)
+    for t in (self.qvel, self.ctrl, self.warm):
+      self._zero_rows(t, mask)
+    self._launch_only(mask, lambda: self.physics.step(200, stream=self._stream()))
+    self.reset_rounds = 1
 
   def reset(self, mask=None):
-    """Re-initialises the selected environments (all if mask is None) from the pool and
-    refreshes the derived arrays (mj_forward with actuation disabled, as Physics.reset does)."""
+    """Re-initialises the selected environments (all if mask is None) with a fresh draw each and refreshes the
+    derived arrays (mj_forward with actuation disabled, as Physics.reset does)."""
     torch = self.torch
     if mask is None:
       mask = torch.ones(self.B, dtype=torch.bool, device=self.device)
       self._host_steps = 0
-    P = self.pool_qpos.shape[1]
-    pick = torch.randint(0, P, (self.B,), device=self.device, generator=self._gen)
-    m2 = mask[None, :]
-    self.qpos.copy_(torch.where(m2, self.pool_qpos[:, pick], self.qpos))
-    self.qvel.copy_(torch.where(m2, self.pool_qvel[:, pick], self.qvel))
-    self.warm.copy_(torch.where(m2, self.pool_warm[:, pick], self.warm))
-    self.time.copy_(torch.where(m2, torch.zeros_like(self.time), self.time))
-    self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
     if self.model.na:
-      self.act.copy_(torch.where(m2, torch.zeros_like(self.act), self.act))
+      self._zero_rows(self.act, mask)
+    self._initialize_episode(mask)
+    self._zero_rows(self.time, mask)
+    self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
     self.physics.invalidate()      # qpos / qvel were edited through the bound tensors
     if self._OUTPUTS:
       # refresh the derived arrays of the environments that were reset, and of those only: the others are left
       # untouched by the launch (env_mode 2), so their acceleration-stage sensors, warm starts and observations
       # do not depend on who else was reset
-      self.env_mode.copy_(torch.where(m2, torch.zeros_like(self.env_mode), torch.full_like(self.env_mode, 2)))
-      self.physics.forward(disable_actuation=True, stream=self._stream())
-      self.env_mode.zero_()
+      self._launch_only(mask, lambda: self.physics.forward(disable_actuation=True, stream=self._stream()))
     return self.observation()
 
   # -- task ----------------------------------------------------------------------------
@@ -205,44 +217,28 @@ class Humanoid(TorchBatchedEnv):
   _COM_VEL_SENSOR = 'torso_subtreelinvel'
   move_speed = 0.0
 
-  def __init__(self, batch_size, move_speed=0.0, time_limit=25.0, pool_size=None, **kw):
+  def __init__(self, batch_size, move_speed=0.0, time_limit=25.0, **kw):
     self.move_speed = float(move_speed)
-    self._pool_size = pool_size
     super().__init__(batch_size, time_limit=time_limit, **kw)
 
-  def _make_start_pool(self):
-    """randomize_limited_and_rotational_joints + rejection of configurations in contact
-    (suite/humanoid.py:160-165), evaluated for whole batches with mj_forward until the pool
-    holds `pool_size` (default B) collision-free states."""
-    torch, m = self.torch, self.model
-    want = self._pool_size or self.B
-    keep = []
-    have = 0
-    for _ in range(1000):
-      q = np.tile(m.qpos0, (self.B, 1))
-      for j in range(m.njnt):
-        t, a = m.jnt_type[j], m.jnt_qposadr[j]
-        if m.jnt_limited[j] and t in (2, 3):
-          q[:, a] = self._rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], self.B)
-        elif t == 3:
-          q[:, a] = self._rs.uniform(-np.pi, np.pi, self.B)
-        elif t == 0:
-          quat = self._rs.rand(self.B, 4)
-          q[:, a + 3:a + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
-      self._upload_qpos(q)
-      self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_()
-      self.physics.forward(disable_actuation=True, stream=self._stream())
-      ok = (self.ncon[0] == 0)
-      keep.append(self.qpos[:, ok].clone())
-      have += int(ok.sum())
-      if have >= want:
+  def _initialize_episode(self, mask):
+    """randomize_limited_and_rotational_joints, redrawn while anything is in contact (suite/humanoid.py:160-165):
+    every round draws the environments still pending, evaluates mj_forward for them alone and keeps those with
+    ncon == 0.  One host sync per round (the loop's exit test), at reset time only."""
+    torch = self.torch
+    pending = mask.clone()
+    for rounds in range(1, 10001):
+      self.qpos.copy_(torch.where(pending[None, :], self._q0, self.qpos))
+      self._randomize(pending, BatchedPhysics.RAND_ALL)
+      for t in (self.qvel, self.ctrl, self.warm):
+        self._zero_rows(t, pending)
+      self._launch_only(pending, lambda: self.physics.forward(disable_actuation=True, stream=self._stream()))
+      pending = pending & (self.ncon[0] > 0)
+      if not bool(pending.any()):
         break
     else:
-      raise RuntimeError('could not fill the pool of collision-free start states')
-    self.pool_qpos = torch.cat(keep, dim=1)[:, :want].contiguous()
-    P = self.pool_qpos.shape[1]
-    self.pool_qvel = torch.zeros((m.nv, P), dtype=self.dtype, device=self.device)
-    self.pool_warm = torch.zeros((m.nv, P), dtype=self.dtype, device=self.device)
+      raise RuntimeError('could not find collision-free start states')
+    self.reset_rounds = rounds
 
   # rows of the (3*nbody, B) / (9*nbody, B) arrays
   def _xpos(self, body):
@@ -317,21 +313,14 @@ class HumanoidCMU(Humanoid):
 
 class _RandomJointStart(TorchBatchedEnv):
   """Start states = randomize_limited_and_rotational_joints (suite/utils/randomizers.py:35-88): limited
-  hinges / sliders ~ U(range), unlimited hinges ~ U(-pi, pi); a pool of B such states, drawn on reset."""
+  hinges / sliders ~ U(range), unlimited hinges ~ U(-pi, pi), drawn on the device for every episode."""
 
-  def _make_start_pool(self):
-    m = self.model
-    q = np.tile(m.qpos0, (self.B, 1))
-    for j in range(m.njnt):
-      t, a = m.jnt_type[j], m.jnt_qposadr[j]
-      if m.jnt_limited[j] and t in (2, 3):
-        q[:, a] = self._rs.uniform(m.jnt_range[j][0], m.jnt_range[j][1], self.B)
-      elif t == 3:
-        q[:, a] = self._rs.uniform(-np.pi, np.pi, self.B)
-    self._upload_qpos(q)
-    self.pool_qpos = self.qpos.clone()
-    self.pool_qvel = self.torch.zeros_like(self.qvel)
-    self.pool_warm = self.torch.zeros_like(self.warm)
+  def _initialize_episode(self, mask):
+    self.qpos.copy_(self.torch.where(mask[None, :], self._q0, self.qpos))
+    self._randomize(mask, BatchedPhysics.RAND_ALL)
+    for t in (self.qvel, self.ctrl, self.warm):
+      self._zero_rows(t, mask)
+    self.reset_rounds = 1
 
   def _sensor(self, name, n):
     adr = self.model.sensor_adr[self.model.name2id(name, 'sensor')]
@@ -415,7 +404,7 @@ class Hopper(_RandomJointStart):
 class Quadruped(TorchBatchedEnv):
   """Quadruped walk / run (suite/quadruped.py:281-342) on device.  Start states: a random orientation,
   raised in 1 cm steps from the floor until nothing touches (`_find_non_contacting_height`), evaluated for
-  the whole pool at once."""
+  all environments being reset at once."""
 
   _MODEL = 'quadruped.xml'
   _OUTPUTS = ('xmat',)
@@ -429,26 +418,28 @@ class Quadruped(TorchBatchedEnv):
     from dm_control_amd.suite import quadruped
     return quadruped.make_model(floor_size=20 * self.desired_speed)
 
-  def _make_start_pool(self):
-    torch, m = self.torch, self.model
-    q = np.tile(m.qpos0, (self.B, 1))
-    quat = self._rs.randn(self.B, 4)
-    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
-    q[:, 2] = 0.0
-    self._upload_qpos(q)
-    self.qvel.zero_(); self.ctrl.zero_(); self.warm.zero_(); self.act.zero_()
-    for _ in range(10000):
-      self.physics.forward(disable_actuation=True, stream=self._stream())
-      touching = self.ncon[0] > 0
-      if not bool(touching.any()):
+  def _initialize_episode(self, mask):
+    """A random orientation (uniform on the sphere, suite/quadruped.py:243-246), raised from the floor in 1 cm steps
+    until nothing touches (`_find_non_contacting_height`), for the masked environments at once."""
+    torch = self.torch
+    self.qpos.copy_(torch.where(mask[None, :], self._q0, self.qpos))
+    self._randomize(mask, BatchedPhysics.RAND_QUATERNION | BatchedPhysics.RAND_FREE_NORMAL)
+    self.qpos[2].copy_(torch.where(mask, torch.zeros_like(self.qpos[2]), self.qpos[2]))
+    for t in (self.qvel, self.ctrl, self.warm):
+      self._zero_rows(t, mask)
+    pending = mask.clone()
+    for rounds in range(1, 10001):
+      self._launch_only(pending, lambda: self.physics.forward(disable_actuation=True, stream=self._stream()))
+      pending = pending & (self.ncon[0] > 0)
+      if not bool(pending.any()):
         break
-      self.qpos[2] += 0.01 * touching.to(self.dtype)
+      self.qpos[2] += 0.01 * pending.to(self.dtype)
     else:
       raise RuntimeError('Failed to find a non-contacting configuration.')
-    self.pool_qpos = self.qpos.clone()
-    self.pool_qvel = torch.zeros_like(self.qvel)
-    self.pool_warm = torch.zeros_like(self.warm)
-    m = self.model
+    self.reset_rounds = rounds
+
+  def _setup(self):
+    torch, m = self.torch, self.model
     hinge = [j for j in range(m.njnt) if m.jnt_type[j] == 3]
     self._hq = torch.tensor([m.jnt_qposadr[j] for j in hinge], device=self.device)
     self._hv = torch.tensor([m.jnt_dofadr[j] for j in hinge], device=self.device)

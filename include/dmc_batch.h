@@ -157,6 +157,23 @@ int dmc_batch_invalidate(dmc_batch* b);
  * edits qpos through a bound tensor inside a captured control step) is part of the graph and replays with it. */
 int dmc_batch_invalidate_async(dmc_batch* b, void* hip_stream);
 
+/* Per-episode joint randomisation on the device: what suite tasks do on the host in
+ * initialize_episode -- suite/utils/randomizers.py:35-88 randomize_limited_and_rotational_joints, the limited-joint
+ * draw of suite/cheetah.py:66-69, the random orientation of suite/quadruped.py:243-246 -- for every environment whose
+ * entry of `d_env_mask` (device, B ints; NULL: all) is non-zero, written straight into the qpos rows.  Draws come
+ * from Philox4x32-10 keyed by (seed ^ env, seed >> 32) with counter (d_draw[env], joint, block, 0); d_draw (device,
+ * B ints, caller-owned) is incremented for the environments that were drawn, so an (environment, draw) pair never
+ * repeats and a rejection loop (suite/humanoid.py:160-165) simply calls again with the mask of those still in contact.
+ * flags: DMC_RAND_LIMITED bounded hinges / sliders ~ U(range) and limited ball joints (axis ~ N(0, I) normalised,
+ * angle ~ U(0, range)); DMC_RAND_UNLIMITED_HINGE ~ U(-pi, pi); DMC_RAND_QUATERNION unlimited ball joints ~ uniform on
+ * the 3-sphere and free-joint quaternions ~ normalised U(0, 1)^4 (as the reference draws them), or uniform on the
+ * sphere with DMC_RAND_FREE_NORMAL.  Free-joint translations are left alone.  Ordered on `hip_stream`; the stashes
+ * are invalidated on the same stream. */
+enum { DMC_RAND_LIMITED = 1, DMC_RAND_UNLIMITED_HINGE = 2, DMC_RAND_QUATERNION = 4, DMC_RAND_FREE_NORMAL = 8,
+       DMC_RAND_ALL = 7 };
+int dmc_batch_randomize_joints(dmc_batch* b, uint64_t seed, int32_t* d_draw, const int32_t* d_env_mask, int flags,
+                               void* hip_stream);
+
 /* Observation gather table: what composer's observation.Updater does per control step for MJCFFeature observables
  * (composer/observation/updater.py:285-295, composer/observation/observable/mjcf.py:43), for the whole batch in one
  * launch.  Row k of the table names element `rows[k]` of the mjData field `field_names[k]` (real-valued fields in

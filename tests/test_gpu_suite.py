@@ -820,3 +820,74 @@ def test_work_queue_and_schedule_do_not_change_results(name, nsub, B, monkeypatc
     for x, y in zip(out['queue'], out[mode]):
       np.testing.assert_array_equal(x, y, err_msg=mode)
   assert out['queue'][3].max() > 8
+
+
+@pytest.mark.parametrize('name,flags', [('humanoid', 7), ('cheetah', 1), ('acrobot', 7), ('quadruped', 4 | 8), ('ball_xml', 7)])
+def test_device_joint_randomizer_matches_the_numpy_mirror(name, flags):
+  """dmc_batch_randomize_joints (suite/utils/randomizers.py:35-88 on the device, Philox4x32-10 per (env, draw, joint))
+  against its numpy restatement tests/philox_mirror.py, whose generator is pinned on the published known answers: same
+  values, masked environments untouched, draw counters advanced for the drawn ones only."""
+  import torch
+  import philox_mirror as pm
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  if name == 'ball_xml':
+    m = mc.compile_xml("""<mujoco><worldbody><body><joint type='ball'/><geom size='.1'/><body pos='0 0 .3'>
+        <joint type='hinge' axis='0 1 0'/><geom size='.1'/></body></body></worldbody></mujoco>""")
+  else:
+    m = mc.compile_xml(common.read_model(name + '.xml'))
+  B = 70
+  b = BatchedPhysics(m, B, precision=64)
+  draw = torch.zeros(B, dtype=torch.int32, device='cuda')
+  want = np.tile(m.qpos0, (B, 1)); wdraw = np.zeros(B, int)
+  for rnd, mask in enumerate([None, np.arange(B) % 3 == 0, np.arange(B) % 2 == 1]):
+    mt = None if mask is None else torch.from_numpy(mask.astype(np.int32)).cuda()
+    b.randomize_joints(1234567890123, draw.data_ptr(), None if mt is None else mt.data_ptr(), flags)
+    b.sync()
+    pm.randomize_joints(m, want, 1234567890123, wdraw, mask, flags)
+    np.testing.assert_allclose(b.get('qpos'), want, rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(draw.cpu().numpy(), wdraw)
+  assert (want != np.tile(m.qpos0, (B, 1))).any()
+  b.close()
+
+
+@pytest.mark.parametrize('domain,task', [('humanoid', 'stand'), ('cheetah', 'run'), ('walker', 'walk'), ('quadruped', 'walk')])
+def test_torch_env_draws_a_fresh_start_state_every_episode(domain, task):
+  """device tasks re-initialise with a NEW draw per episode (no finite pool): two resets give every
+  environment two different start states, humanoids start without contacts (suite/humanoid.py:160-165 rejection),
+  cheetahs settled with time = 0 (suite/cheetah.py:63-76), and a reset of some environments leaves the others
+  bit-identical."""
+  import torch
+  from dm_control_amd.suite import torch_env
+  B = 40
+  env = torch_env.make(domain, task, B, precision=32, seed=5)
+  m = env.model
+  q1 = env.qpos.clone()
+  env.reset()
+  q2 = env.qpos.clone()
+  hinge_rows = [int(m.jnt_qposadr[j]) for j in range(m.njnt) if m.jnt_type[j] == 3 and (m.jnt_limited[j] or domain == 'walker')]
+  if domain == 'quadruped':
+    assert bool((q1[3:7] != q2[3:7]).any(dim=0).all())          # a new orientation per episode
+    np.testing.assert_allclose(torch.linalg.norm(q2[3:7], dim=0).cpu().numpy(), 1, atol=1e-6)
+  else:
+    assert hinge_rows and bool((q1[hinge_rows] != q2[hinge_rows]).any(dim=0).all())
+  assert len({tuple(c) for c in q2.T.cpu().numpy().round(6)}) == B       # and a different one per environment
+  if domain in ('humanoid', 'quadruped'):
+    assert int(env.ncon.max()) == 0 and env.reset_rounds >= 1
+  if domain != 'cheetah':
+    for j in range(m.njnt):
+      if m.jnt_limited[j] and m.jnt_type[j] in (2, 3) and domain != 'quadruped':
+        a = int(m.jnt_qposadr[j])
+        assert float(q2[a].min()) >= m.jnt_range[j][0] - 1e-6 and float(q2[a].max()) <= m.jnt_range[j][1] + 1e-6
+  else:
+    assert float(env.qvel.abs().max()) < 5.0 and float(env.time.max()) == 0.0     # settled for 200 steps, clock reset
+  # partial reset: the others do not move
+  mask = torch.arange(B, device='cuda') % 4 == 0
+  before_q, before_v, before_w = env.qpos.clone(), env.qvel.clone(), env.warm.clone()
+  env.reset(mask)
+  keep = ~mask
+  assert torch.equal(env.qpos[:, keep], before_q[:, keep]) and torch.equal(env.qvel[:, keep], before_v[:, keep])
+  assert torch.equal(env.warm[:, keep], before_w[:, keep])
+  assert bool((env.qpos[:, mask] != before_q[:, mask]).any(dim=0).all())
+  assert int(env._draw.min()) >= 2 and int(env._draw[mask].min()) >= 3
+  env.close()
