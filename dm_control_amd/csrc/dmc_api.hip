@@ -210,7 +210,8 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
   if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
   if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
-  if (!getenv("DMC_NO_KSTASH")) {
+  // (a mocap pose is an input of mj_kinematics that the stash's (qpos, qvel) comparison does not see: no stash for those models)
+  if (!getenv("DMC_NO_KSTASH") && !d.nmocap) {
     const size_t nk = (size_t)d.nq + d.nv + (L.s_qM - L.s_xpos);
     e = hipMalloc(&b->d_kstash, (size_t)b->B * nk * b->elem);
     if (e == hipSuccess) e = hipMalloc((void**)&b->d_kstash_i, (size_t)b->B * sizeof(int));
@@ -237,6 +238,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   const Spec specs[] = {
       {"qpos", d.nq, false}, {"qvel", d.nv, false}, {"ctrl", d.nu, false}, {"qacc_warmstart", d.nv, false},
       {"qfrc_applied", d.nv, false}, {"xfrc_applied", 6*nb, false}, {"time", 1, false}, {"act", d.na, false},
+      {"mocap_pos", 3*d.nmocap, false}, {"mocap_quat", 4*d.nmocap, false},
       {"sensordata", d.nsensordata, false}, {"xpos", 3*nb, false}, {"xquat", 4*nb, false}, {"xmat", 9*nb, false},
       {"xipos", 3*nb, false}, {"geom_xpos", 3*d.ngeom, false}, {"geom_xmat", 9*d.ngeom, false},
       {"site_xpos", 3*d.nsite, false}, {"site_xmat", 9*d.nsite, false}, {"subtree_com", 3*nb, false},
@@ -344,6 +346,7 @@ static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, c
   HIP_TRY(hipSetDevice(b->device));
   if (b->tb.opts.eg_n) b->tb.opts.eg_data = find_field(b, "env_geom")->dev;      // follows dmc_batch_bind
   b->tb.opts.xfrc = b->xfrc_on ? find_field(b, "xfrc_applied")->dev : nullptr; b->tb.opts.xfrc_B = b->B;
+  if (b->tb.L.d.nmocap) { b->tb.opts.mocap_pos = find_field(b, "mocap_pos")->dev; b->tb.opts.mocap_quat = find_field(b, "mocap_quat")->dev; b->tb.opts.mocap_B = b->B; }      // follow dmc_batch_bind
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
   if (b->lpt) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)b->d_cost, b->d_order, b->nitems);
@@ -797,6 +800,15 @@ extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyfra
   if (b->xfrc_on && reset_real("xfrc_applied", nullptr, 6*m.nbody)) return -2;
   if (reset_real("time", nullptr, 1)) return -2;
   if (reset_real("act", nullptr, m.na)) return -2;
+  if (m.nmocap) {      // mj_resetData: the mocap poses start at the bodies' model poses
+    std::vector<double> mp(3 * (size_t)m.nmocap), mq(4 * (size_t)m.nmocap);
+    for (int i = 0; i < m.nbody; i++) if (m.body_mocapid[i] >= 0) {
+      for (int k = 0; k < 3; k++) mp[3*m.body_mocapid[i] + k] = m.body_pos[3*i + k];
+      for (int k = 0; k < 4; k++) mq[4*m.body_mocapid[i] + k] = m.body_quat[4*i + k];
+    }
+    if (reset_real("mocap_pos", mp.data(), 3*m.nmocap)) return -2;
+    if (reset_real("mocap_quat", mq.data(), 4*m.nmocap)) return -2;
+  }
   // mj_resetData clears warnings as well
   Field* w = find_field(b, "warning");
   std::vector<int32_t> wh((size_t)B * DMC_NWARNING, 0);

@@ -862,8 +862,16 @@ struct StepCore {
       normalize4(q);
       for (int k = 0; k < 3; k++) { S(xanchor)[3*jntadr + k] = p[k]; S(xaxis)[3*jntadr + k] = MR(jnt_axis)[3*jntadr + k]; }
     } else {
-      for (int k = 0; k < 3; k++) p[k] = MRC(body_pos)[3*i + k];
-      for (int k = 0; k < 4; k++) q[k] = MRC(body_quat)[4*i + k];
+      const int mid = L.d.nmocap ? MI(body_mocapid)[i] : -1;
+      if (mid >= 0) {      // a mocap body: its pose is data (mjData.mocap_pos / mocap_quat), not model (mj_kinematics)
+        const size_t e = (size_t)SI(imisc)[IM_ENV], MB = (size_t)o.mocap_B;
+        for (int k = 0; k < 3; k++) p[k] = ((const T*)o.mocap_pos)[(size_t)(3*mid + k)*MB + e];
+        for (int k = 0; k < 4; k++) q[k] = ((const T*)o.mocap_quat)[(size_t)(4*mid + k)*MB + e];
+        normalize4(q);
+      } else {
+        for (int k = 0; k < 3; k++) p[k] = MRC(body_pos)[3*i + k];
+        for (int k = 0; k < 4; k++) q[k] = MRC(body_quat)[4*i + k];
+      }
       for (int j = jntadr; j < jntadr + jntnum; j++) {
         const int qa = MI(jnt_qposadr)[j], t = MI(jnt_type)[j];
         T R[9], axis[3], anchor[3];

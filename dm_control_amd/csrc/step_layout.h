@@ -53,6 +53,7 @@ struct StepDims {
   int sitegl;    // 1 (nsite > 32): the real site tables (pos, quat, size) stay in global memory (StepOpts::g_mr) -- composed
                  //   scenes carry render-only sites (soccer: 120 hoarding boards of 136 sites) that only an output
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
+  int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
                  //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables.
@@ -75,6 +76,7 @@ struct StepDims {
   X(body_parentid, d.nbody) X(body_rootid, d.nbody) X(body_jntadr, d.nbody)    \
   X(body_jntnum, d.nbody) X(body_dofadr, d.nbody) X(body_dofnum, d.nbody)      \
   X(body_lastdof, d.nbody)     /* last dof on the path root->body, or -1 */    \
+  X(body_mocapid, d.nmocap ? d.nbody : 0)   /* row of mocap_pos / mocap_quat, -1: not a mocap body */ \
   X(body_anc_lo, d.nstv ? d.nbody : 0) X(body_anc_hi, d.nstv ? d.nbody : 0) /* ancestor-or-self bodies */ \
   X(stv_sensor, d.nstv)        /* the subtreelinvel sensors */                 \
   X(level_adr, d.nlevel + 1) X(level_body, d.nchild)                           \
@@ -264,6 +266,9 @@ struct StepOpts {
   // mjData.xfrc_applied: Cartesian [force(3), torque(3)] per body at its COM, (6 nbody, B) SoA in global memory; null
   // until the caller touches the field (almost every batch): read only where it enters (mj_fwdAcceleration, cfrc_ext)
   const void* xfrc; int xfrc_B;
+  // mjData.mocap_pos / mocap_quat: (3 nmocap, B) / (4 nmocap, B) SoA in batch precision, global memory (models with
+  // mocap bodies only): the pose mj_kinematics gives a mocap body
+  const void* mocap_pos; const void* mocap_quat; int mocap_B;
   // per-environment global scratch, (B, n_gs) reals (StepLayout::gs_*): arrays of the large models that LDS has no room for
   void* gscr;
   // the real model tables in global memory (batch precision): where the large models read the cold ones from

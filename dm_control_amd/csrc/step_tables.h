@@ -97,6 +97,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   std::vector<int> stv;
   for (int i = 0; i < m.nsensor; i++) if (m.sensor_type[i] == DMC_SENS_SUBTREELINVEL) stv.push_back(i);
   d.nstv = (int)stv.size();
+  d.nmocap = m.nmocap;
   for (int i = 0; i < m.nsensor; i++) if (m.sensor_type[i] == DMC_SENS_RANGEFINDER) d.nrf++;
   if (d.nstv && m.nbody > 64) { *err = "subtreelinvel sensors need nbody <= 64"; return false; }
   d.fluid = (m.opt_density > 0 || m.opt_viscosity > 0) ? 1 : 0;
@@ -365,6 +366,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   }
   cpi(L.mi_fric_dof, fric_dof);
   cpi(L.mi_stv_sensor, stv);
+  if (d.nmocap) for (int b = 0; b < m.nbody; b++) mi[L.mi_body_mocapid + b] = m.body_mocapid[b];
   if (d.nstv) for (int b = 0; b < m.nbody; b++) {
     uint64_t mask = 0;
     for (int a = b; ; a = m.body_parentid[a]) { mask |= 1ull << a; if (a == 0) break; }
@@ -421,6 +423,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   o.noslip_iterations = m.opt_noslip_iterations; o.noslip_tolerance = m.opt_noslip_tolerance;
   o.any_damping = 0;
   o.eg_data = nullptr; o.eg_slot = nullptr; o.eg_n = 0; o.eg_B = 0; o.ns_A = nullptr; o.xfrc = nullptr; o.xfrc_B = 0; o.gscr = nullptr; o.g_mr = nullptr;
+  o.mocap_pos = nullptr; o.mocap_quat = nullptr; o.mocap_B = 0;
   for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
   return true;
 }
@@ -435,7 +438,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
   o.noslip_iterations = s.noslip_iterations; o.noslip_tolerance = (T)s.noslip_tolerance;
   o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
-  o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A; o.xfrc = s.xfrc; o.xfrc_B = s.xfrc_B; o.gscr = s.gscr; o.g_mr = s.g_mr;
+  o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A; o.xfrc = s.xfrc; o.xfrc_B = s.xfrc_B; o.mocap_pos = s.mocap_pos; o.mocap_quat = s.mocap_quat; o.mocap_B = s.mocap_B; o.gscr = s.gscr; o.g_mr = s.g_mr;
   return o;
 }
 

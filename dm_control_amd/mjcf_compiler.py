@@ -287,7 +287,7 @@ class Model:
   def sizes(self):
     return {k: int(getattr(self, k)) for k in
             ('nq', 'nv', 'nu', 'na', 'nbody', 'njnt', 'ngeom', 'nsite',
-             'nsensor', 'nsensordata', 'npair', 'nkey', 'ntendon', 'nwrap', 'neq')}
+             'nsensor', 'nsensordata', 'npair', 'nkey', 'ntendon', 'nwrap', 'neq', 'nmocap')}
 
   def pack(self):
     """Serialises into (ints int32[], reals float64[]) per dmc_model_layout.h."""
@@ -537,7 +537,9 @@ class _Compiler:
         parent=parent_id,
         pos=_vec(elem.attrib['pos'], 3) if 'pos' in elem.attrib else np.zeros(3),
         quat=self._orientation(elem.attrib),
-        joints=[], geoms=[], inertial=None)
+        joints=[], geoms=[], inertial=None, mocap=elem.attrib.get('mocap', 'false') == 'true')
+    if body['mocap'] and (is_world or parent_id != 0):
+      raise MjcfError('mocap body %r must be a child of the world body' % body['name'])
     if is_world:
       body['pos'] = np.zeros(3)
       body['quat'] = np.array([1.0, 0, 0, 0])
@@ -565,6 +567,8 @@ class _Compiler:
       elif tag in ('joint', 'freejoint'):
         if is_world:
           raise MjcfError('joints are not allowed in worldbody')
+        if body['mocap']:
+          raise MjcfError('mocap body %r cannot have joints' % body['name'])
         self._parse_joint(child, bid, childclass)
       elif tag == 'geom':
         self._parse_geom(child, bid, childclass)
@@ -950,6 +954,12 @@ class _Compiler:
                              dtype=np.float64)
     # geoms are appended body by body?  Not necessarily contiguous per body
     # (a body's geoms are parsed before its children), so they are: check.
+    # mocap bodies: static children of the world whose pose is mjData.mocap_pos / mocap_quat (row body_mocapid)
+    m.body_mocapid = np.full(nbody, -1, dtype=np.int64)
+    for bid, b in enumerate(self.bodies):
+      if b['mocap']:
+        m.body_mocapid[bid] = int((m.body_mocapid >= 0).sum())
+    m.nmocap = int((m.body_mocapid >= 0).sum())
     m.body_geomadr = np.full(nbody, -1, dtype=np.int64)
     m.body_geomnum = np.zeros(nbody, dtype=np.int64)
     for bid, b in enumerate(self.bodies):

@@ -13,7 +13,7 @@ drop-in.  batch_size == B > 1: every data array gains a leading batch dimension.
 
 `physics.data` is a host mirror of the device arrays: reads fetch lazily (and
 are cached until the next step/forward/reset), writes to the input fields
-(`qpos qvel act ctrl qacc_warmstart qfrc_applied xfrc_applied time`) are uploaded before the
+(`qpos qvel act ctrl qacc_warmstart qfrc_applied xfrc_applied mocap_pos mocap_quat time`) are uploaded before the
 next kernel launch.  High-throughput callers use `physics.batch`
 (`BatchedPhysics`: device pointers, zero-copy binds) instead of the mirror.
 """
@@ -38,12 +38,14 @@ _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margi
                          'body_quat')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
-_INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time')
+_INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
+                 'mocap_quat')
 _INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
 # field -> (row object kind for named access, columns per row)
 _FIELD_AXES = {
     'qpos': ('joint_q', None), 'qvel': ('joint_v', None), 'qacc': ('joint_v', None),
     'qacc_warmstart': ('joint_v', None), 'qfrc_applied': ('joint_v', None), 'xfrc_applied': ('body', 6),
+    'mocap_pos': ('mocap', 3), 'mocap_quat': ('mocap', 4),      # rows named after the mocap bodies (mujoco/index.py:177-267)
     'qfrc_actuator': ('joint_v', None), 'qfrc_bias': ('joint_v', None),
     'qfrc_constraint': ('joint_v', None),
     'ctrl': ('actuator', None), 'actuator_force': ('actuator', None),
@@ -264,6 +266,8 @@ def _make_axes(model):
       'sensor': _Axis(m.names['sensor'], m.sensor_adr, m.sensor_dim),
       'body': _Axis(m.names['body']), 'geom': _Axis(m.names['geom']), 'site': _Axis(m.names['site']),
       'joint': _Axis(m.names['joint']),
+      # mocap_pos / mocap_quat rows: the bodies with body_mocapid >= 0, in mocap-id order
+      'mocap': _Axis([n for _, n in sorted((int(k), m.names['body'][b]) for b, k in enumerate(getattr(m, 'body_mocapid', ())) if k >= 0)]),
   }
 
 
@@ -425,8 +429,10 @@ class Physics(control.Physics):
       if name == 'eq_active':
         n = len(getattr(self.model, 'eq_active0', ()))
         out.append((name, n))
-      elif name in ('mocap_pos', 'mocap_quat', 'userdata', 'plugin_state'):
-        out.append((name, 0))            # no mocap bodies / user data / plugins in a compiled Model
+      elif name in ('mocap_pos', 'mocap_quat'):
+        out.append((name, (3 if name == 'mocap_pos' else 4) * int(getattr(self.model, 'nmocap', 0))))
+      elif name in ('userdata', 'plugin_state'):
+        out.append((name, 0))            # no user data / plugins in a compiled Model
       else:
         out.append((name, int(np.asarray(self.data._get(name)).reshape(self.batch_size, -1).shape[1])))
     return out

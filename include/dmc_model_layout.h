@@ -18,12 +18,12 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 10
+#define DMC_MODEL_VERSION 11
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) \
-  X(nsensor) X(nsensordata) X(npair) X(nkey) X(ntendon) X(nwrap) X(neq) \
+  X(nsensor) X(nsensordata) X(npair) X(nkey) X(ntendon) X(nwrap) X(neq) X(nmocap) \
   X(opt_integrator) X(opt_cone) X(opt_solver) X(opt_iterations) \
   X(opt_ls_iterations) X(opt_noslip_iterations) \
   X(opt_disableflags) X(opt_enableflags)
@@ -39,6 +39,7 @@
   X(body_parentid, nbody) X(body_rootid, nbody) X(body_weldid, nbody) \
   X(body_jntadr, nbody) X(body_jntnum, nbody) X(body_dofadr, nbody) \
   X(body_dofnum, nbody) X(body_geomadr, nbody) X(body_geomnum, nbody) \
+  X(body_mocapid, nbody)   /* row of mjData.mocap_pos / mocap_quat that poses the body, -1: not a mocap body (mujoco/index.py:177-267) */ \
   X(jnt_type, njnt) X(jnt_qposadr, njnt) X(jnt_dofadr, njnt) \
   X(jnt_bodyid, njnt) X(jnt_limited, njnt) \
   X(dof_bodyid, nv) X(dof_jntid, nv) X(dof_parentid, nv) \

@@ -72,6 +72,7 @@ typedef struct {
   /* state */
   double time;
   double *qpos, *qvel, *act, *act_dot, *qacc_warmstart, *ctrl, *qfrc_applied, *xfrc_applied;
+  double *mocap_pos, *mocap_quat; /* (nmocap, 3 / 4): poses of the mocap bodies, inputs like ctrl */
   /* position-dependent */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis;
   double *geom_xpos, *geom_xmat, *site_xpos, *site_xmat;
@@ -330,7 +331,7 @@ double* ora_model_real_field(Model* m, const char* name, int* count) {
 
 #define DATA_REAL_FIELDS(X) \
   X(qpos, m->nq) X(qvel, m->nv) X(act, m->na) X(act_dot, m->na) X(qacc_warmstart, m->nv) X(ctrl, m->nu) \
-  X(qfrc_applied, m->nv) X(xfrc_applied, 6*m->nbody) \
+  X(qfrc_applied, m->nv) X(xfrc_applied, 6*m->nbody) X(mocap_pos, 3*m->nmocap) X(mocap_quat, 4*m->nmocap) \
   X(xpos, 3*m->nbody) X(xquat, 4*m->nbody) X(xmat, 9*m->nbody) X(xipos, 3*m->nbody) \
   X(ximat, 9*m->nbody) X(xanchor, 3*m->njnt) X(xaxis, 3*m->njnt) \
   X(geom_xpos, 3*m->ngeom) X(geom_xmat, 9*m->ngeom) X(site_xpos, 3*m->nsite) X(site_xmat, 9*m->nsite) \
@@ -431,6 +432,10 @@ void ora_reset(const Model* m, Data* d, int key) {
   d->time = 0; d->ncon = 0; d->nefc = 0; d->solver_iter = 0;
   memset(d->warning, 0, sizeof d->warning);
   memcpy(d->qpos, m->qpos0, sizeof(double) * (size_t)m->nq);
+  for (int i = 0; i < m->nbody; i++) if (m->body_mocapid[i] >= 0) {      /* mj_resetData: mocap poses from the model */
+    memcpy(d->mocap_pos + 3*m->body_mocapid[i], m->body_pos + 3*i, 3 * sizeof(double));
+    memcpy(d->mocap_quat + 4*m->body_mocapid[i], m->body_quat + 4*i, 4 * sizeof(double));
+  }
   for (int i = 0; i < m->nbody; i++) { d->xquat[4*i] = 1; d->xmat[9*i] = d->xmat[9*i+4] = d->xmat[9*i+8] = 1;
     d->ximat[9*i] = d->ximat[9*i+4] = d->ximat[9*i+8] = 1; }
   if (key >= 0 && key < m->nkey) {
@@ -460,9 +465,15 @@ static void kinematics(const Model* m, Data* d) {
       memcpy(d->xaxis + 3*jntadr, m->jnt_axis + 3*jntadr, 3 * sizeof(double));
     } else {
       int pid = m->body_parentid[i];
-      mul_mat_vec3(xpos, d->xmat + 9*pid, m->body_pos + 3*i);
-      xpos[0] += d->xpos[3*pid]; xpos[1] += d->xpos[3*pid+1]; xpos[2] += d->xpos[3*pid+2];
-      mul_quat(xquat, d->xquat + 4*pid, m->body_quat + 4*i);
+      if (m->body_mocapid[i] >= 0) {      /* a mocap body: its pose is data, not model (mj_kinematics) */
+        memcpy(xpos, d->mocap_pos + 3*m->body_mocapid[i], 3 * sizeof(double));
+        memcpy(xquat, d->mocap_quat + 4*m->body_mocapid[i], 4 * sizeof(double));
+        normalize4(xquat);
+      } else {
+        mul_mat_vec3(xpos, d->xmat + 9*pid, m->body_pos + 3*i);
+        xpos[0] += d->xpos[3*pid]; xpos[1] += d->xpos[3*pid+1]; xpos[2] += d->xpos[3*pid+2];
+        mul_quat(xquat, d->xquat + 4*pid, m->body_quat + 4*i);
+      }
       for (int j = jntadr; j < jntadr + jntnum; j++) {
         int qa = m->jnt_qposadr[j];
         double* anchor = d->xanchor + 3*j; double* axis = d->xaxis + 3*j;

@@ -25,6 +25,7 @@ struct Emu {
   int kstash_on = 0; std::vector<double> kstash; std::vector<int> kstash_i;      // kinematic stash (doubles: room for either precision)
   std::vector<double> gs;       // the environment's global scratch (persists between launches, like the device buffer)
   std::vector<double> xfrc64; std::vector<float> xfrc32;      // xfrc_applied (6 nbody), empty = not set
+  std::vector<double> mpos64, mquat64; std::vector<float> mpos32, mquat32;      // mocap_pos / mocap_quat (one environment)
 };
 
 static std::string g_err;
@@ -48,6 +49,10 @@ void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_e
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
 void emu_kstash(void* h, int on) { Emu* e = (Emu*)h; const StepLayout& L = e->tb.L; e->kstash_on = on; e->kstash.assign(L.d.nq + L.d.nv + (L.s_qM - L.s_xpos) + 4, 0.0); e->kstash_i.assign(2, 0); }
 void emu_set_xfrc(void* h, const double* x) { Emu* e = (Emu*)h; e->xfrc64.assign(x, x + 6*e->hm.nbody); e->xfrc32.assign(x, x + 6*e->hm.nbody); }
+void emu_set_mocap(void* h, const double* p, const double* q) {
+  Emu* e = (Emu*)h; const int n = e->hm.nmocap;
+  e->mpos64.assign(p, p + 3*n); e->mpos32.assign(p, p + 3*n); e->mquat64.assign(q, q + 4*n); e->mquat32.assign(q, q + 4*n);
+}
 void emu_set_env_geoms(void* h, int n, const int* ids, const double* data) {
   Emu* e = (Emu*)h;
   e->eg_slot.assign(e->hm.ngeom, -1);
@@ -87,8 +92,17 @@ static void run_t(Emu* e, const T* mr, double** f, int** fi, int nstep, int lega
   io.contact_force = buf[24].data(); io.cvel = buf[25].data(); io.act = buf[26].data();
   io.ncon = fi[0]; io.nefc = fi[1]; io.solver_iter = fi[2]; io.warning = fi[3]; io.contact_geom1 = fi[4]; io.contact_geom2 = fi[5];
   io.debug = dbg ? dbuf.data() : nullptr; io.debug_i = dibuf.data(); io.ndebug = dbg ? 1 : 0;
-  io.env_mode = nullptr; io.work = nullptr; io.cost = nullptr; io.order = nullptr; io.trace = nullptr;
+  io.env_mode = nullptr; io.work = nullptr; io.cost = nullptr; io.order = nullptr; io.trace = nullptr; io.trace_slot = 0;
   if (!e->xfrc64.empty()) { o.xfrc = sizeof(T) == 8 ? (const void*)e->xfrc64.data() : (const void*)e->xfrc32.data(); o.xfrc_B = 1; }
+  if (L.d.nmocap) {
+    if (e->mpos64.empty()) {      // mj_resetData: the model poses
+      std::vector<double> p(3*L.d.nmocap), q(4*L.d.nmocap);
+      for (int i = 0; i < e->hm.nbody; i++) if (e->hm.body_mocapid[i] >= 0) { for (int k = 0; k < 3; k++) p[3*e->hm.body_mocapid[i] + k] = e->hm.body_pos[3*i + k]; for (int k = 0; k < 4; k++) q[4*e->hm.body_mocapid[i] + k] = e->hm.body_quat[4*i + k]; }
+      emu_set_mocap(e, p.data(), q.data());
+    }
+    o.mocap_pos = sizeof(T) == 8 ? (const void*)e->mpos64.data() : (const void*)e->mpos32.data();
+    o.mocap_quat = sizeof(T) == 8 ? (const void*)e->mquat64.data() : (const void*)e->mquat32.data(); o.mocap_B = 1;
+  }
   o.g_mr = mr;
   e->gs.resize(L.n_gs + 2); o.gscr = e->gs.data();   // doubles: room for either precision
   if (L.d.nslip) { e->nsA.resize((size_t)L.d.nslip * L.d.nslip + 2); o.ns_A = e->nsA.data(); }

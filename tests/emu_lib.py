@@ -35,6 +35,7 @@ def lib():
     L.emu_invalidate.argtypes = [ctypes.c_void_p]
     L.emu_kstash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_set_xfrc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.emu_set_mocap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_set_env_geoms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
@@ -100,6 +101,13 @@ class EmuPhysics:
 
   def invalidate(self):
     lib().emu_invalidate(self.h)
+
+  def set_mocap(self, pos, quat):
+    """mjData.mocap_pos (nmocap, 3) / mocap_quat (nmocap, 4)."""
+    p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1)
+    q = np.ascontiguousarray(quat, dtype=np.float64).reshape(-1)
+    assert p.size == 3 * self.m.nmocap and q.size == 4 * self.m.nmocap
+    lib().emu_set_mocap(self.h, p.ctypes.data, q.ctypes.data)
 
   def set_xfrc(self, xfrc):
     """mjData.xfrc_applied: (nbody, 6) [force, torque] at the body COMs."""

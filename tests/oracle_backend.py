@@ -28,7 +28,8 @@ class OracleBatch:
     self._rows = dict(qpos=m.nq, qvel=m.nv, act=m.na, ctrl=m.nu, qacc_warmstart=m.nv, qfrc_applied=m.nv, xfrc_applied=6*nb, time=1,
                       sensordata=m.nsensordata, xpos=3*nb, xquat=4*nb, xmat=9*nb, xipos=3*nb, geom_xpos=3*m.ngeom,
                       geom_xmat=9*m.ngeom, site_xpos=3*m.nsite, site_xmat=9*m.nsite, subtree_com=3*nb, qacc=m.nv,
-                      actuator_force=m.nu, qfrc_actuator=m.nv, qfrc_bias=m.nv, qfrc_constraint=m.nv, cvel=6*nb)
+                      actuator_force=m.nu, qfrc_actuator=m.nv, qfrc_bias=m.nv, qfrc_constraint=m.nv, cvel=6*nb,
+                      mocap_pos=3*m.nmocap, mocap_quat=4*m.nmocap)
 
   def close(self):
     self._envs = []
@@ -57,6 +58,8 @@ class OracleBatch:
       return out
     if name == 'time':
       return np.array([[o.time] for o in self._envs])
+    if not self._rows[name]:
+      return np.zeros((B, 0))
     return np.stack([np.array(o.field(name), dtype=np.float64).reshape(-1)[:self._rows[name]] for o in self._envs]).reshape(B, self._rows[name])
 
   def set(self, name, value):
@@ -70,7 +73,7 @@ class OracleBatch:
         o.time = float(a[e, 0])
       else:
         o.field(name)[:rows] = a[e]
-    if name in ('qpos', 'qvel', 'act'):
+    if name in ('qpos', 'qvel', 'act', 'mocap_pos', 'mocap_quat'):
       self._stale = True      # the HIP launch recomputes the position / velocity stage from the state it is given
 
   def set_control(self, control):
