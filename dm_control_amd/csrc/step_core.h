@@ -140,6 +140,12 @@ template <> DMC_DEV float t_atan2<float>(float y, float x) { return atan2f(y, x)
 template <typename T> DMC_DEV T t_fmod(T x, T y) { return (T)fmod((double)x, (double)y); }
 template <> DMC_DEV float t_fmod<float>(float x, float y) { return fmodf(x, y); }
 template <> DMC_DEV float t_exp<float>(float x) { return expf(x); }
+// Correctly rounded fp32 division / square root whatever the build's fp32 division mode (step_kernels_f32 is compiled
+// with the 2.5-ulp hardware forms): for the few places whose branch decisions sit on an absolute 1e-10 (the PGS block
+// updates) and are not on the hot path of any BASELINE configuration.
+template <typename T> DMC_DEV T t_div_exact(T a, T b) { return a / b; }
+template <> DMC_DEV float t_div_exact<float>(float a, float b) { return (float)((double)a / (double)b); }
+template <typename T> DMC_DEV T t_sqrt_exact(T x) { return (T)sqrt((double)x); }
 template <typename T> DMC_DEV T t_abs(T x) { return x < 0 ? -x : x; }
 template <typename T> DMC_DEV T t_max(T a, T b) { return a > b ? a : b; }
 template <typename T> DMC_DEV T t_min(T a, T b) { return a < b ? a : b; }
@@ -1697,6 +1703,8 @@ struct StepCore {
     if (x == 0) return s0;
     T y;
     if (s4 == 1) y = x;
+    // power 2 is MuJoCo's default solimp: squares instead of four pow() expansions (both branches run when lanes diverge)
+    else if (s4 == 2) y = x <= s3 ? (1 / s3) * (x*x) : 1 - (1 / (1 - s3)) * ((1 - x)*(1 - x));
     else if (x <= s3) y = (1 / t_pow(s3, s4 - 1)) * t_pow(x, s4);
     else y = 1 - (1 / t_pow(1 - s3, s4 - 1)) * t_pow(1 - x, s4);
     return s0 + y*(s1 - s0);
@@ -3588,7 +3596,7 @@ struct StepCore {
     const T* fr3 = MR(prm_friction) + 3*con_prm(c);
     const T fri5[5] = {fr3[0], fr3[0], fr3[1], fr3[2], fr3[2]};
     if (f[0] < (T)DMC_MINVAL) {            // normal force too small: normal update, friction cleared
-      f[0] -= rs[0]/A[0];
+      f[0] -= t_div_exact(rs[0], A[0]);
       if (f[0] < 0) f[0] = 0;
 #pragma unroll
       for (int p = 1; p < N; p++) f[p] = 0;
@@ -3602,8 +3610,8 @@ struct StepCore {
 #pragma unroll
       for (int p = 0; p < N; p++) { denom += old[p]*v1[p]; vr += old[p]*rs[p]; }
       if (denom >= (T)DMC_MINVAL) {
-        T x = -vr / denom;
-        if (f[0] + x*old[0] < 0) x = -f[0]/old[0];
+        T x = t_div_exact(-vr, denom);
+        if (f[0] + x*old[0] < 0) x = t_div_exact(-f[0], old[0]);
 #pragma unroll
         for (int p = 0; p < N; p++) f[p] += x*old[p];
       }
@@ -3627,8 +3635,8 @@ struct StepCore {
       if (active) {
         T ss = 0;
 #pragma unroll
-        for (int p = 0; p < M; p++) ss += v[p]*v[p]/(fri[p]*fri[p]);
-        ss = t_sqrt(f[0]*f[0] / t_max((T)DMC_MINVAL, ss));
+        for (int p = 0; p < M; p++) ss += t_div_exact(v[p]*v[p], fri[p]*fri[p]);
+        ss = t_sqrt_exact(t_div_exact(f[0]*f[0], t_max((T)DMC_MINVAL, ss)));
 #pragma unroll
         for (int p = 0; p < M; p++) v[p] *= ss;
       }
@@ -3678,7 +3686,7 @@ struct StepCore {
       DMC_WSYNC();
     }
     for (int i = lane; i < nefc; i += LPE) {
-      ns_A()[i*cap + i] += 1 / S(efc_D)[i];
+      ns_A()[i*cap + i] += t_div_exact((T)1, S(efc_D)[i]);
       S(efc_jv)[i] = row_dot(i, S(qacc_smooth), rm) - S(efc_aref)[i];       // b
     }
     // warm start: the forces of qacc_warmstart through the primal map, kept only if their dual cost beats zero forces
@@ -3711,7 +3719,7 @@ struct StepCore {
         const int dim = t == EFC_ELLIPTIC ? con_dim(EFC_ID(tid)) : 1;
         if (dim == 1) {
           const T a = ns_A()[i*cap + i], r = S(ns_res)[i], old = S(efc_force)[i];
-          T f = old - r/a;
+          T f = old - t_div_exact(r, a);
           if (t == EFC_FRICTION) { const T fl = MR(dof_frictionloss)[EFC_ID(tid)]; if (f < -fl) f = -fl; else if (f > fl) f = fl; }
           else if (t != EFC_EQUALITY) { if (f < 0) f = 0; }
           T delta = f - old;
