@@ -277,17 +277,41 @@ template <int CTRL> DMC_DEV double dpp_f(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 #endif
+// Exchanges across the 16-lane rows / the 32-lane halves of a wave with the gfx950 row / half swaps
+// (v_permlane16_swap / v_permlane32_swap: VALU moves) instead of a trip through the LDS crossbar (ds_bpermute, what
+// __shfl_xor compiles to): swapping a value with itself leaves {even row's copy, odd row's copy} of each row pair in
+// the two results, whose sum / max is the same in both rows.  Reductions sit on the critical path of every solver
+// iteration (their results feed the next branch), ~25 per Newton iteration.
+#ifndef DMC_HOST_EMU
+struct Pair32 { unsigned a, b; };
+DMC_DEV Pair32 swap16(unsigned x) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); Pair32 p = {r[0], r[1]}; return p; }
+DMC_DEV Pair32 swap32(unsigned x) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); Pair32 p = {r[0], r[1]}; return p; }
+template <int W> DMC_DEV Pair32 swapW(unsigned x) { return W == 16 ? swap16(x) : swap32(x); }
+template <int W> DMC_DEV float xsum(float v) { const Pair32 p = swapW<W>(__float_as_uint(v)); return __uint_as_float(p.a) + __uint_as_float(p.b); }
+template <int W> DMC_DEV int xsum(int v) { const Pair32 p = swapW<W>((unsigned)v); return (int)p.a + (int)p.b; }
+template <int W> DMC_DEV double xsum(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const Pair32 lo = swapW<W>((unsigned)u), hi = swapW<W>((unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi.a << 32) | lo.a) + __builtin_bit_cast(double, ((unsigned long long)hi.b << 32) | lo.b);
+}
+template <int W> DMC_DEV int xmax(int v) { const Pair32 p = swapW<W>((unsigned)v); return (int)p.a > (int)p.b ? (int)p.a : (int)p.b; }
+#endif
 // Sum over the LPE lanes of a group; every lane receives the total.  Same
 // pairing tree as an xor butterfly (1, 2, 4, 8 inside a row via DPP quad_perm /
-// row_half_mirror / row_mirror, then 16 and 32 via ds_bpermute).
+// row_half_mirror / row_mirror, then 16 and 32 via the row / half swaps).
 template <int LPE, typename V> DMC_DEV V group_sum(V v) {
 #ifndef DMC_HOST_EMU
   if (LPE >= 2) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
   if (LPE >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
   if (LPE >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
   if (LPE >= 16) v += dpp_f<0x140>(v);  // row_mirror
+#ifdef DMC_NO_PERMLANE_SWAP
   if (LPE >= 32) v += __shfl_xor(v, 16, 64);
   if (LPE >= 64) v += __shfl_xor(v, 32, 64);
+#else
+  if (LPE >= 32) v = xsum<16>(v);
+  if (LPE >= 64) v = xsum<32>(v);
+#endif
 #endif
   return v;
 }
@@ -317,18 +341,41 @@ template <int LPE, typename V> DMC_DEV V wave_bcast(V v, int k) {
 }
 template <int LPE> DMC_DEV int group_max(int v) {
 #ifndef DMC_HOST_EMU
+#ifdef DMC_NO_PERMLANE_SWAP
 #pragma unroll
   for (int o = LPE / 2; o > 0; o >>= 1) { int w = __shfl_xor(v, o, LPE); v = w > v ? w : v; }
+#else
+  int w;
+  if (LPE >= 2) { w = dpp_i<0xB1>(v); v = w > v ? w : v; }
+  if (LPE >= 4) { w = dpp_i<0x4E>(v); v = w > v ? w : v; }
+  if (LPE >= 8) { w = dpp_i<0x141>(v); v = w > v ? w : v; }
+  if (LPE >= 16) { w = dpp_i<0x140>(v); v = w > v ? w : v; }
+  if (LPE >= 32) v = xmax<16>(v);
+  if (LPE >= 64) v = xmax<32>(v);
+#endif
 #endif
   return v;
 }
-// exclusive prefix sum over the group; *total receives the group sum
+// exclusive prefix sum over the group; *total receives the group sum.  Hillis-Steele inside a 16-lane row with DPP
+// row shifts (zeros shifted in), then the row totals travel with row_bcast:15 / row_bcast:31 -- no LDS crossbar trips
+// (__shfl_up is a ds_bpermute: six dependent ones per scan).
 template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 #ifndef DMC_HOST_EMU
   int inc = v;
+#ifdef DMC_NO_PERMLANE_SWAP
 #pragma unroll
   for (int o = 1; o < LPE; o <<= 1) { int w = __shfl_up(inc, o, LPE); if (lane >= o) inc += w; }
   *total = __shfl(inc, LPE - 1, LPE);
+#else
+  (void)lane;
+  if (LPE >= 2) inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);    // row_shr:1
+  if (LPE >= 4) inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);    // row_shr:2
+  if (LPE >= 8) inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);    // row_shr:4
+  if (LPE >= 16) inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
+  if (LPE >= 32) inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+  if (LPE >= 64) inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+  *total = wave_bcast<LPE>(inc, LPE - 1);
+#endif
   return inc - v;
 #else
   (void)lane; *total = v; return 0;
@@ -544,6 +591,9 @@ struct DynLayoutSrc {
   DMC_DEV const StepLayout& get() const { return *p; }
 };
 
+#ifndef DMC_PRIO_ITER
+#define DMC_PRIO_ITER 2   // Newton iteration from which a wave raises its issue priority (fwd_constraint)
+#endif
 template <typename T, int LPE, typename LS> struct StageFns;   // out-of-line stage entry points (below)
 
 template <typename T, int LPE, typename LS = DynLayoutSrc>
@@ -3800,6 +3850,11 @@ struct StepCore {
     DMC_PROF(PROF_SOL_GRAD);
     int iter = 0;
     while (iter < o.iterations) {
+#if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
+      // a launch ends with its slowest wave, and that is one whose solve takes many iterations: from the third
+      // iteration on it wins the issue arbitration against the wave it shares the SIMD with (which has slack)
+      if (iter == DMC_PRIO_ITER) __builtin_amdgcn_s_setprio(2);
+#endif
       T lscost;
       const T alpha = primal_search(nefc, gauss, scale, &lscost);
       DMC_PROF(PROF_SOL_LS);
@@ -3856,6 +3911,9 @@ struct StepCore {
 #endif
       if (improvement < tol_imp || gradient < tol_grad) break;
     }
+#if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
+    __builtin_amdgcn_s_setprio(0);
+#endif
     constraint_force_to_joint(nefc);
     FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
     if (lane == 0) SI(imisc)[IM_ITER] = iter;

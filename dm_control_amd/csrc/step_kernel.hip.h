@@ -39,11 +39,22 @@ struct LaunchGeom {
 
 // bytes of the per-workgroup header in LDS that holds the scalar options (read by
 // the out-of-line stage functions, which cannot see kernel arguments)
-template <typename T> constexpr int opts_lds_bytes() { return (int)((sizeof(StepOpts<T>) + 15) / 16 * 16); }
+// ... followed by a copy of StepIO: its ~60 pointers do not fit the SGPR file next to everything else, and as kernel
+// arguments they were spilled to VGPR lanes in the 16-dword tuples they were loaded in -- every use of ONE pointer
+// read 16 lanes back (2 400 v_readlane in the cheetah kernel).  From LDS a use is one ds_read_b64.
+template <typename T> constexpr int stepopts_lds_bytes() { return (int)((sizeof(StepOpts<T>) + 15) / 16 * 16); }
+#ifdef DMC_IO_KERNARG
+template <typename T> constexpr int opts_lds_bytes() { return stepopts_lds_bytes<T>(); }
+#else
+template <typename T> constexpr int opts_lds_bytes() { return stepopts_lds_bytes<T>() + (int)((sizeof(StepIO<T>) + 15) / 16 * 16); }
+#endif
 
-template <typename T, int LPE, typename LS>
+// QUEUE = false: every wave has exactly one item (the batch fits the resident grid) -- no claim loop, so nothing of
+// the body is "loop invariant": with the loop the kernel arguments are hoisted out of it, spilled to VGPR lanes
+// (106 SGPRs hold a fraction of StepIO's ~60 pointers) and read back with v_readlane where they are used.
+template <typename T, int LPE, typename LS, bool QUEUE>
 __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg, const int* __restrict__ g_mi,
-                                                 const T* __restrict__ g_mr, const int* __restrict__ g_mc, const StepIO<T>& io, int nstep, int legacy,
+                                                 const T* __restrict__ g_mr, const int* __restrict__ g_mc, const StepIO<T>& io_arg, int nstep, int legacy,
                                                  int mode, int outmask, int nsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepLayout& L = ls.get();
@@ -52,7 +63,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   int* mi = reinterpret_cast<int*>(tables);
   T* mr = reinterpret_cast<T*>(tables + (size_t)L.n_mi * sizeof(int));
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int t_entry = io.trace ? (int)(wall_clock64() & 0x7fffffffll) : 0;
+  const int t_entry = io_arg.trace ? (int)(wall_clock64() & 0x7fffffffll) : 0;
   typedef StepCore<T, LPE, LS> Core;
   constexpr int epw = 64 / LPE;
   // XCD-aware mapping: workgroup b runs on XCD b % 8, and each XCD has its own L2.
@@ -61,7 +72,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
   const int lblk = xcd * q + (xcd < r ? xcd : r) + (blockIdx.x >> 3);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wpb = nthr >> 6;      // wave-uniform: the loop state lives in SGPRs
-  const int nitems = (io.B + epw - 1) / epw, nwaves = nblk * wpb;
+  const int nitems = (io_arg.B + epw - 1) / epw, nwaves = nblk * wpb;
   // The first item's state and kinematic stash are requested before the tables are staged and written to the env's
   // LDS scratch before the barrier: one HBM round trip for tables, state and stash.
   const size_t tables_bytes = (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T) + (L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0);
@@ -71,20 +82,27 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   int slot = lblk * wpb + wave;
   int env0 = 0;
   if (slot < nitems) {
-    const int item = io.order ? io.order[slot] : slot;
+    const int item = io_arg.order ? io_arg.order[slot] : slot;
     env0 = item * epw + ((tid / LPE) & (epw - 1));
-    if (env0 >= io.B) env0 = io.B - 1;      // ragged last wave: loads the last environment, runs nothing
-    Core::entry_issue(L, o_arg, io, env0, tid % LPE, mode, legacy, &en, &er);
+    if (env0 >= io_arg.B) env0 = io_arg.B - 1;      // ragged last wave: loads the last environment, runs nothing
+    Core::entry_issue(L, o_arg, io_arg, env0, tid % LPE, mode, legacy, &en, &er);
   }
   // stage the model constant tables once per workgroup (shared by all its envs)
   if (tid == 0) *o_lds = o_arg;
+#ifdef DMC_IO_KERNARG
+  const StepIO<T>& io = io_arg;
+#else
+  StepIO<T>* io_lds = reinterpret_cast<StepIO<T>*>(smem + stepopts_lds_bytes<T>());
+  if (tid == 64 % nthr) *io_lds = io_arg;
+  const StepIO<T>& io = *io_lds;
+#endif
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
   for (int i = tid; i < L.n_mr_lds; i += nthr) mr[i] = g_mr[i];   // large models: only the hot tables (StepLayout::n_mr_lds)
   // small models: the cold tables ride along in LDS (after the real tables); large ones read them from global memory
   int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T));
   const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
   if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
-  if (slot < nitems) Core::entry_commit(L, io, env0, tid % LPE, &en, er, reinterpret_cast<T*>(tables + tables_bytes + (size_t)(tid / LPE) * env_bytes));
+  if (slot < nitems) Core::entry_commit(L, io_arg, env0, tid % LPE, &en, er, reinterpret_cast<T*>(tables + tables_bytes + (size_t)(tid / LPE) * env_bytes));
   __syncthreads();
   // An item is the 64 / LPE environments one wave steps together.  Every wave starts on the item of its position in
   // the grid.  When the grid is only the RESIDENT workgroups of a larger batch (io.work != null), a wave that finishes
@@ -118,7 +136,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
       const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
       io.cost[item] = (int)(dt < 1 ? 1 : (dt > 0x3fffffff ? 0x3fffffff : dt));
     }
-    if (!io.work) break;
+    if (!QUEUE || !io.work) break;
     int nx = 0;
     if ((threadIdx.x & 63) == 0) nx = atomicAdd(io.work, 1);
     slot = nwaves + __builtin_amdgcn_readfirstlane(nx);
@@ -129,21 +147,21 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     // (later items load in place, inside run(): up here the registers are full of what the loop keeps alive)
     en.em = io.env_mode ? io.env_mode[nenv] : 0; en.fast = 0; en.kvalid = 0;
   }
-  if (io.work && (threadIdx.x & 63) == 0) {
+  if (QUEUE && io.work && (threadIdx.x & 63) == 0) {
     // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
     // last wave to arrive can re-arm the queue for the next launch on the stream
     if (atomicAdd(io.work + 1, 1) == nwaves - 1) { atomicExch(io.work, 0); atomicExch(io.work + 1, 0); }
   }
 }
 
-template <typename T, int LPE>
+template <typename T, int LPE, bool QUEUE>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel(const StepLayout* __restrict__ Lp, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
             const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   // generic kernel: the layout lives in device memory (uniform scalar loads); taking
   // the address of a by-value kernel argument would copy it to scratch
   DynLayoutSrc ls; ls.p = Lp;
-  step_kernel_body<T, LPE, DynLayoutSrc>(ls, o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
+  step_kernel_body<T, LPE, DynLayoutSrc, QUEUE>(ls, o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
 }
 
 #if DMC_NSTATIC > 0
@@ -160,11 +178,11 @@ template <int SID> struct StaticLayout;
 DMC_STATIC_IDS(DMC_DEF_STATIC)
 #undef DMC_DEF_STATIC
 
-template <typename T, int LPE, int SID>
+template <typename T, int LPE, int SID, bool QUEUE>
 __global__ void __launch_bounds__(256, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
                    const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
-  step_kernel_body<T, LPE, StaticLayout<SID> >(StaticLayout<SID>(), o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
+  step_kernel_body<T, LPE, StaticLayout<SID>, QUEUE>(StaticLayout<SID>(), o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);
 }
 #endif
 
@@ -172,23 +190,25 @@ template <typename T>
 inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<T>& o,
                                 const int* g_mi, const T* g_mr, const int* g_mc, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
   const dim3 grid(g.grid), block(g.waves * 64);
-#define DMC_LAUNCH(LPE)                                                                                         \
+#define DMC_LAUNCH_Q(LPE, Q)                                                                                    \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, LPE>),                     \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, LPE, Q>),                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((step_kernel<T, LPE>), grid, block, g.lds_bytes, stream, d_layout, o, g_mi, g_mr, g_mc, io, nstep,    \
+    hipLaunchKernelGGL((step_kernel<T, LPE, Q>), grid, block, g.lds_bytes, stream, d_layout, o, g_mi, g_mr, g_mc, io, nstep, \
                        legacy, mode, outmask, nsub);                                                                  \
   }
-#define DMC_LAUNCH_STATIC(LPE, SID)                                                                             \
+#define DMC_LAUNCH(LPE) { if (io.work) DMC_LAUNCH_Q(LPE, true) else DMC_LAUNCH_Q(LPE, false) }
+#define DMC_LAUNCH_STATIC_Q(LPE, SID, Q)                                                                        \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_static<T, LPE, SID>),         \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel_static<T, LPE, SID, Q>),      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);                \
     if (e != hipSuccess) return e;                                                                              \
-    hipLaunchKernelGGL((step_kernel_static<T, LPE, SID>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, g_mc, io,  \
+    hipLaunchKernelGGL((step_kernel_static<T, LPE, SID, Q>), grid, block, g.lds_bytes, stream, o, g_mi, g_mr, g_mc, io,  \
                        nstep, legacy, mode, outmask, nsub);                                                           \
     return hipGetLastError();                                                                                   \
   }
+#define DMC_LAUNCH_STATIC(LPE, SID) { if (io.work) DMC_LAUNCH_STATIC_Q(LPE, SID, true) else DMC_LAUNCH_STATIC_Q(LPE, SID, false) }
 #if DMC_NSTATIC > 0
   // specialised instantiations exist for (static id, lanes) pairs listed in DMC_STATIC_INSTANCES
 #define DMC_X(SID, LPE) if (g.static_id == SID && g.lpe == LPE) DMC_LAUNCH_STATIC(LPE, SID)
@@ -201,6 +221,8 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
   else return hipErrorInvalidValue;
 #undef DMC_LAUNCH
 #undef DMC_LAUNCH_STATIC
+#undef DMC_LAUNCH_Q
+#undef DMC_LAUNCH_STATIC_Q
   return hipGetLastError();
 }
 

@@ -30,11 +30,11 @@ def kernels(obj):
 
 
 def short(name):
-  m = re.search(r'step_kernel(_static)?I([fd])Li(\d+)(?:ELi(\d+))?', name)
+  m = re.search(r'step_kernel(_static)?I([fd])Li(\d+)(?:ELi(\d+))?ELb([01])', name)
   if not m:
     return name[:40]
-  return '%s<%s,%s%s>' % ('static' if m.group(1) else 'generic', 'f32' if m.group(2) == 'f' else 'f64', m.group(3),
-                          (',' + m.group(4)) if m.group(4) else '')
+  return '%s<%s,%s%s>%s' % ('static' if m.group(1) else 'generic', 'f32' if m.group(2) == 'f' else 'f64', m.group(3),
+                            (',' + m.group(4)) if m.group(4) else '', ' queue' if m.group(5) == '1' else '')
 
 
 if __name__ == '__main__':

@@ -80,6 +80,6 @@ def test_hot_kernel_keeps_its_locals_out_of_scratch(tmp_path):
       text += r.stdout
     pos = blob.find(b'\x7fELF', pos + 4)
   sizes = dict(re.findall(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)', text))
-  bench_kernel = [k for k in sizes if 'step_kernel_staticIfLi32ELi0' in k]
+  bench_kernel = [k for k in sizes if 'step_kernel_staticIfLi32ELi0ELb0' in k]      # (no claim loop: the batch fits the grid)
   assert bench_kernel, sorted(sizes)[:5]
   assert int(sizes[bench_kernel[0]]) <= 32, sizes[bench_kernel[0]]
