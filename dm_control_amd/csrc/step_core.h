@@ -2940,6 +2940,23 @@ struct StepCore {
         int i, j;
         tri_unrank(idx, nv, &i, &j);
         T h = S(qM)[i*nv + j];
+        if (!L.d.elliptic) {
+          // four rows per trip: their loads are issued together (one LDS round trip instead of four dependent ones --
+          // the row count is a run-time number, so the loop is not unrolled for us), then accumulated in row order
+          for (int r = 0; r < nefc; r += 4) {
+            int st[4]; T ji[4], jj[4], dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int rr = r + u < nefc ? r + u : r;
+              st[u] = r + u < nefc ? SI(efc_active)[rr] : 0;
+              ji[u] = S(efc_Jd)[rr*nv + i]; jj[u] = S(efc_Jd)[rr*nv + j]; dd[u] = S(efc_D)[rr];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (st[u] == EFC_ST_QUADRATIC && ji[u] != 0) h += (dd[u]*ji[u]) * jj[u];
+          }
+          S(qLH)[idx] = h;
+          continue;
+        }
         for (int r = 0; r < nefc; r++) {
           const int st = SI(efc_active)[r];
           if (L.d.elliptic && st == EFC_ST_CONE) {
@@ -3244,7 +3261,13 @@ struct StepCore {
     if (L.d.jfull) {      // every row dense: one loop, rows in order
       FOR_LANES(i, nv) {
         T f = 0;
-        for (int r = 0; r < nefc; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
+        for (int r = 0; r < nefc; r += 4) {      // four rows per trip, loads issued together, summed in row order
+          T fr[4], jr[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int rr = r + u < nefc ? r + u : r; fr[u] = r + u < nefc ? S(efc_force)[rr] : (T)0; jr[u] = S(efc_Jd)[rr*nv + i]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (fr[u] != 0) f += jr[u]*fr[u];
+        }
         S(qfrc_constraint)[i] = f;
       }
       return;
@@ -3853,7 +3876,11 @@ struct StepCore {
 #if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
       // a launch ends with its slowest wave, and that is one whose solve takes many iterations: from the third
       // iteration on it wins the issue arbitration against the wave it shares the SIMD with (which has slack)
+#ifdef DMC_PRIO_LADDER
+      if (iter == 1) __builtin_amdgcn_s_setprio(1); else if (iter == 2) __builtin_amdgcn_s_setprio(2); else if (iter == 3) __builtin_amdgcn_s_setprio(3);
+#else
       if (iter == DMC_PRIO_ITER) __builtin_amdgcn_s_setprio(2);
+#endif
 #endif
       T lscost;
       const T alpha = primal_search(nefc, gauss, scale, &lscost);
