@@ -3471,15 +3471,10 @@ struct StepCore {
     return la != 0;
   }
   // one Gauss-Seidel block of N friction dimensions starting at slot a; returns the cost change (<= 0)
+  // new forces of one block from its A (N x N), old forces and residual: frictionloss dof, pyramidal pair, or the QCQP
+  // of an elliptic contact's friction dimensions
   template <int N>
-  DMC_DEV T noslip_block(int a, int nf, int t, int id) {
-    T Ac[N*N], old[N], bres[N], fnew[N];
-#pragma unroll
-    for (int p = 0; p < N; p++) {
-      old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
-#pragma unroll
-      for (int q = 0; q < N; q++) Ac[p*N + q] = ns_A()[(a + p)*L.d.nslip + a + q];
-    }
+  DMC_DEV void noslip_block_solve(const T* Ac, const T* old, const T* bres, T* fnew, int t, int id) {
     if (N == 1) {
       const T fl = MR(dof_frictionloss)[id];
       fnew[0] = old[0] - bres[0]/Ac[0];
@@ -3522,6 +3517,17 @@ struct StepCore {
         }
       }
     }
+  }
+  template <int N>
+  DMC_DEV T noslip_block(int a, int nf, int t, int id) {
+    T Ac[N*N], old[N], bres[N], fnew[N];
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) Ac[p*N + q] = ns_A()[(a + p)*L.d.nslip + a + q];
+    }
+    noslip_block_solve<N>(Ac, old, bres, fnew, t, id);
     // cost change of the block; an update that increases the cost is undone
     T change = 0;
 #pragma unroll
@@ -3545,6 +3551,125 @@ struct StepCore {
     }
     DMC_WSYNC();
     return change;
+  }
+  // ---- noslip blocks solved side by side -----------------------------------------------------------------------
+  // Gauss-Seidel over the blocks is sequential only where blocks are COUPLED: A = J_F M^-1 J_F' couples two blocks iff
+  // their contacts share a kinematic tree (M^-1 is block diagonal over the trees), and for uncoupled ones the cross
+  // terms are exact zeros -- the order in which they are solved does not change a bit of the result.  The blocks are
+  // put into levels (a block comes after every lower-indexed block it is coupled to); the blocks of one level are
+  // solved by one lane each instead of one after the other on every lane (the scalar QCQP iteration IS the noslip
+  // time: 31 % of the soccer step, whose four walkers and ball make five independent blocks).  The solving lane
+  // updates the residual of its own rows from its registers; only blocks with a partner also sweep their rows of A
+  // from global memory over the other rows, in block order, which is the order the sequential sweep adds them in.
+  // Up to 16 blocks and trees rooted at bodies 1 .. 63; anything larger keeps the sequential sweep.
+  enum { NS_MAXBLK = 16 };
+  DMC_DEV void ns_tree_bits(int body, unsigned* lo, unsigned* hi) const {
+    if (MI(body_lastdof)[body] < 0) return;      // no dof moves it: nothing of M^-1 behind its Jacobian
+    const int r = MI(body_rootid)[body];
+    if (r < 32) *lo |= 1u << r; else *hi |= 1u << (r - 32);
+  }
+  // plans the sweep: returns the number of blocks (0: keep the sequential sweep), *nlev the number of levels
+  DMC_DEV int noslip_plan(int nf, int* nlev) {
+    *nlev = 0;
+    if (L.d.nbody > 64 || L.d.ntree < 2) return 0;      // (one tree: every block is coupled to every other)
+    DMC_WSYNC();
+    int nb = 0, levmax = 0;
+    for (int a = 0; a < nf; ) {
+      const int i = SI(ns_row)[a], tid = SI(efc_tid)[i], t = EFC_TYPE(tid), id = EFC_ID(tid);
+      int n = 1;
+      if (t == EFC_PYRAMIDAL) n = 2;
+      else if (t == EFC_ELLIPTIC) n = con_dim(id) - 1;
+      if (nb == NS_MAXBLK || a > 255) return 0;
+      unsigned lo = 0, hi = 0;
+      if (t == EFC_FRICTION) ns_tree_bits(MI(dof_bodyid)[id], &lo, &hi);
+      else { ns_tree_bits(con_b1(id), &lo, &hi); ns_tree_bits(con_b2(id), &lo, &hi); }
+      int lev = 1, coupled = 0;
+      for (int k = 0; k < nb; k++) {
+        if (((unsigned)SI(ns_blk)[16 + k] & lo) | ((unsigned)SI(ns_blk)[32 + k] & hi)) {
+          const int d = SI(ns_blk)[k], lk = (d >> 16) & 0xff;
+          if (lk + 1 > lev) lev = lk + 1;
+          coupled = 1;
+          if (lane == 0 && !(d >> 24)) SI(ns_blk)[k] = d | (1 << 24);
+        }
+      }
+      if (lane == 0) { SI(ns_blk)[nb] = a | (n << 8) | (lev << 16) | (coupled << 24); SI(ns_blk)[16 + nb] = (int)lo; SI(ns_blk)[32 + nb] = (int)hi; }
+      DMC_WSYNC();
+      if (lev > levmax) levmax = lev;
+      nb++; a += n;
+    }
+    *nlev = levmax;
+    if (levmax == nb) return 0;      // a chain: nothing to solve side by side
+    return nb;
+  }
+  // one block, solved by ONE lane (the others of the group are on other blocks of the same level): noslip_block's
+  // arithmetic; the lane writes the forces, updates the residual of the block's own rows and leaves the force changes
+  // (efc_jv, dead after the solver) and the cost change (efc_jar[k]) for the group
+  template <int N>
+  DMC_DEV void noslip_block_lane(int a, int t, int id, int k) {
+    T Ac[N*N], old[N], bres[N], fnew[N];
+    const T* Ag = ns_A();
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      old[p] = S(efc_force)[SI(ns_row)[a + p]]; bres[p] = S(ns_res)[a + p]; fnew[p] = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) Ac[p*N + q] = Ag[(a + p)*L.d.nslip + a + q];
+    }
+    noslip_block_solve<N>(Ac, old, bres, fnew, t, id);
+    T change = 0;
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      T tq = 0;
+#pragma unroll
+      for (int q = 0; q < N; q++) tq += Ac[p*N + q]*(fnew[q] - old[q]);
+      change += (T)0.5*(fnew[p] - old[p])*tq + (fnew[p] - old[p])*bres[p];
+    }
+    if (change > (T)1e-10) {
+#pragma unroll
+      for (int p = 0; p < N; p++) fnew[p] = old[p];
+      change = 0;
+    }
+#pragma unroll
+    for (int p = 0; p < N; p++) {
+      const T delta = fnew[p] - old[p];
+      S(efc_force)[SI(ns_row)[a + p]] = fnew[p];
+      S(efc_jv)[a + p] = delta;
+      if (delta != 0) {
+#pragma unroll
+        for (int q = 0; q < N; q++) bres[q] += Ac[p*N + q]*delta;      // rows a .. a + N - 1 of the residual, in the order of the sweep
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < N; q++) S(ns_res)[a + q] = bres[q];
+    S(efc_jar)[k] = change;
+  }
+  // sweep of all blocks by levels; returns the sum of the blocks' cost changes, accumulated in block order
+  DMC_DEV T noslip_sweep_levels(int nf, int nb, int nlev) {
+    for (int lev = 1; lev <= nlev; lev++) {
+      FOR_LANES(k, nb) {
+        const int d = SI(ns_blk)[k];
+        if (((d >> 16) & 0xff) != lev) continue;
+        const int a = d & 0xff, n = (d >> 8) & 0xff;
+        const int tid = SI(efc_tid)[SI(ns_row)[a]], t = EFC_TYPE(tid), id = EFC_ID(tid);
+        if (n == 1) noslip_block_lane<1>(a, t, id, k);
+        else if (n == 2) noslip_block_lane<2>(a, t, id, k);
+        else if (n == 3) noslip_block_lane<3>(a, t, id, k);
+        else noslip_block_lane<5>(a, t, id, k);
+      }
+      DMC_WSYNC();
+      for (int k = 0; k < nb; k++) {      // the rows OUTSIDE a block that its new forces move: only blocks with a partner
+        const int d = SI(ns_blk)[k];
+        if (((d >> 16) & 0xff) != lev || !(d >> 24)) continue;
+        const int a = d & 0xff, n = (d >> 8) & 0xff;
+        for (int p = 0; p < n; p++) {
+          const T delta = S(efc_jv)[a + p];
+          if (delta != 0) { const T* Ap = ns_A() + (a + p)*L.d.nslip; for (int b = lane; b < nf; b += LPE) if (b < a || b >= a + n) S(ns_res)[b] += Ap[b]*delta; }
+          DMC_WSYNC();
+        }
+      }
+    }
+    T total = 0;
+    for (int k = 0; k < nb; k++) total += S(efc_jar)[k];
+    return total;
   }
   // A is symmetric and stored in full, (nslip, nslip) per environment in global memory: entry (i, j), i >= j, is
   // computed once as J_i . (M^-1 J_j^T) and written to both places, so that every later read runs along a row
@@ -3619,6 +3744,12 @@ struct StepCore {
     for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = row_dot(ra, S(qacc), rm) - S(efc_aref)[ra]; }
     DMC_WSYNC();
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
+    int nlev = 0;
+#ifdef DMC_NOSLIP_SEQUENTIAL
+    const int nblk = 0;
+#else
+    const int nblk = noslip_plan(nf, &nlev);
+#endif
     int iter = 0;
     while (iter < o.noslip_iterations) {
       T improvement = 0;
@@ -3626,7 +3757,8 @@ struct StepCore {
         for (int i = lane; i < nefc; i += LPE) { const T f = S(efc_force)[i]; improvement += (T)0.5*f*f / S(efc_D)[i]; }
         improvement = group_sum<LPE>(improvement);
       }
-      for (int a = 0; a < nf; ) {
+      if (nblk) improvement -= noslip_sweep_levels(nf, nblk, nlev);
+      else for (int a = 0; a < nf; ) {
         const int i = SI(ns_row)[a], tid = SI(efc_tid)[i], t = EFC_TYPE(tid), id = EFC_ID(tid);
         int n = 1;
         if (t == EFC_PYRAMIDAL) n = 2;

@@ -53,6 +53,7 @@ struct StepDims {
   int sitegl;    // 1 (nsite > 32): the real site tables (pos, quat, size) stay in global memory (StepOpts::g_mr) -- composed
                  //   scenes carry render-only sites (soccer: 120 hoarding boards of 136 sites) that only an output
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
+  int ntree;     // kinematic trees with at least one dof (M^-1 is block diagonal over them: noslip blocks of different trees are independent)
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
@@ -205,6 +206,7 @@ struct StepDims {
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
+  X(ns_blk, d.nslip ? 48 : 0)  /* noslip: per block (<= 16 blocks) start | size << 8 | level << 16 | coupled << 24, tree mask lo, hi */ \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch

@@ -137,6 +137,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   int nlevel = 0;
   for (int b = 1; b < m.nbody; b++) { depth[b] = depth[m.body_parentid[b]] + 1; nlevel = std::max(nlevel, depth[b]); }
   d.nlevel = nlevel; d.nchild = std::max(0, m.nbody - 1);
+  { std::vector<int> seen(m.nbody, 0); d.ntree = 0; for (int i = 0; i < m.nv; i++) { const int r = m.body_rootid[m.dof_bodyid[i]]; if (!seen[r]) { seen[r] = 1; d.ntree++; } } }
   // M sparsity
   std::vector<int> mp_i, mp_j;
   for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) { mp_i.push_back(i); mp_j.push_back(j); }
