@@ -218,7 +218,8 @@ class BatchedPhysics:
 
   PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
                 'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
-                'euler', 'trailing_step1', 'store', 'noslip', 'sol_hess', 'sol_factor', 'sol_solve', 'ls_setup']
+                'euler', 'trailing_step1', 'store', 'noslip', 'sol_hess', 'sol_factor', 'sol_solve', 'ls_setup',
+                'x1', 'x2', 'x3', 'x4', 'x5', 'x6', 'x7', 'x8']
 
   def prof_enable(self, on=True):
     _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))
@@ -231,16 +232,17 @@ class BatchedPhysics:
 
   # -- debug ----------------------------------------------------------------------------
   def wave_trace(self, enable=None):
-    """enable=True/False switches the trace; no argument: (8, 4, nitems) int array, a ring of the last 8 launches
+    """enable=True/False switches the trace; no argument: (8, 8, nitems) int array, a ring of the last 8 launches
     (slot = launch % 8 since enabling): kernel entry, start and end of every wave item on the 100 MHz constant clock,
-    workgroup index."""
+    workgroup index, then the clock after the opening position / velocity stage, the first acceleration stage, the
+    first integration and the trailing stage."""
     L = _native.lib()
     n = ctypes.c_int(0)
     if enable is not None:
       _native.check(L.dmc_batch_wave_trace(self._ptr, int(bool(enable)), None, ctypes.byref(n)))
       return None
     info = self.info()
-    out = np.zeros((8, 4, (info['B'] * info['lanes_per_env'] + 63) // 64), dtype=np.int32)
+    out = np.zeros((8, 8, (info['B'] * info['lanes_per_env'] + 63) // 64), dtype=np.int32)
     _native.check(L.dmc_batch_wave_trace(self._ptr, 1, out.ctypes.data, ctypes.byref(n)))
     return out
 

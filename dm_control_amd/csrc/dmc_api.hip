@@ -72,7 +72,7 @@ struct dmc_batch {
   void* d_kstash; int* d_kstash_i;      // kinematic stash (StepIO::kstash), on unless DMC_NO_KSTASH
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
-  int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (4, nitems) ints, or null
+  int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (8, nitems) ints, or null
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
@@ -994,15 +994,15 @@ extern "C" int dmc_batch_wave_trace(dmc_batch* b, int enable, int32_t* dst, int*
   if (dst) {
     if (!b->d_trace) return fail("wave trace not enabled");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(dst, b->d_trace, (size_t)32 * n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dst, b->d_trace, (size_t)64 * n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
   }
   HIP_TRY(hipDeviceSynchronize());
   if (b->d_trace) { (void)hipFree(b->d_trace); b->d_trace = nullptr; }
   b->trace_launch = 0;
   if (enable) {
-    HIP_TRY(hipMalloc((void**)&b->d_trace, (size_t)32 * n * sizeof(int)));
-    HIP_TRY(hipMemset(b->d_trace, 0, (size_t)32 * n * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&b->d_trace, (size_t)64 * n * sizeof(int)));
+    HIP_TRY(hipMemset(b->d_trace, 0, (size_t)64 * n * sizeof(int)));
   }
   return 0;
 }
@@ -1016,8 +1016,8 @@ extern "C" int dmc_batch_prof_enable(dmc_batch* b, int enable) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->d_prof) { (void)hipFree(b->d_prof); b->d_prof = nullptr; }
   if (!enable) return 0;
-  HIP_TRY(hipMalloc((void**)&b->d_prof, (size_t)24 * b->B * sizeof(long long)));
-  HIP_TRY(hipMemset(b->d_prof, 0, (size_t)24 * b->B * sizeof(long long)));
+  HIP_TRY(hipMalloc((void**)&b->d_prof, (size_t)32 * b->B * sizeof(long long)));
+  HIP_TRY(hipMemset(b->d_prof, 0, (size_t)32 * b->B * sizeof(long long)));
   return 0;
 }
 // dst: (PROF_N) mean cycles per env, accumulated since enable; returns PROF_N in *n
@@ -1026,9 +1026,9 @@ extern "C" int dmc_batch_prof_get(dmc_batch* b, double* dst, int* n) {
   if (!b->d_prof) return fail("profiling not enabled");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<long long> tmp((size_t)24 * b->B);
+  std::vector<long long> tmp((size_t)32 * b->B);
   HIP_TRY(hipMemcpy(tmp.data(), b->d_prof, tmp.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  for (int k = 0; k < 24; k++) { double s = 0; for (int e = 0; e < b->B; e++) s += (double)tmp[(size_t)k * b->B + e]; dst[k] = s / b->B; }
-  *n = 24;
+  for (int k = 0; k < 32; k++) { double s = 0; for (int e = 0; e < b->B; e++) s += (double)tmp[(size_t)k * b->B + e]; dst[k] = s / b->B; }
+  *n = 32;
   return 0;
 }

@@ -55,13 +55,21 @@
 namespace dmc {
 
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
-#define DMC_PROF(id) do { long long t_ = (long long)__builtin_readcyclecounter(); prof_[id] += t_ - prof_last_; prof_last_ = t_; } while (0)
+// phase cycle counters in the env's LDS scratch (lane 0): the stages stay out of line, so the profiling build has the
+// production kernel's structure (round 2's profiler kept its counters in the core object and had to inline the stages)
+#define DMC_PROF(id) do { if (lane == 0) { const int t_ = (int)__builtin_readcyclecounter(); SI(prof)[id] += t_ - SI(prof)[33]; SI(prof)[33] = t_; } } while (0)
 #else
 #define DMC_PROF(id) ((void)0)
 #endif
+#ifdef DMC_TRACE_SUB
+#define DMC_TSUB(region, cond, row) do { if (DMC_TRACE_SUB == (region) && (cond)) sub_stamp(row); } while (0)
+#else
+#define DMC_TSUB(region, cond, row) ((void)0)
+#endif
 enum { PROF_LOAD = 0, PROF_KIN, PROF_COM, PROF_CRB, PROF_COLL, PROF_CONSTR, PROF_COMVEL, PROF_RNE, PROF_SENS, PROF_ACT,
        PROF_ACC, PROF_SOL_INIT, PROF_SOL_GRAD, PROF_SOL_LS, PROF_SOL_UPD, PROF_EULER, PROF_TRAIL, PROF_STORE,
-       PROF_NOSLIP, PROF_HESS, PROF_FACTOR, PROF_SOLVE, PROF_LS_SETUP, PROF_N };
+       PROF_NOSLIP, PROF_HESS, PROF_FACTOR, PROF_SOLVE, PROF_LS_SETUP, PROF_X1, PROF_X2, PROF_X3, PROF_X4, PROF_X5, PROF_X6,
+       PROF_X7, PROF_X8, PROF_N };      // X1..X8: movable sub-markers of an investigation
 
 // output selection bits (which derived arrays a launch writes back to HBM)
 enum {
@@ -95,9 +103,10 @@ struct StepIO {
   // launch, written by the step kernel; order[k] = the item handed out k-th, built from it before every launch
   // (order_kernel, dmc_api.hip).  Null: items in index order.
   int* cost; const int* order;
-  // optional wave trace (dmc_batch_wave_trace): a ring of the last 8 launches, (8, 4, nitems) ints; per launch the rows
+  // optional wave trace (dmc_batch_wave_trace): a ring of the last 8 launches, (8, 8, nitems) ints; per launch the rows
   // are the constant-rate clock (100 MHz) at which the item's wave entered the kernel (before the tables are staged),
-  // started and finished the item, and its workgroup index; null: no trace
+  // started and finished the item, its workgroup index, and the clock after the opening position / velocity stage, the
+  // (first) acceleration stage, the (first) integration and the trailing stage of a step launch; null: no trace
   int* trace; int trace_slot;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
@@ -608,9 +617,7 @@ struct StepCore {
   int* si;
   int lane;
   double time_;           // simulation time of this env (group-uniform)
-#ifdef DMC_PROFILE
-  long long prof_[24]; long long prof_last_;
-#endif
+
 
   DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
       : ls(ls_), L(ls_.get()), o(o_), mi(mi_), mr(mr_),
@@ -972,11 +979,13 @@ struct StepCore {
   DMC_DEV void kinematics() {
     for (int i = 1 + lane; i < L.d.nbody; i += LPE) body_local_pose(i);
     DMC_WSYNC();
+    DMC_PROF(PROF_X4);
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int k = a0 + lane; k < a1; k += LPE) body_compose(MI(level_body)[k]);
       DMC_WSYNC();
     }
+    DMC_PROF(PROF_X5);
     FOR_LANES(j, L.d.njnt) {
       const int pid = MI(body_parentid)[MI(jnt_bodyid)[j]];
       if (pid != 0) {
@@ -1103,6 +1112,7 @@ struct StepCore {
       }
       DMC_WSYNC();
     }
+    DMC_PROF(PROF_X1);
     FOR_LANES(i, nv) {
       T buf[6]; mul_inert_vec(buf, S(crb) + 10*MI(dof_bodyid)[i], S(cdof) + 6*i);
       for (int k = 0; k < 6; k++) S(mbuf)[6*i + k] = buf[k];
@@ -1115,6 +1125,7 @@ struct StepCore {
       if (L.d.msparse) qMs()[p] = v; else { S(qM)[i*nv + j] = v; S(qM)[j*nv + i] = v; }
     }
     DMC_WSYNC();
+    DMC_PROF(PROF_X2);
     factor_M(false);
   }
   // contact frames (9 reals per contact): LDS, or the global scratch of a large model
@@ -1172,6 +1183,7 @@ struct StepCore {
   DMC_DEV void factor_M(bool with_damping) {
     T* dst = with_damping ? S(qLH) : M_factor();
     scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
+    DMC_PROF(PROF_X3);
     chol_factor_inplace(dst, L.d.nv);
     if (!with_damping && L.d.jglobal && L.d.nslip) {
       DMC_GLB T* g = (DMC_GLB T*)gLM();
@@ -3295,6 +3307,55 @@ struct StepCore {
       S(qfrc_constraint)[i] = f;
     }
   }
+  // H = M + J' D_active J assembled and factored IN REGISTERS (model-specialised small dense models: dense M, every row
+  // dense, no elliptic cones): lane i builds row i of H -- the rows of J are read as broadcasts, four constraint rows
+  // per trip, accumulated in row order exactly like hess_assemble's entries -- and the factorisation is
+  // chol_factor_rows' on the same registers: no packed-index arithmetic, no trip of H through LDS, no fence between
+  // assembly and factorisation (they were 3 us of a 5 us newton_gradient on the cheetah).
+#ifndef DMC_HOST_EMU
+  template <int N>
+  DMC_DEV void hess_factor_rows(int nefc) {
+    static_assert(N >= 1 && N <= LPE, "one lane per matrix row");
+    const bool own = lane < N;
+    const int i = own ? lane : 0;
+    T a[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0;
+    for (int r = 0; r < nefc; r += 4) {
+      int st[4]; T c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rr = r + u < nefc ? r + u : r;
+        st[u] = r + u < nefc ? SI(efc_active)[rr] : 0;
+        const T ji = S(efc_Jd)[rr*N + i];
+        c[u] = (st[u] == EFC_ST_QUADRATIC && ji != 0 && own) ? S(efc_D)[rr]*ji : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (st[u] != EFC_ST_QUADRATIC) continue;      // group-uniform
+        const int rr = r + u;
+#pragma unroll
+        for (int j = 0; j < N; j++) { const T jj = S(efc_Jd)[rr*N + j]; if (c[u] != 0 && j <= lane) a[j] += c[u] * jj; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      T akk = wave_bcast<LPE>(a[k], k);
+      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+      const T inv = t_rsqrt(akk);
+      const T lik = a[k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }
+      a[k] = lane == k ? inv : lik;
+    }
+    DMC_LDS T* A = (DMC_LDS T*)S(qLH);
+    if (own) {
+#pragma unroll
+      for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
+    }
+    DMC_WSYNC();
+  }
+#endif
   // refactor == 0: the active set is unchanged, so H and its factor (still in qLH)
   // are reused -- identical values, none of the O(nv^3) work
   DMC_DEV void newton_gradient(int nefc, int refactor) {
@@ -3307,6 +3368,18 @@ struct StepCore {
     // (no Hessian is ever assembled, so it is still in place)
     if (L.d.cg) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
+#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_HESS_ROWS)
+    if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
+      if (L.d.jfull && !L.d.msparse && !L.d.elliptic) {
+        DMC_WSYNC();
+        hess_factor_rows<LS::kNV>(nefc);
+        DMC_PROF(PROF_FACTOR);
+        chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+        DMC_PROF(PROF_SOLVE);
+        return;
+      }
+    }
+#endif
     hess_assemble(nefc, row_map());
     DMC_PROF(PROF_HESS);
     chol_factor_inplace(S(qLH), nv);
@@ -3315,20 +3388,48 @@ struct StepCore {
     DMC_PROF(PROF_SOLVE);
   }
   typedef dmc::LSPoint<T> LSPoint;
-  DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals) {
+  // Line search on REGISTER-RESIDENT rows: with at most one constraint row per lane (nefc <= LPE) and only one-sided
+  // quadratic rows, the lane keeps its row's (jar, jv, D) for all evaluations of a search -- an evaluation is a few
+  // VALU ops and three reductions, with no call and no LDS round trip (a Newton iteration of the cheetah spends 3.5-6 us
+  // in its 2-8 dependent evaluations; the launch waits for the wave with the most iterations).  Same arithmetic as
+  // ls_eval_lds for the lane's one row.
+  struct LSRows { T jar, jv, D; bool on; };
+  DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals, const LSRows& rw) {
     if (general_rows()) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
+    if (rw.on) {
+      const T a = p->alpha, jar = rw.jar, jv = rw.jv;
+      T q0 = 0, q1 = 0, q2 = 0;
+      if (ls_relative<T>()) {
+        const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
+        if (act_a | act_0) {
+          const T D = rw.D, dj0 = D*jar;
+          if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+          if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+        }
+      } else if (jar + a*jv < 0) {
+        const T D = rw.D, dj0 = D*jar;
+        q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+      }
+      q0 = group_sum<LPE>(q0) + (ls_relative<T>() ? (T)0 : qg[0]); q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
+      p->cost = a*a*q2 + a*q1 + q0;
+      p->d0 = 2*a*q2 + q1;
+      p->d1 = 2*q2;
+      if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+      (*evals)++;
+      return;
+    }
     const DMC_LSVEC(T) rv = ls_eval_lds<T, LPE>(p->alpha, (const DMC_LDS T*)S(efc_jar), (const DMC_LDS T*)S(efc_jv),
                                                 (const DMC_LDS T*)S(efc_D), ls_relative<T>() ? (T)0 : qg[0], qg[1], qg[2], nefc, lane);
     p->alpha = rv[0]; p->cost = rv[1]; p->d0 = rv[2]; p->d1 = rv[3];
     (*evals)++;
   }
-  DMC_DEV int ls_update_bracket(LSPoint* p, const LSPoint* cand, LSPoint* pnext, const T* qg, int nefc, int* evals) {
+  DMC_DEV int ls_update_bracket(LSPoint* p, const LSPoint* cand, LSPoint* pnext, const T* qg, int nefc, int* evals, const LSRows& rw) {
     int flag = 0;
     for (int i = 0; i < 3; i++) {
       if (p->d0 < 0 && cand[i].d0 < 0 && p->d0 < cand[i].d0) { *p = cand[i]; flag = 1; }
       else if (p->d0 > 0 && cand[i].d0 > 0 && p->d0 > cand[i].d0) { *p = cand[i]; flag = 2; }
     }
-    if (flag) { pnext->alpha = p->alpha - p->d0/p->d1; ls_eval(pnext, qg, nefc, evals); }
+    if (flag) { pnext->alpha = p->alpha - p->d0/p->d1; ls_eval(pnext, qg, nefc, evals, rw); }
     return flag;
   }
   DMC_DEV T primal_search(int nefc, T gauss, T scale, T* lscost) {
@@ -3350,10 +3451,17 @@ struct StepCore {
     const T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
     const int lsmax = o.ls_iterations;
     int evals = 0;
+    LSRows rw = {0, 0, 0, false};
+#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_LS_REGS)
+    if (!general_rows() && nefc <= LPE) {
+      rw.on = true;
+      if (lane < nefc) { rw.jar = S(efc_jar)[lane]; rw.jv = S(efc_jv)[lane]; rw.D = S(efc_D)[lane]; }
+    }
+#endif
     DMC_PROF(PROF_LS_SETUP);
     LSPoint p0, p1, p2, pmid, p1next, p2next;
-    p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals);
-    p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals);
+    p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals, rw);
+    p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals, rw);
     if (p0.cost < p1.cost) p1 = p0;
     if (t_abs(p1.d0) < gtol) { *lscost = p1.cost; return p1.alpha; }
     const int dir = p1.d0 < 0 ? 1 : -1;
@@ -3361,23 +3469,23 @@ struct StepCore {
     p2 = p1;
     while (p1.d0*dir <= -gtol && evals < lsmax) {
       p2 = p1; p2update = 1;
-      p1.alpha -= p1.d0/p1.d1; ls_eval(&p1, qg, nefc, &evals);
+      p1.alpha -= p1.d0/p1.d1; ls_eval(&p1, qg, nefc, &evals, rw);
       if (t_abs(p1.d0) < gtol) { *lscost = p1.cost; return p1.alpha; }
     }
     if (evals >= lsmax) { *lscost = p1.cost; return p1.alpha; }
     if (!p2update) { *lscost = p1.cost; return p1.alpha; }
     p2next = p1;
-    p1next.alpha = p1.alpha - p1.d0/p1.d1; ls_eval(&p1next, qg, nefc, &evals);
+    p1next.alpha = p1.alpha - p1.d0/p1.d1; ls_eval(&p1next, qg, nefc, &evals, rw);
     while (evals < lsmax) {
-      pmid.alpha = (T)0.5*(p1.alpha + p2.alpha); ls_eval(&pmid, qg, nefc, &evals);
+      pmid.alpha = (T)0.5*(p1.alpha + p2.alpha); ls_eval(&pmid, qg, nefc, &evals, rw);
       LSPoint cand[3] = {p1next, p2next, pmid};
       bool found = false; T best_cost = 0, best_alpha = 0;   // first candidate of lowest cost (no dynamic indexing)
       for (int i = 0; i < 3; i++) if (t_abs(cand[i].d0) < gtol && (!found || cand[i].cost < best_cost)) {
         found = true; best_cost = cand[i].cost; best_alpha = cand[i].alpha;
       }
       if (found) { *lscost = best_cost; return best_alpha; }
-      const int b1 = ls_update_bracket(&p1, cand, &p1next, qg, nefc, &evals);
-      const int b2 = ls_update_bracket(&p2, cand, &p2next, qg, nefc, &evals);
+      const int b1 = ls_update_bracket(&p1, cand, &p1next, qg, nefc, &evals, rw);
+      const int b2 = ls_update_bracket(&p2, cand, &p2next, qg, nefc, &evals, rw);
       if (!b1 && !b2) { if (pmid.cost < p0.cost) { *lscost = pmid.cost; return pmid.alpha; } return 0; }
     }
     if (p1.cost <= p2.cost && p1.cost < p0.cost) { *lscost = p1.cost; return p1.alpha; }
@@ -4015,8 +4123,10 @@ struct StepCore {
 #endif
 #endif
       T lscost;
+      DMC_TSUB(3, iter == 0, 4);
       const T alpha = primal_search(nefc, gauss, scale, &lscost);
       DMC_PROF(PROF_SOL_LS);
+      DMC_TSUB(3, iter == 0, 5);
       if (alpha == 0) break;
       FOR_LANES(i, nv) { S(qacc)[i] += alpha*S(sv_search)[i]; S(sv_Ma)[i] += alpha*S(sv_Mv)[i]; }
       for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
@@ -4027,8 +4137,10 @@ struct StepCore {
       gauss = gauss_cost();
       cost = cc + gauss;
       DMC_PROF(PROF_SOL_UPD);
+      DMC_TSUB(3, iter == 0, 6);
       newton_gradient(nefc, changed);
       DMC_PROF(PROF_SOL_GRAD);
+      DMC_TSUB(3, iter == 0, 7);
       T beta = 0;
       if (L.d.cg) {      // Polak-Ribiere, restarted when negative
         T num = 0, den = 0;
@@ -4199,14 +4311,15 @@ struct StepCore {
   // Position + velocity stage (mj_step1 without the checks).  partial = only what
   // the outputs need (the trailing mj_step1 of a legacy Physics.step()).
   DMC_DEV void stage_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) {
-    if (!havekin) { kinematics(); DMC_PROF(PROF_KIN); com_pos(); DMC_PROF(PROF_COM); }
-    if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); }
-    if (!partial || (outmask & (OUT_CONTACT | OUT_CONTACT_IDS))) { collision(); DMC_PROF(PROF_COLL); }
-    if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); }
+    if (!havekin) { kinematics(); DMC_PROF(PROF_KIN); DMC_TSUB(1, partial, 4); com_pos(); DMC_PROF(PROF_COM); DMC_TSUB(1, partial, 5); }
+    if (!partial) { crb_mass_matrix(); DMC_PROF(PROF_CRB); DMC_TSUB(2, true, 4); }
+    if (!partial || (outmask & (OUT_CONTACT | OUT_CONTACT_IDS))) { collision(); DMC_PROF(PROF_COLL); DMC_TSUB(2, !partial, 5); }
+    if (!partial) { make_constraint(); DMC_PROF(PROF_CONSTR); DMC_TSUB(2, true, 6); }
     if (!skipsensor) sensors(DMC_STAGE_POS);
     DMC_PROF(PROF_SENS);
-    if (!havekin) { com_vel(); DMC_PROF(PROF_COMVEL); }
-    if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); }
+    DMC_TSUB(1, partial, 6);
+    if (!havekin) { com_vel(); DMC_PROF(PROF_COMVEL); DMC_TSUB(1, partial, 7); }
+    if (!partial) { passive_and_rne(); DMC_PROF(PROF_RNE); DMC_TSUB(2, true, 7); }
     if (!skipsensor) sensors(DMC_STAGE_VEL);
     DMC_PROF(PROF_SENS);
   }
@@ -4216,15 +4329,38 @@ struct StepCore {
     if (!skipsensor) sensors_acc();
     DMC_PROF(PROF_SENS);
   }
+  // investigation builds (-DDMC_TRACE_SUB=<region>): rows 4..7 of the wave trace are taken INSIDE one region of the
+  // pipeline instead (the stage functions reach StepIO through its LDS copy, which follows StepOpts)
+  DMC_DEV void sub_stamp(int row) {
+#if defined(DMC_TRACE_SUB) && !defined(DMC_HOST_EMU)
+    const StepIO<T>* iop = (const StepIO<T>*)((const unsigned char*)&o + (sizeof(StepOpts<T>) + 15) / 16 * 16);
+    if (iop->trace && (threadIdx.x & 63) == 0) {
+      const int epw = 64 / LPE, nitems = (iop->B + epw - 1) / epw;
+      iop->trace[((size_t)(iop->trace_slot & 7) * 8 + row) * nitems + SI(imisc)[IM_ENV] / epw] = (int)(wall_clock64() & 0x7fffffffll);
+    }
+#else
+    (void)row;
+#endif
+  }
+  // wave trace: stage boundaries of the launch's first pass (rows 4..7 of the ring slot), one stamp per wave
+  DMC_DEV void trace_stamp(const StepIO<T>& io, int env, int row) {
+#if !defined(DMC_HOST_EMU) && !defined(DMC_TRACE_SUB)
+    if (io.trace && (threadIdx.x & 63) == 0) {
+      const int epw = 64 / LPE, nitems = (io.B + epw - 1) / epw;
+      io.trace[((size_t)(io.trace_slot & 7) * 8 + row) * nitems + env / epw] = (int)(wall_clock64() & 0x7fffffffll);
+    }
+#else
+    (void)io; (void)env; (void)row;
+#endif
+  }
   DMC_DEV void prof_begin() {
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
-    for (int k = 0; k < 24; k++) prof_[k] = 0;
-    prof_last_ = (long long)__builtin_readcyclecounter();
+    if (lane == 0) { for (int k = 0; k < 33; k++) SI(prof)[k] = 0; SI(prof)[33] = (int)__builtin_readcyclecounter(); }
 #endif
   }
   DMC_DEV void prof_end(const StepIO<T>& io, int env) {
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
-    if (io.prof && lane == 0) for (int k = 0; k < 24; k++) io.prof[(size_t)k*io.B + env] += prof_[k];
+    if (io.prof && lane == 0) for (int k = 0; k < 32; k++) io.prof[(size_t)k*io.B + env] += SI(prof)[k];
 #else
     (void)io; (void)env;
 #endif
@@ -4232,7 +4368,7 @@ struct StepCore {
   // The three heavy stages are entered through out-of-line functions (StageFns):
   // each gets its own register allocation, so the peak pressure of one stage no
   // longer forces spills in the others, and there is one copy of the code.
-#if !defined(DMC_HOST_EMU) && !defined(DMC_PROFILE) && !defined(DMC_INLINE_STAGES)
+#if !defined(DMC_HOST_EMU) && !defined(DMC_INLINE_STAGES)
   DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) {
     StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
                                  (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0) | (havekin ? 4 : 0), outmask);
@@ -4352,9 +4488,11 @@ struct StepCore {
       int stage = 0, retried = 0;
       while (stage < nstage) {
         if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv, havekin && it == 0 && !retried && !trailing);
+        if (it == 0 && stage == 0) trace_stamp(io, env, 4); else if (trailing) trace_stamp(io, env, 7);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
         if (trailing) break;
         call_acc(mode == 2, stage > 0 || !sens_acc);
+        if (it == 0 && stage == 0) trace_stamp(io, env, 5);
         if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
           if (!(o.disableflags & DMC_DSBL_AUTORESET)) { DMC_WSYNC(); reset_state(); retried = 1; continue; }
@@ -4365,6 +4503,7 @@ struct StepCore {
       }
       if (!stepping || trailing) break;
       if (nstage > 1) rk4_finish(); else call_euler();
+      if (it == 0) trace_stamp(io, env, 6);
       DMC_PROF(PROF_EULER);
     }
     if (!stepping) dump_debug(io, env);

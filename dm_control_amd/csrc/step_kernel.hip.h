@@ -125,7 +125,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const int item = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     const int env = item * epw + (g & (epw - 1));
-    int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 4 * nitems : nullptr;
+    int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 8 * nitems : nullptr;
     if (tr && (threadIdx.x & 63) == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en);
     if (tr && (threadIdx.x & 63) == 0) {

@@ -196,6 +196,11 @@ struct StepDims {
 #define STEP_SCRATCH_ALL_REAL(X) \
   STEP_SCRATCH_REAL(X) STEP_SCRATCH_OVL_POS(X) STEP_SCRATCH_OVL_VEL(X) STEP_SCRATCH_OVL_SOL(X)
 
+#ifdef DMC_PROFILE
+#define DMC_PROF_SLOTS 34
+#else
+#define DMC_PROF_SLOTS 0
+#endif
 // ---- per-environment scratch (ints) --------------------------------------------
 #define STEP_SCRATCH_INT(X)                                                    \
   X(con_geom, d.nconmax)  /* geom1 | geom2 << 16 */                            \
@@ -207,6 +212,7 @@ struct StepDims {
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
   X(ns_blk, d.nslip ? 48 : 0)  /* noslip: per block (<= 16 blocks) start | size << 8 | level << 16 | coupled << 24, tree mask lo, hi */ \
+  X(prof, DMC_PROF_SLOTS)   /* profiling builds: cycle counters per phase + the last time stamp */ \
   X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch

@@ -210,9 +210,10 @@ int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int env, double*
 
 /* Wave trace of the last 8 launches (tuning: the tail of a launch whose environments all run at once is its slowest
  * wave; the time between the launches is what is left of a launch once its waves are accounted for).  dst == NULL:
- * enable / disable.  dst != NULL: copies the ring, (8, 4, nitems) ints -- slot (launch % 8), rows = when the item's
- * wave entered the kernel, started and finished the item on the 100 MHz constant clock (low 31 bits), and its
- * workgroup index; *nitems = ceil(B * lanes_per_env / 64). */
+ * enable / disable.  dst != NULL: copies the ring, (8, 8, nitems) ints -- slot (launch % 8), rows = when the item's
+ * wave entered the kernel, started and finished the item on the 100 MHz constant clock (low 31 bits), its workgroup
+ * index, and the clock after the opening position / velocity stage, the first acceleration stage, the first
+ * integration and the trailing stage of a step launch; *nitems = ceil(B * lanes_per_env / 64). */
 int dmc_batch_wave_trace(dmc_batch* b, int enable, int32_t* dst, int* nitems);
 
 /* Per-phase shader-cycle profile of the fused kernel (libraries built with

@@ -33,7 +33,10 @@ for rep in range(4):
   nc = b.get('ncon')[:, 0].reshape(-1, epw).max(axis=1)
   k = 7
   ent0 = tr[k, 0].min(); dur = tr[k, 2] - tr[k, 1]
-  rec = dict(span=int(tr[k, 2].max() - ent0), period=int(ent0 - tr[k - 1, 0].min()), dur_pct=np.percentile(dur, [0, 10, 50, 90, 99, 100]).tolist(),
+  seg = lambda a, b: (tr[k, b] - tr[k, a]).astype(np.float64)
+  stages = dict(staging=seg(0, 1), posvel_open=tr[k, 4] - tr[k, 1], acc=seg(4, 5), euler=seg(5, 6), posvel_trailing=seg(6, 7), store=tr[k, 2] - tr[k, 7])
+  rec = dict(stage_mean_by_iter={name: {int(v): float(np.mean(x[it == v])) for v in np.unique(it)} for name, x in stages.items()},
+             span=int(tr[k, 2].max() - ent0), period=int(ent0 - tr[k - 1, 0].min()), dur_pct=np.percentile(dur, [0, 10, 50, 90, 99, 100]).tolist(),
              by_iter={int(v): [int((it == v).sum()), float(dur[it == v].mean()), int(dur[it == v].max())] for v in np.unique(it)},
              by_ncon={int(v): [int((nc == v).sum()), float(dur[nc == v].mean()), int(dur[nc == v].max())] for v in np.unique(nc)})
   out.append(rec)
