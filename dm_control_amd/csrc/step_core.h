@@ -1180,8 +1180,51 @@ struct StepCore {
   // Large noslip models (jglobal): factored in qLH, where mj_fwdAcceleration still finds it, and copied to the global
   // scratch, from where the noslip pass brings it back once H's factor is done with qLH.
   DMC_DEV T* M_factor() { return S(qLM); }      // aliases qLH when the model does not run noslip or keeps the copy in global memory
+  // dense M (+ diag) factored straight from its rows: lane i loads row i of qM into registers and runs
+  // chol_factor_rows' elimination there -- no packed copy (scatter_M), no unranking of packed indices, one fence less
+#ifndef DMC_HOST_EMU
+  template <int N>
+  DMC_DEV void factor_dense_rows(const T* diag, T diag_scale, T* dst) {
+    const bool own = lane < N;
+    const int i = own ? lane : 0;
+    T a[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0;
+    if (diag) {
+      const T dv = diag_scale*diag[i];
+#pragma unroll
+      for (int j = 0; j < N; j++) if (own && j == lane) a[j] += dv;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      T akk = wave_bcast<LPE>(a[k], k);
+      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+      const T inv = t_rsqrt(akk);
+      const T lik = a[k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }
+      a[k] = lane == k ? inv : lik;
+    }
+    DMC_LDS T* A = (DMC_LDS T*)dst;
+    if (own) {
+#pragma unroll
+      for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
+    }
+    DMC_WSYNC();
+  }
+#endif
   DMC_DEV void factor_M(bool with_damping) {
     T* dst = with_damping ? S(qLH) : M_factor();
+#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_FACTOR_ROWS)
+    if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
+      if (!L.d.msparse) {
+        factor_dense_rows<LS::kNV>(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
+        DMC_PROF(PROF_X3);
+        if (!with_damping && L.d.jglobal && L.d.nslip) { DMC_GLB T* g = (DMC_GLB T*)gLM(); FOR_LANES(k, L.d.ntri) g[k] = dst[k]; }
+        return;
+      }
+    }
+#endif
     scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
     DMC_PROF(PROF_X3);
     chol_factor_inplace(dst, L.d.nv);
