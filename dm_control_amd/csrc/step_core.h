@@ -1035,6 +1035,19 @@ struct StepCore {
     else { const T sc = MR(body_invsubtreemass)[b]; for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = acc[k] * sc; }
   }
   DMC_DEV void com_pos() {
+#ifndef DMC_NO_SUBTREE_SUMS
+    if (L.d.dfs) {      // subtree centres of mass in one pass over the id ranges of the subtrees (see crb_mass_matrix)
+      FOR_LANES(b, L.d.nbody) {
+        const int e = MI(body_subend)[b];
+        T acc[3] = {0, 0, 0};
+        for (int c = b; c < e; c++) { const T mass = MR(body_mass)[c]; for (int k = 0; k < 3; k++) acc[k] += S(xipos)[3*c + k] * mass; }
+        if (MR(body_subtreemass)[b] < (T)DMC_MINVAL) for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = S(xipos)[3*b + k];
+        else { const T sc = MR(body_invsubtreemass)[b]; for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = acc[k] * sc; }
+      }
+      DMC_WSYNC();
+    } else
+#endif
+    {
     for (int lev = L.d.nlevel - 1; lev >= 0; lev--) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int k = a0 + lane; k < a1; k += LPE) subtree_com_body(MI(level_body)[k]);
@@ -1042,6 +1055,7 @@ struct StepCore {
     }
     if (lane == 0) subtree_com_body(0);
     DMC_WSYNC();
+    }
     for (int i = 1 + lane; i < L.d.nbody; i += LPE) {
       T off[3], ci[10]; const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
       for (int k = 0; k < 3; k++) off[k] = S(xipos)[3*i + k] - rc[k];
@@ -1097,6 +1111,21 @@ struct StepCore {
   // ---- CRB mass matrix + factor (mj_crb, mj_factorM) ----------------------------
   DMC_DEV void crb_mass_matrix() {
     const int nv = L.d.nv;
+#ifndef DMC_NO_SUBTREE_SUMS
+    if (L.d.dfs) {
+      // composite inertias as ONE pass of subtree sums: bodies are numbered depth first, so the subtree of b is the id range
+      // [b, subend[b]) -- every (body, component) sums its range with independent loads, instead of nlevel dependent
+      // child-accumulation passes (each a chain of five LDS reads).  Same terms as the level passes, summed in id order.
+      for (int idx = 10 + lane; idx < 10*L.d.nbody; idx += LPE) {
+        const int b = idx / 10, comp = idx - 10*b, e = MI(body_subend)[b];
+        T v = S(cinert)[idx];
+        for (int c = b + 1; c < e; c++) v += S(cinert)[10*c + comp];
+        S(crb)[idx] = v;
+      }
+      DMC_WSYNC();
+    } else
+#endif
+    {
     for (int i = 10 + lane; i < 10*L.d.nbody; i += LPE) S(crb)[i] = S(cinert)[i];
     DMC_WSYNC();
     for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
@@ -1111,6 +1140,7 @@ struct StepCore {
         }
       }
       DMC_WSYNC();
+    }
     }
     DMC_PROF(PROF_X1);
     FOR_LANES(i, nv) {

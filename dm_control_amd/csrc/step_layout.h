@@ -53,6 +53,7 @@ struct StepDims {
   int sitegl;    // 1 (nsite > 32): the real site tables (pos, quat, size) stay in global memory (StepOpts::g_mr) -- composed
                  //   scenes carry render-only sites (soccer: 120 hoarding boards of 136 sites) that only an output
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
+  int dfs;       // 1: bodies are numbered depth first (a subtree is the contiguous range [b, body_subend[b])): subtree sums in one pass
   int ntree;     // kinematic trees with at least one dof (M^-1 is block diagonal over them: noslip blocks of different trees are independent)
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
@@ -77,6 +78,7 @@ struct StepDims {
   X(body_parentid, d.nbody) X(body_rootid, d.nbody) X(body_jntadr, d.nbody)    \
   X(body_jntnum, d.nbody) X(body_dofadr, d.nbody) X(body_dofnum, d.nbody)      \
   X(body_lastdof, d.nbody)     /* last dof on the path root->body, or -1 */    \
+  X(body_subend, d.dfs ? d.nbody : 0)   /* 1 + last body of the subtree below a body (depth-first numbering) */ \
   X(body_mocapid, d.nmocap ? d.nbody : 0)   /* row of mocap_pos / mocap_quat, -1: not a mocap body */ \
   X(body_anc_lo, d.nstv ? d.nbody : 0) X(body_anc_hi, d.nstv ? d.nbody : 0) /* ancestor-or-self bodies */ \
   X(stv_sensor, d.nstv)        /* the subtreelinvel sensors */                 \

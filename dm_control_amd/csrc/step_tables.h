@@ -137,6 +137,14 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   int nlevel = 0;
   for (int b = 1; b < m.nbody; b++) { depth[b] = depth[m.body_parentid[b]] + 1; nlevel = std::max(nlevel, depth[b]); }
   d.nlevel = nlevel; d.nchild = std::max(0, m.nbody - 1);
+  std::vector<int> subend(m.nbody, 0);
+  {      // depth-first numbering: every subtree is a contiguous range of body ids
+    std::vector<int> cnt(m.nbody, 1);
+    for (int b = 0; b < m.nbody; b++) subend[b] = b + 1;
+    for (int b = m.nbody - 1; b >= 1; b--) { const int p = m.body_parentid[b]; cnt[p] += cnt[b]; subend[p] = std::max(subend[p], subend[b]); }
+    d.dfs = 1;
+    for (int b = 0; b < m.nbody; b++) if (subend[b] - b != cnt[b]) d.dfs = 0;
+  }
   { std::vector<int> seen(m.nbody, 0); d.ntree = 0; for (int i = 0; i < m.nv; i++) { const int r = m.body_rootid[m.dof_bodyid[i]]; if (!seen[r]) { seen[r] = 1; d.ntree++; } } }
   // M sparsity
   std::vector<int> mp_i, mp_j;
@@ -281,6 +289,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     }
     cpi(L.mi_body_lastdof, last);
   }
+  if (d.dfs) cpi(L.mi_body_subend, subend);
   {
     int* la = mi + L.mi_level_adr; int* lb = mi + L.mi_level_body;
     int k = 0;
