@@ -2371,6 +2371,39 @@ struct StepCore {
       if (!(o.disableflags & DMC_DSBL_GRAVITY)) { ca[3] = -o.gravity[0]; ca[4] = -o.gravity[1]; ca[5] = -o.gravity[2]; }
     }
     DMC_WSYNC();
+#ifndef DMC_NO_SUBTREE_SUMS
+    if (L.d.dfs && L.d.nv <= 64) {
+      // RNE without a pass per tree level: a body's acceleration is the sum of cdof_dot * qvel over the dofs on its path
+      // (the ancestor mask of its last dof, ascending = root first), so every body evaluates its own chain and its
+      // inertial force in ONE pass; the bias force of dof i is cdof_i . (sum of those forces over the subtree of its
+      // body = an id range, depth-first numbering), evaluated by the dof's lane in a second one.
+      FOR_LANES(i, L.d.nbody) {
+        if (i == 0) continue;
+        T ca[6], cf[6], tmp[6], tmp1[6];
+        for (int a = 0; a < 6; a++) ca[a] = S(cacc)[a];
+        const int ld = MI(body_lastdof)[i];
+        if (ld >= 0) {
+          unsigned lo = (unsigned)MI(dof_anc_lo)[ld], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[ld] : 0u;
+          while (lo) { const int k = __builtin_ctz(lo); lo &= lo - 1; const T v = S(qvel)[k]; const T* cd = S(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
+          while (hi) { const int k = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[k]; const T* cd = S(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
+        }
+        for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = ca[a];
+        mul_inert_vec(cf, S(cinert) + 10*i, ca);
+        mul_inert_vec(tmp, S(cinert) + 10*i, S(cvel) + 6*i);
+        cross_force(tmp1, S(cvel) + 6*i, tmp);
+        for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = cf[a] + tmp1[a];
+      }
+      DMC_WSYNC();
+      FOR_LANES(i, nv) {
+        const int b = MI(dof_bodyid)[i], e = MI(body_subend)[b];
+        T f[6] = {0, 0, 0, 0, 0, 0};
+        for (int c = b; c < e; c++) for (int a = 0; a < 6; a++) f[a] += S(cfrc)[6*c + a];
+        S(qfrc_bias)[i] = dot_n(S(cdof) + 6*i, f, 6);
+      }
+      DMC_WSYNC();
+      return;
+    }
+#endif
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int kk = a0 + lane; kk < a1; kk += LPE) {
@@ -3320,6 +3353,17 @@ struct StepCore {
       for (int k = 0; k < 6; k++) bf[6*b + k] = f[k];
     }
     DMC_WSYNC();
+#ifndef DMC_NO_SUBTREE_SUMS
+    if (L.d.dfs) {      // B + C in one pass: the dof's lane sums the inertial forces over the subtree of its body (an id range)
+      FOR_LANES(i, nv) {
+        const int b = MI(dof_bodyid)[i], e = MI(body_subend)[b];
+        T f[6] = {0, 0, 0, 0, 0, 0};
+        for (int c = b; c < e; c++) for (int a = 0; a < 6; a++) f[a] += bf[6*c + a];
+        res[i] = dot_n(S(cdof) + 6*i, f, 6) + MR(dof_armature)[i]*v[i];
+      }
+      return;
+    }
+#endif
     for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
       const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
       for (int idx = lane; idx < cnt*6; idx += LPE) {
