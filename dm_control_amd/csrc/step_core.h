@@ -956,8 +956,36 @@ struct StepCore {
         }
       }
     }
+    if (flat_kin()) { T* lp = S(crb) + 10*i; for (int k = 0; k < 3; k++) lp[k] = p[k]; for (int k = 0; k < 4; k++) lp[3 + k] = q[k]; return; }
     for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
     for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+  }
+  // Poses composed along each body's own chain instead of one fenced pass per tree depth: the local poses are parked
+  // in the (still unused) composite-inertia buffer, every body walks up its ancestors (world = local_root o ... o
+  // local_body) with independent loads; results differ from the level passes by rounding only.
+  DMC_DEV bool flat_kin() const {
+#ifdef DMC_NO_FLAT_CHAINS
+    return false;
+#else
+    return true;
+#endif
+  }
+  DMC_DEV void body_compose_chain(int i) {
+    T p[3], q[4], m[9];
+    { const T* lp = S(crb) + 10*i; for (int k = 0; k < 3; k++) p[k] = lp[k]; for (int k = 0; k < 4; k++) q[k] = lp[3 + k]; }
+    for (int a = MI(body_parentid)[i]; a != 0; a = MI(body_parentid)[a]) {
+      const T* lp = S(crb) + 10*a;
+      T qa[4] = {lp[3], lp[4], lp[5], lp[6]}, r[3], qq[4];
+      rot_vec_quat(r, p, qa);
+      for (int k = 0; k < 3; k++) p[k] = lp[k] + r[k];
+      mul_quat(qq, qa, q);
+      for (int k = 0; k < 4; k++) q[k] = qq[k];
+    }
+    normalize4(q);
+    quat2mat(m, q);
+    for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
+    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+    for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = m[k];
   }
   DMC_DEV void body_compose(int i) {
     const int pid = MI(body_parentid)[i];
@@ -980,6 +1008,10 @@ struct StepCore {
     for (int i = 1 + lane; i < L.d.nbody; i += LPE) body_local_pose(i);
     DMC_WSYNC();
     DMC_PROF(PROF_X4);
+    if (flat_kin()) {
+      for (int i = 1 + lane; i < L.d.nbody; i += LPE) body_compose_chain(i);
+      DMC_WSYNC();
+    } else
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int k = a0 + lane; k < a1; k += LPE) body_compose(MI(level_body)[k]);
@@ -2279,6 +2311,42 @@ struct StepCore {
     for (int a = 0; a < 6; a++) S(cvel)[6*i + a] = cvel[a];
   }
   DMC_DEV void com_vel() {
+#ifndef DMC_NO_FLAT_CHAINS
+    if (L.d.nv <= 64) {
+      // mj_comVel without a pass per tree level: the velocity a dof sees (cdof_dot = cvel x cdof) is the sum of
+      // cdof * qvel over the dofs BEFORE it on its path -- before its whole triple for the rotational dofs of a ball /
+      // free joint, nothing for a free joint's translations -- and a body's velocity the sum over its whole path (the
+      // ancestor mask of its last dof, ascending = the order the body-by-body recursion adds them in).
+      const int nv = L.d.nv;
+      FOR_LANES(k, nv) {
+        const int j = MI(dof_jntid)[k], t = MI(jnt_type)[j], da = MI(jnt_dofadr)[j];
+        T cdd[6] = {0, 0, 0, 0, 0, 0};
+        if (!(t == DMC_JNT_FREE && k < da + 3)) {
+          const int start = t == DMC_JNT_FREE ? da + 3 : (t == DMC_JNT_BALL ? da : k);
+          unsigned lo = (unsigned)MI(dof_anc_lo)[k], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[k] : 0u;
+          if (start < 32) { lo &= (1u << start) - 1u; hi = 0; } else if (start < 64) hi &= (1u << (start - 32)) - 1u;
+          T cv[6] = {0, 0, 0, 0, 0, 0};
+          while (lo) { const int m = __builtin_ctz(lo); lo &= lo - 1; const T v = S(qvel)[m]; const T* cd = S(cdof) + 6*m; for (int a = 0; a < 6; a++) cv[a] += cd[a]*v; }
+          while (hi) { const int m = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[m]; const T* cd = S(cdof) + 6*m; for (int a = 0; a < 6; a++) cv[a] += cd[a]*v; }
+          cross_motion(cdd, cv, S(cdof) + 6*k);
+        }
+        for (int a = 0; a < 6; a++) S(cdof_dot)[6*k + a] = cdd[a];
+      }
+      FOR_LANES(i, L.d.nbody) {
+        if (i == 0) continue;
+        T cv[6] = {0, 0, 0, 0, 0, 0};
+        const int ld = MI(body_lastdof)[i];
+        if (ld >= 0) {
+          unsigned lo = (unsigned)MI(dof_anc_lo)[ld], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[ld] : 0u;
+          while (lo) { const int m = __builtin_ctz(lo); lo &= lo - 1; const T v = S(qvel)[m]; const T* cd = S(cdof) + 6*m; for (int a = 0; a < 6; a++) cv[a] += cd[a]*v; }
+          while (hi) { const int m = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[m]; const T* cd = S(cdof) + 6*m; for (int a = 0; a < 6; a++) cv[a] += cd[a]*v; }
+        }
+        for (int a = 0; a < 6; a++) S(cvel)[6*i + a] = cv[a];
+      }
+      DMC_WSYNC();
+      return;
+    }
+#endif
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int k = a0 + lane; k < a1; k += LPE) body_com_vel(MI(level_body)[k]);
