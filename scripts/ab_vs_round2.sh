@@ -1,3 +1,4 @@
+# A/B against the round-2 library on ONE box: needs a worktree of the round-2 commit built in _r02/ (git worktree add _r02 45da38f; build there)
 cd "$GRAFT_REPO_ROOT"
 show() { python -c "
 import json,sys
