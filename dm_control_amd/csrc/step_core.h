@@ -3980,16 +3980,36 @@ struct StepCore {
     for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
     const T dinv = own ? Lm[ci] : (T)0;
     T* A = ns_A(); const int cap = L.d.nslip;
+    // M (and its factor) is block diagonal over the kinematic trees: a friction row only has entries in the dofs of its
+    // contact's trees, so the substitutions only need the steps from the first of those dofs to the end of the last
+    // tree (forward) and back to the start of the first (backward) -- the skipped steps would multiply exact zeros.
+    // One environment per wave only (the bounds must be wave-uniform).
+    int t_start = 0, t_end = N;
+    if (LPE == 64 && L.d.ntree > 1 && own) {
+      const unsigned lo = (unsigned)MI(dof_anc_lo)[i], hi = N > 32 ? (unsigned)MI(dof_anc_hi)[i] : 0u;
+      t_start = lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);      // root dof of the lane's tree
+      t_end = MI(dof_subend)[t_start];
+    }
     for (int b = 0; b < nf; b++) {
       T sreg = own ? row_entry(SI(ns_row)[b], i, rm) : (T)0;
+      int kf = 0, kb = 0, ke = N;
+      if (LPE == 64 && L.d.ntree > 1) {
+        const unsigned long long nz = __ballot(sreg != 0);
+        if (nz) {
+          const int first = __builtin_ctzll(nz), last = 63 - __builtin_clzll(nz);
+          kf = first; kb = __builtin_amdgcn_readlane(t_start, first); ke = __builtin_amdgcn_readlane(t_end, last);
+        } else { kf = N; kb = N; ke = 0; }
+      }
 #pragma unroll
       for (int k = 0; k < N; k++) {
+        if (k < kf || k >= ke) continue;
         const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
         if (i == k) sreg = xk;
         if (i > k && own) sreg -= row[k]*xk;
       }
 #pragma unroll
       for (int k = N - 1; k >= 0; k--) {
+        if (k < kb || k >= ke) continue;
         const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
         if (i == k) sreg = xk;
         if (i < k) sreg -= col[k]*xk;
