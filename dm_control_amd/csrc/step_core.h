@@ -3578,9 +3578,114 @@ struct StepCore {
   // VALU ops and three reductions, with no call and no LDS round trip (a Newton iteration of the cheetah spends 3.5-6 us
   // in its 2-8 dependent evaluations; the launch waits for the wave with the most iterations).  Same arithmetic as
   // ls_eval_lds for the lane's one row.
-  struct LSRows { T jar, jv, D; bool on; };
+  // The same for the general row types (equalities, dof friction loss, elliptic contacts): `kind` says what the lane's row
+  // is; the first row of a frictional contact carries the contact's alpha-independent aggregates (ls_prepare_ell's,
+  // computed into registers instead of being parked in LDS), its zone at alpha = 0 and the middle-zone scale; the
+  // contact's other rows carry nothing.  An evaluation of the soccer / 62-dof models was a chain of LDS look-ups (row
+  // type -> contact -> first row -> nine aggregates) per row before the arithmetic started: 22 % / 14 % of their step.
+  enum { LSK_NONE = 0, LSK_EQUALITY, LSK_FRICTION, LSK_ONESIDED, LSK_CONE };
+  struct LSRows { T jar, jv, D; bool on; bool gen; int kind; T f, rf, U0, V0, UU, UV, VV, mu, b0, b1, b2, Dm, NT0; bool bottom0, middle0; };
+  DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
+    g.gen = true; g.kind = LSK_NONE;
+    g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = 0; g.bottom0 = g.middle0 = false;
+    const int i = lane;
+    if (i >= nefc) return;
+    const int tid = SI(efc_tid)[i], ty = EFC_TYPE(tid);
+    g.jar = S(efc_jar)[i]; g.jv = S(efc_jv)[i]; g.D = S(efc_D)[i];
+    if (ty == EFC_EQUALITY) { g.kind = LSK_EQUALITY; return; }
+    if (ty == EFC_FRICTION) { g.kind = LSK_FRICTION; g.f = MR(dof_frictionloss)[EFC_ID(tid)]; g.rf = g.f / g.D; return; }
+    if (ty != EFC_ELLIPTIC) { g.kind = LSK_ONESIDED; return; }
+    const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
+    if (i != r0) return;
+    g.kind = LSK_CONE;
+    const int dim = con_dim(c);
+    const T* fr = MR(prm_friction) + 3*con_prm(c);
+    const T D0 = g.D;
+    const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);
+    T UU = 0, UV = 0, VV = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int j = 0; j < dim; j++) {
+      const T jar = S(efc_jar)[r0 + j], jv = S(efc_jv)[r0 + j], D = S(efc_D)[r0 + j], dj0 = D*jar;
+      b0 += (T)0.5*jar*dj0; b1 += jv*dj0; b2 += (T)0.5*D*jv*jv;
+      if (j) {
+        const T f = fr[j < 3 ? 0 : (j == 3 ? 1 : 2)];
+        const T u = jar*f, v = jv*f;
+        UU += u*u; UV += u*v; VV += v*v;
+      }
+    }
+    g.U0 = g.jar*mu; g.V0 = g.jv*mu; g.UU = UU; g.UV = UV; g.VV = VV; g.mu = mu; g.b0 = b0; g.b1 = b1; g.b2 = b2;
+    g.Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
+    if (UU <= 0) g.bottom0 = g.U0 < 0;      // the contact's zone at alpha = 0 (relative form)
+    else {
+      const T T0 = t_sqrt(UU);
+      if (g.U0 >= mu*T0) {}
+      else if (mu*g.U0 + T0 <= 0) g.bottom0 = true;
+      else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; }
+    }
+  }
+  // ls_eval_ell's arithmetic for the lane's one row
+  DMC_DEV void ls_eval_gen(LSPoint* p, const T* qg, const LSRows& g) {
+    const T a = p->alpha;
+    constexpr bool rel = ls_relative<T>();
+    T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
+    if (g.kind == LSK_EQUALITY) {
+      const T dj0 = g.D*g.jar;
+      if (!rel) q0 += (T)0.5*g.jar*dj0;
+      q1 += g.jv*dj0; q2 += (T)0.5*g.D*g.jv*g.jv;
+    } else if (g.kind == LSK_FRICTION) {
+      const T jar = g.jar, jv = g.jv, D = g.D, f = g.f, rf = g.rf, x = jar + a*jv;
+      if (x <= -rf) { q0 += f*((T)-0.5*rf - jar); q1 += -f*jv; }
+      else if (x >= rf) { q0 += f*((T)-0.5*rf + jar); q1 += f*jv; }
+      else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+      if (rel) {
+        if (jar <= -rf) q0 -= f*((T)-0.5*rf - jar);
+        else if (jar >= rf) q0 -= f*((T)-0.5*rf + jar);
+        else q0 -= (T)0.5*jar*D*jar;
+      }
+    } else if (g.kind == LSK_ONESIDED) {
+      const T jar = g.jar, jv = g.jv;
+      if (rel) {
+        const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
+        if (act_a | act_0) {
+          const T D = g.D, dj0 = D*jar;
+          if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+          if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+        }
+      } else if (jar + a*jv < 0) { const T D = g.D, dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+    } else if (g.kind == LSK_CONE) {
+      const T U0 = g.U0, V0 = g.V0, UU = g.UU, UV = g.UV, VV = g.VV, mu = g.mu, Dm = g.Dm;
+      const T N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
+      bool bottom = false, middle = false;
+      T NT = 0;
+      if (Tsqr <= 0) bottom = N < 0;
+      else {
+        const T Tn = t_sqrt(Tsqr);
+        if (N >= mu*Tn) {}
+        else if (mu*N + Tn <= 0) bottom = true;
+        else {
+          middle = true;
+          const T N1 = V0, T1 = (UV + a*VV)/Tn, T2 = VV/Tn - (UV + a*VV)*T1/(Tn*Tn);
+          const T NT1 = N1 - mu*T1;
+          NT = N - mu*Tn;
+          if (!rel) cc += (T)0.5*Dm*NT*NT;
+          cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+        }
+      }
+      if (!rel) { if (bottom) { q0 += g.b0; q1 += g.b1; q2 += g.b2; } }
+      else {
+        if (bottom) { q1 += g.b1; q2 += g.b2; if (!g.bottom0) q0 += g.b0; }
+        else if (g.bottom0) q0 -= g.b0;
+        if (middle | g.middle0) cc += (T)0.5*Dm*(NT - g.NT0)*(NT + g.NT0);
+      }
+    }
+    q0 = group_sum<LPE>(q0) + (rel ? (T)0 : qg[0]); q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
+    cc = group_sum<LPE>(cc); cd0 = group_sum<LPE>(cd0); cd1 = group_sum<LPE>(cd1);
+    p->cost = a*a*q2 + a*q1 + q0 + cc;
+    p->d0 = 2*a*q2 + q1 + cd0;
+    p->d1 = 2*q2 + cd1;
+    if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
+  }
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals, const LSRows& rw) {
-    if (general_rows()) { ls_eval_ell(p, qg, nefc); (*evals)++; return; }
+    if (general_rows()) { if (rw.gen) ls_eval_gen(p, qg, rw); else ls_eval_ell(p, qg, nefc); (*evals)++; return; }
     if (rw.on) {
       const T a = p->alpha, jar = rw.jar, jv = rw.jv;
       T q0 = 0, q1 = 0, q2 = 0;
@@ -3623,7 +3728,12 @@ struct StepCore {
     mul_M(S(sv_Mv), S(sv_search));
     { const RowMap rm = row_map(); for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = row_dot(i, S(sv_search), rm); }
     DMC_WSYNC();
-    if (L.d.elliptic) ls_prepare_ell(nefc);
+    LSRows rw;
+    rw.jar = rw.jv = rw.D = 0; rw.on = false; rw.gen = false; rw.kind = LSK_NONE;
+#if !defined(DMC_NO_LS_REGS)
+    if (general_rows() && nefc <= LPE && LPE > 1) ls_load_gen(rw, nefc);
+#endif
+    if (L.d.elliptic && !rw.gen) ls_prepare_ell(nefc);
     T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     FOR_LANES(i, nv) {
       const T sr = S(sv_search)[i];
@@ -3636,7 +3746,6 @@ struct StepCore {
     const T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
     const int lsmax = o.ls_iterations;
     int evals = 0;
-    LSRows rw = {0, 0, 0, false};
 #if !defined(DMC_HOST_EMU) && !defined(DMC_NO_LS_REGS)
     if (!general_rows() && nefc <= LPE) {
       rw.on = true;
@@ -3936,11 +4045,22 @@ struct StepCore {
     S(efc_jar)[k] = change;
   }
   // sweep of all blocks by levels; returns the sum of the blocks' cost changes, accumulated in block order
-  DMC_DEV T noslip_sweep_levels(int nf, int nb, int nlev) {
+  // fp32: a block WITHOUT a partner is at the exact optimum of its own QCQP after the first sweep -- no other block's
+  // forces enter its rows of the residual -- and a later sweep would only re-derive the same forces from a residual that
+  // differs by the rounding of its own update (1e-7 relative: the noise floor of the fp32 path); such blocks are solved
+  // once.  fp64 re-solves them every sweep, operation for operation as the oracle does (noslip_tolerance = 0 models run
+  // all their sweeps).
+  DMC_DEV T noslip_sweep_levels(int nf, int nb, int nlev, bool first) {
+#if defined(DMC_EXACT_QCQP) || defined(DMC_NS_RESWEEP_ALL)
+    constexpr bool once = false;
+#else
+    constexpr bool once = sizeof(T) == 4;
+#endif
     for (int lev = 1; lev <= nlev; lev++) {
       FOR_LANES(k, nb) {
         const int d = SI(ns_blk)[k];
         if (((d >> 16) & 0xff) != lev) continue;
+        if (once && !first && !(d >> 24)) { S(efc_jar)[k] = 0; continue; }
         const int a = d & 0xff, n = (d >> 8) & 0xff;
         const int tid = SI(efc_tid)[SI(ns_row)[a]], t = EFC_TYPE(tid), id = EFC_ID(tid);
         if (n == 1) noslip_block_lane<1>(a, t, id, k);
@@ -4020,6 +4140,88 @@ struct StepCore {
       DMC_WSYNC();
     }
   }
+  // The same with one LANE PER FRICTION ROW (at most 64 rows, small nv): lane b keeps row b of J_F and solves
+  // M x = J_b' in its own registers -- the entries of the factor are wave-uniform LDS reads, every FMA works for all rows
+  // at once -- then A[a][b] = J_a . x_b with J_a's entries read across lanes.  The per-row version above is a chain of
+  // 2 N dependent cross-lane steps plus a global-memory round trip PER ROW (12 % of the soccer step for ~10 rows); this
+  // one is ~N^2 FMAs for all rows together.  Operation for operation the same sums (the skipped products are exact zeros).
+  template <int N>
+  DMC_DEV void noslip_build_A_lanes(const DMC_LDS T* Lm_, int nf, const RowMap& rm) {
+    const int b = lane;
+    const bool own = b < nf;
+    const int rb = SI(ns_row)[own ? b : 0];
+    T jd[N], x[N];
+    // row b of J_F as N dense entries, branch-free (all loads in flight together): a friction row is a dof-friction row
+    // (one nonzero) or a contact row (compressed to the dofs of its mask); all-dense models read their dense row
+    if (L.d.jfull) {
+#pragma unroll
+      for (int k = 0; k < N; k++) jd[k] = own ? S(efc_Jd)[rb*N + k] : (T)0;
+    } else {
+      const int tid = SI(efc_tid)[rb];
+      const bool con = rb >= rm.c0;
+      const int c = con ? EFC_ID(tid) : 0;
+      const unsigned mask = !own ? 0u : (con ? con_mask_lo(c) : (1u << simple_dof(tid)));
+      const T one = con ? (T)0 : simple_sign(tid);
+      const auto jr = Jc() + (con ? rb - rm.c0 : 0)*L.d.kmax;
+      const int last = L.d.kmax - 1;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        const int sl = __builtin_popcount(mask & ((1u << k) - 1u));
+        const T v = jr[sl < last ? sl : last];
+        jd[k] = ((mask >> k) & 1u) ? (con ? v : one) : (T)0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) x[k] = jd[k];
+    // The next column's entries are requested before the current one is used.  The loads go through a volatile pointer
+    // and every updated value is pinned (an empty asm) at the end of its column: the updates carry no side effect, and
+    // without the pins instruction selection emits all N^2 / 2 loads of a sweep first and the updates last -- the loaded
+    // factor then lives in scratch memory.
+#define DMC_PIN(v) asm volatile("" : "+v"(v))
+    const volatile DMC_LDS T* Lm = Lm_;
+    T cur[N], nxt[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { cur[i] = Lm[i]; nxt[i] = 0; }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      if (k + 1 < N) {
+        const int cn = tri_c0(k + 1, N);
+#pragma unroll
+        for (int i = k + 1; i < N; i++) nxt[i] = Lm[cn + i - (k + 1)];
+      }
+      const T xk = x[k] * cur[k];
+      x[k] = xk;
+#pragma unroll
+      for (int i = k + 1; i < N; i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
+#pragma unroll
+      for (int i = 0; i < N; i++) cur[i] = nxt[i];
+    }
+    // back substitution: step k needs 1 / L[k][k] and row k of L (entries (k, i), i < k)
+#pragma unroll
+    for (int i = 0; i < N; i++) cur[i] = Lm[tri_c0(i, N) + (N - 1) - i];
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < k; i++) nxt[i] = Lm[tri_c0(i, N) + (k - 1) - i];
+      }
+      const T xk = x[k] * cur[k];
+      x[k] = xk;
+#pragma unroll
+      for (int i = 0; i < k; i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
+#pragma unroll
+      for (int i = 0; i < N; i++) cur[i] = nxt[i];
+    }
+#undef DMC_PIN
+    T* A = ns_A(); const int cap = L.d.nslip;
+    for (int a = 0; a < nf; a++) {
+      T v = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) v += wave_bcast<LPE>(jd[k], a) * x[k];
+      if (own && a >= b) { A[b*cap + a] = v; A[a*cap + b] = v; }
+    }
+    DMC_WSYNC();
+  }
 #endif
   DMC_DEV void noslip(int nefc) {
     const int nv = L.d.nv, cap = L.d.nslip;
@@ -4043,7 +4245,16 @@ struct StepCore {
     const RowMap rm = row_map();
     bool built = false;
 #ifndef DMC_HOST_EMU
-    if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { noslip_build_A_rows<LS::kNV>((const DMC_LDS T*)M_factor(), nf, rm); built = true; }
+#ifndef DMC_NO_NS_LANES
+    // (out of line: its own register allocation -- inside the acceleration stage its 2 N live values spilled)
+    if constexpr (LS::kNV > 0 && LS::kNV <= 32 && LPE == 64) {
+      if (nf <= LPE) {
+        StageFns<T, LPE, LS>::ns_build(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s, (DMC_LDS int*)si, lane, nf);
+        built = true;
+      }
+    }
+#endif
+    if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { if (!built) { noslip_build_A_rows<LS::kNV>((const DMC_LDS T*)M_factor(), nf, rm); built = true; } }
 #endif
     if (!built) for (int b = 0; b < nf; b++) {
       const int rb = SI(ns_row)[b];
@@ -4054,6 +4265,7 @@ struct StepCore {
         for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
     }
+    DMC_PROF(PROF_X6);
     for (int a = lane; a < nf; a += LPE) { const int ra = SI(ns_row)[a]; S(ns_res)[a] = row_dot(ra, S(qacc), rm) - S(efc_aref)[ra]; }
     DMC_WSYNC();
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
@@ -4070,7 +4282,7 @@ struct StepCore {
         for (int i = lane; i < nefc; i += LPE) { const T f = S(efc_force)[i]; improvement += (T)0.5*f*f / S(efc_D)[i]; }
         improvement = group_sum<LPE>(improvement);
       }
-      if (nblk) improvement -= noslip_sweep_levels(nf, nblk, nlev);
+      if (nblk) improvement -= noslip_sweep_levels(nf, nblk, nlev, iter == 0);
       else for (int a = 0; a < nf; ) {
         const int i = SI(ns_row)[a], tid = SI(efc_tid)[i], t = EFC_TYPE(tid), id = EFC_ID(tid);
         int n = 1;
@@ -4088,6 +4300,7 @@ struct StepCore {
       iter++;
       if (improvement < o.noslip_tolerance) break;
     }
+    DMC_PROF(PROF_X7);
     constraint_force_to_joint(nefc);
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
@@ -4744,6 +4957,13 @@ struct StageFns {
                          DMC_LDS int* si, int lane, int flags) {
     Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
     c.stage_acc(flags & 1, flags & 2);
+  }
+  static DMC_FN void ns_build(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
+                              DMC_LDS int* si, int lane, int nf) {
+    if constexpr (LS::kNV > 0 && LS::kNV <= 32 && LPE == 64) {
+      Core c(ls, *(const StepOpts<T>*)o, (const int*)mi, (const T*)mr, gc, (T*)s, (int*)si, lane);
+      c.template noslip_build_A_lanes<LS::kNV>((const DMC_LDS T*)c.M_factor(), nf, c.row_map());
+    }
   }
   static DMC_FN void euler(LS ls, const DMC_LDS StepOpts<T>* o, DMC_LDS int* mi, DMC_LDS T* mr, const int* gc, DMC_LDS T* s,
                            DMC_LDS int* si, int lane) {
