@@ -82,6 +82,7 @@ class Task:
 
   physics_timestep = 0.005
   control_timestep = 0.025
+  restarting = None      # set by Environment.step: (B,) mask of the environments re-initialised in this call
 
   @property
   def entities(self):
@@ -257,7 +258,15 @@ class Environment:
     # and the SAME launch that steps the others runs mj_forward with actuation disabled for these (env_mode 1).
     self._initialize(first)
     p.field('env_mode').copy_(first[None, :].to(torch.int32))
+    # The reference returns reset() for such an environment without calling before_step / get_reward / after_step
+    # (environment.py:412-420): its ctrl is mj_resetData's zero, not the discarded action, and the task's carried
+    # counters do not see this call (`task.restarting`: the mask of environments being re-initialised).
+    task = self.task
+    task.restarting = first
     self._hooks.before_step(p, action, self._rs)
+    ctrl = p.field('ctrl')
+    if ctrl.numel():
+      ctrl.copy_(torch.where(first[None, :], torch.zeros_like(ctrl), ctrl))
     if self.fused:
       # no substep hook (or fusion forced): the substep hooks, if any, see the control step as ONE substep
       self._hooks.before_substep(p, action, self._rs)
@@ -271,7 +280,6 @@ class Environment:
         self.launches += 1
         self._hooks.after_substep(p, self._rs)
     self._hooks.after_step(p, self._rs)
-    task = self.task
     reward = task.get_reward(p)
     discount = task.get_discount(p)
     # ANY new mjWARN_* since the last look = PhysicsError in the reference (engine.py:345-368 compares the warning

@@ -192,7 +192,9 @@ class GoToTarget(environment.Task):
     distance = torch.linalg.norm(self._target - root, dim=0)
     hit = distance < self._distance_tolerance
     if self._moving_target:
-      self._reward_steps += hit.to(torch.int32)
+      restarting = getattr(self, 'restarting', None)      # environments re-initialised in this call: no reward step
+      counted = hit if restarting is None else hit & ~restarting
+      self._reward_steps += counted.to(torch.int32)
     return hit.to(physics.dtype)
 
   # -- observations --------------------------------------------------------------------------------------

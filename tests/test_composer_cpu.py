@@ -90,6 +90,10 @@ def test_time_limit_auto_reset_per_environment():
   np.testing.assert_array_equal(phys.field('qpos')[:, 1].numpy(), m.qpos0)          # re-initialised, not stepped
   assert float(phys.field('time')[0, 1]) == 0.0
   assert not np.array_equal(phys.field('qpos')[:, 0].numpy(), q_before[:, 0].numpy())
+  # the reference returns reset() for it without the step hooks (environment.py:412-420): the discarded action
+  # does not reach its ctrl, and the task is told which environments are restarting
+  assert phys.field('ctrl')[:, 1].abs().max() == 0 and float(phys.field('ctrl')[0, 0]) == 0.3
+  assert task.restarting.tolist() == [False, True, False]
   ts = env.step(a)
   assert ts.step_type.tolist() == [environment.FIRST, environment.MID, environment.FIRST]
 
