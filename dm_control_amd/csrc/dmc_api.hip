@@ -798,13 +798,18 @@ extern "C" int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyfra
   if (reset_real("qacc_warmstart", nullptr, m.nv)) return -2;
   if (reset_real("qfrc_applied", nullptr, m.nv)) return -2;
   if (b->xfrc_on && reset_real("xfrc_applied", nullptr, 6*m.nbody)) return -2;
-  if (reset_real("time", nullptr, 1)) return -2;
-  if (reset_real("act", nullptr, m.na)) return -2;
+  // mj_resetDataKeyframe restores time, the activations and the mocap poses of the keyframe as well
+  if (reset_real("time", keyframe >= 0 ? &m.key_time[keyframe] : nullptr, 1)) return -2;
+  if (reset_real("act", keyframe >= 0 && m.na ? &m.key_act[(size_t)keyframe * m.na] : nullptr, m.na)) return -2;
   if (m.nmocap) {      // mj_resetData: the mocap poses start at the bodies' model poses
     std::vector<double> mp(3 * (size_t)m.nmocap), mq(4 * (size_t)m.nmocap);
     for (int i = 0; i < m.nbody; i++) if (m.body_mocapid[i] >= 0) {
       for (int k = 0; k < 3; k++) mp[3*m.body_mocapid[i] + k] = m.body_pos[3*i + k];
       for (int k = 0; k < 4; k++) mq[4*m.body_mocapid[i] + k] = m.body_quat[4*i + k];
+    }
+    if (keyframe >= 0) {
+      std::copy(m.key_mpos.begin() + (size_t)keyframe * 3 * m.nmocap, m.key_mpos.begin() + (size_t)(keyframe + 1) * 3 * m.nmocap, mp.begin());
+      std::copy(m.key_mquat.begin() + (size_t)keyframe * 4 * m.nmocap, m.key_mquat.begin() + (size_t)(keyframe + 1) * 4 * m.nmocap, mq.begin());
     }
     if (reset_real("mocap_pos", mp.data(), 3*m.nmocap)) return -2;
     if (reset_real("mocap_quat", mq.data(), 4*m.nmocap)) return -2;

@@ -4625,6 +4625,7 @@ struct StepCore {
         const int k = MI(act_adr)[i];
         if (fl & ACTF_DYN_FILTEREXACT) { const T tau = t_max((T)DMC_MINVAL, MR(act_dynprm)[i]); S(act)[k] += S(act_dot)[k] * tau * (1 - t_exp(-dt/tau)); }
         else S(act)[k] += dt*S(act_dot)[k];
+        if (fl & ACTF_ACTLIMITED) S(act)[k] = t_max(MRC(act_actrange)[2*i], t_min(MRC(act_actrange)[2*i + 1], S(act)[k]));   // mj_nextActivation
       }
     }
     if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {

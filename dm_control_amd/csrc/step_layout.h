@@ -144,7 +144,8 @@ struct StepDims {
   X(jnt_solimp, 5 * d.njnt)                                                    \
   X(geom_pos, 3 * d.ngeom) X(geom_quat, 4 * d.ngeom)                           \
   X(act_gear, d.nu) X(act_ctrlrange, 2 * d.nu) X(act_forcerange, 2 * d.nu)     \
-  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)
+  X(act_gainprm, 3 * d.nu) X(act_biasprm, 3 * d.nu)                             \
+  X(act_actrange, d.na ? 2 * d.nu : 0)   /* clamp of the advanced activation (ACTF_ACTLIMITED) */
 // site tables: hot (LDS) for ordinary models, behind the cold tables and left in global memory when StepDims::sitegl
 #define STEP_MODEL_SITE_REAL_TABLES(X)                                         \
   X(site_pos, 3 * d.nsite) X(site_quat, 4 * d.nsite) X(site_size, 3 * d.nsite)
@@ -226,7 +227,8 @@ enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
        ACTF_TENDON = 16 /* act_dof holds a fixed-tendon id */,
-       ACTF_DYN_INTEGRATOR = 32, ACTF_DYN_FILTER = 64, ACTF_DYN_FILTEREXACT = 128, ACTF_DYN_ANY = 32 | 64 | 128 };
+       ACTF_DYN_INTEGRATOR = 32, ACTF_DYN_FILTER = 64, ACTF_DYN_FILTEREXACT = 128, ACTF_DYN_ANY = 32 | 64 | 128,
+       ACTF_ACTLIMITED = 256 /* mj_nextActivation clamps the advanced activation to act_actrange */ };
 // EFC_LIMIT rows carry id = (dof << 1) | upper_side
 enum { EFC_LIMIT = 0, EFC_FRICTIONLESS = 1, EFC_PYRAMIDAL = 2, EFC_ELLIPTIC = 3, EFC_FRICTION = 4, EFC_TENDON_LIMIT = 5, EFC_EQUALITY = 6 };
 enum { EFC_ST_SATISFIED = 0, EFC_ST_QUADRATIC = 1, EFC_ST_CONE = 2, EFC_ST_LINEARNEG = 3, EFC_ST_LINEARPOS = 4 };   /* efc_active values */

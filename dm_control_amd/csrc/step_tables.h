@@ -45,8 +45,8 @@ inline bool host_model_parse(HostModel* m, const int32_t* ints, int nints, const
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
-  (void)ntendon; (void)nwrap; (void)neq; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
+  const int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq, na = m->na, nmocap = m->nmocap;
+  (void)na; (void)nmocap; (void)ntendon; (void)nwrap; (void)neq; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)nsensor; (void)npair; (void)nkey;
 #define X(n, c) { long cnt = (c); if (cnt < 0 || !need_i(cnt)) { *err = "model blob truncated"; return false; } m->n.assign(ints + ip, ints + ip + cnt); ip += cnt; }
   DMC_MODEL_INT_FIELDS(X)
 #undef X
@@ -345,7 +345,14 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.actuator_dyntype[i] == DMC_DYN_INTEGRATOR) fl |= ACTF_DYN_INTEGRATOR;
     else if (m.actuator_dyntype[i] == DMC_DYN_FILTER) fl |= ACTF_DYN_FILTER;
     else if (m.actuator_dyntype[i] == DMC_DYN_FILTEREXACT) fl |= ACTF_DYN_FILTEREXACT;
-    if (d.na) { mi[L.mi_act_adr + i] = (fl & ACTF_DYN_ANY) ? nact++ : -1; mr[L.mr_act_dynprm + i] = m.actuator_dynprm[10*i]; }
+    if (m.actuator_actlimited[i]) {
+      if (!(fl & ACTF_DYN_ANY)) { *err = "actlimited on an actuator without activation dynamics"; return false; }
+      fl |= ACTF_ACTLIMITED;
+    }
+    if (d.na) {
+      mi[L.mi_act_adr + i] = (fl & ACTF_DYN_ANY) ? nact++ : -1; mr[L.mr_act_dynprm + i] = m.actuator_dynprm[10*i];
+      mr[L.mr_act_actrange + 2*i] = m.actuator_actrange[2*i]; mr[L.mr_act_actrange + 2*i + 1] = m.actuator_actrange[2*i + 1];
+    }
     mi[L.mi_act_flags + i] = fl;
     mr[L.mr_act_gear + i] = m.actuator_gear[6*i];
     for (int k = 0; k < 2; k++) { mr[L.mr_act_ctrlrange + 2*i + k] = m.actuator_ctrlrange[2*i + k]; mr[L.mr_act_forcerange + 2*i + k] = m.actuator_forcerange[2*i + k]; }

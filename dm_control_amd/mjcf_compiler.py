@@ -1065,6 +1065,8 @@ class _Compiler:
     m.actuator_trnid = np.full((nu, 2), -1, dtype=np.int64)
     m.actuator_ctrllimited = np.zeros(nu, dtype=np.int64)
     m.actuator_forcelimited = np.zeros(nu, dtype=np.int64)
+    m.actuator_actlimited = np.zeros(nu, dtype=np.int64)
+    m.actuator_actrange = np.zeros((nu, 2))
     m.actuator_gear = np.zeros((nu, 6))
     m.actuator_ctrlrange = np.zeros((nu, 2))
     m.actuator_forcerange = np.zeros((nu, 2))
@@ -1216,8 +1218,8 @@ class _Compiler:
       if dyn not in ('none', 'integrator', 'filter', 'filterexact'):
         raise MjcfError('actuator dyntype %r is not supported' % dyn)
       m.actuator_dyntype[i] = {'none': 0, 'integrator': 1, 'filter': 2, 'filterexact': 3}[dyn]
-      if a.get('actlimited', 'false') == 'true' or (a.get('actlimited', 'auto') == 'auto' and self.autolimits and 'actrange' in a):
-        raise MjcfError('actuator %r: actlimited / actrange is not supported' % a.get('name'))
+      if a.get('actearly', 'false') == 'true':
+        raise MjcfError('actuator %r: actearly is not supported' % a.get('name'))
       m.actuator_gaintype[i] = {'fixed': 0, 'affine': 1}[a.get('gaintype', 'fixed')]
       m.actuator_biastype[i] = {'none': 0, 'affine': 1}[a.get('biastype', 'none')]
       g = _vec(a.get('gear', '1'))
@@ -1231,12 +1233,18 @@ class _Compiler:
         dp = _vec(a['dynprm'])
         m.actuator_dynprm[i, :dp.size] = dp
       for key, lim, rng in (('ctrl', m.actuator_ctrllimited, m.actuator_ctrlrange),
-                            ('force', m.actuator_forcelimited, m.actuator_forcerange)):
+                            ('force', m.actuator_forcelimited, m.actuator_forcerange),
+                            ('act', m.actuator_actlimited, m.actuator_actrange)):
         has = (key + 'range') in a
         if has:
           rng[i] = _vec(a[key + 'range'], 2)
         flag = a.get(key + 'limited', 'auto')
         lim[i] = int((self.autolimits and has) if flag == 'auto' else flag == 'true')
+      if m.actuator_actlimited[i]:
+        if m.actuator_dyntype[i] == 0:
+          raise MjcfError('actuator %r: actlimited needs a dyntype (the actuator has no activation state)' % a.get('name'))
+        if not m.actuator_actrange[i, 0] < m.actuator_actrange[i, 1]:
+          raise MjcfError('actuator %r: actrange[0] must be < actrange[1]' % a.get('name'))
     m.names['actuator'] = names
     # one activation state per actuator with dynamics, in actuator order (mjModel.actuator_actadr)
     m.na = int(np.count_nonzero(m.actuator_dyntype))
@@ -1341,6 +1349,13 @@ class _Compiler:
     m.key_qpos = np.tile(m.qpos0, (nkey, 1)).reshape(nkey, m.nq)
     m.key_qvel = np.zeros((nkey, m.nv))
     m.key_ctrl = np.zeros((nkey, m.nu))
+    # the rest of what mj_resetDataKeyframe restores: time, activations, mocap poses (default: the model's body poses)
+    m.key_time = np.zeros(nkey)
+    m.key_act = np.zeros((nkey, m.na))
+    mocap_bodies = [b for b in range(m.nbody) if m.body_mocapid[b] >= 0]
+    mocap_bodies.sort(key=lambda b: m.body_mocapid[b])
+    m.key_mpos = np.tile(m.body_pos[mocap_bodies].reshape(-1), (nkey, 1)).reshape(nkey, 3 * m.nmocap)
+    m.key_mquat = np.tile(m.body_quat[mocap_bodies].reshape(-1), (nkey, 1)).reshape(nkey, 4 * m.nmocap)
     names = []
     for i, k in enumerate(self.keys):
       names.append(k.get('name'))
@@ -1350,15 +1365,15 @@ class _Compiler:
         m.key_qvel[i] = _vec(k['qvel'], m.nv)
       if 'ctrl' in k:
         m.key_ctrl[i] = _vec(k['ctrl'], m.nu)
-      # mj_resetDataKeyframe also restores key_time and key_act; the batch reset zeroes both, so a keyframe that
-      # asks for anything else is refused instead of silently resetting to the wrong activation state / time
-      if 'time' in k and float(k['time']) != 0.0:
-        raise MjcfError('keyframe %r: a non-zero `time` is not supported' % k.get('name'))
-      if 'act' in k and np.any(np.asarray(_vec(k['act'], m.na) if m.na else [float(x) for x in k['act'].split()]) != 0):
-        raise MjcfError('keyframe %r: non-zero `act` is not supported' % k.get('name'))
-      for unsupported in ('mpos', 'mquat'):
-        if unsupported in k:
-          raise MjcfError('keyframe %r: mocap data (`%s`) is not supported' % (k.get('name'), unsupported))
+      if 'time' in k:
+        m.key_time[i] = float(k['time'])
+      if 'act' in k:
+        m.key_act[i] = _vec(k['act'], m.na)
+      if 'mpos' in k:
+        m.key_mpos[i] = _vec(k['mpos'], 3 * m.nmocap)
+      if 'mquat' in k:
+        q = _vec(k['mquat'], 4 * m.nmocap).reshape(m.nmocap, 4)
+        m.key_mquat[i] = (q / np.linalg.norm(q, axis=1, keepdims=True)).reshape(-1)
     m.names['key'] = names
 
   # -- constants evaluated at qpos0 -------------------------------------------

@@ -79,7 +79,9 @@ int dmc_batch_step2(dmc_batch* b, void* hip_stream);
 int dmc_batch_forward(dmc_batch* b, int disable_actuation, void* hip_stream);
 
 /* Replaces mujoco.mj_resetData / mj_resetDataKeyframe (engine.py:318,323) for the
- * envs whose mask byte is non-zero (mask == NULL: all).  keyframe < 0: qpos0. */
+ * envs whose mask byte is non-zero (mask == NULL: all).  keyframe < 0: qpos0, zero velocities / controls /
+ * activations / time, mocap poses from the model; keyframe >= 0: key_qpos, key_qvel, key_ctrl, key_time, key_act,
+ * key_mpos, key_mquat of that keyframe. */
 int dmc_batch_reset(dmc_batch* b, const uint8_t* env_mask, int keyframe);
 
 /* Field access by mjData name ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "time",

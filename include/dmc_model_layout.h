@@ -18,7 +18,7 @@
 #define DMC_MODEL_LAYOUT_H_
 
 #define DMC_MODEL_MAGIC   0x444D4331  /* 'DMC1' */
-#define DMC_MODEL_VERSION 11
+#define DMC_MODEL_VERSION 12
 
 /* ---- header ints (sizes, then options) --------------------------------- */
 #define DMC_MODEL_HEADER_INTS(X) \
@@ -49,6 +49,7 @@
   X(actuator_trntype, nu) X(actuator_dyntype, nu) X(actuator_gaintype, nu) \
   X(actuator_biastype, nu) X(actuator_trnid, 2*nu) \
   X(actuator_ctrllimited, nu) X(actuator_forcelimited, nu) \
+  X(actuator_actlimited, nu)   /* activation clamped to actuator_actrange when it is advanced (mj_nextActivation) */ \
   X(sensor_type, nsensor) X(sensor_objtype, nsensor) X(sensor_objid, nsensor) \
   X(sensor_adr, nsensor) X(sensor_dim, nsensor) X(sensor_needstage, nsensor) \
   X(sensor_reftype, nsensor) X(sensor_refid, nsensor)   /* reference frame of frame{pos,quat,?axis} sensors (mjtObj, id); refid = -1: world */ \
@@ -75,14 +76,15 @@
   X(geom_rbound, ngeom) \
   X(site_size, 3*nsite) X(site_pos, 3*nsite) X(site_quat, 4*nsite) \
   X(actuator_gear, 6*nu) X(actuator_ctrlrange, 2*nu) \
-  X(actuator_forcerange, 2*nu) X(actuator_gainprm, 10*nu) \
+  X(actuator_forcerange, 2*nu) X(actuator_actrange, 2*nu) X(actuator_gainprm, 10*nu) \
   X(actuator_biasprm, 10*nu) X(actuator_dynprm, 10*nu) \
   X(sensor_cutoff, nsensor) X(wrap_prm, nwrap) \
   X(tendon_stiffness, ntendon) X(tendon_damping, ntendon) X(tendon_lengthspring, ntendon) \
   X(tendon_range, 2*ntendon) X(tendon_margin, ntendon) X(tendon_solref_lim, 2*ntendon) \
   X(tendon_solimp_lim, 5*ntendon) X(tendon_invweight0, ntendon) X(tendon_length0, ntendon) \
   X(eq_solref, 2*neq) X(eq_solimp, 5*neq) X(eq_data, 11*neq) /* mjModel.eq_data rows: connect anchor1(3) anchor2(3); weld anchor2(3) anchor1(3) relquat(4) torquescale; joint / tendon polycoef(5) */ \
-  X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey)
+  X(key_qpos, nq*nkey) X(key_qvel, nv*nkey) X(key_ctrl, nu*nkey) \
+  X(key_time, nkey) X(key_act, na*nkey) X(key_mpos, 3*nmocap*nkey) X(key_mquat, 4*nmocap*nkey)   /* the rest of mj_resetDataKeyframe (engine.py:323) */
 
 /* ---- enums (values follow MuJoCo's mjt* enums as the reference re-exports
  * them, dm_control/mujoco/__init__.py:26; only the subset in use) ---------- */

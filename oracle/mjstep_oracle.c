@@ -279,8 +279,8 @@ Model* ora_model_create(const int32_t* ints, int nints, const double* reals, int
   DMC_MODEL_HEADER_REALS(X)
 #undef X
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
-  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq, na = m->na, nmocap = m->nmocap;
+  (void)na; (void)nmocap; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
   (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) m->n = m->ibuf + ip; ip += (c);
   DMC_MODEL_INT_FIELDS(X)
@@ -310,8 +310,8 @@ double ora_model_opt_real(Model* m, const char* name, int set, double value) {
 }
 int* ora_model_int_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
-  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq, na = m->na, nmocap = m->nmocap;
+  (void)na; (void)nmocap; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
   (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_INT_FIELDS(X)
@@ -320,8 +320,8 @@ int* ora_model_int_field(Model* m, const char* name, int* count) {
 }
 double* ora_model_real_field(Model* m, const char* name, int* count) {
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom;
-  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq;
-  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
+  int nsite = m->nsite, nsensor = m->nsensor, npair = m->npair, nkey = m->nkey, ntendon = m->ntendon, nwrap = m->nwrap, neq = m->neq, na = m->na, nmocap = m->nmocap;
+  (void)na; (void)nmocap; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite;
   (void)nsensor; (void)npair; (void)nkey; (void)ntendon; (void)nwrap; (void)neq;
 #define X(n, c) if (!strcmp(name, #n)) { *count = (c); return m->n; }
   DMC_MODEL_REAL_FIELDS(X)
@@ -442,6 +442,10 @@ void ora_reset(const Model* m, Data* d, int key) {
     memcpy(d->qpos, m->key_qpos + (size_t)key*m->nq, sizeof(double) * (size_t)m->nq);
     memcpy(d->qvel, m->key_qvel + (size_t)key*m->nv, sizeof(double) * (size_t)m->nv);
     memcpy(d->ctrl, m->key_ctrl + (size_t)key*m->nu, sizeof(double) * (size_t)m->nu);
+    d->time = m->key_time[key];
+    memcpy(d->act, m->key_act + (size_t)key*m->na, sizeof(double) * (size_t)m->na);
+    memcpy(d->mocap_pos, m->key_mpos + (size_t)key*3*m->nmocap, sizeof(double) * 3 * (size_t)m->nmocap);
+    memcpy(d->mocap_quat, m->key_mquat + (size_t)key*4*m->nmocap, sizeof(double) * 4 * (size_t)m->nmocap);
   }
 }
 
@@ -2533,6 +2537,8 @@ static void advance(const Model* m, Data* d, const double* qacc, const double* q
       const double tau = mjMAX(MINVAL, m->actuator_dynprm[10*i]);
       d->act[k] += d->act_dot[k] * tau * (1 - exp(-dt/tau));
     } else d->act[k] += dt*d->act_dot[k];
+    /* mj_nextActivation: the advanced activation is clamped to actrange */
+    if (m->actuator_actlimited[i]) d->act[k] = mjMAX(m->actuator_actrange[2*i], mjMIN(m->actuator_actrange[2*i+1], d->act[k]));
     k++;
   }
   for (int i = 0; i < m->nv; i++) d->qvel[i] += dt*qacc[i];
