@@ -2,6 +2,7 @@
 include/dmc_batch.h declares; compute entry points fail loudly without a GPU."""
 import os
 import re
+import sys
 
 import pytest
 
@@ -83,3 +84,29 @@ def test_hot_kernel_keeps_its_locals_out_of_scratch(tmp_path):
   bench_kernel = [k for k in sizes if 'step_kernel_staticIfLi32ELi0ELb0' in k]      # (no claim loop: the batch fits the grid)
   assert bench_kernel, sorted(sizes)[:5]
   assert int(sizes[bench_kernel[0]]) <= 32, sizes[bench_kernel[0]]
+
+
+def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
+  """Every model-specialised fp32 instantiation (configs 2-5 run these): no spilled VGPR, and the private segment no
+  larger than what it is made of today -- the callee-saved registers the out-of-line stage functions save ONCE per
+  physics step in their prologue (acc: 90 dwords for the 62-dof model) and the dynamically indexed polygon / support
+  arrays of the box-box / ellipsoid narrow phases in the position stage, touched only when such a pair is in range
+  (per-function figures: `hipcc -S`, `; ScratchSize`).  The helpers on the solver's inner loops (chol_factor_rows,
+  chol_solve_rows, ls_eval_*) keep at most 20 bytes."""
+  sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+  import kernel_resources
+  from dm_control_amd import build
+  build.build()
+  ks = kernel_resources.kernels(os.path.join(build.CSRC, 'step_kernels_f32.o'))
+  bound = {0: 32, 1: 64, 2: 640, 3: 32, 4: 32, 5: 260, 6: 400, 7: 736}      # static id -> bytes per lane
+  seen = set()
+  for name, r in ks.items():
+    m = re.search(r'step_kernel_staticIfLi(\d+)ELi(\d+)ELb([01])', name)
+    if not m:
+      continue
+    sid = int(m.group(2))
+    seen.add(sid)
+    assert r['vgpr_spill'] == 0, (name, r)
+    assert r['scratch'] <= bound[sid], (name, r)
+    assert r['vgpr'] <= 256
+  assert seen == set(bound)
