@@ -212,15 +212,27 @@ inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
   }
 #define DMC_LAUNCH_STATIC(LPE, SID) { if (io.work) DMC_LAUNCH_STATIC_Q(LPE, SID, true) else DMC_LAUNCH_STATIC_Q(LPE, SID, false) }
 #if DMC_NSTATIC > 0
-  // specialised instantiations exist for (static id, lanes) pairs listed in DMC_STATIC_INSTANCES
+  // specialised instantiations exist for (static id, lanes) pairs listed in DMC_STATIC_INSTANCES; the fp32 ones are
+  // split over two compilation units (build.py: the large models are scheduled with a different strategy)
+#if defined(DMC_UNIT_ILP)
+#define DMC_UNIT_INSTANCES(X) DMC_STATIC_INSTANCES_ILP(X)
+#elif defined(DMC_UNIT_STD)
+#define DMC_UNIT_INSTANCES(X) DMC_STATIC_INSTANCES_STD(X)
+#else
+#define DMC_UNIT_INSTANCES(X) DMC_STATIC_INSTANCES(X)
+#endif
 #define DMC_X(SID, LPE) if (g.static_id == SID && g.lpe == LPE) DMC_LAUNCH_STATIC(LPE, SID)
-  DMC_STATIC_INSTANCES(DMC_X)
+  DMC_UNIT_INSTANCES(DMC_X)
 #undef DMC_X
 #endif
+#if defined(DMC_UNIT_ILP)
+  return hipErrorInvalidValue;      // (this unit holds no generic kernel)
+#else
   if (g.lpe == 64) DMC_LAUNCH(64)
   else if (g.lpe == 32) DMC_LAUNCH(32)
   else if (g.lpe == 16) DMC_LAUNCH(16)
   else return hipErrorInvalidValue;
+#endif
 #undef DMC_LAUNCH
 #undef DMC_LAUNCH_STATIC
 #undef DMC_LAUNCH_Q

@@ -38,7 +38,7 @@ def short(name):
 
 
 if __name__ == '__main__':
-  for unit in sys.argv[1:] or ['step_kernels_f32.o', 'step_kernels_f64.o']:
+  for unit in sys.argv[1:] or ['step_kernels_f32.o', 'step_kernels_f32_ilp.o', 'step_kernels_f64.o']:
     ks = kernels(os.path.join(CSRC, unit))
     print(unit)
     for n in sorted(ks, key=short):

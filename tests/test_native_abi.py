@@ -98,6 +98,10 @@ def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
   from dm_control_amd import build
   build.build()
   ks = kernel_resources.kernels(os.path.join(build.CSRC, 'step_kernels_f32.o'))
+  ilp = kernel_resources.kernels(os.path.join(build.CSRC, 'step_kernels_f32_ilp.o'))      # the large models' unit
+  assert ilp and not set(ilp) & set(ks)
+  assert all(re.search(r'step_kernel_staticIfLi64ELi[567]ELb', n) for n in ilp), sorted(ilp)
+  ks.update(ilp)
   bound = {0: 32, 1: 64, 2: 640, 3: 32, 4: 32, 5: 260, 6: 400, 7: 736}      # static id -> bytes per lane
   seen = set()
   for name, r in ks.items():
