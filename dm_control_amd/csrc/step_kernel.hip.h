@@ -188,8 +188,11 @@ step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restr
 }
 #endif
 
+// (internal linkage: the fp32 units instantiate launch_step_t<float> with DIFFERENT instance lists -- as an inline
+// function with external linkage the linker would keep one body for both, and the large models would silently run the
+// generic kernel: 3x slower, same results)
 template <typename T>
-inline hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<T>& o,
+static hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<T>& o,
                                 const int* g_mi, const T* g_mr, const int* g_mc, const StepIO<T>& io, int nstep, int legacy, int mode, int outmask, int nsub) {
   const dim3 grid(g.grid), block(g.waves * 64);
 #define DMC_LAUNCH_Q(LPE, Q)                                                                                    \

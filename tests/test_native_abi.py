@@ -100,6 +100,13 @@ def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
   ks = kernel_resources.kernels(os.path.join(build.CSRC, 'step_kernels_f32.o'))
   ilp = kernel_resources.kernels(os.path.join(build.CSRC, 'step_kernels_f32_ilp.o'))      # the large models' unit
   assert ilp and not set(ilp) & set(ks)
+  # the two units must not share a host symbol with different bodies (launch_step_t<float> once was a weak symbol in
+  # both: the linker kept the small-model unit's, and configs 4 / 5 ran the generic kernel)
+  import subprocess
+  def weak(obj):
+    out = subprocess.run(['nm', '-C', os.path.join(build.CSRC, obj)], capture_output=True, text=True).stdout
+    return {l.split(' ', 2)[2] for l in out.splitlines() if l[17:18] == 'W' and '__device_stub__' not in l}
+  assert not weak('step_kernels_f32.o') & weak('step_kernels_f32_ilp.o')
   assert all(re.search(r'step_kernel_staticIfLi64ELi[567]ELb', n) for n in ilp), sorted(ilp)
   ks.update(ilp)
   bound = {0: 32, 1: 64, 2: 640, 3: 32, 4: 32, 5: 260, 6: 400, 7: 736}      # static id -> bytes per lane
