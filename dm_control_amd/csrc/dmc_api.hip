@@ -758,6 +758,10 @@ extern "C" int dmc_batch_set_model_real(dmc_batch* b, const char* name, const do
       {"actuator_forcerange", L.mr_act_forcerange, 2 * d.nu, 1, 1},
       {"wrap_prm", L.mr_wrap_prm, d.nwrap, 1, 1},
       {"body_pos", L.mr_body_pos, 3 * d.nbody, 1, 1}, {"body_quat", L.mr_body_quat, 4 * d.nbody, 1, 1},
+      // geom frames / sizes (suite/reacher.py:88-94, suite/fish.py:150-154 move and resize their target geom); like a
+      // write to mjModel, nothing derived at compile time follows (body inertias, geom_rbound, contact-pair mixing)
+      {"geom_pos", L.mr_geom_pos, 3 * d.ngeom, 1, 1}, {"geom_quat", L.mr_geom_quat, 4 * d.ngeom, 1, 1},
+      {"geom_size", L.mr_geom_size, 3 * d.ngeom, 1, 1},
   };
   for (const Slot& s : slots) {
     if (strcmp(name, s.name)) continue;

@@ -80,6 +80,11 @@ def _vec(s, n=None):
   return v
 
 
+def _rgba(a):
+  v = _vec(a.get('rgba', '0.5 0.5 0.5 1'))
+  return v if v.size == 4 else np.array([0.5, 0.5, 0.5, 1.0])
+
+
 def quat_mul(a, b):
   return np.array([
       a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3],
@@ -354,6 +359,7 @@ class _Compiler:
     self.joints = []
     self.geoms = []
     self.sites = []
+    self.lights = []
     self.actuators = []
     self.sensors = []
     self.excludes = []
@@ -574,7 +580,13 @@ class _Compiler:
         self._parse_geom(child, bid, childclass)
       elif tag == 'site':
         self._parse_site(child, bid, childclass)
-      elif tag in ('camera', 'light'):
+      elif tag == 'light':
+        # rendering only: kept as host-side model arrays because tasks move lights (light_pos, suite/swimmer.py)
+        a = dict(self.classes[child.attrib.get('class', childclass) or 'main'].get('light') or {})
+        a.update(child.attrib)
+        self.lights.append(dict(name=a.get('name'), body=bid, pos=_vec(a['pos'], 3) if 'pos' in a else np.zeros(3),
+                                dir=_vec(a['dir'], 3) if 'dir' in a else np.array([0.0, 0, -1])))
+      elif tag == 'camera':
         pass  # rendering only
       elif tag == 'body':
         pass  # handled below so that this body's elements get ids first
@@ -681,11 +693,11 @@ class _Compiler:
         solimp=_solimp(a.get('solimp', '0.9 0.95 0.001 0.5 2')),
         margin=float(a.get('margin', 0)), gap=float(a.get('gap', 0)),
         mass=mass, inertia=inertia)
+    g['rgba'] = _rgba(a)
     if a.get('material') in getattr(self, 'material_alpha', {}):
       g['invisible'] = int(self.material_alpha[a['material']] == 0)
     else:
-      rgba = _vec(a.get('rgba', '0.5 0.5 0.5 1'))
-      g['invisible'] = int(rgba.size == 4 and rgba[3] == 0)
+      g['invisible'] = int(g['rgba'][3] == 0)
     if g['condim'] not in (1, 3, 4, 6):
       raise MjcfError('geom condim must be 1, 3, 4 or 6')
     self.bodies[bid]['geoms'].append(len(self.geoms))
@@ -707,7 +719,7 @@ class _Compiler:
       pos = 0.5 * (ft[:3] + ft[3:])
       quat = z_to_quat(vec)
     self.sites.append(dict(name=a.get('name'), type=stype, body=bid, size=size,
-                           pos=pos, quat=quat))
+                           pos=pos, quat=quat, rgba=_rgba(a)))
 
   # -- actuators / sensors / contact / keyframes --------------------------------
   def _parse_actuators(self):
@@ -818,10 +830,12 @@ class _Compiler:
         wb.append(c)
     # material alpha: rays (rangefinder sensors) skip invisible geoms (rgba alpha 0, or a material with alpha 0)
     self.material_alpha = {}
+    self.materials = []
     for asset in self.root.findall('asset'):
       for mat in asset.findall('material'):
         rgba = _vec(mat.get('rgba', '1 1 1 1'))
         self.material_alpha[mat.get('name')] = float(rgba[3]) if rgba.size == 4 else 1.0
+        self.materials.append((mat.get('name'), rgba if rgba.size == 4 else np.ones(4)))
     self._parse_body(wb, -1, None)
     self._parse_actuators()
     self._parse_tendons()
@@ -973,6 +987,16 @@ class _Compiler:
     m.site_type = np.array([s['type'] for s in self.sites], dtype=np.int64)
     m.site_size = np.array([s['size'] for s in self.sites]).reshape(nsite, 3)
     m.site_pos = np.array([s['pos'] for s in self.sites]).reshape(nsite, 3)
+    # rendering attributes tasks write (suite/finger.py site_rgba, suite/fish.py geom_rgba, suite/swimmer.py light_pos,
+    # suite/base.py mat_rgba): host-side arrays of the facade, never sent to the device
+    m.site_rgba = np.array([s['rgba'] for s in self.sites], dtype=np.float64).reshape(nsite, 4)
+    m.geom_rgba = np.array([g['rgba'] for g in self.geoms], dtype=np.float64).reshape(len(self.geoms), 4)
+    m.nlight = len(self.lights)
+    m.light_bodyid = np.array([l['body'] for l in self.lights], dtype=np.int64)
+    m.light_pos = np.array([l['pos'] for l in self.lights], dtype=np.float64).reshape(m.nlight, 3)
+    m.light_dir = np.array([l['dir'] for l in self.lights], dtype=np.float64).reshape(m.nlight, 3)
+    m.nmat = len(self.materials)
+    m.mat_rgba = np.array([r for _, r in self.materials], dtype=np.float64).reshape(m.nmat, 4)
     m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(nsite, 4)
     # inertial properties
     self._body_inertias(m)
@@ -982,6 +1006,8 @@ class _Compiler:
         'joint': [j['name'] for j in self.joints],
         'geom': [g['name'] for g in self.geoms],
         'site': [s['name'] for s in self.sites],
+        'light': [l['name'] for l in self.lights],
+        'material': [n for n, _ in self.materials],
     }
     for kind, lst in m.names.items():
       named = [x for x in lst if x]

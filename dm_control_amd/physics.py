@@ -35,7 +35,13 @@ _WARNING_NAMES = ['mjWARN_INERTIA', 'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL', 'm
 # episodes; changes are pushed to the device tables before the next launch
 _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margin', 'qpos_spring', 'site_pos',
                          'site_quat', 'site_size', 'actuator_ctrlrange', 'actuator_forcerange', 'wrap_prm', 'body_pos',
-                         'body_quat')
+                         'body_quat',
+                         # geom frames / sizes as tasks rewrite them (suite/reacher.py:88-94, suite/fish.py:150-154:
+                         # the target geom); like MuJoCo, nothing derived at compile time (inertias, geom_rbound) follows
+                         'geom_pos', 'geom_quat', 'geom_size')
+# rendering attributes: writable host arrays (suite/finger.py:139-140 site_rgba, suite/fish.py:115 geom_rgba,
+# suite/swimmer.py light_pos, suite/base.py:104-112 mat_rgba); they never reach the device
+_HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'light_dir')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
 _INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
@@ -53,6 +59,7 @@ _FIELD_AXES = {
     'xpos': ('body', 3), 'xquat': ('body', 4), 'xmat': ('body', 9), 'xipos': ('body', 3),
     'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
     'site_xpos': ('site', 3), 'site_xmat': ('site', 9),
+    'xanchor': ('joint', 3), 'xaxis': ('joint', 3),      # derived on the host (_Data._joint_frames)
 }
 _COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'], 6: ['fx', 'fy', 'fz', 'tx', 'ty', 'tz'],
          9: ['xx', 'xy', 'xz', 'yx', 'yy', 'yz', 'zx', 'zy', 'zz']}
@@ -66,8 +73,58 @@ class _Data:
     object.__setattr__(self, '_cache', {})
     object.__setattr__(self, '_touched', set())
 
+  def _joint_frames(self):
+    """mjData.xanchor / xaxis (joint anchors and axes in the world frame): mj_kinematics' joint loop replayed on the
+    host from qpos and the parents' frames -- each joint's anchor and axis are taken in the body frame accumulated
+    BEFORE that joint moves it, so bodies with several joints cannot be served from the final xpos / xmat."""
+    p, m = self._p, self._p.model
+    B = p.batch_size
+    qpos = np.asarray(p.batch.get('qpos'), dtype=np.float64).reshape(B, -1)
+    xpos = np.asarray(p.batch.get('xpos'), dtype=np.float64).reshape(B, -1, 3)
+    xquat = np.asarray(p.batch.get('xquat'), dtype=np.float64).reshape(B, -1, 4)
+    mpos = np.asarray(p.batch.get('mocap_pos'), dtype=np.float64).reshape(B, -1, 3) if getattr(m, 'nmocap', 0) else None
+    mquat = np.asarray(p.batch.get('mocap_quat'), dtype=np.float64).reshape(B, -1, 4) if getattr(m, 'nmocap', 0) else None
+    C = mjcf_compiler
+    anchor, axis = np.zeros((B, m.njnt, 3)), np.zeros((B, m.njnt, 3))
+    for e in range(B):
+      for b in range(1, m.nbody):
+        j0, jn = int(m.body_jntadr[b]), int(m.body_jntnum[b])
+        if jn == 0:
+          continue
+        if jn == 1 and m.jnt_type[j0] == 0:      # free joint
+          qa = int(m.jnt_qposadr[j0])
+          anchor[e, j0] = qpos[e, qa:qa + 3]
+          axis[e, j0] = m.jnt_axis[j0]
+          continue
+        pid = int(m.body_parentid[b])
+        bp, bq = m.body_pos[b], m.body_quat[b]
+        if getattr(m, 'nmocap', 0) and m.body_mocapid[b] >= 0:
+          bp, bq = mpos[e, m.body_mocapid[b]], mquat[e, m.body_mocapid[b]] / np.linalg.norm(mquat[e, m.body_mocapid[b]])
+        pos = xpos[e, pid] + C.quat_to_mat(xquat[e, pid]) @ bp if pid else np.array(bp, dtype=np.float64)
+        quat = C.quat_mul(xquat[e, pid], bq) if pid else np.array(bq, dtype=np.float64)
+        for j in range(j0, j0 + jn):
+          R = C.quat_to_mat(quat)
+          axis[e, j] = R @ m.jnt_axis[j]
+          anchor[e, j] = R @ m.jnt_pos[j] + pos
+          qa, t = int(m.jnt_qposadr[j]), int(m.jnt_type[j])
+          if t == 2:      # slide
+            pos = pos + axis[e, j] * (qpos[e, qa] - m.qpos0[qa])
+          else:           # ball / hinge: rotate about the anchor
+            if t == 1:
+              qloc = qpos[e, qa:qa + 4] / np.linalg.norm(qpos[e, qa:qa + 4])
+            else:
+              qloc = C.axisangle_to_quat(m.jnt_axis[j], qpos[e, qa] - m.qpos0[qa])
+            quat = C.quat_mul(quat, qloc)
+            pos = anchor[e, j] - C.quat_to_mat(quat) @ m.jnt_pos[j]
+    return anchor, axis
+
   def _fetch(self, name):
     p = self._p
+    if name in ('xanchor', 'xaxis'):
+      # (the device's state: like every derived array, as of the last launch -- edits not yet forwarded are not seen)
+      anchor, axis = self._joint_frames()
+      a = anchor if name == 'xanchor' else axis
+      return a[0] if p.batch_size == 1 else a
     a = p.batch.get(name)
     rows = a.shape[1]
     if name in _FIELD_AXES and _FIELD_AXES[name][1]:
@@ -205,12 +262,18 @@ class _Axis:
       # ragged axes (qpos by joint, sensordata by sensor, ...) always yield a slice,
       # like the reference's RaggedNamedAxis: qpos['slider'] has shape (1,)
       return slice(int(self.starts[i]), int(self.starts[i] + self.sizes[i]))
-    if isinstance(key, (list, tuple, np.ndarray)) and len(key) and isinstance(key[0], (str, bytes)):
-      idx = []
-      for k in key:
-        c = self.convert(k)
-        idx.extend(range(c.start, c.stop) if isinstance(c, slice) else [c])
-      return idx
+    if isinstance(key, (list, np.ndarray)) and len(key):
+      arr = np.asarray(key)
+      if arr.size and isinstance(arr.flat[0], (str, bytes)):
+        if self.starts is None:
+          # an array of names of any shape -> the same shape of indices (mujoco/index.py:364-378): two such keys then
+          # combine by numpy's rules -- paired element by element, or broadcast as in xpos[names.reshape(-1, 1), ['x', 'z']]
+          return np.array([self.convert(k) for k in arr.flat], dtype=np.intp).reshape(arr.shape)
+        idx = []      # ragged rows: the entries of every named element, flattened (index.py:430-442)
+        for k in arr.flat:
+          c = self.convert(k)
+          idx.extend(range(c.start, c.stop))
+        return idx
     return key
 
 
@@ -231,10 +294,7 @@ class FieldIndexer:
       out.append(self._cols.convert(key[1]) if self._cols is not None else key[1])
     if self._batched:
       out = [slice(None)] + out
-    if len(out) > 1 and all(isinstance(o, list) for o in out[-2:]):
-      out[-2] = np.asarray(out[-2])[:, None]   # outer (orthogonal) indexing like the reference
-      out[-1] = np.asarray(out[-1])[None, :]
-    return tuple(out)
+    return tuple(out)      # numpy's own indexing rules from here on, as in the reference (index.py:487-500)
 
   def __getitem__(self, key):
     return self._get()[self._convert(key)]
@@ -266,19 +326,48 @@ def _make_axes(model):
       'sensor': _Axis(m.names['sensor'], m.sensor_adr, m.sensor_dim),
       'body': _Axis(m.names['body']), 'geom': _Axis(m.names['geom']), 'site': _Axis(m.names['site']),
       'joint': _Axis(m.names['joint']),
+      'sensor_row': _Axis(m.names['sensor']), 'tendon': _Axis(m.names.get('tendon', [])),
+      'light': _Axis(m.names.get('light', [])), 'material': _Axis(m.names.get('material', [])),
+      'key': _Axis(m.names.get('key', [])),
       # mocap_pos / mocap_quat rows: the bodies with body_mocapid >= 0, in mocap-id order
       'mocap': _Axis([n for _, n in sorted((int(k), m.names['body'][b]) for b, k in enumerate(getattr(m, 'body_mocapid', ())) if k >= 0)]),
   }
 
 
-_MODEL_FIELD_AXES = {
-    'body_mass': 'body', 'body_pos': 'body', 'body_quat': 'body', 'body_inertia': 'body',
-    'geom_size': 'geom', 'geom_pos': 'geom', 'geom_friction': 'geom', 'geom_type': 'geom',
-    'jnt_range': 'joint', 'jnt_limited': 'joint', 'jnt_type': 'joint', 'jnt_axis': 'joint',
-    'jnt_stiffness': 'joint', 'qpos0': 'joint_q', 'dof_damping': 'joint_v', 'dof_armature': 'joint_v',
-    'actuator_gear': 'actuator', 'actuator_ctrlrange': 'actuator', 'actuator_ctrllimited': 'actuator',
-    'site_pos': 'site', 'site_size': 'site', 'sensor_type': 'sensor',
-}
+# named.model exposes every array of the compiled model whose rows belong to named objects (mujoco/index.py:177-267
+# derives the same from the sizes table): the row axis follows the field's prefix, columns are addressable by name for
+# the fields of index.py:103-174 (_COLUMN_ID_TO_FIELDS).
+_MODEL_PREFIX_AXES = (('body_', 'body'), ('jnt_', 'joint'), ('dof_', 'joint_v'), ('geom_', 'geom'), ('site_', 'site'),
+                      ('actuator_', 'actuator'), ('sensor_', 'sensor_row'), ('tendon_', 'tendon'), ('light_', 'light'),
+                      ('mat_', 'material'), ('key_', 'key'))
+_MODEL_EXTRA_AXES = {'qpos0': 'joint_q', 'qpos_spring': 'joint_q'}
+_XYZ_FIELDS = {'body_pos', 'body_ipos', 'body_inertia', 'jnt_pos', 'jnt_axis', 'geom_size', 'geom_pos', 'site_size',
+               'site_pos', 'light_pos', 'light_dir'}
+_QUAT_FIELDS = {'body_quat', 'body_iquat', 'geom_quat', 'site_quat'}
+_RGBA_FIELDS = {'geom_rgba', 'site_rgba', 'mat_rgba'}
+
+
+def _model_field_axes(model, axes):
+  out = {}
+  for name, value in vars(model).items():
+    if not isinstance(value, np.ndarray) or value.ndim not in (1, 2):
+      continue
+    kind = _MODEL_EXTRA_AXES.get(name)
+    if kind is None:
+      kind = next((k for pre, k in _MODEL_PREFIX_AXES if name.startswith(pre)), None)
+    if kind is None or kind not in axes:
+      continue
+    ax = axes[kind]
+    nrows = (ax.starts[-1] + ax.sizes[-1] if len(ax.names) else 0) if ax.starts is not None else len(ax.names)
+    if value.shape[0] != nrows:
+      continue
+    cols = None
+    if value.ndim == 2:
+      cols = (_Axis(_COLS[3]) if name in _XYZ_FIELDS and value.shape[1] == 3 else
+              _Axis(_COLS[4]) if name in _QUAT_FIELDS and value.shape[1] == 4 else
+              _Axis(['r', 'g', 'b', 'a']) if name in _RGBA_FIELDS and value.shape[1] == 4 else None)
+    out[name] = (ax, cols)
+  return out
 
 
 class Physics(control.Physics):
@@ -311,11 +400,17 @@ class Physics(control.Physics):
       self.model = _copy.copy(model)
       self.model._frozen_private = True
       for name, value in vars(model).items():
-        if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS:
+        if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS:
           view = value.view()
           view.setflags(write=False)
           setattr(self.model, name, view)
+    self._reload_from_data(self.data)
     self.after_reset()
+
+  def _reload_from_data(self, data):
+    """The hook engine.Physics calls whenever it (re)binds an mjData (engine.py:392-430): subclasses override it to
+    reset what they cache per model (suite/quadruped.py:146-151 clears its sensor / hinge name caches here)."""
+    del data
 
   def _push_model(self):
     for f, old in self._model_pushed.items():
@@ -348,9 +443,8 @@ class Physics(control.Physics):
       cols = _Axis(_COLS[ncol]) if ncol else None
       touch = (lambda f=field: self.data._touched.add(f)) if field in _INPUT_FIELDS else None
       setattr(named.data, field, FieldIndexer(lambda f=field: self.data._get(f), axes[rowkind], cols, batched, touch))
-    for field, rowkind in _MODEL_FIELD_AXES.items():
-      if hasattr(self.model, field):
-        setattr(named.model, field, FieldIndexer(lambda f=field: getattr(self.model, f), axes[rowkind], None, False))
+    for field, (ax, cols) in _model_field_axes(self.model, axes).items():
+      setattr(named.model, field, FieldIndexer(lambda f=field: getattr(self.model, f), ax, cols, False))
     self.named = named
 
   # -- the step surface -----------------------------------------------------------------

@@ -39,7 +39,7 @@ class Physics(physics_lib.Physics):
 
   def to_target(self):
     d = self.named.data.site_xpos['target'] - self.named.data.site_xpos['tip']
-    return np.linalg.norm(d, axis=-1)
+    return common.vnorm(d)
 
   def orientations(self):
     return np.concatenate((self.horizontal(), self.vertical()), axis=-1)

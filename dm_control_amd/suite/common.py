@@ -1,5 +1,7 @@
 import os
 
+import numpy as np
+
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
 
 
@@ -27,3 +29,28 @@ def read_model(filename):
   """Physics-only restatement of the reference model of the same name."""
   with open(os.path.join(_ASSETS, filename)) as f:
     return f.read()
+
+
+def vnorm(x):
+  """Euclidean norm over the last axis.  A single environment's vector takes the call the reference's tasks make,
+  `np.linalg.norm(x)` (sqrt of a dot product): numpy's `axis=` path sums the squares in a different order and differs in
+  the last bit, and the task ports are held to the reference's modules bit for bit
+  (tests/test_reference_suite_domains.py)."""
+  x = np.asarray(x)
+  return np.linalg.norm(x) if x.ndim == 1 else np.linalg.norm(x, axis=-1)
+
+
+def vecmat(v, mat):
+  """`v . M` over the last axes: a world vector in the frame whose rotation matrix is M (`v.dot(xmat.reshape(3, 3))` in
+  the reference's tasks).  A single environment takes exactly that call -- einsum accumulates in another order, a last-bit
+  difference the port-vs-reference test would see."""
+  v, mat = np.asarray(v), np.asarray(mat)
+  if v.ndim == 1:
+    return v.dot(mat.reshape(3, 3))
+  return np.einsum('...i,...ij->...j', v, mat.reshape(v.shape[:-1] + (3, 3)))
+
+
+def vdot(a, b):
+  """Dot product over the last axis; a single environment's vectors take `np.dot` as the reference's tasks do."""
+  a, b = np.asarray(a), np.asarray(b)
+  return np.dot(a, b) if a.ndim == 1 else np.sum(a * b, axis=-1)

@@ -70,7 +70,7 @@ class Physics(physics_lib.Physics):
   def dist_to_target(self):
     """Signed distance to the target surface, negative inside (finger.py:122-125)."""
     radius = self.target_radius if self.target_radius is not None else self.named.model.site_size['target'][0]
-    return np.linalg.norm(self.to_target(), axis=-1) - radius
+    return common.vnorm(self.to_target()) - radius
 
 
 def _set_random_joint_angles(physics, random, max_attempts=1000):

@@ -53,8 +53,7 @@ class Physics(physics_lib.Physics):
     data = self.named.data
     target = self.target_pos if self.target_pos is not None else data.geom_xpos['target']
     d = target - data.geom_xpos['mouth']
-    R = np.asarray(data.geom_xmat['mouth']).reshape(d.shape[:-1] + (3, 3))
-    return np.einsum('...i,...ij->...j', d, R)
+    return common.vecmat(d, data.geom_xmat['mouth'])
 
 
 def _randomize_pose(physics, random):
@@ -110,7 +109,7 @@ class Swim(base.Task):
   def get_reward(self, physics):
     gs = physics.named.model.geom_size
     radii = gs['mouth'][0] + gs['target'][0]
-    in_target = rewards.tolerance(np.linalg.norm(physics.mouth_to_target(), axis=-1), bounds=(0, radii),
+    in_target = rewards.tolerance(common.vnorm(physics.mouth_to_target()), bounds=(0, radii),
                                   margin=2 * radii)
     is_upright = 0.5 * (physics.upright() + 1)
     return (7 * in_target + is_upright) / 8

@@ -75,7 +75,7 @@ class Physics(physics_lib.Physics):
     for side in self.SIDES:
       for limb in ('hand', 'foot'):
         d = self.named.data.xpos[side + limb] - torso_pos
-        out.append(np.einsum('...i,...ij->...j', d, frame))
+        out.append(common.vecmat(d, frame))
     return np.concatenate(out, axis=-1)
 
 
@@ -124,7 +124,8 @@ class Humanoid(base.Task):
     if self._move_speed == 0:
       dont_move = rewards.tolerance(horizontal, margin=2).mean(axis=-1)
       return small_control * stand_reward * dont_move
-    speed = np.linalg.norm(horizontal, axis=-1)
+    speed = common.vnorm(horizontal)
     move = rewards.tolerance(speed, bounds=(self._move_speed, float('inf')), margin=self._move_speed,
                              value_at_margin=0, sigmoid='linear')
-    return small_control * stand_reward * (5 * move + 1) / 6
+    move = (5 * move + 1) / 6
+    return small_control * stand_reward * move

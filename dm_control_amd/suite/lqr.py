@@ -71,7 +71,7 @@ TASKS.update(lqr_2_1=(lqr_2_1, None), lqr_6_2=(lqr_6_2, None))
 class Physics(physics_lib.Physics):
 
   def state_norm(self):
-    return np.linalg.norm(self.get_state(), axis=-1)
+    return common.vnorm(self.get_state())
 
 
 class LQRLevel(base.Task):
@@ -90,9 +90,13 @@ class LQRLevel(base.Task):
   def initialize_episode(self, physics):
     """Random state on the sphere of radius sqrt(2)."""
     B, ndof = physics.batch_size, physics.model.nq
-    unit = self.random.randn(B, ndof)
-    q = np.sqrt(2) * unit / np.linalg.norm(unit, axis=-1, keepdims=True)
-    physics.data.qpos = q[0] if B == 1 else q
+    if B == 1:
+      unit = self.random.randn(ndof)
+      q = np.sqrt(2) * unit / np.linalg.norm(unit)
+    else:
+      unit = self.random.randn(B, ndof)
+      q = np.sqrt(2) * unit / np.linalg.norm(unit, axis=-1, keepdims=True)
+    physics.data.qpos = q
     super().initialize_episode(physics)
 
   def get_observation(self, physics):
@@ -103,9 +107,9 @@ class LQRLevel(base.Task):
 
   def get_reward(self, physics):
     position = physics.position()
-    state_cost = 0.5 * np.sum(position * position, axis=-1)
+    state_cost = 0.5 * common.vdot(position, position)
     u = physics.control()
-    control_l2_norm = 0.5 * np.sum(u * u, axis=-1)
+    control_l2_norm = 0.5 * common.vdot(u, u)
     return 1 - (state_cost + control_l2_norm * self._control_cost_coef)
 
   def get_evaluation(self, physics):

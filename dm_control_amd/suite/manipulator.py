@@ -98,7 +98,7 @@ class Physics(physics_lib.Physics):
 
   def site_distance(self, site1, site2):
     d = self.named.data.site_xpos[site1] - self.named.data.site_xpos[site2]
-    return np.linalg.norm(d, axis=-1)
+    return common.vnorm(d)
 
   def target_site_distance(self, site, target_body, offset_local):
     """Distance from `site` to a point rigidly attached to the per-environment ghost target
@@ -113,7 +113,7 @@ class Physics(physics_lib.Physics):
     sp = self.named.data.site_xpos[site]
     py = self.named.model.body_pos[target_body][1] + oy
     target = np.stack([px, np.broadcast_to(py, np.shape(px)), pz], axis=-1)
-    return np.linalg.norm(sp - target, axis=-1)
+    return common.vnorm(sp - target)
 
 
 class Bring(base.Task):
@@ -138,13 +138,18 @@ class Bring(base.Task):
     limited = m.jnt_limited[arm].astype(bool)
     lower = np.where(limited, m.jnt_range[arm, 0], -np.pi)
     upper = np.where(limited, m.jnt_range[arm, 1], np.pi)
-    # one receptacle pose per episode for the whole batch (it collides: a model constant)
+    # The receptacle collides: its pose is a model constant, one per episode for the whole batch.  A single environment
+    # draws it where the reference does (manipulator.py:207-216: inside the rejection loop, after the arm angles), so
+    # that the same seed gives the same episode; a batch draws it once, ahead of the loop.
     shared_target = None
-    if self._insert:
+    rb = m.name2id(self._receptacle, 'body') if self._insert else None
+
+    def place_receptacle(pose):
+      m.body_pos[rb, [0, 2]] = pose[:2]
+      m.body_quat[rb] = [np.cos(pose[2] / 2), 0, np.sin(pose[2] / 2), 0]
+    if self._insert and B > 1:
       shared_target = (uniform(-.4, .4), uniform(.1, .4), uniform(-np.pi / 3, np.pi / 3))
-      rb = m.name2id(self._receptacle, 'body')
-      m.body_pos[rb, [0, 2]] = shared_target[:2]
-      m.body_quat[rb] = [np.cos(shared_target[2] / 2), 0, np.sin(shared_target[2] / 2), 0]
+      place_receptacle(shared_target)
     target = np.zeros((B, 3))
     todo = np.ones(B, dtype=bool)
     while todo.any():
@@ -157,6 +162,9 @@ class Bring(base.Task):
         qpos[e, qadr('finger')] = qpos[e, qadr('thumb')]          # symmetric hand
         if shared_target is not None:
           target[e] = shared_target
+        elif self._insert:
+          target[e] = (uniform(-.4, .4), uniform(.1, .4), uniform(-np.pi / 3, np.pi / 3))
+          place_receptacle(target[e])
         else:
           target[e] = (uniform(-.4, .4), uniform(.1, .4), uniform(-np.pi, np.pi))
         kinds[e] = choice(['in_hand', 'in_target', 'uniform'], p=[_P_IN_HAND, _P_IN_TARGET, 1 - _P_IN_HAND - _P_IN_TARGET])

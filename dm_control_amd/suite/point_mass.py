@@ -41,7 +41,7 @@ class Physics(physics_lib.Physics):
     return self.named.data.geom_xpos['target'] - self.named.data.geom_xpos['pointmass']
 
   def mass_to_target_dist(self):
-    return np.linalg.norm(self.mass_to_target(), axis=-1)
+    return common.vnorm(self.mass_to_target())
 
 
 class PointMass(base.Task):

@@ -75,7 +75,7 @@ TASKS.update(walk=(walk, None), run=(run, None), fetch=(fetch, None))
 
 def _to_frame(vec, frame):
   """vec . frame per environment (the reference's `v.dot(torso_frame)`)."""
-  return np.einsum('...i,...ij->...j', vec, frame)
+  return common.vecmat(vec, frame)
 
 
 class Physics(physics_lib.Physics):
@@ -109,7 +109,7 @@ class Physics(physics_lib.Physics):
     return self.named.data.sensordata[self._sensor_names(_SENS_GYRO, _SENS_ACCELEROMETER)]
 
   def origin_distance(self):
-    return np.asarray(np.linalg.norm(self.named.data.site_xpos['workspace'], axis=-1))
+    return np.asarray(common.vnorm(self.named.data.site_xpos['workspace']))
 
   def origin(self):
     return _to_frame(-self.named.data.xpos['torso'], self._torso_frame())
@@ -127,11 +127,11 @@ class Physics(physics_lib.Physics):
 
   def ball_to_target_distance(self):
     d = self.named.data.site_xpos['target'] - self.named.data.xpos['ball']
-    return np.linalg.norm(d[..., :2], axis=-1)
+    return common.vnorm(d[..., :2])
 
   def self_to_ball_distance(self):
     d = self.named.data.site_xpos['workspace'] - self.named.data.xpos['ball']
-    return np.linalg.norm(d[..., :2], axis=-1)
+    return common.vnorm(d[..., :2])
 
 
 def _find_non_contacting_height(physics, orientation, x_pos=0.0, y_pos=0.0):
@@ -232,4 +232,5 @@ class Fetch(base.Task):
     target_radius = physics.named.model.site_size['target', 0]
     fetch_reward = rewards.tolerance(physics.ball_to_target_distance(), bounds=(0, target_radius),
                                      sigmoid='linear', margin=arena_radius, value_at_margin=0)
-    return _upright_reward(physics) * reach_reward * (0.5 + 0.5*fetch_reward)
+    reach_then_fetch = reach_reward * (0.5 + 0.5*fetch_reward)
+    return _upright_reward(physics) * reach_then_fetch

@@ -47,7 +47,7 @@ class Physics(physics_lib.Physics):
     return target - finger
 
   def finger_to_target_dist(self):
-    return np.linalg.norm(self.finger_to_target(), axis=-1)
+    return common.vnorm(self.finger_to_target())
 
 
 class Reacher(base.Task):

@@ -82,7 +82,7 @@ class Physics(physics_lib.Physics):
     t = self.target_position()
     y = self.named.model.body_pos['target'][1]
     target = np.stack([t[..., 0], np.broadcast_to(y, np.shape(t[..., 0])), t[..., 1]], axis=-1)
-    return np.linalg.norm(self.named.data.site_xpos[site] - target, axis=-1)
+    return common.vnorm(self.named.data.site_xpos[site] - target)
 
 
 class Stack(base.Task):

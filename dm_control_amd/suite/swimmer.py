@@ -76,11 +76,10 @@ class Physics(physics_lib.Physics):
     if self.target_xy is not None:
       target[..., :2] = self.target_xy
     d = target - nose
-    R = np.asarray(self.named.data.xmat['head']).reshape(d.shape[:-1] + (3, 3))
-    return np.einsum('...i,...ij->...j', d, R)[..., :2]
+    return common.vecmat(d, self.named.data.xmat['head'])[..., :2]
 
   def nose_to_target_dist(self):
-    return np.linalg.norm(self.nose_to_target(), axis=-1)
+    return common.vnorm(self.nose_to_target())
 
   def body_velocities(self):
     """Local body velocities: x, y linear and z rotational, per body."""

@@ -170,7 +170,11 @@ def test_named_indexing_keys_match_numeric_indexing(physics):
   np.testing.assert_array_equal(n.sensordata['accelerometer'], sd[0:3])
   np.testing.assert_array_equal(n.xpos['pole', 'y'], xpos[2, 1])
   np.testing.assert_array_equal(n.xmat['cart', ['yy', 'zz']], xmat[1, [4, 8]])
-  np.testing.assert_array_equal(n.xpos[['pole', 'cart'], ['x', 'z']], xpos[[[2], [1]], [0, 2]])   # outer product
+  # two-dimensional named indexing follows numpy's rules (mujoco/index_test.py:132-134): two lists pair up element by
+  # element, a column of names broadcasts against a row of column names
+  np.testing.assert_array_equal(n.xpos[['pole', 'cart'], ['x', 'z']], xpos[[2, 1], [0, 2]])
+  np.testing.assert_array_equal(n.xpos[[['pole'], ['cart']], ['x', 'z']], xpos[[[2], [1]], [0, 2]])
+  np.testing.assert_array_equal(n.xpos[np.array(['pole', 'cart']).reshape(-1, 1), ['x', 'z']], xpos[[[2], [1]], [0, 2]])
   np.testing.assert_array_equal(n.xpos[:, 0], xpos[:, 0])                                          # plain slices pass through
   np.testing.assert_array_equal(n.qpos['slider'], np.asarray(d.qpos)[0:1])                         # ragged rows are slices
   np.testing.assert_array_equal(n.qvel[['slider', 'hinge_1']], np.asarray(d.qvel)[[0, 1]])

@@ -1,0 +1,180 @@
+"""Facade members the reference's own suite modules touch (found by running them unmodified:
+tests/test_reference_suite_domains.py): mjData.xanchor / xaxis, named.model over every model array with the column names
+of mujoco/index.py:103-174, numpy's rules for two-dimensional named keys, model arrays tasks write (geom_pos / geom_size
+reach the physics; *_rgba / light_pos are rendering attributes kept on the host), the `_reload_from_data` hook."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dm_control_amd import mjcf_compiler as mc  # noqa: E402
+from dm_control_amd.suite import common  # noqa: E402
+
+ARM = """
+<mujoco>
+  <option timestep='0.005'/>
+  <asset><material name='self' rgba='.7 .5 .3 1'/><material name='target' rgba='.6 .3 .3 1'/></asset>
+  <worldbody>
+    <light name='lamp' pos='0 0 2'/>
+    <geom name='floor' type='plane' size='2 2 .1'/>
+    <geom name='target' type='sphere' size='.05' pos='.3 .1 .4' contype='0' conaffinity='0' rgba='.5 .6 .7 .8'/>
+    <body name='pad' mocap='true' pos='1 1 1'/>
+    <body name='base' pos='0 0 .6'>
+      <joint name='slide' type='slide' axis='1 0 0' pos='0 .1 0'/>
+      <joint name='yaw' type='hinge' axis='0 0 1' pos='.05 0 0'/>
+      <joint name='pitch' type='hinge' axis='0 1 0' pos='0 0 .05'/>
+      <geom name='link' type='capsule' fromto='0 0 0 .3 0 0' size='.03'/>
+      <site name='tip' pos='.3 0 0' rgba='1 0 0 .5'/>
+      <body name='wrist' pos='.3 0 0' euler='0 30 0'>
+        <joint name='ball' type='ball' pos='0 0 .02'/>
+        <geom name='hand' type='box' size='.04 .03 .02'/>
+      </body>
+    </body>
+    <body name='puck' pos='0 .5 .3'>
+      <freejoint name='free'/>
+      <geom name='puck' type='sphere' size='.05'/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _random_state(m, seed):
+  rs = np.random.RandomState(seed)
+  q = m.qpos0 + rs.uniform(-.6, .6, m.nq)
+  for j in range(m.njnt):
+    a = m.jnt_qposadr[j]
+    if m.jnt_type[j] == 1:
+      q[a:a + 4] = rs.randn(4); q[a:a + 4] /= np.linalg.norm(q[a:a + 4])
+    if m.jnt_type[j] == 0:
+      q[a + 3:a + 7] = rs.randn(4); q[a + 3:a + 7] /= np.linalg.norm(q[a + 3:a + 7])
+  return q
+
+
+@pytest.mark.parametrize('name', ['ARM', 'humanoid.xml', 'cartpole.xml', 'fish.xml', 'humanoid_CMU.xml'])
+def test_xanchor_and_xaxis_replay_mj_kinematics(oracle_backend, name):
+  """The host derivation (joint loop of mj_kinematics from qpos and the parents' frames) against the fp64 oracle's own
+  xanchor / xaxis: bodies with several joints (the anchors of the later ones move with the earlier ones), slide, ball and
+  free joints, a mocap body in the model."""
+  from dm_control_amd import physics as physics_lib
+  from oracle.oracle import OraclePhysics
+  m = mc.compile_xml(ARM if name == 'ARM' else common.read_model(name))
+  phys = physics_lib.Physics(m)
+  o = OraclePhysics(m)
+  for seed in range(3):
+    q = _random_state(m, seed)
+    phys.data.qpos = q
+    phys.forward()
+    o.qpos[:] = q
+    o.forward()
+    np.testing.assert_allclose(phys.data.xanchor, o.xanchor.reshape(-1, 3), atol=1e-14)
+    np.testing.assert_allclose(phys.data.xaxis, o.xaxis.reshape(-1, 3), atol=1e-14)
+  j = m.names['joint'][1]
+  np.testing.assert_array_equal(phys.named.data.xanchor[j, ['x', 'z']], phys.data.xanchor[1, [0, 2]])
+  phys.free()
+
+
+def test_named_model_covers_every_array_with_column_names(oracle_backend):
+  from dm_control_amd import physics as physics_lib
+  phys = physics_lib.Physics.from_xml_string(ARM)
+  nm, m = phys.named.model, phys.model
+  assert nm.geom_pos['target', 'x'] == .3 and nm.geom_pos['target', ['x', 'z']].tolist() == [.3, .4]
+  np.testing.assert_array_equal(nm.geom_rgba['target'], [.5, .6, .7, .8])
+  assert nm.geom_rgba['target', 'a'] == .8 and nm.site_rgba['tip', 'r'] == 1
+  np.testing.assert_array_equal(nm.light_pos['lamp'], [0, 0, 2])
+  np.testing.assert_array_equal(nm.mat_rgba[['self', 'target']], m.mat_rgba[[0, 1]])
+  np.testing.assert_array_equal(nm.body_quat['wrist', ['qw', 'qy']], m.body_quat[m.name2id('wrist', 'body'), [0, 2]])
+  np.testing.assert_array_equal(nm.jnt_axis['pitch'], [0, 1, 0])
+  np.testing.assert_array_equal(nm.dof_damping['ball'], m.dof_damping[3:6])      # dof rows are ragged by joint
+  np.testing.assert_array_equal(nm.qpos0['free'], m.qpos0[-7:])
+  np.testing.assert_array_equal(nm.body_mass[['base', 'puck']], m.body_mass[[2, 4]])
+  # numpy's rules for two keys (mujoco/index_test.py:132-134)
+  xpos = np.asarray(phys.data.xpos)
+  np.testing.assert_array_equal(phys.named.data.xpos[['base', 'puck'], ['x', 'z']], xpos[[2, 4], [0, 2]])
+  names = np.array(['base', 'puck']).reshape(-1, 1)
+  np.testing.assert_array_equal(phys.named.data.xpos[names, ['x', 'z']], xpos[[[2], [4]], [0, 2]])
+  with pytest.raises(KeyError):
+    nm.geom_pos['nope']
+  phys.free()
+
+
+def test_model_writes_rendering_fields_stay_on_the_host_and_geometry_reaches_the_physics(oracle_backend):
+  from dm_control_amd import physics as physics_lib
+  phys = physics_lib.Physics.from_xml_string(ARM)
+  nm = phys.named.model
+  # rendering attributes: plain writable host arrays (suite/finger.py:139-140, suite/fish.py:115, suite/swimmer.py)
+  nm.site_rgba['tip', 3] = 0
+  nm.geom_rgba['target', 'a'] = 0
+  nm.light_pos['lamp', ['x', 'y']] = .5, -.5
+  nm.mat_rgba['self'] = [1, 1, 1, 1]
+  assert phys.model.site_rgba[0, 3] == 0 and phys.model.light_pos[0].tolist() == [.5, -.5, 2]
+  # geometry: the target geom moves (suite/reacher.py:88-94, suite/fish.py:150-154) and the derived arrays follow
+  nm.geom_pos['target', 'x'] = -.2
+  nm.geom_pos['target', 'z'] = .9
+  nm.geom_size['target', 0] = .11
+  phys.forward()
+  np.testing.assert_allclose(phys.named.data.geom_xpos['target'], [-.2, .1, .9])
+  assert phys.model.geom_size[phys.model.name2id('target', 'geom'), 0] == .11
+  # anything else is frozen: the device derives tables from it once (a silent no-op otherwise)
+  with pytest.raises(ValueError):
+    nm.body_mass['base'] = 3.0
+  with pytest.raises(ValueError):
+    nm.geom_friction['hand', 0] = 2.0
+  phys.free()
+
+
+def test_reload_from_data_hook_runs_at_construction_and_reload(oracle_backend):
+  from dm_control_amd import physics as physics_lib
+  calls = []
+
+  class P(physics_lib.Physics):
+    def _reload_from_data(self, data):
+      super()._reload_from_data(data)
+      calls.append(data)
+      self._cache = None
+  p = P.from_xml_string(ARM)
+  assert len(calls) == 1 and p._cache is None and calls[0] is p.data
+  p.reload_from_xml_string(ARM.replace("size='.05' pos='.3 .1 .4'", "size='.06' pos='.3 .1 .4'"))
+  assert len(calls) == 2 and calls[1] is p.data
+  p.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec,tol', [(64, 1e-10), (32, 1e-4)])
+def test_device_geom_frames_and_sizes_rewritten_between_steps(prec, tol):
+  """dmc_batch_set_model_real("geom_pos" / "geom_quat" / "geom_size"): a world-fixed, COLLIDING geom (a ledge under a
+  falling puck) is moved, tilted and resized between steps; trajectories and geom poses against oracles whose model arrays
+  are edited the same way."""
+  from dm_control_amd.batch import BatchedPhysics
+  from oracle.oracle import OraclePhysics, OracleModel
+  xml = ARM.replace("<geom name='floor' type='plane' size='2 2 .1'/>",
+                    "<geom name='floor' type='plane' size='2 2 .1'/><geom name='ledge' type='box' size='.3 .3 .05' pos='0 .5 .1'/>")
+  m = mc.compile_xml(xml)
+  B = 4
+  b = BatchedPhysics(m, B, precision=prec)
+  om = OracleModel(m)
+  refs = [OraclePhysics(om) for _ in range(B)]
+  for o in refs:
+    o.forward()
+  g = m.name2id('ledge', 'geom')
+  pos, quat, size = m.geom_pos.copy(), m.geom_quat.copy(), m.geom_size.copy()
+  for phase in range(3):
+    if phase == 1:
+      pos[g] = [0.05, .45, .16]; quat[g] = [np.cos(.1), np.sin(.1), 0, 0]
+    if phase == 2:
+      size[g] = [.3, .3, .09]
+    b.set_model_real('geom_pos', pos); b.set_model_real('geom_quat', quat); b.set_model_real('geom_size', size)
+    om.field('geom_pos')[:] = pos.ravel(); om.field('geom_quat')[:] = quat.ravel(); om.field('geom_size')[:] = size.ravel()
+    for o in refs:
+      o.forward()      # (a model edit between legacy steps: the derived arrays follow, as Physics.forward does)
+    for _ in range(60):
+      b.step()
+      for o in refs:
+        o.step()
+    np.testing.assert_allclose(b.get('qpos'), np.stack([o.qpos for o in refs]), atol=tol, rtol=0)
+    np.testing.assert_allclose(b.get('geom_xpos').reshape(B, -1, 3)[:, g], np.tile(pos[g], (B, 1)), atol=1e-6)
+  assert b.get('ncon').max() >= 1      # the puck rests on the ledge
+  assert abs(b.get('qpos')[0, -5] - (.09 + .16 + .05)) < 2e-2      # ... on its raised, thickened top (z of the free joint)
+  b.close()
