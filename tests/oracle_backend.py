@@ -81,6 +81,7 @@ class OracleBatch:
 
   def set_model_real(self, name, values):
     self._om.field(name)[:] = np.asarray(values, dtype=np.float64).ravel()
+    self._stale = True      # the device recomputes the opening stage after a model edit (stash epoch bumped)
 
   # -- pipeline -------------------------------------------------------------------------
   def step(self, nstep=1, stream=None):

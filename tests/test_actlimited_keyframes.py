@@ -183,6 +183,7 @@ def test_device_activation_clamp_and_keyframe_reset_match_oracle(prec, tol):
   refs = [OraclePhysics(om) for _ in range(B)]
   mask = np.zeros(B, np.uint8); mask[::2] = 1
   b.reset(mask, keyframe_id=1)
+  b.forward(True)      # (Physics.reset's mj_forward with actuation disabled, as the oracles' reset() does)
   for e, o in enumerate(refs):
     o.reset(1 if mask[e] else None)      # (reset + forward: legacy steps open with mj_step2)
   np.testing.assert_allclose(b.get('time')[:, 0], np.where(mask, 1.25, 0.0))
