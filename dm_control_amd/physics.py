@@ -170,6 +170,8 @@ class _Data:
     self._touched.clear()
 
   def _invalidate(self):
+    """After a launch every handed-out array is dropped: the next access fetches a fresh one.  (The reference's arrays
+    are views into mjData that follow the simulation in place; here a held reference keeps the values it was read with.)"""
     self._cache.clear()
     self._touched.clear()
 

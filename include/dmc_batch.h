@@ -124,7 +124,9 @@ int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value);
  * physics.named.model (e.g. suite/finger.py:139 dof_damping, :169-170 site_pos / site_size):
  * "dof_damping", "jnt_stiffness", "jnt_range", "jnt_margin", "qpos_spring", "site_pos",
  * "site_quat", "site_size", "actuator_ctrlrange", "actuator_forcerange", "wrap_prm"
- * (suite/point_mass.py:113-114), "body_pos", "body_quat" (suite/manipulator.py:201-208).  `values` is the
+ * (suite/point_mass.py:113-114), "body_pos", "body_quat" (suite/manipulator.py:201-208), "geom_pos",
+ * "geom_quat", "geom_size" (suite/reacher.py:88-94, suite/fish.py:150-154; as with a write to mjModel, nothing
+ * derived at compile time -- inertias, geom_rbound, contact-pair mixing -- follows).  `values` is the
  * whole mjModel array (count elements).  Shared by every env of the batch.  Synchronous. */
 int dmc_batch_set_model_real(dmc_batch* b, const char* name, const double* values, int count);
 
