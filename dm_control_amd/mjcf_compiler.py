@@ -19,6 +19,7 @@ serialises them into the blob described by include/dmc_model_layout.h.
 import collections
 import copy
 import hashlib
+import contextlib
 import math
 import xml.etree.ElementTree as ET
 
@@ -275,6 +276,27 @@ class Model:
     self.names = {}      # objtype string -> list of names (index = id)
     self.stat_meaninertia = 1.0
     self.model_name = ''
+
+  # --- reference API: MjModel.disable (wrapper/core.py:389-426) ---
+  @contextlib.contextmanager
+  def disable(self, *flags):
+    """Temporarily sets mjtDisableBit flags, by lower-case name ('gravity', 'contact', 'actuation', ...) or value."""
+    bits = {k[len('DMC_DSBL_'):].lower(): v for k, v in C.items() if k.startswith('DMC_DSBL_')}
+    old = self.opt.disableflags
+    new = old
+    for flag in flags:
+      if isinstance(flag, str):
+        if flag not in bits:
+          raise ValueError("'{}' is not a valid flag name. Valid names: {}".format(flag, ', '.join(bits)))
+        flag = bits[flag]
+      elif int(flag) not in bits.values():
+        raise ValueError('{!r} is not a valid mjtDisableBit'.format(flag))
+      new |= int(flag)
+    self.opt.disableflags = new
+    try:
+      yield
+    finally:
+      self.opt.disableflags = old
 
   # --- reference API: MjModel.name2id / id2name (wrapper/core.py:347-387) ---
   def name2id(self, name, object_type):

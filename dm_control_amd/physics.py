@@ -401,11 +401,14 @@ class Physics(control.Physics):
     if not (getattr(model, '_frozen_private', False) and not np.asarray(model.body_mass).flags.writeable):      # (copy(share_model=True) hands this Physics' own frozen copy on)
       self.model = _copy.copy(model)
       self.model._frozen_private = True
+      self.model.opt = _copy.copy(model.opt)      # option edits of this Physics (model.opt.*, model.disable) stay its own
+      self.model.opt.gravity = np.array(model.opt.gravity, dtype=np.float64)
       for name, value in vars(model).items():
         if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS:
           view = value.view()
           view.setflags(write=False)
           setattr(self.model, name, view)
+    self._opt_pushed = self._opt_snapshot()      # (the batch was created from these options)
     self._reload_from_data(self.data)
     self.after_reset()
 
@@ -414,7 +417,25 @@ class Physics(control.Physics):
     reset what they cache per model (suite/quadruped.py:146-151 clears its sensor / hinge name caches here)."""
     del data
 
+  _OPT_INTS = ('disableflags', 'iterations', 'ls_iterations')
+  _OPT_REALS = ('timestep', 'tolerance', 'ls_tolerance')
+
+  def _opt_snapshot(self):
+    o = self.model.opt
+    return tuple(int(getattr(o, n)) for n in self._OPT_INTS) + tuple(float(getattr(o, n)) for n in self._OPT_REALS) + \
+        tuple(float(g) for g in o.gravity)
+
   def _push_model(self):
+    # mjOption members tasks change at run time (engine.py:326-333 / entities/props/duplo/utils.py:68 model.disable(...),
+    # opt.timestep, opt.gravity): sent to the device when they differ from what it holds
+    snap = self._opt_snapshot()
+    if snap != getattr(self, '_opt_pushed', None):
+      old = getattr(self, '_opt_pushed', None)
+      names = self._OPT_INTS + self._OPT_REALS + ('gravity_x', 'gravity_y', 'gravity_z')
+      for k, (n, v) in enumerate(zip(names, snap)):
+        if old is None or old[k] != v:
+          self.batch.set_opt(n, v)
+      self._opt_pushed = snap
     for f, old in self._model_pushed.items():
       cur = np.asarray(getattr(self.model, f), dtype=np.float64)
       if cur.shape != old.shape or not np.array_equal(cur, old):

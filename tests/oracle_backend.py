@@ -79,6 +79,13 @@ class OracleBatch:
   def set_control(self, control):
     self.set('ctrl', control)
 
+  def set_opt(self, name, value):
+    if name in ('disableflags', 'iterations', 'ls_iterations', 'integrator', 'cone', 'solver'):
+      self._om.opt_int(name, int(value))
+    else:
+      self._om.opt_real(name, float(value))
+    self._stale = True
+
   def set_model_real(self, name, values):
     self._om.field(name)[:] = np.asarray(values, dtype=np.float64).ravel()
     self._stale = True      # the device recomputes the opening stage after a model edit (stash epoch bumped)

@@ -180,3 +180,34 @@ def test_device_geom_frames_and_sizes_rewritten_between_steps(prec, tol):
   # the floor where the original model would leave it (z = 0.05)
   assert b.get('ncon').max() >= 1 and np.all(b.get('qpos')[:, -5] > 0.22)
   b.close()
+
+
+def test_model_disable_and_option_edits_reach_the_physics(oracle_backend):
+  """MjModel.disable (wrapper/core.py:389-426; entities/props/duplo/utils.py:68 steps with gravity off) and run-time
+  writes to model.opt: the options travel to the backend before the next launch and come back after the block."""
+  from dm_control_amd import physics as physics_lib
+  m = mc.compile_xml(ARM)
+  phys = physics_lib.Physics(m)
+  z = lambda: float(phys.named.data.qpos['free'][2])
+  z0 = z()
+  with phys.model.disable('gravity', 'contact'):
+    assert phys.model.opt.disableflags == (1 << 7) | (1 << 4)
+    phys.step(20)
+    assert z() == z0      # nothing pulls the puck down
+  assert phys.model.opt.disableflags == 0
+  phys.step(20)
+  assert z() < z0 - 1e-3      # ... and now it falls
+  t0 = phys.data.time
+  phys.model.opt.timestep = 0.01
+  phys.step()
+  assert abs(phys.data.time - t0 - 0.01) < 1e-12 and phys.timestep() == 0.01
+  phys.model.opt.gravity[2] = +9.81      # an in-place edit of the gravity vector is seen as well
+  zz = z(); v0 = float(phys.named.data.qvel['free'][2])
+  phys.step()
+  assert float(phys.named.data.qvel['free'][2]) > v0
+  with pytest.raises(ValueError, match='not a valid flag name'):
+    with phys.model.disable('gravty'):
+      pass
+  # the caller's compiled model is not edited by this Physics' options
+  assert m.opt.timestep == 0.005 and m.opt.gravity[2] == -9.81 and m.opt.disableflags == 0
+  phys.free()
