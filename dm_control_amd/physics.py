@@ -166,6 +166,13 @@ class _Data:
     p._push_model()
     for name in list(self._touched):
       a = np.asarray(self._cache[name], dtype=np.float64)
+      if name == 'xfrc_applied':
+        # A READ marks an input as touched too (the caller may have written into the array it was handed).  Uploading
+        # xfrc_applied switches the kernel's external-force path on for good (6 nbody reals per environment per step):
+        # all-zero forces are only sent once a non-zero one has been, i.e. when there is something to clear.
+        if not a.any() and not self._p.__dict__.get('_xfrc_sent', False):
+          continue
+        self._p._xfrc_sent = True
       p.batch.set(name, a.reshape(p.batch_size, -1))
     self._touched.clear()
 
@@ -609,7 +616,11 @@ class Physics(control.Physics):
       if not k.startswith('_') and k not in ('model', 'batch', 'data', 'named', 'batch_size'):
         setattr(other, k, _copy.deepcopy(v))
     for name in _INPUT_FIELDS:
-      other.batch.set(name, np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1))
+      a = np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1)
+      if name == 'xfrc_applied' and not a.any():
+        continue      # (a fresh batch holds zeros; sending them would switch its external-force path on for good)
+      other.batch.set(name, a)
+    other._xfrc_sent = bool(self.__dict__.get('_xfrc_sent', False))
     other.legacy_step = self.legacy_step
     other.data._invalidate()
     # refresh derived arrays, then restore the solver warm start that forward()
@@ -639,6 +650,8 @@ class Physics(control.Physics):
     Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'],
                      **st.get('batch_kwargs', {}))
     for n, v in st['fields'].items():
+      if n == 'xfrc_applied' and not np.asarray(v).any():
+        continue
       self.batch.set(n, v)
     self.legacy_step = st['legacy_step']
     for k, v in st.get('attrs', {}).items():
