@@ -617,10 +617,11 @@ class Physics(control.Physics):
         setattr(other, k, _copy.deepcopy(v))
     for name in _INPUT_FIELDS:
       a = np.asarray(self.data._get(name), dtype=np.float64).reshape(self.batch_size, -1)
-      if name == 'xfrc_applied' and not a.any():
-        continue      # (a fresh batch holds zeros; sending them would switch its external-force path on for good)
+      if name == 'xfrc_applied':
+        other._xfrc_sent = bool(a.any())
+        if not a.any():
+          continue      # (a fresh batch holds zeros; sending them would switch its external-force path on for good)
       other.batch.set(name, a)
-    other._xfrc_sent = bool(self.__dict__.get('_xfrc_sent', False))
     other.legacy_step = self.legacy_step
     other.data._invalidate()
     # refresh derived arrays, then restore the solver warm start that forward()
@@ -650,8 +651,10 @@ class Physics(control.Physics):
     Physics.__init__(self, st['cls_model'], batch_size=st['batch_size'], precision=st['precision'],
                      **st.get('batch_kwargs', {}))
     for n, v in st['fields'].items():
-      if n == 'xfrc_applied' and not np.asarray(v).any():
-        continue
+      if n == 'xfrc_applied':
+        self._xfrc_sent = bool(np.asarray(v).any())
+        if not self._xfrc_sent:
+          continue
       self.batch.set(n, v)
     self.legacy_step = st['legacy_step']
     for k, v in st.get('attrs', {}).items():

@@ -211,3 +211,32 @@ def test_model_disable_and_option_edits_reach_the_physics(oracle_backend):
   # the caller's compiled model is not edited by this Physics' options
   assert m.opt.timestep == 0.005 and m.opt.gravity[2] == -9.81 and m.opt.disableflags == 0
   phys.free()
+
+
+def test_zero_xfrc_applied_is_not_uploaded_until_a_wrench_was(oracle_backend):
+  """Reading data.xfrc_applied (or copying / pickling a Physics) must not switch the device's external-force path on;
+  a wrench that was sent must be clearable again, also on a copy / an unpickled Physics."""
+  import pickle
+  from dm_control_amd import physics as physics_lib
+  phys = physics_lib.Physics.from_xml_string(ARM)
+  sent = []
+  real_set = phys.batch.set
+  phys.batch.set = lambda name, a: (sent.append(name), real_set(name, a))[1]
+  _ = phys.data.xfrc_applied      # a read marks the field as touched ...
+  phys.step()
+  assert 'xfrc_applied' not in sent      # ... but all-zero forces stay at home
+  puck = phys.model.name2id('puck', 'body')
+  phys.data.xfrc_applied[puck, 2] = 5.0
+  phys.step()
+  assert sent.count('xfrc_applied') == 1
+  for other in (phys.copy(), pickle.loads(pickle.dumps(phys))):
+    assert other.data.xfrc_applied[puck, 2] == 5.0
+    other.data.xfrc_applied[puck, 2] = 0.0      # clearing it on the copy reaches the copy's backend
+    other.step()
+    assert not np.asarray(other.batch.get('xfrc_applied')).any()
+    other.free()
+  phys.data.xfrc_applied[:] = 0
+  phys.step()
+  assert sent[-1] == 'xfrc_applied' or 'xfrc_applied' in sent[-12:]      # the zeros were sent this time
+  assert not np.asarray(phys.batch.get('xfrc_applied')).any()
+  phys.free()
