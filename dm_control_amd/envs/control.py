@@ -177,6 +177,8 @@ class Environment(dm_env.Environment):
     task.after_step(physics)
     self._step_count += 1
     reward, observation = task.get_reward(physics), self._observe()
+    if isinstance(reward, np.ndarray) and reward.ndim == 0:
+      reward = reward[()]      # a single environment's reward is a (numpy) float, as the reference's tasks return it
     final_discount = 1.0 if self._step_count >= self._step_limit else task.get_termination(physics)
     if final_discount is None:
       return dm_env.transition(reward, observation)

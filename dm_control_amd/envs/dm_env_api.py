@@ -103,8 +103,12 @@ class Array:
     return 'Array(shape=%r, dtype=%r, name=%r)' % (self._shape, self._dtype, self._name)
 
   def __eq__(self, other):
-    return (type(self) is type(other) and self._shape == other._shape and
-            self._dtype == other._dtype and self._name == other._name)
+    # dm_env's specs compare shape and dtype only -- the name is a label (rl/control_test.py:93-95 relies on it)
+    if not isinstance(other, Array):
+      return False
+    return self._shape == other._shape and self._dtype == other._dtype
+
+  __hash__ = None
 
   def validate(self, value):
     value = np.asarray(value)
@@ -147,8 +151,12 @@ class BoundedArray(Array):
         self.shape, self.dtype, self.name, self._minimum, self._maximum)
 
   def __eq__(self, other):
+    if not isinstance(other, BoundedArray):
+      return False
     return (super().__eq__(other) and np.array_equal(self._minimum, other._minimum) and
             np.array_equal(self._maximum, other._maximum))
+
+  __hash__ = None
 
   def validate(self, value):
     value = super().validate(value)

@@ -21,6 +21,7 @@ import copy
 import hashlib
 import contextlib
 import math
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -277,6 +278,11 @@ class Model:
     self.stat_meaninertia = 1.0
     self.model_name = ''
 
+  @property
+  def name(self):
+    """MjModel.name (wrapper/core.py:428-431): the `model` attribute of <mujoco>."""
+    return self.model_name
+
   # --- reference API: MjModel.disable (wrapper/core.py:389-426) ---
   @contextlib.contextmanager
   def disable(self, *flags):
@@ -382,6 +388,7 @@ class _Compiler:
     self.geoms = []
     self.sites = []
     self.lights = []
+    self.cameras = []
     self.actuators = []
     self.sensors = []
     self.excludes = []
@@ -609,7 +616,7 @@ class _Compiler:
         self.lights.append(dict(name=a.get('name'), body=bid, pos=_vec(a['pos'], 3) if 'pos' in a else np.zeros(3),
                                 dir=_vec(a['dir'], 3) if 'dir' in a else np.array([0.0, 0, -1])))
       elif tag == 'camera':
-        pass  # rendering only
+        self.cameras.append(child.attrib.get('name'))      # rendering only: the count and the names (MjModel.ncam)
       elif tag == 'body':
         pass  # handled below so that this body's elements get ids first
       else:
@@ -1019,6 +1026,23 @@ class _Compiler:
     m.light_dir = np.array([l['dir'] for l in self.lights], dtype=np.float64).reshape(m.nlight, 3)
     m.nmat = len(self.materials)
     m.mat_rgba = np.array([r for _, r in self.materials], dtype=np.float64).reshape(m.nmat, 4)
+    # sizes and names of what this backend does not simulate but MjModel counts (suite/suite_test.py:107-139 walks them)
+    m.ncam = len(self.cameras)
+    assets = [e for sec in self.root.findall('asset') for e in sec]
+    custom = [e for sec in self.root.findall('custom') for e in sec]
+
+    def named(elems, tag):
+      out = []
+      for e in elems:
+        if e.tag == tag:
+          f = e.get('file')
+          out.append(e.get('name') or (os.path.splitext(os.path.basename(f))[0] if f else None))
+      return out
+    self._aux_names = dict(camera=list(self.cameras), mesh=named(assets, 'mesh'), hfield=named(assets, 'hfield'),
+                           texture=named(assets, 'texture'), numeric=named(custom, 'numeric'), text=named(custom, 'text'),
+                           tuple=named(custom, 'tuple'))
+    m.nmesh, m.nhfield, m.ntex = (len(self._aux_names[k]) for k in ('mesh', 'hfield', 'texture'))
+    m.nnumeric, m.ntext, m.ntuple = (len(self._aux_names[k]) for k in ('numeric', 'text', 'tuple'))
     m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(nsite, 4)
     # inertial properties
     self._body_inertias(m)
@@ -1031,6 +1055,7 @@ class _Compiler:
         'light': [l['name'] for l in self.lights],
         'material': [n for n, _ in self.materials],
     }
+    m.names.update(self._aux_names)
     for kind, lst in m.names.items():
       named = [x for x in lst if x]
       if len(named) != len(set(named)):
