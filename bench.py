@@ -404,7 +404,9 @@ def main():
   single_device = bool(os.environ.get('DMC_BENCH_SINGLE_DEVICE'))
   if os.environ.get('DMC_BENCH_DRYRUN'):      # harness test hook: the rank layout only, before anything touches a GPU
     check_world(args, world, args.gpus, single_device)
-    print(json.dumps({'dryrun': True, 'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': args.gpus}), flush=True)
+    # one write per rank: print() sends the text and the newline separately, and two ranks' lines can interleave
+    sys.stdout.write(json.dumps({'dryrun': True, 'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': args.gpus}) + '\n')
+    sys.stdout.flush()
     return
   import torch
   check_world(args, world, torch.cuda.device_count(), single_device)
