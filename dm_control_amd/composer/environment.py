@@ -207,7 +207,8 @@ class Environment:
     torch = physics.torch
     self._reset_next = torch.ones(physics.B, dtype=torch.bool, device=physics.device)
     self._host_all_reset = True     # known without a device sync: every env is waiting for its reset
-    self.launches = 0               # physics launches issued (tests / profiling)
+    self.launches = 0               # physics STEP launches issued (tests / profiling)
+    self.forward_launches = 0       # mj_forward launches ahead of the observations (observation_forward tasks)
 
   @property
   def n_sub_steps(self):
@@ -280,6 +281,16 @@ class Environment:
         self.launches += 1
         self._hooks.after_substep(p, self._rs)
     self._hooks.after_step(p, self._rs)
+    if getattr(task, 'observation_forward', False):
+      # In the reference the action reaches mjData through an mjcf binding (walker.apply_action), which marks the physics
+      # dirty; physics.step() does not clear that, so the first observable read through a binding after the substeps
+      # runs mj_forward (mjcf/physics.py:341-342): the acceleration-stage sensors an agent sees (touch, torque,
+      # accelerometer, force) are those of the NEW state under the action just applied, not the last substep's.
+      # Found by running composer/environment.py unmodified on this backend (tests/test_reference_composer.py).
+      # The environments re-initialised in this call keep their mj_forward with actuation disabled (env_mode 2: untouched).
+      p.field('env_mode').copy_((first.to(torch.int32) * 2)[None, :])
+      p.forward()
+      self.forward_launches += 1
     reward = task.get_reward(p)
     discount = task.get_discount(p)
     # ANY new mjWARN_* since the last look = PhysicsError in the reference (engine.py:345-368 compares the warning

@@ -60,6 +60,9 @@ class CMUHumanoidWalker(environment.Entity):
 
 
 class GoToTarget(environment.Task):
+  # the reference's observation update runs mj_forward first (no substep hook reads through a binding before it): see
+  # composer.Environment.step
+  observation_forward = True
 
   def __init__(self, model=None, moving_target=False, target_relative=False, target_relative_dist=1.5,
                steps_before_moving_target=10, distance_tolerance=DEFAULT_DISTANCE_TOLERANCE_TO_TARGET,

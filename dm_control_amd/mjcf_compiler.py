@@ -279,6 +279,12 @@ class Model:
     self.model_name = ''
 
   @property
+  def ptr(self):
+    """MjModel.ptr (wrapper/core.py: the raw mujoco.MjModel that engine calls take): there is no such object here; the
+    compiled model stands in as its own opaque handle, so code that only passes it on keeps working."""
+    return self
+
+  @property
   def name(self):
     """MjModel.name (wrapper/core.py:428-431): the `model` attribute of <mujoco>."""
     return self.model_name
@@ -1026,6 +1032,13 @@ class _Compiler:
     m.light_dir = np.array([l['dir'] for l in self.lights], dtype=np.float64).reshape(m.nlight, 3)
     m.nmat = len(self.materials)
     m.mat_rgba = np.array([r for _, r in self.materials], dtype=np.float64).reshape(m.nmat, 4)
+    # mjModel's frame-coincidence flags: mj_kinematics shortcuts that a write to the frames must clear -- dm_control.mjcf
+    # bindings zero them on every pos / quat write (mjcf/constants.py:52-61).  This backend composes every frame every
+    # time, so they are plain host-side arrays that such writes may clear.
+    m.body_sameframe = np.zeros(len(self.bodies), dtype=np.int64)
+    m.body_simple = np.zeros(len(self.bodies), dtype=np.int64)
+    m.geom_sameframe = np.zeros(len(self.geoms), dtype=np.int64)
+    m.site_sameframe = np.zeros(nsite, dtype=np.int64)
     # sizes and names of what this backend does not simulate but MjModel counts (suite/suite_test.py:107-139 walks them)
     m.ncam = len(self.cameras)
     assets = [e for sec in self.root.findall('asset') for e in sec]

@@ -41,7 +41,8 @@ _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margi
                          'geom_pos', 'geom_quat', 'geom_size')
 # rendering attributes: writable host arrays (suite/finger.py:139-140 site_rgba, suite/fish.py:115 geom_rgba,
 # suite/swimmer.py light_pos, suite/base.py:104-112 mat_rgba); they never reach the device
-_HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'light_dir')
+_HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'light_dir',
+                           'body_sameframe', 'body_simple', 'geom_sameframe', 'site_sameframe')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
 _INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
@@ -55,6 +56,7 @@ _FIELD_AXES = {
     'qfrc_actuator': ('joint_v', None), 'qfrc_bias': ('joint_v', None),
     'qfrc_constraint': ('joint_v', None),
     'ctrl': ('actuator', None), 'actuator_force': ('actuator', None),
+    'act': ('act', None),      # rows named after the actuators that have an activation state (index.py:93-99 'na')
     'sensordata': ('sensor', None),
     'xpos': ('body', 3), 'xquat': ('body', 4), 'xmat': ('body', 9), 'xipos': ('body', 3),
     'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
@@ -72,6 +74,12 @@ class _Data:
     object.__setattr__(self, '_p', physics)
     object.__setattr__(self, '_cache', {})
     object.__setattr__(self, '_touched', set())
+    object.__setattr__(self, '_shadow', {})      # view semantics: what the device holds of each handed-out input array
+
+  @property
+  def ptr(self):
+    """MjData.ptr: an opaque handle (see Model.ptr)."""
+    return self
 
   def _joint_frames(self):
     """mjData.xanchor / xaxis (joint anchors and axes in the world frame): mj_kinematics' joint loop replayed on the
@@ -148,7 +156,12 @@ class _Data:
       except Exception as e:
         raise AttributeError('%s (%s)' % (name, e))
     if name in _INPUT_FIELDS:
-      self._touched.add(name)
+      if self._p.view_semantics:
+        a = self._cache[name]
+        if name not in self._shadow and isinstance(a, np.ndarray) and a.ndim:
+          self._shadow[name] = np.array(a, copy=True)      # writes are found by comparison at upload time
+      else:
+        self._touched.add(name)
     return self._cache[name]
 
   def __setattr__(self, name, value):
@@ -164,6 +177,13 @@ class _Data:
   def _upload(self):
     p = self._p
     p._push_model()
+    if p.view_semantics:
+      # handed-out input arrays may have been written through any reference to them (mjcf bindings keep the ndarray
+      # itself): whatever differs from what the device holds goes up
+      for name, dev in self._shadow.items():
+        cur = self._cache.get(name)
+        if isinstance(cur, np.ndarray) and cur.ndim and not np.array_equal(cur, dev, equal_nan=True):
+          self._touched.add(name)
     for name in list(self._touched):
       a = np.asarray(self._cache[name], dtype=np.float64)
       if name == 'xfrc_applied':
@@ -178,9 +198,27 @@ class _Data:
 
   def _invalidate(self):
     """After a launch every handed-out array is dropped: the next access fetches a fresh one.  (The reference's arrays
-    are views into mjData that follow the simulation in place; here a held reference keeps the values it was read with.)"""
-    self._cache.clear()
+    are views into mjData that follow the simulation in place; here a held reference keeps the values it was read with,
+    unless the Physics was built with `view_semantics`: then every handed-out array is the SAME ndarray for the life of
+    the model, rewritten in place after each launch and watched for writes -- what dm_control.mjcf's bindings, which
+    keep the arrays themselves, rely on.  Single environments only: the copies are per launch.)"""
     self._touched.clear()
+    if not self._p.view_semantics:
+      self._cache.clear()
+      return
+    for name in list(self._cache):
+      old = self._cache[name]
+      try:
+        new = self._fetch(name)
+      except Exception:      # pylint: disable=broad-except
+        del self._cache[name]
+        continue
+      if isinstance(old, np.ndarray) and old.ndim and old.shape == np.shape(new):
+        np.copyto(old, new)
+      else:
+        self._cache[name] = new
+      if name in _INPUT_FIELDS and isinstance(self._cache[name], np.ndarray) and self._cache[name].ndim:
+        self._shadow[name] = np.array(self._cache[name], copy=True)
 
   @property
   def contact(self):
@@ -196,7 +234,9 @@ class _Data:
     out['dist'] = self._get('contact_dist')[:n]
     out['pos'] = self._get('contact_pos').reshape(-1, 3)[:n]
     out['frame'] = self._get('contact_frame').reshape(-1, 9)[:n]
-    return out
+    # a record array: `contact.geom1` on the whole array AND on each element, as with mjData.contact
+    # (locomotion/tasks/go_to_target.py:189-199 iterates it and reads `contact.geom1 / contact.geom2`)
+    return out.view(np.recarray)
 
   def contact_force(self, contact_id):
     """(force, torque) of a contact in the contact frame, 2 x 3 (batch: B x 2 x 3), order
@@ -317,6 +357,15 @@ class FieldIndexer:
   def axes(self):
     return self._rows, self._cols
 
+  # the two private members dm_control.mjcf.physics.Binding reaches for (mjcf/physics.py:286-296)
+  @property
+  def _field(self):
+    return self._get()
+
+  def _convert_key(self, key):
+    out = self._convert(key)
+    return out if isinstance(key, tuple) else out[0]
+
   def __repr__(self):
     return 'FieldIndexer(rows=%r)' % (self._rows.names,)
 
@@ -332,6 +381,10 @@ def _make_axes(model):
   return {
       'joint_q': jq, 'joint_v': jv,
       'actuator': _Axis(m.names['actuator']),
+      # 'na': every actuator, sized by its number of activation states (0 or 1), as index.py:93-99 / :190-215 do
+      'act': _Axis(m.names['actuator'],
+                   np.concatenate([[0], np.cumsum(np.asarray(getattr(m, 'actuator_dyntype', np.zeros(0))) != 0)])[:-1],
+                   (np.asarray(getattr(m, 'actuator_dyntype', np.zeros(0))) != 0).astype(int)),
       'sensor': _Axis(m.names['sensor'], m.sensor_adr, m.sensor_dim),
       'body': _Axis(m.names['body']), 'geom': _Axis(m.names['geom']), 'site': _Axis(m.names['site']),
       'joint': _Axis(m.names['joint']),
@@ -383,6 +436,7 @@ class Physics(control.Physics):
   """Batched MuJoCo-semantics physics on one MI355X (see module docstring)."""
 
   _contexts = None
+  view_semantics = False      # see _Data._invalidate; subclasses that serve dm_control.mjcf bindings switch it on
 
   def __init__(self, model, batch_size=1, device_id=0, precision=64, **batch_kwargs):
     """`precision`: 64 (default: drop-in numerics, tracks the CPU reference to

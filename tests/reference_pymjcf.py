@@ -347,3 +347,63 @@ def soccer_2v2_boxhead(randomizer=None):
   arena = s.pitch.RandomizedPitch(min_size=(32, 24), max_size=(48, 36), keep_aspect_ratio=False, field_box=False, goal_size=None,
                                   randomizer=randomizer)
   return s.task.Task(players=players, arena=arena, ball=s.soccer_ball.SoccerBall(), disable_walker_contacts=False)
+
+
+# ---- engine-bound layers: dm_control.mjcf.physics (bindings) and composer.Environment on THIS package's Physics ----------
+def _array_sizes(facade):
+  """`mjbindings.sizes.array_sizes` for the arrays the facade serves: field -> (row size name[, columns]).  mjcf/physics.py
+  (:63-119) builds the attribute table of `physics.bind(...)` from it."""
+  data = {}
+  rows = {'act': 'na', 'joint_q': 'nq', 'joint_v': 'nv', 'body': 'nbody', 'geom': 'ngeom', 'site': 'nsite', 'actuator': 'nu',
+          'sensor': 'nsensordata', 'mocap': 'nmocap', 'joint': 'njnt'}
+  for name, (kind, ncol) in facade._FIELD_AXES.items():
+    data[name] = (rows[kind],) + ((ncol,) if ncol else ())
+  model = {}
+  prefixes = (('body_', 'nbody'), ('jnt_', 'njnt'), ('dof_', 'nv'), ('geom_', 'ngeom'), ('site_', 'nsite'),
+              ('actuator_', 'nu'), ('sensor_', 'nsensor'), ('tendon_', 'ntendon'), ('light_', 'nlight'), ('mat_', 'nmat'))
+  from dm_control_amd import mjcf_compiler
+  probe = mjcf_compiler.compile_xml("<mujoco><worldbody><light name='l'/><body name='b'><joint name='j'/><geom name='g' size='.1'/>"
+                                    "<site name='s'/></body></worldbody><actuator><motor name='a' joint='j'/></actuator>"
+                                    "<sensor><jointpos name='p' joint='j'/></sensor></mujoco>")
+  for name, value in vars(probe).items():
+    if isinstance(value, np.ndarray) and value.ndim in (1, 2):
+      size = next((s for pre, s in prefixes if name.startswith(pre)), None)
+      if name in ('qpos0', 'qpos_spring'):
+        size = 'nq'
+      if size:
+        model[name] = (size,) + ((value.shape[1],) if value.ndim == 2 else ())
+  return {'mjdata': data, 'mjmodel': model}
+
+
+def bind_engine():
+  """On top of load(): `dm_control.mujoco.Physics` becomes this package's facade (with view semantics: mjcf bindings keep
+  the arrays they are handed), and the reference's mjcf/physics.py, rl/control.py and composer/environment.py are
+  executed unmodified over it.  mjlib.mj_subtreeVel is a no-op (the backend serves subtree velocities itself)."""
+  root = load()
+  if getattr(root, '_dmc_amd_engine', False):
+    return root
+  from dm_control_amd import physics as facade
+  mj = sys.modules['dm_control.mujoco']
+
+  class Physics(facade.Physics):
+    view_semantics = True
+  Physics.__module__ = 'dm_control.mujoco'
+  mj.Physics, mj.action_spec = Physics, facade.action_spec
+  mjb = sys.modules['dm_control.mujoco.wrapper.mjbindings']
+  sizes = types.ModuleType('dm_control.mujoco.wrapper.mjbindings.sizes')
+  sizes.array_sizes = _array_sizes(facade)
+  sys.modules[sizes.__name__] = sizes
+  mjb.sizes = sizes
+  mjb.mjlib.mj_subtreeVel = lambda model_ptr, data_ptr: None
+  _stub('dm_control.rl', os.path.join(REF, 'rl'))
+  _exec('dm_control.rl.control', os.path.join(REF, 'rl/control.py'))
+  mjcf, comp = sys.modules['dm_control.mjcf'], sys.modules['dm_control.composer']
+  flags = sys.modules['absl.flags']
+  _exec('dm_control.mjcf.physics', os.path.join(REF, 'mjcf/physics.py'))
+  mjcf.Physics = mjcf.physics.Physics
+  _exec('dm_control.composer.environment', os.path.join(REF, 'composer/environment.py'))
+  for n in ('Environment', 'EpisodeInitializationError', 'HOOK_NAMES', 'ObservationPadding'):
+    setattr(comp, n, getattr(comp.environment, n))
+  root._dmc_amd_engine = True
+  del flags
+  return root

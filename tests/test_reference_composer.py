@@ -1,0 +1,84 @@
+"""The reference's composer stack on this package's Physics, UNMODIFIED: composer/environment.py
+(`Environment.step / _substep`, the hook dispatch), mjcf/physics.py (`bind`, the synchronising array wrappers),
+composer/observation/updater.py, locomotion/tasks/go_to_target.py, walkers/cmu_humanoid.py + legacy_base.py,
+arenas/floors.py -- executed from /root/reference by tests/reference_pymjcf.py over `dm_control_amd.physics.Physics`
+(CPU tier: the fp64 oracle stands in for the device) -- against this package's device-resident composer
+(`dm_control_amd.composer`, BASELINE config 4) started from the same state: every observation, reward, discount and
+step type of the episode.  Skips where the reference tree is absent (the GPU box)."""
+import sys
+
+import numpy as np
+import pytest
+
+import reference_pymjcf as rp
+
+pytestmark = pytest.mark.skipif(not rp.available(), reason='reference tree not present')
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture
+def engine():
+  rp.bind_engine()
+  yield sys.modules['dm_control.composer']
+  rp.unload()
+
+
+def _ours(B=1):
+  from composer_fake import OracleDevicePhysics
+  from dm_control_amd.composer import environment
+  from dm_control_amd.composer.tasks import go_to_target
+  task = go_to_target.GoToTarget()
+  phys = OracleDevicePhysics(task.model, B, outputs=('sensordata', 'xpos', 'xmat', 'contact_geom1'))
+  return environment.Environment(task, phys, time_limit=30.0, random_state=3), task, phys
+
+
+def test_reference_composer_environment_runs_unmodified_and_matches_the_device_composer(engine, oracle_backend):
+  from dm_control_amd.composer import environment as ours_env
+  ref_task = rp.cmu2019_go_to_target()
+  ref = engine.Environment(task=ref_task, time_limit=30.0, random_state=np.random.RandomState(7),
+                           strip_singleton_obs_buffer_dim=True)
+  assert type(ref).__module__ == 'dm_control.composer.environment'
+  assert ref.physics.__class__.__module__ == 'dm_control.mjcf.physics' and ref.physics.view_semantics
+  ts = ref.reset()
+  env, task, phys = _ours()
+  env.reset()
+  m = task.model
+  # the same model: this package's config-4 asset against what the reference composition compiled to
+  rm = ref.physics.model
+  assert (rm.nq, rm.nv, rm.nu, rm.nbody, rm.ngeom) == (m.nq, m.nv, m.nu, m.nbody, m.ngeom)
+  np.testing.assert_array_equal(rm.body_mass, m.body_mass)
+  assert ref.control_timestep() == pytest.approx(env.control_timestep()) and ref.task.physics_steps_per_control_step == env.n_sub_steps
+  # start this package's episode from the reference's initial state (the two draw from different generators)
+  phys.field('qpos')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qpos))
+  phys.field('qvel')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qvel))
+  task._target[:, 0] = torch.from_numpy(np.array(ref_task.target_position(ref.physics))[:2])
+  phys.mark_as_dirty()
+  phys.forward(disable_actuation=True)
+  spec = ref.action_spec()
+  assert spec.shape == (m.nu,) and spec.minimum.min() == -1 and spec.maximum.max() == 1
+  rs = np.random.RandomState(1)
+  seen = set()
+  for t in range(10):
+    a = rs.uniform(-1, 1, m.nu)
+    r, o = ref.step(a), env.step(torch.from_numpy(a[None]))
+    assert int(r.step_type) == int(o.step_type[0]), t
+    assert float(r.reward) == float(o.reward[0]) and float(r.discount) == float(o.discount[0]), t
+    for key, val in r.observation.items():
+      val = np.asarray(val)
+      short = key.split('/', 1)[1] if '/' in key else key
+      if val.size == 0:
+        continue      # actuator_activation / sensors_force: nothing to observe on this walker
+      assert short in o.observation, key
+      np.testing.assert_allclose(o.observation[short][0].numpy().ravel(), val.ravel(), rtol=0, atol=1e-11, err_msg='%s step %d' % (key, t))
+      seen.add(short)
+  assert {'joints_pos', 'joints_vel', 'end_effectors_pos', 'appendages_pos', 'sensors_touch', 'sensors_torque', 'target',
+          'world_zaxis', 'body_height', 'sensors_gyro', 'sensors_velocimeter', 'sensors_accelerometer'} <= seen
+  # the episode ends the reference's way too: lay both walkers down -> a non-foot geom touches the ground
+  q = np.array(ref.physics.data.qpos); q[2] = 0.12; q[3:7] = [1, 0, 0, 0]
+  ref.physics.data.qpos[:] = q      # (a write straight into the array the facade handed out: view semantics)
+  phys.field('qpos')[:, 0] = torch.from_numpy(q)
+  phys.mark_as_dirty()
+  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64))
+  assert r.last() and int(o.step_type[0]) == ours_env.LAST and float(r.discount) == 0.0 == float(o.discount[0])
+  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64))
+  assert r.first() and int(o.step_type[0]) == ours_env.FIRST
