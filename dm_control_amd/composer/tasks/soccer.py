@@ -157,6 +157,7 @@ class Soccer2v2(environment.Task):
     self._ctrl_rows = [[m.name2id('%s/%s' % (p, a), 'actuator') for a in ('roll', 'steer', 'kick')] for p in _PLAYERS]
     sadr = lambda n: int(m.sensor_adr[m.name2id(n, 'sensor')])
     self._sens = {p: {k: sadr('%s/sensor_torso_%s' % (p, k)) for k in ('vel', 'gyro', 'accel')} for p in _PLAYERS}
+    self._sadr = {n: int(a) for n, a in zip(m.names['sensor'], m.sensor_adr) if n}      # sensor name -> sensordata row
     self._ball_linvel = sadr('soccer_ball/linear_velocity')
     self._ball_angvel = sadr('soccer_ball/angular_velocity')
     self._prev_action = None
@@ -352,25 +353,33 @@ class Soccer2v2(environment.Task):
       a, av, s = self._q[p], self._v[p], self._sens[p]
       put('joints_pos', q[a['kick']]); put('joints_vel', v[av['kick']])
       put('body_height', pos[2])
-      put('end_effectors_pos', torch.zeros((3, B), dtype=physics.dtype, device=physics.device))      # head_body w.r.t. itself
+      # What a player observes of the ball and of the others are the frame sensors CoreObservablesAdder adds to its model
+      # (observables.py:96-198: framepos / framelinvel / frameangvel / frame?axis with reftype="body"): MuJoCo evaluates
+      # objtype / reftype "body" in the bodies' INERTIAL frames (xipos, ximat -- the head's principal axes are a
+      # permutation of its body axes) and velocities RELATIVE to the reference frame.  They are read, not recomputed
+      # from xpos / xmat (round 2 did that, in the body frame: found by running the reference's task on this backend,
+      # tests/test_reference_composer.py).
+      S = lambda name: sd[self._sadr[p + '/' + name]:self._sadr[p + '/' + name] + 3]
+      put('end_effectors_pos', S('head_body_end_effector'))
       put('world_zaxis', physics.field('xmat')[9*self._root[k] + 6:9*self._root[k] + 9])
       put('sensors_gyro', sd[s['gyro']:s['gyro'] + 3]); put('sensors_velocimeter', sd[s['vel']:s['vel'] + 3])
       put('sensors_accelerometer', sd[s['accel']:s['accel'] + 3])
       put('prev_action', self._prev_action[k])
-      put('ball_ego_position', self._ego(ball - pos, R))
-      put('ball_ego_linear_velocity', self._ego(blin - cvel[6*self._root[k] + 3:6*self._root[k] + 6], R))
-      put('ball_ego_angular_velocity', self._ego(bang, R))
+      put('ball_ego_position', S('ball_ego_pos'))
+      put('ball_ego_linear_velocity', S('ball_ego_linvel'))
+      put('ball_ego_angular_velocity', S('ball_ego_angvel'))
       mates = [j for j in range(4) if j != k and _TEAM[j] == _TEAM[k]]
       opps = [j for j in range(4) if _TEAM[j] != _TEAM[k]]
       for prefix, others in (('teammate', mates), ('opponent', opps)):
         for n, j in enumerate(others):
-          opos, oR = frames[j]
-          put('%s_%d_ego_position' % (prefix, n), self._ego(opos - pos, R))
-          put('%s_%d_ego_linear_velocity' % (prefix, n),
-              self._ego(cvel[6*self._root[j] + 3:6*self._root[j] + 6] - cvel[6*self._root[k] + 3:6*self._root[k] + 6], R))
-          # the other's axes in this player's frame (framexaxis / frameyaxis / framezaxis sensors with reftype)
-          rel = torch.einsum('ijb,ikb->jkb', R, oR)            # R^T oR : columns = other's axes
-          put('%s_%d_ego_orientation' % (prefix, n), rel.permute(1, 0, 2).reshape(9, B))
+          pre = '%s_%d' % (prefix, n)
+          put(pre + '_ego_end_effectors_pos', S('head_body_%s_end_effector' % pre))
+          put(pre + '_ego_linear_velocity', S(pre + '_ego_linear_velocity'))
+          put(pre + '_ego_position', S(pre + '_ego_position'))
+          put(pre + '_ego_orientation', torch.cat([S(pre + '_ego_orientation_' + d) for d in 'xyz'], dim=0))
+          # the other's end effectors in the OTHER's frame (observables.py:158-161: its own end_effectors_pos observable)
+          o = _PLAYERS[j] + '/head_body_end_effector'
+          put(pre + '_end_effectors_pos', sd[self._sadr[o]:self._sadr[o] + 3])
       feats = corners if _TEAM[k] == 0 else corners[4:] + corners[:4]
       for name, c in zip(corner_names, feats):
         n = c.shape[0]

@@ -62,6 +62,7 @@ _FIELD_AXES = {
     'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
     'site_xpos': ('site', 3), 'site_xmat': ('site', 9),
     'xanchor': ('joint', 3), 'xaxis': ('joint', 3),      # derived on the host (_Data._joint_frames)
+    'cvel': ('body', 6),      # com-based body velocities (rotational, translational): soccer/observables.py:278 reads them
 }
 _COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'], 6: ['fx', 'fy', 'fz', 'tx', 'ty', 'tz'],
          9: ['xx', 'xy', 'xz', 'yx', 'yy', 'yz', 'zx', 'zy', 'zz']}

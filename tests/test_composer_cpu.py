@@ -235,10 +235,17 @@ def test_soccer_substep_detectors_rewards_and_throw_in():
   assert phys.launches == ['step1'] * 5
   np.testing.assert_array_equal(phys.field('ctrl')[:, 0].numpy(), a[0].reshape(-1).numpy())
   assert ts.reward.shape == (4, 3) and float(ts.reward.abs().max()) == 0.0
-  # egocentric ball position of home0 = (ball - head_body) . xmat(head_body)   (framepos sensor with reftype)
-  hb = m.name2id('home0/head_body', 'body')
-  pos = phys.field('xpos')[3*hb:3*hb + 3, 1].numpy(); R = phys.field('xmat')[9*hb:9*hb + 9, 1].numpy().reshape(3, 3)
-  np.testing.assert_allclose(ts.observation['ball_ego_position'][1, 0].numpy(), (task.ball_xpos(phys)[:, 1].numpy() - pos) @ R, atol=1e-12)
+  # egocentric ball position of home0: the framepos sensor objtype = reftype = "body" of observables.py:182-186, which
+  # MuJoCo evaluates between the bodies' INERTIAL frames: (xipos_ball - xipos_head) . ximat_head
+  def inertial(name, e):
+    b = m.name2id(name, 'body')
+    pos = phys.field('xpos')[3*b:3*b + 3, e].numpy(); R = phys.field('xmat')[9*b:9*b + 9, e].numpy().reshape(3, 3)
+    return pos + R @ m.body_ipos[b], R @ mc.quat_to_mat(m.body_iquat[b])
+  (hp, hR), (bp, _) = inertial('home0/head_body', 1), inertial('soccer_ball/', 1)
+  np.testing.assert_allclose(ts.observation['ball_ego_position'][1, 0].numpy(), (bp - hp) @ hR, atol=1e-12)
+  sid = m.name2id('home0/ball_ego_pos', 'sensor')
+  np.testing.assert_array_equal(ts.observation['ball_ego_position'][1, 0].numpy(),
+                                phys.field('sensordata')[m.sensor_adr[sid]:m.sensor_adr[sid] + 3, 1].numpy())
   # put the ball inside the away goal in env 0 (HOME scores) and off the court in env 2
   bq = task._ball_q
   phys.field('qpos')[bq:bq + 3, 0] = torch.tensor([37.0, 0.0, 1.0], dtype=torch.float64)

@@ -161,11 +161,16 @@ def test_soccer_environment_on_gpu():
     ts = env.step(torch.rand((B, 4, 3), device='cuda', generator=gen) * 2 - 1)
   assert env.launches - l0 == 50
   torch.cuda.synchronize()
-  hb = m.name2id('away1/head_body', 'body')
-  pos = phys.field('xpos')[3*hb:3*hb + 3, 3].cpu().double().numpy()
-  R = phys.field('xmat')[9*hb:9*hb + 9, 3].cpu().double().numpy().reshape(3, 3)
-  ball = task.ball_xpos(phys)[:, 3].cpu().double().numpy()
-  np.testing.assert_allclose(ts.observation['ball_ego_position'][3, 3].cpu().numpy(), (ball - pos) @ R, atol=2e-5)
+  # the framepos sensor objtype = reftype = "body" (observables.py:182-186): between the bodies' INERTIAL frames
+  from dm_control_amd import mjcf_compiler
+
+  def inertial(name, e):
+    b = m.name2id(name, 'body')
+    pos = phys.field('xpos')[3*b:3*b + 3, e].cpu().double().numpy()
+    R = phys.field('xmat')[9*b:9*b + 9, e].cpu().double().numpy().reshape(3, 3)
+    return pos + R @ m.body_ipos[b], R @ mjcf_compiler.quat_to_mat(m.body_iquat[b])
+  (hp, hR), (bp, _) = inertial('away1/head_body', 3), inertial('soccer_ball/', 3)
+  np.testing.assert_allclose(ts.observation['ball_ego_position'][3, 3].cpu().numpy(), (bp - hp) @ hR, atol=2e-5)
   assert float(ts.reward.abs().max()) == 0.0
   bq = task._ball_q
   q = phys.field('qpos')

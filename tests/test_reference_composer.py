@@ -82,3 +82,54 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
   assert r.last() and int(o.step_type[0]) == ours_env.LAST and float(r.discount) == 0.0 == float(o.discount[0])
   r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64))
   assert r.first() and int(o.step_type[0]) == ours_env.FIRST
+
+
+def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(engine, oracle_backend):
+  """locomotion/soccer (task.py, pitch.py detectors with their after_substep hook, soccer_ball.py, boxhead.py, the
+  CoreObservablesAdder observables of observables.py) unmodified on the facade, four agents, against
+  `dm_control_amd.composer.tasks.soccer.Soccer2v2` (BASELINE config 5) from the same state.  Here the reference's one
+  mj_forward per control step happens inside the FIRST substep's after_substep hook (the goal detectors read xpos
+  through a binding while the physics is still dirty from the action), so the acceleration-stage sensors of the
+  observation are the last substep's -- what the device composer reports without an extra launch."""
+  from composer_fake import OracleDevicePhysics
+  from dm_control_amd.composer import environment as ours_env
+  from dm_control_amd.composer.tasks import soccer
+  ref_task = rp.soccer_2v2_boxhead(randomizer=lambda random_state=None: 0.5)      # the 40 x 30 pitch of the config-5 asset
+  ref = engine.Environment(task=ref_task, time_limit=45.0, random_state=np.random.RandomState(5),
+                           strip_singleton_obs_buffer_dim=True)
+  ref.reset()
+  task = soccer.Soccer2v2()
+  assert not getattr(task, 'observation_forward', False)
+  phys = OracleDevicePhysics(task.model, 1, outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), nconmax=24)
+  env = ours_env.Environment(task, phys, time_limit=45.0, random_state=1)
+  env.reset()
+  m, rm = task.model, ref.physics.model
+  assert (rm.nq, rm.nv, rm.nu, rm.nbody, rm.ngeom) == (m.nq, m.nv, m.nu, m.nbody, m.ngeom) and env.n_sub_steps == 5
+  assert list(rm.names['joint']) == list(m.names['joint'])
+  phys.field('qpos')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qpos))
+  phys.field('qvel')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qvel))
+  phys.mark_as_dirty()
+  phys.forward(disable_actuation=True)
+  order = [p.walker.mjcf_model.model for p in ref_task.players]      # the reference's agent order
+  mine = list(soccer._PLAYERS)
+  assert sorted(order) == sorted(mine)
+  rs = np.random.RandomState(2)
+  seen = set()
+  for t in range(6):
+    a = rs.uniform(-1, 1, (4, 3))
+    r = ref.step([a[mine.index(n)] for n in order])
+    o = env.step(torch.from_numpy(a[None]))
+    assert int(r.step_type) == int(o.step_type[0])
+    for i, n in enumerate(order):
+      k = mine.index(n)
+      assert float(np.asarray(r.reward[i])) == float(o.reward[k, 0]), (t, n)
+      for key, val in r.observation[i].items():
+        if key not in o.observation:
+          continue
+        np.testing.assert_allclose(o.observation[key][0, k].numpy().ravel(), np.asarray(val, dtype=np.float64).ravel(),
+                                   rtol=0, atol=1e-8, err_msg='%s %s step %d' % (n, key, t))      # (the reference's extra mj_forward inside the first substep leaves the solver a different path to the same optimum: 2e-9 on the accelerometer)
+        seen.add(key)
+    assert float(r.discount) == float(o.discount[0])
+  assert {'sensors_accelerometer', 'sensors_gyro', 'sensors_velocimeter', 'ball_ego_position', 'ball_ego_linear_velocity',
+          'teammate_0_ego_position', 'opponent_1_ego_orientation', 'team_goal_mid', 'field_front_left', 'joints_pos',
+          'world_zaxis', 'body_height', 'stats_vel_to_ball', 'stats_vel_ball_to_goal'} <= seen, sorted(seen)
