@@ -348,6 +348,9 @@ class Soccer2v2(environment.Task):
     corner_names = ['team_goal_back_right', 'team_goal_mid', 'team_goal_front_left', 'field_front_left',
                     'opponent_goal_back_left', 'opponent_goal_mid', 'opponent_goal_front_right', 'field_back_right']
     dist_to_ball = [torch.linalg.norm(ball - frames[k][0], dim=0) for k in range(4)]
+    # arena.detected_goal() (pitch.py:574-580): the home goal is looked at first -- the ball in it means AWAY scored
+    away_goal_scored = self.home_goal.detected
+    home_goal_scored = self.away_goal.detected & ~away_goal_scored
     for k, p in enumerate(_PLAYERS):
       pos, R = frames[k]
       a, av, s = self._q[p], self._v[p], self._sens[p]
@@ -400,6 +403,15 @@ class Soccer2v2(environment.Task):
       nrm = torch.linalg.norm(direction, dim=0)
       ndir = torch.where(nrm[None, :] > 0, direction / nrm.clamp_min(1e-30), direction)
       put('stats_vel_ball_to_goal', (ndir * blin).sum(dim=0))
+      # observables.py:331-375
+      dists = [torch.linalg.norm(pos - frames[j][0], dim=0) for j in mates]
+      avg = torch.stack(dists).mean(dim=0) if dists else torch.zeros(B, dtype=physics.dtype, device=physics.device)
+      put('stats_home_avg_teammate_dist', avg)
+      put('stats_teammate_spread_out', (avg > 5.).to(physics.dtype))
+      mine_scored = home_goal_scored if _TEAM[k] == 0 else away_goal_scored
+      theirs_scored = away_goal_scored if _TEAM[k] == 0 else home_goal_scored
+      put('stats_home_score', mine_scored.to(physics.dtype))
+      put('stats_away_score', theirs_scored.to(physics.dtype))
     return {name: torch.stack(v, dim=1) for name, v in out.items()}            # (B, 4, n)
 
 

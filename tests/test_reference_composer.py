@@ -124,8 +124,7 @@ def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(en
       k = mine.index(n)
       assert float(np.asarray(r.reward[i])) == float(o.reward[k, 0]), (t, n)
       for key, val in r.observation[i].items():
-        if key not in o.observation:
-          continue
+        assert key in o.observation, key      # every observable the reference's agent gets
         np.testing.assert_allclose(o.observation[key][0, k].numpy().ravel(), np.asarray(val, dtype=np.float64).ravel(),
                                    rtol=0, atol=1e-8, err_msg='%s %s step %d' % (n, key, t))      # (the reference's extra mj_forward inside the first substep leaves the solver a different path to the same optimum: 2e-9 on the accelerometer)
         seen.add(key)
