@@ -142,7 +142,7 @@ def test_reload_from_data_hook_runs_at_construction_and_reload(oracle_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('prec,tol', [(64, 1e-9), (32, 5e-4)])
+@pytest.mark.parametrize('prec,tol', [(64, 1e-9), (32, 2e-3)])      # (fp32: a sphere rolling down a tilted box for 180 steps)
 def test_device_geom_frames_and_sizes_rewritten_between_steps(prec, tol):
   """dmc_batch_set_model_real("geom_pos" / "geom_quat" / "geom_size"): a world-fixed, COLLIDING geom (a ledge under a
   falling puck) is moved, tilted and resized between steps; trajectories and geom poses against oracles whose model arrays
