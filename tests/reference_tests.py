@@ -95,6 +95,18 @@ def _parameters(*cases):
   return deco
 
 
+def _named_parameters(*cases):
+  if len(cases) == 1 and not isinstance(cases[0], (tuple, dict, str)) and hasattr(cases[0], '__iter__'):
+    cases = tuple(cases[0])
+  stripped = []
+  for c in cases:
+    if isinstance(c, dict):
+      stripped.append({k: v for k, v in c.items() if k != 'testcase_name'})
+    else:
+      stripped.append(tuple(c[1:]))      # (name, *args)
+  return _parameters(*stripped) if len(stripped) != 1 else _parameters(stripped)
+
+
 def _install(modules):
   saved = {}
 
@@ -106,6 +118,7 @@ def _install(modules):
   absltest, parameterized = types.ModuleType('absl.testing.absltest'), types.ModuleType('absl.testing.parameterized')
   absltest.TestCase, absltest.main, absltest.mock = _TestCase, (lambda *a, **k: None), _mock
   parameterized.TestCase, parameterized.parameters = _TestCase, _parameters
+  parameterized.named_parameters = _named_parameters
   absl.testing, testing.absltest, testing.parameterized = testing, absltest, parameterized
   for n, m in (('absl', absl), ('absl.testing', testing), ('absl.testing.absltest', absltest),
                ('absl.testing.parameterized', parameterized), ('mock', _mock)):

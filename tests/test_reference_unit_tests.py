@@ -59,3 +59,52 @@ def test_reference_suite_test_passes_on_this_suite(oracle_backend, group):
   skip = _SUITE_SKIP + tuple('SuiteTest.' + g for g in _SUITE_GROUPS if g != group)
   result, report = reference_tests.run('suite/suite_test.py', _suite_modules(), skip=skip)
   _check(result, report, 1)
+
+
+def _exec_reference_module(name, rel):
+  import importlib.util
+  import sys
+  spec = importlib.util.spec_from_file_location(name, reference_tests.REF + '/' + rel)
+  mod = importlib.util.module_from_spec(spec)
+  sys.modules[name] = mod
+  spec.loader.exec_module(mod)
+  return mod
+
+
+@pytest.mark.parametrize('wrapper', ['action_scale', 'action_noise'])
+def test_reference_action_wrappers_and_their_tests_on_this_packages_environment(oracle_backend, wrapper):
+  """suite/wrappers/action_scale.py / action_noise.py are pure dm_env wrappers: executed unmodified over this package's
+  dm_env shim they (a) pass their own unit tests with `dm_control.rl.control` = envs/control.py and (b) wrap an actual
+  `suite.load` environment of this package."""
+  import sys
+  import numpy as np
+  from dm_control_amd import suite
+  from dm_control_amd.envs import control, dm_env_api
+  saved = {k: sys.modules.get(k) for k in ('dm_env', 'dm_env.specs')}
+  sys.modules['dm_env'], sys.modules['dm_env.specs'] = dm_env_api, dm_env_api.specs
+  try:
+    mod = _exec_reference_module('dm_control.suite.wrappers.' + wrapper, 'suite/wrappers/%s.py' % wrapper)
+    result, report = reference_tests.run('suite/wrappers/%s_test.py' % wrapper,
+                                         {'dm_control.rl.control': control, 'dm_control.suite.wrappers.' + wrapper: mod})
+    _check(result, report, 4)
+    env = suite.load('cheetah', 'run', task_kwargs=dict(random=0))
+    if wrapper == 'action_scale':
+      wrapped = mod.Wrapper(env, minimum=-5., maximum=5.)
+      spec = wrapped.action_spec()
+      assert spec.minimum.min() == -5 and spec.maximum.max() == 5 and spec.shape == (6,)
+      wrapped.reset()
+      wrapped.step(np.full(6, 5.0))      # +5 maps to the cheetah's +1
+      np.testing.assert_allclose(env.physics.data.ctrl, np.ones(6))
+    else:
+      wrapped = mod.Wrapper(env, scale=0.1)      # (its noise comes from the TASK's RandomState)
+      wrapped.reset()
+      ts = wrapped.step(np.zeros(6))
+      ctrl = np.array(env.physics.data.ctrl)
+      assert ts.reward is not None and 0 < np.abs(ctrl).max() < 1.0      # noise of 0.1 x the range, clipped into it
+  finally:
+    sys.modules.pop('dm_control.suite.wrappers.' + wrapper, None)
+    for k, v in saved.items():
+      if v is None:
+        sys.modules.pop(k, None)
+      else:
+        sys.modules[k] = v
