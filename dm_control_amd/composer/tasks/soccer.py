@@ -331,7 +331,6 @@ class Soccer2v2(environment.Task):
     sd, q, v = physics.field('sensordata'), physics.field('qpos'), physics.field('qvel')
     ball = self.ball_xpos(physics)
     blin = sd[self._ball_linvel:self._ball_linvel + 3]
-    bang = sd[self._ball_angvel:self._ball_angvel + 3]
     frames = [self._frame(physics, k) for k in range(4)]
     cvel = physics.field('cvel')
     out = {}

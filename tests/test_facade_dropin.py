@@ -202,7 +202,7 @@ def test_model_disable_and_option_edits_reach_the_physics(oracle_backend):
   phys.step()
   assert abs(phys.data.time - t0 - 0.01) < 1e-12 and phys.timestep() == 0.01
   phys.model.opt.gravity[2] = +9.81      # an in-place edit of the gravity vector is seen as well
-  zz = z(); v0 = float(phys.named.data.qvel['free'][2])
+  v0 = float(phys.named.data.qvel['free'][2])
   phys.step()
   assert float(phys.named.data.qvel['free'][2]) > v0
   with pytest.raises(ValueError, match='not a valid flag name'):

@@ -39,7 +39,7 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
                            strip_singleton_obs_buffer_dim=True)
   assert type(ref).__module__ == 'dm_control.composer.environment'
   assert ref.physics.__class__.__module__ == 'dm_control.mjcf.physics' and ref.physics.view_semantics
-  ts = ref.reset()
+  ref.reset()
   env, task, phys = _ours()
   env.reset()
   m = task.model

@@ -55,7 +55,7 @@ def test_reference_domain_module_unmodified_equals_the_task_port(ref_suite, orac
   from dm_control_amd import suite
   mod = ref_suite.load(domain)
   assert mod.__file__.startswith('/root/reference/') and task in mod.SUITE
-  seed, limit = 11, None
+  seed = 11
   ref_env = mod.SUITE[task](random=seed)
   ours = suite.load(domain, task, task_kwargs=dict(random=seed))
   assert type(ref_env).__module__ == 'dm_control.rl.control' and type(ref_env.task).__module__ == 'dm_control.suite.' + domain
