@@ -129,6 +129,20 @@ def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(en
                                    rtol=0, atol=1e-8, err_msg='%s %s step %d' % (n, key, t))      # (the reference's extra mj_forward inside the first substep leaves the solver a different path to the same optimum: 2e-9 on the accelerometer)
         seen.add(key)
     assert float(r.discount) == float(o.discount[0])
+  # a goal: the ball inside the away goal -> HOME scores; rewards, discount and the end of the episode, both stacks
+  bq, bv = task._ball_q, task._ball_v
+  q = np.array(ref.physics.data.qpos); v = np.array(ref.physics.data.qvel)
+  q[bq:bq + 3] = [37.0, 0.0, 1.0]; v[bv:bv + 6] = 0
+  ref.physics.data.qpos[:] = q; ref.physics.data.qvel[:] = v
+  phys.field('qpos')[:, 0] = torch.from_numpy(q); phys.field('qvel')[:, 0] = torch.from_numpy(v)
+  phys.mark_as_dirty()
+  r = ref.step([np.zeros(3)] * 4)
+  o = env.step(torch.zeros((1, 4, 3), dtype=torch.float64))
+  assert r.last() and int(o.step_type[0]) == ours_env.LAST and float(r.discount) == 0.0 == float(o.discount[0])
+  want = {n: float(np.asarray(r.reward[i])) for i, n in enumerate(order)}
+  assert sorted(want.values()) == [-1.0, -1.0, 1.0, 1.0]
+  for k, n in enumerate(mine):
+    assert float(o.reward[k, 0]) == want[n], n
   assert {'sensors_accelerometer', 'sensors_gyro', 'sensors_velocimeter', 'ball_ego_position', 'ball_ego_linear_velocity',
           'teammate_0_ego_position', 'opponent_1_ego_orientation', 'team_goal_mid', 'field_front_left', 'joints_pos',
           'world_zaxis', 'body_height', 'stats_vel_to_ball', 'stats_vel_ball_to_goal'} <= seen, sorted(seen)
