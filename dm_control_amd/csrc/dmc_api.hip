@@ -730,7 +730,7 @@ extern "C" int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double val
   if (!b || !name) return fail("null argument");
   StepOpts<double>& o = b->tb.opts;
   if (bump_epoch(b, 0, true)) return -2;
-  if (!strcmp(name, "timestep")) o.timestep = value;
+  if (!strcmp(name, "timestep")) { o.timestep = value; o.timestep_d = value; }   // timestep_d: what data.time advances by
   else if (!strcmp(name, "tolerance")) o.tolerance = value;
   else if (!strcmp(name, "ls_tolerance")) o.ls_tolerance = value;
   else if (!strcmp(name, "noslip_tolerance")) o.noslip_tolerance = value;
@@ -905,8 +905,9 @@ extern "C" int dmc_batch_debug_get(dmc_batch* b, const char* scratch_name, int e
 // suite/utils/randomizers.py:35-88 (randomize_limited_and_rotational_joints) and the draws of
 // suite/cheetah.py:66-69 / suite/quadruped.py:_find_non_contacting_height for a whole batch, without a host round
 // trip and without a finite pool of start states: a counter-based generator (Philox4x32-10, Salmon et al. 2011) keyed
-// by (seed, env) with counter (draw number of the env, joint, block) -- every (env, episode, joint) has its own
-// stream whatever the batch size, launch order or mask.
+// by the 64-bit seed with counter (draw number of the env, joint, block, env) -- every (env, episode, joint) has its own
+// stream whatever the batch size, launch order or mask, and different seeds give different streams for every env
+// (keying by seed ^ env made seeds below B permutations of one another).
 struct Philox { uint32_t c[4]; };
 __host__ __device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   for (int r = 0; r < 10; r++) {
@@ -931,11 +932,11 @@ __global__ void __launch_bounds__(256) randomize_joints_kernel(T* __restrict__ q
   if (env >= B || (mask && !mask[env])) return;
   const uint32_t k = (uint32_t)draw[env];
   draw[env] = (int)(k + 1);
-  const uint32_t key0 = seed_lo ^ (uint32_t)env, key1 = seed_hi;
+  const uint32_t key0 = seed_lo, key1 = seed_hi, cenv = (uint32_t)env;   // key = the seed alone; env is a counter word
   for (int j = 0; j < njnt; j++) {
     const int type = ji[j], adr = ji[njnt + j], limited = ji[2*njnt + j];
     const double lo = jr[2*j], hi = jr[2*j + 1];
-    const Philox x = philox4x32_10(k, (uint32_t)j, 0u, 0u, key0, key1);
+    const Philox x = philox4x32_10(k, (uint32_t)j, 0u, cenv, key0, key1);
     if (type == DMC_JNT_HINGE || type == DMC_JNT_SLIDE) {
       if (limited) { if (flags & DMC_RAND_LIMITED) qpos[(size_t)adr*B + env] = (T)(lo + (hi - lo) * philox_u01(x.c[0])); }
       else if (type == DMC_JNT_HINGE && (flags & DMC_RAND_UNLIMITED_HINGE))
@@ -943,7 +944,7 @@ __global__ void __launch_bounds__(256) randomize_joints_kernel(T* __restrict__ q
     } else if (type == DMC_JNT_BALL && limited) {
       if (!(flags & DMC_RAND_LIMITED)) continue;
       // random_limited_quaternion: axis ~ normalised N(0, I), angle ~ U(0, range max)
-      const Philox y = philox4x32_10(k, (uint32_t)j, 1u, 0u, key0, key1);
+      const Philox y = philox4x32_10(k, (uint32_t)j, 1u, cenv, key0, key1);
       double n[4];
       box_muller(philox_u01(x.c[0]), philox_u01(x.c[1]), &n[0], &n[1]);
       box_muller(philox_u01(x.c[2]), philox_u01(x.c[3]), &n[2], &n[3]);

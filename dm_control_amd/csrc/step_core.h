@@ -617,6 +617,7 @@ struct StepCore {
   int* si;
   int lane;
   double time_;           // simulation time of this env (group-uniform)
+  int epoch_;             // the stash epoch at launch entry (Entry::epoch)
 
 
   DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
@@ -663,7 +664,7 @@ struct StepCore {
   DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
     env = late(env);
     const int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
-    if (hi[0] != *io.epoch) return false;      // group-uniform: never written, or written before the last host edit
+    if (hi[0] != epoch_) return false;      // group-uniform: never written, or written before the last host edit
     const T* hr = io.stash_r + (size_t)env*L.n_keep;
     FOR_LANES(i, L.n_keep) s[i] = hr[i];
     FOR_LANES(i, L.n_si) si[i] = hi[4 + i];
@@ -678,7 +679,7 @@ struct StepCore {
       FOR_LANES(i, L.n_keep) hr[i] = s[i];
       FOR_LANES(i, L.n_si) hi[4 + i] = si[i];
     }
-    if (lane == 0) hi[0] = valid ? *io.epoch : 0;
+    if (lane == 0) hi[0] = valid ? epoch_ : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
   }
   // ---- kinematic stash ------------------------------------------------------------------------------------------
   // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
@@ -690,7 +691,7 @@ struct StepCore {
   DMC_DEV int kin_count() const { return L.s_qM - L.s_xpos; }
   DMC_DEV bool load_kstash(const StepIO<T>& io, int env) {
     env = late(env);
-    if (io.kstash_i[env] != *io.epoch) return false;
+    if (io.kstash_i[env] != epoch_) return false;
     const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
     const T* h = io.kstash + (size_t)env*(nq + nv + nk);
     int bad = 0;
@@ -709,7 +710,7 @@ struct StepCore {
     FOR_LANES(i, nq) h[i] = S(qpos)[i];
     FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
-    if (lane == 0) io.kstash_i[env] = *io.epoch;
+    if (lane == 0) io.kstash_i[env] = epoch_;
   }
   // ---- launch-entry loads ------------------------------------------------------------------------------------------
   // Everything a launch reads from HBM before it can start -- the env's launch override, its state, the tag of its
@@ -721,7 +722,7 @@ struct StepCore {
   // kinematics pass overwrites it.  Lane i carries element i of every field: models with more than LPE coordinates,
   // and launches that use the full stash (whose copy of the state would overwrite this one), keep the in-place loads.
   static constexpr int kPFKin = LS::kNKin > 0 ? ((LS::kNKin + LPE - 1) / LPE < 24 ? (LS::kNKin + LPE - 1) / LPE : 24) : 0;
-  struct Entry { int em, fast, kvalid; };
+  struct Entry { int em, fast, kvalid, epoch; };
   struct EntryRegs {
     T qpos, qvel, warm, qfrc, ctrl, act, kq, kv;
     int ktag, epoch;
@@ -734,6 +735,7 @@ struct StepCore {
                                   int legacy, Entry* e, EntryRegs* r) {
     e->em = io.env_mode ? io.env_mode[env] : 0;
     e->kvalid = 0;
+    e->epoch = *io.epoch;      // read ONCE per launch: the tags this launch writes carry the epoch it started in
 #if defined(DMC_HOST_EMU) || defined(DMC_NO_ENTRY_LOADS)
     e->fast = 0;
 #else
@@ -750,7 +752,7 @@ struct StepCore {
     r->ctrl = lane < L.d.nu ? io.ctrl[lane*B + env] : (T)0;
     r->act = (L.d.na && lane < L.d.na) ? io.act[lane*B + env] : (T)0;
     if (!kstash_applies(o, io, mode, legacy)) return;
-    r->ktag = io.kstash_i[env]; r->epoch = *io.epoch;
+    r->ktag = io.kstash_i[env]; r->epoch = e->epoch;
     const int nk = L.s_qM - L.s_xpos;
     const T* h = io.kstash + (size_t)env*(nq + nv + nk);
     r->kq = lane < nq ? h[lane] : (T)0;
@@ -1275,19 +1277,19 @@ struct StepCore {
     DMC_WSYNC();
   }
 #endif
-  DMC_DEV void factor_M(bool with_damping) {
+  DMC_DEV void factor_M(bool with_damping, const T* damping = nullptr) {      // damping: the diagonal added as timestep * damping[i]
     T* dst = with_damping ? S(qLH) : M_factor();
 #if !defined(DMC_HOST_EMU) && !defined(DMC_NO_FACTOR_ROWS)
     if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
       if (!L.d.msparse) {
-        factor_dense_rows<LS::kNV>(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
+        factor_dense_rows<LS::kNV>(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
         DMC_PROF(PROF_X3);
         if (!with_damping && L.d.jglobal && L.d.nslip) { DMC_GLB T* g = (DMC_GLB T*)gLM(); FOR_LANES(k, L.d.ntri) g[k] = dst[k]; }
         return;
       }
     }
 #endif
-    scatter_M(with_damping ? MR(dof_damping) : (const T*)nullptr, o.timestep, dst);
+    scatter_M(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
     DMC_PROF(PROF_X3);
     chol_factor_inplace(dst, L.d.nv);
     if (!with_damping && L.d.jglobal && L.d.nslip) {
@@ -4618,6 +4620,31 @@ struct StepCore {
     const int nv = L.d.nv;
     const T dt = o.timestep;
     const T* qacc = S(qacc);
+    const bool implicitfast = o.integrator == DMC_INT_IMPLICITFAST;
+    if (implicitfast) {
+      // mj_implicit, mjINT_IMPLICITFAST: (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint with the velocity
+      // derivatives of the passive and actuator forces and no Coriolis term.  The supported model class (the MJCF
+      // compiler and make_dims refuse damped tendons, velocity-dependent tendon actuators and fluid forces with this
+      // integrator) leaves dF/dv DIAGONAL: -dof_damping[i] (mjd_passive_vel) + gear^2 (biasprm[2] + gainprm[2] u) of
+      // every actuator on dof i whose force is strictly inside its forcerange (mjd_actuator_vel).  The matrix is
+      // always factored: mj_Euler's "any damping" shortcut and mjDSBL_EULERDAMP do not apply.
+      // (evaluated before the activations advance: u is the activation the force was computed from)
+      FOR_LANES(i, nv) {
+        T dd = (o.disableflags & DMC_DSBL_DAMPER) ? (T)0 : MR(dof_damping)[i];
+        if (!(o.disableflags & DMC_DSBL_ACTUATION)) for (int a = 0; a < L.d.nu; a++) {
+          const int fl = MI(act_flags)[a];
+          if ((fl & ACTF_TENDON) || MI(act_dof)[a] != i) continue;
+          if (fl & ACTF_FORCELIMITED) { const T f = S(actuator_force)[a]; if (f <= MRC(act_forcerange)[2*a] || f >= MRC(act_forcerange)[2*a + 1]) continue; }
+          T bv = (fl & ACTF_BIAS_AFFINE) ? MRC(act_biasprm)[3*a + 2] : (T)0;
+          const T gv = (fl & ACTF_GAIN_AFFINE) ? MRC(act_gainprm)[3*a + 2] : (T)0;
+          if (gv != 0) bv += gv * ((L.d.na && (fl & ACTF_DYN_ANY)) ? S(act)[MI(act_adr)[a]] : S(ctrl)[a]);
+          const T gear = MRC(act_gear)[a];
+          dd -= gear*gear*bv;
+        }
+        S(sv_search)[i] = dd;
+      }
+      DMC_WSYNC();
+    }
     // activations first (mj_advance): explicit Euler, or the exact exponential for filterexact
     if (L.d.na) FOR_LANES(i, L.d.nu) {
       const int fl = MI(act_flags)[i];
@@ -4628,10 +4655,10 @@ struct StepCore {
         if (fl & ACTF_ACTLIMITED) S(act)[k] = t_max(MRC(act_actrange)[2*i], t_min(MRC(act_actrange)[2*i + 1], S(act)[k]));   // mj_nextActivation
       }
     }
-    if (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER))) {
+    if (implicitfast || (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER)))) {
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
       DMC_WSYNC();
-      factor_M(true);
+      factor_M(true, implicitfast ? S(sv_search) : MR(dof_damping));
       chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
       qacc = S(sv_Mgrad);
     }
@@ -4835,6 +4862,7 @@ struct StepCore {
   DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask, const Entry& en) {
     const bool stash = io.stash_r != nullptr;
     bool have = false;
+    epoch_ = en.epoch;
     if (mode == 5 && stash) have = load_stash(io, env);
     load_state(io, env, have, en);
     if (mode == 4) {
@@ -4870,6 +4898,7 @@ struct StepCore {
   // en: what entry_issue / entry_commit left for this env and the launch's (mode, legacy)
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en) {
     const int launch_mode = mode;
+    epoch_ = en.epoch;
     if (io.env_mode) {
       const int em = en.em;
       if (em == 2) return;

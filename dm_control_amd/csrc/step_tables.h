@@ -80,12 +80,22 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (m.actuator_dyntype[i] != DMC_DYN_NONE) d.na++;
   }
   if (d.na != m.na) { *err = "model na does not match the number of actuators with dynamics"; return false; }
-  if (d.na && m.opt_integrator != DMC_INT_EULER) { *err = "actuator dynamics are only implemented with the Euler integrator"; return false; }
+  if (d.na && m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_IMPLICITFAST) { *err = "actuator dynamics are only implemented with the Euler and implicitfast integrators"; return false; }
   if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
   if (m.ngeom > 65535) { *err = "kernel supports ngeom <= 65535"; return false; }
   if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
   const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
-  if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4) { *err = "only the Euler and RK4 integrators are implemented in the HIP path"; return false; }
+  if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4 && m.opt_integrator != DMC_INT_IMPLICITFAST) { *err = "only the Euler, RK4 and implicitfast integrators are implemented in the HIP path"; return false; }
+  if (m.opt_integrator == DMC_INT_IMPLICITFAST) {
+    // the integration matrix M - h dF/dv is built with the DIAGONAL velocity derivatives only (StepCore::euler_state)
+    if (m.opt_density > 0 || m.opt_viscosity > 0) { *err = "implicitfast with fluid forces is not implemented"; return false; }
+    for (int t = 0; t < m.ntendon; t++) if (m.tendon_damping[t] > 0) { *err = "implicitfast with damped tendons is not implemented"; return false; }
+    for (int i = 0; i < m.nu; i++) {
+      const bool vel = (m.actuator_biastype[i] == DMC_BIAS_AFFINE && m.actuator_biasprm[10*i + 2] != 0) ||
+                       (m.actuator_gaintype[i] == DMC_GAIN_AFFINE && m.actuator_gainprm[10*i + 2] != 0);
+      if (vel && m.actuator_trntype[i] != DMC_TRN_JOINT) { *err = "implicitfast: velocity-dependent actuator on a tendon transmission is not implemented"; return false; }
+    }
+  }
   d.rk4 = m.opt_integrator == DMC_INT_RK4 ? 1 : 0;
   std::vector<int> fric_dof;
   for (int i = 0; i < m.nv; i++) {

@@ -538,7 +538,13 @@ class _Compiler:
       if 'gravity' in a:
         o.gravity = _vec(a['gravity'], 3)
       if 'integrator' in a:
-        o.integrator = {'Euler': 0, 'RK4': 1, 'implicit': 2, 'implicitfast': 3}[a['integrator']]
+        if a['integrator'] == 'implicit':
+          # mjINT_IMPLICIT needs the Coriolis derivative (mjd_rne_vel) and an LU factorisation of a non-symmetric matrix:
+          # refused by name rather than stepped with another integrator
+          raise MjcfError('integrator="implicit" is not implemented (Euler, RK4 and implicitfast are)')
+        if a['integrator'] not in ('Euler', 'RK4', 'implicitfast'):
+          raise MjcfError('unknown integrator %r' % a['integrator'])
+        o.integrator = {'Euler': 0, 'RK4': 1, 'implicitfast': 3}[a['integrator']]
       if 'cone' in a:
         o.cone = {'pyramidal': 0, 'elliptic': 1}[a['cone']]
       if 'solver' in a:
@@ -617,7 +623,10 @@ class _Compiler:
         self._parse_site(child, bid, childclass)
       elif tag == 'light':
         # rendering only: kept as host-side model arrays because tasks move lights (light_pos, suite/swimmer.py)
-        a = dict(self.classes[child.attrib.get('class', childclass) or 'main'].get('light') or {})
+        cname = child.attrib.get('class', childclass) or 'main'
+        if cname not in self.classes:
+          raise MjcfError('unknown default class %r' % cname)
+        a = dict(self.classes[cname].get('light') or {})
         a.update(child.attrib)
         self.lights.append(dict(name=a.get('name'), body=bid, pos=_vec(a['pos'], 3) if 'pos' in a else np.zeros(3),
                                 dir=_vec(a['dir'], 3) if 'dir' in a else np.array([0.0, 0, -1])))
@@ -1334,8 +1343,22 @@ class _Compiler:
     m.names['actuator'] = names
     # one activation state per actuator with dynamics, in actuator order (mjModel.actuator_actadr)
     m.na = int(np.count_nonzero(m.actuator_dyntype))
-    if m.na and m.opt.integrator != 0:
-      raise MjcfError('actuator dynamics are only supported with the Euler integrator')
+    if m.na and m.opt.integrator not in (0, 3):
+      raise MjcfError('actuator dynamics are only supported with the Euler and implicitfast integrators')
+    if m.opt.integrator == 3:
+      # implicitfast: the velocity derivatives this backend folds into the integration matrix are the DIAGONAL ones
+      # (joint damping, joint-transmission actuators).  Terms that couple dofs -- damped tendons, tendon-transmission
+      # actuators with a velocity-dependent bias / gain -- and the fluid-force derivatives are refused, not dropped.
+      if m.opt.density > 0 or m.opt.viscosity > 0:
+        raise MjcfError('integrator="implicitfast" with fluid forces (density / viscosity) is not implemented')
+      if m.ntendon and np.any(np.asarray(m.tendon_damping) > 0):
+        raise MjcfError('integrator="implicitfast" with damped tendons is not implemented')
+      for i in range(nu):
+        vel_term = (m.actuator_biastype[i] == 1 and m.actuator_biasprm[i, 2] != 0) or \
+                   (m.actuator_gaintype[i] == 1 and m.actuator_gainprm[i, 2] != 0)
+        if vel_term and m.actuator_trntype[i] != 0:
+          raise MjcfError('integrator="implicitfast": actuator %r has a velocity-dependent force on a tendon '
+                          'transmission, which is not implemented' % names[i])
 
   def _sensors(self, m):
     ns = len(self.sensors)

@@ -466,7 +466,11 @@ class Physics(control.Physics):
       self.model.opt = _copy.copy(model.opt)      # option edits of this Physics (model.opt.*, model.disable) stay its own
       self.model.opt.gravity = np.array(model.opt.gravity, dtype=np.float64)
       for name, value in vars(model).items():
-        if isinstance(value, np.ndarray) and name not in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS:
+        if not isinstance(value, np.ndarray):
+          continue
+        if name in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS:
+          setattr(self.model, name, np.array(value))      # this Physics' own copy: its edits must not reach another Physics built from the same Model
+        else:
           view = value.view()
           view.setflags(write=False)
           setattr(self.model, name, view)

@@ -159,7 +159,7 @@ class TorchBatchedEnv:
     self._initialize_episode(mask)
     self._zero_rows(self.time, mask)
     self.steps.copy_(torch.where(mask, torch.zeros_like(self.steps), self.steps))
-    self.physics.invalidate()      # qpos / qvel were edited through the bound tensors
+    self.physics.invalidate(stream=self._stream())      # qpos / qvel were edited through the bound tensors (stream-ordered with the launches)
     if self._OUTPUTS:
       # refresh the derived arrays of the environments that were reset, and of those only: the others are left
       # untouched by the launch (env_mode 2), so their acceleration-stage sensors, warm starts and observations

@@ -2557,6 +2557,50 @@ static void euler(const Model* m, Data* d) {
     advance(m, d, qacc, NULL);
   } else advance(m, d, d->qacc, NULL);
 }
+/* mj_implicit for mjINT_IMPLICITFAST: (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint, where dF/dv keeps the
+ * velocity derivatives of the passive forces (mjd_passive_vel: -dof_damping on the diagonal, -b J_t' J_t per damped
+ * tendon) and of the actuator forces (mjd_actuator_vel: moment' (biasprm[2] + gainprm[2] * ctrl-or-act) moment for
+ * affine bias / gain, skipped for an actuator whose force sits on its forcerange) and drops the Coriolis term (that is
+ * what distinguishes it from mjINT_IMPLICIT), so the matrix stays symmetric positive definite and is Cholesky
+ * factored.  Unlike mj_Euler the solve always happens (no "any damping" shortcut, mjDSBL_EULERDAMP does not apply). */
+static void implicitfast(const Model* m, Data* d) {
+  int nv = m->nv; double h = m->opt_timestep;
+  double *H = d->w_H, *L = d->w_H + (size_t)nv*nv, *qfrc = d->w_grad, *qacc = d->w_Mgrad;
+  double* mom = (double*)calloc((size_t)nv + 1, sizeof(double));
+  memcpy(H, d->qM, sizeof(double) * (size_t)nv * (size_t)nv);
+  for (int i = 0; i < nv; i++) qfrc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+  if (!(m->opt_disableflags & DMC_DSBL_DAMPER)) {
+    for (int i = 0; i < nv; i++) H[i*nv + i] += h*m->dof_damping[i];
+    for (int t = 0; t < m->ntendon; t++) if (m->tendon_damping[t] > 0) {
+      memset(mom, 0, sizeof(double) * (size_t)nv);
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) mom[m->jnt_dofadr[m->wrap_objid[w]]] += m->wrap_prm[w];
+      for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) H[i*nv + j] += h*m->tendon_damping[t]*mom[i]*mom[j];
+    }
+  }
+  if (!(m->opt_disableflags & DMC_DSBL_ACTUATION)) for (int i = 0, kact = 0; i < m->nu; i++) {
+    const int stateful = m->actuator_dyntype[i] != DMC_DYN_NONE;
+    const int k = kact; kact += stateful;
+    if (m->actuator_forcelimited[i] && (d->actuator_force[i] <= m->actuator_forcerange[2*i] || d->actuator_force[i] >= m->actuator_forcerange[2*i + 1])) continue;
+    double bias_vel = 0, gain_vel = 0;
+    if (m->actuator_biastype[i] == DMC_BIAS_AFFINE) bias_vel = m->actuator_biasprm[10*i + 2];
+    if (m->actuator_gaintype[i] == DMC_GAIN_AFFINE) gain_vel = m->actuator_gainprm[10*i + 2];
+    if (gain_vel != 0) bias_vel += gain_vel * (stateful ? d->act[k] : d->ctrl[i]);
+    if (bias_vel == 0) continue;
+    memset(mom, 0, sizeof(double) * (size_t)nv);
+    if (m->actuator_trntype[i] == DMC_TRN_TENDON) {
+      int t = m->actuator_trnid[2*i];
+      for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; w++) mom[m->jnt_dofadr[m->wrap_objid[w]]] += m->actuator_gear[6*i] * m->wrap_prm[w];
+    } else mom[m->jnt_dofadr[m->actuator_trnid[2*i]]] = m->actuator_gear[6*i];
+    for (int a = 0; a < nv; a++) for (int b = 0; b < nv; b++) H[a*nv + b] -= h*bias_vel*mom[a]*mom[b];
+  }
+  free(mom);
+  chol_factor(L, H, nv);
+  chol_solve(qacc, L, qfrc, nv);
+  advance(m, d, qacc, NULL);
+}
+static void integrate(const Model* m, Data* d) {      /* mj_step / mj_step2: Euler, or mj_implicit for implicitfast */
+  if (m->opt_integrator == DMC_INT_IMPLICITFAST) implicitfast(m, d); else euler(m, d);
+}
 static void rk4(const Model* m, Data* d) {
   static const double A[9] = {0.5, 0, 0, 0, 0.5, 0, 0, 0, 1}, B[4] = {1.0/6, 1.0/3, 1.0/3, 1.0/6}, T[3] = {0.5, 0.5, 1};
   int nq = m->nq, nv = m->nv; double h = m->opt_timestep, time = d->time;
@@ -2589,14 +2633,14 @@ void ora_step1(const Model* m, Data* d) {
 void ora_step2(const Model* m, Data* d) {
   fwd_actuation(m, d); fwd_acceleration(m, d); fwd_constraint(m, d); sensor_acc(m, d);
   check_acc(m, d);
-  euler(m, d); /* mj_step2 always integrates with Euler (engine.py:149-154) */
+  integrate(m, d); /* mj_step2: mj_implicit for the implicit integrators, mj_Euler otherwise (RK4 never gets here: engine.py:149-154) */
 }
 void ora_step(const Model* m, Data* d, int nstep) {
   for (int s = 0; s < nstep; s++) {
     check_pos(m, d); check_vel(m, d);
     ora_forward(m, d);
     check_acc(m, d);
-    if (m->opt_integrator == DMC_INT_RK4) rk4(m, d); else euler(m, d);
+    if (m->opt_integrator == DMC_INT_RK4) rk4(m, d); else integrate(m, d);
   }
 }
 /* Physics.step(nstep) with legacy_step=True (engine.py:147-162) */

@@ -35,11 +35,11 @@ def randomize_joints(model, qpos, seed, draw, env_mask=None, flags=ALL):
     if env_mask is not None and not env_mask[env]:
       continue
     k = int(draw[env]); draw[env] = k + 1
-    key = ((seed & MASK) ^ env, (seed >> 32) & MASK)
+    key = (seed & MASK, (seed >> 32) & MASK)     # the seed alone; env is the fourth counter word
     for j in range(model.njnt):
       t, a, lim = int(model.jnt_type[j]), int(model.jnt_qposadr[j]), int(model.jnt_limited[j])
       lo, hi = model.jnt_range[j]
-      x = philox4x32_10((k, j, 0, 0), key)
+      x = philox4x32_10((k, j, 0, env), key)
       if t in (HINGE, SLIDE):
         if lim:
           if flags & LIMITED:
@@ -49,7 +49,7 @@ def randomize_joints(model, qpos, seed, draw, env_mask=None, flags=ALL):
       elif t == BALL and lim:
         if not flags & LIMITED:
           continue
-        y = philox4x32_10((k, j, 1, 0), key)
+        y = philox4x32_10((k, j, 1, env), key)
         n = np.array(box_muller(u01(x[0]), u01(x[1])) + box_muller(u01(x[2]), u01(x[3])))[:3]
         ang = u01(y[0]) * hi
         qpos[env, a] = np.cos(0.5 * ang)

@@ -13,7 +13,7 @@ import os
 import sys
 import types
 
-REF = '/root/reference/dm_control'
+from ref_root import REF  # noqa: E402  (/root/reference/dm_control, or the staged copy on the GPU box)
 
 
 def available():

@@ -30,7 +30,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-REF = '/root/reference/dm_control'
+from ref_root import REF  # noqa: E402  (/root/reference/dm_control, or the staged copy on the GPU box)
 _SAVED = None
 
 

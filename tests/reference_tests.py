@@ -15,7 +15,7 @@ import types
 import unittest
 from unittest import mock as _mock
 
-REF = '/root/reference/dm_control'
+from ref_root import REF  # noqa: E402  (/root/reference/dm_control, or the staged copy on the GPU box)
 
 
 def available():

@@ -240,3 +240,19 @@ def test_zero_xfrc_applied_is_not_uploaded_until_a_wrench_was(oracle_backend):
   assert sent[-1] == 'xfrc_applied' or 'xfrc_applied' in sent[-12:]      # the zeros were sent this time
   assert not np.asarray(phys.batch.get('xfrc_applied')).any()
   phys.free()
+
+
+def test_two_physics_from_one_model_do_not_share_their_writable_arrays(oracle_backend):
+  """A compiled Model may build several Physics (the comment in Physics.__init__ promises it): a write to one's
+  geom_pos / site_rgba must reach neither the caller's Model nor the other Physics."""
+  from dm_control_amd import physics as physics_lib
+  m = mc.compile_xml(ARM)
+  before = m.geom_pos.copy()
+  a, b = physics_lib.Physics(m), physics_lib.Physics(m)
+  a.named.model.geom_pos['target', 'x'] = .9
+  a.named.model.site_rgba['tip', 'a'] = .25
+  np.testing.assert_array_equal(m.geom_pos, before)
+  np.testing.assert_array_equal(b.model.geom_pos, before)
+  assert b.named.model.site_rgba['tip', 'a'] == .5 and a.named.model.site_rgba['tip', 'a'] == .25
+  assert a.named.model.geom_pos['target', 'x'] == .9
+  a.free(); b.free()

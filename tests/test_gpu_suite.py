@@ -243,6 +243,25 @@ def test_physics_facade_semantics():
   p.free(); q.free()
 
 
+def test_timestep_edit_moves_time_by_the_new_timestep():
+  """model.opt.timestep edited at run time (engine.py:326-333 reads it back as physics.timestep()): the dynamics AND
+  the time accumulator of the device use the new value (the accumulator keeps its own fp64 copy of dt)."""
+  from dm_control_amd import physics as pl
+  from dm_control_amd import suite
+  xml = suite.cheetah.get_model_and_assets()[0]
+  for precision in (64, 32):
+    p = pl.Physics.from_xml_string(xml, precision=precision)
+    dt0 = p.timestep()
+    p.step(3)
+    t0 = p.data.time
+    assert abs(t0 - 3 * dt0) < 1e-12
+    p.model.opt.timestep = 0.5 * dt0
+    p.step(4)
+    assert abs(p.data.time - t0 - 2 * dt0) < 1e-12, (p.data.time, t0, dt0)
+    assert p.timestep() == 0.5 * dt0
+    p.free()
+
+
 def test_batched_facade_matches_single():
   from dm_control_amd import physics as pl
   from dm_control_amd import suite

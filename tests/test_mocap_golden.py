@@ -12,7 +12,8 @@ from dm_control_amd import mjcf_compiler as mc
 from dm_control_amd.suite import common
 from oracle.oracle import OraclePhysics
 
-REF_XML = '/root/reference/dm_control/locomotion/walkers/assets/humanoid_CMU_V2019.xml'
+from ref_root import REF  # noqa: E402
+REF_XML = REF + '/locomotion/walkers/assets/humanoid_CMU_V2019.xml'
 
 
 def _check(model, root_joint, tol):

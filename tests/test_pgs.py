@@ -16,7 +16,8 @@ from dm_control_amd.suite import common
 from emu_lib import EmuPhysics
 from oracle.oracle import OraclePhysics
 
-REF_XML = '/root/reference/dm_control/mujoco/testing/assets/humanoid.xml'
+from ref_root import REF  # noqa: E402
+REF_XML = REF + '/mujoco/testing/assets/humanoid.xml'
 CT_FRICTION_DOF, CT_ELLIPTIC, CT_EQUALITY = 4, 3, 6
 
 

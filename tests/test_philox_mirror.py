@@ -59,3 +59,19 @@ def test_draw_rules_follow_the_reference_randomizer():
     qq = np.tile(qd.qpos0, (300, 1))
     pm.randomize_joints(qd, qq, seed=3, draw=np.zeros(300, int), flags=pm.QUATERNION | pm.FREE_NORMAL)
     assert (qq[:, 3:7] < 0).any() and abs(qq[:, 3:7].mean()) < 0.1
+
+
+def test_consecutive_seeds_are_independent_streams():
+  """Seeds 0, 1, 2 ... must not be permutations of one another over a power-of-two batch (keying by seed ^ env was)."""
+  from dm_control_amd import mjcf_compiler as mc
+  from dm_control_amd.suite import common
+  c = mc.compile_xml(common.read_model('cheetah.xml'))
+  B = 16
+  sets = []
+  for seed in (0, 1, 2, 5):
+    q = np.tile(c.qpos0, (B, 1))
+    pm.randomize_joints(c, q, seed=seed, draw=np.zeros(B, int), flags=pm.LIMITED)
+    sets.append({tuple(np.round(r, 12)) for r in q})
+  for i in range(len(sets)):
+    for j in range(i + 1, len(sets)):
+      assert not sets[i] & sets[j]

@@ -4,7 +4,9 @@ composer/observation/updater.py, locomotion/tasks/go_to_target.py, walkers/cmu_h
 arenas/floors.py -- executed from /root/reference by tests/reference_pymjcf.py over `dm_control_amd.physics.Physics`
 (CPU tier: the fp64 oracle stands in for the device) -- against this package's device-resident composer
 (`dm_control_amd.composer`, BASELINE config 4) started from the same state: every observation, reward, discount and
-step type of the episode.  Skips where the reference tree is absent (the GPU box)."""
+step type of the episode.  Each test also has a `hip` variant (`-m gpu`): the
+reference stack then steps through `libdmc_hip.so` (fp64 batch of one behind the facade) and the device composer is the
+product's `DevicePhysics` on the GPU; it needs the reference tree on the GPU box (scripts/stage_reference.sh, tests/ref_root.py)."""
 import sys
 
 import numpy as np
@@ -23,16 +25,39 @@ def engine():
   rp.unload()
 
 
-def _ours(B=1):
-  from composer_fake import OracleDevicePhysics
+BACKENDS = ['oracle', pytest.param('hip', marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def backend(request, monkeypatch):
+  """'oracle': the facade and the device composer both run on the CPU oracle stand-ins; 'hip': both run on the GPU."""
+  if request.param == 'oracle':
+    request.getfixturevalue('oracle_backend')
+  return request.param
+
+
+def _device_physics(backend, model, B, **kw):
+  if backend == 'oracle':
+    from composer_fake import OracleDevicePhysics
+    return OracleDevicePhysics(model, B, **kw)
+  from dm_control_amd.composer.physics import DevicePhysics
+  return DevicePhysics(model, B, precision=64, **kw)
+
+
+def _put(phys, name, values):
+  phys.field(name)[:, 0] = torch.from_numpy(np.asarray(values, dtype=np.float64)).to(phys.device)
+
+
+def _ours(backend, B=1):
   from dm_control_amd.composer import environment
   from dm_control_amd.composer.tasks import go_to_target
   task = go_to_target.GoToTarget()
-  phys = OracleDevicePhysics(task.model, B, outputs=('sensordata', 'xpos', 'xmat', 'contact_geom1'))
+  phys = _device_physics(backend, task.model, B, outputs=('sensordata', 'xpos', 'xmat', 'contact_geom1'))
   return environment.Environment(task, phys, time_limit=30.0, random_state=3), task, phys
 
 
-def test_reference_composer_environment_runs_unmodified_and_matches_the_device_composer(engine, oracle_backend):
+@pytest.mark.parametrize('backend', BACKENDS, indirect=True)
+def test_reference_composer_environment_runs_unmodified_and_matches_the_device_composer(engine, backend):
   from dm_control_amd.composer import environment as ours_env
   ref_task = rp.cmu2019_go_to_target()
   ref = engine.Environment(task=ref_task, time_limit=30.0, random_state=np.random.RandomState(7),
@@ -40,7 +65,7 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
   assert type(ref).__module__ == 'dm_control.composer.environment'
   assert ref.physics.__class__.__module__ == 'dm_control.mjcf.physics' and ref.physics.view_semantics
   ref.reset()
-  env, task, phys = _ours()
+  env, task, phys = _ours(backend)
   env.reset()
   m = task.model
   # the same model: this package's config-4 asset against what the reference composition compiled to
@@ -49,9 +74,9 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
   np.testing.assert_array_equal(rm.body_mass, m.body_mass)
   assert ref.control_timestep() == pytest.approx(env.control_timestep()) and ref.task.physics_steps_per_control_step == env.n_sub_steps
   # start this package's episode from the reference's initial state (the two draw from different generators)
-  phys.field('qpos')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qpos))
-  phys.field('qvel')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qvel))
-  task._target[:, 0] = torch.from_numpy(np.array(ref_task.target_position(ref.physics))[:2])
+  _put(phys, 'qpos', ref.physics.data.qpos)
+  _put(phys, 'qvel', ref.physics.data.qvel)
+  task._target[:, 0] = torch.from_numpy(np.array(ref_task.target_position(ref.physics))[:2]).to(phys.device)
   phys.mark_as_dirty()
   phys.forward(disable_actuation=True)
   spec = ref.action_spec()
@@ -60,7 +85,7 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
   seen = set()
   for t in range(10):
     a = rs.uniform(-1, 1, m.nu)
-    r, o = ref.step(a), env.step(torch.from_numpy(a[None]))
+    r, o = ref.step(a), env.step(torch.from_numpy(a[None]).to(phys.device))
     assert int(r.step_type) == int(o.step_type[0]), t
     assert float(r.reward) == float(o.reward[0]) and float(r.discount) == float(o.discount[0]), t
     for key, val in r.observation.items():
@@ -69,29 +94,29 @@ def test_reference_composer_environment_runs_unmodified_and_matches_the_device_c
       if val.size == 0:
         continue      # actuator_activation / sensors_force: nothing to observe on this walker
       assert short in o.observation, key
-      np.testing.assert_allclose(o.observation[short][0].numpy().ravel(), val.ravel(), rtol=0, atol=1e-11, err_msg='%s step %d' % (key, t))
+      np.testing.assert_allclose(o.observation[short][0].cpu().numpy().ravel(), val.ravel(), rtol=0, atol=1e-11 if backend == 'oracle' else 1e-8, err_msg='%s step %d' % (key, t))
       seen.add(short)
   assert {'joints_pos', 'joints_vel', 'end_effectors_pos', 'appendages_pos', 'sensors_touch', 'sensors_torque', 'target',
           'world_zaxis', 'body_height', 'sensors_gyro', 'sensors_velocimeter', 'sensors_accelerometer'} <= seen
   # the episode ends the reference's way too: lay both walkers down -> a non-foot geom touches the ground
   q = np.array(ref.physics.data.qpos); q[2] = 0.12; q[3:7] = [1, 0, 0, 0]
   ref.physics.data.qpos[:] = q      # (a write straight into the array the facade handed out: view semantics)
-  phys.field('qpos')[:, 0] = torch.from_numpy(q)
+  _put(phys, 'qpos', q)
   phys.mark_as_dirty()
-  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64))
+  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64, device=phys.device))
   assert r.last() and int(o.step_type[0]) == ours_env.LAST and float(r.discount) == 0.0 == float(o.discount[0])
-  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64))
+  r, o = ref.step(np.zeros(m.nu)), env.step(torch.zeros((1, m.nu), dtype=torch.float64, device=phys.device))
   assert r.first() and int(o.step_type[0]) == ours_env.FIRST
 
 
-def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(engine, oracle_backend):
+@pytest.mark.parametrize('backend', BACKENDS, indirect=True)
+def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(engine, backend):
   """locomotion/soccer (task.py, pitch.py detectors with their after_substep hook, soccer_ball.py, boxhead.py, the
   CoreObservablesAdder observables of observables.py) unmodified on the facade, four agents, against
   `dm_control_amd.composer.tasks.soccer.Soccer2v2` (BASELINE config 5) from the same state.  Here the reference's one
   mj_forward per control step happens inside the FIRST substep's after_substep hook (the goal detectors read xpos
   through a binding while the physics is still dirty from the action), so the acceleration-stage sensors of the
   observation are the last substep's -- what the device composer reports without an extra launch."""
-  from composer_fake import OracleDevicePhysics
   from dm_control_amd.composer import environment as ours_env
   from dm_control_amd.composer.tasks import soccer
   ref_task = rp.soccer_2v2_boxhead(randomizer=lambda random_state=None: 0.5)      # the 40 x 30 pitch of the config-5 asset
@@ -100,14 +125,14 @@ def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(en
   ref.reset()
   task = soccer.Soccer2v2()
   assert not getattr(task, 'observation_forward', False)
-  phys = OracleDevicePhysics(task.model, 1, outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), nconmax=24)
+  phys = _device_physics(backend, task.model, 1, outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), nconmax=24)
   env = ours_env.Environment(task, phys, time_limit=45.0, random_state=1)
   env.reset()
   m, rm = task.model, ref.physics.model
   assert (rm.nq, rm.nv, rm.nu, rm.nbody, rm.ngeom) == (m.nq, m.nv, m.nu, m.nbody, m.ngeom) and env.n_sub_steps == 5
   assert list(rm.names['joint']) == list(m.names['joint'])
-  phys.field('qpos')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qpos))
-  phys.field('qvel')[:, 0] = torch.from_numpy(np.array(ref.physics.data.qvel))
+  _put(phys, 'qpos', ref.physics.data.qpos)
+  _put(phys, 'qvel', ref.physics.data.qvel)
   phys.mark_as_dirty()
   phys.forward(disable_actuation=True)
   order = [p.walker.mjcf_model.model for p in ref_task.players]      # the reference's agent order
@@ -118,14 +143,14 @@ def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(en
   for t in range(6):
     a = rs.uniform(-1, 1, (4, 3))
     r = ref.step([a[mine.index(n)] for n in order])
-    o = env.step(torch.from_numpy(a[None]))
+    o = env.step(torch.from_numpy(a[None]).to(phys.device))
     assert int(r.step_type) == int(o.step_type[0])
     for i, n in enumerate(order):
       k = mine.index(n)
       assert float(np.asarray(r.reward[i])) == float(o.reward[k, 0]), (t, n)
       for key, val in r.observation[i].items():
         assert key in o.observation, key      # every observable the reference's agent gets
-        np.testing.assert_allclose(o.observation[key][0, k].numpy().ravel(), np.asarray(val, dtype=np.float64).ravel(),
+        np.testing.assert_allclose(o.observation[key][0, k].cpu().numpy().ravel(), np.asarray(val, dtype=np.float64).ravel(),
                                    rtol=0, atol=1e-8, err_msg='%s %s step %d' % (n, key, t))      # (the reference's extra mj_forward inside the first substep leaves the solver a different path to the same optimum: 2e-9 on the accelerometer)
         seen.add(key)
     assert float(r.discount) == float(o.discount[0])
@@ -134,10 +159,10 @@ def test_reference_soccer_2v2_runs_unmodified_and_matches_the_device_composer(en
   q = np.array(ref.physics.data.qpos); v = np.array(ref.physics.data.qvel)
   q[bq:bq + 3] = [37.0, 0.0, 1.0]; v[bv:bv + 6] = 0
   ref.physics.data.qpos[:] = q; ref.physics.data.qvel[:] = v
-  phys.field('qpos')[:, 0] = torch.from_numpy(q); phys.field('qvel')[:, 0] = torch.from_numpy(v)
+  _put(phys, 'qpos', q); _put(phys, 'qvel', v)
   phys.mark_as_dirty()
   r = ref.step([np.zeros(3)] * 4)
-  o = env.step(torch.zeros((1, 4, 3), dtype=torch.float64))
+  o = env.step(torch.zeros((1, 4, 3), dtype=torch.float64, device=phys.device))
   assert r.last() and int(o.step_type[0]) == ours_env.LAST and float(r.discount) == 0.0 == float(o.discount[0])
   want = {n: float(np.asarray(r.reward[i])) for i, n in enumerate(order)}
   assert sorted(want.values()) == [-1.0, -1.0, 1.0, 1.0]

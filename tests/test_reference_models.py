@@ -11,7 +11,7 @@ from dm_control_amd import mjcf_compiler as mc
 from emu_lib import EmuPhysics
 from oracle.oracle import OraclePhysics
 
-REF = '/root/reference/dm_control'
+from ref_root import REF  # noqa: E402  (/root/reference/dm_control, or the staged copy on the GPU box)
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not mounted')
 
 _MODELS = ['locomotion/walkers/assets/humanoid_CMU_V2019.xml', 'locomotion/walkers/assets/humanoid_CMU_V2020.xml',

@@ -57,9 +57,28 @@ CASES_2 = [(d, t, n, 4) for d, t, n in CASES if d in ('humanoid', 'humanoid_CMU'
 
 @pytest.mark.parametrize('domain,task,nsteps,seed', [c + (11,) for c in CASES] + CASES_2)
 def test_reference_domain_module_unmodified_equals_the_task_port(ref_suite, oracle_backend, domain, task, nsteps, seed):
+  _check_domain(ref_suite, domain, task, nsteps, seed)
+
+
+# the same comparison with NOTHING standing in for the device: the reference's domain module, Task and control.Environment
+# step `libdmc_hip.so` through the facade (needs the reference tree on the GPU box: scripts/stage_reference.sh)
+GPU_CASES = [('cheetah', 'run', 12), ('cartpole', 'swingup', 12), ('humanoid', 'walk', 8), ('humanoid_CMU', 'run', 4),
+             ('walker', 'walk', 12), ('hopper', 'hop', 12), ('finger', 'turn_hard', 12), ('fish', 'swim', 12),
+             ('manipulator', 'bring_ball', 8), ('stacker', 'stack_4', 8), ('quadruped', 'fetch', 6), ('swimmer', 'swimmer6', 8),
+             ('reacher', 'hard', 12), ('ball_in_cup', 'catch', 12), ('lqr', 'lqr_6_2', 12), ('acrobot', 'swingup', 12),
+             ('pendulum', 'swingup', 12), ('point_mass', 'hard', 12)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('domain,task,nsteps', GPU_CASES)
+def test_reference_domain_module_unmodified_on_the_hip_path(ref_suite, domain, task, nsteps):
+  _check_domain(ref_suite, domain, task, nsteps, 11)
+
+
+def _check_domain(ref_suite, domain, task, nsteps, seed):
   from dm_control_amd import suite
   mod = ref_suite.load(domain)
-  assert mod.__file__.startswith('/root/reference/') and task in mod.SUITE
+  assert mod.__file__.startswith(reference_loader.REF) and task in mod.SUITE
   ref_env = mod.SUITE[task](random=seed)
   ours = suite.load(domain, task, task_kwargs=dict(random=seed))
   assert type(ref_env).__module__ == 'dm_control.rl.control' and type(ref_env.task).__module__ == 'dm_control.suite.' + domain
