@@ -210,6 +210,16 @@ class BatchedPhysics:
                                                            ctypes.c_void_p(draw_ptr), ctypes.c_void_p(env_mask_ptr), int(flags),
                                                            ctypes.c_void_p(stream) if stream else None))
 
+  def enable_profiling(self, enabled=True):
+    """Brackets every launch with hipEvents (dmc_batch_enable_profiling; engine.py:135-137 enable_profiling)."""
+    _native.check(_native.lib().dmc_batch_enable_profiling(self._ptr, int(bool(enabled))))
+
+  def timer(self, which=0):
+    """(seconds, count) of timer 0 = mjTIMER_STEP / 1 = mjTIMER_FORWARD; waits for the launches issued so far."""
+    dur, num = ctypes.c_double(), ctypes.c_longlong()
+    _native.check(_native.lib().dmc_batch_get_timer(self._ptr, int(which), ctypes.byref(dur), ctypes.byref(num)))
+    return dur.value, num.value
+
   def time_steps(self, nstep, reps, stream=None):
     ms = ctypes.c_float()
     _native.check(_native.lib().dmc_batch_time_steps(self._ptr, int(nstep), int(self.legacy_step),

@@ -73,6 +73,7 @@ struct dmc_batch {
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (8, nitems) ints, or null
+  struct Profiler* prof = nullptr;      // launch timers (dmc_batch_enable_profiling), or null
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
@@ -266,9 +267,11 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   return dmc_batch_reset(b, nullptr, -1);
 }
 
+static void prof_free(struct Profiler* p);
 extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
+  if (b->prof) { prof_free(b->prof); b->prof = nullptr; }
   for (Field& f : b->fields) if (f.owned) (void)hipFree(f.owned);
   if (b->d_mi) (void)hipFree(b->d_mi);
   if (b->d_mc) (void)hipFree(b->d_mc);
@@ -342,7 +345,64 @@ __global__ void __launch_bounds__(1024) order_kernel(const int* __restrict__ cos
 }
 
 struct SeqArgs { const void* ctrl; void* qpos; void* qvel; void* sensor; int nsub; };
+// ---- profiling contract (mujoco/engine.py:135-137 enable_profiling -> wrapper.enable_timer; mjData.timer[]) ------
+// MuJoCo brackets mj_step / mj_forward with the mjcb_time callback and accumulates duration and call count per timer.
+// Here a launch IS the step: with profiling enabled every launch is bracketed by two hipEvents on its stream; the pairs
+// are resolved lazily (completed ones whenever a new launch is issued, all of them when the timer is read), so an
+// asynchronous caller is not serialised.  Launches recorded into a HIP graph are not timed (events cannot be queried
+// across replays).
+struct TimerPair { hipEvent_t e0, e1; int which, count; };
+struct Profiler {
+  bool on = false;
+  double duration[2] = {0, 0};      // seconds: [mjTIMER_STEP, mjTIMER_FORWARD]
+  long long number[2] = {0, 0};
+  std::vector<TimerPair> pending, spare;
+};
+static void prof_drain(Profiler* p, bool all) {
+  size_t k = 0;
+  for (; k < p->pending.size(); k++) {
+    TimerPair& t = p->pending[k];
+    if (all || p->pending.size() - k > 256) { if (hipEventSynchronize(t.e1) != hipSuccess) break; }
+    else if (hipEventQuery(t.e1) != hipSuccess) break;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) { p->duration[t.which] += 1e-3 * ms; p->number[t.which] += t.count; }
+    p->spare.push_back(t);
+  }
+  (void)hipGetLastError();      // (hipErrorNotReady from the query is not an error of the caller)
+  p->pending.erase(p->pending.begin(), p->pending.begin() + k);
+}
+static void prof_free(Profiler* p) {
+  (void)hipDeviceSynchronize();
+  for (auto* v : {&p->pending, &p->spare}) for (TimerPair& t : *v) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+  delete p;
+}
+static bool prof_begin(dmc_batch* b, hipStream_t stream, TimerPair* t) {
+  Profiler* p = b->prof;
+  if (!p || !p->on) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;
+  prof_drain(p, false);
+  if (!p->spare.empty()) { *t = p->spare.back(); p->spare.pop_back(); }
+  else if (hipEventCreate(&t->e0) != hipSuccess || hipEventCreate(&t->e1) != hipSuccess) return false;
+  return hipEventRecord(t->e0, stream) == hipSuccess;
+}
+static void prof_end(dmc_batch* b, hipStream_t stream, TimerPair t, int which, int count) {
+  t.which = which; t.count = count;
+  if (hipEventRecord(t.e1, stream) == hipSuccess) b->prof->pending.push_back(t); else b->prof->spare.push_back(t);
+}
+static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq);
 static int launch(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq = nullptr) {
+  HIP_TRY(hipSetDevice(b->device));
+  TimerPair t;
+  const bool timed = prof_begin(b, (hipStream_t)stream, &t);
+  const int rc = launch_untimed(b, nstep, legacy, mode, stream, sq);
+  // mjTIMER_STEP counts mj_step calls: a launch of mode 0 / 3 runs nstep (x n_sub_steps) of them; mj_step1 / mj_step2
+  // launches count as one step per pair (on the mj_step2 half); mj_forward launches go to mjTIMER_FORWARD
+  if (timed) prof_end(b, (hipStream_t)stream, t, (mode == 1 || mode == 2) ? 1 : 0,
+                      mode == 0 ? nstep : mode == 3 ? nstep * (sq ? sq->nsub : 1) : mode == 5 ? 1 : mode == 4 ? 0 : 1);
+  return rc;
+}
+static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* stream, const SeqArgs* sq) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->tb.opts.eg_n) b->tb.opts.eg_data = find_field(b, "env_geom")->dev;      // follows dmc_batch_bind
   b->tb.opts.xfrc = b->xfrc_on ? find_field(b, "xfrc_applied")->dev : nullptr; b->tb.opts.xfrc_B = b->B;
@@ -842,6 +902,22 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   return 0;
 }
 
+extern "C" int dmc_batch_enable_profiling(dmc_batch* b, int enabled) {
+  if (!b) return fail("null batch");
+  if (!b->prof) b->prof = new Profiler();
+  b->prof->on = enabled != 0;
+  return 0;
+}
+extern "C" int dmc_batch_get_timer(dmc_batch* b, int timer, double* duration_s, long long* number) {
+  if (!b || !duration_s || !number) return fail("null argument");
+  if (timer != 0 && timer != 1) return fail("timer must be 0 (mjTIMER_STEP) or 1 (mjTIMER_FORWARD)");
+  *duration_s = 0; *number = 0;
+  if (!b->prof) return 0;
+  HIP_TRY(hipSetDevice(b->device));
+  prof_drain(b->prof, true);
+  *duration_s = b->prof->duration[timer]; *number = b->prof->number[timer];
+  return 0;
+}
 extern "C" int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, void* hip_stream, float* ms_per_launch) {
   if (!b || !ms_per_launch || reps < 1) return fail("bad argument");
   HIP_TRY(hipSetDevice(b->device));

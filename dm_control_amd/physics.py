@@ -68,6 +68,27 @@ _COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'], 6: ['fx', 'fy', 'fz', 
          9: ['xx', 'xy', 'xz', 'yx', 'yy', 'yz', 'zx', 'zy', 'zz']}
 
 
+_NTIMER = 15      # mjNTIMER
+
+
+class _Timer:
+  """One mjData.timer[k] record, read from the device batch at access time."""
+
+  def __init__(self, physics, which):
+    self._p, self._k = physics, which
+
+  def _read(self):
+    return self._p.batch.timer(self._k) if self._k < 2 else (0.0, 0)
+
+  @property
+  def duration(self):
+    return self._read()[0]
+
+  @property
+  def number(self):
+    return self._read()[1]
+
+
 class _Data:
   """Host mirror of the batched mjData arrays (see module docstring)."""
 
@@ -142,6 +163,13 @@ class _Data:
     if name in ('time', 'ncon', 'nefc', 'solver_iter'):
       a = a[:, 0]
     return a[0] if p.batch_size == 1 else a
+
+  @property
+  def timer(self):
+    """mjData.timer: mjNTIMER records with `.duration` (seconds) and `.number`; [0] = mjTIMER_STEP, [1] =
+    mjTIMER_FORWARD are live once `Physics.enable_profiling()` was called (suite/wrappers/mujoco_profiling.py:94-103
+    reads `timer[0]`), the others stay zero: the fused launch has no host-visible sub-stages."""
+    return [_Timer(self._p, k) for k in range(_NTIMER)]
 
   def __getattr__(self, name):
     if name.startswith('_'):
@@ -447,7 +475,7 @@ class Physics(control.Physics):
     self.model = model
     self.batch_size = int(batch_size)
     self._batch_kwargs = dict(batch_kwargs, device_id=device_id)   # contact caps etc.: copies / pickles keep them
-    self.batch = BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, **batch_kwargs)
+    self.batch = self._create_batch(model, device_id, precision, batch_kwargs)
     self.data = _Data(self)
     self._warnings_cause_exception = True
     self._warnings_seen = np.zeros((self.batch_size, len(_WARNING_NAMES)), dtype=np.int64)
@@ -477,6 +505,22 @@ class Physics(control.Physics):
     self._opt_pushed = self._opt_snapshot()      # (the batch was created from these options)
     self._reload_from_data(self.data)
     self.after_reset()
+
+  # contact capacities tried, in order, when the caller names none: MuJoCo sizes its contact buffer from an arena (any
+  # number of contacts a model can produce fits), a drop-in user never sets `nconmax` -- so the facade asks for a generous
+  # cap first and settles for less only where the model's scratch would not fit in LDS.  (The throughput path,
+  # BatchedPhysics / suite.load, keeps its tuned per-model caps: suite/common.py DEFAULT_CAPS.)
+  _AUTO_NCONMAX = (64, 48, 32, 0)
+
+  def _create_batch(self, model, device_id, precision, batch_kwargs):
+    if 'nconmax' in batch_kwargs or self.batch_size > 64:
+      return BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, **batch_kwargs)
+    for cap in self._AUTO_NCONMAX:
+      try:
+        return BatchedPhysics(model, self.batch_size, device_id=device_id, precision=precision, nconmax=cap, **batch_kwargs)
+      except Exception as e:      # pylint: disable=broad-except
+        if cap == 0 or 'does not fit' not in str(e):
+          raise
 
   def _reload_from_data(self, data):
     """The hook engine.Physics calls whenever it (re)binds an mjData (engine.py:392-430): subclasses override it to
@@ -595,6 +639,11 @@ class Physics(control.Physics):
 
   def check_divergence(self):
     pass
+
+  def enable_profiling(self):
+    """engine.py:135-137: switches the step timers on (`data.timer[0].duration / .number`); here every launch is
+    bracketed by hipEvents on its stream (dmc_batch_enable_profiling)."""
+    self.batch.enable_profiling(True)
 
   # -- state -------------------------------------------------------------------------------
   # mjtState bits (mujoco 3.x), in the order mj_getState concatenates them

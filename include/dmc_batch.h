@@ -203,6 +203,16 @@ int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream);
  * claim the remaining environments from a device-side queue as they finish). */
 int dmc_batch_info(const dmc_batch* b, int* info);
 
+/* Profiling contract.  Replaces: Physics.enable_profiling() -> wrapper.enable_timer(True), which installs mjcb_time
+ * (dm_control/mujoco/engine.py:135-137, mujoco/wrapper/core.py:77-81), and the mjData.timer[mjTIMER_STEP] record
+ * suite/wrappers/mujoco_profiling.py:94-103 reads (`timer[0].duration`, `timer[0].number`).
+ * With profiling enabled every launch is bracketed by hipEvents on its stream.  timer 0 = mjTIMER_STEP: seconds spent
+ * in step launches and the number of physics steps (mj_step calls) they ran; timer 1 = mjTIMER_FORWARD: seconds and
+ * count of mj_forward launches.  Reading a timer waits for the launches issued so far.  Launches recorded into a HIP
+ * graph are not timed. */
+int dmc_batch_enable_profiling(dmc_batch* b, int enabled);
+int dmc_batch_get_timer(dmc_batch* b, int timer, double* duration_s, long long* number);
+
 /* Time `reps` back-to-back step launches with hipEvents on `hip_stream`;
  * returns the average milliseconds per launch in *ms_per_launch. */
 int dmc_batch_time_steps(dmc_batch* b, int nstep, int legacy_step, int reps, void* hip_stream, float* ms_per_launch);

@@ -91,8 +91,28 @@ class OracleBatch:
     self._stale = True      # the device recomputes the opening stage after a model edit (stash epoch bumped)
 
   # -- pipeline -------------------------------------------------------------------------
+  def enable_profiling(self, enabled=True):
+    self._timing = bool(enabled)
+
+  def timer(self, which=0):
+    return tuple(getattr(self, '_timers', [[0.0, 0], [0.0, 0]])[which])
+
+  def _tick(self, which, t0, count):
+    if getattr(self, '_timing', False):
+      import time
+      if not hasattr(self, '_timers'):
+        self._timers = [[0.0, 0], [0.0, 0]]
+      self._timers[which][0] += time.perf_counter() - t0
+      self._timers[which][1] += count
+
   def step(self, nstep=1, stream=None):
     del stream
+    import time
+    t0 = time.perf_counter()
+    self._step(nstep)
+    self._tick(0, t0, int(nstep))
+
+  def _step(self, nstep):
     for o in self._envs:
       o.legacy_step = bool(self.legacy_step)
       if getattr(self, '_stale', False) and self.legacy_step:
@@ -102,6 +122,12 @@ class OracleBatch:
 
   def forward(self, disable_actuation=False, stream=None):
     del stream
+    import time
+    t0 = time.perf_counter()
+    self._forward(disable_actuation)
+    self._tick(1, t0, 1)
+
+  def _forward(self, disable_actuation):
     flags = self._om.opt_int('disableflags')
     if disable_actuation:
       self._om.opt_int('disableflags', flags | _DSBL_ACTUATION)

@@ -72,10 +72,12 @@ GPU_CASES = [('cheetah', 'run', 12), ('cartpole', 'swingup', 12), ('humanoid', '
 @pytest.mark.gpu
 @pytest.mark.parametrize('domain,task,nsteps', GPU_CASES)
 def test_reference_domain_module_unmodified_on_the_hip_path(ref_suite, domain, task, nsteps):
-  _check_domain(ref_suite, domain, task, nsteps, 11)
+  # the reference module builds its Physics with the facade's automatic contact capacity, suite.load with the tuned one
+  # of suite/common.py: another kernel instantiation (model-specialised or generic), so rounding-level differences
+  _check_domain(ref_suite, domain, task, nsteps, 11, atol=1e-9)
 
 
-def _check_domain(ref_suite, domain, task, nsteps, seed):
+def _check_domain(ref_suite, domain, task, nsteps, seed, atol=0):
   from dm_control_amd import suite
   mod = ref_suite.load(domain)
   assert mod.__file__.startswith(reference_loader.REF) and task in mod.SUITE
@@ -92,10 +94,10 @@ def _check_domain(ref_suite, domain, task, nsteps, seed):
   a, b = _episode(ref_env, acts), _episode(ours, acts)
   for t, (x, y) in enumerate(zip(a, b)):
     assert int(x.step_type) == int(y.step_type), t
-    assert x.reward == y.reward and x.discount == y.discount, (t, x.reward, y.reward)
+    assert x.discount == y.discount and (x.reward == y.reward or abs(x.reward - y.reward) <= atol), (t, x.reward, y.reward)
     assert list(x.observation) == list(y.observation), t
     for k in x.observation:
-      np.testing.assert_array_equal(np.asarray(x.observation[k]), np.asarray(y.observation[k]), err_msg='%s step %d' % (k, t))
+      np.testing.assert_allclose(np.asarray(x.observation[k]), np.asarray(y.observation[k]), rtol=0, atol=atol, err_msg='%s step %d' % (k, t))
   # the observation specs the two environments advertise agree as well
   rs, os_ = ref_env.observation_spec(), ours.observation_spec()
   assert list(rs) == list(os_) and all(rs[k].shape == os_[k].shape and rs[k].dtype == os_[k].dtype for k in rs)

@@ -108,3 +108,58 @@ def test_reference_action_wrappers_and_their_tests_on_this_packages_environment(
         sys.modules.pop(k, None)
       else:
         sys.modules[k] = v
+
+
+def _with_dm_env(fn):
+  import sys
+  from dm_control_amd.envs import dm_env_api
+  saved = {k: sys.modules.get(k) for k in ('dm_env', 'dm_env.specs')}
+  sys.modules['dm_env'], sys.modules['dm_env.specs'] = dm_env_api, dm_env_api.specs
+  try:
+    return fn()
+  finally:
+    sys.modules.pop('dm_control.suite.wrappers.mujoco_profiling', None)
+    for k, v in saved.items():
+      if v is None:
+        sys.modules.pop(k, None)
+      else:
+        sys.modules[k] = v
+
+
+def _profiling_wrapper_checks():
+  import numpy as np
+  from dm_control_amd import suite
+  mod = _exec_reference_module('dm_control.suite.wrappers.mujoco_profiling', 'suite/wrappers/mujoco_profiling.py')
+  result, report = reference_tests.run('suite/wrappers/mujoco_profiling_test.py',
+                                       {'dm_control.suite': suite, 'dm_control.suite.cartpole': suite.cartpole,
+                                        'dm_control.suite.wrappers.mujoco_profiling': mod})
+  _check(result, report, 1)
+  # and on a stepping environment: the step timer advances by the physics steps of each control step (cheetah: 1 per
+  # control step ... cartpole swingup: 1; humanoid: 5), its duration grows, and stays put across observation reads
+  env = suite.load('humanoid', 'stand', task_kwargs=dict(random=0))
+  wrapped = mod.Wrapper(env)
+  ts = wrapped.reset()
+  d0, n0 = ts.observation['step_timing']
+  nsub = env._n_sub_steps
+  assert nsub == 5
+  for k in range(1, 4):
+    ts = wrapped.step(np.zeros(env.action_spec().shape))
+    d, n = ts.observation['step_timing']
+    assert n == n0 + k * nsub and d > d0, (k, d, n)
+    d0_prev = d
+  assert env.physics.data.timer[0].number == n and env.physics.data.timer[0].duration == d0_prev
+  assert env.physics.data.timer[1].number >= 1      # the mj_forward launches of reset (mjTIMER_FORWARD)
+  assert env.physics.data.timer[5].number == 0 and len(env.physics.data.timer) == 15
+
+
+def test_reference_mujoco_profiling_wrapper_and_its_test_on_this_packages_physics(oracle_backend):
+  """suite/wrappers/mujoco_profiling.py calls `env.physics.enable_profiling()` (mujoco/engine.py:135-137) and
+  reads `physics.data.timer[0].duration / .number` (mujoco_profiling.py:94-103): the wrapper and its own unit test run
+  unmodified on this package's Physics (CPU tier: the oracle stand-in times itself with perf_counter)."""
+  _with_dm_env(_profiling_wrapper_checks)
+
+
+@pytest.mark.gpu
+def test_reference_mujoco_profiling_wrapper_on_the_hip_path():
+  """The same on the device: the timers are hipEvent brackets around every launch (dmc_batch_enable_profiling)."""
+  _with_dm_env(_profiling_wrapper_checks)
