@@ -504,7 +504,16 @@ class Physics(control.Physics):
           setattr(self.model, name, view)
     self._opt_pushed = self._opt_snapshot()      # (the batch was created from these options)
     self._reload_from_data(self.data)
-    self.after_reset()
+    try:
+      self.after_reset()
+    except control.PhysicsError as e:
+      # The model's own qpos0 may be a state nobody simulates -- PyMJCF compositions put every attached entity at the
+      # origin until initialize_episode places them (soccer 2v2: 91 overlapping contacts).  MuJoCo's arena holds them
+      # all; this backend's contact capacity is finite, so a capacity warning raised by the CONSTRUCTION-time
+      # mj_forward is logged (the counters keep it) instead of making the model unloadable.  Later launches raise.
+      if not set(str(e).split('raised: ')[-1].split(', ')) <= {'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL'}:
+        raise
+      logging.getLogger(__name__).warning('at the model\'s qpos0: %s', e)
 
   # contact capacities tried, in order, when the caller names none: MuJoCo sizes its contact buffer from an arena (any
   # number of contacts a model can produce fits), a drop-in user never sets `nconmax` -- so the facade asks for a generous

@@ -120,7 +120,9 @@ enum { DMC_DSBL_CONSTRAINT = 1 << 0, DMC_DSBL_EQUALITY = 1 << 1,
        DMC_DSBL_FILTERPARENT = 1 << 10, DMC_DSBL_ACTUATION = 1 << 11,
        DMC_DSBL_REFSAFE = 1 << 12, DMC_DSBL_SENSOR = 1 << 13,
        DMC_DSBL_MIDPHASE = 1 << 14, DMC_DSBL_EULERDAMP = 1 << 15,
-       DMC_DSBL_AUTORESET = 1 << 16 };
+       DMC_DSBL_AUTORESET = 1 << 16,
+       /* constraint islands are a DISABLE flag that defaults to enable (mjcf/schema.xml:102) */
+       DMC_DSBL_NATIVECCD = 1 << 17, DMC_DSBL_ISLAND = 1 << 18, DMC_DSBL_MULTICCD = 1 << 19 };
 enum { DMC_ENBL_OVERRIDE = 1 << 0, DMC_ENBL_ENERGY = 1 << 1 };
 /* mjtWarning order as used by Physics.check_invalid_state
  * (dm_control/mujoco/engine.py:345-368) */

@@ -93,6 +93,9 @@ typedef struct {
   double *efc_vel, *efc_force, *efc_KBIP;
   /* solver stats */
   int solver_iter;
+  int nisland;                 /* constraint islands of the last mj_fwdConstraint (0: solved as one system) */
+  int *dof_island, *efc_island; /* island of each dof / constraint row, -1: none (mjData.dof_island / efc_island) */
+  void* island_scratch;        /* a second Data the per-island sub-problems are assembled in (solve_islands) */
   int warning[DMC_NWARNING];
   /* scratch */
   double *w_Jaref, *w_Jv, *w_Ma, *w_Mv, *w_grad, *w_Mgrad, *w_search, *w_quad, *w_H, *w_tmp;
@@ -367,11 +370,15 @@ Data* ora_data_create(const Model* m) {
   d->efc_type = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
   d->efc_id = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
   d->efc_state = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
+  d->dof_island = (int*)calloc((size_t)m->nv + 1, sizeof(int));
+  d->efc_island = (int*)calloc((size_t)m->njmax + 1, sizeof(int));
   ora_reset(m, d, -1);
   return d;
 }
 void ora_data_free(Data* d) {
-  if (d) { free(d->mem); free(d->contact); free(d->efc_type); free(d->efc_id); free(d->efc_state); free(d); }
+  if (!d) return;
+  if (d->island_scratch) ora_data_free((Data*)d->island_scratch);
+  free(d->mem); free(d->contact); free(d->efc_type); free(d->efc_id); free(d->efc_state); free(d->dof_island); free(d->efc_island); free(d);
 }
 void ora_data_copy(const Model* m, Data* dst, const Data* src) {
   size_t total = 0;
@@ -398,6 +405,7 @@ int ora_data_int(const Data* d, const char* name) {
   if (!strcmp(name, "ncon")) return d->ncon;
   if (!strcmp(name, "nefc")) return d->nefc;
   if (!strcmp(name, "solver_iter")) return d->solver_iter;
+  if (!strcmp(name, "nisland")) return d->nisland;
   return -1;
 }
 int* ora_data_warning(Data* d) { return d->warning; }
@@ -405,6 +413,8 @@ int* ora_data_efc_int(Data* d, const char* name) {
   if (!strcmp(name, "efc_type")) return d->efc_type;
   if (!strcmp(name, "efc_id")) return d->efc_id;
   if (!strcmp(name, "efc_state")) return d->efc_state;
+  if (!strcmp(name, "efc_island")) return d->efc_island;
+  if (!strcmp(name, "dof_island")) return d->dof_island;
   return NULL;
 }
 /* contact i -> out[0..29]: dist, pos3, frame9, includemargin, friction5, solref2,
@@ -2399,6 +2409,99 @@ static void pgs_solve(const Model* m, Data* d) {
   for (int i = 0; i < nv; i++) d->qacc[i] += d->qacc_smooth[i];
   free(res); free(b); free(AR); free(W);
 }
+static int solve_primal(const Model* m, Data* d, double scale);
+/* mj_island: the kinematic trees (maximal sets of bodies joined by joints; the static bodies belong to none) are the
+ * vertices, every constraint row is an edge set over the trees whose dofs it moves, the islands are the connected
+ * components that own at least one row.  Trees without a constraint are in no island: their qacc is qacc_smooth.
+ * The trees a row touches are read off its Jacobian (a row moves a tree iff it has a non-zero entry on one of its dofs);
+ * the rows of one contact always travel together.  Islands are numbered by their lowest dof.  Fills d->dof_island and
+ * d->efc_island, returns the island count. */
+static int find_islands(const Model* m, Data* d) {
+  const int nv = m->nv, nefc = d->nefc, nbody = m->nbody;
+  int* root = (int*)malloc(sizeof(int) * (size_t)(nbody + nv + 2));      /* tree of a body = its ancestor below the world */
+  int* parent = root + nbody + 1;                                        /* union-find over dofs */
+  root[0] = 0;
+  /* (a body welded to the world -- body_weldid 0 -- is static and belongs to no tree: what hangs off it by a joint starts a tree of its own) */
+  for (int b = 1; b < nbody; b++) root[b] = m->body_weldid[m->body_parentid[b]] == 0 ? b : root[m->body_parentid[b]];
+  for (int i = 0; i < nv; i++) parent[i] = i;
+#define FIND(x, r) { r = (x); while (parent[r] != r) r = parent[r]; for (int _y = (x); parent[_y] != _y; ) { int _n = parent[_y]; parent[_y] = r; _y = _n; } }
+#define UNITE(a, b) { int _ra, _rb; FIND(a, _ra); FIND(b, _rb); if (_ra != _rb) { if (_ra < _rb) parent[_rb] = _ra; else parent[_ra] = _rb; } }
+  /* the dofs of one tree are one vertex */
+  for (int i = 1; i < nv; i++) for (int j = i - 1; j >= 0; j--) if (root[m->dof_bodyid[i]] == root[m->dof_bodyid[j]]) { UNITE(i, j); break; }
+  for (int r = 0; r < nefc; r++) {
+    /* rows of one contact (frictionless 1, pyramidal 2 (dim - 1), elliptic dim) form one edge set */
+    int r1 = r + 1;
+    const int t = d->efc_type[r];
+    if (t == CT_PYRAMIDAL || t == CT_ELLIPTIC) while (r1 < nefc && d->efc_type[r1] == t && d->efc_id[r1] == d->efc_id[r]) r1++;
+    int first = -1;
+    for (int q = r; q < r1; q++) for (int i = 0; i < nv; i++) if (d->efc_J[(size_t)q*nv + i] != 0) { if (first < 0) first = i; else UNITE(first, i); }
+    for (int q = r; q < r1; q++) d->efc_island[q] = first;      /* a dof of the edge set for now (-1: a row that moves nothing) */
+    r = r1 - 1;
+  }
+  /* number the components that own a row by their lowest dof */
+  int ni = 0;
+  for (int i = 0; i < nv; i++) d->dof_island[i] = -1;
+  for (int i = 0; i < nv; i++) {
+    int ri; FIND(i, ri);
+    if (ri != i) { d->dof_island[i] = d->dof_island[ri]; continue; }      /* (the root of a component is its lowest dof) */
+    int owns = 0;
+    for (int r = 0; r < nefc && !owns; r++) if (d->efc_island[r] >= 0) { int rr; FIND(d->efc_island[r], rr); owns = rr == i; }
+    if (owns) d->dof_island[i] = ni++;
+  }
+  for (int r = 0; r < nefc; r++) if (d->efc_island[r] >= 0) d->efc_island[r] = d->dof_island[d->efc_island[r]];
+#undef FIND
+#undef UNITE
+  free(root);
+  return ni;
+}
+/* The per-island solves of mj_fwdConstraint: island k's dofs and rows are gathered into a dense sub-problem (M and J
+ * restricted to them: the cross terms are exact zeros), solved by the same mj_solPrimal from the same starting point, and
+ * scattered back.  Dofs in no island take qacc_smooth. */
+static void solve_islands(const Model* m, Data* d, int nisland) {
+  const int nv = m->nv, nefc = d->nefc;
+  if (!d->island_scratch) d->island_scratch = ora_data_create(m);
+  Data* s = (Data*)d->island_scratch;
+  int* dofs = (int*)malloc(sizeof(int) * (size_t)(nv + nefc + nv + 2));
+  int *rows = dofs + nv + 1, *local = rows + nefc;
+  double* floss = (double*)malloc(sizeof(double) * (size_t)(nv + 1));
+  Contact* own_contacts = s->contact;
+  s->contact = d->contact;      /* contact rows keep their contact ids */
+  const double scale = 1 / (m->stat_meaninertia * mjMAX(1, nv));
+  d->solver_iter = 0;
+  for (int i = 0; i < nv; i++) if (d->dof_island[i] < 0) d->qacc[i] = d->qacc_smooth[i];
+  /* (k == nisland: the rows that move no dof -- an all-zero Jacobian row, e.g. a contact between two static bodies --
+   * are in no island; their force is a function of their own constant residual, evaluated as a system without dofs) */
+  for (int k = 0; k <= nisland; k++) {
+    int nd = 0, nr = 0;
+    const int sel = k < nisland ? k : -1;
+    for (int i = 0; i < nv; i++) { local[i] = -1; if (k < nisland && d->dof_island[i] == k) { local[i] = nd; dofs[nd++] = i; } }
+    for (int r = 0; r < nefc; r++) if (d->efc_island[r] == sel) rows[nr++] = r;
+    if (!nr) continue;
+    Model sm = *m;
+    sm.nv = nd;
+    sm.dof_frictionloss = floss;
+    for (int a = 0; a < nd; a++) {
+      floss[a] = m->dof_frictionloss[dofs[a]];
+      s->qacc[a] = d->qacc[dofs[a]]; s->qacc_smooth[a] = d->qacc_smooth[dofs[a]]; s->qfrc_smooth[a] = d->qfrc_smooth[dofs[a]];
+      for (int b = 0; b < nd; b++) { s->qM[(size_t)a*nd + b] = d->qM[(size_t)dofs[a]*nv + dofs[b]]; s->qL[(size_t)a*nd + b] = 0; }
+    }
+    if (m->opt_solver == DMC_SOL_CG) chol_factor(s->qL, s->qM, nd);      /* the CG preconditioner: the island's block of M */
+    for (int q = 0; q < nr; q++) {
+      const int r = rows[q];
+      for (int a = 0; a < nd; a++) s->efc_J[(size_t)q*nd + a] = d->efc_J[(size_t)r*nv + dofs[a]];
+      s->efc_D[q] = d->efc_D[r]; s->efc_R[q] = d->efc_R[r]; s->efc_aref[q] = d->efc_aref[r];
+      s->efc_type[q] = d->efc_type[r];
+      s->efc_id[q] = d->efc_type[r] == CT_FRICTION_DOF ? local[d->efc_id[r]] : d->efc_id[r];
+    }
+    s->nefc = nr;
+    const int it = solve_primal(&sm, s, scale);
+    if (k < nisland && it > d->solver_iter) d->solver_iter = it;      /* the island that took longest */
+    for (int a = 0; a < nd; a++) d->qacc[dofs[a]] = s->qacc[a];
+    for (int q = 0; q < nr; q++) { d->efc_force[rows[q]] = s->efc_force[q]; d->efc_state[rows[q]] = s->efc_state[q]; }
+  }
+  s->contact = own_contacts;
+  free(dofs); free(floss);
+}
 static void fwd_constraint(const Model* m, Data* d) {
   int nv = m->nv, nefc = d->nefc;
   d->solver_iter = 0;
@@ -2425,7 +2528,33 @@ static void fwd_constraint(const Model* m, Data* d) {
     double cs = constraint_update(m, d, jar, 1);
     if (cw > cs) memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
   } else memcpy(d->qacc, d->qacc_smooth, sizeof(double) * (size_t)nv);
-  double scale = 1 / (m->stat_meaninertia * mjMAX(1, nv));
+  /* constraint islands (mj_island; mjDSBL_ISLAND is a DISABLE flag, mjcf/schema.xml:102): the solver runs once per
+   * island -- own line search, own iteration count, own stopping test -- exactly when mj_fwdConstraint does: flag on,
+   * at least one island, no noslip pass, a primal solver (CG / Newton).  PARITY_ASSUMPTIONS rows 8, 37-39. */
+  d->nisland = 0;
+  if (!(m->opt_disableflags & DMC_DSBL_ISLAND) && m->opt_noslip_iterations == 0) {
+    const int ni = find_islands(m, d);
+    /* one island that holds every dof IS the joint problem: solved in place (same rows, same dofs, same arithmetic) */
+    int whole = ni == 1;
+    for (int i = 0; whole && i < nv; i++) if (d->dof_island[i] != 0) whole = 0;
+    for (int r = 0; whole && r < nefc; r++) if (d->efc_island[r] != 0) whole = 0;
+    d->nisland = ni;
+    if (ni > 0 && !whole) { solve_islands(m, d, ni); goto solved; }
+  }
+  d->solver_iter = solve_primal(m, d, 1 / (m->stat_meaninertia * mjMAX(1, nv)));
+solved:
+  /* final forces at the solution */
+  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
+  for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * (size_t)nv);
+  /* the warm start keeps the main solver's solution; noslip then edits qacc / efc_force */
+  if (m->opt_noslip_iterations > 0) noslip(m, d);
+}
+/* mj_solPrimal (Newton / CG) from d->qacc on the system held by (m, d): m->nv dofs, d->nefc rows.  `scale` is the
+ * tolerance scaling 1 / (meaninertia * max(1, nv)) of the WHOLE model, also when (m, d) is an island's sub-problem. */
+static int solve_primal(const Model* m, Data* d, double scale) {
+  int nv = m->nv, nefc = d->nefc;
+  double *jar = d->w_Jaref, *Ma = d->w_Ma;
   for (int i = 0; i < nv; i++) Ma[i] = dot_n(d->qM + (size_t)i*nv, d->qacc, nv);
   for (int i = 0; i < nefc; i++) jar[i] = dot_n(d->efc_J + (size_t)i*nv, d->qacc, nv) - d->efc_aref[i];
   double gauss, cost = total_cost(m, d, constraint_update(m, d, jar, 0), &gauss);
@@ -2459,13 +2588,7 @@ static void fwd_constraint(const Model* m, Data* d) {
     iter++;
     if (improvement < m->opt_tolerance || gradient < m->opt_tolerance) break;
   }
-  d->solver_iter = iter;
-  /* final forces at the solution */
-  for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
-  for (int r = 0; r < nefc; r++) if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[(size_t)r*nv + i]*d->efc_force[r];
-  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * (size_t)nv);
-  /* the warm start keeps the main solver's solution; noslip then edits qacc / efc_force */
-  if (m->opt_noslip_iterations > 0) noslip(m, d);
+  return iter;
 }
 /* mj_contactForce in the contact frame: [normal, tangent1, tangent2, torsion, roll1, roll2] */
 static void contact_force_local(const Model* m, const Data* d, int id, double* f6) {

@@ -132,7 +132,7 @@ class OraclePhysics:
   def __getattr__(self, name):
     if name.startswith('_') or name in ('model', 'm', 'ptr', 'legacy_step'):
       raise AttributeError(name)
-    if name in ('ncon', 'nefc', 'solver_iter'):
+    if name in ('ncon', 'nefc', 'solver_iter', 'nisland'):
       return lib().ora_data_int(self.ptr, name.encode())
     if name in ('efc_type', 'efc_id', 'efc_state'):
       p = lib().ora_data_efc_int(self.ptr, name.encode())
@@ -149,6 +149,14 @@ class OraclePhysics:
   @time.setter
   def time(self, v):
     self.field('time')[0] = v
+
+  def efc_island(self):
+    """mjData.efc_island of the last solve (island of every constraint row, -1: none)."""
+    return np.array(np.ctypeslib.as_array(lib().ora_data_efc_int(self.ptr, b'efc_island'), shape=(max(self.nefc, 1),))[:self.nefc])
+
+  def dof_island(self):
+    """mjData.dof_island of the last solve (island of every dof, -1: its tree has no constraint)."""
+    return np.array(np.ctypeslib.as_array(lib().ora_data_efc_int(self.ptr, b'dof_island'), shape=(len(self.qvel),)))
 
   @property
   def warning(self):
