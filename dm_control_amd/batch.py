@@ -160,8 +160,20 @@ class BatchedPhysics:
   def set_control(self, control):
     self.set('ctrl', control)
 
-  def step(self, nstep=1, stream=None):
-    _native.check(_native.lib().dmc_batch_step(self._ptr, int(nstep), int(self.legacy_step), stream))
+  def step(self, nstep=1, stream=None, forward_after=False):
+    """Physics.step(nstep) for every environment in one launch.  `forward_after` (legacy steps): the launch ends with
+    the rest of mj_forward at the new state -- dmc_batch_step's legacy_step 2."""
+    legacy = int(self.legacy_step)
+    if forward_after:
+      if not legacy:
+        raise ValueError('forward_after needs legacy_step')
+      legacy = 2
+    _native.check(_native.lib().dmc_batch_step(self._ptr, int(nstep), legacy, stream))
+
+  def set_step_probe(self, geom_id, out_ptr, capacity):
+    """dmc_batch_set_step_probe: geom `geom_id`'s world position after every physics step of a step launch goes to the
+    caller's (capacity, 3, B) device array at `out_ptr` (None: off)."""
+    _native.check(_native.lib().dmc_batch_set_step_probe(self._ptr, int(geom_id), ctypes.c_void_p(out_ptr) if out_ptr else None, int(capacity)))
 
   def rollout(self, nsteps, n_sub_steps=1, ctrl_seq=None, qpos_seq=None, qvel_seq=None, sensordata_seq=None,
               stream=None):

@@ -134,6 +134,15 @@ class _EnvironmentHooks:
     self._entity_hooks = {n: [] for n in HOOK_NAMES}
     self._extra = {n: [] for n in HOOK_NAMES}
     self._task_hooks = {}
+    # Entities whose after_substep hook only looks at ONE geom's position can be served from the step kernel's substep
+    # probe (DevicePhysics.substep_probe): they expose `substep_probe_geom` and `after_substeps(physics, trace)`, the
+    # control step stays one launch, and their detections are those of the per-substep hook (position_detector.py's
+    # retain_substep_detections semantics).  Used when every one of them names the same geom; else the hooks run.
+    probed = [e for e in task.entities if getattr(e, 'substep_probe_geom', None) is not None and hasattr(e, 'after_substeps')]
+    geoms = {e.substep_probe_geom for e in probed}
+    self.probe_geom = geoms.pop() if len(geoms) == 1 else None
+    self.probe_entities = probed if self.probe_geom is not None else []
+    self._hook_entities = {}
     for name in HOOK_NAMES:
       h = getattr(task, name)
       self._task_hooks[name] = None if _callable_is_trivial(h) else h
@@ -141,6 +150,7 @@ class _EnvironmentHooks:
         eh = getattr(entity, name, None)
         if eh is not None and not _callable_is_trivial(eh):
           self._entity_hooks[name].append(eh)
+          self._hook_entities[eh] = entity
 
   def add_extra_hook(self, hook_name, hook_callable):
     if hook_name not in HOOK_NAMES:
@@ -149,8 +159,14 @@ class _EnvironmentHooks:
       raise ValueError('{!r} is not a callable'.format(hook_callable))
     self._extra[hook_name].append(hook_callable)
 
-  def has_substep_hooks(self):
-    return any(self._task_hooks[n] or self._entity_hooks[n] or self._extra[n] for n in ('before_substep', 'after_substep'))
+  def has_substep_hooks(self, probed_count=False):
+    """probed_count: also count the after_substep hooks the substep probe can serve."""
+    def left(n):
+      hooks = self._entity_hooks[n]
+      if n == 'after_substep' and not probed_count:
+        hooks = [h for h in hooks if self._hook_entities[h] not in self.probe_entities]
+      return hooks
+    return any(self._task_hooks[n] or left(n) or self._extra[n] for n in ('before_substep', 'after_substep'))
 
   def initialize_episode(self, physics, random_state, mask):
     if self._task_hooks['initialize_episode']:
@@ -218,6 +234,12 @@ class Environment:
   def fused(self):
     return (not self._hooks.has_substep_hooks()) if self._fuse is None else bool(self._fuse)
 
+  @property
+  def probed(self):
+    """The fused launch serves position-only after_substep hooks from the substep probe (their per-substep semantics
+    are kept); `fuse_substeps=True` forces fusion WITHOUT it (the hooks then see the control step as one substep)."""
+    return self._fuse is None and self.fused and bool(self._hooks.probe_entities)
+
   def add_extra_hook(self, hook_name, hook_callable):
     self._hooks.add_extra_hook(hook_name, hook_callable)
 
@@ -268,20 +290,31 @@ class Environment:
     ctrl = p.field('ctrl')
     if ctrl.numel():
       ctrl.copy_(torch.where(first[None, :], torch.zeros_like(ctrl), ctrl))
-    if self.fused:
+    # observation_forward tasks: the launch that ends the control step also runs the rest of mj_forward at the new state
+    # (dmc_batch_step legacy_step 2) -- see below; environments re-initialised in this call are not touched by it
+    obs_forward = bool(getattr(task, 'observation_forward', False))
+    fold = obs_forward and getattr(p, 'supports_forward_after', True)
+    if self.probed:
+      # one launch; the kernel leaves the probed geom's position after every substep, the entities read that trace
+      trace = p.substep_probe(self._hooks.probe_geom, self._n_sub_steps)
+      p.step(self._n_sub_steps, forward_after=fold)
+      self.launches += 1
+      for e in self._hooks.probe_entities:
+        e.after_substeps(p, trace[:self._n_sub_steps])
+    elif self.fused:
       # no substep hook (or fusion forced): the substep hooks, if any, see the control step as ONE substep
       self._hooks.before_substep(p, action, self._rs)
-      p.step(self._n_sub_steps)
+      p.step(self._n_sub_steps, forward_after=fold)
       self.launches += 1
       self._hooks.after_substep(p, self._rs)
     else:
-      for _ in range(self._n_sub_steps):
+      for k in range(self._n_sub_steps):
         self._hooks.before_substep(p, action, self._rs)
-        p.step()
+        p.step(1, forward_after=fold and k == self._n_sub_steps - 1)
         self.launches += 1
         self._hooks.after_substep(p, self._rs)
     self._hooks.after_step(p, self._rs)
-    if getattr(task, 'observation_forward', False):
+    if obs_forward and not fold:
       # In the reference the action reaches mjData through an mjcf binding (walker.apply_action), which marks the physics
       # dirty; physics.step() does not clear that, so the first observable read through a binding after the substeps
       # runs mj_forward (mjcf/physics.py:341-342): the acceleration-stage sensors an agent sees (touch, torque,

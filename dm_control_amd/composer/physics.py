@@ -231,9 +231,19 @@ class DevicePhysics:
     self.batch.forward(disable_actuation=disable_actuation, stream=self.stream())
     self._dirty = False
 
-  def step(self, nstep=1):
-    self.batch.step(nstep, stream=self.stream())
+  def step(self, nstep=1, forward_after=False):
+    self.batch.step(nstep, stream=self.stream(), forward_after=forward_after)
     self._dirty = False
+
+  def substep_probe(self, geom_name, capacity):
+    """(capacity, 3, B) tensor that every step launch fills with the world position of `geom_name` after each of its
+    physics steps (dmc_batch_set_step_probe): position-only after_substep hooks read it after ONE fused launch."""
+    key = ('probe', geom_name)
+    t = self._consts.get(key)
+    if t is None or t.shape[0] < capacity:
+      t = self._consts[key] = self.torch.zeros((capacity, 3, self.B), dtype=self.dtype, device=self.device)
+      self.batch.set_step_probe(self.model.name2id(geom_name, 'geom'), t.data_ptr(), capacity)
+    return t
 
   def step1(self):
     self.batch.step1(stream=self.stream())

@@ -13,8 +13,10 @@ composition produces for that call (scripts/make_pymjcf_goldens.py; element name
   * goal / out-of-court detection by `PositionDetector` volumes on the ball position (entities/props/
     position_detector.py; pitch.py:426-456), evaluated AFTER EVERY SUBSTEP and retained until the end of the control
     step (`retain_substep_detections=True`, pitch.py:262): the detectors are entities with an `after_substep`
-    hook, so by default the control step runs as n_sub_steps launches with the hook in between -- the reference's
-    order.  `Environment(..., fuse_substeps=True)` checks at the end of the control step only (one launch);
+    hook.  They only look at the ball's position, which the step kernel records after every physics step of a launch
+    (the substep probe, dmc_batch_set_step_probe): the control step is ONE launch and the detections are the
+    per-substep ones (`Environment(..., fuse_substeps=False)` runs n_sub_steps launches with the hooks in between, the
+    reference's literal order, to the same result; `fuse_substeps=True` checks at the end of the control step only);
   * reward +1 / -1 per player when a team scores, discount 0 and termination on a goal (task.py:160-209);
     throw-in when the ball left the court (task.py:215-217, :128-135);
   * observations per player (soccer/observables.py CoreObservablesAdder): proprioception (kick joint position /
@@ -125,6 +127,18 @@ class PositionDetector(environment.Entity):
   def after_substep(self, physics, random_state):
     now = self._inside(physics)
     self.detected.copy_((self.detected | now) if self.retain else now)
+
+  # the same from the step kernel's substep probe: the ball's position after every physics step of ONE fused launch
+  substep_probe_geom = 'soccer_ball/geom'
+
+  def after_substeps(self, physics, trace):
+    """trace: (n_sub_steps, 3, B) ball positions.  after_substep applied n times: a retaining detector ORs its
+    per-substep detections into the control step's, a plain one keeps the last."""
+    lo, hi = self.bounds(physics)
+    d = lo.shape[0]
+    inside = ((trace[:, :d] > lo[None]) & (trace[:, :d] < hi[None])).all(dim=1)      # (n, B)
+    now = ~inside if self.inverted else inside
+    self.detected.copy_((self.detected | now.any(dim=0)) if self.retain else now[-1])
 
 
 class Soccer2v2(environment.Task):
@@ -325,93 +339,132 @@ class Soccer2v2(environment.Task):
     n = vec.shape[0]
     return (vec[:, None, :] * R[:n, :n]).sum(dim=0)
 
+  # What a player observes of the ball and of the others are the frame sensors CoreObservablesAdder adds to its model
+  # (observables.py:96-198: framepos / framelinvel / frameangvel / frame?axis with reftype="body"): MuJoCo evaluates
+  # objtype / reftype "body" in the bodies' INERTIAL frames (xipos, ximat -- the head's principal axes are a
+  # permutation of its body axes) and velocities RELATIVE to the reference frame.  They are read, not recomputed
+  # from xpos / xmat (round 2 did that, in the body frame: found by running the reference's task on this backend,
+  # tests/test_reference_composer.py).
+  _CORNER_NAMES = ('team_goal_back_right', 'team_goal_mid', 'team_goal_front_left', 'field_front_left',
+                   'opponent_goal_back_left', 'opponent_goal_mid', 'opponent_goal_front_right', 'field_back_right')
+  _CORNER_DIMS = (2, 3, 2, 2, 2, 3, 2, 2)
+  _STATS = ('stats_vel_to_ball', 'stats_closest_vel_to_ball', 'stats_veloc_forward', 'stats_vel_ball_to_goal',
+            'stats_home_avg_teammate_dist', 'stats_teammate_spread_out', 'stats_home_score', 'stats_away_score')
+
+  def _observation_plan(self, physics):
+    """Built once.  Everything an agent observes that is a row of an mjData field -- proprioception, its kinematic
+    sensors, the ego-centric frame sensors of ball / teammate / opponents -- goes through ONE launch of the gather
+    kernel (observation.GatherTable: a block of identical layout per player, so the (B, 4 P) matrix is the (B, 4, P)
+    observation); the rest (goal / field corners in the player's frame, the stats_* scalars, prev_action) is computed
+    for the four players at once.  Round 3 built the dictionary from ~600 per-player tensor operations: 60 % of the
+    control step at B = 256."""
+    from dm_control_amd.observation import GatherTable
+    torch = physics.torch
+    entries, layout = [], None
+    for k, p in enumerate(_PLAYERS):
+      mates = [j for j in range(4) if j != k and _TEAM[j] == _TEAM[k]]
+      opps = [j for j in range(4) if _TEAM[j] != _TEAM[k]]
+      mine = [('joints_pos', ('qpos', [p + '/kick'])), ('joints_vel', ('qvel', [p + '/kick'])),
+              ('body_height', ('xpos', [p + '/head_body'], 'z')),
+              ('end_effectors_pos', ('sensordata', [p + '/head_body_end_effector'])),
+              ('world_zaxis', ('xmat', [p + '/head_body'], ['zx', 'zy', 'zz'])),
+              ('sensors_gyro', ('sensordata', [p + '/sensor_torso_gyro'])),
+              ('sensors_velocimeter', ('sensordata', [p + '/sensor_torso_vel'])),
+              ('sensors_accelerometer', ('sensordata', [p + '/sensor_torso_accel'])),
+              ('prev_action', None),
+              ('ball_ego_position', ('sensordata', [p + '/ball_ego_pos'])),
+              ('ball_ego_linear_velocity', ('sensordata', [p + '/ball_ego_linvel'])),
+              ('ball_ego_angular_velocity', ('sensordata', [p + '/ball_ego_angvel']))]
+      for prefix, others in (('teammate', mates), ('opponent', opps)):
+        for n, j in enumerate(others):
+          pre = '%s_%d' % (prefix, n)
+          mine += [(pre + '_ego_end_effectors_pos', ('sensordata', ['%s/head_body_%s_end_effector' % (p, pre)])),
+                   (pre + '_ego_linear_velocity', ('sensordata', ['%s/%s_ego_linear_velocity' % (p, pre)])),
+                   (pre + '_ego_position', ('sensordata', ['%s/%s_ego_position' % (p, pre)])),
+                   (pre + '_ego_orientation', ('sensordata', ['%s/%s_ego_orientation_%s' % (p, pre, d) for d in 'xyz'])),
+                   # the other's end effectors in the OTHER's frame (observables.py:158-161: its own end_effectors_pos)
+                   (pre + '_end_effectors_pos', ('sensordata', [_PLAYERS[j] + '/head_body_end_effector']))]
+      mine += [(n, None) for n in self._CORNER_NAMES + self._STATS]
+      table_entries = [e for _, e in mine if e is not None]
+      widths = [GatherTable(self.model, [e]).size for e in table_entries]
+      entries += table_entries
+      if layout is None:      # name -> ('g', offset in the player's gathered block, width) | ('c', offset in the computed block, width)
+        layout, go, it = [], 0, iter(widths)
+        co = 0
+        for name, e in mine:
+          if e is not None:
+            w = next(it); layout.append((name, 'g', go, w)); go += w
+          else:
+            w = 3 if name == 'prev_action' else (self._CORNER_DIMS[self._CORNER_NAMES.index(name)] if name in self._CORNER_NAMES else 1)
+            if name == 'stats_veloc_forward':      # the first component of the velocimeter (observables.py:300-305)
+              layout.append((name, 'v', 0, 1))
+            else:
+              layout.append((name, 'c', co, w)); co += w
+        self._obs_P, self._obs_C = go, co
+    self._obs_table = GatherTable(self.model, entries)
+    assert self._obs_table.size == 4 * self._obs_P
+    self._obs_layout = layout
+    dev = physics.device
+    self._root_t = torch.as_tensor(self._root, dtype=torch.long, device=dev)
+    self._mate_t = torch.as_tensor([1, 0, 3, 2], dtype=torch.long, device=dev)
+    self._team_t = torch.as_tensor(_TEAM, dtype=torch.bool, device=dev)[:, None]                # (4, 1): AWAY
+    self._corner_idx = torch.as_tensor([list(range(8)) if t == 0 else [4, 5, 6, 7, 0, 1, 2, 3] for t in _TEAM], dtype=torch.long, device=dev)
+    self._corner_keep = physics.const([[1.0, 1.0, 1.0 if d == 3 else 0.0] for d in self._CORNER_DIMS])[None, :, :, None]   # (1, 8, 3, 1)
+
   def get_observation(self, physics):
     torch = physics.torch
     B = physics.B
-    sd, q, v = physics.field('sensordata'), physics.field('qpos'), physics.field('qvel')
-    ball = self.ball_xpos(physics)
+    if getattr(self, '_obs_layout', None) is None:
+      self._observation_plan(physics)
+    G = physics.gather(self._obs_table).view(B, 4, self._obs_P)
+    nb = self.model.nbody
+    pos = physics.field('xpos').view(nb, 3, B)[self._root_t]                     # (4, 3, B)
+    R = physics.field('xmat').view(nb, 3, 3, B)[self._root_t]                    # (4, 3, 3, B): R[k, i, j]
+    cv = physics.field('cvel').view(nb, 6, B)[self._root_t][:, 3:5]              # planar com-frame linear velocity of the roots
+    ball = self.ball_xpos(physics)                                               # (3, B)
+    sd = physics.field('sensordata')
     blin = sd[self._ball_linvel:self._ball_linvel + 3]
-    frames = [self._frame(physics, k) for k in range(4)]
-    cvel = physics.field('cvel')
-    out = {}
-    gs = _GOAL_SIZE
-
-    def put(name, t):
-      out.setdefault(name, []).append(t.T if t.dim() == 2 else t[:, None])
-
     home_lo, home_hi = self.home_goal.bounds(physics)
     away_lo, away_hi = self.away_goal.bounds(physics)
     home_mid, away_mid = (home_lo + home_hi) / 2, (away_lo + away_hi) / 2
     f_lo, f_hi = self.field.bounds(physics)
-    corners = [home_lo[:2], home_mid, home_hi[:2], f_hi, away_hi[:2], away_mid, away_lo[:2], f_lo]
-    corner_names = ['team_goal_back_right', 'team_goal_mid', 'team_goal_front_left', 'field_front_left',
-                    'opponent_goal_back_left', 'opponent_goal_mid', 'opponent_goal_front_right', 'field_back_right']
-    dist_to_ball = [torch.linalg.norm(ball - frames[k][0], dim=0) for k in range(4)]
+    z1 = torch.zeros((1, B), dtype=physics.dtype, device=physics.device)
+    pad = lambda c: c if c.shape[0] == 3 else torch.cat([c[:2], z1])
+    corners = torch.stack([pad(c) for c in (home_lo, home_mid, home_hi, f_hi, away_hi, away_mid, away_lo, f_lo)])   # (8, 3, B)
+    # goal / field corners in the player's frame: (c - pos) . R over the corner's own dimensions (2-d corners: the planar block)
+    D = (corners[self._corner_idx] - pos[:, None]) * self._corner_keep           # (4, 8, 3, B)
+    E = torch.einsum('kmib,kijb->kmjb', D, R)
+    # stats (observables.py:262-375)
+    dir_ = ball[None] - pos
+    planar = dir_[:, :2]
+    unit = planar / (torch.linalg.norm(planar, dim=1, keepdim=True) + 1e-7)
+    vel_to_ball = (unit * cv).sum(dim=1)                                         # (4, B)
+    dist = torch.linalg.norm(dir_, dim=1)
+    closest = dist <= dist[self._mate_t]
+    goal_mid = torch.where(self._team_t[:, :, None], home_mid[None], away_mid[None])      # the goal a player attacks
+    direction = goal_mid - ball[None]
+    nrm = torch.linalg.norm(direction, dim=1, keepdim=True)
+    ndir = torch.where(nrm > 0, direction / nrm.clamp_min(1e-30), direction)
+    avg = torch.linalg.norm(pos - pos[self._mate_t], dim=1)
     # arena.detected_goal() (pitch.py:574-580): the home goal is looked at first -- the ball in it means AWAY scored
     away_goal_scored = self.home_goal.detected
     home_goal_scored = self.away_goal.detected & ~away_goal_scored
-    for k, p in enumerate(_PLAYERS):
-      pos, R = frames[k]
-      a, av, s = self._q[p], self._v[p], self._sens[p]
-      put('joints_pos', q[a['kick']]); put('joints_vel', v[av['kick']])
-      put('body_height', pos[2])
-      # What a player observes of the ball and of the others are the frame sensors CoreObservablesAdder adds to its model
-      # (observables.py:96-198: framepos / framelinvel / frameangvel / frame?axis with reftype="body"): MuJoCo evaluates
-      # objtype / reftype "body" in the bodies' INERTIAL frames (xipos, ximat -- the head's principal axes are a
-      # permutation of its body axes) and velocities RELATIVE to the reference frame.  They are read, not recomputed
-      # from xpos / xmat (round 2 did that, in the body frame: found by running the reference's task on this backend,
-      # tests/test_reference_composer.py).
-      S = lambda name: sd[self._sadr[p + '/' + name]:self._sadr[p + '/' + name] + 3]
-      put('end_effectors_pos', S('head_body_end_effector'))
-      put('world_zaxis', physics.field('xmat')[9*self._root[k] + 6:9*self._root[k] + 9])
-      put('sensors_gyro', sd[s['gyro']:s['gyro'] + 3]); put('sensors_velocimeter', sd[s['vel']:s['vel'] + 3])
-      put('sensors_accelerometer', sd[s['accel']:s['accel'] + 3])
-      put('prev_action', self._prev_action[k])
-      put('ball_ego_position', S('ball_ego_pos'))
-      put('ball_ego_linear_velocity', S('ball_ego_linvel'))
-      put('ball_ego_angular_velocity', S('ball_ego_angvel'))
-      mates = [j for j in range(4) if j != k and _TEAM[j] == _TEAM[k]]
-      opps = [j for j in range(4) if _TEAM[j] != _TEAM[k]]
-      for prefix, others in (('teammate', mates), ('opponent', opps)):
-        for n, j in enumerate(others):
-          pre = '%s_%d' % (prefix, n)
-          put(pre + '_ego_end_effectors_pos', S('head_body_%s_end_effector' % pre))
-          put(pre + '_ego_linear_velocity', S(pre + '_ego_linear_velocity'))
-          put(pre + '_ego_position', S(pre + '_ego_position'))
-          put(pre + '_ego_orientation', torch.cat([S(pre + '_ego_orientation_' + d) for d in 'xyz'], dim=0))
-          # the other's end effectors in the OTHER's frame (observables.py:158-161: its own end_effectors_pos observable)
-          o = _PLAYERS[j] + '/head_body_end_effector'
-          put(pre + '_end_effectors_pos', sd[self._sadr[o]:self._sadr[o] + 3])
-      feats = corners if _TEAM[k] == 0 else corners[4:] + corners[:4]
-      for name, c in zip(corner_names, feats):
-        n = c.shape[0]
-        put(name, self._ego(c - pos[:n], R))
-      # stats (observables.py:262-330)
-      dir_ = ball - pos
-      unit = dir_[:2] / (torch.linalg.norm(dir_[:2], dim=0) + 1e-7)
-      # cvel[3:5] of the root body: the reference dots the planar direction with the body's com-frame linear velocity
-      vel_to_ball = (unit * cvel[6*self._root[k] + 3:6*self._root[k] + 5]).sum(dim=0)
-      put('stats_vel_to_ball', vel_to_ball)
-      closest = torch.ones(B, dtype=torch.bool, device=physics.device)
-      for j in mates:
-        closest = closest & (dist_to_ball[k] <= dist_to_ball[j])
-      put('stats_closest_vel_to_ball', torch.where(closest, vel_to_ball, torch.zeros_like(vel_to_ball)))
-      put('stats_veloc_forward', sd[s['vel']])
-      goal_mid = away_mid if _TEAM[k] == 0 else home_mid
-      direction = goal_mid - ball
-      nrm = torch.linalg.norm(direction, dim=0)
-      ndir = torch.where(nrm[None, :] > 0, direction / nrm.clamp_min(1e-30), direction)
-      put('stats_vel_ball_to_goal', (ndir * blin).sum(dim=0))
-      # observables.py:331-375
-      dists = [torch.linalg.norm(pos - frames[j][0], dim=0) for j in mates]
-      avg = torch.stack(dists).mean(dim=0) if dists else torch.zeros(B, dtype=physics.dtype, device=physics.device)
-      put('stats_home_avg_teammate_dist', avg)
-      put('stats_teammate_spread_out', (avg > 5.).to(physics.dtype))
-      mine_scored = home_goal_scored if _TEAM[k] == 0 else away_goal_scored
-      theirs_scored = away_goal_scored if _TEAM[k] == 0 else home_goal_scored
-      put('stats_home_score', mine_scored.to(physics.dtype))
-      put('stats_away_score', theirs_scored.to(physics.dtype))
-    return {name: torch.stack(v, dim=1) for name, v in out.items()}            # (B, 4, n)
+    mine = torch.where(self._team_t, away_goal_scored[None], home_goal_scored[None]).to(physics.dtype)
+    theirs = torch.where(self._team_t, home_goal_scored[None], away_goal_scored[None]).to(physics.dtype)
+    stats = torch.stack([vel_to_ball, torch.where(closest, vel_to_ball, torch.zeros_like(vel_to_ball)),
+                         (ndir * blin[None]).sum(dim=1), avg, (avg > 5.).to(physics.dtype), mine, theirs], dim=1)   # (4, 7, B)
+    pieces = [self._prev_action]                                                 # (4, 3, B)
+    pieces += [E[:, m, :d] for m, d in enumerate(self._CORNER_DIMS)]
+    comp = torch.cat(pieces + [stats], dim=1).permute(2, 0, 1)                   # (B, 4, C)
+    out = {}
+    for name, src, off, w in self._obs_layout:
+      if src == 'g':
+        out[name] = G[:, :, off:off + w]
+      elif src == 'c':
+        out[name] = comp[:, :, off:off + w]
+      else:
+        out[name] = out['sensors_velocimeter'][:, :, :1]
+    return out                                                                   # name -> (B, 4, n)
 
 
 def make(batch_size, device_id=0, precision=32, time_limit=45.0, random_state=0, fuse_substeps=None, **task_kwargs):

@@ -74,6 +74,7 @@ struct dmc_batch {
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (8, nitems) ints, or null
   struct Profiler* prof = nullptr;      // launch timers (dmc_batch_enable_profiling), or null
+  void* d_probe = nullptr; int probe_geom = 0, probe_cap = 0;      // substep probe (dmc_batch_set_step_probe): caller-owned (cap, 3, B) reals
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
@@ -318,6 +319,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->trace = b->d_trace; io->trace_slot = b->d_trace ? b->trace_launch++ : 0;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
+  io->probe = (T*)b->d_probe; io->probe_geom = b->probe_geom; io->probe_cap = b->probe_cap;
   io->stash_r = b->stash_on ? (T*)b->d_stash_r : nullptr; io->stash_i = b->stash_on ? b->d_stash_i : nullptr; io->epoch = b->d_epoch;
 }
 
@@ -428,7 +430,15 @@ static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* s
 extern "C" int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream) {
   if (!b) return fail("null batch");
   if (nstep < 1) return fail("nstep must be >= 1");
-  return launch(b, nstep, legacy_step ? 1 : 0, 0, hip_stream);
+  if (legacy_step == 2 && b->tb.opts.integrator == DMC_INT_RK4) return fail("legacy_step 2 (step + mj_forward) is not implemented for RK4 models");
+  return launch(b, nstep, legacy_step == 2 ? 2 : (legacy_step ? 1 : 0), 0, hip_stream);
+}
+extern "C" int dmc_batch_set_step_probe(dmc_batch* b, int geom_id, void* out_dev, int capacity) {
+  if (!b) return fail("null batch");
+  if (!out_dev || capacity < 1) { b->d_probe = nullptr; b->probe_cap = 0; return 0; }
+  if (geom_id < 0 || geom_id >= b->tb.L.d.ngeom) return fail("geom id out of range");
+  b->d_probe = out_dev; b->probe_geom = geom_id; b->probe_cap = capacity;
+  return 0;
 }
 struct Field;
 static int set_real(dmc_batch* b, Field* f, const double* src);

@@ -108,6 +108,10 @@ struct StepIO {
   // started and finished the item, its workgroup index, and the clock after the opening position / velocity stage, the
   // (first) acceleration stage, the (first) integration and the trailing stage of a step launch; null: no trace
   int* trace; int trace_slot;
+  // substep probe (dmc_batch_set_step_probe): the world position of ONE geom after every physics step of a legacy step
+  // launch, (probe_cap, 3, B) -- what an after_substep hook that only looks at a position needs (the soccer goal /
+  // out-of-court detectors, position_detector.py), so that a control step with such hooks is still one launch; null: off
+  T* probe = nullptr; int probe_geom = 0, probe_cap = 0;
   // rollout mode: per-env-step inputs / outputs, (T, rows, B); any may be null
   const T* ctrl_seq; T *qpos_seq, *qvel_seq, *sensor_seq;
   // optional per-env stash of the position / velocity stage (what mjData keeps between the mj_step1 that ends one
@@ -4922,9 +4926,13 @@ struct StepCore {
     // passes through the single stage_posvel()/stage_acc() call sites: ntotal full
     // passes (+ the trailing mj_step1 pass for legacy_step), or one pass for mj_forward
     const int npass = !stepping ? 1 : ntotal + ((legacy || mode == 3) ? 1 : 0);
+    // legacy == 2: a legacy step whose trailing mj_step1 is followed by the rest of mj_forward at the new state (the
+    // acceleration stage with its sensors, no integration) -- what the reference's composer observes after a control
+    // step (mjcf/physics.py:341-342: the first observable read through a binding forwards the dirty physics)
+    const bool fwd_after = legacy == 2 && mode == 0;
     for (int it = 0; it < npass; it++) {
       const bool trailing = stepping && it == ntotal;
-      const bool partial = trailing && !(stash && mode == 0);
+      const bool partial = trailing && !(stash && mode == 0) && !fwd_after;
       if (mode == 3 && !trailing && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
       if (stepping) { if (check_pos_vel()) { have = false; havekin = false; } }
       const int nstage = (stepping && !trailing && o.integrator == DMC_INT_RK4) ? 4 : 1;
@@ -4932,13 +4940,15 @@ struct StepCore {
       // read afterwards evaluate them: position/velocity sensors in the last pass of a launch and
       // at env-step boundaries of a rollout, acceleration sensors in the pass before those.
       const bool sens_pv = !stepping || it == npass - 1 || (mode == 3 && it % nsub == 0);
-      const bool sens_acc = !stepping || it == ntotal - 1 || (mode == 3 && (it + 1) % nsub == 0);
+      const bool sens_acc = !stepping || (it == ntotal - 1 && !fwd_after) || (mode == 3 && (it + 1) % nsub == 0);
       int stage = 0, retried = 0;
       while (stage < nstage) {
         if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv, havekin && it == 0 && !retried && !trailing);
         if (it == 0 && stage == 0) trace_stamp(io, env, 4); else if (trailing) trace_stamp(io, env, 7);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
-        if (trailing) break;
+        if (io.probe && mode == 0 && stage == 0 && it >= 1 && it <= io.probe_cap)      // the state after `it` physics steps
+          FOR_LANES(k, 3) io.probe[((size_t)(it - 1)*3 + k)*io.B + env] = S(geom_xpos)[3*io.probe_geom + k];
+        if (trailing) { if (fwd_after) call_acc(false, false); break; }
         call_acc(mode == 2, stage > 0 || !sens_acc);
         if (it == 0 && stage == 0) trace_stamp(io, env, 5);
         if (stage == 0 && stepping && !retried && bad_acc()) {
@@ -4955,10 +4965,13 @@ struct StepCore {
       DMC_PROF(PROF_EULER);
     }
     if (!stepping) dump_debug(io, env);
+    // an environment the launch override turned into mj_forward (just re-initialised) reports its one state in every slot
+    if (io.probe && !stepping && launch_mode == 0) for (int t = 0; t < nstep && t < io.probe_cap; t++)
+      FOR_LANES(k, 3) io.probe[((size_t)t*3 + k)*io.B + env] = S(geom_xpos)[3*io.probe_geom + k];
     if (!stepping || legacy || mode == 3) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
     // the stash holds a complete position / velocity stage at the CURRENT state only after a legacy step (after an
     // mj_forward the Cholesky buffer holds the factor of H, not of M; a non-legacy mj_step ends before mj_step1)
-    if (stash) store_stash(io, env, mode == 0 && legacy);
+    if (stash) store_stash(io, env, mode == 0 && legacy && !fwd_after);      // (after the forward the Cholesky buffer holds H's factor)
     // the trailing stage (partial or full) evaluated kinematics / COM frame / velocities at the state being stored
     if (io.kstash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) store_kstash(io, env);
     store_state(io, env);

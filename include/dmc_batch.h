@@ -52,8 +52,20 @@ void dmc_batch_destroy(dmc_batch* b);
 /* Replaces Physics.step(nstep) = mj_step2; mj_step(nstep-1); mj_step1 when
  * legacy_step != 0 (dm_control/mujoco/engine.py:147-162) or mj_step(nstep)
  * otherwise (engine.py:176), for every env, in ONE kernel launch.
+ * legacy_step == 2: the legacy step followed, in the same launch, by the rest of mj_forward at the new state (the
+ * acceleration stage with its sensors, no integration) -- what a composer agent observes: the reference's observation
+ * update forwards the dirty physics before the first observable is read (dm_control/mjcf/physics.py:341-342 after
+ * composer/environment.py:412-465), so touch / torque / accelerometer values are those of the NEW state.
  * hip_stream: hipStream_t to launch on (NULL = default stream).  Asynchronous. */
 int dmc_batch_step(dmc_batch* b, int nstep, int legacy_step, void* hip_stream);
+
+/* Substep probe: the world position of geom `geom_id` after EVERY physics step of a legacy step launch, written to the
+ * caller's device array `out_dev`, (capacity, 3, B) reals of the batch precision (slot k = after k + 1 steps; an
+ * environment the launch override turns into mj_forward reports its one state in every slot).  Replaces an
+ * `after_substep` hook that only reads a position -- composer/environment.py:412-465 runs the hooks between the
+ * mj_step calls; entities/props/position_detector.py:200-260 is such a hook (the soccer goal / out-of-court
+ * detectors with retain_substep_detections) -- so that the control step stays ONE launch.  out_dev NULL: off. */
+int dmc_batch_set_step_probe(dmc_batch* b, int geom_id, void* out_dev, int capacity);
 
 /* Random-action / open-loop rollouts without a launch per step: plays `nsteps`
  * env-steps of `n_sub_steps` physics steps each (the loop of

@@ -113,8 +113,15 @@ class OracleDevicePhysics:
       self._forward(e, disable_actuation)
       self._pull(e, state=False)
 
-  def step(self, nstep=1):
-    self.launches.append('step%d' % nstep)
+  def substep_probe(self, geom_name, capacity):
+    self._probe_geom = self.model.name2id(geom_name, 'geom')
+    self._probe = torch.zeros((capacity, 3, self.B), dtype=torch.float64)
+    return self._probe
+
+  def step(self, nstep=1, forward_after=False):
+    self.launches.append('step%d%s' % (nstep, '+forward' if forward_after else ''))
+    probe = getattr(self, '_probe', None)
+    gx = lambda o: torch.from_numpy(np.array(o.field('geom_xpos')).reshape(-1, 3)[self._probe_geom].copy())
     for e in range(self.B):
       mode = int(self._fields['env_mode'][0, e])
       if mode == 2:
@@ -123,9 +130,19 @@ class OracleDevicePhysics:
       if mode == 1:
         self._forward(e, True)
         self._pull(e, state=False)
+        if probe is not None:
+          probe[:min(nstep, probe.shape[0]), :, e] = gx(self._envs[e])
       else:
         self._envs[e].step1()        # derived arrays of the (possibly edited) state, as the kernel recomputes them
-        self._envs[e].step(int(nstep))
+        if probe is None:
+          self._envs[e].step(int(nstep))
+        else:                        # one legacy step at a time: mj_step2 ... mj_step1 leaves the geom pose of the new state
+          for k in range(int(nstep)):
+            self._envs[e].step(1)
+            if k < probe.shape[0]:
+              probe[k, :, e] = gx(self._envs[e])
+        if forward_after:
+          self._forward(e, False)
         self._pull(e)
 
   def reset(self, mask=None):

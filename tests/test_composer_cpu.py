@@ -223,7 +223,8 @@ def test_soccer_substep_detectors_rewards_and_throw_in():
   env, task, phys = _soccer_env(3)
   m = task.model
   assert (m.nq, m.nv, m.nu) == (31, 30, 12) and env.n_sub_steps == 5
-  assert not env.fused                       # the goal detectors watch every substep (pitch.py:262)
+  # the goal detectors watch every substep (pitch.py:262) -- through the step kernel's substep probe: one launch
+  assert env.fused and env.probed
   ts = env.reset()
   assert ts.observation['ball_ego_position'].shape == (3, 4, 3)
   assert ts.observation['teammate_0_ego_position'].shape == (3, 4, 3) and ts.observation['opponent_1_ego_orientation'].shape == (3, 4, 9)
@@ -232,7 +233,7 @@ def test_soccer_substep_detectors_rewards_and_throw_in():
   a = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (3, 4, 3)))
   phys.launches.clear()
   ts = env.step(a)
-  assert phys.launches == ['step1'] * 5
+  assert phys.launches == ['step5']
   np.testing.assert_array_equal(phys.field('ctrl')[:, 0].numpy(), a[0].reshape(-1).numpy())
   assert ts.reward.shape == (4, 3) and float(ts.reward.abs().max()) == 0.0
   # egocentric ball position of home0: the framepos sensor objtype = reftype = "body" of observables.py:182-186, which
@@ -259,6 +260,41 @@ def test_soccer_substep_detectors_rewards_and_throw_in():
   assert ts.step_type.tolist() == [environment.FIRST, environment.MID, environment.MID]
   b2 = task.ball_xpos(phys)[:, 2].numpy()
   assert abs(b2[1]) < 27.0 * 0.9 + 0.3 and not bool(task.field.detected[2])
+
+
+def test_soccer_probed_launch_equals_the_per_substep_hooks():
+  """A ball that crosses the goal volume INSIDE a control step (in at substep 2, out again by the last one) is a goal
+  for the reference (retain_substep_detections).  The default environment sees it in the probe trace of its single
+  launch exactly as `fuse_substeps=False` does with five launches and the hooks in between; `fuse_substeps=True`, which
+  looks at the end of the control step only, misses it."""
+  outs = {}
+  xml = common.read_model('soccer_2v2_boxhead.xml').replace('<option ', '<option gravity="0 0 0" ', 1)
+  assert 'gravity="0 0 0"' in xml
+  model = mc.compile_xml(xml)
+  model.opt.disableflags = int(model.opt.disableflags) | mc.C['DMC_DSBL_CONTACT']      # ballistic: nothing deflects the ball
+  for mode in (None, False, True):
+    task = soccer.Soccer2v2(model=model)
+    phys = OracleDevicePhysics(task.model, 2, outputs=('sensordata', 'xpos', 'xmat', 'geom_xpos', 'cvel'), nconmax=24)
+    env = environment.Environment(task, phys, time_limit=45.0, random_state=1, fuse_substeps=mode)
+    env.reset()
+    bq, bv = task._ball_q, task._ball_v
+    # env 0: clips the upper front edge of the away goal volume (x > 34.67, z < 5.33) at (40, 0, 60) m/s: inside after
+    # the first substep only; env 1: at rest mid-field
+    phys.field('qpos')[bq:bq + 7, 0] = torch.tensor([34.6, 0.0, 5.0 - 0.35, 1, 0, 0, 0], dtype=torch.float64)
+    phys.field('qvel')[bv:bv + 6, 0] = torch.tensor([40.0, 0.0, 60.0, 0.0, 0.0, 0.0], dtype=torch.float64)
+    phys.mark_as_dirty()
+    phys.launches.clear()
+    ts = env.step(torch.zeros((2, 4, 3), dtype=torch.float64))
+    outs[mode] = (ts.reward.clone(), ts.step_type.clone(), task.away_goal.detected.clone(), task.field.detected.clone(),
+                  {k: v.clone() for k, v in ts.observation.items()}, list(phys.launches))
+  assert outs[None][5] == ['step5'] and outs[False][5] == ['step1'] * 5 and outs[True][5] == ['step5']
+  for a, b in zip(outs[None][:4], outs[False][:4]):
+    assert torch.equal(a, b)
+  for k in outs[None][4]:
+    assert torch.equal(outs[None][4][k], outs[False][4][k]), k
+  assert outs[None][2].tolist() == [True, False] and outs[None][1].tolist() == [environment.LAST, environment.MID]
+  assert outs[None][0][:, 0].tolist() == [1.0, 1.0, -1.0, -1.0]
+  assert outs[True][2].tolist() == [False, False]      # the ball has left the volume again by the end of the control step
 
 
 def test_soccer_fused_checks_detectors_once_per_control_step():

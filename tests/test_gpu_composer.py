@@ -152,14 +152,14 @@ def test_soccer_environment_on_gpu():
   B = 16
   env = composer.make('soccer_2v2', B, random_state=2)
   task, phys, m = env.task, env.physics, env.task.model
-  assert not env.fused and env.n_sub_steps == 5
+  assert env.fused and env.probed and env.n_sub_steps == 5      # the goal detectors read the kernel's substep probe
   ts = env.reset()
   assert tuple(ts.observation['ball_ego_position'].shape) == (B, 4, 3)
   gen = torch.Generator(device='cuda').manual_seed(0)
   l0 = env.launches
   for t in range(10):
     ts = env.step(torch.rand((B, 4, 3), device='cuda', generator=gen) * 2 - 1)
-  assert env.launches - l0 == 50
+  assert env.launches - l0 == 10
   torch.cuda.synchronize()
   # the framepos sensor objtype = reftype = "body" (observables.py:182-186): between the bodies' INERTIAL frames
   from dm_control_amd import mjcf_compiler
@@ -187,6 +187,47 @@ def test_soccer_environment_on_gpu():
   assert int(ts.step_type[0]) == environment.FIRST and not bool(task.field.detected[5])
   assert int(phys.field('warning').sum()) == 0
   env.close()
+
+
+@pytest.mark.parametrize('precision', [64, 32])
+def test_soccer_probed_launch_equals_the_per_substep_hooks_on_gpu(precision):
+  """dmc_batch_set_step_probe: one fused launch whose substep probe feeds the goal / out-of-court detectors against
+  n_sub_steps launches with the after_substep hooks in between (`fuse_substeps=False`): same physics (step(5) == 5 x
+  step()), same detections, rewards, step types and observations over episodes with goals, throw-ins and auto-resets --
+  and a ball that is inside the goal volume for one substep only is a goal for both."""
+  import torch
+  from dm_control_amd import composer
+  from dm_control_amd.composer import environment
+  B = 24
+  envs = [composer.make('soccer_2v2', B, random_state=6, precision=precision, fuse_substeps=f) for f in (None, False)]
+  assert envs[0].probed and not envs[1].fused
+  gen = torch.Generator(device='cuda').manual_seed(3)
+  acts = torch.rand((30, B, 4, 3), device='cuda', generator=gen) * 2 - 1
+  for e in envs:
+    e.reset()
+  dt = envs[0].physics.dtype
+  scored = 0
+  for t in range(30):
+    if t in (3, 11):      # kick the ball towards a goal in a few environments: it crosses the volume within the control step
+      for e in envs:
+        task, p = e.task, e.physics
+        bq, bv = task._ball_q, task._ball_v
+        p.field('qpos')[bq:bq + 7, :4] = torch.tensor([33.0, 0.0, 1.0, 1, 0, 0, 0], device='cuda', dtype=dt)[:, None]
+        p.field('qvel')[bv:bv + 6, :4] = torch.tensor([60.0, 0.0, 2.0, 0, 0, 0], device='cuda', dtype=dt)[:, None]
+        p.mark_as_dirty()
+    out = [e.step(acts[t]) for e in envs]
+    torch.cuda.synchronize()
+    a, b = out
+    assert torch.equal(a.step_type, b.step_type), t
+    assert torch.equal(a.reward, b.reward) and torch.equal(a.discount, b.discount), t
+    for k in a.observation:
+      assert torch.equal(a.observation[k], b.observation[k]), (k, t)
+    scored += int((a.step_type == environment.LAST).sum())
+  assert scored >= 4
+  assert envs[0].launches == 1 + 30 and envs[1].launches == 1 + 150      # one launch per control step against five
+  for e in envs:
+    assert int(e.physics.field('warning')[:8].sum()) == 0
+    e.close()
 
 
 @pytest.mark.parametrize('precision,tol', [(64, 1e-9), (32, 2e-4)])

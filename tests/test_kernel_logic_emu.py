@@ -707,3 +707,27 @@ def test_cg_reaches_the_newton_solution():
     assert a.nefc > 0
     assert np.abs(a.qacc - b.qacc).max() / scale < 1e-6
     assert np.abs(b.qacc - e.qacc).max() / scale < 1e-6      # at this tolerance the kernel's rounding floor on the stopping tests ends CG a few iterations earlier
+
+
+@pytest.mark.parametrize('asset,nsub', [('cheetah', 1), ('humanoid', 5), ('cmu_2019_position_floor', 2)])
+def test_step_with_forward_after_equals_step_then_forward(asset, nsub):
+  """dmc_batch_step legacy_step 2 (the launch a composer control step ends with for observation_forward tasks): the legacy
+  step followed by the rest of mj_forward at the new state in ONE pass over the position / velocity stage -- state, warm
+  start, acceleration-stage sensors and every derived array equal those of a step launch followed by a forward launch."""
+  from dm_control_amd.suite import common
+  m = mc.compile_xml(common.read_model(asset + '.xml'))
+  caps = dict(common.DEFAULT_CAPS.get(asset, {})); caps.pop('precision', None)
+  a, b = EmuPhysics(m, 64, **caps), EmuPhysics(m, 64, **caps)
+  rs = np.random.RandomState(0)
+  q = m.qpos0.copy(); q[2] -= {'cheetah': 0.0, 'humanoid': 0.05, 'cmu_2019_position_floor': 0.25}[asset]      # feet in the floor
+  for p in (a, b):
+    p.qpos[:] = q
+    p.forward()
+  for t in range(12):
+    c = rs.uniform(-1, 1, m.nu)
+    a.ctrl[:] = c; b.ctrl[:] = c
+    a.step(nsub, legacy=2)
+    b.step(nsub); b.forward()
+    for name in ('qpos', 'qvel', 'qacc', 'qacc_warmstart', 'sensordata', 'xpos', 'actuator_force'):
+      np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg='%s step %d' % (name, t))
+  assert a.ncon[0] > 0 or asset == 'cmu_2019_position_floor'
