@@ -289,7 +289,7 @@ class Environment:
     self._hooks.before_step(p, action, self._rs)
     ctrl = p.field('ctrl')
     if ctrl.numel():
-      ctrl.copy_(torch.where(first[None, :], torch.zeros_like(ctrl), ctrl))
+      ctrl.masked_fill_(first[None, :], 0)
     # observation_forward tasks: the launch that ends the control step also runs the rest of mj_forward at the new state
     # (dmc_batch_step legacy_step 2) -- see below; environments re-initialised in this call are not touched by it
     obs_forward = bool(getattr(task, 'observation_forward', False))

@@ -268,7 +268,7 @@ class DevicePhysics:
       m2 = mask[None, :]
       f['qpos'].copy_(torch.where(m2, q0, f['qpos']))
       for n in ('qvel', 'ctrl', 'qacc_warmstart', 'time') + (('act',) if 'act' in f else ()):
-        f[n].copy_(torch.where(m2, torch.zeros_like(f[n]), f[n]))
+        f[n].masked_fill_(m2, 0)      # (one in-place kernel per field: this runs in every control step, under the restart mask)
     self.mark_as_dirty()
 
   def close(self):

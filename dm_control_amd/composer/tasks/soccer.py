@@ -77,26 +77,21 @@ def kickoff_qpos(model):
   return q
 
 
-class PositionDetector(environment.Entity):
-  """Axis-aligned detection volume on the ball's geom position (position_detector.py:42-260)."""
+class PositionDetector:
+  """Axis-aligned detection volume on the ball's geom position (position_detector.py:42-260).  State and bounds live in
+  the task's `DetectorBank` (one evaluation for all detectors); this object is the per-detector view of them."""
 
   def __init__(self, lower, upper, inverted=False, retain_substep_detections=False):
     self.lower, self.upper = np.asarray(lower, float), np.asarray(upper, float)
     self.mid = (self.lower + self.upper) / 2
     self.inverted = inverted
     self.retain = retain_substep_detections
-    self.detected = None      # (B,) bool
-    self._ball_rows = None
-
-  def bind_ball(self, task):
-    self._task = task
+    self.detected = None      # (B,) bool: a row of the bank's state
+    self._lo_t = self._hi_t = None
 
   def bounds(self, physics):
     """(lower, upper) as (d, B) tensors: per-environment once the pitch is randomised (`resize`)."""
-    torch = physics.torch
-    if getattr(self, '_lo_t', None) is None:
-      self._lo_t = torch.as_tensor(self.lower, dtype=physics.dtype, device=physics.device)[:, None].expand(-1, physics.B).clone()
-      self._hi_t = torch.as_tensor(self.upper, dtype=physics.dtype, device=physics.device)[:, None].expand(-1, physics.B).clone()
+    self._bank.materialise(physics)
     return self._lo_t, self._hi_t
 
   def resize(self, physics, pos, size, mask):
@@ -106,39 +101,58 @@ class PositionDetector(environment.Entity):
     lo.copy_(physics.torch.where(m2, pos - size, lo))
     hi.copy_(physics.torch.where(m2, pos + size, hi))
 
-  def _inside(self, physics):
-    p = self._task.ball_xpos(physics)
-    lo, hi = self.bounds(physics)
-    d = lo.shape[0]
-    inside = ((p[:d] > lo) & (p[:d] < hi)).all(dim=0)
-    return ~inside if self.inverted else inside
+
+class DetectorBank(environment.Entity):
+  """The pitch's PositionDetectors as ONE entity: their hooks (initialize_episode, before_step, after_substep;
+  position_detector.py:200-260) evaluated for all detectors in a handful of tensor operations instead of a handful per
+  detector.  `after_substeps` is the same from the step kernel's substep probe (environment.Environment: the control
+  step stays one launch and the detections are the per-substep ones)."""
+
+  substep_probe_geom = 'soccer_ball/geom'
+
+  def __init__(self, detectors, ball_xpos):
+    self.detectors = list(detectors)
+    self._ball_xpos = ball_xpos
+    self.state = None
+    for d in self.detectors:
+      d._bank = self
+
+  def materialise(self, physics):
+    if self.state is not None:
+      return
+    torch = physics.torch
+    n, B, dev = len(self.detectors), physics.B, physics.device
+    self.state = torch.zeros((n, B), dtype=torch.bool, device=dev)
+    # a 2-d detector (the field) is unbounded in z
+    self.lo = torch.full((n, 3, B), -np.inf, dtype=physics.dtype, device=dev)
+    self.hi = torch.full((n, 3, B), np.inf, dtype=physics.dtype, device=dev)
+    for k, d in enumerate(self.detectors):
+      nd = len(d.lower)
+      self.lo[k, :nd] = torch.as_tensor(d.lower, dtype=physics.dtype, device=dev)[:, None]
+      self.hi[k, :nd] = torch.as_tensor(d.upper, dtype=physics.dtype, device=dev)[:, None]
+      d._lo_t, d._hi_t, d.detected = self.lo[k, :nd], self.hi[k, :nd], self.state[k]
+    self.inverted = torch.as_tensor([d.inverted for d in self.detectors], dtype=torch.bool, device=dev)[None, :, None]
+    self.retain = torch.as_tensor([d.retain for d in self.detectors], dtype=torch.bool, device=dev)[:, None]
 
   def initialize_episode(self, physics, random_state, mask):
-    torch = physics.torch
-    if self.detected is None:
-      self.detected = torch.zeros(physics.B, dtype=torch.bool, device=physics.device)
-    self.detected.copy_(self.detected & ~mask)
+    self.materialise(physics)
+    self.state.masked_fill_(mask[None, :], False)
 
   def before_step(self, physics, random_state):
     # position_detector.py before_step: a retained detection is cleared at the start of the next control step
-    if self.retain:
-      self.detected.zero_()
+    self.state.masked_fill_(self.retain, False)
 
   def after_substep(self, physics, random_state):
-    now = self._inside(physics)
-    self.detected.copy_((self.detected | now) if self.retain else now)
-
-  # the same from the step kernel's substep probe: the ball's position after every physics step of ONE fused launch
-  substep_probe_geom = 'soccer_ball/geom'
+    self.after_substeps(physics, self._ball_xpos(physics)[None])
 
   def after_substeps(self, physics, trace):
     """trace: (n_sub_steps, 3, B) ball positions.  after_substep applied n times: a retaining detector ORs its
     per-substep detections into the control step's, a plain one keeps the last."""
-    lo, hi = self.bounds(physics)
-    d = lo.shape[0]
-    inside = ((trace[:, :d] > lo[None]) & (trace[:, :d] < hi[None])).all(dim=1)      # (n, B)
-    now = ~inside if self.inverted else inside
-    self.detected.copy_((self.detected | now.any(dim=0)) if self.retain else now[-1])
+    torch = physics.torch
+    p = trace[:, None]                                                           # (n, 1, 3, B)
+    inside = ((p > self.lo[None]) & (p < self.hi[None])).all(dim=2)             # (n, detectors, B)
+    now = inside ^ self.inverted
+    self.state.copy_(torch.where(self.retain, self.state | now.any(dim=0), now[-1]))
 
 
 class Soccer2v2(environment.Task):
@@ -156,8 +170,7 @@ class Soccer2v2(environment.Task):
     self.away_goal = PositionDetector(away_pos - gs, away_pos + gs, retain_substep_detections=True)
     fs = np.array([_SIZE[0] - 2 * gs[0], _SIZE[1] - 2 * gs[0]])
     self.field = PositionDetector(-fs, fs, inverted=True)
-    for d in (self.home_goal, self.away_goal, self.field):
-      d.bind_ball(self)
+    self.detectors = DetectorBank((self.home_goal, self.away_goal, self.field), self.ball_xpos)
     m = self.model
     self._ball_geom = m.name2id('soccer_ball/geom', 'geom')
     self._ball_body = m.name2id('soccer_ball/', 'body')
@@ -179,7 +192,7 @@ class Soccer2v2(environment.Task):
 
   @property
   def entities(self):
-    return (self.home_goal, self.away_goal, self.field)
+    return (self.detectors,)
 
   def generators(self):
     return [self._gen] if self._gen is not None else []
@@ -242,27 +255,31 @@ class Soccer2v2(environment.Task):
     return lo + (hi - lo) * u
 
   def _place(self, physics, mask):
-    """UniformInitializer._initialize_entities for the masked environments: returns nothing, edits qpos."""
+    """UniformInitializer._initialize_entities (soccer/initializers.py:96-127) for the masked environments: ball and
+    players uniform over the spawn range, players with a uniform yaw; a placement with two entities closer than their
+    bounding radii is redrawn (the reference redraws on detected contacts), up to four times.  All four candidate
+    draws are made at once and every environment takes its first acceptable one: no data-dependent loop, one random
+    tensor, one scatter into qpos (the per-entity version was ~150 small operations in EVERY control step, because the
+    restart mask is only known on the device)."""
     torch = physics.torch
+    B = physics.B
     q = physics.field('qpos')
-    m2 = mask[None, :]
-    spawn = self._size_t * self._spawn_ratio                      # (2, B): spawn_range = arena.size * spawn_ratio
-    unit = lambda: self._uniform(physics, [-1.0, -1.0], [1.0, 1.0]) * spawn
-    ball = unit()
-    pos = [ball]
-    bq = self._ball_q
-    q[bq:bq + 2] = torch.where(m2, ball, q[bq:bq + 2])
-    q[bq + 2] = torch.where(mask, torch.full_like(q[bq + 2], _INIT_BALL_Z - 0.35), q[bq + 2])      # geom centre at z = 0.5 (body + 0.35)
-    for k, p in enumerate(_PLAYERS):
-      xy = unit()
-      pos.append(xy)
-      spot = physics.const(_SPOTS[k])[:, None]
-      a = self._q[p]
-      q[a['root_x']] = torch.where(mask, xy[0] - spot[0], q[a['root_x']])      # slides are relative to the frame
-      q[a['root_y']] = torch.where(mask, xy[1] - spot[1], q[a['root_y']])
-      yaw = self._uniform(physics, [-np.pi], [np.pi])[0]
-      q[a['steer']] = torch.where(mask, yaw, q[a['steer']])
-    return torch.stack(pos)            # (5, 2, B)
+    R = 4
+    u = torch.rand((R, 5, 3, B), generator=self._gen, device=physics.device, dtype=physics.dtype) * 2 - 1
+    spawn = self._size_t * self._spawn_ratio                                     # (2, B): arena.size * spawn_ratio
+    xy = u[:, :, :2] * spawn[None, None]                                         # (R, 5, 2, B): ball, then the players
+    d = torch.linalg.norm(xy[:, :, None] - xy[:, None, :], dim=3)                # (R, 5, 5, B)
+    close = ((d < 1.5) & ~self._eye5).flatten(1, 2).any(dim=1)                   # (R, B)
+    ok = ~close
+    ok[R - 1] = True                                                             # the last draw is kept whatever it is
+    first = ok.to(torch.int8).argmax(dim=0)                                      # first acceptable round per environment
+    sel = torch.gather(u, 0, first[None, None, None, :].expand(1, 5, 3, B))[0]   # (5, 3, B)
+    pos = sel[:, :2] * spawn[None]
+    yaw = sel[1:, 2] * np.pi                                                     # (4, B)
+    z = torch.full((1, B), _INIT_BALL_Z - 0.35, dtype=physics.dtype, device=physics.device)      # geom centre at z = 0.5 (body + 0.35)
+    vals = torch.cat([pos[0], z, (pos[1:] - self._spots_t).reshape(8, B), yaw])  # rows: ball x y z, players x y ..., yaws
+    cur = q[self._place_rows]
+    q.index_copy_(0, self._place_rows, torch.where(mask[None, :], vals, cur))
 
   # -- hooks -------------------------------------------------------------------------------------------
   def initialize_episode(self, physics, random_state, mask):
@@ -272,40 +289,38 @@ class Soccer2v2(environment.Task):
       self._gen.manual_seed(int(random_state.randint(2**31 - 1)))
       self._prev_action = torch.zeros((4, 3, physics.B), dtype=physics.dtype, device=physics.device)
       self._size_t = torch.as_tensor(_SIZE, dtype=physics.dtype, device=physics.device)[:, None].expand(2, physics.B).clone()
+      dev = physics.device
+      self._eye5 = torch.eye(5, dtype=torch.bool, device=dev)[None, :, :, None]
+      self._spots_t = torch.as_tensor(_SPOTS, dtype=physics.dtype, device=dev)[:, :, None]      # slides are relative to the attachment frame
+      bq = self._ball_q
+      rows = [bq, bq + 1, bq + 2] + [self._q[p][k] for p in _PLAYERS for k in ('root_x', 'root_y')] + [self._q[p]['steer'] for p in _PLAYERS]
+      self._place_rows = torch.as_tensor(rows, dtype=torch.long, device=dev)
+      self._ctrl_rows_t = torch.as_tensor([r for rows_ in self._ctrl_rows for r in rows_], dtype=torch.long, device=dev)
     if self._randomize is not None:
       lo, hi = self._randomize
       size = self._uniform(physics, lo, hi)                    # one ratio per axis (keep_aspect_ratio=False)
       self._size_t.copy_(torch.where(mask[None, :], size, self._size_t))
       self._resize_pitch(physics, self._size_t, mask)
-    todo = mask
-    for _ in range(4):                 # redraw placements whose entities overlap (initializers.py:96-127)
-      pos = self._place(physics, todo)
-      d = torch.linalg.norm(pos[:, None] - pos[None, :], dim=2)                    # (5, 5, B)
-      eye = torch.eye(5, dtype=torch.bool, device=physics.device)[:, :, None]
-      close = ((d < 1.5) & ~eye).any(dim=0).any(dim=0)
-      todo = todo & close
-    self._prev_action.copy_(torch.where(mask[None, None, :], torch.zeros_like(self._prev_action), self._prev_action))
+    self._place(physics, mask)
+    self._prev_action.masked_fill_(mask[None, None, :], 0)
     physics.mark_as_dirty()
 
   def before_step(self, physics, action, random_state):
     """action: (B, 4, 3).  task.py:211-217: apply the players' actions, then throw the ball in if it left the court."""
     torch = physics.torch
     a = action.permute(1, 2, 0).to(physics.dtype)              # (4, 3, B)
-    ctrl = physics.field('ctrl')
-    for k in range(4):
-      for j in range(3):
-        ctrl[self._ctrl_rows[k][j]] = a[k, j]
+    physics.field('ctrl').index_copy_(0, self._ctrl_rows_t, a.reshape(12, physics.B))
     self._prev_action.copy_(a)
     off = self.field.detected
-    if off is not None:
+    if off is not None:      # (None before the first initialize_episode)
       # _throw_in (task.py:128-135): ball back at a shrunk position, at rest
       q, v = physics.field('qpos'), physics.field('qvel')
       xy = self.ball_xpos(physics)[:2]
       shrink = self._uniform(physics, [0.7, 0.7], [0.9, 0.9])
       bq, bv = self._ball_q, self._ball_v
       q[bq:bq + 2] = torch.where(off[None, :], xy * shrink, q[bq:bq + 2])
-      q[bq + 2] = torch.where(off, torch.full_like(q[bq + 2], _THROW_IN_BALL_Z - 0.35), q[bq + 2])
-      v[bv:bv + 6] = torch.where(off[None, :], torch.zeros_like(v[bv:bv + 6]), v[bv:bv + 6])
+      q[bq + 2].masked_fill_(off, _THROW_IN_BALL_Z - 0.35)
+      v[bv:bv + 6].masked_fill_(off[None, :], 0)
       physics.mark_as_dirty()
 
   def _scoring_team(self, physics):
