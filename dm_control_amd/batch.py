@@ -103,6 +103,45 @@ class BatchedPhysics:
     fn = _native.lib().dmc_batch_set_int if is_int else _native.lib().dmc_batch_set
     _native.check(fn(self._ptr, name.encode(), a.ctypes.data))
 
+  # -- asynchronous host transfers (dmc_batch_set_async / get_async / get_wait) ------------------------------------------
+  def set_async(self, name, value, stream=None):
+    """Writes the (B, rows) host array `value` (float32 or float64; float32 goes onto the wire as it is for an fp32
+    batch) to field `name`, ordered on `stream` with the launches.  `value` is consumed before the call returns."""
+    rows, is_int = self._rows(name)
+    if is_int:
+      raise ValueError('%s is an int field' % name)
+    if not rows:
+      return
+    a = np.asarray(value)
+    dt = np.float32 if a.dtype == np.float32 else np.float64
+    a = np.ascontiguousarray(np.broadcast_to(a.astype(dt, copy=False).reshape((-1, rows) if a.ndim > 1 else (1, rows)), (self.batch_size, rows)))
+    _native.check(_native.lib().dmc_batch_set_async(self._ptr, name.encode(), a.ctypes.data, 32 if dt == np.float32 else 64, stream))
+
+  def get_async(self, names, stream=None):
+    """Enqueues the read of the real fields `names` as of this point of `stream` (one device-to-host copy for all of
+    them); `get_wait` returns the arrays.  One get at a time."""
+    names = list(names)
+    arr = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+    _native.check(_native.lib().dmc_batch_get_async(self._ptr, len(names), arr, stream))
+    self._pending_get = names
+
+  def get_wait(self, dtype=np.float64):
+    """{name: (B, rows) array of `dtype` (float64 or float32)} of the get enqueued by `get_async`."""
+    names = self._pending_get
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+      raise ValueError('dtype must be float64 or float32')
+    outs = [np.empty((self.batch_size, self._rows(n)[0]), dtype=dt) for n in names]
+    ptrs = (ctypes.c_void_p * len(names))(*[o.ctypes.data if o.size else None for o in outs])
+    _native.check(_native.lib().dmc_batch_get_wait(self._ptr, len(names), ptrs, 32 if dt == np.dtype(np.float32) else 64))
+    self._pending_get = None
+    return dict(zip(names, outs))
+
+  def get_many(self, names, stream=None, dtype=np.float64):
+    """Several real fields with one device-to-host copy and one wait."""
+    self.get_async(names, stream)
+    return self.get_wait(dtype)
+
   def device_ptr(self, name):
     p = _native.lib().dmc_batch_device_ptr(self._ptr, name.encode())
     if not p:

@@ -74,6 +74,7 @@ struct dmc_batch {
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (8, nitems) ints, or null
   struct Profiler* prof = nullptr;      // launch timers (dmc_batch_enable_profiling), or null
+  struct Xfer* xfer = nullptr;      // pinned / device staging of the asynchronous host transfers (dmc_batch_set_async / get_async), or null
   void* d_probe = nullptr; int probe_geom = 0, probe_cap = 0;      // substep probe (dmc_batch_set_step_probe): caller-owned (cap, 3, B) reals
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
@@ -269,10 +270,12 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
 }
 
 static void prof_free(struct Profiler* p);
+static void xfer_free(struct Xfer* x);
 extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   if (b->prof) { prof_free(b->prof); b->prof = nullptr; }
+  if (b->xfer) { xfer_free(b->xfer); b->xfer = nullptr; }
   for (Field& f : b->fields) if (f.owned) (void)hipFree(f.owned);
   if (b->d_mi) (void)hipFree(b->d_mi);
   if (b->d_mc) (void)hipFree(b->d_mc);
@@ -658,11 +661,21 @@ extern "C" int dmc_batch_sync(dmc_batch* b) {
 }
 
 // ---- host <-> device field transfer (env-major host, SoA device) ------------------
+extern "C" int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream);
+extern "C" int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names, void* hip_stream);
+extern "C" int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int host_bits);
+static bool get_in_flight(const dmc_batch* b);
 static int get_real(dmc_batch* b, Field* f, double* dst) {
   const size_t n = (size_t)f->rows * b->B;
   if (!n) return 0;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (!get_in_flight(b)) {      // the pinned / device-transposed path, completed before returning
+    const char* nm = f->name.c_str();
+    if (dmc_batch_get_async(b, 1, &nm, nullptr)) return -2;
+    void* d = dst;
+    return dmc_batch_get_wait(b, 1, &d, 64);
+  }
   if (b->precision == 64 || f->is_f64) {
     std::vector<double> tmp(n);
     HIP_TRY(hipMemcpy(tmp.data(), f->dev, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -677,18 +690,137 @@ static int get_real(dmc_batch* b, Field* f, double* dst) {
 static int set_real(dmc_batch* b, Field* f, const double* src) {
   const size_t n = (size_t)f->rows * b->B;
   if (!n) return 0;
-  if (f->name != "ctrl" && f->name != "qfrc_applied" && f->name != "xfrc_applied") { if (bump_epoch(b, 0, true)) return -2; }   // (the others are inputs of the acceleration stage only)
-  if (f->name == "xfrc_applied") b->xfrc_on = 1;
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  if (b->precision == 64 || f->is_f64) {
-    std::vector<double> tmp(n);
-    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = src[(size_t)e * f->rows + k];
-    HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
-  } else {
-    std::vector<float> tmp(n);
-    for (int k = 0; k < f->rows; k++) for (int e = 0; e < b->B; e++) tmp[(size_t)k * b->B + e] = (float)src[(size_t)e * f->rows + k];
-    HIP_TRY(hipMemcpy(f->dev, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  // (ctrl / qfrc_applied / xfrc_applied are inputs of the acceleration stage only; every other field bumps the stash epoch)
+  // the synchronous form of dmc_batch_set_async: pinned staging, device-side transposition, done before returning
+  if (dmc_batch_set_async(b, f->name.c_str(), src, 64, nullptr)) return -2;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return 0;
+}
+// ---- asynchronous host transfers -------------------------------------------------------------------------------
+// The host side of the boundary is env-major ((B, rows): what numpy callers hold), the device fields are SoA
+// ((rows, B)).  dmc_batch_set / dmc_batch_get transpose and convert element by element on one host thread around
+// synchronous pageable copies.  Here: the host only converts contiguously into PINNED staging (or not at all: fp32 on
+// the wire for fp32 batches), copies are hipMemcpyAsync on the caller's stream, the transposition is a device kernel
+// (LDS tile, coalesced on both sides), and a get of several fields is ONE device-to-host copy and one wait.
+struct Xfer {
+  static constexpr int kSlots = 4;
+  void* h_in[kSlots] = {}; void* d_in[kSlots] = {}; size_t cap_in[kSlots] = {}; hipEvent_t ev_in[kSlots] = {}; int next = 0;
+  void* h_out = nullptr; void* d_out = nullptr; size_t cap_out = 0; hipEvent_t ev_out = nullptr;
+  std::vector<std::pair<Field*, size_t>> pending;      // fields of the enqueued get and their offsets (elements) in the staging
+  bool out_in_flight = false;
+};
+static void xfer_free(Xfer* x) {
+  (void)hipDeviceSynchronize();
+  for (int k = 0; k < Xfer::kSlots; k++) { if (x->h_in[k]) (void)hipHostFree(x->h_in[k]); if (x->d_in[k]) (void)hipFree(x->d_in[k]); if (x->ev_in[k]) (void)hipEventDestroy(x->ev_in[k]); }
+  if (x->h_out) (void)hipHostFree(x->h_out);
+  if (x->d_out) (void)hipFree(x->d_out);
+  if (x->ev_out) (void)hipEventDestroy(x->ev_out);
+  delete x;
+}
+// out[c * ldo + r] = in[r * ldi + c] for r < nr, c < nc  (32 x 32 tiles through LDS)
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int nr, int nc, int ldi, int ldo) {
+  __shared__ T tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) { const int r = r0 + k, c = c0 + tx; if (r < nr && c < nc) tile[k][tx] = in[(size_t)r * ldi + c]; }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) { const int c = c0 + k, r = r0 + tx; if (r < nr && c < nc) out[(size_t)c * ldo + r] = tile[tx][k]; }
+}
+template <typename T>
+static void launch_transpose(const void* in, void* out, int nr, int nc, int ldi, int ldo, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel<T>, dim3((nc + 31) / 32, (nr + 31) / 32), dim3(256), 0, s, (const T*)in, (T*)out, nr, nc, ldi, ldo);
+}
+static bool get_in_flight(const dmc_batch* b) { return b->xfer && b->xfer->out_in_flight; }
+static size_t field_elem(const dmc_batch* b, const Field* f) { return (b->precision == 64 || f->is_f64) ? sizeof(double) : sizeof(float); }
+extern "C" int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream) {
+  if (!b || !name || !src) return fail("null argument");
+  if (host_bits != 64 && host_bits != 32) return fail("host_bits must be 64 or 32");
+  Field* f = find_field(b, name);
+  if (!f || f->is_int) return fail(std::string("unknown real field: ") + name);
+  const size_t n = (size_t)f->rows * b->B;
+  if (!n) return 0;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->xfer) b->xfer = new Xfer();
+  Xfer* x = b->xfer;
+  const int k = x->next; x->next = (k + 1) % Xfer::kSlots;
+  const size_t es = field_elem(b, f), bytes = n * es;
+  if (x->cap_in[k] < bytes) {
+    if (x->ev_in[k]) HIP_TRY(hipEventSynchronize(x->ev_in[k]));
+    if (x->h_in[k]) (void)hipHostFree(x->h_in[k]);
+    if (x->d_in[k]) (void)hipFree(x->d_in[k]);
+    x->h_in[k] = nullptr; x->d_in[k] = nullptr; x->cap_in[k] = 0;
+    HIP_TRY(hipHostMalloc(&x->h_in[k], bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&x->d_in[k], bytes));
+    x->cap_in[k] = bytes;
+    if (!x->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&x->ev_in[k], hipEventDisableTiming));
+  } else HIP_TRY(hipEventSynchronize(x->ev_in[k]));      // the copy that last used this slot (four sets ago) has left the staging
+  // host: contiguous conversion into the pinned slot (no transposition); the caller's array is free again on return
+  if (es == 8) { double* d = (double*)x->h_in[k]; if (host_bits == 64) std::memcpy(d, src, bytes); else { const float* p = (const float*)src; for (size_t i = 0; i < n; i++) d[i] = p[i]; } }
+  else { float* d = (float*)x->h_in[k]; if (host_bits == 32) std::memcpy(d, src, bytes); else { const double* p = (const double*)src; for (size_t i = 0; i < n; i++) d[i] = (float)p[i]; } }
+  HIP_TRY(hipMemcpyAsync(x->d_in[k], x->h_in[k], bytes, hipMemcpyHostToDevice, st));
+  if (es == 8) launch_transpose<double>(x->d_in[k], f->dev, b->B, f->rows, f->rows, b->B, st); else launch_transpose<float>(x->d_in[k], f->dev, b->B, f->rows, f->rows, b->B, st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(x->ev_in[k], st));
+  if (f->name == "xfrc_applied") b->xfrc_on = 1;
+  if (f->name != "ctrl" && f->name != "qfrc_applied" && f->name != "xfrc_applied") return bump_epoch(b, st, false);      // stream-ordered with the edit
+  return 0;
+}
+extern "C" int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names, void* hip_stream) {
+  if (!b || n < 1 || !names) return fail("null argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->xfer) b->xfer = new Xfer();
+  Xfer* x = b->xfer;
+  if (x->out_in_flight) return fail("a get is already enqueued: call dmc_batch_get_wait first");
+  x->pending.clear();
+  size_t bytes = 0;
+  for (int i = 0; i < n; i++) {
+    Field* f = find_field(b, names[i]);
+    if (!f || f->is_int) return fail(std::string("unknown real field: ") + (names[i] ? names[i] : "(null)"));
+    bytes = (bytes + 7) / 8 * 8;
+    x->pending.push_back({f, bytes});
+    bytes += (size_t)f->rows * b->B * field_elem(b, f);
+  }
+  if (x->cap_out < bytes) {
+    if (x->h_out) (void)hipHostFree(x->h_out);
+    if (x->d_out) (void)hipFree(x->d_out);
+    x->h_out = nullptr; x->d_out = nullptr; x->cap_out = 0;
+    HIP_TRY(hipHostMalloc(&x->h_out, bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&x->d_out, bytes));
+    x->cap_out = bytes;
+  }
+  if (!x->ev_out) HIP_TRY(hipEventCreateWithFlags(&x->ev_out, hipEventDisableTiming));
+  for (auto& pf : x->pending) {
+    Field* f = pf.first;
+    if (!f->rows) continue;
+    void* dst = (char*)x->d_out + pf.second;
+    if (field_elem(b, f) == 8) launch_transpose<double>(f->dev, dst, f->rows, b->B, b->B, f->rows, st); else launch_transpose<float>(f->dev, dst, f->rows, b->B, b->B, f->rows, st);
+  }
+  HIP_TRY(hipGetLastError());
+  if (bytes) HIP_TRY(hipMemcpyAsync(x->h_out, x->d_out, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(x->ev_out, st));
+  x->out_in_flight = true;
+  return 0;
+}
+extern "C" int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int host_bits) {
+  if (!b || !dsts) return fail("null argument");
+  if (host_bits != 64 && host_bits != 32) return fail("host_bits must be 64 or 32");
+  Xfer* x = b->xfer;
+  if (!x || !x->out_in_flight) return fail("no get is enqueued");
+  if ((size_t)n != x->pending.size()) return fail("dmc_batch_get_wait: the number of destinations differs from the enqueued get");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipEventSynchronize(x->ev_out));
+  x->out_in_flight = false;
+  for (int i = 0; i < n; i++) {
+    Field* f = x->pending[i].first;
+    const size_t cnt = (size_t)f->rows * b->B, es = field_elem(b, f);
+    if (!cnt || !dsts[i]) continue;
+    const void* srcp = (const char*)x->h_out + x->pending[i].second;
+    if (es == 8) { const double* p = (const double*)srcp; if (host_bits == 64) std::memcpy(dsts[i], p, cnt * 8); else { float* d = (float*)dsts[i]; for (size_t k = 0; k < cnt; k++) d[k] = (float)p[k]; } }
+    else { const float* p = (const float*)srcp; if (host_bits == 32) std::memcpy(dsts[i], p, cnt * 4); else { double* d = (double*)dsts[i]; for (size_t k = 0; k < cnt; k++) d[k] = p[k]; } }
   }
   return 0;
 }

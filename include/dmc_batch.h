@@ -116,6 +116,19 @@ int dmc_batch_set(dmc_batch* b, const char* name, const double* src);
 int dmc_batch_get_int(dmc_batch* b, const char* name, int32_t* dst);
 int dmc_batch_set_int(dmc_batch* b, const char* name, const int32_t* src);
 
+/* The same reads / writes of the MjData views (wrapper/core.py:438-447; engine.py:139-145 set_control writes data.ctrl),
+ * asynchronous on `hip_stream` and sized for a host loop that keeps actions and observations in host memory
+ * (rl/control.py:99-127 with a numpy policy): the host converts contiguously into pinned staging (host_bits = 32 on an
+ * fp32 batch: no conversion at all, fp32 on the wire), copies are hipMemcpyAsync, the (B, rows) <-> (rows, B)
+ * transposition is a device kernel, and a get of several fields is one device-to-host copy and one wait.
+ *   dmc_batch_set_async: `src` (B, rows) of host_bits-wide floats is consumed before the call returns; the write is
+ *     ordered on the stream with the launches (and bumps the stash epoch there, like dmc_batch_invalidate_async).
+ *   dmc_batch_get_async: enqueues the read of `n` real fields (as of this point of the stream); one get at a time.
+ *   dmc_batch_get_wait: waits for it and writes field i, (B, rows_i) of host_bits-wide floats, to dsts[i] (NULL: skip). */
+int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream);
+int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names, void* hip_stream);
+int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int host_bits);
+
 /* Zero-copy access: the SoA device array of a field, (rows, B) in batch
  * precision; and rebinding a field to caller-owned device memory of that shape
  * (e.g. a torch tensor) so producers/consumers on the GPU never round-trip. */

@@ -33,9 +33,35 @@ for t in range(T):
   b.step(nsub)
   q, v, s = b.get('qpos'), b.get('qvel'), b.get('sensordata')
 dt = time.perf_counter() - t0
+# the asynchronous boundary (dmc_batch_set_async / get_async / get_wait): controls staged through pinned memory, the three
+# fields fetched with ONE device-to-host copy and one wait per env-step; fp64 host arrays, then fp32 on the wire
+rates = {}
+for tag, hdt in (('f64_host', np.float64), ('f32_host', np.float32)):
+  c = ctrl.astype(hdt)
+  for t in range(10):
+    b.set_async('ctrl', c[t]); b.step(nsub); b.get_many(('qpos', 'qvel', 'sensordata'), dtype=hdt)
+  t1 = time.perf_counter()
+  for t in range(T):
+    b.set_async('ctrl', c[t])
+    b.step(nsub)
+    o = b.get_many(('qpos', 'qvel', 'sensordata'), dtype=hdt)
+  rates[tag] = B * T / (time.perf_counter() - t1)
+# and with the observation download of step t overlapped with the launch of step t + 1 (the policy sees a one-step-old
+# observation only if it wants to; here the next action does not depend on it: random actions)
+c = ctrl.astype(np.float32)
+b.set_async('ctrl', c[0]); b.step(nsub); b.get_async(('qpos', 'qvel', 'sensordata'))
+t1 = time.perf_counter()
+for t in range(1, T):
+  b.set_async('ctrl', c[t])
+  b.step(nsub)
+  o = b.get_wait(np.float32)
+  b.get_async(('qpos', 'qvel', 'sensordata'))
+b.get_wait(np.float32)
+rates['f32_host_pipelined'] = B * (T - 1) / (time.perf_counter() - t1)
 ms_dev = b.time_steps(nsub, 100)
 out = dict(config=cfg, B=B, env_steps=T, host_buffer_env_steps_per_s=B * T / dt, ms_per_env_step_host_buffers=1e3 * dt / T,
            ms_per_launch_device_resident=ms_dev, device_resident_env_steps_per_s=B / (ms_dev * 1e-3),
+           async_boundary_env_steps_per_s=rates,
            bytes_per_env_step=dict(host_to_device=8 * B * m.nu, device_to_host=8 * B * (m.nq + m.nv + m.nsensordata)),
            note='fp64 host arrays (the facade\'s numpy dtype) converted to / from the fp32 SoA device fields by the library; '
                 'one synchronous set + 3 synchronous gets per env-step')

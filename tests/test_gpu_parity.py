@@ -1015,3 +1015,34 @@ def test_pgs_solver_on_device(cone, condim, precision, tol):
   assert worst < tol, worst
   assert iters >= 10 and nefc >= 12 and not b.get('warning').any()
   b.close()
+
+
+@pytest.mark.parametrize('precision', [32, 64])
+def test_async_host_transfers_equal_the_synchronous_ones(cheetah, precision):
+  """dmc_batch_set_async / get_async / get_wait (pinned staging, device-side transposition, one copy for several fields,
+  fp32 on the wire) against dmc_batch_set / dmc_batch_get: same device contents, same host values; more sets in a row
+  than staging slots; trajectories driven through either boundary are identical."""
+  m = cheetah
+  B = 37                                   # not a multiple of the transposition tile
+  a, b = _batch(m, B, precision=precision), _batch(m, B, precision=precision)
+  rs = np.random.RandomState(0)
+  q = _cheetah_init(m, B)
+  a.set('qpos', q); b.set_async('qpos', q)
+  for hdt in (np.float64, np.float32):
+    for t in range(9):                     # > 4 staging slots
+      c = rs.uniform(-1, 1, (B, m.nu)).astype(hdt)
+      a.set('ctrl', c); b.set_async('ctrl', c)
+      a.step(); b.step()
+      got = b.get_many(('qpos', 'qvel', 'sensordata', 'time'), dtype=hdt)
+      for n in ('qpos', 'qvel', 'sensordata', 'time'):
+        want = a.get(n)
+        assert got[n].dtype == hdt and got[n].shape == want.shape
+        np.testing.assert_array_equal(got[n], want.astype(hdt), err_msg=n)
+  # an enqueued get is a snapshot of its point in the stream: a later step does not change what it returns
+  before = a.get('qpos')
+  b.get_async(('qpos',))
+  b.step()
+  np.testing.assert_array_equal(b.get_wait()['qpos'], before)
+  with pytest.raises(Exception, match='no get is enqueued'):
+    b._pending_get = ['qpos']; b.get_wait()
+  a.close(); b.close()
