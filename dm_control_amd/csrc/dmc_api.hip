@@ -719,18 +719,33 @@ static void xfer_free(Xfer* x) {
   if (x->ev_out) (void)hipEventDestroy(x->ev_out);
   delete x;
 }
-// out[c * ldo + r] = in[r * ldi + c] for r < nr, c < nc  (32 x 32 tiles through LDS)
+// out[c * ldo + r] = in[r * ldi + c] for r < nr, c < nc  (32 x 32 tiles through LDS).  `in` / `out` may be PINNED HOST
+// memory (device-mapped): the set kernel reads the caller's staged (B, rows) array over PCIe and the get kernel writes
+// the (B, rows) arrays straight into the host staging -- no separate hipMemcpyAsync on either side.
 template <typename T>
-__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int nr, int nc, int ldi, int ldo) {
-  __shared__ T tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+__device__ inline void transpose_tile(const T* __restrict__ in, T* __restrict__ out, int nr, int nc, int ldi, int ldo, int bx, int by, T (*tile)[33]) {
+  const int c0 = bx * 32, r0 = by * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) { const int r = r0 + k, c = c0 + tx; if (r < nr && c < nc) tile[k][tx] = in[(size_t)r * ldi + c]; }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) { const int c = c0 + k, r = r0 + tx; if (r < nr && c < nc) out[(size_t)c * ldo + r] = tile[tx][k]; }
 }
 template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int nr, int nc, int ldi, int ldo) {
+  __shared__ T tile[32][33];
+  transpose_tile<T>(in, out, nr, nc, ldi, ldo, blockIdx.x, blockIdx.y, tile);
+}
+template <typename T>
 static void launch_transpose(const void* in, void* out, int nr, int nc, int ldi, int ldo, hipStream_t s) {
   hipLaunchKernelGGL(transpose_kernel<T>, dim3((nc + 31) / 32, (nr + 31) / 32), dim3(256), 0, s, (const T*)in, (T*)out, nr, nc, ldi, ldo);
+}
+// every field of a get in ONE launch: blockIdx.z = field
+struct GetTable { const void* src[8]; void* dst[8]; int rows[8]; int wide[8]; int n; };
+__global__ void __launch_bounds__(256) get_pack_kernel(GetTable t, int B) {
+  __shared__ double tile64[32][33];
+  const int f = blockIdx.z;
+  if ((int)blockIdx.y * 32 >= t.rows[f]) return;
+  if (t.wide[f]) transpose_tile<double>((const double*)t.src[f], (double*)t.dst[f], t.rows[f], B, B, t.rows[f], blockIdx.x, blockIdx.y, tile64);
+  else transpose_tile<float>((const float*)t.src[f], (float*)t.dst[f], t.rows[f], B, B, t.rows[f], blockIdx.x, blockIdx.y, (float (*)[33])tile64);
 }
 static bool get_in_flight(const dmc_batch* b) { return b->xfer && b->xfer->out_in_flight; }
 static size_t field_elem(const dmc_batch* b, const Field* f) { return (b->precision == 64 || f->is_f64) ? sizeof(double) : sizeof(float); }
@@ -752,16 +767,16 @@ extern "C" int dmc_batch_set_async(dmc_batch* b, const char* name, const void* s
     if (x->h_in[k]) (void)hipHostFree(x->h_in[k]);
     if (x->d_in[k]) (void)hipFree(x->d_in[k]);
     x->h_in[k] = nullptr; x->d_in[k] = nullptr; x->cap_in[k] = 0;
-    HIP_TRY(hipHostMalloc(&x->h_in[k], bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&x->d_in[k], bytes));
+    HIP_TRY(hipHostMalloc(&x->h_in[k], bytes, hipHostMallocMapped));
     x->cap_in[k] = bytes;
     if (!x->ev_in[k]) HIP_TRY(hipEventCreateWithFlags(&x->ev_in[k], hipEventDisableTiming));
   } else HIP_TRY(hipEventSynchronize(x->ev_in[k]));      // the copy that last used this slot (four sets ago) has left the staging
   // host: contiguous conversion into the pinned slot (no transposition); the caller's array is free again on return
   if (es == 8) { double* d = (double*)x->h_in[k]; if (host_bits == 64) std::memcpy(d, src, bytes); else { const float* p = (const float*)src; for (size_t i = 0; i < n; i++) d[i] = p[i]; } }
   else { float* d = (float*)x->h_in[k]; if (host_bits == 32) std::memcpy(d, src, bytes); else { const double* p = (const double*)src; for (size_t i = 0; i < n; i++) d[i] = (float)p[i]; } }
-  HIP_TRY(hipMemcpyAsync(x->d_in[k], x->h_in[k], bytes, hipMemcpyHostToDevice, st));
-  if (es == 8) launch_transpose<double>(x->d_in[k], f->dev, b->B, f->rows, f->rows, b->B, st); else launch_transpose<float>(x->d_in[k], f->dev, b->B, f->rows, f->rows, b->B, st);
+  void* hin = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&hin, x->h_in[k], 0));
+  if (es == 8) launch_transpose<double>(hin, f->dev, b->B, f->rows, f->rows, b->B, st); else launch_transpose<float>(hin, f->dev, b->B, f->rows, f->rows, b->B, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(x->ev_in[k], st));
   if (f->name == "xfrc_applied") b->xfrc_on = 1;
@@ -784,23 +799,26 @@ extern "C" int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names
     x->pending.push_back({f, bytes});
     bytes += (size_t)f->rows * b->B * field_elem(b, f);
   }
+  if (n > 8) return fail("at most 8 fields per get");
   if (x->cap_out < bytes) {
     if (x->h_out) (void)hipHostFree(x->h_out);
-    if (x->d_out) (void)hipFree(x->d_out);
-    x->h_out = nullptr; x->d_out = nullptr; x->cap_out = 0;
-    HIP_TRY(hipHostMalloc(&x->h_out, bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&x->d_out, bytes));
+    x->h_out = nullptr; x->cap_out = 0;
+    HIP_TRY(hipHostMalloc(&x->h_out, bytes, hipHostMallocMapped));
     x->cap_out = bytes;
   }
   if (!x->ev_out) HIP_TRY(hipEventCreateWithFlags(&x->ev_out, hipEventDisableTiming));
-  for (auto& pf : x->pending) {
-    Field* f = pf.first;
-    if (!f->rows) continue;
-    void* dst = (char*)x->d_out + pf.second;
-    if (field_elem(b, f) == 8) launch_transpose<double>(f->dev, dst, f->rows, b->B, b->B, f->rows, st); else launch_transpose<float>(f->dev, dst, f->rows, b->B, b->B, f->rows, st);
+  void* hout = nullptr;
+  if (bytes) HIP_TRY(hipHostGetDevicePointer(&hout, x->h_out, 0));
+  GetTable t; t.n = n;
+  int maxrows = 0;
+  for (int i = 0; i < 8; i++) { t.src[i] = nullptr; t.dst[i] = nullptr; t.rows[i] = 0; t.wide[i] = 0; }
+  for (int i = 0; i < n; i++) {
+    Field* f = x->pending[i].first;
+    t.src[i] = f->dev; t.dst[i] = (char*)hout + x->pending[i].second; t.rows[i] = f->rows; t.wide[i] = field_elem(b, f) == 8;
+    maxrows = std::max(maxrows, f->rows);
   }
+  if (maxrows) hipLaunchKernelGGL(get_pack_kernel, dim3((b->B + 31) / 32, (maxrows + 31) / 32, n), dim3(256), 0, st, t, b->B);
   HIP_TRY(hipGetLastError());
-  if (bytes) HIP_TRY(hipMemcpyAsync(x->h_out, x->d_out, bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(x->ev_out, st));
   x->out_in_flight = true;
   return 0;
