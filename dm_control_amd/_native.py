@@ -15,7 +15,7 @@ EXPORTS = [
     'dmc_batch_set_output_mask', 'dmc_batch_set_opt_int', 'dmc_batch_set_opt_real',
     'dmc_batch_set_model_real',
     'dmc_batch_step1', 'dmc_batch_step2', 'dmc_batch_sync', 'dmc_batch_invalidate', 'dmc_batch_invalidate_async', 'dmc_batch_info', 'dmc_batch_time_steps',
-    'dmc_batch_enable_profiling', 'dmc_batch_get_timer', 'dmc_batch_set_step_probe', 'dmc_batch_set_async', 'dmc_batch_get_async', 'dmc_batch_get_wait',
+    'dmc_batch_enable_profiling', 'dmc_batch_get_timer', 'dmc_batch_set_step_probe', 'dmc_batch_set_async', 'dmc_batch_get_async', 'dmc_batch_get_wait', 'dmc_batch_get_staged',
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
     'dmc_batch_set_env_geoms', 'dmc_env_geom_pack', 'dmc_batch_wave_trace', 'dmc_batch_randomize_joints',
@@ -85,6 +85,8 @@ def lib():
   L.dmc_batch_set_async.argtypes = [vp, cs, vp, ci, vp]
   L.dmc_batch_get_async.argtypes = [vp, ci, ctypes.POINTER(cs), vp]
   L.dmc_batch_get_wait.argtypes = [vp, ci, ctypes.POINTER(vp), ci]
+  L.dmc_batch_get_staged.argtypes = [vp, ci]
+  L.dmc_batch_get_staged.restype = vp
   L.dmc_batch_get_timer.argtypes = [vp, ci, ctypes.POINTER(cd), ctypes.POINTER(ctypes.c_longlong)]
   L.dmc_batch_debug_enable.argtypes = [vp, ci]
   L.dmc_batch_debug_get.argtypes = [vp, cs, ci, vp, ctypes.POINTER(ci)]

@@ -125,9 +125,28 @@ class BatchedPhysics:
     _native.check(_native.lib().dmc_batch_get_async(self._ptr, len(names), arr, stream))
     self._pending_get = names
 
-  def get_wait(self, dtype=np.float64):
-    """{name: (B, rows) array of `dtype` (float64 or float32)} of the get enqueued by `get_async`."""
+  def get_wait(self, dtype=np.float64, copy=True):
+    """{name: (B, rows) array of `dtype` (float64 or float32)} of the get enqueued by `get_async`.  copy=False: read-only
+    views of the pinned staging in the batch's own precision (no host copy at all), valid until the next `get_async`."""
     names = self._pending_get
+    if not copy:
+      L = _native.lib()
+      _native.check(L.dmc_batch_get_wait(self._ptr, len(names), (ctypes.c_void_p * len(names))(), 64))
+      self._pending_get = None
+      out = {}
+      for i, n in enumerate(names):
+        rows = self._rows(n)[0]
+        dt = np.float64 if (self.precision == 64 or n == 'time') else np.float32
+        if not rows:
+          out[n] = np.zeros((self.batch_size, 0), dtype=dt)
+          continue
+        p = L.dmc_batch_get_staged(self._ptr, i)
+        if not p:
+          raise _native.NativeError(L.dmc_last_error().decode())
+        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double if dt == np.float64 else ctypes.c_float)), shape=(self.batch_size, rows))
+        a.flags.writeable = False
+        out[n] = a
+      return out
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
       raise ValueError('dtype must be float64 or float32')
@@ -137,10 +156,10 @@ class BatchedPhysics:
     self._pending_get = None
     return dict(zip(names, outs))
 
-  def get_many(self, names, stream=None, dtype=np.float64):
+  def get_many(self, names, stream=None, dtype=np.float64, copy=True):
     """Several real fields with one device-to-host copy and one wait."""
     self.get_async(names, stream)
-    return self.get_wait(dtype)
+    return self.get_wait(dtype, copy=copy)
 
   def device_ptr(self, name):
     p = _native.lib().dmc_batch_device_ptr(self._ptr, name.encode())

@@ -842,6 +842,10 @@ extern "C" int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int ho
   }
   return 0;
 }
+extern "C" const void* dmc_batch_get_staged(dmc_batch* b, int i) {
+  if (!b || !b->xfer || b->xfer->out_in_flight || i < 0 || (size_t)i >= b->xfer->pending.size()) { fail("no completed get holds that field"); return nullptr; }
+  return (const char*)b->xfer->h_out + b->xfer->pending[i].second;
+}
 extern "C" int dmc_batch_field_rows(const dmc_batch* b, const char* name, int* rows, int* is_int) {
   if (!b || !name) return fail("null argument");
   Field* f = find_field(const_cast<dmc_batch*>(b), name);

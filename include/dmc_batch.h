@@ -128,6 +128,10 @@ int dmc_batch_set_int(dmc_batch* b, const char* name, const int32_t* src);
 int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream);
 int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names, void* hip_stream);
 int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int host_bits);
+/* Field i of the last completed get where it lies in the pinned staging, (B, rows_i) in the batch's own precision
+ * ("time": float64) -- valid until the next dmc_batch_get_async: the zero-copy form of dmc_batch_get_wait (pass NULL
+ * destinations to it, then read here). */
+const void* dmc_batch_get_staged(dmc_batch* b, int i);
 
 /* Zero-copy access: the SoA device array of a field, (rows, B) in batch
  * precision; and rebinding a field to caller-owned device memory of that shape

@@ -46,6 +46,13 @@ for tag, hdt in (('f64_host', np.float64), ('f32_host', np.float32)):
     b.step(nsub)
     o = b.get_many(('qpos', 'qvel', 'sensordata'), dtype=hdt)
   rates[tag] = B * T / (time.perf_counter() - t1)
+t1 = time.perf_counter()
+c = ctrl.astype(np.float32)
+for t in range(T):
+  b.set_async('ctrl', c[t])
+  b.step(nsub)
+  o = b.get_many(('qpos', 'qvel', 'sensordata'), copy=False)      # views of the pinned staging: no host copy
+rates['f32_host_zero_copy'] = B * T / (time.perf_counter() - t1)
 # and with the observation download of step t overlapped with the launch of step t + 1 (the policy sees a one-step-old
 # observation only if it wants to; here the next action does not depend on it: random actions)
 c = ctrl.astype(np.float32)

@@ -1045,6 +1045,10 @@ def test_async_host_transfers_equal_the_synchronous_ones(cheetah, precision):
         want = a.get(n)
         assert got[n].dtype == hdt and got[n].shape == want.shape
         np.testing.assert_array_equal(got[n], want.astype(hdt), err_msg=n)
+  z = b.get_many(('qpos', 'time'), copy=False)      # views of the pinned staging, in the batch's own precision
+  assert z['qpos'].dtype == (np.float64 if precision == 64 else np.float32) and z['time'].dtype == np.float64 and not z['qpos'].flags.writeable
+  np.testing.assert_array_equal(z['qpos'], a.get('qpos').astype(z['qpos'].dtype))
+  np.testing.assert_array_equal(z['time'], a.get('time'))
   # an enqueued get is a snapshot of its point in the stream: a later step does not change what it returns
   before = a.get('qpos')
   b.get_async(('qpos',))
