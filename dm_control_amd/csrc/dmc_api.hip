@@ -941,6 +941,7 @@ extern "C" int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value) 
       return fail("cannot enable contacts: the model has geom pair types the collision kernel does not implement");
     o.disableflags = value;
   }
+  else if (!strcmp(name, "islands")) o.islands = value < 0 ? -1 : (value ? 1 : 0);      // per-island solves: 1 / 0 / -1 = by precision
   else if (!strcmp(name, "iterations")) o.iterations = value;
   else if (!strcmp(name, "ls_iterations")) o.ls_iterations = value;
   else if (!strcmp(name, "noslip_iterations")) {

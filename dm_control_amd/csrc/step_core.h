@@ -4519,6 +4519,22 @@ struct StepCore {
       else evaluated = true;
     } else FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
     DMC_WSYNC();
+    int iter;
+    if (L.d.island && (o.islands < 0 ? sizeof(T) == 8 : o.islands != 0) && !(o.disableflags & DMC_DSBL_ISLAND) && solve_islands(nefc, &iter)) {}
+    else iter = primal_solve(nefc, evaluated, cc, gauss, changed);
+    constraint_force_to_joint(nefc);
+    FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
+    if (lane == 0) SI(imisc)[IM_ITER] = iter;
+    DMC_WSYNC();
+    // the warm start keeps the main solver's solution; noslip then edits qacc / efc_force
+    DMC_PROF(PROF_SOL_UPD);
+    if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
+    DMC_PROF(PROF_NOSLIP);
+  }
+  // mj_solPrimal (Newton / CG) from S(qacc) over every dof and row of the environment; `evaluated`: M a, J a - aref, the
+  // forces, the active set and the cost (cc, gauss, changed) of the starting point are already in place
+  DMC_DEV int primal_solve(int nefc, bool evaluated, T cc, T gauss, int changed) {
+    const int nv = L.d.nv;
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
     if (!evaluated) {
       mul_M(S(sv_Ma), S(qacc));
@@ -4622,14 +4638,98 @@ struct StepCore {
 #if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
     __builtin_amdgcn_s_setprio(0);
 #endif
-    constraint_force_to_joint(nefc);
-    FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
-    if (lane == 0) SI(imisc)[IM_ITER] = iter;
+    return iter;
+  }
+  // ---- constraint islands (mj_island + the per-island solves of mj_fwdConstraint; the oracle's find_islands /
+  // solve_islands) -------------------------------------------------------------------------------------------------
+  // Trees are named by their ROOT DOF (the lowest dof of the ancestor mask; nv <= 64, so a set of trees is a 64-bit
+  // mask); every constraint row joins the trees whose dofs it moves; the islands are the connected components that own
+  // a row.  Island k is then solved with the SAME joint solver: the dofs outside it are parked at qacc_smooth (their
+  // block of M is independent, so their gradient is rounding noise) and the rows outside it are switched off by scaling
+  // their D by a power of two far below the working precision (exactly undone afterwards) -- the island's iterates are
+  // those of its own sub-problem to that precision, with its own line search, iteration count and stopping test.
+  // One island that holds every dof and row is the joint problem: solved in place (bit-identical to the flag disabled).
+  typedef unsigned long long u64;
+#ifdef DMC_HOST_EMU
+#define DMC_ATOMIC_OR(p, v) (*(p) |= (v))
+#else
+#define DMC_ATOMIC_OR(p, v) atomicOr((p), (v))
+#endif
+  DMC_DEV static int ctz64(u64 x) { return (unsigned)x ? __builtin_ctz((unsigned)x) : 32 + __builtin_ctz((unsigned)(x >> 32)); }
+  DMC_DEV int dof_root(int i) const { return ctz64((u64)(unsigned)MI(dof_anc_lo)[i] | (u64)(unsigned)MI(dof_anc_hi)[i] << 32); }
+  DMC_DEV u64 isl_comp(int t) const { return (u64)(unsigned)SI(isl_comp)[2*t] | (u64)(unsigned)SI(isl_comp)[2*t + 1] << 32; }
+  DMC_DEV u64 row_trees(int r) const { return (u64)(unsigned)SI(efc_tree)[2*r] | (u64)(unsigned)SI(efc_tree)[2*r + 1] << 32; }
+  DMC_DEV bool solve_islands(int nefc, int* iter_out) {
+    const int nv = L.d.nv;
+    const RowMap rm = row_map();
+    FOR_LANES(i, nv) { const bool root = dof_root(i) == i; SI(isl_comp)[2*i] = (root && i < 32) ? (int)(1u << i) : 0; SI(isl_comp)[2*i + 1] = (root && i >= 32) ? (int)(1u << (i - 32)) : 0; }
     DMC_WSYNC();
-    // the warm start keeps the main solver's solution; noslip then edits qacc / efc_force
-    DMC_PROF(PROF_SOL_UPD);
-    if (L.d.nslip) { if (o.noslip_iterations > 0) noslip(nefc); }
-    DMC_PROF(PROF_NOSLIP);
+    for (int r = lane; r < nefc; r += LPE) {
+      u64 tm = 0;
+      for (int i = 0; i < nv; i++) if (row_entry(r, i, rm) != 0) tm |= (u64)1 << dof_root(i);
+      SI(efc_tree)[2*r] = (int)(unsigned)tm; SI(efc_tree)[2*r + 1] = (int)(unsigned)(tm >> 32);
+      for (u64 m = tm; m; m &= m - 1) { const int t = ctz64(m); DMC_ATOMIC_OR(&SI(isl_comp)[2*t], (int)(unsigned)tm); DMC_ATOMIC_OR(&SI(isl_comp)[2*t + 1], (int)(unsigned)(tm >> 32)); }
+    }
+    DMC_WSYNC();
+    // the rows of one contact travel together (a tangential row may move nothing on its own): every contact row takes
+    // the union over its contact's rows (in place: the masks only grow towards that union)
+    for (int r = lane; r < nefc; r += LPE) {
+      const int tid = SI(efc_tid)[r], ty = EFC_TYPE(tid);
+      if (ty != EFC_FRICTIONLESS && ty != EFC_PYRAMIDAL && ty != EFC_ELLIPTIC) continue;
+      const int c = EFC_ID(tid), r0 = SI(con_efc)[c], nr = contact_rows(con_dim(c));
+      u64 tm = 0;
+      for (int q = r0; q < r0 + nr && q < nefc; q++) tm |= row_trees(q);
+      SI(efc_tree)[2*r] = (int)(unsigned)tm; SI(efc_tree)[2*r + 1] = (int)(unsigned)(tm >> 32);
+    }
+    DMC_WSYNC();
+    // transitive closure: every pass at least doubles the path length covered (6 passes: 64 trees).  In place: the masks only
+    // grow towards the closure, so a lane reading another tree's half-updated mask still reads a subset of the answer
+    for (int pass = 0; pass < 6; pass++) {
+      FOR_LANES(t, nv) {
+        const u64 c = isl_comp(t);
+        u64 x = c;
+        for (u64 m = c; m; m &= m - 1) x |= isl_comp(ctz64(m));
+        SI(isl_comp)[2*t] = (int)(unsigned)x; SI(isl_comp)[2*t + 1] = (int)(unsigned)(x >> 32);
+      }
+      DMC_WSYNC();
+    }
+    // the islands: components that own a row, named by their lowest tree
+    u64 rowtrees = 0, roots = 0;
+    for (int r = 0; r < nefc; r++) rowtrees |= row_trees(r);
+    for (int t = 0; t < nv; t++) if (isl_comp(t)) roots |= (u64)1 << t;
+    int nisl = 0; u64 covered = 0;
+    for (int t = 0; t < nv; t++) { const u64 C = isl_comp(t); if (C && ctz64(C) == t && (C & rowtrees)) { nisl++; covered |= C; } }
+    bool whole = nisl == 1 && covered == roots;
+    if (whole) for (int r = 0; r < nefc; r++) if (!row_trees(r)) whole = false;
+#ifdef DMC_HOST_EMU
+    if (getenv("DMC_EMU_TRACE")) { fprintf(stderr, "  islands: nefc %d nisl %d whole %d covered %llx roots %llx rowtrees %llx rows:", nefc, nisl, (int)whole, covered, roots, rowtrees); for (int r = 0; r < nefc; r++) fprintf(stderr, " %llx", row_trees(r)); fprintf(stderr, "\n"); }
+#endif
+    if (nisl == 0 || whole) return false;
+    const T eps = sizeof(T) == 8 ? (T)8.271806125530277e-25 : (T)9.094947017729282e-13;      // 2^-80 / 2^-40
+    FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];      // the start values (the warm-start choice has been made; the array is rewritten at the end)
+    DMC_WSYNC();
+    int itmax = 0;
+    for (int t = 0; t < nv; t++) {
+      const u64 C = isl_comp(t);
+      if (!C || ctz64(C) != t || !(C & rowtrees)) continue;
+      FOR_LANES(i, nv) S(qacc)[i] = ((C >> dof_root(i)) & 1) ? S(qacc_warmstart)[i] : S(qacc_smooth)[i];
+      for (int r = lane; r < nefc; r += LPE) if (!(row_trees(r) & C)) S(efc_D)[r] *= eps;
+      DMC_WSYNC();
+      const int it = primal_solve(nefc, false, 0, 0, 1);
+      FOR_LANES(i, nv) if ((C >> dof_root(i)) & 1) S(qacc_warmstart)[i] = S(qacc)[i];
+      for (int r = lane; r < nefc; r += LPE) if (!(row_trees(r) & C)) S(efc_D)[r] *= 1 / eps;
+      DMC_WSYNC();
+      if (it > itmax) itmax = it;
+    }
+    // trees without a constraint take qacc_smooth; forces and states of every row at the assembled solution
+    FOR_LANES(i, nv) S(qacc)[i] = ((covered >> dof_root(i)) & 1) ? S(qacc_warmstart)[i] : S(qacc_smooth)[i];
+    DMC_WSYNC();
+    jar_from(S(qacc), nefc);
+    DMC_WSYNC();
+    constraint_update(nefc);
+    DMC_WSYNC();
+    *iter_out = itmax;
+    return true;
   }
 
   // ---- integration (mj_Euler with implicit joint damping) ---------------------------------

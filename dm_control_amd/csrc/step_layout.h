@@ -55,6 +55,8 @@ struct StepDims {
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
   int dfs;       // 1: bodies are numbered depth first (a subtree is the contiguous range [b, body_subend[b])): subtree sums in one pass
   int ntree;     // kinematic trees with at least one dof (M^-1 is block diagonal over them: noslip blocks of different trees are independent)
+  int island;    // 1: the model can have more than one constraint island (two or more kinematic trees, no noslip pass, a
+                 //   primal solver): scratch for the island partition (StepCore::find_islands)
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
@@ -213,6 +215,8 @@ struct StepDims {
   X(con_dofs, d.jfull ? 0 : d.nconmax * d.kwords)  /* the mask's dofs in ascending order, one byte each */ \
   X(efc_tid, d.njmax)   /* (id << 3) | type */                                 \
   X(efc_active, d.njmax) /* active set the current factor of H was built for */ \
+  X(isl_comp, d.island ? 2 * d.nv : 0)    /* islands: 64-bit mask (over root dofs = trees) of the component each tree is in */ \
+  X(efc_tree, d.island ? 2 * d.njmax : 0) /* islands: 64-bit mask of the trees each constraint row moves */ \
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
   X(ns_blk, d.nslip ? 48 : 0)  /* noslip: per block (<= 16 blocks) start | size << 8 | level << 16 | coupled << 24, tree mask lo, hi */ \
   X(prof, DMC_PROF_SLOTS)   /* profiling builds: cycle counters per phase + the last time stamp */ \
@@ -267,6 +271,8 @@ struct StepOpts {
   T timestep, gravity[3], impratio, tolerance, ls_tolerance, meaninertia, density, viscosity, noslip_tolerance;
   int integrator, cone, iterations, ls_iterations, disableflags, noslip_iterations;
   int any_damping;   // some dof_damping > 0 (Euler implicit-damping path)
+  int islands;       // per-island solves (mj_island semantics): 1 on, 0 off (one joint solve: the same minimiser), -1 = by
+                     // precision (fp64 on: tracks the CPU reference; fp32 off: throughput)
   double timestep_d; // fp64 copy for the time accumulator
   // per-environment model deltas: world-fixed geoms whose pose / size differ between environments (soccer pitch
   // randomisation, per-env targets).  eg_data: (16 eg_n, eg_B) SoA in batch precision, rows of geom slot k:

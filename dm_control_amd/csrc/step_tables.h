@@ -250,6 +250,10 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   // Jacobian storage classes (step_layout.h): dense rows for equalities / tendon limits, none for the
   // one-nonzero friction / joint-limit rows, kmax entries per contact row
   d.cg = m.opt_solver == DMC_SOL_CG ? 1 : 0;
+  { // kinematic trees proper: dofs with the same root dof (what hangs off a static body by a joint is a tree of its own)
+    int nroot = 0;
+    for (int i = 0; i < m.nv; i++) if (m.dof_parentid[i] < 0) nroot++;
+    d.island = (nroot > 1 && m.opt_noslip_iterations == 0 && m.opt_solver != DMC_SOL_PGS) ? 1 : 0; }
   d.pgs = m.opt_solver == DMC_SOL_PGS ? 1 : 0;
   if (d.pgs) d.nslip = njmax;      // the dual solver keeps a residual entry and a row of AR for EVERY constraint row
   d.jfull = m.nv <= 16 ? 1 : 0;
@@ -448,7 +452,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   o.integrator = m.opt_integrator; o.cone = m.opt_cone; o.iterations = m.opt_iterations;
   o.ls_iterations = m.opt_ls_iterations; o.disableflags = m.opt_disableflags;
   o.noslip_iterations = m.opt_noslip_iterations; o.noslip_tolerance = m.opt_noslip_tolerance;
-  o.any_damping = 0;
+  o.any_damping = 0; o.islands = -1;
   o.eg_data = nullptr; o.eg_slot = nullptr; o.eg_n = 0; o.eg_B = 0; o.ns_A = nullptr; o.xfrc = nullptr; o.xfrc_B = 0; o.gscr = nullptr; o.g_mr = nullptr;
   o.mocap_pos = nullptr; o.mocap_quat = nullptr; o.mocap_B = 0;
   for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) o.any_damping = 1;
@@ -464,7 +468,7 @@ inline StepOpts<T> step_opts_cast(const StepOpts<double>& s) {
   o.integrator = s.integrator; o.cone = s.cone;
   o.iterations = s.iterations; o.ls_iterations = s.ls_iterations; o.disableflags = s.disableflags;
   o.noslip_iterations = s.noslip_iterations; o.noslip_tolerance = (T)s.noslip_tolerance;
-  o.any_damping = s.any_damping; o.timestep_d = s.timestep_d;
+  o.any_damping = s.any_damping; o.timestep_d = s.timestep_d; o.islands = s.islands;
   o.eg_data = s.eg_data; o.eg_slot = s.eg_slot; o.eg_n = s.eg_n; o.eg_B = s.eg_B; o.ns_A = s.ns_A; o.xfrc = s.xfrc; o.xfrc_B = s.xfrc_B; o.mocap_pos = s.mocap_pos; o.mocap_quat = s.mocap_quat; o.mocap_B = s.mocap_B; o.gscr = s.gscr; o.g_mr = s.g_mr;
   return o;
 }

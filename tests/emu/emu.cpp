@@ -47,6 +47,7 @@ int emu_dims(void* h, int* out) {
 }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
+void emu_set_islands(void* h, int v) { ((Emu*)h)->tb.opts.islands = v; }      // StepOpts::islands: 1 on, 0 off, -1 by precision
 void emu_kstash(void* h, int on) { Emu* e = (Emu*)h; const StepLayout& L = e->tb.L; e->kstash_on = on; e->kstash.assign(L.d.nq + L.d.nv + (L.s_qM - L.s_xpos) + 4, 0.0); e->kstash_i.assign(2, 0); }
 void emu_set_xfrc(void* h, const double* x) { Emu* e = (Emu*)h; e->xfrc64.assign(x, x + 6*e->hm.nbody); e->xfrc32.assign(x, x + 6*e->hm.nbody); }
 void emu_set_mocap(void* h, const double* p, const double* q) {

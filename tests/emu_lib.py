@@ -33,6 +33,7 @@ def lib():
     L.emu_free.argtypes = [ctypes.c_void_p]
     L.emu_stash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_invalidate.argtypes = [ctypes.c_void_p]
+    L.emu_set_islands.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_kstash.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.emu_set_xfrc.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.emu_set_mocap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -72,6 +73,10 @@ class EmuPhysics:
     self.f['qpos'][:m.nq] = m.qpos0
     self.dbg = np.zeros(self.n_sr)
     self.dbgi = np.zeros(self.n_si, np.int32)
+
+  def set_islands(self, v):
+    """StepOpts::islands: 1 per-island solves, 0 one joint solve, -1 by precision (fp64 on, fp32 off)."""
+    lib().emu_set_islands(self.h, int(v))
 
   def __del__(self):
     if getattr(self, 'h', None):

@@ -617,18 +617,13 @@ def test_box_piles_match_oracle(precision, tol, lanes):
   b = _batch(m, B, precision=precision, lanes_per_env=lanes, nconmax=32)
   b.set('qpos', q)
   b.step(300)
-  # Five free bodies are up to five constraint islands.  The device solves them as ONE system (PARITY_ASSUMPTIONS row 8):
-  # against the oracle with `island="disable"` (the same algorithm) the tolerance is the logic tolerance; against the
-  # oracle's per-island solves (MuJoCo's default) the two iteration paths end within the solver tolerance of each other
-  # every step, which over 300 steps of a pile settling is 6e-9 (measured, oracle vs oracle)
-  import copy
-  md = copy.copy(m); md.opt = copy.copy(m.opt); md.opt.disableflags = int(m.opt.disableflags) | mc.C['DMC_DSBL_ISLAND']
-  for model, t in ((md, tol), (m, max(tol, 1e-7))):
-    ora = _oracles(model, q)
-    for o in ora:
-      o.step(300)
-    np.testing.assert_array_equal(b.get('ncon')[:, 0] > 0, [o.ncon > 0 for o in ora])
-    np.testing.assert_allclose(b.get('qpos'), np.array([o.qpos for o in ora]), rtol=0, atol=t)
+  # Five free bodies are up to five constraint islands: the fp64 batch solves per island like the oracle (StepCore::
+  # solve_islands, on by default in fp64), the fp32 batch jointly (the same minimiser; 6e-9 apart over these 300 steps)
+  ora = _oracles(m, q)
+  for o in ora:
+    o.step(300)
+  np.testing.assert_array_equal(b.get('ncon')[:, 0] > 0, [o.ncon > 0 for o in ora])
+  np.testing.assert_allclose(b.get('qpos'), np.array([o.qpos for o in ora]), rtol=0, atol=tol)
   assert not b.get('warning').any()
   b.close()
 

@@ -152,3 +152,97 @@ def test_suite_multi_tree_models_track_the_one_system_solve(oracle_backend, doma
   assert err < 1e-6, err
   if domain != 'finger':      # (the finger's spinner is only ever reached through the finger: one island at most)
     assert seen >= 2, seen
+
+
+# ---- the kernel core and the device -------------------------------------------------------------------------------
+@pytest.mark.parametrize('option,condim', [('', 3), ("cone='elliptic' impratio='3'", 4), ("solver='CG'", 3)])
+def test_kernel_core_island_solves_follow_the_oracle(option, condim):
+  """StepCore::solve_islands (fp64: on by default): the partition and the per-island iterates of the kernel core against
+  the oracle's gathered sub-problems over a rollout in which legs touch down and lift off -- qacc to 1e-11 every step
+  (the joint solve of the same core, `set_islands(0)`, differs from both at the solver's tolerance, not at rounding)."""
+  from emu_lib import EmuPhysics
+  from oracle.oracle import OraclePhysics
+  legs = [('a', -1.5), ('b', 0.0), ('c', 1.5)]
+  xml = scene(legs, option=option, condim=condim)
+  m = mc.compile_xml(xml)
+  q, v, _ = _settled_state(3)
+  e, j, o = EmuPhysics(m, 64), EmuPhysics(m, 64), OraclePhysics(m)
+  j.set_islands(0)
+  for p in (e, j, o):
+    p.qpos[:] = q; p.qvel[:] = v
+  o.forward()
+  rs = np.random.RandomState(4)
+  worst_i = worst_j = 0.0
+  most = 0
+  for t in range(150):
+    c = rs.uniform(-1, 1, m.nu)
+    for p in (e, j, o):
+      p.ctrl[:] = c
+      p.step()
+    most = max(most, o.nisland)
+    worst_i = max(worst_i, np.abs(e.qpos - o.qpos).max())
+    worst_j = max(worst_j, np.abs(j.qpos - o.qpos).max())
+  print('measured: kernel core vs island oracle over 150 steps: per-island solves %.2e, joint solve %.2e (islands up to %d)' % (worst_i, worst_j, most))
+  assert most == 3
+  assert worst_i < 1e-11, worst_i
+  assert worst_j < (1e-4 if 'CG' in option else 1e-6), worst_j      # (CG stops at a looser point: its joint and per-island answers differ more)
+
+
+def test_kernel_core_islands_off_in_fp32_by_default_and_identical_for_one_tree():
+  from emu_lib import EmuPhysics
+  legs = [('a', -1.5), ('b', 0.0)]
+  m = mc.compile_xml(scene(legs))
+  q, v, c = _settled_state(2)
+  a, b = EmuPhysics(m, 32), EmuPhysics(m, 32)
+  b.set_islands(0)
+  for p in (a, b):
+    p.qpos[:] = q; p.qvel[:] = v; p.ctrl[:] = c
+    for _ in range(30):
+      p.step()
+  np.testing.assert_array_equal(a.qpos, b.qpos)      # fp32: the throughput instantiation solves jointly unless asked
+  # one tree: the island that holds everything is the joint problem, solved in place
+  m1 = mc.compile_xml(scene([('a', 0)]))
+  q1, v1, c1 = _settled_state(1)
+  a, b = EmuPhysics(m1, 64), EmuPhysics(m1, 64)
+  b.set_islands(0)
+  for p in (a, b):
+    p.qpos[:] = q1; p.qvel[:] = v1; p.ctrl[:] = c1
+    for _ in range(30):
+      p.step()
+  np.testing.assert_array_equal(a.qpos, b.qpos)
+
+
+@pytest.mark.gpu
+def test_device_island_solves_follow_the_oracle():
+  """The same on the device, fp64 (islands on by default) and fp32 with the option switched on, against per-environment
+  oracles; `islands = 0` gives the joint solve."""
+  from dm_control_amd.batch import BatchedPhysics
+  from oracle.oracle import OraclePhysics, OracleModel
+  legs = [('a', -1.5), ('b', 0.0), ('c', 1.5)]
+  m = mc.compile_xml(scene(legs, option="cone='elliptic'"))
+  B = 6
+  rs = np.random.RandomState(8)
+  q = np.stack([_settled_state(3)[0] + 0.05 * rs.randn(9) for _ in range(B)])
+  om = OracleModel(m)
+  refs = [OraclePhysics(om) for _ in range(B)]
+  for k, o in enumerate(refs):
+    o.qpos[:] = q[k]; o.forward()
+  b64, b32, bj = BatchedPhysics(m, B, precision=64), BatchedPhysics(m, B, precision=32), BatchedPhysics(m, B, precision=64)
+  b32.set_opt('islands', 1); bj.set_opt('islands', 0)
+  for b in (b64, b32, bj):
+    b.set('qpos', q)
+  most = 0
+  for t in range(120):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    for b in (b64, b32, bj):
+      b.set('ctrl', c); b.step()
+    for k, o in enumerate(refs):
+      o.ctrl[:] = c[k]; o.step(); most = max(most, o.nisland)
+  qo = np.stack([o.qpos for o in refs])
+  assert most == 3
+  np.testing.assert_allclose(b64.get('qpos'), qo, rtol=0, atol=1e-10)
+  np.testing.assert_allclose(bj.get('qpos'), qo, rtol=0, atol=1e-6)
+  np.testing.assert_allclose(b32.get('qpos'), qo, rtol=0, atol=2e-3)
+  for b in (b64, b32, bj):
+    assert not b.get('warning').any()
+    b.close()
