@@ -175,7 +175,7 @@ class BatchedPhysics:
 
   def set_opt(self, name, value):
     L = _native.lib()
-    if isinstance(value, (int, np.integer, bool)) and name in ('disableflags', 'iterations', 'ls_iterations', 'noslip_iterations', 'stash'):
+    if isinstance(value, (int, np.integer, bool)) and name in ('disableflags', 'iterations', 'ls_iterations', 'noslip_iterations', 'stash', 'islands'):
       _native.check(L.dmc_batch_set_opt_int(self._ptr, name.encode(), int(value)))
     else:
       _native.check(L.dmc_batch_set_opt_real(self._ptr, name.encode(), float(value)))
