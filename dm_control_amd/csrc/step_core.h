@@ -129,6 +129,9 @@ struct StepIO {
   int ndebug;
 };
 
+#ifndef DMC_STATIC_FEATURES
+#define DMC_STATIC_FEATURES 1
+#endif
 // ---------------------------------------------------------------------------
 // scalar math (expression order mirrors the oracle)
 // ---------------------------------------------------------------------------
@@ -621,7 +624,6 @@ struct StepCore {
   int* si;
   int lane;
   double time_;           // simulation time of this env (group-uniform)
-  int epoch_;             // the stash epoch at launch entry (Entry::epoch)
 
 
   DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
@@ -668,7 +670,7 @@ struct StepCore {
   DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
     env = late(env);
     const int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
-    if (hi[0] != epoch_) return false;      // group-uniform: never written, or written before the last host edit
+    if (hi[0] != SI(imisc)[IM_EPOCH]) return false;      // group-uniform: never written, or written before the last host edit
     const T* hr = io.stash_r + (size_t)env*L.n_keep;
     FOR_LANES(i, L.n_keep) s[i] = hr[i];
     FOR_LANES(i, L.n_si) si[i] = hi[4 + i];
@@ -683,7 +685,7 @@ struct StepCore {
       FOR_LANES(i, L.n_keep) hr[i] = s[i];
       FOR_LANES(i, L.n_si) hi[4 + i] = si[i];
     }
-    if (lane == 0) hi[0] = valid ? epoch_ : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
+    if (lane == 0) hi[0] = valid ? SI(imisc)[IM_EPOCH] : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
   }
   // ---- kinematic stash ------------------------------------------------------------------------------------------
   // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
@@ -695,7 +697,7 @@ struct StepCore {
   DMC_DEV int kin_count() const { return L.s_qM - L.s_xpos; }
   DMC_DEV bool load_kstash(const StepIO<T>& io, int env) {
     env = late(env);
-    if (io.kstash_i[env] != epoch_) return false;
+    if (io.kstash_i[env] != SI(imisc)[IM_EPOCH]) return false;
     const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
     const T* h = io.kstash + (size_t)env*(nq + nv + nk);
     int bad = 0;
@@ -714,7 +716,7 @@ struct StepCore {
     FOR_LANES(i, nq) h[i] = S(qpos)[i];
     FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
-    if (lane == 0) io.kstash_i[env] = epoch_;
+    if (lane == 0) io.kstash_i[env] = SI(imisc)[IM_EPOCH];
   }
   // ---- launch-entry loads ------------------------------------------------------------------------------------------
   // Everything a launch reads from HBM before it can start -- the env's launch override, its state, the tag of its
@@ -725,6 +727,12 @@ struct StepCore {
   // (override -> state -> tag -> compare -> data).  The stash is copied SPECULATIVELY: when it turns out stale the
   // kinematics pass overwrites it.  Lane i carries element i of every field: models with more than LPE coordinates,
   // and launches that use the full stash (whose copy of the state would overwrite this one), keep the in-place loads.
+  // Launch features only some callers need -- the substep probe, legacy_step 2 (step + mj_forward), the implicitfast
+  // integrator -- are compiled into the generic kernels and into the model-specialised kernels of the units that define
+  // DMC_STATIC_FEATURES 1 (the large models, fp64).  The fp32 kernels specialised for the small suite models leave them
+  // out (a launch that needs one runs the generic kernel: launch_step_t): on the 9-dof model they cost 6 VGPRs, 14
+  // spilled SGPRs, 2.6 KB of code and 1.2 % of the launch (A/B on one box, profiles/r04_ab_vs_round3.log).
+  static constexpr bool kFeat = LS::kNV <= 0 || DMC_STATIC_FEATURES;
   static constexpr int kPFKin = LS::kNKin > 0 ? ((LS::kNKin + LPE - 1) / LPE < 24 ? (LS::kNKin + LPE - 1) / LPE : 24) : 0;
   struct Entry { int em, fast, kvalid, epoch; };
   struct EntryRegs {
@@ -4630,7 +4638,7 @@ struct StepCore {
       // improvements of a few 1e-8: such a solve ran into the iteration cap (config 4: 0.02 % of the solves, 100
       // iterations against a mean of 3.4 and a 99.9th percentile of 11, profiles/r04_iter_hist_cfg4.json -- and a launch
       // waits for its longest item).  It ends when the gradient has not fallen by 10 % in six consecutive iterations.
-      if (sizeof(T) == 4 && !L.d.cg) {      // (Newton only: CG converges linearly and may legitimately crawl)
+      if (sizeof(T) == 4 && !L.d.cg && L.d.nv > 32) {      // (Newton only: CG converges linearly and may legitimately crawl; the stall was only ever seen on the 62-dof models, and the small kernels have no registers to spare)
         if (gradient < (T)0.9*gbest) { gbest = gradient; stall = 0; }
         else if (++stall >= DMC_STALL_ITERS && iter >= 2*DMC_STALL_ITERS) break;
       }
@@ -4737,7 +4745,7 @@ struct StepCore {
     const int nv = L.d.nv;
     const T dt = o.timestep;
     const T* qacc = S(qacc);
-    const bool implicitfast = o.integrator == DMC_INT_IMPLICITFAST;
+    const bool implicitfast = kFeat && o.integrator == DMC_INT_IMPLICITFAST;
     if (implicitfast) {
       // mj_implicit, mjINT_IMPLICITFAST: (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint with the velocity
       // derivatives of the passive and actuator forces and no Coriolis term.  The supported model class (the MJCF
@@ -4979,7 +4987,8 @@ struct StepCore {
   DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask, const Entry& en) {
     const bool stash = io.stash_r != nullptr;
     bool have = false;
-    epoch_ = en.epoch;
+    if (lane == 0) SI(imisc)[IM_EPOCH] = en.epoch;      // (kept in LDS, not in a register, for the whole launch)
+    DMC_WSYNC();
     if (mode == 5 && stash) have = load_stash(io, env);
     load_state(io, env, have, en);
     if (mode == 4) {
@@ -5006,6 +5015,15 @@ struct StepCore {
     if (stash) store_stash(io, env, false);
     store_state(io, env);
   }
+  // substep probe (StepIO::probe): slots [first, first + count) take the probed geom's current world position
+  DMC_DEV void probe_store(const StepIO<T>& io, int env, int first, int count) {
+    if constexpr (!kFeat) return;
+    env = late(env);      // (addresses derived from env are formed here, not kept alive across the pass loop)
+    T* p = io.probe;
+    if (!p) return;
+    const int cap = io.probe_cap, g = io.probe_geom;
+    for (int t = first; t < first + count && t < cap; t++) FOR_LANES(k, 3) p[((size_t)t*3 + k)*io.B + env] = S(geom_xpos)[3*g + k];
+  }
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub) {
     Entry en; EntryRegs er;
     entry_issue(L, o, io, env, lane, mode, legacy, &en, &er);
@@ -5015,7 +5033,7 @@ struct StepCore {
   // en: what entry_issue / entry_commit left for this env and the launch's (mode, legacy)
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en) {
     const int launch_mode = mode;
-    epoch_ = en.epoch;
+    if (lane == 0) SI(imisc)[IM_EPOCH] = en.epoch;      // (kept in LDS, not in a register, for the whole launch)
     if (io.env_mode) {
       const int em = en.em;
       if (em == 2) return;
@@ -5042,7 +5060,7 @@ struct StepCore {
     // legacy == 2: a legacy step whose trailing mj_step1 is followed by the rest of mj_forward at the new state (the
     // acceleration stage with its sensors, no integration) -- what the reference's composer observes after a control
     // step (mjcf/physics.py:341-342: the first observable read through a binding forwards the dirty physics)
-    const bool fwd_after = legacy == 2 && mode == 0;
+    const bool fwd_after = kFeat && legacy == 2 && mode == 0;
     for (int it = 0; it < npass; it++) {
       const bool trailing = stepping && it == ntotal;
       const bool partial = trailing && !(stash && mode == 0) && !fwd_after;
@@ -5053,16 +5071,16 @@ struct StepCore {
       // read afterwards evaluate them: position/velocity sensors in the last pass of a launch and
       // at env-step boundaries of a rollout, acceleration sensors in the pass before those.
       const bool sens_pv = !stepping || it == npass - 1 || (mode == 3 && it % nsub == 0);
-      const bool sens_acc = !stepping || (it == ntotal - 1 && !fwd_after) || (mode == 3 && (it + 1) % nsub == 0);
+      const bool sens_acc = !stepping || (it == ntotal - 1 && !fwd_after) || (trailing && fwd_after) || (mode == 3 && (it + 1) % nsub == 0);
       int stage = 0, retried = 0;
       while (stage < nstage) {
         if (!(have && it == 0 && !retried)) call_posvel(partial, outmask, stage > 0 || !sens_pv, havekin && it == 0 && !retried && !trailing);
         if (it == 0 && stage == 0) trace_stamp(io, env, 4); else if (trailing) trace_stamp(io, env, 7);
         if (mode == 3 && stage == 0 && it > 0 && it % nsub == 0) store_seq(io, env, it / nsub - 1);
-        if (io.probe && mode == 0 && stage == 0 && it >= 1 && it <= io.probe_cap)      // the state after `it` physics steps
-          FOR_LANES(k, 3) io.probe[((size_t)(it - 1)*3 + k)*io.B + env] = S(geom_xpos)[3*io.probe_geom + k];
-        if (trailing) { if (fwd_after) call_acc(false, false); break; }
-        call_acc(mode == 2, stage > 0 || !sens_acc);
+        if (mode == 0 && stage == 0 && it >= 1) probe_store(io, env, it - 1, 1);      // the state after `it` physics steps
+        if (trailing && !fwd_after) break;
+        call_acc(mode == 2, stage > 0 || !sens_acc);      // (the ONE call site of the acceleration stage)
+        if (trailing) break;      // legacy_step 2: the launch ends with mj_forward's acceleration stage at the new state
         if (it == 0 && stage == 0) trace_stamp(io, env, 5);
         if (stage == 0 && stepping && !retried && bad_acc()) {
           if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_BADQACC]++;     // mj_checkAcc: reset + forward
@@ -5079,8 +5097,7 @@ struct StepCore {
     }
     if (!stepping) dump_debug(io, env);
     // an environment the launch override turned into mj_forward (just re-initialised) reports its one state in every slot
-    if (io.probe && !stepping && launch_mode == 0) for (int t = 0; t < nstep && t < io.probe_cap; t++)
-      FOR_LANES(k, 3) io.probe[((size_t)t*3 + k)*io.B + env] = S(geom_xpos)[3*io.probe_geom + k];
+    if (!stepping && launch_mode == 0) probe_store(io, env, 0, nstep);
     if (!stepping || legacy || mode == 3) { DMC_PROF(PROF_TRAIL); store_outputs(io, env, outmask); }
     // the stash holds a complete position / velocity stage at the CURRENT state only after a legacy step (after an
     // mj_forward the Cholesky buffer holds the factor of H, not of M; a non-legacy mj_step ends before mj_step1)

@@ -224,7 +224,9 @@ static hipError_t launch_step_t(const LaunchGeom& g, hipStream_t stream, const S
 #else
 #define DMC_UNIT_INSTANCES(X) DMC_STATIC_INSTANCES(X)
 #endif
-#define DMC_X(SID, LPE) if (g.static_id == SID && g.lpe == LPE) DMC_LAUNCH_STATIC(LPE, SID)
+  // (a specialised kernel built without the optional launch features -- step_core.h kFeat -- hands such launches to the generic one)
+  const bool need_feat = legacy == 2 || io.probe != nullptr || o.integrator == DMC_INT_IMPLICITFAST;
+#define DMC_X(SID, LPE) if (g.static_id == SID && g.lpe == LPE && (DMC_STATIC_FEATURES || !need_feat)) DMC_LAUNCH_STATIC(LPE, SID)
   DMC_UNIT_INSTANCES(DMC_X)
 #undef DMC_X
 #endif

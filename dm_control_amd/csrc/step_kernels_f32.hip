@@ -1,6 +1,7 @@
 // fp32 instantiation (production precision for BASELINE config "cheetah run fp32"): the generic kernels and the
 // model-specialised ones of the small models; the large models' live in step_kernels_f32_ilp.hip.
 #define DMC_UNIT_STD 1
+#define DMC_STATIC_FEATURES 0   // the small models' specialised kernels: no probe / step+forward / implicitfast (step_core.h kFeat)
 #include "step_kernel.hip.h"
 namespace dmc {
 hipError_t launch_step_f32_ilp(const LaunchGeom& g, hipStream_t stream, const StepLayout* d_layout, const StepOpts<float>& o,

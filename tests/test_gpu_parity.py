@@ -1052,3 +1052,35 @@ def test_async_host_transfers_equal_the_synchronous_ones(cheetah, precision):
   with pytest.raises(Exception, match='no get is enqueued'):
     b._pending_get = ['qpos']; b.get_wait()
   a.close(); b.close()
+
+
+def test_optional_launch_features_on_a_small_specialised_model(cheetah):
+  """The fp32 kernels specialised for the small suite models are built without the optional launch features (substep
+  probe, legacy_step 2 = step + mj_forward, implicitfast: step_core.h kFeat): a launch that needs one runs the generic
+  kernel on the same batch -- same state layout, results equal to rounding (the two kernels order some sums differently)."""
+  import torch
+  m = cheetah
+  B = 16
+  q = _cheetah_init(m, B)
+  a, b = _batch(m, B, precision=32), _batch(m, B, precision=32)
+  assert a.info()['static_id'] >= 0
+  probe = torch.zeros((4, 3, B), dtype=torch.float32, device='cuda')
+  g = m.name2id('ffoot', 'geom')
+  b.set_step_probe(g, probe.data_ptr(), 4)
+  rs = np.random.RandomState(0)
+  for x in (a, b):
+    x.set('qpos', q)
+  for t in range(5):
+    c = rs.uniform(-1, 1, (B, m.nu))
+    a.set('ctrl', c); b.set('ctrl', c)
+    trace = []
+    for k in range(3):
+      a.step(1)
+      trace.append(a.get('geom_xpos')[:, 3*g:3*g + 3])
+    a.forward()
+    b.step(3, forward_after=True)
+    torch.cuda.synchronize()
+    for n in ('qpos', 'qvel', 'qacc', 'sensordata'):
+      np.testing.assert_allclose(b.get(n), a.get(n), rtol=0, atol=2e-4 * max(1.0, np.abs(a.get(n)).max()), err_msg=n)
+    np.testing.assert_allclose(probe[:3].cpu().numpy().transpose(0, 2, 1), np.stack(trace), rtol=0, atol=1e-5)
+  a.close(); b.close()
