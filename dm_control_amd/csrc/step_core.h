@@ -1289,53 +1289,12 @@ struct StepCore {
     DMC_WSYNC();
   }
 #endif
-  // the factors of M and of M + h diag(damping) in one pass: two independent elimination chains per lane, interleaved
-  // (each column step of one waits on a cross-lane broadcast the other can fill); same arithmetic per chain as
-  // factor_dense_rows, so both factors are bit-identical to the ones made separately
-#ifndef DMC_HOST_EMU
-  template <int N>
-  DMC_DEV void factor_dense_rows2(const T* diag, T diag_scale, T* dstM, T* dstD) {
-    const bool own = lane < N;
-    const int i = own ? lane : 0;
-    T a[N], d[N];
-#pragma unroll
-    for (int j = 0; j < N; j++) { a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0; d[j] = a[j]; }
-    { const T dv = diag_scale*diag[i];
-#pragma unroll
-      for (int j = 0; j < N; j++) if (own && j == lane) d[j] += dv; }
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      T akk = wave_bcast<LPE>(a[k], k), dkk = wave_bcast<LPE>(d[k], k);
-      if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
-      if (dkk < (T)DMC_MINVAL) dkk = (T)DMC_MINVAL;
-      const T inva = t_rsqrt(akk), invd = t_rsqrt(dkk);
-      const T lika = a[k] * inva, likd = d[k] * invd;
-#pragma unroll
-      for (int j = k + 1; j < N; j++) {
-        const T ljka = wave_bcast<LPE>(lika, j), ljkd = wave_bcast<LPE>(likd, j);
-        a[j] = a[j] - lika * ljka; d[j] = d[j] - likd * ljkd;
-      }
-      a[k] = lane == k ? inva : lika; d[k] = lane == k ? invd : likd;
-    }
-    DMC_LDS T* A = (DMC_LDS T*)dstM; DMC_LDS T* D = (DMC_LDS T*)dstD;
-    if (own) {
-#pragma unroll
-      for (int j = 0; j < N; j++) if (j <= lane) { A[tri_c0(j, N) + lane - j] = a[j]; D[tri_c0(j, N) + lane - j] = d[j]; }
-    }
-    DMC_WSYNC();
-  }
-#endif
-  // mj_Euler's implicit joint damping applies (and the model keeps its factor from the position stage, StepDims::eulerfac)
-  DMC_DEV bool euler_factor_kept() const {
-    return L.d.eulerfac && o.any_damping && o.integrator == DMC_INT_EULER && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER));
-  }
   DMC_DEV void factor_M(bool with_damping, const T* damping = nullptr) {      // damping: the diagonal added as timestep * damping[i]
     T* dst = with_damping ? S(qLH) : M_factor();
 #if !defined(DMC_HOST_EMU) && !defined(DMC_NO_FACTOR_ROWS)
     if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
       if (!L.d.msparse) {
-        if (!with_damping && euler_factor_kept()) factor_dense_rows2<LS::kNV>(MR(dof_damping), o.timestep, dst, S(qLD));
-        else factor_dense_rows<LS::kNV>(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
+        factor_dense_rows<LS::kNV>(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
         DMC_PROF(PROF_X3);
         if (!with_damping && L.d.jglobal && L.d.nslip) { DMC_GLB T* g = (DMC_GLB T*)gLM(); FOR_LANES(k, L.d.ntri) g[k] = dst[k]; }
         return;
@@ -4824,15 +4783,8 @@ struct StepCore {
     if (implicitfast || (o.any_damping && !(o.disableflags & (DMC_DSBL_EULERDAMP | DMC_DSBL_DAMPER)))) {
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
       DMC_WSYNC();
-      bool kept = false;
-#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_FACTOR_ROWS)
-      if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) kept = !implicitfast && !L.d.msparse && euler_factor_kept();
-#endif
-      if (kept) chol_solve(S(sv_Mgrad), S(qLD), S(sv_grad), nv);      // (the factor was made beside M's in the position stage)
-      else {
-        factor_M(true, implicitfast ? S(sv_search) : MR(dof_damping));
-        chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
-      }
+      factor_M(true, implicitfast ? S(sv_search) : MR(dof_damping));
+      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
       qacc = S(sv_Mgrad);
     }
     FOR_LANES(i, nv) S(qvel)[i] += dt*qacc[i];

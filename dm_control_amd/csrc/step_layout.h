@@ -55,8 +55,6 @@ struct StepDims {
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
   int dfs;       // 1: bodies are numbered depth first (a subtree is the contiguous range [b, body_subend[b])): subtree sums in one pass
   int ntree;     // kinematic trees with at least one dof (M^-1 is block diagonal over them: noslip blocks of different trees are independent)
-  int eulerfac;  // 1 (dense M, nv <= 16, damped joints, Euler): the factor of M + h diag(damping) that mj_Euler needs is made in the
-                 //   position stage together with M's (two independent elimination chains in flight) and kept in qLD
   int island;    // 1: the model can have more than one constraint island (two or more kinematic trees, no noslip pass, a
                  //   primal solver): scratch for the island partition (StepCore::find_islands)
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
@@ -169,7 +167,6 @@ struct StepDims {
   X(cvel, 6 * d.nbody)                                                         \
   X(qM, d.jglobal == 2 ? 0 : (d.msparse ? d.nM : d.nv * d.nv))  /* sparse: entry p is M(i, j) of the (i, j) list (mpair); global scratch if jglobal */ \
   X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
-  X(qLD, d.eulerfac ? d.ntri : 0)   /* the factor of M + h diag(damping) for mj_Euler's implicit damping (StepDims::eulerfac) */ \
   X(qLM, (d.nslip && !d.jglobal) ? d.ntri : 0)   /* noslip models: the factor of M kept beside that of H (noslip needs M^-1 after the solve); global scratch if jglobal */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \

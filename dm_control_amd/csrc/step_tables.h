@@ -257,9 +257,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   d.pgs = m.opt_solver == DMC_SOL_PGS ? 1 : 0;
   if (d.pgs) d.nslip = njmax;      // the dual solver keeps a residual entry and a row of AR for EVERY constraint row
   d.jfull = m.nv <= 16 ? 1 : 0;
-  { bool damped = false;
-    for (int i = 0; i < m.nv; i++) if (m.dof_damping[i] > 0) damped = true;
-    d.eulerfac = (m.nv <= 16 && damped && m.opt_integrator == DMC_INT_EULER) ? 1 : 0; }      // (msparse is nv > 16: these models keep M dense)
   d.njdense = d.jfull ? njmax : std::min(njmax, d.neqrow + 2 * d.nlimten);
   // contact rows with a stored Jacobian: by default every contact slot may use its maximum number of rows; a
   // smaller pool (njcon > 0) trades LDS for a DMC_WARN_CNSTRFULL when the live contacts need more rows than that
