@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-4 closing measurement session, one box, final library: the GPU test tier (with the reference tree staged:
+# scripts/stage_reference.sh), bench lines of configs 5, 4, 3, 2 (parity legs, CPU baseline, live PMC passes), the
+# driver's command line, rocprofv3 kernel stats of every config, the device environments, the all-task soak, wave tails,
+# the host-buffer boundary.  Outputs -> gpurun_out/r04_* (scripts/r04_profiles.py copies the summaries into profiles/).
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$(pwd)
+timeout 300 python -m pytest tests -m gpu -q -rs 2>&1 | tail -8 > gpurun_out/r04_gputests.log; tail -2 gpurun_out/r04_gputests.log
+timeout 200 python -m pytest tests/test_reference_host_layers.py tests/test_reference_suite_domains.py tests/test_reference_composer.py tests/test_reference_unit_tests.py -m gpu -v 2>&1 | grep -E "PASSED|FAILED|SKIPPED|passed|failed" > gpurun_out/r04_reference_on_hip.log; tail -1 gpurun_out/r04_reference_on_hip.log
+for c in 5 4 3 2; do
+  timeout 300 python bench.py --config $c > gpurun_out/r04_bench_cfg$c.json 2> gpurun_out/r04_bench_cfg$c.err; echo "bench cfg$c rc=$?"
+  python -c "
+import json
+d=json.load(open('gpurun_out/r04_bench_cfg$c.json')); print('cfg$c', round(d['value']), d['ms_per_step'], d['roofline'].get('traffic_over_algorithmic'), d.get('roofline_issue',{}).get('frac'), d.get('roofline_issue',{}).get('clock_ghz_raw'))"
+done
+timeout 100 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_driver_cmd.json 2>/dev/null; echo "driver cmd rc=$?"
+cd /tmp
+for c in 2 3 4 5; do
+  K=200; [ $c != 2 ] && K=30
+  DMC_BENCH_NO_PMC=1 timeout 240 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r04_prof_cfg$c -o r04 --output-format csv -- python $R/bench.py --config $c --steps $K --warmup 5 --no-cpu-baseline --parity-steps 0 > $R/gpurun_out/r04_prof_bench_cfg$c.json 2> $R/gpurun_out/r04_prof_cfg$c.err; echo "rocprof cfg$c rc=$?"
+done
+cd $R
+GRAPH=1 T=300 timeout 400 python scripts/composer_runs.py > gpurun_out/r04_composer.log 2>&1; echo "composer rc=$?"; cp gpurun_out/composer_runs.json gpurun_out/r04_composer_runs.json
+T=300 timeout 900 python scripts/soak.py > gpurun_out/r04_soak.log 2>&1; echo "soak rc=$?"; cp gpurun_out/soak.json gpurun_out/r04_soak_all_tasks.json
+timeout 100 python scripts/tail_probe.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cheetah.json gpurun_out/r04_wave_tail_cfg2.json
+for c in 3 4 5; do CONFIG=$c timeout 200 python scripts/tail_probe_cfg.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cfg$c.json gpurun_out/r04_wave_tail_cfg$c.json; done
+CONFIG=2 timeout 100 python scripts/pcie_probe.py > /dev/null 2>&1; cp gpurun_out/pcie_probe_cfg2.json gpurun_out/r04_pcie_probe_cfg2.json
+CONFIG=4 STEPS=20 timeout 200 python scripts/iter_hist.py 2>&1 | tail -2
+python scripts/r04_profiles.py
