@@ -45,6 +45,7 @@ _HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'l
                            'body_sameframe', 'body_simple', 'geom_sameframe', 'site_sameframe')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
+_INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2', 'env_mode')
 _INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
                  'mocap_quat')
 _INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
@@ -97,6 +98,9 @@ class _Data:
     object.__setattr__(self, '_cache', {})
     object.__setattr__(self, '_touched', set())
     object.__setattr__(self, '_shadow', {})      # view semantics: what the device holds of each handed-out input array
+    object.__setattr__(self, '_reads', set())    # device fields fetched since the last launch ...
+    object.__setattr__(self, '_habit', ())       # ... and those fetched after the launch before: prefetched together
+    object.__setattr__(self, '_prefetched', {})
 
   @property
   def ptr(self):
@@ -155,7 +159,9 @@ class _Data:
       anchor, axis = self._joint_frames()
       a = anchor if name == 'xanchor' else axis
       return a[0] if p.batch_size == 1 else a
-    a = p.batch.get(name)
+    a = self._prefetched.pop(name, None)
+    if a is None:
+      a = self._fetch_device(name)
     rows = a.shape[1]
     if name in _FIELD_AXES and _FIELD_AXES[name][1]:
       c = _FIELD_AXES[name][1]
@@ -163,6 +169,25 @@ class _Data:
     if name in ('time', 'ncon', 'nefc', 'solver_iter'):
       a = a[:, 0]
     return a[0] if p.batch_size == 1 else a
+
+  def _fetch_device(self, name):
+    """One field from the device.  A host loop reads the same few fields after every step (a suite task: qpos, qvel,
+    sensordata, ...): the real fields read after the PREVIOUS launch are fetched together with this one -- one
+    device-to-host copy and one wait (dmc_batch_get_async / get_wait) instead of one synchronous round trip per field."""
+    b = self._p.batch
+    self._reads.add(name)
+    want = [n for n in self._habit if n != name and n not in self._cache and n not in self._prefetched]
+    if want and hasattr(b, 'get_many'):
+      want = [n for n in want if n not in _INT_FIELDS and n not in ('xanchor', 'xaxis')][:7]      # (a get holds at most 8 fields)
+      if want and name not in _INT_FIELDS:
+        try:
+          got = b.get_many([name] + want)
+          for n in want:
+            self._prefetched[n] = got[n]
+          return got[name]
+        except Exception:      # pylint: disable=broad-except
+          pass                 # (a field the batch does not have: fall back to the plain read)
+    return b.get(name)
 
   @property
   def timer(self):
@@ -232,6 +257,10 @@ class _Data:
     the model, rewritten in place after each launch and watched for writes -- what dm_control.mjcf's bindings, which
     keep the arrays themselves, rely on.  Single environments only: the copies are per launch.)"""
     self._touched.clear()
+    if self._reads:
+      object.__setattr__(self, '_habit', tuple(sorted(self._reads)))
+    self._reads.clear()
+    self._prefetched.clear()
     if not self._p.view_semantics:
       self._cache.clear()
       return

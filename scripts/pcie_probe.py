@@ -65,6 +65,18 @@ for t in range(1, T):
   b.get_async(('qpos', 'qvel', 'sensordata'))
 b.get_wait(np.float32)
 rates['f32_host_pipelined'] = B * (T - 1) / (time.perf_counter() - t1)
+# the numpy FACADE a drop-in user gets (Physics.set_control / step / data.qpos ...): reads are fetched together from the second step on
+from dm_control_amd import physics as physics_lib  # noqa: E402
+fp = physics_lib.Physics(m, batch_size=B, precision=32, **caps)
+fp.step(50)
+for t in range(10):
+  fp.set_control(ctrl[t]); fp.step(nsub); _ = (fp.data.qpos, fp.data.qvel, fp.data.sensordata)
+t1 = time.perf_counter()
+for t in range(T):
+  fp.set_control(ctrl[t]); fp.step(nsub)
+  _ = (fp.data.qpos, fp.data.qvel, fp.data.sensordata)
+rates['numpy_facade'] = B * T / (time.perf_counter() - t1)
+fp.free()
 ms_dev = b.time_steps(nsub, 100)
 out = dict(config=cfg, B=B, env_steps=T, host_buffer_env_steps_per_s=B * T / dt, ms_per_env_step_host_buffers=1e3 * dt / T,
            ms_per_launch_device_resident=ms_dev, device_resident_env_steps_per_s=B / (ms_dev * 1e-3),

@@ -91,6 +91,11 @@ class OracleBatch:
     self._stale = True      # the device recomputes the opening stage after a model edit (stash epoch bumped)
 
   # -- pipeline -------------------------------------------------------------------------
+  def get_many(self, names, stream=None, dtype=np.float64, copy=True):
+    del stream, copy
+    self.get_many_calls = getattr(self, 'get_many_calls', 0) + 1
+    return {n: np.asarray(self.get(n), dtype=dtype) for n in names}
+
   def enable_profiling(self, enabled=True):
     self._timing = bool(enabled)
 

@@ -257,3 +257,27 @@ def test_copy_keeps_subclass_episode_state_and_owns_its_model(oracle_backend):
   assert c.model is not p.model and p.copy(share_model=True).model is p.model
   c.model.dof_damping[0] = 9.0
   assert p.model.dof_damping[0] != 9.0
+
+
+def test_facade_fetches_the_fields_a_loop_reads_in_one_round_trip(oracle_backend):
+  """A host loop reads the same few mjData fields after every step: from the second iteration on the facade fetches
+  them together (BatchedPhysics.get_many: one device-to-host copy and one wait) instead of field by field, and the values
+  are those of single reads."""
+  import numpy as np
+  from dm_control_amd import physics as physics_lib
+  from dm_control_amd.suite import common
+  p = physics_lib.Physics.from_xml_string(common.read_model('cheetah.xml'), batch_size=3)
+  q = physics_lib.Physics.from_xml_string(common.read_model('cheetah.xml'), batch_size=3)
+  rs = np.random.RandomState(0)
+  for t in range(4):
+    c = rs.uniform(-1, 1, (3, 6))
+    p.set_control(c); q.set_control(c)
+    p.step(); q.step()
+    calls0 = getattr(p.batch, 'get_many_calls', 0)
+    a = (np.array(p.data.qpos), np.array(p.data.qvel), np.array(p.data.sensordata))
+    calls = getattr(p.batch, 'get_many_calls', 0) - calls0
+    assert calls <= 1 if t == 0 else calls == 1, (t, calls)      # from the second pass on: ONE round trip for the three reads
+    np.testing.assert_array_equal(a[1], q.batch.get('qvel'))
+    np.testing.assert_array_equal(a[2], q.batch.get('sensordata'))
+    np.testing.assert_array_equal(a[0], q.batch.get('qpos'))
+  p.free(); q.free()
