@@ -98,6 +98,7 @@ class _Data:
     object.__setattr__(self, '_cache', {})
     object.__setattr__(self, '_touched', set())
     object.__setattr__(self, '_shadow', {})      # view semantics: what the device holds of each handed-out input array
+    object.__setattr__(self, '_written', set())  # inputs assigned through data.<name> = ... since the last launch
     object.__setattr__(self, '_reads', set())    # device fields fetched since the last launch ...
     object.__setattr__(self, '_habit', ())       # ... and those fetched after the launch before: prefetched together
     object.__setattr__(self, '_prefetched', {})
@@ -215,7 +216,11 @@ class _Data:
         if name not in self._shadow and isinstance(a, np.ndarray) and a.ndim:
           self._shadow[name] = np.array(a, copy=True)      # writes are found by comparison at upload time
       else:
+        # a read hands out an array the caller may write into: kept beside a copy, and uploaded only if it differs
         self._touched.add(name)
+        a = self._cache[name]
+        if name not in self._shadow and isinstance(a, np.ndarray) and a.ndim:
+          self._shadow[name] = np.array(a, copy=True)
     return self._cache[name]
 
   def __setattr__(self, name, value):
@@ -227,6 +232,7 @@ class _Data:
     else:
       cur[...] = value
     self._touched.add(name)
+    self._written.add(name)
 
   def _upload(self):
     p = self._p
@@ -238,8 +244,13 @@ class _Data:
         cur = self._cache.get(name)
         if isinstance(cur, np.ndarray) and cur.ndim and not np.array_equal(cur, dev, equal_nan=True):
           self._touched.add(name)
+    send = getattr(p.batch, 'set_async', None) or p.batch.set      # (stream-ordered with the launches: the facade uses the null stream throughout)
     for name in list(self._touched):
       a = np.asarray(self._cache[name], dtype=np.float64)
+      if not p.view_semantics:
+        dev = self._shadow.get(name)
+        if dev is not None and name not in self._written and dev.shape == a.shape and np.array_equal(a, dev, equal_nan=True):
+          continue      # only read since the last launch: the device already holds these values
       if name == 'xfrc_applied':
         # A READ marks an input as touched too (the caller may have written into the array it was handed).  Uploading
         # xfrc_applied switches the kernel's external-force path on for good (6 nbody reals per environment per step):
@@ -247,8 +258,11 @@ class _Data:
         if not a.any() and not self._p.__dict__.get('_xfrc_sent', False):
           continue
         self._p._xfrc_sent = True
-      p.batch.set(name, a.reshape(p.batch_size, -1))
+      send(name, a.reshape(p.batch_size, -1))
     self._touched.clear()
+    self._written.clear()
+    if not p.view_semantics:
+      self._shadow.clear()
 
   def _invalidate(self):
     """After a launch every handed-out array is dropped: the next access fetches a fresh one.  (The reference's arrays
@@ -263,6 +277,8 @@ class _Data:
     self._prefetched.clear()
     if not self._p.view_semantics:
       self._cache.clear()
+      self._shadow.clear()
+      self._written.clear()
       return
     for name in list(self._cache):
       old = self._cache[name]
