@@ -136,21 +136,21 @@ class BatchedPhysics:
       out = {}
       for i, n in enumerate(names):
         rows = self._rows(n)[0]
-        dt = np.float64 if (self.precision == 64 or n == 'time') else np.float32
+        dt = np.int32 if self._rows(n)[1] else np.float64 if (self.precision == 64 or n == 'time') else np.float32
         if not rows:
           out[n] = np.zeros((self.batch_size, 0), dtype=dt)
           continue
         p = L.dmc_batch_get_staged(self._ptr, i)
         if not p:
           raise _native.NativeError(L.dmc_last_error().decode())
-        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double if dt == np.float64 else ctypes.c_float)), shape=(self.batch_size, rows))
+        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double if dt == np.float64 else ctypes.c_int32 if dt == np.int32 else ctypes.c_float)), shape=(self.batch_size, rows))
         a.flags.writeable = False
         out[n] = a
       return out
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
       raise ValueError('dtype must be float64 or float32')
-    outs = [np.empty((self.batch_size, self._rows(n)[0]), dtype=dt) for n in names]
+    outs = [np.empty((self.batch_size, self._rows(n)[0]), dtype=np.int32 if self._rows(n)[1] else dt) for n in names]
     ptrs = (ctypes.c_void_p * len(names))(*[o.ctypes.data if o.size else None for o in outs])
     _native.check(_native.lib().dmc_batch_get_wait(self._ptr, len(names), ptrs, 32 if dt == np.dtype(np.float32) else 64))
     self._pending_get = None

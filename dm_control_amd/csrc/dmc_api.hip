@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(256) get_pack_kernel(GetTable t, int B) {
   else transpose_tile<float>((const float*)t.src[f], (float*)t.dst[f], t.rows[f], B, B, t.rows[f], blockIdx.x, blockIdx.y, (float (*)[33])tile64);
 }
 static bool get_in_flight(const dmc_batch* b) { return b->xfer && b->xfer->out_in_flight; }
-static size_t field_elem(const dmc_batch* b, const Field* f) { return (b->precision == 64 || f->is_f64) ? sizeof(double) : sizeof(float); }
+static size_t field_elem(const dmc_batch* b, const Field* f) { return f->is_int ? sizeof(int32_t) : (b->precision == 64 || f->is_f64) ? sizeof(double) : sizeof(float); }
 extern "C" int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream) {
   if (!b || !name || !src) return fail("null argument");
   if (host_bits != 64 && host_bits != 32) return fail("host_bits must be 64 or 32");
@@ -794,7 +794,7 @@ extern "C" int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names
   size_t bytes = 0;
   for (int i = 0; i < n; i++) {
     Field* f = find_field(b, names[i]);
-    if (!f || f->is_int) return fail(std::string("unknown real field: ") + (names[i] ? names[i] : "(null)"));
+    if (!f) return fail(std::string("unknown field: ") + (names[i] ? names[i] : "(null)"));      // (int32 fields travel as they are)
     bytes = (bytes + 7) / 8 * 8;
     x->pending.push_back({f, bytes});
     bytes += (size_t)f->rows * b->B * field_elem(b, f);
@@ -837,6 +837,7 @@ extern "C" int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int ho
     const size_t cnt = (size_t)f->rows * b->B, es = field_elem(b, f);
     if (!cnt || !dsts[i]) continue;
     const void* srcp = (const char*)x->h_out + x->pending[i].second;
+    if (f->is_int) { std::memcpy(dsts[i], srcp, cnt * 4); continue; }      // int32 whatever host_bits says
     if (es == 8) { const double* p = (const double*)srcp; if (host_bits == 64) std::memcpy(dsts[i], p, cnt * 8); else { float* d = (float*)dsts[i]; for (size_t k = 0; k < cnt; k++) d[k] = (float)p[k]; } }
     else { const float* p = (const float*)srcp; if (host_bits == 32) std::memcpy(dsts[i], p, cnt * 4); else { double* d = (double*)dsts[i]; for (size_t k = 0; k < cnt; k++) d[k] = p[k]; } }
   }

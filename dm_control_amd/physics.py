@@ -45,7 +45,6 @@ _HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'l
                            'body_sameframe', 'body_simple', 'geom_sameframe', 'site_sameframe')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
-_INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2', 'env_mode')
 _INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
                  'mocap_quat')
 _INT_FIELDS = ('ncon', 'nefc', 'solver_iter', 'warning', 'contact_geom1', 'contact_geom2')
@@ -179,8 +178,8 @@ class _Data:
     self._reads.add(name)
     want = [n for n in self._habit if n != name and n not in self._cache and n not in self._prefetched]
     if want and hasattr(b, 'get_many'):
-      want = [n for n in want if n not in _INT_FIELDS and n not in ('xanchor', 'xaxis')][:7]      # (a get holds at most 8 fields)
-      if want and name not in _INT_FIELDS:
+      want = [n for n in want if n not in ('xanchor', 'xaxis', 'contact')][:7]      # (a get holds at most 8 fields)
+      if want:
         try:
           got = b.get_many([name] + want)
           for n in want:
@@ -672,7 +671,8 @@ class Physics(control.Physics):
     """Raises PhysicsError (or logs, under suppress_physics_errors) if the
     enclosed launch incremented any warning counter (engine.py:345-368)."""
     yield
-    w = self.batch.get('warning').astype(np.int64)
+    # (the first device read after a launch: the fields the caller's loop reads come back in the same round trip)
+    w = np.asarray(self.data._fetch_device('warning')).astype(np.int64)
     new = w > self._warnings_seen
     self._warnings_seen = w
     if new.any():

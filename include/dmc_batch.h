@@ -124,7 +124,8 @@ int dmc_batch_set_int(dmc_batch* b, const char* name, const int32_t* src);
  *   dmc_batch_set_async: `src` (B, rows) of host_bits-wide floats is consumed before the call returns; the write is
  *     ordered on the stream with the launches (and bumps the stash epoch there, like dmc_batch_invalidate_async).
  *   dmc_batch_get_async: enqueues the read of `n` real fields (as of this point of the stream); one get at a time.
- *   dmc_batch_get_wait: waits for it and writes field i, (B, rows_i) of host_bits-wide floats, to dsts[i] (NULL: skip). */
+ *   dmc_batch_get_wait: waits for it and writes field i, (B, rows_i) of host_bits-wide floats, to dsts[i] (NULL: skip);
+ *     int fields ("warning", "ncon", ...) may be part of a get and arrive as int32. */
 int dmc_batch_set_async(dmc_batch* b, const char* name, const void* src, int host_bits, void* hip_stream);
 int dmc_batch_get_async(dmc_batch* b, int n, const char* const* names, void* hip_stream);
 int dmc_batch_get_wait(dmc_batch* b, int n, void* const* dsts, int host_bits);
