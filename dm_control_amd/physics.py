@@ -225,6 +225,18 @@ class _Data:
   def __setattr__(self, name, value):
     if name not in _INPUT_FIELDS:
       raise AttributeError('data.%s is read-only' % name)
+    if name not in self._cache and name != 'time' and np.ndim(value) >= 1:
+      # a whole-array assignment (set_control's `data.ctrl = action`): nothing to fetch from the device first
+      m = self._p.model
+      n = dict(qpos=m.nq, qvel=m.nv, act=m.na, ctrl=m.nu, qacc_warmstart=m.nv, qfrc_applied=m.nv, xfrc_applied=6 * m.nbody,
+               mocap_pos=3 * getattr(m, 'nmocap', 0), mocap_quat=4 * getattr(m, 'nmocap', 0))[name]
+      c = _FIELD_AXES[name][1]
+      shape = (n // c, c) if c else (n,)
+      if self._p.batch_size > 1:
+        shape = (self._p.batch_size,) + shape
+      if np.shape(value) == shape or (np.size(value) == int(np.prod(shape)) and not self._p.view_semantics):
+        self._cache[name] = np.empty(shape, dtype=np.float64)
+        self._shadow.pop(name, None)
     cur = self._get(name)
     if np.ndim(cur) == 0:
       self._cache[name] = np.asarray(float(value))
