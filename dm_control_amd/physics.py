@@ -162,6 +162,8 @@ class _Data:
     a = self._prefetched.pop(name, None)
     if a is None:
       a = self._fetch_device(name)
+    else:
+      self._reads.add(name)      # (served from the prefetch: still part of what this loop reads)
     rows = a.shape[1]
     if name in _FIELD_AXES and _FIELD_AXES[name][1]:
       c = _FIELD_AXES[name][1]
@@ -536,6 +538,7 @@ class Physics(control.Physics):
     self._warnings_cause_exception = True
     self._warnings_seen = np.zeros((self.batch_size, len(_WARNING_NAMES)), dtype=np.int64)
     self._build_named()
+    self._model_flat = None
     self._model_pushed = {f: np.array(getattr(model, f), dtype=np.float64, copy=True)
                           for f in _MUTABLE_MODEL_FIELDS if hasattr(model, f)}
     # Every other model array feeds tables that are derived once at batch creation (contact-pair mixing, inertias,
@@ -611,6 +614,10 @@ class Physics(control.Physics):
         if old is None or old[k] != v:
           self.batch.set_opt(n, v)
       self._opt_pushed = snap
+    flat = np.concatenate([np.asarray(getattr(self.model, f), dtype=np.float64).ravel() for f in self._model_pushed])
+    if self._model_flat is not None and flat.shape == self._model_flat.shape and np.array_equal(flat, self._model_flat, equal_nan=True):
+      return      # (one comparison for all the writable model arrays: this runs before every launch)
+    self._model_flat = flat
     for f, old in self._model_pushed.items():
       cur = np.asarray(getattr(self.model, f), dtype=np.float64)
       if cur.shape != old.shape or not np.array_equal(cur, old):
