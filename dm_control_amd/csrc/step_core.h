@@ -2119,6 +2119,27 @@ struct StepCore {
         if (lane == 0) { S(efc_aref)[r] = dist; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_TENDON_LIMIT, t); }
       }
     }
+    // ball-joint limits (mj_instantiateLimit, mjJNT_BALL): the rotation angle against max(range), one dense row with
+    // J = -axis on the joint's three dofs.  Emitted here, after the tendon limits, because they need Jacobian storage
+    // (MuJoCo and the oracle emit them in joint order: same rows, same minimiser); id = ntendon + joint
+    if (L.d.nlimball && enabled && !(o.disableflags & DMC_DSBL_LIMIT)) for (int kb = 0; kb < L.d.nlimball; kb++) {
+      const int j = MI(limball)[kb], qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j];
+      const T q0 = S(qpos)[qa], q1 = S(qpos)[qa + 1], q2 = S(qpos)[qa + 2], q3 = S(qpos)[qa + 3];
+      const T qn = t_sqrt(q0*q0 + q1*q1 + q2*q2 + q3*q3);
+      T ax[3] = {q1/qn, q2/qn, q3/qn};
+      const T sn = t_sqrt(ax[0]*ax[0] + ax[1]*ax[1] + ax[2]*ax[2]);
+      T angle = 2*t_atan2(sn, q0/qn);
+      if (angle > (T)3.14159265358979323846) angle -= (T)6.283185307179586476925286766559;
+      if (sn < (T)DMC_MINVAL) { ax[0] = ax[1] = ax[2] = 0; angle = 0; } else for (int k = 0; k < 3; k++) ax[k] /= sn;
+      if (angle < 0) { angle = -angle; for (int k = 0; k < 3; k++) ax[k] = -ax[k]; }
+      const T margin = MRC(jnt_margin)[j];
+      const T dist = t_max(MRC(jnt_range)[2*j], MRC(jnt_range)[2*j + 1]) - angle;
+      if (!(dist < margin)) continue;
+      if (nefc >= njmax || ndense >= L.d.njdense) { overflow = 1; continue; }
+      const int r = nefc++, jr = ndense++;
+      FOR_LANES(dd, nv) S(efc_Jd)[jr*nv + dd] = dd == da ? -ax[0] : dd == da + 1 ? -ax[1] : dd == da + 2 ? -ax[2] : (T)0;      // (no dynamic index into the axis: no scratch)
+      if (lane == 0) { S(efc_aref)[r] = dist; S(efc_D)[r] = margin; SI(efc_tid)[r] = EFC_TID(EFC_TENDON_LIMIT, L.d.ntendon + j); }
+    }
     const int nefc_lim = nefc;
     // contact rows: headers, and the dof mask of each contact's Jacobian rows (the dofs on exactly one of
     // the two bodies' chains: on a shared ancestor dof the two bodies move together and the entry is 0)
@@ -2243,6 +2264,10 @@ struct StepCore {
         const int jn = MI(dof_jntid)[id >> 1];
         solref = MRC(jnt_solref) + 2*jn; solimp = MRC(jnt_solimp) + 5*jn;
         dA = MR(dof_invweight0)[id >> 1];
+      } else if (type == EFC_TENDON_LIMIT && id >= L.d.ntendon) {      // a ball-joint limit (dense limit row of joint id - ntendon)
+        const int jn = id - L.d.ntendon;
+        solref = MRC(jnt_solref) + 2*jn; solimp = MRC(jnt_solimp) + 5*jn;
+        dA = MR(dof_invweight0)[MI(jnt_dofadr)[jn]];
       } else if (type == EFC_TENDON_LIMIT) {
         solref = MR(tendon_solref_lim) + 2*id; solimp = MR(tendon_solimp_lim) + 5*id;
         dA = MR(tendon_invweight0)[id];

@@ -31,6 +31,7 @@ struct StepDims {
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)
   int nlimten;   // tendons with a length limit (fixed or site-to-site spatial)
+  int nlimball;  // limited ball joints (one dense limit row each, emitted after the tendon limits)
   int neq;       // active equality constraints (tendon, joint: 1 row; connect: 3; weld: 6)
   int neqrow;    // their rows
   int nprm;      // distinct contact-parameter tuples (margin, gap, friction, solref, solimp) over the pairs
@@ -103,6 +104,7 @@ struct StepDims {
   X(tendon_adr, d.ntendon) X(tendon_num, d.ntendon) X(wrap_dof, d.nwrap) X(wrap_qpos, d.nwrap) \
   X(wrap_site, d.nwrap)        /* site id of a spatial-tendon wrap, -1 for joint wraps */ \
   X(limten, d.nlimten)         /* the limited tendons */                       \
+  X(limball, d.nlimball)       /* the limited ball joints */                   \
   X(eq_type, d.neq) X(eq_obj1, d.neq) X(eq_obj2, d.neq)   /* mjtEq, tendon / joint / body ids (-1: none) */ \
   X(eq_rowadr, d.neq)          /* first constraint row of each equality (equality rows come first) */
 

@@ -138,10 +138,12 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     d.neqrow += et == DMC_EQ_CONNECT ? 3 : (et == DMC_EQ_WELD ? 6 : 1);
   }
   d.neq = (int)eq_src.size();
+  std::vector<int> limball;
   for (int j = 0; j < m.njnt; j++) {
-    if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) { *err = "ball joint limits are not implemented"; return false; }
+    if (m.jnt_type[j] == DMC_JNT_BALL && m.jnt_limited[j]) limball.push_back(j);
     if ((m.jnt_type[j] == DMC_JNT_BALL || m.jnt_type[j] == DMC_JNT_FREE) && m.jnt_stiffness[j] != 0) { *err = "free/ball joint springs are not implemented"; return false; }
   }
+  d.nlimball = (int)limball.size();
   // tree levels
   std::vector<int> depth(m.nbody, 0);
   int nlevel = 0;
@@ -257,7 +259,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   d.pgs = m.opt_solver == DMC_SOL_PGS ? 1 : 0;
   if (d.pgs) d.nslip = njmax;      // the dual solver keeps a residual entry and a row of AR for EVERY constraint row
   d.jfull = m.nv <= 16 ? 1 : 0;
-  d.njdense = d.jfull ? njmax : std::min(njmax, d.neqrow + 2 * d.nlimten);
+  d.njdense = d.jfull ? njmax : std::min(njmax, d.neqrow + 2 * d.nlimten + d.nlimball);
   // contact rows with a stored Jacobian: by default every contact slot may use its maximum number of rows; a
   // smaller pool (njcon > 0) trades LDS for a DMC_WARN_CNSTRFULL when the live contacts need more rows than that
   d.njcon = std::min(njmax, nconmax * maxrow_per_contact);
@@ -410,7 +412,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     mi[L.mi_wrap_dof + w] = site ? 0 : m.jnt_dofadr[m.wrap_objid[w]]; mi[L.mi_wrap_qpos + w] = site ? 0 : m.jnt_qposadr[m.wrap_objid[w]];
     mi[L.mi_wrap_site + w] = site ? m.wrap_objid[w] : -1;
   }
-  cpi(L.mi_limten, limten);
+  cpi(L.mi_limten, limten); cpi(L.mi_limball, limball);
   if (d.nlimten) {
     cpr(L.mr_tendon_range, m.tendon_range); cpr(L.mr_tendon_margin, m.tendon_margin); cpr(L.mr_tendon_solref_lim, m.tendon_solref_lim);
     cpr(L.mr_tendon_solimp_lim, m.tendon_solimp_lim);

@@ -6,7 +6,8 @@ _FREE, _BALL, _SLIDE, _HINGE = 0, 1, 2, 3
 
 
 def randomize_limited_and_rotational_joints(physics, random=None, env_mask=None):
-  """Bounded hinges/sliders ~ U(range); unbounded hinges ~ U(-pi, pi); free/ball
+  """Bounded hinges/sliders ~ U(range); unbounded hinges ~ U(-pi, pi); limited ball joints: a rotation about a
+  random axis by U(0, range max); free/ball
   quaternions random unit (the reference draws free-joint quaternions with
   `rand`, ball ones with `randn`; kept); free translations untouched.  With a
   batch, only environments selected by `env_mask` are re-drawn."""
@@ -23,7 +24,12 @@ def randomize_limited_and_rotational_joints(physics, random=None, env_mask=None)
         if t in (_HINGE, _SLIDE):
           qpos[e, a] = random.uniform(lo, hi)
         elif t == _BALL:
-          raise NotImplementedError('limited ball joints')
+          # random_limited_quaternion (randomizers.py:22-32): axis ~ normalised N(0, I), angle ~ U(0, range max)
+          axis = random.randn(3)
+          axis /= np.linalg.norm(axis)
+          angle = random.rand() * hi
+          qpos[e, a] = np.cos(0.5 * angle)
+          qpos[e, a + 1:a + 4] = np.sin(0.5 * angle) * axis
       elif t == _HINGE:
         qpos[e, a] = random.uniform(-np.pi, np.pi)
       elif t == _BALL:

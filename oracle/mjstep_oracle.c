@@ -1313,7 +1313,30 @@ static void make_constraint(const Model* m, Data* d) {
   if (!(m->opt_disableflags & DMC_DSBL_LIMIT)) for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j]) continue;
     int t = m->jnt_type[j];
-    if (t != DMC_JNT_SLIDE && t != DMC_JNT_HINGE) continue; /* ball limits not restated */
+    if (t == DMC_JNT_BALL) {
+      /* mj_instantiateLimit, ball: the rotation angle (mju_quat2Vel: axis = unit vec of the quaternion's vector part, angle
+       * = 2 atan2(|vec|, w) taken in (-pi, pi]; a negative angle flips the axis) against max(range); one row, J = -axis on
+       * the joint's three dofs */
+      const double* q = d->qpos + m->jnt_qposadr[j];
+      double qn = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+      double w = q[0]/qn, ax[3] = {q[1]/qn, q[2]/qn, q[3]/qn};
+      double sn = sqrt(ax[0]*ax[0] + ax[1]*ax[1] + ax[2]*ax[2]);
+      double angle = 2*atan2(sn, w);
+      if (angle > DMC_PI) angle -= 2*DMC_PI;
+      if (sn < MINVAL) { ax[0] = ax[1] = ax[2] = 0; angle = 0; } else for (int k = 0; k < 3; k++) ax[k] /= sn;
+      if (angle < 0) { angle = -angle; for (int k = 0; k < 3; k++) ax[k] = -ax[k]; }
+      double margin = m->jnt_margin[j];
+      double dist = mjMAX(m->jnt_range[2*j], m->jnt_range[2*j + 1]) - angle;
+      if (dist < margin) {
+        if (d->nefc >= m->njmax) { d->warning[DMC_WARN_CNSTRFULL]++; return; }
+        int r = d->nefc++;
+        memset(d->efc_J + (size_t)r*nv, 0, sizeof(double) * (size_t)nv);
+        for (int k = 0; k < 3; k++) d->efc_J[(size_t)r*nv + m->jnt_dofadr[j] + k] = -ax[k];
+        d->efc_pos[r] = dist; d->efc_margin[r] = margin; d->efc_type[r] = CT_LIMIT; d->efc_id[r] = j;
+      }
+      continue;
+    }
+    if (t != DMC_JNT_SLIDE && t != DMC_JNT_HINGE) continue; /* (free joints have no limits) */
     double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
     for (int side = -1; side <= 1; side += 2) {
       double dist = side * (m->jnt_range[2*j + (side + 1)/2] - value);
