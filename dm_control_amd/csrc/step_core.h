@@ -2264,7 +2264,7 @@ struct StepCore {
         const int jn = MI(dof_jntid)[id >> 1];
         solref = MRC(jnt_solref) + 2*jn; solimp = MRC(jnt_solimp) + 5*jn;
         dA = MR(dof_invweight0)[id >> 1];
-      } else if (type == EFC_TENDON_LIMIT && id >= L.d.ntendon) {      // a ball-joint limit (dense limit row of joint id - ntendon)
+      } else if (L.d.nlimball && type == EFC_TENDON_LIMIT && id >= L.d.ntendon) {      // a ball-joint limit (dense limit row of joint id - ntendon)
         const int jn = id - L.d.ntendon;
         solref = MRC(jnt_solref) + 2*jn; solimp = MRC(jnt_solimp) + 5*jn;
         dA = MR(dof_invweight0)[MI(jnt_dofadr)[jn]];
