@@ -659,6 +659,9 @@ struct StepCore {
   // Opaque copy of an env index: stops the compiler from forming HBM addresses long before
   // they are used and carrying them across the out-of-line stage calls (callee-saved VGPRs,
   // spilled to scratch once there are too many).
+  // the stash epoch of the launch, kept in a spare slot of the env's `misc` reals (bit-cast: every int32 survives a float / double slot)
+  DMC_DEV void set_epoch(int e) { if (sizeof(T) == 4) { float f; __builtin_memcpy(&f, &e, 4); S(misc)[MISC_EPOCH] = (T)f; } else S(misc)[MISC_EPOCH] = (T)e; }
+  DMC_DEV int get_epoch() const { if (sizeof(T) == 4) { const float f = (float)S(misc)[MISC_EPOCH]; int e; __builtin_memcpy(&e, &f, 4); return e; } return (int)S(misc)[MISC_EPOCH]; }
   DMC_DEV static int late(int env) {
 #ifndef DMC_HOST_EMU
     asm volatile("" : "+v"(env));
@@ -670,7 +673,7 @@ struct StepCore {
   DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
     env = late(env);
     const int* hi = io.stash_i + (size_t)env*(L.n_si + 4);
-    if (hi[0] != SI(imisc)[IM_EPOCH]) return false;      // group-uniform: never written, or written before the last host edit
+    if (hi[0] != get_epoch()) return false;      // group-uniform: never written, or written before the last host edit
     const T* hr = io.stash_r + (size_t)env*L.n_keep;
     FOR_LANES(i, L.n_keep) s[i] = hr[i];
     FOR_LANES(i, L.n_si) si[i] = hi[4 + i];
@@ -685,7 +688,7 @@ struct StepCore {
       FOR_LANES(i, L.n_keep) hr[i] = s[i];
       FOR_LANES(i, L.n_si) hi[4 + i] = si[i];
     }
-    if (lane == 0) hi[0] = valid ? SI(imisc)[IM_EPOCH] : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
+    if (lane == 0) hi[0] = valid ? get_epoch() : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
   }
   // ---- kinematic stash ------------------------------------------------------------------------------------------
   // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
@@ -697,7 +700,7 @@ struct StepCore {
   DMC_DEV int kin_count() const { return L.s_qM - L.s_xpos; }
   DMC_DEV bool load_kstash(const StepIO<T>& io, int env) {
     env = late(env);
-    if (io.kstash_i[env] != SI(imisc)[IM_EPOCH]) return false;
+    if (io.kstash_i[env] != get_epoch()) return false;
     const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
     const T* h = io.kstash + (size_t)env*(nq + nv + nk);
     int bad = 0;
@@ -716,7 +719,7 @@ struct StepCore {
     FOR_LANES(i, nq) h[i] = S(qpos)[i];
     FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
-    if (lane == 0) io.kstash_i[env] = SI(imisc)[IM_EPOCH];
+    if (lane == 0) io.kstash_i[env] = get_epoch();
   }
   // ---- launch-entry loads ------------------------------------------------------------------------------------------
   // Everything a launch reads from HBM before it can start -- the env's launch override, its state, the tag of its
@@ -5012,7 +5015,7 @@ struct StepCore {
   DMC_DEV void run_split(const StepIO<T>& io, int env, int mode, int outmask, const Entry& en) {
     const bool stash = io.stash_r != nullptr;
     bool have = false;
-    if (lane == 0) SI(imisc)[IM_EPOCH] = en.epoch;      // (kept in LDS, not in a register, for the whole launch)
+    if (lane == 0) set_epoch(en.epoch);      // (kept in LDS, not in a register, for the whole launch)
     DMC_WSYNC();
     if (mode == 5 && stash) have = load_stash(io, env);
     load_state(io, env, have, en);
@@ -5058,7 +5061,7 @@ struct StepCore {
   // en: what entry_issue / entry_commit left for this env and the launch's (mode, legacy)
   DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en) {
     const int launch_mode = mode;
-    if (lane == 0) SI(imisc)[IM_EPOCH] = en.epoch;      // (kept in LDS, not in a register, for the whole launch)
+    if (lane == 0) set_epoch(en.epoch);      // (kept in LDS, not in a register, for the whole launch)
     if (io.env_mode) {
       const int em = en.em;
       if (em == 2) return;

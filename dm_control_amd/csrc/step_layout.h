@@ -222,14 +222,13 @@ struct StepDims {
   X(ns_row, d.nslip)     /* noslip: constraint row of each friction dimension */ \
   X(ns_blk, d.nslip ? 48 : 0)  /* noslip: per block (<= 16 blocks) start | size << 8 | level << 16 | coupled << 24, tree mask lo, hi */ \
   X(prof, DMC_PROF_SLOTS)   /* profiling builds: cycle counters per phase + the last time stamp */ \
-  X(imisc, 17)
+  X(imisc, 16)
 
 // indices into the `misc` / `imisc` scratch
-enum { MISC_TIME = 0 };
+enum { MISC_TIME = 0, MISC_EPOCH = 1 /* the stash epoch the launch started in (Entry::epoch), bit-cast: the tags it writes carry this one */ };
 enum { IM_NCON = 0, IM_NEFC = 1, IM_ITER = 2, IM_WARN = 3 /* ..11: DMC_NWARNING counters */,
        IM_ROW_S0 = 12, IM_ROW_TL0 = 13, IM_ROW_C0 = 14 /* first simple / tendon-limit / contact row */,
-       IM_ENV = 15 /* the environment's index in the batch (per-env model deltas) */,
-       IM_EPOCH = 16 /* the stash epoch the launch started in (Entry::epoch): the tags it writes carry this one */ };
+       IM_ENV = 15 /* the environment's index in the batch (per-env model deltas) */ };
 
 // act_flags bits
 enum { ACTF_CTRLLIMITED = 1, ACTF_FORCELIMITED = 2, ACTF_GAIN_AFFINE = 4, ACTF_BIAS_AFFINE = 8,
