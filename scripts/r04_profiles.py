@@ -4,14 +4,16 @@ device environments, soak, wave tails, the host-buffer boundary, logs."""
 import csv, glob, json, os, shutil, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
+PRE = os.environ.get('OUT_PREFIX', 'r04')      # a second session of the round is filed under another prefix (r04b)
+OUT = lambda f: os.path.join(P, f.replace('r04_', PRE + '_', 1))
 for f in ['r04_bench_cfg%d.json' % c for c in (2, 3, 4, 5)] + ['r04_bench_driver_cmd.json', 'r04_composer_runs.json', 'r04_soak_all_tasks.json',
          'r04_pcie_probe_cfg2.json', 'r04_gputests.log', 'r04_reference_on_hip.log'] + ['r04_wave_tail_cfg%d.json' % c for c in (2, 3, 4, 5)]:
   if os.path.exists(os.path.join(G, f)):
-    shutil.copy(os.path.join(G, f), os.path.join(P, f))
+    shutil.copy(os.path.join(G, f), OUT(f))
 for c in (2, 3, 4, 5):
   stats = glob.glob(os.path.join(G, 'r04_prof_cfg%d' % c, '**', '*kernel_stats.csv'), recursive=True)
   if stats:
-    shutil.copy(stats[0], os.path.join(P, 'r04_rocprof_kernel_stats_cfg%d.csv' % c))
+    shutil.copy(stats[0], OUT('r04_rocprof_kernel_stats_cfg%d.csv' % c))
   rows = []
   for f in glob.glob(os.path.join(G, 'r04_prof_cfg%d' % c, '**', '*kernel_trace.csv'), recursive=True):
     rows += [r for r in csv.DictReader(open(f)) if 'step_kernel' in r['Kernel_Name']]
@@ -37,5 +39,5 @@ for c in (2, 3, 4, 5):
     idx = [i for i, d in enumerate(dur) if d < 3 * med]
     timed = [dur[i] for i in idx[-K:]] if len(idx) >= K else single
     out['timed_launches'] = dict(n=len(timed), avg_us=sum(timed) / len(timed), median_us=statistics.median(timed), max_us=max(timed))
-  json.dump(out, open(os.path.join(P, 'r04_kernel_stats_cfg%d.json' % c), 'w'), indent=1)
+  json.dump(out, open(OUT('r04_kernel_stats_cfg%d.json' % c), 'w'), indent=1)
   print('cfg', c, out.get('timed_launches'), out['bench_line'])
