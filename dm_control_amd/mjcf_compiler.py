@@ -865,8 +865,8 @@ class _Compiler:
     self._parse_compiler_option(m)
     self._parse_defaults()
     wbs = self.root.findall('worldbody')
-    if not wbs:
-      raise MjcfError('missing <worldbody>')
+    if not wbs:      # MuJoCo compiles a model without one to the bare world body
+      wbs = [ET.SubElement(self.root, 'worldbody')]
     # merge multiple worldbody sections
     wb = wbs[0]
     for extra in wbs[1:]:
@@ -1416,41 +1416,11 @@ class _Compiler:
     m.names['sensor'] = names
 
   def _pairs(self, m):
-    """Static candidate geom pairs = MuJoCo's body-pair/geom-pair filters that
-    do not depend on the state: same/welded body,
-    parent-child (filterparent), contype/conaffinity, <exclude>."""
-    excl = set()
+    m.exclude_bodies = []
     for b1, b2 in self.excludes:
       i1, i2 = m.names['body'].index(b1), m.names['body'].index(b2)
-      excl.add((min(i1, i2), max(i1, i2)))
-    filterparent = not (m.opt.disableflags & C['DMC_DSBL_FILTERPARENT'])
-    weld = m.body_weldid
-    pairs = []
-    for b1 in range(m.nbody):
-      for b2 in range(b1 + 1, m.nbody):
-        if not m.body_geomnum[b1] or not m.body_geomnum[b2]:
-          continue
-        if (b1, b2) in excl:
-          continue
-        w1, w2 = weld[b1], weld[b2]
-        if w1 == w2:
-          continue
-        wp1 = weld[m.body_parentid[w1]]
-        wp2 = weld[m.body_parentid[w2]]
-        if filterparent and w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
-          continue
-        for g1 in range(m.body_geomadr[b1], m.body_geomadr[b1] + m.body_geomnum[b1]):
-          for g2 in range(m.body_geomadr[b2], m.body_geomadr[b2] + m.body_geomnum[b2]):
-            if not ((m.geom_contype[g1] & m.geom_conaffinity[g2]) or
-                    (m.geom_contype[g2] & m.geom_conaffinity[g1])):
-              continue
-            t1, t2 = m.geom_type[g1], m.geom_type[g2]
-            if t1 == _GEOM['plane'] and t2 == _GEOM['plane']:
-              continue
-            pairs.append((g2, g1) if t1 > t2 else (g1, g2))
-    m.npair = len(pairs)
-    m.pair_geom1 = np.array([p[0] for p in pairs], dtype=np.int64)
-    m.pair_geom2 = np.array([p[1] for p in pairs], dtype=np.int64)
+      m.exclude_bodies.append((min(i1, i2), max(i1, i2)))
+    candidate_pairs(m)
 
   def _keyframes(self, m):
     nkey = len(self.keys)
@@ -1653,6 +1623,42 @@ def _robust_inverse(mat):
 
 _COMPILE_CACHE = collections.OrderedDict()
 _COMPILE_CACHE_SIZE = 16
+
+
+def candidate_pairs(m):
+  """Static candidate geom pairs = MuJoCo's body-pair/geom-pair filters that
+  do not depend on the state: same/welded body,
+  parent-child (filterparent), contype/conaffinity, <exclude>.  Writes m.npair / pair_geom1 / pair_geom2 (also called
+  by the Physics facade when a task rewrites geom_contype / geom_conaffinity at run time)."""
+  excl = set(getattr(m, 'exclude_bodies', ()))
+  filterparent = not (m.opt.disableflags & C['DMC_DSBL_FILTERPARENT'])
+  weld = m.body_weldid
+  pairs = []
+  for b1 in range(m.nbody):
+    for b2 in range(b1 + 1, m.nbody):
+      if not m.body_geomnum[b1] or not m.body_geomnum[b2]:
+        continue
+      if (b1, b2) in excl:
+        continue
+      w1, w2 = weld[b1], weld[b2]
+      if w1 == w2:
+        continue
+      wp1 = weld[m.body_parentid[w1]]
+      wp2 = weld[m.body_parentid[w2]]
+      if filterparent and w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
+        continue
+      for g1 in range(m.body_geomadr[b1], m.body_geomadr[b1] + m.body_geomnum[b1]):
+        for g2 in range(m.body_geomadr[b2], m.body_geomadr[b2] + m.body_geomnum[b2]):
+          if not ((m.geom_contype[g1] & m.geom_conaffinity[g2]) or
+                  (m.geom_contype[g2] & m.geom_conaffinity[g1])):
+            continue
+          t1, t2 = m.geom_type[g1], m.geom_type[g2]
+          if t1 == _GEOM['plane'] and t2 == _GEOM['plane']:
+            continue
+          pairs.append((g2, g1) if t1 > t2 else (g1, g2))
+  m.npair = len(pairs)
+  m.pair_geom1 = np.array([p[0] for p in pairs], dtype=np.int64)
+  m.pair_geom2 = np.array([p[1] for p in pairs], dtype=np.int64)
 
 
 def compile_xml(xml_string, assets=None, cache=True):

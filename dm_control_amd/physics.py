@@ -43,6 +43,10 @@ _MUTABLE_MODEL_FIELDS = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margi
 # suite/swimmer.py light_pos, suite/base.py:104-112 mat_rgba); they never reach the device
 _HOST_ONLY_MODEL_FIELDS = ('geom_rgba', 'site_rgba', 'mat_rgba', 'light_pos', 'light_dir',
                            'body_sameframe', 'body_simple', 'geom_sameframe', 'site_sameframe')
+# the collision filter bits: a write changes WHICH geom pairs the device tests -- a table that is laid out at batch creation
+# -- so the batch is rebuilt from the edited model before the next launch (composer/initializers/prop_initializer.py:138-160
+# switches props' contacts off while it places them, then back on); see Physics._rebuild_batch
+_STRUCTURAL_MODEL_FIELDS = ('geom_contype', 'geom_conaffinity')
 _INVALID_PHYSICS_STATE = ('Physics state is invalid. Warning(s) raised: {warning_names}')
 
 _INPUT_FIELDS = ('qpos', 'qvel', 'act', 'ctrl', 'qacc_warmstart', 'qfrc_applied', 'xfrc_applied', 'time', 'mocap_pos',
@@ -276,6 +280,10 @@ class _Data:
     self._written.clear()
     if not p.view_semantics:
       self._shadow.clear()
+    if p.__dict__.pop('_needs_forward', False):      # a batch rebuilt by _push_model: see Physics._rebuild_batch
+      warm = p.batch.get('qacc_warmstart')
+      p.batch.forward(True)
+      p.batch.set('qacc_warmstart', warm)
 
   def _invalidate(self):
     """After a launch every handed-out array is dropped: the next access fetches a fresh one.  (The reference's arrays
@@ -555,13 +563,14 @@ class Physics(control.Physics):
       for name, value in vars(model).items():
         if not isinstance(value, np.ndarray):
           continue
-        if name in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS:
+        if name in _MUTABLE_MODEL_FIELDS + _HOST_ONLY_MODEL_FIELDS + _STRUCTURAL_MODEL_FIELDS:
           setattr(self.model, name, np.array(value))      # this Physics' own copy: its edits must not reach another Physics built from the same Model
         else:
           view = value.view()
           view.setflags(write=False)
           setattr(self.model, name, view)
     self._opt_pushed = self._opt_snapshot()      # (the batch was created from these options)
+    self._filter_pushed = self._filter_snapshot()
     self._reload_from_data(self.data)
     try:
       self.after_reset()
@@ -603,7 +612,46 @@ class Physics(control.Physics):
     return tuple(int(getattr(o, n)) for n in self._OPT_INTS) + tuple(float(getattr(o, n)) for n in self._OPT_REALS) + \
         tuple(float(g) for g in o.gravity)
 
+  def _filter_snapshot(self):
+    return np.concatenate([np.asarray(getattr(self.model, f), dtype=np.int64).ravel() for f in _STRUCTURAL_MODEL_FIELDS])
+
+  def _rebuild_batch(self):
+    """A new device batch for the model as it now stands (its candidate pair list recomputed), holding the input state of
+    the old one.  mj_step / mj_forward would simply see the new filter bits at their next collision pass; here the pair
+    table is part of the batch's layout.  The derived arrays of the new batch are brought up by a forward pass at the end
+    of the pending upload (Data._upload), with the solver warm start restored as copy() does -- so a legacy-order step
+    (step2 first) that follows finds contact forces of the NEW filter where MuJoCo's would still be the old one's.  The
+    warning counters restart with the batch."""
+    model = self.model
+    mjcf_compiler.candidate_pairs(model)
+    for name in ('pair_geom1', 'pair_geom2'):
+      getattr(model, name).setflags(write=False)
+    kw = {k: v for k, v in self._batch_kwargs.items() if k != 'device_id'}
+    old = self.batch
+    kw.setdefault('nconmax', old.info()['nconmax'])      # (the contact arrays handed out keep their shape)
+    try:
+      batch = self._create_batch(model, self._batch_kwargs.get('device_id', 0), old.precision, kw)
+    except Exception:      # pylint: disable=broad-except  (more pairs than before: that cap may no longer fit)
+      del kw['nconmax']
+      batch = self._create_batch(model, self._batch_kwargs.get('device_id', 0), old.precision, kw)
+    for name in _INPUT_FIELDS:
+      a = np.asarray(old.get(name), dtype=np.float64).reshape(self.batch_size, -1)
+      if name == 'xfrc_applied' and not a.any():
+        continue
+      batch.set(name, a)
+    self.batch = batch      # (created from the model's current arrays and options: nothing else to re-send)
+    self._opt_pushed = self._opt_snapshot()
+    for f in self._model_pushed:
+      self._model_pushed[f] = np.array(getattr(model, f), dtype=np.float64, copy=True)
+    self._model_flat = None
+    self._needs_forward = True
+    self._warnings_seen[:] = 0
+
   def _push_model(self):
+    filt = self._filter_snapshot()
+    if not np.array_equal(filt, self._filter_pushed):
+      self._filter_pushed = filt
+      self._rebuild_batch()
     # mjOption members tasks change at run time (engine.py:326-333 / entities/props/duplo/utils.py:68 model.disable(...),
     # opt.timestep, opt.gravity): sent to the device when they differ from what it holds
     snap = self._opt_snapshot()

@@ -141,6 +141,7 @@ def _absl_adapter():
 def _mulquat(res, a, b):
   w1, x1, y1, z1 = a
   w2, x2, y2, z2 = b
+  res = np.asarray(res)      # (the C function writes the buffer itself: no ndarray subclass hooks)
   res[:] = [w1*w2 - x1*x2 - y1*y2 - z1*z2, w1*x2 + x1*w2 + y1*z2 - z1*y2,
             w1*y2 - x1*z2 + y1*w2 + z1*x2, w1*z2 + x1*y2 - y1*x2 + z1*w2]
 
@@ -150,7 +151,17 @@ def _rotvecquat(res, vec, q):
   R = np.array([[1 - 2*(y*y + z*z), 2*(x*y - w*z), 2*(x*z + w*y)],
                 [2*(x*y + w*z), 1 - 2*(x*x + z*z), 2*(y*z - w*x)],
                 [2*(x*z - w*y), 2*(y*z + w*x), 1 - 2*(x*x + y*y)]])
-  res[:] = R @ np.asarray(vec, float)
+  np.asarray(res)[:] = R @ np.asarray(vec, float)
+
+
+def _quat2vel(res, quat, dt):
+  """mju_quat2Vel: the angular velocity that takes the identity to `quat` in `dt` (axis * angle / dt, angle in (-pi, pi])."""
+  axis = np.asarray(quat[1:4], float)
+  s = np.linalg.norm(axis)
+  speed = 2.0 * np.arctan2(s, quat[0])
+  if speed > np.pi:
+    speed -= 2.0 * np.pi
+  np.asarray(res)[:] = (axis / s if s > 0 else axis) * speed / dt
 
 
 def _map_structure(fn, *structs):
@@ -212,7 +223,7 @@ def load():
   wrapper.MjvOption = MjvOption
   _exec('dm_control.mujoco.wrapper.util', os.path.join(REF, 'mujoco/wrapper/util.py'))
   mjb = _stub('dm_control.mujoco.wrapper.mjbindings')
-  mjlib = types.SimpleNamespace(mju_mulQuat=_mulquat, mju_rotVecQuat=_rotvecquat)
+  mjlib = types.SimpleNamespace(mju_mulQuat=_mulquat, mju_rotVecQuat=_rotvecquat, mju_quat2Vel=_quat2vel)
   mjb.mjlib = mjlib
   enums = types.ModuleType('dm_control.mujoco.wrapper.mjbindings.enums')
   sys.modules[enums.__name__] = enums
@@ -317,14 +328,9 @@ def cmu2019_go_to_target():
   return loco.tasks.go_to_target.GoToTarget(walker=walker, arena=arena, physics_timestep=0.005, control_timestep=0.03)
 
 
-def soccer_2v2_boxhead(randomizer=None):
-  """locomotion/soccer/__init__.py:92-148 `load(team_size=2, walker_type=WalkerType.BOXHEAD)` up to the
-  composer.Environment call (the package __init__ also imports the Ant / rodent / mocap-initialised humanoid
-  walkers, which need h5py and the engine; the BoxHead path does not): SoccerBall(), four BoxHead players
-  home0 / away0 / home1 / away1 (`_make_players`, :73-84), RandomizedPitch(min_size=(32, 24), max_size=(48, 36),
-  keep_aspect_ratio=False, field_box=False, goal_size=None), Task(disable_walker_contacts=False).  `randomizer`
-  (pitch.py:624: a callable returning the size ratio in [0, 1]; default Uniform) lets a caller fix the pitch size.  Returns
-  the task."""
+def _soccer_modules():
+  """`dm_control.locomotion.soccer` with the names its __init__ (:21-44) re-exports, minus the Humanoid / Ant / mocap
+  walkers (h5py and the mocap data are absent here) and the render-only camera.py."""
   loco = _locomotion_modules()
   if 'dm_control.entities' not in sys.modules:
     _stub('dm_control.entities', os.path.join(REF, 'entities'))
@@ -334,9 +340,31 @@ def soccer_2v2_boxhead(randomizer=None):
     props.PositionDetector = props.position_detector.PositionDetector
     props.Primitive = props.primitive.Primitive
   if 'dm_control.locomotion.soccer' not in sys.modules:
-    _stub('dm_control.locomotion.soccer', os.path.join(REF, 'locomotion/soccer'))
+    pkg = _stub('dm_control.locomotion.soccer', os.path.join(REF, 'locomotion/soccer'))
     for n in ('team', 'initializers', 'observables', 'soccer_ball', 'pitch', 'boxhead', 'task'):
       _exec('dm_control.locomotion.soccer.' + n, os.path.join(REF, 'locomotion/soccer', n + '.py'))
+    _stub('dm_control.locomotion.soccer.camera')      # render-only (engine.MovableCamera); the name its test file imports
+    for mod, names in (('boxhead', ('BoxHead',)), ('initializers', ('Initializer', 'UniformInitializer')),
+                       ('observables', ('CoreObservablesAdder', 'InterceptionObservablesAdder', 'MultiObservablesAdder',
+                                        'ObservablesAdder')),
+                       ('pitch', ('MINI_FOOTBALL_GOAL_SIZE', 'MINI_FOOTBALL_MAX_AREA_PER_HUMANOID',
+                                  'MINI_FOOTBALL_MIN_AREA_PER_HUMANOID', 'Pitch', 'RandomizedPitch')),
+                       ('soccer_ball', ('regulation_soccer_ball', 'SoccerBall')), ('task', ('MultiturnTask', 'Task')),
+                       ('team', ('Player', 'RGBA_BLUE', 'RGBA_RED', 'Team'))):
+      for name in names:
+        setattr(pkg, name, getattr(getattr(pkg, mod), name))
+  return loco
+
+
+def soccer_2v2_boxhead(randomizer=None):
+  """locomotion/soccer/__init__.py:92-148 `load(team_size=2, walker_type=WalkerType.BOXHEAD)` up to the
+  composer.Environment call (the package __init__ also imports the Ant / rodent / mocap-initialised humanoid
+  walkers, which need h5py and the engine; the BoxHead path does not): SoccerBall(), four BoxHead players
+  home0 / away0 / home1 / away1 (`_make_players`, :73-84), RandomizedPitch(min_size=(32, 24), max_size=(48, 36),
+  keep_aspect_ratio=False, field_box=False, goal_size=None), Task(disable_walker_contacts=False).  `randomizer`
+  (pitch.py:624: a callable returning the size ratio in [0, 1]; default Uniform) lets a caller fix the pitch size.  Returns
+  the task."""
+  loco = _soccer_modules()
   s = loco.soccer
   players = []
   for i in range(2):

@@ -75,6 +75,20 @@ class _TestCase(unittest.TestCase, metaclass=_ParamMeta):
         return True
     return Ctx()
 
+  def assertSameStructure(self, a, b, aname='a', bname='b', msg=None):
+    def walk(x, y, path):
+      if isinstance(x, dict) and isinstance(y, dict):
+        self.assertEqual(set(x), set(y), '%s: keys differ' % path)
+        for k in x:
+          walk(x[k], y[k], '%s[%r]' % (path, k))
+      elif isinstance(x, (list, tuple)) and isinstance(y, (list, tuple)):
+        self.assertEqual(len(x), len(y), '%s: lengths differ' % path)
+        for i, (u, v) in enumerate(zip(x, y)):
+          walk(u, v, '%s[%d]' % (path, i))
+      else:
+        self.assertEqual(x, y, msg or '%s differs' % path)
+    walk(a, b, aname)
+
   def assertBetween(self, value, lo, hi, msg=None):
     self.assertTrue(lo <= value <= hi, msg or '%r not in [%r, %r]' % (value, lo, hi))
 
@@ -126,6 +140,8 @@ def _install(modules):
   from dm_control_amd.envs import dm_env_api
   put('dm_env', dm_env_api)
   put('dm_env.specs', dm_env_api.specs)
+  if modules is None:      # the caller has a whole `dm_control` tree in sys.modules already (reference_pymjcf.bind_engine)
+    return saved
   root = types.ModuleType('dm_control')
   root.__path__ = []
   put('dm_control', root)
@@ -153,7 +169,8 @@ def _restore(saved):
 
 
 def run(test_file, modules, skip=()):
-  """Executes REF/<test_file> with `modules` ({'dm_control.rl.control': module, ...}) standing in for the reference's
+  """Executes REF/<test_file> with `modules` ({'dm_control.rl.control': module, ...}; None = leave the `dm_control`
+  already in sys.modules alone) standing in for the reference's
   and runs every TestCase in it (`skip`: 'Class.method' prefixes that need something outside this backend's scope).
   Returns (unittest result, text report)."""
   saved = _install(modules)

@@ -282,3 +282,54 @@ def test_facade_fetches_the_fields_a_loop_reads_in_one_round_trip(oracle_backend
     np.testing.assert_array_equal(a[2], q.batch.get('sensordata'))
     np.testing.assert_array_equal(a[0], q.batch.get('qpos'))
   p.free(); q.free()
+
+
+# ---- collision filter bits rewritten at run time (composer/initializers/prop_initializer.py:138-160) ---------------------
+_FILTER_XML = """<mujoco><option timestep='0.002'/><worldbody>
+<geom name='floor' type='plane' size='2 2 .1'/>
+<body name='a' pos='0 0 .1'><freejoint/><geom name='ga' type='sphere' size='.1'/></body>
+<body name='b' pos='.5 0 .1'><freejoint/><geom name='gb' type='sphere' size='.1'/></body>
+<body name='c' pos='.5 0 .32'><freejoint/><geom name='gc' type='box' size='.1 .1 .1'/></body>
+</worldbody></mujoco>"""
+
+
+def check_collision_filter_edits(make, atol=0.0):
+  """`make(xml)` -> Physics.  Switching a geom's contype / conaffinity off at run time removes its pairs from the next
+  launch on (the device batch is rebuilt; state, time and run-time model edits carry over), and the continuation equals
+  that of a Physics compiled with those bits from the start and put in the same state; switching them back restores the
+  pairs."""
+  full = (1 << 13) - 1      # mjSTATE_INTEGRATION: time, qpos, qvel, act, warm start and every user input
+  p = make(_FILTER_XML)
+  p.model.dof_damping[:] = 0.05      # a run-time edit the rebuilt batch must keep
+  p.step(40)
+  assert int(np.asarray(p.data.ncon).ravel()[0]) >= 3      # a on floor, b on floor, c on b
+  t0, state, warm = p.data.time, p.get_state(full).copy(), np.array(p.data.qacc_warmstart)
+  ia = p.model.name2id('ga', 'geom')
+  p.model.geom_contype[ia] = 0
+  p.named.model.geom_conaffinity['ga'] = 0
+  p.step(5)
+  assert abs(p.data.time - (t0 + 5 * 0.002)) < 1e-12
+  q = make(_FILTER_XML.replace("name='ga'", "name='ga' contype='0' conaffinity='0'"))
+  q.model.dof_damping[:] = 0.05
+  q.set_state(state, full)
+  q.forward()
+  q.data.qacc_warmstart = warm
+  q.step(5)
+  np.testing.assert_allclose(np.asarray(p.data.qpos), np.asarray(q.data.qpos), rtol=0, atol=atol)
+  np.testing.assert_allclose(np.asarray(p.data.qvel), np.asarray(q.data.qvel), rtol=0, atol=atol)
+  z = float(np.asarray(p.named.data.xpos['a'])[2])
+  p.step(200)
+  assert float(np.asarray(p.named.data.xpos['a'])[2]) < z - 0.05      # a falls through the floor; b and c stay
+  assert float(np.asarray(p.named.data.xpos['b'])[2]) > 0.09 and float(np.asarray(p.named.data.xpos['c'])[2]) > 0.29
+  p.model.geom_contype[ia] = 1
+  p.model.geom_conaffinity[ia] = 1
+  with p.reset_context():
+    p.data.qpos[:3] = [0, 0, 0.1]
+    p.data.qvel[:6] = 0
+  p.step(50)
+  assert float(np.asarray(p.named.data.xpos['a'])[2]) > 0.09      # rests on the floor again
+  assert int(np.asarray(p.data.ncon).ravel()[0]) >= 3
+
+
+def test_collision_filter_bits_are_writable_and_rebuild_the_batch(oracle_backend):
+  check_collision_filter_edits(physics_lib.Physics.from_xml_string)

@@ -910,3 +910,12 @@ def test_torch_env_draws_a_fresh_start_state_every_episode(domain, task):
   assert bool((env.qpos[:, mask] != before_q[:, mask]).any(dim=0).all())
   assert int(env._draw.min()) >= 2 and int(env._draw[mask].min()) >= 3
   env.close()
+
+
+def test_collision_filter_bits_rewritten_at_run_time_on_the_device():
+  """geom_contype / geom_conaffinity writes (composer/initializers/prop_initializer.py:138-160): the facade rebuilds the
+  device batch from the edited model and carries the state over; the continuation equals that of a model compiled with
+  the bits from the start (tests/test_facade_cpu.py holds the scenario)."""
+  from test_facade_cpu import check_collision_filter_edits
+  from dm_control_amd import physics as pl
+  check_collision_filter_edits(pl.Physics.from_xml_string, atol=1e-12)
