@@ -83,7 +83,6 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   if (d.na && m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_IMPLICITFAST) { *err = "actuator dynamics are only implemented with the Euler and implicitfast integrators"; return false; }
   if (m.nv > 64) { *err = "kernel supports nv <= 64"; return false; }
   if (m.ngeom > 65535) { *err = "kernel supports ngeom <= 65535"; return false; }
-  if (m.nv < 1) { *err = "model has no degrees of freedom"; return false; }
   const bool elliptic = m.opt_cone == DMC_CONE_ELLIPTIC;
   if (m.opt_integrator != DMC_INT_EULER && m.opt_integrator != DMC_INT_RK4 && m.opt_integrator != DMC_INT_IMPLICITFAST) { *err = "only the Euler, RK4 and implicitfast integrators are implemented in the HIP path"; return false; }
   if (m.opt_integrator == DMC_INT_IMPLICITFAST) {

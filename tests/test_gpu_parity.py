@@ -1084,3 +1084,30 @@ def test_optional_launch_features_on_a_small_specialised_model(cheetah):
       np.testing.assert_allclose(b.get(n), a.get(n), rtol=0, atol=2e-4 * max(1.0, np.abs(a.get(n)).max()), err_msg=n)
     np.testing.assert_allclose(probe[:3].cpu().numpy().transpose(0, 2, 1), np.stack(trace), rtol=0, atol=1e-5)
   a.close(); b.close()
+
+
+_STATIC_WORLD = """<mujoco><worldbody><geom name='f' type='plane' size='1 1 .1'/>
+<body name='post' pos='0 0 1' euler='0 30 0'><geom type='sphere' size='.1'/><site name='s' pos='.1 0 0'/></body></worldbody>
+<sensor><framepos objtype='site' objname='s'/><framezaxis objtype='site' objname='s'/></sensor></mujoco>"""
+
+
+@pytest.mark.parametrize('xml', ['<mujoco/>', _STATIC_WORLD], ids=['empty', 'static_world'])
+@pytest.mark.parametrize('precision', [64, 32])
+def test_models_without_degrees_of_freedom_step_on_the_device(xml, precision):
+  """MuJoCo steps a model with nv = 0 (the reference's composer tests build such arenas: composer/environment_test.py):
+  time advances, the poses and position sensors are evaluated, nothing else moves."""
+  from oracle.oracle import OraclePhysics
+  m = mc.compile_xml(xml)
+  assert m.nv == 0
+  b = _batch(m, 3, precision=precision)
+  b.forward(False)
+  b.step(4)
+  o = OraclePhysics(m)
+  o.forward()
+  o.step(4)
+  np.testing.assert_allclose(b.get('time').ravel(), [o.time] * 3, rtol=0, atol=1e-12)
+  assert not b.get('warning').any() and not b.get('ncon').any()
+  tol = 1e-12 if precision == 64 else 1e-6
+  np.testing.assert_allclose(b.get('xpos')[0], np.asarray(o.xpos).ravel(), rtol=0, atol=tol)
+  if m.nsensordata:
+    np.testing.assert_allclose(b.get('sensordata')[0], np.asarray(o.sensordata).ravel(), rtol=0, atol=tol)

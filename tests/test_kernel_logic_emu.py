@@ -731,3 +731,22 @@ def test_step_with_forward_after_equals_step_then_forward(asset, nsub):
     for name in ('qpos', 'qvel', 'qacc', 'qacc_warmstart', 'sensordata', 'xpos', 'actuator_force'):
       np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg='%s step %d' % (name, t))
   assert a.ncon[0] > 0 or asset == 'cmu_2019_position_floor'
+
+
+def test_models_without_degrees_of_freedom():
+  """nv = 0 (an arena with nothing in it, a static world): the kernel core steps it -- time, poses, position sensors."""
+  for xml in ('<mujoco/>', "<mujoco><worldbody><body name='p' pos='0 0 1'><geom type='sphere' size='.1'/><site name='s' pos='.1 0 0'/>"
+              "</body></worldbody><sensor><framepos objtype='site' objname='s'/></sensor></mujoco>"):
+    m = mc.compile_xml(xml)
+    assert m.nv == 0
+    o = OraclePhysics(m)
+    o.forward()
+    o.step(3)
+    for prec in (64, 32):
+      e = EmuPhysics(m, prec=prec)
+      e.forward()
+      e.step(3)
+      assert abs(float(np.asarray(e.time).ravel()[0]) - o.time) < 1e-12
+      np.testing.assert_allclose(np.asarray(e.xpos).ravel(), np.asarray(o.xpos).ravel(), atol=1e-6)
+      if m.nsensordata:
+        np.testing.assert_allclose(np.asarray(e.sensordata).ravel(), np.asarray(o.sensordata).ravel(), atol=1e-6)
