@@ -799,17 +799,16 @@ class _Compiler:
           limited = 'range' in a
         if e.tag == 'spatial':
           # Spatial tendons: straight segments through sites.  A force-free one only draws a line
-          # (suite/lqr.py:174-180) and is skipped; a length limit (suite/ball_in_cup.xml) is supported.
+          # (suite/lqr.py:174-180) but keeps its row in the model (ntendon, names, data.ten_length); a length limit
+          # (suite/ball_in_cup.xml) is supported.
           if not all(w.tag == 'site' for w in e) or len(e) < 2:
             raise MjcfError('spatial tendon %r: only site-to-site paths are supported' % a.get('name'))
           if any(float(a.get(k, 0)) != 0 for k in ('stiffness', 'damping', 'frictionloss')):
             raise MjcfError('spatial tendon %r: springs / dampers / friction are not supported' % a.get('name'))
           if any(act.get('tendon') == a.get('name') for act in self.actuators):
             raise MjcfError('spatial tendon %r: actuator transmissions are not supported' % a.get('name'))
-          if not limited:
-            continue
           self.tendons.append(dict(name=a.get('name'), spatial=True, wraps=[(w.attrib['site'], 1.0) for w in e],
-                                   stiffness=0.0, damping=0.0, limited=True, attrs=a))
+                                   stiffness=0.0, damping=0.0, limited=limited, attrs=a))
           continue
         if float(a.get('frictionloss', 0)) != 0:
           raise MjcfError('tendon %r: frictionloss is not supported' % a.get('name'))

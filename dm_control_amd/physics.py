@@ -66,6 +66,7 @@ _FIELD_AXES = {
     'subtree_com': ('body', 3), 'geom_xpos': ('geom', 3), 'geom_xmat': ('geom', 9),
     'site_xpos': ('site', 3), 'site_xmat': ('site', 9),
     'xanchor': ('joint', 3), 'xaxis': ('joint', 3),      # derived on the host (_Data._joint_frames)
+    'ten_length': ('tendon', None), 'ten_velocity': ('tendon', None),      # derived on the host (_Data._tendons)
     'cvel': ('body', 6),      # com-based body velocities (rotational, translational): soccer/observables.py:278 reads them
 }
 _COLS = {3: ['x', 'y', 'z'], 4: ['qw', 'qx', 'qy', 'qz'], 6: ['fx', 'fy', 'fz', 'tx', 'ty', 'tz'],
@@ -156,8 +157,46 @@ class _Data:
             pos = anchor[e, j] - C.quat_to_mat(quat) @ m.jnt_pos[j]
     return anchor, axis
 
+  def _tendons(self):
+    """mjData.ten_length / ten_velocity (mj_tendon, mj_fwdVelocity: `ten_velocity = ten_J qvel`) from the device's state
+    as of the last launch -- the kernel re-derives the few tendon lengths where it needs them and stores none.  Fixed
+    tendons: the coefficient-weighted sum of joint coordinates / velocities; site-to-site spatial tendons: the segment
+    lengths, and their rates from the sites' velocities (com-based `cvel` of the body, moved to the site)."""
+    p, m = self._p, self._p.model
+    B, nt = p.batch_size, m.ntendon
+    length, velocity = np.zeros((B, nt)), np.zeros((B, nt))
+    get = lambda n, *shape: np.asarray(p.batch.get(n), dtype=np.float64).reshape((B,) + shape)
+    qpos, qvel = get('qpos', m.nq), get('qvel', m.nv)
+    spatial = [t for t in range(nt) if m.tendon_num[t] and m.wrap_type[m.tendon_adr[t]] != mjcf_compiler.C['DMC_WRAP_JOINT']]
+    if spatial:
+      sx, cvel, com = get('site_xpos', m.nsite, 3), get('cvel', m.nbody, 6), get('subtree_com', m.nbody, 3)
+    for t in range(nt):
+      w0, wn = int(m.tendon_adr[t]), int(m.tendon_num[t])
+      if t not in spatial:
+        for w in range(w0, w0 + wn):
+          j = int(m.wrap_objid[w])
+          length[:, t] += m.wrap_prm[w] * qpos[:, m.jnt_qposadr[j]]
+          velocity[:, t] += m.wrap_prm[w] * qvel[:, m.jnt_dofadr[j]]
+        continue
+      def point(w):
+        sid = int(m.wrap_objid[w])
+        b = int(m.site_bodyid[sid])
+        pos = sx[:, sid]
+        return pos, cvel[:, b, 3:] + np.cross(cvel[:, b, :3], pos - com[:, m.body_rootid[b]])
+      for w in range(w0, w0 + wn - 1):
+        (p0, v0), (p1, v1) = point(w), point(w + 1)
+        dif = p1 - p0
+        n = np.linalg.norm(dif, axis=-1)
+        length[:, t] += n
+        ok = n > mjcf_compiler.C['DMC_MINVAL']
+        velocity[ok, t] += np.einsum('ek,ek->e', dif[ok] / n[ok, None], (v1 - v0)[ok])
+    return length, velocity
+
   def _fetch(self, name):
     p = self._p
+    if name in ('ten_length', 'ten_velocity'):
+      a = self._tendons()[name == 'ten_velocity']
+      return a[0] if p.batch_size == 1 else a
     if name in ('xanchor', 'xaxis'):
       # (the device's state: like every derived array, as of the last launch -- edits not yet forwarded are not seen)
       anchor, axis = self._joint_frames()
@@ -184,7 +223,7 @@ class _Data:
     self._reads.add(name)
     want = [n for n in self._habit if n != name and n not in self._cache and n not in self._prefetched]
     if want and hasattr(b, 'get_many'):
-      want = [n for n in want if n not in ('xanchor', 'xaxis', 'contact')][:7]      # (a get holds at most 8 fields)
+      want = [n for n in want if n not in ('xanchor', 'xaxis', 'contact', 'ten_length', 'ten_velocity')][:7]      # (a get holds at most 8 fields)
       if want:
         try:
           got = b.get_many([name] + want)

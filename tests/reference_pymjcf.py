@@ -383,7 +383,7 @@ def _array_sizes(facade):
   (:63-119) builds the attribute table of `physics.bind(...)` from it."""
   data = {}
   rows = {'act': 'na', 'joint_q': 'nq', 'joint_v': 'nv', 'body': 'nbody', 'geom': 'ngeom', 'site': 'nsite', 'actuator': 'nu',
-          'sensor': 'nsensordata', 'mocap': 'nmocap', 'joint': 'njnt'}
+          'sensor': 'nsensordata', 'mocap': 'nmocap', 'joint': 'njnt', 'tendon': 'ntendon'}
   for name, (kind, ncol) in facade._FIELD_AXES.items():
     data[name] = (rows[kind],) + ((ncol,) if ncol else ())
   model = {}

@@ -333,3 +333,41 @@ def check_collision_filter_edits(make, atol=0.0):
 
 def test_collision_filter_bits_are_writable_and_rebuild_the_batch(oracle_backend):
   check_collision_filter_edits(physics_lib.Physics.from_xml_string)
+
+
+# ---- data.ten_length / data.ten_velocity (locomotion/walkers/rodent.py:279-285 observes them) -----------------------------
+_TENDON_XML = """<mujoco><option timestep='0.002'/><worldbody>
+<body name='a' pos='0 0 1'><joint name='j1' type='hinge' axis='0 1 0'/><geom type='capsule' fromto='0 0 0 .3 0 0' size='.02'/>
+ <site name='s1' pos='.3 0 0'/>
+ <body name='b' pos='.3 0 0'><joint name='j2' type='hinge' axis='0 1 0'/><geom type='capsule' fromto='0 0 0 .3 0 0' size='.02'/>
+  <site name='s2' pos='.3 0 .05'/></body></body>
+<body name='c' pos='0 .4 1'><joint name='j3' type='slide' axis='0 0 1'/><geom type='sphere' size='.05'/><site name='s3'/></body>
+<site name='s0' pos='0 0 1.5'/></worldbody>
+<tendon><fixed name='f'><joint joint='j1' coef='0.6'/><joint joint='j2' coef='-0.4'/></fixed>
+<spatial name='sp'><site site='s0'/><site site='s1'/><site site='s2'/></spatial>
+<spatial name='sq'><site site='s2'/><site site='s3'/></spatial></tendon></mujoco>"""
+
+
+def check_tendon_length_and_velocity(make, atol):
+  """The facade's ten_length equals the oracle's mj_tendon, ten_velocity equals ten_J qvel, along a swinging rollout
+  (fixed tendon, a two-segment spatial tendon anchored in the world, a spatial tendon between two moving bodies)."""
+  from oracle.oracle import OracleModel, OraclePhysics
+  p = make(_TENDON_XML)
+  with p.reset_context():
+    p.data.qpos[:] = [0.3, -0.5, 0.1]
+    p.data.qvel[:] = [1.0, -2.0, 0.5]
+  o = OraclePhysics(OracleModel(p.model))
+  for k in range(4):
+    o.qpos[:] = np.asarray(p.data.qpos)
+    o.qvel[:] = np.asarray(p.data.qvel)
+    o.forward()
+    np.testing.assert_allclose(p.data.ten_length, np.asarray(o.ten_length), rtol=0, atol=atol)
+    J = np.asarray(o.ten_J).reshape(p.model.ntendon, p.model.nv)
+    np.testing.assert_allclose(p.data.ten_velocity, J @ np.asarray(o.qvel), rtol=0, atol=atol)
+    np.testing.assert_allclose(p.named.data.ten_length['sp'], np.asarray(o.ten_length)[1], rtol=0, atol=atol)
+    p.step(25)
+  assert abs(p.data.ten_velocity).max() > 0.1
+
+
+def test_tendon_length_and_velocity_are_served(oracle_backend):
+  check_tendon_length_and_velocity(physics_lib.Physics.from_xml_string, 1e-12)

@@ -919,3 +919,11 @@ def test_collision_filter_bits_rewritten_at_run_time_on_the_device():
   from test_facade_cpu import check_collision_filter_edits
   from dm_control_amd import physics as pl
   check_collision_filter_edits(pl.Physics.from_xml_string, atol=1e-12)
+
+
+def test_tendon_length_and_velocity_on_the_device():
+  """data.ten_length / ten_velocity (locomotion/walkers/rodent.py:279-285): derived by the facade from the device's
+  qpos / qvel / site_xpos / cvel; equal to the oracle's mj_tendon and ten_J qvel."""
+  from test_facade_cpu import check_tendon_length_and_velocity
+  from dm_control_amd import physics as pl
+  check_tendon_length_and_velocity(pl.Physics.from_xml_string, 1e-10)
