@@ -41,7 +41,7 @@
 #define DMC_DEV __device__ __forceinline__
 // out-of-line device functions (one copy of the code for all call sites) taking
 // explicitly LDS-qualified pointers so that they still compile to ds_* ops
-#define DMC_FN __device__ __attribute__((noinline))
+#define DMC_FN __device__ __attribute__((noinline, not_tail_called))
 #define DMC_LDS __attribute__((address_space(3)))
 #define DMC_GLB __attribute__((address_space(1)))   // the per-env global scratch: global_load / global_store, not flat
 #define DMC_WSYNC()                                             \
