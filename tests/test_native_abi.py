@@ -86,13 +86,15 @@ def test_hot_kernel_keeps_its_locals_out_of_scratch(tmp_path):
   assert int(sizes[bench_kernel[0]]) <= 32, sizes[bench_kernel[0]]
 
 
-def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
-  """Every model-specialised fp32 instantiation (configs 2-5 run these): no spilled VGPR, and the private segment no
-  larger than what it is made of today -- the callee-saved registers the out-of-line stage functions save ONCE per
-  physics step in their prologue (acc: 90 dwords for the 62-dof model) and the dynamically indexed polygon / support
-  arrays of the box-box / ellipsoid narrow phases in the position stage, touched only when such a pair is in range
-  (per-function figures: `hipcc -S`, `; ScratchSize`).  The helpers on the solver's inner loops (chol_factor_rows,
-  chol_solve_rows, ls_eval_*) keep at most 20 bytes."""
+def test_static_fp32_kernels_private_segment_stays_bounded():
+  """Every model-specialised fp32 instantiation (configs 2-5 run these).  The small models' kernels spill no VGPR.  The
+  three large ones (static ids 5-7) keep the values that live across their out-of-line stage calls -- the kernel's I/O
+  pointers -- in the private segment: stored once at kernel start, reloaded where an I/O stage needs them (the stage
+  functions are `not_tail_called`, so LLVM's interprocedural register allocation lets them skip the callee-saved VGPR
+  saves that used to cost 90 stores + 90 loads per call; `scripts/scratch_by_function.py` shows where every access is).
+  What is left beside that: the dynamically indexed polygon / support arrays of the box-box / ellipsoid narrow phases in
+  the position stage, touched only when such a pair is in range.  The helpers on the solver's inner loops
+  (chol_factor_rows, chol_solve_rows, ls_eval_*) keep at most 20 bytes."""
   sys.path.insert(0, os.path.join(ROOT, 'scripts'))
   import kernel_resources
   from dm_control_amd import build
@@ -109,7 +111,8 @@ def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
   assert not weak('step_kernels_f32.o') & weak('step_kernels_f32_ilp.o')
   assert all(re.search(r'step_kernel_staticIfLi64ELi[567]ELb', n) for n in ilp), sorted(ilp)
   ks.update(ilp)
-  bound = {0: 32, 1: 64, 2: 640, 3: 32, 4: 32, 5: 260, 6: 400, 7: 736}      # static id -> bytes per lane
+  bound = {0: 32, 1: 32, 2: 640, 3: 32, 4: 32, 5: 200, 6: 330, 7: 690}      # static id -> bytes per lane
+  spill = {5: 48, 6: 72, 7: 16}      # VGPRs the kernel body parks across the stage calls (none in the small models' kernels)
   seen = set()
   for name, r in ks.items():
     m = re.search(r'step_kernel_staticIfLi(\d+)ELi(\d+)ELb([01])', name)
@@ -117,7 +120,7 @@ def test_no_static_fp32_kernel_spills_registers_and_scratch_stays_bounded():
       continue
     sid = int(m.group(2))
     seen.add(sid)
-    assert r['vgpr_spill'] == 0, (name, r)
+    assert r['vgpr_spill'] <= spill.get(sid, 0), (name, r)
     assert r['scratch'] <= bound[sid], (name, r)
     assert r['vgpr'] <= 256
   assert seen == set(bound)
