@@ -1664,12 +1664,75 @@ struct StepCore {
   }
   // narrow phase for one pair; returns the mask of valid slots of h[0..3]
   // (slot order = MuJoCo's contact order); tang = optional shared tangent
+  // ---- sphere / capsule against a cylinder (the oracle's point_cylinder / sphere_cylinder_core / collide_capsule_cylinder) ----
+  // closest point of the SOLID cylinder (centre p, unit axis a, radius R, half-height H) to q; returns the distance
+  DMC_DEV static T point_cylinder(const T* q, const T* p, const T* a, T R, T H, T* closest) {
+    const T v[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+    const T x = dot3(v, a), perp[3] = {v[0] - x*a[0], v[1] - x*a[1], v[2] - x*a[2]};
+    const T d = t_sqrt(dot3(perp, perp)), xc = t_max(-H, t_min(H, x)), sc = d > R ? R/d : (T)1;
+    for (int k = 0; k < 3; k++) closest[k] = p[k] + xc*a[k] + sc*perp[k];
+    const T dif[3] = {q[0] - closest[0], q[1] - closest[1], q[2] - closest[2]};
+    return t_sqrt(dot3(dif, dif));
+  }
+  DMC_DEV static int sphere_cylinder_core(Hit* hit, T margin, const T* ps, T rs, const T* p2, const T* m2, const T* s2) {
+    const T a[3] = {m2[2], m2[5], m2[8]}, R = s2[0], H = s2[1];
+    T closest[3], n[3], dist;
+    const T g = point_cylinder(ps, p2, a, R, H, closest);
+    if (g >= (T)DMC_MINVAL) {
+      dist = g - rs;
+      for (int k = 0; k < 3; k++) n[k] = (closest[k] - ps[k]) / g;
+    } else {      // centre inside the solid: out through the nearest face
+      const T v[3] = {ps[0] - p2[0], ps[1] - p2[1], ps[2] - p2[2]};
+      const T x = dot3(v, a), perp[3] = {v[0] - x*a[0], v[1] - x*a[1], v[2] - x*a[2]}, d = t_sqrt(dot3(perp, perp));
+      if (H - t_abs(x) < R - d) { dist = -(H - t_abs(x)) - rs; for (int k = 0; k < 3; k++) n[k] = x >= 0 ? -a[k] : a[k]; }
+      else {
+        dist = -(R - d) - rs;
+        if (d < (T)DMC_MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] = -perp[k] / d;
+      }
+    }
+    if (dist > margin) return 0;
+    hit->dist = dist;
+    for (int k = 0; k < 3; k++) { hit->pos[k] = ps[k] + n[k]*(rs + dist*(T)0.5); hit->nrm[k] = n[k]; }
+    return 1;
+  }
+  // slope of the point-to-cylinder distance along the capsule axis at p1 + t u (nondecreasing in t)
+  DMC_DEV static T segment_slope(T t, const T* p1, const T* u, const T* p2, const T* a, T R, T H) {
+    const T q[3] = {p1[0] + t*u[0], p1[1] + t*u[1], p1[2] + t*u[2]};
+    T closest[3];
+    const T g = point_cylinder(q, p2, a, R, H, closest);
+    if (g < (T)DMC_MINVAL) return 0;
+    return ((q[0] - closest[0])*u[0] + (q[1] - closest[1])*u[1] + (q[2] - closest[2])*u[2]) / g;
+  }
+  DMC_DEV static T slope_crossing(T thr, T h, const T* p1, const T* u, const T* p2, const T* a, T R, T H) {
+    if (segment_slope(-h, p1, u, p2, a, R, H) > thr) return -h;
+    if (!(segment_slope(h, p1, u, p2, a, R, H) > thr)) return h;
+    T lo = -h, hi = h;
+    for (int it = 0; it < (sizeof(T) == 4 ? 28 : 60); it++) {
+      const T t = (T)0.5*(lo + hi);
+      if (segment_slope(t, p1, u, p2, a, R, H) > thr) hi = t; else lo = t;
+    }
+    return (T)0.5*(lo + hi);
+  }
+  // returns 0 / 1 contacts, or -1 when the capsule's axis reaches the cylinder (no unique closest pair: the caller warns)
+  DMC_DEV static int capsule_cylinder(Hit* hit, T margin, const T* p1, const T* m1, const T* s1, const T* p2, const T* m2, const T* s2) {
+    const T u[3] = {m1[2], m1[5], m1[8]}, a[3] = {m2[2], m2[5], m2[8]};
+    const T tol = sizeof(T) == 4 ? (T)1e-4 : (T)1e-7;
+    const T ta = slope_crossing(-tol, s1[1], p1, u, p2, a, s2[0], s2[1]);
+    const T tb = slope_crossing(tol, s1[1], p1, u, p2, a, s2[0], s2[1]);
+    const T t = (T)0.5*(ta + tb);
+    const T q[3] = {p1[0] + t*u[0], p1[1] + t*u[1], p1[2] + t*u[2]};
+    T closest[3];
+    if (point_cylinder(q, p2, a, s2[0], s2[1], closest) < (sizeof(T) == 4 ? (T)1e-5 : (T)1e-9)*(s2[0] + s2[1])) return -1;
+    return sphere_cylinder_core(hit, margin, q, s1[0], p2, m2, s2);
+  }
   DMC_DEV int narrow_phase(int g1, int g2, T margin, Hits* h, T* tang, bool* has_tang, bool* guard) {
     int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
-    // cylinders have no narrow phase here: they are tested as their enclosing capsule
-    // (same radius / half-length); a hit only raises DMC_WARN_COLLISION (see collision())
+    // cylinders: against a plane, a sphere or a capsule the narrow phase is restated; every other pair is tested as the
+    // cylinder's enclosing capsule (same radius / half-length) and a hit only raises DMC_WARN_COLLISION (see collision())
     const bool plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;
-    *guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && !plane_cyl;
+    const bool cyl_pair = L.d.ncylx && t2 == DMC_GEOM_CYLINDER && (t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE);
+    const bool cyl_capsule = cyl_pair && t1 == DMC_GEOM_CAPSULE;
+    *guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && !plane_cyl && !cyl_pair;
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
@@ -1765,6 +1828,12 @@ struct StepCore {
       T dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       T bound = rb1 + rb2 + margin;
       if (dot3(dif, dif) > bound*bound) return 0;
+    }
+    if (L.d.ncylx && cyl_pair) {
+      if (!cyl_capsule) return sphere_cylinder_core(&h->s0, margin, p1, s1[0], p2, m2, s2);
+      const int r = capsule_cylinder(&h->s0, margin, p1, m1, s1, p2, m2, s2);
+      if (r < 0) { *guard = true; return 1; }      // the axis reaches the cylinder: DMC_WARN_COLLISION, no contact
+      return r;
     }
     if (L.d.nell && t2 == DMC_GEOM_ELLIPSOID) return ellipsoid_pair(&h->s0, margin, t1, p1, m1, s1, p2, m2, s2);
     if (L.d.nbox && t2 == DMC_GEOM_BOX) {

@@ -26,7 +26,8 @@ struct StepDims {
   int ntri;      // nv (nv + 1) / 2: lower-triangle entries of an nv x nv matrix
   int elliptic;  // 1: frictional contacts use elliptic cones (one row per contact-frame axis)
   int nfric;     // dofs with frictionloss > 0 (one Huber-cost row each)
-  int ncyl;      // candidate pairs involving a cylinder (guard test only, never a contact)
+  int ncyl;      // candidate pairs involving a cylinder other than plane-cylinder (a guard test may raise DMC_WARN_COLLISION)
+  int ncylx;     // of those, sphere-cylinder / capsule-cylinder pairs: narrow phase restated (closest point of the solid cylinder)
   int ntendon, nwrap;  // fixed tendons (actuator transmissions, springs / dampers)
   int fluid;     // 1: option density / viscosity > 0 (inertia-box fluid forces in mj_passive)
   int nstv;      // number of subtreelinvel sensors (each is one masked reduction over the bodies)

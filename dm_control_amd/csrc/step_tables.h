@@ -169,12 +169,16 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
   for (int p = 0; p < m.npair; p++) {
     const int g1 = m.pair_geom1[p], g2 = m.pair_geom2[p];
     int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-    // cylinders: guard test as enclosing capsules (DMC_WARN_COLLISION), never a contact
+    // cylinders: against a plane, a sphere or a capsule a real narrow phase; any other pair is guard-tested as the enclosing
+    // capsule (DMC_WARN_COLLISION) and never yields a contact
     const bool plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;   // analytic, up to 4 contacts
     const bool cyl = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && !plane_cyl;
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     if (cyl) d.ncyl++;
+    // a sphere or a capsule against a cylinder has a real narrow phase (one contact); the other cylinder pairs stay guarded
+    const bool cylx = cyl && m.geom_type[g2] == DMC_GEOM_CYLINDER && (m.geom_type[g1] == DMC_GEOM_SPHERE || m.geom_type[g1] == DMC_GEOM_CAPSULE);
+    if (cylx) d.ncylx++;
     const bool ell = t2 == DMC_GEOM_ELLIPSOID && (t1 == DMC_GEOM_PLANE || t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE || t1 == DMC_GEOM_ELLIPSOID) && !cyl;
     if (ell) d.nell++;
     // (a cylinder against a box is guard-tested as its enclosing capsule like every other cylinder pair)
@@ -198,7 +202,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     if (pr1 == pr2) dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
     else dim = m.geom_condim[pr1 > pr2 ? g1 : g2];
     pdim[p] = dim;
-    if (cyl) nc = 0;
+    if (cyl && !cylx) nc = 0;
     maxc += nc; maxr += nc * (dim == 1 ? 1 : (elliptic ? dim : 2*(dim - 1)));
   }
   // contact parameters (mixing rules: max / priority / solmix).  Most pairs of a

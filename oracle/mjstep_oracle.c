@@ -662,6 +662,79 @@ static int collide_sphere_capsule(Contact* c, double margin, const double* p1, c
   double q[3] = {p2[0] + axis[0]*x, p2[1] + axis[1]*x, p2[2] + axis[2]*x};
   return raw_sphere_sphere(c, margin, p1, s1[0], q, s2[0]);
 }
+/* ---- sphere / capsule against a cylinder ------------------------------------------------------------------------------
+ * MuJoCo: sphere-cylinder is analytic (mjc_SphereCylinder: side / cap / rim cases, nearest face when the centre is
+ * inside), capsule-cylinder goes through its convex collider (one contact: the pair of closest points, contact point
+ * half way between the surfaces).  Both are restated as exact geometry: the closest point of the SOLID cylinder to a point
+ * is closed form; for the capsule the point runs over the axis segment, along which that distance is convex, so the
+ * minimiser is found by bisection on its slope (the middle of the stretch where the slope vanishes).  A capsule whose AXIS touches or enters the
+ * cylinder (penetration deeper than its radius) has no unique closest pair: returns -1 and the caller raises
+ * DMC_WARN_COLLISION, as for the cylinder pairs that are not restated (cylinder-cylinder, box-cylinder, ellipsoid). */
+static double point_cylinder(const double* q, const double* p, const double* a, double R, double H, double* closest) {
+  double v[3] = {q[0] - p[0], q[1] - p[1], q[2] - p[2]};
+  double x = dot3(v, a), perp[3] = {v[0] - x*a[0], v[1] - x*a[1], v[2] - x*a[2]};
+  double d = sqrt(dot3(perp, perp)), xc = mjMAX(-H, mjMIN(H, x)), sc = d > R ? R/d : 1.0;
+  for (int k = 0; k < 3; k++) closest[k] = p[k] + xc*a[k] + sc*perp[k];
+  double dif[3] = {q[0] - closest[0], q[1] - closest[1], q[2] - closest[2]};
+  return sqrt(dot3(dif, dif));
+}
+static int sphere_cylinder_core(Contact* c, double margin, const double* ps, double rs,
+                                const double* p2, const double* m2, const double* s2) {
+  double a[3] = {m2[2], m2[5], m2[8]}, R = s2[0], H = s2[1], closest[3];
+  double g = point_cylinder(ps, p2, a, R, H, closest), n[3], dist;
+  if (g >= MINVAL) {      /* centre outside: side, cap or rim, whichever holds the closest point */
+    dist = g - rs;
+    for (int k = 0; k < 3; k++) n[k] = (closest[k] - ps[k]) / g;
+  } else {                /* centre inside the solid: out through the nearest face */
+    double v[3] = {ps[0] - p2[0], ps[1] - p2[1], ps[2] - p2[2]};
+    double x = dot3(v, a), perp[3] = {v[0] - x*a[0], v[1] - x*a[1], v[2] - x*a[2]}, d = sqrt(dot3(perp, perp));
+    if (H - fabs(x) < R - d) { dist = -(H - fabs(x)) - rs; for (int k = 0; k < 3; k++) n[k] = x >= 0 ? -a[k] : a[k]; }
+    else {
+      dist = -(R - d) - rs;
+      if (d < MINVAL) { n[0] = 1; n[1] = n[2] = 0; } else for (int k = 0; k < 3; k++) n[k] = -perp[k] / d;
+    }
+  }
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->pos[k] = ps[k] + n[k]*(rs + dist*0.5); c->frame[k] = n[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
+static int collide_sphere_cylinder(Contact* c, double margin, const double* p1, const double* s1,
+                                   const double* p2, const double* m2, const double* s2) {
+  return sphere_cylinder_core(c, margin, p1, s1[0], p2, m2, s2);
+}
+/* slope of the point-to-cylinder distance along the unit direction u at q = p1 + t u (the cosine between u and the
+ * direction away from the closest point); nondecreasing in t because the distance to a convex set is convex */
+static double segment_slope(double t, const double* p1, const double* u, const double* p2, const double* a, double R, double H) {
+  double q[3] = {p1[0] + t*u[0], p1[1] + t*u[1], p1[2] + t*u[2]}, closest[3];
+  double g = point_cylinder(q, p2, a, R, H, closest);
+  if (g < MINVAL) return 0;
+  return ((q[0] - closest[0])*u[0] + (q[1] - closest[1])*u[1] + (q[2] - closest[2])*u[2]) / g;
+}
+/* first t of [-h, h] at which that slope exceeds thr (h if it never does): bisection on the monotone slope */
+static double slope_crossing(double thr, double h, const double* p1, const double* u, const double* p2, const double* a, double R, double H) {
+  if (segment_slope(-h, p1, u, p2, a, R, H) > thr) return -h;
+  if (!(segment_slope(h, p1, u, p2, a, R, H) > thr)) return h;
+  double lo = -h, hi = h;
+  for (int it = 0; it < 60; it++) {
+    const double t = 0.5*(lo + hi);
+    if (segment_slope(t, p1, u, p2, a, R, H) > thr) hi = t; else lo = t;
+  }
+  return 0.5*(lo + hi);
+}
+static int collide_capsule_cylinder(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
+                                    const double* p2, const double* m2, const double* s2) {
+  double u[3] = {m1[2], m1[5], m1[8]}, a[3] = {m2[2], m2[5], m2[8]}, closest[3], q[3];
+  /* the minimiser of the distance over the axis segment: where its slope changes sign.  When the slope is (numerically)
+   * zero over a stretch -- the capsule lies along the cap or alongside the cylinder -- the middle of that stretch */
+  const double tol = 1e-7;
+  const double ta = slope_crossing(-tol, s1[1], p1, u, p2, a, s2[0], s2[1]);
+  const double tb = slope_crossing(tol, s1[1], p1, u, p2, a, s2[0], s2[1]);
+  const double t = 0.5*(ta + tb);
+  for (int k = 0; k < 3; k++) q[k] = p1[k] + t*u[k];
+  if (point_cylinder(q, p2, a, s2[0], s2[1], closest) < 1e-9*(s2[0] + s2[1])) return -1;      /* the axis reaches the cylinder */
+  return sphere_cylinder_core(c, margin, q, s1[0], p2, m2, s2);
+}
 static int collide_capsule_capsule(Contact* c, double margin, const double* p1, const double* m1, const double* s1,
                                    const double* p2, const double* m2, const double* s2) {
   double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
@@ -1100,13 +1173,21 @@ static void collision(const Model* m, Data* d) {
     if (d->ncon + 4 > m->nconmax) { d->warning[DMC_WARN_CONTACTFULL]++; break; }
     Contact* c = d->contact + d->ncon;
     int n = 0;
-    /* cylinders have no restated narrow phase: they are tested as their enclosing capsule
-     * (same radius / half-length) and a hit only raises DMC_WARN_COLLISION */
-    const int guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && t1 != DMC_GEOM_PLANE;
+    /* cylinders: against a plane, a sphere or a capsule the narrow phase is restated; every other pair is tested as
+     * the cylinder's enclosing capsule (same radius / half-length) and a hit only raises DMC_WARN_COLLISION */
+    const int cyl_pair = t2 == DMC_GEOM_CYLINDER && (t1 == DMC_GEOM_SPHERE || t1 == DMC_GEOM_CAPSULE);      /* restated exactly */
+    const int guard = (t1 == DMC_GEOM_CYLINDER || t2 == DMC_GEOM_CYLINDER) && t1 != DMC_GEOM_PLANE && !cyl_pair;
     const int plane_cyl = t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CYLINDER;
+    if (cyl_pair) {
+      n = t1 == DMC_GEOM_SPHERE ? collide_sphere_cylinder(c, margin, p1, s1, p2, m2, s2)
+                                : collide_capsule_cylinder(c, margin, p1, m1, s1, p2, m2, s2);
+      if (n < 0) { d->warning[DMC_WARN_COLLISION]++; continue; }
+      t1 = t2 = -1;      /* (handled: none of the branches below) */
+    }
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
-    if (plane_cyl) n = collide_plane_cylinder(c, margin, p1, m1, p2, m2, s2);
+    if (cyl_pair) {}
+    else if (plane_cyl) n = collide_plane_cylinder(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_SPHERE) { double nrm[3] = {m1[2], m1[5], m1[8]}; n = raw_plane_sphere(c, margin, p1, nrm, p2, s2[0]); }
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_CAPSULE) n = collide_plane_capsule(c, margin, p1, m1, p2, m2, s2);
     else if (t1 == DMC_GEOM_PLANE && t2 == DMC_GEOM_BOX) n = collide_plane_box(c, margin, p1, m1, p2, m2, s2);

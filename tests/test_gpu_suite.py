@@ -384,12 +384,13 @@ def test_model_constants_rewritten_between_episodes():
 
 
 def test_cylinder_pairs_are_guarded_not_silently_ignored():
-  """Only plane-cylinder has a narrow phase: a cylinder coming within range of any other geom
-  (tested as its enclosing capsule) raises the dmcWARN_COLLISION counter instead of a contact."""
+  """A cylinder has a narrow phase against a plane, a sphere and a capsule (tests/test_cylinder_contacts.py); two
+  cylinders coming within range of each other (tested as their enclosing capsules) raise the dmcWARN_COLLISION counter
+  instead of a contact; a box or an ellipsoid against a cylinder is refused when the batch is created."""
   from dm_control_amd.batch import BatchedPhysics
   m = mc.compile_xml("""
   <mujoco><worldbody>
-    <geom name='post' type='sphere' size='.1'/>
+    <geom name='post' type='cylinder' size='.1 .05'/>
     <body name='can' pos='0 0 .6'><freejoint/><geom type='cylinder' size='.1 .1'/></body>
   </worldbody></mujoco>""")
   b = BatchedPhysics(m, 2, precision=64)

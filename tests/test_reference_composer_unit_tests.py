@@ -7,7 +7,7 @@ host stacks).  CPU tier: the fp64 oracle stands in for the device; `hip` variant
 
 A test that ends in `physics.render(...)` (camera observables) is outside this backend's scope: those are counted -- the
 expected number per file is pinned below -- and everything else in the file has to pass.  Files NOT run, and why:
-mjcf/physics_test.py (its arm model needs a cylinder-capsule narrow phase and geom-distance sensors), locomotion/tasks/
+mjcf/physics_test.py (its arm model has geom-distance sensors between bodies that carry boxes), locomotion/tasks/
 reach_test.py and walkers/rodent_test.py (every test but one builds the rodent's egocentric camera observable; the
 rodent's 74 dofs are also beyond the device's nv <= 64), escape / bowl (height fields), the mocap-initialised and
 soccer-humanoid walkers (h5py / mocap data absent)."""
