@@ -8,6 +8,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$(pwd)
 timeout 400 python -m pytest tests -m gpu -q -rs -n 4 2>&1 | tail -8 > gpurun_out/r04_gputests.log; tail -2 gpurun_out/r04_gputests.log
 timeout 300 python -m pytest tests/test_reference_host_layers.py tests/test_reference_suite_domains.py tests/test_reference_composer.py tests/test_reference_unit_tests.py tests/test_reference_composer_unit_tests.py -m gpu -v 2>&1 | grep -E "PASSED|FAILED|SKIPPED|passed|failed" > gpurun_out/r04_reference_on_hip.log; tail -1 gpurun_out/r04_reference_on_hip.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04_smoke.log 2>&1; tail -2 gpurun_out/r04_smoke.log
 for c in 5 4 3 2; do
   timeout 300 python bench.py --config $c > gpurun_out/r04_bench_cfg$c.json 2> gpurun_out/r04_bench_cfg$c.err; echo "bench cfg$c rc=$?"
   python -c "
