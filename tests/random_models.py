@@ -3,7 +3,7 @@ with a random mix of the features both implementations support."""
 import numpy as np
 
 
-def random_model_xml(seed, ellipsoids=False, noslip=0):
+def random_model_xml(seed, ellipsoids=False, noslip=0, cylinders=False):
   rs = np.random.RandomState(seed)
   rs2 = np.random.RandomState(7919 + seed)   # separate stream: the base models keep their seeds
   cone = rs.choice(['pyramidal', 'elliptic'])
@@ -18,7 +18,7 @@ def random_model_xml(seed, ellipsoids=False, noslip=0):
          '<default><geom condim="%d" friction="%g 0.01 0.002"/><joint damping="%g" armature="0.01"/></default>' % (
              condim, rs.uniform(.3, 1.2), rs.uniform(0.02, .5)),
          '<worldbody>', '<geom name="floor" type="plane" size="5 5 .1"/>']
-  joints, sites, bodies = [], [], []
+  joints, sites, bodies, roots = [], [], [], []
   counter = [0]
 
   def body(depth, parent_len):
@@ -30,7 +30,9 @@ def random_model_xml(seed, ellipsoids=False, noslip=0):
     radius = rs.uniform(.02, .05)
     lines = []
     if depth == 0:
-      lines.append('<body name="%s" pos="%g %g %g">' % (name, rs.uniform(-1, 1), rs.uniform(-1, 1), rs.uniform(.25, .6)))
+      root_pos = (rs.uniform(-1, 1), rs.uniform(-1, 1), rs.uniform(.25, .6))
+      roots.append(root_pos)
+      lines.append('<body name="%s" pos="%g %g %g">' % ((name,) + root_pos))
       kind = rs.choice(['free', 'planar', 'hinge'])
       if kind == 'free':
         lines.append('<freejoint name="j%d"/>' % k)
@@ -86,6 +88,16 @@ def random_model_xml(seed, ellipsoids=False, noslip=0):
 
   for _ in range(nroots):
     out += body(0, 0.0)
+  if cylinders:
+    # static cylinders lying and standing where the trees come down (sphere-cylinder / capsule-cylinder pairs; not with
+    # ellipsoids: that pair type is refused)
+    rs3 = np.random.RandomState(104729 + seed)
+    for c in range(3):
+      q = rs3.randn(4)
+      x0, y0, _ = roots[c % len(roots)]
+      out.append('<geom name="cyl%d" type="cylinder" pos="%g %g %g" quat="%g %g %g %g" size="%g %g"/>' % (
+          (c, x0 + rs3.uniform(-.1, .4), y0 + rs3.uniform(-.1, .1), rs3.uniform(.02, .12)) + tuple(q / np.linalg.norm(q)) +
+          (rs3.uniform(.05, .15), rs3.uniform(.03, .12))))
   out.append('</worldbody>')
   tendons, eqs = [], []
   hinges = [j for j in joints]

@@ -720,6 +720,33 @@ def test_random_models_match_oracle(seed, ellipsoids, noslip):
   b.close()
 
 
+@pytest.mark.parametrize('seed,noslip', [(s, 0) for s in range(200, 210)] + [(s, 3) for s in range(217, 221)])
+def test_random_models_with_cylinders_match_oracle(seed, noslip):
+  """The fuzzing above with three static cylinders under the trees: sphere-cylinder / capsule-cylinder contacts on the
+  device (fp64 kernel vs oracle)."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from random_models import random_model_xml
+  m = mc.compile_xml(random_model_xml(seed, False, noslip, cylinders=True))
+  B = 4
+  rs = np.random.RandomState(3000 + seed)
+  q = np.tile(m.qpos0, (B, 1))
+  v = rs.uniform(-.5, .5, (B, m.nv))
+  b = _batch(m, B, precision=64, lanes_per_env=(64, 32, 16)[seed % 3])
+  b.set('qpos', q); b.set('qvel', v)
+  ora = _oracles(m, q, v)
+  from oracle import oracle
+  for t in range(15):
+    a = rs.uniform(-1, 1, (B, m.nu))
+    b.set_control(a)
+    b.step(10)
+    oracle.rollout_legacy(ora, a[None], nsub=10)
+  qo = np.stack([o.qpos for o in ora])
+  assert _rel_err(b.get('qpos'), qo) <= 1e-6
+  np.testing.assert_array_equal(b.get('warning').sum(axis=0), np.sum([o.warning for o in ora], axis=0))
+  b.close()
+
+
 # ---- the HBM stash of the position / velocity stage between legacy steps --------------------------
 @pytest.mark.parametrize('name,precision,lanes', [('cheetah', 32, 32), ('cheetah', 64, 16), ('cartpole', 32, 32),
                                                   ('hopper', 32, 32), ('humanoid', 32, 64)])
