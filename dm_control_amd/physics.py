@@ -679,6 +679,11 @@ class Physics(control.Physics):
         continue
       batch.set(name, a)
     self.batch = batch      # (created from the model's current arrays and options: nothing else to re-send)
+    if self.__dict__.get('_profiling', False):
+      batch.enable_profiling(True)      # (the step timers restart with the batch)
+    close = getattr(old, 'close', None)
+    if close:
+      close()
     self._opt_pushed = self._opt_snapshot()
     for f in self._model_pushed:
       self._model_pushed[f] = np.array(getattr(model, f), dtype=np.float64, copy=True)
@@ -803,6 +808,7 @@ class Physics(control.Physics):
   def enable_profiling(self):
     """engine.py:135-137: switches the step timers on (`data.timer[0].duration / .number`); here every launch is
     bracketed by hipEvents on its stream (dmc_batch_enable_profiling)."""
+    self._profiling = True
     self.batch.enable_profiling(True)
 
   # -- state -------------------------------------------------------------------------------
