@@ -114,7 +114,9 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   // allow.  Workgroups of more than 4 waves were tried (512 threads: humanoid 7 environments in one workgroup instead
   // of 2 x 3) and measured slower (1.20 M vs 1.29 M env-steps/s), so 4 waves stays the largest shape.
   const int force_w = getenv("DMC_WAVES") ? atoi(getenv("DMC_WAVES")) : 0;      // tuning studies only
-  for (int w = 4; w >= 1; w--) {
+  // ... with one exception: FIVE waves when that is what holds one more environment than any smaller shape (the 62-dof
+  // models at offload level 3: 5 x 29.8 KB + one 10.8 KB table copy = 159.6 KB; +25 % residency, round 4)
+  for (int w = 5; w >= 1; w--) {
     if (force_w && w != force_w) continue;
     const size_t bytes = tables + (size_t)w * epw * env_bytes;
     if (bytes > lds_cu) continue;

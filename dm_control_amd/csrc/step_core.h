@@ -643,6 +643,7 @@ struct StepCore {
 #define MRS(n) ((L.d.sitegl ? (const T*)o.g_mr : (const T*)mr) + L.mr_##n)   // a site table (STEP_MODEL_SITE_REAL_TABLES)
 #define GC(n) (gc + L.mc_##n)
 #define S(n) (s + L.s_##n)
+#define SG(n) (sg_##n())      // arrays that live in global scratch at offload level 3
 #define SI(n) (si + L.si_##n)
 #define FOR_LANES(i, n) for (int i = lane; i < (n); i += LPE)
 
@@ -650,11 +651,11 @@ struct StepCore {
   // which at compile time; the round trip through the global address space lets the compiler emit global_load.
   DMC_DEV const T* mrc() const {
 #ifndef DMC_HOST_EMU
-    if constexpr (LS::kJGlobal == 2) return (const T*)(const DMC_GLB T*)o.g_mr;
+    if constexpr (LS::kJGlobal >= 2) return (const T*)(const DMC_GLB T*)o.g_mr;
     else if constexpr (LS::kJGlobal >= 0) return mr;
     else
 #endif
-    return L.d.jglobal == 2 ? (const T*)o.g_mr : mr;
+    return L.d.jglobal >= 2 ? (const T*)o.g_mr : mr;
   }
   // Opaque copy of an env index: stops the compiler from forming HBM addresses long before
   // they are used and carrying them across the out-of-line stage calls (callee-saved VGPRs,
@@ -803,7 +804,7 @@ struct StepCore {
       if (k < 0) continue;
       const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
       for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
-      for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
+      for (int j = 0; j < 9; j++) SG(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
     }
     DMC_WSYNC();
   }
@@ -833,11 +834,11 @@ struct StepCore {
       for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
       SI(imisc)[IM_NCON] = 0; SI(imisc)[IM_NEFC] = 0; SI(imisc)[IM_ITER] = 0;
       // world body
-      T* xp = S(xpos); T* xq = S(xquat); T* xm = S(xmat); T* xi = S(xipos);
+      T* xp = S(xpos); T* xq = SG(xquat); T* xm = S(xmat); T* xi = S(xipos);
       xp[0] = xp[1] = xp[2] = 0; xi[0] = xi[1] = xi[2] = 0;
       xq[0] = 1; xq[1] = xq[2] = xq[3] = 0;
       for (int k = 0; k < 9; k++) xm[k] = (k % 4 == 0) ? (T)1 : (T)0;
-      for (int k = 0; k < 10; k++) S(cinert)[k] = 0;
+      for (int k = 0; k < 10; k++) SG(cinert)[k] = 0;
       for (int k = 0; k < 6; k++) S(cvel)[k] = 0;
     }
     if (!L.d.msparse) FOR_LANES(i, L.d.nv * L.d.nv) S(qM)[i] = 0;
@@ -866,19 +867,19 @@ struct StepCore {
     const int nb = L.d.nbody;
     if (mask & OUT_SENSOR) FOR_LANES(i, L.d.nsensordata) io.sensordata[(size_t)i*B + env] = S(sensordata)[i];
     if (mask & OUT_XPOS) FOR_LANES(i, 3*nb) io.xpos[(size_t)i*B + env] = S(xpos)[i];
-    if (mask & OUT_XQUAT) FOR_LANES(i, 4*nb) io.xquat[(size_t)i*B + env] = S(xquat)[i];
+    if (mask & OUT_XQUAT) FOR_LANES(i, 4*nb) io.xquat[(size_t)i*B + env] = SG(xquat)[i];
     if (mask & OUT_XMAT) FOR_LANES(i, 9*nb) io.xmat[(size_t)i*B + env] = S(xmat)[i];
     if (mask & OUT_XIPOS) FOR_LANES(i, 3*nb) io.xipos[(size_t)i*B + env] = S(xipos)[i];
     if (mask & OUT_SUBTREE_COM) FOR_LANES(i, 3*nb) io.subtree_com[(size_t)i*B + env] = S(subtree_com)[i];
     if (mask & OUT_GEOM) {
       FOR_LANES(i, 3*L.d.ngeom) io.geom_xpos[(size_t)i*B + env] = S(geom_xpos)[i];
-      FOR_LANES(i, 9*L.d.ngeom) io.geom_xmat[(size_t)i*B + env] = S(geom_xmat)[i];
+      FOR_LANES(i, 9*L.d.ngeom) io.geom_xmat[(size_t)i*B + env] = SG(geom_xmat)[i];
     }
     if (mask & OUT_SITE) FOR_LANES(sid, L.d.nsite) {
       int b = MI(site_bodyid)[sid]; T v[3], q[4], m[9];
       mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*sid);
       for (int k = 0; k < 3; k++) io.site_xpos[(size_t)(3*sid + k)*B + env] = S(xpos)[3*b + k] + v[k];
-      mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*sid);
+      mul_quat(q, SG(xquat) + 4*b, MRS(site_quat) + 4*sid);
       quat2mat(m, q);
       for (int k = 0; k < 9; k++) io.site_xmat[(size_t)(9*sid + k)*B + env] = m[k];
     }
@@ -975,7 +976,7 @@ struct StepCore {
     }
     if (flat_kin()) { T* lp = S(crb) + 10*i; for (int k = 0; k < 3; k++) lp[k] = p[k]; for (int k = 0; k < 4; k++) lp[3 + k] = q[k]; return; }
     for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
-    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+    for (int k = 0; k < 4; k++) SG(xquat)[4*i + k] = q[k];
   }
   // Poses composed along each body's own chain instead of one fenced pass per tree depth: the local poses are parked
   // in the (still unused) composite-inertia buffer, every body walks up its ancestors (world = local_root o ... o
@@ -1001,7 +1002,7 @@ struct StepCore {
     normalize4(q);
     quat2mat(m, q);
     for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
-    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+    for (int k = 0; k < 4; k++) SG(xquat)[4*i + k] = q[k];
     for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = m[k];
   }
   DMC_DEV void body_compose(int i) {
@@ -1009,16 +1010,16 @@ struct StepCore {
     T p[3], q[4], m[9];
     if (pid == 0) {
       for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*i + k];
-      for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*i + k];
+      for (int k = 0; k < 4; k++) q[k] = SG(xquat)[4*i + k];
     } else {
       mul_mat_vec3(p, S(xmat) + 9*pid, S(xpos) + 3*i);
       for (int k = 0; k < 3; k++) p[k] += S(xpos)[3*pid + k];
-      mul_quat(q, S(xquat) + 4*pid, S(xquat) + 4*i);
+      mul_quat(q, SG(xquat) + 4*pid, SG(xquat) + 4*i);
     }
     normalize4(q);
     quat2mat(m, q);
     for (int k = 0; k < 3; k++) S(xpos)[3*i + k] = p[k];
-    for (int k = 0; k < 4; k++) S(xquat)[4*i + k] = q[k];
+    for (int k = 0; k < 4; k++) SG(xquat)[4*i + k] = q[k];
     for (int k = 0; k < 9; k++) S(xmat)[9*i + k] = m[k];
   }
   DMC_DEV void kinematics() {
@@ -1048,7 +1049,7 @@ struct StepCore {
       T v[3], q[4], m[9];
       mul_mat_vec3(v, S(xmat) + 9*i, MRC(body_ipos) + 3*i);
       for (int k = 0; k < 3; k++) S(xipos)[3*i + k] = S(xpos)[3*i + k] + v[k];
-      mul_quat(q, S(xquat) + 4*i, MRC(body_iquat) + 4*i);
+      mul_quat(q, SG(xquat) + 4*i, MRC(body_iquat) + 4*i);
       quat2mat(m, q);
       for (int k = 0; k < 9; k++) S(ximat)[9*i + k] = m[k];
     }
@@ -1057,15 +1058,15 @@ struct StepCore {
       if (k >= 0) {      // a world-fixed geom with a per-environment pose: its world frame IS that pose
         const T* eg = (const T*)o.eg_data + (size_t)16*k*o.eg_B + SI(imisc)[IM_ENV];
         for (int j = 0; j < 3; j++) S(geom_xpos)[3*g + j] = eg[(size_t)j*o.eg_B];
-        for (int j = 0; j < 9; j++) S(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
+        for (int j = 0; j < 9; j++) SG(geom_xmat)[9*g + j] = eg[(size_t)(3 + j)*o.eg_B];
         continue;
       }
       const int b = MI(geom_bodyid)[g]; T v[3], q[4], m[9];
       mul_mat_vec3(v, S(xmat) + 9*b, MRC(geom_pos) + 3*g);
       for (int k = 0; k < 3; k++) S(geom_xpos)[3*g + k] = S(xpos)[3*b + k] + v[k];
-      mul_quat(q, S(xquat) + 4*b, MRC(geom_quat) + 4*g);
+      mul_quat(q, SG(xquat) + 4*b, MRC(geom_quat) + 4*g);
       quat2mat(m, q);
-      for (int k = 0; k < 9; k++) S(geom_xmat)[9*g + k] = m[k];
+      for (int k = 0; k < 9; k++) SG(geom_xmat)[9*g + k] = m[k];
     }
     DMC_WSYNC();
   }
@@ -1109,7 +1110,7 @@ struct StepCore {
       T off[3], ci[10]; const T* rc = S(subtree_com) + 3*MI(body_rootid)[i];
       for (int k = 0; k < 3; k++) off[k] = S(xipos)[3*i + k] - rc[k];
       inert_com(ci, MRC(body_inertia) + 3*i, S(ximat) + 9*i, off, MR(body_mass)[i]);
-      for (int k = 0; k < 10; k++) S(cinert)[10*i + k] = ci[k];
+      for (int k = 0; k < 10; k++) SG(cinert)[10*i + k] = ci[k];
     }
     FOR_LANES(j, L.d.njnt) {
       const int da = 6*MI(jnt_dofadr)[j], bi = MI(jnt_bodyid)[j], t = MI(jnt_type)[j];
@@ -1167,15 +1168,15 @@ struct StepCore {
       // child-accumulation passes (each a chain of five LDS reads).  Same terms as the level passes, summed in id order.
       for (int idx = 10 + lane; idx < 10*L.d.nbody; idx += LPE) {
         const int b = idx / 10, comp = idx - 10*b, e = MI(body_subend)[b];
-        T v = S(cinert)[idx];
-        for (int c = b + 1; c < e; c++) v += S(cinert)[10*c + comp];
+        T v = SG(cinert)[idx];
+        for (int c = b + 1; c < e; c++) v += SG(cinert)[10*c + comp];
         S(crb)[idx] = v;
       }
       DMC_WSYNC();
     } else
 #endif
     {
-    for (int i = 10 + lane; i < 10*L.d.nbody; i += LPE) S(crb)[i] = S(cinert)[i];
+    for (int i = 10 + lane; i < 10*L.d.nbody; i += LPE) S(crb)[i] = SG(cinert)[i];
     DMC_WSYNC();
     for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
       const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
@@ -1210,21 +1211,34 @@ struct StepCore {
   // contact frames (9 reals per contact): LDS, or the global scratch of a large model
   DMC_DEV T* conF() const {
 #ifndef DMC_HOST_EMU
-    if constexpr (LS::kJGlobal == 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_cf);
+    if constexpr (LS::kJGlobal >= 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_cf);
     else if constexpr (LS::kJGlobal >= 0) return S(con_frame);
     else
 #endif
-    return L.d.jglobal == 2 ? gscr() + L.gs_cf : S(con_frame);
+    return L.d.jglobal >= 2 ? gscr() + L.gs_cf : S(con_frame);
   }
+  // ---- level-3 arrays (xquat, geom_xmat, cinert, cdof_dot): LDS, or the global scratch of the largest models ------------
+#ifndef DMC_HOST_EMU
+#define DMC_SG_ACCESSOR(name)                                                                         \
+  DMC_DEV T* sg_##name() const {                                                                      \
+    if constexpr (LS::kJGlobal >= 3) return (T*)(DMC_GLB T*)(gscr() + L.gs_##name);                  \
+    else if constexpr (LS::kJGlobal >= 0) return s + L.s_##name;                                      \
+    else return L.d.jglobal >= 3 ? gscr() + L.gs_##name : s + L.s_##name;                             \
+  }
+#else
+#define DMC_SG_ACCESSOR(name) DMC_DEV T* sg_##name() const { return L.d.jglobal >= 3 ? gscr() + L.gs_##name : s + L.s_##name; }
+#endif
+  DMC_SG_ACCESSOR(xquat) DMC_SG_ACCESSOR(geom_xmat) DMC_SG_ACCESSOR(cinert) DMC_SG_ACCESSOR(cdof_dot)
+#undef DMC_SG_ACCESSOR
   // ---- sparse mass matrix ------------------------------------------------------------
   // the nM tree-sparse entries (msparse models): LDS, or the global scratch of a large model
   DMC_DEV T* qMs() const {
 #ifndef DMC_HOST_EMU
-    if constexpr (LS::kJGlobal == 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_M);
+    if constexpr (LS::kJGlobal >= 2) return (T*)(DMC_GLB T*)(gscr() + L.gs_M);
     else if constexpr (LS::kJGlobal >= 0) return S(qM);
     else
 #endif
-    return L.d.jglobal == 2 ? gscr() + L.gs_M : S(qM);
+    return L.d.jglobal >= 2 ? gscr() + L.gs_M : S(qM);
   }
   // qLH <- M (+ diag), packed by columns: zero fill, then the nonzeros (i, j) of the (i, j) list; the list is
   // read from global memory one trip ahead of its use
@@ -1736,7 +1750,7 @@ struct StepCore {
     if (t1 == DMC_GEOM_CYLINDER) t1 = DMC_GEOM_CAPSULE;
     if (t2 == DMC_GEOM_CYLINDER) t2 = DMC_GEOM_CAPSULE;
     const T *p1 = S(geom_xpos) + 3*g1, *p2 = S(geom_xpos) + 3*g2;
-    const T *m1 = S(geom_xmat) + 9*g1, *m2 = S(geom_xmat) + 9*g2;
+    const T *m1 = SG(geom_xmat) + 9*g1, *m2 = SG(geom_xmat) + 9*g2;
     // sizes and bounding radii as private copies: shared model tables, or the environment's own values
     T s1[3], s2[3], rb1 = MR(geom_rbound)[g1], rb2 = MR(geom_rbound)[g2];
     for (int k = 0; k < 3; k++) { s1[k] = MR(geom_size)[3*g1 + k]; s2[k] = MR(geom_size)[3*g2 + k]; }
@@ -2110,7 +2124,7 @@ struct StepCore {
         T quat[4] = {1, 0, 0, 0}, q2inv[4] = {1, 0, 0, 0}, err[4] = {1, 0, 0, 0};
         if (et == DMC_EQ_WELD) {
           T rel[4] = {data[6], data[7], data[8], data[9]}, q1[4], q2[4];
-          for (int a = 0; a < 4; a++) { q1[a] = S(xquat)[4*o1 + a]; q2[a] = S(xquat)[4*o2 + a]; }
+          for (int a = 0; a < 4; a++) { q1[a] = SG(xquat)[4*o1 + a]; q2[a] = SG(xquat)[4*o2 + a]; }
           mul_quat(quat, q1, rel);
           q2inv[0] = q2[0]; q2inv[1] = -q2[1]; q2inv[2] = -q2[2]; q2inv[3] = -q2[3];
           mul_quat(err, q2inv, quat);
@@ -2399,14 +2413,14 @@ struct StepCore {
     for (int j = MI(body_jntadr)[i]; j < MI(body_jntadr)[i] + MI(body_jntnum)[i]; j++) {
       const int t = MI(jnt_type)[j];
       if (t == DMC_JNT_FREE) {
-        for (int k = 0; k < 18; k++) S(cdof_dot)[6*bda + k] = 0;
+        for (int k = 0; k < 18; k++) SG(cdof_dot)[6*bda + k] = 0;
         for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) cvel[a] += S(cdof)[6*(bda + k) + a] * S(qvel)[bda + k];
         dofs += 3;
       }
       if (t == DMC_JNT_FREE || t == DMC_JNT_BALL) {
         for (int k = 0; k < 3; k++) {
           cross_motion(cdd, cvel, S(cdof) + 6*(bda + dofs + k));
-          for (int a = 0; a < 6; a++) S(cdof_dot)[6*(bda + dofs + k) + a] = cdd[a];
+          for (int a = 0; a < 6; a++) SG(cdof_dot)[6*(bda + dofs + k) + a] = cdd[a];
         }
         for (int a = 0; a < 6; a++) tmp[a] = 0;
         for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) tmp[a] += S(cdof)[6*(bda + dofs + k) + a] * S(qvel)[bda + dofs + k];
@@ -2414,7 +2428,7 @@ struct StepCore {
         dofs += 3;
       } else {
         cross_motion(cdd, cvel, S(cdof) + 6*(bda + dofs));
-        for (int a = 0; a < 6; a++) S(cdof_dot)[6*(bda + dofs) + a] = cdd[a];
+        for (int a = 0; a < 6; a++) SG(cdof_dot)[6*(bda + dofs) + a] = cdd[a];
         for (int a = 0; a < 6; a++) cvel[a] += S(cdof)[6*(bda + dofs) + a] * S(qvel)[bda + dofs];
         dofs += 1;
       }
@@ -2441,7 +2455,7 @@ struct StepCore {
           while (hi) { const int m = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[m]; const T* cd = S(cdof) + 6*m; for (int a = 0; a < 6; a++) cv[a] += cd[a]*v; }
           cross_motion(cdd, cv, S(cdof) + 6*k);
         }
-        for (int a = 0; a < 6; a++) S(cdof_dot)[6*k + a] = cdd[a];
+        for (int a = 0; a < 6; a++) SG(cdof_dot)[6*k + a] = cdd[a];
       }
       FOR_LANES(i, L.d.nbody) {
         if (i == 0) continue;
@@ -2479,7 +2493,7 @@ struct StepCore {
                           t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[2] - I[1]) / mass * (T)6),
                           t_sqrt(t_max((T)DMC_MINVAL, I[0] + I[1] - I[2]) / mass * (T)6)};
         T q[4], im[9], lvel[6], lfrc[6] = {0, 0, 0, 0, 0, 0};
-        mul_quat(q, S(xquat) + 4*b, MRC(body_iquat) + 4*b);
+        mul_quat(q, SG(xquat) + 4*b, MRC(body_iquat) + 4*b);
         quat2mat(im, q);
         object_velocity(b, S(xipos) + 3*b, im, lvel);
         const T pi = (T)3.14159265358979323846;
@@ -2563,12 +2577,12 @@ struct StepCore {
         const int ld = MI(body_lastdof)[i];
         if (ld >= 0) {
           unsigned lo = (unsigned)MI(dof_anc_lo)[ld], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[ld] : 0u;
-          while (lo) { const int k = __builtin_ctz(lo); lo &= lo - 1; const T v = S(qvel)[k]; const T* cd = S(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
-          while (hi) { const int k = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[k]; const T* cd = S(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
+          while (lo) { const int k = __builtin_ctz(lo); lo &= lo - 1; const T v = S(qvel)[k]; const T* cd = SG(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
+          while (hi) { const int k = 32 + __builtin_ctz(hi); hi &= hi - 1; const T v = S(qvel)[k]; const T* cd = SG(cdof_dot) + 6*k; for (int a = 0; a < 6; a++) ca[a] += cd[a]*v; }
         }
         for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = ca[a];
-        mul_inert_vec(cf, S(cinert) + 10*i, ca);
-        mul_inert_vec(tmp, S(cinert) + 10*i, S(cvel) + 6*i);
+        mul_inert_vec(cf, SG(cinert) + 10*i, ca);
+        mul_inert_vec(tmp, SG(cinert) + 10*i, S(cvel) + 6*i);
         cross_force(tmp1, S(cvel) + 6*i, tmp);
         for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = cf[a] + tmp1[a];
       }
@@ -2589,11 +2603,11 @@ struct StepCore {
         const int i = MI(level_body)[kk], bda = MI(body_dofadr)[i];
         T tmp[6], tmp1[6], ca[6], cf[6];
         for (int a = 0; a < 6; a++) tmp[a] = 0;
-        for (int k = 0; k < MI(body_dofnum)[i]; k++) for (int a = 0; a < 6; a++) tmp[a] += S(cdof_dot)[6*(bda + k) + a] * S(qvel)[bda + k];
+        for (int k = 0; k < MI(body_dofnum)[i]; k++) for (int a = 0; a < 6; a++) tmp[a] += SG(cdof_dot)[6*(bda + k) + a] * S(qvel)[bda + k];
         for (int a = 0; a < 6; a++) ca[a] = S(cacc)[6*MI(body_parentid)[i] + a] + tmp[a];
         for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = ca[a];
-        mul_inert_vec(cf, S(cinert) + 10*i, ca);
-        mul_inert_vec(tmp, S(cinert) + 10*i, S(cvel) + 6*i);
+        mul_inert_vec(cf, SG(cinert) + 10*i, ca);
+        mul_inert_vec(tmp, SG(cinert) + 10*i, S(cvel) + 6*i);
         cross_force(tmp1, S(cvel) + 6*i, tmp);
         for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = cf[a] + tmp1[a];
       }
@@ -2697,10 +2711,10 @@ struct StepCore {
         T csum[6], tmp[6], tmp1[6], tmp2[6];
         for (int a = 0; a < 6; a++) csum[a] = S(cacc)[6*MI(body_parentid)[i] + a];
         for (int k = 0; k < MI(body_dofnum)[i]; k++) for (int a = 0; a < 6; a++)
-          csum[a] += S(cdof_dot)[6*(bda + k) + a]*S(qvel)[bda + k] + S(cdof)[6*(bda + k) + a]*S(qacc)[bda + k];
+          csum[a] += SG(cdof_dot)[6*(bda + k) + a]*S(qvel)[bda + k] + S(cdof)[6*(bda + k) + a]*S(qacc)[bda + k];
         for (int a = 0; a < 6; a++) S(cacc)[6*i + a] = csum[a];
-        mul_inert_vec(tmp, S(cinert) + 10*i, csum);
-        mul_inert_vec(tmp1, S(cinert) + 10*i, S(cvel) + 6*i);
+        mul_inert_vec(tmp, SG(cinert) + 10*i, csum);
+        mul_inert_vec(tmp1, SG(cinert) + 10*i, S(cvel) + 6*i);
         cross_force(tmp2, S(cvel) + 6*i, tmp1);
         for (int a = 0; a < 6; a++) S(cfrc)[6*i + a] = tmp[a] + tmp2[a] - S(cfrc_ext)[6*i + a];
       }
@@ -2845,7 +2859,7 @@ struct StepCore {
       T v[3], q[4], smat[9], spos[3];
       mul_mat_vec3(v, S(xmat) + 9*body, MRS(site_pos) + 3*id);
       for (int k = 0; k < 3; k++) spos[k] = S(xpos)[3*body + k] + v[k];
-      mul_quat(q, S(xquat) + 4*body, MRS(site_quat) + 4*id);
+      mul_quat(q, SG(xquat) + 4*body, MRS(site_quat) + 4*id);
       quat2mat(smat, q);
       const T* rc = S(subtree_com) + 3*MI(body_rootid)[body];
       if (t == DMC_SENS_TOUCH) {
@@ -2890,16 +2904,16 @@ struct StepCore {
       const int b = MI(site_bodyid)[rid]; T v[3];
       mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*rid);
       for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*b + k] + v[k];
-      mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*rid);
+      mul_quat(q, SG(xquat) + 4*b, MRS(site_quat) + 4*rid);
     } else if (rt == DMC_OBJ_GEOM) {
       for (int k = 0; k < 3; k++) p[k] = S(geom_xpos)[3*rid + k];
-      mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[rid], MRC(geom_quat) + 4*rid);
+      mul_quat(q, SG(xquat) + 4*MI(geom_bodyid)[rid], MRC(geom_quat) + 4*rid);
     } else if (rt == DMC_OBJ_BODY) {
       for (int k = 0; k < 3; k++) p[k] = S(xipos)[3*rid + k];
-      mul_quat(q, S(xquat) + 4*rid, MRC(body_iquat) + 4*rid);
+      mul_quat(q, SG(xquat) + 4*rid, MRC(body_iquat) + 4*rid);
     } else {
       for (int k = 0; k < 3; k++) p[k] = S(xpos)[3*rid + k];
-      for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*rid + k];
+      for (int k = 0; k < 4; k++) q[k] = SG(xquat)[4*rid + k];
     }
   }
   DMC_DEV void sensors(int stage) {
@@ -2919,12 +2933,12 @@ struct StepCore {
           // column c of quat2mat(q) = q rotating the unit vector e_c (no matrix held in memory:
           // selecting between a local array and an LDS array through a pointer pins it in scratch)
           T q[4], e[3] = {c == 0 ? (T)1 : (T)0, c == 1 ? (T)1 : (T)0, c == 2 ? (T)1 : (T)0}, col[3];
-          if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
-          else mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
+          if (ot == DMC_OBJ_SITE) mul_quat(q, SG(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
+          else mul_quat(q, SG(xquat) + 4*id, MRC(body_iquat) + 4*id);
           rot_vec_quat(col, e, q);
           out[0] = col[0]; out[1] = col[1]; out[2] = col[2];
         } else {
-          const T* Rp = ot == DMC_OBJ_GEOM ? S(geom_xmat) + 9*id : S(xmat) + 9*id;
+          const T* Rp = ot == DMC_OBJ_GEOM ? SG(geom_xmat) + 9*id : S(xmat) + 9*id;
           out[0] = Rp[c]; out[1] = Rp[3 + c]; out[2] = Rp[6 + c];
         }
         if (otr >> 16) {      // the axis in the reference frame: conj(q_ref) rotates it
@@ -2961,12 +2975,12 @@ struct StepCore {
         T v[3], sp[3], q[4], e[3] = {0, 0, 1}, vec[3];
         mul_mat_vec3(v, S(xmat) + 9*sb, MRS(site_pos) + 3*id);
         for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*sb + k] + v[k];
-        mul_quat(q, S(xquat) + 4*sb, MRS(site_quat) + 4*id);
+        mul_quat(q, SG(xquat) + 4*sb, MRS(site_quat) + 4*id);
         rot_vec_quat(vec, e, q);
         T best = -1;
         for (int g = 0; g < L.d.ngeom; g++) {
           if (MI(geom_bodyid)[g] == sb || MI(geom_invisible)[g]) continue;
-          const T x = ray_geom_any(S(geom_xpos) + 3*g, S(geom_xmat) + 9*g, MR(geom_size) + 3*g, sp, vec, MI(geom_type)[g]);
+          const T x = ray_geom_any(S(geom_xpos) + 3*g, SG(geom_xmat) + 9*g, MR(geom_size) + 3*g, sp, vec, MI(geom_type)[g]);
           if (x >= 0 && (best < 0 || x < best)) best = x;
         }
         out[0] = best;
@@ -2974,10 +2988,10 @@ struct StepCore {
       else if (t == DMC_SENS_FRAMEQUAT) {
         const int otr = MI(sensor_objtype)[i], ot = otr & 255;
         T q[4];
-        if (ot == DMC_OBJ_SITE) mul_quat(q, S(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
-        else if (ot == DMC_OBJ_GEOM) mul_quat(q, S(xquat) + 4*MI(geom_bodyid)[id], MRC(geom_quat) + 4*id);
-        else if (ot == DMC_OBJ_BODY) mul_quat(q, S(xquat) + 4*id, MRC(body_iquat) + 4*id);
-        else for (int k = 0; k < 4; k++) q[k] = S(xquat)[4*id + k];
+        if (ot == DMC_OBJ_SITE) mul_quat(q, SG(xquat) + 4*MI(site_bodyid)[id], MRS(site_quat) + 4*id);
+        else if (ot == DMC_OBJ_GEOM) mul_quat(q, SG(xquat) + 4*MI(geom_bodyid)[id], MRC(geom_quat) + 4*id);
+        else if (ot == DMC_OBJ_BODY) mul_quat(q, SG(xquat) + 4*id, MRC(body_iquat) + 4*id);
+        else for (int k = 0; k < 4; k++) q[k] = SG(xquat)[4*id + k];
         if (otr >> 16) {      // conj(q_ref) q
           T qr[4], pr[3], qq[4];
           sensor_ref_pose((otr >> 8) & 255, (otr >> 16) - 1, pr, qr);
@@ -3031,7 +3045,7 @@ struct StepCore {
         const int b = MI(site_bodyid)[id]; T v[3], q[4], m[9], sp[3], v6[6];
         mul_mat_vec3(v, S(xmat) + 9*b, MRS(site_pos) + 3*id);
         for (int k = 0; k < 3; k++) sp[k] = S(xpos)[3*b + k] + v[k];
-        mul_quat(q, S(xquat) + 4*b, MRS(site_quat) + 4*id);
+        mul_quat(q, SG(xquat) + 4*b, MRS(site_quat) + 4*id);
         quat2mat(m, q);
         object_velocity(b, sp, m, v6);
         for (int k = 0; k < 3; k++) out[k] = t == DMC_SENS_GYRO ? v6[k] : v6[3 + k];
@@ -3527,7 +3541,7 @@ struct StepCore {
         unsigned lo = (unsigned)MI(dof_anc_lo)[ld], hi = nv > 32 ? (unsigned)MI(dof_anc_hi)[ld] : 0u;
         while (lo) { const int j = __builtin_ctz(lo); lo &= lo - 1; const T vj = v[j]; const T* cd = S(cdof) + 6*j; for (int k = 0; k < 6; k++) a[k] += cd[k]*vj; }
         while (hi) { const int j = 32 + __builtin_ctz(hi); hi &= hi - 1; const T vj = v[j]; const T* cd = S(cdof) + 6*j; for (int k = 0; k < 6; k++) a[k] += cd[k]*vj; }
-        mul_inert_vec(f, S(cinert) + 10*b, a);
+        mul_inert_vec(f, SG(cinert) + 10*b, a);
       }
       for (int k = 0; k < 6; k++) bf[6*b + k] = f[k];
     }
@@ -5209,6 +5223,7 @@ struct StepCore {
 #undef MR
 #undef GC
 #undef S
+#undef SG
 #undef SI
 #undef FOR_LANES
 };

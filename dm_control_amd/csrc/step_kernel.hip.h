@@ -25,6 +25,9 @@ struct LaunchGeom {
 #ifndef DMC_MIN_WAVES
 #define DMC_MIN_WAVES 2   // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef DMC_MAX_THREADS
+#define DMC_MAX_THREADS 320   // workgroups of up to five waves: five 62-dof environments share a CU's LDS (one table copy)
+#endif
 
 // Build-generated: LDS layouts of the suite models, baked in as compile-time
 // constants (dm_control_amd/build.py -> gen_static_layouts).  A batch whose
@@ -157,7 +160,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
 }
 
 template <typename T, int LPE, bool QUEUE>
-__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
+__global__ void __launch_bounds__(DMC_MAX_THREADS, DMC_MIN_WAVES)
 step_kernel(const StepLayout* __restrict__ Lp, StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
             const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   // generic kernel: the layout lives in device memory (uniform scalar loads); taking
@@ -181,7 +184,7 @@ DMC_STATIC_IDS(DMC_DEF_STATIC)
 #undef DMC_DEF_STATIC
 
 template <typename T, int LPE, int SID, bool QUEUE>
-__global__ void __launch_bounds__(256, DMC_MIN_WAVES)
+__global__ void __launch_bounds__(DMC_MAX_THREADS, DMC_MIN_WAVES)
 step_kernel_static(StepOpts<T> o, const int* __restrict__ g_mi, const T* __restrict__ g_mr,
                    const int* __restrict__ g_mc, StepIO<T> io, int nstep, int legacy, int mode, int outmask, int nsub) {
   step_kernel_body<T, LPE, StaticLayout<SID>, QUEUE>(StaticLayout<SID>(), o, g_mi, g_mr, g_mc, io, nstep, legacy, mode, outmask, nsub);

@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 // StepDims::jglobal of a model with nv dofs
-#define DMC_JGLOBAL_LEVEL(nv) ((nv) > 32 ? 2 : ((nv) > 16 ? 1 : 0))
+#define DMC_JGLOBAL_LEVEL(nv) ((nv) > 48 ? 3 : ((nv) > 32 ? 2 : ((nv) > 16 ? 1 : 0)))
 
 struct StepDims {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;
@@ -62,7 +62,9 @@ struct StepDims {
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
   int jglobal;   // what lives in the environment's global scratch / in global memory instead of LDS (DMC_JGLOBAL_LEVEL):
                  //   1 (nv > 16): the compressed contact rows (efc_Jc) and, for noslip models, the kept factor of M;
-                 //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables.
+                 //   2 (nv > 32): also the sparse M, the contact frames and the cold real model tables;
+                 //   3 (nv > 48): also xquat, geom_xmat, cinert and cdof_dot (written once per stage, read in a few places):
+                 //   the 4.8 KB that let a FIFTH 62-dof environment share a CU's LDS.
                  // The residency per CU of these models is bounded by LDS and their step is long enough that a few L2
                  // round trips do not show: level 1 took humanoid 6 -> 8 and the 62-dof models 2 -> 3 environments per
                  // CU, level 2 the 62-dof models to 4; on the 27 / 30-dof models level 2 gains no residency and costs 1-2 %.
@@ -162,20 +164,20 @@ struct StepDims {
   X(qpos, d.nq) X(qvel, d.nv) X(ctrl, d.nu) X(qacc_warmstart, d.nv)            \
   X(act, d.na) X(act_dot, d.na)                                                \
   X(qfrc_applied, d.nv)                                                        \
-  X(xpos, 3 * d.nbody) X(xquat, 4 * d.nbody) X(xmat, 9 * d.nbody)              \
+  X(xpos, 3 * d.nbody) X(xquat, d.jglobal >= 3 ? 0 : 4 * d.nbody) X(xmat, 9 * d.nbody)              \
   X(xipos, 3 * d.nbody)                                                        \
-  X(geom_xpos, 3 * d.ngeom) X(geom_xmat, 9 * d.ngeom)                          \
+  X(geom_xpos, 3 * d.ngeom) X(geom_xmat, d.jglobal >= 3 ? 0 : 9 * d.ngeom)                          \
   X(subtree_com, 3 * d.nbody)                                                  \
-  X(cinert, 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, 6 * d.nv)              \
+  X(cinert, d.jglobal >= 3 ? 0 : 10 * d.nbody) X(cdof, 6 * d.nv) X(cdof_dot, d.jglobal >= 3 ? 0 : 6 * d.nv)              \
   X(cvel, 6 * d.nbody)                                                         \
-  X(qM, d.jglobal == 2 ? 0 : (d.msparse ? d.nM : d.nv * d.nv))  /* sparse: entry p is M(i, j) of the (i, j) list (mpair); global scratch if jglobal */ \
+  X(qM, d.jglobal >= 2 ? 0 : (d.msparse ? d.nM : d.nv * d.nv))  /* sparse: entry p is M(i, j) of the (i, j) list (mpair); global scratch if jglobal */ \
   X(qLH, d.ntri)        /* Cholesky of M, later of H / M+hB: lower triangle packed by columns */ \
   X(qLM, (d.nslip && !d.jglobal) ? d.ntri : 0)   /* noslip models: the factor of M kept beside that of H (noslip needs M^-1 after the solve); global scratch if jglobal */ \
   X(qfrc_bias, d.nv) X(qfrc_passive, d.nv) X(qfrc_actuator, d.nv)              \
   X(qfrc_smooth, d.nv) X(qacc_smooth, d.nv) X(qacc, d.nv)                      \
   X(qfrc_constraint, d.nv) X(actuator_force, d.nu)                             \
   X(sensordata, d.nsensordata)                                                 \
-  X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, d.jglobal == 2 ? 0 : 9 * d.nconmax) \
+  X(con_dist, d.nconmax) X(con_pos, 3 * d.nconmax) X(con_frame, d.jglobal >= 2 ? 0 : 9 * d.nconmax) \
   X(efc_Jd, d.njdense * d.nv) X(efc_Jc, (d.jglobal || d.jfull) ? 0 : d.njcon * d.kmax)                      \
   X(efc_D, d.njmax)     /* holds efc_margin until the row parameters are made */ \
   X(efc_aref, d.njmax)  /* holds efc_pos until the row parameters are made */    \
@@ -266,6 +268,7 @@ struct StepLayout {
   int n_sr, n_si;          // per-env scratch sizes (elements)
   int n_keep;              // reals before the overlay region: what survives a stage (the per-env stash in HBM)
   int n_gs, gs_Jc, gs_LM, gs_M, gs_cf;  // per-env global scratch (reals; 0 unless d.jglobal): size, offsets of efc_Jc, the factor of M, sparse M, con_frame
+  int gs_xquat, gs_geom_xmat, gs_cinert, gs_cdof_dot;      // level 3: the kinematic arrays that left LDS
 };
 
 // scalar options broadcast to every wave
@@ -326,14 +329,21 @@ static inline void step_layout_build(StepLayout* L, const StepDims& d) {
 #undef X
   if (!d.nslip || d.jglobal) L->s_qLM = L->s_qLH;   // no noslip: M's factor is not needed after H's took the buffer -- one buffer
   L->n_gs = L->gs_Jc = L->gs_LM = L->gs_M = L->gs_cf = 0;
+  L->gs_xquat = L->gs_geom_xmat = L->gs_cinert = L->gs_cdof_dot = 0;
   if (d.jglobal) {
     int g = (d.njcon * d.kmax + 31) & ~31;     // 128-byte granules: an environment's arrays never share a cache line
     L->gs_LM = g;
     if (d.nslip) g += (d.ntri + 31) & ~31;
     L->gs_M = g;
-    if (d.jglobal == 2) g += (d.nM + 31) & ~31;
+    if (d.jglobal >= 2) g += (d.nM + 31) & ~31;
     L->gs_cf = g;
-    if (d.jglobal == 2) g += (9 * d.nconmax + 31) & ~31;
+    if (d.jglobal >= 2) g += (9 * d.nconmax + 31) & ~31;
+    if (d.jglobal >= 3) {
+      L->gs_xquat = g; g += (4 * d.nbody + 31) & ~31;
+      L->gs_geom_xmat = g; g += (9 * d.ngeom + 31) & ~31;
+      L->gs_cinert = g; g += (10 * d.nbody + 31) & ~31;
+      L->gs_cdof_dot = g; g += (6 * d.nv + 31) & ~31;
+    }
     L->n_gs = g;
   }
   o = (o + 3) & ~3;
@@ -369,8 +379,12 @@ static inline int step_layout_find(const StepLayout* L, const char* name, int* o
   const StepDims& d = L->d;
   // the debug dump appends the environment's global scratch after its n_sr LDS reals
   if (d.jglobal && !strcmp(name, "efc_Jc")) { *off = L->n_sr + L->gs_Jc; *cnt = d.njcon * d.kmax; *kind = 0; return 1; }
-  if (d.jglobal == 2 && !strcmp(name, "qM")) { *off = L->n_sr + L->gs_M; *cnt = d.nM; *kind = 0; return 1; }
-  if (d.jglobal == 2 && !strcmp(name, "con_frame")) { *off = L->n_sr + L->gs_cf; *cnt = 9 * d.nconmax; *kind = 0; return 1; }
+  if (d.jglobal >= 2 && !strcmp(name, "qM")) { *off = L->n_sr + L->gs_M; *cnt = d.nM; *kind = 0; return 1; }
+  if (d.jglobal >= 2 && !strcmp(name, "con_frame")) { *off = L->n_sr + L->gs_cf; *cnt = 9 * d.nconmax; *kind = 0; return 1; }
+  if (d.jglobal >= 3 && !strcmp(name, "xquat")) { *off = L->n_sr + L->gs_xquat; *cnt = 4 * d.nbody; *kind = 0; return 1; }
+  if (d.jglobal >= 3 && !strcmp(name, "geom_xmat")) { *off = L->n_sr + L->gs_geom_xmat; *cnt = 9 * d.ngeom; *kind = 0; return 1; }
+  if (d.jglobal >= 3 && !strcmp(name, "cinert")) { *off = L->n_sr + L->gs_cinert; *cnt = 10 * d.nbody; *kind = 0; return 1; }
+  if (d.jglobal >= 3 && !strcmp(name, "cdof_dot")) { *off = L->n_sr + L->gs_cdof_dot; *cnt = 6 * d.nv; *kind = 0; return 1; }
 #define X(n, c) if (!strcmp(name, #n)) { *off = L->s_##n; *cnt = (c); *kind = 0; return 1; }
   STEP_SCRATCH_ALL_REAL(X)
 #undef X
