@@ -1138,3 +1138,14 @@ def test_models_without_degrees_of_freedom_step_on_the_device(xml, precision):
   np.testing.assert_allclose(b.get('xpos')[0], np.asarray(o.xpos).ravel(), rtol=0, atol=tol)
   if m.nsensordata:
     np.testing.assert_allclose(b.get('sensordata')[0], np.asarray(o.sensordata).ravel(), rtol=0, atol=tol)
+
+
+def test_config4_model_holds_five_environments_per_cu():
+  """Offload level 3 + five-wave workgroups: the 62-dof walker of BASELINE config 4 at its production caps
+  keeps FIVE environments resident per CU in fp32 (a field added to the LDS scratch would silently cost the fifth: -8 %)."""
+  m = _model('cmu_2019_position_floor')
+  b = _batch(m, 4096, precision=32, nconmax=48)      # (a batch that fills the chip: small ones are spread one wave per CU)
+  info = b.info()
+  assert info['static_id'] >= 0 and info['envs_per_cu'] == 5 and info['waves_per_block'] == 5, info
+  assert info['lds_bytes_per_block'] <= 160 * 1024
+  b.close()
