@@ -17,6 +17,7 @@ Output: `Model` with numpy arrays named like mjModel fields, plus `pack()` which
 serialises them into the blob described by include/dmc_model_layout.h.
 """
 import collections
+import threading
 import copy
 import hashlib
 import contextlib
@@ -40,7 +41,7 @@ _DISABLE_FLAGS = ['constraint', 'equality', 'frictionloss', 'limit', 'contact',
                   'eulerdamp', 'autoreset', 'nativeccd', 'island', 'multiccd']
 _ENABLE_FLAGS = ['override', 'energy', 'fwdinv', 'invdiscrete', 'sleep',
                  'diagexact']
-_ACTUATOR_TAGS = ('motor', 'position', 'velocity', 'general')
+_ACTUATOR_TAGS = ('motor', 'position', 'velocity', 'general', 'cylinder')
 # sensor tag -> (type, object attribute, objtype, dim, needstage)
 _SENSORS = {
     'touch': (C['DMC_SENS_TOUCH'], 'site', C['DMC_OBJ_SITE'], 1, 3),
@@ -171,8 +172,20 @@ class _DefaultClass:
 def _actuator_to_general(tag, a):
   """Rewrites motor/position/velocity shortcut attributes as `general` ones
   (schema: dm_control/mjcf/schema.xml:447-476 and the shortcut elements)."""
-  out = {k: v for k, v in a.items() if k not in ('kp', 'kv')}
-  if tag == 'motor':
+  out = {k: v for k, v in a.items() if k not in ('kp', 'kv', 'timeconst', 'area', 'diameter', 'bias')}
+  if tag == 'cylinder':
+    # pneumatic / hydraulic cylinder (schema.xml <cylinder>): first-order filter on the control with time constant
+    # `timeconst`, gain = piston area (from `diameter` when given), affine bias `bias`
+    area = float(a.get('area', 1))
+    if 'diameter' in a:
+      area = np.pi / 4 * float(a['diameter']) ** 2
+    out['dyntype'] = 'filter'
+    out['dynprm'] = '%r' % float(a.get('timeconst', 1))
+    out['gaintype'] = 'fixed'
+    out['gainprm'] = '%r' % area
+    out['biastype'] = 'affine'
+    out['biasprm'] = a.get('bias', '0 0 0')
+  elif tag == 'motor':
     out.setdefault('gaintype', 'fixed')
     out.setdefault('biastype', 'none')
     out.setdefault('dyntype', 'none')
@@ -198,6 +211,20 @@ def _actuator_to_general(tag, a):
 # ----------------------------------------------------------------------------
 # geometry
 # ----------------------------------------------------------------------------
+def _stl_vertices(data):
+  """Vertices (V, 3) of an STL asset: binary (80-byte header, uint32 triangle count, 50 bytes per facet) or ASCII."""
+  if len(data) >= 84:
+    n = int(np.frombuffer(data[80:84], dtype='<u4')[0])
+    if len(data) == 84 + 50 * n:
+      rec = np.frombuffer(data[84:], dtype=np.dtype([('n', '<f4', 3), ('v', '<f4', (3, 3)), ('a', '<u2')]))
+      return rec['v'].reshape(-1, 3).astype(np.float64)
+  verts = [[float(x) for x in line.split()[1:4]] for line in data.decode('latin-1').splitlines()
+           if line.strip().startswith('vertex')]
+  if not verts:
+    raise MjcfError('mesh asset is not an STL file')
+  return np.array(verts, dtype=np.float64)
+
+
 def _geom_volume_inertia(gtype, size):
   """Volume and unit-density principal inertia (about the geom centre, in the
   geom frame) of a primitive.  Capsule = cylinder + two hemispheres."""
@@ -395,6 +422,8 @@ class _Compiler:
     self.sites = []
     self.lights = []
     self.cameras = []
+    self.camera_specs = []
+    self.meshes = {}      # name -> (V, 3) vertices of the STL asset
     self.actuators = []
     self.sensors = []
     self.excludes = []
@@ -416,6 +445,21 @@ class _Compiler:
         return f.read()
     except OSError:
       raise MjcfError('include file %r not found in assets' % fname)
+
+  def _asset_bytes(self, fname):
+    for c in (fname, fname.lstrip('./'), './' + fname.lstrip('./')):
+      if c in self.assets:
+        t = self.assets[c]
+        return t if isinstance(t, bytes) else t.encode('latin-1')
+    base = fname.split('/')[-1]
+    for k, t in self.assets.items():
+      if k.split('/')[-1] == base:
+        return t if isinstance(t, bytes) else t.encode('latin-1')
+    try:
+      with open(fname, 'rb') as f:
+        return f.read()
+    except OSError:
+      raise MjcfError('asset file %r not found' % fname)
 
   def _expand_includes(self, elem):
     i = 0
@@ -631,7 +675,16 @@ class _Compiler:
         self.lights.append(dict(name=a.get('name'), body=bid, pos=_vec(a['pos'], 3) if 'pos' in a else np.zeros(3),
                                 dir=_vec(a['dir'], 3) if 'dir' in a else np.array([0.0, 0, -1])))
       elif tag == 'camera':
-        self.cameras.append(child.attrib.get('name'))      # rendering only: the count and the names (MjModel.ncam)
+        # rendering only (MjModel.ncam, cam_* arrays): nothing on the device reads them
+        cname = child.attrib.get('class', childclass) or 'main'
+        if cname not in self.classes:
+          raise MjcfError('unknown default class %r' % cname)
+        a = dict(self.classes[cname].get('camera') or {})
+        a.update(child.attrib)
+        self.cameras.append(a.get('name'))
+        self.camera_specs.append(dict(body=bid, pos=_vec(a['pos'], 3) if 'pos' in a else np.zeros(3),
+                                      quat=self._orientation(a), fovy=float(a.get('fovy', 45)),
+                                      mode=('fixed', 'track', 'trackcom', 'targetbody', 'targetbodycom').index(a.get('mode', 'fixed'))))
       elif tag == 'body':
         pass  # handled below so that this body's elements get ids first
       else:
@@ -688,8 +741,18 @@ class _Compiler:
   def _parse_geom(self, elem, bid, childclass):
     a = self._resolve('geom', elem, childclass)
     gtype = _GEOM[a.get('type', 'sphere')]
-    if gtype in (_GEOM['hfield'], _GEOM['mesh']):
-      raise MjcfError('mesh/hfield geoms are not supported')
+    if gtype == _GEOM['hfield']:
+      raise MjcfError('hfield geoms are not supported')
+    mesh_verts = None
+    if gtype == _GEOM['mesh']:
+      # Scenery only: a mesh geom of the WORLD body that no moving geom can collide with would never reach the narrow
+      # phase, so it compiles (frame at the centroid of its vertices, half-extents of its bounding box as `size`);
+      # a mesh that could collide or that carries mass needs the convex-mesh narrow phase this backend does not have.
+      if a.get('mesh') not in self.meshes:
+        raise MjcfError('geom refers to unknown mesh %r' % a.get('mesh'))
+      if bid != 0:
+        raise MjcfError('mesh geoms are only supported as scenery of the world body (mesh collision is not implemented)')
+      mesh_verts = self.meshes[a['mesh']]
     size = np.zeros(3)
     if 'size' in a:
       s = _vec(a['size'])
@@ -710,8 +773,12 @@ class _Compiler:
         size[2] = length / 2
       pos = 0.5 * (ft[:3] + ft[3:])
       quat = z_to_quat(vec)
+    if mesh_verts is not None:
+      lo, hi = mesh_verts.min(axis=0), mesh_verts.max(axis=0)
+      pos = pos + rot_vec(quat, 0.5 * (lo + hi))
+      size = np.maximum(0.5 * (hi - lo), MINVAL)
     need = {_GEOM['sphere']: 1, _GEOM['capsule']: 2, _GEOM['cylinder']: 2,
-            _GEOM['box']: 3, _GEOM['ellipsoid']: 3, _GEOM['plane']: 0}[gtype]
+            _GEOM['box']: 3, _GEOM['ellipsoid']: 3, _GEOM['plane']: 0, _GEOM['mesh']: 3}[gtype]
     if gtype != _GEOM['plane'] and np.any(size[:need] <= 0):
       raise MjcfError('geom %r: size must be positive' % a.get('name'))
     fr = np.array([1.0, 0.005, 0.0001])
@@ -879,6 +946,14 @@ class _Compiler:
         rgba = _vec(mat.get('rgba', '1 1 1 1'))
         self.material_alpha[mat.get('name')] = float(rgba[3]) if rgba.size == 4 else 1.0
         self.materials.append((mat.get('name'), rgba if rgba.size == 4 else np.ones(4)))
+      for tex in asset.findall('texture'):
+        if tex.get('file'):
+          self._asset_bytes(tex.get('file'))      # (render-only; a missing file fails the load as it does in MuJoCo)
+      for mesh in asset.findall('mesh'):
+        f = mesh.get('file')
+        if f:
+          name = mesh.get('name') or os.path.splitext(os.path.basename(f))[0]
+          self.meshes[name] = _stl_vertices(self._asset_bytes(f)) * (_vec(mesh.get('scale', '1 1 1'), 3))
     self._parse_body(wb, -1, None)
     self._parse_actuators()
     self._parse_tendons()
@@ -1049,6 +1124,12 @@ class _Compiler:
     m.site_sameframe = np.zeros(nsite, dtype=np.int64)
     # sizes and names of what this backend does not simulate but MjModel counts (suite/suite_test.py:107-139 walks them)
     m.ncam = len(self.cameras)
+    cs = self.camera_specs
+    m.cam_bodyid = np.array([c['body'] for c in cs], dtype=np.int64)
+    m.cam_mode = np.array([c['mode'] for c in cs], dtype=np.int64)
+    m.cam_pos = np.array([c['pos'] for c in cs], dtype=np.float64).reshape(len(cs), 3)
+    m.cam_quat = np.array([c['quat'] for c in cs], dtype=np.float64).reshape(len(cs), 4)
+    m.cam_fovy = np.array([c['fovy'] for c in cs], dtype=np.float64)
     assets = [e for sec in self.root.findall('asset') for e in sec]
     custom = [e for sec in self.root.findall('custom') for e in sec]
 
@@ -1064,6 +1145,19 @@ class _Compiler:
                            tuple=named(custom, 'tuple'))
     m.nmesh, m.nhfield, m.ntex = (len(self._aux_names[k]) for k in ('mesh', 'hfield', 'texture'))
     m.nnumeric, m.ntext, m.ntuple = (len(self._aux_names[k]) for k in ('numeric', 'text', 'tuple'))
+    # <custom><numeric>: host-side constants tasks read by name (mujoco/index.py:93-99 'nnumericdata'); `size` pads with zeros
+    nums = []
+    for e in custom:
+      if e.tag == 'numeric':
+        d = _vec(e.get('data', '0'))
+        n = int(e.get('size', d.size))
+        nums.append(np.concatenate([d, np.zeros(max(0, n - d.size))])[:max(n, 1)])
+    m.numeric_size = np.array([a.size for a in nums], dtype=np.int64)
+    m.numeric_adr = np.concatenate([[0], np.cumsum(m.numeric_size)])[:-1].astype(np.int64) if nums else np.zeros(0, dtype=np.int64)
+    m.numeric_data = np.concatenate(nums) if nums else np.zeros(0)
+    m.nnumericdata = int(m.numeric_data.size)
+    m.mesh_vert = (np.concatenate([self.meshes[n] for n in self._aux_names['mesh'] if n in self.meshes])
+                   if any(n in self.meshes for n in self._aux_names['mesh']) else np.zeros((0, 3)))
     m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(nsite, 4)
     # inertial properties
     self._body_inertias(m)
@@ -1621,6 +1715,7 @@ def _robust_inverse(mat):
 
 
 _COMPILE_CACHE = collections.OrderedDict()
+_COMPILE_LOCK = threading.Lock()
 _COMPILE_CACHE_SIZE = 16
 
 
@@ -1654,6 +1749,8 @@ def candidate_pairs(m):
           t1, t2 = m.geom_type[g1], m.geom_type[g2]
           if t1 == _GEOM['plane'] and t2 == _GEOM['plane']:
             continue
+          if _GEOM['mesh'] in (t1, t2):
+            raise MjcfError('a mesh geom is in contact range of a moving geom: mesh collision is not implemented')
           pairs.append((g2, g1) if t1 > t2 else (g1, g2))
   m.npair = len(pairs)
   m.pair_geom1 = np.array([p[0] for p in pairs], dtype=np.int64)
@@ -1676,12 +1773,14 @@ def compile_xml(xml_string, assets=None, cache=True):
     v = assets[k]
     h.update(b'\0' + k.encode() + b'\0' + (v if isinstance(v, bytes) else v.encode()))
   key = h.digest()
-  hit = _COMPILE_CACHE.get(key)
+  with _COMPILE_LOCK:      # (models are loaded from several threads at once: mujoco/thread_safety_test.py:53-75)
+    hit = _COMPILE_CACHE.get(key)
+    if hit is not None:
+      _COMPILE_CACHE.move_to_end(key)
   if hit is None:
     hit = _Compiler(xml_string, assets).compile()
-    _COMPILE_CACHE[key] = hit
-    while len(_COMPILE_CACHE) > _COMPILE_CACHE_SIZE:
-      _COMPILE_CACHE.popitem(last=False)
-  else:
-    _COMPILE_CACHE.move_to_end(key)
+    with _COMPILE_LOCK:
+      _COMPILE_CACHE[key] = hit
+      while len(_COMPILE_CACHE) > _COMPILE_CACHE_SIZE:
+        _COMPILE_CACHE.popitem(last=False)
   return copy.deepcopy(hit)

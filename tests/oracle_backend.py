@@ -125,6 +125,20 @@ class OracleBatch:
       o.step(int(nstep))
     self._stale = False
 
+  def step1(self, stream=None):
+    del stream
+    for o in self._envs:
+      o.step1()
+    self._stale = False
+
+  def step2(self, stream=None):
+    del stream
+    for o in self._envs:
+      if getattr(self, '_stale', False):
+        o.step1()      # (dmc_batch_step2 recomputes the stage when the state was edited in between)
+      o.step2()
+    self._stale = False
+
   def forward(self, disable_actuation=False, stream=None):
     del stream
     import time

@@ -89,6 +89,10 @@ class _TestCase(unittest.TestCase, metaclass=_ParamMeta):
         self.assertEqual(x, y, msg or '%s differs' % path)
     walk(a, b, aname)
 
+  def assertContainsSubset(self, expected_subset, actual_set, msg=None):
+    missing = set(expected_subset) - set(actual_set)
+    self.assertFalse(missing, msg or 'missing elements: %r' % sorted(missing))
+
   def assertBetween(self, value, lo, hi, msg=None):
     self.assertTrue(lo <= value <= hi, msg or '%r not in [%r, %r]' % (value, lo, hi))
 
@@ -131,6 +135,9 @@ def _install(modules):
   absl.__path__, testing.__path__ = [], []
   absltest, parameterized = types.ModuleType('absl.testing.absltest'), types.ModuleType('absl.testing.parameterized')
   absltest.TestCase, absltest.main, absltest.mock = _TestCase, (lambda *a, **k: None), _mock
+  import tempfile
+  absltest.get_default_test_tmpdir = lambda: os.path.join(tempfile.gettempdir(), 'dmc_amd_absl_testing')
+  absltest.unittest = unittest
   parameterized.TestCase, parameterized.parameters = _TestCase, _parameters
   parameterized.named_parameters = _named_parameters
   absl.testing, testing.absltest, testing.parameterized = testing, absltest, parameterized
