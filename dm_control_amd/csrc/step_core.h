@@ -4787,7 +4787,6 @@ struct StepCore {
       u64 tm = 0;
       for (int i = 0; i < nv; i++) if (row_entry(r, i, rm) != 0) tm |= (u64)1 << dof_root(i);
       SI(efc_tree)[2*r] = (int)(unsigned)tm; SI(efc_tree)[2*r + 1] = (int)(unsigned)(tm >> 32);
-      for (u64 m = tm; m; m &= m - 1) { const int t = ctz64(m); DMC_ATOMIC_OR(&SI(isl_comp)[2*t], (int)(unsigned)tm); DMC_ATOMIC_OR(&SI(isl_comp)[2*t + 1], (int)(unsigned)(tm >> 32)); }
     }
     DMC_WSYNC();
     // the rows of one contact travel together (a tangential row may move nothing on its own): every contact row takes
@@ -4799,6 +4798,13 @@ struct StepCore {
       u64 tm = 0;
       for (int q = r0; q < r0 + nr && q < nefc; q++) tm |= row_trees(q);
       SI(efc_tree)[2*r] = (int)(unsigned)tm; SI(efc_tree)[2*r + 1] = (int)(unsigned)(tm >> 32);
+    }
+    DMC_WSYNC();
+    // every row joins the trees of its (unioned) mask -- AFTER the union: the normal row of an elliptic contact may move
+    // only tree B and a tangent row only tree A; mj_island unites all dofs over the whole row group of the contact
+    for (int r = lane; r < nefc; r += LPE) {
+      const u64 tm = row_trees(r);
+      for (u64 m = tm; m; m &= m - 1) { const int t = ctz64(m); DMC_ATOMIC_OR(&SI(isl_comp)[2*t], (int)(unsigned)tm); DMC_ATOMIC_OR(&SI(isl_comp)[2*t + 1], (int)(unsigned)(tm >> 32)); }
     }
     DMC_WSYNC();
     // transitive closure: every pass at least doubles the path length covered (6 passes: 64 trees).  In place: the masks only

@@ -779,6 +779,7 @@ _OUT = ('sensordata', 'xpos', 'xquat', 'xmat', 'xipos', 'geom_xpos', 'geom_xmat'
         'actuator_force', 'qfrc_actuator', 'qfrc_bias', 'qfrc_constraint', 'cvel')
 _DERIVED = ('ximat', 'xanchor', 'xaxis', 'cam_xpos', 'cam_xmat', 'light_xpos', 'light_xdir', 'ten_length', 'ten_velocity', 'wrap_xpos',
             'M', 'qM', 'qLD', 'qLDiagInv', 'subtree_linvel', 'subtree_angmom', 'act_dot', 'energy', 'qfrc_passive')
+_ON_REQUEST = ('subtree_linvel', 'subtree_angmom')
 # field -> shape as (size name | int, ...): what mjbindings.sizes.array_sizes lists for mjData
 DATA_SHAPES = {
     'qpos': ('nq',), 'qvel': ('nv',), 'act': ('na',), 'ctrl': ('nu',), 'qacc_warmstart': ('nv',), 'qfrc_applied': ('nv',),
@@ -963,6 +964,7 @@ class MjData(metaclass=_DataMeta):
     old, self._batch = self._batch, batch
     self._nconmax = int(batch.info().get('nconmax', 0)) or 16
     self._pushed = tuple(a.copy() for a in self._packed_model())
+    self._fingerprint = self._model_fingerprint()
     if carry is not None:
       for name, a in carry.items():
         if name == 'xfrc_applied' and not a.any():
@@ -1059,8 +1061,30 @@ class MjData(metaclass=_DataMeta):
   _MUTABLE = ('dof_damping', 'jnt_stiffness', 'jnt_range', 'jnt_margin', 'qpos_spring', 'site_pos', 'site_quat', 'site_size',
               'actuator_ctrlrange', 'actuator_forcerange', 'wrap_prm', 'body_pos', 'body_quat', 'geom_pos', 'geom_quat', 'geom_size')
 
+  def _model_fingerprint(self):
+    """Every number the model blob is made of, flat (one concatenate: this runs before every launch)."""
+    c = self._model._c
+    x = _extras(c)
+    names = x.get('_blob_fields')
+    if names is None:
+      names = x['_blob_fields'] = [n for n, _ in _layout.INT_FIELDS] + [n for n, _ in _layout.REAL_FIELDS]
+    o = c.opt
+    parts = [np.asarray(getattr(c, n), dtype=np.float64).ravel() for n in names]
+    parts.append(np.array([o.timestep, o.gravity[0], o.gravity[1], o.gravity[2], o.impratio, o.tolerance, o.ls_tolerance,
+                           o.noslip_tolerance, o.density, o.viscosity, c.stat_meaninertia, o.integrator, o.cone, o.solver,
+                           o.iterations, o.ls_iterations, o.noslip_iterations, o.disableflags, o.enableflags], dtype=np.float64))
+    ea = self._arrays.get('eq_active')
+    if ea is not None:
+      parts.append(np.asarray(ea, dtype=np.float64))
+    return np.concatenate(parts)
+
   def _sync_model(self):
     """Brings the device's model tables up to the MjModel as it stands now (see the module docstring)."""
+    fp = self._model_fingerprint()
+    old = self.__dict__.get('_fingerprint')
+    if old is not None and old.shape == fp.shape and np.array_equal(fp, old, equal_nan=True):
+      return
+    self._fingerprint = fp
     ints, reals = self._packed_model()
     pi, pr = self._pushed
     if ints.shape == pi.shape and reals.shape == pr.shape and np.array_equal(ints, pi) and np.array_equal(reals, pr, equal_nan=True):
@@ -1191,7 +1215,9 @@ class MjData(metaclass=_DataMeta):
       # mj_fwdActuation zeroes its COPY of a bad control vector: mjData.ctrl keeps what the caller wrote, the device's
       # array does not -- the next launch uploads (and reports) it again
       self._shadow['ctrl'] = np.asarray(b.get('ctrl'), dtype=np.float64).reshape(self._shape('ctrl'))
-    self._refresh_fields([n for n in self._arrays if n in _OUT or n in _DERIVED or n == 'contact'])
+    # (subtree_linvel / subtree_angmom: mj_subtreeVel is not part of mj_step / mj_forward -- as in MuJoCo they are brought up
+    # by an explicit mj_subtreeVel call, which legacy_base.Walker.after_substep makes)
+    self._refresh_fields([n for n in self._arrays if n in _OUT or (n in _DERIVED and n not in _ON_REQUEST) or n == 'contact'])
 
   def _host_callbacks(self):
     """mjcb_control / mjcb_passive: called on the host before the launch of ONE physics step.  Whatever mjcb_passive adds
@@ -1237,10 +1263,10 @@ class MjData(metaclass=_DataMeta):
       b.step2()
     elif kind == 'forward':
       b.forward(bool(int(self._model._c.opt.disableflags) & C['DMC_DSBL_ACTUATION']))
-    if extra is not None:
-      fa[:] = keep
-    self._fresh_forward = kind == 'forward'
+    self._fresh_forward = kind == 'forward' and extra is None
     self._after_launch(kind in ('step', 'step2'))
+    if extra is not None:
+      fa[:] = keep      # (differs from what the device now holds: the next launch uploads it)
 
   def _ensure_forward(self):
     """mj_fwdActuation / mj_fwdAcceleration / mj_fwdConstraint: the fused kernel cannot run one stage of mj_forward
@@ -1259,12 +1285,23 @@ class MjData(metaclass=_DataMeta):
 
   # -- copy / pickle ------------------------------------------------------------------------------------------------
   def _snapshot(self):
+    """Everything a copy needs: the inputs, and every derived array AS IT STANDS (after mj_step the position-dependent
+    arrays belong to the state before the integration; a copy must show the same values, so they are carried, not
+    recomputed)."""
     self._upload()
+    arrays = {k: np.array(v) for k, v in self._arrays.items()}
+    if self._outputs_valid:
+      for n in _OUT:
+        if n not in arrays:
+          arrays[n] = np.asarray(self._batch.get(n), dtype=np.float64).reshape(self._shape(n))
+      if 'contact' not in arrays:
+        self.contact      # pylint: disable=pointless-statement  (materialises the buffer)
+        arrays['contact'] = np.array(self._arrays['contact'])
     return {'inputs': {n: np.asarray(self._batch.get(n), dtype=np.float64) for n in _IN},
-            'time': self._time, 'arrays': {k: np.array(v) for k, v in self._arrays.items()},
+            'time': self._time, 'arrays': arrays,
             'ints': dict(self._ints), 'warning': {k: v.copy() for k, v in self._warning._fields.items()},
             'solver': {k: v.copy() for k, v in self._solver._fields.items()},
-            'outputs_valid': self._outputs_valid, 'fresh_forward': self._fresh_forward}
+            'outputs_valid': self._outputs_valid}
 
   def _restore(self, snap):
     b = self._batch
@@ -1275,22 +1312,14 @@ class MjData(metaclass=_DataMeta):
         self._xfrc_sent = True
       b.set(n, a.reshape(1, -1))
     b.set('time', np.array([[snap['time']]]))
-    if snap['outputs_valid']:
-      # the derived arrays of the device are brought up at the copied state; the solver warm start that mj_forward moved is
-      # put back, so that the copy continues bit-identically (engine_test.py:549-572, core_test.py:172-200)
-      b.forward(bool(int(self._model._c.opt.disableflags) & C['DMC_DSBL_ACTUATION']))
-      b.set('qacc_warmstart', snap['inputs']['qacc_warmstart'].reshape(1, -1))
-      self._warn_dev[:] = 0
-      w = np.asarray(b.get('warning')).astype(np.int64).ravel()
-      self._warn_dev[:w.size] = w[:self._warn_dev.size]
     self._pull_inputs()
-    self._outputs_valid = snap['outputs_valid']
     self._fresh_forward = False
     self._ints = dict(snap['ints'])
     for k, v in snap['warning'].items():
       self._warning._fields[k][...] = v
     for k, v in snap['solver'].items():
       self._solver._fields[k][...] = v
+    self._outputs_valid = False      # (materialise without reading THIS batch's device arrays: they hold nothing yet)
     for k, v in snap['arrays'].items():
       if k == 'contact':
         self.contact      # pylint: disable=pointless-statement  (allocates the buffer)
@@ -1298,6 +1327,7 @@ class MjData(metaclass=_DataMeta):
         self._arrays['contact'][:n] = v[:n]
       else:
         np.copyto(self._array(k), v)
+    self._outputs_valid = snap['outputs_valid']
 
   def __copy__(self):
     other = MjData(self._model)
@@ -1330,42 +1360,79 @@ def _unpickle_data(model, snap):
 # ---------------------------------------------------------------------------------------------------------------------
 # host-side derivations of the mjData arrays the kernel keeps on chip
 # ---------------------------------------------------------------------------------------------------------------------
+def _cross(a, b):
+  return np.stack([a[..., 1]*b[..., 2] - a[..., 2]*b[..., 1], a[..., 2]*b[..., 0] - a[..., 0]*b[..., 2],
+                   a[..., 0]*b[..., 1] - a[..., 1]*b[..., 0]], axis=-1)
+
+
+def _joint_plan(c):
+  """Per model: the joints grouped by their rank counted from the LAST joint of their body (pass r of joint_frames
+  handles every rank-r joint of the model at once)."""
+  x = _extras(c)
+  plan = x.get('_joint_plan')
+  if plan is None:
+    rank = np.zeros(c.njnt, dtype=np.int64)
+    for b in range(c.nbody):
+      j0, jn = int(c.body_jntadr[b]), int(c.body_jntnum[b])
+      for k in range(jn):
+        rank[j0 + k] = jn - 1 - k
+    typ = np.asarray(c.jnt_type, dtype=np.int64)
+    passes = []
+    for r in range(int(rank.max()) + 1 if c.njnt else 0):
+      js = np.nonzero(rank == r)[0]
+      passes.append({'j': js, 'b': np.asarray(c.jnt_bodyid, dtype=np.int64)[js], 't': typ[js],
+                     'qa': np.asarray(c.jnt_qposadr, dtype=np.int64)[js]})
+    plan = x['_joint_plan'] = passes
+  return plan
+
+
 def joint_frames(c, qpos, xpos, xquat, mocap_pos=None, mocap_quat=None):
-  """mjData.xanchor / xaxis: mj_kinematics' joint loop replayed from qpos and the parents' frames -- each joint's anchor and
-  axis are taken in the body frame accumulated BEFORE that joint moves it."""
-  Cq = mjcf_compiler
+  """mjData.xanchor / xaxis.  mj_kinematics takes each joint's anchor and axis in the body frame accumulated BEFORE that
+  joint moves it; here the walk runs the other way, from the body's FINAL frame (the device's xpos / xquat) back through
+  its joints: a hinge or ball rotation leaves its own anchor and axis where they were, a slide moves the frame along its
+  axis.  One vectorised pass per joint rank within a body (at most three in the suite models)."""
+  del mocap_pos, mocap_quat      # (a mocap body has no joints; its children start from its device frame like any other)
   anchor, axis = np.zeros((c.njnt, 3)), np.zeros((c.njnt, 3))
-  nmocap = int(getattr(c, 'nmocap', 0))
-  for b in range(1, c.nbody):
-    j0, jn = int(c.body_jntadr[b]), int(c.body_jntnum[b])
-    if jn == 0:
-      continue
-    if jn == 1 and c.jnt_type[j0] == 0:
-      qa = int(c.jnt_qposadr[j0])
-      anchor[j0] = qpos[qa:qa + 3]
-      axis[j0] = c.jnt_axis[j0]
-      continue
-    pid = int(c.body_parentid[b])
-    bp, bq = c.body_pos[b], c.body_quat[b]
-    if nmocap and c.body_mocapid[b] >= 0 and mocap_pos is not None:
-      k = int(c.body_mocapid[b])
-      bp, bq = mocap_pos[k], mocap_quat[k] / np.linalg.norm(mocap_quat[k])
-    pos = xpos[pid] + Cq.quat_to_mat(xquat[pid]) @ bp if pid else np.array(bp, dtype=np.float64)
-    quat = Cq.quat_mul(xquat[pid], bq) if pid else np.array(bq, dtype=np.float64)
-    for j in range(j0, j0 + jn):
-      R = Cq.quat_to_mat(quat)
-      axis[j] = R @ c.jnt_axis[j]
-      anchor[j] = R @ c.jnt_pos[j] + pos
-      qa, t = int(c.jnt_qposadr[j]), int(c.jnt_type[j])
-      if t == 2:
-        pos = pos + axis[j] * (qpos[qa] - c.qpos0[qa])
-      else:
-        if t == 1:
-          qloc = qpos[qa:qa + 4] / np.linalg.norm(qpos[qa:qa + 4])
-        else:
-          qloc = Cq.axisangle_to_quat(c.jnt_axis[j], qpos[qa] - c.qpos0[qa])
-        quat = Cq.quat_mul(quat, qloc)
-        pos = anchor[j] - Cq.quat_to_mat(quat) @ c.jnt_pos[j]
+  if not c.njnt:
+    return anchor, axis
+  pos, quat = np.array(xpos, dtype=np.float64), np.array(xquat, dtype=np.float64)      # current frame per body
+  jaxis, jpos = np.asarray(c.jnt_axis, dtype=np.float64), np.asarray(c.jnt_pos, dtype=np.float64)
+  q0 = np.asarray(c.qpos0, dtype=np.float64)
+  for ps in _joint_plan(c):
+    js, bs, ts, qa = ps['j'], ps['b'], ps['t'], ps['qa']
+    R = _quat_to_mat_rows(quat[bs]).reshape(-1, 3, 3)
+    ax = np.einsum('nij,nj->ni', R, jaxis[js])
+    an = pos[bs] + np.einsum('nij,nj->ni', R, jpos[js])
+    free, ball, slide, hinge = ts == 0, ts == 1, ts == 2, ts == 3
+    if free.any():
+      k = np.nonzero(free)[0]
+      an[k] = np.stack([qpos[qa[k]], qpos[qa[k] + 1], qpos[qa[k] + 2]], axis=1)
+      ax[k] = jaxis[js[k]]
+    if slide.any():
+      k = np.nonzero(slide)[0]
+      shift = ax[k] * (qpos[qa[k]] - q0[qa[k]])[:, None]
+      an[k] -= shift
+      pos[bs[k]] -= shift
+    rot = hinge | ball
+    if rot.any():
+      k = np.nonzero(rot)[0]
+      qloc = np.zeros((k.size, 4))
+      kh = hinge[k]
+      if kh.any():
+        ang = (qpos[qa[k[kh]]] - q0[qa[k[kh]]]) / 2
+        qloc[kh, 0] = np.cos(ang)
+        qloc[kh, 1:] = jaxis[js[k[kh]]] * np.sin(ang)[:, None]
+      kb = ~kh
+      if kb.any():
+        qb = np.stack([qpos[qa[k[kb]] + i] for i in range(4)], axis=1)
+        qloc[kb] = qb / np.linalg.norm(qb, axis=1, keepdims=True)
+      qprev = _quat_mul_rows(quat[bs[k]], qloc * np.array([1.0, -1, -1, -1]))
+      quat[bs[k]] = qprev
+      Rp = _quat_to_mat_rows(qprev).reshape(-1, 3, 3)
+      pos[bs[k]] = an[k] - np.einsum('nij,nj->ni', Rp, jpos[js[k]])
+      if kb.any():      # (a ball joint turns its own nominal axis: mjData.xaxis is the axis BEFORE the joint acts)
+        ax[k[kb]] = np.einsum('nij,nj->ni', Rp[kb], jaxis[js[k[kb]]])
+    anchor[js], axis[js] = an, ax
   return anchor, axis
 
 
@@ -1383,34 +1450,45 @@ def _quat_to_mat_rows(q):
                    2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z], axis=1)
 
 
+def _dof_plan(c):
+  x = _extras(c)
+  plan = x.get('_dof_plan')
+  if plan is None:
+    nv = c.nv
+    kind = np.zeros(nv, dtype=np.int64)      # 0: world axis (free translation), 1: a column of the body's xmat, 2: the joint's xaxis
+    col, jnt, body, rot, fixed_anchor = (np.zeros(nv, dtype=np.int64) for _ in range(5))
+    for j in range(c.njnt):
+      d, t, b = int(c.jnt_dofadr[j]), int(c.jnt_type[j]), int(c.jnt_bodyid[j])
+      n = {0: 6, 1: 3}.get(t, 1)
+      jnt[d:d + n], body[d:d + n] = j, b
+      if t == 0:
+        kind[d:d + 3], col[d:d + 3] = 0, np.arange(3)
+        kind[d + 3:d + 6], col[d + 3:d + 6], rot[d + 3:d + 6], fixed_anchor[d + 3:d + 6] = 1, np.arange(3), 1, 1
+      elif t == 1:
+        kind[d:d + 3], col[d:d + 3], rot[d:d + 3] = 1, np.arange(3), 1
+      else:
+        kind[d], rot[d] = 2, int(t == 3)
+    plan = x['_dof_plan'] = dict(kind=kind, col=col, jnt=jnt, body=body, rot=rot.astype(bool), free_rot=fixed_anchor.astype(bool))
+  return plan
+
+
 def mass_matrix(c, xpos, xmat, xipos, ximat, xanchor, xaxis):
   """Dense joint-space inertia M(q) (what mj_crb leaves in mjData.M) from world-frame body Jacobians:
   M = sum_b m_b Jp_b' Jp_b + Jr_b' (R_b I_b R_b') Jr_b + diag(dof_armature)."""
   nv, nb = c.nv, c.nbody
   x = _extras(c)
-  axis, anchor, rot = np.zeros((nv, 3)), np.zeros((nv, 3)), np.zeros(nv, dtype=bool)
-  for j in range(c.njnt):
-    d, t, b = int(c.jnt_dofadr[j]), int(c.jnt_type[j]), int(c.jnt_bodyid[j])
-    R = xmat[b].reshape(3, 3)
-    if t == 0:
-      axis[d:d + 3] = np.eye(3)
-      axis[d + 3:d + 6] = R.T
-      anchor[d + 3:d + 6] = xpos[b]
-      rot[d + 3:d + 6] = True
-    elif t == 1:
-      axis[d:d + 3] = R.T
-      anchor[d:d + 3] = xanchor[j]
-      rot[d:d + 3] = True
-    else:
-      axis[d] = xaxis[j]
-      anchor[d] = xanchor[j]
-      rot[d] = t == 3
+  p = _dof_plan(c)
+  R = np.asarray(xmat, dtype=np.float64).reshape(nb, 3, 3)
+  axis = np.where((p['kind'] == 2)[:, None], xaxis[p['jnt']], R[p['body'], :, p['col']])
+  axis = np.where((p['kind'] == 0)[:, None], np.eye(3)[p['col']], axis)
+  anchor = np.where(p['free_rot'][:, None], xpos[p['body']], xanchor[p['jnt']])
+  rot = p['rot']
   mask = x['body_dofmask']                                   # (nb, nv)
   r = xipos[:, None, :] - anchor[None, :, :]                 # (nb, nv, 3)
-  jp = np.where(rot[None, :, None], np.cross(axis[None, :, :], r), axis[None, :, :]) * mask[:, :, None]
+  jp = np.where(rot[None, :, None], _cross(np.broadcast_to(axis[None, :, :], r.shape), r), axis[None, :, :]) * mask[:, :, None]
   jr = np.where(rot[None, :, None], axis[None, :, :], 0.0) * mask[:, :, None]
-  R = ximat.reshape(nb, 3, 3)
-  jl = np.einsum('bji,bkj->bki', R, jr)                      # angular Jacobian in the inertial frame: (nb, nv, 3)
+  Ri = np.asarray(ximat, dtype=np.float64).reshape(nb, 3, 3)
+  jl = np.einsum('bji,bkj->bki', Ri, jr)                     # angular Jacobian in the inertial frame: (nb, nv, 3)
   M = np.einsum('b,bki,bli->kl', np.asarray(c.body_mass, dtype=np.float64), jp, jp)
   M += np.einsum('bki,bi,bli->kl', jl, np.asarray(c.body_inertia, dtype=np.float64), jl)
   M[np.diag_indices(nv)] += np.asarray(c.dof_armature, dtype=np.float64)
@@ -1611,22 +1689,17 @@ def _subtree_vel(d, dev, xpos, ximat):
   mass = np.asarray(c.body_mass, dtype=np.float64)
   sub = _extras(c)['subtree'].astype(np.float64)                  # (root, body)
   ang = cvel[:, :3]
-  lin = cvel[:, 3:] + np.cross(ang, xipos - com[np.asarray(c.body_rootid)])      # velocity of each body's own COM
+  lin = cvel[:, 3:] + _cross(ang, xipos - com[np.asarray(c.body_rootid)])      # velocity of each body's own COM
   msub = np.maximum(sub @ mass, mjMINVAL)
   vsub = (sub @ (mass[:, None] * lin)) / msub[:, None]
   if 'subtree_linvel' in A:
     np.copyto(A['subtree_linvel'], vsub)
   if 'subtree_angmom' in A:
     R = ximat.reshape(nb, 3, 3)
-    Iw = np.einsum('bij,bj,bkj->bik', R, np.asarray(c.body_inertia, dtype=np.float64), R)
-    spin = np.einsum('bik,bk->bi', Iw, ang)
-    out = np.zeros((nb, 3))
-    for r in range(nb):
-      members = sub[r] > 0
-      dx = xipos[members] - com[r]
-      dv = lin[members] - vsub[r]
-      out[r] = spin[members].sum(axis=0) + np.sum(mass[members, None] * np.cross(dx, dv), axis=0)
-    np.copyto(A['subtree_angmom'], out)
+    spin = np.einsum('bij,bj,bkj,bk->bi', R, np.asarray(c.body_inertia, dtype=np.float64), R, ang)
+    # sum_b [I w + m (x - X) x (v - V)] = sum_b [I w + m x x v] - M X x V   (X, V: the subtree's centre of mass and its velocity)
+    own = spin + mass[:, None] * _cross(xipos, lin)
+    np.copyto(A['subtree_angmom'], sub @ own - msub[:, None] * _cross(com, vsub))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1835,7 +1908,7 @@ def mj_objectVelocity(m, d, objtype, objid, res, flg_local):
   if int(objtype) not in kinds:
     raise FatalError('mj_objectVelocity: invalid object type %d' % int(objtype))
   kind, posf, matf = kinds[int(objtype)]
-  get = lambda n, *shape: np.asarray(d._batch.get(n), dtype=np.float64).reshape(shape)
+  get = lambda n, *shape: d._array(n).reshape(shape)
   objid = int(objid)
   body = objid if kind == 'body' else int(c.geom_bodyid[objid]) if kind == 'geom' else int(c.site_bodyid[objid])
   n = {'body': c.nbody, 'geom': c.ngeom, 'site': c.nsite}[kind]

@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/.."
 rm -rf _refstage
 mkdir -p _refstage
-(cd /root/reference && find dm_control \( -name '*.py' -o -name '*.xml' -o -name 'test_00*.textproto' -o -path '*soccer/assets/boxhead/*.png' -o -path '*soccer/assets/pitch/*.png' -o -path '*soccer/assets/soccer_ball/*.png' -o -path '*walkers/assets/jumping_ball/*.png' \) -size -600k -print0 | tar --null -T - -cf -) | tar -xf - -C _refstage
+(cd /root/reference && find dm_control \( -name '*.py' -o -name '*.xml' -o -name 'test_00*.textproto' -o -path '*soccer/assets/boxhead/*.png' -o -path '*soccer/assets/pitch/*.png' -o -path '*soccer/assets/soccer_ball/*.png' -o -path '*walkers/assets/jumping_ball/*.png' -o -path '*mujoco/testing/assets/*.stl' -o -path '*mujoco/testing/assets/deepmind.png' \) -size -600k -print0 | tar --null -T - -cf -) | tar -xf - -C _refstage
 du -sh _refstage

@@ -246,3 +246,43 @@ def test_device_island_solves_follow_the_oracle():
   for b in (b64, b32, bj):
     assert not b.get('warning').any()
     b.close()
+
+
+ORTHOGONAL = """<mujoco><option timestep='0.004' cone='elliptic' impratio='2'/><worldbody>
+  <body name='cart' pos='0 0 .1'>
+    <joint name='cart_x' type='slide' axis='1 0 0' damping='.1'/>
+    <geom name='deck' type='box' size='.5 .3 .1' mass='2' friction='.6 .005 .0001'/>
+  </body>
+  <body name='ball' pos='0 0 .29'>
+    <joint name='ball_z' type='slide' axis='0 0 1'/>
+    <geom name='ball' type='sphere' size='.1' mass='1' friction='.6 .005 .0001'/>
+  </body>
+</worldbody><actuator><motor joint='cart_x' gear='10'/></actuator></mujoco>"""
+
+
+def test_one_contact_whose_rows_move_disjoint_trees_is_one_island():
+  """An elliptic contact between a cart that can only slide along x and a ball that can only move along z: the NORMAL row
+  moves only the ball's tree, the TANGENT row only the cart's.  mj_island unites the trees over the whole row group of a
+  contact, so this is ONE island (the friction on the cart is bounded by the normal force on the ball); joining the trees
+  from each row's own dofs would leave two islands, each solved with the other's dofs parked."""
+  from emu_lib import EmuPhysics
+  from oracle.oracle import OraclePhysics
+  m = mc.compile_xml(ORTHOGONAL)
+  e, j, o = EmuPhysics(m, 64), EmuPhysics(m, 64), OraclePhysics(m)
+  j.set_islands(0)
+  o.forward()
+  worst_e = worst_j = 0.0
+  most = 0
+  for t in range(200):
+    c = [np.sin(0.05 * t)]
+    for p in (e, j, o):
+      p.ctrl[:] = c
+      p.step()
+    most = max(most, o.nisland)
+    worst_e = max(worst_e, np.abs(e.qpos - o.qpos).max())
+    worst_j = max(worst_j, np.abs(j.qpos - o.qpos).max())
+  print('measured: orthogonal sliders, kernel core vs oracle %.2e (islands on), %.2e (joint solve); islands %d' % (worst_e, worst_j, most))
+  assert most == 1
+  assert abs(o.qpos[0]) > 1e-3      # the cart did move: the tangent row carried force
+  assert worst_e < 1e-10, worst_e
+  assert worst_j < 1e-10, worst_j
