@@ -4802,6 +4802,8 @@ struct StepCore {
     DMC_WSYNC();
     // every row joins the trees of its (unioned) mask -- AFTER the union: the normal row of an elliptic contact may move
     // only tree B and a tangent row only tree A; mj_island unites all dofs over the whole row group of the contact
+    // (joined before the union, A and B stayed two components that both owned every row of the contact: each was then
+    // solved as the joint problem -- right answer, twice the work)
     for (int r = lane; r < nefc; r += LPE) {
       const u64 tm = row_trees(r);
       for (u64 m = tm; m; m &= m - 1) { const int t = ctz64(m); DMC_ATOMIC_OR(&SI(isl_comp)[2*t], (int)(unsigned)tm); DMC_ATOMIC_OR(&SI(isl_comp)[2*t + 1], (int)(unsigned)(tm >> 32)); }

@@ -946,9 +946,6 @@ class _Compiler:
         rgba = _vec(mat.get('rgba', '1 1 1 1'))
         self.material_alpha[mat.get('name')] = float(rgba[3]) if rgba.size == 4 else 1.0
         self.materials.append((mat.get('name'), rgba if rgba.size == 4 else np.ones(4)))
-      for tex in asset.findall('texture'):
-        if tex.get('file'):
-          self._asset_bytes(tex.get('file'))      # (render-only; a missing file fails the load as it does in MuJoCo)
       for mesh in asset.findall('mesh'):
         f = mesh.get('file')
         if f:

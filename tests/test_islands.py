@@ -263,8 +263,11 @@ ORTHOGONAL = """<mujoco><option timestep='0.004' cone='elliptic' impratio='2'/><
 def test_one_contact_whose_rows_move_disjoint_trees_is_one_island():
   """An elliptic contact between a cart that can only slide along x and a ball that can only move along z: the NORMAL row
   moves only the ball's tree, the TANGENT row only the cart's.  mj_island unites the trees over the whole row group of a
-  contact, so this is ONE island (the friction on the cart is bounded by the normal force on the ball); joining the trees
-  from each row's own dofs would leave two islands, each solved with the other's dofs parked."""
+  contact, so this is ONE island (the friction on the cart is bounded by the normal force on the ball).  The kernel joins
+  the trees AFTER the per-contact union of the row masks; joining them from each row's own dofs left two
+  components that both owned every row of the contact -- measured here before the fix: the same answer to 6e-17, because a
+  parked dof is a start value and not a constraint, so each "island" solve was the joint problem over again (twice the
+  work, not a wrong cone)."""
   from emu_lib import EmuPhysics
   from oracle.oracle import OraclePhysics
   m = mc.compile_xml(ORTHOGONAL)
