@@ -127,8 +127,12 @@ class BatchedPhysics:
 
   def get_wait(self, dtype=np.float64, copy=True):
     """{name: (B, rows) array of `dtype` (float64 or float32)} of the get enqueued by `get_async`.  copy=False: read-only
-    views of the pinned staging in the batch's own precision (no host copy at all), valid until the next `get_async`."""
-    names = self._pending_get
+    views of the pinned staging in the batch's own precision (no host copy at all), valid until the next read of ANY kind
+    from this batch -- `get`, `get_async`, `get_many` all go through the one staging buffer, which a larger read also
+    re-allocates: copy what must outlive that."""
+    names = getattr(self, '_pending_get', None)
+    if names is None:
+      raise RuntimeError('get_wait without a pending get_async')
     if not copy:
       L = _native.lib()
       _native.check(L.dmc_batch_get_wait(self._ptr, len(names), (ctypes.c_void_p * len(names))(), 64))

@@ -13,6 +13,8 @@ fused HIP kernel through zero-copy bound tensors (`dmc_batch_bind`).
 """
 import numpy as np
 
+from dm_control_amd import mjcf_compiler
+
 from dm_control_amd.batch import BatchedPhysics, OUT
 
 # mjData fields a task may read, the output bit that makes the kernel write them, and whether they are state
@@ -168,6 +170,9 @@ class DevicePhysics:
       self.batch.bind(name, t.data_ptr())
       self._fields[name] = t
     self._dirty = True
+    # dmc_batch_step refuses legacy_step 2 (the step launch that ends with mj_forward) for RK4 models: an
+    # observation_forward task on such a model takes the separate forward launch (composer/environment.py)
+    self.supports_forward_after = int(model.opt.integrator) != mjcf_compiler.C['DMC_INT_RK4']
     self.reset()
 
   # -- fields ------------------------------------------------------------------------------------

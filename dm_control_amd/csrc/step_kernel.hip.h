@@ -13,7 +13,7 @@ namespace dmc {
 
 struct LaunchGeom {
   int lpe;             // lanes per environment: 64, 32 or 16
-  int waves;           // wavefronts per workgroup (1..4)
+  int waves;           // wavefronts per workgroup (1..5: five where only a five-wave group holds one more environment)
   int envs_per_block;  // waves * 64 / lpe
   int lds_bytes;       // dynamic LDS per workgroup
   int grid;            // workgroups: one per envs_per_block environments, or (queue != 0) only the resident ones

@@ -386,6 +386,7 @@ class _Data:
     p.batch.forward(False)
     p.batch.set('qacc_warmstart', warm)      # a query must not move the solver's warm start
     self._cache.clear()
+    self._prefetched.clear()      # (read before this forward: stale now)
     w = p.batch.get('contact_force').reshape(p.batch_size, -1, 2, 3)[:, contact_id]
     return w[0] if p.batch_size == 1 else w
 
