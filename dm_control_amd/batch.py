@@ -303,7 +303,12 @@ class BatchedPhysics:
   PROF_NAMES = ['load', 'kinematics', 'com_pos', 'crb_chol', 'collision', 'constraint', 'com_vel', 'rne',
                 'sensors', 'actuation', 'fwd_acc', 'sol_init', 'sol_grad', 'sol_linesearch', 'sol_update',
                 'euler', 'trailing_step1', 'store', 'noslip', 'sol_hess', 'sol_factor', 'sol_solve', 'ls_setup',
-                'x1', 'x2', 'x3', 'x4', 'x5', 'x6', 'x7', 'x8']
+                # the sub-markers (step_core.h PROF_X1..X8) by where they stand: composite inertias / entries of M (mj_crb), the
+                # factorisations of M and M + h D (mj_factorM: position stage and Euler), the joints' local poses / the
+                # composition along the chains (mj_kinematics), noslip's A = J_F M^-1 J_F' / its sweeps, and the tail of
+                # fwd_constraint after the solver (forces at the solution, qfrc_constraint = J' f)
+                'crb_composite', 'crb_entries', 'factor_M', 'kin_local_poses', 'kin_compose', 'noslip_build_A',
+                'noslip_sweeps', 'constraint_tail']
 
   def prof_enable(self, on=True):
     _native.check(_native.lib().dmc_batch_prof_enable(self._ptr, int(on)))

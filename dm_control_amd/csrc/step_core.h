@@ -553,6 +553,20 @@ template <typename T> struct LSPoint { T alpha, cost, d0, d1; };
 // is also what the solver's stopping test uses as the iteration's improvement (exact to ~1e-6 of itself instead of to
 // an ulp of the total).  fp64 keeps the oracle's absolute form, operation for operation.
 template <typename T> DMC_DEV constexpr bool ls_relative() { return sizeof(T) == 4; }
+// fp32, round 5: the relative form ANCHORED on the gradient.  The derivative of the cost along the search direction at
+// alpha = 0 is grad . search -- a sum of nv small products of a vector the solver already holds to ~8 ulp of |M a| --
+// but the line search rebuilt it as s.(M a - qfrc_smooth) + sum_rows D jar jv: two sums of magnitude 1e2 - 1e3 that
+// cancel to 1e-4 in a late iteration, i.e. to the rounding noise of their terms.  The search then saw "no descent"
+// (alpha = 0) with the gradient still 160 x above its floor and the solve stopped two iterations before the fp64 one:
+// the residual qacc error of 3e-4 |qacc| WAS the one-step fp32 error of the 62-dof model (dm_control_amd/DESIGN.md
+// section 2, measured on the host build: 8.9e-6 -> see there).  Anchored: the linear coefficient is grad . search, and
+// every row contributes only what CHANGES against its zone at alpha = 0 (a row in the same zone at both ends adds
+// nothing to it, exactly; a switching row adds its own small term).  Same function of alpha in exact arithmetic.
+#ifdef DMC_NO_LS_ANCHOR
+template <typename T> DMC_DEV constexpr bool ls_anchored() { return false; }
+#else
+template <typename T> DMC_DEV constexpr bool ls_anchored() { return ls_relative<T>(); }
+#endif
 // Returned as a 4-vector {alpha, cost, d0, d1}: a pointer argument pins the caller's
 // points in scratch memory, and returning the struct itself by value measured 2x
 // slower on the whole kernel (MI355X, ROCm 7.2) -- the vector comes back in v0..v3.
@@ -577,8 +591,8 @@ DMC_FN DMC_LSVEC(T) ls_eval_lds(T a, const DMC_LDS T* jar_, const DMC_LDS T* jv_
       const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
       if (act_a | act_0) {
         const T D = D_[i], dj0 = D*jar;
-        if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
-        if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+        if (act_a) { if (!ls_anchored<T>()) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        if (act_a != act_0) { q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0; if (ls_anchored<T>()) q1 += act_a ? jv*dj0 : -(jv*dj0); }
       }
     } else if (jar + a*jv < 0) {
       const T D = D_[i], dj0 = D*jar;
@@ -3412,31 +3426,53 @@ struct StepCore {
     }
     DMC_WSYNC();
   }
+  // Middle-zone cost of a frictional contact, anchored form (ls_anchored): the cost at alpha minus the cost at 0 minus
+  // alpha x its slope at 0, and the slope at alpha minus the slope at 0.  With NT = N - mu T the cost is 1/2 Dm NT^2; late
+  // in a solve NT moves by less than an fp32 ulp of itself along the whole search, so NT(alpha) - NT(0) must not be
+  // formed from the two values: T(alpha) - T(0) = alpha (2 UV + alpha VV) / (T(alpha) + T(0)) =: alpha W, and with
+  // E = VV T0 - UV W:   dNT = alpha (V0 - mu W),   NT1(alpha) - NT1(0) = -mu alpha E / (T T0),
+  // dNT - alpha NT1(0) = -mu alpha^2 E / ((T + T0) T0)   -- products only.
+  DMC_DEV static void cone_middle_anchored(T a, bool middle, bool middle0, T Dm, T NT, T NT1, T Tn, T NT0, T T0,
+                                           T V0, T UV, T VV, T mu, T* cc, T* cd0) {
+    if (middle && middle0) {
+      const T W = (2*UV + a*VV)/(Tn + T0), E = VV*T0 - UV*W;
+      const T dNT = a*(V0 - mu*W), dNT1 = -mu*a*E/(Tn*T0), dlin = -mu*a*a*E/((Tn + T0)*T0);
+      *cc += Dm*(NT0*dlin + (T)0.5*dNT*dNT);
+      *cd0 += Dm*(NT0*dNT1 + dNT*NT1);
+    } else {
+      if (middle) { *cc += (T)0.5*Dm*NT*NT; *cd0 += Dm*NT*NT1; }
+      if (middle0) { const T l0 = Dm*NT0*(V0 - mu*UV/T0); *cc -= (T)0.5*Dm*NT0*NT0 + a*l0; *cd0 -= l0; }      // l0: the slope at alpha = 0
+    }
+  }
   // line-search point for elliptic models: quadratic rows as in ls_eval_lds, plus
   // the non-quadratic middle-zone term of every frictional contact
   DMC_DEV void ls_eval_ell(dmc::LSPoint<T>* p, const T* qg, int nefc) {
     const T a = p->alpha;
     constexpr bool rel = ls_relative<T>();      // cost relative to alpha = 0 (fp32), see ls_relative
+    constexpr bool anch = ls_anchored<T>();     // ... with the linear term anchored on grad . search, see ls_anchored
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
       if (EFC_TYPE(tid) == EFC_EQUALITY) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i], dj0 = D*jar;
         if (!rel) q0 += (T)0.5*jar*dj0;
-        q1 += jv*dj0; q2 += (T)0.5*D*jv*jv;
+        if (!anch) q1 += jv*dj0;
+        q2 += (T)0.5*D*jv*jv;
         continue;
       }
       if (EFC_TYPE(tid) == EFC_FRICTION) {
         const T jar = S(efc_jar)[i], jv = S(efc_jv)[i], D = S(efc_D)[i];
         const T f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D, x = jar + a*jv;
-        if (x <= -rf) { q0 += f*((T)-0.5*rf - jar); q1 += -f*jv; }
-        else if (x >= rf) { q0 += f*((T)-0.5*rf + jar); q1 += f*jv; }
-        else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+        const int za = x <= -rf ? -1 : (x >= rf ? 1 : 0), z0 = jar <= -rf ? -1 : (jar >= rf ? 1 : 0);
+        if (za < 0) { q0 += f*((T)-0.5*rf - jar); if (!anch) q1 += -f*jv; }
+        else if (za > 0) { q0 += f*((T)-0.5*rf + jar); if (!anch) q1 += f*jv; }
+        else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; if (!anch) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
         if (rel) {      // minus the row's cost at alpha = 0 (Huber: linear outside |jar| < rf)
-          if (jar <= -rf) q0 -= f*((T)-0.5*rf - jar);
-          else if (jar >= rf) q0 -= f*((T)-0.5*rf + jar);
+          if (z0 < 0) q0 -= f*((T)-0.5*rf - jar);
+          else if (z0 > 0) q0 -= f*((T)-0.5*rf + jar);
           else q0 -= (T)0.5*jar*D*jar;
         }
+        if (anch && za != z0) q1 += (za < 0 ? -f*jv : (za > 0 ? f*jv : jv*(D*jar))) - (z0 < 0 ? -f*jv : (z0 > 0 ? f*jv : jv*(D*jar)));
         continue;
       }
       if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
@@ -3445,8 +3481,8 @@ struct StepCore {
           const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
           if (act_a | act_0) {
             const T D = S(efc_D)[i], dj0 = D*jar;
-            if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
-            if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+            if (act_a) { if (!anch) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+            if (act_a != act_0) { q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0; if (anch) q1 += act_a ? jv*dj0 : -(jv*dj0); }
           }
         } else if (jar + a*jv < 0) { const T D = S(efc_D)[i], dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
         continue;
@@ -3458,40 +3494,46 @@ struct StepCore {
       const T UV = S(efc_cb)[r0], VV = S(efc_cb)[r0 + 1], mu = S(efc_cb)[r0 + 2];
       const T N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
       bool bottom = false, middle = false;
-      T NT = 0, Dm = 0;
+      T NT = 0, Dm = 0, NT1 = 0, Tn = 0;
       if (Tsqr <= 0) bottom = N < 0;
       else {
-        const T Tn = t_sqrt(Tsqr);
+        Tn = t_sqrt(Tsqr);
         if (N >= mu*Tn) {}
         else if (mu*N + Tn <= 0) bottom = true;
         else {
           middle = true;
           Dm = S(efc_D)[r0] / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
           const T N1 = V0, T1 = (UV + a*VV)/Tn, T2 = VV/Tn - (UV + a*VV)*T1/(Tn*Tn);
-          const T NT1 = N1 - mu*T1;
+          NT1 = N1 - mu*T1;
           NT = N - mu*Tn;
           if (!rel) cc += (T)0.5*Dm*NT*NT;
-          cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+          if (!anch) cd0 += Dm*NT*NT1;
+          cd1 += Dm*(NT1*NT1 - NT*mu*T2);
         }
       }
       if (!rel) { if (bottom) { q0 += S(efc_cg)[r0]; q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; } continue; }
       // relative form: the contact's cost at alpha minus its cost at 0, by the pair of zones
       bool bottom0 = false, middle0 = false;
-      T NT0 = 0;
+      T NT0 = 0, T0 = 0;
       if (UU <= 0) bottom0 = U0 < 0;
       else {
-        const T T0 = t_sqrt(UU);
+        T0 = t_sqrt(UU);
         if (U0 >= mu*T0) {}
         else if (mu*U0 + T0 <= 0) bottom0 = true;
         else { middle0 = true; NT0 = U0 - mu*T0; }
       }
-      if (bottom) { q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; if (!bottom0) q0 += S(efc_cg)[r0]; }
+      if (bottom) { if (!anch || !bottom0) q1 += S(efc_cg)[r0 + 1]; q2 += S(efc_cg)[r0 + 2]; if (!bottom0) q0 += S(efc_cg)[r0]; }
       else if (bottom0) q0 -= S(efc_cg)[r0];
+      if (anch && bottom0 && !bottom) q1 -= S(efc_cg)[r0 + 1];
       if (middle | middle0) {
         if (!middle0 || !middle) Dm = S(efc_D)[r0] / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
-        cc += (T)0.5*Dm*(NT - NT0)*(NT + NT0);      // 1/2 Dm (NT^2 - NT0^2); a zone that is not the middle one has NT = 0
+        if (!anch) cc += (T)0.5*Dm*(NT - NT0)*(NT + NT0);      // 1/2 Dm (NT^2 - NT0^2); a zone that is not the middle one has NT = 0
+        else cone_middle_anchored(a, middle, middle0, Dm, NT, NT1, Tn, NT0, T0, V0, UV, VV, mu, &cc, &cd0);
       }
     }
+#ifdef DMC_HOST_EMU
+    if (getenv("DMC_EMU_TRACE_LS2")) fprintf(stderr, "      eval_ell a %.9e: q0 %.6e q1rows %.6e q2rows %.6e cc %.6e cd0 %.6e | qg %.6e %.6e %.6e\n", (double)a, (double)q0, (double)q1, (double)q2, (double)cc, (double)cd0, (double)qg[0], (double)qg[1], (double)qg[2]);
+#endif
     q0 = group_sum<LPE>(q0) + (rel ? (T)0 : qg[0]); q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
     cc = group_sum<LPE>(cc); cd0 = group_sum<LPE>(cd0); cd1 = group_sum<LPE>(cd1);
     p->cost = a*a*q2 + a*q1 + q0 + cc;
@@ -3709,10 +3751,10 @@ struct StepCore {
   // contact's other rows carry nothing.  An evaluation of the soccer / 62-dof models was a chain of LDS look-ups (row
   // type -> contact -> first row -> nine aggregates) per row before the arithmetic started: 22 % / 14 % of their step.
   enum { LSK_NONE = 0, LSK_EQUALITY, LSK_FRICTION, LSK_ONESIDED, LSK_CONE };
-  struct LSRows { T jar, jv, D; bool on; bool gen; int kind; T f, rf, U0, V0, UU, UV, VV, mu, b0, b1, b2, Dm, NT0; bool bottom0, middle0; };
+  struct LSRows { T jar, jv, D; bool on; bool gen; int kind; T f, rf, U0, V0, UU, UV, VV, mu, b0, b1, b2, Dm, NT0, T0; bool bottom0, middle0; };
   DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
     g.gen = true; g.kind = LSK_NONE;
-    g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = 0; g.bottom0 = g.middle0 = false;
+    g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = g.T0 = 0; g.bottom0 = g.middle0 = false;
     const int i = lane;
     if (i >= nefc) return;
     const int tid = SI(efc_tid)[i], ty = EFC_TYPE(tid);
@@ -3744,62 +3786,71 @@ struct StepCore {
       const T T0 = t_sqrt(UU);
       if (g.U0 >= mu*T0) {}
       else if (mu*g.U0 + T0 <= 0) g.bottom0 = true;
-      else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; }
+      else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; g.T0 = T0; }      // (T0: the anchored form's reference point)
     }
   }
   // ls_eval_ell's arithmetic for the lane's one row
   DMC_DEV void ls_eval_gen(LSPoint* p, const T* qg, const LSRows& g) {
     const T a = p->alpha;
     constexpr bool rel = ls_relative<T>();
+    constexpr bool anch = ls_anchored<T>();
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     if (g.kind == LSK_EQUALITY) {
       const T dj0 = g.D*g.jar;
       if (!rel) q0 += (T)0.5*g.jar*dj0;
-      q1 += g.jv*dj0; q2 += (T)0.5*g.D*g.jv*g.jv;
+      if (!anch) q1 += g.jv*dj0;
+      q2 += (T)0.5*g.D*g.jv*g.jv;
     } else if (g.kind == LSK_FRICTION) {
       const T jar = g.jar, jv = g.jv, D = g.D, f = g.f, rf = g.rf, x = jar + a*jv;
-      if (x <= -rf) { q0 += f*((T)-0.5*rf - jar); q1 += -f*jv; }
-      else if (x >= rf) { q0 += f*((T)-0.5*rf + jar); q1 += f*jv; }
-      else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+      const int za = x <= -rf ? -1 : (x >= rf ? 1 : 0), z0 = jar <= -rf ? -1 : (jar >= rf ? 1 : 0);
+      if (za < 0) { q0 += f*((T)-0.5*rf - jar); if (!anch) q1 += -f*jv; }
+      else if (za > 0) { q0 += f*((T)-0.5*rf + jar); if (!anch) q1 += f*jv; }
+      else { const T dj0 = D*jar; q0 += (T)0.5*jar*dj0; if (!anch) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
       if (rel) {
-        if (jar <= -rf) q0 -= f*((T)-0.5*rf - jar);
-        else if (jar >= rf) q0 -= f*((T)-0.5*rf + jar);
+        if (z0 < 0) q0 -= f*((T)-0.5*rf - jar);
+        else if (z0 > 0) q0 -= f*((T)-0.5*rf + jar);
         else q0 -= (T)0.5*jar*D*jar;
       }
+      if (anch && za != z0) q1 += (za < 0 ? -f*jv : (za > 0 ? f*jv : jv*(D*jar))) - (z0 < 0 ? -f*jv : (z0 > 0 ? f*jv : jv*(D*jar)));
     } else if (g.kind == LSK_ONESIDED) {
       const T jar = g.jar, jv = g.jv;
       if (rel) {
         const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
         if (act_a | act_0) {
           const T D = g.D, dj0 = D*jar;
-          if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
-          if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+          if (act_a) { if (!anch) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+          if (act_a != act_0) { q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0; if (anch) q1 += act_a ? jv*dj0 : -(jv*dj0); }
         }
       } else if (jar + a*jv < 0) { const T D = g.D, dj0 = D*jar; q0 += (T)0.5*jar*dj0; q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
     } else if (g.kind == LSK_CONE) {
       const T U0 = g.U0, V0 = g.V0, UU = g.UU, UV = g.UV, VV = g.VV, mu = g.mu, Dm = g.Dm;
       const T N = U0 + a*V0, Tsqr = UU + a*(2*UV + a*VV);
       bool bottom = false, middle = false;
-      T NT = 0;
+      T NT = 0, NT1 = 0, Tn = 0;
       if (Tsqr <= 0) bottom = N < 0;
       else {
-        const T Tn = t_sqrt(Tsqr);
+        Tn = t_sqrt(Tsqr);
         if (N >= mu*Tn) {}
         else if (mu*N + Tn <= 0) bottom = true;
         else {
           middle = true;
           const T N1 = V0, T1 = (UV + a*VV)/Tn, T2 = VV/Tn - (UV + a*VV)*T1/(Tn*Tn);
-          const T NT1 = N1 - mu*T1;
+          NT1 = N1 - mu*T1;
           NT = N - mu*Tn;
           if (!rel) cc += (T)0.5*Dm*NT*NT;
-          cd0 += Dm*NT*NT1; cd1 += Dm*(NT1*NT1 - NT*mu*T2);
+          if (!anch) cd0 += Dm*NT*NT1;
+          cd1 += Dm*(NT1*NT1 - NT*mu*T2);
         }
       }
       if (!rel) { if (bottom) { q0 += g.b0; q1 += g.b1; q2 += g.b2; } }
       else {
-        if (bottom) { q1 += g.b1; q2 += g.b2; if (!g.bottom0) q0 += g.b0; }
+        if (bottom) { if (!anch || !g.bottom0) q1 += g.b1; q2 += g.b2; if (!g.bottom0) q0 += g.b0; }
         else if (g.bottom0) q0 -= g.b0;
-        if (middle | g.middle0) cc += (T)0.5*Dm*(NT - g.NT0)*(NT + g.NT0);
+        if (anch && g.bottom0 && !bottom) q1 -= g.b1;
+        if (middle | g.middle0) {
+          if (!anch) cc += (T)0.5*Dm*(NT - g.NT0)*(NT + g.NT0);
+          else cone_middle_anchored(a, middle, g.middle0, Dm, NT, NT1, Tn, g.NT0, g.T0, V0, UV, VV, mu, &cc, &cd0);
+        }
       }
     }
     q0 = group_sum<LPE>(q0) + (rel ? (T)0 : qg[0]); q1 = group_sum<LPE>(q1) + qg[1]; q2 = group_sum<LPE>(q2) + qg[2];
@@ -3818,8 +3869,8 @@ struct StepCore {
         const bool act_a = jar + a*jv < 0, act_0 = jar < 0;
         if (act_a | act_0) {
           const T D = rw.D, dj0 = D*jar;
-          if (act_a) { q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
-          if (act_a != act_0) q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0;
+          if (act_a) { if (!ls_anchored<T>()) q1 += jv*dj0; q2 += (T)0.5*D*jv*jv; }
+          if (act_a != act_0) { q0 += (act_a ? (T)0.5 : (T)-0.5)*jar*dj0; if (ls_anchored<T>()) q1 += act_a ? jv*dj0 : -(jv*dj0); }
         }
       } else if (jar + a*jv < 0) {
         const T D = rw.D, dj0 = D*jar;
@@ -3862,9 +3913,11 @@ struct StepCore {
     T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     FOR_LANES(i, nv) {
       const T sr = S(sv_search)[i];
-      a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; a3 += sr*S(sv_Mv)[i]; a4 += sr*sr;
+      if (ls_anchored<T>()) a1 += sr*S(sv_grad)[i];      // grad . search: the slope at alpha = 0 itself (see ls_anchored)
+      else { a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; }
+      a3 += sr*S(sv_Mv)[i]; a4 += sr*sr;
     }
-    a1 = group_sum<LPE>(a1); a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
+    a1 = group_sum<LPE>(a1); if (!ls_anchored<T>()) a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
     T qg[3] = {gauss, a1 - a2, (T)0.5*a3};
     const T snorm = t_sqrt(a4);
     if (snorm < (T)DMC_MINVAL) return 0;
@@ -3881,6 +3934,10 @@ struct StepCore {
     LSPoint p0, p1, p2, pmid, p1next, p2next;
     p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals, rw);
     p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals, rw);
+#ifdef DMC_HOST_EMU
+    if (getenv("DMC_EMU_TRACE_LS")) fprintf(stderr, "    ls: p0 cost %.6e d0 %.6e d1 %.6e | p1 alpha %.9e cost %.6e d0 %.6e d1 %.6e | gtol %.3e qg1 %.6e\n",
+                                           (double)p0.cost, (double)p0.d0, (double)p0.d1, (double)p1.alpha, (double)p1.cost, (double)p1.d0, (double)p1.d1, (double)gtol, (double)qg[1]);
+#endif
     if (p0.cost < p1.cost) p1 = p0;
     if (t_abs(p1.d0) < gtol) { *lscost = p1.cost; return p1.alpha; }
     const int dir = p1.d0 < 0 ? 1 : -1;
@@ -4690,6 +4747,9 @@ struct StepCore {
       const T alpha = primal_search(nefc, gauss, scale, &lscost);
       DMC_PROF(PROF_SOL_LS);
       DMC_TSUB(3, iter == 0, 5);
+#ifdef DMC_HOST_EMU
+      if (getenv("DMC_EMU_TRACE_LS")) fprintf(stderr, "    ls returned alpha %.9e lscost %.6e\n", (double)alpha, (double)lscost);
+#endif
       if (alpha == 0) break;
       FOR_LANES(i, nv) { S(qacc)[i] += alpha*S(sv_search)[i]; S(sv_Ma)[i] += alpha*S(sv_Mv)[i]; }
       for (int i = lane; i < nefc; i += LPE) S(efc_jar)[i] += alpha*S(efc_jv)[i];
@@ -4738,7 +4798,18 @@ struct StepCore {
 #endif
       const T ulp = sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16;
       const T tol_imp = ls_relative<T>() ? o.tolerance : t_max(o.tolerance, epsimp*ulp*scale*t_abs(cost));
-      const T tol_grad = t_max(o.tolerance, 8*ulp*scale*t_sqrt(ma2));
+      // fp32, round 5: an EXACT Newton step.  With every row in a quadratic / linear zone, an unchanged active set and the line search
+      // returning the Newton point (alpha = 1), the step minimised the quadratic it was computed from: the new gradient is
+      // zero in exact arithmetic (the fp64 solver sees ~1e-14 and stops here) and what fp32 shows -- measured 1x - 7x the
+      // 8-ulp floor on the cheetah -- is the rounding of M a - qfrc_smooth - J' f itself.  Iterating on it moves qacc by
+      // less than that noise (improvement ~1e-10) and cost the 9-dof model 13 % more Newton iterations than the fp64
+      // reference (1.34 vs 1.18 per step; a launch waits for the wave with the most).  The floor is 64 ulp there.
+#ifdef DMC_NO_EXACT_STEP_FLOOR
+      const bool exact_step = false;
+#else
+      const bool exact_step = sizeof(T) == 4 && !L.d.cg && !changed && t_abs(alpha - 1) < (T)1e-3;      // (`changed` is also set by any contact in the cone's middle zone, whose cost is not quadratic)
+#endif
+      const T tol_grad = t_max(o.tolerance, (exact_step ? 64 : 8)*ulp*scale*t_sqrt(ma2));
 #ifdef DMC_HOST_EMU
       if (getenv("DMC_EMU_TRACE")) fprintf(stderr, "  newton iter %d alpha %.6e cost %.9e improvement %.3e (tol %.3e) gradient %.3e (tol %.3e) changed %d\n",
                                             iter, (double)alpha, (double)cost, (double)improvement, (double)tol_imp, (double)gradient, (double)tol_grad, changed);
@@ -5016,6 +5087,7 @@ struct StepCore {
   // Acceleration stage (mj_step2 without the integrator)
   DMC_DEV void stage_acc(bool disable_actuation, bool skipsensor) {
     fwd_actuation(disable_actuation); DMC_PROF(PROF_ACT); fwd_acceleration(); DMC_PROF(PROF_ACC); fwd_constraint();
+    DMC_PROF(PROF_X8);      // (what fwd_constraint does after the solver's last marker: forces at the solution, J' f)
     if (!skipsensor) sensors_acc();
     DMC_PROF(PROF_SENS);
   }

@@ -142,7 +142,10 @@ _SCENE = """<mujoco><option timestep='0.002'/><worldbody>
 </worldbody></mujoco>"""
 
 
-@pytest.mark.parametrize('prec,tol', [(64, 1e-9), (32, 2e-3)])
+# fp32: free bodies tumbling for 600 steps, open loop.  The error stays below 1e-5 for 500 steps; at step 502 a contact is
+# just touching and fp32 / fp64 activate it a step apart (MuJoCo's dynamics are discontinuous there), after which the two
+# trajectories are 2e-3 apart: the tolerance is the device test's (below), not a statement about the step.
+@pytest.mark.parametrize('prec,tol', [(64, 1e-9), (32, 5e-3)])
 def test_kernel_core_matches_oracle_with_cylinder_contacts(prec, tol):
   from emu_lib import EmuPhysics
 
