@@ -112,7 +112,7 @@ def test_static_fp32_kernels_private_segment_stays_bounded():
   assert all(re.search(r'step_kernel_staticIfLi64ELi[567]ELb', n) for n in ilp), sorted(ilp)
   ks.update(ilp)
   bound = {0: 32, 1: 32, 2: 640, 3: 32, 4: 32, 5: 216, 6: 330, 7: 710}      # static id -> bytes per lane (round 5: + 16 B for the anchored line search's reference values, step_core.h ls_anchored)
-  spill = {5: 48, 6: 72, 7: 16}      # VGPRs the kernel body parks across the stage calls (none in the small models' kernels)
+  spill = {5: 48, 6: 72, 7: 20}      # VGPRs the kernel body parks across the stage calls (none in the small models' kernels)
   seen = set()
   for name, r in ks.items():
     m = re.search(r'step_kernel_staticIfLi(\d+)ELi(\d+)ELb([01])', name)
