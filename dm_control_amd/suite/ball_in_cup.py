@@ -42,7 +42,7 @@ class Physics(physics_lib.Physics):
     d = np.abs(self.ball_to_target())
     target_size = self.named.model.site_size['target'][[0, 2]]
     ball_size = self.named.model.geom_size['ball'][0]
-    return np.asarray(np.all(d < target_size - ball_size, axis=-1), dtype=np.float64)
+    return common.asarray(np.all(d < target_size - ball_size, axis=-1), dtype=np.float64)
 
 
 class BallInCup(base.Task):

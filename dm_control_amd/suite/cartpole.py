@@ -67,7 +67,7 @@ class Physics(physics_lib.Physics):
     return self.named.data.xmat[2:, 'zz']
 
   def bounded_position(self):
-    cart = np.asarray(self.cart_position())[..., None]
+    cart = common.asarray(self.cart_position())[..., None]
     poles = self.named.data.xmat[2:, ['zz', 'xz']]
     return np.concatenate([cart, poles.reshape(poles.shape[:-2] + (-1,))], axis=-1)
 

@@ -31,12 +31,28 @@ def read_model(filename):
     return f.read()
 
 
+def asarray(x, dtype=None):
+  """`np.asarray(x, dtype)` for the task code: numpy inputs take exactly that call; a device array (suite/device_env.TArr:
+  the same task code evaluated on GPU tensors) stays where it is."""
+  if type(x).__name__ == 'TArr':
+    return x.astype(dtype) if dtype is not None else x
+  return np.asarray(x) if dtype is None else np.asarray(x, dtype=dtype)
+
+
+def array_copy(x, dtype=None):
+  """`np.array(x, dtype, copy=True)` likewise."""
+  if type(x).__name__ == 'TArr':
+    y = x.copy()
+    return y.astype(dtype) if dtype is not None else y
+  return np.array(x, copy=True) if dtype is None else np.array(x, dtype=dtype, copy=True)
+
+
 def vnorm(x):
   """Euclidean norm over the last axis.  A single environment's vector takes the call the reference's tasks make,
   `np.linalg.norm(x)` (sqrt of a dot product): numpy's `axis=` path sums the squares in a different order and differs in
   the last bit, and the task ports are held to the reference's modules bit for bit
   (tests/test_reference_suite_domains.py)."""
-  x = np.asarray(x)
+  x = asarray(x)
   return np.linalg.norm(x) if x.ndim == 1 else np.linalg.norm(x, axis=-1)
 
 
@@ -44,7 +60,7 @@ def vecmat(v, mat):
   """`v . M` over the last axes: a world vector in the frame whose rotation matrix is M (`v.dot(xmat.reshape(3, 3))` in
   the reference's tasks).  A single environment takes exactly that call -- einsum accumulates in another order, a last-bit
   difference the port-vs-reference test would see."""
-  v, mat = np.asarray(v), np.asarray(mat)
+  v, mat = asarray(v), asarray(mat)
   if v.ndim == 1:
     return v.dot(mat.reshape(3, 3))
   return np.einsum('...i,...ij->...j', v, mat.reshape(v.shape[:-1] + (3, 3)))
@@ -52,5 +68,5 @@ def vecmat(v, mat):
 
 def vdot(a, b):
   """Dot product over the last axis; a single environment's vectors take `np.dot` as the reference's tasks do."""
-  a, b = np.asarray(a), np.asarray(b)
+  a, b = asarray(a), asarray(b)
   return np.dot(a, b) if a.ndim == 1 else np.sum(a * b, axis=-1)

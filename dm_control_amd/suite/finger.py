@@ -102,7 +102,7 @@ class Spin(base.Task):
     return obs
 
   def get_reward(self, physics):
-    return np.asarray(physics.hinge_velocity() <= -_SPIN_VELOCITY, dtype=np.float64)
+    return common.asarray(physics.hinge_velocity() <= -_SPIN_VELOCITY, dtype=np.float64)
 
 
 class Turn(base.Task):
@@ -133,7 +133,7 @@ class Turn(base.Task):
     return obs
 
   def get_reward(self, physics):
-    return np.asarray(physics.dist_to_target() <= 0, dtype=np.float64)
+    return common.asarray(physics.dist_to_target() <= 0, dtype=np.float64)
 
 
 spin = _make(lambda random: Spin(random=random))

@@ -113,7 +113,7 @@ class LQRLevel(base.Task):
     return 1 - (state_cost + control_l2_norm * self._control_cost_coef)
 
   def get_evaluation(self, physics):
-    return np.asarray(physics.state_norm() <= 0.01, dtype=np.float64)
+    return common.asarray(physics.state_norm() <= 0.01, dtype=np.float64)
 
   def get_termination(self, physics):
     if np.all(physics.state_norm() < self._TERMINAL_TOL):

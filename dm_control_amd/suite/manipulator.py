@@ -90,7 +90,7 @@ class Physics(physics_lib.Physics):
   def target_2d_pose(self, target_body):
     if self.target_pose is None:
       return self.body_2d_pose(target_body)
-    tp = np.asarray(self.target_pose)
+    tp = common.asarray(self.target_pose)
     return np.concatenate([tp[..., :2], _quat_y(tp[..., 2])], axis=-1)
 
   def touch(self):
@@ -103,7 +103,7 @@ class Physics(physics_lib.Physics):
   def target_site_distance(self, site, target_body, offset_local):
     """Distance from `site` to a point rigidly attached to the per-environment ghost target
     (offset_local: the target site's position in the target body frame)."""
-    tp = np.asarray(self.target_pose)
+    tp = common.asarray(self.target_pose)
     x, z, ang = tp[..., 0], tp[..., 1], tp[..., 2]
     c, s = np.cos(ang), np.sin(ang)
     ox, oy, oz = offset_local

@@ -89,14 +89,14 @@ class Physics(physics_lib.Physics):
     return [self.model.id2name(i, 'sensor') for i in np.nonzero(np.isin(st, types))[0]]
 
   def torso_upright(self):
-    return np.asarray(self.named.data.xmat['torso', 'zz'])
+    return common.asarray(self.named.data.xmat['torso', 'zz'])
 
   def torso_velocity(self):
     return self.named.data.sensordata['velocimeter'].copy()
 
   def egocentric_state(self):
     hinges = [self.model.id2name(j, 'joint') for j in np.nonzero(np.asarray(self.model.jnt_type) == 3)[0]]
-    return np.concatenate([self.named.data.qpos[hinges], self.named.data.qvel[hinges], np.asarray(self.data.act)], axis=-1)
+    return np.concatenate([self.named.data.qpos[hinges], self.named.data.qvel[hinges], common.asarray(self.data.act)], axis=-1)
 
   def toe_positions(self):
     d = self.named.data.xpos[_TOES] - self.named.data.xpos['torso'][..., None, :]
@@ -109,7 +109,7 @@ class Physics(physics_lib.Physics):
     return self.named.data.sensordata[self._sensor_names(_SENS_GYRO, _SENS_ACCELEROMETER)]
 
   def origin_distance(self):
-    return np.asarray(common.vnorm(self.named.data.site_xpos['workspace']))
+    return common.asarray(common.vnorm(self.named.data.site_xpos['workspace']))
 
   def origin(self):
     return _to_frame(-self.named.data.xpos['torso'], self._torso_frame())

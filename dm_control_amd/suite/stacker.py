@@ -72,7 +72,7 @@ class Physics(physics_lib.Physics):
   def target_position(self):
     if self.target_xz is None:
       return self.named.data.xpos['target'][..., [0, 2]]
-    return np.array(self.target_xz, dtype=np.float64, copy=True)      # (a fresh array per observation, like the indexed read above)
+    return common.array_copy(self.target_xz, dtype=np.float64)      # (a fresh array per observation, like the indexed read above)
 
   def touch(self):
     return np.log1p(self._q(_TOUCH_SENSORS, 'sensordata'))

@@ -72,7 +72,7 @@ class Physics(physics_lib.Physics):
   def nose_to_target(self):
     """Vector from the nose to the target in the head's local frame (x, y)."""
     nose = self.named.data.geom_xpos['nose']
-    target = np.array(self.named.data.geom_xpos['target'], dtype=np.float64, copy=True)
+    target = common.array_copy(self.named.data.geom_xpos['target'], dtype=np.float64)
     if self.target_xy is not None:
       target[..., :2] = self.target_xy
     d = target - nose
@@ -83,12 +83,12 @@ class Physics(physics_lib.Physics):
 
   def body_velocities(self):
     """Local body velocities: x, y linear and z rotational, per body."""
-    sd = np.asarray(self.data.sensordata)
+    sd = common.asarray(self.data.sensordata)
     xvel_local = sd[..., 12:].reshape(sd.shape[:-1] + (-1, 6))
     return xvel_local[..., [0, 1, 5]].reshape(sd.shape[:-1] + (-1,))
 
   def joints(self):
-    return np.array(self.data.qpos[..., 3:], copy=True)
+    return common.array_copy(self.data.qpos[..., 3:])
 
 
 class Swimmer(base.Task):
