@@ -21,7 +21,7 @@ OUT_ALL = 0x7fffffff
 class BatchedPhysics:
 
   def __init__(self, model, batch_size, device_id=0, precision=32, nconmax=0,
-               njmax=0, lanes_per_env=0, njcon=0):
+               njmax=0, lanes_per_env=0, njcon=0, specialise=None):
     if not isinstance(model, mjcf_compiler.Model):
       raise TypeError('model must be a compiled mjcf_compiler.Model')
     L = _native.lib()
@@ -42,6 +42,10 @@ class BatchedPhysics:
       self._model_ptr = None
       _native.check(rc)
     self.legacy_step = True
+    # a model without a baked specialised kernel takes the one built for it on demand, if there is one (specialise.py)
+    self._user_caps = (int(nconmax), int(njmax), int(njcon))
+    from dm_control_amd import specialise as _spec
+    self.specialised = _spec.attach(self, specialise)
 
   @classmethod
   def from_xml_string(cls, xml_string, batch_size, assets=None, **kw):

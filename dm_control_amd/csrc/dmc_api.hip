@@ -3,6 +3,7 @@
 // and launches the fused step kernel.  No CPU fallback exists: every entry point
 // that computes runs the HIP kernel or returns an error.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,9 @@ struct dmc_batch {
   int trace_launch;    // launches since the trace was switched on (ring slot = trace_launch % 8)
   int* d_rj_i; double* d_rj_r;      // joint randomisation: (4, njnt) ints {type, qposadr, limited, 0} and (2, njnt) ranges
   int* d_eg_slot;      // per-env world geoms: (ngeom) slot table on the device (field "env_geom" holds the values)
+  // a model-specialised kernel built on demand for this model (dmc_batch_attach_specialised): the loaded object, its launch
+  // entry, whether it holds the optional launch features (step_core.h kFeat)
+  void* spec_so = nullptr; void* spec_launch = nullptr; int spec_features = 0;
 };
 
 extern "C" const char* dmc_last_error(void) { return g_err.c_str(); }
@@ -417,18 +421,54 @@ static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* s
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
   if (b->lpt) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)b->d_cost, b->d_order, b->nitems);
+  // a specialisation plugin takes the launch unless it was built lean and the launch needs an optional feature
+  const bool need_feat = legacy == 2 || b->d_probe != nullptr || b->tb.opts.integrator == DMC_INT_IMPLICITFAST;
+  const bool spec = b->spec_launch && (b->spec_features || !need_feat);
   if (b->precision == 64) {
     StepIO<double> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (double*)sq->qvel : nullptr; io.sensor_seq = sq ? (double*)sq->sensor : nullptr;
+    if (spec) {
+      typedef int (*fn_t)(const LaunchGeom*, void*, const StepLayout*, const StepOpts<double>*, const int*, const double*, const int*, const StepIO<double>*, int, int, int, int, int);
+      e = (hipError_t)((fn_t)b->spec_launch)(&b->geom, stream, b->d_layout, &b->tb.opts, b->d_mi, (const double*)b->d_mr, b->d_mc, &io, nstep, legacy, mode, b->outmask, nsub);
+    } else
     e = launch_step_f64(b->geom, (hipStream_t)stream, b->d_layout, b->tb.opts, b->d_mi, (const double*)b->d_mr, b->d_mc, io, nstep, legacy, mode, b->outmask, nsub);
   } else {
     StepIO<float> io; fill_io(b, &io);
     io.ctrl_seq = sq ? (const float*)sq->ctrl : nullptr; io.qpos_seq = sq ? (float*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (float*)sq->qvel : nullptr; io.sensor_seq = sq ? (float*)sq->sensor : nullptr;
+    if (spec) {
+      typedef int (*fn_t)(const LaunchGeom*, void*, const StepLayout*, const StepOpts<float>*, const int*, const float*, const int*, const StepIO<float>*, int, int, int, int, int);
+      const StepOpts<float> of = step_opts_cast<float>(b->tb.opts);
+      e = (hipError_t)((fn_t)b->spec_launch)(&b->geom, stream, b->d_layout, &of, b->d_mi, (const float*)b->d_mr, b->d_mc, &io, nstep, legacy, mode, b->outmask, nsub);
+    } else
     e = launch_step_f32(b->geom, (hipStream_t)stream, b->d_layout, step_opts_cast<float>(b->tb.opts), b->d_mi, (const float*)b->d_mr, b->d_mc, io, nstep, legacy, mode, b->outmask, nsub);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e), -2);
+  return 0;
+}
+
+extern "C" int dmc_batch_attach_specialised(dmc_batch* b, const char* so_path) {
+  if (!b || !so_path) return fail("null argument");
+  void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(std::string("cannot load ") + so_path + ": " + dlerror());
+  typedef const StepLayout* (*layout_t)();
+  typedef void (*info_t)(int*);
+  layout_t fl = (layout_t)dlsym(h, "dmc_spec_layout");
+  info_t fi = (info_t)dlsym(h, "dmc_spec_info");
+  void* launch = dlsym(h, "dmc_spec_launch");
+  if (!fl || !fi || !launch) { dlclose(h); return fail("not a specialisation plugin (dmc_spec_* symbols missing)"); }
+  int info[8]; fi(info);
+  const int so = b->precision == 64 ? (int)sizeof(StepOpts<double>) : (int)sizeof(StepOpts<float>);
+  const int sio = b->precision == 64 ? (int)sizeof(StepIO<double>) : (int)sizeof(StepIO<float>);
+  if (info[0] != (int)sizeof(StepLayout) || info[1] != so || info[2] != sio || info[3] != DMC_MODEL_VERSION || info[7] != (int)sizeof(LaunchGeom)) {
+    dlclose(h); return fail("the plugin was built from other sources than this library (struct sizes / model version differ)");
+  }
+  if (info[4] != b->precision) { dlclose(h); return fail("the plugin was built for another precision"); }
+  if (info[5] != b->geom.lpe) { dlclose(h); return fail("the plugin was built for another lanes-per-environment shape"); }
+  if (memcmp(fl(), &b->tb.L, sizeof(StepLayout)) != 0) { dlclose(h); return fail("the plugin's layout is not this batch's (another model or other caps)"); }
+  if (b->spec_so) dlclose(b->spec_so);
+  b->spec_so = h; b->spec_launch = launch; b->spec_features = info[6];
   return 0;
 }
 
@@ -1060,7 +1100,7 @@ extern "C" int dmc_batch_info(const dmc_batch* b, int* info) {
   info[0] = b->B; info[1] = b->precision; info[2] = b->geom.lpe; info[3] = b->geom.waves; info[4] = b->geom.envs_per_block;
   info[5] = b->geom.lds_bytes; info[6] = b->geom.grid; info[7] = L.d.nconmax; info[8] = L.d.njmax;
   info[9] = (int)((size_t)L.n_sr * b->elem + (size_t)L.n_si * sizeof(int));
-  info[10] = b->geom.static_id;
+  info[10] = b->spec_launch ? 1000 : b->geom.static_id;      // 1000: a specialisation plugin is attached
   info[11] = L.d.kmax;
   info[12] = b->geom.lds_bytes - b->geom.envs_per_block * info[9];
   { long blocks = (160L * 1024) / b->geom.lds_bytes; if (blocks * b->geom.waves > 8) blocks = 8 / b->geom.waves; info[13] = (int)(blocks * b->geom.envs_per_block); }

@@ -33,7 +33,9 @@ struct LaunchGeom {
 // constants (dm_control_amd/build.py -> gen_static_layouts).  A batch whose
 // runtime layout equals a baked one runs the specialised instantiation, in which
 // every LDS offset is an immediate and every size a constant.
-#if defined(DMC_PROFILE) && __has_include("static_layouts_prof.gen.h")
+#if defined(DMC_LAYOUTS_HEADER)      // a specialisation plugin (step_kernel_spec.hip): ONE model's layout, generated at run time
+#include DMC_LAYOUTS_HEADER
+#elif defined(DMC_PROFILE) && __has_include("static_layouts_prof.gen.h")
 #include "static_layouts_prof.gen.h"
 #elif __has_include("static_layouts.gen.h")
 #include "static_layouts.gen.h"

@@ -49,6 +49,16 @@ int dmc_batch_create_caps(const dmc_model* m, int batch_size, int device_id, int
                           const int* caps, int ncaps, dmc_batch** out);
 void dmc_batch_destroy(dmc_batch* b);
 
+/* Model-specialised kernels on demand.  The library carries specialised instantiations of the step kernel for a fixed
+ * list of assets (the LDS layout as a compile-time constant: offsets become immediates, the Cholesky factor lives in
+ * registers); any other model -- a composer environment recompiled with another body count (composer/environment.py:
+ * 377-383), a user's MJCF (engine.py:446-476 from_xml_string) -- runs the generic kernel, 2 - 2.7 x slower.
+ * dm_control_amd/specialise.py compiles csrc/step_kernel_spec.hip for ONE model (hipcc, cached on disk by the hash of
+ * the model blob, the caps, the precision and the sources) into a shared object; this call loads it next to the batch,
+ * checks that its layout IS the batch's (byte for byte) and that it was built from the same sources, and routes the
+ * batch's launches through it.  The object stays loaded for the life of the process. */
+int dmc_batch_attach_specialised(dmc_batch* b, const char* so_path);
+
 /* Replaces Physics.step(nstep) = mj_step2; mj_step(nstep-1); mj_step1 when
  * legacy_step != 0 (dm_control/mujoco/engine.py:147-162) or mj_step(nstep)
  * otherwise (engine.py:176), for every env, in ONE kernel launch.

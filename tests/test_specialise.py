@@ -1,0 +1,135 @@
+"""Model-specialised kernels on demand (dm_control_amd/specialise.py, dmc_batch_attach_specialised).
+
+CPU tier: the cache key, the generated header and a cross-compile of the plugin for an unseen model (hipcc needs no GPU).
+`-m gpu`: the plugin attached to a batch gives the generic kernel's trajectory (fp64 to rounding, fp32 to the kernels'
+usual distance), is refused for another model or other caps, and a baked model keeps its baked kernel."""
+import os
+
+import numpy as np
+import pytest
+
+from dm_control_amd import mjcf_compiler as mc
+from dm_control_amd import specialise
+from dm_control_amd.suite import common
+
+UNSEEN = """
+<mujoco>
+  <option timestep="0.004"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 .1"/>
+    <body name="hip" pos="0 0 .6">
+      <joint name="x" type="slide" axis="1 0 0"/><joint name="z" type="slide" axis="0 0 1"/><joint name="tilt" type="hinge" axis="0 1 0"/>
+      <geom type="capsule" fromto="-.2 0 0 .2 0 0" size=".05" mass="3"/>
+      <body name="leg" pos=".2 0 0">
+        <joint name="knee" type="hinge" axis="0 1 0" range="-60 60" limited="true" damping=".2"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -.35" size=".04" mass="1"/>
+        <body name="foot" pos="0 0 -.35">
+          <joint name="ankle" type="hinge" axis="0 1 0" range="-40 40" limited="true" damping=".1"/>
+          <geom type="capsule" fromto="-.05 0 0 .12 0 0" size=".03" mass=".4"/>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+  <actuator><motor joint="knee" gear="30"/><motor joint="ankle" gear="15"/></actuator>
+  <sensor><jointpos joint="knee"/><subtreelinvel body="hip"/></sensor>
+</mujoco>
+"""
+
+
+def test_key_depends_on_model_caps_precision_and_sources(tmp_path, monkeypatch):
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  m = mc.compile_xml(UNSEEN)
+  k = specialise.key(m, 32, 32, (0, 0, 0))
+  assert k == specialise.key(mc.compile_xml(UNSEEN), 32, 32, (0, 0, 0))
+  assert k != specialise.key(m, 64, 32, (0, 0, 0)) and k != specialise.key(m, 32, 64, (0, 0, 0))
+  assert k != specialise.key(m, 32, 32, (24, 0, 0))
+  m2 = mc.compile_xml(UNSEEN.replace('mass="3"', 'mass="3.5"'))
+  assert k != specialise.key(m2, 32, 32, (0, 0, 0))
+  assert specialise.mode() == 'cached'
+  monkeypatch.setenv('DMC_SPECIALISE', '1')
+  assert specialise.mode() == 'build'
+
+
+def test_plugin_cross_compiles_for_an_unseen_model(tmp_path, monkeypatch):
+  """hipcc builds the plugin without a GPU; the object exports the three entry points the library looks up."""
+  import subprocess
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  m = mc.compile_xml(UNSEEN)
+  p = specialise.build(m, 32)
+  assert os.path.exists(p) and p == specialise.path_for(m, 32, 32, (0, 0, 0))
+  syms = subprocess.run(['nm', '-D', p], capture_output=True, text=True).stdout
+  for s in ('dmc_spec_layout', 'dmc_spec_info', 'dmc_spec_launch'):
+    assert s in syms
+  t = os.path.getmtime(p)
+  assert specialise.build(m, 32) == p and os.path.getmtime(p) == t      # cached
+
+
+def _roll(b, m, T, seed=0):
+  rs = np.random.RandomState(seed)
+  B = b.batch_size
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, 2:] += rs.uniform(-.3, .3, (B, m.nq - 2))
+  b.set('qpos', q)
+  for _ in range(T):
+    b.set('ctrl', rs.uniform(-1, 1, (B, m.nu)))
+    b.step()
+  return b.get('qpos'), b.get('sensordata')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol', [(64, 1e-11), (32, 2e-4)])
+def test_attached_plugin_follows_the_generic_kernel(tmp_path, monkeypatch, precision, tol):
+  from dm_control_amd.batch import BatchedPhysics
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  m = mc.compile_xml(UNSEEN)
+  g = BatchedPhysics(m, 64, precision=precision, specialise='off')
+  assert g.specialised == 'off' and g.info()['static_id'] == -1
+  s = BatchedPhysics(m, 64, precision=precision, specialise='cached')
+  assert s.specialised == 'missing'
+  s.close()
+  s = BatchedPhysics(m, 64, precision=precision, specialise='build')
+  assert s.specialised == 'attached' and s.info()['static_id'] == 1000
+  qg, sg = _roll(g, m, 150)
+  qs, ss = _roll(s, m, 150)
+  assert np.isfinite(qs).all() and not s.get('warning').any()
+  np.testing.assert_allclose(qs, qg, rtol=0, atol=tol)
+  np.testing.assert_allclose(ss, sg, rtol=0, atol=tol * 50)
+  # forward / step1 / step2 / rollout modes run through the plugin too
+  s.forward(); s.step1(); s.step2(); s.step(3)
+  assert not s.get('warning').any()
+  # a second batch of the same model finds the object in the cache
+  s2 = BatchedPhysics(m, 8, precision=precision, specialise='cached')
+  assert s2.specialised == 'attached'
+  for b in (g, s, s2):
+    b.close()
+
+
+@pytest.mark.gpu
+def test_plugin_of_another_model_or_other_caps_is_refused(tmp_path, monkeypatch):
+  from dm_control_amd import _native
+  from dm_control_amd.batch import BatchedPhysics
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  m = mc.compile_xml(UNSEEN)
+  p = specialise.build(m, 32)
+  other = mc.compile_xml(common.read_model('pendulum.xml'))
+  b = BatchedPhysics(other, 4, precision=32, specialise='off')
+  assert _native.lib().dmc_batch_attach_specialised(b._ptr, p.encode()) != 0
+  assert b'layout' in _native.lib().dmc_last_error()
+  b.step()
+  b.close()
+  b = BatchedPhysics(m, 4, precision=32, nconmax=24, specialise='off')      # same model, other caps: another layout
+  assert _native.lib().dmc_batch_attach_specialised(b._ptr, p.encode()) != 0
+  b.close()
+  b = BatchedPhysics(m, 4, precision=64, specialise='off')
+  assert _native.lib().dmc_batch_attach_specialised(b._ptr, p.encode()) != 0
+  assert b'precision' in _native.lib().dmc_last_error()
+  b.close()
+
+
+@pytest.mark.gpu
+def test_baked_models_keep_their_baked_kernel():
+  from dm_control_amd.batch import BatchedPhysics
+  m = mc.compile_xml(common.read_model('cheetah.xml'))
+  b = BatchedPhysics(m, 16, precision=32, specialise='build')
+  assert b.specialised == 'baked' and 0 <= b.info()['static_id'] < 1000
+  b.close()
