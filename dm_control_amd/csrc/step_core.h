@@ -562,6 +562,11 @@ template <typename T> DMC_DEV constexpr bool ls_relative() { return sizeof(T) ==
 // section 2, measured on the host build: 8.9e-6 -> see there).  Anchored: the linear coefficient is grad . search, and
 // every row contributes only what CHANGES against its zone at alpha = 0 (a row in the same zone at both ends adds
 // nothing to it, exactly; a switching row adds its own small term).  Same function of alpha in exact arithmetic.
+// Where: measured on the device (profiles/r05_ab_variants.log, one box): the 62-dof walker (general rows, cones in the middle
+// zone) -- one-step error p99 1.9e-6 -> 4.2e-7, max 3.9e-5 -> 8.8e-6, for 1.1 % of its speed; the 27-dof humanoid (one-sided
+// quadratic rows: the anchored form is a few instructions there) max 2.3e-6 -> 8.2e-7, free; the 30-dof soccer model
+// (general rows; already at 2.5e-7 without it) paid 5.5 % for nothing.  So: every model whose rows are all one-sided
+// quadratic, and the general-row models with more than 32 dofs (StepCore::anchored()).
 #ifdef DMC_NO_LS_ANCHOR
 template <typename T> DMC_DEV constexpr bool ls_anchored() { return false; }
 #else
@@ -3426,6 +3431,7 @@ struct StepCore {
     }
     DMC_WSYNC();
   }
+  DMC_DEV bool anchored() const { return ls_anchored<T>() && (!general_rows() || L.d.nv > 32); }
   // Middle-zone cost of a frictional contact, anchored form (ls_anchored): the cost at alpha minus the cost at 0 minus
   // alpha x its slope at 0, and the slope at alpha minus the slope at 0.  With NT = N - mu T the cost is 1/2 Dm NT^2; late
   // in a solve NT moves by less than an fp32 ulp of itself along the whole search, so NT(alpha) - NT(0) must not be
@@ -3449,7 +3455,7 @@ struct StepCore {
   DMC_DEV void ls_eval_ell(dmc::LSPoint<T>* p, const T* qg, int nefc) {
     const T a = p->alpha;
     constexpr bool rel = ls_relative<T>();      // cost relative to alpha = 0 (fp32), see ls_relative
-    constexpr bool anch = ls_anchored<T>();     // ... with the linear term anchored on grad . search, see ls_anchored
+    const bool anch = anchored();               // ... with the linear term anchored on grad . search, see ls_anchored
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     for (int i = lane; i < nefc; i += LPE) {
       const int tid = SI(efc_tid)[i];
@@ -3793,7 +3799,7 @@ struct StepCore {
   DMC_DEV void ls_eval_gen(LSPoint* p, const T* qg, const LSRows& g) {
     const T a = p->alpha;
     constexpr bool rel = ls_relative<T>();
-    constexpr bool anch = ls_anchored<T>();
+    const bool anch = anchored();
     T q0 = 0, q1 = 0, q2 = 0, cc = 0, cd0 = 0, cd1 = 0;
     if (g.kind == LSK_EQUALITY) {
       const T dj0 = g.D*g.jar;
@@ -3911,13 +3917,14 @@ struct StepCore {
 #endif
     if (L.d.elliptic && !rw.gen) ls_prepare_ell(nefc);
     T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    const bool anch = anchored();
     FOR_LANES(i, nv) {
       const T sr = S(sv_search)[i];
-      if (ls_anchored<T>()) a1 += sr*S(sv_grad)[i];      // grad . search: the slope at alpha = 0 itself (see ls_anchored)
+      if (anch) a1 += sr*S(sv_grad)[i];      // grad . search: the slope at alpha = 0 itself (see ls_anchored)
       else { a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; }
       a3 += sr*S(sv_Mv)[i]; a4 += sr*sr;
     }
-    a1 = group_sum<LPE>(a1); if (!ls_anchored<T>()) a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
+    a1 = group_sum<LPE>(a1); if (!anch) a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
     T qg[3] = {gauss, a1 - a2, (T)0.5*a3};
     const T snorm = t_sqrt(a4);
     if (snorm < (T)DMC_MINVAL) return 0;
@@ -4807,7 +4814,11 @@ struct StepCore {
 #ifdef DMC_NO_EXACT_STEP_FLOOR
       const bool exact_step = false;
 #else
-      const bool exact_step = sizeof(T) == 4 && !L.d.cg && !changed && t_abs(alpha - 1) < (T)1e-3;      // (`changed` is also set by any contact in the cone's middle zone, whose cost is not quadratic)
+      // Where: the 9-dof model (-14 % iterations, +0.9 % per single-step launch -- which waits for its slowest wave -- +3 % in
+      // rollout mode; one-step error unchanged at 4.9e-7 max).  On the 27-dof humanoid it bought 1.5 % for a 5 x larger
+      // one-step maximum (8.2e-7 -> 4.0e-6) and on the 62-dof walker nothing for 8.8e-6 -> 4.3e-5
+      // (profiles/r05_ab_variants.log): models with nv <= 16 only.
+      const bool exact_step = sizeof(T) == 4 && !L.d.cg && L.d.nv <= 16 && !changed && t_abs(alpha - 1) < (T)1e-3;      // (`changed` is also set by any contact in the cone's middle zone, whose cost is not quadratic)
 #endif
       const T tol_grad = t_max(o.tolerance, (exact_step ? 64 : 8)*ulp*scale*t_sqrt(ma2));
 #ifdef DMC_HOST_EMU

@@ -98,11 +98,11 @@ class TArr:
       if isinstance(k, TArr):
         return k.t
       if isinstance(k, np.ndarray):
-        return torch.as_tensor(k, device=self.t.device)
+        return _const(k, self.t.device)
       if isinstance(k, (list, tuple)) and len(k) and not isinstance(k[0], (slice, type(Ellipsis), type(None))):
         a = np.asarray(k)
         if a.dtype.kind in 'iub':
-          return torch.as_tensor(a, device=self.t.device)
+          return _const(a, self.t.device)
       if isinstance(k, np.integer):
         return int(k)
       return k
@@ -198,6 +198,26 @@ class TArr:
     return fn(*args, **kwargs)
 
 
+_CONST = {}      # host constants that reached a torch op (index arrays, model scalars, targets): one device copy each
+
+
+def _const(a, device, dtype=None):
+  """Device tensor of the numpy array `a`, cached by content.  The task code hands the same small host arrays to every
+  step (index lists from named indexing, model constants); uploading them per step would also be illegal while the step
+  is being captured into a graph (a pageable host-to-device copy synchronises): the warm-up run before the capture fills
+  this cache, the capture run only reads it."""
+  import torch
+  a = np.ascontiguousarray(a)
+  k = (a.tobytes(), a.dtype.str, a.shape, str(device), dtype)
+  t = _CONST.get(k)
+  if t is None:
+    t = torch.as_tensor(a, device=device)
+    if dtype is not None and t.is_floating_point():
+      t = t.to(dtype)
+    _CONST[k] = t
+  return t
+
+
 def _torch_dtype(dtype):
   import torch
   if isinstance(dtype, torch.dtype):
@@ -217,13 +237,22 @@ def _tensor(x, ref):
   if isinstance(x, np.ndarray):
     if x.ndim == 0:
       return x.item()
-    t = torch.as_tensor(x, device=ref.device)
-    return t.to(ref.dtype) if t.is_floating_point() and ref.is_floating_point() else t
+    return _const(x, ref.device, ref.dtype if (x.dtype.kind == 'f' and ref.is_floating_point()) else None)
   if isinstance(x, (np.floating, np.integer, np.bool_)):
     return x.item()
   if isinstance(x, (list, tuple)):
     return _tensor(np.asarray(x), ref)
   return x
+
+
+def _scalar(x, fl, device):
+  """0-d device tensor of a python scalar, cached (see _const)."""
+  import torch
+  k = ('scalar', x, type(x).__name__, fl if isinstance(x, float) else None, str(device))
+  t = _CONST.get(k)
+  if t is None:
+    t = _CONST[k] = torch.tensor(x, dtype=fl if isinstance(x, float) else None, device=device)
+  return t
 
 
 def _reduce(name, x, axis, keepdims):
@@ -261,9 +290,9 @@ def _where(cond, a=None, b=None):
   ta, tb = _tensor(a, ref), _tensor(b, ref)
   fl = next((t.dtype for t in (ta, tb) if isinstance(t, torch.Tensor) and t.is_floating_point()), None) or TArr.default_float or torch.float64
   if not isinstance(ta, torch.Tensor):
-    ta = torch.tensor(ta, dtype=fl if isinstance(ta, float) else None, device=ref.device)
+    ta = _scalar(ta, fl, ref.device)
   if not isinstance(tb, torch.Tensor):
-    tb = torch.tensor(tb, dtype=fl if isinstance(tb, float) else None, device=ref.device)
+    tb = _scalar(tb, fl, ref.device)
   return TArr(torch.where(c, ta, tb))
 
 
@@ -272,7 +301,7 @@ def _cat(fn):
     import torch
     ref = _first(arrays)
     ts = [_tensor(a, ref) for a in arrays]
-    ts = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t, device=ref.device) for t in ts]
+    ts = [t if isinstance(t, torch.Tensor) else _const(np.asarray(t), ref.device) for t in ts]
     fl = next((t.dtype for t in ts if t.is_floating_point()), None)
     if fl is not None:
       ts = [t.to(fl) if t.is_floating_point() else t for t in ts]
@@ -310,7 +339,7 @@ def _build_tables():
     def run(*xs):
       ref = next(x for x in xs if isinstance(x, torch.Tensor))
       fl = ref.dtype if ref.is_floating_point() else (TArr.default_float or torch.float64)
-      return fn(*[x if isinstance(x, torch.Tensor) else torch.tensor(x, dtype=fl if isinstance(x, float) else None, device=ref.device) for x in xs])
+      return fn(*[x if isinstance(x, torch.Tensor) else _scalar(x, fl, ref.device) for x in xs])
     return run
   for k in ('maximum', 'minimum', 'arctan2', 'logical_and', 'logical_or', 'hypot', 'power', 'add', 'subtract', 'multiply', 'true_divide',
             'divide', 'less', 'less_equal', 'greater', 'greater_equal', 'equal', 'not_equal'):
@@ -585,10 +614,12 @@ class GenericDeviceEnv:
     torch = self.torch
     if self._graph is None:
       self._g_action = action.clone()
+      state = [self._tensors[n] for n in ('qpos', 'qvel', 'qacc_warmstart', 'time', 'ctrl', 'act') if n in self._tensors]
+      saved = [t.clone() for t in state]
       side = torch.cuda.Stream()
       side.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(side):              # warm-up off the default stream, as graph capture requires
-        self._g_out = self._control_step(self._g_action)
+      with torch.cuda.stream(side):              # warm-up off the default stream, as graph capture requires; it also fills
+        self._control_step(self._g_action)       # the cache of device constants (_const), so that the capture run uploads nothing
       torch.cuda.current_stream().wait_stream(side)
       reads = TArr.host_reads
       graph = torch.cuda.CUDAGraph()
@@ -596,8 +627,9 @@ class GenericDeviceEnv:
         self._g_out = self._control_step(self._g_action)
       if TArr.host_reads != reads:
         raise RuntimeError('the task layer read the device during capture')
+      for t, v in zip(state, saved):             # the warm-up step is taken back: the replay below is this call's step
+        t.copy_(v)
       self._graph = graph
-      return self._g_out      # (the capture run itself does not execute: replay below on the next call)
     self._g_action.copy_(action)
     self._graph.replay()
     return self._g_out
@@ -606,9 +638,7 @@ class GenericDeviceEnv:
     """action: (B, nu) tensor on the device.  Returns (obs, reward, done); when the time limit is reached every
     environment restarts and the returned observation is the new episode's first."""
     if self._capture:
-      if self._graph is None:
-        self._captured_step(action)      # captures (no execution) ...
-      obs, rew = self._captured_step(action)      # ... then every step is a replay
+      obs, rew = self._captured_step(action)
     else:
       obs, rew = self._control_step(action)
     self.steps += 1

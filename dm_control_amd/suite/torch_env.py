@@ -59,8 +59,9 @@ class TorchBatchedEnv:
   _CONTROL_TIMESTEP = None  # None: one physics step per env step unless n_sub_steps is given
   _RUN_SPEED = 10.0
 
-  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=None):
+  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=None, capture=False):
     import torch
+    self._capture, self._graph = bool(capture), None
     self.torch = torch
     self.device = torch.device('cuda', device_id)
     self.model = mjcf_compiler.compile_xml(self._model_xml())
@@ -177,9 +178,45 @@ class TorchBatchedEnv:
     speed = self.sensordata[0]
     return self.torch.clamp(speed / self._RUN_SPEED, 0.0, 1.0)
 
+  def _steady_step(self, action):
+    """A control step in which no environment can finish: ctrl write, the physics launch, counters, reward, observation --
+    device operations only, no host decision."""
+    self.ctrl.copy_(action.T.to(self.dtype))
+    self.physics.step(self.n_sub_steps, stream=self._stream())
+    self.steps += 1
+    return self.observation(), self.reward().clone(), self.steps >= self.step_limit
+
+  def _graph_step(self, action):
+    """The steady step as a HIP graph (torch.cuda.CUDAGraph; the physics kernel is launched on the capturing stream): the
+    ~10 small launches of the task layer cost one replay.  Returns the graph's own output tensors, rewritten by the next
+    replay."""
+    torch = self.torch
+    if self._graph is None:
+      self._g_action = action.clone()
+      state = [self.qpos, self.qvel, self.warm, self.time, self.ctrl, self.steps] + ([self.act] if self.model.na else [])
+      saved = [t.clone() for t in state]
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):              # warm-up off the default stream, as graph capture requires
+        self._steady_step(self._g_action)
+      torch.cuda.current_stream().wait_stream(side)
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        self._g_out = self._steady_step(self._g_action)
+      for t, v in zip(state, saved):             # the warm-up step is taken back: the replay below is this call's step
+        t.copy_(v)
+      self._graph = graph
+    self._g_action.copy_(action)
+    self._graph.replay()
+    return self._g_out
+
   def step(self, action):
     """action: (B, nu) tensor on device.  Returns (obs, reward, done) tensors; finished
     environments are auto-reset (their returned obs is the fresh start state)."""
+    if self._capture and self._host_steps + 1 < self.step_limit:      # nobody can reach the limit in this step
+      out = self._graph_step(action)
+      self._host_steps += 1
+      return out
     self.ctrl.copy_(action.T.to(self.dtype))
     self.physics.step(self.n_sub_steps, stream=self._stream())
     self.steps += 1

@@ -16,8 +16,9 @@ from dm_control_amd.suite import device_env, torch_env
 
 B = int(os.environ.get('B', 4096))
 out = {'torch_env': [], 'device_env': []}
-for domain, task, T in (('cheetah', 'run', 1000), ('humanoid', 'stand', 1000)):
-  env = torch_env.make(domain, task, B, precision=32, seed=0)
+for domain, task, T, graph in (('cheetah', 'run', 1000, False), ('cheetah', 'run', 1000, True), ('humanoid', 'stand', 1000, False),
+                               ('humanoid', 'stand', 1000, True)):
+  env = torch_env.make(domain, task, B, precision=32, seed=0, capture=graph)
   nu = env.model.nu
   g = torch.Generator(device='cuda').manual_seed(0)
   acts = torch.rand((100, B, nu), device='cuda', generator=g) * 2 - 1
@@ -37,7 +38,7 @@ for domain, task, T in (('cheetah', 'run', 1000), ('humanoid', 'stand', 1000)):
     env.physics.step(env.n_sub_steps, stream=torch.cuda.current_stream().cuda_stream)
   torch.cuda.synchronize()
   dp = (time.perf_counter() - t1) / 200
-  r = dict(task='%s %s' % (domain, task), B=B, env_steps=T, n_sub_steps=env.n_sub_steps, env_steps_per_s=B * T / dt,
+  r = dict(task='%s %s' % (domain, task), mode='HIP graph' if graph else 'eager', B=B, env_steps=T, n_sub_steps=env.n_sub_steps, env_steps_per_s=B * T / dt,
            physics_only_env_steps_per_s=B / dp, ratio=(B * T / dt) / (B / dp), obs_finite=bool(torch.isfinite(obs).all()),
            warnings=env.physics.get('warning').sum(axis=0).tolist())
   print(json.dumps(r), flush=True)

@@ -89,11 +89,27 @@ def test_attached_plugin_follows_the_generic_kernel(tmp_path, monkeypatch, preci
   s.close()
   s = BatchedPhysics(m, 64, precision=precision, specialise='build')
   assert s.specialised == 'attached' and s.info()['static_id'] == 1000
-  qg, sg = _roll(g, m, 150)
-  qs, ss = _roll(s, m, 150)
-  assert np.isfinite(qs).all() and not s.get('warning').any()
-  np.testing.assert_allclose(qs, qg, rtol=0, atol=tol)
-  np.testing.assert_allclose(ss, sg, rtol=0, atol=tol * 50)
+  # fp64 open loop; fp32 step by step from the generic kernel's state (two fp32 kernels with different operation orders
+  # part ways at the first just-touching contact of a 150-step rollout: what is compared is the step)
+  if precision == 64:
+    qg, sg = _roll(g, m, 150)
+    qs, ss = _roll(s, m, 150)
+    np.testing.assert_allclose(qs, qg, rtol=0, atol=tol)
+    np.testing.assert_allclose(ss, sg, rtol=0, atol=tol * 50)
+  else:
+    rs = np.random.RandomState(0)
+    q = np.tile(m.qpos0, (64, 1)); q[:, 2:] += rs.uniform(-.3, .3, (64, m.nq - 2))
+    g.set('qpos', q)
+    worst = 0.0
+    for _ in range(150):
+      c = rs.uniform(-1, 1, (64, m.nu))
+      for f in ('qpos', 'qvel', 'qacc_warmstart'):
+        s.set(f, g.get(f))
+      for b in (g, s):
+        b.set('ctrl', c); b.step()
+      worst = max(worst, float(np.abs(s.get('qpos') - g.get('qpos')).max()))
+    assert worst < 2e-5, worst
+  assert np.isfinite(s.get('qpos')).all() and not s.get('warning').any()
   # forward / step1 / step2 / rollout modes run through the plugin too
   s.forward(); s.step1(); s.step2(); s.step(3)
   assert not s.get('warning').any()
