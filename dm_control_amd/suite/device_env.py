@@ -222,6 +222,10 @@ def _torch_dtype(dtype):
   import torch
   if isinstance(dtype, torch.dtype):
     return dtype
+  # numpy code says float64 for "a float": on the device that is the batch's own precision (mixing the two would also
+  # stop torch's einsum / where, which do not promote)
+  if np.dtype(dtype) == np.float64 and TArr.default_float is not None:
+    return TArr.default_float
   return {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
           np.dtype(np.int64): torch.int64, np.dtype(np.bool_): torch.bool}[np.dtype(dtype)]
 

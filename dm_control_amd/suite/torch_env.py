@@ -105,6 +105,7 @@ class TorchBatchedEnv:
     self._mask_i = torch.zeros(self.B, dtype=torch.int32, device=self.device)
     self._q0 = torch.from_numpy(np.ascontiguousarray(m.qpos0, dtype=np.float64)).to(self.device, self.dtype)[:, None]
     self.reset_rounds = 0      # launches the last reset needed (rejection / raising loops)
+    self._none_done = torch.zeros(self.B, dtype=torch.bool, device=self.device)
     self._setup()
     self.reset()
 
@@ -176,7 +177,7 @@ class TorchBatchedEnv:
   def reward(self):
     """rewards.tolerance(speed, bounds=(10, inf), margin=10, value_at_margin=0, 'linear')."""
     speed = self.sensordata[0]
-    return self.torch.clamp(speed / self._RUN_SPEED, 0.0, 1.0)
+    return self.torch.clamp(speed * (1.0 / self._RUN_SPEED), 0.0, 1.0)
 
   def _steady_step(self, action):
     """A control step in which no environment can finish: ctrl write, the physics launch, counters, reward, observation --
@@ -221,8 +222,13 @@ class TorchBatchedEnv:
     self.physics.step(self.n_sub_steps, stream=self._stream())
     self.steps += 1
     self._host_steps += 1
-    reward = self.reward().clone()
-    done = self.steps >= self.step_limit
+    reward = self.reward()
+    # (no environment has taken more steps than the host-side count: below the limit `done` is all-false without asking)
+    if self._host_steps >= self.step_limit:
+      reward = reward.clone()      # (a reset below may rewrite what the reward is a view of)
+      done = self.steps >= self.step_limit
+    else:
+      done = self._none_done
     obs = self.observation()
     # The time limit is the only termination, and no environment has taken more steps than the
     # host-side count since the last reset of everything: before that count reaches the limit

@@ -133,8 +133,9 @@ def test_plugin_of_another_model_or_other_caps_is_refused(tmp_path, monkeypatch)
   assert b'layout' in _native.lib().dmc_last_error()
   b.step()
   b.close()
-  b = BatchedPhysics(m, 4, precision=32, nconmax=24, specialise='off')      # same model, other caps: another layout
+  b = BatchedPhysics(m, 4, precision=32, nconmax=2, specialise='off')      # same model, a contact cap below its default: another layout
   assert _native.lib().dmc_batch_attach_specialised(b._ptr, p.encode()) != 0
+  assert b'layout' in _native.lib().dmc_last_error()
   b.close()
   b = BatchedPhysics(m, 4, precision=64, specialise='off')
   assert _native.lib().dmc_batch_attach_specialised(b._ptr, p.encode()) != 0
