@@ -459,12 +459,12 @@ extern "C" int dmc_batch_attach_specialised(dmc_batch* b, const char* so_path) {
   void* launch = dlsym(h, "dmc_spec_launch");
   if (!fl || !fi || !launch) { dlclose(h); return fail("not a specialisation plugin (dmc_spec_* symbols missing)"); }
   int info[8]; fi(info);
+  if (info[4] != b->precision) { dlclose(h); return fail("the plugin was built for another precision"); }
   const int so = b->precision == 64 ? (int)sizeof(StepOpts<double>) : (int)sizeof(StepOpts<float>);
   const int sio = b->precision == 64 ? (int)sizeof(StepIO<double>) : (int)sizeof(StepIO<float>);
   if (info[0] != (int)sizeof(StepLayout) || info[1] != so || info[2] != sio || info[3] != DMC_MODEL_VERSION || info[7] != (int)sizeof(LaunchGeom)) {
     dlclose(h); return fail("the plugin was built from other sources than this library (struct sizes / model version differ)");
   }
-  if (info[4] != b->precision) { dlclose(h); return fail("the plugin was built for another precision"); }
   if (info[5] != b->geom.lpe) { dlclose(h); return fail("the plugin was built for another lanes-per-environment shape"); }
   if (memcmp(fl(), &b->tb.L, sizeof(StepLayout)) != 0) { dlclose(h); return fail("the plugin's layout is not this batch's (another model or other caps)"); }
   if (b->spec_so) dlclose(b->spec_so);
