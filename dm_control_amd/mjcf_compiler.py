@@ -459,7 +459,7 @@ class _Compiler:
       with open(fname, 'rb') as f:
         return f.read()
     except OSError:
-      raise MjcfError('asset file %r not found' % fname)
+      raise MjcfError('mesh / texture asset file %r not found' % fname)
 
   def _expand_includes(self, elem):
     i = 0

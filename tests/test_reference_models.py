@@ -51,7 +51,7 @@ def test_every_suite_xml_except_mesh_and_hfield_models_compiles():
     except mc.MjcfError as ex:
       refused[name] = str(ex)
   assert set(refused) == {'dog.xml', 'quadruped.xml'}, refused         # meshes; height field (escape task only)
-  assert all('mesh/hfield' in v for v in refused.values())
+  assert all(('mesh' in v or 'hfield' in v) for v in refused.values()), refused      # dog: mesh assets / mesh geoms on moving bodies; quadruped: the escape task's height field
   assert len(ok) == 17
 
 
