@@ -88,6 +88,7 @@ def parse(argv=None):
   ap.add_argument('--parity-envs', type=int, default=None)
   ap.add_argument('--parity-steps', type=int, default=None)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--pipeline', type=int, default=2, help='part-batches of the pipelined leg (0 / 1 = skip)')
   ap.add_argument('--cpu-envs', type=int, default=4096)
   ap.add_argument('--cpu-seconds', type=float, default=10.0)
   ap.add_argument('--pmc-child', action='store_true', help='internal: only the timed launches (run under rocprofv3 by the parent)')
@@ -543,6 +544,57 @@ def main():
   torch.cuda.synchronize()
   rollout_elapsed = max_over_ranks(time.perf_counter() - r0)
 
+  # ---- pipelined leg: the SAME B environments as P independent part-batches on P streams (part p's launch t+1 waits for
+  # part p's launch t only, so the straggler tail of one part's queued launch overlaps the next part's launch).  A usage
+  # mode of the existing API (P BatchedPhysics objects), reported beside `value`, never as `value`.
+  pipe = None
+  P = args.pipeline
+  if P > 1 and B % P == 0:
+    Bp = B // P
+    parts, pstreams, pctrl = [], [], []
+    for p in range(P):
+      ph = BatchedPhysics(model, Bp, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes, **caps)
+      ph.set('qpos', q0[p*Bp:(p+1)*Bp])
+      ph.set_output_mask(mask)
+      ps = torch.cuda.Stream()
+      if cfg['asset'] == 'cheetah':
+        zc = torch.zeros((model.nu, Bp), dtype=tdtype, device=dev)
+        ph.bind('ctrl', zc.data_ptr())
+        ph.step(200, stream=ps.cuda_stream)
+        torch.cuda.synchronize()
+        ph.set('time', np.zeros((Bp, 1)))
+      else:
+        ph.forward()
+      parts.append(ph); pstreams.append(ps)
+      pctrl.append(actions[:, :, p*Bp:(p+1)*Bp].contiguous())
+    torch.cuda.synchronize()
+
+    def run_parts(t0, n):
+      for t in range(t0, t0 + n):
+        for p in range(P):
+          parts[p].bind('ctrl', pctrl[p][t].data_ptr())
+          parts[p].step(nsub, stream=pstreams[p].cuda_stream)
+
+    run_parts(0, W)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    p0 = time.perf_counter()
+    run_parts(W, K)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    pipe_elapsed = max_over_ranks(time.perf_counter() - p0)
+    pipe_q = np.concatenate([ph.get('qpos') for ph in parts], axis=0)
+    pipe = dict(value=world * B * K / pipe_elapsed, unit='env-steps/s', parts=P, batch_per_part=Bp, steps=K,
+                ms_per_env_step=1e3 * pipe_elapsed / K,
+                max_abs_qpos_diff_vs_single_batch=float(np.max(np.abs(pipe_q - q_end))),
+                note='same environments, actions and step count as `value`, stepped as %d independent part-batches on %d HIP '
+                     'streams (one Physics.step() launch per part per env-step); the end state is compared with the '
+                     'single-batch run' % (P, P))
+    for ph in parts:
+      ph.close()
+
   # ---- agent-interface collectives (N > 1): actions scattered from rank 0, observations gathered to all ranks
   coll = None
   if world > 1:
@@ -636,6 +688,8 @@ def main():
                                'wait_any_over_wave_cycles': (pmc['SQ_WAIT_ANY'] / pmc['SQ_WAVE_CYCLES'])
                                if pmc.get('SQ_WAIT_ANY') and pmc.get('SQ_WAVE_CYCLES') else None,
                                'source': pmc_source}
+    if pipe:
+      out['pipelined'] = pipe
     if coll:
       out['collectives'] = coll
     nthreads = os.cpu_count() or 1
