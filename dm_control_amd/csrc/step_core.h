@@ -26,6 +26,7 @@
 #ifdef DMC_HOST_EMU
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #endif
 
 #include "../../include/dmc_model_layout.h"
@@ -53,6 +54,9 @@
 #endif
 
 namespace dmc {
+#ifdef DMC_HOST_EMU
+inline int& emu_split_solves() { static int n = 0; return n; }      // solves whose H was taken as block diagonal over the trees (tests)
+#endif
 
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
 // phase cycle counters in the env's LDS scratch (lane 0): the stages stay out of line, so the profiling build has the
@@ -500,6 +504,81 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   DMC_WSYNC();
 }
 #endif
+// ---- block diagonal over the kinematic trees (StepDims::treemax) ------------------------------------------------
+// M -- and H = M + J'DJ as long as no constraint row moves two trees -- is block diagonal over the kinematic trees of a
+// multi-body scene (soccer 2v2: five trees of six dofs).  The row-per-lane routines above run the N columns one after
+// the other, N (N + 1) / 2 cross-lane broadcasts + FMAs, of which all but the in-tree ones multiply exact zeros; a lone
+// wave per SIMD pays ~9 cycles per instruction, so the 30 x 30 factorisation was 16 k cycles, 8 % of the soccer step, and
+// each substitution 11 k.  Here every tree eliminates ITS column kk = 0 .. TM-1 at the same time: the pivot lane differs
+// per tree, so the broadcasts are per-lane-addressed (ds_bpermute) instead of v_readlane: TM (TM + 1) / 2 of them for
+// the whole matrix.  Entry for entry the same operations in the same order as chol_factor_rows / chol_solve_rows --
+// what is skipped is  a - 0 * x -- so the results are bit-identical.  t0 / t1: first dof / 1 + last dof of the lane's
+// tree.  One environment per wave (LPE = 64).
+#ifndef DMC_HOST_EMU
+DMC_DEV float lane_read(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v))); }
+DMC_DEV double lane_read(double v, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T, int LPE, int N, int TM>
+DMC_FN void chol_factor_trees(DMC_LDS T* A, int lane, int t0, int t1) {
+  static_assert(LPE == 64 && N <= LPE, "one lane per matrix row, one environment per wave");
+  DMC_WSYNC();
+  T a[TM];
+  const bool own = lane < N;
+#pragma unroll
+  for (int kk = 0; kk < TM; kk++) { const int j = t0 + kk; a[kk] = (own && j <= lane) ? A[tri_c0(j, N) + lane - j] : (T)0; }
+#pragma unroll
+  for (int kk = 0; kk < TM; kk++) {
+    const int src = t0 + kk;
+    T akk = lane_read(a[kk], src);
+    if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
+    const T inv = t_rsqrt(akk);
+    const T lik = (own && src < t1) ? a[kk] * inv : (T)0;      // (a tree with fewer than TM dofs sits these columns out)
+#pragma unroll
+    for (int jj = kk + 1; jj < TM; jj++) { const T ljk = lane_read(lik, t0 + jj); a[jj] = a[jj] - lik * ljk; }
+    a[kk] = lane == src ? inv : lik;
+  }
+#pragma unroll
+  for (int kk = 0; kk < TM; kk++) { const int j = t0 + kk; if (own && j <= lane) A[tri_c0(j, N) + lane - j] = a[kk]; }
+  DMC_WSYNC();
+}
+template <typename T, int LPE, int N, int TM>
+DMC_FN void chol_solve_trees(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* b, int lane, int t0, int t1) {
+  static_assert(LPE == 64 && N <= LPE, "one lane per unknown, one environment per wave");
+  const int i = lane;
+  const bool own = i < N;
+  const int ci = tri_c0(own ? i : 0, N);
+  T row[TM], col[TM], dk[TM];
+  const T dinv = own ? Lm[ci] : (T)0;      // 1 / L[i][i]
+#pragma unroll
+  for (int kk = 0; kk < TM; kk++) {
+    const int k = t0 + kk;
+    row[kk] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0;
+    col[kk] = (own && k > i && k < t1) ? Lm[ci + k - i] : (T)0;
+    dk[kk] = lane_read(dinv, k);
+  }
+  T sreg = own ? b[i] : (T)0;
+#pragma unroll
+  for (int kk = 0; kk < TM; kk++) {
+    const int k = t0 + kk;
+    const T xk = lane_read(sreg, k) * dk[kk];
+    if (i == k) sreg = xk;
+    if (i > k && own) sreg -= row[kk]*xk;
+  }
+#pragma unroll
+  for (int kk = TM - 1; kk >= 0; kk--) {
+    const int k = t0 + kk;
+    const T xk = lane_read(sreg, k) * dk[kk];
+    if (i == k) sreg = xk;
+    if (i < k && k < t1 && own) sreg -= col[kk]*xk;
+  }
+  if (own) x[i] = sreg;
+  DMC_WSYNC();
+}
+#endif
 // x = (L L')^-1 b (x may alias b); Lm as produced by chol_factor_lds
 //   n <= LPE : lane i carries x[i] in a register; the pivot value travels by a
 //              cross-lane broadcast, no LDS round trip, no fence inside the loops.
@@ -622,6 +701,7 @@ struct DynLayoutSrc {
   static constexpr int kNV = 0;   // nv only known at run time
   static constexpr int kJGlobal = -1;   // so is StepDims::jglobal
   static constexpr int kNKin = 0;       // and the size of the kinematic stash
+  static constexpr int kTreeMax = 0;    // and StepDims::treemax (the side-by-side tree factorisations are register routines)
   const StepLayout* p;
   DMC_DEV const StepLayout& get() const { return *p; }
 };
@@ -643,6 +723,7 @@ struct StepCore {
   int* si;
   int lane;
   double time_;           // simulation time of this env (group-uniform)
+  bool hsplit;            // this solve's H is block diagonal over the kinematic trees (h_split; group-uniform)
 
 
   DMC_DEV StepCore(LS ls_, const StepOpts<T>& o_, const int* mi_, const T* mr_, const int* gc_, T* s_, int* si_, int lane_)
@@ -654,7 +735,7 @@ struct StepCore {
 #else
         gc(gc_),
 #endif
-        s(s_), si(si_), lane(lane_), time_(0) {}
+        s(s_), si(si_), lane(lane_), time_(0), hsplit(false) {}
 
 #define MI(n) (mi + L.mi_##n)
 #define MR(n) (mr + L.mr_##n)
@@ -1161,14 +1242,34 @@ struct StepCore {
   }
 
   // ---- dense Cholesky / solves in LDS (out-of-line: chol_factor_lds / chol_solve_lds) ----
-  DMC_DEV void chol_factor_inplace(T* A, int n) {
+  // `split`: the matrix is block diagonal over the kinematic trees (M always; H when h_split())
+  static constexpr bool kSplit = LS::kTreeMax > 0 && LPE == 64 && LS::kNV <= LPE
+#ifdef DMC_NO_TREE_SPLIT
+                                 && false
+#endif
+      ;
+  DMC_DEV void chol_factor_inplace(T* A, int n, bool split = false) {
 #ifndef DMC_HOST_EMU
+    if constexpr (kSplit) {
+      if (split) {
+        const int t0 = lane < LS::kNV ? MI(dof_tree0)[lane] : 0, t1 = lane < LS::kNV ? MI(dof_tree1)[lane] : 0;
+        chol_factor_trees<T, LPE, LS::kNV, LS::kTreeMax>((DMC_LDS T*)A, lane, t0, t1);
+        return;
+      }
+    }
     if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { chol_factor_rows<T, LPE, LS::kNV>((DMC_LDS T*)A, lane); return; }
 #endif
     chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane);
   }
-  DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n) {
+  DMC_DEV void chol_solve(T* x, const T* Lm, const T* b, int n, bool split = false) {
 #ifndef DMC_HOST_EMU
+    if constexpr (kSplit) {
+      if (split) {
+        const int t0 = lane < LS::kNV ? MI(dof_tree0)[lane] : 0, t1 = lane < LS::kNV ? MI(dof_tree1)[lane] : 0;
+        chol_solve_trees<T, LPE, LS::kNV, LS::kTreeMax>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, lane, t0, t1);
+        return;
+      }
+    }
     if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { chol_solve_rows<T, LPE, LS::kNV>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, lane); return; }
 #endif
     chol_solve_lds<T, LPE>((DMC_LDS T*)x, (const DMC_LDS T*)Lm, (const DMC_LDS T*)b, n, lane);
@@ -1339,7 +1440,7 @@ struct StepCore {
 #endif
     scatter_M(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
     DMC_PROF(PROF_X3);
-    chol_factor_inplace(dst, L.d.nv);
+    chol_factor_inplace(dst, L.d.nv, true);      // M (+ a diagonal) is block diagonal over the trees
     if (!with_damping && L.d.jglobal && L.d.nslip) {
       DMC_GLB T* g = (DMC_GLB T*)gLM();
       FOR_LANES(i, L.d.ntri) g[i] = dst[i];
@@ -3163,7 +3264,7 @@ struct StepCore {
       }
     }
     DMC_WSYNC();
-    chol_solve(S(qacc_smooth), M_factor(), S(qfrc_smooth), L.d.nv);
+    chol_solve(S(qacc_smooth), M_factor(), S(qfrc_smooth), L.d.nv, true);
   }
 
   // ---- Newton solver on the primal (mj_fwdConstraint / mj_solNewton) -----------------
@@ -3397,6 +3498,71 @@ struct StepCore {
       }
       DMC_WSYNC();
     }
+  }
+  // H of a split solve (h_split): only the entries inside the trees' diagonal blocks exist, and the side-by-side
+  // factorisation and substitutions read nothing else.  One lane per in-tree entry (StepDims::ntreetri: 105 for five 6-dof
+  // trees, against 465 packed entries zero-filled, the scatter of M and one FENCED pass per contact -- 1.8 k instructions
+  // per assembly on the soccer model, where an instruction of a lone wave costs ~9 cycles): M(i, j) from the sparse M, the
+  // diagonal sum of the one-nonzero rows, then the contacts IN ORDER -- a contact adds to the entry when both dofs are in
+  // its mask -- so every entry is the same sum in the same order as hess_assemble's.
+  DMC_DEV void hess_assemble_split(int nefc, const RowMap& rm) {
+    const int nv = L.d.nv, K = L.d.kmax;
+    FOR_LANES(i, nv) {
+      T dsum = 0;
+      for (int r = rm.s0; r < rm.tl0; r += 4) {      // four rows per trip: their loads are issued together
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool in = r + u < rm.tl0;
+          const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
+          const T dd = in ? S(efc_D)[r + u] : (T)0;
+          if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
+        }
+      }
+      S(sv_Mgrad)[i] = dsum;
+    }
+#ifdef DMC_HOST_EMU
+    FOR_LANES(t, L.d.ntri) S(qLH)[t] = 0;      // (the emulation factors the whole matrix)
+#endif
+    DMC_WSYNC();
+    const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
+    const auto Jc_base = Jc();
+    for (int t = lane; t < L.d.ntreetri; t += LPE) {
+      const int pk = MI(tree_tri)[t], i = pk & 0xffff, j = pk >> 16, mix = MI(tree_trim)[t];
+      T h = mix >= 0 ? qMs()[mix] : (T)0;
+      if (i == j) h += S(sv_Mgrad)[i];
+      for (int c = 0; c < ncon; c++) {
+        const int r0 = SI(con_efc)[c];
+        if (r0 < 0) continue;
+        const int nrow = contact_rows(con_dim(c));
+        const bool cone = L.d.elliptic && SI(efc_active)[r0] == EFC_ST_CONE;
+        bool any = cone;
+        for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) any = any || SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC;
+        if (!any) continue;               // group-uniform
+        const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
+        const int a = mask_slot(lo, hi, i), b2 = mask_slot(lo, hi, j);
+        if (a < 0 || b2 < 0) continue;
+        const auto J = Jc_base + (r0 - rm.c0)*K;
+        T acc = 0;
+        if (cone) {
+          T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+          for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) {
+            const T ji = J[q*K + a], jj = J[q*K + b2];
+            const T ca = S(efc_ca)[r0 + q];
+            Pi += ca*ji; Pj += ca*jj;
+            if (q) { const T cb = S(efc_cb)[r0 + q]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r0 + q]*ji*jj; }
+          }
+          acc = S(efc_cg)[r0]*(Pi*Pj) - S(efc_cb)[r0]*(Wi*Wj) + g;
+        } else {
+          for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
+            const T ji = J[q*K + a];
+            if (ji != 0) acc += (S(efc_D)[r0 + q]*ji) * J[q*K + b2];
+          }
+        }
+        h += acc;
+      }
+      S(qLH)[tri_at(i, j, nv)] = h;
+    }
+    DMC_WSYNC();
   }
   // Once per line search (elliptic models): what a frictional contact contributes to every evaluation depends on alpha
   // only through N = U0 + alpha V0 and T^2 = UU + alpha (2 UV + alpha VV); those aggregates, the regularised mu and the
@@ -3724,8 +3890,8 @@ struct StepCore {
     DMC_PROF(PROF_SOL_GRAD);
     // CG (mj_solPrimal with flg_Newton = 0): the gradient preconditioned with M^-1 -- the factor mj_factorM left
     // (no Hessian is ever assembled, so it is still in place)
-    if (L.d.cg) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
-    if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv); DMC_PROF(PROF_SOLVE); return; }
+    if (L.d.cg) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv, true); DMC_PROF(PROF_SOLVE); return; }
+    if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv, hsplit); DMC_PROF(PROF_SOLVE); return; }
 #if !defined(DMC_HOST_EMU) && !defined(DMC_NO_HESS_ROWS)
     if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
       if (L.d.jfull && !L.d.msparse && !L.d.elliptic) {
@@ -3738,12 +3904,53 @@ struct StepCore {
       }
     }
 #endif
+#ifdef DMC_HOST_EMU
+    // The emulation factors H in full either way.  With hsplit set it checks what the device relies on: the full
+    // assembly has an exact zero wherever an entry joins two trees, and the in-tree assembly produces the same bits.
     hess_assemble(nefc, row_map());
+    if (hsplit) {
+      T* full = (T*)malloc(sizeof(T)*L.d.ntri);
+      for (int t = 0; t < L.d.ntri; t++) full[t] = S(qLH)[t];
+      for (int i = 0; i < nv; i++) for (int j = 0; j < MI(dof_tree0)[i]; j++) if (full[tri_at(i, j, nv)] != 0) {
+        fprintf(stderr, "h_split: H(%d, %d) = %g joins two trees\n", i, j, (double)full[tri_at(i, j, nv)]); abort();
+      }
+      hess_assemble_split(nefc, row_map());
+      for (int t = 0; t < L.d.ntri; t++) if (memcmp(&full[t], &S(qLH)[t], sizeof(T))) {
+        fprintf(stderr, "hess_assemble_split: packed entry %d is %.17g, hess_assemble has %.17g\n", t, (double)S(qLH)[t], (double)full[t]); abort();
+      }
+      free(full);
+    }
+#else
+#ifndef DMC_NO_TREE_SPLIT
+    if (hsplit) hess_assemble_split(nefc, row_map()); else
+#endif
+    hess_assemble(nefc, row_map());
+#endif
     DMC_PROF(PROF_HESS);
-    chol_factor_inplace(S(qLH), nv);
+    chol_factor_inplace(S(qLH), nv, hsplit);
     DMC_PROF(PROF_FACTOR);
-    chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+    chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv, hsplit);
     DMC_PROF(PROF_SOLVE);
+  }
+  // Is H = M + J'DJ of this solve block diagonal over the kinematic trees?  Yes unless a constraint row moves two of them:
+  // a contact between bodies of two trees (its dof mask leaves the tree of its first dof), or any dense row (equalities,
+  // tendon limits -- not looked at, taken as coupling).  Dof-friction and joint-limit rows have one nonzero.  Decided once
+  // per solve from the rows that exist, active or not.
+  DMC_DEV bool h_split(int nefc) {
+    if (!L.d.treemax) return false;
+    const RowMap rm = row_map();
+    if (rm.s0 > 0 || rm.c0 > rm.tl0) return false;
+    const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
+    int coupled = 0;
+    for (int c = lane; c < ncon; c += LPE) {
+      if (SI(con_efc)[c] < 0) continue;
+      const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
+      if (!(lo | hi)) continue;
+      const int first = lo ? __builtin_ctz(lo) : 32 + __builtin_ctz(hi);
+      const int last = hi ? 63 - __builtin_clz(hi) : 31 - __builtin_clz(lo);
+      if (last >= MI(dof_tree1)[first]) coupled = 1;
+    }
+    return group_max<LPE>(coupled) == 0;
   }
   typedef dmc::LSPoint<T> LSPoint;
   // Line search on REGISTER-RESIDENT rows: with at most one constraint row per lane (nefc <= LPE) and only one-sided
@@ -4449,7 +4656,7 @@ struct StepCore {
       const int rb = SI(ns_row)[b];
       FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(rb, i, rm);
       DMC_WSYNC();
-      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv);
+      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv, true);
       { T* A = ns_A(); const int cap = L.d.nslip;
         for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
@@ -4494,7 +4701,7 @@ struct StepCore {
     DMC_WSYNC();
     FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
     DMC_WSYNC();
-    chol_solve(S(qacc), M_factor(), S(sv_grad), nv);
+    chol_solve(S(qacc), M_factor(), S(sv_grad), nv, true);
     DMC_WSYNC();
   }
   // ---- PGS (mj_solPGS; option solver="PGS", dm_control/mjcf/schema.xml:69-72; same algorithm and operation order as the
@@ -4600,7 +4807,7 @@ struct StepCore {
     if (!built) for (int b = 0; b < nefc; b++) {
       FOR_LANES(i, nv) S(sv_grad)[i] = row_entry(b, i, rm);
       DMC_WSYNC();
-      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv);
+      chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv, true);
       { T* A = ns_A();
         for (int a = b + lane; a < nefc; a += LPE) { const T v = row_dot(a, S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; } }
       DMC_WSYNC();
@@ -4662,7 +4869,7 @@ struct StepCore {
     // dualFinish: qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 qfrc_constraint
     constraint_force_to_joint(nefc);
     DMC_WSYNC();
-    chol_solve(S(sv_Mgrad), M_factor(), S(qfrc_constraint), nv);
+    chol_solve(S(sv_Mgrad), M_factor(), S(qfrc_constraint), nv, true);
     FOR_LANES(i, nv) { const T a = S(qacc_smooth)[i] + S(sv_Mgrad)[i]; S(qacc)[i] = a; S(qacc_warmstart)[i] = a; }
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
     DMC_WSYNC();
@@ -4729,6 +4936,17 @@ struct StepCore {
       gauss = gauss_cost();
     }
     T cost = cc + gauss;
+    // (device: only the kernels that have the side-by-side routines leave H's other entries unwritten)
+#ifdef DMC_HOST_EMU
+    hsplit = !L.d.cg && h_split(nefc);
+    emu_split_solves() += hsplit ? 1 : 0;
+#else
+    hsplit = false;
+    if constexpr (kSplit) hsplit = !L.d.cg && h_split(nefc);
+#endif
+#ifdef DMC_HOST_EMU
+    if (getenv("DMC_EMU_TRACE_SPLIT")) fprintf(stderr, "h_split %d (treemax %d, ncon %d)\n", (int)hsplit, L.d.treemax, SI(imisc)[IM_NCON]);
+#endif
     DMC_PROF(PROF_SOL_INIT);
     newton_gradient(nefc, 1);
     FOR_LANES(i, nv) S(sv_search)[i] = -S(sv_Mgrad)[i];
@@ -4985,7 +5203,7 @@ struct StepCore {
       FOR_LANES(i, nv) S(sv_grad)[i] = S(qfrc_smooth)[i] + S(qfrc_constraint)[i];
       DMC_WSYNC();
       factor_M(true, implicitfast ? S(sv_search) : MR(dof_damping));
-      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv);
+      chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv, true);
       qacc = S(sv_Mgrad);
     }
     FOR_LANES(i, nv) S(qvel)[i] += dt*qacc[i];

@@ -180,6 +180,7 @@ template <int SID> struct StaticLayout;
     static constexpr int kJGlobal = DMC_JGLOBAL_LEVEL(DMC_STATIC_NV_##ID);   /* StepDims::jglobal */ \
     static constexpr StepLayout kL = DMC_STATIC_LAYOUT_##ID;                                      \
     static constexpr int kNKin = kL.s_qM - kL.s_xpos;   /* reals of the kinematic stash */       \
+    static constexpr int kTreeMax = kL.d.treemax;   /* > 0: factorisations run the kinematic trees side by side */ \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_STATIC_IDS(DMC_DEF_STATIC)

@@ -57,6 +57,10 @@ struct StepDims {
                  //   pass over ALL sites ever reads; sensors touch a handful, one per lane
   int dfs;       // 1: bodies are numbered depth first (a subtree is the contiguous range [b, body_subend[b])): subtree sums in one pass
   int ntree;     // kinematic trees with at least one dof (M^-1 is block diagonal over them: noslip blocks of different trees are independent)
+  int treemax;   // > 0: the dofs of every kinematic tree are one contiguous range and the largest tree has treemax <= nv / 2
+                 //   dofs: M (always) and H = M + J'DJ (unless a constraint row moves two trees) are block diagonal over the
+                 //   trees, and their factorisations / substitutions run the trees side by side (StepCore::split_*)
+  int ntreetri;  // treemax models: entries of the lower triangles of the trees' diagonal blocks (the only entries of H a split solve has)
   int island;    // 1: the model can have more than one constraint island (two or more kinematic trees, no noslip pass, a
                  //   primal solver): scratch for the island partition (StepCore::find_islands)
   int nmocap;    // mocap bodies: static children of the world posed by mjData.mocap_pos / mocap_quat (StepOpts::mocap_*)
@@ -96,6 +100,9 @@ struct StepDims {
   X(dof_anc_lo, d.nv) X(dof_anc_hi, d.nv)  /* bitmask of ancestor dofs (incl. self) */ \
   X(dof_madr, d.nv + 1)        /* first entry of row i of the sparse M (entries: i, parent(i), ...) */ \
   X(dof_subend, d.nv)          /* 1 + last dof of the subtree below dof i */   \
+  X(dof_tree0, d.treemax ? d.nv : 0) X(dof_tree1, d.treemax ? d.nv : 0)  /* first dof / 1 + last dof of the kinematic tree of dof i */ \
+  X(tree_tri, d.ntreetri)      /* the in-tree entries (i >= j, same tree) as i | j << 16, tree after tree */ \
+  X(tree_trim, d.ntreetri)     /* their place in the sparse M (index into qM's nM entries), -1: not an ancestor pair, M(i, j) = 0 */ \
   X(geom_type, d.ngeom) X(geom_bodyid, d.ngeom)                                \
   X(geom_invisible, d.nrf ? d.ngeom : 0)  /* rays skip geoms with alpha 0 */   \
   X(site_bodyid, d.nsite) X(site_type, d.nsite)                                \

@@ -157,6 +157,20 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     for (int b = 0; b < m.nbody; b++) if (subend[b] - b != cnt[b]) d.dfs = 0;
   }
   { std::vector<int> seen(m.nbody, 0); d.ntree = 0; for (int i = 0; i < m.nv; i++) { const int r = m.body_rootid[m.dof_bodyid[i]]; if (!seen[r]) { seen[r] = 1; d.ntree++; } } }
+  {      // trees as contiguous dof ranges (bodies are numbered so that a tree's dofs follow each other; checked, not assumed)
+    d.treemax = 0;
+    int big = 0, run = 0; bool contiguous = true;
+    std::vector<int> closed(m.nbody, 0);
+    for (int i = 0; i < m.nv; i++) {
+      const int r = m.body_rootid[m.dof_bodyid[i]];
+      if (i > 0 && r != m.body_rootid[m.dof_bodyid[i - 1]]) { closed[m.body_rootid[m.dof_bodyid[i - 1]]] = 1; run = 0; }
+      if (closed[r]) contiguous = false;
+      run++; big = std::max(big, run);
+    }
+    if (d.ntree >= 2 && contiguous && m.nv > 16 && m.nv <= 64 && 2 * big <= m.nv) d.treemax = big;      // (nv <= 16: dense M, register Hessians)
+    d.ntreetri = 0;
+    if (d.treemax) for (int i = 0; i < m.nv; i++) for (int j = 0; j <= i; j++) if (m.body_rootid[m.dof_bodyid[i]] == m.body_rootid[m.dof_bodyid[j]]) d.ntreetri++;
+  }
   // M sparsity
   std::vector<int> mp_i, mp_j;
   for (int i = 0; i < m.nv; i++) for (int j = i; j >= 0; j = m.dof_parentid[j]) { mp_i.push_back(i); mp_j.push_back(j); }
@@ -343,6 +357,25 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
       int end = i + 1;
       for (int dd = i + 1; dd < m.nv; dd++) for (int j = dd; j >= 0; j = m.dof_parentid[j]) if (j == i) { end = dd + 1; break; }
       mi[L.mi_dof_subend + i] = end;
+    }
+    if (d.treemax) {
+      for (int i = 0, t0 = 0; i < m.nv; i++) {
+        if (i > 0 && m.body_rootid[m.dof_bodyid[i]] != m.body_rootid[m.dof_bodyid[i - 1]]) t0 = i;
+        mi[L.mi_dof_tree0 + i] = t0;
+      }
+      for (int i = m.nv - 1, t1 = m.nv; i >= 0; i--) {
+        if (i < m.nv - 1 && m.body_rootid[m.dof_bodyid[i]] != m.body_rootid[m.dof_bodyid[i + 1]]) t1 = i + 1;
+        mi[L.mi_dof_tree1 + i] = t1;
+      }
+      int k = 0;      // in-tree entries, column by column inside each tree (the order of the packed triangle)
+      for (int j = 0; j < m.nv; j++) for (int i = j; i < m.nv; i++) {
+        if (m.body_rootid[m.dof_bodyid[i]] != m.body_rootid[m.dof_bodyid[j]]) continue;
+        int idx = -1, step = 0;
+        for (int a = i; a >= 0; a = m.dof_parentid[a], step++) if (a == j) { idx = mi[L.mi_dof_madr + i] + step; break; }
+        mi[L.mi_tree_tri + k] = i | (j << 16);
+        mi[L.mi_tree_trim + k] = idx;
+        k++;
+      }
     }
   }
   cpi(L.mi_geom_type, m.geom_type); cpi(L.mi_geom_bodyid, m.geom_bodyid);

@@ -45,6 +45,17 @@ int emu_dims(void* h, int* out) {
   out[0] = L.n_sr + L.n_gs; out[1] = L.n_si; out[2] = L.d.nconmax; out[3] = L.d.njmax; out[4] = L.n_mi; out[5] = L.n_mr; out[6] = L.d.kmax; out[7] = L.n_mc;
   return 0;
 }
+// StepDims::treemax models: {treemax, ntreetri, ntree} and the tables dof_tree0 / dof_tree1 (nv each), tree_tri / tree_trim
+int emu_tree_tables(void* h, int* dims, int* t0, int* t1, int* tri, int* trim) {
+  Emu* e = (Emu*)h; const StepLayout& L = e->tb.L; const int* mi = e->tb.mi.data();
+  dims[0] = L.d.treemax; dims[1] = L.d.ntreetri; dims[2] = L.d.ntree;
+  if (L.d.treemax) {
+    for (int i = 0; i < L.d.nv; i++) { t0[i] = mi[L.mi_dof_tree0 + i]; t1[i] = mi[L.mi_dof_tree1 + i]; }
+    for (int k = 0; k < L.d.ntreetri; k++) { tri[k] = mi[L.mi_tree_tri + k]; trim[k] = mi[L.mi_tree_trim + k]; }
+  }
+  return 0;
+}
+int emu_split_solves_count() { return emu_split_solves(); }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
 void emu_set_islands(void* h, int v) { ((Emu*)h)->tb.opts.islands = v; }      // StepOpts::islands: 1 on, 0 off, -1 by precision

@@ -39,6 +39,7 @@ def lib():
     L.emu_set_mocap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_set_env_geoms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     L.emu_dims.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.emu_tree_tables.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 5
     L.emu_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_int)] * 3
     L.emu_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -73,6 +74,21 @@ class EmuPhysics:
     self.f['qpos'][:m.nq] = m.qpos0
     self.dbg = np.zeros(self.n_sr)
     self.dbgi = np.zeros(self.n_si, np.int32)
+
+  def tree_tables(self):
+    """StepDims::treemax models: dict(treemax, ntreetri, ntree, tree0, tree1, tri (i, j) pairs, trim)."""
+    nv = self.m.nv
+    dims = np.zeros(3, np.int32); t0 = np.zeros(max(nv, 1), np.int32); t1 = np.zeros(max(nv, 1), np.int32)
+    tri = np.zeros(nv*(nv + 1)//2 + 1, np.int32); trim = np.zeros(nv*(nv + 1)//2 + 1, np.int32)
+    lib().emu_tree_tables(self.h, dims.ctypes.data, t0.ctypes.data, t1.ctypes.data, tri.ctypes.data, trim.ctypes.data)
+    n = int(dims[1])
+    return dict(treemax=int(dims[0]), ntreetri=n, ntree=int(dims[2]), tree0=t0[:nv], tree1=t1[:nv],
+                tri=np.stack([tri[:n] & 0xffff, tri[:n] >> 16], 1), trim=trim[:n])
+
+  @staticmethod
+  def split_solves():
+    """Solves (all emulated batches of this process) whose Hessian was taken as block diagonal over the trees."""
+    return int(lib().emu_split_solves_count())
 
   def set_islands(self, v):
     """StepOpts::islands: 1 per-island solves, 0 one joint solve, -1 by precision (fp64 on, fp32 off)."""
