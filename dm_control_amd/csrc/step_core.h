@@ -3526,10 +3526,16 @@ struct StepCore {
     DMC_WSYNC();
     const int ncon = rm.c0 < nefc ? SI(imisc)[IM_NCON] : 0;
     const auto Jc_base = Jc();
-    for (int t = lane; t < L.d.ntreetri; t += LPE) {
-      const int pk = MI(tree_tri)[t], i = pk & 0xffff, j = pk >> 16, mix = MI(tree_trim)[t];
-      T h = mix >= 0 ? qMs()[mix] : (T)0;
-      if (i == j) h += S(sv_Mgrad)[i];
+    // two entries per lane and trip (t and t + LPE): the walk over the contacts -- a chain of dependent look-ups per
+    // contact (row, state, mask, Jacobian entries) -- is paid once for both
+    for (int t = lane; t < L.d.ntreetri; t += 2*LPE) {
+      const bool two = t + LPE < L.d.ntreetri;
+      const int pk0 = MI(tree_tri)[t], pk1 = MI(tree_tri)[two ? t + LPE : t];
+      const int mix0 = MI(tree_trim)[t], mix1 = MI(tree_trim)[two ? t + LPE : t];
+      const int i0 = pk0 & 0xffff, j0 = pk0 >> 16, i1 = pk1 & 0xffff, j1 = pk1 >> 16;
+      T h0 = mix0 >= 0 ? qMs()[mix0] : (T)0, h1 = mix1 >= 0 ? qMs()[mix1] : (T)0;
+      if (i0 == j0) h0 += S(sv_Mgrad)[i0];
+      if (i1 == j1) h1 += S(sv_Mgrad)[i1];
       for (int c = 0; c < ncon; c++) {
         const int r0 = SI(con_efc)[c];
         if (r0 < 0) continue;
@@ -3539,28 +3545,40 @@ struct StepCore {
         for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) any = any || SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC;
         if (!any) continue;               // group-uniform
         const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
-        const int a = mask_slot(lo, hi, i), b2 = mask_slot(lo, hi, j);
-        if (a < 0 || b2 < 0) continue;
+        const int a0 = mask_slot(lo, hi, i0), b0 = mask_slot(lo, hi, j0), a1 = mask_slot(lo, hi, i1), b1 = mask_slot(lo, hi, j1);
+        const bool in0 = a0 >= 0 && b0 >= 0, in1 = two && a1 >= 0 && b1 >= 0;
+        if (!in0 && !in1) continue;
+        const int sa0 = in0 ? a0 : 0, sb0 = in0 ? b0 : 0, sa1 = in1 ? a1 : 0, sb1 = in1 ? b1 : 0;
         const auto J = Jc_base + (r0 - rm.c0)*K;
-        T acc = 0;
+        T acc0 = 0, acc1 = 0;
         if (cone) {
-          T Pi = 0, Pj = 0, Wi = 0, Wj = 0, g = 0;
+          T Pi0 = 0, Pj0 = 0, Wi0 = 0, Wj0 = 0, g0 = 0, Pi1 = 0, Pj1 = 0, Wi1 = 0, Wj1 = 0, g1 = 0;
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) {
-            const T ji = J[q*K + a], jj = J[q*K + b2];
+            const T ji0 = J[q*K + sa0], jj0 = J[q*K + sb0], ji1 = J[q*K + sa1], jj1 = J[q*K + sb1];
             const T ca = S(efc_ca)[r0 + q];
-            Pi += ca*ji; Pj += ca*jj;
-            if (q) { const T cb = S(efc_cb)[r0 + q]; Wi += cb*ji; Wj += cb*jj; g += S(efc_cg)[r0 + q]*ji*jj; }
+            Pi0 += ca*ji0; Pj0 += ca*jj0; Pi1 += ca*ji1; Pj1 += ca*jj1;
+            if (q) {
+              const T cb = S(efc_cb)[r0 + q], cg = S(efc_cg)[r0 + q];
+              Wi0 += cb*ji0; Wj0 += cb*jj0; g0 += cg*ji0*jj0;
+              Wi1 += cb*ji1; Wj1 += cb*jj1; g1 += cg*ji1*jj1;
+            }
           }
-          acc = S(efc_cg)[r0]*(Pi*Pj) - S(efc_cb)[r0]*(Wi*Wj) + g;
+          const T cg0 = S(efc_cg)[r0], cb0 = S(efc_cb)[r0];
+          acc0 = cg0*(Pi0*Pj0) - cb0*(Wi0*Wj0) + g0;
+          acc1 = cg0*(Pi1*Pj1) - cb0*(Wi1*Wj1) + g1;
         } else {
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
-            const T ji = J[q*K + a];
-            if (ji != 0) acc += (S(efc_D)[r0 + q]*ji) * J[q*K + b2];
+            const T dq = S(efc_D)[r0 + q];
+            const T ji0 = J[q*K + sa0], ji1 = J[q*K + sa1];
+            if (ji0 != 0) acc0 += (dq*ji0) * J[q*K + sb0];
+            if (ji1 != 0) acc1 += (dq*ji1) * J[q*K + sb1];
           }
         }
-        h += acc;
+        if (in0) h0 += acc0;
+        if (in1) h1 += acc1;
       }
-      S(qLH)[tri_at(i, j, nv)] = h;
+      S(qLH)[tri_at(i0, j0, nv)] = h0;
+      if (two) S(qLH)[tri_at(i1, j1, nv)] = h1;
     }
     DMC_WSYNC();
   }

@@ -13,7 +13,10 @@
 #include <stdint.h>
 
 // StepDims::jglobal of a model with nv dofs
-#define DMC_JGLOBAL_LEVEL(nv) ((nv) > 48 ? 3 : ((nv) > 32 ? 2 : ((nv) > 16 ? 1 : 0)))
+#ifndef DMC_JGLOBAL_NV1
+#define DMC_JGLOBAL_NV1 16      // (experiment knob: dofs from which level 1 applies)
+#endif
+#define DMC_JGLOBAL_LEVEL(nv) ((nv) > 48 ? 3 : ((nv) > 32 ? 2 : ((nv) > DMC_JGLOBAL_NV1 ? 1 : 0)))
 
 struct StepDims {
   int nq, nv, nu, nbody, njnt, ngeom, nsite, nsensor, nsensordata, npair;

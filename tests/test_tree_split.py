@@ -14,11 +14,12 @@ from dm_control_amd.suite import common
 from emu_lib import EmuPhysics
 
 
-def boxes(n=4, gap=0.6):
-  body = ''.join('<body name="b%d" pos="%g 0 .1"><freejoint/><geom type="box" size=".1 .1 .1" mass="1"/></body>' % (k, gap*k)
+def boxes(n=4, gap=0.6, friction=1.0):
+  fr = 'friction="%g .005 .0001"' % friction
+  body = ''.join('<body name="b%d" pos="%g 0 .1"><freejoint/><geom type="box" size=".1 .1 .1" mass="1" %s/></body>' % (k, gap*k, fr)
                  for k in range(n))
-  return mc.compile_xml('<mujoco><option timestep="0.004"/><worldbody><geom name="floor" type="plane" size="5 5 .1"/>%s'
-                        '</worldbody></mujoco>' % body)
+  return mc.compile_xml('<mujoco><option timestep="0.004"/><worldbody><geom name="floor" type="plane" size="5 5 .1" %s/>%s'
+                        '</worldbody></mujoco>' % (fr, body))
 
 
 def test_tables_of_the_soccer_model():
@@ -86,16 +87,17 @@ def test_boxes_apart_split_boxes_in_contact_do_not():
 def test_plugin_with_tree_routines_follows_the_generic_kernel(tmp_path, monkeypatch, precision, tol):
   from dm_control_amd.batch import BatchedPhysics
   monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
-  m = boxes(4, gap=0.45)
+  m = boxes(4, gap=0.45, friction=0.1)
   B = 32
-  g = BatchedPhysics(m, B, precision=precision, lanes_per_env=64, specialise='off')
-  s = BatchedPhysics(m, B, precision=precision, lanes_per_env=64, specialise='build')
+  caps = dict(lanes_per_env=64, nconmax=40, njmax=200)
+  g = BatchedPhysics(m, B, precision=precision, specialise='off', **caps)
+  s = BatchedPhysics(m, B, precision=precision, specialise='build', **caps)
   assert s.specialised == 'attached' and g.info()['static_id'] == -1
   rs = np.random.RandomState(0)
   q = np.tile(m.qpos0, (B, 1))
   v = np.zeros((B, m.nv))
-  v[:, 0] = rs.uniform(0, 4, B)      # the first box slides at the others: solves with and without a box-box contact
-  v[:, 6 * 3] = -rs.uniform(0, 4, B)
+  v[:, 0] = rs.uniform(1, 3, B)      # the outer boxes slide at the inner ones: solves with and without a box-box contact
+  v[:, 6 * 3] = -rs.uniform(1, 3, B)
   for b in (g, s):
     b.set('qpos', q); b.set('qvel', v)
   worst, pairs = 0.0, 0
