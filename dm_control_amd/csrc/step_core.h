@@ -55,7 +55,8 @@
 
 namespace dmc {
 #ifdef DMC_HOST_EMU
-inline int& emu_split_solves() { static int n = 0; return n; }      // solves whose H was taken as block diagonal over the trees (tests)
+inline int& emu_split_solves() { static int n = 0; return n; }
+inline long long* emu_ls_counts() { static long long n[2] = {0, 0}; return n; }      // line searches, their cost evaluations      // solves whose H was taken as block diagonal over the trees (tests)
 #endif
 
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
@@ -702,10 +703,14 @@ struct DynLayoutSrc {
   static constexpr int kJGlobal = -1;   // so is StepDims::jglobal
   static constexpr int kNKin = 0;       // and the size of the kinematic stash
   static constexpr int kTreeMax = 0;    // and StepDims::treemax (the side-by-side tree factorisations are register routines)
+  static constexpr int kTreeUni = 0;
   const StepLayout* p;
   DMC_DEV const StepLayout& get() const { return *p; }
 };
 
+#ifndef DMC_LS_SLOPE_ULPS
+#define DMC_LS_SLOPE_ULPS 16   // fp32 line search: slope floor in ulp of the slope at alpha = 0 (primal_search)
+#endif
 #ifndef DMC_PRIO_ITER
 #define DMC_PRIO_ITER 2   // Newton iteration from which a wave raises its issue priority (fwd_constraint)
 #endif
@@ -4092,6 +4097,9 @@ struct StepCore {
     if (p->d1 <= 0) p->d1 = (T)DMC_MINVAL;
   }
   DMC_DEV void ls_eval(LSPoint* p, const T* qg, int nefc, int* evals, const LSRows& rw) {
+#ifdef DMC_HOST_EMU
+    emu_ls_counts()[1]++;
+#endif
     if (general_rows()) { if (rw.gen) ls_eval_gen(p, qg, rw); else ls_eval_ell(p, qg, nefc); (*evals)++; return; }
     if (rw.on) {
       const T a = p->alpha, jar = rw.jar, jv = rw.jv;
@@ -4131,6 +4139,9 @@ struct StepCore {
   }
   DMC_DEV T primal_search(int nefc, T gauss, T scale, T* lscost) {
     *lscost = 0;      // cost of the returned point (relative to alpha = 0 in fp32: minus the iteration's improvement)
+#ifdef DMC_HOST_EMU
+    emu_ls_counts()[0]++;
+#endif
     const int nv = L.d.nv;
     mul_M(S(sv_Mv), S(sv_search));
     { const RowMap rm = row_map(); for (int i = lane; i < nefc; i += LPE) S(efc_jv)[i] = row_dot(i, S(sv_search), rm); }
@@ -4153,7 +4164,7 @@ struct StepCore {
     T qg[3] = {gauss, a1 - a2, (T)0.5*a3};
     const T snorm = t_sqrt(a4);
     if (snorm < (T)DMC_MINVAL) return 0;
-    const T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
+    T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
     const int lsmax = o.ls_iterations;
     int evals = 0;
 #if !defined(DMC_HOST_EMU) && !defined(DMC_NO_LS_REGS)
@@ -4165,6 +4176,20 @@ struct StepCore {
     DMC_PROF(PROF_LS_SETUP);
     LSPoint p0, p1, p2, pmid, p1next, p2next;
     p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals, rw);
+#ifndef DMC_NO_LS_SLOPE_FLOOR
+    // fp32: the slope cannot be resolved below a few ulp of the slope at alpha = 0 (the sums that form it are that
+    // large), while MuJoCo's gtol = tolerance * ls_tolerance * |search| / scale sits ~1e-10 below it: fp64 gets there in
+    // 4.5 evaluations per search (quadratic convergence), fp32 never did and refined the bracket until no candidate
+    // improved it -- 11 evaluations per search on the elliptic models, a quarter of their step.  A point whose slope is
+    // within DMC_LS_SLOPE_ULPS ulp of the starting slope is the minimum as far as fp32 can tell: alpha is then off by
+    // that relative amount, the cost by its square.
+#ifdef DMC_HOST_EMU
+    { const char* u = getenv("DMC_LS_SLOPE_ULPS");      // (probe knob of the emulation: scripts/ls_floor_probe.py)
+      if (sizeof(T) == 4) gtol = t_max(gtol, (T)((u ? atof(u) : (double)DMC_LS_SLOPE_ULPS) * 1.1920929e-7) * t_abs(p0.d0)); }
+#else
+    if (sizeof(T) == 4) gtol = t_max(gtol, (T)(DMC_LS_SLOPE_ULPS * 1.1920929e-7) * t_abs(p0.d0));
+#endif
+#endif
     p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals, rw);
 #ifdef DMC_HOST_EMU
     if (getenv("DMC_EMU_TRACE_LS")) fprintf(stderr, "    ls: p0 cost %.6e d0 %.6e d1 %.6e | p1 alpha %.9e cost %.6e d0 %.6e d1 %.6e | gtol %.3e qg1 %.6e\n",
@@ -4594,38 +4619,50 @@ struct StepCore {
 #define DMC_PIN(v) asm volatile("" : "+v"(v))
     const volatile DMC_LDS T* Lm = Lm_;
     T cur[N], nxt[N];
+    // Trees of equal size (StepDims::treeuni: soccer's five 6-dof trees): the factor of M is block diagonal with blocks
+    // known at compile time, so column k only reaches to the end / row k only back to the start of its tree -- 2 x 105
+    // loads and FMAs instead of 2 x 465 for N = 30; the skipped ones multiply exact zeros.
+#ifdef DMC_NO_TREE_SPLIT
+    constexpr int TB = N;
+#else
+    constexpr int TB = (LS::kTreeUni && LS::kTreeMax > 0) ? LS::kTreeMax : N;
+#endif
+#define DMC_TEND(k) ((((k) / TB) + 1) * TB < N ? (((k) / TB) + 1) * TB : N)
+#define DMC_TBEG(k) (((k) / TB) * TB)
 #pragma unroll
-    for (int i = 0; i < N; i++) { cur[i] = Lm[i]; nxt[i] = 0; }
+    for (int i = 0; i < N; i++) { cur[i] = i < DMC_TEND(0) ? Lm[i] : (T)0; nxt[i] = 0; }
 #pragma unroll
     for (int k = 0; k < N; k++) {
       if (k + 1 < N) {
         const int cn = tri_c0(k + 1, N);
 #pragma unroll
-        for (int i = k + 1; i < N; i++) nxt[i] = Lm[cn + i - (k + 1)];
+        for (int i = k + 1; i < DMC_TEND(k + 1); i++) nxt[i] = Lm[cn + i - (k + 1)];
       }
       const T xk = x[k] * cur[k];
       x[k] = xk;
 #pragma unroll
-      for (int i = k + 1; i < N; i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
+      for (int i = k + 1; i < DMC_TEND(k); i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
 #pragma unroll
       for (int i = 0; i < N; i++) cur[i] = nxt[i];
     }
     // back substitution: step k needs 1 / L[k][k] and row k of L (entries (k, i), i < k)
 #pragma unroll
-    for (int i = 0; i < N; i++) cur[i] = Lm[tri_c0(i, N) + (N - 1) - i];
+    for (int i = DMC_TBEG(N - 1); i < N; i++) cur[i] = Lm[tri_c0(i, N) + (N - 1) - i];
 #pragma unroll
     for (int k = N - 1; k >= 0; k--) {
       if (k > 0) {
 #pragma unroll
-        for (int i = 0; i < k; i++) nxt[i] = Lm[tri_c0(i, N) + (k - 1) - i];
+        for (int i = DMC_TBEG(k - 1); i < k; i++) nxt[i] = Lm[tri_c0(i, N) + (k - 1) - i];
       }
       const T xk = x[k] * cur[k];
       x[k] = xk;
 #pragma unroll
-      for (int i = 0; i < k; i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
+      for (int i = DMC_TBEG(k); i < k; i++) { x[i] -= cur[i]*xk; DMC_PIN(x[i]); }
 #pragma unroll
       for (int i = 0; i < N; i++) cur[i] = nxt[i];
     }
+#undef DMC_TEND
+#undef DMC_TBEG
 #undef DMC_PIN
     T* A = ns_A(); const int cap = L.d.nslip;
     for (int a = 0; a < nf; a++) {

@@ -181,6 +181,7 @@ template <int SID> struct StaticLayout;
     static constexpr StepLayout kL = DMC_STATIC_LAYOUT_##ID;                                      \
     static constexpr int kNKin = kL.s_qM - kL.s_xpos;   /* reals of the kinematic stash */       \
     static constexpr int kTreeMax = kL.d.treemax;   /* > 0: factorisations run the kinematic trees side by side */ \
+    static constexpr int kTreeUni = kL.d.treeuni;   /* trees of equal size: the block structure of M's factor is a compile-time fact */ \
     __device__ __forceinline__ const StepLayout& get() const { return kStaticLayout##ID; } \
   };
 DMC_STATIC_IDS(DMC_DEF_STATIC)

@@ -63,6 +63,7 @@ struct StepDims {
   int treemax;   // > 0: the dofs of every kinematic tree are one contiguous range and the largest tree has treemax <= nv / 2
                  //   dofs: M (always) and H = M + J'DJ (unless a constraint row moves two trees) are block diagonal over the
                  //   trees, and their factorisations / substitutions run the trees side by side (StepCore::split_*)
+  int treeuni;   // treemax models: 1 when every tree has exactly treemax dofs (tree t = dofs [t treemax, (t + 1) treemax): known at compile time)
   int ntreetri;  // treemax models: entries of the lower triangles of the trees' diagonal blocks (the only entries of H a split solve has)
   int island;    // 1: the model can have more than one constraint island (two or more kinematic trees, no noslip pass, a
                  //   primal solver): scratch for the island partition (StepCore::find_islands)

@@ -168,6 +168,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
       run++; big = std::max(big, run);
     }
     if (d.ntree >= 2 && contiguous && m.nv > 16 && m.nv <= 64 && 2 * big <= m.nv) d.treemax = big;      // (nv <= 16: dense M, register Hessians)
+    d.treeuni = d.treemax && d.ntree * d.treemax == m.nv;      // (the largest has treemax, the sum is nv: all equal)
     d.ntreetri = 0;
     if (d.treemax) for (int i = 0; i < m.nv; i++) for (int j = 0; j <= i; j++) if (m.body_rootid[m.dof_bodyid[i]] == m.body_rootid[m.dof_bodyid[j]]) d.ntreetri++;
   }

@@ -1,0 +1,30 @@
+"""Line-search cost evaluations per search and Newton iterations per step of the emulated kernel core (fp32) under the
+bench workloads -- the emulation runs the same algorithm as the device, so the counts are the device's."""
+import os
+import sys, ctypes, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import bench
+from emu_lib import EmuPhysics, lib
+from dm_control_amd.suite import common
+for prec in (32,):
+ for cid in (5, 4, 3, 2):
+  cfg = bench.CONFIGS[cid]
+  m = bench.load_model(cfg['asset'])
+  caps = {k: v for k, v in common.DEFAULT_CAPS.get(cfg['asset'], {}).items() if k in ('nconmax','njmax','njcon')}
+  rs = np.random.RandomState(0)
+  out = (ctypes.c_longlong*2)()
+  lib().emu_ls_counts_get(out); c0 = list(out)
+  iters = 0; steps = 0
+  if cid == 3:
+    q0 = np.tile(m.qpos0, (4, 1)); q0[:, 2] = 0.3
+  else:
+    q0 = bench.initial_qpos(cfg, m, 4, 0)
+  for env in range(2):
+    e = EmuPhysics(m, prec, **caps)
+    e.qpos[:] = q0[env]
+    for t in range(30 if cid != 2 else 200):
+      e.ctrl[:] = rs.uniform(-1,1,m.nu)
+      for k in range(cfg['nsub']):
+        e.step(1); iters += int(e.solver_iter[0]); steps += 1
+  lib().emu_ls_counts_get(out)
+  print('prec', prec, 'config', cid, 'ls calls per step %.2f' % ((out[0]-c0[0])/steps), 'evals per ls %.2f' % ((out[1]-c0[1])/max(1,out[0]-c0[0])), 'iters/step %.2f' % (iters/steps))
