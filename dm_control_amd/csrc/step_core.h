@@ -56,7 +56,7 @@
 namespace dmc {
 #ifdef DMC_HOST_EMU
 inline int& emu_split_solves() { static int n = 0; return n; }
-inline long long* emu_ls_counts() { static long long n[2] = {0, 0}; return n; }      // line searches, their cost evaluations      // solves whose H was taken as block diagonal over the trees (tests)
+inline long long* emu_ls_counts() { static long long n[6] = {0, 0, 0, 0, 0, 0}; return n; }      // line searches, their cost evaluations, noslip passes, their sweeps, QCQP calls, their iterations      // solves whose H was taken as block diagonal over the trees (tests)
 #endif
 
 #if defined(DMC_PROFILE) && !defined(DMC_HOST_EMU)
@@ -489,6 +489,7 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
   const T dinv = own ? Lm[ci] : (T)0;      // 1 / L[i][i]
   T sreg = own ? b[i] : (T)0;
+#ifdef DMC_SOLVE_ROWS_R4
 #pragma unroll
   for (int k = 0; k < N; k++) {
     const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
@@ -502,6 +503,20 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
     if (i < k) sreg -= col[k]*xk;
   }
   if (own) x[i] = sreg;
+#else
+  // Step k needs x_k = s_k / L[k][k]: every lane forms its own s_i * dinv_i (one VALU op, and lane k's is the value),
+  // ONE cross-lane read fetches it, and the update is an unconditional FMA -- row[k] / col[k] are zeros where the
+  // step does not reach, so lane k keeps its finished s_k and its x_k is s_k * dinv_k again after the loop.  Three
+  // instructions per step instead of ~20 (two broadcasts, a scalar product moved back to a VGPR, a write-lane and two
+  // predicated updates: 2 603 instructions for N = 62, 8 % of the 62-dof step).  The same products and differences as
+  // before, bit for bit.
+#pragma unroll
+  for (int k = 0; k < N; k++) { const T xk = wave_bcast<LPE>(sreg*dinv, k); sreg = sreg - row[k]*xk; }
+  sreg = sreg*dinv;
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) { const T xk = wave_bcast<LPE>(sreg*dinv, k); sreg = sreg - col[k]*xk; }
+  if (own) x[i] = sreg*dinv;
+#endif
   DMC_WSYNC();
 }
 #endif
@@ -4301,7 +4316,13 @@ struct StepCore {
       const T delta = -val/deriv;
       if (delta < (fast ? t_max((T)1e-10, (T)(4*1.1920929e-7)*la) : (T)1e-10)) break;
       la += delta;
+#ifdef DMC_HOST_EMU
+      emu_ls_counts()[5]++;
+#endif
     }
+#ifdef DMC_HOST_EMU
+    emu_ls_counts()[4]++;
+#endif
     if (fail) {
 #pragma unroll
       for (int i = 0; i < N; i++) res[i] = 0;
@@ -4559,6 +4580,7 @@ struct StepCore {
           kf = first; kb = __builtin_amdgcn_readlane(t_start, first); ke = __builtin_amdgcn_readlane(t_end, last);
         } else { kf = N; kb = N; ke = 0; }
       }
+#ifdef DMC_SOLVE_ROWS_R4
 #pragma unroll
       for (int k = 0; k < N; k++) {
         if (k < kf || k >= ke) continue;
@@ -4574,6 +4596,24 @@ struct StepCore {
         if (i < k) sreg -= col[k]*xk;
       }
       if (own) S(sv_Mgrad)[i] = sreg;
+#else
+      // (chol_solve_rows' three-instruction steps: one product per lane, one cross-lane read, one unconditional FMA; a lane
+      // outside the swept range holds s = 0 throughout)
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        if (k < kf || k >= ke) continue;
+        const T xk = wave_bcast<LPE>(sreg*dinv, k);
+        sreg = sreg - row[k]*xk;
+      }
+      sreg = sreg*dinv;
+#pragma unroll
+      for (int k = N - 1; k >= 0; k--) {
+        if (k < kb || k >= ke) continue;
+        const T xk = wave_bcast<LPE>(sreg*dinv, k);
+        sreg = sreg - col[k]*xk;
+      }
+      if (own) S(sv_Mgrad)[i] = sreg*dinv;
+#endif
       DMC_WSYNC();
       for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; }
       DMC_WSYNC();
@@ -4748,9 +4788,21 @@ struct StepCore {
         a += n;
       }
       improvement *= scale;
+#ifdef DMC_HOST_EMU
+      if (getenv("DMC_EMU_TRACE_NS")) fprintf(stderr, "noslip sweep %d improvement %.6e (tol %.1e)\n", iter, (double)improvement, (double)o.noslip_tolerance);
+#endif
       iter++;
       if (improvement < o.noslip_tolerance) break;
+#if !defined(DMC_EXACT_QCQP) && !defined(DMC_NS_RESWEEP_ALL)
+      // fp32 solves a block without a partner once (noslip_sweep_levels): when NO block has one -- one level: every
+      // contact on a tree of its own, the usual state of the soccer pitch -- the later sweeps would skip every block and
+      // add up zeros (noslip_tolerance = 0 never ends them: 0 < 0), so the pass ends here with the same forces
+      if (sizeof(T) == 4 && nblk && nlev == 1) break;
+#endif
     }
+#ifdef DMC_HOST_EMU
+    emu_ls_counts()[2]++; emu_ls_counts()[3] += iter;
+#endif
     DMC_PROF(PROF_X7);
     constraint_force_to_joint(nefc);
     DMC_WSYNC();

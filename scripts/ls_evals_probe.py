@@ -6,13 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import bench
 from emu_lib import EmuPhysics, lib
 from dm_control_amd.suite import common
-for prec in (32,):
- for cid in (5, 4, 3, 2):
+for prec in (64, 32):
+ for cid in (5, 4):
   cfg = bench.CONFIGS[cid]
   m = bench.load_model(cfg['asset'])
   caps = {k: v for k, v in common.DEFAULT_CAPS.get(cfg['asset'], {}).items() if k in ('nconmax','njmax','njcon')}
   rs = np.random.RandomState(0)
-  out = (ctypes.c_longlong*2)()
+  out = (ctypes.c_longlong*6)()
   lib().emu_ls_counts_get(out); c0 = list(out)
   iters = 0; steps = 0
   if cid == 3:
@@ -27,4 +27,5 @@ for prec in (32,):
       for k in range(cfg['nsub']):
         e.step(1); iters += int(e.solver_iter[0]); steps += 1
   lib().emu_ls_counts_get(out)
-  print('prec', prec, 'config', cid, 'ls calls per step %.2f' % ((out[0]-c0[0])/steps), 'evals per ls %.2f' % ((out[1]-c0[1])/max(1,out[0]-c0[0])), 'iters/step %.2f' % (iters/steps))
+  print('prec', prec, 'config', cid, 'ls calls per step %.2f' % ((out[0]-c0[0])/steps), 'evals per ls %.2f' % ((out[1]-c0[1])/max(1,out[0]-c0[0])), 'iters/step %.2f' % (iters/steps),
+        'noslip sweeps per pass %.2f' % ((out[3]-c0[3])/max(1,out[2]-c0[2])), 'qcqp iterations per call %.2f (%.1f calls per step)' % ((out[5]-c0[5])/max(1,out[4]-c0[4]), (out[4]-c0[4])/steps))

@@ -35,7 +35,7 @@ for env in range(NE):
 out = {}
 for ulps in sys.argv[1:] or ['0', '16']:
   os.environ['DMC_LS_SLOPE_ULPS'] = ulps
-  cnt = (ctypes.c_longlong * 2)()
+  cnt = (ctypes.c_longlong * 6)()
   lib().emu_ls_counts_get(cnt); c0 = list(cnt)
   e = EmuPhysics(m, 32, **caps)
   errs, iters = [], 0
