@@ -360,6 +360,29 @@ template <int LPE, typename V> DMC_DEV V wave_bcast(V v, int k) {
   (void)k; return v;
 #endif
 }
+// The same when every lane that holds something sits in the FIRST 16-lane row of its group (one lane per matrix row of a
+// model with nv <= 16): the gfx90a+ DPP control row_newbcast:k hands lane k of each 16-lane row to all lanes of that row
+// in ONE VALU move (folded into the consuming multiply where the encoding allows) -- against two v_readlane, a trip
+// through two SGPRs and a v_cndmask per value for two environments per wave.  The 9 x 9 factorisations of the cheetah
+// were ~200 instructions of which 135 were these broadcasts; the lanes of the group's other rows receive the value of
+// THEIR row's lane k, which nothing reads (they own no matrix row).  k must be a constant after unrolling.
+#ifndef DMC_HOST_EMU
+template <typename V> DMC_DEV V row_bcast16(V v, int k) {
+  switch (k & 15) {
+    case 0: return dpp_f<0x150>(v); case 1: return dpp_f<0x151>(v); case 2: return dpp_f<0x152>(v); case 3: return dpp_f<0x153>(v);
+    case 4: return dpp_f<0x154>(v); case 5: return dpp_f<0x155>(v); case 6: return dpp_f<0x156>(v); case 7: return dpp_f<0x157>(v);
+    case 8: return dpp_f<0x158>(v); case 9: return dpp_f<0x159>(v); case 10: return dpp_f<0x15A>(v); case 11: return dpp_f<0x15B>(v);
+    case 12: return dpp_f<0x15C>(v); case 13: return dpp_f<0x15D>(v); case 14: return dpp_f<0x15E>(v); default: return dpp_f<0x15F>(v);
+  }
+}
+#endif
+// broadcast of matrix row k's value among the N <= LPE row-holding lanes of a group
+template <int LPE, int N, typename V> DMC_DEV V bcast_rows(V v, int k) {
+#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_ROW_NEWBCAST)
+  if constexpr (N <= 16 && LPE >= 16) return row_bcast16(v, k);
+#endif
+  return wave_bcast<LPE>(v, k);
+}
 template <int LPE> DMC_DEV int group_max(int v) {
 #ifndef DMC_HOST_EMU
 #ifdef DMC_NO_PERMLANE_SWAP
@@ -459,12 +482,12 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? A[tri_c0(j, N) + lane - j] : (T)0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    T akk = wave_bcast<LPE>(a[k], k);
+    T akk = bcast_rows<LPE, N>(a[k], k);
     if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
     const T inv = t_rsqrt(akk);
     const T lik = a[k] * inv;
 #pragma unroll
-    for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }
+    for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
     a[k] = lane == k ? inv : lik;
   }
   if (own) {
@@ -511,10 +534,10 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   // predicated updates: 2 603 instructions for N = 62, 8 % of the 62-dof step).  The same products and differences as
   // before, bit for bit.
 #pragma unroll
-  for (int k = 0; k < N; k++) { const T xk = wave_bcast<LPE>(sreg*dinv, k); sreg = sreg - row[k]*xk; }
+  for (int k = 0; k < N; k++) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = sreg - row[k]*xk; }
   sreg = sreg*dinv;
 #pragma unroll
-  for (int k = N - 1; k >= 0; k--) { const T xk = wave_bcast<LPE>(sreg*dinv, k); sreg = sreg - col[k]*xk; }
+  for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = sreg - col[k]*xk; }
   if (own) x[i] = sreg*dinv;
 #endif
   DMC_WSYNC();
@@ -1430,12 +1453,12 @@ struct StepCore {
     }
 #pragma unroll
     for (int k = 0; k < N; k++) {
-      T akk = wave_bcast<LPE>(a[k], k);
+      T akk = bcast_rows<LPE, N>(a[k], k);
       if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
       a[k] = lane == k ? inv : lik;
     }
     DMC_LDS T* A = (DMC_LDS T*)dst;
@@ -3902,12 +3925,12 @@ struct StepCore {
     }
 #pragma unroll
     for (int k = 0; k < N; k++) {
-      T akk = wave_bcast<LPE>(a[k], k);
+      T akk = bcast_rows<LPE, N>(a[k], k);
       if (akk < (T)DMC_MINVAL) akk = (T)DMC_MINVAL;
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = wave_bcast<LPE>(lik, j); a[j] = a[j] - lik * ljk; }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
       a[k] = lane == k ? inv : lik;
     }
     DMC_LDS T* A = (DMC_LDS T*)S(qLH);
