@@ -367,13 +367,23 @@ template <int LPE, typename V> DMC_DEV V wave_bcast(V v, int k) {
 // were ~200 instructions of which 135 were these broadcasts; the lanes of the group's other rows receive the value of
 // THEIR row's lane k, which nothing reads (they own no matrix row).  k must be a constant after unrolling.
 #ifndef DMC_HOST_EMU
+template <int CTRL> DMC_DEV float dpp_all(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+template <int CTRL> DMC_DEV double dpp_all(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename V> DMC_DEV V row_bcast16(V v, int k) {
+#ifndef DMC_NO_DPP_BOUND      // (every lane of a row_newbcast has a source: bound_ctrl spares the move that initialises "old")
+#define dpp_f dpp_all
+#endif
   switch (k & 15) {
     case 0: return dpp_f<0x150>(v); case 1: return dpp_f<0x151>(v); case 2: return dpp_f<0x152>(v); case 3: return dpp_f<0x153>(v);
     case 4: return dpp_f<0x154>(v); case 5: return dpp_f<0x155>(v); case 6: return dpp_f<0x156>(v); case 7: return dpp_f<0x157>(v);
     case 8: return dpp_f<0x158>(v); case 9: return dpp_f<0x159>(v); case 10: return dpp_f<0x15A>(v); case 11: return dpp_f<0x15B>(v);
     case 12: return dpp_f<0x15C>(v); case 13: return dpp_f<0x15D>(v); case 14: return dpp_f<0x15E>(v); default: return dpp_f<0x15F>(v);
   }
+#undef dpp_f
 }
 #endif
 // broadcast of matrix row k's value among the N <= LPE row-holding lanes of a group
@@ -3904,6 +3914,7 @@ struct StepCore {
     const bool own = lane < N;
     const int i = own ? lane : 0;
     T a[N];
+#ifdef DMC_HESS_ROWS_V1
 #pragma unroll
     for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0;
     for (int r = 0; r < nefc; r += 4) {
@@ -3923,6 +3934,38 @@ struct StepCore {
         for (int j = 0; j < N; j++) { const T jj = S(efc_Jd)[rr*N + j]; if (c[u] != 0 && j <= lane) a[j] += c[u] * jj; }
       }
     }
+#else
+    // Branch-free (round 5): every lane builds its WHOLE row (M is stored symmetric; the entries right of the diagonal are
+    // never read by the elimination's valid lanes), the row's loads carry no predicate -- a lane outside the matrix reads
+    // row 0, a trip's padding rows re-read the trip's first row with a zero weight -- and a row that is not in the
+    // quadratic zone enters with weight zero: a + 0 * J_rj is a, to the bit (the Jacobian is finite).  What the compiler made
+    // of the predicated form was a v_cmp / exec-mask / load / restore sequence per entry and three DEPENDENT LDS round
+    // trips per constraint row (state, then J_ri, then D) -- 2.7 us per assembly + factorisation of the 9-dof model, of which
+    // the arithmetic is a tenth.  nv <= 16: J_rj comes from lane j's own J_rj by a DPP row broadcast instead of nine
+    // wave-uniform LDS reads per row.
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = S(qM)[i*N + j];
+    for (int r = 0; r < nefc; r += 4) {
+      T c[4], ji[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rr = r + u < nefc ? r + u : r;
+        const int st = SI(efc_active)[rr];
+        ji[u] = S(efc_Jd)[rr*N + i];
+        const T w = (r + u < nefc && st == EFC_ST_QUADRATIC) ? S(efc_D)[rr] : (T)0;
+        c[u] = w*ji[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+          T jj;
+          if constexpr (N <= 16 && LPE >= 16) jj = bcast_rows<LPE, N>(ji[u], j); else jj = S(efc_Jd)[(r + u < nefc ? r + u : r)*N + j];
+          a[j] += c[u] * jj;
+        }
+      }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
       T akk = bcast_rows<LPE, N>(a[k], k);

@@ -7,12 +7,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dm_control_amd import mjcf_compiler as mc
 from dm_control_amd.batch import BatchedPhysics, OUT
-region = int(os.environ['DMC_LIB_VARIANT'][3:])
+# REGION=<n>: the on-demand specialised kernel built with DMC_SPEC_FLAGS=-DDMC_TRACE_SUB=<n> (scripts/spec_variants.py);
+# B=<batch>: 512 = one wave per CU, i.e. the latency of a wave that has its SIMD to itself (the tail of a launch)
+if os.environ.get('REGION'):
+  region = int(os.environ['REGION'])
+  os.environ['DMC_NO_STATIC'] = '1'
+  os.environ['DMC_SPEC_FLAGS'] = (os.environ.get('EXTRA_FLAGS', '') + ' -DDMC_TRACE_SUB=%d' % region).strip()
+else:
+  region = int(os.environ['DMC_LIB_VARIANT'][3:])
 names = {1: ['start->after kinematics (acc, euler, kin)', 'com_pos', 'sensors(pos)', 'com_vel', 'sensors(vel)+store'],
          2: ['start->after crb+factor', 'collision', 'make_constraint', 'sensors(pos)+rne', 'rest (acc, euler, trailing, store)'],
          3: ['start->first iteration', 'primal_search', 'update+constraint_update+gauss', 'newton_gradient', 'rest']}[region]
 m = mc.compile_xml(open(os.path.join(ROOT, 'dm_control_amd/suite/assets/cheetah.xml')).read())
-B = 4096
+B = int(os.environ.get('B', 4096))
 lim = m.jnt_limited == 1
 lo, hi = m.jnt_range[lim].T
 q0 = np.tile(m.qpos0, (B, 1))
@@ -36,7 +43,7 @@ pts = [tr[k, 1], tr[k, 4], tr[k, 5], tr[k, 6], tr[k, 7], tr[k, 2]]
 ok = np.all([p > 0 for p in pts], axis=0)
 if region == 3:
   ok &= it >= 1
-print('region', region, 'waves with all stamps', int(ok.sum()))
+print('region', region, 'B', B, 'waves with all stamps', int(ok.sum()), b.info().get('static_id'))
 for i, n in enumerate(names):
   seg = (pts[i + 1] - pts[i])[ok] / 100.0
   by = {int(v): round(float(seg[it[ok] == v].mean()), 2) for v in np.unique(it[ok])}
