@@ -456,6 +456,29 @@ DMC_DEV void tri_unrank(int t, int m, int* i, int* j) {
 // In-place Cholesky of a packed lower triangle, same operation order as the oracle.  On exit: strict
 // lower part = L, diagonal = 1/L[k][k].  Two wave fences per column: scale column k, then every
 // remaining entry (i, j), j > k, is updated by one lane with  A[i][j] -= L[i][k] L[j][k].
+// a - b c: in the fp32 kernels ONE fused operation, said explicitly -- left to the contraction pass, the SLP vectoriser first
+// pairs the products of neighbouring columns into v_pk_mul_f32 and the fusion is lost (two moves, a packed product and two
+// subtractions where two FMAs do); in fp64 the two roundings of the oracle.
+template <typename T> DMC_DEV T nmsub(T a, T b, T c) {
+#ifndef DMC_HOST_EMU
+  if constexpr (sizeof(T) == 4) return __builtin_fmaf(-b, c, a);
+#endif
+  return a - b * c;
+}
+#ifndef DMC_HOST_EMU
+// Row-per-lane factor -> the packed triangle (column j at tri_c0(j, N), rows j .. N-1): lane i holds (i, j) for j <= i.
+// Stored WITHOUT a predicate per column: the columns go out last to first, and a lane above the diagonal (i < j) aims
+// its don't-care value at tri_c0(j, N) + i - j -- a slot of an EARLIER column (>= 0 because tri_c0(j, N) >= j), which that
+// column's own store, issued later by the same wave, overwrites with the entry that belongs there.  One exec mask for
+// the N row-holding lanes instead of a compare / mask / branch / restore sequence per column (9 x 8 instructions on the
+// 9-dof model, a quarter of the factorisation).
+template <typename T, int N> DMC_DEV void store_factor_rows(DMC_LDS T* A, const T* a, int lane) {
+  if (lane < N) {
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) { A[tri_c0(j, N) + lane - j] = a[j]; asm volatile("" ::: "memory"); }      // (in THIS order: to one lane the nine addresses are unrelated)
+  }
+}
+#endif
 template <typename T, int LPE>
 DMC_FN void chol_factor_lds(DMC_LDS T* A, int n, int lane) {
   const int ntri = (n*(n + 1)) >> 1;
@@ -489,7 +512,11 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   T a[N];
   const bool own = lane < N;
 #pragma unroll
-  for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? A[tri_c0(j, N) + lane - j] : (T)0;
+  for (int j = 0; j < N; j++) {      // (unpredicated loads, the value selected afterwards: a predicated load costs an exec-mask round trip each)
+    const int i_ = own && j <= lane ? lane : j;
+    const T v = A[tri_c0(j, N) + i_ - j];
+    a[j] = (own && j <= lane) ? v : (T)0;
+  }
 #pragma unroll
   for (int k = 0; k < N; k++) {
     T akk = bcast_rows<LPE, N>(a[k], k);
@@ -497,13 +524,10 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
     const T inv = t_rsqrt(akk);
     const T lik = a[k] * inv;
 #pragma unroll
-    for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
+    for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
     a[k] = lane == k ? inv : lik;
   }
-  if (own) {
-#pragma unroll
-    for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
-  }
+  store_factor_rows<T, N>(A, a, lane);
   DMC_WSYNC();
 }
 #endif
@@ -519,9 +543,13 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   const int ci = tri_c0(own ? i : 0, N);
   T row[N], col[N];
 #pragma unroll
-  for (int k = 0; k < N; k++) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
-  const T dinv = own ? Lm[ci] : (T)0;      // 1 / L[i][i]
-  T sreg = own ? b[i] : (T)0;
+  for (int k = 0; k < N; k++) {      // (unpredicated loads from in-range addresses, the values selected afterwards)
+    const T r_ = Lm[tri_c0(k, N) + ((own && k < i) ? i - k : 0)], c_ = Lm[ci + ((own && k > i) ? k - i : 0)];
+    row[k] = (own && k < i) ? r_ : (T)0; col[k] = (own && k > i) ? c_ : (T)0;
+  }
+  const T dinv_ = Lm[ci], b_ = b[own ? i : 0];
+  const T dinv = own ? dinv_ : (T)0;      // 1 / L[i][i]
+  T sreg = own ? b_ : (T)0;
 #ifdef DMC_SOLVE_ROWS_R4
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -544,10 +572,10 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   // predicated updates: 2 603 instructions for N = 62, 8 % of the 62-dof step).  The same products and differences as
   // before, bit for bit.
 #pragma unroll
-  for (int k = 0; k < N; k++) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = sreg - row[k]*xk; }
+  for (int k = 0; k < N; k++) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub(sreg, row[k], xk); }
   sreg = sreg*dinv;
 #pragma unroll
-  for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = sreg - col[k]*xk; }
+  for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub(sreg, col[k], xk); }
   if (own) x[i] = sreg*dinv;
 #endif
   DMC_WSYNC();
@@ -1455,11 +1483,11 @@ struct StepCore {
     const int i = own ? lane : 0;
     T a[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0;
+    for (int j = 0; j < N; j++) a[j] = S(qM)[i*N + j];      // (the whole row, unpredicated: hess_factor_rows)
     if (diag) {
       const T dv = diag_scale*diag[i];
 #pragma unroll
-      for (int j = 0; j < N; j++) if (own && j == lane) a[j] += dv;
+      for (int j = 0; j < N; j++) a[j] = (j == lane) ? a[j] + dv : a[j];
     }
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -1468,14 +1496,10 @@ struct StepCore {
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
       a[k] = lane == k ? inv : lik;
     }
-    DMC_LDS T* A = (DMC_LDS T*)dst;
-    if (own) {
-#pragma unroll
-      for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
-    }
+    store_factor_rows<T, N>((DMC_LDS T*)dst, a, lane);
     DMC_WSYNC();
   }
 #endif
@@ -3973,14 +3997,10 @@ struct StepCore {
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = a[j] - lik * ljk; }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
       a[k] = lane == k ? inv : lik;
     }
-    DMC_LDS T* A = (DMC_LDS T*)S(qLH);
-    if (own) {
-#pragma unroll
-      for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
-    }
+    store_factor_rows<T, N>((DMC_LDS T*)S(qLH), a, lane);
     DMC_WSYNC();
   }
 #endif

@@ -2,6 +2,8 @@
 config: CONFIG=2..5 [B=<batch>]."""
 import json, os, sys
 os.environ['DMC_USE_PROF'] = '1'
+if os.environ.get('PLUGIN'):      # a profiling plugin (scripts/spec_variants.py with -DDMC_PROFILE=1) on the profiling library
+  os.environ['DMC_NO_STATIC'] = '1'; os.environ['DMC_SPEC_PLUGIN'] = os.path.abspath(os.environ['PLUGIN'])
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
