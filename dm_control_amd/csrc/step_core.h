@@ -3813,11 +3813,15 @@ struct StepCore {
     T cost = 0;
     int changed = 0;
     for (int i = lane; i < nefc; i += LPE) {
-      const T jar = S(efc_jar)[i];
+      // (branch-free: D is read beside jar, not after the test on it -- a predicated read is a second LDS round trip
+      // behind an exec-mask sequence; the sums see the same terms, a zero where the row is satisfied)
+      const T jar = S(efc_jar)[i], D = S(efc_D)[i];
+      const int old = track ? SI(efc_active)[i] : 0;
       const int act = jar < 0;
-      if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
-      else S(efc_force)[i] = 0;
-      if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
+      const T dj = D*jar;
+      S(efc_force)[i] = act ? -dj : (T)0;
+      if (sizeof(T) == 4) cost += act ? (T)0.5*dj*jar : (T)0; else if (act) cost += (T)0.5*D*jar*jar;
+      if (track) { changed |= old != act; SI(efc_active)[i] = act; }
     }
     cost = group_sum<LPE>(cost);
     if (track) *track = group_max<LPE>(changed);
@@ -3895,9 +3899,9 @@ struct StepCore {
         for (int r = 0; r < nefc; r += 4) {      // four rows per trip, loads issued together, summed in row order
           T fr[4], jr[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int rr = r + u < nefc ? r + u : r; fr[u] = r + u < nefc ? S(efc_force)[rr] : (T)0; jr[u] = S(efc_Jd)[rr*nv + i]; }
+          for (int u = 0; u < 4; u++) { const int rr = r + u < nefc ? r + u : r; const T w = S(efc_force)[rr]; fr[u] = r + u < nefc ? w : (T)0; jr[u] = S(efc_Jd)[rr*nv + i]; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) if (fr[u] != 0) f += jr[u]*fr[u];
+          for (int u = 0; u < 4; u++) { if (sizeof(T) == 4) f += jr[u]*fr[u]; else f = fr[u] != 0 ? f + jr[u]*fr[u] : f; }      // (a zero force adds a zero: no branch)
         }
         S(qfrc_constraint)[i] = f;
       }
