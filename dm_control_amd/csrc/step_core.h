@@ -459,9 +459,11 @@ DMC_DEV void tri_unrank(int t, int m, int* i, int* j) {
 // a - b c: in the fp32 kernels ONE fused operation, said explicitly -- left to the contraction pass, the SLP vectoriser first
 // pairs the products of neighbouring columns into v_pk_mul_f32 and the fusion is lost (two moves, a packed product and two
 // subtractions where two FMAs do); in fp64 the two roundings of the oracle.
-template <typename T> DMC_DEV T nmsub(T a, T b, T c) {
+// (FUSE: the small row routines, N <= 16; the larger ones keep the expression the compiler has always seen -- on the 27-dof
+// model the explicit form bought nothing and moved the mean iteration count, profiles/r05_s7_ab_large_models.log)
+template <bool FUSE, typename T> DMC_DEV T nmsub(T a, T b, T c) {
 #ifndef DMC_HOST_EMU
-  if constexpr (sizeof(T) == 4) return __builtin_fmaf(-b, c, a);
+  if constexpr (FUSE && sizeof(T) == 4) return __builtin_fmaf(-b, c, a);
 #endif
   return a - b * c;
 }
@@ -473,6 +475,13 @@ template <typename T> DMC_DEV T nmsub(T a, T b, T c) {
 // the N row-holding lanes instead of a compare / mask / branch / restore sequence per column (9 x 8 instructions on the
 // 9-dof model, a quarter of the factorisation).
 template <typename T, int N> DMC_DEV void store_factor_rows(DMC_LDS T* A, const T* a, int lane) {
+#ifdef DMC_PRED_STORES
+  if (lane < N) {
+#pragma unroll
+    for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
+  }
+  return;
+#endif
   if (lane < N) {
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) { A[tri_c0(j, N) + lane - j] = a[j]; asm volatile("" ::: "memory"); }      // (in THIS order: to one lane the nine addresses are unrelated)
@@ -512,10 +521,13 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   T a[N];
   const bool own = lane < N;
 #pragma unroll
-  for (int j = 0; j < N; j++) {      // (unpredicated loads, the value selected afterwards: a predicated load costs an exec-mask round trip each)
-    const int i_ = own && j <= lane ? lane : j;
-    const T v = A[tri_c0(j, N) + i_ - j];
-    a[j] = (own && j <= lane) ? v : (T)0;
+  for (int j = 0; j < N; j++) {      // (N <= 16: unpredicated loads, the value selected afterwards -- a predicated load costs an exec-mask round trip each)
+    if constexpr (N > 16) a[j] = (own && j <= lane) ? A[tri_c0(j, N) + lane - j] : (T)0;      // (27 dofs: 3 % faster predicated -- half the reads)
+    else {
+      const int i_ = own && j <= lane ? lane : j;
+      const T v = A[tri_c0(j, N) + i_ - j];
+      a[j] = (own && j <= lane) ? v : (T)0;
+    }
   }
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -524,7 +536,7 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
     const T inv = t_rsqrt(akk);
     const T lik = a[k] * inv;
 #pragma unroll
-    for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
+    for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub<(N <= 16)>(a[j], lik, ljk); }
     a[k] = lane == k ? inv : lik;
   }
   store_factor_rows<T, N>(A, a, lane);
@@ -543,9 +555,12 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   const int ci = tri_c0(own ? i : 0, N);
   T row[N], col[N];
 #pragma unroll
-  for (int k = 0; k < N; k++) {      // (unpredicated loads from in-range addresses, the values selected afterwards)
-    const T r_ = Lm[tri_c0(k, N) + ((own && k < i) ? i - k : 0)], c_ = Lm[ci + ((own && k > i) ? k - i : 0)];
-    row[k] = (own && k < i) ? r_ : (T)0; col[k] = (own && k > i) ? c_ : (T)0;
+  for (int k = 0; k < N; k++) {      // (N <= 16: unpredicated loads from in-range addresses, the values selected afterwards)
+    if constexpr (N > 16) { row[k] = (own && k < i) ? Lm[tri_c0(k, N) + i - k] : (T)0; col[k] = (own && k > i) ? Lm[ci + k - i] : (T)0; }
+    else {
+      const T r_ = Lm[tri_c0(k, N) + ((own && k < i) ? i - k : 0)], c_ = Lm[ci + ((own && k > i) ? k - i : 0)];
+      row[k] = (own && k < i) ? r_ : (T)0; col[k] = (own && k > i) ? c_ : (T)0;
+    }
   }
   const T dinv_ = Lm[ci], b_ = b[own ? i : 0];
   const T dinv = own ? dinv_ : (T)0;      // 1 / L[i][i]
@@ -572,10 +587,10 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   // predicated updates: 2 603 instructions for N = 62, 8 % of the 62-dof step).  The same products and differences as
   // before, bit for bit.
 #pragma unroll
-  for (int k = 0; k < N; k++) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub(sreg, row[k], xk); }
+  for (int k = 0; k < N; k++) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub<(N <= 16)>(sreg, row[k], xk); }
   sreg = sreg*dinv;
 #pragma unroll
-  for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub(sreg, col[k], xk); }
+  for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub<(N <= 16)>(sreg, col[k], xk); }
   if (own) x[i] = sreg*dinv;
 #endif
   DMC_WSYNC();
@@ -1496,7 +1511,7 @@ struct StepCore {
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub<(N <= 16)>(a[j], lik, ljk); }
       a[k] = lane == k ? inv : lik;
     }
     store_factor_rows<T, N>((DMC_LDS T*)dst, a, lane);
@@ -3815,6 +3830,13 @@ struct StepCore {
     for (int i = lane; i < nefc; i += LPE) {
       // (branch-free: D is read beside jar, not after the test on it -- a predicated read is a second LDS round trip
       // behind an exec-mask sequence; the sums see the same terms, a zero where the row is satisfied)
+#ifdef DMC_CU_BRANCHY
+      const T jar = S(efc_jar)[i];
+      const int act = jar < 0;
+      if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
+      else S(efc_force)[i] = 0;
+      if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
+#else
       const T jar = S(efc_jar)[i], D = S(efc_D)[i];
       const int old = track ? SI(efc_active)[i] : 0;
       const int act = jar < 0;
@@ -3822,6 +3844,7 @@ struct StepCore {
       S(efc_force)[i] = act ? -dj : (T)0;
       if (sizeof(T) == 4) cost += act ? (T)0.5*dj*jar : (T)0; else if (act) cost += (T)0.5*D*jar*jar;
       if (track) { changed |= old != act; SI(efc_active)[i] = act; }
+#endif
     }
     cost = group_sum<LPE>(cost);
     if (track) *track = group_max<LPE>(changed);
@@ -4001,7 +4024,7 @@ struct StepCore {
       const T inv = t_rsqrt(akk);
       const T lik = a[k] * inv;
 #pragma unroll
-      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub(a[j], lik, ljk); }
+      for (int j = k + 1; j < N; j++) { const T ljk = bcast_rows<LPE, N>(lik, j); a[j] = nmsub<(N <= 16)>(a[j], lik, ljk); }
       a[k] = lane == k ? inv : lik;
     }
     store_factor_rows<T, N>((DMC_LDS T*)S(qLH), a, lane);
