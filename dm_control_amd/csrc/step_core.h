@@ -2279,7 +2279,13 @@ struct StepCore {
       const unsigned char* dofs = con_dof_list(c);
       const int kc = con_ndof(c);
       T acc = 0;
+#ifdef DMC_ROW_DOT_PRED
       for (int k = 0; k < L.d.kmax; k++) if (k < kc) acc += jr[k] * x[dofs[k]];
+#else
+      // (the slots past the contact's dof count are read like the others -- they exist, their dof byte addresses some word of
+      // the scratch -- and their product is dropped: no exec-mask sequence per slot)
+      for (int k = 0; k < L.d.kmax; k++) { const T j_ = jr[k], x_ = x[dofs[k]], t_ = acc + j_ * x_; acc = k < kc ? t_ : acc; }
+#endif
       return acc;
     }
     if (r >= rm.s0 && r < rm.tl0) { const int tid = SI(efc_tid)[r]; return simple_sign(tid) * x[simple_dof(tid)]; }
@@ -3935,6 +3941,7 @@ struct StepCore {
     FOR_LANES(i, nv) {
       T f = 0;
       if (L.d.njdense) for (int r = 0; r < rm.s0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
+#ifdef DMC_CFJ_PRED
       for (int r = rm.s0; r < rm.tl0; r++) {
         const T fr = S(efc_force)[r];
         const int tid = SI(efc_tid)[r];
@@ -3950,6 +3957,26 @@ struct StepCore {
         const auto jc = Jc_base + (r0 - rm.c0)*K + slot;
         for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q]; if (fr != 0) f += jc[q*K]*fr; }
       }
+#else
+      // (no lane-dependent branch around a load: a dof outside the contact's mask reads slot 0 and keeps its sum -- what sat
+      // behind `if (slot < 0) continue` was an exec-mask sequence and, for the models whose contact rows live in global
+      // memory, one dependent global round trip per row inside it)
+      for (int r = rm.s0; r < rm.tl0; r++) {
+        const T fr = S(efc_force)[r];
+        const int tid = SI(efc_tid)[r];
+        const T t_ = f + simple_sign(tid)*fr;
+        f = (fr != 0 && simple_dof(tid) == i) ? t_ : f;
+      }
+      if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) { const T fr = S(efc_force)[r], t_ = f + S(efc_Jd)[(rm.s0 + r - rm.tl0)*nv + i]*fr; f = fr != 0 ? t_ : f; }
+      for (int c = 0; c < ncon; c++) {
+        const int r0 = SI(con_efc)[c];
+        if (r0 < 0) continue;      // (group-uniform)
+        const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), i);
+        const int nrow = contact_rows(con_dim(c));
+        const auto jc = Jc_base + (r0 - rm.c0)*K + (slot < 0 ? 0 : slot);
+        for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q], t_ = f + jc[q*K]*fr; f = (slot >= 0 && fr != 0) ? t_ : f; }
+      }
+#endif
       S(qfrc_constraint)[i] = f;
     }
   }
