@@ -3515,9 +3515,16 @@ struct StepCore {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const bool in = r + u < rm.tl0;
+#ifdef DMC_HSPLIT_PRED
           const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
           const T dd = in ? S(efc_D)[r + u] : (T)0;
           if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
+#else
+          const int rr = in ? r + u : r;      // (a padding row re-reads the trip's first row: no load behind a predicate)
+          const int st = SI(efc_active)[rr], tid = SI(efc_tid)[rr];
+          const T dd = S(efc_D)[rr], t_ = dsum + dd;
+          dsum = (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) ? t_ : dsum;
+#endif
         }
       }
       S(sv_Mgrad)[i] = dsum;
@@ -3589,7 +3596,12 @@ struct StepCore {
         } else {
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
             const T ji = J[q*K + a];
+#ifdef DMC_HSPLIT_PRED
             if (ji != 0) acc += (S(efc_D)[r0 + q]*ji) * J[q*K + b2];
+#else
+            const T jj = J[q*K + b2], t_ = acc + (S(efc_D)[r0 + q]*ji) * jj;
+            acc = ji != 0 ? t_ : acc;
+#endif
           }
         }
         S(qLH)[tri_at(i, j, nv)] += acc;
@@ -3611,9 +3623,16 @@ struct StepCore {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const bool in = r + u < rm.tl0;
+#ifdef DMC_HSPLIT_PRED
           const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
           const T dd = in ? S(efc_D)[r + u] : (T)0;
           if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
+#else
+          const int rr = in ? r + u : r;      // (a padding row re-reads the trip's first row: no load behind a predicate)
+          const int st = SI(efc_active)[rr], tid = SI(efc_tid)[rr];
+          const T dd = S(efc_D)[rr], t_ = dsum + dd;
+          dsum = (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) ? t_ : dsum;
+#endif
         }
       }
       S(sv_Mgrad)[i] = dsum;
@@ -3645,7 +3664,11 @@ struct StepCore {
         const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
         const int a0 = mask_slot(lo, hi, i0), b0 = mask_slot(lo, hi, j0), a1 = mask_slot(lo, hi, i1), b1 = mask_slot(lo, hi, j1);
         const bool in0 = a0 >= 0 && b0 >= 0, in1 = two && a1 >= 0 && b1 >= 0;
+#ifdef DMC_HSPLIT_PRED
         if (!in0 && !in1) continue;
+#endif
+        // (no lane-dependent skip: an entry outside the contact's mask reads slot 0 and drops the sum -- the skip put the
+        // global loads of the contact's Jacobian behind an exec-mask sequence)
         const int sa0 = in0 ? a0 : 0, sb0 = in0 ? b0 : 0, sa1 = in1 ? a1 : 0, sb1 = in1 ? b1 : 0;
         const auto J = Jc_base + (r0 - rm.c0)*K;
         T acc0 = 0, acc1 = 0;
@@ -3668,8 +3691,13 @@ struct StepCore {
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
             const T dq = S(efc_D)[r0 + q];
             const T ji0 = J[q*K + sa0], ji1 = J[q*K + sa1];
+#ifdef DMC_HSPLIT_PRED
             if (ji0 != 0) acc0 += (dq*ji0) * J[q*K + sb0];
             if (ji1 != 0) acc1 += (dq*ji1) * J[q*K + sb1];
+#else
+            const T jj0 = J[q*K + sb0], jj1 = J[q*K + sb1], t0 = acc0 + (dq*ji0) * jj0, t1 = acc1 + (dq*ji1) * jj1;
+            acc0 = ji0 != 0 ? t0 : acc0; acc1 = ji1 != 0 ? t1 : acc1;
+#endif
           }
         }
         if (in0) h0 += acc0;
