@@ -3376,6 +3376,7 @@ struct StepCore {
   // middle zone it also leaves the rank structure of the block Hessian
   //   Hc = Dm [ p p' + c (diag(g) - w w') ]   (p, w: combinations of the block's rows)
   // in efc_ca / efc_cb / efc_cg for newton_gradient.
+#ifdef DMC_CUELL_V1
   DMC_DEV T constraint_update_ell(int nefc, int* track) {
     T cost = 0;
     int changed = 0;
@@ -3460,6 +3461,108 @@ struct StepCore {
   // only touch the kc x kc block of its own dofs, so its lanes run over the kc (kc + 1) / 2 dof pairs of that
   // block (no two lanes on the same entry; a wave fence between contacts).  efc_active holds the state
   // constraint_update recorded.
+#else
+  // Round 5: every load sits at the top of the trip without a predicate (clamped indices), the row types are told apart on
+  // registers, and the block of a frictional contact is six statically indexed rows under a `j < dim` guard -- the
+  // run-time trip counts had put U[] / fj[] in scratch memory and every row's (jar, D) behind its own LDS round trip
+  // inside three nested exec-mask regions.  Same expressions, same order of the sums.
+  DMC_DEV T constraint_update_ell(int nefc, int* track) {
+    T cost = 0;
+    int changed = 0;
+    for (int i = lane; i < nefc; i += LPE) {
+      const int tid = SI(efc_tid)[i], ty = EFC_TYPE(tid), id = EFC_ID(tid);
+      const T jar = S(efc_jar)[i], D = S(efc_D)[i];
+      const int old = SI(efc_active)[i];
+      const bool ell = ty == EFC_ELLIPTIC;
+      const int c = ell ? id : 0;
+      const int r0 = SI(con_efc)[c], info = SI(con_info)[c];
+      const bool head = ell && i == r0;
+      const int rb = head ? r0 : i;      // (a lane that heads no block re-reads its own row)
+      T jr[6], Dr[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {      // (rows past the block are read and ignored; the device reads at most five words past the array, inside the scratch)
+#ifdef DMC_HOST_EMU
+        const int rj = rb + j < L.d.njmax ? rb + j : rb;
+#else
+        const int rj = rb + j;
+#endif
+        jr[j] = S(efc_jar)[rj]; Dr[j] = S(efc_D)[rj];
+      }
+      const T floss = MR(dof_frictionloss)[ty == EFC_FRICTION ? id : 0];
+      const T* fr = MR(prm_friction) + 3*(head ? prm_of_info(info) : 0);
+      const T fr0 = fr[0], fr1 = fr[1], fr2 = fr[2];
+      if (!ell) {
+        // (the new total of every zone is formed as `cost + term`, the expression the branches had: the same contraction, the
+        // same bits -- the iteration counts of the 62-dof model move with the last bit of this sum)
+        const T fq = -D*jar, tq = cost + (T)0.5*D*jar*jar;
+        int st; T force, tot;
+        if (ty == EFC_EQUALITY) { st = EFC_ST_QUADRATIC; force = fq; tot = tq; }      // two-sided: always quadratic
+        else if (ty == EFC_FRICTION) {
+          // Huber cost: quadratic for |jar| < R*floss, linear (force saturated at +-floss) outside
+          const T f = floss, rf = f / D;
+          const T tn = cost + f*((T)-0.5*rf - jar), tp = cost + f*((T)-0.5*rf + jar);
+          if (jar <= -rf) { st = EFC_ST_LINEARNEG; force = f; tot = tn; }
+          else if (jar >= rf) { st = EFC_ST_LINEARPOS; force = -f; tot = tp; }
+          else { st = EFC_ST_QUADRATIC; force = fq; tot = tq; }
+        } else {
+          const bool act = jar < 0;
+          st = act ? 1 : 0; force = act ? fq : (T)0; tot = act ? tq : cost;
+        }
+        S(efc_force)[i] = force; cost = tot;
+        if (track) { changed |= old != st; SI(efc_active)[i] = st; }
+        continue;
+      }
+      if (!head) continue;
+      const int dim = info & 0xff;
+      const T D0 = Dr[0];
+      const T mu = fr0 * t_sqrt(D0 / Dr[1]);   // regularised cone: mu sqrt(R1/R0)
+      T U[6], fj[6], Tn = 0;
+      U[0] = jr[0]*mu; fj[0] = mu;
+#pragma unroll
+      for (int j = 1; j < 6; j++) {
+        fj[j] = j < 3 ? fr0 : (j == 3 ? fr1 : fr2);
+        U[j] = jr[j]*fj[j];
+        if (j < dim) Tn += U[j]*U[j];
+      }
+      Tn = t_sqrt(Tn);
+      const T N = U[0];
+      int st;
+      if (N >= mu*Tn || (Tn <= 0 && N >= 0)) {
+        st = EFC_ST_SATISFIED;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) S(efc_force)[r0 + j] = 0;
+      } else if (mu*N + Tn <= 0 || (Tn <= 0 && N < 0)) {
+        st = EFC_ST_QUADRATIC;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) { S(efc_force)[r0 + j] = -Dr[j]*jr[j]; cost += (T)0.5*Dr[j]*jr[j]*jr[j]; }
+      } else {
+        st = EFC_ST_CONE;
+        const T Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu)), NT = N - mu*Tn;
+        cost += (T)0.5*Dm*NT*NT;
+        const T f0 = -Dm*NT*mu;
+        S(efc_force)[r0] = f0;
+        const T cc = -NT*mu/Tn;   // > 0
+        S(efc_ca)[r0] = mu; S(efc_cb)[r0] = Dm*cc; S(efc_cg)[r0] = Dm;
+#pragma unroll
+        for (int j = 1; j < 6; j++) if (j < dim) {
+          const T uh = U[j]/Tn;
+          S(efc_force)[r0 + j] = -f0/Tn * U[j]*fj[j];
+          S(efc_ca)[r0 + j] = -mu*uh*fj[j]; S(efc_cb)[r0 + j] = uh*fj[j]; S(efc_cg)[r0 + j] = Dm*cc*fj[j]*fj[j];
+        }
+      }
+      if (track) {
+        // a cone-zone Hessian depends on the residual itself, not just on the zone
+        if (old != st || st == EFC_ST_CONE) changed = 1;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j < dim) SI(efc_active)[r0 + j] = st;
+      }
+    }
+    cost = group_sum<LPE>(cost);
+    if (track) *track = group_max<LPE>(changed);
+    DMC_WSYNC();
+    return cost;
+  }
+#endif
   DMC_DEV void hess_assemble(int nefc, const RowMap& rm) {
     const int nv = L.d.nv, K = L.d.kmax;
     if (L.d.jfull && !L.d.msparse) {
