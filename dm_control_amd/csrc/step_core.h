@@ -4274,6 +4274,7 @@ struct StepCore {
   // type -> contact -> first row -> nine aggregates) per row before the arithmetic started: 22 % / 14 % of their step.
   enum { LSK_NONE = 0, LSK_EQUALITY, LSK_FRICTION, LSK_ONESIDED, LSK_CONE };
   struct LSRows { T jar, jv, D; bool on; bool gen; int kind; T f, rf, U0, V0, UU, UV, VV, mu, b0, b1, b2, Dm, NT0, T0; bool bottom0, middle0; };
+#ifdef DMC_LSLOAD_V1
   DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
     g.gen = true; g.kind = LSK_NONE;
     g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = g.T0 = 0; g.bottom0 = g.middle0 = false;
@@ -4311,6 +4312,63 @@ struct StepCore {
       else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; g.T0 = T0; }      // (T0: the anchored form's reference point)
     }
   }
+#else
+  // (round 5: loads first and unpredicated, the contact block as six statically indexed rows -- see constraint_update_ell)
+  DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
+    g.gen = true; g.kind = LSK_NONE;
+    g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = g.T0 = 0; g.bottom0 = g.middle0 = false;
+    const bool in = lane < nefc;
+    const int i = in ? lane : 0;
+    const int tid = SI(efc_tid)[i], ty = EFC_TYPE(tid), id = EFC_ID(tid);
+    const bool ell = in && ty == EFC_ELLIPTIC;
+    const int c = ell ? id : 0;
+    const int r0 = SI(con_efc)[c], info = SI(con_info)[c];
+    const bool head = ell && i == r0;
+    T jr[6], jvv[6], Dr[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+#ifdef DMC_HOST_EMU
+      const int rj = i + j < L.d.njmax ? i + j : i;
+#else
+      const int rj = i + j;
+#endif
+      jr[j] = S(efc_jar)[rj]; jvv[j] = S(efc_jv)[rj]; Dr[j] = S(efc_D)[rj];
+    }
+    const T floss = MR(dof_frictionloss)[(in && ty == EFC_FRICTION) ? id : 0];
+    const T* fr = MR(prm_friction) + 3*(head ? prm_of_info(info) : 0);
+    const T fr0 = fr[0], fr1 = fr[1], fr2 = fr[2];
+    if (!in) return;
+    g.jar = jr[0]; g.jv = jvv[0]; g.D = Dr[0];
+    if (ty == EFC_EQUALITY) { g.kind = LSK_EQUALITY; return; }
+    if (ty == EFC_FRICTION) { g.kind = LSK_FRICTION; g.f = floss; g.rf = g.f / g.D; return; }
+    if (ty != EFC_ELLIPTIC) { g.kind = LSK_ONESIDED; return; }
+    if (!head) return;
+    g.kind = LSK_CONE;
+    const int dim = info & 0xff;
+    const T D0 = g.D;
+    const T mu = fr0 * t_sqrt(D0 / Dr[1]);
+    T UU = 0, UV = 0, VV = 0, b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) {
+      const T jar = jr[j], jv = jvv[j], D = Dr[j], dj0 = D*jar;
+      b0 += (T)0.5*jar*dj0; b1 += jv*dj0; b2 += (T)0.5*D*jv*jv;
+      if (j) {
+        const T f = j < 3 ? fr0 : (j == 3 ? fr1 : fr2);
+        const T u = jar*f, v = jv*f;
+        UU += u*u; UV += u*v; VV += v*v;
+      }
+    }
+    g.U0 = g.jar*mu; g.V0 = g.jv*mu; g.UU = UU; g.UV = UV; g.VV = VV; g.mu = mu; g.b0 = b0; g.b1 = b1; g.b2 = b2;
+    g.Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
+    if (UU <= 0) g.bottom0 = g.U0 < 0;      // the contact's zone at alpha = 0 (relative form)
+    else {
+      const T T0 = t_sqrt(UU);
+      if (g.U0 >= mu*T0) {}
+      else if (mu*g.U0 + T0 <= 0) g.bottom0 = true;
+      else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; g.T0 = T0; }      // (T0: the anchored form's reference point)
+    }
+  }
+#endif
   // ls_eval_ell's arithmetic for the lane's one row
   DMC_DEV void ls_eval_gen(LSPoint* p, const T* qg, const LSRows& g) {
     const T a = p->alpha;
