@@ -5046,12 +5046,28 @@ struct StepCore {
   DMC_DEV void noslip(int nefc) {
     const int nv = L.d.nv, cap = L.d.nslip;
     int nf = 0, over = 0;
+#if defined(DMC_HOST_EMU) || defined(DMC_NS_SCAN_SERIAL)
     for (int i = 0; i < nefc; i++) {
       const int tid = SI(efc_tid)[i], t = EFC_TYPE(tid);
       bool take = t == EFC_FRICTION || t == EFC_PYRAMIDAL;
       if (t == EFC_ELLIPTIC) take = i != SI(con_efc)[EFC_ID(tid)];
       if (take) { if (nf < cap) { if (lane == 0) SI(ns_row)[nf] = i; nf++; } else over = 1; }
     }
+#else
+    // the friction rows in row order: one lane per row and a prefix sum (the row-by-row walk was two dependent LDS round
+    // trips per row for every lane: ~3 k cycles for the 15 rows of a soccer step)
+    for (int i0 = 0; i0 < nefc; i0 += LPE) {
+      const int i = i0 + lane, ii = i < nefc ? i : 0;
+      const int tid = SI(efc_tid)[ii], t = EFC_TYPE(tid);
+      const int r0 = SI(con_efc)[t == EFC_ELLIPTIC ? EFC_ID(tid) : 0];
+      const int take = (i < nefc && (t == EFC_FRICTION || t == EFC_PYRAMIDAL || (t == EFC_ELLIPTIC && i != r0))) ? 1 : 0;
+      int total;
+      const int pos = nf + group_scan<LPE>(take, lane, &total);
+      if (take && pos < cap) SI(ns_row)[pos] = i;
+      nf += total;
+    }
+    if (nf > cap) over = 1;
+#endif
     if (over) { if (lane == 0) SI(imisc)[IM_WARN + DMC_WARN_CNSTRFULL]++; return; }   // more friction rows than the cap: step without noslip
     if (!nf) return;
     // M^-1 through the factor of M computed in the position stage and kept beside H's factor: in qLM, or (large
