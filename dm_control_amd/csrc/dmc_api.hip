@@ -182,6 +182,7 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   if (ncaps < 0 || (ncaps > 0 && !caps)) return fail("null argument");
   const int nconmax = ncaps > 0 ? caps[0] : 0, njmax = ncaps > 1 ? caps[1] : 0, lanes_per_env = ncaps > 2 ? caps[2] : 0;
   const int njcon = ncaps > 3 ? caps[3] : 0;
+  int jlevel = ncaps > 4 ? caps[4] - 1 : -1;      // caps[4]: StepDims::jglobal + 1, 0 = automatic
   if (!m || !out) return fail("null argument");
   if (batch_size < 1) return fail("batch_size must be >= 1");
   if (precision != 32 && precision != 64) return fail("precision must be 32 or 64");
@@ -194,8 +195,27 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   b->elem = precision == 64 ? sizeof(double) : sizeof(float);
   b->outmask = OUT_ALL; b->ndebug = 0; b->d_debug = nullptr; b->d_debug_i = nullptr; b->d_mi = nullptr; b->d_mc = nullptr; b->d_mr = nullptr; b->d_stash_r = nullptr; b->d_stash_i = nullptr; b->d_epoch = nullptr; b->stash_on = 0; b->stash_auto = 0; b->d_eg_slot = nullptr; b->xfrc_on = 0; b->d_ns_A = nullptr; b->d_gscr = nullptr; b->d_work = nullptr; b->d_kstash = nullptr; b->d_kstash_i = nullptr; b->d_cost = nullptr; b->d_order = nullptr; b->lpt = 0; b->nitems = 0; b->d_prof = nullptr; b->d_layout = nullptr; b->d_trace = nullptr; b->trace_launch = 0; b->d_rj_i = nullptr; b->d_rj_r = nullptr;
   std::string err;
-  if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon)) { delete b; return fail(err); }
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || ncu < 1) ncu = 256; b->ncu = ncu; }
+  // The contact rows and the kept factor of M leave LDS for the per-env global scratch on the 17 .. 32-dof models so that
+  // more environments are resident per CU (level 1: config 3 +24 %).  A batch of at most one environment per CU has
+  // nothing to gain from residency and pays a global round trip wherever a row is read: it keeps them in LDS
+  // (soccer 2v2, B = 256: +3 %; at B = 4096 the same choice costs 8 %).  DMC_JLEVEL=<n>: tuning override.
+  if (jlevel < 0 && getenv("DMC_JLEVEL")) jlevel = atoi(getenv("DMC_JLEVEL"));
+  const bool small_auto = jlevel < 0 && batch_size <= b->ncu && DMC_JGLOBAL_LEVEL(m->hm.nv) == 1;
+  if (!step_tables_build(&b->tb, m->hm, nconmax, njmax, &err, njcon, small_auto ? 0 : jlevel)) { delete b; return fail(err); }
+  if (small_auto) {
+    // ... unless only the default layout has a baked model-specialised kernel (the generic one is 2 - 3 x slower: that
+    // would be a bad trade for a global round trip per row)
+    if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
+    if (b->geom.static_id < 0) {
+      StepTables def;
+      if (step_tables_build(&def, m->hm, nconmax, njmax, &err, njcon, -1)) {
+        StepTables keep = b->tb; LaunchGeom kg = b->geom;
+        b->tb = def;
+        if (choose_geometry(b, lanes_per_env) || b->geom.static_id < 0) { b->tb = keep; b->geom = kg; }
+      }
+    }
+  }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
   const StepLayout& L = b->tb.L;
   const StepDims& d = L.d;

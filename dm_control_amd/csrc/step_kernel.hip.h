@@ -177,8 +177,8 @@ template <int SID> struct StaticLayout;
   static __device__ const StepLayout kStaticLayout##ID = DMC_STATIC_LAYOUT_##ID;     \
   template <> struct StaticLayout<ID> {                                               \
     static constexpr int kNV = DMC_STATIC_NV_##ID;   /* compile-time nv: register-resident Cholesky */ \
-    static constexpr int kJGlobal = DMC_JGLOBAL_LEVEL(DMC_STATIC_NV_##ID);   /* StepDims::jglobal */ \
     static constexpr StepLayout kL = DMC_STATIC_LAYOUT_##ID;                                      \
+    static constexpr int kJGlobal = kL.d.jglobal;   /* (a small batch keeps the contact rows in LDS: jlevel of step_tables_build) */ \
     static constexpr int kNKin = kL.s_qM - kL.s_xpos;   /* reals of the kinematic stash */       \
     static constexpr int kTreeMax = kL.d.treemax;   /* > 0: factorisations run the kinematic trees side by side */ \
     static constexpr int kTreeUni = kL.d.treeuni;   /* trees of equal size: the block structure of M's factor is a compile-time fact */ \

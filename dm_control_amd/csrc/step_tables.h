@@ -70,7 +70,8 @@ struct StepTables {
 };
 
 // returns false + err for models the kernel does not support
-inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, int njmax, std::string* err, int njcon = 0) {
+// jlevel: StepDims::jglobal (what leaves LDS for the per-env global scratch), -1 = DMC_JGLOBAL_LEVEL(nv)
+inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, int njmax, std::string* err, int njcon = 0, int jlevel = -1) {
   StepDims d;
   std::memset(&d, 0, sizeof d);
   d.nq = m.nq; d.nv = m.nv; d.nu = m.nu; d.nbody = m.nbody; d.njnt = m.njnt; d.ngeom = m.ngeom;
@@ -300,7 +301,7 @@ inline bool step_tables_build(StepTables* t, const HostModel& m, int nconmax, in
     d.kwords = (kmax + 3) / 4;
   }
   d.msparse = m.nv > 16 ? 1 : 0;
-  d.jglobal = DMC_JGLOBAL_LEVEL(m.nv);
+  d.jglobal = (jlevel >= 0 && jlevel <= DMC_JGLOBAL_LEVEL(m.nv)) ? jlevel : DMC_JGLOBAL_LEVEL(m.nv);      // (an override only ever keeps MORE in LDS)
   d.sitegl = m.nsite > 32 ? 1 : 0;
   d.maxrow = maxrow_per_contact;
   d.coldlds = (d.nM + 2 * m.npair) <= 256 ? 1 : 0;

@@ -40,7 +40,9 @@ void dmc_model_destroy(dmc_model* m);
  * counters like MuJoCo's own caps.  lanes_per_env: 64, 32 or 16 (0 = automatic: 32 for nv <= 12, else 64). */
 int dmc_batch_create(const dmc_model* m, int batch_size, int device_id, int precision,
                      int nconmax, int njmax, int lanes_per_env, dmc_batch** out);
-/* The same with the capacity knobs as a list: caps = {nconmax, njmax, lanes_per_env, njcon} (missing or 0 = automatic).
+/* The same with the capacity knobs as a list: caps = {nconmax, njmax, lanes_per_env, njcon, jlevel + 1} (missing or 0 =
+ * automatic; jlevel: how much of the per-env scratch leaves LDS for global memory -- 0 keeps the contact rows and the kept
+ * factor of M in LDS, the automatic choice for a batch of at most one environment per CU).
  * njcon: contact rows with a stored Jacobian.  The default lets every contact slot use the most rows a contact of
  * the model can have (nconmax x that); a smaller pool keeps LDS for a second / third resident environment and
  * raises DMC_WARN_CNSTRFULL (the contact is dropped, as MuJoCo does when njmax is hit) when the live contacts of one

@@ -15,7 +15,7 @@ prec = int(os.environ.get('PRECISION', 32))
 for k, flags in enumerate(sys.argv[2:] or ['']):
   os.environ['DMC_SPEC_FLAGS'] = flags
   t = time.time()
-  p = specialise.warm(m, precision=prec, **caps)
+  p = specialise.warm(m, precision=prec, jlevel=(int(os.environ['JLEVEL']) if os.environ.get('JLEVEL') else None), **caps)      # JLEVEL=0: the kernel of a small batch (config 5)
   if os.environ.get('NAME'):
     q = os.path.join(os.path.dirname(p), 'v_%s_cfg%s%s.so' % (os.environ['NAME'], sys.argv[1], '_%d' % k if k else ''))
     shutil.copyfile(p, q); p = q

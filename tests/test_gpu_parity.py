@@ -1149,3 +1149,38 @@ def test_config4_model_holds_five_environments_per_cu():
   assert info['static_id'] >= 0 and info['envs_per_cu'] == 5 and info['waves_per_block'] == 5, info
   assert info['lds_bytes_per_block'] <= 160 * 1024
   b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name, nconmax', [('soccer_2v2_boxhead', 24), ('humanoid', 24)])
+def test_a_small_batch_keeps_its_contact_rows_in_lds(name, nconmax, monkeypatch):
+  """17 .. 32 dofs: the contact rows and the kept factor of M live in the per-env global scratch so that more environments
+  are resident per CU -- unless the batch is at most one environment per CU AND a model-specialised kernel exists for
+  the all-in-LDS layout (dmc_api.hip; caps[4] / DMC_JLEVEL force either).  Only WHERE the rows are stored differs: the
+  trajectories are bit-identical."""
+  m = _model(name)
+  B, T = 64, 40
+  rs = np.random.RandomState(3)
+  acts = rs.uniform(-1, 1, (T, B, m.nu))
+  monkeypatch.delenv('DMC_JLEVEL', raising=False)
+  b = _batch(m, B, precision=32, nconmax=nconmax)
+  info = b.info()
+  b.close()
+  assert info['static_id'] >= 0, info      # (the small batch never trades a baked kernel for the generic one)
+  if name == 'soccer_2v2_boxhead': assert info['global_scratch_bytes_per_env'] == 0, info
+  big = _batch(m, 4096, precision=32, nconmax=nconmax)
+  assert big.info()['global_scratch_bytes_per_env'] > 0
+  big.close()
+  out = {}
+  if name == 'humanoid': monkeypatch.setenv('DMC_NO_STATIC', '1')      # (only level 1 is baked for it: compare the generic kernel with itself)
+  for level in ('0', '1'):
+    monkeypatch.setenv('DMC_JLEVEL', level)
+    b = _batch(m, B, precision=32, nconmax=nconmax)
+    assert (b.info()['global_scratch_bytes_per_env'] == 0) == (level == '0'), b.info()
+    b.forward()
+    for t in range(T):
+      b.set_control(acts[t]); b.step(2)
+    out[level] = (b.get('qpos'), b.get('qvel'), b.get('sensordata'), b.get('warning'))
+    b.close()
+  for x, y in zip(out['0'], out['1']):
+    assert np.array_equal(x, y)
