@@ -5362,9 +5362,16 @@ struct StepCore {
     } else FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
     DMC_WSYNC();
     int iter;
-    if (L.d.island && (o.islands < 0 ? sizeof(T) == 8 : o.islands != 0) && !(o.disableflags & DMC_DSBL_ISLAND) && solve_islands(nefc, &iter)) {}
-    else iter = primal_solve(nefc, evaluated, cc, gauss, changed);
-    constraint_force_to_joint(nefc);
+    if (L.d.island && (o.islands < 0 ? sizeof(T) == 8 : o.islands != 0) && !(o.disableflags & DMC_DSBL_ISLAND) && solve_islands(nefc, &iter)) constraint_force_to_joint(nefc);
+    else {
+      iter = primal_solve(nefc, evaluated, cc, gauss, changed);
+      // (qfrc_constraint = J' efc_force is already that of the solution: every exit of primal_solve is preceded by a
+      // newton_gradient at the final (qacc, efc_force), whose first act is this product -- forming it again was 5 % of the
+      // 9-dof step)
+#ifdef DMC_CFJ_TWICE
+      constraint_force_to_joint(nefc);
+#endif
+    }
     FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
     DMC_WSYNC();
