@@ -35,8 +35,10 @@ for c in (2, 3, 4, 5):
              longer_launches=dict(n=len(other), median_us=statistics.median(other) if other else None, max_us=max(other) if other else None,
                                   note='the settle launch(es) and the rollout-mode launches of the same kernel'))
   if K:
-    # the K timed launches are the last K single-step launches before the rollout launches
-    idx = [i for i, d in enumerate(dur) if d < 3 * med]
+    # the K timed launches are the K single-step launches right before the FIRST rollout-mode launch (what follows the
+    # rollout launches is the pipelined leg: part-batches on two streams, not the timed whole-batch launches)
+    first_long = next((i for i, d in enumerate(dur) if d >= 3 * med and i >= K), len(dur))
+    idx = [i for i in range(first_long) if dur[i] < 3 * med]
     timed = [dur[i] for i in idx[-K:]] if len(idx) >= K else single
     out['timed_launches'] = dict(n=len(timed), avg_us=sum(timed) / len(timed), median_us=statistics.median(timed), max_us=max(timed))
   json.dump(out, open(OUT('r05_kernel_stats_cfg%d.json' % c), 'w'), indent=1)
