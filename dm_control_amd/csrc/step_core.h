@@ -865,6 +865,10 @@ struct StepCore {
 #endif
     return env;
   }
+  // StepIO's arrays are global memory: said so, their accesses are global_load / global_store instead of flat ones (a flat
+  // access counts on lgkmcnt as well, so every LDS read after a flat store waited for the store's address to resolve)
+  template <typename P> DMC_DEV static DMC_GLB P* G(P* p) { return (DMC_GLB P*)p; }
+  template <typename P> DMC_DEV static const DMC_GLB P* G(const P* p) { return (const DMC_GLB P*)p; }
   // ---- state I/O (SoA in HBM <-> LDS) --------------------------------------
   // the per-env stash: everything the stages keep in LDS (persistent reals + all ints), env-major in HBM
   DMC_DEV bool load_stash(const StepIO<T>& io, int env) {
@@ -912,11 +916,11 @@ struct StepCore {
   DMC_DEV void store_kstash(const StepIO<T>& io, int env) {
     env = late(env);
     const int nq = L.d.nq, nv = L.d.nv, nk = kin_count();
-    T* h = io.kstash + (size_t)env*(nq + nv + nk);
+    DMC_GLB T* h = G(io.kstash) + (size_t)env*(nq + nv + nk);
     FOR_LANES(i, nq) h[i] = S(qpos)[i];
     FOR_LANES(i, nv) h[nq + i] = S(qvel)[i];
     FOR_LANES(i, nk) h[nq + nv + i] = S(xpos)[i];
-    if (lane == 0) io.kstash_i[env] = get_epoch();
+    if (lane == 0) G(io.kstash_i)[env] = get_epoch();
   }
   // ---- launch-entry loads ------------------------------------------------------------------------------------------
   // Everything a launch reads from HBM before it can start -- the env's launch override, its state, the tag of its
@@ -957,16 +961,16 @@ struct StepCore {
     if (!e->fast) return;
     const size_t B = (size_t)io.B;
     const int nq = L.d.nq, nv = L.d.nv;
-    r->qpos = lane < nq ? io.qpos[lane*B + env] : (T)0;
-    r->qvel = lane < nv ? io.qvel[lane*B + env] : (T)0;
-    r->warm = lane < nv ? io.qacc_warmstart[lane*B + env] : (T)0;
-    r->qfrc = (io.qfrc_applied && lane < nv) ? io.qfrc_applied[lane*B + env] : (T)0;
-    r->ctrl = lane < L.d.nu ? io.ctrl[lane*B + env] : (T)0;
-    r->act = (L.d.na && lane < L.d.na) ? io.act[lane*B + env] : (T)0;
+    r->qpos = lane < nq ? G(io.qpos)[lane*B + env] : (T)0;
+    r->qvel = lane < nv ? G(io.qvel)[lane*B + env] : (T)0;
+    r->warm = lane < nv ? G(io.qacc_warmstart)[lane*B + env] : (T)0;
+    r->qfrc = (io.qfrc_applied && lane < nv) ? G(io.qfrc_applied)[lane*B + env] : (T)0;
+    r->ctrl = lane < L.d.nu ? G(io.ctrl)[lane*B + env] : (T)0;
+    r->act = (L.d.na && lane < L.d.na) ? G(io.act)[lane*B + env] : (T)0;
     if (!kstash_applies(o, io, mode, legacy)) return;
-    r->ktag = io.kstash_i[env]; r->epoch = e->epoch;
+    r->ktag = G(io.kstash_i)[env]; r->epoch = e->epoch;
     const int nk = L.s_qM - L.s_xpos;
-    const T* h = io.kstash + (size_t)env*(nq + nv + nk);
+    const DMC_GLB T* h = G(io.kstash) + (size_t)env*(nq + nv + nk);
     r->kq = lane < nq ? h[lane] : (T)0;
     r->kv = lane < nv ? h[nq + lane] : (T)0;
 #pragma unroll
@@ -1022,7 +1026,7 @@ struct StepCore {
     }
     if (lane == 0) SI(imisc)[IM_ENV] = env;
     if (have_stash) {      // the derived arrays come from the stash; only this launch's warning counters start at zero
-      if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
+      if (LPE >= 16) { if (lane < DMC_NWARNING) SI(imisc)[IM_WARN + lane] = 0; } else if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) SI(imisc)[IM_WARN + k] = 0;
       DMC_WSYNC();
       return;
     }
@@ -1044,16 +1048,16 @@ struct StepCore {
   DMC_DEV void store_state(const StepIO<T>& io, int env) {
     env = late(env);
     const int B = io.B;
-    FOR_LANES(i, L.d.nq) io.qpos[(size_t)i*B + env] = S(qpos)[i];
+    FOR_LANES(i, L.d.nq) G(io.qpos)[(size_t)i*B + env] = S(qpos)[i];
     FOR_LANES(i, L.d.nv) {
-      io.qvel[(size_t)i*B + env] = S(qvel)[i];
-      io.qacc_warmstart[(size_t)i*B + env] = S(qacc_warmstart)[i];
+      G(io.qvel)[(size_t)i*B + env] = S(qvel)[i];
+      G(io.qacc_warmstart)[(size_t)i*B + env] = S(qacc_warmstart)[i];
     }
-    if (L.d.na) FOR_LANES(i, L.d.na) io.act[(size_t)i*B + env] = S(act)[i];
-    if (lane == 0) {
-      io.time[env] = time_;
-      for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) io.warning[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
-    }
+    if (L.d.na) FOR_LANES(i, L.d.na) G(io.act)[(size_t)i*B + env] = S(act)[i];
+    if (lane == 0) G(io.time)[env] = time_;
+    // (one lane per warning counter: lane 0 walking the nine of them was nine dependent LDS round trips at the end of every wave)
+    if (LPE >= 16) { if (lane < DMC_NWARNING) { const int w = SI(imisc)[IM_WARN + lane]; if (w) G(io.warning)[(size_t)lane*B + env] += w; } }
+    else if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) G(io.warning)[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
     // ctrl may have been zeroed by a BADCTRL warning (mj_fwdActuation semantics)
     if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) io.ctrl[(size_t)i*B + env] = S(ctrl)[i];
   }
@@ -1061,12 +1065,12 @@ struct StepCore {
     env = late(env);
     const int B = io.B;
     const int nb = L.d.nbody;
-    if (mask & OUT_SENSOR) FOR_LANES(i, L.d.nsensordata) io.sensordata[(size_t)i*B + env] = S(sensordata)[i];
-    if (mask & OUT_XPOS) FOR_LANES(i, 3*nb) io.xpos[(size_t)i*B + env] = S(xpos)[i];
-    if (mask & OUT_XQUAT) FOR_LANES(i, 4*nb) io.xquat[(size_t)i*B + env] = SG(xquat)[i];
-    if (mask & OUT_XMAT) FOR_LANES(i, 9*nb) io.xmat[(size_t)i*B + env] = S(xmat)[i];
+    if (mask & OUT_SENSOR) FOR_LANES(i, L.d.nsensordata) G(io.sensordata)[(size_t)i*B + env] = S(sensordata)[i];
+    if (mask & OUT_XPOS) FOR_LANES(i, 3*nb) G(io.xpos)[(size_t)i*B + env] = S(xpos)[i];
+    if (mask & OUT_XQUAT) FOR_LANES(i, 4*nb) G(io.xquat)[(size_t)i*B + env] = SG(xquat)[i];
+    if (mask & OUT_XMAT) FOR_LANES(i, 9*nb) G(io.xmat)[(size_t)i*B + env] = S(xmat)[i];
     if (mask & OUT_XIPOS) FOR_LANES(i, 3*nb) io.xipos[(size_t)i*B + env] = S(xipos)[i];
-    if (mask & OUT_SUBTREE_COM) FOR_LANES(i, 3*nb) io.subtree_com[(size_t)i*B + env] = S(subtree_com)[i];
+    if (mask & OUT_SUBTREE_COM) FOR_LANES(i, 3*nb) G(io.subtree_com)[(size_t)i*B + env] = S(subtree_com)[i];
     if (mask & OUT_GEOM) {
       FOR_LANES(i, 3*L.d.ngeom) io.geom_xpos[(size_t)i*B + env] = S(geom_xpos)[i];
       FOR_LANES(i, 9*L.d.ngeom) io.geom_xmat[(size_t)i*B + env] = SG(geom_xmat)[i];
@@ -1087,7 +1091,7 @@ struct StepCore {
     }
     if (mask & OUT_ACTUATOR) FOR_LANES(i, L.d.nu) io.actuator_force[(size_t)i*B + env] = S(actuator_force)[i];
     if (lane == 0) {
-      io.ncon[env] = SI(imisc)[IM_NCON]; io.nefc[env] = SI(imisc)[IM_NEFC]; io.solver_iter[env] = SI(imisc)[IM_ITER];
+      G(io.ncon)[env] = SI(imisc)[IM_NCON]; G(io.nefc)[env] = SI(imisc)[IM_NEFC]; G(io.solver_iter)[env] = SI(imisc)[IM_ITER];
     }
     if ((mask & OUT_CONTACT_IDS) && !(mask & OUT_CONTACT)) {
       const int nc = SI(imisc)[IM_NCON];
