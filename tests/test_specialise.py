@@ -48,6 +48,33 @@ def test_key_depends_on_model_caps_precision_and_sources(tmp_path, monkeypatch):
   assert specialise.mode() == 'cached'
   monkeypatch.setenv('DMC_SPECIALISE', '1')
   assert specialise.mode() == 'build'
+  # round 5: the layout level of a small batch (caps[3] = jglobal + 1) and tuning flags are part of the key
+  assert k != specialise.key(m, 32, 32, (0, 0, 0, 1))
+  monkeypatch.setenv('DMC_SPEC_FLAGS', '-DDMC_NO_ROW_NEWBCAST')
+  assert k != specialise.key(m, 32, 32, (0, 0, 0))
+  monkeypatch.delenv('DMC_SPEC_FLAGS')
+  assert k == specialise.key(m, 32, 32, (0, 0, 0))
+
+
+def test_layout_level_override_changes_only_where_the_contact_rows_live():
+  """gen_static_layouts with jlevel + 1 = 1 (caps[3]): a 17 .. 32-dof model keeps the compressed contact rows in LDS (no
+  per-env global scratch) -- the layout dmc_batch_create gives a batch of at most one environment per CU; the level of a
+  model that is at level 0 anyway (nv <= 16) cannot be raised by the override."""
+  import subprocess, tempfile
+  from dm_control_amd import build
+  from dm_control_amd.suite import common
+  build.generate_static_layouts()
+  tool = os.path.join(build.CSRC, 'gen_static_layouts')
+  def layout(name, *caps):
+    m = mc.compile_xml(common.read_model(name + '.xml'))
+    ints, reals = m.pack()
+    with tempfile.TemporaryDirectory() as td:
+      fi, fr = os.path.join(td, 'i.bin'), os.path.join(td, 'r.bin')
+      ints.tofile(fi); reals.tofile(fr)
+      return subprocess.check_output([tool, name, fi, fr] + [str(c) for c in caps]).decode().strip()
+  assert layout('soccer_2v2_boxhead', 24, 0, 0, 1) != layout('soccer_2v2_boxhead', 24, 0, 0, 0) == layout('soccer_2v2_boxhead', 24, 0)
+  assert layout('soccer_2v2_boxhead', 24, 0, 0, 2) == layout('soccer_2v2_boxhead', 24, 0)      # level 1 is its default
+  assert layout('cheetah', 0, 0, 0, 2) == layout('cheetah', 0, 0)      # (an override never moves MORE out of LDS)
 
 
 def test_plugin_cross_compiles_for_an_unseen_model(tmp_path, monkeypatch):
