@@ -373,17 +373,14 @@ template <int CTRL> DMC_DEV double dpp_all(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// (every lane of a row_newbcast has a source lane: bound_ctrl spares the move that would initialise the "old" value)
 template <typename V> DMC_DEV V row_bcast16(V v, int k) {
-#ifndef DMC_NO_DPP_BOUND      // (every lane of a row_newbcast has a source: bound_ctrl spares the move that initialises "old")
-#define dpp_f dpp_all
-#endif
   switch (k & 15) {
-    case 0: return dpp_f<0x150>(v); case 1: return dpp_f<0x151>(v); case 2: return dpp_f<0x152>(v); case 3: return dpp_f<0x153>(v);
-    case 4: return dpp_f<0x154>(v); case 5: return dpp_f<0x155>(v); case 6: return dpp_f<0x156>(v); case 7: return dpp_f<0x157>(v);
-    case 8: return dpp_f<0x158>(v); case 9: return dpp_f<0x159>(v); case 10: return dpp_f<0x15A>(v); case 11: return dpp_f<0x15B>(v);
-    case 12: return dpp_f<0x15C>(v); case 13: return dpp_f<0x15D>(v); case 14: return dpp_f<0x15E>(v); default: return dpp_f<0x15F>(v);
+    case 0: return dpp_all<0x150>(v); case 1: return dpp_all<0x151>(v); case 2: return dpp_all<0x152>(v); case 3: return dpp_all<0x153>(v);
+    case 4: return dpp_all<0x154>(v); case 5: return dpp_all<0x155>(v); case 6: return dpp_all<0x156>(v); case 7: return dpp_all<0x157>(v);
+    case 8: return dpp_all<0x158>(v); case 9: return dpp_all<0x159>(v); case 10: return dpp_all<0x15A>(v); case 11: return dpp_all<0x15B>(v);
+    case 12: return dpp_all<0x15C>(v); case 13: return dpp_all<0x15D>(v); case 14: return dpp_all<0x15E>(v); default: return dpp_all<0x15F>(v);
   }
-#undef dpp_f
 }
 #endif
 // broadcast of matrix row k's value among the N <= LPE row-holding lanes of a group
@@ -3380,92 +3377,6 @@ struct StepCore {
   // middle zone it also leaves the rank structure of the block Hessian
   //   Hc = Dm [ p p' + c (diag(g) - w w') ]   (p, w: combinations of the block's rows)
   // in efc_ca / efc_cb / efc_cg for newton_gradient.
-#ifdef DMC_CUELL_V1
-  DMC_DEV T constraint_update_ell(int nefc, int* track) {
-    T cost = 0;
-    int changed = 0;
-    for (int i = lane; i < nefc; i += LPE) {
-      const int tid = SI(efc_tid)[i];
-      if (EFC_TYPE(tid) == EFC_EQUALITY) {   // two-sided: always quadratic
-        const T jar = S(efc_jar)[i], D = S(efc_D)[i];
-        S(efc_force)[i] = -D*jar; cost += (T)0.5*D*jar*jar;
-        if (track) { if (SI(efc_active)[i] != EFC_ST_QUADRATIC) changed = 1; SI(efc_active)[i] = EFC_ST_QUADRATIC; }
-        continue;
-      }
-      if (EFC_TYPE(tid) == EFC_FRICTION) {
-        // Huber cost: quadratic for |jar| < R*floss, linear (force saturated at +-floss) outside
-        const T jar = S(efc_jar)[i], D = S(efc_D)[i], f = MR(dof_frictionloss)[EFC_ID(tid)], rf = f / D;
-        int st;
-        if (jar <= -rf) { st = EFC_ST_LINEARNEG; S(efc_force)[i] = f; cost += f*((T)-0.5*rf - jar); }
-        else if (jar >= rf) { st = EFC_ST_LINEARPOS; S(efc_force)[i] = -f; cost += f*((T)-0.5*rf + jar); }
-        else { st = EFC_ST_QUADRATIC; S(efc_force)[i] = -D*jar; cost += (T)0.5*D*jar*jar; }
-        if (track) { if (SI(efc_active)[i] != st) changed = 1; SI(efc_active)[i] = st; }
-        continue;
-      }
-      if (EFC_TYPE(tid) != EFC_ELLIPTIC) {
-        const T jar = S(efc_jar)[i];
-        const int act = jar < 0;
-        if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
-        else S(efc_force)[i] = 0;
-        if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
-        continue;
-      }
-      const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
-      if (i != r0) continue;
-      const int dim = con_dim(c);
-      const T* fr = MR(prm_friction) + 3*con_prm(c);
-      const T D0 = S(efc_D)[r0];
-      const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);   // regularised cone: mu sqrt(R1/R0)
-      T U[6], fj[6], Tn = 0;
-      U[0] = S(efc_jar)[r0]*mu; fj[0] = mu;
-      for (int j = 1; j < dim; j++) {
-        fj[j] = fr[j < 3 ? 0 : (j == 3 ? 1 : 2)];
-        U[j] = S(efc_jar)[r0 + j]*fj[j]; Tn += U[j]*U[j];
-      }
-      Tn = t_sqrt(Tn);
-      const T N = U[0];
-      int st;
-      if (N >= mu*Tn || (Tn <= 0 && N >= 0)) {
-        st = EFC_ST_SATISFIED;
-        for (int j = 0; j < dim; j++) S(efc_force)[r0 + j] = 0;
-      } else if (mu*N + Tn <= 0 || (Tn <= 0 && N < 0)) {
-        st = EFC_ST_QUADRATIC;
-        for (int j = 0; j < dim; j++) {
-          const T jar = S(efc_jar)[r0 + j], D = S(efc_D)[r0 + j];
-          S(efc_force)[r0 + j] = -D*jar; cost += (T)0.5*D*jar*jar;
-        }
-      } else {
-        st = EFC_ST_CONE;
-        const T Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu)), NT = N - mu*Tn;
-        cost += (T)0.5*Dm*NT*NT;
-        const T f0 = -Dm*NT*mu;
-        S(efc_force)[r0] = f0;
-        const T cc = -NT*mu/Tn;   // > 0
-        S(efc_ca)[r0] = mu; S(efc_cb)[r0] = Dm*cc; S(efc_cg)[r0] = Dm;
-        for (int j = 1; j < dim; j++) {
-          const T uh = U[j]/Tn;
-          S(efc_force)[r0 + j] = -f0/Tn * U[j]*fj[j];
-          S(efc_ca)[r0 + j] = -mu*uh*fj[j]; S(efc_cb)[r0 + j] = uh*fj[j]; S(efc_cg)[r0 + j] = Dm*cc*fj[j]*fj[j];
-        }
-      }
-      if (track) {
-        // a cone-zone Hessian depends on the residual itself, not just on the zone
-        if (SI(efc_active)[r0] != st || st == EFC_ST_CONE) changed = 1;
-        for (int j = 0; j < dim; j++) SI(efc_active)[r0 + j] = st;
-      }
-    }
-    cost = group_sum<LPE>(cost);
-    if (track) *track = group_max<LPE>(changed);
-    DMC_WSYNC();
-    return cost;
-  }
-  // H = M + J' D_active J (+ the cone blocks of elliptic contacts) into qLH, packed by columns.  Assembled by
-  // storage class: M scattered from its (i, j) list with the one-nonzero friction / limit rows already on the
-  // diagonal; dense equality / tendon-limit rows entry by entry; then ONE CONTACT AT A TIME: a contact's rows
-  // only touch the kc x kc block of its own dofs, so its lanes run over the kc (kc + 1) / 2 dof pairs of that
-  // block (no two lanes on the same entry; a wave fence between contacts).  efc_active holds the state
-  // constraint_update recorded.
-#else
   // Round 5: every load sits at the top of the trip without a predicate (clamped indices), the row types are told apart on
   // registers, and the block of a frictional contact is six statically indexed rows under a `j < dim` guard -- the
   // run-time trip counts had put U[] / fj[] in scratch memory and every row's (jar, D) behind its own LDS round trip
@@ -3566,7 +3477,6 @@ struct StepCore {
     DMC_WSYNC();
     return cost;
   }
-#endif
   DMC_DEV void hess_assemble(int nefc, const RowMap& rm) {
     const int nv = L.d.nv, K = L.d.kmax;
     if (L.d.jfull && !L.d.msparse) {
@@ -4127,27 +4037,6 @@ struct StepCore {
     const bool own = lane < N;
     const int i = own ? lane : 0;
     T a[N];
-#ifdef DMC_HESS_ROWS_V1
-#pragma unroll
-    for (int j = 0; j < N; j++) a[j] = (own && j <= lane) ? S(qM)[i*N + j] : (T)0;
-    for (int r = 0; r < nefc; r += 4) {
-      int st[4]; T c[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int rr = r + u < nefc ? r + u : r;
-        st[u] = r + u < nefc ? SI(efc_active)[rr] : 0;
-        const T ji = S(efc_Jd)[rr*N + i];
-        c[u] = (st[u] == EFC_ST_QUADRATIC && ji != 0 && own) ? S(efc_D)[rr]*ji : (T)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (st[u] != EFC_ST_QUADRATIC) continue;      // group-uniform
-        const int rr = r + u;
-#pragma unroll
-        for (int j = 0; j < N; j++) { const T jj = S(efc_Jd)[rr*N + j]; if (c[u] != 0 && j <= lane) a[j] += c[u] * jj; }
-      }
-    }
-#else
     // Branch-free (round 5): every lane builds its WHOLE row (M is stored symmetric; the entries right of the diagonal are
     // never read by the elimination's valid lanes), the row's loads carry no predicate -- a lane outside the matrix reads
     // row 0, a trip's padding rows re-read the trip's first row with a zero weight -- and a row that is not in the
@@ -4178,7 +4067,6 @@ struct StepCore {
         }
       }
     }
-#endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
       T akk = bcast_rows<LPE, N>(a[k], k);
@@ -4278,45 +4166,6 @@ struct StepCore {
   // type -> contact -> first row -> nine aggregates) per row before the arithmetic started: 22 % / 14 % of their step.
   enum { LSK_NONE = 0, LSK_EQUALITY, LSK_FRICTION, LSK_ONESIDED, LSK_CONE };
   struct LSRows { T jar, jv, D; bool on; bool gen; int kind; T f, rf, U0, V0, UU, UV, VV, mu, b0, b1, b2, Dm, NT0, T0; bool bottom0, middle0; };
-#ifdef DMC_LSLOAD_V1
-  DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
-    g.gen = true; g.kind = LSK_NONE;
-    g.f = g.rf = g.U0 = g.V0 = g.UU = g.UV = g.VV = g.mu = g.b0 = g.b1 = g.b2 = g.Dm = g.NT0 = g.T0 = 0; g.bottom0 = g.middle0 = false;
-    const int i = lane;
-    if (i >= nefc) return;
-    const int tid = SI(efc_tid)[i], ty = EFC_TYPE(tid);
-    g.jar = S(efc_jar)[i]; g.jv = S(efc_jv)[i]; g.D = S(efc_D)[i];
-    if (ty == EFC_EQUALITY) { g.kind = LSK_EQUALITY; return; }
-    if (ty == EFC_FRICTION) { g.kind = LSK_FRICTION; g.f = MR(dof_frictionloss)[EFC_ID(tid)]; g.rf = g.f / g.D; return; }
-    if (ty != EFC_ELLIPTIC) { g.kind = LSK_ONESIDED; return; }
-    const int c = EFC_ID(tid), r0 = SI(con_efc)[c];
-    if (i != r0) return;
-    g.kind = LSK_CONE;
-    const int dim = con_dim(c);
-    const T* fr = MR(prm_friction) + 3*con_prm(c);
-    const T D0 = g.D;
-    const T mu = fr[0] * t_sqrt(D0 / S(efc_D)[r0 + 1]);
-    T UU = 0, UV = 0, VV = 0, b0 = 0, b1 = 0, b2 = 0;
-    for (int j = 0; j < dim; j++) {
-      const T jar = S(efc_jar)[r0 + j], jv = S(efc_jv)[r0 + j], D = S(efc_D)[r0 + j], dj0 = D*jar;
-      b0 += (T)0.5*jar*dj0; b1 += jv*dj0; b2 += (T)0.5*D*jv*jv;
-      if (j) {
-        const T f = fr[j < 3 ? 0 : (j == 3 ? 1 : 2)];
-        const T u = jar*f, v = jv*f;
-        UU += u*u; UV += u*v; VV += v*v;
-      }
-    }
-    g.U0 = g.jar*mu; g.V0 = g.jv*mu; g.UU = UU; g.UV = UV; g.VV = VV; g.mu = mu; g.b0 = b0; g.b1 = b1; g.b2 = b2;
-    g.Dm = D0 / t_max((T)DMC_MINVAL, mu*mu*(1 + mu*mu));
-    if (UU <= 0) g.bottom0 = g.U0 < 0;      // the contact's zone at alpha = 0 (relative form)
-    else {
-      const T T0 = t_sqrt(UU);
-      if (g.U0 >= mu*T0) {}
-      else if (mu*g.U0 + T0 <= 0) g.bottom0 = true;
-      else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; g.T0 = T0; }      // (T0: the anchored form's reference point)
-    }
-  }
-#else
   // (round 5: loads first and unpredicated, the contact block as six statically indexed rows -- see constraint_update_ell)
   DMC_DEV void ls_load_gen(LSRows& g, int nefc) {
     g.gen = true; g.kind = LSK_NONE;
@@ -4372,7 +4221,6 @@ struct StepCore {
       else { g.middle0 = true; g.NT0 = g.U0 - mu*T0; g.T0 = T0; }      // (T0: the anchored form's reference point)
     }
   }
-#endif
   // ls_eval_ell's arithmetic for the lane's one row
   DMC_DEV void ls_eval_gen(LSPoint* p, const T* qg, const LSRows& g) {
     const T a = p->alpha;
