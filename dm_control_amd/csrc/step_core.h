@@ -2285,7 +2285,11 @@ struct StepCore {
 #else
       // (the slots past the contact's dof count are read like the others -- they exist, their dof byte addresses some word of
       // the scratch -- and their product is dropped: no exec-mask sequence per slot)
+#ifdef DMC_HOST_EMU
+      for (int k = 0; k < L.d.kmax; k++) { const T j_ = jr[k], x_ = x[k < kc ? dofs[k] : 0], t_ = acc + j_ * x_; acc = k < kc ? t_ : acc; }      // (the host build stays inside x)
+#else
       for (int k = 0; k < L.d.kmax; k++) { const T j_ = jr[k], x_ = x[dofs[k]], t_ = acc + j_ * x_; acc = k < kc ? t_ : acc; }
+#endif
 #endif
       return acc;
     }

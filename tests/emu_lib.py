@@ -23,9 +23,18 @@ def lib():
   if _lib is None:
     csrc = os.path.join(os.path.dirname(_HERE), 'dm_control_amd', 'csrc')
     deps = [_SRC] + [os.path.join(csrc, f) for f in ('step_core.h', 'step_layout.h', 'step_tables.h')]
-    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in deps):
-      subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-unknown-pragmas',
-                             '-o', _LIB, _SRC])
+    stale = lambda: not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(d) for d in deps)
+    if stale():
+      # (pytest-xdist workers may all find it stale at once: one builds under a lock, into a temporary that is moved in
+      # place atomically -- a worker never loads a half-written object)
+      import fcntl
+      with open(_LIB + '.lock', 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if stale():
+          tmp = _LIB + '.%d.tmp' % os.getpid()
+          subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-Wno-unknown-pragmas',
+                                 '-o', tmp, _SRC])
+          os.replace(tmp, _LIB)
     L = ctypes.CDLL(_LIB)
     L.emu_last_error.restype = ctypes.c_char_p
     L.emu_create.restype = ctypes.c_void_p
