@@ -648,7 +648,9 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherPtrs ptrs, const Gath
   __shared__ T tile[64][65];
   const int tx = threadIdx.x, ty = threadIdx.y;      // (64, 4)
   const int env0 = blockIdx.x * 64;
-  for (int k0 = 0; k0 < nrows; k0 += 64) {
+  // one 64 x 64 tile per workgroup: blockIdx.y walks the observation rows (a small batch -- soccer, B = 256: four
+  // workgroups -- used to walk all its row tiles inside each of them: 61 us per control step)
+  for (int k0 = blockIdx.y * 64; k0 < nrows; k0 += 64 * gridDim.y) {
     for (int kk = ty; kk < 64; kk += 4) {
       const int k = k0 + kk, env = env0 + tx;
       T v = 0;
@@ -708,7 +710,10 @@ extern "C" int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream) {
   for (int q = 0; q < 16; q++) ptrs.p[q] = nullptr;
   for (size_t q = 0; q < g->field_names.size(); q++) ptrs.p[q] = find_field(b, g->field_names[q].c_str())->dev;   // honours rebinding
   HIP_TRY(hipSetDevice(b->device));
-  const dim3 grid((b->B + 63) / 64), block(64, 4);
+  // (row tiles across blockIdx.y while the batch alone does not fill the chip: at least ~2 workgroups per CU in flight)
+  const int gx = (b->B + 63) / 64, ktiles = (g->nrows + 63) / 64;
+  const int gy = std::max(1, std::min(ktiles, (2 * b->ncu + gx - 1) / gx));
+  const dim3 grid(gx, gy), block(64, 4);
   if (b->precision == 64) hipLaunchKernelGGL(gather_kernel<double>, grid, block, 0, (hipStream_t)hip_stream, ptrs, g->d_rows, g->nrows, b->B, (double*)out);
   else hipLaunchKernelGGL(gather_kernel<float>, grid, block, 0, (hipStream_t)hip_stream, ptrs, g->d_rows, g->nrows, b->B, (float*)out);
   HIP_TRY(hipGetLastError());

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$(pwd); cd /tmp
-for m in eager graph; do
+for m in ${MODES:-eager graph}; do
   MODE=$m timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ctrace_$m -o ct --output-format csv -- python $R/scripts/composer_trace.py 2>&1 | grep "ms per"
   python - <<PY
 import csv,glob,collections
