@@ -92,6 +92,10 @@ def parse(argv=None):
   ap.add_argument('--cpu-envs', type=int, default=4096)
   ap.add_argument('--cpu-seconds', type=float, default=10.0)
   ap.add_argument('--pmc-child', action='store_true', help='internal: only the timed launches (run under rocprofv3 by the parent)')
+  ap.add_argument('--extra', type=int, default=None,
+                  help='short legs of the other BASELINE configs (3, 4, 5) and of Environment.step on config 2 under "extra" '
+                       '(default: on for the default invocation -- config 2 on one GPU -- off otherwise)')
+  ap.add_argument('--extra-steps', type=int, default=12, help='timed launches of each extra config leg (>= 10)')
   return ap.parse_args(argv)
 
 
@@ -329,7 +333,7 @@ def rel_err(qg, qo):
   return np.abs(qg - qo).max(axis=1) / np.maximum(1.0, np.abs(qo).max(axis=1))
 
 
-def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads):
+def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads, only=None):
   """GPU vs the fp64 oracle on the first envs, same states and actions: open loop (both integrate on their own)
   and teacher-forced (the GPU state is overwritten by the oracle's before every env-step)."""
   from dm_control_amd.batch import BatchedPhysics
@@ -347,6 +351,8 @@ def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads):
     # forced before every PHYSICS step: the arithmetic error of one mj_step.  Between the forcings of 'teacher-forced' lie
     # n_sub_steps physics steps, over which a contact that fp32 and fp64 activate one step apart already changes the outcome
     modes.insert(2, ('teacher-forced-physics-step', args.precision))
+  if only:
+    modes = [m for m in modes if m[0] in only]
   for mode, prec in modes:
     chk, err = None, None
     # the fp64 scratch of the 62-dof models fits in LDS up to 32 .. 40 contacts: the parity leg lowers the cap if needed
@@ -406,6 +412,108 @@ def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads):
     res[mode]['oracle_warnings'] = [int(x) for x in np.sum([p.warning for p in refs], axis=0)]
     chk.close()
   return res
+
+
+def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=16, parity_steps=4):
+  """A short leg of another BASELINE config for the default line's `extra`: the same workload, start states, actions and
+  launch as `bench.py --config <cfgid>` (one Physics.step(n_sub_steps) launch per env-step, actions resident in HBM), W
+  untimed + K timed launches bracketed by HIP events on the launch stream, the nominal HBM roofline of the kernel, and the
+  fp32 error of ONE env-step from the oracle's state (teacher-forced, `parity_envs` environments x `parity_steps` steps)."""
+  import torch
+  from dm_control_amd.batch import BatchedPhysics, OUT
+  from dm_control_amd.suite import common
+  cfg = CONFIGS[cfgid]
+  model = load_model(cfg['asset'])
+  nsub, B = cfg['nsub'], cfg['batch']
+  dev = torch.device('cuda', local_rank)
+  caps = dict(common.DEFAULT_CAPS.get(cfg['asset'], {}))
+  caps.pop('precision', None)
+  t_leg = time.perf_counter()
+  phys = BatchedPhysics(model, B, device_id=local_rank, precision=32, **caps)
+  phys.set('qpos', initial_qpos(cfg, model, B, seed0=0, phys=phys))
+  stream = torch.cuda.current_stream().cuda_stream
+  rs = np.random.RandomState(1234)
+  acts = torch.from_numpy(np.ascontiguousarray(rs.uniform(-1, 1, (W + K, B, model.nu)).astype(np.float32).transpose(0, 2, 1))).to(dev).contiguous()
+  mask = 0
+  for name in cfg['outputs']:
+    mask |= OUT[name]
+  phys.set_output_mask(mask)
+  phys.forward()
+  for t in range(W):
+    phys.bind('ctrl', acts[t].data_ptr()); phys.step(nsub, stream=stream)
+  torch.cuda.synchronize()
+  q0, v0, w0 = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for t in range(W, W + K):
+    phys.bind('ctrl', acts[t].data_ptr()); phys.step(nsub, stream=stream)
+  ev1.record()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  kernel_ms = ev0.elapsed_time(ev1) / K
+  warn = [int(x) for x in phys.get('warning').sum(axis=0)]
+  info = phys.info()
+  phys.close()
+  achieved = cfg['algo_bytes'] * B / (kernel_ms * 1e-3) / 1e9
+  out = dict(workload='BASELINE config %d: %s, batch %d, random actions, legacy Physics.step(%d), one launch per env-step'
+                      % (cfgid, cfg['workload'], B, nsub),
+             value=B * K / elapsed, unit='env-steps/s', physics_steps_per_s=B * K * nsub / elapsed, steps=K, warmup=W,
+             ms_per_step=1e3 * elapsed / K, kernel_ms_avg=kernel_ms, dtype='f32', warnings_after_run=warn,
+             roofline={'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                       'algorithmic_bytes_per_launch': cfg['algo_bytes'] * B, 'traffic': None,
+                       'note': 'nominal bound; counters: bench.py --config %d' % cfgid},
+             launch={k: info[k] for k in ('lanes_per_env', 'waves_per_block', 'envs_per_cu', 'static_id', 'work_queue')})
+  try:
+    ne = min(parity_envs, B)
+    pa = np.random.RandomState(77).uniform(-1, 1, (parity_steps, ne, model.nu)).astype(np.float32)
+    pargs = argparse.Namespace(precision=32, lanes=0)
+    res = parity(model, cfg, pargs, local_rank, q0[:ne], v0[:ne], w0[:ne], pa, nthreads, only=('teacher-forced',))
+    tf = res['teacher-forced']
+    out['one_step_parity'] = dict(max=tf['per_step']['max'], median=tf['per_step']['median'], envs=ne, steps=parity_steps,
+                                  just_touching=tf['just_touching']['steps'],
+                                  note='fp32 kernel, one env-step (%d physics steps) from the fp64 oracle\'s state; rel. qpos error' % nsub)
+  except Exception as ex:  # pylint: disable=broad-except
+    out['one_step_parity'] = dict(error=repr(ex)[:300])
+  out['leg_seconds'] = time.perf_counter() - t_leg
+  return out
+
+
+def env_step_leg(local_rank, B=4096, K=1000, W=20):
+  """Row a1 (control.Environment.step, rl/control.py:99-127) on config 2's workload: the device-resident cheetah run
+  environment (suite/torch_env.py) -- action write, the physics launch, observation, reward, step counters and the
+  per-environment auto-reset -- in the timed region, next to the physics-only rate of the same batch object.  K = one
+  episode (1000 steps): exactly one restart of every environment (joint randomisation + the 200 settle steps of
+  Cheetah.initialize_episode, suite/cheetah.py:63-76) falls into the timed region, the rate it is amortised at."""
+  import torch
+  from dm_control_amd.suite import torch_env
+  t_leg = time.perf_counter()
+  env = torch_env.make('cheetah', 'run', B, device_id=local_rank)
+  dev = torch.device('cuda', local_rank)
+  acts = torch.rand((W + K, B, env.model.nu), device=dev) * 2 - 1
+  for t in range(W):
+    env.step(acts[t])
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(W, W + K):
+    obs, rew, done = env.step(acts[t])
+  torch.cuda.synchronize()
+  el = time.perf_counter() - t0
+  stream = torch.cuda.current_stream().cuda_stream
+  for t in range(W):
+    env.physics.step(env.n_sub_steps, stream=stream)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(K):
+    env.physics.step(env.n_sub_steps, stream=stream)
+  torch.cuda.synchronize()
+  el_phys = time.perf_counter() - t0
+  out = dict(workload="suite 'cheetah run' as a device-resident environment (torch_env): obs (B, 17) + reward + done + auto-reset per step",
+             value=B * K / el, unit='env-steps/s', steps=K, warmup=W, ms_per_step=1e3 * el / K, batch=B,
+             physics_only_same_batch=B * K / el_phys, env_over_physics=el_phys / el,
+             finite=bool(torch.isfinite(obs).all().item()), leg_seconds=time.perf_counter() - t_leg)
+  env.close()
+  return out
 
 
 def main():
@@ -720,6 +828,20 @@ def main():
           out['cpu_baseline'] = cpu_baseline(model, nsub, q_end[:nb], v_end[:nb], w_end[:nb], action_fn, nthreads, args.cpu_seconds)
       except Exception as ex:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'value': None, 'error': repr(ex)}
+    do_extra = args.extra if args.extra is not None else int(args.config == 2 and world == 1 and args.batch is None and args.precision == 32)
+    if do_extra:
+      # the other BASELINE configs and row a1 in the driver's line; each leg reports its own seconds
+      extra = {'configs': {}}
+      for c in (3, 4, 5):
+        try:
+          extra['configs'][str(c)] = quick_config_leg(c, args, local_rank, nthreads, K=max(10, args.extra_steps))
+        except Exception as ex:  # pylint: disable=broad-except
+          extra['configs'][str(c)] = {'error': repr(ex)[:300]}
+      try:
+        extra['env_step'] = env_step_leg(local_rank)
+      except Exception as ex:  # pylint: disable=broad-except
+        extra['env_step'] = {'error': repr(ex)[:300]}
+      out['extra'] = extra
     print(json.dumps(out), flush=True)
   phys.close()
   if world > 1:

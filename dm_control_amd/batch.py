@@ -45,11 +45,27 @@ class BatchedPhysics:
     # a model without a baked specialised kernel takes the one built for it on demand, if there is one (specialise.py)
     self._user_caps = (int(nconmax), int(njmax), int(njcon))
     from dm_control_amd import specialise as _spec
+    self._spec_future = None
     self.specialised = _spec.attach(self, specialise)
 
   @classmethod
   def from_xml_string(cls, xml_string, batch_size, assets=None, **kw):
     return cls(mjcf_compiler.compile_xml(xml_string, assets), batch_size, **kw)
+
+  def _poll_specialised(self):
+    # a specialised kernel that was being compiled in the background takes over at the first launch after its build
+    if self._spec_future is not None:
+      from dm_control_amd import specialise as _spec
+      _spec.poll(self)
+
+  def wait_specialised(self, timeout=None):
+    """Blocks until a background build of this model's specialised kernel (specialise.py, the default for models
+    without a baked kernel) has finished and switches the batch over.  Callers that record their launches into a HIP
+    graph call this before capturing: a graph keeps the kernel it was captured with.  Returns `self.specialised`."""
+    if self._spec_future is not None:
+      from dm_control_amd import specialise as _spec
+      _spec.poll(self, block=True, timeout=timeout)
+    return self.specialised
 
   def close(self):
     L = _native.lib()
@@ -229,6 +245,7 @@ class BatchedPhysics:
   def step(self, nstep=1, stream=None, forward_after=False):
     """Physics.step(nstep) for every environment in one launch.  `forward_after` (legacy steps): the launch ends with
     the rest of mj_forward at the new state -- dmc_batch_step's legacy_step 2."""
+    self._poll_specialised()
     legacy = int(self.legacy_step)
     if forward_after:
       if not legacy:
@@ -245,6 +262,7 @@ class BatchedPhysics:
               stream=None):
     """`nsteps` env-steps in ONE launch; *_seq are device pointers to (nsteps, rows, B)
     arrays in batch precision (None: skip)."""
+    self._poll_specialised()
     _native.check(_native.lib().dmc_batch_rollout(self._ptr, int(nsteps), int(n_sub_steps), ctrl_seq, qpos_seq,
                                                   qvel_seq, sensordata_seq, stream))
 
@@ -257,6 +275,7 @@ class BatchedPhysics:
     _native.check(_native.lib().dmc_batch_step2(self._ptr, stream))
 
   def forward(self, disable_actuation=False, stream=None):
+    self._poll_specialised()
     _native.check(_native.lib().dmc_batch_forward(self._ptr, int(disable_actuation), stream))
 
   def reset(self, env_mask=None, keyframe_id=None):

@@ -72,6 +72,8 @@ struct dmc_batch {
   int ncu;             // compute units of the device
   void* d_kstash; int* d_kstash_i;      // kinematic stash (StepIO::kstash), on unless DMC_NO_KSTASH
   int *d_cost, *d_order; int lpt, nitems;      // longest-first scheduling of queued launches (StepIO::cost / order)
+  int* d_prog = nullptr; int max_slices = 0;   // sliced items of queued multi-step launches (StepIO::prog / slices)
+  unsigned long long* d_hand = nullptr; int hand_n = 0; int nxcd = 1;      // hand-off records of the pieces; queues per launch (one per XCD)
   void* d_gscr;        // large models: (B, n_gs) reals of per-env global scratch (StepOpts::gscr)
   int* d_trace;        // wave trace (dmc_batch_wave_trace): ring of 8 launches x (8, nitems) ints, or null
   struct Profiler* prof = nullptr;      // launch timers (dmc_batch_enable_profiling), or null
@@ -206,14 +208,17 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
   if (small_auto) {
     // ... unless only the default layout has a baked model-specialised kernel (the generic one is 2 - 3 x slower: that
     // would be a bad trade for a global round trip per row)
-    if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
-    if (b->geom.static_id < 0) {
+    // ... and unless the level-0 layout does not fit 160 KiB of LDS at all (a large caller-chosen nconmax / njmax): the
+    // default level, which keeps those rows out of LDS, is what such a batch was built with before this choice existed
+    const bool fits = choose_geometry(b, lanes_per_env) == 0;
+    if (!fits || b->geom.static_id < 0) {
       StepTables def;
       if (step_tables_build(&def, m->hm, nconmax, njmax, &err, njcon, -1)) {
         StepTables keep = b->tb; LaunchGeom kg = b->geom;
         b->tb = def;
-        if (choose_geometry(b, lanes_per_env) || b->geom.static_id < 0) { b->tb = keep; b->geom = kg; }
-      }
+        const bool def_fits = choose_geometry(b, lanes_per_env) == 0;
+        if (fits && (!def_fits || b->geom.static_id < 0)) { b->tb = keep; b->geom = kg; }
+      } else if (!fits) { delete b; return fail(err); }
     }
   }
   if (choose_geometry(b, lanes_per_env)) { delete b; return -1; }
@@ -236,8 +241,9 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
     e = hipMalloc((void**)&b->d_epoch, sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(b->d_epoch, &one, sizeof(int), hipMemcpyHostToDevice);
     if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc stash epoch: ") + hipGetErrorString(e), -2); } }
-  e = hipMalloc((void**)&b->d_work, 2 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(b->d_work, 0, 2 * sizeof(int));
+  // work[1]: finished waves; work[32 (1 + x)]: head of XCD x's queue (a 128-byte line each)
+  e = hipMalloc((void**)&b->d_work, 32 * 9 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(b->d_work, 0, 32 * 9 * sizeof(int));
   if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc work queue: ") + hipGetErrorString(e), -2); }
   // (a mocap pose is an input of mj_kinematics that the stash's (qpos, qvel) comparison does not see: no stash for those models)
   if (!getenv("DMC_NO_KSTASH") && !d.nmocap) {
@@ -246,6 +252,25 @@ extern "C" int dmc_batch_create_caps(const dmc_model* m, int batch_size, int dev
     if (e == hipSuccess) e = hipMalloc((void**)&b->d_kstash_i, (size_t)b->B * sizeof(int));
     if (e == hipSuccess) e = hipMemset(b->d_kstash_i, 0, (size_t)b->B * sizeof(int));      // epoch 0: never valid
     if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc kinematic stash: ") + hipGetErrorString(e), -2); }
+  }
+  if (b->geom.queue) {
+    // queued step launches of several physics steps hand an item out in pieces (StepIO::slices; DMC_SLICES=<n>: at most n
+    // pieces, 1 = whole items)
+    const int nit = (b->B * b->geom.lpe + 63) / 64;
+    // One queue per XCD, served by the waves that run on it (step_kernel_body): what an environment leaves in global
+    // memory between its pieces then stays behind ONE L2.  An MI355X in SPX mode is 8 XCDs x 32 CUs; a device of at most
+    // one XCD's worth of CUs (CPX partitions) has one L2 and one queue; anything else keeps whole items in one queue
+    // per launch (DMC_XCDS overrides the count).
+    b->nxcd = getenv("DMC_XCDS") ? std::max(1, std::min(8, atoi(getenv("DMC_XCDS")))) : (b->ncu == 256 ? 8 : 1);
+    if (b->geom.grid < 8 * b->nxcd) b->nxcd = 1;      // (every queue needs waves of its own XCD: the dispatcher deals workgroups round)
+    const bool one_l2_per_queue = b->nxcd > 1 || b->ncu <= 40 || getenv("DMC_XCDS");
+    b->max_slices = getenv("DMC_SLICES") ? atoi(getenv("DMC_SLICES")) : (one_l2_per_queue ? 8 : 1);
+    auto hw = [&](int n) { return b->precision == 64 ? n : (n + 1) / 2; };
+    b->hand_n = hw(d.nq) + 2 * hw(d.nv) + hw(d.na) + 1;
+    e = hipMalloc((void**)&b->d_prog, (size_t)nit * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(b->d_prog, 0, (size_t)nit * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->d_hand, (size_t)b->B * b->hand_n * sizeof(unsigned long long));
+    if (e != hipSuccess) { dmc_batch_destroy(b); return fail(std::string("hipMalloc piece counters: ") + hipGetErrorString(e), -2); }
   }
   if (b->geom.queue && !getenv("DMC_NO_LPT")) {
     b->nitems = (b->B * b->geom.lpe + 63) / 64;
@@ -321,6 +346,8 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_kstash_i) (void)hipFree(b->d_kstash_i);
   if (b->d_cost) (void)hipFree(b->d_cost);
   if (b->d_order) (void)hipFree(b->d_order);
+  if (b->d_prog) (void)hipFree(b->d_prog);
+  if (b->d_hand) (void)hipFree(b->d_hand);
   if (b->d_trace) (void)hipFree(b->d_trace);
   if (b->d_rj_i) (void)hipFree(b->d_rj_i);
   if (b->d_rj_r) (void)hipFree(b->d_rj_r);
@@ -345,6 +372,8 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->env_mode = (const int*)P("env_mode");
   io->work = b->geom.queue ? b->d_work : nullptr;
   io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
+  io->prog = nullptr; io->slices = 0; io->hand = b->d_hand; io->hand_n = b->hand_n;      // (slices: launch_untimed, step launches of a queued batch only)
+  io->nxcd = b->geom.queue ? b->nxcd : 1;
   io->trace = b->d_trace; io->trace_slot = b->d_trace ? b->trace_launch++ : 0;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
@@ -440,12 +469,15 @@ static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* s
   if (b->tb.L.d.nmocap) { b->tb.opts.mocap_pos = find_field(b, "mocap_pos")->dev; b->tb.opts.mocap_quat = find_field(b, "mocap_quat")->dev; b->tb.opts.mocap_B = b->B; }      // follow dmc_batch_bind
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
+  // pieces of a queued Physics.step(nstep) launch (never with the full stash, whose trailing stage belongs to the last step)
+  const int slices = (b->geom.queue && b->d_prog && mode == 0 && !b->stash_on) ? std::min(nstep, b->max_slices) : 1;
   if (b->lpt) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)b->d_cost, b->d_order, b->nitems);
   // a specialisation plugin takes the launch unless it was built lean and the launch needs an optional feature
   const bool need_feat = legacy == 2 || b->d_probe != nullptr || b->tb.opts.integrator == DMC_INT_IMPLICITFAST;
   const bool spec = b->spec_launch && (b->spec_features || !need_feat);
   if (b->precision == 64) {
     StepIO<double> io; fill_io(b, &io);
+    if (slices > 1) { io.prog = b->d_prog; io.slices = slices; }
     io.ctrl_seq = sq ? (const double*)sq->ctrl : nullptr; io.qpos_seq = sq ? (double*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (double*)sq->qvel : nullptr; io.sensor_seq = sq ? (double*)sq->sensor : nullptr;
     if (spec) {
@@ -455,6 +487,7 @@ static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* s
     e = launch_step_f64(b->geom, (hipStream_t)stream, b->d_layout, b->tb.opts, b->d_mi, (const double*)b->d_mr, b->d_mc, io, nstep, legacy, mode, b->outmask, nsub);
   } else {
     StepIO<float> io; fill_io(b, &io);
+    if (slices > 1) { io.prog = b->d_prog; io.slices = slices; }
     io.ctrl_seq = sq ? (const float*)sq->ctrl : nullptr; io.qpos_seq = sq ? (float*)sq->qpos : nullptr;
     io.qvel_seq = sq ? (float*)sq->qvel : nullptr; io.sensor_seq = sq ? (float*)sq->sensor : nullptr;
     if (spec) {

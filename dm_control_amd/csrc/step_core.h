@@ -108,6 +108,19 @@ struct StepIO {
   // launch, written by the step kernel; order[k] = the item handed out k-th, built from it before every launch
   // (order_kernel, dmc_api.hip).  Null: items in index order.
   int* cost; const int* order;
+  // Sliced items (queued step launches of more than one physics step): the item's env-step is handed out as `slices`
+  // pieces of consecutive physics steps, round by round -- piece s of every item before piece s + 1 of any -- so that
+  // the launch ends within one PIECE of the last claim instead of within one whole env-step (a fallen 62-dof walker's
+  // six substeps take 6 ms of an 8 ms launch, and what an item will cost is only half predictable from its last
+  // launch).  Between pieces the state travels through the state arrays (nothing else is carried: every pass rebuilds
+  // its derived arrays); prog[item] = pieces completed, zeroed by the launch's last wave.  slices <= 1 or prog == null:
+  // whole items.  Between two pieces (qpos, qvel, qacc_warmstart, act, time) live in `hand`, an env-major record of
+  // hand_n 8-byte words per env written with write-through (sc1) stores and read with loads that bypass the reading
+  // CU's L1 (StepCore::store_handoff / load_handoff; MI355X_MICROARCH.md, inter-workgroup visibility: 8-byte agent-scope
+  // atomics on both sides need no fence); the SoA state arrays are written by the last piece only.
+  // nxcd: queues of a queued launch, one per XCD (step_kernel_body); 1 = a single queue.
+  int* prog = nullptr; int slices = 0; int nxcd = 1;
+  unsigned long long* hand = nullptr; int hand_n = 0;
   // optional wave trace (dmc_batch_wave_trace): a ring of the last 8 launches, (8, 8, nitems) ints; per launch the rows
   // are the constant-rate clock (100 MHz) at which the item's wave entered the kernel (before the tables are staged),
   // started and finished the item, its workgroup index, and the clock after the opening position / velocity stage, the
@@ -888,6 +901,69 @@ struct StepCore {
     }
     if (lane == 0) hi[0] = valid ? get_epoch() : 0;      // the epoch the launch STARTED in: a bump that lands mid-launch must not be adopted
   }
+  // ---- hand-off between the pieces of a sliced item (StepIO::slices / hand) ---------------------------------------------
+  // The record travels between waves that may sit on different CUs.  Written with relaxed agent-scope 8-byte atomic stores
+  // (global_store_dwordx2 sc1: write-through), read with relaxed agent-scope 8-byte atomic loads (sc1: not served by the
+  // reader's L1, which another CU's stores never refresh); the producer waits for vmcnt(0) before it raises the item's
+  // flag and the consumer polls the flag before it loads (step_kernel_body).
+#ifndef DMC_HOST_EMU
+  typedef unsigned long long u64h;
+  DMC_DEV static int hand_words(int n) { return sizeof(T) == 8 ? n : (n + 1) / 2; }
+  DMC_DEV static int hand_record_words(const StepDims& d) { return hand_words(d.nq) + 2*hand_words(d.nv) + hand_words(d.na) + 1; }
+  DMC_DEV void hand_put(u64h* dst, const T* src, int n) {
+    if (sizeof(T) == 8) { FOR_LANES(i, n) { u64h w; const T v = src[i]; __builtin_memcpy(&w, &v, 8); __hip_atomic_store(dst + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+    else FOR_LANES(i, (n + 1) / 2) {
+      const float lo = (float)src[2*i], hi = 2*i + 1 < n ? (float)src[2*i + 1] : 0.0f;
+      const u64h w = (u64h)__float_as_uint(lo) | (u64h)__float_as_uint(hi) << 32;
+      __hip_atomic_store(dst + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  DMC_DEV void hand_get(T* dst, const u64h* src, int n) {
+    if (sizeof(T) == 8) { FOR_LANES(i, n) { const u64h w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); T v; __builtin_memcpy(&v, &w, 8); dst[i] = v; } }
+    else FOR_LANES(i, (n + 1) / 2) {
+      const u64h w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dst[2*i] = (T)__uint_as_float((unsigned)w);
+      if (2*i + 1 < n) dst[2*i + 1] = (T)__uint_as_float((unsigned)(w >> 32));
+    }
+  }
+  DMC_DEV void store_handoff(const StepIO<T>& io, int env) {
+    env = late(env);
+    const int nq = L.d.nq, nv = L.d.nv, na = L.d.na;
+    u64h* h = io.hand + (size_t)env * io.hand_n;
+    hand_put(h, S(qpos), nq); h += hand_words(nq);
+    hand_put(h, S(qvel), nv); h += hand_words(nv);
+    hand_put(h, S(qacc_warmstart), nv); h += hand_words(nv);
+    if (na) { hand_put(h, S(act), na); h += hand_words(na); }
+    if (lane == 0) { u64h w; const double t = time_; __builtin_memcpy(&w, &t, 8); __hip_atomic_store(h, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    const int B = io.B;
+    // this piece's warnings (a later piece on another CU adds its own: where atomics execute, not through an L1)
+    if (LPE >= 16) { if (lane < DMC_NWARNING) { const int w = SI(imisc)[IM_WARN + lane]; if (w) atomicAdd(io.warning + (size_t)lane*B + env, w); } }
+    else if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) atomicAdd(io.warning + (size_t)k*B + env, SI(imisc)[IM_WARN + k]);
+    // ctrl zeroed by a BADCTRL warning (mj_fwdActuation) stays zeroed for the pieces that follow
+    if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) {
+      if (sizeof(T) == 8) { u64h w; const T v = S(ctrl)[i]; __builtin_memcpy(&w, &v, 8); __hip_atomic_store((u64h*)(io.ctrl + (size_t)i*B + env), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else __hip_atomic_store((unsigned*)(io.ctrl + (size_t)i*B + env), __float_as_uint((float)S(ctrl)[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  DMC_DEV void load_handoff(const StepIO<T>& io, int env) {
+    env = late(env);
+    const int nq = L.d.nq, nv = L.d.nv, na = L.d.na, B = io.B;
+    const u64h* h = io.hand + (size_t)env * io.hand_n;
+    hand_get(S(qpos), h, nq); h += hand_words(nq);
+    hand_get(S(qvel), h, nv); h += hand_words(nv);
+    hand_get(S(qacc_warmstart), h, nv); h += hand_words(nv);
+    if (na) { hand_get(S(act), h, na); h += hand_words(na); FOR_LANES(i, na) S(act_dot)[i] = 0; }
+    { const u64h w = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); double t; __builtin_memcpy(&t, &w, 8); time_ = t; }
+    FOR_LANES(i, nv) S(qfrc_applied)[i] = io.qfrc_applied ? io.qfrc_applied[(size_t)i*B + env] : (T)0;      // (an input: constant over the launch)
+    FOR_LANES(i, L.d.nu) {      // (an earlier piece may have zeroed it: BADCTRL)
+      if (sizeof(T) == 8) { const u64h w = __hip_atomic_load((const u64h*)(io.ctrl + (size_t)i*B + env), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); T v; __builtin_memcpy(&v, &w, 8); S(ctrl)[i] = v; }
+      else S(ctrl)[i] = (T)__uint_as_float(__hip_atomic_load((const unsigned*)(io.ctrl + (size_t)i*B + env), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+#else
+  DMC_DEV void store_handoff(const StepIO<T>&, int) {}
+  DMC_DEV void load_handoff(const StepIO<T>&, int) {}
+#endif
   // ---- kinematic stash ------------------------------------------------------------------------------------------
   // A legacy Physics.step() ends with mj_step1 at the new state and the next one begins with mj_step2 on those
   // results (engine.py:147-162).  Across launches LDS is lost, so the opening position / velocity stage is recomputed
@@ -1005,9 +1081,10 @@ struct StepCore {
     }
     DMC_WSYNC();
   }
-  DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash, const Entry& en) {
+  DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash, const Entry& en, bool from_hand = false) {
     const int B = io.B;
-    if (en.fast) {      // the state is in LDS already (entry_commit)
+    if (from_hand) load_handoff(io, env);      // a later piece of a sliced item: the state the previous piece handed over
+    else if (en.fast) {      // the state is in LDS already (entry_commit)
       if (L.d.na && lane < L.d.na) S(act_dot)[lane] = 0;
       time_ = io.time[env];      // (not needed before the state is stored: nothing waits for it here)
     } else {
@@ -1053,8 +1130,13 @@ struct StepCore {
     if (L.d.na) FOR_LANES(i, L.d.na) G(io.act)[(size_t)i*B + env] = S(act)[i];
     if (lane == 0) G(io.time)[env] = time_;
     // (one lane per warning counter: lane 0 walking the nine of them was nine dependent LDS round trips at the end of every wave)
-    if (LPE >= 16) { if (lane < DMC_NWARNING) { const int w = SI(imisc)[IM_WARN + lane]; if (w) G(io.warning)[(size_t)lane*B + env] += w; } }
-    else if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) G(io.warning)[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
+    // (atomics: an earlier piece of a sliced item may have added its own from another CU, which this CU's L1 would not show)
+#ifndef DMC_HOST_EMU
+    if (LPE >= 16) { if (lane < DMC_NWARNING) { const int w = SI(imisc)[IM_WARN + lane]; if (w) atomicAdd(io.warning + (size_t)lane*B + env, w); } }
+    else if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) atomicAdd(io.warning + (size_t)k*B + env, SI(imisc)[IM_WARN + k]);
+#else
+    if (lane == 0) for (int k = 0; k < DMC_NWARNING; k++) if (SI(imisc)[IM_WARN + k]) G(io.warning)[(size_t)k*B + env] += SI(imisc)[IM_WARN + k];
+#endif
     // ctrl may have been zeroed by a BADCTRL warning (mj_fwdActuation semantics)
     if (SI(imisc)[IM_WARN + DMC_WARN_BADCTRL]) FOR_LANES(i, L.d.nu) io.ctrl[(size_t)i*B + env] = S(ctrl)[i];
   }
@@ -5218,7 +5300,10 @@ struct StepCore {
     } else FOR_LANES(i, nv) S(qacc)[i] = S(qacc_smooth)[i];
     DMC_WSYNC();
     int iter;
-    if (L.d.island && (o.islands < 0 ? sizeof(T) == 8 : o.islands != 0) && !(o.disableflags & DMC_DSBL_ISLAND) && solve_islands(nefc, &iter)) constraint_force_to_joint(nefc);
+    // islands -1 (default): per-island solves where they change the answer measurably -- fp64 batches (held to the CPU
+    // reference) and CG at any precision (CG stops at a looser point: joint vs per-island answers 4.9e-6 apart); fp32
+    // Newton solves jointly (8e-15 apart, and a solve per island on one wave saves nothing)
+    if (L.d.island && (o.islands < 0 ? (sizeof(T) == 8 || L.d.cg) : o.islands != 0) && !(o.disableflags & DMC_DSBL_ISLAND) && solve_islands(nefc, &iter)) constraint_force_to_joint(nefc);
     else {
       iter = primal_solve(nefc, evaluated, cc, gauss, changed);
       // (qfrc_constraint = J' efc_force is already that of the solution: every exit of primal_solve is preceded by a
@@ -5766,7 +5851,13 @@ struct StepCore {
     run(io, env, nstep, legacy, mode, outmask, nsub, en);
   }
   // en: what entry_issue / entry_commit left for this env and the launch's (mode, legacy)
-  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en) {
+  // piece / npieces (sliced items of a queued launch, StepIO::slices): this call runs the physics steps
+  // [piece * nstep / npieces, (piece + 1) * nstep / npieces) of a mode-0 launch from the state the previous piece stored;
+  // the last piece also runs what ends the launch (the trailing mj_step1, outputs, the kinematic stash).  Every pass
+  // rebuilds its derived arrays from (qpos, qvel, act, qacc_warmstart, time), so a cut between the integration of one
+  // physics step and the position stage of the next recomputes nothing.
+  DMC_DEV void run(const StepIO<T>& io, int env, int nstep, int legacy, int mode, int outmask, int nsub, const Entry& en,
+                   int piece = 0, int npieces = 1) {
     const int launch_mode = mode;
     if (lane == 0) set_epoch(en.epoch);      // (kept in LDS, not in a register, for the whole launch)
     if (io.env_mode) {
@@ -5774,15 +5865,17 @@ struct StepCore {
       if (em == 2) return;
       if (em == 1 && (mode == 0 || mode >= 4)) mode = 2;
     }
+    if (mode != 0 && piece > 0) return;      // (an env the launch override turned into mj_forward: one pass, in the first piece)
+    if (mode != 0) npieces = 1;
     if (mode >= 4) { run_split(io, env, mode, outmask, en); return; }
     prof_begin();
     const bool stash = io.stash_r != nullptr;
     bool have = false;
     if (stash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) have = load_stash(io, env);
-    load_state(io, env, have, en);
+    load_state(io, env, have, en, piece > 0);
     bool havekin = false;
     // (the stash was only prefetched for a launch that steps: an env switched to mj_forward by env_mode has none)
-    if (io.kstash && mode == 0 && launch_mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) {
+    if (piece == 0 && io.kstash && mode == 0 && launch_mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) {
       if (!en.fast) havekin = load_kstash(io, env);
       else if (en.kvalid) { havekin = true; DMC_WSYNC(); kstash_env_geoms(); }
     }
@@ -5796,7 +5889,10 @@ struct StepCore {
     // acceleration stage with its sensors, no integration) -- what the reference's composer observes after a control
     // step (mjcf/physics.py:341-342: the first observable read through a binding forwards the dirty physics)
     const bool fwd_after = kFeat && legacy == 2 && mode == 0;
-    for (int it = 0; it < npass; it++) {
+    const bool last_piece = piece == npieces - 1;
+    const int it_lo = npieces > 1 ? (int)((long long)piece * ntotal / npieces) : 0;
+    const int it_hi = (npieces > 1 && !last_piece) ? (int)((long long)(piece + 1) * ntotal / npieces) : npass;
+    for (int it = it_lo; it < it_hi; it++) {
       const bool trailing = stepping && it == ntotal;
       const bool partial = trailing && !(stash && mode == 0) && !fwd_after;
       if (mode == 3 && !trailing && it % nsub == 0 && io.ctrl_seq) load_ctrl_seq(io, env, it / nsub);
@@ -5830,6 +5926,7 @@ struct StepCore {
       if (it == 0) trace_stamp(io, env, 6);
       DMC_PROF(PROF_EULER);
     }
+    if (!last_piece) { store_handoff(io, env); DMC_PROF(PROF_STORE); prof_end(io, env); return; }      // (the next piece takes it from here)
     if (!stepping) dump_debug(io, env);
     // an environment the launch override turned into mj_forward (just re-initialised) reports its one state in every slot
     if (!stepping && launch_mode == 0) probe_store(io, env, 0, nstep);

@@ -86,13 +86,40 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   const size_t env_bytes = (size_t)L.n_sr * sizeof(T) + (size_t)L.n_si * sizeof(int);
   typename Core::Entry en;
   typename Core::EntryRegs er;
-  int slot = lblk * wpb + wave;
+  // Queued launches (QUEUE: the grid is only the RESIDENT workgroups of a larger batch): one queue PER XCD.  Queue x holds
+  // the items at positions x, x + NX, x + 2 NX ... of the hand-out order (longest first, dealt round: the queues' predicted
+  // sums are balanced) as `npieces` rounds -- piece s of each of its items before piece s + 1 of any (StepIO::slices) --
+  // and is served by the waves that RUN on XCD x (HW_REG_XCC_ID: the hardware's answer, not an assumption about
+  // dispatch), so that everything an environment leaves in global memory between its pieces is written and read
+  // through ONE L2.  (The per-XCD L2s are not coherent with each other: two of them holding dirty lines of the same
+  // per-env scratch could write them back in either order.)  A position is claimed with one atomicAdd on the queue's head.
+  const int NX = (QUEUE && io_arg.work && io_arg.nxcd > 1) ? io_arg.nxcd : 1;
+  const int xq = NX > 1 ? (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)NX) : 0;      // HW_REG_XCC_ID[3:0]
+  const int nq_items = (nitems - xq + NX - 1) / NX;      // items of this wave's queue
+  const int npieces = (QUEUE && io_arg.work && io_arg.prog && io_arg.slices > 1 && mode == 0) ? io_arg.slices : 1;
+  const int nslots = nq_items * npieces;
+  int* const head = (QUEUE && io_arg.work) ? io_arg.work + 32 * (1 + xq) : nullptr;      // (a 128-byte line per head)
+  int slot = lblk * wpb + wave, piece = 0;
+  bool have_item = slot < nitems;
+  if (QUEUE && head) {
+    int nx = 0;
+    if ((tid & 63) == 0) nx = atomicAdd(head, 1);
+    nx = __builtin_amdgcn_readfirstlane(nx);
+    have_item = nx < nslots;
+    piece = nx / nq_items;
+    slot = (nx - piece * nq_items) * NX + xq;
+  }
   int env0 = 0;
-  if (slot < nitems) {
+  if (have_item && piece == 0) {
     const int item = io_arg.order ? io_arg.order[slot] : slot;
     env0 = item * epw + ((tid / LPE) & (epw - 1));
     if (env0 >= io_arg.B) env0 = io_arg.B - 1;      // ragged last wave: loads the last environment, runs nothing
     Core::entry_issue(L, o_arg, io_arg, env0, tid % LPE, mode, legacy, &en, &er);
+  } else if (have_item) {      // (a wave whose first claim is already a later piece: loads in place, as every later claim does)
+    const int item = io_arg.order ? io_arg.order[slot] : slot;
+    int e0 = item * epw + ((tid / LPE) & (epw - 1));
+    if (e0 >= io_arg.B) e0 = io_arg.B - 1;
+    en.em = io_arg.env_mode ? io_arg.env_mode[e0] : 0; en.fast = 0; en.kvalid = 0; en.epoch = *io_arg.epoch;
   }
   // stage the model constant tables once per workgroup (shared by all its envs)
   if (tid == 0) *o_lds = o_arg;
@@ -109,14 +136,18 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   int* mc_lds = reinterpret_cast<int*>(tables + (size_t)L.n_mi * sizeof(int) + (size_t)L.n_mr_lds * sizeof(T));
   const size_t cold_bytes = L.d.coldlds ? (size_t)L.n_mc * sizeof(int) : 0;
   if (L.d.coldlds) for (int i = tid; i < L.n_mc; i += nthr) mc_lds[i] = g_mc[i];
-  if (slot < nitems) Core::entry_commit(L, io_arg, env0, tid % LPE, &en, er, reinterpret_cast<T*>(tables + tables_bytes + (size_t)(tid / LPE) * env_bytes));
+  if (have_item && piece == 0) Core::entry_commit(L, io_arg, env0, tid % LPE, &en, er, reinterpret_cast<T*>(tables + tables_bytes + (size_t)(tid / LPE) * env_bytes));
   __syncthreads();
-  // An item is the 64 / LPE environments one wave steps together.  Every wave starts on the item of its position in
-  // the grid.  When the grid is only the RESIDENT workgroups of a larger batch (io.work != null), a wave that finishes
-  // takes the next unclaimed item from the queue: the waves of a workgroup do not wait for its slowest environment,
-  // and a launch is not a whole number of rounds (a fallen 62-dof humanoid steps several times longer than a
-  // standing one; with 4-wave workgroups handed out whole, one launch per env-step ran 1.5x longer than the rollout).
-  if (slot < nitems) for (;;) {
+  // An item is the 64 / LPE environments one wave steps together.  Without a queue every wave has the item of its
+  // position in the grid.  With one, a wave that finishes claims the next position of its XCD's queue: the waves of a
+  // workgroup do not wait for its slowest environment, and a launch is not a whole number of rounds (a fallen 62-dof
+  // humanoid steps several times longer than a standing one; with 4-wave workgroups handed out whole, one launch per
+  // env-step ran 1.5x longer than the rollout).  Sliced items (npieces > 1): a piece is `nstep / npieces` physics steps of
+  // the item; piece s waits for piece s - 1 of its item, which was claimed earlier from the same head and is therefore
+  // running or done -- no wait can be circular.  Round 6, config 4 on one box: whole items 8.90 ms per launch (the queue
+  // runs dry at 62 % of the launch, the waves then idle behind items of up to 6 ms whose cost the previous launch
+  // predicts with a rank correlation of 0.53), pieces 7.4 ms.
+  if (have_item) for (;;) {
     // The per-lane pointers are re-derived from the thread index on every trip (behind an opaque copy, so that the
     // compiler does not hoist them): otherwise they stay live across the out-of-line stage calls of run() and are
     // spilled to scratch memory there -- 11 VGPRs on the cheetah kernel, 6 x the algorithmic HBM writes of a launch.
@@ -130,34 +161,50 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     // longest first: an environment that took long last time (a fallen humanoid with 20 contacts) is started early,
     // so that the launch does not end waiting for one that was started last
     const int item = io.order ? io.order[slot] : slot;
-    const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     const int env = item * epw + (g & (epw - 1));
     int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 8 * nitems : nullptr;
-    if (tr && (threadIdx.x & 63) == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
-    if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en);
-    if (tr && (threadIdx.x & 63) == 0) {
+    if (QUEUE && piece > 0)      // (the state itself is read with loads that bypass this CU's L1: StepCore::load_handoff)
+      while (__hip_atomic_load(io.prog + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) __builtin_amdgcn_s_sleep(8);
+    const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
+    if (tr && (threadIdx.x & 63) == 0 && piece == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
+    if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en, piece, npieces);
+    if (tr && (threadIdx.x & 63) == 0 && piece == npieces - 1) {
       tr[2*nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
       tr[3*nitems + item] = (int)blockIdx.x;
     }
     if (io.cost && (threadIdx.x & 63) == 0) {
-      const long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
-      io.cost[item] = (int)(dt < 1 ? 1 : (dt > 0x3fffffff ? 0x3fffffff : dt));
+      long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
+      dt = dt < 1 ? 1 : (dt > 0x07ffffff ? 0x07ffffff : dt);
+      // (the pieces of an item may run on different CUs: the sum is formed where atomics execute, not in an L1)
+      if (piece == 0) __hip_atomic_store(io.cost + item, (int)dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else atomicAdd(io.cost + item, (int)dt);
     }
-    if (!QUEUE || !io.work) break;
+    if (QUEUE && piece < npieces - 1) {
+      // the hand-off record was written with write-through (sc1) stores: once they are acknowledged the flag may go
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(io.prog + item, piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!QUEUE || !head) break;
     int nx = 0;
-    if ((threadIdx.x & 63) == 0) nx = atomicAdd(io.work, 1);
-    slot = nwaves + __builtin_amdgcn_readfirstlane(nx);
-    if (slot >= nitems) break;
+    if ((threadIdx.x & 63) == 0) nx = atomicAdd(head, 1);
+    nx = __builtin_amdgcn_readfirstlane(nx);
+    if (nx >= nslots) break;
+    piece = nx / nq_items;
+    slot = (nx - piece * nq_items) * NX + xq;
     const int nitem = io.order ? io.order[slot] : slot;
     int nenv = nitem * epw + ((threadIdx.x / LPE) & (epw - 1));
     if (nenv >= io.B) nenv = io.B - 1;
     // (later items load in place, inside run(): up here the registers are full of what the loop keeps alive)
     en.em = io.env_mode ? io.env_mode[nenv] : 0; en.fast = 0; en.kvalid = 0;
   }
-  if (QUEUE && io.work && (threadIdx.x & 63) == 0) {
-    // every wave makes exactly one failing claim (or none, if it never had an item) before it gets here, so the
-    // last wave to arrive can re-arm the queue for the next launch on the stream
-    if (atomicAdd(io.work + 1, 1) == nwaves - 1) { atomicExch(io.work, 0); atomicExch(io.work + 1, 0); }
+  if (QUEUE && io_arg.work && (threadIdx.x & 63) == 0) {
+    // every wave makes exactly one failing claim before it gets here, so the last wave to arrive can re-arm the queues
+    // for the next launch on the stream
+    if (atomicAdd(io_arg.work + 1, 1) == nwaves - 1) {
+      atomicExch(io_arg.work + 1, 0);
+      for (int x = 0; x < NX; x++) atomicExch(io_arg.work + 32 * (1 + x), 0);
+      if (npieces > 1) for (int i = 0; i < nitems; i++) io_arg.prog[i] = 0;      // (every piece is complete: nobody reads it any more)
+    }
   }
 }
 

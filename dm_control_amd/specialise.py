@@ -7,7 +7,12 @@ same host code the library uses (`gen_static_layouts`), the flags are those of t
 the batch.  A cold build is one hipcc run (about a minute for a small model, a few for a 60-dof one); a warm cache is a
 dlopen.
 
-  DMC_SPECIALISE = cached (default): attach when the object is already in the cache, never compile implicitly
+  DMC_SPECIALISE = background (default): attach when the object is in the cache; otherwise compile it in a background thread
+                                     (the batch runs the generic kernel meanwhile -- 2 - 3 x slower, logged once) and
+                                     switch over at the first launch after the build has finished
+                                     (`BatchedPhysics.wait_specialised()` blocks for it: callers that capture their
+                                     launches into a HIP graph do that first)
+                   cached:           attach when the object is already in the cache, never compile implicitly
                    build | 1:        compile at batch creation when it is missing (blocks for the build)
                    0:                never
   DMC_SPEC_CACHE:  cache directory (default: dm_control_amd/_spec_cache, in-tree so that it travels with the checkout)
@@ -20,11 +25,15 @@ dlopen.
 `warm(model, precision=32, **caps)` builds ahead of time (e.g. once per composer model); `BatchedPhysics(...,
 specialise=...)` overrides the environment per batch.  Batches whose layout equals a baked one keep the baked kernel.
 """
+import concurrent.futures
 import hashlib
+import logging
 import os
 import shlex
+import shutil
 import subprocess
 import tempfile
+import threading
 
 import numpy as np
 
@@ -43,9 +52,34 @@ def cache_dir():
   return d
 
 
+_log = logging.getLogger('dm_control_amd.specialise')
+_toolchain = None
+_pool = None
+_pool_lock = threading.Lock()
+_tool_lock = threading.Lock()
+_inflight = {}      # plugin path -> Future of the background build producing it
+
+
 def mode():
-  m = os.environ.get('DMC_SPECIALISE', 'cached').lower()
-  return {'1': 'build', 'true': 'build', 'build': 'build', '0': 'off', 'off': 'off', 'false': 'off'}.get(m, 'cached')
+  m = os.environ.get('DMC_SPECIALISE', 'background').lower()
+  return {'1': 'build', 'true': 'build', 'build': 'build', '0': 'off', 'off': 'off', 'false': 'off',
+          'cached': 'cached'}.get(m, 'background')
+
+
+def toolchain_id():
+  """What besides the sources decides the object: the offload architecture and the compiler (the cache is in-tree and
+  travels with the checkout -- possibly to a box with another ROCm).  Empty compiler part where hipcc is absent: such a
+  box can only use objects built elsewhere with the same image."""
+  global _toolchain
+  if _toolchain is None:
+    ver = ''
+    try:
+      ver = subprocess.run([_build.HIPCC, '--version'], capture_output=True, text=True, timeout=60).stdout
+    except Exception:      # pylint: disable=broad-except
+      pass
+    keep = [l.strip() for l in ver.splitlines() if l.startswith(('HIP version', 'AMD clang version', 'clang version'))]
+    _toolchain = _build.ARCH + '|' + '|'.join(keep)
+  return _toolchain
 
 
 def source_hash():
@@ -68,7 +102,7 @@ def key(model, precision, lpe, caps):
   ints, reals = model.pack()
   h = hashlib.sha1()
   h.update(ints.tobytes()); h.update(reals.tobytes())
-  h.update(repr((int(precision), int(lpe), tuple(int(c) for c in caps), _lean(model), source_hash())).encode())
+  h.update(repr((int(precision), int(lpe), tuple(int(c) for c in caps), _lean(model), source_hash(), toolchain_id())).encode())
   h.update(os.environ.get('DMC_SPEC_FLAGS', '').encode())
   return h.hexdigest()[:24]
 
@@ -86,7 +120,8 @@ def build(model, precision=32, lpe=None, caps=(0, 0, 0), verbose=False):
     return out
   # (-DDMC_PROFILE=1 among DMC_SPEC_FLAGS: the layout with the phase counters, for batches of libdmc_hip_prof.so)
   prof = 'DMC_PROFILE' in os.environ.get('DMC_SPEC_FLAGS', '')
-  _build.generate_static_layouts(profile=prof)      # (makes sure the layout tool is built)
+  with _tool_lock:
+    _build.generate_static_layouts(profile=prof)      # (makes sure the layout tool is built)
   tool = os.path.join(CSRC, 'gen_static_layouts' + ('_prof' if prof else ''))
   ints, reals = model.pack()
   with tempfile.TemporaryDirectory() as td:
@@ -127,9 +162,53 @@ def warm(model, precision=32, lanes_per_env=0, nconmax=0, njmax=0, njcon=0, verb
   return build(model, precision, lanes_per_env or None, caps, verbose)
 
 
+def _describe(batch):
+  m = batch.model
+  return '%s (nv %d, B %d, fp%d)' % (getattr(m, 'model_name', None) or 'model', m.nv, batch.batch_size, batch.precision)
+
+
+def _try_attach(batch, path):
+  """dmc_batch_attach_specialised, without taking the batch down: an object the library refuses (built for another
+  layout level, profile build, another model behind DMC_SPEC_PLUGIN, a foreign architecture in a copied cache) is logged
+  and the batch keeps the generic kernel."""
+  from dm_control_amd import _native
+  rc = _native.lib().dmc_batch_attach_specialised(batch._ptr, path.encode())      # pylint: disable=protected-access
+  if rc != 0:
+    _log.warning('dm_control_amd: %s keeps the generic step kernel: %s was refused (%s)', _describe(batch), path,
+                 _native.lib().dmc_last_error().decode(errors='replace'))
+    return False
+  return True
+
+
+def build_async(model, precision, lpe, caps):
+  """The plugin's build as a Future (one per object path, at most two hipcc runs at a time).  The workers are daemon
+  threads: a process that exits while a build is running does not wait for it (the object appears under its final name
+  only when complete)."""
+  global _pool
+  out = path_for(model, precision, lpe, caps)
+  with _pool_lock:
+    f = _inflight.get(out)
+    if f is not None and not (f.done() and f.exception() is not None):
+      return f
+    if _pool is None:
+      _pool = threading.Semaphore(2)
+    f = concurrent.futures.Future()
+    _inflight[out] = f
+
+  def work():
+    with _pool:
+      try:
+        f.set_result(build(model, precision, lpe, caps))
+      except BaseException as ex:      # pylint: disable=broad-except
+        f.set_exception(ex)
+  threading.Thread(target=work, name='dmc-specialise', daemon=True).start()
+  return f
+
+
 def attach(batch, how=None):
-  """Attaches the model's plugin to a BatchedPhysics that has no baked kernel.  Returns 'baked', 'attached', 'missing'
-  (not cached and not asked to build) or 'off'."""
+  """Attaches the model's plugin to a BatchedPhysics that has no baked kernel.  Returns 'baked', 'attached', 'building'
+  (a background build was started: `poll` / `wait` switch the batch over), 'missing' (not cached and not asked to build,
+  or the object was refused) or 'off'."""
   from dm_control_amd import _native
   how = how or mode()
   if how == 'off' or not hasattr(_native.lib(), 'dmc_batch_attach_specialised'):
@@ -142,8 +221,50 @@ def attach(batch, how=None):
     caps = caps + (1,)      # the batch keeps everything in LDS (a small batch, or caps[4] / DMC_JLEVEL): so must its kernel
   p = os.environ.get('DMC_SPEC_PLUGIN') or path_for(batch.model, batch.precision, info['lanes_per_env'], caps)
   if not os.path.exists(p):
-    if how != 'build':
+    if how == 'cached':
+      _log.info('dm_control_amd: %s runs the generic step kernel (2 - 3 x slower than a specialised one): none is cached and '
+                'DMC_SPECIALISE=cached never builds; specialise.warm(model) builds it', _describe(batch))
       return 'missing'
-    build(batch.model, batch.precision, info['lanes_per_env'], caps)
-  _native.check(_native.lib().dmc_batch_attach_specialised(batch._ptr, p.encode()))      # pylint: disable=protected-access
-  return 'attached'
+    if shutil.which(_build.HIPCC) is None and not os.path.exists(_build.HIPCC):
+      _log.warning('dm_control_amd: %s runs the generic step kernel (2 - 3 x slower): no specialised kernel is cached and '
+                   'hipcc is not available to build one', _describe(batch))
+      return 'missing'
+    if how == 'background':
+      # (one environment stepped through the (MjModel, MjData) seam gains nothing a 15 - 25 s compile is worth)
+      if batch.batch_size < int(os.environ.get('DMC_SPEC_MIN_BATCH', '16')):
+        return 'missing'
+      batch._spec_future = build_async(batch.model, batch.precision, info['lanes_per_env'], caps)      # pylint: disable=protected-access
+      batch._spec_path = p      # pylint: disable=protected-access
+      _log.warning('dm_control_amd: %s runs the generic step kernel (2 - 3 x slower) while its specialised kernel is being '
+                   'compiled in the background (one hipcc run, cached in %s)', _describe(batch), cache_dir())
+      return 'building'
+    try:
+      build(batch.model, batch.precision, info['lanes_per_env'], caps)
+    except (subprocess.CalledProcessError, OSError) as ex:
+      _log.warning('dm_control_amd: %s keeps the generic step kernel: the build of its specialised kernel failed (%r)',
+                   _describe(batch), ex)
+      return 'missing'
+  return 'attached' if _try_attach(batch, p) else 'missing'
+
+
+def poll(batch, block=False, timeout=None):
+  """Switches a batch whose plugin was being built in the background over to it once the build has finished (called
+  by BatchedPhysics before a launch: a dictionary lookup while nothing is pending).  Returns batch.specialised."""
+  f = getattr(batch, '_spec_future', None)
+  if f is None:
+    return batch.specialised
+  if not block and not f.done():
+    return batch.specialised
+  try:
+    f.result(timeout=timeout)
+    ok = _try_attach(batch, batch._spec_path)      # pylint: disable=protected-access
+  except concurrent.futures.TimeoutError:
+    return batch.specialised
+  except Exception as ex:      # pylint: disable=broad-except
+    _log.warning('dm_control_amd: %s keeps the generic step kernel: the background build failed (%r)', _describe(batch), ex)
+    ok = False
+  batch._spec_future = None      # pylint: disable=protected-access
+  batch.specialised = 'attached' if ok else 'missing'
+  if ok:
+    _log.warning('dm_control_amd: %s switched to its specialised step kernel', _describe(batch))
+  return batch.specialised

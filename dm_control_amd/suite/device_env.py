@@ -495,7 +495,7 @@ class GenericDeviceEnv:
   (B,)) device tensors.  See the module docstring."""
 
   def __init__(self, domain, task, batch_size, precision=32, device_id=0, seed=0, capture=True, task_kwargs=None,
-               termination_check_every=25, _device='cuda'):
+               termination_check_every=25, copy_outputs=True, _device='cuda'):
     import torch
     from dm_control_amd import physics as facade
     from dm_control_amd import suite
@@ -548,6 +548,9 @@ class GenericDeviceEnv:
     self.steps = 0
     self._graph = None
     self._capture = bool(capture) and self.device.type == 'cuda'
+    # a replayed HIP graph writes its results into the same tensors every step: copy_outputs (default) hands the caller
+    # its own copies (obs_t kept across step t + 1 stays obs_t); False returns the graph's output tensors themselves
+    self._copy_outputs = bool(copy_outputs)
     self._term_every = int(termination_check_every)
     self._has_termination = type(self.task).get_termination is not _base_termination()
     TArr.default_float = self.dtype
@@ -640,9 +643,12 @@ class GenericDeviceEnv:
 
   def step(self, action):
     """action: (B, nu) tensor on the device.  Returns (obs, reward, done); when the time limit is reached every
-    environment restarts and the returned observation is the new episode's first."""
+    environment restarts and the returned observation is the new episode's first.  With `capture=True,
+    copy_outputs=False` obs and reward are the HIP graph's own output tensors, overwritten by the next step()."""
     if self._capture:
       obs, rew = self._captured_step(action)
+      if self._copy_outputs:
+        obs, rew = obs.clone(), rew.clone()
     else:
       obs, rew = self._control_step(action)
     self.steps += 1

@@ -59,9 +59,14 @@ class TorchBatchedEnv:
   _CONTROL_TIMESTEP = None  # None: one physics step per env step unless n_sub_steps is given
   _RUN_SPEED = 10.0
 
-  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=None, capture=False):
+  def __init__(self, batch_size, device_id=0, precision=32, time_limit=10.0, seed=0, n_sub_steps=None, capture=False,
+               copy_outputs=True):
     import torch
     self._capture, self._graph = bool(capture), None
+    # capture=True: a replayed HIP graph writes its results into the SAME tensors every step.  copy_outputs (default)
+    # hands the caller its own copies, so that obs_t kept across step t + 1 stays obs_t; copy_outputs=False returns the
+    # graph's own output tensors (no copy: valid until the next step() call).
+    self._copy_outputs = bool(copy_outputs)
     self.torch = torch
     self.device = torch.device('cuda', device_id)
     self.model = mjcf_compiler.compile_xml(self._model_xml())
@@ -213,11 +218,12 @@ class TorchBatchedEnv:
 
   def step(self, action):
     """action: (B, nu) tensor on device.  Returns (obs, reward, done) tensors; finished
-    environments are auto-reset (their returned obs is the fresh start state)."""
+    environments are auto-reset (their returned obs is the fresh start state).  With `capture=True, copy_outputs=False`
+    the returned tensors are the HIP graph's own outputs, which the NEXT step() overwrites: clone what must outlive it."""
     if self._capture and self._host_steps + 1 < self.step_limit:      # nobody can reach the limit in this step
       out = self._graph_step(action)
       self._host_steps += 1
-      return out
+      return tuple(t.clone() for t in out) if self._copy_outputs else out
     self.ctrl.copy_(action.T.to(self.dtype))
     self.physics.step(self.n_sub_steps, stream=self._stream())
     self.steps += 1

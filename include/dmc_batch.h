@@ -163,7 +163,8 @@ int dmc_batch_set_output_mask(dmc_batch* b, int mask);
  * to enable: dm_control/mjcf/schema.xml:102).  1 = one solve per island, as MuJoCo does when the flag is on, no noslip
  * pass is configured and the solver is CG / Newton; 0 = one joint solve (the same minimiser: the cross blocks are exact
  * zeros; measured 1e-14 .. 6e-9 apart with Newton, 5e-6 with CG over a few hundred steps); -1 (default) = by precision:
- * fp64 batches solve per island (they track the CPU reference), fp32 batches jointly (throughput). */
+ * fp64 batches solve per island (they track the CPU reference) and so do CG models at any precision (round 6: CG's
+ * joint answer is the one that differs measurably); fp32 Newton batches solve jointly (throughput). */
 int dmc_batch_set_opt_int(dmc_batch* b, const char* name, int value);
 int dmc_batch_set_opt_real(dmc_batch* b, const char* name, double value);
 

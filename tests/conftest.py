@@ -8,6 +8,12 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 
+# The test tier builds hundreds of small throw-away models; the product default (specialise.py: compile every unseen
+# model's kernel in a background thread) would queue a hipcc run for each.  Tests run the generic kernel unless they ask
+# for a specialised one (tests/test_specialise.py covers the default mode explicitly).
+os.environ.setdefault('DMC_SPECIALISE', 'cached')
+
+
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 

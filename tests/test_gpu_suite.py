@@ -695,7 +695,7 @@ def test_torch_env_matches_host_task(domain, task):
 
 
 @pytest.mark.parametrize('name,nsub,caps', [('cmu_2019_position_floor', 6, dict(nconmax=48)), ('soccer_2v2_boxhead', 5, dict(nconmax=24)),
-                                            ('humanoid_CMU', 10, dict(nconmax=64))])
+                                            ('humanoid_CMU', 10, dict(nconmax=96))])
 def test_baseline_62dof_and_soccer_models_fp64_open_loop(name, nsub, caps):
   """BASELINE configs 4 / 5 (and the suite's humanoid_CMU) on the fp64 instantiation of the kernel, OPEN LOOP against
   the oracle, with the production contact caps: since the contact rows, sparse M and cold tables moved to global
@@ -809,7 +809,9 @@ def test_baseline_62dof_and_soccer_fp32_error_of_one_physics_step(cfgid):
 @pytest.mark.parametrize('name,nsub,B', [('humanoid', 5, 4096), ('cmu_2019_position_floor', 6, 2048)])
 def test_work_queue_and_schedule_do_not_change_results(name, nsub, B, monkeypatch):
   """A batch larger than the chip holds runs a resident-only grid whose waves claim environments from a device queue,
-  longest first (include/dmc_batch.h: work_queue).  Which wave steps an environment, and when, must not matter: the
+  longest first (include/dmc_batch.h: work_queue), and -- round 6 -- hands every environment's env-step out in PIECES of
+  physics steps, round by round (StepIO::slices: the state travels through the state arrays between the pieces, which
+  may run on different waves, CUs and XCDs).  Which wave steps an environment, and when, must not matter: the
   trajectories equal those of the static one-workgroup-per-4-environments grid bit for bit."""
   from dm_control_amd import mjcf_compiler as mc
   from dm_control_amd.batch import BatchedPhysics
@@ -823,8 +825,9 @@ def test_work_queue_and_schedule_do_not_change_results(name, nsub, B, monkeypatc
   q[:B // 8, 2] -= 0.6          # some start in the ground: many contacts, long steps
   acts = rs.uniform(-1, 1, (6, B, m.nu))
   out = {}
-  for mode, env in (('queue', {}), ('index_order', {'DMC_NO_LPT': '1'}), ('static', {'DMC_NO_QUEUE': '1'})):
-    for k in ('DMC_NO_LPT', 'DMC_NO_QUEUE'):
+  for mode, env in (('queue', {}), ('index_order', {'DMC_NO_LPT': '1'}), ('static', {'DMC_NO_QUEUE': '1'}),
+                    ('whole_items', {'DMC_SLICES': '1'}), ('two_pieces', {'DMC_SLICES': '2'})):
+    for k in ('DMC_NO_LPT', 'DMC_NO_QUEUE', 'DMC_SLICES'):
       monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
       monkeypatch.setenv(k, v)
@@ -834,12 +837,54 @@ def test_work_queue_and_schedule_do_not_change_results(name, nsub, B, monkeypatc
     for a in acts:
       b.set_control(a)
       b.step(nsub)
-    out[mode] = (b.get('qpos'), b.get('qvel'), b.get('sensordata'), b.get('ncon'), b.get('warning'))
+    out[mode] = (b.get('qpos'), b.get('qvel'), b.get('sensordata'), b.get('ncon'), b.get('warning'), b.get('qacc_warmstart'),
+                 b.get('time'), b.get('nefc'), b.get('solver_iter'), b.get('xpos'))
     b.close()
-  for mode in ('index_order', 'static'):
+  for mode in ('index_order', 'static', 'whole_items', 'two_pieces'):
     for x, y in zip(out['queue'], out[mode]):
       np.testing.assert_array_equal(x, y, err_msg=mode)
   assert out['queue'][3].max() > 8
+
+
+def test_sliced_items_with_probe_forward_after_and_launch_overrides(monkeypatch):
+  """Sliced items (StepIO::slices) under everything a device environment asks of a step launch: the substep probe (one
+  geom's position after every physics step), legacy_step 2 (the launch ends with mj_forward at the new state), per-env
+  launch overrides (env_mode 1: mj_forward without actuation instead, 2: untouched) and launches of different nstep on
+  one batch.  Pieces against whole items (DMC_SLICES=1): bit for bit."""
+  import torch
+  from dm_control_amd import mjcf_compiler as mc
+  from dm_control_amd.batch import BatchedPhysics
+  from dm_control_amd.suite import common
+  m = mc.compile_xml(common.read_model('humanoid.xml'))
+  caps = dict(common.DEFAULT_CAPS.get('humanoid', {})); caps['precision'] = 32
+  B = 4096
+  rs = np.random.RandomState(11)
+  q = np.tile(m.qpos0, (B, 1))
+  q[:, 7:] += rs.uniform(-0.3, 0.3, (B, m.nq - 7))
+  q[:B // 8, 2] -= 0.6
+  acts = rs.uniform(-1, 1, (4, B, m.nu))
+  em = np.zeros((B, 1), np.int32); em[5::7] = 1; em[3::11] = 2
+  g = m.name2id('left_left_foot', 'geom')
+  out = {}
+  for mode in ('pieces', 'whole'):
+    monkeypatch.delenv('DMC_SLICES', raising=False)
+    if mode == 'whole': monkeypatch.setenv('DMC_SLICES', '1')
+    b = BatchedPhysics(m, B, **caps)
+    assert b.info()['work_queue'] == 1
+    probe = torch.zeros((5, 3, B), dtype=torch.float32, device='cuda')
+    b.set_step_probe(g, probe.data_ptr(), 5)
+    b.set('qpos', q)
+    res = []
+    for t, a in enumerate(acts):
+      b.set_control(a)
+      b.set('env_mode', em if t == 2 else np.zeros((B, 1), np.int32))
+      b.step(5 if t != 1 else 3, forward_after=(t % 2 == 0))
+      torch.cuda.synchronize()
+      res += [b.get(n) for n in ('qpos', 'qvel', 'qacc_warmstart', 'sensordata', 'time', 'ncon', 'warning')] + [probe.cpu().numpy().copy()]
+    out[mode] = res
+    b.close()
+  for x, y in zip(out['pieces'], out['whole']):
+    np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize('name,flags', [('humanoid', 7), ('cheetah', 1), ('acrobot', 7), ('quadruped', 4 | 8), ('ball_xml', 7)])

@@ -212,6 +212,26 @@ def test_kernel_core_islands_off_in_fp32_by_default_and_identical_for_one_tree()
   np.testing.assert_array_equal(a.qpos, b.qpos)
 
 
+def test_kernel_core_fp32_cg_solves_per_island_by_default():
+  """Round 6: the default (`islands` = -1) means per-island solves wherever the joint answer differs
+  measurably from MuJoCo's -- fp64, and CG at ANY precision (CG stops at a looser point: 4.9e-6 between the two forms) --
+  and the joint solve only for fp32 Newton (8e-15 apart)."""
+  from emu_lib import EmuPhysics
+  legs = [('a', -1.5), ('b', 0.0), ('c', 1.5)]
+  m = mc.compile_xml(scene(legs, option="solver='CG'"))
+  q, v, c = _settled_state(3)
+  out = {}
+  for name, isl in (('default', None), ('on', 1), ('off', 0)):
+    p = EmuPhysics(m, 32)
+    if isl is not None: p.set_islands(isl)
+    p.qpos[:] = q; p.qvel[:] = v; p.ctrl[:] = c
+    for _ in range(30):
+      p.step()
+    out[name] = p.qpos.copy()
+  np.testing.assert_array_equal(out['default'], out['on'])
+  assert np.abs(out['default'] - out['off']).max() > 0      # (the joint CG solve is a different iterate sequence)
+
+
 @pytest.mark.gpu
 def test_device_island_solves_follow_the_oracle():
   """The same on the device, fp64 (islands on by default) and fp32 with the option switched on, against per-environment

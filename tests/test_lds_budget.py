@@ -23,7 +23,7 @@ def _fit(r, waves, envs_per_wave=1, elem=4):
 
 @pytest.mark.parametrize('spec,waves,blocks,global_kb', [
     ('cmu_2019_position_floor:48', 5, 1, 30),      # BASELINE config 4: FIVE environments per CU in one 5-wave workgroup (offload level 3; +8 %)
-    ('humanoid_CMU:64', 4, 1, 20),                 # suite humanoid_CMU at its production contact cap
+    ('humanoid_CMU:96', 4, 1, 20),                 # suite humanoid_CMU at its production contact cap
     ('humanoid:24', 4, 2, 4),                      # BASELINE config 3: 2 workgroups x 4 = 8 per CU
     ('soccer_2v2_boxhead:24', 1, 4, 4),            # BASELINE config 5 (the reference's composed model: 113 sensors, 62 geoms; 5 with the round-2 restatement)
 ])
@@ -37,7 +37,7 @@ def test_fp32_residency_of_the_baseline_models(spec, waves, blocks, global_kb):
 
 def test_small_models_keep_everything_in_lds_and_fp64_fits_for_the_62_dof_models():
   assert lds_report.report('cheetah')['n_gs'] == 0
-  for spec in ('cmu_2019_position_floor:48', 'humanoid_CMU:64'):
+  for spec in ('cmu_2019_position_floor:48', 'humanoid_CMU:96'):
     r = lds_report.report(spec)
     fit, env, tables = _fit(r, 2, elem=8)
     assert fit >= 1, (spec, env, tables)      # fp64 parity runs of these models: one 2-wave workgroup = two environments per CU

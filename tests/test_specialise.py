@@ -45,9 +45,18 @@ def test_key_depends_on_model_caps_precision_and_sources(tmp_path, monkeypatch):
   assert k != specialise.key(m, 32, 32, (24, 0, 0))
   m2 = mc.compile_xml(UNSEEN.replace('mass="3"', 'mass="3.5"'))
   assert k != specialise.key(m2, 32, 32, (0, 0, 0))
+  monkeypatch.delenv('DMC_SPECIALISE', raising=False)      # (tests/conftest.py pins 'cached' for the test tier)
+  assert specialise.mode() == 'background'      # the product default: build in a background thread, switch over when done
+  monkeypatch.setenv('DMC_SPECIALISE', 'cached')
   assert specialise.mode() == 'cached'
   monkeypatch.setenv('DMC_SPECIALISE', '1')
   assert specialise.mode() == 'build'
+  # round 6: the offload architecture and the compiler are part of the key -- the cache is in-tree and travels
+  assert 'gfx950' in specialise.toolchain_id() and 'clang version' in specialise.toolchain_id()
+  monkeypatch.setattr(specialise, '_toolchain', 'gfx950|some other compiler')
+  assert k != specialise.key(m, 32, 32, (0, 0, 0))
+  monkeypatch.undo()
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
   # round 5: the layout level of a small batch (caps[3] = jglobal + 1) and tuning flags are part of the key
   assert k != specialise.key(m, 32, 32, (0, 0, 0, 1))
   monkeypatch.setenv('DMC_SPEC_FLAGS', '-DDMC_NO_ROW_NEWBCAST')
@@ -176,4 +185,63 @@ def test_baked_models_keep_their_baked_kernel():
   m = mc.compile_xml(common.read_model('cheetah.xml'))
   b = BatchedPhysics(m, 16, precision=32, specialise='build')
   assert b.specialised == 'baked' and 0 <= b.info()['static_id'] < 1000
+  b.close()
+
+
+@pytest.mark.gpu
+def test_default_mode_builds_in_the_background_and_switches_over(tmp_path, monkeypatch, caplog):
+  """The product default (DMC_SPECIALISE unset): a model never seen before starts on the generic kernel -- said so in
+  one log line -- while ONE hipcc run compiles its specialised kernel in a background thread; the batch switches over at
+  the first launch after the build (or at `wait_specialised()`), mid-episode, on the same state; the trajectory stays
+  the generic kernel's to the kernels' usual distance and a second batch of the model finds the object in the cache."""
+  import logging
+  from dm_control_amd.batch import BatchedPhysics
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  monkeypatch.delenv('DMC_SPECIALISE', raising=False)
+  m = mc.compile_xml(UNSEEN.replace('mass="3"', 'mass="3.25"'))
+  rs = np.random.RandomState(2)
+  B = 64
+  q = np.tile(m.qpos0, (B, 1)); q[:, 2:] += rs.uniform(-.3, .3, (B, m.nq - 2))
+  acts = rs.uniform(-1, 1, (40, B, m.nu))
+  ref = BatchedPhysics(m, B, precision=64, specialise='off')
+  with caplog.at_level(logging.INFO, logger='dm_control_amd.specialise'):
+    b = BatchedPhysics(m, B, precision=64)
+    assert b.specialised == 'building' and b.info()['static_id'] == -1
+    assert any('generic step kernel' in r.getMessage() and 'background' in r.getMessage() for r in caplog.records)
+    for x in (ref, b):
+      x.set('qpos', q)
+    for t in range(20):
+      for x in (ref, b):
+        x.set('ctrl', acts[t]); x.step()
+    assert b.wait_specialised(timeout=600) == 'attached' and b.info()['static_id'] == 1000
+    assert any('switched to its specialised' in r.getMessage() for r in caplog.records)
+  for t in range(20, 40):
+    for x in (ref, b):
+      x.set('ctrl', acts[t]); x.step()
+  np.testing.assert_allclose(b.get('qpos'), ref.get('qpos'), rtol=0, atol=1e-10)
+  assert not b.get('warning').any()
+  b2 = BatchedPhysics(m, B, precision=64)
+  assert b2.specialised == 'attached'
+  small = BatchedPhysics(m, 1, precision=32)      # (one environment behind the mujoco seam: not worth a compile)
+  assert small.specialised == 'missing'
+  for x in (ref, b, b2, small):
+    x.close()
+
+
+@pytest.mark.gpu
+def test_a_refused_object_leaves_the_batch_on_the_generic_kernel(tmp_path, monkeypatch, caplog):
+  """an object the library refuses (here: another model's, forced through DMC_SPEC_PLUGIN) must not raise out
+  of the constructor -- the batch logs it and runs the generic kernel."""
+  import logging
+  from dm_control_amd.batch import BatchedPhysics
+  monkeypatch.setenv('DMC_SPEC_CACHE', str(tmp_path))
+  p = specialise.build(mc.compile_xml(UNSEEN), 32)
+  monkeypatch.setenv('DMC_SPEC_PLUGIN', p)
+  other = mc.compile_xml(common.read_model('pendulum.xml'))
+  with caplog.at_level(logging.WARNING, logger='dm_control_amd.specialise'):
+    b = BatchedPhysics(other, 32, precision=32, specialise='cached')
+  assert b.specialised == 'missing' and b.info()['static_id'] == -1
+  assert any('refused' in r.getMessage() for r in caplog.records)
+  b.step(3)
+  assert np.isfinite(b.get('qpos')).all()
   b.close()
