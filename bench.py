@@ -414,11 +414,14 @@ def parity(model, cfg, args, local_rank, q, v, w, acts, nthreads, only=None):
   return res
 
 
-def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=16, parity_steps=4):
+def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=16, parity_steps=4, span=100):
   """A short leg of another BASELINE config for the default line's `extra`: the same workload, start states, actions and
-  launch as `bench.py --config <cfgid>` (one Physics.step(n_sub_steps) launch per env-step, actions resident in HBM), W
-  untimed + K timed launches bracketed by HIP events on the launch stream, the nominal HBM roofline of the kernel, and the
-  fp32 error of ONE env-step from the oracle's state (teacher-forced, `parity_envs` environments x `parity_steps` steps)."""
+  launch as `bench.py --config <cfgid>` (one Physics.step(n_sub_steps) launch per env-step, actions resident in HBM).  That
+  run times the `span` = 100 launches after W = 5 warm-up steps, over which the ragdolls of configs 3 / 4 fall and a launch
+  gets slower; this leg walks the same `span` launches and times K of them, evenly spread, each bracketed by its own pair
+  of HIP events on the launch stream -- the same workload at a twelfth of the events.  Beside it: the nominal HBM roofline
+  of the kernel and the fp32 error of ONE env-step from the oracle's state (teacher-forced, `parity_envs` environments x
+  `parity_steps` steps)."""
   import torch
   from dm_control_amd.batch import BatchedPhysics, OUT
   from dm_control_amd.suite import common
@@ -433,7 +436,7 @@ def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=1
   phys.set('qpos', initial_qpos(cfg, model, B, seed0=0, phys=phys))
   stream = torch.cuda.current_stream().cuda_stream
   rs = np.random.RandomState(1234)
-  acts = torch.from_numpy(np.ascontiguousarray(rs.uniform(-1, 1, (W + K, B, model.nu)).astype(np.float32).transpose(0, 2, 1))).to(dev).contiguous()
+  acts = torch.from_numpy(np.ascontiguousarray(rs.uniform(-1, 1, (W + span, B, model.nu)).astype(np.float32).transpose(0, 2, 1))).to(dev).contiguous()
   mask = 0
   for name in cfg['outputs']:
     mask |= OUT[name]
@@ -443,15 +446,19 @@ def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=1
     phys.bind('ctrl', acts[t].data_ptr()); phys.step(nsub, stream=stream)
   torch.cuda.synchronize()
   q0, v0, w0 = phys.get('qpos'), phys.get('qvel'), phys.get('qacc_warmstart')
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  for t in range(W, W + K):
+  timed = set(int(round(x)) for x in np.linspace(W, W + span - 1, K))
+  pairs = []
+  for t in range(W, W + span):
+    if t in timed:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
     phys.bind('ctrl', acts[t].data_ptr()); phys.step(nsub, stream=stream)
-  ev1.record()
+    if t in timed:
+      e1.record(); pairs.append((e0, e1))
   torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  kernel_ms = ev0.elapsed_time(ev1) / K
+  K = len(pairs)
+  kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / K
+  elapsed = kernel_ms * 1e-3 * K      # (the timed launches only; the gaps between launches belong to the untimed ones too)
   warn = [int(x) for x in phys.get('warning').sum(axis=0)]
   info = phys.info()
   phys.close()
@@ -459,7 +466,7 @@ def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=1
   out = dict(workload='BASELINE config %d: %s, batch %d, random actions, legacy Physics.step(%d), one launch per env-step'
                       % (cfgid, cfg['workload'], B, nsub),
              value=B * K / elapsed, unit='env-steps/s', physics_steps_per_s=B * K * nsub / elapsed, steps=K, warmup=W,
-             ms_per_step=1e3 * elapsed / K, kernel_ms_avg=kernel_ms, dtype='f32', warnings_after_run=warn,
+             launches_walked=span, ms_per_step=1e3 * elapsed / K, kernel_ms_avg=kernel_ms, dtype='f32', warnings_after_run=warn,
              roofline={'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                        'algorithmic_bytes_per_launch': cfg['algo_bytes'] * B, 'traffic': None,
                        'note': 'nominal bound; counters: bench.py --config %d' % cfgid},
@@ -500,12 +507,12 @@ def env_step_leg(local_rank, B=4096, K=1000, W=20):
   torch.cuda.synchronize()
   el = time.perf_counter() - t0
   stream = torch.cuda.current_stream().cuda_stream
-  for t in range(W):
-    env.physics.step(env.n_sub_steps, stream=stream)
+  for t in range(W):      # physics only: the same action writes and launches, no task layer
+    env.ctrl.copy_(acts[t].T); env.physics.step(env.n_sub_steps, stream=stream)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
-  for t in range(K):
-    env.physics.step(env.n_sub_steps, stream=stream)
+  for t in range(W, W + K):
+    env.ctrl.copy_(acts[t].T); env.physics.step(env.n_sub_steps, stream=stream)
   torch.cuda.synchronize()
   el_phys = time.perf_counter() - t0
   out = dict(workload="suite 'cheetah run' as a device-resident environment (torch_env): obs (B, 17) + reward + done + auto-reset per step",
@@ -719,7 +726,64 @@ def main():
       shard.gather(obs)
     torch.cuda.synchronize(); barrier()
     coll_ms = max_over_ranks((time.perf_counter() - c0) / reps * 1e3)
+    # ---- the same exchange overlapped with the step: the shard as two part-batches, part p's all-gather / scatter in
+    # flight while part p + 1's launch runs (sharding.PipelinedExchange); the "policy" on rank 0 consumes the gathered
+    # observations of a part before it emits that part's next actions (a_{t+1} = pi(o_t))
+    overlapped = None
+    try:
+      P2 = 2
+      if B % P2 == 0:
+        Bp = B // P2
+        ex = sharding.PipelinedExchange(B * world, parts=P2, dist=dist, device=red_dev)
+        pp, pbuf = [], []
+        for p_ in range(P2):
+          ph = BatchedPhysics(model, Bp, device_id=local_rank, precision=args.precision, lanes_per_env=args.lanes, **caps)
+          tq = torch.zeros((model.nq, Bp), dtype=tdtype, device=dev); tv = torch.zeros((model.nv, Bp), dtype=tdtype, device=dev)
+          tsn = torch.zeros((max(1, model.nsensordata), Bp), dtype=tdtype, device=dev); tc = torch.zeros((model.nu, Bp), dtype=tdtype, device=dev)
+          ph.bind('qpos', tq.data_ptr()); ph.bind('qvel', tv.data_ptr()); ph.bind('sensordata', tsn.data_ptr()); ph.bind('ctrl', tc.data_ptr())
+          ph.set('qpos', q_end[p_*Bp:(p_+1)*Bp]); ph.set('qvel', v_end[p_*Bp:(p_+1)*Bp])
+          ph.set_output_mask(mask); ph.forward()
+          pp.append(ph); pbuf.append((tq, tv, tsn, tc))
+        torch.cuda.synchronize()
+        table = torch.rand((8, world * Bp, model.nu), device=red_dev) * 2 - 1 if rank == 0 else None
+
+        def observe(p_):
+          tq, tv, tsn, _ = pbuf[p_]
+          return torch.cat([tq, tv, tsn[:model.nsensordata]], dim=0).T.to(torch.float32).to(red_dev)
+
+        def policy(t, o):
+          return table[t % 8] + 0.0 * o[:, :1]      # (depends on the gathered observations: cannot be issued before them)
+
+        def loop(n, t0_):
+          for t in range(t0_, t0_ + n):
+            for p_ in range(P2):
+              a = ex.scatter_wait(p_)
+              pbuf[p_][3].copy_(a.T.to(dev).to(tdtype))
+              pp[p_].step(nsub, stream=stream)
+              ex.gather_async(p_, observe(p_))
+            for p_ in range(P2):
+              o = ex.gather_wait(p_)
+              ex.scatter_async(p_, policy(t, o) if rank == 0 else None, model.nu)
+        for p_ in range(P2):
+          ex.scatter_async(p_, table[0] if rank == 0 else None, model.nu)
+        Ko = min(K, 50)
+        loop(3, 0)
+        torch.cuda.synchronize(); barrier()
+        o0 = time.perf_counter()
+        loop(Ko, 3)
+        torch.cuda.synchronize(); barrier()
+        ov_s = max_over_ranks(time.perf_counter() - o0)
+        for p_ in range(P2):
+          ex.scatter_wait(p_)
+        overlapped = dict(value=world * B * Ko / ov_s, unit='env-steps/s', steps=Ko, parts=P2, ms_per_env_step=1e3 * ov_s / Ko,
+                          note='policy on rank 0; the shard of every rank as %d part-batches, the exchange of one part in flight '
+                               'while the other part steps (sharding.PipelinedExchange)' % P2)
+        for ph in pp:
+          ph.close()
+    except Exception as ex_:  # pylint: disable=broad-except
+      overlapped = dict(error=repr(ex_)[:300])
     coll = dict(ms_per_env_step=coll_ms, backend=backend, n_ranks_seen=dist.get_world_size(),
+                env_steps_per_s_with_exchange_overlapped=(overlapped or {}).get('value'), overlapped=overlapped,
                 action_bytes=int(B * world * model.nu * 4), observation_bytes=int(B * world * nobs * 4),
                 env_steps_per_s_with_exchange=world * B / (elapsed / K + coll_ms * 1e-3),
                 note='scatter of (B, nu) fp32 actions from rank 0 + all_gather of (B, nq+nv+nsensordata) fp32 '

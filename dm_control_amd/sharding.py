@@ -5,6 +5,12 @@ one process per GPU, with NO collective inside the physics step.  The only
 exchanges are at the agent interface: actions (B, nu) scattered from the learner
 rank and observations / rewards gathered back -- `torch.distributed` over RCCL
 (`backend='nccl'` on ROCm) on the GPU box, `gloo` in CPU tests.
+
+`ShardedEnvBatch` issues the exchange in line with the step (what `bench.py`'s `collectives` leg prices as
+"serialised").  `PipelinedExchange` is the overlap-ready form: every rank's shard is stepped as P part-batches (P = 2:
+double buffering) with one set of exchange buffers and one pending collective per part, so that the all-gather of part
+p's observations and the scatter of its next actions are in flight while part p + 1's step launch runs -- an on-policy
+loop cannot overlap an environment's exchange with ITS OWN next step (a_{t+1} = pi(o_t)), it can with the other half's.
 """
 import numpy as np
 
@@ -116,3 +122,96 @@ class ShardedEnvBatch:
     t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class PipelinedExchange:
+  """Double-buffered agent-interface exchange for P part-batches per rank (see the module docstring).
+
+  Part p of rank r owns the environments `part_bounds[p]` of r's shard; globally, part p is the union of every rank's
+  part p, ordered by rank -- `gather_wait(p)` returns that (B_p, n) matrix and `scatter_async(p, actions)` takes one of the
+  same row order.  Collectives are issued with `async_op=True`: with NCCL / RCCL they are enqueued on the communicator's
+  own stream behind whatever the current stream has produced, and `*_wait` makes the current stream (not the host) wait
+  for them; with gloo they run on its worker threads.  The order of the calls is the overlap:
+
+      for p in parts:  a = scatter_wait(p); step(p, a); gather_async(p, observe(p))     # part p + 1's launch is enqueued
+      for p in parts:  o = gather_wait(p); scatter_async(p, policy(o))                   # behind part p's all-gather
+
+  Every environment sees exactly the operations, in exactly the order, of the serial loop (scatter, step, gather) -- the
+  parts only interleave -- so trajectories are bit-equal to `ShardedEnvBatch`'s (tests/test_sharding_gloo.py)."""
+
+  def __init__(self, global_batch, parts=2, dist=None, device='cpu'):
+    import torch
+    self._torch = torch
+    self.dist = dist
+    self.world = dist.get_world_size() if dist is not None else 1
+    self.rank = dist.get_rank() if dist is not None else 0
+    self.parts = int(parts)
+    self.device = device
+    self.lo, self.hi = shard_bounds(global_batch, self.world, self.rank)
+    local = self.hi - self.lo
+    sizes = set(shard_sizes(global_batch, self.world))
+    if len(sizes) != 1 or local % self.parts:
+      raise ValueError('PipelinedExchange needs equal shards that divide into %d equal parts (got shard sizes %s)'
+                       % (self.parts, sorted(sizes)))
+    self.part_size = local // self.parts
+    # local row ranges of this rank's parts, and the global env index of every row of part p's gathered matrix
+    self.part_bounds = [(p * self.part_size, (p + 1) * self.part_size) for p in range(self.parts)]
+    self._buffers = {}
+    self._pending_gather = [None] * self.parts
+    self._pending_scatter = [None] * self.parts
+
+  def global_rows(self, p):
+    """Environment index (in the global batch) of every row of part p's gathered matrix / global action matrix."""
+    rows = []
+    for r in range(self.world):
+      lo = shard_bounds(self.part_size * self.parts * self.world, self.world, r)[0] + p * self.part_size
+      rows.extend(range(lo, lo + self.part_size))
+    return np.asarray(rows)
+
+  def _buffer(self, tag, shape, dtype):
+    key = (tag, tuple(shape), dtype)
+    b = self._buffers.get(key)
+    if b is None:
+      b = self._buffers[key] = self._torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+    return b
+
+  def gather_async(self, p, local):
+    """local: (part_size, n) observations of this rank's part p (consumed when the call returns: it is copied into the
+    part's own send buffer, so the caller's tensor -- e.g. a HIP graph's output -- may be rewritten by the next step)."""
+    tail = tuple(local.shape[1:])
+    send = self._buffer(('obs_send', p), (self.part_size,) + tail, local.dtype)
+    send.copy_(local)
+    if self.world == 1:
+      self._pending_gather[p] = (None, send)
+      return
+    recv = self._buffer(('obs_recv', p), (self.world * self.part_size,) + tail, local.dtype)
+    self._pending_gather[p] = (self.dist.all_gather_into_tensor(recv, send, async_op=True), recv)
+
+  def gather_wait(self, p):
+    work, recv = self._pending_gather[p]
+    self._pending_gather[p] = None
+    if work is not None:
+      work.wait()
+    return recv
+
+  def scatter_async(self, p, actions_global, nu, src=0):
+    """actions_global: (world * part_size, nu) float32 on rank `src` (None elsewhere), rows as `global_rows(p)`."""
+    torch = self._torch
+    out = self._buffer(('act_recv', p), (self.part_size, nu), torch.float32)
+    if self.world == 1:
+      out.copy_(actions_global)
+      self._pending_scatter[p] = (None, out)
+      return
+    chunks = None
+    if self.rank == src:
+      stage = self._buffer(('act_stage', p), (self.world * self.part_size, nu), torch.float32)
+      stage.copy_(actions_global)
+      chunks = list(stage.split(self.part_size))
+    self._pending_scatter[p] = (self.dist.scatter(out, chunks, src=src, async_op=True), out)
+
+  def scatter_wait(self, p):
+    work, out = self._pending_scatter[p]
+    self._pending_scatter[p] = None
+    if work is not None:
+      work.wait()
+    return out
