@@ -88,7 +88,7 @@ def parse(argv=None):
   ap.add_argument('--parity-envs', type=int, default=None)
   ap.add_argument('--parity-steps', type=int, default=None)
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--pipeline', type=int, default=2, help='part-batches of the pipelined leg (0 / 1 = skip)')
+  ap.add_argument('--pipeline', type=str, default='2,4', help='part-batch counts of the pipelined leg, comma-separated (0 / 1 = skip)')
   ap.add_argument('--cpu-envs', type=int, default=4096)
   ap.add_argument('--cpu-seconds', type=float, default=10.0)
   ap.add_argument('--pmc-child', action='store_true', help='internal: only the timed launches (run under rocprofv3 by the parent)')
@@ -662,9 +662,10 @@ def main():
   # ---- pipelined leg: the SAME B environments as P independent part-batches on P streams (part p's launch t+1 waits for
   # part p's launch t only, so the straggler tail of one part's queued launch overlaps the next part's launch).  A usage
   # mode of the existing API (P BatchedPhysics objects), reported beside `value`, never as `value`.
-  pipe = None
-  P = args.pipeline
-  if P > 1 and B % P == 0:
+  pipe, pipes = None, []
+  for P in [int(x) for x in str(args.pipeline).split(',') if x.strip()]:
+    if not (P > 1 and B % P == 0):
+      continue
     Bp = B // P
     parts, pstreams, pctrl = [], [], []
     for p in range(P):
@@ -709,6 +710,9 @@ def main():
                      'single-batch run' % (P, P))
     for ph in parts:
       ph.close()
+    pipes.append(pipe)
+  if pipes:      # `pipelined`: the best part count; every count measured is listed under `by_parts`
+    pipe = dict(max(pipes, key=lambda d_: d_['value']), by_parts={str(d_['parts']): d_['value'] for d_ in pipes})
 
   # ---- agent-interface collectives (N > 1): actions scattered from rank 0, observations gathered to all ranks
   coll = None

@@ -19,7 +19,7 @@ EXPORTS = [
     'dmc_batch_debug_enable', 'dmc_batch_debug_get', 'dmc_batch_prof_enable',
     'dmc_batch_prof_get', 'dmc_gather_create', 'dmc_gather_destroy', 'dmc_gather_run',
     'dmc_batch_set_env_geoms', 'dmc_env_geom_pack', 'dmc_batch_wave_trace', 'dmc_batch_randomize_joints',
-    'dmc_batch_attach_specialised',
+    'dmc_batch_attach_specialised', 'dmc_batch_set_task_args', 'dmc_batch_enable_task',
 ]
 
 _lib = None
@@ -97,6 +97,9 @@ def lib():
   L.dmc_batch_randomize_joints.argtypes = [vp, ctypes.c_uint64, vp, vp, ci, vp]
   if hasattr(L, 'dmc_batch_attach_specialised'):      # (absent from the older libraries A/B runs load as variants)
     L.dmc_batch_attach_specialised.argtypes = [vp, cs]
+  if hasattr(L, 'dmc_batch_set_task_args'):
+    L.dmc_batch_set_task_args.argtypes = [vp, vp, ci]
+    L.dmc_batch_enable_task.argtypes = [vp, ci]
   _lib = L
   return L
 

@@ -67,6 +67,15 @@ class BatchedPhysics:
       _spec.poll(self, block=True, timeout=timeout)
     return self.specialised
 
+  def set_task_args(self, blob):
+    """dmc_batch_set_task_args: the argument block (bytes) of the task epilogue the attached kernel was built with."""
+    buf = (ctypes.c_char * len(blob)).from_buffer_copy(blob)
+    _native.check(_native.lib().dmc_batch_set_task_args(self._ptr, ctypes.cast(buf, ctypes.c_void_p), len(blob)))
+
+  def enable_task(self, on):
+    """dmc_batch_enable_task: whether the step launches enqueued from now on end with the task epilogue."""
+    _native.check(_native.lib().dmc_batch_enable_task(self._ptr, int(bool(on))))
+
   def close(self):
     L = _native.lib()
     if getattr(self, '_ptr', None):

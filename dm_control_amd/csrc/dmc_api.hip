@@ -85,6 +85,8 @@ struct dmc_batch {
   // a model-specialised kernel built on demand for this model (dmc_batch_attach_specialised): the loaded object, its launch
   // entry, whether it holds the optional launch features (step_core.h kFeat)
   void* spec_so = nullptr; void* spec_launch = nullptr; int spec_features = 0;
+  int spec_task_bytes = 0;      // > 0: the attached kernel carries a task epilogue with an argument block of this size
+  void* d_task_args = nullptr; int task_on = 0;      // its arguments on the device; whether the next step launches run it
 };
 
 extern "C" const char* dmc_last_error(void) { return g_err.c_str(); }
@@ -348,6 +350,7 @@ extern "C" void dmc_batch_destroy(dmc_batch* b) {
   if (b->d_order) (void)hipFree(b->d_order);
   if (b->d_prog) (void)hipFree(b->d_prog);
   if (b->d_hand) (void)hipFree(b->d_hand);
+  if (b->d_task_args) (void)hipFree(b->d_task_args);
   if (b->d_trace) (void)hipFree(b->d_trace);
   if (b->d_rj_i) (void)hipFree(b->d_rj_i);
   if (b->d_rj_r) (void)hipFree(b->d_rj_r);
@@ -374,6 +377,7 @@ static void fill_io(dmc_batch* b, StepIO<T>* io) {
   io->cost = b->lpt ? b->d_cost : nullptr; io->order = b->lpt ? b->d_order : nullptr;
   io->prog = nullptr; io->slices = 0; io->hand = b->d_hand; io->hand_n = b->hand_n;      // (slices: launch_untimed, step launches of a queued batch only)
   io->nxcd = b->geom.queue ? b->nxcd : 1;
+  io->task_args = (b->task_on && b->spec_launch) ? b->d_task_args : nullptr;
   io->trace = b->d_trace; io->trace_slot = b->d_trace ? b->trace_launch++ : 0;
   io->debug = (T*)b->d_debug; io->debug_i = b->d_debug_i; io->ndebug = b->ndebug;
   io->kstash = (T*)b->d_kstash; io->kstash_i = b->d_kstash_i;
@@ -522,6 +526,26 @@ extern "C" int dmc_batch_attach_specialised(dmc_batch* b, const char* so_path) {
   if (memcmp(fl(), &b->tb.L, sizeof(StepLayout)) != 0) { dlclose(h); return fail("the plugin's layout is not this batch's (another model or other caps)"); }
   if (b->spec_so) dlclose(b->spec_so);
   b->spec_so = h; b->spec_launch = launch; b->spec_features = info[6];
+  typedef int (*tb_t)();
+  tb_t tb = (tb_t)dlsym(h, "dmc_spec_task_args_bytes");
+  b->spec_task_bytes = tb ? tb() : 0;
+  b->task_on = 0;
+  return 0;
+}
+
+extern "C" int dmc_batch_set_task_args(dmc_batch* b, const void* args, int nbytes) {
+  if (!b || !args) return fail("null argument");
+  if (!b->spec_task_bytes) return fail("the batch's kernel carries no task epilogue (attach a plugin built with a task header)");
+  if (nbytes != b->spec_task_bytes) return fail("task argument block: size differs from the one the kernel was generated with");
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->d_task_args) HIP_TRY(hipMalloc(&b->d_task_args, (size_t)nbytes));
+  HIP_TRY(hipMemcpy(b->d_task_args, args, (size_t)nbytes, hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int dmc_batch_enable_task(dmc_batch* b, int on) {
+  if (!b) return fail("null batch");
+  if (on && (!b->spec_task_bytes || !b->d_task_args)) return fail("no task epilogue to enable (dmc_batch_set_task_args first)");
+  b->task_on = on ? 1 : 0;
   return 0;
 }
 

@@ -121,6 +121,11 @@ struct StepIO {
   // nxcd: queues of a queued launch, one per XCD (step_kernel_body); 1 = a single queue.
   int* prog = nullptr; int slices = 0; int nxcd = 1;
   unsigned long long* hand = nullptr; int hand_n = 0;
+  // Task epilogue (kernels built with -DDMC_TASK_HEADER: suite/fused_env.py): device copy of the generated task layer's
+  // argument block; non-null: after an environment's step launch the wave that ran it evaluates that environment's
+  // observation / reward / termination and, where the episode ended, writes the next start state -- the whole
+  // control.Environment.step (rl/control.py:99-127) in one launch.  Ignored by kernels built without a task.
+  const void* task_args = nullptr;
   // optional wave trace (dmc_batch_wave_trace): a ring of the last 8 launches, (8, 8, nitems) ints; per launch the rows
   // are the constant-rate clock (100 MHz) at which the item's wave entered the kernel (before the tables are staged),
   // started and finished the item, its workgroup index, and the clock after the opening position / velocity stage, the

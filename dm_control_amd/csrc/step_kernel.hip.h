@@ -8,6 +8,10 @@
 #define DMC_STEP_CORE_HEADER "step_core.h"
 #endif
 #include DMC_STEP_CORE_HEADER
+#ifdef DMC_TASK_HEADER      // (a specialisation plugin with a task epilogue: dm_control_amd/suite/fused_env.py)
+#define DMC_TASK_IN_KERNEL 1
+#include DMC_TASK_HEADER
+#endif
 
 namespace dmc {
 
@@ -168,6 +172,14 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     if (tr && (threadIdx.x & 63) == 0 && piece == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en, piece, npieces);
+#ifdef DMC_TASK_HEADER
+    // the generated task layer of this model's task (suite/fused_env.py), by one lane per environment: it reads what the
+    // launch has just stored (loads that bypass the L1, after the wave's stores are acknowledged)
+    if (io.task_args && mode == 0 && piece == npieces - 1 && env < io.B) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) dmc_task::task_post(*(const dmc_task::PostArgs*)io.task_args, env);
+    }
+#endif
     if (tr && (threadIdx.x & 63) == 0 && piece == npieces - 1) {
       tr[2*nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
       tr[3*nitems + item] = (int)blockIdx.x;

@@ -30,3 +30,7 @@ extern "C" int dmc_spec_launch(const LaunchGeom* g, void* stream, const StepLayo
   gg.static_id = 0;
   return (int)launch_step_t<spec_real>(gg, (hipStream_t)stream, d_layout, *o, g_mi, g_mr, g_mc, *io, nstep, legacy, mode, outmask, nsub);
 }
+#ifdef DMC_TASK_HEADER
+// the size of the task's argument block this kernel was generated with (dmc_batch_set_task_args checks it)
+extern "C" int dmc_spec_task_args_bytes() { return (int)sizeof(dmc_task::PostArgs); }
+#endif

@@ -98,24 +98,28 @@ def _lean(model):
   return model.nv < 30
 
 
-def key(model, precision, lpe, caps):
+def key(model, precision, lpe, caps, task_header=None):
   ints, reals = model.pack()
   h = hashlib.sha1()
+  if task_header:      # a kernel with a task epilogue (suite/fused_env.py): the generated header is part of the object
+    with open(task_header, 'rb') as fh:
+      h.update(b'task:' + fh.read())
   h.update(ints.tobytes()); h.update(reals.tobytes())
   h.update(repr((int(precision), int(lpe), tuple(int(c) for c in caps), _lean(model), source_hash(), toolchain_id())).encode())
   h.update(os.environ.get('DMC_SPEC_FLAGS', '').encode())
   return h.hexdigest()[:24]
 
 
-def path_for(model, precision, lpe, caps):
-  return os.path.join(cache_dir(), 'libdmc_spec_%s.so' % key(model, precision, lpe, caps))
+def path_for(model, precision, lpe, caps, task_header=None):
+  return os.path.join(cache_dir(), 'libdmc_spec_%s.so' % key(model, precision, lpe, caps, task_header))
 
 
-def build(model, precision=32, lpe=None, caps=(0, 0, 0), verbose=False):
+def build(model, precision=32, lpe=None, caps=(0, 0, 0), verbose=False, task_header=None):
   """Compiles the plugin for (model, caps = (nconmax, njmax, njcon) as given to the batch, precision, lanes); returns its
-  path.  No-op when it is cached."""
+  path.  No-op when it is cached.  task_header: a task layer generated by suite/fused_env.py, evaluated by the kernel
+  itself at the end of every step launch (the kernel then holds the optional launch features too)."""
   lpe = int(lpe or (32 if model.nv <= 12 else 64))
-  out = path_for(model, precision, lpe, caps)
+  out = path_for(model, precision, lpe, caps, task_header)
   if os.path.exists(out):
     return out
   # (-DDMC_PROFILE=1 among DMC_SPEC_FLAGS: the layout with the phase counters, for batches of libdmc_hip_prof.so)
@@ -146,6 +150,8 @@ def build(model, precision=32, lpe=None, caps=(0, 0, 0), verbose=False):
         flags += ['-mllvm', '-amdgpu-sched-strategy=max-ilp']      # as build.py's unit of the large models
     flags += ['-DDMC_LAYOUTS_HEADER="%s"' % hdr, '-DDMC_SPEC_PRECISION=%d' % precision, '-DDMC_SPEC_LPE=%d' % lpe,
               '-DDMC_STATIC_FEATURES=%d' % (0 if (_lean(model) and precision == 32) else 1)]
+    if task_header:
+      flags += ['-DDMC_TASK_HEADER="%s"' % os.path.abspath(task_header)]
     flags += shlex.split(os.environ.get('DMC_SPEC_FLAGS', ''))
     tmp = out + '.%d.tmp' % os.getpid()
     cmd = [_build.HIPCC] + flags + ['-shared', '-o', tmp, os.path.join(CSRC, 'step_kernel_spec.hip')]
@@ -268,3 +274,23 @@ def poll(batch, block=False, timeout=None):
   if ok:
     _log.warning('dm_control_amd: %s switched to its specialised step kernel', _describe(batch))
   return batch.specialised
+
+
+def attach_task(batch, task_header, verbose=False):
+  """Builds (blocking; cached) and attaches this batch's specialised kernel WITH the task epilogue of `task_header` -- also
+  for a model whose plain kernel is baked into the library.  Returns True, or False when the object could not be built or
+  was refused (the caller keeps its separate task kernel)."""
+  info = batch.info()
+  caps = tuple(getattr(batch, '_user_caps', (0, 0, 0)))
+  if batch.model.nv > 16 and info['global_scratch_bytes_per_env'] == 0:
+    caps = caps + (1,)
+  try:
+    p = build(batch.model, batch.precision, info['lanes_per_env'], caps, verbose=verbose, task_header=task_header)
+  except (subprocess.CalledProcessError, OSError) as ex:
+    _log.warning('dm_control_amd: %s: the kernel with the task epilogue could not be built (%r)', _describe(batch), ex)
+    return False
+  batch._spec_future = None      # pylint: disable=protected-access  (a plain kernel still building in the background is not wanted any more)
+  if not _try_attach(batch, p):
+    return False
+  batch.specialised = 'attached'
+  return True

@@ -35,14 +35,14 @@ def read_model(filename):
 def asarray(x, dtype=None):
   """`np.asarray(x, dtype)` for the task code: numpy inputs take exactly that call; a device array (suite/device_env.TArr:
   the same task code evaluated on GPU tensors) stays where it is."""
-  if type(x).__name__ == 'TArr':
+  if type(x).__name__ in ('TArr', 'SArr'):
     return x.astype(dtype) if dtype is not None else x
   return np.asarray(x) if dtype is None else np.asarray(x, dtype=dtype)
 
 
 def array_copy(x, dtype=None):
   """`np.array(x, dtype, copy=True)` likewise."""
-  if type(x).__name__ == 'TArr':
+  if type(x).__name__ in ('TArr', 'SArr'):
     y = x.copy()
     return y.astype(dtype) if dtype is not None else y
   return np.array(x, copy=True) if dtype is None else np.array(x, dtype=dtype, copy=True)

@@ -437,7 +437,7 @@ def _make_view_class(cls):
       host = self.__dict__['_host']
       if name in host.__dict__ or hasattr(type(host), name):
         val = getattr(host, name)
-        if isinstance(val, np.ndarray) and val.ndim >= 1 and val.shape[0] == self.batch_size and val.dtype.kind == 'f':
+        if isinstance(val, np.ndarray) and val.ndim >= 1 and val.dtype.kind == 'f' and (val.shape[0] == self.batch_size or self.batch_size == 1):
           return self._episode_tensor(name, val)
         return val
       raise AttributeError(name)
@@ -553,13 +553,23 @@ class GenericDeviceEnv:
     self._copy_outputs = bool(copy_outputs)
     self._term_every = int(termination_check_every)
     self._has_termination = type(self.task).get_termination is not _base_termination()
-    TArr.default_float = self.dtype
+    # host constants that reach a torch op are cached on the device PER ENVIRONMENT (a captured graph reads them by
+    # address: they must live exactly as long as this environment) and python floats take THIS environment's precision:
+    # both are switched in at the start of every call (two environments of different precision in one process)
+    self._consts = {}
+    self._activate()
     self.reset()
+
+  def _activate(self):
+    global _CONST
+    _CONST = self._consts
+    TArr.default_float = self.dtype
 
   # -- episode start ---------------------------------------------------------------------------------------------------
   def reset(self):
     """Restarts every environment: the host port's `initialize_episode` under `reset_context` through the facade, exactly
     what `control.Environment.reset` does (rl/control.py:70-83)."""
+    self._activate()
     p = self.host_physics
     p.data._invalidate()      # pylint: disable=protected-access  (the device moved since the facade last looked)
     with p.reset_context():
@@ -574,7 +584,9 @@ class GenericDeviceEnv:
     for k, val in vars(p).items():
       if k.startswith('_') or k in ('model', 'batch', 'data', 'named', 'batch_size', 'legacy_step'):
         continue
-      if isinstance(val, np.ndarray) and val.ndim >= 1 and val.shape[0] == self.B and val.dtype.kind == 'f':
+      # (B == 1: the ports drop the batch axis -- `xy[0] if B == 1 else xy` -- so ANY float array is per-episode data that
+      # must be refreshed in place: as a host array it would be baked into the captured graph at its first value)
+      if isinstance(val, np.ndarray) and val.ndim >= 1 and val.dtype.kind == 'f' and (val.shape[0] == self.B or self.B == 1):
         v.__dict__[k] = v._episode_tensor(k, val)
       else:
         v.__dict__[k] = val
@@ -583,12 +595,14 @@ class GenericDeviceEnv:
 
   # -- task --------------------------------------------------------------------------------------------------------------
   def observation(self):
+    self._activate()
     obs = self.task.get_observation(self.view)
     self.observation_layout = collections.OrderedDict((k, tuple(v.shape[1:])) for k, v in obs.items())
     ts = [v.t.reshape(self.B, -1).to(self.dtype) for v in obs.values()]
     return self.torch.cat(ts, dim=1)
 
   def reward(self):
+    self._activate()
     r = self.task.get_reward(self.view)
     if isinstance(r, TArr):
       return r.t.to(self.dtype).reshape(self.B)
@@ -644,7 +658,9 @@ class GenericDeviceEnv:
   def step(self, action):
     """action: (B, nu) tensor on the device.  Returns (obs, reward, done); when the time limit is reached every
     environment restarts and the returned observation is the new episode's first.  With `capture=True,
-    copy_outputs=False` obs and reward are the HIP graph's own output tensors, overwritten by the next step()."""
+    copy_outputs=False` obs and reward are the HIP graph's own output tensors, overwritten by the next step().
+    (Per-environment episode ends and restarts without the host: suite/fused_env.py.)"""
+    self._activate()
     if self._capture:
       obs, rew = self._captured_step(action)
       if self._copy_outputs:
@@ -667,6 +683,7 @@ class GenericDeviceEnv:
 
   def close(self):
     self._graph = None
+    self._consts = {}
     self.host_physics.free()
 
 

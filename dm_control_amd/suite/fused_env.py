@@ -1,0 +1,1122 @@
+"""Suite tasks as device-resident environments whose whole task layer is ONE generated HIP kernel (SURVEY.md 8(f) row 1;
+VERDICT r05 #3).
+
+`suite/device_env.py` runs the host ports' `get_observation / get_reward` on GPU tensors through numpy's dispatch
+protocols: correct for all 45 tasks, but every numpy call becomes its own 3 - 4 us torch kernel, and a cartpole step is
+70 us of physics next to ~30 of them (env rate 0.45 of the physics rate, round 5).  This module compiles the same task
+code instead:
+
+  trace    the host port's `get_observation / get_reward / termination_mask` are executed ONCE on a symbolic view of the
+           physics -- the domain's own `Physics` subclass at batch size 1 (the single-environment code path, i.e. the
+           reference's own formulas), whose `data.*` arrays are numpy object arrays of expression nodes (`SArr`; leaves =
+           "row k of field F of this environment").  numpy does the shape work (named indexing, slicing, concatenation,
+           reshape); arithmetic, ufuncs, `np.where`, norms, dot / einsum build a hash-consed expression DAG.
+  codegen  the DAG of every observation entry, the reward and the termination flag is written out as straight-line C++,
+           one GPU thread per environment (the batch is the thread index: every task expression is per-environment),
+           compiled by hipcc for gfx950 into a small shared object cached by source hash (as specialise.py's plugins).
+  run      a control step is three launches recorded in one HIP graph:
+             pre   environments whose episode ended in the previous step take a start state (and the per-episode task
+                   attributes: targets ...) from a device-resident pool drawn by the host port's own
+                   `initialize_episode`, get `env_mode` 1 (mj_forward without actuation instead of a step,
+                   rl/control.py:232-253) and step count 0; the action matrix (B, nu) is transposed into `ctrl`
+             step  the fused physics launch (dmc_batch_step with the per-environment launch override)
+             post  observation (B, nobs), reward, termination, step counters, `done` / `first` / `discount` -- per
+                   ENVIRONMENT: an lqr environment ends at the step its own state norm falls below the tolerance
+                   (suite/lqr.py:264), not when the whole batch has
+  No host read per step, episode boundaries included.  dm_env semantics, vectorised: the step in which an episode ends
+  returns its last observation / reward with done = True; the NEXT step returns the first observation of the new episode
+  (first = True, reward 0) while the rest of the batch steps -- the reference's LAST / FIRST pair (rl/control.py:99-127).
+
+torch is plumbing here (memory, the graph capture); the physics is the fused HIP step kernel, the task layer the generated one.
+"""
+import collections
+import ctypes
+import hashlib
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# expression DAG
+# ---------------------------------------------------------------------------------------------------------------------
+class Sym:
+  """One scalar expression node.  kind: 'f' real, 'b' boolean, 'i' integer."""
+  __slots__ = ('op', 'args', 'kind', 'id')
+
+  def __init__(self, op, args, kind, id_):
+    self.op, self.args, self.kind, self.id = op, args, kind, id_
+
+  def __repr__(self):
+    return 'Sym(%s#%d)' % (self.op, self.id)
+
+  def __bool__(self):
+    raise TypeError('fused_env: the task code branched on a device value (%r); per-environment decisions must be '
+                    'np.where expressions' % (self,))
+
+  __float__ = __int__ = __index__ = __bool__
+
+
+_UNARY_C = {'neg': '-%s', 'abs': 'fabs(%s)', 'sqrt': 'sqrt(%s)', 'exp': 'exp(%s)', 'log': 'log(%s)', 'log1p': 'log1p(%s)',
+            'sin': 'sin(%s)', 'cos': 'cos(%s)', 'tan': 'tan(%s)', 'arcsin': 'asin(%s)', 'arccos': 'acos(%s)',
+            'arctan': 'atan(%s)', 'sinh': 'sinh(%s)', 'cosh': 'cosh(%s)', 'tanh': 'tanh(%s)', 'arccosh': 'acosh(%s)',
+            'arctanh': 'atanh(%s)', 'arcsinh': 'asinh(%s)', 'expm1': 'expm1(%s)', 'floor': 'floor(%s)', 'ceil': 'ceil(%s)',
+            'log2': 'log2(%s)', 'log10': 'log10(%s)', 'sign': '(T)((%s > 0) - (%s < 0))', 'not': '!%s'}
+_UNARY_NP = {'neg': np.negative, 'abs': np.abs, 'sqrt': np.sqrt, 'exp': np.exp, 'log': np.log, 'log1p': np.log1p,
+             'sin': np.sin, 'cos': np.cos, 'tan': np.tan, 'arcsin': np.arcsin, 'arccos': np.arccos, 'arctan': np.arctan,
+             'sinh': np.sinh, 'cosh': np.cosh, 'tanh': np.tanh, 'arccosh': np.arccosh, 'arctanh': np.arctanh,
+             'arcsinh': np.arcsinh, 'expm1': np.expm1, 'floor': np.floor, 'ceil': np.ceil, 'log2': np.log2,
+             'log10': np.log10, 'sign': np.sign, 'not': np.logical_not}
+_BINARY_C = {'add': '%s + %s', 'sub': '%s - %s', 'mul': '%s * %s', 'div': '%s / %s', 'pow': 'pow(%s, %s)',
+             'max': 'fmax(%s, %s)', 'min': 'fmin(%s, %s)', 'arctan2': 'atan2(%s, %s)', 'hypot': 'hypot(%s, %s)',
+             'lt': '%s < %s', 'le': '%s <= %s', 'gt': '%s > %s', 'ge': '%s >= %s', 'eq': '%s == %s', 'ne': '%s != %s',
+             'and': '%s && %s', 'or': '%s || %s'}
+_BINARY_NP = {'add': np.add, 'sub': np.subtract, 'mul': np.multiply, 'div': np.true_divide, 'pow': np.power,
+              'max': np.maximum, 'min': np.minimum, 'arctan2': np.arctan2, 'hypot': np.hypot, 'lt': np.less,
+              'le': np.less_equal, 'gt': np.greater, 'ge': np.greater_equal, 'eq': np.equal, 'ne': np.not_equal,
+              'and': np.logical_and, 'or': np.logical_or}
+_BOOL_OPS = {'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'and', 'or', 'not'}
+
+
+class Graph:
+  """Hash-consed expression nodes; constants are folded in double precision at trace time."""
+
+  def __init__(self):
+    self.nodes = []
+    self._index = {}
+    self.fields = []      # (name, kind) of the mjData fields the expressions load from, in first-use order
+    self.attrs = []       # names of the per-episode attributes
+
+  def _make(self, op, args, kind):
+    key = (op, kind, tuple(a.id if isinstance(a, Sym) else ('c', type(a).__name__, a) for a in args))
+    n = self._index.get(key)
+    if n is None:
+      n = Sym(op, tuple(args), kind, len(self.nodes))
+      self.nodes.append(n)
+      self._index[key] = n
+    return n
+
+  def const(self, v):
+    if isinstance(v, (bool, np.bool_)):
+      return self._make('const', (bool(v),), 'b')
+    return self._make('const', (float(v),), 'f')
+
+  def lift(self, x):
+    if isinstance(x, Sym):
+      return x
+    if isinstance(x, (bool, np.bool_, int, float, np.integer, np.floating)):
+      return self.const(x)
+    raise TypeError('fused_env: cannot use %r (%s) in a task expression' % (x, type(x).__name__))
+
+  def load(self, field, row, kind='f'):
+    if (field, kind) not in self.fields:
+      self.fields.append((field, kind))
+    return self._make('load', (self.fields.index((field, kind)), int(row)), kind)
+
+  def attr(self, name, j, width):
+    if (name, width) not in self.attrs:
+      self.attrs.append((name, width))
+    return self._make('attr', (self.attrs.index((name, width)), int(j)), 'f')
+
+  def unary(self, op, x):
+    x = self.lift(x)
+    if x.op == 'const':
+      with np.errstate(all='ignore'):
+        return self.const(_UNARY_NP[op](x.args[0]))
+    if op == 'not' and x.kind != 'b':
+      x = self.binary('ne', x, 0.0)
+    return self._make(op, (x,), 'b' if op in _BOOL_OPS else 'f')
+
+  def binary(self, op, x, y):
+    x, y = self.lift(x), self.lift(y)
+    if x.op == 'const' and y.op == 'const':
+      with np.errstate(all='ignore'):
+        return self.const(_BINARY_NP[op](x.args[0], y.args[0]))
+    if op in ('and', 'or'):
+      x = x if x.kind == 'b' else self.binary('ne', x, 0.0)
+      y = y if y.kind == 'b' else self.binary('ne', y, 0.0)
+    # cheap identities the task code produces in bulk (x * 1, x + 0, x ** 2)
+    if op == 'pow' and y.op == 'const':
+      if y.args[0] == 2.0:
+        return self.binary('mul', x, x)
+      if y.args[0] == 1.0:
+        return x
+      if y.args[0] == 0.5:
+        return self.unary('sqrt', x)
+    if op == 'mul':
+      for a, b in ((x, y), (y, x)):
+        if a.op == 'const' and a.kind == 'f' and a.args[0] == 1.0:
+          return b
+    if op == 'add':
+      for a, b in ((x, y), (y, x)):
+        if a.op == 'const' and a.kind == 'f' and a.args[0] == 0.0 and b.kind == 'f':
+          return b
+    if op == 'sub' and y.op == 'const' and y.args[0] == 0.0 and x.kind == 'f':
+      return x
+    if op == 'div' and y.op == 'const' and y.args[0] == 1.0 and x.kind == 'f':
+      return x
+    return self._make(op, (x, y), 'b' if op in _BOOL_OPS else 'f')
+
+  def where(self, c, x, y):
+    c, x, y = self.lift(c), self.lift(x), self.lift(y)
+    if c.kind != 'b':
+      c = self.binary('ne', c, 0.0)
+    if c.op == 'const':
+      return x if c.args[0] else y
+    if x is y:
+      return x
+    kind = 'b' if (x.kind == 'b' and y.kind == 'b') else 'f'
+    return self._make('where', (c, x, y), kind)
+
+
+def evaluate(g, outputs, load, attr):
+  """Reference interpreter of the DAG in float64 numpy (tests: the generated kernel and the host port must both agree
+  with it).  load(field, row) / attr(name, j) return the leaf values (scalars or (B,) arrays)."""
+  val = {}
+
+  def ev(n):
+    stack = [n]
+    while stack:
+      m = stack[-1]
+      if m.id in val:
+        stack.pop()
+        continue
+      todo = [a for a in m.args if isinstance(a, Sym) and a.id not in val]
+      if todo:
+        stack.extend(todo)
+        continue
+      stack.pop()
+      xs = [val[a.id] if isinstance(a, Sym) else a for a in m.args]
+      with np.errstate(all='ignore'):
+        if m.op == 'const':
+          v = m.args[0]
+        elif m.op == 'load':
+          name, kind = g.fields[m.args[0]]
+          v = load(name, m.args[1])
+        elif m.op == 'attr':
+          v = attr(g.attrs[m.args[0]][0], m.args[1])
+        elif m.op == 'where':
+          v = np.where(xs[0], xs[1], xs[2])
+        elif m.op in _UNARY_NP:
+          v = _UNARY_NP[m.op](np.asarray(xs[0], dtype=bool if m.op == 'not' else np.float64))
+        else:
+          v = _BINARY_NP[m.op](*[np.asarray(x, dtype=bool if m.op in ('and', 'or') else np.float64) for x in xs])
+      val[m.id] = v
+    return val[n.id]
+  return [ev(n) for n in outputs]
+
+
+_G = None      # the graph being traced (one trace at a time; guarded by FusedDeviceEnv)
+
+
+def _g():
+  if _G is None:
+    raise RuntimeError('fused_env: symbolic arrays are only alive during a trace')
+  return _G
+
+
+def _obj(x):
+  """Operand -> numpy object array of Sym / python scalars."""
+  if isinstance(x, SArr):
+    return x.a
+  if isinstance(x, Sym):
+    a = np.empty((), dtype=object); a[()] = x
+    return a
+  return np.asarray(x)
+
+
+def _elementwise(fn, *xs):
+  out = np.frompyfunc(fn, len(xs), 1)(*[_obj(x) for x in xs])
+  if not isinstance(out, np.ndarray):
+    a = np.empty((), dtype=object); a[()] = out
+    out = a
+  return SArr(out)
+
+
+class SArr:
+  """numpy-compatible array of expression nodes (single-environment shapes; the batch is the kernel's thread index)."""
+
+  __array_priority__ = 2000
+  __hash__ = None
+
+  def __init__(self, a):
+    if not isinstance(a, np.ndarray):
+      b = np.empty((), dtype=object); b[()] = a
+      a = b
+    self.a = a
+
+  shape = property(lambda self: self.a.shape)
+  ndim = property(lambda self: self.a.ndim)
+  size = property(lambda self: self.a.size)
+  dtype = property(lambda self: np.dtype(np.float64))
+  T = property(lambda self: SArr(self.a.T))
+
+  def __len__(self):
+    return len(self.a)
+
+  def __iter__(self):
+    return (SArr(x) for x in self.a)
+
+  def __repr__(self):
+    return 'SArr(shape=%r)' % (self.a.shape,)
+
+  def _host(self, *a, **k):
+    raise TypeError('fused_env: the task code converted a device value to a host value (np.asarray / float / bool / if); '
+                    'per-environment decisions must stay numpy expressions')
+  __array__ = __float__ = __bool__ = __int__ = _host
+
+  def __getitem__(self, key):
+    if isinstance(key, tuple):
+      key = tuple(k.a if isinstance(k, SArr) else k for k in key)
+    return SArr(self.a[key])
+
+  def __setitem__(self, key, value):
+    self.a[key] = _obj(value)
+
+  def _bin(self, op, o, rev=False):
+    g = _g()
+    return _elementwise((lambda p, q: g.binary(op, q, p)) if rev else (lambda p, q: g.binary(op, p, q)), self, o)
+
+  def __add__(self, o): return self._bin('add', o)
+  def __radd__(self, o): return self._bin('add', o, True)
+  def __sub__(self, o): return self._bin('sub', o)
+  def __rsub__(self, o): return self._bin('sub', o, True)
+  def __mul__(self, o): return self._bin('mul', o)
+  def __rmul__(self, o): return self._bin('mul', o, True)
+  def __truediv__(self, o): return self._bin('div', o)
+  def __rtruediv__(self, o): return self._bin('div', o, True)
+  def __pow__(self, o): return self._bin('pow', o)
+  def __rpow__(self, o): return self._bin('pow', o, True)
+  def __lt__(self, o): return self._bin('lt', o)
+  def __le__(self, o): return self._bin('le', o)
+  def __gt__(self, o): return self._bin('gt', o)
+  def __ge__(self, o): return self._bin('ge', o)
+  def __eq__(self, o): return self._bin('eq', o)
+  def __ne__(self, o): return self._bin('ne', o)
+  def __and__(self, o): return self._bin('and', o)
+  def __rand__(self, o): return self._bin('and', o, True)
+  def __or__(self, o): return self._bin('or', o)
+  def __ror__(self, o): return self._bin('or', o, True)
+  def __invert__(self): return _elementwise(lambda p: _g().unary('not', p), self)
+  def __neg__(self): return _elementwise(lambda p: _g().unary('neg', p), self)
+  def __pos__(self): return self
+  def __abs__(self): return _elementwise(lambda p: _g().unary('abs', p), self)
+
+  def reshape(self, *shape):
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+      shape = tuple(shape[0])
+    return SArr(self.a.reshape(tuple(int(s) for s in shape)))
+
+  def ravel(self): return SArr(self.a.reshape(-1))
+  def flatten(self): return SArr(self.a.reshape(-1).copy())
+  def copy(self): return SArr(self.a.copy())
+  def astype(self, dtype, copy=True): return self
+  def squeeze(self, axis=None): return SArr(self.a.squeeze() if axis is None else self.a.squeeze(axis))
+  def dot(self, other): return _dot(self, other)
+  def clip(self, lo=None, hi=None): return _clip(self, lo, hi)
+  def sum(self, axis=None, keepdims=False): return _reduce('add', self, axis, keepdims)
+  def mean(self, axis=None, keepdims=False): return _mean(self, axis, keepdims)
+  def prod(self, axis=None, keepdims=False): return _reduce('mul', self, axis, keepdims)
+  def min(self, axis=None, keepdims=False): return _reduce('min', self, axis, keepdims)
+  def max(self, axis=None, keepdims=False): return _reduce('max', self, axis, keepdims)
+  def all(self, axis=None, keepdims=False): return _reduce('and', self, axis, keepdims)
+  def any(self, axis=None, keepdims=False): return _reduce('or', self, axis, keepdims)
+
+  def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+    if method != '__call__' or kwargs.get('out') is not None:
+      return NotImplemented
+    name = ufunc.__name__
+    g = _g()
+    if name in _UFUNC_UNARY:
+      op = _UFUNC_UNARY[name]
+      return _elementwise(lambda p: g.unary(op, p), inputs[0])
+    if name in _UFUNC_BINARY:
+      op = _UFUNC_BINARY[name]
+      return _elementwise(lambda p, q: g.binary(op, p, q), inputs[0], inputs[1])
+    if name == 'square':
+      return _elementwise(lambda p: g.binary('mul', p, p), inputs[0])
+    if name == 'reciprocal':
+      return _elementwise(lambda p: g.binary('div', 1.0, p), inputs[0])
+    if name in ('isfinite',):
+      return _elementwise(lambda p: g.binary('lt', g.unary('abs', p), float('inf')), inputs[0])
+    if name == 'isnan':
+      return _elementwise(lambda p: g.binary('ne', p, p), inputs[0])
+    return NotImplemented
+
+  def __array_function__(self, func, types, args, kwargs):
+    fn = _FUNCS.get(func)
+    if fn is None:
+      return NotImplemented
+    return fn(*args, **kwargs)
+
+
+_UFUNC_UNARY = {'negative': 'neg', 'absolute': 'abs', 'fabs': 'abs', 'sqrt': 'sqrt', 'exp': 'exp', 'log': 'log', 'log1p': 'log1p',
+                'sin': 'sin', 'cos': 'cos', 'tan': 'tan', 'arcsin': 'arcsin', 'arccos': 'arccos', 'arctan': 'arctan',
+                'sinh': 'sinh', 'cosh': 'cosh', 'tanh': 'tanh', 'arccosh': 'arccosh', 'arctanh': 'arctanh', 'arcsinh': 'arcsinh',
+                'expm1': 'expm1', 'floor': 'floor', 'ceil': 'ceil', 'log2': 'log2', 'log10': 'log10', 'sign': 'sign',
+                'logical_not': 'not'}
+_UFUNC_BINARY = {'add': 'add', 'subtract': 'sub', 'multiply': 'mul', 'true_divide': 'div', 'divide': 'div', 'power': 'pow',
+                 'maximum': 'max', 'minimum': 'min', 'arctan2': 'arctan2', 'hypot': 'hypot', 'less': 'lt', 'less_equal': 'le',
+                 'greater': 'gt', 'greater_equal': 'ge', 'equal': 'eq', 'not_equal': 'ne', 'logical_and': 'and',
+                 'logical_or': 'or'}
+
+
+def _reduce(op, x, axis, keepdims):
+  g = _g()
+  a = _obj(x)
+  if a.size == 0:
+    raise ValueError('fused_env: reduction of an empty array')
+  uf = np.frompyfunc(lambda p, q: g.binary(op, p, q), 2, 1)
+  if axis is None:
+    out = uf.reduce(a.reshape(-1))
+    if keepdims:
+      o = np.empty((1,) * a.ndim, dtype=object); o[(0,) * a.ndim] = out
+      out = o
+    return SArr(out)
+  axes = tuple(axis) if isinstance(axis, (tuple, list)) else (int(axis),)
+  out = a
+  for ax in sorted((ax % a.ndim for ax in axes), reverse=True):
+    out = uf.reduce(out, axis=ax, keepdims=keepdims)
+  return SArr(out)
+
+
+def _mean(x, axis=None, keepdims=False):
+  a = _obj(x)
+  if axis is None:
+    n = a.size
+  else:
+    axes = tuple(axis) if isinstance(axis, (tuple, list)) else (int(axis),)
+    n = int(np.prod([a.shape[ax] for ax in axes]))
+  return _reduce('add', x, axis, keepdims) / float(n)
+
+
+def _clip(x, lo=None, hi=None, **k):
+  g = _g()
+  out = x if isinstance(x, SArr) else SArr(_obj(x))
+  if lo is not None:
+    out = _elementwise(lambda p, q: g.binary('max', p, q), out, lo)
+  if hi is not None:
+    out = _elementwise(lambda p, q: g.binary('min', p, q), out, hi)
+  return out
+
+
+def _where(cond, a=None, b=None):
+  g = _g()
+  return _elementwise(lambda c, p, q: g.where(c, p, q), cond, a, b)
+
+
+def _norm(x, ord=None, axis=None, keepdims=False):
+  if ord not in (None, 2):
+    raise NotImplementedError('fused_env: np.linalg.norm with ord=%r' % (ord,))
+  g = _g()
+  sq = x * x
+  s = _reduce('add', sq, axis, keepdims)
+  return _elementwise(lambda p: g.unary('sqrt', p), s)
+
+
+def _dot(a, b):
+  A, B = _obj(a), _obj(b)
+  g = _g()
+  mul = np.frompyfunc(lambda p, q: g.binary('mul', p, q), 2, 1)
+  add = np.frompyfunc(lambda p, q: g.binary('add', p, q), 2, 1)
+  if A.ndim == 0 or B.ndim == 0:
+    return SArr(mul(A, B))
+  if B.ndim == 1:
+    return SArr(add.reduce(mul(A, B), axis=-1))
+  # (.., k) . (.., k, n): contraction of A's last with B's second-to-last axis (np.dot)
+  prod = mul(A[..., :, None] if A.ndim == 1 else A.reshape(A.shape + (1,)), B if A.ndim == 1 else B.reshape((1,) * (A.ndim - 1) + B.shape))
+  return SArr(add.reduce(prod, axis=-2))
+
+
+def _einsum(spec, *ops, **kw):
+  """Small generic einsum over object arrays (explicit output; sizes are a handful)."""
+  spec = spec.replace(' ', '')
+  ins, out = spec.split('->') if '->' in spec else (spec, None)
+  terms = ins.split(',')
+  arrs = [_obj(o) for o in ops]
+  # expand ellipses to explicit letters
+  free = [c for c in 'ABCDEFGH']
+  nell = max((a.ndim - len(t.replace('...', '')) for t, a in zip(terms, arrs) if '...' in t), default=0)
+  ell = ''.join(free[:nell])
+  terms = [t.replace('...', ell[len(ell) - (a.ndim - len(t.replace('...', ''))):]) if '...' in t else t for t, a in zip(terms, arrs)]
+  if out is None:
+    allc = ''.join(terms)
+    out = ''.join(sorted(c for c in set(allc) if allc.count(c) == 1))
+  out = out.replace('...', ell)
+  dims = {}
+  for t, a in zip(terms, arrs):
+    for c, n in zip(t, a.shape):
+      dims[c] = n
+  contracted = [c for c in dims if c not in out]
+  g = _g()
+  res = np.empty(tuple(dims[c] for c in out), dtype=object)
+  for oidx in np.ndindex(*res.shape) if res.ndim else [()]:
+    env = dict(zip(out, oidx))
+    acc = None
+    for cidx in np.ndindex(*[dims[c] for c in contracted]) if contracted else [()]:
+      env.update(zip(contracted, cidx))
+      term = None
+      for t, a in zip(terms, arrs):
+        v = a[tuple(env[c] for c in t)]
+        term = v if term is None else g.binary('mul', term, v)
+      acc = term if acc is None else g.binary('add', acc, term)
+    res[oidx] = acc
+  return SArr(res)
+
+
+def _cat(fn):
+  def run(arrays, axis=0, **kw):
+    return SArr(fn([_obj(a) if isinstance(a, SArr) else np.asarray(a, dtype=object) for a in arrays], axis=axis))
+  return run
+
+
+def _cross(a, b, **k):
+  A, B = _obj(a), _obj(b)
+  ax, ay, az = (SArr(A[..., i]) for i in range(3))
+  bx, by, bz = (SArr(B[..., i]) for i in range(3))
+  return SArr(np.stack([(ay * bz - az * by).a, (az * bx - ax * bz).a, (ax * by - ay * bx).a], axis=-1))
+
+
+_FUNCS = {
+    np.concatenate: _cat(np.concatenate), np.stack: _cat(np.stack), np.hstack: lambda arrays: _cat(np.concatenate)([np.atleast_1d(_obj(a)) for a in arrays], axis=-1),
+    np.where: _where, np.linalg.norm: _norm, np.einsum: _einsum, np.dot: _dot, np.clip: _clip, np.cross: _cross,
+    np.sum: lambda x, axis=None, keepdims=False, **k: _reduce('add', x, axis, keepdims),
+    np.mean: lambda x, axis=None, keepdims=False, **k: _mean(x, axis, keepdims),
+    np.prod: lambda x, axis=None, keepdims=False, **k: _reduce('mul', x, axis, keepdims),
+    np.min: lambda x, axis=None, keepdims=False, **k: _reduce('min', x, axis, keepdims),
+    np.max: lambda x, axis=None, keepdims=False, **k: _reduce('max', x, axis, keepdims),
+    np.amin: lambda x, axis=None, keepdims=False, **k: _reduce('min', x, axis, keepdims),
+    np.amax: lambda x, axis=None, keepdims=False, **k: _reduce('max', x, axis, keepdims),
+    np.all: lambda x, axis=None, keepdims=False, **k: _reduce('and', x, axis, keepdims),
+    np.any: lambda x, axis=None, keepdims=False, **k: _reduce('or', x, axis, keepdims),
+    np.shape: lambda x: x.shape, np.ndim: lambda x: x.ndim, np.size: lambda x: x.size,
+    np.reshape: lambda x, shape, **k: x.reshape(shape), np.ravel: lambda x, **k: x.ravel(),
+    np.squeeze: lambda x, axis=None: x.squeeze(axis), np.expand_dims: lambda x, axis: SArr(np.expand_dims(x.a, axis)),
+    np.broadcast_to: lambda x, shape, **k: SArr(np.broadcast_to(x.a, tuple(shape))),
+    np.zeros_like: lambda x, dtype=None, **k: np.zeros(x.shape), np.ones_like: lambda x, dtype=None, **k: np.ones(x.shape),
+    np.copy: lambda x, **k: x.copy(), np.atleast_1d: lambda x: x if x.ndim else x.reshape(1),
+    np.transpose: lambda x, axes=None: SArr(np.transpose(x.a, axes)),
+    np.isscalar: lambda x: False,
+}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the symbolic view: the domain's Physics subclass, one environment, expression leaves instead of numbers
+# ---------------------------------------------------------------------------------------------------------------------
+class _SymData:
+
+  def __init__(self, view):
+    object.__setattr__(self, '_v', view)
+
+  def __getattr__(self, name):
+    v = self._v
+    rows = v._rows.get(name)
+    if rows is None:
+      raise AttributeError('data.%s is not served on the device (bound fields: %s)' % (name, sorted(v._rows)))
+    return v._leaf_array(name, rows)
+
+  def __setattr__(self, name, value):
+    raise AttributeError('the symbolic view is read-only')
+
+
+def _make_sym_view_class(cls):
+  from dm_control_amd import physics as facade
+
+  class SymView(cls):
+    """`cls` (a suite domain's Physics) at batch size 1 whose `data` arrays are SArr leaves."""
+
+    def __init__(self):      # pylint: disable=super-init-not-called
+      raise TypeError('built by FusedDeviceEnv')
+
+    def __getattr__(self, name):
+      if name.startswith('_'):
+        raise AttributeError(name)
+      host = self.__dict__['_host']
+      attrs = self.__dict__['_attrs']
+      if name in attrs:
+        width, shape = attrs[name]
+        g = _g()
+        a = np.empty(width, dtype=object)
+        for j in range(width):
+          a[j] = g.attr(name, j, width)
+        return SArr(a.reshape(shape))
+      if name in host.__dict__ or hasattr(type(host), name):
+        return getattr(host, name)
+      raise AttributeError(name)
+
+    def _leaf_array(self, name, rows):
+      g = _g()
+      kind = 'i' if name in ('ncon', 'nefc', 'solver_iter') else 'f'
+      a = np.empty(max(rows, 0), dtype=object)
+      for k in range(rows):
+        a[k] = g.load(name, k, kind)
+      ncol = facade._FIELD_AXES.get(name, (None, None))[1]      # pylint: disable=protected-access
+      if name in ('time', 'ncon', 'nefc', 'solver_iter'):
+        return SArr(a[0])
+      if ncol:
+        return SArr(a.reshape(rows // ncol, ncol))
+      return SArr(a)
+
+    def control(self): return self.data.ctrl.copy()
+    def position(self): return self.data.qpos.copy()
+    def velocity(self): return self.data.qvel.copy()
+    def activation(self): return self.data.act.copy()
+    def state(self): return self.get_state()
+    def time(self): return self.data.time
+    def timestep(self): return self.model.opt.timestep
+
+    def get_state(self, sig=None):
+      if sig is not None:
+        raise NotImplementedError('state signatures are served by the facade')
+      parts = [self.data.qpos, self.data.qvel] + ([self.data.act] if self.model.na else [])
+      return np.concatenate(parts, axis=-1)
+
+    def step(self, *a, **k): raise TypeError('the symbolic view does not step')
+    forward = reset = after_reset = set_control = step
+
+    def free(self):
+      pass
+
+    def __del__(self):
+      pass
+  SymView.__name__ = 'Sym' + cls.__name__
+  return SymView
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# code generation
+# ---------------------------------------------------------------------------------------------------------------------
+def _emit(g, outputs, T):
+  """Straight-line C++ for the nodes `outputs` depend on.  Returns (lines, name-of-node function)."""
+  need, order = set(), []
+  stack = [(n, False) for n in outputs]
+  while stack:
+    n, done = stack.pop()
+    if done:
+      order.append(n)
+      continue
+    if n.id in need:
+      continue
+    need.add(n.id)
+    stack.append((n, True))
+    for a in n.args:
+      if isinstance(a, Sym) and a.id not in need:
+        stack.append((a, False))
+
+  def lit(v):
+    if isinstance(v, bool):
+      return 'true' if v else 'false'
+    if math.isinf(v):
+      return '(T)INFINITY' if v > 0 else '(T)(-INFINITY)'
+    if math.isnan(v):
+      return '(T)NAN'
+    return '(T)%s' % repr(float(v))
+
+  def ref(n, as_kind=None):
+    if n.op == 'const':
+      s = lit(n.args[0])
+      k = n.kind
+    else:
+      s, k = 'v%d' % n.id, n.kind
+    if as_kind == 'f' and k == 'b':
+      return '(%s ? (T)1 : (T)0)' % s
+    if as_kind == 'f' and k == 'i':
+      return '(T)%s' % s
+    return s
+  lines = []
+  # every load first: they are independent of each other, so the thread has them all in flight before the first use
+  # (inside the step kernel this function is the tail of the launch's critical path: one memory round trip, not one per leaf)
+  order = [n for n in order if n.op in ('load', 'attr')] + [n for n in order if n.op not in ('load', 'attr')]
+  for n in order:
+    if n.op == 'const':
+      continue
+    ty = {'f': 'T', 'b': 'bool', 'i': 'int'}[n.kind]
+    if n.op == 'load':
+      f, row = n.args
+      name, kind = g.fields[f]
+      cty = 'int' if kind == 'i' else ('double' if name == 'time' else 'T')
+      expr = 'ld(&((const %s*)a.field[%d])[(size_t)%d * B + e])' % (cty, f, row)
+      if name == 'time':
+        expr = '(T)' + expr
+    elif n.op == 'attr':
+      k, j = n.args
+      expr = 'ld(&((const T*)a.attr[%d])[(size_t)e * %d + %d])' % (k, g.attrs[k][1], j)
+    elif n.op == 'where':
+      c, x, y = n.args
+      ak = n.kind
+      expr = '%s ? %s : %s' % (ref(c), ref(x, ak), ref(y, ak))
+    elif n.op in _UNARY_C:
+      fmt = _UNARY_C[n.op]
+      x = ref(n.args[0], None if n.op == 'not' else 'f')
+      expr = fmt % ((x,) * fmt.count('%s'))
+    else:
+      ak = None if n.op in ('and', 'or') else 'f'
+      expr = _BINARY_C[n.op] % (ref(n.args[0], ak), ref(n.args[1], ak))
+    lines.append('  const %s v%d = %s;' % (ty, n.id, expr))
+  return lines, ref
+
+
+_HDR = r'''// GENERATED by dm_control_amd/suite/fused_env.py -- the task layer of %(title)s
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+namespace dmc_task {
+typedef %(T)s T;
+#ifdef DMC_TASK_IN_KERNEL
+// inside the step kernel: the launch's own stores are read back past the CU's L1 (sc1 loads, served by the L2)
+template <typename P> __device__ inline P ld(const P* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+template <typename P> __device__ inline P ld(const P* p) { return *p; }
+#endif
+// what a restart writes: the state fields (rows, B) from their pools (rounds, rows, B), the per-episode task attributes
+// (B, w) from theirs (rounds, B, w), the episode's counters and the launch override of the NEXT physics launch
+struct Episode {
+  int B, rounds;
+  unsigned char* pending;     // (B): the next physics launch is this environment's FIRST (fresh state, env_mode 1)
+  int* env_mode;              // (B): dmc_batch_step's per-environment launch override (1: mj_forward without actuation)
+  int* steps; int* episode;   // (B)
+  void* state[%(nstate)d]; const void* pool[%(nstate)d];
+  void* attr[%(nattr1)d]; const void* attr_pool[%(nattr1)d];
+};
+struct PostArgs {
+  int B, step_limit;
+  const void* field[%(nfield1)d];
+  const void* attr[%(nattr1)d];      // (in the order the expressions first use them)
+  T* obs; T* reward; T* discount;
+  unsigned char* done; unsigned char* first; unsigned char* terminated;
+  Episode ep;
+};
+__device__ inline unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__device__ inline void restart(const Episode& a, int e) {
+  const int B = a.B;
+  const int ep = a.episode[e];
+  const int r = (int)(mix((unsigned)ep * 0x9e3779b9U + (unsigned)e) %% (unsigned)a.rounds);
+%(pre_copy)s
+  a.steps[e] = 0; a.episode[e] = ep + 1;
+  a.pending[e] = 1; a.env_mode[e] = 1;
+}
+// one environment's task layer after its physics launch: observation, reward, termination, the step's flags -- and, when
+// the episode ends here, the start state of the next one (its first observation is the NEXT step's)
+__device__ inline void task_post(const PostArgs& a, int e) {
+  const int B = a.B;
+%(body)s
+  const bool f = a.ep.pending[e] != 0;      // this launch was the episode's first (mj_forward at the start state)
+  const int st = a.ep.steps[e] + (f ? 0 : 1);
+  const bool term = !f && (%(term)s);
+  const bool d = !f && (term || st >= a.step_limit);
+  a.reward[e] = f ? (T)0 : (%(reward)s);
+  a.discount[e] = term ? (T)%(term_discount)s : (T)1;
+  a.terminated[e] = term ? 1 : 0;
+  a.done[e] = d ? 1 : 0; a.first[e] = f ? 1 : 0;
+%(obs_store)s
+  if (d) restart(a.ep, e);
+  else { a.ep.steps[e] = st; a.ep.pending[e] = 0; a.ep.env_mode[e] = 0; }
+}
+}  // namespace dmc_task
+'''
+
+_SRC = r'''// GENERATED by dm_control_amd/suite/fused_env.py -- the task layer of %(title)s as kernels of its own
+#include "%(header)s"
+using namespace dmc_task;
+extern "C" __global__ void __launch_bounds__(256) restart_kernel(Episode a, const unsigned char* mask) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.B && mask[e]) restart(a, e);
+}
+extern "C" __global__ void __launch_bounds__(256) post_kernel(PostArgs a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.B) task_post(a, e);
+}
+extern "C" int fused_restart(void* stream, const Episode* a, const unsigned char* mask) {
+  hipLaunchKernelGGL(restart_kernel, dim3((a->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a, mask);
+  return (int)hipGetLastError();
+}
+extern "C" int fused_post(void* stream, const PostArgs* a) {
+  hipLaunchKernelGGL(post_kernel, dim3((a->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  return (int)hipGetLastError();
+}
+'''
+
+
+def _compile(src, verbose=False, extra_key=''):
+  from dm_control_amd import build as _build
+  from dm_control_amd import specialise
+  key = hashlib.sha1((src + extra_key + specialise.toolchain_id()).encode()).hexdigest()[:24]
+  out = os.path.join(specialise.cache_dir(), 'libdmc_task_%s.so' % key)
+  if not os.path.exists(out):
+    cu = out[:-3] + '.%d.hip' % os.getpid()
+    with open(cu, 'w') as f:
+      f.write(src)
+    tmp = out + '.%d.tmp' % os.getpid()
+    cmd = [_build.HIPCC, '--offload-arch=' + _build.ARCH, '-O3', '-std=c++17', '-fPIC', '-shared', '-o', tmp, cu]
+    if verbose:
+      print(' '.join(cmd))
+    try:
+      subprocess.check_call(cmd)
+      os.replace(tmp, out)
+    finally:
+      if os.path.exists(cu):
+        os.remove(cu)
+  return out
+
+
+_STATE_FIELDS = ('qpos', 'qvel', 'act', 'qacc_warmstart', 'time')
+_NOT_ATTRS = ('model', 'batch', 'data', 'named', 'batch_size', 'legacy_step')
+
+
+def episode_attrs(p, B):
+  """What the task hung on the physics at episode start (targets, radii ...): name -> ((B, w) float array, the shape one
+  environment's code sees).  Float arrays with a leading batch axis (any float array when B == 1, where the ports drop
+  that axis)."""
+  out = collections.OrderedDict()
+  for k, val in vars(p).items():
+    if k.startswith('_') or k in _NOT_ATTRS:
+      continue
+    if isinstance(val, np.ndarray) and val.dtype.kind == 'f' and val.ndim >= 1 and (val.shape[0] == B or B == 1):
+      batched = val.shape[0] == B and B > 1
+      v = val.reshape(B, -1) if batched else val.reshape(1, -1)
+      out[k] = (np.ascontiguousarray(v), tuple(val.shape[1:]) if batched else tuple(val.shape))
+  return out
+
+
+def field_rows(p, names):
+  rows = {}
+  for name in names:
+    try:
+      r = p.batch._rows      # pylint: disable=protected-access
+      nrow = r(name)[0] if callable(r) else (r[name] if name in r else int(np.asarray(p.batch.get(name)).shape[1]))
+    except Exception:      # pylint: disable=broad-except
+      continue
+    if nrow:
+      rows[name] = int(nrow)
+  return rows
+
+
+def served_fields():
+  from dm_control_amd import physics as facade
+  return [n for n in facade._FIELD_AXES if n not in ('xanchor', 'xaxis', 'ten_length', 'ten_velocity')] + ['time', 'ncon']      # pylint: disable=protected-access
+
+
+def trace(host_env, precision=64, title='task'):
+  """The TaskProgram of a host environment (`suite.load(..., physics_kwargs=dict(batch_size=B))`) in its current
+  episode: what FusedDeviceEnv builds, without a device (tests: the DAG against the host port on the oracle stand-in)."""
+  p = host_env.physics
+  B = int(getattr(p, 'batch_size', 1))
+  rows = field_rows(p, served_fields())
+  attrs = collections.OrderedDict((k, (v.shape[1], shape)) for k, (v, shape) in episode_attrs(p, B).items())
+  return TaskProgram(title, host_env.task, _make_sym_view_class(type(p)), p, rows, attrs, precision)
+
+
+class TaskProgram:
+  """The traced and generated task layer of one (domain, task, model): source text, object path, field / attribute lists."""
+
+  def __init__(self, title, task, view_cls, host_physics, rows, attrs, precision):
+    global _G
+    g = Graph()
+    if _G is not None:
+      raise RuntimeError('fused_env: nested trace')
+    _G = g
+    try:
+      v = object.__new__(view_cls)
+      v.__dict__.update(_host=host_physics, _rows=rows, _attrs=attrs, model=host_physics.model, batch_size=1)
+      v.__dict__['data'] = _SymData(v)
+      # what the task hung on the physics at episode start: INSTANCE attributes of the view (the domain classes declare
+      # them as class attributes -- `target_xy = None` -- which a plain lookup finds before __getattr__): per-environment
+      # arrays as expression leaves, everything else (radii, flags) as the host's value
+      for k, val in vars(host_physics).items():
+        if not k.startswith('_') and k not in _NOT_ATTRS and k not in attrs:
+          v.__dict__[k] = val
+      for k, (width, shape) in attrs.items():
+        leaves = np.empty(width, dtype=object)
+        for j in range(width):
+          leaves[j] = g.attr(k, j, width)
+        v.__dict__[k] = SArr(leaves.reshape(shape))
+      from dm_control_amd import physics as facade
+      named = facade._Named()      # pylint: disable=protected-access
+      named.model = host_physics.named.model
+      named.data = facade._Named()      # pylint: disable=protected-access
+      axes = facade._make_axes(host_physics.model)      # pylint: disable=protected-access
+      for field, (rowkind, ncol) in facade._FIELD_AXES.items():      # pylint: disable=protected-access
+        if field in rows:
+          cols = facade._Axis(facade._COLS[ncol]) if ncol else None      # pylint: disable=protected-access
+          setattr(named.data, field, facade.FieldIndexer(lambda f=field: getattr(v.data, f), axes[rowkind], cols, False))
+      v.__dict__['named'] = named
+      obs = task.get_observation(v)
+      self.observation_layout = collections.OrderedDict()
+      obs_nodes = []
+      for k, val in obs.items():
+        a = _obj(val) if isinstance(val, (SArr, Sym)) else np.asarray(val, dtype=np.float64)
+        self.observation_layout[k] = tuple(a.shape)
+        obs_nodes += [g.lift(x) for x in a.reshape(-1)]
+      r = task.get_reward(v)
+      ra = _obj(r) if isinstance(r, (SArr, Sym)) else np.asarray(r, dtype=np.float64)
+      if ra.size != 1:
+        raise ValueError('fused_env: the reward of one environment must be a scalar, got shape %r' % (ra.shape,))
+      reward = g.lift(ra.reshape(-1)[0])
+      term, term_discount = g.const(False), 0.0
+      tm = getattr(task, 'termination_mask', None)
+      if tm is not None:
+        t = tm(v)
+        if t is not None:
+          ta = _obj(t)
+          term = g.lift(ta.reshape(-1)[0])
+          term_discount = float(getattr(task, 'termination_discount', 0.0))
+    finally:
+      _G = None
+    T = 'float' if precision == 32 else 'double'
+    lines, ref = _emit(g, obs_nodes + [reward, term], T)
+    nobs = len(obs_nodes)
+    store = ['  a.obs[(size_t)e * %d + %d] = %s;' % (nobs, j, ref(n, 'f')) for j, n in enumerate(obs_nodes)]
+    self.graph, self.nobs = g, nobs
+    self.obs_nodes, self.reward_node, self.term_node, self.term_discount = obs_nodes, reward, term, term_discount
+    self.fields = list(g.fields)
+    self.attrs = list(g.attrs)
+    self.state = [f for f in _STATE_FIELDS if rows.get(f, 0) > 0]
+    self.state_rows = [rows[f] for f in self.state]
+    self.all_attrs = [(k, w) for k, (w, _) in attrs.items()]
+    pre = []
+    for i, (f, n) in enumerate(zip(self.state, self.state_rows)):
+      cty = 'double' if f == 'time' else 'T'
+      pre.append('  for (int k = 0; k < %d; k++) ((%s*)a.state[%d])[(size_t)k * B + e] = ((const %s*)a.pool[%d])[((size_t)r * %d + k) * B + e];'
+                 % (n, cty, i, cty, i, n))
+    for i, (k, w) in enumerate(self.all_attrs):
+      pre.append('  for (int k = 0; k < %d; k++) ((T*)a.attr[%d])[(size_t)e * %d + k] = ((const T*)a.attr_pool[%d])[((size_t)r * B + e) * %d + k];'
+                 % (w, i, w, i, w))
+    # post's attribute slots follow the ORDER OF USE in the expressions; pre's follow all_attrs
+    self.header = _HDR % dict(title=title, T=T, nstate=max(1, len(self.state)), nattr1=max(1, len(self.all_attrs), len(self.attrs)),
+                              nfield1=max(1, len(self.fields)), pre_copy='\n'.join(pre), body='\n'.join(lines),
+                              term=ref(term), reward=ref(reward, 'f'), term_discount=repr(term_discount), obs_store='\n'.join(store))
+    self.title = title
+    self.source = self.header      # (what the tests inspect; the stand-alone kernels include it)
+    self.n_nodes = len(lines)
+    self.precision = precision
+
+  def build(self, verbose=False):
+    """Writes the generated header into the cache (`header_path`: what a step kernel with the task epilogue includes) and
+    compiles the stand-alone kernels (restart, post) into `path`."""
+    from dm_control_amd import specialise
+    key = hashlib.sha1(self.header.encode()).hexdigest()[:24]
+    self.header_path = os.path.join(specialise.cache_dir(), 'task_%s.gen.h' % key)
+    if not os.path.exists(self.header_path):
+      tmp = self.header_path + '.%d.tmp' % os.getpid()
+      with open(tmp, 'w') as f:
+        f.write(self.header)
+      os.replace(tmp, self.header_path)
+    self.path = _compile(_SRC % dict(title=self.title, header=self.header_path), verbose, extra_key=self.header)
+    return self.path
+
+
+def _cstruct(fields):
+  class S(ctypes.Structure):
+    _fields_ = fields
+  return S
+
+
+class FusedDeviceEnv:
+  """B environments of `suite.<domain>.<task>` resident on one GPU, the task layer as one generated kernel; `step(action)`
+  -> (obs (B, n), reward (B,), done (B,)) device tensors; `first`, `discount`, `terminated` hold the step's other flags.
+  See the module docstring.  `pool_rounds` start states per environment are drawn by the host port's `initialize_episode`
+  at construction (`refill_pool()` redraws them between steps)."""
+
+  def __init__(self, domain, task, batch_size, precision=32, device_id=0, seed=0, capture=True, task_kwargs=None,
+               pool_rounds=4, copy_outputs=True, inline=True, verbose=False):
+    """inline: the task layer runs INSIDE the step kernel (a specialised kernel is built for (model, task) with the
+    generated function as its epilogue: one hipcc run of 15 - 25 s, cached) -- an environment step is then the physics
+    launch alone; False, or when that build is not possible: the same function as a small kernel of its own behind the
+    physics launch."""
+    import torch
+    from dm_control_amd import suite
+    self.torch = torch
+    self.B = int(batch_size)
+    self.device = torch.device('cuda', device_id)
+    self.dtype = torch.float32 if precision == 32 else torch.float64
+    self.precision = precision
+    kw = dict(task_kwargs or {})
+    kw.setdefault('random', seed)
+    pk = dict(batch_size=self.B, precision=precision, device_id=device_id)
+    if inline:
+      pk['specialise'] = 'cached'      # (the kernel specialised for (model, TASK) replaces the model's plain one below: no point in building that)
+    self.host_env = suite.load(domain, task, task_kwargs=kw, physics_kwargs=pk)
+    p = self.host_env.physics
+    self.host_physics, self.task, self.model = p, self.host_env.task, p.model
+    self.n_sub_steps = int(self.host_env._n_sub_steps)      # pylint: disable=protected-access
+    lim = self.host_env._step_limit      # pylint: disable=protected-access
+    self.step_limit = 2 ** 30 if lim == float('inf') else int(math.ceil(float(lim)))
+    p.batch.wait_specialised()      # (a launch recorded into a HIP graph keeps the kernel it was captured with)
+    # bind every field the facade serves from the device to a torch tensor (zero copy)
+    self._tensors = {}
+    rows = field_rows(p, served_fields() + ['env_mode'])
+    for name, nrow in rows.items():
+      dt = torch.float64 if name == 'time' else torch.int32 if name in ('ncon', 'nefc', 'solver_iter', 'env_mode') else self.dtype
+      t = torch.zeros((nrow, self.B), dtype=dt, device=self.device)
+      p.batch.bind(name, t.data_ptr())
+      self._tensors[name] = t
+    rows.pop('env_mode')
+    # ---- the start-state pool: the host port's own initialize_episode, `pool_rounds` times for the whole batch
+    self.rounds = int(pool_rounds)
+    self._state_names = [f for f in _STATE_FIELDS if f in rows]
+    self._pool = {f: torch.zeros((self.rounds, rows[f], self.B), dtype=self._tensors[f].dtype, device=self.device) for f in self._state_names}
+    self._attr_pool, self._attr_live, attrs = {}, {}, collections.OrderedDict()
+    self._draw_pool(attrs)
+    # ---- trace + generate + compile
+    self.program = prog = TaskProgram('%s.%s' % (domain, task), self.task, _make_sym_view_class(type(p)), p, rows, attrs, precision)
+    prog.build(verbose)
+    self.observation_layout = prog.observation_layout
+    self._lib = ctypes.CDLL(prog.path)
+    vp = ctypes.c_void_p
+    ns, na = max(1, len(prog.state)), max(1, len(prog.all_attrs), len(prog.attrs))
+    Episode = _cstruct([('B', ctypes.c_int), ('rounds', ctypes.c_int), ('pending', vp), ('env_mode', vp), ('steps', vp), ('episode', vp),
+                        ('state', vp * ns), ('pool', vp * ns), ('attr', vp * na), ('attr_pool', vp * na)])
+    PostArgs = _cstruct([('B', ctypes.c_int), ('step_limit', ctypes.c_int), ('field', vp * max(1, len(prog.fields))), ('attr', vp * na),
+                         ('obs', vp), ('reward', vp), ('discount', vp), ('done', vp), ('first', vp), ('terminated', vp), ('ep', Episode)])
+    self._lib.fused_restart.argtypes = [vp, ctypes.POINTER(Episode), vp]
+    self._lib.fused_post.argtypes = [vp, ctypes.POINTER(PostArgs)]
+    B, dev = self.B, self.device
+    u8 = torch.uint8
+    self.pending = torch.zeros(B, dtype=u8, device=dev)
+    self.first = torch.zeros(B, dtype=u8, device=dev)
+    self.done = torch.zeros(B, dtype=u8, device=dev)
+    self.terminated = torch.zeros(B, dtype=u8, device=dev)
+    self.steps = torch.zeros(B, dtype=torch.int32, device=dev)
+    self.episode = torch.zeros(B, dtype=torch.int32, device=dev)
+    self.obs = torch.zeros((B, prog.nobs), dtype=self.dtype, device=dev)
+    self.reward = torch.zeros(B, dtype=self.dtype, device=dev)
+    self.discount = torch.ones(B, dtype=self.dtype, device=dev)
+    self._all = torch.ones(B, dtype=u8, device=dev)
+    self.ctrl = self._tensors.get('ctrl')
+    ep = Episode()
+    ep.B, ep.rounds = B, self.rounds
+    ep.pending, ep.env_mode = self.pending.data_ptr(), self._tensors['env_mode'].data_ptr()
+    ep.steps, ep.episode = self.steps.data_ptr(), self.episode.data_ptr()
+    for i, f in enumerate(prog.state):
+      ep.state[i], ep.pool[i] = self._tensors[f].data_ptr(), self._pool[f].data_ptr()
+    for i, (k, w) in enumerate(prog.all_attrs):
+      ep.attr[i], ep.attr_pool[i] = self._attr_live[k].data_ptr(), self._attr_pool[k].data_ptr()
+    post = PostArgs()
+    post.B, post.step_limit = B, self.step_limit
+    for i, (f, kind) in enumerate(prog.fields):
+      post.field[i] = self._tensors[f].data_ptr()
+    for i, (k, w) in enumerate(prog.attrs):
+      post.attr[i] = self._attr_live[k].data_ptr()
+    post.obs, post.reward, post.discount = self.obs.data_ptr(), self.reward.data_ptr(), self.discount.data_ptr()
+    post.done, post.first, post.terminated = self.done.data_ptr(), self.first.data_ptr(), self.terminated.data_ptr()
+    post.ep = ep
+    self._ep, self._post = ep, post
+    # ---- the task layer inside the step kernel
+    self.inline = False
+    if inline:
+      from dm_control_amd import specialise
+      if specialise.attach_task(p.batch, prog.header_path, verbose=verbose):
+        p.batch.set_task_args(bytes(post))
+        self.inline = True
+    self._graph = None
+    # inline: the control step IS one launch -- replaying it from a graph costs more than launching it (a replay's fixed
+    # cost is ~10 us on the host and a few on the device: lqr 39.4 vs 29.5 us per step, round 6)
+    self._capture = bool(capture) and not self.inline
+    self._copy_outputs = bool(copy_outputs)
+    self.restart()      # every environment starts an episode with the first step
+
+  # -- start states ------------------------------------------------------------------------------------------------------
+  def _draw_pool(self, attrs=None):
+    torch = self.torch
+    p = self.host_physics
+    for r in range(self.rounds):
+      p.data._invalidate()      # pylint: disable=protected-access
+      with p.reset_context():
+        self.task.initialize_episode(p)
+      torch.cuda.synchronize()
+      for f in self._state_names:
+        self._pool[f][r].copy_(self._tensors[f])
+      for k, (v, shape) in episode_attrs(p, self.B).items():
+        if k not in self._attr_pool:
+          if attrs is None:
+            raise RuntimeError('fused_env: the task set a new per-episode attribute %r after the trace' % k)
+          self._attr_pool[k] = torch.zeros((self.rounds, self.B, v.shape[1]), dtype=self.dtype, device=self.device)
+          self._attr_live[k] = torch.zeros((self.B, v.shape[1]), dtype=self.dtype, device=self.device)
+          attrs[k] = (v.shape[1], shape)
+        self._attr_pool[k][r].copy_(torch.as_tensor(v, device=self.device).to(self.dtype))
+
+  def refill_pool(self):
+    """Draws `pool_rounds` fresh start states (and per-episode task attributes) for every environment with the host
+    port's `initialize_episode` -- host RNG, exactly what `suite.load(...).reset()` does -- and uploads them.  It steps
+    nothing, but it rewrites the live state on the way: every environment starts a new episode at the next step."""
+    self._draw_pool()
+    self.restart()
+
+  def restart(self, mask=None):
+    """The environments of `mask` ((B,) bool / uint8 device tensor; default: all) start a new episode with the next
+    step: start state and task attributes from the pool, step count 0, `first` in that step."""
+    m = self._all if mask is None else mask.to(self.torch.uint8).contiguous()
+    rc = self._lib.fused_restart(self._stream(), ctypes.byref(self._ep), m.data_ptr())
+    if rc:
+      raise RuntimeError('fused_restart: hip error %d' % rc)
+
+  # -- stepping ----------------------------------------------------------------------------------------------------------
+  def _stream(self):
+    return self.torch.cuda.current_stream().cuda_stream
+
+  def _launches(self):
+    st = self._stream()
+    b = self.host_physics.batch
+    b.legacy_step = True
+    if self.inline:      # the step launch ends with the task layer (a host-side flag read when the launch is enqueued)
+      b.enable_task(True)
+      try:
+        b.step(self.n_sub_steps, stream=st)
+      finally:
+        b.enable_task(False)
+      return
+    b.step(self.n_sub_steps, stream=st)
+    rc = self._lib.fused_post(st, ctypes.byref(self._post))
+    if rc:
+      raise RuntimeError('fused_post: hip error %d' % rc)
+
+  def step(self, action):
+    """action: (B, nu) device tensor.  Returns (obs, reward, done); `self.first / discount / terminated` describe the same
+    step.  Environments flagged done restart in the NEXT call (first = True there).  With `copy_outputs=False` the
+    returned tensors are the environment's own buffers, rewritten by the next step."""
+    torch = self.torch
+    if self.ctrl is not None:
+      self.ctrl.copy_(action.T)      # (B, nu) -> the batch's (nu, B) control rows: the one launch outside the graph
+    if self._capture:
+      if self._graph is None:
+        saved = [self.pending, self.steps, self.episode, self._tensors['env_mode']] + [self._tensors[f] for f in self._state_names] + list(self._attr_live.values())
+        keep = [t.clone() for t in saved]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+          self._launches()      # warm-up off the default stream, as graph capture requires
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+          self._launches()
+        for t, v in zip(saved, keep):
+          t.copy_(v)      # the warm-up run is taken back: the replay below is this call's step
+        self._graph = graph
+      self._graph.replay()
+    else:
+      self._launches()
+    if self._copy_outputs:
+      return self.obs.clone(), self.reward.clone(), self.done.bool()
+    return self.obs, self.reward, self.done.bool()
+
+  def reset(self):
+    """Every environment starts a new episode; returns its first observation (one step whose launch only evaluates the
+    start states: `first` is set for all, rewards are 0)."""
+    self.restart()
+    z = self.torch.zeros((self.B, self.model.nu), dtype=self.dtype, device=self.device)
+    return self.step(z)[0]
+
+  def warnings(self):
+    return self.host_physics.batch.get('warning')
+
+  def close(self):
+    self._graph = None
+    self.host_physics.free()
+
+
+def make(domain, task, batch_size, **kwargs):
+  return FusedDeviceEnv(domain, task, batch_size, **kwargs)

@@ -119,3 +119,11 @@ class LQRLevel(base.Task):
     if np.all(physics.state_norm() < self._TERMINAL_TOL):
       return 0.0
     return None
+
+  # per-environment form for the device-resident environments (suite/fused_env.py): where the reference's test
+  # (suite/lqr.py:264: `if physics.state_norm() < _TERMINAL_TOL: return 0.0`) holds, that environment's episode ends with
+  # discount `termination_discount` -- each environment at its own step, not when the whole batch has converged
+  termination_discount = 0.0
+
+  def termination_mask(self, physics):
+    return physics.state_norm() < self._TERMINAL_TOL

@@ -61,6 +61,17 @@ void dmc_batch_destroy(dmc_batch* b);
  * batch's launches through it.  The object stays loaded for the life of the process. */
 int dmc_batch_attach_specialised(dmc_batch* b, const char* so_path);
 
+/* control.Environment.step in one launch (dm_control/rl/control.py:99-127: before_step, physics.step, reward, observation,
+ * termination).  dm_control_amd/suite/fused_env.py compiles a suite task's own get_observation / get_reward /
+ * termination code into a device function; a specialised kernel built with that function (`DMC_TASK_HEADER`) runs it
+ * for every environment at the end of its step launch -- observation (B, nobs), reward, discount, done / first flags
+ * and, where the episode ended, the start state of the next one -- so that an environment step costs no launch beside
+ * the physics.  set_task_args uploads the function's argument block (device pointers of the field / output / pool
+ * arrays; its size is checked against the attached kernel's); enable_task says whether the step launches issued from
+ * now on run it (a host-side flag read when a launch is enqueued, so a HIP graph keeps what it was captured with). */
+int dmc_batch_set_task_args(dmc_batch* b, const void* args, int nbytes);
+int dmc_batch_enable_task(dmc_batch* b, int on);
+
 /* Replaces Physics.step(nstep) = mj_step2; mj_step(nstep-1); mj_step1 when
  * legacy_step != 0 (dm_control/mujoco/engine.py:147-162) or mj_step(nstep)
  * otherwise (engine.py:176), for every env, in ONE kernel launch.
@@ -248,7 +259,12 @@ int dmc_gather_run(dmc_gather* g, void* out, void* hip_stream);
  * 160 KiB LDS budget; global_scratch_bytes_per_env: what a tree-sparse model (nv > 16) keeps in
  * device memory instead of LDS -- the compressed contact rows and, with noslip, the factor of M; work_queue: 1 when
  * the batch is larger than what the chip holds at once, so `grid` is only the resident workgroups and their waves
- * claim the remaining environments from a device-side queue as they finish). */
+ * claim the remaining environments from a device-side queue as they finish.  Round 6: one queue per XCD, served by the
+ * waves that run on it, and a Physics.step(nstep > 1) launch hands every environment out in up to 8 PIECES of physics
+ * steps, round by round -- piece s of every environment before piece s + 1 of any; the state travels between pieces
+ * through a per-environment hand-off record -- so that the launch ends within one physics step of the last claim
+ * instead of within one env-step: trajectories bit-identical, config 4 460 k -> 577 k env-steps/s.  DMC_SLICES=1
+ * restores whole items). */
 int dmc_batch_info(const dmc_batch* b, int* info);
 
 /* Profiling contract.  Replaces: Physics.enable_profiling() -> wrapper.enable_timer(True), which installs mjcb_time

@@ -56,6 +56,27 @@ def test_restart_refreshes_the_per_episode_device_copies_in_place(oracle_backend
   env.close()
 
 
+def test_single_environment_targets_are_refreshed_in_place_too(oracle_backend):
+  """with B = 1 the ports drop the batch axis (`xy[0] if B == 1 else xy`): `target_xy` is a (2,) array, which
+  must still become a device tensor rewritten in place by a restart -- as a host constant it would be baked into the
+  captured graph at the first episode's value.  Two environments of different precision keep their own float type."""
+  import torch
+  env = device_env.make('reacher', 'easy', 1, precision=64, _device='cpu', capture=False, seed=1)
+  other = device_env.make('reacher', 'easy', 2, precision=32, _device='cpu', capture=False, seed=1)
+  env.step(torch.zeros(1, env.model.nu, dtype=torch.float64))
+  t1 = env.view.target_xy.t
+  first = t1.clone()
+  env.reset()
+  t2 = env.view.target_xy.t
+  assert t2.data_ptr() == t1.data_ptr() and not torch.equal(first, t2) and tuple(t2.shape) == (2,)
+  np.testing.assert_allclose(t2.numpy(), env.host_physics.target_xy)
+  obs, rew, _ = env.step(torch.zeros(1, env.model.nu, dtype=torch.float64))
+  assert obs.dtype == torch.float64 and rew.dtype == torch.float64      # (the fp32 environment built after it did not change that)
+  o32, r32, _ = other.step(torch.zeros(2, other.model.nu, dtype=torch.float32))
+  assert o32.dtype == torch.float32 and env._consts is not other._consts
+  env.close(); other.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('domain,task', ALL_TASKS)
 def test_device_env_matches_the_host_task_on_the_device(domain, task):
