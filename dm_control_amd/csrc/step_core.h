@@ -37,7 +37,10 @@
 #define DMC_FN inline
 #define DMC_LDS
 #define DMC_GLB
-#define DMC_WSYNC() ((void)0)
+// (host build: a counter -- how many wave-level fences one step executes is what a match on several waves would have to
+// turn into workgroup barriers: scripts/multiwave_probe.py)
+#define DMC_WSYNC() ((void)++dmc_emu_wsync_count)
+static long long dmc_emu_wsync_count = 0;
 #else
 #define DMC_DEV __device__ __forceinline__
 // out-of-line device functions (one copy of the code for all call sites) taking
@@ -1924,7 +1927,10 @@ struct StepCore {
     for (int k = 0; k < 3; k++) { const T dk = dot3(nref, cI[k]); if (-t_abs(dk) < incdot) { incdot = -t_abs(dk); inc = k; } }
     const T incsign = dot3(nref, cI[inc]) > 0 ? (T)-1 : (T)1;
     const int i1 = (inc + 1) % 3, i2 = (inc + 2) % 3, r1 = (ax + 1) % 3, r2 = (ax + 2) % 3;
-    T poly[16][3], tmp[16][3];
+    // (a quad clipped by four half-planes has at most eight vertices: each clip of a convex polygon adds at most one.  The
+    // arrays are indexed at run time, i.e. they live in scratch memory: 2 x 8 x 3 reals, half of what 16 slots took; the
+    // guards below only matter if rounding ever made a clipped polygon non-convex)
+    T poly[8][3], tmp[8][3];
     int np_ = 4;
     for (int v = 0; v < 4; v++) {
       const T a = (v == 0 || v == 3) ? (T)1 : (T)-1, b = v < 2 ? (T)1 : (T)-1;
@@ -1938,8 +1944,8 @@ struct StepCore {
       for (int v = 0; v < np_; v++) {
         const T* P = poly[v]; const T* Q = poly[(v + 1) % np_];
         const T dp = lim - sg*P[coord], dq = lim - sg*Q[coord];
-        if (dp >= 0) { tmp[nn][0] = P[0]; tmp[nn][1] = P[1]; tmp[nn][2] = P[2]; nn++; }
-        if ((dp >= 0) != (dq >= 0)) { const T f = dp/(dp - dq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f*(Q[k] - P[k]); nn++; }
+        if (dp >= 0 && nn < 8) { tmp[nn][0] = P[0]; tmp[nn][1] = P[1]; tmp[nn][2] = P[2]; nn++; }
+        if ((dp >= 0) != (dq >= 0) && nn < 8) { const T f = dp/(dp - dq); for (int k = 0; k < 3; k++) tmp[nn][k] = P[k] + f*(Q[k] - P[k]); nn++; }
       }
       np_ = nn;
       for (int v = 0; v < np_; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];

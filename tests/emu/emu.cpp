@@ -56,6 +56,7 @@ int emu_tree_tables(void* h, int* dims, int* t0, int* t1, int* tri, int* trim) {
   return 0;
 }
 int emu_split_solves_count() { return emu_split_solves(); }
+long long emu_wsync_count() { return dmc_emu_wsync_count; }
 void emu_ls_counts_get(long long* out) { for (int k = 0; k < 6; k++) out[k] = emu_ls_counts()[k]; }
 void emu_stash(void* h, int on) { Emu* e = (Emu*)h; e->stash_on = on; e->stash_epoch++; e->stash_r64.assign(e->tb.L.n_keep + 4, 0.0); e->stash_r32.assign(e->tb.L.n_keep + 4, 0.f); e->stash_i.assign(e->tb.L.n_si + 4, 0); }
 void emu_invalidate(void* h) { ((Emu*)h)->stash_epoch++; }
