@@ -353,6 +353,8 @@ class Environment:
     time around 3.4 ms of physics), is paid once.  Every tensor the step carries over (reset flags, task state,
     detector state) is updated in place, so a replay continues where the previous one ended."""
     torch = self.physics.torch
+    # (a graph keeps the kernel it was captured with: a specialised kernel still compiling in the background is waited for)
+    getattr(getattr(self.physics, 'batch', None), 'wait_specialised', lambda: None)()
     if self._host_all_reset:
       self.reset()
     self._g_action = example_action.clone()

@@ -474,7 +474,8 @@ static int launch_untimed(dmc_batch* b, int nstep, int legacy, int mode, void* s
   hipError_t e;
   const int nsub = sq ? sq->nsub : 1;
   // pieces of a queued Physics.step(nstep) launch (never with the full stash, whose trailing stage belongs to the last step)
-  const int slices = (b->geom.queue && b->d_prog && mode == 0 && !b->stash_on) ? std::min(nstep, b->max_slices) : 1;
+  // (models of more than 16 dofs: the kernels of the small ones are built without the hand-off code, step_core.h kSlices)
+  const int slices = (b->geom.queue && b->d_prog && mode == 0 && !b->stash_on && b->tb.L.d.nv > 16) ? std::min(nstep, b->max_slices) : 1;
   if (b->lpt) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int*)b->d_cost, b->d_order, b->nitems);
   // a specialisation plugin takes the launch unless it was built lean and the launch needs an optional feature
   const bool need_feat = legacy == 2 || b->d_probe != nullptr || b->tb.opts.integrator == DMC_INT_IMPLICITFAST;

@@ -347,13 +347,8 @@ template <int LPE, typename V> DMC_DEV V group_sum(V v) {
   if (LPE >= 4) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
   if (LPE >= 8) v += dpp_f<0x141>(v);   // row_half_mirror
   if (LPE >= 16) v += dpp_f<0x140>(v);  // row_mirror
-#ifdef DMC_NO_PERMLANE_SWAP
-  if (LPE >= 32) v += __shfl_xor(v, 16, 64);
-  if (LPE >= 64) v += __shfl_xor(v, 32, 64);
-#else
   if (LPE >= 32) v = xsum<16>(v);
   if (LPE >= 64) v = xsum<32>(v);
-#endif
 #endif
   return v;
 }
@@ -413,10 +408,6 @@ template <int LPE, int N, typename V> DMC_DEV V bcast_rows(V v, int k) {
 }
 template <int LPE> DMC_DEV int group_max(int v) {
 #ifndef DMC_HOST_EMU
-#ifdef DMC_NO_PERMLANE_SWAP
-#pragma unroll
-  for (int o = LPE / 2; o > 0; o >>= 1) { int w = __shfl_xor(v, o, LPE); v = w > v ? w : v; }
-#else
   int w;
   if (LPE >= 2) { w = dpp_i<0xB1>(v); v = w > v ? w : v; }
   if (LPE >= 4) { w = dpp_i<0x4E>(v); v = w > v ? w : v; }
@@ -424,7 +415,6 @@ template <int LPE> DMC_DEV int group_max(int v) {
   if (LPE >= 16) { w = dpp_i<0x140>(v); v = w > v ? w : v; }
   if (LPE >= 32) v = xmax<16>(v);
   if (LPE >= 64) v = xmax<32>(v);
-#endif
 #endif
   return v;
 }
@@ -434,11 +424,6 @@ template <int LPE> DMC_DEV int group_max(int v) {
 template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
 #ifndef DMC_HOST_EMU
   int inc = v;
-#ifdef DMC_NO_PERMLANE_SWAP
-#pragma unroll
-  for (int o = 1; o < LPE; o <<= 1) { int w = __shfl_up(inc, o, LPE); if (lane >= o) inc += w; }
-  *total = __shfl(inc, LPE - 1, LPE);
-#else
   (void)lane;
   if (LPE >= 2) inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);    // row_shr:1
   if (LPE >= 4) inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);    // row_shr:2
@@ -447,7 +432,6 @@ template <int LPE> DMC_DEV int group_scan(int v, int lane, int* total) {
   if (LPE >= 32) inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
   if (LPE >= 64) inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
   *total = wave_bcast<LPE>(inc, LPE - 1);
-#endif
   return inc - v;
 #else
   (void)lane; *total = v; return 0;
@@ -756,11 +740,7 @@ template <typename T> DMC_DEV constexpr bool ls_relative() { return sizeof(T) ==
 // quadratic rows: the anchored form is a few instructions there) max 2.3e-6 -> 8.2e-7, free; the 30-dof soccer model
 // (general rows; already at 2.5e-7 without it) paid 5.5 % for nothing.  So: every model whose rows are all one-sided
 // quadratic, and the general-row models with more than 32 dofs (StepCore::anchored()).
-#ifdef DMC_NO_LS_ANCHOR
-template <typename T> DMC_DEV constexpr bool ls_anchored() { return false; }
-#else
 template <typename T> DMC_DEV constexpr bool ls_anchored() { return ls_relative<T>(); }
-#endif
 // Returned as a 4-vector {alpha, cost, d0, d1}: a pointer argument pins the caller's
 // points in scratch memory, and returning the struct itself by value measured 2x
 // slower on the whole kernel (MI355X, ROCm 7.2) -- the vector comes back in v0..v3.
@@ -1018,6 +998,10 @@ struct StepCore {
   // out (a launch that needs one runs the generic kernel: launch_step_t): on the 9-dof model they cost 6 VGPRs, 14
   // spilled SGPRs, 2.6 KB of code and 1.2 % of the launch (A/B on one box, profiles/r04_ab_vs_round3.log).
   static constexpr bool kFeat = LS::kNV <= 0 || DMC_STATIC_FEATURES;
+  // sliced items (StepIO::slices): compiled into the generic kernels and the kernels specialised for models of more than
+  // 16 dofs -- the ones whose queued multi-step launches end on a long item; the small models' kernels sit at their
+  // register budget (the hand-off code cost the queued 9-dof kernel 460 B of scratch per lane) and their items are short
+  static constexpr bool kSlices = LS::kNV <= 0 || LS::kNV > 16;
   static constexpr int kPFKin = LS::kNKin > 0 ? ((LS::kNKin + LPE - 1) / LPE < 24 ? (LS::kNKin + LPE - 1) / LPE : 24) : 0;
   struct Entry { int em, fast, kvalid, epoch; };
   struct EntryRegs {
@@ -1033,7 +1017,7 @@ struct StepCore {
     e->em = io.env_mode ? io.env_mode[env] : 0;
     e->kvalid = 0;
     e->epoch = *io.epoch;      // read ONCE per launch: the tags this launch writes carry the epoch it started in
-#if defined(DMC_HOST_EMU) || defined(DMC_NO_ENTRY_LOADS)
+#ifdef DMC_HOST_EMU
     e->fast = 0;
 #else
     e->fast = (L.d.nq <= LPE && L.d.nv <= LPE && L.d.nu <= LPE && L.d.na <= LPE && !io.stash_r) ? 1 : 0;
@@ -1091,7 +1075,7 @@ struct StepCore {
   }
   DMC_DEV void load_state(const StepIO<T>& io, int env, bool have_stash, const Entry& en, bool from_hand = false) {
     const int B = io.B;
-    if (from_hand) load_handoff(io, env);      // a later piece of a sliced item: the state the previous piece handed over
+    if (kSlices && from_hand) load_handoff(io, env);      // a later piece of a sliced item: the state the previous piece handed over
     else if (en.fast) {      // the state is in LDS already (entry_commit)
       if (L.d.na && lane < L.d.na) S(act_dot)[lane] = 0;
       time_ = io.time[env];      // (not needed before the state is stored: nothing waits for it here)
@@ -1269,11 +1253,7 @@ struct StepCore {
   // in the (still unused) composite-inertia buffer, every body walks up its ancestors (world = local_root o ... o
   // local_body) with independent loads; results differ from the level passes by rounding only.
   DMC_DEV bool flat_kin() const {
-#ifdef DMC_NO_FLAT_CHAINS
-    return false;
-#else
     return true;
-#endif
   }
   DMC_DEV void body_compose_chain(int i) {
     T p[3], q[4], m[9];
@@ -1372,7 +1352,6 @@ struct StepCore {
     else { const T sc = MR(body_invsubtreemass)[b]; for (int k = 0; k < 3; k++) S(subtree_com)[3*b + k] = acc[k] * sc; }
   }
   DMC_DEV void com_pos() {
-#ifndef DMC_NO_SUBTREE_SUMS
     if (L.d.dfs) {      // subtree centres of mass in one pass over the id ranges of the subtrees (see crb_mass_matrix)
       FOR_LANES(b, L.d.nbody) {
         const int e = MI(body_subend)[b];
@@ -1383,7 +1362,6 @@ struct StepCore {
       }
       DMC_WSYNC();
     } else
-#endif
     {
     for (int lev = L.d.nlevel - 1; lev >= 0; lev--) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
@@ -1468,7 +1446,6 @@ struct StepCore {
   // ---- CRB mass matrix + factor (mj_crb, mj_factorM) ----------------------------
   DMC_DEV void crb_mass_matrix() {
     const int nv = L.d.nv;
-#ifndef DMC_NO_SUBTREE_SUMS
     if (L.d.dfs) {
       // composite inertias as ONE pass of subtree sums: bodies are numbered depth first, so the subtree of b is the id range
       // [b, subend[b]) -- every (body, component) sums its range with independent loads, instead of nlevel dependent
@@ -1481,7 +1458,6 @@ struct StepCore {
       }
       DMC_WSYNC();
     } else
-#endif
     {
     for (int i = 10 + lane; i < 10*L.d.nbody; i += LPE) S(crb)[i] = SG(cinert)[i];
     DMC_WSYNC();
@@ -1611,7 +1587,7 @@ struct StepCore {
 #endif
   DMC_DEV void factor_M(bool with_damping, const T* damping = nullptr) {      // damping: the diagonal added as timestep * damping[i]
     T* dst = with_damping ? S(qLH) : M_factor();
-#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_FACTOR_ROWS)
+#ifndef DMC_HOST_EMU
     if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
       if (!L.d.msparse) {
         factor_dense_rows<LS::kNV>(with_damping ? damping : (const T*)nullptr, o.timestep, dst);
@@ -2752,7 +2728,6 @@ struct StepCore {
     for (int a = 0; a < 6; a++) S(cvel)[6*i + a] = cvel[a];
   }
   DMC_DEV void com_vel() {
-#ifndef DMC_NO_FLAT_CHAINS
     if (L.d.nv <= 64) {
       // mj_comVel without a pass per tree level: the velocity a dof sees (cdof_dot = cvel x cdof) is the sum of
       // cdof * qvel over the dofs BEFORE it on its path -- before its whole triple for the rotational dofs of a ball /
@@ -2787,7 +2762,6 @@ struct StepCore {
       DMC_WSYNC();
       return;
     }
-#endif
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int k = a0 + lane; k < a1; k += LPE) body_com_vel(MI(level_body)[k]);
@@ -2880,7 +2854,6 @@ struct StepCore {
       if (!(o.disableflags & DMC_DSBL_GRAVITY)) { ca[3] = -o.gravity[0]; ca[4] = -o.gravity[1]; ca[5] = -o.gravity[2]; }
     }
     DMC_WSYNC();
-#ifndef DMC_NO_SUBTREE_SUMS
     if (L.d.dfs && L.d.nv <= 64) {
       // RNE without a pass per tree level: a body's acceleration is the sum of cdof_dot * qvel over the dofs on its path
       // (the ancestor mask of its last dof, ascending = root first), so every body evaluates its own chain and its
@@ -2912,7 +2885,6 @@ struct StepCore {
       DMC_WSYNC();
       return;
     }
-#endif
     for (int lev = 0; lev < L.d.nlevel; lev++) {
       const int a0 = MI(level_adr)[lev], a1 = MI(level_adr)[lev + 1];
       for (int kk = a0 + lane; kk < a1; kk += LPE) {
@@ -4030,7 +4002,6 @@ struct StepCore {
       for (int k = 0; k < 6; k++) bf[6*b + k] = f[k];
     }
     DMC_WSYNC();
-#ifndef DMC_NO_SUBTREE_SUMS
     if (L.d.dfs) {      // B + C in one pass: the dof's lane sums the inertial forces over the subtree of its body (an id range)
       FOR_LANES(i, nv) {
         const int b = MI(dof_bodyid)[i], e = MI(body_subend)[b];
@@ -4040,7 +4011,6 @@ struct StepCore {
       }
       return;
     }
-#endif
     for (int lev = L.d.nlevel - 2; lev >= 0; lev--) {
       const int a0 = MI(level_adr)[lev], cnt = MI(level_adr)[lev + 1] - a0;
       for (int idx = lane; idx < cnt*6; idx += LPE) {
@@ -4190,7 +4160,7 @@ struct StepCore {
     // (no Hessian is ever assembled, so it is still in place)
     if (L.d.cg) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), M_factor(), S(sv_grad), nv, true); DMC_PROF(PROF_SOLVE); return; }
     if (!refactor) { DMC_WSYNC(); chol_solve(S(sv_Mgrad), S(qLH), S(sv_grad), nv, hsplit); DMC_PROF(PROF_SOLVE); return; }
-#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_HESS_ROWS)
+#ifndef DMC_HOST_EMU
     if constexpr (LS::kNV > 0 && LS::kNV <= 16 && LS::kNV <= LPE) {
       if (L.d.jfull && !L.d.msparse && !L.d.elliptic) {
         DMC_WSYNC();
@@ -4441,9 +4411,7 @@ struct StepCore {
     DMC_WSYNC();
     LSRows rw;
     rw.jar = rw.jv = rw.D = 0; rw.on = false; rw.gen = false; rw.kind = LSK_NONE;
-#if !defined(DMC_NO_LS_REGS)
     if (general_rows() && nefc <= LPE && LPE > 1) ls_load_gen(rw, nefc);
-#endif
     if (L.d.elliptic && !rw.gen) ls_prepare_ell(nefc);
     T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     const bool anch = anchored();
@@ -4460,7 +4428,7 @@ struct StepCore {
     T gtol = o.tolerance * o.ls_tolerance * snorm / scale;
     const int lsmax = o.ls_iterations;
     int evals = 0;
-#if !defined(DMC_HOST_EMU) && !defined(DMC_NO_LS_REGS)
+#ifndef DMC_HOST_EMU
     if (!general_rows() && nefc <= LPE) {
       rw.on = true;
       if (lane < nefc) { rw.jar = S(efc_jar)[lane]; rw.jv = S(efc_jv)[lane]; rw.D = S(efc_D)[lane]; }
@@ -4469,7 +4437,6 @@ struct StepCore {
     DMC_PROF(PROF_LS_SETUP);
     LSPoint p0, p1, p2, pmid, p1next, p2next;
     p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals, rw);
-#ifndef DMC_NO_LS_SLOPE_FLOOR
     // fp32: the slope cannot be resolved below a few ulp of the slope at alpha = 0 (the sums that form it are that
     // large), while MuJoCo's gtol = tolerance * ls_tolerance * |search| / scale sits ~1e-10 below it: fp64 gets there in
     // 4.5 evaluations per search (quadratic convergence), fp32 never did and refined the bracket until no candidate
@@ -4481,7 +4448,6 @@ struct StepCore {
       if (sizeof(T) == 4) gtol = t_max(gtol, (T)((u ? atof(u) : (double)DMC_LS_SLOPE_ULPS) * 1.1920929e-7) * t_abs(p0.d0)); }
 #else
     if (sizeof(T) == 4) gtol = t_max(gtol, (T)(DMC_LS_SLOPE_ULPS * 1.1920929e-7) * t_abs(p0.d0));
-#endif
 #endif
     p1.alpha = p0.alpha - p0.d0/p0.d1; ls_eval(&p1, qg, nefc, &evals, rw);
 #ifdef DMC_HOST_EMU
@@ -5030,7 +4996,6 @@ struct StepCore {
     const RowMap rm = row_map();
     bool built = false;
 #ifndef DMC_HOST_EMU
-#ifndef DMC_NO_NS_LANES
     // (out of line: its own register allocation -- inside the acceleration stage its 2 N live values spilled)
     if constexpr (LS::kNV > 0 && LS::kNV <= 32 && LPE == 64) {
       if (nf <= LPE) {
@@ -5038,7 +5003,6 @@ struct StepCore {
         built = true;
       }
     }
-#endif
     if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { if (!built) { noslip_build_A_rows<LS::kNV>((const DMC_LDS T*)M_factor(), nf, rm); built = true; } }
 #endif
     if (!built) for (int b = 0; b < nf; b++) {
@@ -5320,9 +5284,6 @@ struct StepCore {
       // (qfrc_constraint = J' efc_force is already that of the solution: every exit of primal_solve is preceded by a
       // newton_gradient at the final (qacc, efc_force), whose first act is this product -- forming it again was 5 % of the
       // 9-dof step)
-#ifdef DMC_CFJ_TWICE
-      constraint_force_to_joint(nefc);
-#endif
     }
     FOR_LANES(i, nv) S(qacc_warmstart)[i] = S(qacc)[i];
     if (lane == 0) SI(imisc)[IM_ITER] = iter;
@@ -5369,14 +5330,10 @@ struct StepCore {
 #define DMC_STALL_ITERS 6
 #endif
     while (iter < o.iterations) {
-#if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
+#ifndef DMC_HOST_EMU
       // a launch ends with its slowest wave, and that is one whose solve takes many iterations: from the third
       // iteration on it wins the issue arbitration against the wave it shares the SIMD with (which has slack)
-#ifdef DMC_PRIO_LADDER
-      if (iter == 1) __builtin_amdgcn_s_setprio(1); else if (iter == 2) __builtin_amdgcn_s_setprio(2); else if (iter == 3) __builtin_amdgcn_s_setprio(3);
-#else
       if (iter == DMC_PRIO_ITER) __builtin_amdgcn_s_setprio(2);
-#endif
 #endif
       T lscost;
       DMC_TSUB(3, iter == 0, 4);
@@ -5440,15 +5397,11 @@ struct StepCore {
       // 8-ulp floor on the cheetah -- is the rounding of M a - qfrc_smooth - J' f itself.  Iterating on it moves qacc by
       // less than that noise (improvement ~1e-10) and cost the 9-dof model 13 % more Newton iterations than the fp64
       // reference (1.34 vs 1.18 per step; a launch waits for the wave with the most).  The floor is 64 ulp there.
-#ifdef DMC_NO_EXACT_STEP_FLOOR
-      const bool exact_step = false;
-#else
       // Where: the 9-dof model (-14 % iterations, +0.9 % per single-step launch -- which waits for its slowest wave -- +3 % in
       // rollout mode; one-step error unchanged at 4.9e-7 max).  On the 27-dof humanoid it bought 1.5 % for a 5 x larger
       // one-step maximum (8.2e-7 -> 4.0e-6) and on the 62-dof walker nothing for 8.8e-6 -> 4.3e-5
       // (profiles/r05_ab_variants.log): models with nv <= 16 only.
       const bool exact_step = sizeof(T) == 4 && !L.d.cg && L.d.nv <= 16 && !changed && t_abs(alpha - 1) < (T)1e-3;      // (`changed` is also set by any contact in the cone's middle zone, whose cost is not quadratic)
-#endif
       const T tol_grad = t_max(o.tolerance, (exact_step ? 64 : 8)*ulp*scale*t_sqrt(ma2));
 #ifdef DMC_HOST_EMU
       if (getenv("DMC_EMU_TRACE")) fprintf(stderr, "  newton iter %d alpha %.6e cost %.9e improvement %.3e (tol %.3e) gradient %.3e (tol %.3e) changed %d\n",
@@ -5465,7 +5418,7 @@ struct StepCore {
         else if (++stall >= DMC_STALL_ITERS && iter >= 2*DMC_STALL_ITERS) break;
       }
     }
-#if !defined(DMC_NO_SOLVER_PRIO) && !defined(DMC_HOST_EMU)
+#ifndef DMC_HOST_EMU
     __builtin_amdgcn_s_setprio(0);
 #endif
     return iter;
@@ -5770,7 +5723,7 @@ struct StepCore {
   // The three heavy stages are entered through out-of-line functions (StageFns):
   // each gets its own register allocation, so the peak pressure of one stage no
   // longer forces spills in the others, and there is one copy of the code.
-#if !defined(DMC_HOST_EMU) && !defined(DMC_INLINE_STAGES)
+#ifndef DMC_HOST_EMU
   DMC_DEV void call_posvel(bool partial, int outmask, bool skipsensor, bool havekin = false) {
     StageFns<T, LPE, LS>::posvel(ls, (const DMC_LDS StepOpts<T>*)&o, (DMC_LDS int*)mi, (DMC_LDS T*)mr, gc, (DMC_LDS T*)s,
                                  (DMC_LDS int*)si, lane, (partial ? 1 : 0) | (skipsensor ? 2 : 0) | (havekin ? 4 : 0), outmask);
@@ -5876,6 +5829,7 @@ struct StepCore {
       if (em == 2) return;
       if (em == 1 && (mode == 0 || mode >= 4)) mode = 2;
     }
+    if constexpr (!kSlices) { piece = 0; npieces = 1; }
     if (mode != 0 && piece > 0) return;      // (an env the launch override turned into mj_forward: one pass, in the first piece)
     if (mode != 0) npieces = 1;
     if (mode >= 4) { run_split(io, env, mode, outmask, en); return; }
@@ -5883,7 +5837,7 @@ struct StepCore {
     const bool stash = io.stash_r != nullptr;
     bool have = false;
     if (stash && mode == 0 && legacy && o.integrator != DMC_INT_RK4) have = load_stash(io, env);
-    load_state(io, env, have, en, piece > 0);
+    load_state(io, env, have, en, kSlices && piece > 0);
     bool havekin = false;
     // (the stash was only prefetched for a launch that steps: an env switched to mj_forward by env_mode has none)
     if (piece == 0 && io.kstash && mode == 0 && launch_mode == 0 && legacy && !have && o.integrator != DMC_INT_RK4) {
@@ -5937,7 +5891,7 @@ struct StepCore {
       if (it == 0) trace_stamp(io, env, 6);
       DMC_PROF(PROF_EULER);
     }
-    if (!last_piece) { store_handoff(io, env); DMC_PROF(PROF_STORE); prof_end(io, env); return; }      // (the next piece takes it from here)
+    if constexpr (kSlices) if (!last_piece) { store_handoff(io, env); DMC_PROF(PROF_STORE); prof_end(io, env); return; }      // (the next piece takes it from here)
     if (!stepping) dump_debug(io, env);
     // an environment the launch override turned into mj_forward (just re-initialised) reports its one state in every slot
     if (!stepping && launch_mode == 0) probe_store(io, env, 0, nstep);

@@ -54,11 +54,7 @@ struct LaunchGeom {
 // arguments they were spilled to VGPR lanes in the 16-dword tuples they were loaded in -- every use of ONE pointer
 // read 16 lanes back (2 400 v_readlane in the cheetah kernel).  From LDS a use is one ds_read_b64.
 template <typename T> constexpr int stepopts_lds_bytes() { return (int)((sizeof(StepOpts<T>) + 15) / 16 * 16); }
-#ifdef DMC_IO_KERNARG
-template <typename T> constexpr int opts_lds_bytes() { return stepopts_lds_bytes<T>(); }
-#else
 template <typename T> constexpr int opts_lds_bytes() { return stepopts_lds_bytes<T>() + (int)((sizeof(StepIO<T>) + 15) / 16 * 16); }
-#endif
 
 // QUEUE = false: every wave has exactly one item (the batch fits the resident grid) -- no claim loop, so nothing of
 // the body is "loop invariant": with the loop the kernel arguments are hoisted out of it, spilled to VGPR lanes
@@ -97,12 +93,21 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
   // dispatch), so that everything an environment leaves in global memory between its pieces is written and read
   // through ONE L2.  (The per-XCD L2s are not coherent with each other: two of them holding dirty lines of the same
   // per-env scratch could write them back in either order.)  A position is claimed with one atomicAdd on the queue's head.
-  const int NX = (QUEUE && io_arg.work && io_arg.nxcd > 1) ? io_arg.nxcd : 1;
+  // the argument structs go to LDS first (read from there by everything behind the barrier): with the queue's claim -- an
+  // atomic round trip -- in front of these copies the compiler parked both structs in every lane's scratch (+ 500 B)
+  if (tid == 0) *o_lds = o_arg;
+  StepIO<T>* io_lds = reinterpret_cast<StepIO<T>*>(smem + stepopts_lds_bytes<T>());
+  if (tid == 64 % nthr) *io_lds = io_arg;
+  const StepIO<T>& io = *io_lds;
+  int* const q_work = QUEUE ? io_arg.work : nullptr;
+  int* const q_prog = QUEUE ? io_arg.prog : nullptr;
+  const int q_slices = QUEUE ? io_arg.slices : 0, q_nxcd = QUEUE ? io_arg.nxcd : 1;
+  const int NX = (QUEUE && q_work && q_nxcd > 1) ? q_nxcd : 1;
   const int xq = NX > 1 ? (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)NX) : 0;      // HW_REG_XCC_ID[3:0]
   const int nq_items = (nitems - xq + NX - 1) / NX;      // items of this wave's queue
-  const int npieces = (QUEUE && io_arg.work && io_arg.prog && io_arg.slices > 1 && mode == 0) ? io_arg.slices : 1;
+  const int npieces = (Core::kSlices && QUEUE && q_work && q_prog && q_slices > 1 && mode == 0) ? q_slices : 1;
   const int nslots = nq_items * npieces;
-  int* const head = (QUEUE && io_arg.work) ? io_arg.work + 32 * (1 + xq) : nullptr;      // (a 128-byte line per head)
+  int* const head = (QUEUE && q_work) ? q_work + 32 * (1 + xq) : nullptr;      // (a 128-byte line per head)
   int slot = lblk * wpb + wave, piece = 0;
   bool have_item = slot < nitems;
   if (QUEUE && head) {
@@ -110,8 +115,8 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     if ((tid & 63) == 0) nx = atomicAdd(head, 1);
     nx = __builtin_amdgcn_readfirstlane(nx);
     have_item = nx < nslots;
-    piece = nx / nq_items;
-    slot = (nx - piece * nq_items) * NX + xq;
+    for (piece = 0; nx >= nq_items && piece < npieces - 1; piece++) nx -= nq_items;      // (at most seven trips: no division sequence)
+    slot = nx * NX + xq;
   }
   int env0 = 0;
   if (have_item && piece == 0) {
@@ -126,14 +131,6 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     en.em = io_arg.env_mode ? io_arg.env_mode[e0] : 0; en.fast = 0; en.kvalid = 0; en.epoch = *io_arg.epoch;
   }
   // stage the model constant tables once per workgroup (shared by all its envs)
-  if (tid == 0) *o_lds = o_arg;
-#ifdef DMC_IO_KERNARG
-  const StepIO<T>& io = io_arg;
-#else
-  StepIO<T>* io_lds = reinterpret_cast<StepIO<T>*>(smem + stepopts_lds_bytes<T>());
-  if (tid == 64 % nthr) *io_lds = io_arg;
-  const StepIO<T>& io = *io_lds;
-#endif
   for (int i = tid; i < L.n_mi; i += nthr) mi[i] = g_mi[i];
   for (int i = tid; i < L.n_mr_lds; i += nthr) mr[i] = g_mr[i];   // large models: only the hot tables (StepLayout::n_mr_lds)
   // small models: the cold tables ride along in LDS (after the real tables); large ones read them from global memory
@@ -168,7 +165,7 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const int env = item * epw + (g & (epw - 1));
     int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 8 * nitems : nullptr;
     if (QUEUE && piece > 0)      // (the state itself is read with loads that bypass this CU's L1: StepCore::load_handoff)
-      while (__hip_atomic_load(io.prog + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) __builtin_amdgcn_s_sleep(8);
+      while (__hip_atomic_load(q_prog + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) __builtin_amdgcn_s_sleep(8);
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     if (tr && (threadIdx.x & 63) == 0 && piece == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en, piece, npieces);
@@ -194,28 +191,28 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     if (QUEUE && piece < npieces - 1) {
       // the hand-off record was written with write-through (sc1) stores: once they are acknowledged the flag may go
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if ((threadIdx.x & 63) == 0) __hip_atomic_store(io.prog + item, piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(q_prog + item, piece + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!QUEUE || !head) break;
     int nx = 0;
     if ((threadIdx.x & 63) == 0) nx = atomicAdd(head, 1);
     nx = __builtin_amdgcn_readfirstlane(nx);
     if (nx >= nslots) break;
-    piece = nx / nq_items;
-    slot = (nx - piece * nq_items) * NX + xq;
+    for (piece = 0; nx >= nq_items && piece < npieces - 1; piece++) nx -= nq_items;
+    slot = nx * NX + xq;
     const int nitem = io.order ? io.order[slot] : slot;
     int nenv = nitem * epw + ((threadIdx.x / LPE) & (epw - 1));
     if (nenv >= io.B) nenv = io.B - 1;
     // (later items load in place, inside run(): up here the registers are full of what the loop keeps alive)
     en.em = io.env_mode ? io.env_mode[nenv] : 0; en.fast = 0; en.kvalid = 0;
   }
-  if (QUEUE && io_arg.work && (threadIdx.x & 63) == 0) {
+  if (QUEUE && q_work && (threadIdx.x & 63) == 0) {
     // every wave makes exactly one failing claim before it gets here, so the last wave to arrive can re-arm the queues
     // for the next launch on the stream
-    if (atomicAdd(io_arg.work + 1, 1) == nwaves - 1) {
-      atomicExch(io_arg.work + 1, 0);
-      for (int x = 0; x < NX; x++) atomicExch(io_arg.work + 32 * (1 + x), 0);
-      if (npieces > 1) for (int i = 0; i < nitems; i++) io_arg.prog[i] = 0;      // (every piece is complete: nobody reads it any more)
+    if (atomicAdd(q_work + 1, 1) == nwaves - 1) {
+      atomicExch(q_work + 1, 0);
+      for (int x = 0; x < NX; x++) atomicExch(q_work + 32 * (1 + x), 0);
+      if (npieces > 1) for (int i = 0; i < nitems; i++) q_prog[i] = 0;      // (every piece is complete: nobody reads it any more)
     }
   }
 }

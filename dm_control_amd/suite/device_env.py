@@ -634,6 +634,7 @@ class GenericDeviceEnv:
   def _captured_step(self, action):
     torch = self.torch
     if self._graph is None:
+      getattr(self.host_physics.batch, 'wait_specialised', lambda: None)()      # (a graph keeps the kernel it was captured with)
       self._g_action = action.clone()
       state = [self._tensors[n] for n in ('qpos', 'qvel', 'qacc_warmstart', 'time', 'ctrl', 'act') if n in self._tensors]
       saved = [t.clone() for t in state]

@@ -198,6 +198,7 @@ class TorchBatchedEnv:
     replay."""
     torch = self.torch
     if self._graph is None:
+      self.physics.wait_specialised()      # (a graph keeps the kernel it was captured with)
       self._g_action = action.clone()
       state = [self.qpos, self.qvel, self.warm, self.time, self.ctrl, self.steps] + ([self.act] if self.model.na else [])
       saved = [t.clone() for t in state]
