@@ -488,10 +488,11 @@ def quick_config_leg(cfgid, args, local_rank, nthreads, K=12, W=5, parity_envs=1
 
 def env_step_leg(local_rank, B=4096, K=1000, W=20):
   """Row a1 (control.Environment.step, rl/control.py:99-127) on config 2's workload: the device-resident cheetah run
-  environment (suite/torch_env.py) -- action write, the physics launch, observation, reward, step counters and the
-  per-environment auto-reset -- in the timed region, next to the physics-only rate of the same batch object.  K = one
-  episode (1000 steps): exactly one restart of every environment (joint randomisation + the 200 settle steps of
-  Cheetah.initialize_episode, suite/cheetah.py:63-76) falls into the timed region, the rate it is amortised at."""
+  environment -- action write, the physics launch, observation, reward, step counters and the per-environment restart -- in
+  the timed region, next to the physics-only rate of the same batch object.  K = one episode (1000 steps): exactly one
+  restart of every environment falls into the timed region.  Two task layers: suite/fused_env.py (`value`: the compiled
+  one) and the hand-written suite/torch_env.py (`torch_env`: joint randomisation + the 200 settle steps of
+  Cheetah.initialize_episode, suite/cheetah.py:63-76, at every restart)."""
   import torch
   from dm_control_amd.suite import torch_env
   t_leg = time.perf_counter()
@@ -515,11 +516,40 @@ def env_step_leg(local_rank, B=4096, K=1000, W=20):
     env.ctrl.copy_(acts[t].T); env.physics.step(env.n_sub_steps, stream=stream)
   torch.cuda.synchronize()
   el_phys = time.perf_counter() - t0
-  out = dict(workload="suite 'cheetah run' as a device-resident environment (torch_env): obs (B, 17) + reward + done + auto-reset per step",
-             value=B * K / el, unit='env-steps/s', steps=K, warmup=W, ms_per_step=1e3 * el / K, batch=B,
-             physics_only_same_batch=B * K / el_phys, env_over_physics=el_phys / el,
-             finite=bool(torch.isfinite(obs).all().item()), leg_seconds=time.perf_counter() - t_leg)
+  hand = dict(value=B * K / el, unit='env-steps/s', steps=K, ms_per_step=1e3 * el / K, physics_only_same_batch=B * K / el_phys,
+              env_over_physics=el_phys / el, finite=bool(torch.isfinite(obs).all().item()),
+              note='suite/torch_env.py: hand-written torch task layer, start states drawn on the device per episode (200 settle steps per restart)')
   env.close()
+  # the same environment through suite/fused_env.py: the host port's task code compiled into the epilogue of the step kernel
+  # (one launch per env-step), per-environment episode ends, restarts from a device-resident pool of start states drawn by
+  # the port's own initialize_episode at construction
+  from dm_control_amd.suite import fused_env
+  fe = fused_env.make('cheetah', 'run', B, precision=32, device_id=local_rank, copy_outputs=False)
+  for t in range(W):
+    fe.step(acts[t])
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(W, W + K):
+    fobs, frew, fdone = fe.step(acts[t])
+  torch.cuda.synchronize()
+  fel = time.perf_counter() - t0
+  ctrl = fe._tensors['ctrl']      # pylint: disable=protected-access
+  fe.restart(); fe.step(acts[0])
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(W, W + K):
+    ctrl.copy_(acts[t].T); fe.host_physics.batch.step(fe.n_sub_steps, stream=stream)
+  torch.cuda.synchronize()
+  fel_phys = time.perf_counter() - t0
+  out = dict(workload="suite 'cheetah run' as a device-resident environment: obs (B, 17) + reward + done / first flags + per-environment restarts, "
+                      "every step; %d steps = one episode of every environment" % K,
+             value=B * K / fel, unit='env-steps/s', steps=K, warmup=W, ms_per_step=1e3 * fel / K, batch=B,
+             physics_only_same_batch=B * K / fel_phys, env_over_physics=fel_phys / fel, launches_per_env_step=1 if fe.inline else 2,
+             task_layer='suite/fused_env.py: get_observation / get_reward of suite/cheetah.py traced and generated as the epilogue of the step kernel'
+                        if fe.inline else 'suite/fused_env.py: generated task kernel behind the physics launch',
+             episodes_started=int(fe.episode.sum().item()), finite=bool(torch.isfinite(fobs).all().item()),
+             torch_env=hand, leg_seconds=time.perf_counter() - t_leg)
+  fe.close()
   return out
 
 

@@ -28,4 +28,6 @@ timeout 1200 python scripts/fused_env_runs.py > gpurun_out/r06_fused_env_runs.lo
 timeout 100 python scripts/tail_probe.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cheetah.json gpurun_out/r06_wave_tail_cfg2.json
 CONFIG=5 timeout 200 python scripts/tail_probe_cfg.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cfg5.json gpurun_out/r06_wave_tail_cfg5.json
 for c in 4 3; do CONFIG=$c timeout 300 python scripts/queue_probe.py > /dev/null 2>&1; cp gpurun_out/queue_probe_cfg$c.json gpurun_out/r06_queue_probe_cfg$c.json; done
+DMC_BENCH_SINGLE_DEVICE=1 DMC_BENCH_BACKEND=gloo DMC_BENCH_NO_PMC=1 timeout 600 python bench.py --gpus 2 --config 2 --steps 50 --warmup 5 --no-cpu-baseline --parity-steps 0 --pipeline 0 2>/dev/null | tail -1 > gpurun_out/r06_2rank_gloo_single_device.json; echo "2-rank harness rc=$?"
+REPS=2 bash scripts/ab_vs_round5.sh > /dev/null 2>&1; tail -16 gpurun_out/r06_ab_vs_round5.log
 python scripts/r06_profiles.py

@@ -8,7 +8,7 @@ PRE = os.environ.get('OUT_PREFIX', 'r06')      # a second session of the round i
 OUT = lambda f: os.path.join(P, f.replace('r06_', PRE + '_', 1))
 for f in ['r06_bench_cfg%d.json' % c for c in (2, 3, 4, 5)] + ['r06_bench_driver_cmd.json', 'r06_composer_runs.json', 'r06_soak_all_tasks.json',
          'r06_pcie_probe_cfg2.json', 'r06_gputests.log', 'r06_reference_on_hip.log', 'r06_config_runs.json', 'r06_smoke.log', 'r06_fused_env_runs.json',
-         'r06_queue_probe_cfg3.json', 'r06_queue_probe_cfg4.json', 'r06_bench_driver_cmd_pmc.json', 'r06_ab_vs_round5.log'] + ['r06_bench_f64_cfg%d.json' % c for c in (2, 3, 4, 5)] + ['r06_wave_tail_cfg%d.json' % c for c in (2, 3, 4, 5)]:
+         'r06_queue_probe_cfg3.json', 'r06_queue_probe_cfg4.json', 'r06_bench_driver_cmd_pmc.json', 'r06_ab_vs_round5.log', 'r06_2rank_gloo_single_device.json', 'r06_fused_env_runs.log'] + ['r06_bench_f64_cfg%d.json' % c for c in (2, 3, 4, 5)] + ['r06_wave_tail_cfg%d.json' % c for c in (2, 3, 4, 5)]:
   if os.path.exists(os.path.join(G, f)):
     shutil.copy(os.path.join(G, f), OUT(f))
 for c in (2, 3, 4, 5):
