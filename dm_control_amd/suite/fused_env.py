@@ -210,7 +210,8 @@ def evaluate(g, outputs, load, attr):
   return [ev(n) for n in outputs]
 
 
-_G = None      # the graph being traced (one trace at a time; guarded by FusedDeviceEnv)
+_G = None      # the graph being traced (one trace at a time: _TRACE_LOCK)
+_TRACE_LOCK = __import__('threading').Lock()
 
 
 def _g():
@@ -816,8 +817,7 @@ class TaskProgram:
   def __init__(self, title, task, view_cls, host_physics, rows, attrs, precision):
     global _G
     g = Graph()
-    if _G is not None:
-      raise RuntimeError('fused_env: nested trace')
+    _TRACE_LOCK.acquire()
     _G = g
     try:
       v = object.__new__(view_cls)
@@ -866,6 +866,7 @@ class TaskProgram:
           term_discount = float(getattr(task, 'termination_discount', 0.0))
     finally:
       _G = None
+      _TRACE_LOCK.release()
     T = 'float' if precision == 32 else 'double'
     lines, ref = _emit(g, obs_nodes + [reward, term], T)
     nobs = len(obs_nodes)
@@ -1005,6 +1006,18 @@ class FusedDeviceEnv:
     post.done, post.first, post.terminated = self.done.data_ptr(), self.first.data_ptr(), self.terminated.data_ptr()
     post.ep = ep
     self._ep, self._post = ep, post
+    # the launch writes back only what the task layer reads (default: every derived array, contact lists included --
+    # 10 us of a 76 us cheetah launch)
+    from dm_control_amd.batch import OUT
+    bit = dict(sensordata='sensor', xpos='xpos', xquat='xquat', xmat='xmat', xipos='xipos', geom_xpos='geom', geom_xmat='geom',
+               site_xpos='site', site_xmat='site', subtree_com='subtree_com', qacc='qacc', actuator_force='actuator',
+               qfrc_actuator='qfrc', qfrc_bias='qfrc', qfrc_constraint='qfrc', cvel='cvel')
+    mask = 0
+    for f, _ in prog.fields:
+      if f in bit:
+        mask |= OUT[bit[f]]
+    self.output_mask = mask
+    p.batch.set_output_mask(mask)
     # ---- the task layer inside the step kernel
     self.inline = False
     if inline:
@@ -1023,6 +1036,15 @@ class FusedDeviceEnv:
   def _draw_pool(self, attrs=None):
     torch = self.torch
     p = self.host_physics
+    from dm_control_amd.batch import OUT_ALL
+    p.batch.set_output_mask(OUT_ALL)      # (the host port's initialize_episode may read any derived array through the facade)
+    try:
+      self._draw_rounds(p, torch, attrs)
+    finally:
+      if getattr(self, 'output_mask', None) is not None:
+        p.batch.set_output_mask(self.output_mask)
+
+  def _draw_rounds(self, p, torch, attrs):
     for r in range(self.rounds):
       p.data._invalidate()      # pylint: disable=protected-access
       with p.reset_context():
