@@ -805,6 +805,13 @@ struct DynLayoutSrc {
 #endif
 template <typename T, int LPE, typename LS> struct StageFns;   // out-of-line stage entry points (below)
 
+// What a task epilogue (StepIO::task_args; suite/fused_env.py) may read straight from the environment's LDS scratch at the
+// end of its launch instead of reading the launch's stores back from global memory: the arrays store_state /
+// store_outputs copy row for row.  (Not here: site poses, which only exist as stores; xquat / geom_xmat, which the
+// large models keep in global memory.)
+template <typename T>
+struct TaskLds { const T *qpos, *qvel, *ctrl, *act, *sensordata, *xpos, *xmat, *xipos, *subtree_com, *geom_xpos, *cvel; };
+
 template <typename T, int LPE, typename LS = DynLayoutSrc>
 struct StepCore {
   LS ls;
@@ -5800,6 +5807,12 @@ struct StepCore {
     store_state(io, env);
   }
   // substep probe (StepIO::probe): slots [first, first + count) take the probed geom's current world position
+  DMC_DEV TaskLds<T> task_lds() const {
+    TaskLds<T> v;
+    v.qpos = S(qpos); v.qvel = S(qvel); v.ctrl = S(ctrl); v.act = S(act); v.sensordata = S(sensordata); v.xpos = S(xpos);
+    v.xmat = S(xmat); v.xipos = S(xipos); v.subtree_com = S(subtree_com); v.geom_xpos = S(geom_xpos); v.cvel = S(cvel);
+    return v;
+  }
   DMC_DEV void probe_store(const StepIO<T>& io, int env, int first, int count) {
     if constexpr (!kFeat) return;
     env = late(env);      // (addresses derived from env are formed here, not kept alive across the pass loop)

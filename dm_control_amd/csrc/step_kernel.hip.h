@@ -173,8 +173,9 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     // the generated task layer of this model's task (suite/fused_env.py), by one lane per environment: it reads what the
     // launch has just stored (loads that bypass the L1, after the wave's stores are acknowledged)
     if (io.task_args && mode == 0 && piece == npieces - 1 && env < io.B) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) dmc_task::task_post(*(const dmc_task::PostArgs*)io.task_args, env);
+      // (what the function reads from global memory -- and the state a restart overwrites -- was stored by this wave: drained first)
+      if (dmc_task::kReadsGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) dmc_task::task_post(*(const dmc_task::PostArgs*)io.task_args, env, core.task_lds());
     }
 #endif
     if (tr && (threadIdx.x & 63) == 0 && piece == npieces - 1) {

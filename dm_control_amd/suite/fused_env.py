@@ -640,9 +640,7 @@ def _emit(g, outputs, T):
       f, row = n.args
       name, kind = g.fields[f]
       cty = 'int' if kind == 'i' else ('double' if name == 'time' else 'T')
-      expr = 'ld(&((const %s*)a.field[%d])[(size_t)%d * B + e])' % (cty, f, row)
-      if name == 'time':
-        expr = '(T)' + expr
+      expr = 'LD_F%d(%d)' % (f, row)
     elif n.op == 'attr':
       k, j = n.args
       expr = 'ld(&((const T*)a.attr[%d])[(size_t)e * %d + %d])' % (k, g.attrs[k][1], j)
@@ -702,8 +700,16 @@ __device__ inline void restart(const Episode& a, int e) {
 }
 // one environment's task layer after its physics launch: observation, reward, termination, the step's flags -- and, when
 // the episode ends here, the start state of the next one (its first observation is the NEXT step's)
-__device__ inline void task_post(const PostArgs& a, int e) {
+#ifdef DMC_TASK_IN_KERNEL
+typedef dmc::TaskLds<T> Lds;      // the environment's own arrays in LDS, row for row what the launch stored (step_core.h)
+#define DMC_TASK_LDS(name, row) (v.name[row])
+#else
+struct Lds {};
+#endif
+%(ld_macros)s
+__device__ inline void task_post(const PostArgs& a, int e, const Lds& v = Lds()) {
   const int B = a.B;
+  (void)B; (void)v;
 %(body)s
   const bool f = a.ep.pending[e] != 0;      // this launch was the episode's first (mj_forward at the start state)
   const int st = a.ep.steps[e] + (f ? 0 : 1);
@@ -714,8 +720,12 @@ __device__ inline void task_post(const PostArgs& a, int e) {
   a.terminated[e] = term ? 1 : 0;
   a.done[e] = d ? 1 : 0; a.first[e] = f ? 1 : 0;
 %(obs_store)s
-  if (d) restart(a.ep, e);
-  else { a.ep.steps[e] = st; a.ep.pending[e] = 0; a.ep.env_mode[e] = 0; }
+  if (d) {
+#ifdef DMC_TASK_IN_KERNEL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the launch's own stores of the state a restart overwrites)
+#endif
+    restart(a.ep, e);
+  } else { a.ep.steps[e] = st; a.ep.pending[e] = 0; a.ep.env_mode[e] = 0; }
 }
 }  // namespace dmc_task
 '''
@@ -887,7 +897,21 @@ class TaskProgram:
       pre.append('  for (int k = 0; k < %d; k++) ((T*)a.attr[%d])[(size_t)e * %d + k] = ((const T*)a.attr_pool[%d])[((size_t)r * B + e) * %d + k];'
                  % (w, i, w, i, w))
     # post's attribute slots follow the ORDER OF USE in the expressions; pre's follow all_attrs
-    self.header = _HDR % dict(title=title, T=T, nstate=max(1, len(self.state)), nattr1=max(1, len(self.all_attrs), len(self.attrs)),
+    # one load macro per field: inside the step kernel the arrays that live in the environment's LDS scratch are read there
+    # (no wait for the launch's stores, no memory round trip at the tail of the launch), everything else from global memory
+    in_lds = ('qpos', 'qvel', 'ctrl', 'act', 'sensordata', 'xpos', 'xmat', 'xipos', 'subtree_com', 'geom_xpos', 'cvel')
+    macros = []
+    for f, (name, kind) in enumerate(g.fields):
+      cty = 'int' if kind == 'i' else ('double' if name == 'time' else 'T')
+      glob = '%sld(&((const %s*)a.field[%d])[(size_t)(row) * B + e])' % ('(T)' if name == 'time' else '', cty, f)
+      if name in in_lds and kind == 'f':
+        macros += ['#ifdef DMC_TASK_IN_KERNEL', '#define LD_F%d(row) DMC_TASK_LDS(%s, row)' % (f, name), '#else',
+                   '#define LD_F%d(row) %s' % (f, glob), '#endif']
+      else:
+        macros.append('#define LD_F%d(row) %s' % (f, glob))
+    reads_global = any(not (name in in_lds and kind == 'f') for name, kind in g.fields) or bool(g.attrs)
+    macros.append('static constexpr bool kReadsGlobal = %s;' % ('true' if reads_global else 'false'))
+    self.header = _HDR % dict(title=title, T=T, ld_macros='\n'.join(macros), nstate=max(1, len(self.state)), nattr1=max(1, len(self.all_attrs), len(self.attrs)),
                               nfield1=max(1, len(self.fields)), pre_copy='\n'.join(pre), body='\n'.join(lines),
                               term=ref(term), reward=ref(reward, 'f'), term_discount=repr(term_discount), obs_store='\n'.join(store))
     self.title = title
@@ -981,6 +1005,7 @@ class FusedDeviceEnv:
     self.first = torch.zeros(B, dtype=u8, device=dev)
     self.done = torch.zeros(B, dtype=u8, device=dev)
     self.terminated = torch.zeros(B, dtype=u8, device=dev)
+    self._done_bool = self.done.view(torch.bool)
     self.steps = torch.zeros(B, dtype=torch.int32, device=dev)
     self.episode = torch.zeros(B, dtype=torch.int32, device=dev)
     self.obs = torch.zeros((B, prog.nobs), dtype=self.dtype, device=dev)
@@ -1122,8 +1147,8 @@ class FusedDeviceEnv:
     else:
       self._launches()
     if self._copy_outputs:
-      return self.obs.clone(), self.reward.clone(), self.done.bool()
-    return self.obs, self.reward, self.done.bool()
+      return self.obs.clone(), self.reward.clone(), self._done_bool.clone()
+    return self.obs, self.reward, self._done_bool      # (a bool VIEW of the flag bytes: `done.bool()` would be one more launch per step)
 
   def reset(self):
     """Every environment starts a new episode; returns its first observation (one step whose launch only evaluates the
