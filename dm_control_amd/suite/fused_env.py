@@ -14,15 +14,16 @@ code instead:
   codegen  the DAG of every observation entry, the reward and the termination flag is written out as straight-line C++,
            one GPU thread per environment (the batch is the thread index: every task expression is per-environment),
            compiled by hipcc for gfx950 into a small shared object cached by source hash (as specialise.py's plugins).
-  run      a control step is three launches recorded in one HIP graph:
-             pre   environments whose episode ended in the previous step take a start state (and the per-episode task
-                   attributes: targets ...) from a device-resident pool drawn by the host port's own
-                   `initialize_episode`, get `env_mode` 1 (mj_forward without actuation instead of a step,
-                   rl/control.py:232-253) and step count 0; the action matrix (B, nu) is transposed into `ctrl`
-             step  the fused physics launch (dmc_batch_step with the per-environment launch override)
-             post  observation (B, nobs), reward, termination, step counters, `done` / `first` / `discount` -- per
-                   ENVIRONMENT: an lqr environment ends at the step its own state norm falls below the tolerance
-                   (suite/lqr.py:264), not when the whole batch has
+  run      ONE generated device function, `task_post(args, env)`: observation (B, nobs), reward, termination, the step
+           counter, `done` / `first` / `discount` / `terminated` -- per ENVIRONMENT: an lqr environment ends at the step its
+           own state norm falls below the tolerance (suite/lqr.py:264), not when the whole batch has -- and, where the
+           episode ended, the next start state (and the per-episode task attributes: targets ...) from a device-resident
+           pool drawn by the host port's own `initialize_episode`, with that environment's launch override set to
+           mj_forward without actuation (rl/control.py:232-253) for the next launch.  It runs
+             inline   (default) as the epilogue of a step kernel specialised for (model, task): one lane of the wave that
+                      stepped an environment evaluates it on the environment's own LDS arrays -- Environment.step is ONE
+                      launch (plus the (B, nu) -> (nu, B) action copy; `step(None)` when the policy writes `env.ctrl`)
+             or       as a small kernel of its own behind the physics launch (both recorded in one HIP graph).
   No host read per step, episode boundaries included.  dm_env semantics, vectorised: the step in which an episode ends
   returns its last observation / reward with done = True; the NEXT step returns the first observation of the new episode
   (first = True, reward 0) while the rest of the batch steps -- the reference's LAST / FIRST pair (rl/control.py:99-127).
@@ -1121,13 +1122,15 @@ class FusedDeviceEnv:
     if rc:
       raise RuntimeError('fused_post: hip error %d' % rc)
 
-  def step(self, action):
-    """action: (B, nu) device tensor.  Returns (obs, reward, done); `self.first / discount / terminated` describe the same
-    step.  Environments flagged done restart in the NEXT call (first = True there).  With `copy_outputs=False` the
-    returned tensors are the environment's own buffers, rewritten by the next step."""
+  def step(self, action=None):
+    """action: (B, nu) device tensor -- or None when the caller has written the controls into `self.ctrl` itself (the
+    batch's own (nu, B) control rows: a policy that emits that layout saves the transposing copy, the one launch a step
+    makes beside the physics).  Returns (obs, reward, done); `self.first / discount / terminated` describe the same step.
+    Environments flagged done restart in the NEXT call (first = True there).  With `copy_outputs=False` the returned
+    tensors are the environment's own buffers, rewritten by the next step."""
     torch = self.torch
-    if self.ctrl is not None:
-      self.ctrl.copy_(action.T)      # (B, nu) -> the batch's (nu, B) control rows: the one launch outside the graph
+    if self.ctrl is not None and action is not None:
+      self.ctrl.copy_(action.T)      # (B, nu) -> the batch's (nu, B) control rows
     if self._capture:
       if self._graph is None:
         saved = [self.pending, self.steps, self.episode, self._tensors['env_mode']] + [self._tensors[f] for f in self._state_names] + list(self._attr_live.values())
