@@ -24,7 +24,7 @@ for c in 2 3 4 5; do
 done
 cd $R
 GRAPH=1 T=300 timeout 400 python scripts/composer_runs.py > gpurun_out/r06_composer.log 2>&1; echo "composer rc=$?"; cp gpurun_out/composer_runs.json gpurun_out/r06_composer_runs.json
-timeout 1200 python scripts/fused_env_runs.py > gpurun_out/r06_fused_env_runs.log 2>&1; tail -1 gpurun_out/r06_fused_env_runs.log
+T=1000 timeout 1800 python scripts/fused_env_runs.py > gpurun_out/r06_fused_env_runs.log 2>&1; tail -1 gpurun_out/r06_fused_env_runs.log
 timeout 100 python scripts/tail_probe.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cheetah.json gpurun_out/r06_wave_tail_cfg2.json
 CONFIG=5 timeout 200 python scripts/tail_probe_cfg.py > /dev/null 2>&1; cp gpurun_out/tail_probe_cfg5.json gpurun_out/r06_wave_tail_cfg5.json
 for c in 4 3; do CONFIG=$c timeout 300 python scripts/queue_probe.py > /dev/null 2>&1; cp gpurun_out/queue_probe_cfg$c.json gpurun_out/r06_queue_probe_cfg$c.json; done
