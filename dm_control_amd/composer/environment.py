@@ -275,6 +275,12 @@ class Environment:
     p, torch = self.physics, self.physics.torch
     if self._host_all_reset:
       return self.reset()
+    # a task may offer the whole control step as a few launches of its own kernels (tasks/soccer.py); None = not here
+    device_step = getattr(self.task, 'device_step', None)
+    if device_step is not None:
+      ts = device_step(self, action)
+      if ts is not None:
+        return ts
     first = self._reset_next.clone()
     # environments whose episode ended last step start a new one now; the others take a regular step.  The
     # re-initialisation is data-dependent but needs no host decision: the state edits are applied under the mask,

@@ -31,6 +31,9 @@ recompiles; a batch shares one compiled model, so the 4 walls and 20 goal posts 
 (`DevicePhysics.declare_env_geoms`, dmc_batch_set_env_geoms) and their rows of the 'env_geom' tensor are rewritten on
 device under the reset mask.  Default: the fixed 40 x 30 pitch of the asset.
 """
+import ctypes
+import os
+
 import numpy as np
 
 from dm_control_amd import mjcf_compiler
@@ -75,6 +78,44 @@ def kickoff_qpos(model):
     q[qx], q[qy] = xy
   q[a['ball_q'] + 2] = 0.5
   return q
+
+
+
+# ---- the task layer as two kernels (soccer_task.hip) ----------------------------------------------------------------
+def _args_struct(real):
+  P = ctypes.c_void_p
+  ints = [(n, ctypes.c_int) for n in ('B', 'nq', 'nv', 'nu', 'nsub', 'rounds', 'ball_q', 'ball_v', 'ball_geom', 'ball_linvel')]
+  fields = ints + [('place_rows', ctypes.c_int * 15), ('ctrl_rows', ctypes.c_int * 12), ('root', ctypes.c_int * 4), ('ncomp', ctypes.c_int),
+                   ('time_limit', ctypes.c_double), ('spawn_ratio', real), ('ball_z', real), ('pi', real)]
+  fields += [(n, P) for n in ('qpos', 'qvel', 'ctrl', 'warm', 'time', 'env_mode', 'warning', 'qpos0', 'size', 'state', 'lo', 'hi',
+                              'prev_action', 'geom_xpos', 'xpos', 'xmat', 'cvel', 'sensordata', 'action', 'u_place', 'u_shrink',
+                              'trace', 'reset_next', 'reward', 'discount', 'step_type', 'comp')]
+
+  class SoccerArgs(ctypes.Structure):
+    _fields_ = fields
+  return SoccerArgs
+
+
+_KERNELS = {}
+
+
+def task_kernels(precision, verbose=False):
+  """(library, SoccerArgs) of soccer_task.hip for fp32 / fp64: compiled by hipcc for gfx950 on first use into the in-tree
+  plugin cache (as the model-specialised step kernels and the suite's generated task layers are)."""
+  k = _KERNELS.get(precision)
+  if k is None:
+    from dm_control_amd.suite import fused_env
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'soccer_task.hip')) as f:
+      src = '#define DMC_SOCCER_REAL %s\n' % ('float' if precision == 32 else 'double') + f.read()
+    lib = ctypes.CDLL(fused_env._compile(src, verbose=verbose))
+    S = _args_struct(ctypes.c_float if precision == 32 else ctypes.c_double)
+    if lib.soccer_args_size() != ctypes.sizeof(S):
+      raise RuntimeError('soccer_task.hip: SoccerArgs is %d bytes on the device side, %d here' % (lib.soccer_args_size(), ctypes.sizeof(S)))
+    for fn in (lib.soccer_pre, lib.soccer_post):
+      fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(S)]
+      fn.restype = ctypes.c_int
+    k = _KERNELS[precision] = (lib, S)
+  return k
 
 
 class PositionDetector:
@@ -157,7 +198,8 @@ class DetectorBank(environment.Entity):
 
 class Soccer2v2(environment.Task):
 
-  def __init__(self, model=None, control_timestep=0.025, spawn_ratio=_SPAWN_RATIO, randomize_pitch=None):
+  def __init__(self, model=None, control_timestep=0.025, spawn_ratio=_SPAWN_RATIO, randomize_pitch=None, task_kernels=True):
+    self._task_kernels = bool(task_kernels)      # device_step: the control step's task layer as two kernels (soccer_task.hip)
     self.model = model or mjcf_compiler.compile_xml(common.read_model(_ASSET + '.xml'))
     self.set_timesteps(control_timestep=control_timestep, physics_timestep=0.005)      # task.py:105-106
     self._spawn_ratio = spawn_ratio
@@ -342,6 +384,80 @@ class Soccer2v2(environment.Task):
   def should_terminate_episode(self, physics):
     return self.home_goal.detected | self.away_goal.detected
 
+  # -- the control step as launches ------------------------------------------------------------------
+  def device_step(self, env, action):
+    """`composer.Environment.step` for this task on the device in six launches -- two random draws, `soccer_pre`, the
+    physics launch with the substep probe, `soccer_post`, the observation gather -- instead of the ~150 small tensor
+    operations of the hooks above (0.5 ms next to 0.9 ms of physics at B = 256).  Same random stream, same results
+    (tests/test_gpu_composer.py::test_soccer_task_kernels_equal_the_tensor_task_layer).  Returns None where it does
+    not apply (a randomised pitch, extra hooks, unfused substeps, a physics without device tensors): the caller then
+    runs the hooks."""
+    p = env.physics
+    torch = p.torch
+    if (not self._task_kernels or self._randomize is not None or not env.probed or self._gen is None or self.model.na or
+        getattr(p, 'batch', None) is None or not hasattr(p.batch, 'set_step_probe') or p.device.type != 'cuda' or
+        any(env._hooks._extra.values()) or os.environ.get('DMC_SOCCER_KERNELS', '1') == '0'):
+      return None
+    B, n_sub = p.B, env.n_sub_steps
+    d = self.__dict__.get('_dev')
+    if d is None or d['B'] != B or d['n_sub'] != n_sub:
+      d = self._dev = self._device_plan(env)
+    a = d['args']
+    act = action if (action.dtype == p.dtype and action.is_contiguous() and action.device == p.device) else d['act'].copy_(action)
+    a.action = act.data_ptr()
+    torch.rand(d['u_place'].shape, generator=self._gen, device=p.device, dtype=p.dtype, out=d['u_place'])      # _place's draw
+    torch.rand(d['u_shrink'].shape, generator=self._gen, device=p.device, dtype=p.dtype, out=d['u_shrink'])    # the throw-in's
+    reward = torch.empty((4, B), dtype=p.dtype, device=p.device)
+    discount = torch.empty(B, dtype=p.dtype, device=p.device)
+    step_type = torch.empty(B, dtype=torch.int32, device=p.device)
+    comp = torch.empty((B, 4, self._obs_C), dtype=p.dtype, device=p.device)
+    a.reward, a.discount, a.step_type, a.comp = reward.data_ptr(), discount.data_ptr(), step_type.data_ptr(), comp.data_ptr()
+    lib, st = d['lib'], p.stream()
+    rc = lib.soccer_pre(st, ctypes.byref(a))
+    if rc:
+      raise RuntimeError('soccer_pre: hip error %d' % rc)
+    p.mark_as_dirty()
+    p.step(n_sub)
+    env.launches += 1
+    rc = lib.soccer_post(st, ctypes.byref(a))
+    if rc:
+      raise RuntimeError('soccer_post: hip error %d' % rc)
+    G = p.gather(self._obs_table).view(B, 4, self._obs_P)
+    return environment.TimeStep(step_type=step_type, reward=reward, discount=discount, observation=self._observation_views(G, comp))
+
+  def _device_plan(self, env):
+    p = env.physics
+    torch = p.torch
+    B, n_sub, m = p.B, env.n_sub_steps, self.model
+    if getattr(self, '_obs_layout', None) is None:
+      self._observation_plan(p)
+    self.detectors.materialise(p)
+    lib, S = task_kernels(32 if p.dtype == torch.float32 else 64)
+    R = 4
+    d = dict(B=B, n_sub=n_sub, lib=lib,
+             u_place=torch.empty((R, 5, 3, B), dtype=p.dtype, device=p.device), u_shrink=torch.empty((2, B), dtype=p.dtype, device=p.device),
+             act=torch.empty((B, 4, 3), dtype=p.dtype, device=p.device), qpos0=p.const(m.qpos0),
+             trace=p.substep_probe(env._hooks.probe_geom, n_sub))
+    a = S()
+    a.B, a.nq, a.nv, a.nu, a.nsub, a.rounds = B, m.nq, m.nv, m.nu, n_sub, R
+    a.ball_q, a.ball_v, a.ball_geom, a.ball_linvel = self._ball_q, self._ball_v, self._ball_geom, self._ball_linvel
+    a.place_rows[:] = [int(r) for r in self._place_rows.tolist()]
+    a.ctrl_rows[:] = [int(r) for r in self._ctrl_rows_t.tolist()]
+    a.root[:] = self._root
+    a.ncomp = self._obs_C
+    a.time_limit = float(env._time_limit)
+    a.spawn_ratio, a.ball_z, a.pi = self._spawn_ratio, _INIT_BALL_Z - 0.35, np.pi
+    assert _THROW_IN_BALL_Z == _INIT_BALL_Z
+    for name in ('qpos', 'qvel', 'ctrl', 'time', 'env_mode', 'warning', 'geom_xpos', 'xpos', 'xmat', 'cvel', 'sensordata'):
+      setattr(a, name, p.field(name).data_ptr())
+    a.warm = p.field('qacc_warmstart').data_ptr()
+    a.qpos0, a.size = d['qpos0'].data_ptr(), self._size_t.data_ptr()
+    a.state, a.lo, a.hi = self.detectors.state.data_ptr(), self.detectors.lo.data_ptr(), self.detectors.hi.data_ptr()
+    a.prev_action, a.u_place, a.u_shrink = self._prev_action.data_ptr(), d['u_place'].data_ptr(), d['u_shrink'].data_ptr()
+    a.trace, a.reset_next = d['trace'].data_ptr(), env._reset_next.data_ptr()
+    d['args'] = a
+    return d
+
   # -- observations --------------------------------------------------------------------------------------
   def _frame(self, physics, k):
     b = self._root[k]
@@ -471,6 +587,10 @@ class Soccer2v2(environment.Task):
     pieces = [self._prev_action]                                                 # (4, 3, B)
     pieces += [E[:, m, :d] for m, d in enumerate(self._CORNER_DIMS)]
     comp = torch.cat(pieces + [stats], dim=1).permute(2, 0, 1)                   # (B, 4, C)
+    return self._observation_views(G, comp)
+
+  def _observation_views(self, G, comp):
+    """The observation dictionary over the gathered (B, 4, P) and the computed (B, 4, C) blocks."""
     out = {}
     for name, src, off, w in self._obs_layout:
       if src == 'g':

@@ -8,8 +8,12 @@ from dm_control_amd import composer
 
 out = []
 T = int(os.environ.get('T', 1000))
-for name, B, kw in (('cmu_go_to_target', 4096, {}), ('soccer_2v2', 256, {}), ('soccer_2v2', 256, dict(fuse_substeps=True)),
+ONLY = os.environ.get('ONLY')
+for name, B, kw in (('cmu_go_to_target', 4096, {}), ('soccer_2v2', 256, {}), ('soccer_2v2', 256, dict(task_kernels=False)),
+                    ('soccer_2v2', 256, dict(fuse_substeps=True)), ('soccer_2v2', 4096, {}), ('soccer_2v2', 4096, dict(task_kernels=False)),
                     ('soccer_2v2', 4096, dict(fuse_substeps=True))):
+  if ONLY and ONLY not in name:
+    continue
   env = composer.make(name, B, **kw)
   m = env.task.model
   shape = (B, 4, 3) if name.startswith('soccer') else (B, m.nu)

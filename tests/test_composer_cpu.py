@@ -348,3 +348,16 @@ def test_soccer_pitch_resize_rows_reproduce_the_compiled_pitch():
   assert abs(float(lo[0, 1]) + 32.0) < 1e-12 and abs(float(hi[1, 1]) - 24 * 0.33) < 1e-12
   flo, fhi = task.field.bounds(p)
   assert abs(float(fhi[0, 1]) - (32.0 - 32. / 6.)) < 1e-12 and float(fhi[0, 2]) == 40.0 - 32. / 6.      # masked-out env keeps 40 x 30
+
+
+def test_soccer_task_kernels_build_and_agree_on_their_argument_struct():
+  """tasks/soccer_task.hip cross-compiles for gfx950 (no GPU needed) and its SoccerArgs has the size of the ctypes
+  mirror in tasks/soccer.py, for both precisions (task_kernels() raises on a mismatch); the entry points exist."""
+  import ctypes
+  for precision in (32, 64):
+    lib, S = soccer.task_kernels(precision)
+    assert lib.soccer_args_size() == ctypes.sizeof(S)
+    assert hasattr(lib, 'soccer_pre') and hasattr(lib, 'soccer_post')
+  env, _, _ = _soccer_env(2)
+  # the CPU stand-in has no device tensors: the environment runs the hooks
+  assert env.task.device_step(env, None) is None

@@ -199,7 +199,7 @@ def test_soccer_probed_launch_equals_the_per_substep_hooks_on_gpu(precision):
   from dm_control_amd import composer
   from dm_control_amd.composer import environment
   B = 24
-  envs = [composer.make('soccer_2v2', B, random_state=6, precision=precision, fuse_substeps=f) for f in (None, False)]
+  envs = [composer.make('soccer_2v2', B, random_state=6, precision=precision, fuse_substeps=f, task_kernels=False) for f in (None, False)]      # (both as tensor operations: the task kernels have their own test below)
   assert envs[0].probed and not envs[1].fused
   gen = torch.Generator(device='cuda').manual_seed(3)
   acts = torch.rand((30, B, 4, 3), device='cuda', generator=gen) * 2 - 1
@@ -234,6 +234,63 @@ def test_soccer_probed_launch_equals_the_per_substep_hooks_on_gpu(precision):
   print('measured: soccer probed vs hooked launches, fp%d: max observation difference %.2e over 30 control steps' % (precision, worst))
   assert scored >= 4
   assert envs[0].launches == 1 + 30 and envs[1].launches == 1 + 150      # one launch per control step against five
+  for e in envs:
+    assert int(e.physics.field('warning')[:8].sum()) == 0
+    e.close()
+
+
+@pytest.mark.parametrize('precision', [64, 32])
+def test_soccer_task_kernels_equal_the_tensor_task_layer(precision):
+  """tasks/soccer_task.hip (`Soccer2v2.device_step`: the control step as six launches) against the task's hooks as tensor
+  operations (`task_kernels=False`, ~150 launches), from the same seeds over episodes with goals, throw-ins, time-limit
+  ends and auto-resets: same placements and throw-ins (the same random stream, bit-equal states), step types, rewards,
+  discounts; observations equal to rounding (the einsum / norm reductions of the tensor form may sum in another order)."""
+  import torch
+  from dm_control_amd import composer
+  from dm_control_amd.composer import environment
+  B = 40
+  envs = [composer.make('soccer_2v2', B, random_state=9, precision=precision, time_limit=0.4, task_kernels=k) for k in (True, False)]
+  gen = torch.Generator(device='cuda').manual_seed(5)
+  T = 48
+  acts = torch.rand((T, B, 4, 3), device='cuda', generator=gen) * 2 - 1
+  for e in envs:
+    e.reset()
+  dt = envs[0].physics.dtype
+  ends, throw_ins, worst = 0, 0, 0.0
+  for t in range(T):
+    for e in envs:
+      task, p = e.task, e.physics
+      bq, bv = task._ball_q, task._ball_v
+      if t in (3, 21):      # a shot that crosses the goal volume within the control step, in a few environments
+        p.field('qpos')[bq:bq + 7, :4] = torch.tensor([33.0, 0.0, 1.0, 1, 0, 0, 0], device='cuda', dtype=dt)[:, None]
+        p.field('qvel')[bv:bv + 6, :4] = torch.tensor([60.0, 0.0, 2.0, 0, 0, 0], device='cuda', dtype=dt)[:, None]
+        p.mark_as_dirty()
+      if t in (5, 30):      # balls rolling off the court: thrown in at the next control step
+        p.field('qpos')[bq:bq + 3, 8:14] = torch.tensor([0.0, -27.5, 0.2], device='cuda', dtype=dt)[:, None]
+        p.field('qvel')[bv:bv + 6, 8:14] = 0
+        p.mark_as_dirty()
+    if t in (6, 31):
+      throw_ins += int(envs[0].task.field.detected.sum())
+      assert torch.equal(envs[0].task.field.detected, envs[1].task.field.detected)
+    a, b = [e.step(acts[t]) for e in envs]
+    torch.cuda.synchronize()
+    assert torch.equal(a.step_type, b.step_type), t
+    assert torch.equal(a.reward, b.reward) and torch.equal(a.discount, b.discount), t
+    for f in ('qpos', 'qvel', 'ctrl'):
+      assert torch.equal(envs[0].physics.field(f), envs[1].physics.field(f)), (f, t)
+    assert torch.equal(envs[0].task.detectors.state, envs[1].task.detectors.state), t
+    assert set(a.observation) == set(b.observation)
+    for k in a.observation:
+      assert a.observation[k].shape == b.observation[k].shape, k
+      err = float((a.observation[k] - b.observation[k]).abs().max() / max(1.0, float(b.observation[k].abs().max())))
+      worst = max(worst, err)
+      assert err <= (1e-12 if precision == 64 else 2e-6), (k, t, err)
+    ends += int((a.step_type == environment.LAST).sum())
+  print('measured: soccer task kernels vs tensor task layer, fp%d: max relative observation difference %.2e over %d control steps, '
+        '%d episode ends, %d throw-ins' % (precision, worst, T, ends, throw_ins))
+  assert envs[0].task._dev is not None and '_dev' not in envs[1].task.__dict__
+  assert ends >= B + 4 and throw_ins >= 6      # every environment ran into the time limit at least once; goals; throw-ins
+  assert envs[0].launches == envs[1].launches == 1 + T
   for e in envs:
     assert int(e.physics.field('warning')[:8].sum()) == 0
     e.close()
