@@ -545,6 +545,137 @@ DMC_FN void chol_factor_rows(DMC_LDS T* A, int lane) {
   DMC_WSYNC();
 }
 #endif
+// The same factorisation on the MATRIX CORES for the large fp32 models (32 < N <= 64, one environment per wave): blocked
+// right-looking U'U on 16 x 16 tiles held in the accumulator layout of v_mfma_f32_16x16x4_f32 -- lane 16 g + c, register r
+// of a tile = its element (4 g + r, c).  Fed as BOTH operands, register by register, two tiles X, Y in that layout give
+// X'Y (operand A reads lane l as A[l & 15][l >> 4], operand B as B[l >> 4][l & 15]: register r of X is X'[i][4 k + r],
+// register r of Y is Y[4 k + r][j], and the four instructions r = 0 .. 3 cover the sixteen k) -- which is the trailing update
+// A_ij -= U_ki' U_kj of the upper-triangular form, in place, with no layout conversion: 40 matrix instructions do what
+// 1 891 v_readlane + v_fma pairs do in chol_factor_rows<62>.  The sixteen columns of a diagonal tile are eliminated on
+// the vector ALU, together with the rest of their block row (which is the panel solve): the pivot comes by v_readlane,
+// the column below it by DPP row_newbcast (the diagonal tile is kept whole and symmetric, so column C0 of a row group is
+// lane C0 of that row group), the scaled pivot row reaches the other row groups through one ds_bpermute per tile; rows at
+// or above the pivot get a zero multiplier instead of a predicate.  Rows / columns N .. 63 enter as the identity.  The
+// packed triangle leaves as chol_factor_rows leaves it (scaled columns, 1 / L_kk on the diagonal); the sums run in another
+// order (the products of a tile update are added k-slot by k-slot), so the factor differs from chol_factor_rows' by
+// rounding.  Measured (scripts/chol_mfma_probe.hip, profiles/r06_chol_mfma_probe.log): 2 191 instructions against 5 118,
+// 17.0 k cycles per factorisation against 38.9 k with five waves per CU.
+#if !defined(DMC_HOST_EMU)
+typedef float dmc_f4 __attribute__((ext_vector_type(4)));
+template <int N> struct CholTiles {
+  static constexpr int NB = (N + 15) / 16;
+  struct LaneInfo { int g, col4, lane; float fgt[3]; };      // fgt[q] = 1 where the lane's row group g > q, else 0
+  // the value of the lane of the same column in row group GC, for every row group: on the diagonal tile (the critical
+  // chain) by two VALU swaps, on the rest of the block row through the LDS crossbar (off the chain; 18.5 k -> 15.3 k cycles)
+  template <int GC, bool DIAG> static DMC_DEV float bcast_rowgroup(float x, int col4) {
+    if constexpr (!DIAG) return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(col4 + 64 * GC, __builtin_bit_cast(int, x)));
+    else {
+      const unsigned u = __builtin_bit_cast(unsigned, x);
+      const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // h[0]: row groups (0 1 0 1), h[1]: (2 3 2 3)
+      const unsigned y = GC < 2 ? h[0] : h[1];
+      const auto q = __builtin_amdgcn_permlane16_swap(y, y, false, false);      // q[0]: the even group everywhere, q[1]: the odd
+      return __builtin_bit_cast(float, (GC & 1) ? q[1] : q[0]);
+    }
+  }
+  template <int K, int C0> static DMC_DEV void eliminate_column(dmc_f4 (&t)[NB][NB], const LaneInfo& tl) {
+    constexpr int GC = C0 >> 2, RC = C0 & 3;
+    dmc_f4& D = t[K][K];
+    const float inv = __builtin_amdgcn_rsqf(__builtin_amdgcn_fmed3f(readlane_t(D[RC], 16 * GC + C0), (float)DMC_MINVAL, __builtin_inff()));
+    // the column below the pivot, scaled; rows at or above the pivot row get a zero multiplier, folded into the scale
+    // (4 g + r > C0  <=>  r > RC ? g >= GC : g > GC)
+    const float inv_ge = GC == 0 ? inv : inv * tl.fgt[GC > 0 ? GC - 1 : 0];
+    const float inv_gt = GC == 3 ? 0.f : inv * tl.fgt[GC < 3 ? GC : 0];
+    float ui[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) ui[r] = (GC == 3 && r <= RC) ? 0.f : dpp_all<0x150 + C0>(D[r]) * (r > RC ? inv_ge : inv_gt);
+    const float scale = tl.g == GC ? inv : 1.f;      // the pivot row itself is scaled in place
+#pragma unroll
+    for (int j = K; j < NB; j++) {
+      dmc_f4& P = t[K][j];
+      P[RC] = P[RC] * scale;
+      const float X = j == K ? bcast_rowgroup<GC, true>(P[RC], tl.col4) : bcast_rowgroup<GC, false>(P[RC], tl.col4);
+#pragma unroll
+      for (int r = 0; r < 4; r++) if (!(GC == 3 && r <= RC)) P[r] = P[r] - ui[r] * X;
+    }
+    D[RC] = (tl.lane == 16 * GC + C0) ? inv : D[RC];      // the packed form keeps 1 / L_kk on the diagonal
+  }
+  template <int K, int C0> struct Columns {
+    static DMC_DEV void run(dmc_f4 (&t)[NB][NB], const LaneInfo& tl) {
+      eliminate_column<K, C0>(t, tl);
+      if constexpr (C0 + 1 < 16) Columns<K, C0 + 1>::run(t, tl);
+    }
+  };
+  template <int K> static DMC_DEV void block_column(dmc_f4 (&t)[NB][NB], const LaneInfo& tl) {
+    Columns<K, 0>::run(t, tl);
+#pragma unroll
+    for (int i = K + 1; i < NB; i++) {
+      const dmc_f4 nx = -t[K][i];
+#pragma unroll
+      for (int j = i; j < NB; j++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(nx[r], t[K][j][r], t[i][j], 0, 0, 0);
+      }
+    }
+    if constexpr (K + 1 < NB) block_column<K + 1>(t, tl);
+  }
+  static DMC_DEV constexpr int c0(int j) { return j * N - ((j * (j - 1)) >> 1); }      // tri_c0(j, N)
+  // Packed index of element (R, C), R <= C, of tile (bi, bj), register r, for the lane (g, c): tri_c0(R) + C - R with
+  // R = R0 + G (R0 = 16 bi + r, G = 4 g)  =  [tri_c0(R0) + 16 bj - R0] + [tri_c0(G) - G + c] - R0 G
+  static DMC_DEV void factor(DMC_LDS float* A, int lane) {
+    static_assert(N > 16 && N <= 64, "two to four tiles a side");
+    const int g = lane >> 4, c = lane & 15, G = 4 * g;
+    LaneInfo tl; tl.g = g; tl.col4 = 4 * c; tl.lane = lane;
+#pragma unroll
+    for (int q = 0; q < 3; q++) tl.fgt[q] = g > q ? 1.f : 0.f;
+    const int up = c0(G) - G + c;                      // lane part of the upper-triangle index
+    const int tc = ((c * (2 * N + 1 - c)) >> 1) - c;   // tri_c0(c) - c: lane part of the mirrored (lower-triangle) index
+    dmc_f4 t[NB][NB];
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+      for (int bj = bi; bj < NB; bj++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int R0 = 16 * bi + r;
+          int at = c0(R0) + 16 * bj - R0 + up - R0 * G;
+          if (bi == bj) {      // the diagonal tiles enter whole (symmetric): below the diagonal the mirrored entry
+            const int low = c0(16 * bi) + tc - 16 * bi * c + R0 - 16 * bi + G;
+            at = (G + r <= c) ? at : low;
+          }
+          float v = A[at];      // (unpredicated: an index past the triangle reads a neighbouring array, the value is dropped)
+          if (16 * bj + 15 >= N) { const bool in = (16 * bj + c < N) && (bi < bj || 16 * bi + G + r < N); v = in ? v : ((bi == bj && G + r == c) ? 1.f : 0.f); }
+          t[bi][bj][r] = v;
+        }
+    block_column<0>(t, tl);
+    // stores: an entry that does not exist (below the diagonal of a diagonal tile, past column N) aims at the slot of the
+    // lane's entry (row 4 g, column 16 + c) -- which exists for every lane and is stored LAST, over whatever landed there
+    const int safe = 16 + up;
+#pragma unroll
+    for (int bi = NB - 1; bi >= 0; bi--)
+#pragma unroll
+      for (int bj = NB - 1; bj >= bi; bj--)
+#pragma unroll
+        for (int r = 3; r >= 0; r--) {
+          const int R0 = 16 * bi + r;
+          int at = c0(R0) + 16 * bj - R0 + up - R0 * G;
+          bool ok = true;
+          if (bi == bj) ok = G + r <= c;
+          if (16 * bj + 15 >= N) ok = ok && (16 * bj + c < N);
+          if (bi == bj || 16 * bj + 15 >= N) at = ok ? at : safe;
+          if (!(bi == 0 && bj == 1 && r == 0)) A[at] = t[bi][bj][r];
+        }
+    asm volatile("" ::: "memory");
+    A[safe] = t[0][1][0];
+  }
+};
+template <int LPE, int N>
+DMC_FN void chol_factor_tiles(DMC_LDS float* A, int lane) {
+  static_assert(LPE == 64, "one environment per wave");
+  DMC_WSYNC();
+  CholTiles<N>::factor(A, lane);
+  DMC_WSYNC();
+}
+#endif
 // Substitution for model-specialised kernels: lane i loads its row and its column of L up
 // front (all loads in flight together), then both sweeps run on registers and v_readlane --
 // no LDS access inside the 2 N dependent steps.  Same operations as chol_solve_lds.
@@ -1420,6 +1551,12 @@ struct StepCore {
                                  && false
 #endif
       ;
+  // fp32 models of 33 .. 64 dofs on one wave per environment factor on the matrix cores (chol_factor_tiles)
+  static constexpr bool kTiles = sizeof(T) == 4 && LPE == 64 && LS::kNV > 32 && LS::kNV <= 64
+#if defined(DMC_NO_CHOL_TILES) || defined(DMC_HOST_EMU)
+                                 && false
+#endif
+      ;
   DMC_DEV void chol_factor_inplace(T* A, int n, bool split = false) {
 #ifndef DMC_HOST_EMU
     if constexpr (kSplit) {
@@ -1429,6 +1566,7 @@ struct StepCore {
         return;
       }
     }
+    if constexpr (kTiles) { chol_factor_tiles<LPE, LS::kNV>((DMC_LDS float*)A, lane); return; }
     if constexpr (LS::kNV > 0 && LS::kNV <= LPE) { chol_factor_rows<T, LPE, LS::kNV>((DMC_LDS T*)A, lane); return; }
 #endif
     chol_factor_lds<T, LPE>((DMC_LDS T*)A, n, lane);
