@@ -601,7 +601,7 @@ template <int N> struct CholTiles {
   }
   template <int K, int C0> struct Columns {
     static DMC_DEV void run(dmc_f4 (&t)[NB][NB], const LaneInfo& tl) {
-      eliminate_column<K, C0>(t, tl);
+      if constexpr (16 * K + C0 < N) eliminate_column<K, C0>(t, tl);      // (the columns past N are the identity's)
       if constexpr (C0 + 1 < 16) Columns<K, C0 + 1>::run(t, tl);
     }
   };
@@ -622,7 +622,7 @@ template <int N> struct CholTiles {
   // Packed index of element (R, C), R <= C, of tile (bi, bj), register r, for the lane (g, c): tri_c0(R) + C - R with
   // R = R0 + G (R0 = 16 bi + r, G = 4 g)  =  [tri_c0(R0) + 16 bj - R0] + [tri_c0(G) - G + c] - R0 G
   static DMC_DEV void factor(DMC_LDS float* A, int lane) {
-    static_assert(N > 16 && N <= 64, "two to four tiles a side");
+    static_assert(N > 32 && N <= 64, "three or four tiles a side (store()'s spare slot is an entry of column 16 + c: N >= 32; below 33 dofs the row form is as fast)");
     const int g = lane >> 4, c = lane & 15, G = 4 * g;
     LaneInfo tl; tl.g = g; tl.col4 = 4 * c; tl.lane = lane;
 #pragma unroll
