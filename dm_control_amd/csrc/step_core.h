@@ -4558,26 +4558,15 @@ struct StepCore {
     rw.jar = rw.jv = rw.D = 0; rw.on = false; rw.gen = false; rw.kind = LSK_NONE;
     if (general_rows() && nefc <= LPE && LPE > 1) ls_load_gen(rw, nefc);
     if (L.d.elliptic && !rw.gen) ls_prepare_ell(nefc);
-    T a1 = 0, a2 = 0, a3 = 0, a4 = 0, gs = 0;
+    T a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     const bool anch = anchored();
-    // fp32 Newton: the point alpha = 0 is not evaluated (-DDMC_NO_LS_SKIP_P0: evaluated).  Its cost is 0 by definition of the relative
-    // form, its slope is grad . search, and its curvature search' H search is  - grad . search  because the search
-    // direction IS - H^-1 grad with the factor of H at this very point (newton_gradient refactors whenever the active
-    // set or a cone-zone Hessian moved): the first trial step is alpha = 1, the Newton point.  One evaluation of ~4.5 per
-    // search saved; the same function of alpha in exact arithmetic (CG and fp64 keep the evaluation).
-#ifndef DMC_NO_LS_SKIP_P0
-    const bool skip0 = sizeof(T) == 4 && !L.d.cg;
-#else
-    const bool skip0 = false;
-#endif
     FOR_LANES(i, nv) {
       const T sr = S(sv_search)[i];
       if (anch) a1 += sr*S(sv_grad)[i];      // grad . search: the slope at alpha = 0 itself (see ls_anchored)
-      else { a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; if (skip0) gs += sr*S(sv_grad)[i]; }
+      else { a1 += sr*S(sv_Ma)[i]; a2 += S(qfrc_smooth)[i]*sr; }
       a3 += sr*S(sv_Mv)[i]; a4 += sr*sr;
     }
     a1 = group_sum<LPE>(a1); if (!anch) a2 = group_sum<LPE>(a2); a3 = group_sum<LPE>(a3); a4 = group_sum<LPE>(a4);
-    if (skip0) gs = anch ? a1 : group_sum<LPE>(gs);
     T qg[3] = {gauss, a1 - a2, (T)0.5*a3};
     const T snorm = t_sqrt(a4);
     if (snorm < (T)DMC_MINVAL) return 0;
@@ -4592,9 +4581,7 @@ struct StepCore {
 #endif
     DMC_PROF(PROF_LS_SETUP);
     LSPoint p0, p1, p2, pmid, p1next, p2next;
-    p0.alpha = 0;
-    if (skip0 && gs < 0) { p0.cost = 0; p0.d0 = gs; p0.d1 = -gs; evals++; }
-    else ls_eval(&p0, qg, nefc, &evals, rw);
+    p0.alpha = 0; ls_eval(&p0, qg, nefc, &evals, rw);
     // fp32: the slope cannot be resolved below a few ulp of the slope at alpha = 0 (the sums that form it are that
     // large), while MuJoCo's gtol = tolerance * ls_tolerance * |search| / scale sits ~1e-10 below it: fp64 gets there in
     // 4.5 evaluations per search (quadratic convergence), fp32 never did and refined the bracket until no candidate
