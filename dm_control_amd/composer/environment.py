@@ -212,7 +212,13 @@ class _EnvironmentHooks:
 class Environment:
   """B composer-style environments of one task on one GPU."""
 
-  def __init__(self, task, physics, time_limit=float('inf'), random_state=None, n_sub_steps=None, fuse_substeps=None):
+  def __init__(self, task, physics, time_limit=float('inf'), random_state=None, n_sub_steps=None, fuse_substeps=None,
+               observation_options=None, delayed_observation_padding='zero', strip_singleton_obs_buffer_dim=True):
+    """observation_options: {observable name: dict(update_interval=, buffer_size=, delay=, aggregator=)} -- the attributes the
+    reference sets on `task.observables[...]` / `entity.observables.<name>` (observable/base.py:55-63), in physics steps;
+    `delayed_observation_padding` ('zero' / 'initial_value') and `strip_singleton_obs_buffer_dim` are
+    `composer.Environment`'s arguments of the same names (composer/environment.py:188-196; the reference's default for the
+    latter is False -- this class has always returned (B, n), which is True).  See composer/updater.py."""
     self.task = task
     self.physics = physics
     self._time_limit = time_limit
@@ -225,6 +231,11 @@ class Environment:
     self._host_all_reset = True     # known without a device sync: every env is waiting for its reset
     self.launches = 0               # physics STEP launches issued (tests / profiling)
     self.forward_launches = 0       # mj_forward launches ahead of the observations (observation_forward tasks)
+    self._updater = None
+    if observation_options or delayed_observation_padding != 'zero' or not strip_singleton_obs_buffer_dim:
+      from dm_control_amd.composer import updater
+      self._updater = updater.Updater(torch, physics.B, self._n_sub_steps, observation_options,
+                                      pad=delayed_observation_padding, strip_singleton_buffer_dim=strip_singleton_obs_buffer_dim)
 
   @property
   def n_sub_steps(self):
@@ -265,10 +276,14 @@ class Environment:
     self._reset_next.zero_()
     self._host_all_reset = False
     B = self.physics.B
+    obs = self.task.get_observation(self.physics)
+    if self._updater is not None:
+      self._updater.start(obs, mask)      # Updater.reset: the first sample, at time 0
+      obs = self._updater.read(obs)
     return TimeStep(step_type=torch.full((B,), FIRST, dtype=torch.int32, device=self.physics.device),
                     reward=torch.zeros(B, dtype=self.physics.dtype, device=self.physics.device),
                     discount=torch.ones(B, dtype=self.physics.dtype, device=self.physics.device),
-                    observation=self.task.get_observation(self.physics))
+                    observation=obs)
 
   # -- one control step (environment.py:412-465) --------------------------------------------------------
   def step(self, action):
@@ -276,7 +291,7 @@ class Environment:
     if self._host_all_reset:
       return self.reset()
     # a task may offer the whole control step as a few launches of its own kernels (tasks/soccer.py); None = not here
-    device_step = getattr(self.task, 'device_step', None)
+    device_step = getattr(self.task, 'device_step', None) if self._updater is None else None
     if device_step is not None:
       ts = device_step(self, action)
       if ts is not None:
@@ -300,7 +315,20 @@ class Environment:
     # (dmc_batch_step legacy_step 2) -- see below; environments re-initialised in this call are not touched by it
     obs_forward = bool(getattr(task, 'observation_forward', False))
     fold = obs_forward and getattr(p, 'supports_forward_after', True)
-    if self.probed:
+    upd = self._updater
+    running = ~first
+    substeps = upd is not None and upd.needs_substeps      # an observable is sampled between the physics steps
+    if substeps:
+      # updater.py:292-301 after every substep (composer/environment.py:455-458); the last one's pass is the closing one below
+      for k in range(self._n_sub_steps):
+        self._hooks.before_substep(p, action, self._rs)
+        p.step(1, forward_after=fold and k == self._n_sub_steps - 1)
+        self.launches += 1
+        self._hooks.after_substep(p, self._rs)
+        upd.advance(1, running)
+        if k < self._n_sub_steps - 1:
+          upd.sample(task.get_observation(p), running)
+    elif self.probed:
       # one launch; the kernel leaves the probed geom's position after every substep, the entities read that trace
       trace = p.substep_probe(self._hooks.probe_geom, self._n_sub_steps)
       p.step(self._n_sub_steps, forward_after=fold)
@@ -319,6 +347,8 @@ class Environment:
         p.step(1, forward_after=fold and k == self._n_sub_steps - 1)
         self.launches += 1
         self._hooks.after_substep(p, self._rs)
+    if upd is not None and not substeps:
+      upd.advance(self._n_sub_steps, running)
     self._hooks.after_step(p, self._rs)
     if obs_forward and not fold:
       # In the reference the action reaches mjData through an mjcf binding (walker.apply_action), which marks the physics
@@ -341,6 +371,10 @@ class Environment:
     reward = torch.where(diverged if reward.dim() == 1 else diverged[None, :], torch.zeros_like(reward), reward)
     discount = torch.where(diverged, zero, discount)
     obs = task.get_observation(p)
+    if upd is not None:
+      upd.sample(obs, running)      # the pass after the control step's last physics step
+      upd.start(obs, first)         # environments re-initialised in this call: Updater.reset, the first sample of the new episode
+      obs = upd.read(obs)
     step_type = torch.where(first, torch.full_like(first, FIRST, dtype=torch.int32),
                             torch.where(terminating, torch.full_like(first, LAST, dtype=torch.int32),
                                         torch.full_like(first, MID, dtype=torch.int32)))

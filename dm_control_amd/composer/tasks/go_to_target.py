@@ -229,9 +229,13 @@ class GoToTarget(environment.Task):
     return obs
 
 
-def make(batch_size, device_id=0, precision=32, time_limit=30.0, random_state=0, **task_kwargs):
+def make(batch_size, device_id=0, precision=32, time_limit=30.0, random_state=0, observation_options=None,
+         delayed_observation_padding='zero', strip_singleton_obs_buffer_dim=True, **task_kwargs):
   """`composer.Environment(GoToTarget(CMUHumanoidPositionControlled(), Floor()), time_limit=30)` for a batch
-  (locomotion/examples/basic_cmu_2019.py:97-118: physics 0.005 s, control 0.03 s)."""
+  (locomotion/examples/basic_cmu_2019.py:97-118: physics 0.005 s, control 0.03 s).  `observation_options` & co:
+  composer/updater.py (buffered / delayed / aggregated observables)."""
   task = GoToTarget(**task_kwargs)
   physics = task.make_physics(batch_size, device_id=device_id, precision=precision)
-  return environment.Environment(task, physics, time_limit=time_limit, random_state=random_state)
+  return environment.Environment(task, physics, time_limit=time_limit, random_state=random_state,
+                                 observation_options=observation_options, delayed_observation_padding=delayed_observation_padding,
+                                 strip_singleton_obs_buffer_dim=strip_singleton_obs_buffer_dim)

@@ -602,9 +602,13 @@ class Soccer2v2(environment.Task):
     return out                                                                   # name -> (B, 4, n)
 
 
-def make(batch_size, device_id=0, precision=32, time_limit=45.0, random_state=0, fuse_substeps=None, **task_kwargs):
+def make(batch_size, device_id=0, precision=32, time_limit=45.0, random_state=0, fuse_substeps=None, observation_options=None,
+         delayed_observation_padding='zero', strip_singleton_obs_buffer_dim=True, **task_kwargs):
   """`soccer.load(team_size=2, time_limit=45., walker_type=WalkerType.BOXHEAD)` (soccer/__init__.py:92-148) for a
-  batch, on the fixed pitch of the asset."""
+  batch, on the fixed pitch of the asset.  `observation_options` & co: composer/updater.py (buffered / delayed observables;
+  the control step then runs through the tensor task layer, not the task kernels)."""
   task = Soccer2v2(**task_kwargs)
   physics = task.make_physics(batch_size, device_id=device_id, precision=precision)
-  return environment.Environment(task, physics, time_limit=time_limit, random_state=random_state, fuse_substeps=fuse_substeps)
+  return environment.Environment(task, physics, time_limit=time_limit, random_state=random_state, fuse_substeps=fuse_substeps,
+                                 observation_options=observation_options, delayed_observation_padding=delayed_observation_padding,
+                                 strip_singleton_obs_buffer_dim=strip_singleton_obs_buffer_dim)
