@@ -477,13 +477,6 @@ template <bool FUSE, typename T> DMC_DEV T nmsub(T a, T b, T c) {
 // the N row-holding lanes instead of a compare / mask / branch / restore sequence per column (9 x 8 instructions on the
 // 9-dof model, a quarter of the factorisation).
 template <typename T, int N> DMC_DEV void store_factor_rows(DMC_LDS T* A, const T* a, int lane) {
-#ifdef DMC_PRED_STORES
-  if (lane < N) {
-#pragma unroll
-    for (int j = 0; j < N; j++) if (j <= lane) A[tri_c0(j, N) + lane - j] = a[j];
-  }
-  return;
-#endif
   if (lane < N) {
 #pragma unroll
     for (int j = N - 1; j >= 0; j--) { A[tri_c0(j, N) + lane - j] = a[j]; asm volatile("" ::: "memory"); }      // (in THIS order: to one lane the nine addresses are unrelated)
@@ -698,21 +691,6 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
   const T dinv_ = Lm[ci], b_ = b[own ? i : 0];
   const T dinv = own ? dinv_ : (T)0;      // 1 / L[i][i]
   T sreg = own ? b_ : (T)0;
-#ifdef DMC_SOLVE_ROWS_R4
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
-    if (i == k) sreg = xk;
-    if (i > k && own) sreg -= row[k]*xk;
-  }
-#pragma unroll
-  for (int k = N - 1; k >= 0; k--) {
-    const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
-    if (i == k) sreg = xk;
-    if (i < k) sreg -= col[k]*xk;
-  }
-  if (own) x[i] = sreg;
-#else
   // Step k needs x_k = s_k / L[k][k]: every lane forms its own s_i * dinv_i (one VALU op, and lane k's is the value),
   // ONE cross-lane read fetches it, and the update is an unconditional FMA -- row[k] / col[k] are zeros where the
   // step does not reach, so lane k keeps its finished s_k and its x_k is s_k * dinv_k again after the loop.  Three
@@ -725,7 +703,6 @@ DMC_FN void chol_solve_rows(DMC_LDS T* x, const DMC_LDS T* Lm, const DMC_LDS T* 
 #pragma unroll
   for (int k = N - 1; k >= 0; k--) { const T xk = bcast_rows<LPE, N>(sreg*dinv, k); sreg = nmsub<(N <= 16)>(sreg, col[k], xk); }
   if (own) x[i] = sreg*dinv;
-#endif
   DMC_WSYNC();
 }
 #endif
@@ -2494,16 +2471,12 @@ struct StepCore {
       const unsigned char* dofs = con_dof_list(c);
       const int kc = con_ndof(c);
       T acc = 0;
-#ifdef DMC_ROW_DOT_PRED
-      for (int k = 0; k < L.d.kmax; k++) if (k < kc) acc += jr[k] * x[dofs[k]];
-#else
       // (the slots past the contact's dof count are read like the others -- they exist, their dof byte addresses some word of
       // the scratch -- and their product is dropped: no exec-mask sequence per slot)
 #ifdef DMC_HOST_EMU
       for (int k = 0; k < L.d.kmax; k++) { const T j_ = jr[k], x_ = x[k < kc ? dofs[k] : 0], t_ = acc + j_ * x_; acc = k < kc ? t_ : acc; }      // (the host build stays inside x)
 #else
       for (int k = 0; k < L.d.kmax; k++) { const T j_ = jr[k], x_ = x[dofs[k]], t_ = acc + j_ * x_; acc = k < kc ? t_ : acc; }
-#endif
 #endif
       return acc;
     }
@@ -3746,16 +3719,10 @@ struct StepCore {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const bool in = r + u < rm.tl0;
-#ifdef DMC_HSPLIT_PRED
-          const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
-          const T dd = in ? S(efc_D)[r + u] : (T)0;
-          if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
-#else
           const int rr = in ? r + u : r;      // (a padding row re-reads the trip's first row: no load behind a predicate)
           const int st = SI(efc_active)[rr], tid = SI(efc_tid)[rr];
           const T dd = S(efc_D)[rr], t_ = dsum + dd;
           dsum = (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) ? t_ : dsum;
-#endif
         }
       }
       S(sv_Mgrad)[i] = dsum;
@@ -3827,12 +3794,8 @@ struct StepCore {
         } else {
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
             const T ji = J[q*K + a];
-#ifdef DMC_HSPLIT_PRED
-            if (ji != 0) acc += (S(efc_D)[r0 + q]*ji) * J[q*K + b2];
-#else
             const T jj = J[q*K + b2], t_ = acc + (S(efc_D)[r0 + q]*ji) * jj;
             acc = ji != 0 ? t_ : acc;
-#endif
           }
         }
         S(qLH)[tri_at(i, j, nv)] += acc;
@@ -3854,16 +3817,10 @@ struct StepCore {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const bool in = r + u < rm.tl0;
-#ifdef DMC_HSPLIT_PRED
-          const int st = in ? SI(efc_active)[r + u] : 0, tid = in ? SI(efc_tid)[r + u] : 0;
-          const T dd = in ? S(efc_D)[r + u] : (T)0;
-          if (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) dsum += dd;
-#else
           const int rr = in ? r + u : r;      // (a padding row re-reads the trip's first row: no load behind a predicate)
           const int st = SI(efc_active)[rr], tid = SI(efc_tid)[rr];
           const T dd = S(efc_D)[rr], t_ = dsum + dd;
           dsum = (in && st == EFC_ST_QUADRATIC && simple_dof(tid) == i) ? t_ : dsum;
-#endif
         }
       }
       S(sv_Mgrad)[i] = dsum;
@@ -3895,9 +3852,6 @@ struct StepCore {
         const unsigned lo = con_mask_lo(c), hi = con_mask_hi(c);
         const int a0 = mask_slot(lo, hi, i0), b0 = mask_slot(lo, hi, j0), a1 = mask_slot(lo, hi, i1), b1 = mask_slot(lo, hi, j1);
         const bool in0 = a0 >= 0 && b0 >= 0, in1 = two && a1 >= 0 && b1 >= 0;
-#ifdef DMC_HSPLIT_PRED
-        if (!in0 && !in1) continue;
-#endif
         // (no lane-dependent skip: an entry outside the contact's mask reads slot 0 and drops the sum -- the skip put the
         // global loads of the contact's Jacobian behind an exec-mask sequence)
         const int sa0 = in0 ? a0 : 0, sb0 = in0 ? b0 : 0, sa1 = in1 ? a1 : 0, sb1 = in1 ? b1 : 0;
@@ -3922,13 +3876,8 @@ struct StepCore {
           for (int q = 0; q < L.d.maxrow; q++) if (q < nrow && SI(efc_active)[r0 + q] == EFC_ST_QUADRATIC) {
             const T dq = S(efc_D)[r0 + q];
             const T ji0 = J[q*K + sa0], ji1 = J[q*K + sa1];
-#ifdef DMC_HSPLIT_PRED
-            if (ji0 != 0) acc0 += (dq*ji0) * J[q*K + sb0];
-            if (ji1 != 0) acc1 += (dq*ji1) * J[q*K + sb1];
-#else
             const T jj0 = J[q*K + sb0], jj1 = J[q*K + sb1], t0 = acc0 + (dq*ji0) * jj0, t1 = acc1 + (dq*ji1) * jj1;
             acc0 = ji0 != 0 ? t0 : acc0; acc1 = ji1 != 0 ? t1 : acc1;
-#endif
           }
         }
         if (in0) h0 += acc0;
@@ -4095,13 +4044,6 @@ struct StepCore {
     for (int i = lane; i < nefc; i += LPE) {
       // (branch-free: D is read beside jar, not after the test on it -- a predicated read is a second LDS round trip
       // behind an exec-mask sequence; the sums see the same terms, a zero where the row is satisfied)
-#ifdef DMC_CU_BRANCHY
-      const T jar = S(efc_jar)[i];
-      const int act = jar < 0;
-      if (act) { S(efc_force)[i] = -S(efc_D)[i]*jar; cost += (T)0.5*S(efc_D)[i]*jar*jar; }
-      else S(efc_force)[i] = 0;
-      if (track) { if (SI(efc_active)[i] != act) changed = 1; SI(efc_active)[i] = act; }
-#else
       const T jar = S(efc_jar)[i], D = S(efc_D)[i];
       const int old = track ? SI(efc_active)[i] : 0;
       const int act = jar < 0;
@@ -4109,7 +4051,6 @@ struct StepCore {
       S(efc_force)[i] = act ? -dj : (T)0;
       if (sizeof(T) == 4) cost += act ? (T)0.5*dj*jar : (T)0; else if (act) cost += (T)0.5*D*jar*jar;
       if (track) { changed |= old != act; SI(efc_active)[i] = act; }
-#endif
     }
     cost = group_sum<LPE>(cost);
     if (track) *track = group_max<LPE>(changed);
@@ -4198,23 +4139,6 @@ struct StepCore {
     FOR_LANES(i, nv) {
       T f = 0;
       if (L.d.njdense) for (int r = 0; r < rm.s0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[r*nv + i]*fr; }
-#ifdef DMC_CFJ_PRED
-      for (int r = rm.s0; r < rm.tl0; r++) {
-        const T fr = S(efc_force)[r];
-        const int tid = SI(efc_tid)[r];
-        if (fr != 0 && simple_dof(tid) == i) f += simple_sign(tid)*fr;
-      }
-      if (L.d.njdense) for (int r = rm.tl0; r < rm.c0; r++) { const T fr = S(efc_force)[r]; if (fr != 0) f += S(efc_Jd)[(rm.s0 + r - rm.tl0)*nv + i]*fr; }
-      for (int c = 0; c < ncon; c++) {
-        const int r0 = SI(con_efc)[c];
-        if (r0 < 0) continue;
-        const int slot = mask_slot(con_mask_lo(c), con_mask_hi(c), i);
-        if (slot < 0) continue;
-        const int nrow = contact_rows(con_dim(c));
-        const auto jc = Jc_base + (r0 - rm.c0)*K + slot;
-        for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q]; if (fr != 0) f += jc[q*K]*fr; }
-      }
-#else
       // (no lane-dependent branch around a load: a dof outside the contact's mask reads slot 0 and keeps its sum -- what sat
       // behind `if (slot < 0) continue` was an exec-mask sequence and, for the models whose contact rows live in global
       // memory, one dependent global round trip per row inside it)
@@ -4233,7 +4157,6 @@ struct StepCore {
         const auto jc = Jc_base + (r0 - rm.c0)*K + (slot < 0 ? 0 : slot);
         for (int q = 0; q < L.d.maxrow; q++) if (q < nrow) { const T fr = S(efc_force)[r0 + q], t_ = f + jc[q*K]*fr; f = (slot >= 0 && fr != 0) ? t_ : f; }
       }
-#endif
       S(qfrc_constraint)[i] = f;
     }
   }
@@ -4969,23 +4892,6 @@ struct StepCore {
           kf = first; kb = __builtin_amdgcn_readlane(t_start, first); ke = __builtin_amdgcn_readlane(t_end, last);
         } else { kf = N; kb = N; ke = 0; }
       }
-#ifdef DMC_SOLVE_ROWS_R4
-#pragma unroll
-      for (int k = 0; k < N; k++) {
-        if (k < kf || k >= ke) continue;
-        const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
-        if (i == k) sreg = xk;
-        if (i > k && own) sreg -= row[k]*xk;
-      }
-#pragma unroll
-      for (int k = N - 1; k >= 0; k--) {
-        if (k < kb || k >= ke) continue;
-        const T xk = wave_bcast<LPE>(sreg, k) * wave_bcast<LPE>(dinv, k);
-        if (i == k) sreg = xk;
-        if (i < k) sreg -= col[k]*xk;
-      }
-      if (own) S(sv_Mgrad)[i] = sreg;
-#else
       // (chol_solve_rows' three-instruction steps: one product per lane, one cross-lane read, one unconditional FMA; a lane
       // outside the swept range holds s = 0 throughout)
 #pragma unroll
@@ -5002,7 +4908,6 @@ struct StepCore {
         sreg = sreg - col[k]*xk;
       }
       if (own) S(sv_Mgrad)[i] = sreg*dinv;
-#endif
       DMC_WSYNC();
       for (int a = b + lane; a < nf; a += LPE) { const T v = row_dot(SI(ns_row)[a], S(sv_Mgrad), rm); A[b*cap + a] = v; A[a*cap + b] = v; }
       DMC_WSYNC();
@@ -5164,11 +5069,7 @@ struct StepCore {
     DMC_WSYNC();
     const T scale = 1 / (o.meaninertia * (T)(nv > 1 ? nv : 1));
     int nlev = 0;
-#ifdef DMC_NOSLIP_SEQUENTIAL
-    const int nblk = 0;
-#else
     const int nblk = noslip_plan(nf, &nlev);
-#endif
     int iter = 0;
     while (iter < o.noslip_iterations) {
       T improvement = 0;
