@@ -278,6 +278,7 @@ class Environment:
     B = self.physics.B
     obs = self.task.get_observation(self.physics)
     if self._updater is not None:
+      obs = self._updater.corrupt(obs)
       self._updater.start(obs, mask)      # Updater.reset: the first sample, at time 0
       obs = self._updater.read(obs)
     return TimeStep(step_type=torch.full((B,), FIRST, dtype=torch.int32, device=self.physics.device),
@@ -327,7 +328,7 @@ class Environment:
         self._hooks.after_substep(p, self._rs)
         upd.advance(1, running)
         if k < self._n_sub_steps - 1:
-          upd.sample(task.get_observation(p), running)
+          upd.sample(upd.corrupt(task.get_observation(p)), running)
     elif self.probed:
       # one launch; the kernel leaves the probed geom's position after every substep, the entities read that trace
       trace = p.substep_probe(self._hooks.probe_geom, self._n_sub_steps)
@@ -372,6 +373,7 @@ class Environment:
     discount = torch.where(diverged, zero, discount)
     obs = task.get_observation(p)
     if upd is not None:
+      obs = upd.corrupt(obs)
       upd.sample(obs, running)      # the pass after the control step's last physics step
       upd.start(obs, first)         # environments re-initialised in this call: Updater.reset, the first sample of the new episode
       obs = upd.read(obs)

@@ -31,7 +31,7 @@ import collections
 
 PAD_ZERO, PAD_INITIAL = 'zero', 'initial_value'      # composer.ObservationPadding.ZERO / INITIAL_VALUE
 
-DEFAULTS = dict(update_interval=1, buffer_size=1, delay=0, aggregator=None)
+DEFAULTS = dict(update_interval=1, buffer_size=1, delay=0, aggregator=None, corruptor=None)
 
 
 def _median(torch, buf):
@@ -75,6 +75,11 @@ class _Buffered:
       if agg not in AGGREGATORS:
         raise KeyError('Unrecognized aggregator name: %r. Valid names: %s.' % (agg, sorted(AGGREGATORS)))
     self.U, self.S, self.D, self.aggregator = opt['update_interval'], opt['buffer_size'], opt['delay'], agg
+    # observable/base.py:129-138: the corruptor acts on every SAMPLE, before it is buffered (the aggregator sees corrupted
+    # values); here a callable of the (B, ...) tensor -- its noise, if any, comes from the caller's own device generator
+    self.corruptor = opt['corruptor']
+    if self.corruptor is not None and not callable(self.corruptor):
+      raise ValueError('observable %r: corruptor must be a callable of the (B, ...) sample' % name)
     self.ring_size = self.S + self.D // self.U + 2
     self.every_control_step = self.U % n_sub_steps == 0
     self.default = (self.U, self.S, self.D) == (1, 1, 0)      # the value at the read IS the observation: no ring
@@ -136,7 +141,7 @@ class _Buffered:
 class Updater:
   """`observation.Updater` for the dict of (B, ...) tensors a batched task's `get_observation` returns.
 
-  options: {observable name: dict(update_interval=, buffer_size=, delay=, aggregator=)}; names not listed keep the
+  options: {observable name: dict(update_interval=, buffer_size=, delay=, aggregator=, corruptor=)}; names not listed keep the
   defaults (interval 1, buffer 1, no delay: the value at the end of the control step).  `pad`: PAD_ZERO / PAD_INITIAL
   (`delayed_observation_padding`), `strip_singleton_buffer_dim` as in the reference's constructor."""
 
@@ -167,6 +172,17 @@ class Updater:
     missing = [n for n in self._options if n not in obs]
     if missing:
       raise KeyError('observation options name unknown observable(s): %s' % missing)
+
+  def corrupt(self, obs):
+    """The observables' corruptors on one pass of raw values (call ONCE per pass: `sample`, `start` and `read` of a pass must see
+    the same corrupted sample)."""
+    if not any(b.corruptor is not None for b in self._buffers.values()):
+      return obs
+    out = type(obs)()
+    for name, value in obs.items():
+      b = self._buffers.get(name)
+      out[name] = b.corruptor(value) if b is not None and b.corruptor is not None else value
+    return out
 
   def start(self, obs, mask):
     """Episode start of the masked environments with their first observation `obs` (dict of (B, ...))."""

@@ -220,3 +220,38 @@ def test_environment_history_of_physics_steps_takes_one_launch_per_substep():
       np.testing.assert_allclose(tb.observation['joints_pos'][:, i].numpy(), fine[n - 3 + i].numpy(), rtol=0, atol=1e-8, err_msg=str((t, i)))
     assert not torch.equal(tb.observation['joints_pos'][:, 0], tb.observation['joints_pos'][:, 2])
   assert int(tb.step_type[0]) == environment.MID
+
+
+def test_corruptor_acts_on_samples_before_they_are_buffered(ref):
+  """observable/base.py:129-138: the aggregator sees corrupted samples; an observable without a ring is corrupted at the read."""
+  upd_mod, obs_mod = ref
+  world = _World(2)
+  corrupt_np = lambda v, random_state=None: np.round(v) * 2.0
+  corrupt_t = lambda v: torch.round(v) * 2.0
+  for opts in (dict(update_interval=1, delay=1, buffer_size=3, aggregator='sum'), dict(update_interval=1, delay=0, buffer_size=1, aggregator=None)):
+    world.t[:] = 0
+    obs = [obs_mod.Generic(lambda physics, e=e: world.value(e), corruptor=corrupt_np, **opts) for e in range(2)]
+    ups = []
+    for o in obs:
+      o.enabled = True
+      u = upd_mod.Updater({'x': o}, physics_steps_per_control_step=2, strip_singleton_buffer_dim=True)
+      u.reset(_NoPhysics(), None)
+      ups.append(u)
+    b = bu.Updater(torch, 2, 2, {'x': dict(corruptor=corrupt_t, **opts)}, strip_singleton_buffer_dim=True)
+    values = lambda: {'x': torch.from_numpy(np.stack([world.value(e) for e in range(2)]))}
+    everyone = torch.ones(2, dtype=torch.bool)
+    first = b.corrupt(values()); b.start(first, everyone)
+    for c in range(6):
+      for u in ups:
+        u.prepare_for_next_control_step()
+      for k in range(2):
+        world.t += 1
+        for u in ups:
+          u.update()
+        b.advance(1, everyone)
+        if k == 0 and b.needs_substeps:
+          b.sample(b.corrupt(values()), everyone)
+      o = b.corrupt(values()); b.sample(o, everyone)
+      got = b.read(o)['x'].numpy()
+      for e in range(2):
+        np.testing.assert_array_equal(got[e], np.array(ups[e].get_observation()['x']))
