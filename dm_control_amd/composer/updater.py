@@ -97,7 +97,10 @@ class _Buffered:
     m = mask.reshape((self.B,) + (1,) * (value.dim() - 1))
     self.ring[0] = torch.where(m, value, self.ring[0])
     if keep_first:
-      self.first = torch.where(m, value, self.first) if self.first is not None else value.clone()
+      if self.first is None:
+        self.first = value.clone()
+      else:
+        self.first.copy_(torch.where(m, value, self.first))      # (in place: carried state keeps its address under graph replay)
 
   def sample(self, torch, value, age, mask):
     """`Updater.update` at the environments' ages (physics steps since their `start`): those of `mask` whose age is a

@@ -482,9 +482,10 @@ def test_invalidation_inside_a_captured_graph_reaches_the_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,shape,hist,delayed', [('cmu_go_to_target', None, 'joints_pos', 'sensors_touch'),
-                                                    ('soccer_2v2', (4, 3), 'joints_vel', 'ball_ego_position')])
-def test_buffered_and_delayed_observations_on_the_device(name, shape, hist, delayed):
+@pytest.mark.parametrize('name,shape,hist,delayed,pad', [('cmu_go_to_target', None, 'joints_pos', 'sensors_touch', 'zero'),
+                                                        ('cmu_go_to_target', None, 'joints_pos', 'sensors_touch', 'initial_value'),
+                                                        ('soccer_2v2', (4, 3), 'joints_vel', 'ball_ego_position', 'zero')])
+def test_buffered_and_delayed_observations_on_the_device(name, shape, hist, delayed, pad):
   """composer/updater.py on the device: a history of three control steps and a one-control-step delay, per-environment
   episode clocks (go-to-target walkers fall at different steps), eager and as a replayed HIP graph.  Row i of the history
   at control step t is the plain environment's observation of step t - 2 + i (zeros before the episode began); the
@@ -496,8 +497,8 @@ def test_buffered_and_delayed_observations_on_the_device(name, shape, hist, dela
   plain = composer.make(name, B, random_state=9, **kw)
   n = plain.n_sub_steps
   opts = {hist: dict(update_interval=n, buffer_size=3), delayed: dict(update_interval=n, delay=n)}
-  eager = composer.make(name, B, random_state=9, observation_options=opts, **kw)
-  graph = composer.make(name, B, random_state=9, observation_options=opts, **kw)
+  eager = composer.make(name, B, random_state=9, observation_options=opts, delayed_observation_padding=pad, **kw)
+  graph = composer.make(name, B, random_state=9, observation_options=opts, delayed_observation_padding=pad, **kw)
   m = plain.task.model
   ashape = (B,) + (shape if shape else (m.nu,))
   gen = torch.Generator(device='cuda').manual_seed(1)
@@ -510,24 +511,29 @@ def test_buffered_and_delayed_observations_on_the_device(name, shape, hist, dela
   graph.capture(acts[0])
   age = torch.full((B,), 2, dtype=torch.int64, device='cuda')
   restarts = 0
+  first_obs = {k: seen[0].observation[k].clone() for k in (hist, delayed)}      # the episode's first sample per environment
   for t in range(1, 40):
     p = plain.step(acts[t]); seen.append(p)
     a = eager.step(acts[t]); b = graph.step_graph(acts[t])
     torch.cuda.synchronize()
     assert eager.launches == plain.launches
     assert torch.equal(a.step_type, p.step_type) and torch.equal(a.reward, p.reward)
-    age = torch.where(p.step_type == composer.FIRST, torch.zeros_like(age), age + 1)
-    restarts += int((p.step_type == composer.FIRST).sum())
+    started = p.step_type == composer.FIRST
+    age = torch.where(started, torch.zeros_like(age), age + 1)
+    restarts += int(started.sum())
+    for k in first_obs:
+      first_obs[k] = torch.where(started.reshape((B,) + (1,) * (first_obs[k].dim() - 1)), p.observation[k], first_obs[k])
+    padding = (lambda k, like: torch.zeros_like(like)) if pad == 'zero' else (lambda k, like: first_obs[k])
     h = a.observation[hist]
     assert h.shape[1] == 3 and h.shape[0] == B
     for i in range(3):
       back = 2 - i
       old = seen[-1 - back].observation[hist]
       live = (age >= back).reshape((B,) + (1,) * (old.dim() - 1))
-      assert torch.equal(h[:, i], torch.where(live, old, torch.zeros_like(old))), (t, i)
+      assert torch.equal(h[:, i], torch.where(live, old, padding(hist, old))), (t, i)
     old = seen[-2].observation[delayed]
     live = (age >= 1).reshape((B,) + (1,) * (old.dim() - 1))
-    assert torch.equal(a.observation[delayed], torch.where(live, old, torch.zeros_like(old))), t
+    assert torch.equal(a.observation[delayed], torch.where(live, old, padding(delayed, old))), t
     for k in p.observation:
       if k not in (hist, delayed):
         assert torch.equal(a.observation[k], p.observation[k]), (k, t)
