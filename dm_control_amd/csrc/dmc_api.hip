@@ -124,7 +124,7 @@ static int choose_geometry(dmc_batch* b, int lanes_per_env) {
   const int force_w = getenv("DMC_WAVES") ? atoi(getenv("DMC_WAVES")) : 0;      // tuning studies only
   // ... with one exception: FIVE waves when that is what holds one more environment than any smaller shape (the 62-dof
   // models at offload level 3: 5 x 29.8 KB + one 10.8 KB table copy = 159.6 KB; +25 % residency, round 4)
-  for (int w = 5; w >= 1; w--) {
+  for (int w = force_w > 5 ? force_w : 5; w >= 1; w--) {      // (more than five waves only when forced: needs kernels built with -DDMC_MAX_THREADS=<64 w>)
     if (force_w && w != force_w) continue;
     const size_t bytes = tables + (size_t)w * epw * env_bytes;
     if (bytes > lds_cu) continue;
