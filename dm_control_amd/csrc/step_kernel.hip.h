@@ -164,8 +164,10 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     const int item = io.order ? io.order[slot] : slot;
     const int env = item * epw + (g & (epw - 1));
     int* tr = io.trace ? io.trace + (size_t)(io.trace_slot & 7) * 8 * nitems : nullptr;
+    const long long tw0 = tr ? (long long)wall_clock64() : 0;
     if (QUEUE && piece > 0)      // (the state itself is read with loads that bypass this CU's L1: StepCore::load_handoff)
       while (__hip_atomic_load(q_prog + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < piece) __builtin_amdgcn_s_sleep(8);
+    const long long tw1 = tr ? (long long)wall_clock64() : 0;
     const long long t0 = io.cost ? (long long)__builtin_readcyclecounter() : 0;
     if (tr && (threadIdx.x & 63) == 0 && piece == 0) { tr[item] = t_entry; tr[nitems + item] = (int)(wall_clock64() & 0x7fffffffll); }
     if (env < io.B) core.run(io, env, nstep, legacy, mode, outmask, nsub, en, piece, npieces);
@@ -181,6 +183,11 @@ __device__ __forceinline__ void step_kernel_body(LS ls, const StepOpts<T>& o_arg
     if (tr && (threadIdx.x & 63) == 0 && piece == npieces - 1) {
       tr[2*nitems + item] = (int)(wall_clock64() & 0x7fffffffll);
       tr[3*nitems + item] = (int)blockIdx.x;
+    }
+    if (tr && (threadIdx.x & 63) == 0) {      // rows 4 / 5: ticks this item's pieces waited for their predecessors / ran (scripts/queue_wait_probe.py)
+      const int wt = (int)(tw1 - tw0), rn = (int)((long long)wall_clock64() - tw1);
+      if (piece == 0) { __hip_atomic_store(tr + 4*nitems + item, wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(tr + 5*nitems + item, rn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else { atomicAdd(tr + 4*nitems + item, wt); atomicAdd(tr + 5*nitems + item, rn); }
     }
     if (io.cost && (threadIdx.x & 63) == 0) {
       long long dt = ((long long)__builtin_readcyclecounter() - t0) >> 6;
